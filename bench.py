@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py -- batched DoNothing env.step throughput of the MI355X power-flow engine.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--env NAME] [--batch B] [--cascade]
+
+One "step" = one pass of the hot path over one batch: for every lane (independent environment copy)
+chronics row -> injections -> AC Newton-Raphson power flow (init="dc", <=10 iterations, 1e-8 MVA) ->
+result extraction -> overflow bookkeeping, i.e. what ``Environment.step`` asks of the Backend for a
+DoNothing agent with ``NO_OVERFLOW_DISCONNECTION=True`` (the setting of the reference's own DoNothing
+profiler, _profiling/profiler_do_nothing.py:42-65).  Inputs (chronics tables, lane state) are resident
+in HBM before the timed region; outputs stay in HBM.
+
+Workload (BASELINE.json configs[1], SURVEY.md 8(d) cfg 2): ``l2rpn_case14_sandbox``, batch = 4096 lanes
+per GPU, lane k reads chronics row (t + 7k) mod 576 with loads scaled by 1 + 0.05 N(0,1)
+(``default_rng(k)``) and prod_p rescaled to 1.02 * sum(load).
+
+Multi-GPU: the lanes are independent, so the batch is sharded statically, 4096 lanes per rank (weak
+scaling), one process per GPU, NO collective on the data path; torch.distributed (RCCL) is only used for
+the barrier and the max-over-ranks timing the contract asks for.
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+F64_PEAK_TFLOPS = 78.6         # MI355X FP64 vector == FP64 matrix peak (spec)
+
+
+def synth_lane_scale(B: int, n_load: int, rank_offset: int = 0) -> np.ndarray:
+    sc = np.empty((B, 2 * n_load), dtype=np.float32)
+    for k in range(B):
+        rng = np.random.default_rng(rank_offset + k)
+        sc[k] = 1.0 + 0.05 * rng.standard_normal(2 * n_load)
+    return sc
+
+
+def cpu_baseline(m, ch, T, budget_s=12.0):
+    """Time the CPU oracle (a port of the reference's pandapower arithmetic, see oracle/) on a bounded
+    sample of the SAME workload, single host thread.  Reported baseline, not the target."""
+    try:
+        from oracle import pf_oracle_c
+        have_c = pf_oracle_c.available()
+    except Exception:
+        have_c = False
+    from oracle.pf_oracle import LaneState, solve
+    n_done = 0
+    t0 = time.perf_counter()
+    if have_c:
+        n_done, elapsed = pf_oracle_c.time_steps(m, ch, T, budget_s)
+        impl = "oracle/pf_oracle.c (gcc -O2, float64 dense NR)"
+    else:
+        vn = m.sub_vn_kv[m.gen_sub].astype(np.float32)
+        while time.perf_counter() - t0 < budget_s:
+            k = n_done
+            row = (7 * k) % T
+            rng = np.random.default_rng(k)
+            sc = (1.0 + 0.05 * rng.standard_normal(2 * m.n_load)).astype(np.float32)
+            st = LaneState.from_model(m)
+            st.load_p = (ch["load_p"][row] * sc[:m.n_load]).astype(np.float64)
+            st.load_q = (ch["load_q"][row] * sc[m.n_load:]).astype(np.float64)
+            st.gen_p = ch["prod_p"][row].astype(np.float64)
+            st.gen_vm = (ch["prod_v"][row] / vn).astype(np.float64)
+            solve(m, st)
+            n_done += 1
+        elapsed = time.perf_counter() - t0
+        impl = "oracle/pf_oracle.py (numpy, float64 dense NR)"
+    return {"value": n_done / elapsed, "unit": "env steps/sec", "cores": 1, "kind": "port",
+            "sample": f"{n_done} lane-steps of the same synthetic workload in {elapsed:.1f} s, 1 thread, {impl}",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--env", default="l2rpn_case14_sandbox")
+    ap.add_argument("--batch", type=int, default=4096, help="lanes per GPU")
+    ap.add_argument("--cascade", action="store_true", help="enable overflow disconnections (cascade loop)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    try:
+        import torch  # noqa: F811  (device plumbing + RCCL barrier only)
+    except Exception:
+        torch = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from grid2op_amd.grid_model import GridModel
+    from grid2op_amd.engine import PowerFlowEngine
+
+    m = GridModel.load_npz(os.path.join(GOLD, f"{args.env}.grid.npz"))
+    ch = dict(np.load(os.path.join(GOLD, f"{args.env}.chronics.npz")))
+    if "prod_v" not in ch:
+        ch["prod_v"] = np.tile((m.gen_vm0 * m.sub_vn_kv[m.gen_sub]).astype(np.float32), (ch["prod_p"].shape[0], 1))
+    B = args.batch
+    eng = PowerFlowEngine(m, n_lanes=B, device=local_rank)
+    tab = eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"])
+    T = tab.shape[0]
+    eng.upload_chronics(tab)
+    eng.set_lane_chronics(lane_offset=(7 * (rank * B + np.arange(B))) % T, lane_scale=synth_lane_scale(B, m.n_load, rank * B))
+    if "thermal_limits" in ch:
+        eng.set_thermal_limits(ch["thermal_limits"])
+    step_kw = dict(rebalance=1.02, cascade=args.cascade)
+
+    def sync_all():
+        eng.sync()
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    t = 0
+    for _ in range(args.warmup):
+        eng.step(t, **step_kw)
+        t += 1
+    eng.sync()
+    eng.kernel_time()                      # drop warm-up events
+    eng.set_profiling(True)                # HIP events on the engine's own stream around every launch
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step(t, **step_kw)
+        t += 1
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    kern_ms, n_launch = eng.kernel_time()
+    eng.set_profiling(False)
+    r = eng.results()
+    frac_conv = float(r.converged.mean())
+    mean_iter = float(r.n_iter[r.converged].mean()) if r.converged.any() else float("nan")
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    total_steps = world * B * args.steps
+    value = total_steps / elapsed
+
+    if rank == 0:
+        bytes_step = eng.algorithmic_bytes_per_step()
+        avg_launch_s = (kern_ms / max(n_launch, 1)) * 1e-3
+        achieved_gbs = bytes_step * B / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        # algorithmic flops per AC power flow: iters*(2/3 J^3 + 2 J^2), dense, J = NR unknowns
+        J = float(eng.results(0, 1).status[0, 2]) * 2 - 2 - int((~m.gen_slack).sum() >= 0) * 0   # upper bound 2(nb-1)
+        nb = int(eng.results(0, 1).status[0, 2])
+        npv = len(set(m.gen_sub[~m.gen_slack].tolist()) - set(m.gen_sub[m.gen_slack].tolist()))
+        J = 2 * (nb - 1) - npv
+        flops_pf = (mean_iter if mean_iter == mean_iter else 0) * (2.0 / 3.0 * J ** 3 + 2.0 * J ** 2)
+        res = {
+            "metric": "env steps/sec (batched DoNothing)",
+            "value": value,
+            "unit": "env steps/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.env} AC Newton-Raphson DoNothing env.step, batch={B} lanes per GPU "
+                                   f"(row (t+7k) mod {T}, loads x (1+0.05 N(0,1)), prod_p rebalanced to 1.02 sum(load))",
+                       "env": args.env, "lanes_per_gpu": B, "cascade": bool(args.cascade), "max_iter": 10,
+                       "tol_mva": 1e-8, "parallelism": f"independent lanes, static shard x{world}, no collective"},
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "gpf::step_kernel<false>", "avg_launch_us": avg_launch_s * 1e6, "launches": int(n_launch),
+                         "algorithmic_bytes_per_step": bytes_step,
+                         "note": "small dense FP64 factorisations dominate: the kernel is issue/latency bound, not HBM "
+                                 "bound (SURVEY.md 8(d)); the FP64 figure below is the relevant ceiling",
+                         "f64": {"achieved_tflops": flops_pf * B / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0,
+                                 "peak_tflops": F64_PEAK_TFLOPS, "algorithmic_flops_per_step": flops_pf, "J": J}},
+            "frac_converged": frac_conv,
+            "mean_nr_iterations": mean_iter,
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(m, ch, T)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,135 @@
+"""ctypes binding of ``libgridpf.so`` (C ABI: ``include/gridpf.h``).
+
+There is NO fallback: if the shared library is missing or no HIP device is available the engine
+cannot be created and every call raises `GridPFError`.  (The CPU oracle under ``oracle/`` is test
+infrastructure only and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+__all__ = ["lib", "GridPFError", "GpfGridDesc", "GpfLayout", "library_path", "EXPORTED_SYMBOLS"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libgridpf.so"
+
+EXPORTED_SYMBOLS = [
+    "gpf_last_error", "gpf_version", "gpf_create", "gpf_destroy", "gpf_get_layout", "gpf_n_lanes",
+    "gpf_set_injections", "gpf_set_topology", "gpf_get_injections", "gpf_get_topology", "gpf_disconnect_line",
+    "gpf_reset_lanes", "gpf_copy_lanes", "gpf_fanout_n1", "gpf_runpf", "gpf_get_results", "gpf_upload_chronics",
+    "gpf_set_lane_chronics", "gpf_set_thermal_limits", "gpf_step", "gpf_get_step_outputs", "gpf_sync",
+    "gpf_set_profiling", "gpf_get_kernel_time", "gpf_device_pointers",
+]
+
+
+class GridPFError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return os.environ.get("GRIDPF_LIB", os.path.join(_HERE, _LIB_NAME))
+
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_fp = C.POINTER(C.c_float)
+_bp = C.POINTER(C.c_uint8)
+
+
+class GpfGridDesc(C.Structure):
+    _fields_ = [
+        ("n_sub", C.c_int32), ("n_busbar", C.c_int32),
+        ("n_line", C.c_int32), ("n_gen", C.c_int32), ("n_load", C.c_int32), ("n_storage", C.c_int32),
+        ("n_shunt", C.c_int32), ("dim_topo", C.c_int32),
+        ("sn_mva", C.c_double),
+        ("sub_vn_kv", _dp),
+        ("line_or_sub", _ip), ("line_ex_sub", _ip), ("line_or_pos_topo_vect", _ip), ("line_ex_pos_topo_vect", _ip),
+        ("br_y", _dp), ("br_bdc", _dp),
+        ("gen_sub", _ip), ("gen_pos_topo_vect", _ip), ("gen_min_q", _dp), ("gen_max_q", _dp), ("gen_slack", _bp),
+        ("load_sub", _ip), ("load_pos_topo_vect", _ip),
+        ("storage_sub", _ip), ("storage_pos_topo_vect", _ip),
+        ("shunt_sub", _ip), ("shunt_fact", _dp),
+        ("init_inj", _dp), ("init_topo", _ip), ("init_shunt_bus", _ip),
+    ]
+
+
+class GpfLayout(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "n_inj", "inj_gen_p", "inj_gen_vm", "inj_load_p", "inj_load_q", "inj_storage_p", "inj_storage_q",
+        "inj_shunt_p", "inj_shunt_q",
+        "n_out", "out_p_or", "out_q_or", "out_v_or", "out_a_or", "out_theta_or",
+        "out_p_ex", "out_q_ex", "out_v_ex", "out_a_ex", "out_theta_ex",
+        "out_gen_p", "out_gen_q", "out_gen_v", "out_gen_theta",
+        "out_load_p", "out_load_q", "out_load_v", "out_load_theta",
+        "out_storage_p", "out_storage_q", "out_storage_v", "out_storage_theta",
+        "out_shunt_p", "out_shunt_q", "out_shunt_v",
+        "n_chron", "chron_load_p", "chron_load_q", "chron_prod_p", "chron_prod_v", "nb_total")]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load ``libgridpf.so`` (built in-tree by ``__graft_entry__.build()``); fail loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise GridPFError(
+            f"{path} not found: the HIP engine is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(there is no CPU fallback).")
+    try:
+        L = C.CDLL(path)
+    except OSError as exc:
+        raise GridPFError(f"cannot load {path}: {exc}") from exc
+    h = C.c_void_p
+    i32 = C.c_int32
+    L.gpf_last_error.restype = C.c_char_p
+    L.gpf_last_error.argtypes = []
+    L.gpf_version.restype = C.c_int
+    L.gpf_create.argtypes = [C.POINTER(GpfGridDesc), i32, i32, C.POINTER(h)]
+    L.gpf_destroy.argtypes = [h]
+    L.gpf_get_layout.argtypes = [h, C.POINTER(GpfLayout)]
+    L.gpf_n_lanes.argtypes = [h]
+    L.gpf_set_injections.argtypes = [h, i32, i32, _dp]
+    L.gpf_set_topology.argtypes = [h, i32, i32, _ip, _ip]
+    L.gpf_get_injections.argtypes = [h, i32, i32, _dp]
+    L.gpf_get_topology.argtypes = [h, i32, i32, _ip, _ip]
+    L.gpf_disconnect_line.argtypes = [h, i32, i32]
+    L.gpf_reset_lanes.argtypes = [h, i32, i32]
+    L.gpf_copy_lanes.argtypes = [h, i32, i32, i32]
+    L.gpf_fanout_n1.argtypes = [h, i32, i32, i32, _ip]
+    L.gpf_runpf.argtypes = [h, i32, i32, i32, i32, C.c_double]
+    L.gpf_get_results.argtypes = [h, i32, i32, _fp, _ip, _ip, _bp, _ip, _dp, _dp]
+    L.gpf_upload_chronics.argtypes = [h, i32, i32, _fp]
+    L.gpf_set_lane_chronics.argtypes = [h, _ip, _ip, _fp]
+    L.gpf_set_thermal_limits.argtypes = [h, _fp]
+    L.gpf_step.argtypes = [h, i32, i32, C.c_double, C.c_double, i32, C.c_float, C.c_float, i32, i32]
+    L.gpf_get_step_outputs.argtypes = [h, i32, i32, _fp, _ip, _ip]
+    L.gpf_sync.argtypes = [h]
+    L.gpf_set_profiling.argtypes = [h, i32]
+    L.gpf_get_kernel_time.argtypes = [h, _dp, C.POINTER(C.c_int64)]
+    L.gpf_device_pointers.argtypes = [h, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("gpf_last_error",):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().gpf_last_error()
+        raise GridPFError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(a: Optional[np.ndarray], ctype):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(ctype))

@@ -1,0 +1,633 @@
+// gridpf_capi.hip -- host side of libgridpf.so: the C ABI declared in include/gridpf.h.
+// Owns the device buffers of one engine (static grid tables + lane-major per-lane state), one HIP
+// stream, and launches the kernels of gridpf_kernels.hpp.  gfx950 only; no fallback path: if HIP is
+// unavailable every entry point fails with GPF_E_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gridpf.h"
+#include "gridpf_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess)                                                                   \
+      return fail(GPF_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));         \
+  } while (0)
+
+template <typename T>
+struct DevArr {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    n = count;
+    if (count == 0) { p = nullptr; return hipSuccess; }
+    return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+  }
+  hipError_t upload(const T* src, size_t count) {
+    hipError_t e = alloc(count);
+    if (e != hipSuccess || count == 0) return e;
+    return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+}  // namespace
+
+struct gpf_engine {
+  int device = 0;
+  int n_lanes = 0;
+  hipStream_t stream = nullptr;
+  gpf::GridDev g{};
+  gpf::OutOff oo{};
+  gpf_layout layout{};
+  // static tables (device)
+  DevArr<double> sub_vn_kv, br_y, br_bdc, gen_min_q, gen_max_q, shunt_fact;
+  DevArr<int> line_or_sub, line_ex_sub, line_or_pos, line_ex_pos, gen_sub, gen_pos, load_sub, load_pos, sto_sub, sto_pos,
+      shunt_sub;
+  DevArr<unsigned char> gen_slack;
+  // host copies needed to size launches
+  std::vector<int> h_line_or_sub, h_line_ex_sub, h_line_or_pos, h_line_ex_pos, h_gen_sub, h_gen_pos, h_load_sub, h_load_pos,
+      h_sto_sub, h_sto_pos, h_shunt_sub;
+  std::vector<unsigned char> h_gen_slack;
+  std::vector<double> h_init_inj;
+  std::vector<int> h_init_topo, h_init_shunt_bus;
+  // per-lane state (device)
+  DevArr<double> inj, bus_vm, bus_va, work;
+  DevArr<int> topo, shunt_bus, topo_out, shunt_bus_out, status, overflow_count, disc_round, lane_table, lane_offset, tmp_lines;
+  DevArr<float> out, chron, lane_scale, thermal_limit, rho;
+  DevArr<unsigned char> line_status;
+  DevArr<double> d_init_inj;
+  DevArr<int> d_init_topo, d_init_shunt_bus;
+  int chron_T = 0, chron_tables = 0;
+  bool has_scale = false;
+  // per-lane capacity bookkeeping (host): number of active buses / NR unknowns of each lane
+  std::vector<int> lane_nb, lane_nj;
+  int init_nb = 0, init_nj = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  double acc_ms = 0.0;
+  long long acc_launches = 0;
+
+  gpf::Bufs bufs() const {
+    gpf::Bufs b{};
+    b.inj = inj.p; b.topo = topo.p; b.shunt_bus = shunt_bus.p; b.out = out.p; b.topo_out = topo_out.p;
+    b.shunt_bus_out = shunt_bus_out.p; b.line_status = line_status.p; b.status = status.p;
+    b.bus_vm = bus_vm.p; b.bus_va = bus_va.p; b.work = work.p; b.work_stride = 0;
+    b.chron = chron.p; b.lane_table = lane_table.p; b.lane_offset = lane_offset.p;
+    b.lane_scale = has_scale ? lane_scale.p : nullptr;
+    b.thermal_limit = thermal_limit.p; b.rho = rho.p; b.overflow_count = overflow_count.p; b.disc_round = disc_round.p;
+    return b;
+  }
+};
+
+namespace {
+
+// number of active buses and Newton unknowns of one lane (host mirror of K1's counting)
+void count_lane(const gpf_engine* e, const int* topo, const int* shunt_bus, int& nb, int& nj) {
+  const gpf::GridDev& g = e->g;
+  std::vector<unsigned char> act(g.nb_tot, 0), type(g.nb_tot, 0);
+  auto mark = [&](int sub, int local) -> int {
+    if (local < 1 || local > g.n_busbar) return -1;
+    int gb = sub + (local - 1) * g.n_sub;
+    act[gb] = 1;
+    return gb;
+  };
+  for (int l = 0; l < g.n_line; ++l) {
+    int bo = topo[e->h_line_or_pos[l]], be = topo[e->h_line_ex_pos[l]];
+    if (bo >= 1 && be >= 1) { mark(e->h_line_or_sub[l], bo); mark(e->h_line_ex_sub[l], be); }
+  }
+  for (int i = 0; i < g.n_gen; ++i) {
+    int gb = mark(e->h_gen_sub[i], topo[e->h_gen_pos[i]]);
+    if (gb >= 0) type[gb] = std::max<unsigned char>(type[gb], e->h_gen_slack[i] ? 2 : 1);
+  }
+  for (int i = 0; i < g.n_load; ++i) mark(e->h_load_sub[i], topo[e->h_load_pos[i]]);
+  for (int i = 0; i < g.n_sto; ++i) mark(e->h_sto_sub[i], topo[e->h_sto_pos[i]]);
+  if (shunt_bus)
+    for (int i = 0; i < g.n_shunt; ++i) mark(e->h_shunt_sub[i], shunt_bus[i]);
+  nb = 0;
+  nj = 0;
+  for (int b = 0; b < g.nb_tot; ++b) {
+    if (!act[b]) continue;
+    ++nb;
+    if (type[b] == 0) nj += 2;
+    else if (type[b] == 1) nj += 1;
+  }
+}
+
+struct LaunchPlan {
+  int nbc, nJ;
+  bool big;
+  size_t lds;
+};
+
+constexpr size_t LDS_SMALL_LIMIT = 64 * 1024;   // above this Y and J move to an HBM/L2 workspace
+constexpr size_t LDS_HARD_LIMIT = 160 * 1024;
+
+int plan_launch(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
+  int nb = 1, nj = 1;
+  for (int k = lane0; k < lane0 + n; ++k) {
+    nb = std::max(nb, e->lane_nb[k]);
+    nj = std::max(nj, e->lane_nj[k]);
+  }
+  p.nbc = (nb + 1) & ~1;
+  p.nJ = (nj + 1) & ~1;
+  size_t small = gpf::lds_bytes(e->g, p.nbc, p.nJ, false);
+  p.big = small > LDS_SMALL_LIMIT;
+  p.lds = gpf::lds_bytes(e->g, p.nbc, p.nJ, p.big);
+  if (p.lds > LDS_HARD_LIMIT) return fail(GPF_E_CAPACITY, "grid too large: per-instance LDS footprint exceeds 160 KiB");
+  if (p.big) {
+    size_t stride = (size_t)2 * p.nbc * p.nbc + (size_t)p.nJ * (p.nJ + 1);
+    size_t need = stride * (size_t)e->n_lanes;
+    if (e->work.n < need) {
+      HIP_TRY(hipStreamSynchronize(e->stream));
+      e->work.release();
+      HIP_TRY(e->work.alloc(need));
+    }
+  }
+  return GPF_OK;
+}
+
+size_t work_stride(const LaunchPlan& p) { return (size_t)2 * p.nbc * p.nbc + (size_t)p.nJ * (p.nJ + 1); }
+
+int prof_begin(gpf_engine* e, hipEvent_t& a, hipEvent_t& b) {
+  if (e->ev_used == e->ev_pool.size()) {
+    hipEvent_t x, y;
+    HIP_TRY(hipEventCreate(&x));
+    HIP_TRY(hipEventCreate(&y));
+    e->ev_pool.emplace_back(x, y);
+  }
+  a = e->ev_pool[e->ev_used].first;
+  b = e->ev_pool[e->ev_used].second;
+  ++e->ev_used;
+  HIP_TRY(hipEventRecord(a, e->stream));
+  return GPF_OK;
+}
+
+int drain_events(gpf_engine* e) {
+  for (size_t i = 0; i < e->ev_used; ++i) {
+    HIP_TRY(hipEventSynchronize(e->ev_pool[i].second));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev_pool[i].first, e->ev_pool[i].second));
+    e->acc_ms += ms;
+    e->acc_launches += 1;
+  }
+  e->ev_used = 0;
+  return GPF_OK;
+}
+
+bool check_range(gpf_engine* e, int lane0, int n) { return e && lane0 >= 0 && n >= 0 && lane0 + n <= e->n_lanes; }
+
+}  // namespace
+
+extern "C" {
+
+const char* gpf_last_error(void) { return g_err.c_str(); }
+int gpf_version(void) { return 100; }
+
+int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_handle* out_h) {
+  if (!d || !out_h || n_lanes <= 0) return fail(GPF_E_INVALID, "gpf_create: bad arguments");
+  if (d->n_sub <= 0 || d->n_busbar <= 0 || d->n_line < 0 || d->n_gen <= 0) return fail(GPF_E_INVALID, "gpf_create: bad sizes");
+  if (d->n_line > 256) return fail(GPF_E_CAPACITY, "gpf_create: n_line > 256 not supported by the step kernel");
+  int ndev = 0;
+  hipError_t e0 = hipGetDeviceCount(&ndev);
+  if (e0 != hipSuccess || ndev == 0)
+    return fail(GPF_E_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e0));
+  if (device < 0 || device >= ndev) return fail(GPF_E_INVALID, "gpf_create: bad device index");
+  HIP_TRY(hipSetDevice(device));
+  gpf_engine* e = new gpf_engine();
+  e->device = device;
+  e->n_lanes = n_lanes;
+  gpf::GridDev& g = e->g;
+  g.n_sub = d->n_sub; g.n_busbar = d->n_busbar; g.nb_tot = d->n_sub * d->n_busbar;
+  g.n_line = d->n_line; g.n_gen = d->n_gen; g.n_load = d->n_load; g.n_sto = d->n_storage; g.n_shunt = d->n_shunt;
+  g.dim_topo = d->dim_topo; g.sn_mva = d->sn_mva;
+  const int nl = g.n_line, ng = g.n_gen, nd = g.n_load, ns = g.n_sto, nsh = g.n_shunt;
+  e->oo = gpf::make_offsets(nl, ng, nd, ns, nsh);
+  g.n_inj = 2 * ng + 2 * nd + 2 * ns + 2 * nsh;
+  g.n_out = 10 * nl + 4 * ng + 4 * nd + 4 * ns + 3 * nsh;
+  g.n_chron = 2 * nd + 2 * ng;
+  gpf_layout& L = e->layout;
+  const gpf::OutOff& o = e->oo;
+  L.n_inj = g.n_inj; L.inj_gen_p = o.inj_gen_p; L.inj_gen_vm = o.inj_gen_vm; L.inj_load_p = o.inj_load_p;
+  L.inj_load_q = o.inj_load_q; L.inj_storage_p = o.inj_sto_p; L.inj_storage_q = o.inj_sto_q; L.inj_shunt_p = o.inj_sh_p;
+  L.inj_shunt_q = o.inj_sh_q;
+  L.n_out = g.n_out; L.out_p_or = o.p_or; L.out_q_or = o.q_or; L.out_v_or = o.v_or; L.out_a_or = o.a_or; L.out_theta_or = o.th_or;
+  L.out_p_ex = o.p_ex; L.out_q_ex = o.q_ex; L.out_v_ex = o.v_ex; L.out_a_ex = o.a_ex; L.out_theta_ex = o.th_ex;
+  L.out_gen_p = o.gen_p; L.out_gen_q = o.gen_q; L.out_gen_v = o.gen_v; L.out_gen_theta = o.gen_th;
+  L.out_load_p = o.load_p; L.out_load_q = o.load_q; L.out_load_v = o.load_v; L.out_load_theta = o.load_th;
+  L.out_storage_p = o.sto_p; L.out_storage_q = o.sto_q; L.out_storage_v = o.sto_v; L.out_storage_theta = o.sto_th;
+  L.out_shunt_p = o.sh_p; L.out_shunt_q = o.sh_q; L.out_shunt_v = o.sh_v;
+  L.n_chron = g.n_chron; L.chron_load_p = 0; L.chron_load_q = nd; L.chron_prod_p = 2 * nd; L.chron_prod_v = 2 * nd + ng;
+  L.nb_total = g.nb_tot;
+
+  auto cp = [](std::vector<int>& dst, const int32_t* src, int n) { dst.assign(src, src + n); };
+  cp(e->h_line_or_sub, d->line_or_sub, nl); cp(e->h_line_ex_sub, d->line_ex_sub, nl);
+  cp(e->h_line_or_pos, d->line_or_pos_topo_vect, nl); cp(e->h_line_ex_pos, d->line_ex_pos_topo_vect, nl);
+  cp(e->h_gen_sub, d->gen_sub, ng); cp(e->h_gen_pos, d->gen_pos_topo_vect, ng);
+  cp(e->h_load_sub, d->load_sub, nd); cp(e->h_load_pos, d->load_pos_topo_vect, nd);
+  if (ns) { cp(e->h_sto_sub, d->storage_sub, ns); cp(e->h_sto_pos, d->storage_pos_topo_vect, ns); }
+  if (nsh) cp(e->h_shunt_sub, d->shunt_sub, nsh);
+  e->h_gen_slack.assign(d->gen_slack, d->gen_slack + ng);
+  e->h_init_inj.assign(d->init_inj, d->init_inj + g.n_inj);
+  e->h_init_topo.assign(d->init_topo, d->init_topo + g.dim_topo);
+  if (nsh) e->h_init_shunt_bus.assign(d->init_shunt_bus, d->init_shunt_bus + nsh);
+  // basic validation of the index tables (a wrong table would make the kernels read out of bounds)
+  auto in_range = [](const std::vector<int>& v, int hi) { for (int x : v) if (x < 0 || x >= hi) return false; return true; };
+  if (!in_range(e->h_line_or_sub, g.n_sub) || !in_range(e->h_line_ex_sub, g.n_sub) || !in_range(e->h_gen_sub, g.n_sub) ||
+      !in_range(e->h_load_sub, g.n_sub) || !in_range(e->h_sto_sub, g.n_sub) || !in_range(e->h_shunt_sub, g.n_sub) ||
+      !in_range(e->h_line_or_pos, g.dim_topo) || !in_range(e->h_line_ex_pos, g.dim_topo) || !in_range(e->h_gen_pos, g.dim_topo) ||
+      !in_range(e->h_load_pos, g.dim_topo) || !in_range(e->h_sto_pos, g.dim_topo)) {
+    delete e;
+    return fail(GPF_E_INVALID, "gpf_create: index table out of range");
+  }
+
+#define UP(arr, src, count)                                                  \
+  do {                                                                       \
+    hipError_t _e = e->arr.upload(src, (size_t)(count));                     \
+    if (_e != hipSuccess) { gpf_destroy(e); return fail(GPF_E_DEVICE, std::string("upload " #arr ": ") + hipGetErrorString(_e)); } \
+  } while (0)
+#define AL(arr, count)                                                       \
+  do {                                                                       \
+    hipError_t _e = e->arr.alloc((size_t)(count));                           \
+    if (_e != hipSuccess) { gpf_destroy(e); return fail(GPF_E_DEVICE, std::string("alloc " #arr ": ") + hipGetErrorString(_e)); } \
+  } while (0)
+  UP(sub_vn_kv, d->sub_vn_kv, g.n_sub);
+  UP(line_or_sub, d->line_or_sub, nl); UP(line_ex_sub, d->line_ex_sub, nl);
+  UP(line_or_pos, d->line_or_pos_topo_vect, nl); UP(line_ex_pos, d->line_ex_pos_topo_vect, nl);
+  UP(br_y, d->br_y, 8 * (size_t)nl); UP(br_bdc, d->br_bdc, nl);
+  UP(gen_sub, d->gen_sub, ng); UP(gen_pos, d->gen_pos_topo_vect, ng);
+  UP(gen_min_q, d->gen_min_q, ng); UP(gen_max_q, d->gen_max_q, ng); UP(gen_slack, d->gen_slack, ng);
+  UP(load_sub, d->load_sub, nd); UP(load_pos, d->load_pos_topo_vect, nd);
+  UP(sto_sub, d->storage_sub, ns); UP(sto_pos, d->storage_pos_topo_vect, ns);
+  UP(shunt_sub, d->shunt_sub, nsh); UP(shunt_fact, d->shunt_fact, nsh);
+  UP(d_init_inj, d->init_inj, g.n_inj); UP(d_init_topo, d->init_topo, g.dim_topo); UP(d_init_shunt_bus, d->init_shunt_bus, nsh);
+  g.sub_vn_kv = e->sub_vn_kv.p; g.line_or_sub = e->line_or_sub.p; g.line_ex_sub = e->line_ex_sub.p;
+  g.line_or_pos = e->line_or_pos.p; g.line_ex_pos = e->line_ex_pos.p; g.br_y = e->br_y.p; g.br_bdc = e->br_bdc.p;
+  g.gen_sub = e->gen_sub.p; g.gen_pos = e->gen_pos.p; g.gen_min_q = e->gen_min_q.p; g.gen_max_q = e->gen_max_q.p;
+  g.gen_slack = e->gen_slack.p; g.load_sub = e->load_sub.p; g.load_pos = e->load_pos.p; g.sto_sub = e->sto_sub.p;
+  g.sto_pos = e->sto_pos.p; g.shunt_sub = e->shunt_sub.p; g.shunt_fact = e->shunt_fact.p;
+
+  const size_t B = (size_t)n_lanes;
+  AL(inj, B * g.n_inj); AL(topo, B * g.dim_topo); AL(shunt_bus, B * nsh);
+  AL(out, B * g.n_out); AL(topo_out, B * g.dim_topo); AL(shunt_bus_out, B * nsh); AL(line_status, B * nl);
+  AL(status, B * 4); AL(bus_vm, B * g.nb_tot); AL(bus_va, B * g.nb_tot);
+  AL(overflow_count, B * nl); AL(disc_round, B * nl); AL(rho, B * nl);
+  AL(lane_table, B); AL(lane_offset, B); AL(thermal_limit, nl); AL(tmp_lines, std::max<size_t>(B, 1));
+#undef UP
+#undef AL
+  hipError_t es = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+  if (es != hipSuccess) { gpf_destroy(e); return fail(GPF_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(es)); }
+  count_lane(e, e->h_init_topo.data(), nsh ? e->h_init_shunt_bus.data() : nullptr, e->init_nb, e->init_nj);
+  e->lane_nb.assign(n_lanes, e->init_nb);
+  e->lane_nj.assign(n_lanes, e->init_nj);
+  HIP_TRY(hipMemsetAsync(e->status.p, 0xFF, B * 4 * sizeof(int), e->stream));
+  HIP_TRY(hipMemsetAsync(e->overflow_count.p, 0, B * nl * sizeof(int), e->stream));
+  HIP_TRY(hipMemsetAsync(e->lane_table.p, 0, B * sizeof(int), e->stream));
+  HIP_TRY(hipMemsetAsync(e->lane_offset.p, 0, B * sizeof(int), e->stream));
+  {
+    std::vector<float> lim(nl, 1e30f);
+    HIP_TRY(hipMemcpyAsync(e->thermal_limit.p, lim.data(), nl * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  *out_h = e;
+  int rc = gpf_reset_lanes(e, 0, n_lanes);
+  if (rc != GPF_OK) { gpf_destroy(e); *out_h = nullptr; return rc; }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_destroy(gpf_handle e) {
+  if (!e) return GPF_OK;
+  (void)hipSetDevice(e->device);
+  if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
+  for (auto& pr : e->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  e->sub_vn_kv.release(); e->br_y.release(); e->br_bdc.release(); e->gen_min_q.release(); e->gen_max_q.release();
+  e->shunt_fact.release(); e->line_or_sub.release(); e->line_ex_sub.release(); e->line_or_pos.release();
+  e->line_ex_pos.release(); e->gen_sub.release(); e->gen_pos.release(); e->load_sub.release(); e->load_pos.release();
+  e->sto_sub.release(); e->sto_pos.release(); e->shunt_sub.release(); e->gen_slack.release();
+  e->inj.release(); e->bus_vm.release(); e->bus_va.release(); e->work.release(); e->topo.release(); e->shunt_bus.release();
+  e->topo_out.release(); e->shunt_bus_out.release(); e->status.release(); e->overflow_count.release(); e->disc_round.release();
+  e->lane_table.release(); e->lane_offset.release(); e->tmp_lines.release(); e->out.release(); e->chron.release();
+  e->lane_scale.release(); e->thermal_limit.release(); e->rho.release(); e->line_status.release();
+  e->d_init_inj.release(); e->d_init_topo.release(); e->d_init_shunt_bus.release();
+  delete e;
+  return GPF_OK;
+}
+
+int gpf_get_layout(gpf_handle e, gpf_layout* out) {
+  if (!e || !out) return fail(GPF_E_INVALID, "gpf_get_layout: null");
+  *out = e->layout;
+  return GPF_OK;
+}
+
+int gpf_n_lanes(gpf_handle e) { return e ? e->n_lanes : GPF_E_INVALID; }
+
+int gpf_set_injections(gpf_handle e, int32_t lane0, int32_t n, const double* inj) {
+  if (!check_range(e, lane0, n) || !inj) return fail(GPF_E_INVALID, "gpf_set_injections: bad range");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(e->inj.p + (size_t)lane0 * e->g.n_inj, inj, (size_t)n * e->g.n_inj * sizeof(double),
+                         hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));   // the host buffer may be reused by the caller right away
+  return GPF_OK;
+}
+
+int gpf_set_topology(gpf_handle e, int32_t lane0, int32_t n, const int32_t* topo, const int32_t* shunt_bus) {
+  if (!check_range(e, lane0, n) || !topo) return fail(GPF_E_INVALID, "gpf_set_topology: bad range");
+  HIP_TRY(hipSetDevice(e->device));
+  const gpf::GridDev& g = e->g;
+  for (int k = 0; k < n; ++k) {
+    const int* t = topo + (size_t)k * g.dim_topo;
+    for (int i = 0; i < g.dim_topo; ++i)
+      if (t[i] > g.n_busbar) return fail(GPF_E_INVALID, "gpf_set_topology: local bus id > n_busbar");
+  }
+  HIP_TRY(hipMemcpyAsync(e->topo.p + (size_t)lane0 * g.dim_topo, topo, (size_t)n * g.dim_topo * sizeof(int),
+                         hipMemcpyHostToDevice, e->stream));
+  std::vector<int> sb_host;
+  if (shunt_bus && g.n_shunt) {
+    for (size_t i = 0; i < (size_t)n * g.n_shunt; ++i)
+      if (shunt_bus[i] > g.n_busbar) return fail(GPF_E_INVALID, "gpf_set_topology: shunt bus id > n_busbar");
+    HIP_TRY(hipMemcpyAsync(e->shunt_bus.p + (size_t)lane0 * g.n_shunt, shunt_bus, (size_t)n * g.n_shunt * sizeof(int),
+                           hipMemcpyHostToDevice, e->stream));
+  } else if (g.n_shunt) {
+    sb_host.resize((size_t)n * g.n_shunt);
+    HIP_TRY(hipMemcpyAsync(sb_host.data(), e->shunt_bus.p + (size_t)lane0 * g.n_shunt, sb_host.size() * sizeof(int),
+                           hipMemcpyDeviceToHost, e->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (int k = 0; k < n; ++k) {
+    const int* sb = nullptr;
+    if (g.n_shunt) sb = shunt_bus ? shunt_bus + (size_t)k * g.n_shunt : sb_host.data() + (size_t)k * g.n_shunt;
+    count_lane(e, topo + (size_t)k * g.dim_topo, sb, e->lane_nb[lane0 + k], e->lane_nj[lane0 + k]);
+  }
+  return GPF_OK;
+}
+
+int gpf_get_injections(gpf_handle e, int32_t lane0, int32_t n, double* inj) {
+  if (!check_range(e, lane0, n) || !inj) return fail(GPF_E_INVALID, "gpf_get_injections: bad range");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(inj, e->inj.p + (size_t)lane0 * e->g.n_inj, (size_t)n * e->g.n_inj * sizeof(double),
+                         hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_get_topology(gpf_handle e, int32_t lane0, int32_t n, int32_t* topo, int32_t* shunt_bus) {
+  if (!check_range(e, lane0, n)) return fail(GPF_E_INVALID, "gpf_get_topology: bad range");
+  HIP_TRY(hipSetDevice(e->device));
+  if (topo)
+    HIP_TRY(hipMemcpyAsync(topo, e->topo.p + (size_t)lane0 * e->g.dim_topo, (size_t)n * e->g.dim_topo * sizeof(int),
+                           hipMemcpyDeviceToHost, e->stream));
+  if (shunt_bus && e->g.n_shunt)
+    HIP_TRY(hipMemcpyAsync(shunt_bus, e->shunt_bus.p + (size_t)lane0 * e->g.n_shunt, (size_t)n * e->g.n_shunt * sizeof(int),
+                           hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_disconnect_line(gpf_handle e, int32_t lane, int32_t line_id) {
+  if (!check_range(e, lane, 1) || line_id < 0 || line_id >= e->g.n_line) return fail(GPF_E_INVALID, "gpf_disconnect_line: bad ids");
+  HIP_TRY(hipSetDevice(e->device));
+  const int m1 = -1;
+  int* row = e->topo.p + (size_t)lane * e->g.dim_topo;
+  HIP_TRY(hipMemcpyAsync(row + e->h_line_or_pos[line_id], &m1, sizeof(int), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(row + e->h_line_ex_pos[line_id], &m1, sizeof(int), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;   // removing a branch never increases the bus / unknown counts: capacity bookkeeping unchanged
+}
+
+int gpf_reset_lanes(gpf_handle e, int32_t lane0, int32_t n) {
+  if (!check_range(e, lane0, n)) return fail(GPF_E_INVALID, "gpf_reset_lanes: bad range");
+  HIP_TRY(hipSetDevice(e->device));
+  const gpf::GridDev& g = e->g;
+  // replicate the pristine rows (host staging keeps this a plain strided copy)
+  std::vector<double> inj((size_t)n * g.n_inj);
+  std::vector<int> topo((size_t)n * g.dim_topo), sb((size_t)n * g.n_shunt);
+  for (int k = 0; k < n; ++k) {
+    std::copy(e->h_init_inj.begin(), e->h_init_inj.end(), inj.begin() + (size_t)k * g.n_inj);
+    std::copy(e->h_init_topo.begin(), e->h_init_topo.end(), topo.begin() + (size_t)k * g.dim_topo);
+    if (g.n_shunt) std::copy(e->h_init_shunt_bus.begin(), e->h_init_shunt_bus.end(), sb.begin() + (size_t)k * g.n_shunt);
+  }
+  HIP_TRY(hipMemcpyAsync(e->inj.p + (size_t)lane0 * g.n_inj, inj.data(), inj.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->topo.p + (size_t)lane0 * g.dim_topo, topo.data(), topo.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  if (g.n_shunt)
+    HIP_TRY(hipMemcpyAsync(e->shunt_bus.p + (size_t)lane0 * g.n_shunt, sb.data(), sb.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemsetAsync(e->overflow_count.p + (size_t)lane0 * g.n_line, 0, (size_t)n * g.n_line * sizeof(int), e->stream));
+  HIP_TRY(hipMemsetAsync(e->status.p + (size_t)lane0 * 4, 0xFF, (size_t)n * 4 * sizeof(int), e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (int k = lane0; k < lane0 + n; ++k) { e->lane_nb[k] = e->init_nb; e->lane_nj[k] = e->init_nj; }
+  return GPF_OK;
+}
+
+int gpf_copy_lanes(gpf_handle e, int32_t src, int32_t dst, int32_t n) {
+  if (!check_range(e, src, n) || !check_range(e, dst, n)) return fail(GPF_E_INVALID, "gpf_copy_lanes: bad range");
+  if (src == dst || n == 0) return GPF_OK;
+  if (std::abs(src - dst) < n) return fail(GPF_E_INVALID, "gpf_copy_lanes: overlapping ranges");
+  HIP_TRY(hipSetDevice(e->device));
+  const gpf::GridDev& g = e->g;
+#define CP(arr, stride)                                                                                                     \
+  if ((stride) > 0)                                                                                                         \
+  HIP_TRY(hipMemcpyAsync(e->arr.p + (size_t)dst * (stride), e->arr.p + (size_t)src * (stride),                              \
+                         (size_t)n * (stride) * sizeof(*e->arr.p), hipMemcpyDeviceToDevice, e->stream))
+  CP(inj, g.n_inj); CP(topo, g.dim_topo); CP(shunt_bus, g.n_shunt); CP(out, g.n_out); CP(topo_out, g.dim_topo);
+  CP(shunt_bus_out, g.n_shunt); CP(line_status, g.n_line); CP(status, 4); CP(bus_vm, g.nb_tot); CP(bus_va, g.nb_tot);
+  CP(overflow_count, g.n_line); CP(disc_round, g.n_line); CP(rho, g.n_line);
+#undef CP
+  for (int k = 0; k < n; ++k) { e->lane_nb[dst + k] = e->lane_nb[src + k]; e->lane_nj[dst + k] = e->lane_nj[src + k]; }
+  return GPF_OK;
+}
+
+int gpf_fanout_n1(gpf_handle e, int32_t src, int32_t dst0, int32_t n_out, const int32_t* out_lines) {
+  if (!check_range(e, src, 1) || !check_range(e, dst0, n_out) || !out_lines) return fail(GPF_E_INVALID, "gpf_fanout_n1: bad range");
+  if (src >= dst0 && src < dst0 + n_out) return fail(GPF_E_INVALID, "gpf_fanout_n1: source inside destination range");
+  if (n_out == 0) return GPF_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  if (e->tmp_lines.n < (size_t)n_out) { e->tmp_lines.release(); HIP_TRY(e->tmp_lines.alloc(n_out)); }
+  HIP_TRY(hipMemcpyAsync(e->tmp_lines.p, out_lines, (size_t)n_out * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(gpf::fanout_kernel, dim3(n_out), dim3(64), 0, e->stream, e->g, e->bufs(), src, dst0, n_out, e->tmp_lines.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(e->stream));   // out_lines may be reused by the caller
+  for (int k = 0; k < n_out; ++k) { e->lane_nb[dst0 + k] = e->lane_nb[src]; e->lane_nj[dst0 + k] = e->lane_nj[src]; }
+  return GPF_OK;
+}
+
+int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max_iter, double tol_mva) {
+  if (!check_range(e, lane0, n)) return fail(GPF_E_INVALID, "gpf_runpf: bad range");
+  if (n == 0) return GPF_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  LaunchPlan p;
+  int rc = plan_launch(e, lane0, n, p);
+  if (rc != GPF_OK) return rc;
+  gpf::Bufs b = e->bufs();
+  b.work_stride = (long long)work_stride(p);
+  const double tol_pu = tol_mva / e->g.sn_mva;
+  hipEvent_t ea = nullptr, eb = nullptr;
+  if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
+  if (p.big) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    hipLaunchKernelGGL(gpf::runpf_kernel<true>, dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->g, b, e->oo, lane0, p.nbc, p.nJ,
+                       is_dc, max_iter, tol_pu);
+  } else {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    hipLaunchKernelGGL(gpf::runpf_kernel<false>, dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->g, b, e->oo, lane0, p.nbc, p.nJ,
+                       is_dc, max_iter, tol_pu);
+  }
+  HIP_TRY(hipGetLastError());
+  if (e->profiling) HIP_TRY(hipEventRecord(eb, e->stream));
+  return GPF_OK;
+}
+
+int gpf_get_results(gpf_handle e, int32_t lane0, int32_t n, float* out, int32_t* topo_vect, int32_t* shunt_bus,
+                    uint8_t* line_status, int32_t* status, double* bus_vm, double* bus_va) {
+  if (!check_range(e, lane0, n)) return fail(GPF_E_INVALID, "gpf_get_results: bad range");
+  HIP_TRY(hipSetDevice(e->device));
+  const gpf::GridDev& g = e->g;
+#define DL(dst, arr, stride)                                                                                   \
+  if ((dst) && (stride) > 0)                                                                                   \
+  HIP_TRY(hipMemcpyAsync(dst, e->arr.p + (size_t)lane0 * (stride), (size_t)n * (stride) * sizeof(*e->arr.p),   \
+                         hipMemcpyDeviceToHost, e->stream))
+  DL(out, out, g.n_out); DL(topo_vect, topo_out, g.dim_topo); DL(shunt_bus, shunt_bus_out, g.n_shunt);
+  DL(line_status, line_status, g.n_line); DL(status, status, 4); DL(bus_vm, bus_vm, g.nb_tot); DL(bus_va, bus_va, g.nb_tot);
+#undef DL
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_upload_chronics(gpf_handle e, int32_t n_tables, int32_t T, const float* data) {
+  if (!e || n_tables <= 0 || T <= 0 || !data) return fail(GPF_E_INVALID, "gpf_upload_chronics: bad arguments");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->chron.release();
+  HIP_TRY(e->chron.upload(data, (size_t)n_tables * T * e->g.n_chron));
+  e->chron_T = T;
+  e->chron_tables = n_tables;
+  return GPF_OK;
+}
+
+int gpf_set_lane_chronics(gpf_handle e, const int32_t* lane_table, const int32_t* lane_offset, const float* lane_scale) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_set_lane_chronics: null");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t B = e->n_lanes;
+  if (lane_table) {
+    for (size_t k = 0; k < B; ++k)
+      if (lane_table[k] < 0 || (e->chron_tables && lane_table[k] >= e->chron_tables)) return fail(GPF_E_INVALID, "lane_table out of range");
+    HIP_TRY(hipMemcpyAsync(e->lane_table.p, lane_table, B * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  }
+  if (lane_offset) HIP_TRY(hipMemcpyAsync(e->lane_offset.p, lane_offset, B * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  if (lane_scale) {
+    if (!e->lane_scale.p) HIP_TRY(e->lane_scale.alloc(B * 2 * e->g.n_load));
+    HIP_TRY(hipMemcpyAsync(e->lane_scale.p, lane_scale, B * 2 * e->g.n_load * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    e->has_scale = true;
+  } else {
+    e->has_scale = false;
+  }
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_set_thermal_limits(gpf_handle e, const float* limit_a) {
+  if (!e || !limit_a) return fail(GPF_E_INVALID, "gpf_set_thermal_limits: null");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(e->thermal_limit.p, limit_a, e->g.n_line * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double rebalance, int32_t cascade, float hard_overflow,
+             float soft_overflow, int32_t nb_ts_allowed, int32_t max_rounds) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_step: null");
+  if (!e->chron.p || e->chron_T <= 0) return fail(GPF_E_INVALID, "gpf_step: no chronics uploaded");
+  HIP_TRY(hipSetDevice(e->device));
+  LaunchPlan p;
+  int rc = plan_launch(e, 0, e->n_lanes, p);
+  if (rc != GPF_OK) return rc;
+  gpf::Bufs b = e->bufs();
+  b.work_stride = (long long)work_stride(p);
+  gpf::StepArgs sa{};
+  sa.t = t; sa.T = e->chron_T; sa.rebalance_on = rebalance > 0.0 ? 1 : 0; sa.rebalance = rebalance; sa.cascade = cascade;
+  sa.nb_ts_allowed = nb_ts_allowed; sa.max_rounds = max_rounds; sa.hard_overflow = hard_overflow; sa.soft_overflow = soft_overflow;
+  const double tol_pu = tol_mva / e->g.sn_mva;
+  hipEvent_t ea = nullptr, eb = nullptr;
+  if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
+  if (p.big) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    hipLaunchKernelGGL(gpf::step_kernel<true>, dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->g, b, e->oo, p.nbc, p.nJ,
+                       max_iter, tol_pu, sa);
+  } else {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
+    hipLaunchKernelGGL(gpf::step_kernel<false>, dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->g, b, e->oo, p.nbc, p.nJ,
+                       max_iter, tol_pu, sa);
+  }
+  HIP_TRY(hipGetLastError());
+  if (e->profiling) HIP_TRY(hipEventRecord(eb, e->stream));
+  return GPF_OK;
+}
+
+int gpf_get_step_outputs(gpf_handle e, int32_t lane0, int32_t n, float* rho, int32_t* overflow_count, int32_t* disc_round) {
+  if (!check_range(e, lane0, n)) return fail(GPF_E_INVALID, "gpf_get_step_outputs: bad range");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t nl = e->g.n_line;
+  if (rho) HIP_TRY(hipMemcpyAsync(rho, e->rho.p + lane0 * nl, n * nl * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  if (overflow_count)
+    HIP_TRY(hipMemcpyAsync(overflow_count, e->overflow_count.p + lane0 * nl, n * nl * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  if (disc_round)
+    HIP_TRY(hipMemcpyAsync(disc_round, e->disc_round.p + lane0 * nl, n * nl * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_sync(gpf_handle e) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_sync: null");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_set_profiling(gpf_handle e, int32_t enabled) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_set_profiling: null");
+  e->profiling = enabled != 0;
+  return GPF_OK;
+}
+
+int gpf_get_kernel_time(gpf_handle e, double* total_ms, int64_t* n_launches) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_get_kernel_time: null");
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = drain_events(e);
+  if (rc != GPF_OK) return rc;
+  if (total_ms) *total_ms = e->acc_ms;
+  if (n_launches) *n_launches = e->acc_launches;
+  e->acc_ms = 0.0;
+  e->acc_launches = 0;
+  return GPF_OK;
+}
+
+int gpf_device_pointers(gpf_handle e, void** ptrs, void** stream) {
+  if (!e || !ptrs) return fail(GPF_E_INVALID, "gpf_device_pointers: null");
+  ptrs[0] = e->inj.p; ptrs[1] = e->topo.p; ptrs[2] = e->shunt_bus.p; ptrs[3] = e->out.p; ptrs[4] = e->topo_out.p;
+  ptrs[5] = e->line_status.p; ptrs[6] = e->status.p; ptrs[7] = e->chron.p;
+  if (stream) *stream = e->stream;
+  return GPF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,296 @@
+"""`PowerFlowEngine`: the batched MI355X power-flow engine (Python over the C ABI, no grid2op needed).
+
+One engine = one grid (`GridModel`) x ``n_lanes`` independent grid instances ("lanes": environment
+copies or N-1 contingencies) resident in the HBM of one GPU.  All arithmetic happens in
+``libgridpf.so`` (hand-written HIP for gfx950); this module only marshals numpy arrays.
+
+The single-environment drop-in `grid2op_amd.backend.HipBackend` is a one-lane view on such an engine;
+the batched stepping API (`upload_chronics` / `step`) is what ``bench.py`` measures.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from . import _capi
+from ._capi import GpfGridDesc, GpfLayout, GridPFError, check, ptr
+from .grid_model import GridModel
+
+__all__ = ["PowerFlowEngine", "LaneResults", "GridPFError", "ST_CONVERGED", "STATUS_TEXT"]
+
+ST_CONVERGED = 0
+STATUS_TEXT = {
+    0: "converged",
+    1: "Newton-Raphson did not converge within max_iter iterations",
+    2: "islanded grid (an active bus is not connected to the slack bus)",
+    3: "no in-service slack generator",
+    4: "singular matrix",
+    5: "engine capacity exceeded",
+    -1: "power flow not run",
+}
+
+_OUT_FIELDS = [
+    ("p_or", "n_line"), ("q_or", "n_line"), ("v_or", "n_line"), ("a_or", "n_line"), ("theta_or", "n_line"),
+    ("p_ex", "n_line"), ("q_ex", "n_line"), ("v_ex", "n_line"), ("a_ex", "n_line"), ("theta_ex", "n_line"),
+    ("gen_p", "n_gen"), ("gen_q", "n_gen"), ("gen_v", "n_gen"), ("gen_theta", "n_gen"),
+    ("load_p", "n_load"), ("load_q", "n_load"), ("load_v", "n_load"), ("load_theta", "n_load"),
+    ("storage_p", "n_storage"), ("storage_q", "n_storage"), ("storage_v", "n_storage"), ("storage_theta", "n_storage"),
+    ("shunt_p", "n_shunt"), ("shunt_q", "n_shunt"), ("shunt_v", "n_shunt"),
+]
+_INJ_FIELDS = [("gen_p", "n_gen"), ("gen_vm", "n_gen"), ("load_p", "n_load"), ("load_q", "n_load"),
+               ("storage_p", "n_storage"), ("storage_q", "n_storage"), ("shunt_p", "n_shunt"), ("shunt_q", "n_shunt")]
+
+
+@dataclass
+class LaneResults:
+    """Results of ``n`` lanes; every float field is a float32 ``[n, n_el]`` view of one ``out`` block."""
+    out: np.ndarray
+    topo_vect: np.ndarray
+    shunt_bus: np.ndarray
+    line_status: np.ndarray
+    status: np.ndarray           # [n, 4] {status, n_iter, n_active_bus, n_cascade_rounds}
+    bus_vm: np.ndarray           # float64 [n, nb_total] (pu), NaN for inactive buses
+    bus_va: np.ndarray           # float64 [n, nb_total] (deg)
+    _slices: Dict[str, slice]
+
+    def __getattr__(self, name):
+        sl = self.__dict__.get("_slices", {}).get(name)
+        if sl is None:
+            raise AttributeError(name)
+        return self.out[:, sl]
+
+    @property
+    def converged(self) -> np.ndarray:
+        return self.status[:, 0] == ST_CONVERGED
+
+    @property
+    def n_iter(self) -> np.ndarray:
+        return self.status[:, 1]
+
+
+class PowerFlowEngine:
+    def __init__(self, model: GridModel, n_lanes: int = 1, device: int = 0, n_busbar: int = 2):
+        self.model = model
+        self.n_busbar = int(n_busbar)
+        self._lib = _capi.lib()
+        self._h = C.c_void_p()
+        m = model
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        br_y = np.empty((m.n_line, 8), dtype=np.float64)
+        for k, y in enumerate((m.br_yff, m.br_yft, m.br_ytf, m.br_ytt)):
+            br_y[:, 2 * k] = y.real
+            br_y[:, 2 * k + 1] = y.imag
+        init_inj = np.concatenate([f64(m.gen_p0), f64(m.gen_vm0), f64(m.load_p0), f64(m.load_q0), f64(m.storage_p0),
+                                   f64(m.storage_q0), f64(m.shunt_p0), f64(m.shunt_q0)])
+        keep = dict(
+            sub_vn_kv=f64(m.sub_vn_kv), line_or_sub=i32(m.line_or_sub), line_ex_sub=i32(m.line_ex_sub),
+            line_or_pos=i32(m.line_or_pos_topo_vect), line_ex_pos=i32(m.line_ex_pos_topo_vect), br_y=br_y,
+            br_bdc=f64(m.br_bdc), gen_sub=i32(m.gen_sub), gen_pos=i32(m.gen_pos_topo_vect), gen_min_q=f64(m.gen_min_q),
+            gen_max_q=f64(m.gen_max_q), gen_slack=np.ascontiguousarray(m.gen_slack, dtype=np.uint8),
+            load_sub=i32(m.load_sub), load_pos=i32(m.load_pos_topo_vect), sto_sub=i32(m.storage_sub),
+            sto_pos=i32(m.storage_pos_topo_vect), shunt_sub=i32(m.shunt_sub), shunt_fact=f64(m.shunt_fact),
+            init_inj=init_inj, init_topo=i32(m.initial_topo_vect()), init_shunt_bus=i32(m.initial_shunt_bus()))
+        d = GpfGridDesc()
+        d.n_sub, d.n_busbar = m.n_sub, self.n_busbar
+        d.n_line, d.n_gen, d.n_load, d.n_storage, d.n_shunt, d.dim_topo = (m.n_line, m.n_gen, m.n_load, m.n_storage,
+                                                                              m.n_shunt, m.dim_topo)
+        d.sn_mva = m.sn_mva
+        d.sub_vn_kv = ptr(keep["sub_vn_kv"], C.c_double)
+        d.line_or_sub = ptr(keep["line_or_sub"], C.c_int32)
+        d.line_ex_sub = ptr(keep["line_ex_sub"], C.c_int32)
+        d.line_or_pos_topo_vect = ptr(keep["line_or_pos"], C.c_int32)
+        d.line_ex_pos_topo_vect = ptr(keep["line_ex_pos"], C.c_int32)
+        d.br_y = ptr(keep["br_y"], C.c_double)
+        d.br_bdc = ptr(keep["br_bdc"], C.c_double)
+        d.gen_sub = ptr(keep["gen_sub"], C.c_int32)
+        d.gen_pos_topo_vect = ptr(keep["gen_pos"], C.c_int32)
+        d.gen_min_q = ptr(keep["gen_min_q"], C.c_double)
+        d.gen_max_q = ptr(keep["gen_max_q"], C.c_double)
+        d.gen_slack = ptr(keep["gen_slack"], C.c_uint8)
+        d.load_sub = ptr(keep["load_sub"], C.c_int32)
+        d.load_pos_topo_vect = ptr(keep["load_pos"], C.c_int32)
+        d.storage_sub = ptr(keep["sto_sub"], C.c_int32)
+        d.storage_pos_topo_vect = ptr(keep["sto_pos"], C.c_int32)
+        d.shunt_sub = ptr(keep["shunt_sub"], C.c_int32)
+        d.shunt_fact = ptr(keep["shunt_fact"], C.c_double)
+        d.init_inj = ptr(keep["init_inj"], C.c_double)
+        d.init_topo = ptr(keep["init_topo"], C.c_int32)
+        d.init_shunt_bus = ptr(keep["init_shunt_bus"], C.c_int32)
+        check(self._lib.gpf_create(C.byref(d), int(n_lanes), int(device), C.byref(self._h)), "gpf_create")
+        self.n_lanes = int(n_lanes)
+        self.device = int(device)
+        lay = GpfLayout()
+        check(self._lib.gpf_get_layout(self._h, C.byref(lay)), "gpf_get_layout")
+        self.layout = lay
+        self.n_inj, self.n_out, self.n_chron, self.nb_total = lay.n_inj, lay.n_out, lay.n_chron, lay.nb_total
+        sizes = dict(n_line=m.n_line, n_gen=m.n_gen, n_load=m.n_load, n_storage=m.n_storage, n_shunt=m.n_shunt)
+        self.out_slices = {}
+        for name, sz in _OUT_FIELDS:
+            key = "out_" + name
+            off = getattr(lay, key)
+            self.out_slices[name] = slice(off, off + sizes[sz])
+        self.inj_slices = {}
+        for name, sz in _INJ_FIELDS:
+            off = getattr(lay, "inj_" + name)
+            self.inj_slices[name] = slice(off, off + sizes[sz])
+        self.init_inj = init_inj.copy()
+
+    # ------------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.gpf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _range(self, lane0, n):
+        if n is None:
+            n = self.n_lanes - lane0
+        return int(lane0), int(n)
+
+    # ---- state --------------------------------------------------------------------------------------
+    def pack_injections(self, n: int = 1, **fields) -> np.ndarray:
+        """``[n, n_inj]`` float64 rows starting from the pristine injections; override by field name."""
+        inj = np.tile(self.init_inj, (n, 1))
+        for k, v in fields.items():
+            inj[:, self.inj_slices[k]] = v
+        return inj
+
+    def set_injections(self, inj: np.ndarray, lane0: int = 0):
+        inj = np.ascontiguousarray(inj, dtype=np.float64).reshape(-1, self.n_inj)
+        check(self._lib.gpf_set_injections(self._h, lane0, inj.shape[0], ptr(inj, C.c_double)), "gpf_set_injections")
+
+    def get_injections(self, lane0: int = 0, n: Optional[int] = None) -> np.ndarray:
+        lane0, n = self._range(lane0, n)
+        inj = np.empty((n, self.n_inj), dtype=np.float64)
+        check(self._lib.gpf_get_injections(self._h, lane0, n, ptr(inj, C.c_double)), "gpf_get_injections")
+        return inj
+
+    def set_topology(self, topo: np.ndarray, shunt_bus: Optional[np.ndarray] = None, lane0: int = 0):
+        topo = np.ascontiguousarray(topo, dtype=np.int32).reshape(-1, self.model.dim_topo)
+        sb = None
+        if shunt_bus is not None and self.model.n_shunt:
+            sb = np.ascontiguousarray(shunt_bus, dtype=np.int32).reshape(-1, self.model.n_shunt)
+            assert sb.shape[0] == topo.shape[0]
+        check(self._lib.gpf_set_topology(self._h, lane0, topo.shape[0], ptr(topo, C.c_int32), ptr(sb, C.c_int32)),
+              "gpf_set_topology")
+
+    def get_topology(self, lane0: int = 0, n: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+        lane0, n = self._range(lane0, n)
+        topo = np.empty((n, self.model.dim_topo), dtype=np.int32)
+        sb = np.empty((n, self.model.n_shunt), dtype=np.int32)
+        check(self._lib.gpf_get_topology(self._h, lane0, n, ptr(topo, C.c_int32), ptr(sb, C.c_int32)), "gpf_get_topology")
+        return topo, sb
+
+    def disconnect_line(self, lane: int, line_id: int):
+        check(self._lib.gpf_disconnect_line(self._h, lane, line_id), "gpf_disconnect_line")
+
+    def reset(self, lane0: int = 0, n: Optional[int] = None):
+        lane0, n = self._range(lane0, n)
+        check(self._lib.gpf_reset_lanes(self._h, lane0, n), "gpf_reset_lanes")
+
+    def copy_lanes(self, src: int, dst: int, n: int = 1):
+        check(self._lib.gpf_copy_lanes(self._h, src, dst, n), "gpf_copy_lanes")
+
+    def fanout_n1(self, src_lane: int, dst_lane0: int, out_lines):
+        ol = np.ascontiguousarray(out_lines, dtype=np.int32)
+        check(self._lib.gpf_fanout_n1(self._h, src_lane, dst_lane0, ol.size, ptr(ol, C.c_int32)), "gpf_fanout_n1")
+
+    # ---- solve --------------------------------------------------------------------------------------
+    def runpf(self, lane0: int = 0, n: Optional[int] = None, is_dc: bool = False, max_iter: int = 10,
+              tol_mva: float = 1e-8):
+        lane0, n = self._range(lane0, n)
+        check(self._lib.gpf_runpf(self._h, lane0, n, int(bool(is_dc)), int(max_iter), float(tol_mva)), "gpf_runpf")
+
+    def results(self, lane0: int = 0, n: Optional[int] = None, with_bus: bool = True) -> LaneResults:
+        lane0, n = self._range(lane0, n)
+        m = self.model
+        out = np.empty((n, self.n_out), dtype=np.float32)
+        tv = np.empty((n, m.dim_topo), dtype=np.int32)
+        sb = np.empty((n, m.n_shunt), dtype=np.int32)
+        ls = np.empty((n, m.n_line), dtype=np.uint8)
+        st = np.empty((n, 4), dtype=np.int32)
+        bvm = np.empty((n, self.nb_total), dtype=np.float64) if with_bus else None
+        bva = np.empty((n, self.nb_total), dtype=np.float64) if with_bus else None
+        check(self._lib.gpf_get_results(self._h, lane0, n, ptr(out, C.c_float), ptr(tv, C.c_int32), ptr(sb, C.c_int32),
+                                        ptr(ls, C.c_uint8), ptr(st, C.c_int32), ptr(bvm, C.c_double), ptr(bva, C.c_double)),
+              "gpf_get_results")
+        return LaneResults(out=out, topo_vect=tv, shunt_bus=sb, line_status=ls.astype(bool), status=st, bus_vm=bvm,
+                           bus_va=bva, _slices=self.out_slices)
+
+    # ---- batched stepping -----------------------------------------------------------------------------
+    def pack_chronics(self, load_p, load_q, prod_p, prod_v) -> np.ndarray:
+        """``[..., T, n_chron]`` float32 table from the four ``[..., T, n]`` chronics arrays."""
+        return np.ascontiguousarray(np.concatenate([load_p, load_q, prod_p, prod_v], axis=-1), dtype=np.float32)
+
+    def upload_chronics(self, tables: np.ndarray):
+        tables = np.ascontiguousarray(tables, dtype=np.float32)
+        if tables.ndim == 2:
+            tables = tables[None]
+        assert tables.shape[2] == self.n_chron, (tables.shape, self.n_chron)
+        check(self._lib.gpf_upload_chronics(self._h, tables.shape[0], tables.shape[1], ptr(tables, C.c_float)),
+              "gpf_upload_chronics")
+        self.chron_T = tables.shape[1]
+
+    def set_lane_chronics(self, lane_table=None, lane_offset=None, lane_scale=None):
+        lt = None if lane_table is None else np.ascontiguousarray(lane_table, dtype=np.int32)
+        lo = None if lane_offset is None else np.ascontiguousarray(lane_offset, dtype=np.int32)
+        ls = None if lane_scale is None else np.ascontiguousarray(lane_scale, dtype=np.float32)
+        if lt is not None:
+            assert lt.size == self.n_lanes
+        if lo is not None:
+            assert lo.size == self.n_lanes
+        if ls is not None:
+            assert ls.shape == (self.n_lanes, 2 * self.model.n_load)
+        check(self._lib.gpf_set_lane_chronics(self._h, ptr(lt, C.c_int32), ptr(lo, C.c_int32), ptr(ls, C.c_float)),
+              "gpf_set_lane_chronics")
+
+    def set_thermal_limits(self, limit_a):
+        lim = np.ascontiguousarray(limit_a, dtype=np.float32)
+        assert lim.size == self.model.n_line
+        check(self._lib.gpf_set_thermal_limits(self._h, ptr(lim, C.c_float)), "gpf_set_thermal_limits")
+
+    def step(self, t: int, max_iter: int = 10, tol_mva: float = 1e-8, rebalance: float = 0.0, cascade: bool = False,
+             hard_overflow: float = 2.0, soft_overflow: float = 1.0, nb_ts_allowed: int = 2, max_rounds: int = 16):
+        """One DoNothing ``env.step`` for every lane (asynchronous)."""
+        check(self._lib.gpf_step(self._h, int(t), int(max_iter), float(tol_mva), float(rebalance), int(bool(cascade)),
+                                 float(hard_overflow), float(soft_overflow), int(nb_ts_allowed), int(max_rounds)), "gpf_step")
+
+    def step_outputs(self, lane0: int = 0, n: Optional[int] = None):
+        lane0, n = self._range(lane0, n)
+        nl = self.model.n_line
+        rho = np.empty((n, nl), dtype=np.float32)
+        oc = np.empty((n, nl), dtype=np.int32)
+        dr = np.empty((n, nl), dtype=np.int32)
+        check(self._lib.gpf_get_step_outputs(self._h, lane0, n, ptr(rho, C.c_float), ptr(oc, C.c_int32), ptr(dr, C.c_int32)),
+              "gpf_get_step_outputs")
+        return rho, oc, dr
+
+    # ---- measurement -------------------------------------------------------------------------------------
+    def sync(self):
+        check(self._lib.gpf_sync(self._h), "gpf_sync")
+
+    def set_profiling(self, enabled: bool):
+        check(self._lib.gpf_set_profiling(self._h, int(bool(enabled))), "gpf_set_profiling")
+
+    def kernel_time(self) -> Tuple[float, int]:
+        ms = C.c_double(0.0)
+        n = C.c_int64(0)
+        check(self._lib.gpf_get_kernel_time(self._h, C.byref(ms), C.byref(n)), "gpf_get_kernel_time")
+        return ms.value, n.value
+
+    def algorithmic_bytes_per_step(self) -> int:
+        """inputs at API dtype + outputs at API dtype, topology unchanged."""
+        m = self.model
+        bytes_in = 4 * (2 * m.n_load + 2 * m.n_gen + m.n_storage)
+        bytes_out = 4 * (8 * m.n_line + 3 * m.n_gen + 3 * m.n_load + 3 * m.n_storage
+                         + (2 * m.n_line + m.n_load + m.n_gen + m.n_storage) + 4 * m.n_shunt) + 4 * m.dim_topo + m.n_line
+        return bytes_in + bytes_out

@@ -1,0 +1,171 @@
+/* gridpf.h -- C ABI of libgridpf.so: the MI355X-native batched power-flow engine behind the
+ * grid2op Backend plugin surface.
+ *
+ * The reference (Grid2op/grid2op, 100 % Python) has no FFI of its own: its Backend plugin calls the
+ * third-party package pandapower.  This header declares the entry points a grid2op Backend binds
+ * instead (via ctypes, see INTEGRATION.md and grid2op_amd/_capi.py); each one cites the reference
+ * interface it replaces.  Paths are relative to the reference checkout.
+ *
+ * Conventions: every function returns 0 on success and a negative GPF_E_* code on failure (message via
+ * gpf_last_error()); no exception crosses the ABI; the caller owns every host buffer; a handle is
+ * thread-compatible (use one handle per host thread); all work of a handle is queued on ONE HIP
+ * stream owned by the handle and the gpf_get_* calls synchronise that stream.
+ *
+ * A "lane" is one independent grid instance (one environment copy or one N-1 contingency).  All
+ * per-lane buffers are lane-major: row `lane` of a [n_lanes][stride] array.
+ *
+ * Units (same as grid2op/Backend/backend.py:563-760): MW, MVAr, kV, A, degrees; buses are LOCAL bus
+ * ids 1..n_busbar, -1 = disconnected; generator voltage setpoints are in per unit.
+ */
+#ifndef GRIDPF_H
+#define GRIDPF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPF_OK 0
+#define GPF_E_INVALID (-1)   /* bad argument                                  */
+#define GPF_E_DEVICE (-2)    /* HIP runtime error (no device, OOM, launch)    */
+#define GPF_E_CAPACITY (-3)  /* grid too large for the compiled kernels       */
+
+/* per-lane solver status written by gpf_runpf / gpf_step (status[lane*4 + 0]) */
+#define GPF_ST_CONVERGED 0
+#define GPF_ST_MAXITER 1     /* Newton did not reach the tolerance in max_iter iterations */
+#define GPF_ST_ISLANDED 2    /* an active bus is not connected to a reference bus         */
+#define GPF_ST_NOSLACK 3     /* no in-service slack generator                             */
+#define GPF_ST_SINGULAR 4    /* zero / non finite pivot                                   */
+#define GPF_ST_CAPACITY 5    /* more active buses than the handle was sized for           */
+#define GPF_ST_NOTRUN (-1)
+
+typedef struct gpf_engine* gpf_handle;
+
+/* Static description of one grid = what PandaPowerBackend.load_grid + _init_private_attrs derive
+ * from the grid file (grid2op/Backend/pandaPowerBackend.py:356-617, 670-874) plus the per-unit
+ * branch model pandapower's pd2ppc/makeYbus builds.  Arrays are copied by gpf_create.            */
+typedef struct gpf_grid_desc {
+  int32_t n_sub, n_busbar;                 /* global bus = sub + (local-1)*n_sub (GridObjects.py:4683) */
+  int32_t n_line, n_gen, n_load, n_storage, n_shunt, dim_topo;
+  double sn_mva;
+  const double* sub_vn_kv;                 /* [n_sub]                                              */
+  const int32_t* line_or_sub;              /* [n_line] lines first, then trafos (:462-471)         */
+  const int32_t* line_ex_sub;
+  const int32_t* line_or_pos_topo_vect;    /* [n_line] positions in topo_vect (GridObjects.py:1409) */
+  const int32_t* line_ex_pos_topo_vect;
+  const double* br_y;                      /* [n_line][8] yff.re,yff.im,yft.re,yft.im,ytf.re,ytf.im,ytt.re,ytt.im (pu) */
+  const double* br_bdc;                    /* [n_line] 1/(x*ratio) DC susceptance (pu)             */
+  const int32_t* gen_sub;                  /* [n_gen]                                              */
+  const int32_t* gen_pos_topo_vect;
+  const double* gen_min_q;                 /* [n_gen] MVAr, used for the Q split of co-located gens */
+  const double* gen_max_q;
+  const uint8_t* gen_slack;                /* [n_gen] 1 = slack generator (reference bus follows it) */
+  const int32_t* load_sub;                 /* [n_load]                                             */
+  const int32_t* load_pos_topo_vect;
+  const int32_t* storage_sub;              /* [n_storage]                                          */
+  const int32_t* storage_pos_topo_vect;
+  const int32_t* shunt_sub;                /* [n_shunt]                                            */
+  const double* shunt_fact;                /* [n_shunt] step*(vn_bus/vn_shunt)^2                   */
+  /* pristine lane state (what reset() restores, pandaPowerBackend.py:334-354, 872) */
+  const double* init_inj;                  /* [n_inj] see gpf_layout                               */
+  const int32_t* init_topo;                /* [dim_topo]                                           */
+  const int32_t* init_shunt_bus;           /* [n_shunt]                                            */
+} gpf_grid_desc;
+
+/* Row layouts of the per-lane buffers (offsets in elements). */
+typedef struct gpf_layout {
+  /* injections row (double): what apply_action scatters (pandaPowerBackend.py:925-969) */
+  int32_t n_inj;
+  int32_t inj_gen_p, inj_gen_vm, inj_load_p, inj_load_q, inj_storage_p, inj_storage_q, inj_shunt_p, inj_shunt_q;
+  /* results row (float = grid2op dt_float): what _fetch_data_pf_converged gathers (:1122-1218) */
+  int32_t n_out;
+  int32_t out_p_or, out_q_or, out_v_or, out_a_or, out_theta_or;
+  int32_t out_p_ex, out_q_ex, out_v_ex, out_a_ex, out_theta_ex;
+  int32_t out_gen_p, out_gen_q, out_gen_v, out_gen_theta;
+  int32_t out_load_p, out_load_q, out_load_v, out_load_theta;
+  int32_t out_storage_p, out_storage_q, out_storage_v, out_storage_theta;
+  int32_t out_shunt_p, out_shunt_q, out_shunt_v;
+  /* chronics row (float): load_p[n_load], load_q[n_load], prod_p[n_gen], prod_v[n_gen] (kV) */
+  int32_t n_chron;
+  int32_t chron_load_p, chron_load_q, chron_prod_p, chron_prod_v;
+  int32_t nb_total;                        /* n_sub*n_busbar: row length of the bus voltage buffers */
+} gpf_layout;
+
+const char* gpf_last_error(void);
+int gpf_version(void);
+
+/* load_grid (pandaPowerBackend.py:356): build an engine with `n_lanes` lanes on HIP device `device`.
+ * Every lane starts in the pristine state. */
+int gpf_create(const gpf_grid_desc* desc, int32_t n_lanes, int32_t device, gpf_handle* out);
+/* close (pandaPowerBackend.py:1411-1423) */
+int gpf_destroy(gpf_handle h);
+int gpf_get_layout(gpf_handle h, gpf_layout* out);
+int gpf_n_lanes(gpf_handle h);
+
+/* apply_action, injection half (pandaPowerBackend.py:925-969): overwrite rows lane0..lane0+n-1.
+ * inj is [n][n_inj] double. */
+int gpf_set_injections(gpf_handle h, int32_t lane0, int32_t n, const double* inj);
+/* apply_action, topology half (:920-922, 941-951, 964-975): topo is [n][dim_topo] local bus ids
+ * (the layout of _BackendAction.current_topo.values), shunt_bus is [n][n_shunt] (may be NULL). */
+int gpf_set_topology(gpf_handle h, int32_t lane0, int32_t n, const int32_t* topo, const int32_t* shunt_bus);
+int gpf_get_injections(gpf_handle h, int32_t lane0, int32_t n, double* inj);
+int gpf_get_topology(gpf_handle h, int32_t lane0, int32_t n, int32_t* topo, int32_t* shunt_bus);
+/* _disconnect_line (:1464-1475): both ends of line `line_id` of lane `lane` go to -1. */
+int gpf_disconnect_line(gpf_handle h, int32_t lane, int32_t line_id);
+/* reset (:334-354): back to the pristine state. */
+int gpf_reset_lanes(gpf_handle h, int32_t lane0, int32_t n);
+/* copy (:1289-1409): device-side copy of the complete state (inputs and last results) of `n` lanes. */
+int gpf_copy_lanes(gpf_handle h, int32_t src_lane0, int32_t dst_lane0, int32_t n);
+/* N-1 fan-out (Reward/n1Reward.py:75-99, Observation/_obsEnv.py:321-503): lanes dst0+k (k < n_out)
+ * become copies of `src_lane` with line out_lines[k] disconnected (out_lines[k] < 0: plain copy). */
+int gpf_fanout_n1(gpf_handle h, int32_t src_lane, int32_t dst_lane0, int32_t n_out, const int32_t* out_lines);
+
+/* runpf (pandaPowerBackend.py:1220-1255 -> pp.runpp / pp.rundcpp :1078-1120): one AC Newton-Raphson
+ * (init="dc", <= max_iter iterations, ||F||inf < tol_mva/sn_mva) or DC power flow per lane, then the
+ * result extraction of _fetch_data_pf_converged.  Asynchronous (queued on the handle's stream). */
+int gpf_runpf(gpf_handle h, int32_t lane0, int32_t n, int32_t is_dc, int32_t max_iter, double tol_mva);
+
+/* Getters (pandaPowerBackend.py:1566-1619, 278-301, 1439-1462, 1486): synchronise, then copy rows
+ * lane0..lane0+n-1.  Any pointer may be NULL.
+ *   out         [n][n_out]    float   (NaN everywhere when the lane did not converge, :1257-1287)
+ *   topo_vect   [n][dim_topo] int32   (-1 everywhere when not converged)
+ *   shunt_bus   [n][n_shunt]  int32
+ *   line_status [n][n_line]   uint8
+ *   status      [n][4]        int32   {GPF_ST_*, n_iter, n_active_bus, n_cascade_rounds}
+ *   bus_vm/va   [n][nb_total] double  pu / degrees, NaN for inactive buses (pre-cast parity checks) */
+int gpf_get_results(gpf_handle h, int32_t lane0, int32_t n, float* out, int32_t* topo_vect, int32_t* shunt_bus,
+                    uint8_t* line_status, int32_t* status, double* bus_vm, double* bus_va);
+
+/* ---- batched environment stepping (device-resident chronics) ----------------
+ * chronics: [n_tables][T][n_chron] float, resident in HBM.  Lane k reads row
+ * (t + lane_offset[k]) mod T of table lane_table[k]; loads are multiplied by lane_scale[k][0..2*n_load)
+ * (NULL = 1); if `rebalance` != 0 the non-slack prod_p are rescaled so that sum(prod_p) =
+ * rebalance * sum(load_p) (Environment/baseEnv.py:2516-2563 feeds these 4 vectors each step). */
+int gpf_upload_chronics(gpf_handle h, int32_t n_tables, int32_t T, const float* data);
+int gpf_set_lane_chronics(gpf_handle h, const int32_t* lane_table, const int32_t* lane_offset, const float* lane_scale);
+int gpf_set_thermal_limits(gpf_handle h, const float* limit_a /* [n_line] */);
+/* One DoNothing env.step for every lane (Environment/baseEnv.py:3562 -> Backend.next_grid_state
+ * backend.py:1433-1521): chronics row -> injections -> AC power flow -> results -> overflow counters;
+ * when `cascade` != 0 lines above hard_overflow*limit (or soft-overflowed for more than nb_ts_allowed
+ * steps) are tripped and the power flow re-run, at most max_rounds times. Asynchronous. */
+int gpf_step(gpf_handle h, int32_t t, int32_t max_iter, double tol_mva, double rebalance, int32_t cascade,
+             float hard_overflow, float soft_overflow, int32_t nb_ts_allowed, int32_t max_rounds);
+/* rho = a_or / thermal_limit (backend.py:1145-1168) and overflow counters of the last gpf_step. */
+int gpf_get_step_outputs(gpf_handle h, int32_t lane0, int32_t n, float* rho, int32_t* overflow_count,
+                         int32_t* disc_round);
+
+/* ---- measurement ---------------------------------------------------------------------------------------- */
+int gpf_sync(gpf_handle h);
+/* When enabled every solver launch is bracketed by HIP events on the handle's stream. */
+int gpf_set_profiling(gpf_handle h, int32_t enabled);
+/* Sum of the event-measured durations (ms) and number of solver launches since the last call. */
+int gpf_get_kernel_time(gpf_handle h, double* total_ms, int64_t* n_launches);
+/* Raw device pointers + the stream, for zero-copy interop (torch.as_tensor / DLPack on the Python side).
+ * ptrs[0..7] = inj, topo, shunt_bus, out, topo_vect, line_status, status, chronics; stream = hipStream_t */
+int gpf_device_pointers(gpf_handle h, void** ptrs, void** stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRIDPF_H */

@@ -1,0 +1,322 @@
+"""GPU parity tests: the HIP engine (through the C ABI) vs the CPU oracle, on the committed fixtures.
+
+Tolerances (stated per the north star: max line-flow error < 1e-4 pu on a 100 MVA base = 1e-2 MW):
+* float64 bus voltages (pre-cast):  |dVm| < 1e-9 pu, |dVa| < 1e-7 deg
+* float32 outputs: |x - oracle| <= 2e-6*|oracle| + abs_tol with abs_tol = 2e-4 (MW, MVAr, kV, deg), i.e. a few
+  float32 ulps of the largest flows -- two orders of magnitude inside the 1e-2 MW bar
+* topo_vect / line_status / shunt_bus / convergence flags: bit-exact
+"""
+import numpy as np
+import pytest
+
+from oracle.pf_oracle import LaneState, solve
+
+pytestmark = pytest.mark.gpu
+
+F32_FIELDS = ["p_or", "q_or", "v_or", "a_or", "theta_or", "p_ex", "q_ex", "v_ex", "a_ex", "theta_ex",
+              "gen_p", "gen_q", "gen_v", "gen_theta", "load_p", "load_q", "load_v", "load_theta",
+              "storage_p", "storage_q", "storage_v", "storage_theta", "shunt_p", "shunt_q", "shunt_v"]
+
+
+def _engine(model, n_lanes, n_busbar=2):
+    from grid2op_amd.engine import PowerFlowEngine
+    return PowerFlowEngine(model, n_lanes=n_lanes, device=0, n_busbar=n_busbar)
+
+
+def _pack(eng, states):
+    inj = np.stack([np.concatenate([s.gen_p, s.gen_vm, s.load_p, s.load_q, s.storage_p, s.storage_q, s.shunt_p, s.shunt_q])
+                    for s in states])
+    topo = np.stack([s.topo for s in states])
+    sb = np.stack([s.shunt_bus for s in states]) if eng.model.n_shunt else None
+    return inj, topo, sb
+
+
+def _compare(m, r, k, o, a_rel=5e-6):
+    assert bool(r.converged[k]) == bool(o.converged), (k, r.status[k], o.reason)
+    assert np.array_equal(r.topo_vect[k], o.topo_vect), k
+    assert np.array_equal(r.line_status[k], o.line_status), k
+    if m.n_shunt:
+        assert np.array_equal(r.shunt_bus[k], o.shunt_bus), k
+    if not o.converged:
+        for f in F32_FIELDS:
+            assert np.all(np.isnan(getattr(r, f)[k])), (k, f)
+        return 0.0
+    assert r.n_iter[k] == o.n_iter, (k, r.n_iter[k], o.n_iter)
+    act = ~np.isnan(o.bus_vm)
+    assert np.array_equal(~np.isnan(r.bus_vm[k]), act)
+    assert np.abs(r.bus_vm[k][act] - o.bus_vm[act]).max() < 1e-9
+    dva = np.abs(r.bus_va[k][act] - o.bus_va[act])
+    dva = np.minimum(dva, 360.0 - dva)
+    assert dva.max() < 1e-7
+    worst = 0.0
+    for f in F32_FIELDS:
+        got = getattr(r, f)[k].astype(np.float64)
+        ref = getattr(o, f)
+        if ref.size == 0:
+            continue
+        tol = 2e-4 + a_rel * np.abs(ref)
+        err = np.abs(got - ref)
+        assert np.all(err <= tol), (k, f, float(err.max()), got, ref)
+        worst = max(worst, float(err.max()))
+    return worst
+
+
+@pytest.mark.parametrize("name", ["rte_case5_example", "l2rpn_case14_sandbox", "educ_case14_storage", "test_case14",
+                                  "l2rpn_neurips_2020_track1"])
+def test_stored_state_matches_oracle_and_golden(name, load_model, load_npz):
+    m = load_model(name)
+    eng = _engine(m, 2)
+    eng.runpf()
+    r = eng.results()
+    o = solve(m, LaneState.from_model(m))
+    assert o.converged
+    for k in range(2):
+        _compare(m, r, k, o)
+    try:
+        g = load_npz(f"{name}.res.npz")
+    except FileNotFoundError:
+        g = {}
+    if "line_p_from_mw" in g and not np.isnan(g["line_p_from_mw"]).any():   # pandapower's own numbers (golden)
+        nl = m.n_powerline
+        assert np.abs(r.p_or[0][:nl] - g["line_p_from_mw"]).max() < 2e-4 + 5e-6 * np.abs(g["line_p_from_mw"]).max()
+        assert np.abs(r.a_or[0][:nl] - 1000 * g["line_i_from_ka"]).max() < 2e-4 + 5e-6 * 1000 * np.abs(g["line_i_from_ka"]).max()
+        vm_ok = ~np.isnan(g["bus_vm_pu"]) if "bus_vm_pu" in g else None
+        if vm_ok is not None:
+            assert np.abs(r.bus_vm[0][:m.n_sub][vm_ok] - g["bus_vm_pu"][vm_ok]).max() < 1e-9
+    eng.close()
+
+
+def _random_states(m, n, rng, n_busbar=2, p_split=0.3, p_line_off=0.3):
+    states = []
+    for _ in range(n):
+        s = LaneState.from_model(m)
+        s.load_p = (s.load_p * rng.uniform(0.7, 1.2, m.n_load)).astype(np.float32).astype(np.float64)
+        s.load_q = (s.load_q * rng.uniform(0.7, 1.2, m.n_load)).astype(np.float32).astype(np.float64)
+        s.gen_p = (s.gen_p * rng.uniform(0.8, 1.1, m.n_gen)).astype(np.float32).astype(np.float64)
+        s.gen_vm = s.gen_vm * rng.uniform(0.98, 1.02, m.n_gen)
+        if m.n_storage:
+            s.storage_p = rng.uniform(-3, 3, m.n_storage)
+        if rng.random() < p_line_off:
+            for l in rng.choice(m.n_line, size=rng.integers(1, 3), replace=False):
+                s.topo[m.line_or_pos_topo_vect[l]] = -1
+                s.topo[m.line_ex_pos_topo_vect[l]] = -1
+        if rng.random() < p_split:
+            # move a random subset of the elements of one substation to busbar 2
+            sub = rng.integers(0, m.n_sub)
+            start = int(np.concatenate(([0], np.cumsum(m.sub_info)))[sub])
+            pos = np.arange(start, start + m.sub_info[sub])
+            mv = pos[rng.random(len(pos)) < 0.5]
+            s.topo[mv] = np.where(s.topo[mv] >= 1, 2, s.topo[mv])
+        if m.n_shunt and rng.random() < 0.2:
+            s.shunt_bus[rng.integers(0, m.n_shunt)] = rng.choice([-1, 2])
+        states.append(s)
+    return states
+
+
+@pytest.mark.parametrize("name,n,seed", [("l2rpn_case14_sandbox", 96, 0), ("rte_case5_example", 48, 1),
+                                         ("educ_case14_storage", 48, 2), ("l2rpn_neurips_2020_track1", 24, 3)])
+def test_random_injections_and_topologies(name, n, seed, load_model):
+    """Random injections, line outages, bus splits, shunt moves -- including lanes that island / diverge."""
+    m = load_model(name)
+    rng = np.random.default_rng(seed)
+    states = _random_states(m, n, rng)
+    eng = _engine(m, n)
+    inj, topo, sb = _pack(eng, states)
+    eng.set_injections(inj)
+    eng.set_topology(topo, sb)
+    eng.runpf()
+    r = eng.results()
+    n_conv = 0
+    for k, s in enumerate(states):
+        o = solve(m, s)
+        _compare(m, r, k, o)
+        n_conv += int(o.converged)
+    assert n_conv > n // 2
+    eng.close()
+
+
+def test_dc_mode(load_model, load_npz):
+    m = load_model("test_case14")
+    ka = load_npz("known_answers.npz")
+    eng = _engine(m, 3)
+    eng.runpf(is_dc=True)
+    r = eng.results()
+    o = solve(m, LaneState.from_model(m), is_dc=True)
+    assert r.converged.all()
+    assert np.abs(r.p_or[0] - ka["p_or_dc"]).max() < 1e-4         # grid2op/tests/BaseBackendTest.py:262-287
+    assert np.abs(r.p_or[1] - o.p_or).max() < 1e-4
+    assert np.all(r.q_or == 0) and np.all(r.gen_q == 0)
+    assert np.abs(r.gen_p[2] - o.gen_p).max() < 2e-4
+    eng.runpf(is_dc=False)
+    r = eng.results()
+    assert np.abs(r.p_or[0] - ka["p_or_ac"]).max() < 1e-4         # :289-319
+    assert np.abs(r.a_or[0] / ka["a_or_init"] - 1).max() < 1e-6   # :1584-1607
+    eng.close()
+
+
+def test_islanded_and_divergence_flags(load_model):
+    """aaa_test_backend_interface.py:1095-1164 semantics per lane: NaN outputs, topo_vect=-1, status!=0."""
+    m = load_model("l2rpn_case14_sandbox")
+    eng = _engine(m, 4)
+    states = [LaneState.from_model(m) for _ in range(4)]
+    for l in range(m.n_line):                         # lane 1: isolate substation 13
+        if m.line_or_sub[l] == 13 or m.line_ex_sub[l] == 13:
+            states[1].topo[m.line_or_pos_topo_vect[l]] = -1
+            states[1].topo[m.line_ex_pos_topo_vect[l]] = -1
+    states[2].load_p = states[2].load_p * 50.0        # lane 2: impossible loading -> no convergence
+    states[3].topo[m.gen_pos_topo_vect[np.nonzero(m.gen_slack)[0][0]]] = -1   # lane 3: slack disconnected
+    inj, topo, sb = _pack(eng, states)
+    eng.set_injections(inj)
+    eng.set_topology(topo, sb)
+    for dc in (False, True):
+        eng.runpf(is_dc=dc)
+        r = eng.results()
+        assert r.status[0, 0] == 0
+        assert r.status[1, 0] == 2 and r.status[3, 0] == 3
+        if not dc:
+            assert r.status[2, 0] == 1 and r.n_iter[2] == 10
+        for k in (1, 3) if dc else (1, 2, 3):
+            assert np.all(np.isnan(r.out[k])) and np.all(r.topo_vect[k] == -1) and not r.line_status[k].any()
+            assert not solve(m, states[k], is_dc=dc).converged
+    eng.close()
+
+
+def test_reset_copy_disconnect_fanout(load_model):
+    m = load_model("l2rpn_case14_sandbox")
+    nl = m.n_line
+    eng = _engine(m, 2 + nl)
+    base = LaneState.from_model(m)
+    base.load_p = base.load_p * 0.9
+    inj, topo, sb = _pack(eng, [base])
+    eng.set_injections(inj, lane0=0)
+    eng.copy_lanes(0, 1)
+    eng.disconnect_line(1, 3)
+    eng.fanout_n1(0, 2, np.arange(nl))                # lanes 2.. = N-1 contingencies of lane 0
+    eng.runpf()
+    r = eng.results()
+    _compare(m, r, 0, solve(m, base))
+    s1 = base.copy()
+    s1.topo[m.line_or_pos_topo_vect[3]] = -1
+    s1.topo[m.line_ex_pos_topo_vect[3]] = -1
+    _compare(m, r, 1, solve(m, s1))
+    for l in range(nl):
+        s = base.copy()
+        s.topo[m.line_or_pos_topo_vect[l]] = -1
+        s.topo[m.line_ex_pos_topo_vect[l]] = -1
+        _compare(m, r, 2 + l, solve(m, s))
+    assert np.array_equal(r.out[1], r.out[2 + 3], equal_nan=True)
+    eng.reset(0, 2)
+    eng.runpf(0, 2)
+    r = eng.results(0, 2)
+    o = solve(m, LaneState.from_model(m))
+    _compare(m, r, 0, o)
+    _compare(m, r, 1, o)
+    eng.close()
+
+
+def test_three_busbars(load_model):
+    """aaa_test_backend_interface.py:1632 (n_busbar_per_sub = 3)."""
+    m = load_model("l2rpn_case14_sandbox")
+    eng = _engine(m, 1, n_busbar=3)
+    s = LaneState.from_model(m)
+    # substation 1: line 0 (ex) + gen on busbar 3, the rest stays on busbar 1
+    s.topo[m.line_ex_pos_topo_vect[0]] = 3
+    s.topo[m.gen_pos_topo_vect[0]] = 3
+    inj, topo, sb = _pack(eng, [s])
+    eng.set_injections(inj)
+    eng.set_topology(topo, sb)
+    eng.runpf()
+    r = eng.results()
+    _compare(m, r, 0, solve(m, s, n_busbar=3))
+    assert r.topo_vect[0][m.gen_pos_topo_vect[0]] == 3
+    eng.close()
+
+
+def test_batched_step_matches_oracle(load_model, load_npz):
+    """Device-resident chronics -> injections (float32, incl. the float32 prod_v/kV division) -> AC PF."""
+    m = load_model("l2rpn_case14_sandbox")
+    ch = load_npz("l2rpn_case14_sandbox.chronics.npz")
+    B = 32
+    eng = _engine(m, B)
+    tab = eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"])
+    eng.upload_chronics(tab)
+    rng = np.random.default_rng(5)
+    off = 7 * np.arange(B)
+    scale = (1 + 0.05 * rng.standard_normal((B, 2 * m.n_load))).astype(np.float32)
+    eng.set_lane_chronics(lane_offset=off, lane_scale=scale)
+    eng.set_thermal_limits(ch["thermal_limits"])
+    T = tab.shape[0]
+    for t in (0, 11):
+        eng.step(t, rebalance=1.02)
+        r = eng.results()
+        rho, _, _ = eng.step_outputs()
+        for k in range(B):
+            row = (t + off[k]) % T
+            s = LaneState.from_model(m)
+            lp = ch["load_p"][row] * scale[k, :m.n_load]
+            lq = ch["load_q"][row] * scale[k, m.n_load:]
+            pp = ch["prod_p"][row].copy()
+            ns = ~m.gen_slack
+            fac = np.float32(1.02 * lp.astype(np.float64).sum() / pp[ns].astype(np.float64).sum())
+            pp[ns] = pp[ns] * fac
+            s.load_p, s.load_q, s.gen_p = lp.astype(np.float64), lq.astype(np.float64), pp.astype(np.float64)
+            s.gen_vm = (ch["prod_v"][row] / m.sub_vn_kv[m.gen_sub].astype(np.float32)).astype(np.float64)
+            o = solve(m, s)
+            _compare(m, r, k, o)
+            assert np.allclose(rho[k], o.a_or / ch["thermal_limits"], rtol=1e-5, atol=1e-6)
+    eng.close()
+
+
+def test_cascade_matches_host_loop(load_model, load_npz):
+    """Backend.next_grid_state (backend.py:1476-1520) on device vs the same loop driven from the host."""
+    m = load_model("l2rpn_case14_sandbox")
+    ch = load_npz("l2rpn_case14_sandbox.chronics.npz")
+    B = 8
+    eng = _engine(m, B)
+    tab = eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"])
+    eng.upload_chronics(tab)
+    eng.set_lane_chronics(lane_offset=np.arange(B) * 3)
+    lim = ch["thermal_limits"].copy()
+    # tighten limits so that some lines hard-overflow at the first step
+    eng.step(0)
+    a0 = eng.results().a_or.copy()
+    lim = (np.median(a0, axis=0) * 0.8).astype(np.float32) + 1.0
+    lim[[4, 9]] = np.median(a0, axis=0)[[4, 9]] * 0.45
+    eng.set_thermal_limits(lim)
+    eng.reset()
+    hard, soft, nbts = 2.0, 1.0, 2
+    eng.step(0, cascade=True, hard_overflow=hard, soft_overflow=soft, nb_ts_allowed=nbts)
+    r = eng.results()
+    rho, ovc, dr = eng.step_outputs()
+    for k in range(B):
+        row = (0 + 3 * k) % tab.shape[0]
+        s = LaneState.from_model(m)
+        s.load_p, s.load_q = ch["load_p"][row].astype(np.float64), ch["load_q"][row].astype(np.float64)
+        s.gen_p = ch["prod_p"][row].astype(np.float64)
+        s.gen_vm = (ch["prod_v"][row] / m.sub_vn_kv[m.gen_sub].astype(np.float32)).astype(np.float64)
+        counter = np.zeros(m.n_line, int)
+        inc = np.zeros(m.n_line, bool)
+        disc = np.full(m.n_line, -1)
+        it = 0
+        while True:
+            o = solve(m, s)
+            if not o.converged:
+                break
+            a = o.a_or.astype(np.float32)
+            st = o.line_status
+            to_disc = (a > np.float32(hard) * lim) & st
+            mask = (a > np.float32(soft) * lim) & st & ~inc
+            counter[mask] += 1
+            inc[mask] = True
+            to_disc |= (counter > nbts) & st
+            if not to_disc.any():
+                break
+            disc[to_disc] = it
+            for l in np.nonzero(to_disc)[0]:
+                s.topo[m.line_or_pos_topo_vect[l]] = -1
+                s.topo[m.line_ex_pos_topo_vect[l]] = -1
+            it += 1
+        assert np.array_equal(dr[k], disc), (k, dr[k], disc)
+        _compare(m, r, k, o)
+    assert (dr >= 0).any()
+    eng.close()
