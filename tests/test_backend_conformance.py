@@ -1,0 +1,54 @@
+"""Run the REFERENCE's own backend conformance kit against the host logic of `HipBackend`.
+
+* grid2op/tests/aaa_test_backend_interface.py  ``AAATestBackendAPI`` (41 ordered tests)
+* grid2op/_create_test_suite.py ``create_test_suite`` (BaseBackendTest suites, test_Environment, BaseRedispTest)
+
+These need the read-only reference checkout (they are the reference's tests, imported from /root/reference, never
+copied) and therefore only run in the build container; on the GPU box they are skipped.  The compute engine is
+swapped for the CPU oracle (tests/conformance_backend.py) because this container has no GPU: what is certified here
+is the façade (apply_action / status / getter conventions), the engine itself is certified against the same oracle
+by the ``-m gpu`` parity tests.
+"""
+import os
+import sys
+import unittest
+import warnings
+
+import pytest
+
+from conftest import REFERENCE, have_reference
+
+if not have_reference():
+    pytest.skip("reference checkout not available (GPU box)", allow_module_level=True)
+
+_SHIM = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_refshim")
+for p in (REFERENCE, _SHIM):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("_GRID2OP_FORCE_TEST", "1")
+warnings.filterwarnings("ignore")
+
+from grid2op.tests.aaa_test_backend_interface import AAATestBackendAPI  # noqa: E402
+from conformance_backend import OracleHipBackend  # noqa: E402
+
+
+class TestBackendAPI_HipBackend(AAATestBackendAPI, unittest.TestCase):
+    def make_backend(self, detailed_infos_for_cascading_failures=False):
+        return OracleHipBackend(detailed_infos_for_cascading_failures=detailed_infos_for_cascading_failures)
+
+
+def _this_make_backend(self, detailed_infos_for_cascading_failures=False):
+    return OracleHipBackend(detailed_infos_for_cascading_failures=detailed_infos_for_cascading_failures)
+
+
+from grid2op._create_test_suite import create_test_suite  # noqa: E402
+
+create_test_suite(make_backend_fun=_this_make_backend, add_name_cls="HipBackend", add_to_module=__name__,
+                  extended_test=True)
+
+# test_Environment.BaseTestLoadingBackendPandaPower builds its backend through ``get_backend`` (hard-wired to
+# PandaPowerBackend in the reference) instead of ``make_backend``: point it at the backend under test.
+_cls = globals().get("TestLoadingBackendPandaPower_HipBackend")
+if _cls is not None:
+    _cls.get_backend = lambda self, detailed_infos_for_cascading_failures=True: OracleHipBackend(
+        detailed_infos_for_cascading_failures=detailed_infos_for_cascading_failures)

@@ -1,0 +1,65 @@
+"""CPU-only checks of the C-ABI shared library: it loads, exports every symbol ``include/gridpf.h`` declares, and
+fails loudly (no CPU fallback) when no GPU is present."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_functions():
+    txt = open(os.path.join(ROOT, "include", "gridpf.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpf_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    import __graft_entry__ as entry
+    entry.build()
+    from grid2op_amd import _capi
+    L = _capi.lib()
+    declared = _declared_functions()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/gridpf.h but not exported by libgridpf.so"
+    assert sorted(_capi.EXPORTED_SYMBOLS) == declared
+    assert L.gpf_version() >= 100
+
+
+def test_no_silent_cpu_fallback(load_model):
+    """Without a GPU the product path must raise (a CPU fallback would void every parity claim)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("a GPU is present")
+    except ImportError:
+        pass
+    from grid2op_amd.engine import PowerFlowEngine, GridPFError
+    m = load_model("rte_case5_example")
+    with pytest.raises(GridPFError):
+        PowerFlowEngine(m, n_lanes=2)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "grid2op_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "pf_oracle" not in txt or f == "_capi.py" and "oracle/" in txt, f
+
+
+def test_layout_struct_matches_header():
+    from grid2op_amd._capi import GpfLayout, GpfGridDesc
+    txt = open(os.path.join(ROOT, "include", "gridpf.h")).read()
+    lay = txt[txt.index("typedef struct gpf_layout"):txt.index("} gpf_layout;")]
+    lay = re.sub(r"/\*.*?\*/", "", lay, flags=re.S)
+    names = re.findall(r"\b([a-z_]+)\s*[,;]", lay.split("{", 1)[1])
+    assert names == [f[0] for f in GpfLayout._fields_]
+    desc = txt[txt.index("typedef struct gpf_grid_desc"):txt.index("} gpf_grid_desc;")]
+    desc = re.sub(r"/\*.*?\*/", "", desc, flags=re.S)
+    dnames = re.findall(r"\*?\s*([a-z_0-9]+)\s*[,;]", desc.split("{", 1)[1])
+    assert dnames == [f[0] for f in GpfGridDesc._fields_]

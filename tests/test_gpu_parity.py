@@ -287,3 +287,33 @@ def test_cascade_matches_host_loop(load_model, load_npz):
         _compare(m, r, k, o)
     assert (dr >= 0).any()
     eng.close()
+
+
+def test_facade_call_sequence_hip_vs_oracle_engine(load_model):
+    """`HipBackend.runpf` drives its engine with set_injections / set_topology / runpf / results.  grid2op itself is
+    not installed on the GPU box, so the façade is certified against the reference's conformance kit with the oracle
+    engine (tests/test_backend_conformance.py, CPU); this test closes the loop by running the SAME call sequence on
+    the HIP engine and on the oracle engine and comparing every field the façade reads."""
+    from oracle_engine import OracleEngine
+    m = load_model("educ_case14_storage")
+    rng = np.random.default_rng(21)
+    hip = _engine(m, 1)
+    orc = OracleEngine(m, 1)
+    for s in [LaneState.from_model(m)] + random_states(m, 20, rng):
+        inj, topo, sb = pack_states(m, [s])
+        for dc in (False, True):
+            for e in (hip, orc):
+                e.set_injections(inj, lane0=0)
+                e.set_topology(topo, sb, lane0=0)
+                e.runpf(0, 1, is_dc=dc, max_iter=10, tol_mva=1e-8)
+            a, b = hip.results(0, 1), orc.results(0, 1)
+            assert a.status[0, 0] == b.status[0, 0]
+            assert np.array_equal(a.topo_vect, b.topo_vect) and np.array_equal(a.line_status, b.line_status)
+            assert np.array_equal(a.shunt_bus, b.shunt_bus)
+            if a.status[0, 0] != 0:
+                assert np.isnan(a.out).all() and np.isnan(b.out).all()
+                continue
+            assert np.allclose(a.out, b.out, rtol=5e-6, atol=2e-4)
+            act = ~np.isnan(b.bus_vm)
+            assert np.abs(a.bus_vm[act] - b.bus_vm[act]).max() < 1e-9
+    hip.close()
