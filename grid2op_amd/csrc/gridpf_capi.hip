@@ -7,12 +7,14 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/gridpf.h"
 #include "gridpf_kernels.hpp"
+#include "gridpf_small.hpp"
 
 namespace {
 
@@ -83,6 +85,11 @@ struct gpf_engine {
   // per-lane capacity bookkeeping (host): number of active buses / NR unknowns of each lane
   std::vector<int> lane_nb, lane_nj;
   int init_nb = 0, init_nj = 0;
+  bool force_generic = false;   // GRIDPF_FORCE_GENERIC=1: always use the generic (v1) kernels
+  // device-resident kernel parameter block (kernel v2 takes ONE pointer)
+  gpf::DevParams h_params{};
+  gpf::DevParams* d_params = nullptr;
+  bool params_valid = false;
   // profiling
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -140,6 +147,7 @@ struct LaunchPlan {
   int nbc, nJ;
   bool big;
   size_t lds;
+  int small_nmax;   // 0: generic LDS kernels (v1); 24/32/48/64: register-resident kernels (v2)
 };
 
 constexpr size_t LDS_SMALL_LIMIT = 64 * 1024;   // above this Y and J move to an HBM/L2 workspace
@@ -153,6 +161,20 @@ int plan_launch(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
   }
   p.nbc = (nb + 1) & ~1;
   p.nJ = (nj + 1) & ~1;
+  p.small_nmax = 0;
+  if (!e->force_generic && p.nJ <= 64) {
+    const int nmax = p.nJ <= 24 ? 24 : p.nJ <= 32 ? 32 : p.nJ <= 48 ? 48 : 64;
+    const size_t l = nmax == 24 ? gpf::lds_bytes_small<24>(e->g, p.nbc, p.nJ)
+                   : nmax == 32 ? gpf::lds_bytes_small<32>(e->g, p.nbc, p.nJ)
+                   : nmax == 48 ? gpf::lds_bytes_small<48>(e->g, p.nbc, p.nJ)
+                                : gpf::lds_bytes_small<64>(e->g, p.nbc, p.nJ);
+    if (l <= LDS_SMALL_LIMIT) {
+      p.small_nmax = nmax;
+      p.big = false;
+      p.lds = l;
+      return GPF_OK;
+    }
+  }
   size_t small = gpf::lds_bytes(e->g, p.nbc, p.nJ, false);
   p.big = small > LDS_SMALL_LIMIT;
   p.lds = gpf::lds_bytes(e->g, p.nbc, p.nJ, p.big);
@@ -165,6 +187,20 @@ int plan_launch(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
       e->work.release();
       HIP_TRY(e->work.alloc(need));
     }
+  }
+  return GPF_OK;
+}
+
+int upload_params(gpf_engine* e, const gpf::Bufs& b) {
+  gpf::DevParams hp{};
+  hp.g = e->g;
+  hp.b = b;
+  hp.oo = e->oo;
+  if (!e->d_params) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_params), sizeof(gpf::DevParams)));
+  if (!e->params_valid || std::memcmp(&hp, &e->h_params, sizeof(hp)) != 0) {
+    e->h_params = hp;
+    HIP_TRY(hipMemcpyAsync(e->d_params, &e->h_params, sizeof(hp), hipMemcpyHostToDevice, e->stream));
+    e->params_valid = true;
   }
   return GPF_OK;
 }
@@ -218,6 +254,10 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   HIP_TRY(hipSetDevice(device));
   gpf_engine* e = new gpf_engine();
   e->device = device;
+  {
+    const char* fg = std::getenv("GRIDPF_FORCE_GENERIC");
+    e->force_generic = fg && fg[0] == '1';
+  }
   e->n_lanes = n_lanes;
   gpf::GridDev& g = e->g;
   g.n_sub = d->n_sub; g.n_busbar = d->n_busbar; g.nb_tot = d->n_sub * d->n_busbar;
@@ -332,6 +372,7 @@ int gpf_destroy(gpf_handle e) {
   e->lane_table.release(); e->lane_offset.release(); e->tmp_lines.release(); e->out.release(); e->chron.release();
   e->lane_scale.release(); e->thermal_limit.release(); e->rho.release(); e->line_status.release();
   e->d_init_inj.release(); e->d_init_topo.release(); e->d_init_shunt_bus.release();
+  if (e->d_params) (void)hipFree(e->d_params);
   delete e;
   return GPF_OK;
 }
@@ -483,8 +524,16 @@ int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
   b.work_stride = (long long)work_stride(p);
   const double tol_pu = tol_mva / e->g.sn_mva;
   hipEvent_t ea = nullptr, eb = nullptr;
+  if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
-  if (p.big) {
+#define LAUNCH_RUNPF_SMALL(NM)                                                                                              \
+  hipLaunchKernelGGL(gpf::runpf_small_kernel<NM>, dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, lane0, p.nbc,   \
+                     p.nJ, is_dc, max_iter, tol_pu)
+  if (p.small_nmax == 24) LAUNCH_RUNPF_SMALL(24);
+  else if (p.small_nmax == 32) LAUNCH_RUNPF_SMALL(32);
+  else if (p.small_nmax == 48) LAUNCH_RUNPF_SMALL(48);
+  else if (p.small_nmax == 64) LAUNCH_RUNPF_SMALL(64);
+  else if (p.big) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
     hipLaunchKernelGGL(gpf::runpf_kernel<true>, dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->g, b, e->oo, lane0, p.nbc, p.nJ,
                        is_dc, max_iter, tol_pu);
@@ -569,8 +618,16 @@ int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double r
   sa.nb_ts_allowed = nb_ts_allowed; sa.max_rounds = max_rounds; sa.hard_overflow = hard_overflow; sa.soft_overflow = soft_overflow;
   const double tol_pu = tol_mva / e->g.sn_mva;
   hipEvent_t ea = nullptr, eb = nullptr;
+  if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
-  if (p.big) {
+#define LAUNCH_STEP_SMALL(NM)                                                                                               \
+  hipLaunchKernelGGL(gpf::step_small_kernel<NM>, dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, p.nbc,   \
+                     p.nJ, max_iter, tol_pu, sa)
+  if (p.small_nmax == 24) LAUNCH_STEP_SMALL(24);
+  else if (p.small_nmax == 32) LAUNCH_STEP_SMALL(32);
+  else if (p.small_nmax == 48) LAUNCH_STEP_SMALL(48);
+  else if (p.small_nmax == 64) LAUNCH_STEP_SMALL(64);
+  else if (p.big) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
     hipLaunchKernelGGL(gpf::step_kernel<true>, dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->g, b, e->oo, p.nbc, p.nJ,
                        max_iter, tol_pu, sa);
