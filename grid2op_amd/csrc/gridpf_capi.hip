@@ -162,13 +162,16 @@ int plan_launch(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
   p.nbc = (nb + 1) & ~1;
   p.nJ = (nj + 1) & ~1;
   p.small_nmax = 0;
-  if (!e->force_generic && p.nJ <= 64) {
+  if (!e->force_generic && p.nJ <= 64 && p.nbc <= 64 && e->g.nb_tot <= 127) {
     const int nmax = p.nJ <= 24 ? 24 : p.nJ <= 32 ? 32 : p.nJ <= 48 ? 48 : 64;
-    const size_t l = nmax == 24 ? gpf::lds_bytes_small<24>(e->g, p.nbc, p.nJ)
-                   : nmax == 32 ? gpf::lds_bytes_small<32>(e->g, p.nbc, p.nJ)
-                   : nmax == 48 ? gpf::lds_bytes_small<48>(e->g, p.nbc, p.nJ)
-                                : gpf::lds_bytes_small<64>(e->g, p.nbc, p.nJ);
+    const size_t l = nmax == 24 ? gpf::lds_bytes_small<24, 2>(e->g, p.nbc, p.nJ)
+                   : nmax == 32 ? gpf::lds_bytes_small<32, 2>(e->g, p.nbc, p.nJ)
+                   : nmax == 48 ? gpf::lds_bytes_small<48, 1>(e->g, p.nbc, p.nJ)
+                                : gpf::lds_bytes_small<64, 1>(e->g, p.nbc, p.nJ);
     if (l <= LDS_SMALL_LIMIT) {
+#ifdef GPF_TIMING
+      if (e->work.n < (size_t)e->n_lanes * 32) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->n_lanes * 32)); }
+#endif
       p.small_nmax = nmax;
       p.big = false;
       p.lds = l;
@@ -526,13 +529,13 @@ int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
   hipEvent_t ea = nullptr, eb = nullptr;
   if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
-#define LAUNCH_RUNPF_SMALL(NM)                                                                                              \
-  hipLaunchKernelGGL(gpf::runpf_small_kernel<NM>, dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, lane0, p.nbc,   \
+#define LAUNCH_RUNPF_SMALL(NM, LP)                                                                                              \
+  hipLaunchKernelGGL((gpf::runpf_small_kernel<NM, LP>), dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, lane0, p.nbc,   \
                      p.nJ, is_dc, max_iter, tol_pu)
-  if (p.small_nmax == 24) LAUNCH_RUNPF_SMALL(24);
-  else if (p.small_nmax == 32) LAUNCH_RUNPF_SMALL(32);
-  else if (p.small_nmax == 48) LAUNCH_RUNPF_SMALL(48);
-  else if (p.small_nmax == 64) LAUNCH_RUNPF_SMALL(64);
+  if (p.small_nmax == 24) LAUNCH_RUNPF_SMALL(24, 2);
+  else if (p.small_nmax == 32) LAUNCH_RUNPF_SMALL(32, 2);
+  else if (p.small_nmax == 48) LAUNCH_RUNPF_SMALL(48, 1);
+  else if (p.small_nmax == 64) LAUNCH_RUNPF_SMALL(64, 1);
   else if (p.big) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
     hipLaunchKernelGGL(gpf::runpf_kernel<true>, dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->g, b, e->oo, lane0, p.nbc, p.nJ,
@@ -620,13 +623,13 @@ int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double r
   hipEvent_t ea = nullptr, eb = nullptr;
   if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
-#define LAUNCH_STEP_SMALL(NM)                                                                                               \
-  hipLaunchKernelGGL(gpf::step_small_kernel<NM>, dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, p.nbc,   \
+#define LAUNCH_STEP_SMALL(NM, LP)                                                                                               \
+  hipLaunchKernelGGL((gpf::step_small_kernel<NM, LP>), dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, p.nbc,   \
                      p.nJ, max_iter, tol_pu, sa)
-  if (p.small_nmax == 24) LAUNCH_STEP_SMALL(24);
-  else if (p.small_nmax == 32) LAUNCH_STEP_SMALL(32);
-  else if (p.small_nmax == 48) LAUNCH_STEP_SMALL(48);
-  else if (p.small_nmax == 64) LAUNCH_STEP_SMALL(64);
+  if (p.small_nmax == 24) LAUNCH_STEP_SMALL(24, 2);
+  else if (p.small_nmax == 32) LAUNCH_STEP_SMALL(32, 2);
+  else if (p.small_nmax == 48) LAUNCH_STEP_SMALL(48, 1);
+  else if (p.small_nmax == 64) LAUNCH_STEP_SMALL(64, 1);
   else if (p.big) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
     hipLaunchKernelGGL(gpf::step_kernel<true>, dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->g, b, e->oo, p.nbc, p.nJ,
@@ -678,6 +681,15 @@ int gpf_get_kernel_time(gpf_handle e, double* total_ms, int64_t* n_launches) {
   e->acc_launches = 0;
   return GPF_OK;
 }
+
+#ifdef GPF_TIMING
+int gpf_debug_read_work(gpf_handle e, double* out, int64_t n) {
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(out, e->work.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  return GPF_OK;
+}
+#endif
 
 int gpf_device_pointers(gpf_handle e, void** ptrs, void** stream) {
   if (!e || !ptrs) return fail(GPF_E_INVALID, "gpf_device_pointers: null");

@@ -1,25 +1,44 @@
-// gridpf_small.hpp -- kernel v2 for small / medium grids (Newton unknowns n <= NMAX <= 64).
+// gridpf_small.hpp -- kernel v3 for small / medium grids (Newton unknowns n <= NMAX <= 64, active buses <= 64).
 //
-// Same pipeline and same arithmetic as gridpf_kernels.hpp (one wavefront per grid instance), but the
-// linear algebra is REGISTER RESIDENT:
-//   * each SIMD lane owns ONE ROW of the compact Jacobian [J | -F] in VGPRs (statically indexed, fully unrolled);
-//   * Gauss-Jordan elimination with partial pivoting: the pivot is found with a 6-step DPP max-reduction on a
-//     32-bit key (high word of |a_ik| with the lane id in the low 6 bits), the pivot row is broadcast with
-//     v_readlane (wave-uniform lane -> SGPR operands of the FMAs); no LDS traffic, no barrier, no back-substitution;
-//   * the Jacobian rows are assembled by the owning lane (dense over the buses, every entry written once) through
-//     a conflict-free LDS row buffer (row stride = NMAX+2 doubles) so that the register file is indexed statically;
-//   * sincos is a branch-free Cody-Waite + fdlibm-kernel implementation (angles here are a few radians at most);
-//   * kernel parameters are one pointer to a device-resident DevParams block (no SGPR spilling).
+// Same pipeline and arithmetic as gridpf_kernels.hpp (one wavefront per grid instance) but built around what the
+// per-phase cycle stamps (tools/phase_timing.py) showed to matter on MI355X for 14..36-bus grids: the kernel is bound
+// by instruction issue and by dependent-latency chains, not by HBM.
+//   * REGISTER-RESIDENT Gauss-Jordan with partial pivoting.  LPR SIMD lanes share one row of the compact Jacobian
+//     [J | -F] (column j lives in sub-lane j % LPR), so a 22-unknown system occupies 44 lanes with 13 values each.
+//     Pivot search = 6-step DPP max-reduction on a 32-bit key (high word of |a_ik|, lane id in the low 6 bits); the
+//     pivot row is broadcast through a small LDS buffer (ds_write_b128 / ds_read_b128, in-order within the wave, no
+//     barrier); candidate reciprocals are computed before the reduction so the divide is off the critical path; no
+//     back-substitution (Gauss-Jordan).
+//   * Jacobian rows are assembled by their LPR lanes (buses split between the sub-lanes, partial S combined with a
+//     DPP quad permute) through a conflict-free LDS row buffer laid out exactly as the register file wants it.
+//   * Ybus and B' are assembled by BRANCH lanes with native LDS f64 atomics (ds_add_f64) instead of per-bus gather
+//     loops over global tables (41.8k -> ~2k cycles).
+//   * The lane's injection row and topology row are staged in LDS once; per-bus data used by the assembly loop is
+//     one packed 32-byte record (e, f, 1/|V|, pidx, qidx).
+//   * Generator Q-split / slack-P reductions use v_readlane instead of loops over global tables.
+//   * Branch-free Cody-Waite + fdlibm-kernel sincos; kernel parameters by pointer to a device-resident block.
 #pragma once
 #include "gridpf_kernels.hpp"
 
 namespace gpf {
+
+#ifdef GPF_TIMING
+#define GPF_STAMP(k) do { if (tid == 0) P->b.work[(size_t)inst * 32 + (k)] = (double)(long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define GPF_STAMP(k) do {} while (0)
+#endif
+
+#ifndef GPF_MINW
+#define GPF_MINW(NMAX) ((NMAX) <= 24 ? 4 : (NMAX) <= 32 ? 3 : 2)
+#endif
 
 struct DevParams {
   GridDev g;
   Bufs b;
   OutOff oo;
 };
+
+typedef signed char i8;
 
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -39,25 +58,62 @@ __device__ __forceinline__ unsigned wave_umax(unsigned v) {
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// value held by sub-lane SRC of every group of LPR consecutive lanes (LPR = 1, 2 or 4: a DPP quad permute)
+template <int LPR, int SRC>
+__device__ __forceinline__ double group_bcast(double v) {
+  if (LPR == 1) return v;
+  constexpr int S2 = SRC & 1;
+  constexpr int ctrl = (LPR == 2) ? (S2 | (S2 << 2) | ((2 + S2) << 4) | ((2 + S2) << 6))
+                                  : ((SRC & 3) | ((SRC & 3) << 2) | ((SRC & 3) << 4) | ((SRC & 3) << 6));
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// sum over the LPR lanes of a group (every lane gets the total)
+template <int LPR>
+__device__ __forceinline__ double group_sum(double v) {
+  if (LPR == 1) return v;
+  {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, true);   // quad_perm:[1,0,3,2]
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, true);
+    v += __hiloint2double(hi, lo);
+  }
+  if (LPR == 4) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x4E, 0xf, 0xf, true);   // quad_perm:[2,3,0,1]
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x4E, 0xf, 0xf, true);
+    v += __hiloint2double(hi, lo);
+  }
+  return v;
+}
+
+// 1/x to full double precision for normal, non-zero x (v_rcp_f64 + two Newton steps); no denormal / special-case
+// handling -- callers test the pivot magnitude separately.
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-x, r, 1.0);
+  r = fma(r, e, r);
+  return r;
+}
+
 // sin / cos for |x| up to a few thousand radians: Cody-Waite reduction by pi/2 (3-part constant with FMA) +
 // the fdlibm __kernel_sin / __kernel_cos minimax polynomials on [-pi/4, pi/4] (< 1 ulp).
 __device__ __forceinline__ void fast_sincos(double x, double& s, double& c) {
   const double TWO_OVER_PI = 0.63661977236758134308;
-  const double P1 = 1.57079632673412561417e+00;   // first 33 bits of pi/2
-  const double P2 = 6.07710050650619224932e-11;   // next 33 bits
-  const double P3 = 2.02226624879595063154e-21;   // tail
+  const double P1 = 1.57079632673412561417e+00;
+  const double P2 = 6.07710050650619224932e-11;
+  const double P3 = 2.02226624879595063154e-21;
   const double kf = rint(x * TWO_OVER_PI);
   double r = fma(-kf, P1, x);
   r = fma(-kf, P2, r);
   r = fma(-kf, P3, r);
   const int q = (int)kf;
   const double z = r * r;
-  // sin kernel
   const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
                S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
   const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2), S1);
   const double sr = fma(r * z, ps, r);
-  // cos kernel
   const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
                C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
   const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
@@ -72,132 +128,275 @@ __device__ __forceinline__ void fast_sincos(double x, double& s, double& c) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Register-resident Gauss-Jordan.  Lane `lane` owns row `lane` (rows >= n are idle).  a[0..NMAX-1] = matrix row,
-// a[NMAX] = right-hand side.  Columns k >= n are skipped.  On return the lane that pivoted column k holds x_k in
-// `x` and k in `mycol` (-1 for idle lanes).  Returns false on a zero pivot.
-template <int NMAX>
-__device__ __forceinline__ bool gj_solve(double (&a)[NMAX + 1], int n, int lane, double& x, int& mycol) {
-  bool used = lane >= n;
+// Geometry of the register-resident solver.
+template <int NMAX, int LPR>
+struct Geo {
+  static_assert(NMAX % LPR == 0, "NMAX must be a multiple of LPR");
+  static constexpr int NC = NMAX / LPR;                 // matrix columns per lane
+  static constexpr int NV = (NC + 2) & ~1;              // values per lane (columns + rhs), padded to even (16-byte slots)
+  static constexpr int RHS = NC;                        // slot of the right-hand side (every sub-lane keeps a copy)
+  // position of column `col` of row `row` in the lane-major row buffer R
+  __device__ static __forceinline__ int pos(int row, int col) { return (row * LPR + (col % LPR)) * NV + col / LPR; }
+};
+
+// Register-resident Gauss-Jordan with partial pivoting.  lane = row*LPR + sub; a[idx] = column idx*LPR+sub of the
+// row (idx < NC), a[RHS] = right-hand side.  Rows >= n are idle.  `pb` = LDS pivot-row buffer (LPR*NV doubles).
+// On return every lane of the row that pivoted column k has mycol = k and x = x_k.  Returns false on a zero pivot.
+template <int NMAX, int LPR, int NV>
+__device__ __forceinline__ bool gj_solve(double (&a)[NV], int n, int lane, double* __restrict__ pb, double& x, int& mycol) {
+  using G = Geo<NMAX, LPR>;
+  static_assert(NV == G::NV, "register row size mismatch");
+  const int row = lane / LPR, sub = lane % LPR;
+  bool used = row >= n;
   bool ok = true;
-  double piv = 1.0;
+  double inv_piv = 1.0;
   mycol = -1;
+  double* my_pb = pb + sub * NV;
 #pragma unroll
   for (int k = 0; k < NMAX; ++k) {
     if (k < n) {   // wave-uniform
-      const double av = fabs(a[k]);
-      unsigned key = (((unsigned)__double2hiint(av)) & ~63u) | (unsigned)lane;
-      if (used) key = (unsigned)lane;
+      const int ks = k % LPR, ki = k / LPR;
+      const bool owner = (LPR == 1) || (sub == ks);
+      const double akk = a[ki];
+      unsigned key = (((unsigned)__double2hiint(fabs(akk))) & ~63u) | (unsigned)lane;
+      if (used || !owner) key = (unsigned)lane;
+      const double cand = fast_rcp(akk);                 // independent of the reduction: overlaps with it
       const unsigned best = wave_umax(key);
-      const int p = (int)(best & 63u);
+      const int pl = (int)(best & 63u);
       if ((best >> 6) == 0u) ok = false;
-      const double pk = readlane_f64(a[k], p);
-      const double rp = 1.0 / pk;
-      double m = a[k] * rp;
-      if (lane == p) { used = true; mycol = k; m = 0.0; piv = pk; }
+      const double rp = readlane_f64(cand, pl);
+      const double m_own = akk * rp;
+      double m = (LPR == 1) ? m_own
+                            : (ks == 0 ? group_bcast<LPR, 0>(m_own)
+                                       : ks == 1 ? group_bcast<LPR, 1>(m_own)
+                                                 : ks == 2 ? group_bcast<LPR, 2>(m_own) : group_bcast<LPR, 3>(m_own));
+      const bool in_prow = (row == pl / LPR);
+      if (in_prow) {
+        used = true; mycol = k; inv_piv = rp; m = 0.0;
+        // publish the live part of the pivot row (slots >= ki) for the other rows
 #pragma unroll
-      for (int j = k + 1; j <= NMAX; ++j) {
-        const double pj = readlane_f64(a[j], p);
-        a[j] = fma(-m, pj, a[j]);
+        for (int idx = ki & ~1; idx < NV; idx += 2) {
+          double2 v2; v2.x = a[idx]; v2.y = a[idx + 1];
+          *reinterpret_cast<double2*>(my_pb + idx) = v2;
+        }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int idx = ki & ~1; idx < NV; idx += 2) {
+        const double2 v2 = *reinterpret_cast<const double2*>(my_pb + idx);
+        a[idx] = fma(-m, v2.x, a[idx]);
+        a[idx + 1] = fma(-m, v2.y, a[idx + 1]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
-  x = a[NMAX] / piv;
+  x = a[G::RHS] * inv_piv;
   return ok;
 }
 
-// LDS carve of the small kernels ------------------------------------------------------------------------------------
-struct CarveS {
-  double *vm, *va, *e, *f, *ivm, *Psp, *Qsp, *Sre, *Sim, *vset, *Pd, *Qd, *Gs, *dx;
-  double* Y;      // [nbc][ldy] complex (re, im interleaved), ldy = nbc | 1
-  double* R;      // [nrows][NMAX + 2] row buffer (Jacobian / B' rows); Sre/Sim alias its head after the Newton loop
-  int *gmap, *gid, *btype, *pidx, *qidx, *lab, *pbus, *qbus;
-  int *lor_c, *lex_c, *gen_c, *load_c, *sto_c, *sh_c;
+// ---------------------------------------------------------------------------------------------------
+struct BusRec {      // per-bus record read by the Jacobian assembly loop (two ds_read_b128)
+  double e, f, ivm;
+  int pidx, qidx;
 };
 
-template <int NMAX>
+struct CarveS {
+  double* R;         // [<=64 lanes][NV] lane-major row buffer (Jacobian / B' rows); its head is reused as pivot-row
+                     // buffer, solution vector and (after the Newton loop) bus injections
+  double* Y;         // [nbc][ldy] complex (re, im interleaved), ldy = nbc | 1
+  BusRec* rec;       // [nbc]
+  double *vm, *va, *Psp, *Qsp, *vset, *Pd, *Qd, *Gs;     // [nbc]
+  double* inj;       // [n_inj] staged injection row of the lane
+  double *dx, *Sre, *Sim, *pb;                           // aliases inside R
+  int *btype, *lab;  // [nbc]
+  int* topo;         // [dim_topo] staged topology row (aliases R during K1)
+  i8* gmap;          // [nb_tot]
+  i8 *pbus, *qbus;   // [NMAX]
+  i8 *lor_c, *lex_c, *gen_c, *load_c, *sto_c, *sh_c;
+};
+
+template <int NMAX, int LPR>
+__host__ __device__ inline size_t rbuf_doubles(const GridDev& g, int nbc, int nrows) {
+  using G = Geo<NMAX, LPR>;
+  size_t rbuf = (size_t)nrows * LPR * G::NV;
+  const size_t min_r = (size_t)LPR * G::NV + NMAX + 2 * (size_t)nbc;       // pivot buffer + dx + Sre/Sim
+  if (rbuf < min_r) rbuf = min_r;
+  const size_t topo_d = ((size_t)g.dim_topo + 1) / 2 + 1;
+  if (rbuf < topo_d) rbuf = topo_d;
+  return (rbuf + 1) & ~(size_t)1;
+}
+
+template <int NMAX, int LPR>
 __host__ __device__ inline size_t lds_bytes_small(const GridDev& g, int nbc, int nrows) {
   const size_t ldy = (size_t)(nbc | 1);
-  size_t rbuf = (size_t)nrows * (NMAX + 2);
-  if (rbuf < (size_t)2 * nbc) rbuf = (size_t)2 * nbc;
-  size_t nd = (size_t)11 * nbc + (size_t)NMAX + 2 * (size_t)nbc * ldy + rbuf;
-  size_t ni = (size_t)g.nb_tot + 4 * (size_t)nbc + 2 * (size_t)NMAX + 2 * (size_t)g.n_line + g.n_gen + g.n_load + g.n_sto +
-              g.n_shunt;
-  return nd * 8 + ((ni * 4 + 7) & ~(size_t)7);
+  const size_t nd = rbuf_doubles<NMAX, LPR>(g, nbc, nrows) + 2 * (size_t)nbc * ldy + 4 * (size_t)nbc /*BusRec*/ + 8 * (size_t)nbc +
+                    (size_t)g.n_inj;
+  const size_t ni = 2 * (size_t)nbc;
+  const size_t n8 = (size_t)g.nb_tot + 2 * (size_t)NMAX + 2 * (size_t)g.n_line + g.n_gen + g.n_load + g.n_sto + g.n_shunt;
+  return nd * 8 + ni * 4 + ((n8 + 15) & ~(size_t)15);
 }
 
-template <int NMAX>
+template <int NMAX, int LPR>
 __device__ inline void carve_small(CarveS& c, unsigned char* base, const GridDev& g, int nbc, int nrows) {
+  using G = Geo<NMAX, LPR>;
   const int ldy = nbc | 1;
   double* d = reinterpret_cast<double*>(base);
-  size_t rbuf = (size_t)nrows * (NMAX + 2);
-  if (rbuf < (size_t)2 * nbc) rbuf = (size_t)2 * nbc;
-  c.R = d; c.Sre = d; c.Sim = d + nbc; d += rbuf;     // first: 16-byte aligned rows for ds_read_b128
+  c.R = d;
+  c.pb = d;                                  // pivot-row buffer: first LPR*NV doubles
+  c.dx = d + LPR * G::NV;                    // solution vector: next NMAX doubles
+  c.Sre = d + LPR * G::NV + NMAX;            // bus injections (only live after the Newton loop)
+  c.Sim = c.Sre + nbc;
+  c.topo = reinterpret_cast<int*>(d);        // staged topology row (only live during K1)
+  d += rbuf_doubles<NMAX, LPR>(g, nbc, nrows);
   c.Y = d; d += (size_t)2 * nbc * ldy;
-  c.vm = d; d += nbc; c.va = d; d += nbc; c.e = d; d += nbc; c.f = d; d += nbc; c.ivm = d; d += nbc;
-  c.Psp = d; d += nbc; c.Qsp = d; d += nbc;
+  c.rec = reinterpret_cast<BusRec*>(d); d += (size_t)4 * nbc;
+  c.vm = d; d += nbc; c.va = d; d += nbc; c.Psp = d; d += nbc; c.Qsp = d; d += nbc;
   c.vset = d; d += nbc; c.Pd = d; d += nbc; c.Qd = d; d += nbc; c.Gs = d; d += nbc;
-  c.dx = d; d += NMAX;
+  c.inj = d; d += g.n_inj;
   int* i = reinterpret_cast<int*>(d);
-  c.gmap = i; i += g.nb_tot;
-  c.gid = nullptr; c.btype = i; i += nbc; c.pidx = i; i += nbc; c.qidx = i; i += nbc; c.lab = i; i += nbc;
-  c.pbus = i; i += NMAX; c.qbus = i; i += NMAX;
-  c.lor_c = i; i += g.n_line; c.lex_c = i; i += g.n_line;
-  c.gen_c = i; i += g.n_gen; c.load_c = i; i += g.n_load; c.sto_c = i; i += g.n_sto; c.sh_c = i; i += g.n_shunt;
-}
-
-// K1 for the small kernels: identical to build_topology() but on CarveS (kept separate to avoid a template on the
-// carve type in the generic kernels).
-__device__ inline int build_topology_s(const GridDev& g, CarveS& c, const int* __restrict__ topo,
-                                       const int* __restrict__ shunt_bus, unsigned char* __restrict__ status_out, int nbc,
-                                       int tid) {
-  Carve cc{};
-  cc.gmap = c.gmap; cc.gid = c.lab;  /* gid unused by the small kernels: lab doubles as scratch */ cc.lor_c = c.lor_c; cc.lex_c = c.lex_c; cc.gen_c = c.gen_c; cc.load_c = c.load_c;
-  cc.sto_c = c.sto_c; cc.sh_c = c.sh_c;
-  return build_topology(g, cc, topo, shunt_bus, status_out, nbc, tid);
+  c.btype = i; i += nbc; c.lab = i; i += nbc;
+  i8* q = reinterpret_cast<i8*>(i);
+  c.gmap = q; q += g.nb_tot;
+  c.pbus = q; q += NMAX; c.qbus = q; q += NMAX;
+  c.lor_c = q; q += g.n_line; c.lex_c = q; q += g.n_line;
+  c.gen_c = q; q += g.n_gen; c.load_c = q; q += g.n_load; c.sto_c = q; q += g.n_sto; c.sh_c = q; q += g.n_shunt;
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int NMAX>
+// K1 (small): element -> compact bus maps (int8), active-bus mask, dense renumbering.  Needs nb_tot <= 127.
+__device__ inline int build_topology_small(const GridDev& g, CarveS& c, const int* __restrict__ topo_g,
+                                           const int* __restrict__ shunt_bus, unsigned char* __restrict__ status_out, int nbc,
+                                           int tid) {
+  const int ns = g.n_sub;
+  for (int i = tid; i < g.dim_topo; i += WAVE) c.topo[i] = topo_g[i];     // coalesced row load, then LDS gathers
+  for (int i = tid; i < g.nb_tot; i += WAVE) c.gmap[i] = 0;
+  __syncthreads();
+  const int* topo = c.topo;
+  for (int l = tid; l < g.n_line; l += WAVE) {
+    const int bo = topo[g.line_or_pos[l]], be = topo[g.line_ex_pos[l]];
+    const bool on = (bo >= 1) && (be >= 1);
+    const int go = on ? g.line_or_sub[l] + (bo - 1) * ns : -1;
+    const int ge = on ? g.line_ex_sub[l] + (be - 1) * ns : -1;
+    c.lor_c[l] = (i8)go;
+    c.lex_c[l] = (i8)ge;
+    if (on) { c.gmap[go] = 1; c.gmap[ge] = 1; }
+    if (status_out) status_out[l] = on ? 1 : 0;
+  }
+  for (int i = tid; i < g.n_gen; i += WAVE) {
+    const int b = topo[g.gen_pos[i]];
+    const int gb = (b >= 1) ? g.gen_sub[i] + (b - 1) * ns : -1;
+    c.gen_c[i] = (i8)gb;
+    if (gb >= 0) c.gmap[gb] = 1;
+  }
+  for (int i = tid; i < g.n_load; i += WAVE) {
+    const int b = topo[g.load_pos[i]];
+    const int gb = (b >= 1) ? g.load_sub[i] + (b - 1) * ns : -1;
+    c.load_c[i] = (i8)gb;
+    if (gb >= 0) c.gmap[gb] = 1;
+  }
+  for (int i = tid; i < g.n_sto; i += WAVE) {
+    const int b = topo[g.sto_pos[i]];
+    const int gb = (b >= 1) ? g.sto_sub[i] + (b - 1) * ns : -1;
+    c.sto_c[i] = (i8)gb;
+    if (gb >= 0) c.gmap[gb] = 1;
+  }
+  for (int i = tid; i < g.n_shunt; i += WAVE) {
+    const int b = shunt_bus[i];
+    const int gb = (b >= 1) ? g.shunt_sub[i] + (b - 1) * ns : -1;
+    c.sh_c[i] = (i8)gb;
+    if (gb >= 0) c.gmap[gb] = 1;
+  }
+  __syncthreads();
+  int base = 0;
+  for (int i0 = 0; i0 < g.nb_tot; i0 += WAVE) {
+    const int i = i0 + tid;
+    const int act = (i < g.nb_tot) ? (int)c.gmap[i] : 0;
+    const unsigned long long m = __ballot(act);
+    const int rank = base + __popcll(m & ((1ull << tid) - 1ull));
+    if (i < g.nb_tot) c.gmap[i] = (i8)(act ? rank : -1);
+    base += __popcll(m);
+  }
+  __syncthreads();
+  const int nb = base;
+  if (nb > nbc) return -1;
+  for (int l = tid; l < g.n_line; l += WAVE) {
+    const int go = c.lor_c[l], ge = c.lex_c[l];
+    c.lor_c[l] = go >= 0 ? c.gmap[go] : (i8)-1;
+    c.lex_c[l] = ge >= 0 ? c.gmap[ge] : (i8)-1;
+  }
+  for (int i = tid; i < g.n_gen; i += WAVE) { const int b = c.gen_c[i]; c.gen_c[i] = b >= 0 ? c.gmap[b] : (i8)-1; }
+  for (int i = tid; i < g.n_load; i += WAVE) { const int b = c.load_c[i]; c.load_c[i] = b >= 0 ? c.gmap[b] : (i8)-1; }
+  for (int i = tid; i < g.n_sto; i += WAVE) { const int b = c.sto_c[i]; c.sto_c[i] = b >= 0 ? c.gmap[b] : (i8)-1; }
+  for (int i = tid; i < g.n_shunt; i += WAVE) { const int b = c.sh_c[i]; c.sh_c[i] = b >= 0 ? c.gmap[b] : (i8)-1; }
+  __syncthreads();
+  return nb;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// One complete power flow of one instance.  `inj_staged`: c.inj already holds the lane's injection row.
+template <int NMAX, int LPR>
 __device__ inline int solve_instance_small(const DevParams* __restrict__ P, CarveS& c, int inst, int nbc, int nrows, int is_dc,
-                                           int max_iter, double tol_pu, int tid, int& n_iter_out, int& nb_out) {
+                                           int max_iter, double tol_pu, int tid, bool inj_staged, int& n_iter_out, int& nb_out) {
+  using G = Geo<NMAX, LPR>;
+  constexpr int NV = G::NV;
   const GridDev& g = P->g;
   const Bufs& b = P->b;
   const OutOff& oo = P->oo;
-  const double* __restrict__ inj = b.inj + (size_t)inst * g.n_inj;
-  const int* __restrict__ topo = b.topo + (size_t)inst * g.dim_topo;
+  const int* __restrict__ topo_g = b.topo + (size_t)inst * g.dim_topo;
   const int* __restrict__ shb = b.shunt_bus + (size_t)inst * g.n_shunt;
   unsigned char* lstat = b.line_status + (size_t)inst * g.n_line;
-  constexpr int LDR = NMAX + 2;
   n_iter_out = 0;
   nb_out = 0;
+  GPF_STAMP(0);
+  if (!inj_staged) {
+    const double* __restrict__ inj_g = b.inj + (size_t)inst * g.n_inj;
+    for (int i = tid; i < g.n_inj; i += WAVE) c.inj[i] = inj_g[i];
+  }
+  const double* __restrict__ inj = c.inj;
 
   // ---- K1 ----------------------------------------------------------------------------------------------------------
-  const int nb = build_topology_s(g, c, topo, shb, lstat, nbc, tid);
+  const int nb = build_topology_small(g, c, topo_g, shb, lstat, nbc, tid);
   if (nb < 0) return 5;
   nb_out = nb;
   const int ldy = nbc | 1;
   const double sn = g.sn_mva;
   const double inv_sn = 1.0 / sn;
+  GPF_STAMP(1);
 
-  // ---- bus types / injections: thread per bus gathers over the elements (oracle summation order) ---------------------
+  // ---- bus types / injections: thread per bus gathers over the (LDS-staged) elements, oracle summation order --------
   for (int ci = tid; ci < nb; ci += WAVE) {
     int bt = BT_PQ;
     double Pg = 0.0, vs = 1.0;
     for (int i = 0; i < g.n_gen; ++i) {
-      if (c.gen_c[i] == ci) {
-        if (g.gen_slack[i]) bt = BT_REF;
-        else { if (bt != BT_REF) bt = BT_PV; Pg += inj[oo.inj_gen_p + i] * inv_sn; }
-        vs = inj[oo.inj_gen_vm + i];
+      const bool hit = c.gen_c[i] == ci;
+      const bool sl = g.gen_slack[i] != 0;          // wave-uniform
+      const double gp = inj[oo.inj_gen_p + i], gv = inj[oo.inj_gen_vm + i];
+      if (hit) {
+        if (sl) bt = BT_REF;
+        else { if (bt != BT_REF) bt = BT_PV; Pg += gp * inv_sn; }
+        vs = gv;
       }
     }
     double pd = 0.0, qd = 0.0;
-    for (int i = 0; i < g.n_load; ++i)
-      if (c.load_c[i] == ci) { pd += inj[oo.inj_load_p + i]; qd += inj[oo.inj_load_q + i]; }
-    for (int i = 0; i < g.n_sto; ++i)
-      if (c.sto_c[i] == ci) { pd += inj[oo.inj_sto_p + i]; qd += inj[oo.inj_sto_q + i]; }
+    for (int i = 0; i < g.n_load; ++i) {
+      const bool hit = c.load_c[i] == ci;
+      const double lp = inj[oo.inj_load_p + i], lq = inj[oo.inj_load_q + i];
+      if (hit) { pd += lp; qd += lq; }
+    }
+    for (int i = 0; i < g.n_sto; ++i) {
+      const bool hit = c.sto_c[i] == ci;
+      const double sp = inj[oo.inj_sto_p + i], sq = inj[oo.inj_sto_q + i];
+      if (hit) { pd += sp; qd += sq; }
+    }
     double gs = 0.0;
-    for (int i = 0; i < g.n_shunt; ++i)
-      if (c.sh_c[i] == ci) gs += inj[oo.inj_sh_p + i] * g.shunt_fact[i] * inv_sn;
+    for (int i = 0; i < g.n_shunt; ++i) {
+      const bool hit = c.sh_c[i] == ci;
+      const double sp = inj[oo.inj_sh_p + i] * g.shunt_fact[i] * inv_sn;
+      if (hit) gs += sp;
+    }
     c.btype[ci] = bt;
     c.vset[ci] = vs;
     c.Pd[ci] = pd;
@@ -219,10 +418,10 @@ __device__ inline int solve_instance_small(const DevParams* __restrict__ P, Carv
     if (ci < nb) {
       const int pi = (bt == BT_PQ || bt == BT_PV) ? npvpq + __popcll(mp & below) : -1;
       const int qi = (bt == BT_PQ) ? npq + __popcll(mq & below) : -1;
-      c.pidx[ci] = pi;
-      c.qidx[ci] = qi;
-      if (pi >= 0 && pi < NMAX) c.pbus[pi] = ci;
-      if (qi >= 0 && qi < NMAX) c.qbus[qi] = ci;
+      c.rec[ci].pidx = pi;
+      c.rec[ci].qidx = qi;
+      if (pi >= 0 && pi < NMAX) c.pbus[pi] = (i8)ci;
+      if (qi >= 0 && qi < NMAX) c.qbus[qi] = (i8)ci;
     }
     npvpq += __popcll(mp);
     npq += __popcll(mq);
@@ -231,7 +430,8 @@ __device__ inline int solve_instance_small(const DevParams* __restrict__ P, Carv
   __syncthreads();
   if (nref == 0) return 3;
   const int n = npvpq + npq;
-  if (n > NMAX || n > nrows || npvpq > nrows) return 5;
+  if (n > NMAX || n > nrows || n * LPR > WAVE) return 5;
+  GPF_STAMP(2);
 
   // ---- connectivity ----------------------------------------------------------------------------------------------------
   for (int sweep = 0; sweep < nb; ++sweep) {
@@ -251,145 +451,185 @@ __device__ inline int solve_instance_small(const DevParams* __restrict__ P, Carv
     for (int ci = tid; ci < nb; ci += WAVE) bad |= (c.lab[ci] == 0);
     if (__any(bad)) return 2;
   }
+  GPF_STAMP(3);
 
-  // ---- K2 + K3 assembly: one pass over the branches per bus row builds the Ybus row (AC) and the B' row (DC) ---------------
-  // B' rows live in the row buffer R (row = pidx of the bus), zeroed by the owning lane first.
-  for (int ci = tid; ci < nb; ci += WAVE) {
-    double* Yr = c.Y + (size_t)2 * ci * ldy;
-    for (int j = 0; j < 2 * nb; ++j) Yr[j] = 0.0;
-    const int pi = c.pidx[ci];
-    double* Rr = c.R + (size_t)(pi >= 0 ? pi : 0) * LDR;
-    if (pi >= 0)
-      for (int j = 0; j < npvpq; ++j) Rr[j] = 0.0;
-    double diag = 0.0;
-    for (int l = 0; l < g.n_line; ++l) {
-      const int f = c.lor_c[l], t = c.lex_c[l];
-      if (f < 0 || (f != ci && t != ci)) continue;
-      const double* y = g.br_y + (size_t)8 * l;
-      if (f == ci) {
-        Yr[2 * f] += y[0]; Yr[2 * f + 1] += y[1];
-        Yr[2 * t] += y[2]; Yr[2 * t + 1] += y[3];
-      }
-      if (t == ci) {
-        Yr[2 * f] += y[4]; Yr[2 * f + 1] += y[5];
-        Yr[2 * t] += y[6]; Yr[2 * t + 1] += y[7];
-      }
-      if (pi >= 0 && f != t) {
-        const double bb = g.br_bdc[l];
-        diag += bb;
-        const int po = c.pidx[(f == ci) ? t : f];
-        if (po >= 0) Rr[po] -= bb;
+  // ---- K2 + K3 assembly with LDS f64 atomics from the BRANCH lanes -----------------------------------------------------------
+  for (int e = tid; e < 2 * nb * ldy; e += WAVE) c.Y[e] = 0.0;
+  if (tid < npvpq * LPR) {
+    double* Rz = c.R + (size_t)tid * NV;
+#pragma unroll
+    for (int idx = 0; idx < NV; ++idx) Rz[idx] = 0.0;
+  }
+  __syncthreads();
+  for (int l = tid; l < g.n_line; l += WAVE) {
+    const int f = c.lor_c[l], t = c.lex_c[l];
+    if (f < 0) continue;
+    if (!is_dc) {
+      const double4* y4 = reinterpret_cast<const double4*>(g.br_y + (size_t)8 * l);
+      const double4 ya = y4[0], yb = y4[1];          // yff.re, yff.im, yft.re, yft.im | ytf.re, ytf.im, ytt.re, ytt.im
+      double* Yf = c.Y + (size_t)2 * f * ldy;
+      double* Yt = c.Y + (size_t)2 * t * ldy;
+      atomicAdd(&Yf[2 * f], ya.x); atomicAdd(&Yf[2 * f + 1], ya.y);
+      atomicAdd(&Yf[2 * t], ya.z); atomicAdd(&Yf[2 * t + 1], ya.w);
+      atomicAdd(&Yt[2 * f], yb.x); atomicAdd(&Yt[2 * f + 1], yb.y);
+      atomicAdd(&Yt[2 * t], yb.z); atomicAdd(&Yt[2 * t + 1], yb.w);
+    }
+    if (f != t) {
+      const double bb = g.br_bdc[l];
+      const int pf = c.rec[f].pidx, pt = c.rec[t].pidx;
+      if (pf >= 0) atomicAdd(&c.R[G::pos(pf, pf)], bb);
+      if (pt >= 0) atomicAdd(&c.R[G::pos(pt, pt)], bb);
+      if (pf >= 0 && pt >= 0) { atomicAdd(&c.R[G::pos(pf, pt)], -bb); atomicAdd(&c.R[G::pos(pt, pf)], -bb); }
+    }
+  }
+  if (!is_dc) {
+    for (int s = tid; s < g.n_shunt; s += WAVE) {
+      const int ci = c.sh_c[s];
+      if (ci >= 0) {
+        const double fct = g.shunt_fact[s] * inv_sn;
+        atomicAdd(&c.Y[(size_t)2 * ci * ldy + 2 * ci], inj[oo.inj_sh_p + s] * fct);
+        atomicAdd(&c.Y[(size_t)2 * ci * ldy + 2 * ci + 1], -inj[oo.inj_sh_q + s] * fct);
       }
     }
-    for (int s = 0; s < g.n_shunt; ++s) {
-      if (c.sh_c[s] == ci) {
-        Yr[2 * ci] += inj[oo.inj_sh_p + s] * g.shunt_fact[s] * inv_sn;
-        Yr[2 * ci + 1] -= inj[oo.inj_sh_q + s] * g.shunt_fact[s] * inv_sn;
-      }
-    }
+  }
+  for (int ci = tid; ci < nb; ci += WAVE) {           // DC right-hand side (a copy in every sub-lane segment)
+    const int pi = c.rec[ci].pidx;
     if (pi >= 0) {
-      Rr[pi] += diag;
-      Rr[NMAX] = c.Psp[ci] - c.Gs[ci];
+      const double rhs = c.Psp[ci] - c.Gs[ci];
+#pragma unroll
+      for (int s = 0; s < LPR; ++s) c.R[(size_t)(pi * LPR + s) * NV + G::RHS] = rhs;
     }
   }
   __syncthreads();
+  GPF_STAMP(4);
 
-  double a[NMAX + 1];
+  double a[NV];
   // ---- K3: DC solve ------------------------------------------------------------------------------------------------------
   {
-    const double* Rr = c.R + (size_t)(tid < nrows ? tid : 0) * LDR;
+    const bool on = tid < npvpq * LPR;
+    const double* Rl = c.R + (size_t)(on ? tid : 0) * NV;
 #pragma unroll
-    for (int j = 0; j <= NMAX; ++j) a[j] = (tid < npvpq && (j < npvpq || j == NMAX)) ? Rr[j] : 0.0;
+    for (int idx = 0; idx < NV; idx += 2) {
+      const double2 v2 = *reinterpret_cast<const double2*>(Rl + idx);
+      a[idx] = on ? v2.x : 0.0;
+      a[idx + 1] = on ? v2.y : 0.0;
+    }
+    __syncthreads();                 // everybody holds its row: the buffer head may now be reused (pivot rows, dx)
     double x;
     int mycol;
-    bool ok = gj_solve<NMAX>(a, npvpq, tid, x, mycol);
-    if (mycol >= 0) {
+    bool ok = gj_solve<NMAX, LPR, NV>(a, npvpq, tid, c.pb, x, mycol);
+    if (mycol >= 0 && (tid % LPR) == 0) {
       c.dx[mycol] = x;
       if (!(fabs(x) < 1e300)) ok = false;
     }
     __syncthreads();
     if (__any(!ok)) return 4;
     for (int ci = tid; ci < nb; ci += WAVE) {
-      const int pi = c.pidx[ci];
+      const int pi = c.rec[ci].pidx;
       c.va[ci] = (pi >= 0) ? c.dx[pi] : 0.0;
       c.vm[ci] = (c.btype[ci] == BT_PQ) ? 1.0 : c.vset[ci];
     }
     __syncthreads();
   }
+  GPF_STAMP(5);
 
   int status = 0;
   int it = 0;
   if (!is_dc) {
     // ---- K4/K5: Newton-Raphson ---------------------------------------------------------------------------------------------
     bool converged = false;
-    const bool row_on = tid < n;
-    const bool isQ = tid >= npvpq;
-    const int ib = row_on ? (isQ ? c.qbus[tid - npvpq] : c.pbus[tid]) : 0;
+    const int row = tid / LPR, sub = tid % LPR;
+    const bool row_on = row < n;
+    const bool isQ = row >= npvpq;
+    const int ib = row_on ? (isQ ? (int)c.qbus[row - npvpq] : (int)c.pbus[row]) : 0;
     const double Pi = c.Psp[ib], Qi = c.Qsp[ib];
-    const int pii = c.pidx[ib], qii = c.qidx[ib];
-    double* Rr = c.R + (size_t)(tid < nrows ? tid : 0) * LDR;
+    const int pii = c.rec[ib].pidx, qii = c.rec[ib].qidx;
+    double* Rrow = c.R + (size_t)(row_on ? row : 0) * LPR * NV;    // this row's LPR segments
+    const double* Rl = c.R + (size_t)(row_on ? tid : 0) * NV;      // this lane's segment
     double Sr_last = 0.0, Si_last = 0.0;
     while (true) {
       for (int ci = tid; ci < nb; ci += WAVE) {
         double s, co;
         fast_sincos(c.va[ci], s, co);
         const double vmi = c.vm[ci];
-        c.e[ci] = vmi * co;
-        c.f[ci] = vmi * s;
-        c.ivm[ci] = 1.0 / vmi;
+        c.rec[ci].e = vmi * co;
+        c.rec[ci].f = vmi * s;
+        c.rec[ci].ivm = 1.0 / vmi;
       }
       __syncthreads();
-      // Row assembly (dense over the buses): T_ij = V_i conj(Y_ij V_j); S_i = sum_j T_ij
+      if (it == 1) GPF_STAMP(10);
+      // Row assembly: T_ij = V_i conj(Y_ij V_j), S_i = sum_j T_ij; the LPR lanes of a row split the buses j
       double fabs_mis = 0.0;
       bool bad = false;
+      double Sr = 0.0, Si = 0.0, Tr = 0.0, Ti = 0.0;
       if (row_on) {
-        const double ei = c.e[ib], fi = c.f[ib];
+        const double ei = c.rec[ib].e, fi = c.rec[ib].f;
         const double* Yr = c.Y + (size_t)2 * ib * ldy;
-        double Sr = 0.0, Si = 0.0, Tr = 0.0, Ti = 0.0;
-        for (int j = 0; j < nb; ++j) {
-          const double yr = Yr[2 * j], yi = Yr[2 * j + 1];
-          const double ej = c.e[j], fj = c.f[j];
-          const double aa = yr * ej - yi * fj, bb = yr * fj + yi * ej;
+#pragma unroll 2
+        for (int j = sub; j < nb; j += LPR) {
+          const double2 y = *reinterpret_cast<const double2*>(Yr + 2 * j);
+          const BusRec rj = c.rec[j];
+          const double aa = y.x * rj.e - y.y * rj.f, bb = y.x * rj.f + y.y * rj.e;
           const double tr_ = ei * aa + fi * bb;
           const double ti_ = fi * aa - ei * bb;
           Sr += tr_;
           Si += ti_;
-          const int pj = c.pidx[j], qj = c.qidx[j];
-          if (pj >= 0) Rr[pj] = isQ ? -tr_ : ti_;
-          if (qj >= 0) Rr[npvpq + qj] = (isQ ? ti_ : tr_) * c.ivm[j];
+          if (rj.pidx >= 0) Rrow[(rj.pidx % LPR) * NV + rj.pidx / LPR] = isQ ? -tr_ : ti_;
+          if (rj.qidx >= 0) {
+            const int cq = npvpq + rj.qidx;
+            Rrow[(cq % LPR) * NV + cq / LPR] = (isQ ? ti_ : tr_) * rj.ivm;
+          }
           if (j == ib) { Tr = tr_; Ti = ti_; }
         }
-        const double ivmi = c.ivm[ib];
-        // diagonal block: dS/dVa_ii = j (S - T_ii), dS/dVm_ii = (T_ii + S) / |V_i|
-        Rr[pii] = isQ ? (Sr - Tr) : (Ti - Si);
-        if (qii >= 0) Rr[npvpq + qii] = (isQ ? (Ti + Si) : (Tr + Sr)) * ivmi;
+      }
+      Sr = group_sum<LPR>(Sr);
+      Si = group_sum<LPR>(Si);
+      if (row_on) {
+        if ((ib % LPR) == sub) {
+          // diagonal block: dS/dVa_ii = j (S - T_ii), dS/dVm_ii = (T_ii + S) / |V_i|
+          const double ivmi = c.rec[ib].ivm;
+          Rrow[(pii % LPR) * NV + pii / LPR] = isQ ? (Sr - Tr) : (Ti - Si);
+          if (qii >= 0) {
+            const int cq = npvpq + qii;
+            Rrow[(cq % LPR) * NV + cq / LPR] = (isQ ? (Ti + Si) : (Tr + Sr)) * ivmi;
+          }
+        }
         const double mis = isQ ? (Si - Qi) : (Sr - Pi);
-        Rr[NMAX] = -mis;
+        Rrow[sub * NV + G::RHS] = -mis;                 // every sub-lane keeps a copy of the right-hand side
         fabs_mis = fabs(mis);
         if (!(fabs_mis <= 1e300)) bad = true;
         Sr_last = Sr;
         Si_last = Si;
       }
-      // reference buses (no row): their S is needed by the result stage only -> computed there
-      // ||F||inf < tol  <=>  no row has |F_row| >= tol (no floating-point reduction needed)
+      // ||F||inf < tol  <=>  no row has |F_row| >= tol
       const bool any_ge = __any(row_on && !(fabs_mis < tol_pu));
       if (__any(bad)) { status = 1; break; }
       if (!any_ge) { converged = true; break; }
       if (it >= max_iter) break;
       ++it;
+      __syncthreads();               // the LPR lanes of a row wrote each other's segments
+      if (it == 2) GPF_STAMP(11);
 #pragma unroll
-      for (int j = 0; j <= NMAX; ++j) a[j] = (row_on && (j < n || j == NMAX)) ? Rr[j] : 0.0;
+      for (int idx = 0; idx < NV; idx += 2) {
+        const double2 v2 = *reinterpret_cast<const double2*>(Rl + idx);
+        // columns >= n of the compact system are not part of it: zero them (slot RHS is always live)
+        const int c0 = idx * LPR + sub, c1 = (idx + 1) * LPR + sub;
+        a[idx] = (row_on && (c0 < n || idx == G::RHS)) ? v2.x : 0.0;
+        a[idx + 1] = (row_on && (c1 < n || idx + 1 == G::RHS)) ? v2.y : 0.0;
+      }
+      __syncthreads();
       double x;
       int mycol;
-      bool ok = gj_solve<NMAX>(a, n, tid, x, mycol);
-      if (mycol >= 0) {
+      bool ok = gj_solve<NMAX, LPR, NV>(a, n, tid, c.pb, x, mycol);
+      if (mycol >= 0 && sub == 0) {
         c.dx[mycol] = x;
         if (!(fabs(x) < 1e300)) ok = false;
       }
       __syncthreads();
+      if (it == 2) GPF_STAMP(12);
       if (__any(!ok)) { status = 4; break; }
       for (int ci = tid; ci < nb; ci += WAVE) {
-        const int pi = c.pidx[ci], qi = c.qidx[ci];
+        const int pi = c.rec[ci].pidx, qi = c.rec[ci].qidx;
         double va = c.va[ci], vm = c.vm[ci];
         if (pi >= 0) va += c.dx[pi];
         if (qi >= 0) vm += c.dx[npvpq + qi];
@@ -401,11 +641,12 @@ __device__ inline int solve_instance_small(const DevParams* __restrict__ P, Carv
       __syncthreads();
     }
     if (status == 0 && !converged) status = 1;
-    __syncthreads();                       // the row buffer is dead from here on: its head becomes Sre / Sim
-    if (row_on && !isQ) { c.Sre[ib] = Sr_last; c.Sim[ib] = Si_last; }
+    __syncthreads();                       // the row buffer is dead from here on: part of it becomes Sre / Sim
+    if (row_on && !isQ && sub == 0) { c.Sre[ib] = Sr_last; c.Sim[ib] = Si_last; }
   }
   n_iter_out = it;
   if (status != 0) return status;
+  GPF_STAMP(6);
 
   // ---- K6: result extraction -----------------------------------------------------------------------------------------------
   float* out = b.out + (size_t)inst * g.n_out;
@@ -427,16 +668,16 @@ __device__ inline int solve_instance_small(const DevParams* __restrict__ P, Carv
   } else {
     // bus injections of the buses that own no Jacobian row (reference buses): S = V conj(Ybus V)
     for (int ci = tid; ci < nb; ci += WAVE) {
-      if (c.pidx[ci] >= 0) continue;
+      if (c.rec[ci].pidx >= 0) continue;
       const double* Yr = c.Y + (size_t)2 * ci * ldy;
       double ir = 0.0, ii = 0.0;
       for (int j = 0; j < nb; ++j) {
         const double yr = Yr[2 * j], yi = Yr[2 * j + 1];
-        ir += yr * c.e[j] - yi * c.f[j];
-        ii += yr * c.f[j] + yi * c.e[j];
+        ir += yr * c.rec[j].e - yi * c.rec[j].f;
+        ii += yr * c.rec[j].f + yi * c.rec[j].e;
       }
-      c.Sre[ci] = c.e[ci] * ir + c.f[ci] * ii;
-      c.Sim[ci] = c.f[ci] * ir - c.e[ci] * ii;
+      c.Sre[ci] = c.rec[ci].e * ir + c.rec[ci].f * ii;
+      c.Sim[ci] = c.rec[ci].f * ir - c.rec[ci].e * ii;
     }
   }
   __syncthreads();
@@ -452,12 +693,13 @@ __device__ inline int solve_instance_small(const DevParams* __restrict__ P, Carv
         pf = (c.va[f] - c.va[t]) * g.br_bdc[l] * sn;
         pt = -pf; qf = 0.0; qt = 0.0;
       } else {
-        const double* y = g.br_y + (size_t)8 * l;
-        const double ef = c.e[f], ff = c.f[f], et = c.e[t], ft = c.f[t];
-        const double ifr = y[0] * ef - y[1] * ff + y[2] * et - y[3] * ft;
-        const double ifi = y[0] * ff + y[1] * ef + y[2] * ft + y[3] * et;
-        const double itr = y[4] * ef - y[5] * ff + y[6] * et - y[7] * ft;
-        const double iti = y[4] * ff + y[5] * ef + y[6] * ft + y[7] * et;
+        const double4* y4 = reinterpret_cast<const double4*>(g.br_y + (size_t)8 * l);
+        const double4 ya = y4[0], yb = y4[1];
+        const double ef = c.rec[f].e, ff = c.rec[f].f, et = c.rec[t].e, ft = c.rec[t].f;
+        const double ifr = ya.x * ef - ya.y * ff + ya.z * et - ya.w * ft;
+        const double ifi = ya.x * ff + ya.y * ef + ya.z * ft + ya.w * et;
+        const double itr = yb.x * ef - yb.y * ff + yb.z * et - yb.w * ft;
+        const double iti = yb.x * ff + yb.y * ef + yb.z * ft + yb.w * et;
         pf = (ef * ifr + ff * ifi) * sn;  qf = (ff * ifr - ef * ifi) * sn;
         pt = (et * itr + ft * iti) * sn;  qt = (ft * itr - et * iti) * sn;
       }
@@ -496,36 +738,55 @@ __device__ inline int solve_instance_small(const DevParams* __restrict__ P, Carv
     out[oo.sh_v + i] = on ? (float)(v * g.sub_vn_kv[g.shunt_sub[i]]) : 0.f;
     sbo[i] = on ? shb[i] : -1;
   }
-  for (int i = tid; i < g.n_gen; i += WAVE) {
-    const int ci = c.gen_c[i];
-    float gp = 0.f, gq = 0.f, gv = 0.f, gth = 0.f;
-    if (ci >= 0) {
-      int cnt = 0, nslack = 0;
-      double qmin_t = 0.0, qmax_t = 0.0, p_others = 0.0;
-      for (int k = 0; k < g.n_gen; ++k) {
-        if (c.gen_c[k] == ci) {
+  // generators: pypower pfsoln.  Lane i owns generator i (+64, ...); the per-bus totals are accumulated with
+  // v_readlane over the generators (uniform loop, no table reloads).
+  for (int i0 = 0; i0 < g.n_gen; i0 += WAVE) {
+    const int i = i0 + tid;
+    const bool have = i < g.n_gen;
+    const int ci = have ? (int)c.gen_c[i] : -1;
+    const double my_minq = have ? g.gen_min_q[i] : 0.0, my_maxq = have ? g.gen_max_q[i] : 0.0;
+    const int my_slack = have ? (int)g.gen_slack[i] : 0;
+    const double my_p = have ? inj[oo.inj_gen_p + i] : 0.0;
+    int cnt = 0, nslack = 0;
+    double qmin_t = 0.0, qmax_t = 0.0, p_others = 0.0;
+    for (int k0 = 0; k0 < g.n_gen; k0 += WAVE) {
+      const int k_ = k0 + tid;
+      const bool hk = k_ < g.n_gen;
+      const int kc = hk ? (int)c.gen_c[k_] : -2;
+      const double kminq = hk ? g.gen_min_q[k_] : 0.0, kmaxq = hk ? g.gen_max_q[k_] : 0.0;
+      const int ksl = hk ? (int)g.gen_slack[k_] : 0;
+      const double kp = hk ? inj[oo.inj_gen_p + k_] : 0.0;
+      const int kn = min(WAVE, g.n_gen - k0);
+      for (int kk = 0; kk < kn; ++kk) {
+        const int bc = __builtin_amdgcn_readlane(kc, kk);
+        const double bminq = readlane_f64(kminq, kk), bmaxq = readlane_f64(kmaxq, kk), bp = readlane_f64(kp, kk);
+        const int bsl = __builtin_amdgcn_readlane(ksl, kk);
+        if (bc == ci && ci >= 0) {
           ++cnt;
-          qmin_t += g.gen_min_q[k];
-          qmax_t += g.gen_max_q[k];
-          if (g.gen_slack[k]) ++nslack; else p_others += inj[oo.inj_gen_p + k];
+          qmin_t += bminq;
+          qmax_t += bmaxq;
+          if (bsl) ++nslack; else p_others += bp;
         }
       }
+    }
+    float gp = 0.f, gq = 0.f, gv = 0.f, gth = 0.f;
+    if (ci >= 0) {
       const double qtot = c.Sim[ci] * sn + c.Qd[ci];
       double q;
       if (is_dc) q = 0.0;
       else if (cnt == 1) q = qtot;
       else if (qmin_t == qmax_t) q = qtot / cnt;
-      else q = g.gen_min_q[i] + (qtot - qmin_t) / (qmax_t - qmin_t + 2.220446049250313e-16) * (g.gen_max_q[i] - g.gen_min_q[i]);
-      double p = inj[oo.inj_gen_p + i];
-      if (g.gen_slack[i]) p = (c.Sre[ci] * sn + c.Pd[ci] - p_others) / nslack;
+      else q = my_minq + (qtot - qmin_t) / (qmax_t - qmin_t + 2.220446049250313e-16) * (my_maxq - my_minq);
+      double p = my_p;
+      if (my_slack) p = (c.Sre[ci] * sn + c.Pd[ci] - p_others) / nslack;
       gp = (float)p; gq = (float)q;
       gv = (float)(c.vm[ci] * g.sub_vn_kv[g.gen_sub[i]]);
       gth = (float)(c.va[ci] * RAD2DEG);
     }
-    out[oo.gen_p + i] = gp; out[oo.gen_q + i] = gq; out[oo.gen_v + i] = gv; out[oo.gen_th + i] = gth;
+    if (have) { out[oo.gen_p + i] = gp; out[oo.gen_q + i] = gq; out[oo.gen_v + i] = gv; out[oo.gen_th + i] = gth; }
   }
   int* to = b.topo_out + (size_t)inst * g.dim_topo;
-  for (int i = tid; i < g.dim_topo; i += WAVE) { const int v = topo[i]; to[i] = v >= 1 ? v : -1; }
+  for (int i = tid; i < g.dim_topo; i += WAVE) { const int v = topo_g[i]; to[i] = v >= 1 ? v : -1; }
   __syncthreads();
   for (int l = tid; l < g.n_line; l += WAVE) {
     if (c.lor_c[l] < 0) { to[g.line_or_pos[l]] = -1; to[g.line_ex_pos[l]] = -1; }
@@ -538,20 +799,21 @@ __device__ inline int solve_instance_small(const DevParams* __restrict__ P, Carv
     bvm[i] = ci >= 0 ? c.vm[ci] : nand;
     bva[i] = ci >= 0 ? c.va[ci] * RAD2DEG : nand;
   }
+  GPF_STAMP(7);
   return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int NMAX>
-__global__ __launch_bounds__(WAVE, (NMAX <= 24 ? 4 : NMAX <= 48 ? 3 : 2)) void runpf_small_kernel(const DevParams* __restrict__ P, int lane0, int nbc, int nrows, int is_dc,
-                                                           int max_iter, double tol_pu) {
+template <int NMAX, int LPR>
+__global__ __launch_bounds__(WAVE, GPF_MINW(NMAX)) void runpf_small_kernel(const DevParams* __restrict__ P, int lane0, int nbc,
+                                                                           int nrows, int is_dc, int max_iter, double tol_pu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int inst = lane0 + blockIdx.x;
   const int tid = threadIdx.x;
   CarveS c;
-  carve_small<NMAX>(c, smem, P->g, nbc, nrows);
+  carve_small<NMAX, LPR>(c, smem, P->g, nbc, nrows);
   int n_iter, nb;
-  const int st = solve_instance_small<NMAX>(P, c, inst, nbc, nrows, is_dc, max_iter, tol_pu, tid, n_iter, nb);
+  const int st = solve_instance_small<NMAX, LPR>(P, c, inst, nbc, nrows, is_dc, max_iter, tol_pu, tid, false, n_iter, nb);
   __syncthreads();
   if (st != 0) write_nan_results(P->g, P->b, inst, tid);
   if (tid == 0) {
@@ -560,9 +822,9 @@ __global__ __launch_bounds__(WAVE, (NMAX <= 24 ? 4 : NMAX <= 48 ? 3 : 2)) void r
   }
 }
 
-template <int NMAX>
-__global__ __launch_bounds__(WAVE, (NMAX <= 24 ? 4 : NMAX <= 48 ? 3 : 2)) void step_small_kernel(const DevParams* __restrict__ P, int nbc, int nrows, int max_iter,
-                                                          double tol_pu, StepArgs sa) {
+template <int NMAX, int LPR>
+__global__ __launch_bounds__(WAVE, GPF_MINW(NMAX)) void step_small_kernel(const DevParams* __restrict__ P, int nbc, int nrows,
+                                                                          int max_iter, double tol_pu, StepArgs sa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const GridDev& g = P->g;
   const Bufs& b = P->b;
@@ -570,8 +832,9 @@ __global__ __launch_bounds__(WAVE, (NMAX <= 24 ? 4 : NMAX <= 48 ? 3 : 2)) void s
   const int inst = blockIdx.x;
   const int tid = threadIdx.x;
   CarveS c;
-  carve_small<NMAX>(c, smem, g, nbc, nrows);
-  // ---- K9: chronics row -> injections ---------------------------------------------------------------------------------------
+  carve_small<NMAX, LPR>(c, smem, g, nbc, nrows);
+  GPF_STAMP(8);
+  // ---- K9: chronics row -> injections (kept in LDS for the solver, written back to the lane state in HBM) ---------------------
   {
     const int tab = b.lane_table ? b.lane_table[inst] : 0;
     const int off = b.lane_offset ? b.lane_offset[inst] : 0;
@@ -579,13 +842,17 @@ __global__ __launch_bounds__(WAVE, (NMAX <= 24 ? 4 : NMAX <= 48 ? 3 : 2)) void s
     if (row < 0) row += sa.T;
     const float* __restrict__ ch = b.chron + ((size_t)tab * sa.T + row) * g.n_chron;
     const float* __restrict__ sc = b.lane_scale ? b.lane_scale + (size_t)inst * 2 * g.n_load : nullptr;
-    double* inj = b.inj + (size_t)inst * g.n_inj;
+    double* inj_g = b.inj + (size_t)inst * g.n_inj;
+    // storage / shunt set-points are not driven by the chronics: stage the lane's current values
+    for (int i = oo.inj_sto_p + tid; i < g.n_inj; i += WAVE) c.inj[i] = inj_g[i];
     double sum_load = 0.0, sum_prod = 0.0;
     for (int i = tid; i < g.n_load; i += WAVE) {
       float lp = ch[i], lq = ch[g.n_load + i];
       if (sc) { lp *= sc[i]; lq *= sc[g.n_load + i]; }
-      inj[oo.inj_load_p + i] = (double)lp;
-      inj[oo.inj_load_q + i] = (double)lq;
+      c.inj[oo.inj_load_p + i] = (double)lp;
+      c.inj[oo.inj_load_q + i] = (double)lq;
+      inj_g[oo.inj_load_p + i] = (double)lp;
+      inj_g[oo.inj_load_q + i] = (double)lq;
       sum_load += (double)lp;
     }
     for (int i = tid; i < g.n_gen; i += WAVE)
@@ -601,8 +868,11 @@ __global__ __launch_bounds__(WAVE, (NMAX <= 24 ? 4 : NMAX <= 48 ? 3 : 2)) void s
       if (!g.gen_slack[i]) pp *= scale_p;
       const float pv_kv = ch[2 * g.n_load + g.n_gen + i];
       const float vn = (float)g.sub_vn_kv[g.gen_sub[i]];
-      inj[oo.inj_gen_p + i] = (double)pp;
-      inj[oo.inj_gen_vm + i] = (double)(pv_kv / vn);
+      const double vm_pu = (double)(pv_kv / vn);         // float32 division, as pandaPowerBackend.py:927
+      c.inj[oo.inj_gen_p + i] = (double)pp;
+      c.inj[oo.inj_gen_vm + i] = vm_pu;
+      inj_g[oo.inj_gen_p + i] = (double)pp;
+      inj_g[oo.inj_gen_vm + i] = vm_pu;
     }
     __syncthreads();
   }
@@ -623,7 +893,7 @@ __global__ __launch_bounds__(WAVE, (NMAX <= 24 ? 4 : NMAX <= 48 ? 3 : 2)) void s
     if (l < g.n_line) dround[l] = -1;
   }
   while (true) {
-    st = solve_instance_small<NMAX>(P, c, inst, nbc, nrows, 0, max_iter, tol_pu, tid, n_iter, nb);
+    st = solve_instance_small<NMAX, LPR>(P, c, inst, nbc, nrows, 0, max_iter, tol_pu, tid, true, n_iter, nb);
     __syncthreads();
     if (st != 0 || !sa.cascade) break;
     int any_disc = 0;
@@ -649,6 +919,7 @@ __global__ __launch_bounds__(WAVE, (NMAX <= 24 ? 4 : NMAX <= 48 ? 3 : 2)) void s
     if (rounds >= sa.max_rounds) break;
     ++rounds;
   }
+  GPF_STAMP(9);
   if (st != 0) write_nan_results(g, b, inst, tid);
   __syncthreads();
   for (int l = tid; l < g.n_line; l += WAVE) {

@@ -1,0 +1,45 @@
+#!/usr/bin/env python
+"""Developer tool: per-phase cycle counts of the small-grid step kernel (needs a -DGPF_TIMING build of the library).
+
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DGPF_TIMING grid2op_amd/csrc/gridpf_capi.hip -o /tmp/libgridpf_timing.so
+    GRIDPF_LIB=/tmp/libgridpf_timing.so python tools/phase_timing.py [batch]
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from grid2op_amd.grid_model import GridModel  # noqa: E402
+from grid2op_amd.engine import PowerFlowEngine  # noqa: E402
+from grid2op_amd import _capi  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+env = sys.argv[2] if len(sys.argv) > 2 else "l2rpn_case14_sandbox"
+gold = os.path.join(ROOT, "tests", "golden")
+m = GridModel.load_npz(os.path.join(gold, f"{env}.grid.npz"))
+ch = dict(np.load(os.path.join(gold, f"{env}.chronics.npz")))
+eng = PowerFlowEngine(m, n_lanes=B)
+eng.upload_chronics(eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"]))
+eng.set_lane_chronics(lane_offset=(7 * np.arange(B)) % ch["load_p"].shape[0])
+for t in range(5):
+    eng.step(t, rebalance=1.02)
+eng.sync()
+L = _capi.lib()
+buf = np.zeros((B, 32))
+L.gpf_debug_read_work.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int64]
+assert L.gpf_debug_read_work(eng._h, buf.ctypes.data_as(C.POINTER(C.c_double)), buf.size) == 0
+names = {8: "kernel start", 0: "K9 chronics gather done / solve start", 1: "K1 topology", 2: "bus types+numbering", 3: "connectivity",
+         4: "Ybus + B' assembly", 5: "DC solve", 10: "NR it1: sincos", 11: "NR it1: assembly+check (up to reload it2..)",
+         12: "NR it2: reload+GJ", 6: "Newton loop total", 7: "results", 9: "back in step kernel"}
+order = [8, 0, 1, 2, 3, 4, 5, 6, 7, 9]
+med = np.median(buf, axis=0)
+print(f"batch {B}: median cycle counts per phase (s_memtime ticks)")
+prev = med[8]
+for k in order[1:]:
+    print(f"  {names[k]:45s} {med[k] - prev:10.0f}")
+    prev = med[k]
+print(f"  {'TOTAL':45s} {med[9] - med[8]:10.0f}")
+print("  inside Newton: sincos(it1 start..)->", med[10] - med[5], " assembly it1..reload it2:", med[11] - med[10], " GJ it2:", med[12] - med[11])
