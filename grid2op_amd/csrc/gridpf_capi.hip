@@ -15,6 +15,8 @@
 #include "../../include/gridpf.h"
 #include "gridpf_kernels.hpp"
 #include "gridpf_small.hpp"
+#include "gridpf_sparse.hpp"
+#include "gridpf_symbolic.hpp"
 
 namespace {
 
@@ -85,7 +87,19 @@ struct gpf_engine {
   // per-lane capacity bookkeeping (host): number of active buses / NR unknowns of each lane
   std::vector<int> lane_nb, lane_nj;
   int init_nb = 0, init_nj = 0;
+  bool lpr1 = false;            // GRIDPF_LPR1=1: one lane per Jacobian row for n <= 24 (experiment)
   bool force_generic = false;   // GRIDPF_FORCE_GENERIC=1: always use the generic (v1) kernels
+  // block-sparse path (kernel S)
+  gpf::Symbolic sym;
+  DevArr<int> sym_buf;
+  gpf::SymDev sym_dev{};
+  gpf::DevParamsS h_params_s{};
+  gpf::DevParamsS* d_params_s = nullptr;
+  bool params_s_valid = false;
+  bool force_sparse = false;   // GRIDPF_FORCE_SPARSE=1
+  bool dense_small_64 = false; // GRIDPF_DENSE64=1: use the dense register kernels up to n = 64 (experiment)
+  std::vector<int> lane_mb;    // max live busbars in one substation, per lane
+  int init_mb = 1;
   // device-resident kernel parameter block (kernel v2 takes ONE pointer)
   gpf::DevParams h_params{};
   gpf::DevParams* d_params = nullptr;
@@ -112,7 +126,7 @@ struct gpf_engine {
 namespace {
 
 // number of active buses and Newton unknowns of one lane (host mirror of K1's counting)
-void count_lane(const gpf_engine* e, const int* topo, const int* shunt_bus, int& nb, int& nj) {
+void count_lane(const gpf_engine* e, const int* topo, const int* shunt_bus, int& nb, int& nj, int& mb) {
   const gpf::GridDev& g = e->g;
   std::vector<unsigned char> act(g.nb_tot, 0), type(g.nb_tot, 0);
   auto mark = [&](int sub, int local) -> int {
@@ -141,6 +155,12 @@ void count_lane(const gpf_engine* e, const int* topo, const int* shunt_bus, int&
     if (type[b] == 0) nj += 2;
     else if (type[b] == 1) nj += 1;
   }
+  mb = 1;
+  for (int s = 0; s < g.n_sub; ++s) {
+    int c = 0;
+    for (int k = 0; k < g.n_busbar; ++k) c += act[s + k * g.n_sub];
+    mb = std::max(mb, c);
+  }
 }
 
 struct LaunchPlan {
@@ -148,6 +168,7 @@ struct LaunchPlan {
   bool big;
   size_t lds;
   int small_nmax;   // 0: generic LDS kernels (v1); 24/32/48/64: register-resident kernels (v2)
+  int sparse_nb;    // 0: no; 1..3: block-sparse kernel S with NB busbars per substation block
 };
 
 constexpr size_t LDS_SMALL_LIMIT = 64 * 1024;   // above this Y and J move to an HBM/L2 workspace
@@ -162,9 +183,14 @@ int plan_launch(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
   p.nbc = (nb + 1) & ~1;
   p.nJ = (nj + 1) & ~1;
   p.small_nmax = 0;
-  if (!e->force_generic && p.nJ <= 64 && p.nbc <= 64 && e->g.nb_tot <= 127) {
+  p.sparse_nb = 0;
+  int mb = 1;
+  for (int k = lane0; k < lane0 + n; ++k) mb = std::max(mb, e->lane_mb[k]);
+  // dense register-resident kernels for tiny systems (n <= 32); block-sparse kernel S beyond (3x faster at n = 56)
+  const int small_max_n = e->dense_small_64 ? 64 : 32;
+  if (!e->force_generic && !e->force_sparse && p.nJ <= small_max_n && p.nbc <= 64 && e->g.nb_tot <= 127) {
     const int nmax = p.nJ <= 24 ? 24 : p.nJ <= 32 ? 32 : p.nJ <= 48 ? 48 : 64;
-    const size_t l = nmax == 24 ? gpf::lds_bytes_small<24, 2>(e->g, p.nbc, p.nJ)
+    const size_t l = nmax == 24 ? (e->lpr1 ? gpf::lds_bytes_small<24, 1>(e->g, p.nbc, p.nJ) : gpf::lds_bytes_small<24, 2>(e->g, p.nbc, p.nJ))
                    : nmax == 32 ? gpf::lds_bytes_small<32, 2>(e->g, p.nbc, p.nJ)
                    : nmax == 48 ? gpf::lds_bytes_small<48, 1>(e->g, p.nbc, p.nJ)
                                 : gpf::lds_bytes_small<64, 1>(e->g, p.nbc, p.nJ);
@@ -173,6 +199,21 @@ int plan_launch(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
       if (e->work.n < (size_t)e->n_lanes * 32) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->n_lanes * 32)); }
 #endif
       p.small_nmax = nmax;
+      p.big = false;
+      p.lds = l;
+      return GPF_OK;
+    }
+  }
+  if (!e->force_generic && e->g.n_sub * mb <= 32000 && e->g.n_busbar <= 3) {
+    const int nbk = mb == 1 ? 1 : e->g.n_busbar;
+    const size_t l = nbk == 1 ? gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, e->sym.nslot_y)
+                   : nbk == 2 ? gpf::lds_bytes_sparse<2>(e->g, e->sym.nslot, e->sym.nslot_y)
+                              : gpf::lds_bytes_sparse<3>(e->g, e->sym.nslot, e->sym.nslot_y);
+    if (l <= LDS_HARD_LIMIT) {
+#ifdef GPF_TIMING
+      if (e->work.n < (size_t)e->n_lanes * 32) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->n_lanes * 32)); }
+#endif
+      p.sparse_nb = nbk;
       p.big = false;
       p.lds = l;
       return GPF_OK;
@@ -204,6 +245,21 @@ int upload_params(gpf_engine* e, const gpf::Bufs& b) {
     e->h_params = hp;
     HIP_TRY(hipMemcpyAsync(e->d_params, &e->h_params, sizeof(hp), hipMemcpyHostToDevice, e->stream));
     e->params_valid = true;
+  }
+  return GPF_OK;
+}
+
+int upload_params_s(gpf_engine* e, const gpf::Bufs& b) {
+  gpf::DevParamsS hp{};
+  hp.g = e->g;
+  hp.b = b;
+  hp.oo = e->oo;
+  hp.sym = e->sym_dev;
+  if (!e->d_params_s) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_params_s), sizeof(gpf::DevParamsS)));
+  if (!e->params_s_valid || std::memcmp(&hp, &e->h_params_s, sizeof(hp)) != 0) {
+    e->h_params_s = hp;
+    HIP_TRY(hipMemcpyAsync(e->d_params_s, &e->h_params_s, sizeof(hp), hipMemcpyHostToDevice, e->stream));
+    e->params_s_valid = true;
   }
   return GPF_OK;
 }
@@ -260,6 +316,12 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   {
     const char* fg = std::getenv("GRIDPF_FORCE_GENERIC");
     e->force_generic = fg && fg[0] == '1';
+    const char* fs = std::getenv("GRIDPF_FORCE_SPARSE");
+    e->force_sparse = fs && fs[0] == '1';
+    const char* d64 = std::getenv("GRIDPF_DENSE64");
+    e->dense_small_64 = d64 && d64[0] == '1';
+    const char* l1 = std::getenv("GRIDPF_LPR1");
+    e->lpr1 = l1 && l1[0] == '1';
   }
   e->n_lanes = n_lanes;
   gpf::GridDev& g = e->g;
@@ -342,9 +404,28 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
 #undef AL
   hipError_t es = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
   if (es != hipSuccess) { gpf_destroy(e); return fail(GPF_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(es)); }
-  count_lane(e, e->h_init_topo.data(), nsh ? e->h_init_shunt_bus.data() : nullptr, e->init_nb, e->init_nj);
+  count_lane(e, e->h_init_topo.data(), nsh ? e->h_init_shunt_bus.data() : nullptr, e->init_nb, e->init_nj, e->init_mb);
   e->lane_nb.assign(n_lanes, e->init_nb);
   e->lane_nj.assign(n_lanes, e->init_nj);
+  e->lane_mb.assign(n_lanes, e->init_mb);
+  {
+    // symbolic analysis of the substation graph for the block-sparse kernels (once per grid)
+    e->sym = gpf::build_symbolic(g.n_sub, nl, e->h_line_or_sub.data(), e->h_line_ex_sub.data());
+    const gpf::Symbolic& S = e->sym;
+    std::vector<int> flat;
+    auto put = [&flat](const std::vector<int>& v) { size_t off = flat.size(); flat.insert(flat.end(), v.begin(), v.end()); return off; };
+    const size_t o_perm = put(S.perm), o_sr = put(S.slot_row), o_sc = put(S.slot_col), o_lb = put(S.l_begin), o_ls = put(S.l_slot),
+                 o_lr = put(S.l_row), o_ub = put(S.u_begin), o_us = put(S.u_slot), o_uc = put(S.u_col), o_ob = put(S.op_begin),
+                 o_od = put(S.op_dst), o_ol = put(S.op_l), o_ou = put(S.op_u), o_br = put(S.br_slot);
+    hipError_t eu = e->sym_buf.upload(flat.data(), flat.size());
+    if (eu != hipSuccess) { gpf_destroy(e); return fail(GPF_E_DEVICE, std::string("upload symbolic: ") + hipGetErrorString(eu)); }
+    gpf::SymDev& D = e->sym_dev;
+    const int* base = e->sym_buf.p;
+    D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.max_l = S.max_l;
+    D.perm = base + o_perm; D.slot_row = base + o_sr; D.slot_col = base + o_sc; D.l_begin = base + o_lb; D.l_slot = base + o_ls;
+    D.l_row = base + o_lr; D.u_begin = base + o_ub; D.u_slot = base + o_us; D.u_col = base + o_uc; D.op_begin = base + o_ob;
+    D.op_dst = base + o_od; D.op_l = base + o_ol; D.op_u = base + o_ou; D.br_slot = base + o_br;
+  }
   HIP_TRY(hipMemsetAsync(e->status.p, 0xFF, B * 4 * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->overflow_count.p, 0, B * nl * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->lane_table.p, 0, B * sizeof(int), e->stream));
@@ -376,6 +457,8 @@ int gpf_destroy(gpf_handle e) {
   e->lane_scale.release(); e->thermal_limit.release(); e->rho.release(); e->line_status.release();
   e->d_init_inj.release(); e->d_init_topo.release(); e->d_init_shunt_bus.release();
   if (e->d_params) (void)hipFree(e->d_params);
+  if (e->d_params_s) (void)hipFree(e->d_params_s);
+  e->sym_buf.release();
   delete e;
   return GPF_OK;
 }
@@ -423,7 +506,7 @@ int gpf_set_topology(gpf_handle e, int32_t lane0, int32_t n, const int32_t* topo
   for (int k = 0; k < n; ++k) {
     const int* sb = nullptr;
     if (g.n_shunt) sb = shunt_bus ? shunt_bus + (size_t)k * g.n_shunt : sb_host.data() + (size_t)k * g.n_shunt;
-    count_lane(e, topo + (size_t)k * g.dim_topo, sb, e->lane_nb[lane0 + k], e->lane_nj[lane0 + k]);
+    count_lane(e, topo + (size_t)k * g.dim_topo, sb, e->lane_nb[lane0 + k], e->lane_nj[lane0 + k], e->lane_mb[lane0 + k]);
   }
   return GPF_OK;
 }
@@ -480,7 +563,7 @@ int gpf_reset_lanes(gpf_handle e, int32_t lane0, int32_t n) {
   HIP_TRY(hipMemsetAsync(e->overflow_count.p + (size_t)lane0 * g.n_line, 0, (size_t)n * g.n_line * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->status.p + (size_t)lane0 * 4, 0xFF, (size_t)n * 4 * sizeof(int), e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  for (int k = lane0; k < lane0 + n; ++k) { e->lane_nb[k] = e->init_nb; e->lane_nj[k] = e->init_nj; }
+  for (int k = lane0; k < lane0 + n; ++k) { e->lane_nb[k] = e->init_nb; e->lane_nj[k] = e->init_nj; e->lane_mb[k] = e->init_mb; }
   return GPF_OK;
 }
 
@@ -498,7 +581,7 @@ int gpf_copy_lanes(gpf_handle e, int32_t src, int32_t dst, int32_t n) {
   CP(shunt_bus_out, g.n_shunt); CP(line_status, g.n_line); CP(status, 4); CP(bus_vm, g.nb_tot); CP(bus_va, g.nb_tot);
   CP(overflow_count, g.n_line); CP(disc_round, g.n_line); CP(rho, g.n_line);
 #undef CP
-  for (int k = 0; k < n; ++k) { e->lane_nb[dst + k] = e->lane_nb[src + k]; e->lane_nj[dst + k] = e->lane_nj[src + k]; }
+  for (int k = 0; k < n; ++k) { e->lane_nb[dst + k] = e->lane_nb[src + k]; e->lane_nj[dst + k] = e->lane_nj[src + k]; e->lane_mb[dst + k] = e->lane_mb[src + k]; }
   return GPF_OK;
 }
 
@@ -512,7 +595,7 @@ int gpf_fanout_n1(gpf_handle e, int32_t src, int32_t dst0, int32_t n_out, const 
   hipLaunchKernelGGL(gpf::fanout_kernel, dim3(n_out), dim3(64), 0, e->stream, e->g, e->bufs(), src, dst0, n_out, e->tmp_lines.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(e->stream));   // out_lines may be reused by the caller
-  for (int k = 0; k < n_out; ++k) { e->lane_nb[dst0 + k] = e->lane_nb[src]; e->lane_nj[dst0 + k] = e->lane_nj[src]; }
+  for (int k = 0; k < n_out; ++k) { e->lane_nb[dst0 + k] = e->lane_nb[src]; e->lane_nj[dst0 + k] = e->lane_nj[src]; e->lane_mb[dst0 + k] = e->lane_mb[src]; }
   return GPF_OK;
 }
 
@@ -528,11 +611,24 @@ int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
   const double tol_pu = tol_mva / e->g.sn_mva;
   hipEvent_t ea = nullptr, eb = nullptr;
   if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
+  if (p.sparse_nb) { rc = upload_params_s(e, b); if (rc != GPF_OK) return rc; }
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
+#define LAUNCH_RUNPF_SPARSE(NBK)                                                                                            \
+  do {                                                                                                                      \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<NBK>),                              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                   \
+    hipLaunchKernelGGL(gpf::runpf_sparse_kernel<NBK>, dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->d_params_s, lane0,     \
+                       is_dc, max_iter, tol_pu);                                                                            \
+  } while (0)
+  if (p.sparse_nb == 1) LAUNCH_RUNPF_SPARSE(1);
+  else if (p.sparse_nb == 2) LAUNCH_RUNPF_SPARSE(2);
+  else if (p.sparse_nb == 3) LAUNCH_RUNPF_SPARSE(3);
+  else
 #define LAUNCH_RUNPF_SMALL(NM, LP)                                                                                              \
   hipLaunchKernelGGL((gpf::runpf_small_kernel<NM, LP>), dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, lane0, p.nbc,   \
                      p.nJ, is_dc, max_iter, tol_pu)
-  if (p.small_nmax == 24) LAUNCH_RUNPF_SMALL(24, 2);
+  if (p.small_nmax == 24 && e->lpr1) LAUNCH_RUNPF_SMALL(24, 1);
+  else if (p.small_nmax == 24) LAUNCH_RUNPF_SMALL(24, 2);
   else if (p.small_nmax == 32) LAUNCH_RUNPF_SMALL(32, 2);
   else if (p.small_nmax == 48) LAUNCH_RUNPF_SMALL(48, 1);
   else if (p.small_nmax == 64) LAUNCH_RUNPF_SMALL(64, 1);
@@ -622,11 +718,24 @@ int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double r
   const double tol_pu = tol_mva / e->g.sn_mva;
   hipEvent_t ea = nullptr, eb = nullptr;
   if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
+  if (p.sparse_nb) { rc = upload_params_s(e, b); if (rc != GPF_OK) return rc; }
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
+#define LAUNCH_STEP_SPARSE(NBK)                                                                                             \
+  do {                                                                                                                      \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<NBK>),                               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                   \
+    hipLaunchKernelGGL(gpf::step_sparse_kernel<NBK>, dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->d_params_s,    \
+                       max_iter, tol_pu, sa);                                                                               \
+  } while (0)
+  if (p.sparse_nb == 1) LAUNCH_STEP_SPARSE(1);
+  else if (p.sparse_nb == 2) LAUNCH_STEP_SPARSE(2);
+  else if (p.sparse_nb == 3) LAUNCH_STEP_SPARSE(3);
+  else
 #define LAUNCH_STEP_SMALL(NM, LP)                                                                                               \
   hipLaunchKernelGGL((gpf::step_small_kernel<NM, LP>), dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, p.nbc,   \
                      p.nJ, max_iter, tol_pu, sa)
-  if (p.small_nmax == 24) LAUNCH_STEP_SMALL(24, 2);
+  if (p.small_nmax == 24 && e->lpr1) LAUNCH_STEP_SMALL(24, 1);
+  else if (p.small_nmax == 24) LAUNCH_STEP_SMALL(24, 2);
   else if (p.small_nmax == 32) LAUNCH_STEP_SMALL(32, 2);
   else if (p.small_nmax == 48) LAUNCH_STEP_SMALL(48, 1);
   else if (p.small_nmax == 64) LAUNCH_STEP_SMALL(64, 1);

@@ -28,6 +28,10 @@ namespace gpf {
 #define GPF_STAMP(k) do {} while (0)
 #endif
 
+#ifndef GPF_GJ_LDS_BCAST
+#define GPF_GJ_LDS_BCAST 1
+#endif
+
 #ifndef GPF_MINW
 #define GPF_MINW(NMAX) ((NMAX) <= 24 ? 4 : (NMAX) <= 32 ? 3 : 2)
 #endif
@@ -171,8 +175,14 @@ __device__ __forceinline__ bool gj_solve(double (&a)[NV], int n, int lane, doubl
                                        : ks == 1 ? group_bcast<LPR, 1>(m_own)
                                                  : ks == 2 ? group_bcast<LPR, 2>(m_own) : group_bcast<LPR, 3>(m_own));
       const bool in_prow = (row == pl / LPR);
+      if (in_prow) { used = true; mycol = k; inv_piv = rp; m = 0.0; }
+      if (LPR == 1) {
+        // one lane per row: the pivot lane is wave-uniform -> v_readlane straight into SGPR operands of the FMAs
+#pragma unroll
+        for (int idx = ki; idx < NV - 1; ++idx) a[idx] = fma(-m, readlane_f64(a[idx], pl), a[idx]);
+      } else {
+#if GPF_GJ_LDS_BCAST
       if (in_prow) {
-        used = true; mycol = k; inv_piv = rp; m = 0.0;
         // publish the live part of the pivot row (slots >= ki) for the other rows
 #pragma unroll
         for (int idx = ki & ~1; idx < NV; idx += 2) {
@@ -191,6 +201,18 @@ __device__ __forceinline__ bool gj_solve(double (&a)[NV], int n, int lane, doubl
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+#else
+      // pull the live part of the pivot row (slots >= ki) from the lane of the pivot row that holds the same
+      // column class: ds_bpermute (LDS crossbar, no LDS memory traffic, no write->read dependency)
+      const int src = ((pl / LPR) * LPR + sub) << 2;
+#pragma unroll
+      for (int idx = ki; idx < NV - 1; ++idx) {
+        const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(a[idx]));
+        const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(a[idx]));
+        a[idx] = fma(-m, __hiloint2double(hi, lo), a[idx]);
+      }
+#endif
+      }
     }
   }
   x = a[G::RHS] * inv_piv;

@@ -1,0 +1,793 @@
+// gridpf_sparse.hpp -- kernel S: block-sparse Newton-Raphson for LARGE grids (e.g. the 118-substation grids).
+//
+// One wavefront per grid instance, everything in LDS, but the linear algebra is a right-looking BLOCK-SPARSE LU on the
+// substation graph (host-side symbolic analysis: gridpf_symbolic.hpp).  A block couples the NB busbars x {theta, |V|}
+// of two substations (BS = 2*NB); rows / columns of inactive buses, reference buses and PV voltage magnitudes are
+// identity, so ONE static pattern serves every topology (bus splits, outages) of the grid.  NB = 1 is used when no
+// substation of the batch has more than one live busbar (the common case), NB = n_busbar otherwise.
+//
+// Work per factorisation is O(sum_k deg_k^2 * BS^3) (~10^4 FMA for 118 substations) instead of 2/3 n^3 = 4.6e6 for
+// the dense Jacobian, and the 0.3 MB dense matrix (which cannot live in the 160 KB LDS) shrinks to a ~25 KB block
+// array.  Assembly uses native LDS f64 atomics from branch / element lanes; the pipeline (K9, K1..K7) and the
+// arithmetic conventions are those of gridpf_kernels.hpp / gridpf_small.hpp.
+#pragma once
+#include "gridpf_small.hpp"
+
+namespace gpf {
+
+struct SymDev {
+  int n, nslot, nslot_y, max_l;
+  const int *perm, *slot_row, *slot_col;
+  const int *l_begin, *l_slot, *l_row;
+  const int *u_begin, *u_slot, *u_col;
+  const int *op_begin, *op_dst, *op_l, *op_u;
+  const int* br_slot;   // [n_line][4]
+};
+
+struct DevParamsS {
+  GridDev g;
+  Bufs b;
+  OutOff oo;
+  SymDev sym;
+};
+
+#ifdef GPF_TIMING
+#define GPF_STAMPS(k) do { if (tid == 0) P->b.work[(size_t)inst * 32 + (k)] = (double)(long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define GPF_STAMPS(k) do {} while (0)
+#endif
+
+typedef short i16;
+
+template <int NB>
+struct CarveP {
+  static constexpr int BS = 2 * NB;
+  double* A;      // [nslot][BS*BS] row-major blocks
+  double* Yb;     // [nslot_y][NB*NB][2]
+  double* rhs;    // [n_sub][BS]
+  double *vm, *va, *e, *f, *ivm, *Psp, *Qsp, *vset, *Pd, *Qd, *Gs, *Sre, *Sim;   // [nbus]
+  double* inj;    // [n_inj]
+  int *btype, *lab, *vidx;   // [nbus]
+  int* topo;      // alias of A during K1
+  i16 *lor_b, *lex_b, *gen_b, *load_b, *sto_b, *sh_b;
+  i8* sub_bb;     // [n_sub] live busbar (local id) of each substation (NB == 1)
+};
+
+template <int NB>
+__host__ __device__ inline size_t lds_bytes_sparse(const GridDev& g, int nslot, int nslot_y) {
+  constexpr int BS = 2 * NB;
+  const size_t nbus = (size_t)g.n_sub * NB;
+  size_t a_d = (size_t)nslot * BS * BS;
+  const size_t topo_d = ((size_t)g.dim_topo + 1) / 2 + 1;
+  if (a_d < topo_d) a_d = topo_d;
+  const size_t nd = a_d + (size_t)nslot_y * NB * NB * 2 + (size_t)g.n_sub * BS + 13 * nbus + (size_t)g.n_inj;
+  const size_t ni = 3 * nbus;
+  const size_t n16 = 2 * (size_t)g.n_line + g.n_gen + g.n_load + g.n_sto + g.n_shunt;
+  return nd * 8 + ni * 4 + ((n16 * 2 + g.n_sub + 15) & ~(size_t)15);
+}
+
+template <int NB>
+__device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const GridDev& g, int nslot, int nslot_y) {
+  constexpr int BS = 2 * NB;
+  const size_t nbus = (size_t)g.n_sub * NB;
+  double* d = reinterpret_cast<double*>(base);
+  size_t a_d = (size_t)nslot * BS * BS;
+  const size_t topo_d = ((size_t)g.dim_topo + 1) / 2 + 1;
+  if (a_d < topo_d) a_d = topo_d;
+  c.A = d; c.topo = reinterpret_cast<int*>(d); d += a_d;
+  c.Yb = d; d += (size_t)nslot_y * NB * NB * 2;
+  c.rhs = d; d += (size_t)g.n_sub * BS;
+  c.vm = d; d += nbus; c.va = d; d += nbus; c.e = d; d += nbus; c.f = d; d += nbus; c.ivm = d; d += nbus;
+  c.Psp = d; d += nbus; c.Qsp = d; d += nbus; c.vset = d; d += nbus; c.Pd = d; d += nbus; c.Qd = d; d += nbus;
+  c.Gs = d; d += nbus; c.Sre = d; d += nbus; c.Sim = d; d += nbus;
+  c.inj = d; d += g.n_inj;
+  int* i = reinterpret_cast<int*>(d);
+  c.btype = i; i += nbus; c.lab = i; i += nbus; c.vidx = i; i += nbus;
+  i16* q = reinterpret_cast<i16*>(i);
+  c.lor_b = q; q += g.n_line; c.lex_b = q; q += g.n_line;
+  c.gen_b = q; q += g.n_gen; c.load_b = q; q += g.n_load; c.sto_b = q; q += g.n_sto; c.sh_b = q; q += g.n_shunt;
+  c.sub_bb = reinterpret_cast<i8*>(q);
+}
+
+constexpr int BT_OFF = -1;   // inactive bus
+
+// inverse of a BS x BS block held in registers (BS = 2: closed form; BS > 2: Gauss-Jordan with partial pivoting).
+template <int BS>
+__device__ __forceinline__ bool block_inverse(const double (&D)[BS * BS], double (&Di)[BS * BS]) {
+  if (BS == 2) {
+    const double det = D[0] * D[3] - D[1] * D[2];
+    const double r = 1.0 / det;
+    Di[0] = D[3] * r; Di[1] = -D[1] * r; Di[2] = -D[2] * r; Di[3] = D[0] * r;
+    return fabs(det) > 1e-300 && fabs(det) < 1e300;
+  }
+  double M[BS][2 * BS];
+#pragma unroll
+  for (int r = 0; r < BS; ++r)
+#pragma unroll
+    for (int q = 0; q < BS; ++q) { M[r][q] = D[r * BS + q]; M[r][BS + q] = (r == q) ? 1.0 : 0.0; }
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < BS; ++k) {
+    // partial pivoting by conditional row swaps (branch-free, fully unrolled)
+#pragma unroll
+    for (int r = k + 1; r < BS; ++r) {
+      const bool sw = fabs(M[r][k]) > fabs(M[k][k]);
+#pragma unroll
+      for (int q = 0; q < 2 * BS; ++q) {
+        const double a = M[k][q], b = M[r][q];
+        M[k][q] = sw ? b : a;
+        M[r][q] = sw ? a : b;
+      }
+    }
+    const double pv = M[k][k];
+    if (!(fabs(pv) > 1e-300) || !(fabs(pv) < 1e300)) ok = false;
+    const double rp = 1.0 / pv;
+#pragma unroll
+    for (int q = 0; q < 2 * BS; ++q) M[k][q] *= rp;
+#pragma unroll
+    for (int r = 0; r < BS; ++r) {
+      if (r == k) continue;
+      const double m = M[r][k];
+#pragma unroll
+      for (int q = 0; q < 2 * BS; ++q) M[r][q] = fma(-m, M[k][q], M[r][q]);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < BS; ++r)
+#pragma unroll
+    for (int q = 0; q < BS; ++q) Di[r * BS + q] = M[r][BS + q];
+  return ok;
+}
+
+// Block-sparse LU + solve, in place in LDS.  A: blocks; rhs: [n][BS] right-hand side -> solution.
+template <int BS>
+__device__ inline bool block_lu_solve(const SymDev& S, double* __restrict__ A, double* __restrict__ rhs, int tid) {
+  constexpr int B2 = BS * BS;
+  bool ok = true;
+  const int n = S.n;
+  for (int k = 0; k < n; ++k) {
+    const int p = S.perm[k];
+    const int lb = S.l_begin[k], le = S.l_begin[k + 1];
+    const int nl = le - lb;
+    // (a) inverse of the pivot block (every lane, in registers)
+    double D[B2], Di[B2];
+    {
+      const double* Ad = A + (size_t)p * B2;    // diag slot of substation p is slot p
+#pragma unroll
+      for (int q = 0; q < B2; ++q) D[q] = Ad[q];
+    }
+    if (!block_inverse<BS>(D, Di)) ok = false;
+    // (b) scale the pivot block row: U'_pj = Di * A_pj, b'_p = Di * b_p.  Items (e, r, q) of one block read the
+    //     whole block column q, so each 64-item chunk (a whole number of blocks) is read, then written.
+    const int items_b = nl * B2 + BS;
+    for (int base = 0; base < items_b; base += WAVE) {
+      const int it = base + tid;
+      double acc = 0.0;
+      if (it < nl * B2) {
+        const int e = it / B2, r = (it % B2) / BS, q = it % BS;
+        const double* Au = A + (size_t)S.u_slot[lb + e] * B2;
+#pragma unroll
+        for (int m = 0; m < BS; ++m) acc = fma(Di[r * BS + m], Au[m * BS + q], acc);
+      } else if (it < items_b) {
+        const int r = it - nl * B2;
+        const double* bp = rhs + (size_t)p * BS;
+#pragma unroll
+        for (int m = 0; m < BS; ++m) acc = fma(Di[r * BS + m], bp[m], acc);
+      }
+      __syncthreads();    // all reads of this chunk are done
+      if (it < nl * B2) A[(size_t)S.u_slot[lb + it / B2] * B2 + (it % B2)] = acc;
+      else if (it < items_b) rhs[(size_t)p * BS + (it - nl * B2)] = acc;
+      __syncthreads();
+    }
+    // (c) trailing update A_ij -= A_ip * U'_pj and b_i -= A_ip * b'_p
+    const int ob = S.op_begin[k], oe = S.op_begin[k + 1];
+    const int items_c = (oe - ob) * B2;
+    for (int it = tid; it < items_c; it += WAVE) {
+      const int o = ob + it / B2, r = (it % B2) / BS, q = it % BS;
+      const double* Al = A + (size_t)S.op_l[o] * B2;
+      const double* Au = A + (size_t)S.op_u[o] * B2;
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < BS; ++m) acc = fma(Al[r * BS + m], Au[m * BS + q], acc);
+      A[(size_t)S.op_dst[o] * B2 + r * BS + q] -= acc;
+    }
+    for (int it = tid; it < nl * BS; it += WAVE) {
+      const int e = it / BS, r = it % BS;
+      const double* Al = A + (size_t)S.l_slot[lb + e] * B2;
+      const double* bp = rhs + (size_t)p * BS;
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < BS; ++m) acc = fma(Al[r * BS + m], bp[m], acc);
+      rhs[(size_t)S.l_row[lb + e] * BS + r] -= acc;
+    }
+    __syncthreads();
+  }
+  // back substitution: x_p = b'_p - sum_j U'_pj x_j
+  for (int k = n - 1; k >= 0; --k) {
+    const int p = S.perm[k];
+    const int ub = S.u_begin[k], ue = S.u_begin[k + 1];
+    if (tid < BS) {
+      double acc = rhs[(size_t)p * BS + tid];
+      for (int e = ub; e < ue; ++e) {
+        const double* Au = A + (size_t)S.u_slot[e] * B2 + tid * BS;
+        const double* xj = rhs + (size_t)S.u_col[e] * BS;
+#pragma unroll
+        for (int m = 0; m < BS; ++m) acc = fma(-Au[m], xj[m], acc);
+      }
+      rhs[(size_t)p * BS + tid] = acc;
+    }
+    __syncthreads();
+  }
+  return ok;
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int NB>
+__device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, CarveP<NB>& c, int inst, int is_dc, int max_iter,
+                                            double tol_pu, int tid, bool inj_staged, int& n_iter_out, int& nb_out) {
+  constexpr int BS = 2 * NB;
+  constexpr int B2 = BS * BS;
+  const GridDev& g = P->g;
+  const Bufs& b = P->b;
+  const OutOff& oo = P->oo;
+  const SymDev& S = P->sym;
+  const int nsub = g.n_sub;
+  const int nbus = nsub * NB;
+  const int* __restrict__ topo_g = b.topo + (size_t)inst * g.dim_topo;
+  const int* __restrict__ shb = b.shunt_bus + (size_t)inst * g.n_shunt;
+  unsigned char* lstat = b.line_status + (size_t)inst * g.n_line;
+  n_iter_out = 0;
+  nb_out = 0;
+  GPF_STAMPS(0);
+  if (!inj_staged) {
+    const double* __restrict__ inj_g = b.inj + (size_t)inst * g.n_inj;
+    for (int i = tid; i < g.n_inj; i += WAVE) c.inj[i] = inj_g[i];
+  }
+  const double* __restrict__ inj = c.inj;
+  const double sn = g.sn_mva, inv_sn = 1.0 / sn;
+
+  // ---- K1: element -> bus, bus activity / types / injections with LDS atomics from the element lanes ---------------------
+  for (int i = tid; i < g.dim_topo; i += WAVE) c.topo[i] = topo_g[i];
+  for (int i = tid; i < nbus; i += WAVE) {
+    c.btype[i] = BT_OFF; c.vidx[i] = -1; c.lab[i] = 0;
+    c.Psp[i] = 0.0; c.Pd[i] = 0.0; c.Qd[i] = 0.0; c.Gs[i] = 0.0;
+  }
+  if (NB == 1) for (int i = tid; i < nsub; i += WAVE) c.sub_bb[i] = 1;
+  __syncthreads();
+  const int* topo = c.topo;
+  auto bus_of = [&](int sub, int local) -> int { return (NB == 1) ? sub : sub * NB + (local - 1); };
+  for (int l = tid; l < g.n_line; l += WAVE) {
+    const int bo = topo[g.line_or_pos[l]], be = topo[g.line_ex_pos[l]];
+    const bool on = (bo >= 1) && (be >= 1);
+    const int so = g.line_or_sub[l], se = g.line_ex_sub[l];
+    const int fo = on ? bus_of(so, bo) : -1, fe = on ? bus_of(se, be) : -1;
+    c.lor_b[l] = (i16)fo;
+    c.lex_b[l] = (i16)fe;
+    lstat[l] = on ? 1 : 0;
+    if (on) {
+      atomicMax(&c.btype[fo], BT_PQ);
+      atomicMax(&c.btype[fe], BT_PQ);
+      if (NB == 1) { c.sub_bb[so] = (i8)bo; c.sub_bb[se] = (i8)be; }
+    }
+  }
+  for (int i = tid; i < g.n_gen; i += WAVE) {
+    const int lb = topo[g.gen_pos[i]];
+    const int sb = g.gen_sub[i];
+    const int bu = lb >= 1 ? bus_of(sb, lb) : -1;
+    c.gen_b[i] = (i16)bu;
+    if (bu >= 0) {
+      const bool sl = g.gen_slack[i] != 0;
+      atomicMax(&c.btype[bu], sl ? BT_REF : BT_PV);
+      if (!sl) atomicAdd(&c.Psp[bu], inj[oo.inj_gen_p + i] * inv_sn);
+      atomicMax(&c.vidx[bu], i);
+      if (NB == 1) c.sub_bb[sb] = (i8)lb;
+    }
+  }
+  for (int i = tid; i < g.n_load; i += WAVE) {
+    const int lb = topo[g.load_pos[i]];
+    const int sb = g.load_sub[i];
+    const int bu = lb >= 1 ? bus_of(sb, lb) : -1;
+    c.load_b[i] = (i16)bu;
+    if (bu >= 0) {
+      atomicMax(&c.btype[bu], BT_PQ);
+      atomicAdd(&c.Pd[bu], inj[oo.inj_load_p + i]);
+      atomicAdd(&c.Qd[bu], inj[oo.inj_load_q + i]);
+      if (NB == 1) c.sub_bb[sb] = (i8)lb;
+    }
+  }
+  for (int i = tid; i < g.n_sto; i += WAVE) {
+    const int lb = topo[g.sto_pos[i]];
+    const int sb = g.sto_sub[i];
+    const int bu = lb >= 1 ? bus_of(sb, lb) : -1;
+    c.sto_b[i] = (i16)bu;
+    if (bu >= 0) {
+      atomicMax(&c.btype[bu], BT_PQ);
+      atomicAdd(&c.Pd[bu], inj[oo.inj_sto_p + i]);
+      atomicAdd(&c.Qd[bu], inj[oo.inj_sto_q + i]);
+      if (NB == 1) c.sub_bb[sb] = (i8)lb;
+    }
+  }
+  for (int i = tid; i < g.n_shunt; i += WAVE) {
+    const int lb = shb[i];
+    const int sb = g.shunt_sub[i];
+    const int bu = lb >= 1 ? bus_of(sb, lb) : -1;
+    c.sh_b[i] = (i16)bu;
+    if (bu >= 0) {
+      atomicMax(&c.btype[bu], BT_PQ);
+      atomicAdd(&c.Gs[bu], inj[oo.inj_sh_p + i] * g.shunt_fact[i] * inv_sn);
+      if (NB == 1) c.sub_bb[sb] = (i8)lb;
+    }
+  }
+  __syncthreads();
+  int nb = 0, nref = 0;
+  for (int i0 = 0; i0 < nbus; i0 += WAVE) {
+    const int i = i0 + tid;
+    const int bt = i < nbus ? c.btype[i] : BT_OFF;
+    if (i < nbus) {
+      const int vi = c.vidx[i];
+      c.vset[i] = vi >= 0 ? inj[oo.inj_gen_vm + vi] : 1.0;
+      const double pg = c.Psp[i];
+      c.Psp[i] = pg - c.Pd[i] * inv_sn;
+      c.Qsp[i] = -c.Qd[i] * inv_sn;
+      c.lab[i] = (bt == BT_REF) ? 1 : 0;
+    }
+    nb += __popcll(__ballot(bt != BT_OFF));
+    nref += __popcll(__ballot(bt == BT_REF));
+  }
+  nb_out = nb;
+  __syncthreads();
+  if (nref == 0) return 3;
+  GPF_STAMPS(1);
+
+  // ---- connectivity ----------------------------------------------------------------------------------------------------
+  for (int sweep = 0; sweep < nb; ++sweep) {
+    int changed = 0;
+    for (int l = tid; l < g.n_line; l += WAVE) {
+      const int f = c.lor_b[l], t = c.lex_b[l];
+      if (f >= 0) {
+        const int lf = c.lab[f], lt = c.lab[t];
+        if (lf != lt) { c.lab[f] = 1; c.lab[t] = 1; changed = 1; }
+      }
+    }
+    __syncthreads();
+    if (!__any(changed)) break;
+  }
+  {
+    int bad = 0;
+    for (int i = tid; i < nbus; i += WAVE) bad |= (c.btype[i] != BT_OFF && c.lab[i] == 0);
+    if (__any(bad)) return 2;
+  }
+  GPF_STAMPS(2);
+
+  // ---- K2: block Ybus (original pattern) + K3: DC matrix in the block array, both with LDS atomics ----------------------------
+  for (int i = tid; i < S.nslot_y * NB * NB * 2; i += WAVE) c.Yb[i] = 0.0;
+  for (int i = tid; i < S.nslot * B2; i += WAVE) c.A[i] = 0.0;
+  __syncthreads();
+  auto lidx = [&](int bus) -> int { return (NB == 1) ? 0 : bus % NB; };
+  for (int l = tid; l < g.n_line; l += WAVE) {
+    const int f = c.lor_b[l], t = c.lex_b[l];
+    if (f < 0) continue;
+    const int bi = lidx(f), bj = lidx(t);
+    const int sff = S.br_slot[4 * l + 0], sft = S.br_slot[4 * l + 1], stf = S.br_slot[4 * l + 2], stt = S.br_slot[4 * l + 3];
+    if (!is_dc) {
+      const double4* y4 = reinterpret_cast<const double4*>(g.br_y + (size_t)8 * l);
+      const double4 ya = y4[0], yb = y4[1];
+      double* y;
+      y = c.Yb + ((size_t)sff * NB * NB + bi * NB + bi) * 2; atomicAdd(&y[0], ya.x); atomicAdd(&y[1], ya.y);
+      y = c.Yb + ((size_t)sft * NB * NB + bi * NB + bj) * 2; atomicAdd(&y[0], ya.z); atomicAdd(&y[1], ya.w);
+      y = c.Yb + ((size_t)stf * NB * NB + bj * NB + bi) * 2; atomicAdd(&y[0], yb.x); atomicAdd(&y[1], yb.y);
+      y = c.Yb + ((size_t)stt * NB * NB + bj * NB + bj) * 2; atomicAdd(&y[0], yb.z); atomicAdd(&y[1], yb.w);
+    }
+    if (f != t) {
+      const double bb = g.br_bdc[l];
+      const bool ff_ = c.btype[f] != BT_REF, tf_ = c.btype[t] != BT_REF;     // theta row / column live?
+      const int rf = 2 * bi, rt = 2 * bj;
+      if (ff_) atomicAdd(&c.A[(size_t)sff * B2 + rf * BS + rf], bb);
+      if (tf_) atomicAdd(&c.A[(size_t)stt * B2 + rt * BS + rt], bb);
+      if (ff_ && tf_) {
+        atomicAdd(&c.A[(size_t)sft * B2 + rf * BS + rt], -bb);
+        atomicAdd(&c.A[(size_t)stf * B2 + rt * BS + rf], -bb);
+      }
+    }
+  }
+  if (!is_dc) {
+    for (int s = tid; s < g.n_shunt; s += WAVE) {
+      const int bu = c.sh_b[s];
+      if (bu >= 0) {
+        const int bi = lidx(bu);
+        const int sub = (NB == 1) ? bu : bu / NB;
+        const double fct = g.shunt_fact[s] * inv_sn;
+        double* y = c.Yb + ((size_t)sub * NB * NB + bi * NB + bi) * 2;       // diag slot of a substation == its index
+        atomicAdd(&y[0], inj[oo.inj_sh_p + s] * fct);
+        atomicAdd(&y[1], -inj[oo.inj_sh_q + s] * fct);
+      }
+    }
+  }
+  __syncthreads();
+  // identity rows (fixed variables) + DC right-hand side
+  for (int i = tid; i < nbus; i += WAVE) {
+    const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
+    const int bt = c.btype[i];
+    double* Ad = c.A + (size_t)sub * B2;
+    const bool th_live = (bt == BT_PQ || bt == BT_PV);
+    if (!th_live) Ad[(2 * bi) * BS + 2 * bi] = 1.0;
+    Ad[(2 * bi + 1) * BS + 2 * bi + 1] = 1.0;                    // |V| rows are identity in the DC system
+    c.rhs[(size_t)sub * BS + 2 * bi] = th_live ? (c.Psp[i] - c.Gs[i]) : 0.0;
+    c.rhs[(size_t)sub * BS + 2 * bi + 1] = 0.0;
+  }
+  __syncthreads();
+  GPF_STAMPS(3);
+  {
+    bool ok = block_lu_solve<BS>(S, c.A, c.rhs, tid);
+    for (int i = tid; i < nbus; i += WAVE) {
+      const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
+      const double th = c.rhs[(size_t)sub * BS + 2 * bi];
+      const int bt = c.btype[i];
+      c.va[i] = (bt == BT_PQ || bt == BT_PV) ? th : 0.0;
+      c.vm[i] = (bt == BT_PQ || bt == BT_OFF) ? 1.0 : c.vset[i];
+      if (bt != BT_OFF && !(fabs(th) < 1e300)) ok = false;
+    }
+    __syncthreads();
+    if (__any(!ok)) return 4;
+  }
+  GPF_STAMPS(4);
+
+  int status = 0, it = 0;
+  if (!is_dc) {
+    bool converged = false;
+    const int n_pairs = S.nslot_y * NB * NB;
+    while (true) {
+      for (int i = tid; i < nbus; i += WAVE) {
+        double s, co;
+        fast_sincos(c.va[i], s, co);
+        const double vmi = c.vm[i];
+        c.e[i] = vmi * co;
+        c.f[i] = vmi * s;
+        c.ivm[i] = 1.0 / vmi;
+        c.Sre[i] = 0.0;
+        c.Sim[i] = 0.0;
+      }
+      for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += WAVE) c.A[i] = 0.0;     // fill blocks start at zero
+      __syncthreads();
+      // Jacobian blocks from the Ybus blocks: T_ij = V_i conj(Y_ij V_j); S_i += T_ij (LDS atomics)
+      for (int pr = tid; pr < n_pairs; pr += WAVE) {
+        const int slot = pr / (NB * NB), bi = (pr / NB) % NB, bj = pr % NB;
+        const int si = S.slot_row[slot], sj = S.slot_col[slot];
+        const int i = si * NB + bi, j = sj * NB + bj;
+        const int bti = c.btype[i], btj = c.btype[j];
+        const double yr = c.Yb[(size_t)pr * 2], yi = c.Yb[(size_t)pr * 2 + 1];
+        const double ei = c.e[i], fi = c.f[i], ej = c.e[j], fj = c.f[j];
+        const double aa = yr * ej - yi * fj, bb = yr * fj + yi * ej;
+        const double tr_ = ei * aa + fi * bb;
+        const double ti_ = fi * aa - ei * bb;
+        const bool act = (bti != BT_OFF) && (btj != BT_OFF);
+        if (act && (yr != 0.0 || yi != 0.0)) { atomicAdd(&c.Sre[i], tr_); atomicAdd(&c.Sim[i], ti_); }
+        const bool rowP = (bti == BT_PQ || bti == BT_PV), rowQ = (bti == BT_PQ);
+        const bool colT = (btj == BT_PQ || btj == BT_PV), colV = (btj == BT_PQ);
+        const double ivmj = c.ivm[j];
+        double* Ab = c.A + (size_t)slot * B2 + (2 * bi) * BS + 2 * bj;
+        // [dP/dth dP/dV; dQ/dth dQ/dV] = [Im T, Re T/|Vj|; -Re T, Im T/|Vj|]  (diagonal S-terms are added below)
+        Ab[0] = (rowP && colT) ? ti_ : 0.0;
+        Ab[1] = (rowP && colV) ? tr_ * ivmj : 0.0;
+        Ab[BS] = (rowQ && colT) ? -tr_ : 0.0;
+        Ab[BS + 1] = (rowQ && colV) ? ti_ * ivmj : 0.0;
+      }
+      __syncthreads();
+      double fabs_mis = 0.0;
+      bool bad = false;
+      for (int i = tid; i < nbus; i += WAVE) {
+        const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
+        const int bt = c.btype[i];
+        const bool rowP = (bt == BT_PQ || bt == BT_PV), rowQ = (bt == BT_PQ);
+        double* Ad = c.A + (size_t)sub * B2 + (2 * bi) * BS + 2 * bi;
+        const double Sr = c.Sre[i], Si = c.Sim[i], ivmi = c.ivm[i];
+        // dS/dVa_ii += j S_i ; dS/dVm_ii += S_i / |V_i| ; identity on the fixed variables
+        if (rowP) Ad[0] += -Si; else Ad[0] = 1.0;
+        if (rowQ) { Ad[1] += Sr * ivmi; Ad[BS] += Sr; Ad[BS + 1] += Si * ivmi; }
+        else { Ad[BS + 1] = 1.0; if (rowP) { /* PV: dP/dV column is fixed -> 0 */ } }
+        const double mp = rowP ? (Sr - c.Psp[i]) : 0.0;
+        const double mq = rowQ ? (Si - c.Qsp[i]) : 0.0;
+        c.rhs[(size_t)sub * BS + 2 * bi] = -mp;
+        c.rhs[(size_t)sub * BS + 2 * bi + 1] = -mq;
+        const double am = fmax(fabs(mp), fabs(mq));
+        if (!(am <= 1e300)) bad = true;
+        fabs_mis = fmax(fabs_mis, am);
+      }
+      const bool any_ge = __any(!(fabs_mis < tol_pu));
+      if (__any(bad)) { status = 1; break; }
+      if (!any_ge) { converged = true; break; }
+      if (it >= max_iter) break;
+      ++it;
+      __syncthreads();
+      const bool ok = block_lu_solve<BS>(S, c.A, c.rhs, tid);
+      bool fin = true;
+      for (int i = tid; i < nbus; i += WAVE) {
+        const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
+        const int bt = c.btype[i];
+        if (bt == BT_OFF) continue;
+        double va = c.va[i], vm = c.vm[i];
+        const double dth = c.rhs[(size_t)sub * BS + 2 * bi], dv = c.rhs[(size_t)sub * BS + 2 * bi + 1];
+        if (!(fabs(dth) < 1e300) || !(fabs(dv) < 1e300)) fin = false;
+        if (bt == BT_PQ || bt == BT_PV) va += dth;
+        if (bt == BT_PQ) vm += dv;
+        if (vm < 0.0) { vm = -vm; va += 3.14159265358979323846; }
+        if (fabs(va) > 3.14159265358979323846) va = remainder(va, 6.28318530717958647692);
+        c.va[i] = va;
+        c.vm[i] = vm;
+      }
+      __syncthreads();
+      if (__any(!ok) || __any(!fin)) { status = 4; break; }
+    }
+    if (status == 0 && !converged) status = 1;
+  }
+  n_iter_out = it;
+  if (status != 0) return status;
+  GPF_STAMPS(5);
+
+  // ---- K6: results ---------------------------------------------------------------------------------------------------------
+  float* out = b.out + (size_t)inst * g.n_out;
+  const double RAD2DEG = 57.295779513082320877;
+  const double SQRT3 = 1.7320508075688772935;
+  __syncthreads();
+  if (is_dc) {
+    for (int i = tid; i < nbus; i += WAVE) { c.Sre[i] = c.Gs[i]; c.Sim[i] = 0.0; }
+    __syncthreads();
+    for (int l = tid; l < g.n_line; l += WAVE) {
+      const int f = c.lor_b[l], t = c.lex_b[l];
+      if (f < 0) continue;
+      const double fl = (c.va[f] - c.va[t]) * g.br_bdc[l];
+      atomicAdd(&c.Sre[f], fl);
+      atomicAdd(&c.Sre[t], -fl);
+    }
+    __syncthreads();
+  }
+  for (int l = tid; l < g.n_line; l += WAVE) {
+    const int f = c.lor_b[l], t = c.lex_b[l];
+    float p_or = 0.f, q_or = 0.f, v_or = 0.f, a_or = 0.f, th_or = 0.f;
+    float p_ex = 0.f, q_ex = 0.f, v_ex = 0.f, a_ex = 0.f, th_ex = 0.f;
+    if (f >= 0) {
+      const double vnf = g.sub_vn_kv[g.line_or_sub[l]], vnt = g.sub_vn_kv[g.line_ex_sub[l]];
+      const double vmf = c.vm[f], vmt = c.vm[t];
+      double pf, qf, pt, qt;
+      if (is_dc) {
+        pf = (c.va[f] - c.va[t]) * g.br_bdc[l] * sn;
+        pt = -pf; qf = 0.0; qt = 0.0;
+      } else {
+        const double4* y4 = reinterpret_cast<const double4*>(g.br_y + (size_t)8 * l);
+        const double4 ya = y4[0], yb = y4[1];
+        const double ef = c.e[f], ff = c.f[f], et = c.e[t], ft = c.f[t];
+        const double ifr = ya.x * ef - ya.y * ff + ya.z * et - ya.w * ft;
+        const double ifi = ya.x * ff + ya.y * ef + ya.z * ft + ya.w * et;
+        const double itr = yb.x * ef - yb.y * ff + yb.z * et - yb.w * ft;
+        const double iti = yb.x * ff + yb.y * ef + yb.z * ft + yb.w * et;
+        pf = (ef * ifr + ff * ifi) * sn;  qf = (ff * ifr - ef * ifi) * sn;
+        pt = (et * itr + ft * iti) * sn;  qt = (ft * itr - et * iti) * sn;
+      }
+      p_or = (float)pf; q_or = (float)qf; p_ex = (float)pt; q_ex = (float)qt;
+      a_or = (float)(sqrt(pf * pf + qf * qf) / (SQRT3 * vmf * vnf) * 1000.0);
+      a_ex = (float)(sqrt(pt * pt + qt * qt) / (SQRT3 * vmt * vnt) * 1000.0);
+      v_or = (float)(vmf * vnf); v_ex = (float)(vmt * vnt);
+      th_or = (float)(c.va[f] * RAD2DEG); th_ex = (float)(c.va[t] * RAD2DEG);
+    }
+    out[oo.p_or + l] = p_or; out[oo.q_or + l] = q_or; out[oo.v_or + l] = v_or; out[oo.a_or + l] = a_or; out[oo.th_or + l] = th_or;
+    out[oo.p_ex + l] = p_ex; out[oo.q_ex + l] = q_ex; out[oo.v_ex + l] = v_ex; out[oo.a_ex + l] = a_ex; out[oo.th_ex + l] = th_ex;
+  }
+  for (int i = tid; i < g.n_load; i += WAVE) {
+    const int bu = c.load_b[i];
+    const bool on = bu >= 0;
+    out[oo.load_p + i] = on ? (float)inj[oo.inj_load_p + i] : 0.f;
+    out[oo.load_q + i] = (on && !is_dc) ? (float)inj[oo.inj_load_q + i] : 0.f;
+    out[oo.load_v + i] = on ? (float)(c.vm[bu] * g.sub_vn_kv[g.load_sub[i]]) : 0.f;
+    out[oo.load_th + i] = on ? (float)(c.va[bu] * RAD2DEG) : 0.f;
+  }
+  for (int i = tid; i < g.n_sto; i += WAVE) {
+    const int bu = c.sto_b[i];
+    const bool on = bu >= 0;
+    out[oo.sto_p + i] = on ? (float)inj[oo.inj_sto_p + i] : 0.f;
+    out[oo.sto_q + i] = (on && !is_dc) ? (float)inj[oo.inj_sto_q + i] : 0.f;
+    out[oo.sto_v + i] = on ? (float)(c.vm[bu] * g.sub_vn_kv[g.sto_sub[i]]) : 0.f;
+    out[oo.sto_th + i] = on ? (float)(c.va[bu] * RAD2DEG) : 0.f;
+  }
+  int* sbo = b.shunt_bus_out + (size_t)inst * g.n_shunt;
+  for (int i = tid; i < g.n_shunt; i += WAVE) {
+    const int bu = c.sh_b[i];
+    const bool on = bu >= 0;
+    const double v = on ? c.vm[bu] : 0.0;
+    out[oo.sh_p + i] = on ? (float)(inj[oo.inj_sh_p + i] * g.shunt_fact[i] * v * v) : 0.f;
+    out[oo.sh_q + i] = (on && !is_dc) ? (float)(inj[oo.inj_sh_q + i] * g.shunt_fact[i] * v * v) : 0.f;
+    out[oo.sh_v + i] = on ? (float)(v * g.sub_vn_kv[g.shunt_sub[i]]) : 0.f;
+    sbo[i] = on ? shb[i] : -1;
+  }
+  // generators (pypower pfsoln): per-bus totals accumulated in LDS with atomics, then a per-generator pass
+  {
+    double* qmin_t = c.e;    // e / f / ivm are dead from here on for the bus-level accumulators? (e, f still used above only)
+    double* qmax_t = c.f;
+    double* p_oth = c.ivm;
+    int* cnt = c.lab;
+    int* nsl = c.vidx;
+    __syncthreads();
+    for (int i = tid; i < nbus; i += WAVE) { qmin_t[i] = 0.0; qmax_t[i] = 0.0; p_oth[i] = 0.0; cnt[i] = 0; nsl[i] = 0; }
+    __syncthreads();
+    // sequential over generators per bus would be the oracle's order; sums of <= a few terms: atomics are fine
+    for (int i = tid; i < g.n_gen; i += WAVE) {
+      const int bu = c.gen_b[i];
+      if (bu < 0) continue;
+      atomicAdd(&cnt[bu], 1);
+      atomicAdd(&qmin_t[bu], g.gen_min_q[i]);
+      atomicAdd(&qmax_t[bu], g.gen_max_q[i]);
+      if (g.gen_slack[i]) atomicAdd(&nsl[bu], 1); else atomicAdd(&p_oth[bu], inj[oo.inj_gen_p + i]);
+    }
+    __syncthreads();
+    for (int i = tid; i < g.n_gen; i += WAVE) {
+      const int bu = c.gen_b[i];
+      float gp = 0.f, gq = 0.f, gv = 0.f, gth = 0.f;
+      if (bu >= 0) {
+        const double qtot = c.Sim[bu] * sn + c.Qd[bu];
+        const int cn = cnt[bu];
+        const double mn = g.gen_min_q[i], mx = g.gen_max_q[i];
+        double q;
+        if (is_dc) q = 0.0;
+        else if (cn == 1) q = qtot;
+        else if (qmin_t[bu] == qmax_t[bu]) q = qtot / cn;
+        else q = mn + (qtot - qmin_t[bu]) / (qmax_t[bu] - qmin_t[bu] + 2.220446049250313e-16) * (mx - mn);
+        double p = inj[oo.inj_gen_p + i];
+        if (g.gen_slack[i]) p = (c.Sre[bu] * sn + c.Pd[bu] - p_oth[bu]) / nsl[bu];
+        gp = (float)p; gq = (float)q;
+        gv = (float)(c.vm[bu] * g.sub_vn_kv[g.gen_sub[i]]);
+        gth = (float)(c.va[bu] * RAD2DEG);
+      }
+      out[oo.gen_p + i] = gp; out[oo.gen_q + i] = gq; out[oo.gen_v + i] = gv; out[oo.gen_th + i] = gth;
+    }
+  }
+  int* to = b.topo_out + (size_t)inst * g.dim_topo;
+  for (int i = tid; i < g.dim_topo; i += WAVE) { const int v = topo_g[i]; to[i] = v >= 1 ? v : -1; }
+  __syncthreads();
+  for (int l = tid; l < g.n_line; l += WAVE) {
+    if (c.lor_b[l] < 0) { to[g.line_or_pos[l]] = -1; to[g.line_ex_pos[l]] = -1; }
+  }
+  double* bvm = b.bus_vm + (size_t)inst * g.nb_tot;
+  double* bva = b.bus_va + (size_t)inst * g.nb_tot;
+  const double nand = __builtin_nan("");
+  for (int i = tid; i < g.nb_tot; i += WAVE) {
+    const int sub = i % nsub, lb = i / nsub + 1;            // global bus = sub + (local-1)*n_sub
+    int bu;
+    if (NB == 1) bu = (c.sub_bb[sub] == lb) ? sub : -1;
+    else bu = (lb <= NB) ? sub * NB + (lb - 1) : -1;
+    const bool on = bu >= 0 && c.btype[bu] != BT_OFF;
+    bvm[i] = on ? c.vm[bu] : nand;
+    bva[i] = on ? c.va[bu] * RAD2DEG : nand;
+  }
+  GPF_STAMPS(6);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(WAVE) void runpf_sparse_kernel(const DevParamsS* __restrict__ P, int lane0, int is_dc, int max_iter,
+                                                            double tol_pu) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int inst = lane0 + blockIdx.x;
+  const int tid = threadIdx.x;
+  CarveP<NB> c;
+  carve_sparse<NB>(c, smem, P->g, P->sym.nslot, P->sym.nslot_y);
+  int n_iter, nb;
+  const int st = solve_instance_sparse<NB>(P, c, inst, is_dc, max_iter, tol_pu, tid, false, n_iter, nb);
+  __syncthreads();
+  if (st != 0) write_nan_results(P->g, P->b, inst, tid);
+  if (tid == 0) {
+    int* s = P->b.status + (size_t)inst * 4;
+    s[0] = st; s[1] = n_iter; s[2] = nb; s[3] = 0;
+  }
+}
+
+template <int NB>
+__global__ __launch_bounds__(WAVE) void step_sparse_kernel(const DevParamsS* __restrict__ P, int max_iter, double tol_pu,
+                                                           StepArgs sa) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const GridDev& g = P->g;
+  const Bufs& b = P->b;
+  const OutOff& oo = P->oo;
+  const int inst = blockIdx.x;
+  const int tid = threadIdx.x;
+  CarveP<NB> c;
+  carve_sparse<NB>(c, smem, g, P->sym.nslot, P->sym.nslot_y);
+  GPF_STAMPS(8);
+  {
+    const int tab = b.lane_table ? b.lane_table[inst] : 0;
+    const int off = b.lane_offset ? b.lane_offset[inst] : 0;
+    int row = (sa.t + off) % sa.T;
+    if (row < 0) row += sa.T;
+    const float* __restrict__ ch = b.chron + ((size_t)tab * sa.T + row) * g.n_chron;
+    const float* __restrict__ sc = b.lane_scale ? b.lane_scale + (size_t)inst * 2 * g.n_load : nullptr;
+    double* inj_g = b.inj + (size_t)inst * g.n_inj;
+    for (int i = oo.inj_sto_p + tid; i < g.n_inj; i += WAVE) c.inj[i] = inj_g[i];
+    double sum_load = 0.0, sum_prod = 0.0;
+    for (int i = tid; i < g.n_load; i += WAVE) {
+      float lp = ch[i], lq = ch[g.n_load + i];
+      if (sc) { lp *= sc[i]; lq *= sc[g.n_load + i]; }
+      c.inj[oo.inj_load_p + i] = (double)lp;
+      c.inj[oo.inj_load_q + i] = (double)lq;
+      inj_g[oo.inj_load_p + i] = (double)lp;
+      inj_g[oo.inj_load_q + i] = (double)lq;
+      sum_load += (double)lp;
+    }
+    for (int i = tid; i < g.n_gen; i += WAVE)
+      if (!g.gen_slack[i]) sum_prod += (double)ch[2 * g.n_load + i];
+    float scale_p = 1.0f;
+    if (sa.rebalance_on) {
+      sum_load = wave_sum(sum_load);
+      sum_prod = wave_sum(sum_prod);
+      scale_p = (sum_prod > 0.0) ? (float)(sa.rebalance * sum_load / sum_prod) : 1.0f;
+    }
+    for (int i = tid; i < g.n_gen; i += WAVE) {
+      float pp = ch[2 * g.n_load + i];
+      if (!g.gen_slack[i]) pp *= scale_p;
+      const float pv_kv = ch[2 * g.n_load + g.n_gen + i];
+      const float vn = (float)g.sub_vn_kv[g.gen_sub[i]];
+      const double vm_pu = (double)(pv_kv / vn);
+      c.inj[oo.inj_gen_p + i] = (double)pp;
+      c.inj[oo.inj_gen_vm + i] = vm_pu;
+      inj_g[oo.inj_gen_p + i] = (double)pp;
+      inj_g[oo.inj_gen_vm + i] = vm_pu;
+    }
+    __syncthreads();
+  }
+  int n_iter = 0, nb = 0, st = 0, rounds = 0;
+  int* ovc = b.overflow_count + (size_t)inst * g.n_line;
+  int* dround = b.disc_round + (size_t)inst * g.n_line;
+  float* rho = b.rho + (size_t)inst * g.n_line;
+  float* out = b.out + (size_t)inst * g.n_out;
+  int* topo = b.topo + (size_t)inst * g.dim_topo;
+  constexpr int MAXK = 4;
+  int loc[MAXK];
+  bool inc[MAXK];
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) {
+    const int l = tid + k * WAVE;
+    loc[k] = (l < g.n_line) ? ovc[l] : 0;
+    inc[k] = false;
+    if (l < g.n_line) dround[l] = -1;
+  }
+  while (true) {
+    st = solve_instance_sparse<NB>(P, c, inst, 0, max_iter, tol_pu, tid, true, n_iter, nb);
+    __syncthreads();
+    if (st != 0 || !sa.cascade) break;
+    int any_disc = 0;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k) {
+      const int l = tid + k * WAVE;
+      if (l >= g.n_line) continue;
+      const float a = out[oo.a_or + l];
+      const float lim = b.thermal_limit[l];
+      const bool on = c.lor_b[l] >= 0;
+      bool disc = on && (a > sa.hard_overflow * lim);
+      if (on && (a > sa.soft_overflow * lim) && !inc[k]) { loc[k] += 1; inc[k] = true; }
+      if (on && loc[k] > sa.nb_ts_allowed) disc = true;
+      if (disc) {
+        topo[g.line_or_pos[l]] = -1;
+        topo[g.line_ex_pos[l]] = -1;
+        dround[l] = rounds;
+        any_disc = 1;
+      }
+    }
+    __syncthreads();
+    if (!__any(any_disc)) break;
+    if (rounds >= sa.max_rounds) break;
+    ++rounds;
+  }
+  GPF_STAMPS(9);
+  if (st != 0) write_nan_results(g, b, inst, tid);
+  __syncthreads();
+  for (int l = tid; l < g.n_line; l += WAVE) {
+    const float lim = b.thermal_limit[l];
+    const float a = out[oo.a_or + l];
+    rho[l] = a / lim;
+    if (a > sa.soft_overflow * lim) ovc[l] += 1; else ovc[l] = 0;
+  }
+  if (tid == 0) {
+    int* s = b.status + (size_t)inst * 4;
+    s[0] = st; s[1] = n_iter; s[2] = nb; s[3] = rounds;
+  }
+}
+
+}  // namespace gpf

@@ -56,7 +56,7 @@ def _compare(m, r, k, o, a_rel=5e-6):
 
 
 @pytest.mark.parametrize("name", ["rte_case5_example", "l2rpn_case14_sandbox", "educ_case14_storage", "test_case14",
-                                  "l2rpn_neurips_2020_track1"])
+                                  "l2rpn_neurips_2020_track1", "l2rpn_wcci_2022_dev", "l2rpn_idf_2023"])
 def test_stored_state_matches_oracle_and_golden(name, load_model, load_npz):
     m = load_model(name)
     eng = _engine(m, 2)
@@ -70,6 +70,8 @@ def test_stored_state_matches_oracle_and_golden(name, load_model, load_npz):
         g = load_npz(f"{name}.res.npz")
     except FileNotFoundError:
         g = {}
+    if name == "l2rpn_idf_2023":
+        g = {}          # its embedded results belong to another injection state
     if "line_p_from_mw" in g and not np.isnan(g["line_p_from_mw"]).any():   # pandapower's own numbers (golden)
         nl = m.n_powerline
         assert np.abs(r.p_or[0][:nl] - g["line_p_from_mw"]).max() < 2e-4 + 5e-6 * np.abs(g["line_p_from_mw"]).max()
@@ -81,7 +83,8 @@ def test_stored_state_matches_oracle_and_golden(name, load_model, load_npz):
 
 
 @pytest.mark.parametrize("name,n,seed", [("l2rpn_case14_sandbox", 96, 0), ("rte_case5_example", 48, 1),
-                                         ("educ_case14_storage", 48, 2), ("l2rpn_neurips_2020_track1", 24, 3)])
+                                         ("educ_case14_storage", 48, 2), ("l2rpn_neurips_2020_track1", 24, 3),
+                                         ("l2rpn_wcci_2022_dev", 16, 4)])
 def test_random_injections_and_topologies(name, n, seed, load_model):
     """Random injections, line outages, bus splits, shunt moves -- including lanes that island / diverge."""
     m = load_model(name)
