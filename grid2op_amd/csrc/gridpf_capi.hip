@@ -414,17 +414,14 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     const gpf::Symbolic& S = e->sym;
     std::vector<int> flat;
     auto put = [&flat](const std::vector<int>& v) { size_t off = flat.size(); flat.insert(flat.end(), v.begin(), v.end()); return off; };
-    const size_t o_perm = put(S.perm), o_sr = put(S.slot_row), o_sc = put(S.slot_col), o_lb = put(S.l_begin), o_ls = put(S.l_slot),
-                 o_lr = put(S.l_row), o_ub = put(S.u_begin), o_us = put(S.u_slot), o_uc = put(S.u_col), o_ob = put(S.op_begin),
-                 o_od = put(S.op_dst), o_ol = put(S.op_l), o_ou = put(S.op_u), o_br = put(S.br_slot);
+    const size_t o_sr = put(S.slot_row), o_sc = put(S.slot_col), o_br = put(S.br_slot), o_pr = put(S.prog);
     hipError_t eu = e->sym_buf.upload(flat.data(), flat.size());
     if (eu != hipSuccess) { gpf_destroy(e); return fail(GPF_E_DEVICE, std::string("upload symbolic: ") + hipGetErrorString(eu)); }
+    if (S.nslot > 65535 || g.n_sub > 32767) { gpf_destroy(e); return fail(GPF_E_CAPACITY, "grid too large for the 16-bit packed symbolic program"); }
     gpf::SymDev& D = e->sym_dev;
     const int* base = e->sym_buf.p;
-    D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.max_l = S.max_l;
-    D.perm = base + o_perm; D.slot_row = base + o_sr; D.slot_col = base + o_sc; D.l_begin = base + o_lb; D.l_slot = base + o_ls;
-    D.l_row = base + o_lr; D.u_begin = base + o_ub; D.u_slot = base + o_us; D.u_col = base + o_uc; D.op_begin = base + o_ob;
-    D.op_dst = base + o_od; D.op_l = base + o_ol; D.op_u = base + o_ou; D.br_slot = base + o_br;
+    D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off;
+    D.slot_row = base + o_sr; D.slot_col = base + o_sc; D.br_slot = base + o_br; D.prog = base + o_pr;
   }
   HIP_TRY(hipMemsetAsync(e->status.p, 0xFF, B * 4 * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->overflow_count.p, 0, B * nl * sizeof(int), e->stream));

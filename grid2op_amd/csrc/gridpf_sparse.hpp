@@ -16,12 +16,11 @@
 namespace gpf {
 
 struct SymDev {
-  int n, nslot, nslot_y, max_l;
-  const int *perm, *slot_row, *slot_col;
-  const int *l_begin, *l_slot, *l_row;
-  const int *u_begin, *u_slot, *u_col;
-  const int *op_begin, *op_dst, *op_l, *op_u;
+  int n, nslot, nslot_y, n_levels, back_off;
+  const int* slot_row;
+  const int* slot_col;
   const int* br_slot;   // [n_line][4]
+  const int* prog;      // level-scheduled program (layout: gridpf_symbolic.hpp)
 };
 
 struct DevParamsS {
@@ -139,82 +138,106 @@ __device__ __forceinline__ bool block_inverse(const double (&D)[BS * BS], double
   return ok;
 }
 
-// Block-sparse LU + solve, in place in LDS.  A: blocks; rhs: [n][BS] right-hand side -> solution.
+// Level-scheduled block-sparse LU + solve, in place in LDS.  A: [nslot][BS*BS] blocks; rhs: [n][BS] right-hand
+// side -> solution.  All pivots of a level are eliminated concurrently; trailing updates that hit the same block
+// are combined with LDS f64 atomics.
 template <int BS>
 __device__ inline bool block_lu_solve(const SymDev& S, double* __restrict__ A, double* __restrict__ rhs, int tid) {
   constexpr int B2 = BS * BS;
+  constexpr int CHB = (WAVE / B2) * B2;      // U-block items per chunk: whole blocks only
+  constexpr int CHR = (WAVE / BS) * BS;
+  const int* __restrict__ prog = S.prog;
   bool ok = true;
-  const int n = S.n;
-  for (int k = 0; k < n; ++k) {
-    const int p = S.perm[k];
-    const int lb = S.l_begin[k], le = S.l_begin[k + 1];
-    const int nl = le - lb;
-    // (a) inverse of the pivot block (every lane, in registers)
-    double D[B2], Di[B2];
-    {
-      const double* Ad = A + (size_t)p * B2;    // diag slot of substation p is slot p
+  for (int lv = 0; lv < S.n_levels; ++lv) {
+    const int* h = prog + 8 * lv;
+    const int piv_off = h[0], n_piv = h[1], b_off = h[2], n_b = h[3], c_off = h[4], n_c = h[5], r_off = h[6], n_r = h[7];
+    // (a) invert the pivot blocks in place
+    for (int q = tid; q < n_piv; q += WAVE) {
+      double* Ad = A + (size_t)prog[piv_off + q] * B2;      // diag slot of substation p is slot p
+      double D[B2], Di[B2];
 #pragma unroll
-      for (int q = 0; q < B2; ++q) D[q] = Ad[q];
+      for (int m = 0; m < B2; ++m) D[m] = Ad[m];
+      if (!block_inverse<BS>(D, Di)) ok = false;
+#pragma unroll
+      for (int m = 0; m < B2; ++m) Ad[m] = Di[m];
     }
-    if (!block_inverse<BS>(D, Di)) ok = false;
-    // (b) scale the pivot block row: U'_pj = Di * A_pj, b'_p = Di * b_p.  Items (e, r, q) of one block read the
-    //     whole block column q, so each 64-item chunk (a whole number of blocks) is read, then written.
-    const int items_b = nl * B2 + BS;
-    for (int base = 0; base < items_b; base += WAVE) {
+    __syncthreads();
+    // (b) scale the pivot block rows: U'_pj = Dinv_p * A_pj (whole blocks per chunk: read, then write)
+    for (int base = 0; base < n_b * B2; base += CHB) {
       const int it = base + tid;
+      const bool on = tid < CHB && it < n_b * B2;
       double acc = 0.0;
-      if (it < nl * B2) {
-        const int e = it / B2, r = (it % B2) / BS, q = it % BS;
-        const double* Au = A + (size_t)S.u_slot[lb + e] * B2;
+      int us = 0;
+      if (on) {
+        const unsigned w = (unsigned)prog[b_off + it / B2];
+        us = (int)(w & 0xffffu);
+        const int r = (it % B2) / BS, q = it % BS;
+        const double* Di = A + (size_t)(w >> 16) * B2 + r * BS;
+        const double* Au = A + (size_t)us * B2 + q;
 #pragma unroll
-        for (int m = 0; m < BS; ++m) acc = fma(Di[r * BS + m], Au[m * BS + q], acc);
-      } else if (it < items_b) {
-        const int r = it - nl * B2;
-        const double* bp = rhs + (size_t)p * BS;
-#pragma unroll
-        for (int m = 0; m < BS; ++m) acc = fma(Di[r * BS + m], bp[m], acc);
+        for (int m = 0; m < BS; ++m) acc = fma(Di[m], Au[m * BS], acc);
       }
-      __syncthreads();    // all reads of this chunk are done
-      if (it < nl * B2) A[(size_t)S.u_slot[lb + it / B2] * B2 + (it % B2)] = acc;
-      else if (it < items_b) rhs[(size_t)p * BS + (it - nl * B2)] = acc;
+      __syncthreads();
+      if (on) A[(size_t)us * B2 + (it % B2)] = acc;
       __syncthreads();
     }
-    // (c) trailing update A_ij -= A_ip * U'_pj and b_i -= A_ip * b'_p
-    const int ob = S.op_begin[k], oe = S.op_begin[k + 1];
-    const int items_c = (oe - ob) * B2;
-    for (int it = tid; it < items_c; it += WAVE) {
-      const int o = ob + it / B2, r = (it % B2) / BS, q = it % BS;
-      const double* Al = A + (size_t)S.op_l[o] * B2;
-      const double* Au = A + (size_t)S.op_u[o] * B2;
+    //     and the pivot right-hand sides: b'_p = Dinv_p * b_p
+    for (int base = 0; base < n_piv * BS; base += CHR) {
+      const int it = base + tid;
+      const bool on = tid < CHR && it < n_piv * BS;
+      double acc = 0.0;
+      int p = 0;
+      if (on) {
+        p = prog[piv_off + it / BS];
+        const double* Di = A + (size_t)p * B2 + (it % BS) * BS;
+        const double* bp = rhs + (size_t)p * BS;
+#pragma unroll
+        for (int m = 0; m < BS; ++m) acc = fma(Di[m], bp[m], acc);
+      }
+      __syncthreads();
+      if (on) rhs[(size_t)p * BS + (it % BS)] = acc;
+      __syncthreads();
+    }
+    // (c) trailing updates A[dst] -= A[l] * U'[u] and rhs[row] -= A[l] * b'[p] (LDS atomics: blocks / rows may collide)
+    for (int it = tid; it < n_c * B2; it += WAVE) {
+      const int o = it / B2, r = (it % B2) / BS, q = it % BS;
+      const unsigned w0 = (unsigned)prog[c_off + 2 * o];
+      const int u = prog[c_off + 2 * o + 1];
+      const double* Al = A + (size_t)(w0 >> 16) * B2 + r * BS;
+      const double* Au = A + (size_t)u * B2 + q;
       double acc = 0.0;
 #pragma unroll
-      for (int m = 0; m < BS; ++m) acc = fma(Al[r * BS + m], Au[m * BS + q], acc);
-      A[(size_t)S.op_dst[o] * B2 + r * BS + q] -= acc;
+      for (int m = 0; m < BS; ++m) acc = fma(Al[m], Au[m * BS], acc);
+      atomicAdd(&A[(size_t)(w0 & 0xffffu) * B2 + r * BS + q], -acc);
     }
-    for (int it = tid; it < nl * BS; it += WAVE) {
-      const int e = it / BS, r = it % BS;
-      const double* Al = A + (size_t)S.l_slot[lb + e] * B2;
+    for (int it = tid; it < n_r * BS; it += WAVE) {
+      const int o = it / BS, r = it % BS;
+      const unsigned w0 = (unsigned)prog[r_off + 2 * o];
+      const int p = prog[r_off + 2 * o + 1];
+      const double* Al = A + (size_t)(w0 & 0xffffu) * B2 + r * BS;
       const double* bp = rhs + (size_t)p * BS;
       double acc = 0.0;
 #pragma unroll
-      for (int m = 0; m < BS; ++m) acc = fma(Al[r * BS + m], bp[m], acc);
-      rhs[(size_t)S.l_row[lb + e] * BS + r] -= acc;
+      for (int m = 0; m < BS; ++m) acc = fma(Al[m], bp[m], acc);
+      atomicAdd(&rhs[(size_t)(w0 >> 16) * BS + r], -acc);
     }
     __syncthreads();
   }
-  // back substitution: x_p = b'_p - sum_j U'_pj x_j
-  for (int k = n - 1; k >= 0; --k) {
-    const int p = S.perm[k];
-    const int ub = S.u_begin[k], ue = S.u_begin[k + 1];
-    if (tid < BS) {
-      double acc = rhs[(size_t)p * BS + tid];
-      for (int e = ub; e < ue; ++e) {
-        const double* Au = A + (size_t)S.u_slot[e] * B2 + tid * BS;
-        const double* xj = rhs + (size_t)S.u_col[e] * BS;
+  // back substitution, levels in reverse: x_p = b'_p - sum_j U'_pj x_j  (pivots of a level are independent)
+  for (int lv = S.n_levels - 1; lv >= 0; --lv) {
+    const int tab = prog[S.back_off + 2 * lv], n_piv = prog[S.back_off + 2 * lv + 1];
+    for (int it = tid; it < n_piv * BS; it += WAVE) {
+      const int q = it / BS, r = it % BS;
+      const int p = prog[tab + 3 * q], u_off = prog[tab + 3 * q + 1], nu = prog[tab + 3 * q + 2];
+      double acc = rhs[(size_t)p * BS + r];
+      for (int e = 0; e < nu; ++e) {
+        const unsigned w = (unsigned)prog[u_off + e];
+        const double* Au = A + (size_t)(w >> 16) * B2 + r * BS;
+        const double* xj = rhs + (size_t)(w & 0xffffu) * BS;
 #pragma unroll
         for (int m = 0; m < BS; ++m) acc = fma(-Au[m], xj[m], acc);
       }
-      rhs[(size_t)p * BS + tid] = acc;
+      rhs[(size_t)p * BS + r] = acc;
     }
     __syncthreads();
   }

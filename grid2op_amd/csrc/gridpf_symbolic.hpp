@@ -3,9 +3,12 @@
 // The Newton Jacobian and the DC matrix of a grid have the sparsity of its SUBSTATION graph when they are stored
 // as dense blocks per (substation, substation) pair (block = all busbars x {theta, |V|} of the two substations):
 // bus splits, line outages, PV/PQ/reference changes only change VALUES inside blocks (rows / columns of inactive
-// or fixed variables become identity).  The symbolic factorisation -- elimination order (minimum degree), fill
-// pattern, and the list of block operations of a right-looking block LU without inter-block pivoting -- is
-// therefore computed ONCE per grid at gpf_create and shared by every lane and every topology.
+// or fixed variables become identity).  The symbolic factorisation is therefore computed ONCE per grid at
+// gpf_create and shared by every lane and every topology:
+//   * LEVEL-SCHEDULED minimum-degree ordering: each level is an independent set of low-degree substations that are
+//     eliminated concurrently (their trailing updates may hit the same block -> the device uses LDS f64 atomics);
+//   * fill pattern, block slots;
+//   * a flat int32 "program" (level headers + packed item lists) that the device streams with coalesced loads.
 //
 // (The reference's solver is sparse too: pandapower calls scipy.sparse.linalg.spsolve / KLU per Newton iteration,
 // grid2op/Backend/pandaPowerBackend.py:1081-1083.)
@@ -21,19 +24,19 @@ struct Symbolic {
   int n = 0;                       // number of substations (block rows)
   int nslot = 0;                   // blocks of L+U including fill; slots [0, nslot_y) = original pattern (diag first)
   int nslot_y = 0;
-  std::vector<int> perm;           // perm[k] = substation eliminated at step k
+  int n_levels = 0;
   std::vector<int> slot_row, slot_col;   // [nslot]
-  std::vector<int> diag_slot;      // [n] slot of (s, s)  (== s by construction)
-  // per elimination step k (pivot p = perm[k]):
-  std::vector<int> l_begin;        // [n+1] range into l_slot / l_row: blocks (i, p), i not yet eliminated
-  std::vector<int> l_slot, l_row;
-  std::vector<int> u_begin;        // [n+1] range into u_slot / u_col: blocks (p, j), j not yet eliminated
-  std::vector<int> u_slot, u_col;
-  std::vector<int> op_begin;       // [n+1] range into op_dst / op_l / op_u:  A[dst] -= A[l] * A[u]
-  std::vector<int> op_dst, op_l, op_u;
-  // branch -> slots of its four blocks (ff, ft, tf, tt) for the atomics-based assembly
-  std::vector<int> br_slot;        // [n_line][4]
-  int max_l = 0, max_ops = 0;
+  std::vector<int> br_slot;        // [n_line][4] slots of the (ff, ft, tf, tt) blocks of every branch
+  // flat program (all offsets are indices into `prog`):
+  //   prog[0 .. 8*n_levels)            level headers {piv_off, n_piv, b_off, n_b, c_off, n_c, r_off, n_r}
+  //   pivots      : substation ids
+  //   b-items     : one int per U block          (pivot_sub << 16) | u_slot        -> U' = Dinv * A
+  //   c-items     : two ints per trailing update  dst | (l_slot << 16), u_slot     -> A[dst] -= A[l] * U'[u]
+  //   r-items     : two ints per L block          l_slot | (l_row << 16), pivot_sub -> rhs[l_row] -= A[l] * b'[p]
+  //   back headers: per level {bk_off, n_piv}; per pivot {sub, u_off, n_u}; u entries (u_slot << 16) | u_col
+  std::vector<int> prog;
+  int back_off = 0;                // offset of the back-substitution level table: [n_levels]{piv_tab_off, n_piv}
+  int max_level_piv = 0;
 };
 
 inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, const int* line_ex_sub) {
@@ -44,9 +47,6 @@ inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, co
     const int a = line_or_sub[l], b = line_ex_sub[l];
     if (a != b) { adj[a].insert(b); adj[b].insert(a); }
   }
-  // slots of the original pattern: diagonal first (slot s = (s, s)), then the off-diagonal pairs
-  auto key = [n_sub](int r, int c) { return (int64_t)r * n_sub + c; };
-  std::vector<std::pair<int64_t, int>> slot_of;   // sorted lookup built at the end; use a map while building
   std::vector<std::vector<std::pair<int, int>>> row_slots(n_sub);   // row -> (col, slot)
   auto add_slot = [&](int r, int c) -> int {
     for (auto& pr : row_slots[r]) if (pr.first == c) return pr.second;
@@ -56,8 +56,7 @@ inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, co
     row_slots[r].push_back({c, s});
     return s;
   };
-  S.diag_slot.resize(n_sub);
-  for (int s = 0; s < n_sub; ++s) S.diag_slot[s] = add_slot(s, s);
+  for (int s = 0; s < n_sub; ++s) add_slot(s, s);                    // diagonal first: slot s == (s, s)
   for (int s = 0; s < n_sub; ++s)
     for (int t : adj[s]) add_slot(s, t);
   S.nslot_y = (int)S.slot_row.size();
@@ -69,47 +68,99 @@ inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, co
     S.br_slot[4 * l + 2] = add_slot(b, a);
     S.br_slot[4 * l + 3] = add_slot(b, b);
   }
-  // minimum-degree ordering with symbolic elimination on the (symmetric) substation graph
+  // ---- level-scheduled minimum-degree elimination -------------------------------------------------------------------
+  struct Level {
+    std::vector<int> piv, b_items, c_items, r_items;
+    std::vector<std::vector<int>> u_entries;   // per pivot: (u_slot << 16) | u_col
+  };
+  std::vector<Level> levels;
   std::vector<std::set<int>> g = adj;
   std::vector<char> done(n_sub, 0);
-  S.perm.reserve(n_sub);
-  S.l_begin.push_back(0);
-  S.u_begin.push_back(0);
-  S.op_begin.push_back(0);
-  for (int k = 0; k < n_sub; ++k) {
-    int best = -1;
-    size_t bd = (size_t)-1;
-    for (int s = 0; s < n_sub; ++s)
-      if (!done[s] && g[s].size() < bd) { bd = g[s].size(); best = s; }
-    const int p = best;
-    done[p] = 1;
-    S.perm.push_back(p);
-    std::vector<int> nb(g[p].begin(), g[p].end());     // remaining neighbours (sorted)
-    for (int i : nb) {
-      S.l_slot.push_back(add_slot(i, p));
-      S.l_row.push_back(i);
-      S.u_slot.push_back(add_slot(p, i));
-      S.u_col.push_back(i);
+  int remaining = n_sub;
+  while (remaining > 0) {
+    size_t mind = (size_t)-1;
+    for (int s = 0; s < n_sub; ++s) if (!done[s]) mind = std::min(mind, g[s].size());
+    // independent set of nodes of degree <= mind + 1, lowest degree first
+    std::vector<int> cand;
+    for (int s = 0; s < n_sub; ++s) if (!done[s] && g[s].size() <= mind + 1) cand.push_back(s);
+    std::stable_sort(cand.begin(), cand.end(), [&](int a, int b) { return g[a].size() < g[b].size(); });
+    std::vector<char> blocked(n_sub, 0);
+    Level L;
+    for (int s : cand) {
+      if (blocked[s]) continue;
+      L.piv.push_back(s);
+      blocked[s] = 1;
+      for (int t : g[s]) blocked[t] = 1;
     }
-    for (int i : nb)
+    // symbolic elimination of the whole level (pivots are pairwise non-adjacent, so the order inside is irrelevant)
+    for (int p : L.piv) {
+      std::vector<int> nb(g[p].begin(), g[p].end());
+      std::vector<int> ue;
       for (int j : nb) {
-        S.op_dst.push_back(add_slot(i, j));             // creates fill when (i, j) is new
-        S.op_l.push_back(add_slot(i, p));
-        S.op_u.push_back(add_slot(p, j));
+        const int us = add_slot(p, j);
+        L.b_items.push_back((p << 16) | us);
+        ue.push_back((us << 16) | j);
+        const int ls = add_slot(j, p);
+        L.r_items.push_back(ls | (j << 16));
+        L.r_items.push_back(p);
       }
-    // graph update: clique among the neighbours, remove p
-    for (int i : nb) {
-      g[i].erase(p);
-      for (int j : nb) if (i != j) g[i].insert(j);
+      L.u_entries.push_back(ue);
+      for (int i : nb)
+        for (int j : nb) {
+          const int dst = add_slot(i, j), ls = add_slot(i, p), us = add_slot(p, j);
+          L.c_items.push_back(dst | (ls << 16));
+          L.c_items.push_back(us);
+        }
     }
-    g[p].clear();
-    S.l_begin.push_back((int)S.l_slot.size());
-    S.u_begin.push_back((int)S.u_slot.size());
-    S.op_begin.push_back((int)S.op_dst.size());
-    S.max_l = std::max<int>(S.max_l, (int)nb.size());
-    S.max_ops = std::max<int>(S.max_ops, (int)(nb.size() * nb.size()));
+    for (int p : L.piv) {
+      std::vector<int> nb(g[p].begin(), g[p].end());
+      for (int i : nb) {
+        g[i].erase(p);
+        for (int j : nb) if (i != j) g[i].insert(j);
+      }
+      g[p].clear();
+      done[p] = 1;
+      --remaining;
+    }
+    S.max_level_piv = std::max<int>(S.max_level_piv, (int)L.piv.size());
+    levels.push_back(std::move(L));
   }
   S.nslot = (int)S.slot_row.size();
+  S.n_levels = (int)levels.size();
+  // ---- flatten -------------------------------------------------------------------------------------------------------
+  std::vector<int>& P = S.prog;
+  P.assign((size_t)8 * S.n_levels, 0);
+  for (int lv = 0; lv < S.n_levels; ++lv) {
+    const Level& L = levels[lv];
+    int* h = nullptr;
+    const int piv_off = (int)P.size();
+    P.insert(P.end(), L.piv.begin(), L.piv.end());
+    const int b_off = (int)P.size();
+    P.insert(P.end(), L.b_items.begin(), L.b_items.end());
+    const int c_off = (int)P.size();
+    P.insert(P.end(), L.c_items.begin(), L.c_items.end());
+    const int r_off = (int)P.size();
+    P.insert(P.end(), L.r_items.begin(), L.r_items.end());
+    h = P.data() + (size_t)8 * lv;
+    h[0] = piv_off; h[1] = (int)L.piv.size(); h[2] = b_off; h[3] = (int)L.b_items.size();
+    h[4] = c_off; h[5] = (int)L.c_items.size() / 2; h[6] = r_off; h[7] = (int)L.r_items.size() / 2;
+  }
+  S.back_off = (int)P.size();
+  P.resize(P.size() + (size_t)2 * S.n_levels, 0);
+  for (int lv = 0; lv < S.n_levels; ++lv) {
+    const Level& L = levels[lv];
+    const int tab_off = (int)P.size();
+    P.resize(P.size() + (size_t)3 * L.piv.size(), 0);
+    for (size_t q = 0; q < L.piv.size(); ++q) {
+      const int u_off = (int)P.size();
+      P.insert(P.end(), L.u_entries[q].begin(), L.u_entries[q].end());
+      P[tab_off + 3 * q + 0] = L.piv[q];
+      P[tab_off + 3 * q + 1] = u_off;
+      P[tab_off + 3 * q + 2] = (int)L.u_entries[q].size();
+    }
+    P[S.back_off + 2 * lv + 0] = tab_off;
+    P[S.back_off + 2 * lv + 1] = (int)L.piv.size();
+  }
   return S;
 }
 
