@@ -98,6 +98,7 @@ struct gpf_engine {
   bool params_s_valid = false;
   bool force_sparse = false;   // GRIDPF_FORCE_SPARSE=1
   bool dense_small_64 = false; // GRIDPF_DENSE64=1: use the dense register kernels up to n = 64 (experiment)
+  bool dense_small = false;    // GRIDPF_DENSE=1: dense register-resident kernels (gridpf_small.hpp) for n <= 32
   std::vector<int> lane_mb;    // max live busbars in one substation, per lane
   int init_mb = 1;
   // device-resident kernel parameter block (kernel v2 takes ONE pointer)
@@ -169,6 +170,7 @@ struct LaunchPlan {
   size_t lds;
   int small_nmax;   // 0: generic LDS kernels (v1); 24/32/48/64: register-resident kernels (v2)
   int sparse_nb;    // 0: no; 1..3: block-sparse kernel S with NB busbars per substation block
+  bool sparse_stage; // program staged in LDS (small grids) or streamed from L2 (keeps 3 instances per CU on 118-bus grids)
 };
 
 constexpr size_t LDS_SMALL_LIMIT = 64 * 1024;   // above this Y and J move to an HBM/L2 workspace
@@ -184,11 +186,12 @@ int plan_launch(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
   p.nJ = (nj + 1) & ~1;
   p.small_nmax = 0;
   p.sparse_nb = 0;
+  p.sparse_stage = false;
   int mb = 1;
   for (int k = lane0; k < lane0 + n; ++k) mb = std::max(mb, e->lane_mb[k]);
   // dense register-resident kernels for tiny systems (n <= 32); block-sparse kernel S beyond (3x faster at n = 56)
   const int small_max_n = e->dense_small_64 ? 64 : 32;
-  if (!e->force_generic && !e->force_sparse && p.nJ <= small_max_n && p.nbc <= 64 && e->g.nb_tot <= 127) {
+  if (!e->force_generic && !e->force_sparse && e->dense_small && p.nJ <= small_max_n && p.nbc <= 64 && e->g.nb_tot <= 127) {
     const int nmax = p.nJ <= 24 ? 24 : p.nJ <= 32 ? 32 : p.nJ <= 48 ? 48 : 64;
     const size_t l = nmax == 24 ? (e->lpr1 ? gpf::lds_bytes_small<24, 1>(e->g, p.nbc, p.nJ) : gpf::lds_bytes_small<24, 2>(e->g, p.nbc, p.nJ))
                    : nmax == 32 ? gpf::lds_bytes_small<32, 2>(e->g, p.nbc, p.nJ)
@@ -206,14 +209,22 @@ int plan_launch(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
   }
   if (!e->force_generic && e->g.n_sub * mb <= 32000 && e->g.n_busbar <= 3) {
     const int nbk = mb == 1 ? 1 : e->g.n_busbar;
-    const size_t l = nbk == 1 ? gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, e->sym.nslot_y)
-                   : nbk == 2 ? gpf::lds_bytes_sparse<2>(e->g, e->sym.nslot, e->sym.nslot_y)
-                              : gpf::lds_bytes_sparse<3>(e->g, e->sym.nslot, e->sym.nslot_y);
+    const int npr = (int)e->sym.prog.size();
+    auto need = [&](int nprog) -> size_t {
+      return nbk == 1 ? gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, e->sym.nslot_y, nprog)
+           : nbk == 2 ? gpf::lds_bytes_sparse<2>(e->g, e->sym.nslot, e->sym.nslot_y, nprog)
+                      : gpf::lds_bytes_sparse<3>(e->g, e->sym.nslot, e->sym.nslot_y, nprog);
+    };
+    // stage the program in LDS only when that does not cost occupancy (instances per CU = 160 KiB / footprint)
+    const size_t l_st = need(npr), l_gl = need(0);
+    const bool stage = l_st <= LDS_HARD_LIMIT && (LDS_HARD_LIMIT / l_st == LDS_HARD_LIMIT / l_gl || LDS_HARD_LIMIT / l_st >= 8);
+    const size_t l = stage ? l_st : l_gl;
     if (l <= LDS_HARD_LIMIT) {
 #ifdef GPF_TIMING
       if (e->work.n < (size_t)e->n_lanes * 32) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->n_lanes * 32)); }
 #endif
       p.sparse_nb = nbk;
+      p.sparse_stage = stage;
       p.big = false;
       p.lds = l;
       return GPF_OK;
@@ -318,8 +329,11 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     e->force_generic = fg && fg[0] == '1';
     const char* fs = std::getenv("GRIDPF_FORCE_SPARSE");
     e->force_sparse = fs && fs[0] == '1';
+    const char* dn = std::getenv("GRIDPF_DENSE");
+    e->dense_small = dn && dn[0] == '1';
     const char* d64 = std::getenv("GRIDPF_DENSE64");
     e->dense_small_64 = d64 && d64[0] == '1';
+    if (e->dense_small_64) e->dense_small = true;
     const char* l1 = std::getenv("GRIDPF_LPR1");
     e->lpr1 = l1 && l1[0] == '1';
   }
@@ -420,7 +434,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     if (S.nslot > 65535 || g.n_sub > 32767) { gpf_destroy(e); return fail(GPF_E_CAPACITY, "grid too large for the 16-bit packed symbolic program"); }
     gpf::SymDev& D = e->sym_dev;
     const int* base = e->sym_buf.p;
-    D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off;
+    D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.n_prog = (int)S.prog.size();
     D.slot_row = base + o_sr; D.slot_col = base + o_sc; D.br_slot = base + o_br; D.prog = base + o_pr;
   }
   HIP_TRY(hipMemsetAsync(e->status.p, 0xFF, B * 4 * sizeof(int), e->stream));
@@ -610,16 +624,19 @@ int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
   if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
   if (p.sparse_nb) { rc = upload_params_s(e, b); if (rc != GPF_OK) return rc; }
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
-#define LAUNCH_RUNPF_SPARSE(NBK)                                                                                            \
+#define LAUNCH_RUNPF_SPARSE(NBK, ST)                                                                                            \
   do {                                                                                                                      \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<NBK>),                              \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<NBK, ST>),                              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                   \
-    hipLaunchKernelGGL(gpf::runpf_sparse_kernel<NBK>, dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->d_params_s, lane0,     \
+    hipLaunchKernelGGL((gpf::runpf_sparse_kernel<NBK, ST>), dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->d_params_s, lane0,     \
                        is_dc, max_iter, tol_pu);                                                                            \
   } while (0)
-  if (p.sparse_nb == 1) LAUNCH_RUNPF_SPARSE(1);
-  else if (p.sparse_nb == 2) LAUNCH_RUNPF_SPARSE(2);
-  else if (p.sparse_nb == 3) LAUNCH_RUNPF_SPARSE(3);
+  if (p.sparse_nb == 1 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(1, true);
+  else if (p.sparse_nb == 1) LAUNCH_RUNPF_SPARSE(1, false);
+  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(2, true);
+  else if (p.sparse_nb == 2) LAUNCH_RUNPF_SPARSE(2, false);
+  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(3, true);
+  else if (p.sparse_nb == 3) LAUNCH_RUNPF_SPARSE(3, false);
   else
 #define LAUNCH_RUNPF_SMALL(NM, LP)                                                                                              \
   hipLaunchKernelGGL((gpf::runpf_small_kernel<NM, LP>), dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, lane0, p.nbc,   \
@@ -717,16 +734,19 @@ int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double r
   if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
   if (p.sparse_nb) { rc = upload_params_s(e, b); if (rc != GPF_OK) return rc; }
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
-#define LAUNCH_STEP_SPARSE(NBK)                                                                                             \
+#define LAUNCH_STEP_SPARSE(NBK, ST)                                                                                             \
   do {                                                                                                                      \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<NBK>),                               \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<NBK, ST>),                               \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                   \
-    hipLaunchKernelGGL(gpf::step_sparse_kernel<NBK>, dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->d_params_s,    \
+    hipLaunchKernelGGL((gpf::step_sparse_kernel<NBK, ST>), dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->d_params_s,    \
                        max_iter, tol_pu, sa);                                                                               \
   } while (0)
-  if (p.sparse_nb == 1) LAUNCH_STEP_SPARSE(1);
-  else if (p.sparse_nb == 2) LAUNCH_STEP_SPARSE(2);
-  else if (p.sparse_nb == 3) LAUNCH_STEP_SPARSE(3);
+  if (p.sparse_nb == 1 && p.sparse_stage) LAUNCH_STEP_SPARSE(1, true);
+  else if (p.sparse_nb == 1) LAUNCH_STEP_SPARSE(1, false);
+  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_STEP_SPARSE(2, true);
+  else if (p.sparse_nb == 2) LAUNCH_STEP_SPARSE(2, false);
+  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_STEP_SPARSE(3, true);
+  else if (p.sparse_nb == 3) LAUNCH_STEP_SPARSE(3, false);
   else
 #define LAUNCH_STEP_SMALL(NM, LP)                                                                                               \
   hipLaunchKernelGGL((gpf::step_small_kernel<NM, LP>), dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, p.nbc,   \

@@ -16,7 +16,7 @@
 namespace gpf {
 
 struct SymDev {
-  int n, nslot, nslot_y, n_levels, back_off;
+  int n, nslot, nslot_y, n_levels, back_off, n_prog;
   const int* slot_row;
   const int* slot_col;
   const int* br_slot;   // [n_line][4]
@@ -50,23 +50,24 @@ struct CarveP {
   int* topo;      // alias of A during K1
   i16 *lor_b, *lex_b, *gen_b, *load_b, *sto_b, *sh_b;
   i8* sub_bb;     // [n_sub] live busbar (local id) of each substation (NB == 1)
+  int* prog;      // [n_prog] LDS copy of the level-scheduled program
 };
 
 template <int NB>
-__host__ __device__ inline size_t lds_bytes_sparse(const GridDev& g, int nslot, int nslot_y) {
+__host__ __device__ inline size_t lds_bytes_sparse(const GridDev& g, int nslot, int nslot_y, int n_prog) {
   constexpr int BS = 2 * NB;
   const size_t nbus = (size_t)g.n_sub * NB;
   size_t a_d = (size_t)nslot * BS * BS;
   const size_t topo_d = ((size_t)g.dim_topo + 1) / 2 + 1;
   if (a_d < topo_d) a_d = topo_d;
   const size_t nd = a_d + (size_t)nslot_y * NB * NB * 2 + (size_t)g.n_sub * BS + 13 * nbus + (size_t)g.n_inj;
-  const size_t ni = 3 * nbus;
+  const size_t ni = 3 * nbus + (((size_t)n_prog + 3) & ~(size_t)3);
   const size_t n16 = 2 * (size_t)g.n_line + g.n_gen + g.n_load + g.n_sto + g.n_shunt;
   return nd * 8 + ni * 4 + ((n16 * 2 + g.n_sub + 15) & ~(size_t)15);
 }
 
 template <int NB>
-__device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const GridDev& g, int nslot, int nslot_y) {
+__device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const GridDev& g, int nslot, int nslot_y, int n_prog) {
   constexpr int BS = 2 * NB;
   const size_t nbus = (size_t)g.n_sub * NB;
   double* d = reinterpret_cast<double*>(base);
@@ -81,6 +82,7 @@ __device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const Gr
   c.Gs = d; d += nbus; c.Sre = d; d += nbus; c.Sim = d; d += nbus;
   c.inj = d; d += g.n_inj;
   int* i = reinterpret_cast<int*>(d);
+  c.prog = i; i += ((size_t)n_prog + 3) & ~(size_t)3;          // 16-byte aligned: headers are read as int4
   c.btype = i; i += nbus; c.lab = i; i += nbus; c.vidx = i; i += nbus;
   i16* q = reinterpret_cast<i16*>(i);
   c.lor_b = q; q += g.n_line; c.lex_b = q; q += g.n_line;
@@ -142,11 +144,11 @@ __device__ __forceinline__ bool block_inverse(const double (&D)[BS * BS], double
 // side -> solution.  All pivots of a level are eliminated concurrently; trailing updates that hit the same block
 // are combined with LDS f64 atomics.
 template <int BS>
-__device__ inline bool block_lu_solve(const SymDev& S, double* __restrict__ A, double* __restrict__ rhs, int tid) {
+__device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ prog, double* __restrict__ A,
+                                      double* __restrict__ rhs, int tid) {
   constexpr int B2 = BS * BS;
   constexpr int CHB = (WAVE / B2) * B2;      // U-block items per chunk: whole blocks only
   constexpr int CHR = (WAVE / BS) * BS;
-  const int* __restrict__ prog = S.prog;
   bool ok = true;
   for (int lv = 0; lv < S.n_levels; ++lv) {
     const int* h = prog + 8 * lv;
@@ -162,7 +164,35 @@ __device__ inline bool block_lu_solve(const SymDev& S, double* __restrict__ A, d
       for (int m = 0; m < B2; ++m) Ad[m] = Di[m];
     }
     __syncthreads();
-    // (b) scale the pivot block rows: U'_pj = Dinv_p * A_pj (whole blocks per chunk: read, then write)
+    // (b) scale the pivot block rows and right-hand sides: U'_pj = Dinv_p * A_pj, b'_p = Dinv_p * b_p
+    //     (items of one block read a whole block column: every pass reads first, then writes)
+    if (n_b * B2 + n_piv * BS <= WAVE) {
+      const int nu = n_b * B2;
+      double acc = 0.0;
+      int dst = -1;            // >= 0: A element index; <= -2: rhs element index -(dst+2)
+      if (tid < nu) {
+        const unsigned w = (unsigned)prog[b_off + tid / B2];
+        const int us = (int)(w & 0xffffu);
+        const int r = (tid % B2) / BS, q = tid % BS;
+        const double* Di = A + (size_t)(w >> 16) * B2 + r * BS;
+        const double* Au = A + (size_t)us * B2 + q;
+#pragma unroll
+        for (int m = 0; m < BS; ++m) acc = fma(Di[m], Au[m * BS], acc);
+        dst = us * B2 + (tid % B2);
+      } else if (tid < nu + n_piv * BS) {
+        const int it = tid - nu;
+        const int p = prog[piv_off + it / BS];
+        const double* Di = A + (size_t)p * B2 + (it % BS) * BS;
+        const double* bp = rhs + (size_t)p * BS;
+#pragma unroll
+        for (int m = 0; m < BS; ++m) acc = fma(Di[m], bp[m], acc);
+        dst = -(p * BS + (it % BS)) - 2;
+      }
+      __syncthreads();
+      if (dst >= 0) A[dst] = acc;
+      else if (dst <= -2) rhs[-(dst + 2)] = acc;
+      __syncthreads();
+    } else {
     for (int base = 0; base < n_b * B2; base += CHB) {
       const int it = base + tid;
       const bool on = tid < CHB && it < n_b * B2;
@@ -181,7 +211,6 @@ __device__ inline bool block_lu_solve(const SymDev& S, double* __restrict__ A, d
       if (on) A[(size_t)us * B2 + (it % B2)] = acc;
       __syncthreads();
     }
-    //     and the pivot right-hand sides: b'_p = Dinv_p * b_p
     for (int base = 0; base < n_piv * BS; base += CHR) {
       const int it = base + tid;
       const bool on = tid < CHR && it < n_piv * BS;
@@ -197,6 +226,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, double* __restrict__ A, d
       __syncthreads();
       if (on) rhs[(size_t)p * BS + (it % BS)] = acc;
       __syncthreads();
+    }
     }
     // (c) trailing updates A[dst] -= A[l] * U'[u] and rhs[row] -= A[l] * b'[p] (LDS atomics: blocks / rows may collide)
     for (int it = tid; it < n_c * B2; it += WAVE) {
@@ -245,7 +275,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, double* __restrict__ A, d
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int NB>
+template <int NB, bool STAGE>
 __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, CarveP<NB>& c, int inst, int is_dc, int max_iter,
                                             double tol_pu, int tid, bool inj_staged, int& n_iter_out, int& nb_out) {
   constexpr int BS = 2 * NB;
@@ -441,7 +471,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
   __syncthreads();
   GPF_STAMPS(3);
   {
-    bool ok = block_lu_solve<BS>(S, c.A, c.rhs, tid);
+    bool ok = block_lu_solve<BS>(S, STAGE ? (const int*)c.prog : S.prog, c.A, c.rhs, tid);
     for (int i = tid; i < nbus; i += WAVE) {
       const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
       const double th = c.rhs[(size_t)sub * BS + 2 * bi];
@@ -522,7 +552,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       if (it >= max_iter) break;
       ++it;
       __syncthreads();
-      const bool ok = block_lu_solve<BS>(S, c.A, c.rhs, tid);
+      const bool ok = block_lu_solve<BS>(S, STAGE ? (const int*)c.prog : S.prog, c.A, c.rhs, tid);
       bool fin = true;
       for (int i = tid; i < nbus; i += WAVE) {
         const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
@@ -685,16 +715,17 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int NB>
-__global__ __launch_bounds__(WAVE) void runpf_sparse_kernel(const DevParamsS* __restrict__ P, int lane0, int is_dc, int max_iter,
+template <int NB, bool STAGE>
+__global__ __launch_bounds__(WAVE, (NB == 1 ? 4 : 2)) void runpf_sparse_kernel(const DevParamsS* __restrict__ P, int lane0, int is_dc, int max_iter,
                                                             double tol_pu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int inst = lane0 + blockIdx.x;
   const int tid = threadIdx.x;
   CarveP<NB> c;
-  carve_sparse<NB>(c, smem, P->g, P->sym.nslot, P->sym.nslot_y);
+  carve_sparse<NB>(c, smem, P->g, P->sym.nslot, P->sym.nslot_y, STAGE ? P->sym.n_prog : 0);
+  if (STAGE) for (int i = threadIdx.x; i < P->sym.n_prog; i += WAVE) c.prog[i] = P->sym.prog[i];   // visible after the first barrier
   int n_iter, nb;
-  const int st = solve_instance_sparse<NB>(P, c, inst, is_dc, max_iter, tol_pu, tid, false, n_iter, nb);
+  const int st = solve_instance_sparse<NB, STAGE>(P, c, inst, is_dc, max_iter, tol_pu, tid, false, n_iter, nb);
   __syncthreads();
   if (st != 0) write_nan_results(P->g, P->b, inst, tid);
   if (tid == 0) {
@@ -703,8 +734,8 @@ __global__ __launch_bounds__(WAVE) void runpf_sparse_kernel(const DevParamsS* __
   }
 }
 
-template <int NB>
-__global__ __launch_bounds__(WAVE) void step_sparse_kernel(const DevParamsS* __restrict__ P, int max_iter, double tol_pu,
+template <int NB, bool STAGE>
+__global__ __launch_bounds__(WAVE, (NB == 1 ? 4 : 2)) void step_sparse_kernel(const DevParamsS* __restrict__ P, int max_iter, double tol_pu,
                                                            StepArgs sa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const GridDev& g = P->g;
@@ -713,7 +744,8 @@ __global__ __launch_bounds__(WAVE) void step_sparse_kernel(const DevParamsS* __r
   const int inst = blockIdx.x;
   const int tid = threadIdx.x;
   CarveP<NB> c;
-  carve_sparse<NB>(c, smem, g, P->sym.nslot, P->sym.nslot_y);
+  carve_sparse<NB>(c, smem, g, P->sym.nslot, P->sym.nslot_y, STAGE ? P->sym.n_prog : 0);
+  if (STAGE) for (int i = threadIdx.x; i < P->sym.n_prog; i += WAVE) c.prog[i] = P->sym.prog[i];   // visible after the first barrier
   GPF_STAMPS(8);
   {
     const int tab = b.lane_table ? b.lane_table[inst] : 0;
@@ -772,7 +804,7 @@ __global__ __launch_bounds__(WAVE) void step_sparse_kernel(const DevParamsS* __r
     if (l < g.n_line) dround[l] = -1;
   }
   while (true) {
-    st = solve_instance_sparse<NB>(P, c, inst, 0, max_iter, tol_pu, tid, true, n_iter, nb);
+    st = solve_instance_sparse<NB, STAGE>(P, c, inst, 0, max_iter, tol_pu, tid, true, n_iter, nb);
     __syncthreads();
     if (st != 0 || !sa.cascade) break;
     int any_disc = 0;
