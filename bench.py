@@ -73,6 +73,38 @@ def cpu_baseline(m, ch, T, budget_s=12.0):
             "host_cpus": os.cpu_count()}
 
 
+def measured_traffic_bytes():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC run (profiles/r01_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes of this same command, KiB -> bytes, FETCH doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def run_workload(eng, steps, warmup, step_kw, sync_all):
+    t = 0
+    for _ in range(warmup):
+        eng.step(t, **step_kw)
+        t += 1
+    eng.sync()
+    eng.kernel_time()
+    eng.set_profiling(True)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.step(t, **step_kw)
+        t += 1
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    kern_ms, n_launch = eng.kernel_time()
+    eng.set_profiling(False)
+    return elapsed, kern_ms, n_launch
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +114,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="lanes per GPU")
     ap.add_argument("--cascade", action="store_true", help="enable overflow disconnections (cascade loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the 118-substation secondary workload")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -127,22 +160,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    t = 0
-    for _ in range(args.warmup):
-        eng.step(t, **step_kw)
-        t += 1
-    eng.sync()
-    eng.kernel_time()                      # drop warm-up events
-    eng.set_profiling(True)                # HIP events on the engine's own stream around every launch
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.step(t, **step_kw)
-        t += 1
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    kern_ms, n_launch = eng.kernel_time()
-    eng.set_profiling(False)
+    elapsed, kern_ms, n_launch = run_workload(eng, args.steps, args.warmup, step_kw, sync_all)
     r = eng.results()
     frac_conv = float(r.converged.mean())
     mean_iter = float(r.n_iter[r.converged].mean()) if r.converged.any() else float("nan")
@@ -178,8 +196,8 @@ def main():
                        "env": args.env, "lanes_per_gpu": B, "cascade": bool(args.cascade), "max_iter": 10,
                        "tol_mva": 1e-8, "parallelism": f"independent lanes, static shard x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "gpf::step_kernel<false>", "avg_launch_us": avg_launch_s * 1e6, "launches": int(n_launch),
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": (measured_traffic_bytes() or {}).get("hbm_bytes_per_launch"),
+                         "kernel": "gpf::step_sparse_kernel<1, true>", "avg_launch_us": avg_launch_s * 1e6, "launches": int(n_launch),
                          "algorithmic_bytes_per_step": bytes_step,
                          "note": "small dense FP64 factorisations dominate: the kernel is issue/latency bound, not HBM "
                                  "bound (SURVEY.md 8(d)); the FP64 figure below is the relevant ceiling",
@@ -192,8 +210,44 @@ def main():
             res["cpu_baseline"] = cpu_baseline(m, ch, T)
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
     eng.close()
+
+    # ---- secondary workload: the 118-substation grid of BASELINE.json configs[3] (1024 lanes per GPU) -------------------
+    sec = None
+    if not args.no_secondary and args.env == "l2rpn_case14_sandbox":
+        env2, B2 = "l2rpn_wcci_2022_dev", 1024
+        m2 = GridModel.load_npz(os.path.join(GOLD, f"{env2}.grid.npz"))
+        ch2 = dict(np.load(os.path.join(GOLD, f"{env2}.chronics.npz")))
+        if "prod_v" not in ch2:
+            ch2["prod_v"] = np.tile((m2.gen_vm0 * m2.sub_vn_kv[m2.gen_sub]).astype(np.float32), (ch2["prod_p"].shape[0], 1))
+        eng2 = PowerFlowEngine(m2, n_lanes=B2, device=local_rank)
+        tab2 = eng2.pack_chronics(ch2["load_p"], ch2["load_q"], ch2["prod_p"], ch2["prod_v"])
+        T2 = tab2.shape[0]
+        eng2.upload_chronics(tab2)
+        l0, _ = lane_range(world * B2, world, rank)
+        off2, sc2 = synthetic_lane_inputs(m2.n_load, T2, l0 + np.arange(B2))
+        eng2.set_lane_chronics(lane_offset=off2, lane_scale=sc2)
+        steps2 = max(10, args.steps // 4)
+
+        def sync2():
+            eng2.sync()
+            if dist is not None:
+                dist.barrier()
+                torch.cuda.synchronize()
+        el2, k2, n2 = run_workload(eng2, steps2, max(2, args.warmup // 4), dict(rebalance=1.02, cascade=args.cascade), sync2)
+        el2 = max_over_ranks(el2, dist, device="cuda" if dist is not None else None)
+        r2 = eng2.results()
+        if rank == 0:
+            b2 = eng2.algorithmic_bytes_per_step()
+            sec = {"workload": f"{env2} (118 substations) AC NR DoNothing env.step, batch={B2} lanes per GPU", "value": world * B2 * steps2 / el2,
+                   "unit": "env steps/sec", "ms_per_step": el2 / steps2 * 1e3, "steps": steps2,
+                   "avg_launch_us": k2 / max(n2, 1) * 1e3, "algorithmic_bytes_per_step": b2,
+                   "hbm_gbs": b2 * B2 / (k2 / max(n2, 1) * 1e-3) / 1e9 if k2 > 0 else 0.0,
+                   "frac_converged": float(r2.converged.mean()), "mean_nr_iterations": float(r2.n_iter[r2.converged].mean())}
+        eng2.close()
+    if rank == 0:
+        res["secondary"] = sec
+        print(json.dumps(res))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

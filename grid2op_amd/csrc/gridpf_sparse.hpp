@@ -788,36 +788,30 @@ __global__ __launch_bounds__(WAVE, (NB == 1 ? 4 : 2)) void step_sparse_kernel(co
     __syncthreads();
   }
   int n_iter = 0, nb = 0, st = 0, rounds = 0;
-  int* ovc = b.overflow_count + (size_t)inst * g.n_line;
+  int* ovc = b.overflow_count + (size_t)inst * g.n_line;    // env._protection_counter (persistent)
   int* dround = b.disc_round + (size_t)inst * g.n_line;
   float* rho = b.rho + (size_t)inst * g.n_line;
   float* out = b.out + (size_t)inst * g.n_out;
   int* topo = b.topo + (size_t)inst * g.dim_topo;
-  constexpr int MAXK = 4;
-  int loc[MAXK];
-  bool inc[MAXK];
-#pragma unroll
-  for (int k = 0; k < MAXK; ++k) {
-    const int l = tid + k * WAVE;
-    loc[k] = (l < g.n_line) ? ovc[l] : 0;
-    inc[k] = false;
-    if (l < g.n_line) dround[l] = -1;
-  }
+  for (int l = tid; l < g.n_line; l += WAVE) dround[l] = -1;
+  // Backend.next_grid_state keeps a LOCAL copy of the protection counters that is advanced at most once per line
+  // and per call (backend.py:1476-1520): local value = ovc + (line already counted this call ? 1 : 0); the "already
+  // counted" flag lives in bit 30 of disc_round's scratch twin (rho buffer reused as int scratch until the end).
+  int* inc_flag = reinterpret_cast<int*>(rho);
+  if (sa.cascade) for (int l = tid; l < g.n_line; l += WAVE) inc_flag[l] = 0;
   while (true) {
     st = solve_instance_sparse<NB, STAGE>(P, c, inst, 0, max_iter, tol_pu, tid, true, n_iter, nb);
     __syncthreads();
     if (st != 0 || !sa.cascade) break;
     int any_disc = 0;
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k) {
-      const int l = tid + k * WAVE;
-      if (l >= g.n_line) continue;
+    for (int l = tid; l < g.n_line; l += WAVE) {
       const float a = out[oo.a_or + l];
       const float lim = b.thermal_limit[l];
       const bool on = c.lor_b[l] >= 0;
       bool disc = on && (a > sa.hard_overflow * lim);
-      if (on && (a > sa.soft_overflow * lim) && !inc[k]) { loc[k] += 1; inc[k] = true; }
-      if (on && loc[k] > sa.nb_ts_allowed) disc = true;
+      int inc = inc_flag[l];
+      if (on && (a > sa.soft_overflow * lim) && !inc) { inc = 1; inc_flag[l] = 1; }
+      if (on && (ovc[l] + inc) > sa.nb_ts_allowed) disc = true;
       if (disc) {
         topo[g.line_or_pos[l]] = -1;
         topo[g.line_ex_pos[l]] = -1;
