@@ -126,7 +126,9 @@ def main():
         import torch  # noqa: F811  (device plumbing + RCCL barrier only)
     except Exception:
         torch = None
-    if world > 1:
+    # launched by torch.distributed.run (RANK / MASTER_ADDR set): always go through RCCL, even with one rank,
+    # so that the N>1 code path (init, barrier, max-reduce) is the one exercised on a single-GPU box too
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
         import torch.distributed as dist  # noqa: F811
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))

@@ -57,6 +57,15 @@ struct DevArr {
 
 }  // namespace
 
+struct LaunchPlan {
+  int nbc, nJ;
+  bool big;
+  size_t lds;
+  int small_nmax;   // 0: generic LDS kernels (v1); 24/32/48/64: register-resident kernels (v2)
+  int sparse_nb;    // 0: no; 1..3: block-sparse kernel S with NB busbars per substation block
+  bool sparse_stage; // program staged in LDS (small grids) or streamed from L2 (keeps 3 instances per CU on 118-bus grids)
+};
+
 struct gpf_engine {
   int device = 0;
   int n_lanes = 0;
@@ -105,6 +114,8 @@ struct gpf_engine {
   gpf::DevParams h_params{};
   gpf::DevParams* d_params = nullptr;
   bool params_valid = false;
+  bool plan_valid = false;      // cached launch plan of the whole batch (invalidated by every topology mutation)
+  LaunchPlan plan_cached{};
   // profiling
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -164,19 +175,21 @@ void count_lane(const gpf_engine* e, const int* topo, const int* shunt_bus, int&
   }
 }
 
-struct LaunchPlan {
-  int nbc, nJ;
-  bool big;
-  size_t lds;
-  int small_nmax;   // 0: generic LDS kernels (v1); 24/32/48/64: register-resident kernels (v2)
-  int sparse_nb;    // 0: no; 1..3: block-sparse kernel S with NB busbars per substation block
-  bool sparse_stage; // program staged in LDS (small grids) or streamed from L2 (keeps 3 instances per CU on 118-bus grids)
-};
 
 constexpr size_t LDS_SMALL_LIMIT = 64 * 1024;   // above this Y and J move to an HBM/L2 workspace
 constexpr size_t LDS_HARD_LIMIT = 160 * 1024;
 
+int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p);
+
 int plan_launch(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
+  const bool whole = (lane0 == 0 && n == e->n_lanes);
+  if (whole && e->plan_valid) { p = e->plan_cached; return GPF_OK; }
+  int rc = plan_launch_uncached(e, lane0, n, p);
+  if (rc == GPF_OK && whole) { e->plan_cached = p; e->plan_valid = true; }
+  return rc;
+}
+
+int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
   int nb = 1, nj = 1;
   for (int k = lane0; k < lane0 + n; ++k) {
     nb = std::max(nb, e->lane_nb[k]);
@@ -211,9 +224,10 @@ int plan_launch(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
     const int nbk = mb == 1 ? 1 : e->g.n_busbar;
     const int npr = (int)e->sym.prog.size();
     auto need = [&](int nprog) -> size_t {
-      return nbk == 1 ? gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, e->sym.nslot_y, nprog)
-           : nbk == 2 ? gpf::lds_bytes_sparse<2>(e->g, e->sym.nslot, e->sym.nslot_y, nprog)
-                      : gpf::lds_bytes_sparse<3>(e->g, e->sym.nslot, e->sym.nslot_y, nprog);
+      const bool st = nprog > 0;
+      return nbk == 1 ? gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, e->sym.nslot_y, nprog, st)
+           : nbk == 2 ? gpf::lds_bytes_sparse<2>(e->g, e->sym.nslot, e->sym.nslot_y, nprog, st)
+                      : gpf::lds_bytes_sparse<3>(e->g, e->sym.nslot, e->sym.nslot_y, nprog, st);
     };
     // stage the program in LDS only when that does not cost occupancy (instances per CU = 160 KiB / footprint)
     const size_t l_st = need(npr), l_gl = need(0);
@@ -519,6 +533,7 @@ int gpf_set_topology(gpf_handle e, int32_t lane0, int32_t n, const int32_t* topo
     if (g.n_shunt) sb = shunt_bus ? shunt_bus + (size_t)k * g.n_shunt : sb_host.data() + (size_t)k * g.n_shunt;
     count_lane(e, topo + (size_t)k * g.dim_topo, sb, e->lane_nb[lane0 + k], e->lane_nj[lane0 + k], e->lane_mb[lane0 + k]);
   }
+  e->plan_valid = false;
   return GPF_OK;
 }
 
@@ -575,6 +590,7 @@ int gpf_reset_lanes(gpf_handle e, int32_t lane0, int32_t n) {
   HIP_TRY(hipMemsetAsync(e->status.p + (size_t)lane0 * 4, 0xFF, (size_t)n * 4 * sizeof(int), e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   for (int k = lane0; k < lane0 + n; ++k) { e->lane_nb[k] = e->init_nb; e->lane_nj[k] = e->init_nj; e->lane_mb[k] = e->init_mb; }
+  e->plan_valid = false;
   return GPF_OK;
 }
 
@@ -593,6 +609,7 @@ int gpf_copy_lanes(gpf_handle e, int32_t src, int32_t dst, int32_t n) {
   CP(overflow_count, g.n_line); CP(disc_round, g.n_line); CP(rho, g.n_line);
 #undef CP
   for (int k = 0; k < n; ++k) { e->lane_nb[dst + k] = e->lane_nb[src + k]; e->lane_nj[dst + k] = e->lane_nj[src + k]; e->lane_mb[dst + k] = e->lane_mb[src + k]; }
+  e->plan_valid = false;
   return GPF_OK;
 }
 
@@ -607,6 +624,7 @@ int gpf_fanout_n1(gpf_handle e, int32_t src, int32_t dst0, int32_t n_out, const 
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(e->stream));   // out_lines may be reused by the caller
   for (int k = 0; k < n_out; ++k) { e->lane_nb[dst0 + k] = e->lane_nb[src]; e->lane_nj[dst0 + k] = e->lane_nj[src]; e->lane_mb[dst0 + k] = e->lane_mb[src]; }
+  e->plan_valid = false;
   return GPF_OK;
 }
 

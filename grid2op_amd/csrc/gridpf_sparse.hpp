@@ -44,9 +44,11 @@ struct CarveP {
   double* A;      // [nslot][BS*BS] row-major blocks
   double* Yb;     // [nslot_y][NB*NB][2]
   double* rhs;    // [n_sub][BS]
-  double *vm, *va, *e, *f, *ivm, *Psp, *Qsp, *vset, *Pd, *Qd, *Gs, *Sre, *Sim;   // [nbus]
-  double* inj;    // [n_inj]
-  int *btype, *lab, *vidx;   // [nbus]
+  double *vm, *va, *e, *f, *Psp, *Qsp, *Sre, *Sim;   // [nbus]
+  double* Gs;     // [nbus] aliases e (shunt conductance: only needed before the Newton loop and by the DC results)
+  double* inj;    // [n_inj] staged injection row (only when STAGE; otherwise the lane's row in HBM/L2 is read directly)
+  int* btype;     // [nbus]
+  int *lab, *vidx;   // [nbus] alias Sre / Sim (connectivity labels, last-generator index: dead before the Newton loop)
   int* topo;      // alias of A during K1
   i16 *lor_b, *lex_b, *gen_b, *load_b, *sto_b, *sh_b;
   i8* sub_bb;     // [n_sub] live busbar (local id) of each substation (NB == 1)
@@ -54,20 +56,21 @@ struct CarveP {
 };
 
 template <int NB>
-__host__ __device__ inline size_t lds_bytes_sparse(const GridDev& g, int nslot, int nslot_y, int n_prog) {
+__host__ __device__ inline size_t lds_bytes_sparse(const GridDev& g, int nslot, int nslot_y, int n_prog, bool stage_inj) {
   constexpr int BS = 2 * NB;
   const size_t nbus = (size_t)g.n_sub * NB;
   size_t a_d = (size_t)nslot * BS * BS;
   const size_t topo_d = ((size_t)g.dim_topo + 1) / 2 + 1;
   if (a_d < topo_d) a_d = topo_d;
-  const size_t nd = a_d + (size_t)nslot_y * NB * NB * 2 + (size_t)g.n_sub * BS + 13 * nbus + (size_t)g.n_inj;
-  const size_t ni = 3 * nbus + (((size_t)n_prog + 3) & ~(size_t)3);
+  const size_t nd = a_d + (size_t)nslot_y * NB * NB * 2 + (size_t)g.n_sub * BS + 8 * nbus + (stage_inj ? (size_t)g.n_inj : 0);
+  const size_t ni = nbus + (((size_t)n_prog + 3) & ~(size_t)3);
   const size_t n16 = 2 * (size_t)g.n_line + g.n_gen + g.n_load + g.n_sto + g.n_shunt;
   return nd * 8 + ni * 4 + ((n16 * 2 + g.n_sub + 15) & ~(size_t)15);
 }
 
 template <int NB>
-__device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const GridDev& g, int nslot, int nslot_y, int n_prog) {
+__device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const GridDev& g, int nslot, int nslot_y, int n_prog,
+                                    bool stage_inj) {
   constexpr int BS = 2 * NB;
   const size_t nbus = (size_t)g.n_sub * NB;
   double* d = reinterpret_cast<double*>(base);
@@ -77,13 +80,14 @@ __device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const Gr
   c.A = d; c.topo = reinterpret_cast<int*>(d); d += a_d;
   c.Yb = d; d += (size_t)nslot_y * NB * NB * 2;
   c.rhs = d; d += (size_t)g.n_sub * BS;
-  c.vm = d; d += nbus; c.va = d; d += nbus; c.e = d; d += nbus; c.f = d; d += nbus; c.ivm = d; d += nbus;
-  c.Psp = d; d += nbus; c.Qsp = d; d += nbus; c.vset = d; d += nbus; c.Pd = d; d += nbus; c.Qd = d; d += nbus;
-  c.Gs = d; d += nbus; c.Sre = d; d += nbus; c.Sim = d; d += nbus;
-  c.inj = d; d += g.n_inj;
+  c.vm = d; d += nbus; c.va = d; d += nbus; c.e = d; c.Gs = d; d += nbus; c.f = d; d += nbus;
+  c.Psp = d; d += nbus; c.Qsp = d; d += nbus;
+  c.Sre = d; c.lab = reinterpret_cast<int*>(d); d += nbus;
+  c.Sim = d; c.vidx = reinterpret_cast<int*>(d); d += nbus;
+  c.inj = d; if (stage_inj) d += g.n_inj;
   int* i = reinterpret_cast<int*>(d);
   c.prog = i; i += ((size_t)n_prog + 3) & ~(size_t)3;          // 16-byte aligned: headers are read as int4
-  c.btype = i; i += nbus; c.lab = i; i += nbus; c.vidx = i; i += nbus;
+  c.btype = i; i += nbus;
   i16* q = reinterpret_cast<i16*>(i);
   c.lor_b = q; q += g.n_line; c.lex_b = q; q += g.n_line;
   c.gen_b = q; q += g.n_gen; c.load_b = q; q += g.n_load; c.sto_b = q; q += g.n_sto; c.sh_b = q; q += g.n_shunt;
@@ -292,18 +296,18 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
   n_iter_out = 0;
   nb_out = 0;
   GPF_STAMPS(0);
-  if (!inj_staged) {
-    const double* __restrict__ inj_g = b.inj + (size_t)inst * g.n_inj;
+  const double* __restrict__ inj_g = b.inj + (size_t)inst * g.n_inj;
+  if (STAGE && !inj_staged) {
     for (int i = tid; i < g.n_inj; i += WAVE) c.inj[i] = inj_g[i];
   }
-  const double* __restrict__ inj = c.inj;
+  const double* __restrict__ inj = STAGE ? (const double*)c.inj : inj_g;
   const double sn = g.sn_mva, inv_sn = 1.0 / sn;
 
   // ---- K1: element -> bus, bus activity / types / injections with LDS atomics from the element lanes ---------------------
   for (int i = tid; i < g.dim_topo; i += WAVE) c.topo[i] = topo_g[i];
   for (int i = tid; i < nbus; i += WAVE) {
-    c.btype[i] = BT_OFF; c.vidx[i] = -1; c.lab[i] = 0;
-    c.Psp[i] = 0.0; c.Pd[i] = 0.0; c.Qd[i] = 0.0; c.Gs[i] = 0.0;
+    c.btype[i] = BT_OFF; c.vidx[i] = -1;
+    c.Psp[i] = 0.0; c.Qsp[i] = 0.0; c.Gs[i] = 0.0;
   }
   if (NB == 1) for (int i = tid; i < nsub; i += WAVE) c.sub_bb[i] = 1;
   __syncthreads();
@@ -343,8 +347,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     c.load_b[i] = (i16)bu;
     if (bu >= 0) {
       atomicMax(&c.btype[bu], BT_PQ);
-      atomicAdd(&c.Pd[bu], inj[oo.inj_load_p + i]);
-      atomicAdd(&c.Qd[bu], inj[oo.inj_load_q + i]);
+      atomicAdd(&c.Psp[bu], -inj[oo.inj_load_p + i] * inv_sn);
+      atomicAdd(&c.Qsp[bu], -inj[oo.inj_load_q + i] * inv_sn);
       if (NB == 1) c.sub_bb[sb] = (i8)lb;
     }
   }
@@ -355,8 +359,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     c.sto_b[i] = (i16)bu;
     if (bu >= 0) {
       atomicMax(&c.btype[bu], BT_PQ);
-      atomicAdd(&c.Pd[bu], inj[oo.inj_sto_p + i]);
-      atomicAdd(&c.Qd[bu], inj[oo.inj_sto_q + i]);
+      atomicAdd(&c.Psp[bu], -inj[oo.inj_sto_p + i] * inv_sn);
+      atomicAdd(&c.Qsp[bu], -inj[oo.inj_sto_q + i] * inv_sn);
       if (NB == 1) c.sub_bb[sb] = (i8)lb;
     }
   }
@@ -378,10 +382,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     const int bt = i < nbus ? c.btype[i] : BT_OFF;
     if (i < nbus) {
       const int vi = c.vidx[i];
-      c.vset[i] = vi >= 0 ? inj[oo.inj_gen_vm + vi] : 1.0;
-      const double pg = c.Psp[i];
-      c.Psp[i] = pg - c.Pd[i] * inv_sn;
-      c.Qsp[i] = -c.Qd[i] * inv_sn;
+      // initial |V|: set-point of the last in-service generator on PV / reference buses, 1 pu elsewhere
+      c.vm[i] = (vi >= 0 && (bt == BT_PV || bt == BT_REF)) ? inj[oo.inj_gen_vm + vi] : 1.0;
       c.lab[i] = (bt == BT_REF) ? 1 : 0;
     }
     nb += __popcll(__ballot(bt != BT_OFF));
@@ -477,7 +479,6 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       const double th = c.rhs[(size_t)sub * BS + 2 * bi];
       const int bt = c.btype[i];
       c.va[i] = (bt == BT_PQ || bt == BT_PV) ? th : 0.0;
-      c.vm[i] = (bt == BT_PQ || bt == BT_OFF) ? 1.0 : c.vset[i];
       if (bt != BT_OFF && !(fabs(th) < 1e300)) ok = false;
     }
     __syncthreads();
@@ -496,7 +497,6 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
         const double vmi = c.vm[i];
         c.e[i] = vmi * co;
         c.f[i] = vmi * s;
-        c.ivm[i] = 1.0 / vmi;
         c.Sre[i] = 0.0;
         c.Sim[i] = 0.0;
       }
@@ -517,7 +517,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
         if (act && (yr != 0.0 || yi != 0.0)) { atomicAdd(&c.Sre[i], tr_); atomicAdd(&c.Sim[i], ti_); }
         const bool rowP = (bti == BT_PQ || bti == BT_PV), rowQ = (bti == BT_PQ);
         const bool colT = (btj == BT_PQ || btj == BT_PV), colV = (btj == BT_PQ);
-        const double ivmj = c.ivm[j];
+        const double ivmj = fast_rcp(c.vm[j]);
         double* Ab = c.A + (size_t)slot * B2 + (2 * bi) * BS + 2 * bj;
         // [dP/dth dP/dV; dQ/dth dQ/dV] = [Im T, Re T/|Vj|; -Re T, Im T/|Vj|]  (diagonal S-terms are added below)
         Ab[0] = (rowP && colT) ? ti_ : 0.0;
@@ -533,7 +533,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
         const int bt = c.btype[i];
         const bool rowP = (bt == BT_PQ || bt == BT_PV), rowQ = (bt == BT_PQ);
         double* Ad = c.A + (size_t)sub * B2 + (2 * bi) * BS + 2 * bi;
-        const double Sr = c.Sre[i], Si = c.Sim[i], ivmi = c.ivm[i];
+        const double Sr = c.Sre[i], Si = c.Sim[i], ivmi = fast_rcp(c.vm[i]);
         // dS/dVa_ii += j S_i ; dS/dVm_ii += S_i / |V_i| ; identity on the fixed variables
         if (rowP) Ad[0] += -Si; else Ad[0] = 1.0;
         if (rowQ) { Ad[1] += Sr * ivmi; Ad[BS] += Sr; Ad[BS + 1] += Si * ivmi; }
@@ -651,31 +651,31 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     out[oo.sh_v + i] = on ? (float)(v * g.sub_vn_kv[g.shunt_sub[i]]) : 0.f;
     sbo[i] = on ? shb[i] : -1;
   }
-  // generators (pypower pfsoln): per-bus totals accumulated in LDS with atomics, then a per-generator pass
+  // generators (pypower pfsoln): per-bus totals accumulated in LDS with atomics (the block array is dead by now and
+  // serves as scratch), then a per-generator pass.  Bus balances: total generation at a bus = S_inj - (P,Q)_spec,
+  // i.e. slack P = (Re S - Psp) * sn (Psp already holds +other generators -loads) and Q_gen,total = (Im S - Qsp) * sn.
   {
-    double* qmin_t = c.e;    // e / f / ivm are dead from here on for the bus-level accumulators? (e, f still used above only)
-    double* qmax_t = c.f;
-    double* p_oth = c.ivm;
-    int* cnt = c.lab;
-    int* nsl = c.vidx;
+    double* qmin_t = c.A;
+    double* qmax_t = c.A + nbus;
+    int* cnt = reinterpret_cast<int*>(c.A + 2 * (size_t)nbus);
+    int* nsl = cnt + nbus;
     __syncthreads();
-    for (int i = tid; i < nbus; i += WAVE) { qmin_t[i] = 0.0; qmax_t[i] = 0.0; p_oth[i] = 0.0; cnt[i] = 0; nsl[i] = 0; }
+    for (int i = tid; i < nbus; i += WAVE) { qmin_t[i] = 0.0; qmax_t[i] = 0.0; cnt[i] = 0; nsl[i] = 0; }
     __syncthreads();
-    // sequential over generators per bus would be the oracle's order; sums of <= a few terms: atomics are fine
     for (int i = tid; i < g.n_gen; i += WAVE) {
       const int bu = c.gen_b[i];
       if (bu < 0) continue;
       atomicAdd(&cnt[bu], 1);
       atomicAdd(&qmin_t[bu], g.gen_min_q[i]);
       atomicAdd(&qmax_t[bu], g.gen_max_q[i]);
-      if (g.gen_slack[i]) atomicAdd(&nsl[bu], 1); else atomicAdd(&p_oth[bu], inj[oo.inj_gen_p + i]);
+      if (g.gen_slack[i]) atomicAdd(&nsl[bu], 1);
     }
     __syncthreads();
     for (int i = tid; i < g.n_gen; i += WAVE) {
       const int bu = c.gen_b[i];
       float gp = 0.f, gq = 0.f, gv = 0.f, gth = 0.f;
       if (bu >= 0) {
-        const double qtot = c.Sim[bu] * sn + c.Qd[bu];
+        const double qtot = (c.Sim[bu] - c.Qsp[bu]) * sn;
         const int cn = cnt[bu];
         const double mn = g.gen_min_q[i], mx = g.gen_max_q[i];
         double q;
@@ -684,7 +684,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
         else if (qmin_t[bu] == qmax_t[bu]) q = qtot / cn;
         else q = mn + (qtot - qmin_t[bu]) / (qmax_t[bu] - qmin_t[bu] + 2.220446049250313e-16) * (mx - mn);
         double p = inj[oo.inj_gen_p + i];
-        if (g.gen_slack[i]) p = (c.Sre[bu] * sn + c.Pd[bu] - p_oth[bu]) / nsl[bu];
+        if (g.gen_slack[i]) p = (c.Sre[bu] - c.Psp[bu]) * sn / nsl[bu];
         gp = (float)p; gq = (float)q;
         gv = (float)(c.vm[bu] * g.sub_vn_kv[g.gen_sub[i]]);
         gth = (float)(c.va[bu] * RAD2DEG);
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(WAVE, (NB == 1 ? 4 : 2)) void runpf_sparse_kernel(c
   const int inst = lane0 + blockIdx.x;
   const int tid = threadIdx.x;
   CarveP<NB> c;
-  carve_sparse<NB>(c, smem, P->g, P->sym.nslot, P->sym.nslot_y, STAGE ? P->sym.n_prog : 0);
+  carve_sparse<NB>(c, smem, P->g, P->sym.nslot, P->sym.nslot_y, STAGE ? P->sym.n_prog : 0, STAGE);
   if (STAGE) for (int i = threadIdx.x; i < P->sym.n_prog; i += WAVE) c.prog[i] = P->sym.prog[i];   // visible after the first barrier
   int n_iter, nb;
   const int st = solve_instance_sparse<NB, STAGE>(P, c, inst, is_dc, max_iter, tol_pu, tid, false, n_iter, nb);
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(WAVE, (NB == 1 ? 4 : 2)) void step_sparse_kernel(co
   const int inst = blockIdx.x;
   const int tid = threadIdx.x;
   CarveP<NB> c;
-  carve_sparse<NB>(c, smem, g, P->sym.nslot, P->sym.nslot_y, STAGE ? P->sym.n_prog : 0);
+  carve_sparse<NB>(c, smem, g, P->sym.nslot, P->sym.nslot_y, STAGE ? P->sym.n_prog : 0, STAGE);
   if (STAGE) for (int i = threadIdx.x; i < P->sym.n_prog; i += WAVE) c.prog[i] = P->sym.prog[i];   // visible after the first barrier
   GPF_STAMPS(8);
   {
@@ -755,13 +755,12 @@ __global__ __launch_bounds__(WAVE, (NB == 1 ? 4 : 2)) void step_sparse_kernel(co
     const float* __restrict__ ch = b.chron + ((size_t)tab * sa.T + row) * g.n_chron;
     const float* __restrict__ sc = b.lane_scale ? b.lane_scale + (size_t)inst * 2 * g.n_load : nullptr;
     double* inj_g = b.inj + (size_t)inst * g.n_inj;
-    for (int i = oo.inj_sto_p + tid; i < g.n_inj; i += WAVE) c.inj[i] = inj_g[i];
+    if (STAGE) for (int i = oo.inj_sto_p + tid; i < g.n_inj; i += WAVE) c.inj[i] = inj_g[i];
     double sum_load = 0.0, sum_prod = 0.0;
     for (int i = tid; i < g.n_load; i += WAVE) {
       float lp = ch[i], lq = ch[g.n_load + i];
       if (sc) { lp *= sc[i]; lq *= sc[g.n_load + i]; }
-      c.inj[oo.inj_load_p + i] = (double)lp;
-      c.inj[oo.inj_load_q + i] = (double)lq;
+      if (STAGE) { c.inj[oo.inj_load_p + i] = (double)lp; c.inj[oo.inj_load_q + i] = (double)lq; }
       inj_g[oo.inj_load_p + i] = (double)lp;
       inj_g[oo.inj_load_q + i] = (double)lq;
       sum_load += (double)lp;
@@ -780,8 +779,7 @@ __global__ __launch_bounds__(WAVE, (NB == 1 ? 4 : 2)) void step_sparse_kernel(co
       const float pv_kv = ch[2 * g.n_load + g.n_gen + i];
       const float vn = (float)g.sub_vn_kv[g.gen_sub[i]];
       const double vm_pu = (double)(pv_kv / vn);
-      c.inj[oo.inj_gen_p + i] = (double)pp;
-      c.inj[oo.inj_gen_vm + i] = vm_pu;
+      if (STAGE) { c.inj[oo.inj_gen_p + i] = (double)pp; c.inj[oo.inj_gen_vm + i] = vm_pu; }
       inj_g[oo.inj_gen_p + i] = (double)pp;
       inj_g[oo.inj_gen_vm + i] = vm_pu;
     }
