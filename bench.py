@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--cascade", action="store_true", help="enable overflow disconnections (cascade loop)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 118-substation secondary workload")
+    ap.add_argument("--n1", action="store_true",
+                    help="BASELINE.json configs[2]: every env copy is stepped together with its N-1 contingencies "
+                         "(one extra lane per line, that line forced off), all fused into the same launch")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -142,13 +145,28 @@ def main():
     if "prod_v" not in ch:
         ch["prod_v"] = np.tile((m.gen_vm0 * m.sub_vn_kv[m.gen_sub]).astype(np.float32), (ch["prod_p"].shape[0], 1))
     B = args.batch
+    n_envs = B
+    fan = 1
+    if args.n1:
+        fan = 1 + m.n_line
+        B = n_envs * fan
     eng = PowerFlowEngine(m, n_lanes=B, device=local_rank)
     tab = eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"])
     T = tab.shape[0]
     eng.upload_chronics(tab)
-    lane0, n_mine = lane_range(world * B, world, rank)          # contiguous block of GLOBAL lane ids (weak scaling)
-    assert n_mine == B
-    offsets, scale = synthetic_lane_inputs(m.n_load, T, lane0 + np.arange(B))
+    lane0, n_mine = lane_range(world * n_envs, world, rank)     # contiguous block of GLOBAL env ids (weak scaling)
+    assert n_mine == n_envs
+    offsets, scale = synthetic_lane_inputs(m.n_load, T, lane0 + np.arange(n_envs))
+    if args.n1:
+        # lane (k, c): env k, contingency c (c = 0: intact grid, c >= 1: line c-1 forced off); the contingencies of one
+        # env sit on the same GPU and share its chronics row / jitter
+        offsets = np.repeat(offsets, fan)
+        scale = np.repeat(scale, fan, axis=0)
+        topo = np.tile(m.initial_topo_vect(), (B, 1))
+        for c in range(1, fan):
+            topo[c::fan, m.line_or_pos_topo_vect[c - 1]] = -1
+            topo[c::fan, m.line_ex_pos_topo_vect[c - 1]] = -1
+        eng.set_topology(topo)
     eng.set_lane_chronics(lane_offset=offsets, lane_scale=scale)
     if "thermal_limits" in ch:
         eng.set_thermal_limits(ch["thermal_limits"])
@@ -168,7 +186,7 @@ def main():
     mean_iter = float(r.n_iter[r.converged].mean()) if r.converged.any() else float("nan")
 
     elapsed = max_over_ranks(elapsed, dist, device="cuda" if dist is not None else None)
-    total_steps = world * B * args.steps
+    total_steps = world * n_envs * args.steps
     value = total_steps / elapsed
 
     if rank == 0:
@@ -195,7 +213,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.env} AC Newton-Raphson DoNothing env.step, batch={B} lanes per GPU "
                                    f"(row (t+7k) mod {T}, loads x (1+0.05 N(0,1)), prod_p rebalanced to 1.02 sum(load))",
-                       "env": args.env, "lanes_per_gpu": B, "cascade": bool(args.cascade), "max_iter": 10,
+                       "env": args.env, "lanes_per_gpu": B, "envs_per_gpu": n_envs, "n1_fanout": fan, "cascade": bool(args.cascade), "max_iter": 10,
                        "tol_mva": 1e-8, "parallelism": f"independent lanes, static shard x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": (measured_traffic_bytes() or {}).get("hbm_bytes_per_launch"),
