@@ -320,3 +320,59 @@ def test_facade_call_sequence_hip_vs_oracle_engine(load_model):
             act = ~np.isnan(b.bus_vm)
             assert np.abs(a.bus_vm[act] - b.bus_vm[act]).max() < 1e-9
     hip.close()
+
+
+def test_full_batch_properties_case14(load_model, load_npz):
+    """BASELINE.json configs[1] at FULL size (4096 lanes): size-independent properties instead of a per-lane oracle
+    run -- (1) Kirchhoff's current law at every bus of every lane from the float32 outputs (the reference's own physics
+    oracle: Backend.check_kirchhoff backend.py:1576, tolerance 1e-2 MW/MVAr in helper_path_test.py:50-51),
+    (2) i = |S| / (sqrt(3) v) identity (BaseBackendTest.py:321-333), (3) losses >= 0, (4) permutation invariance:
+    a lane's result does not depend on its position in the batch, (5) run-to-run reproducibility, (6) a C-oracle spot
+    check of 64 random lanes."""
+    from bench import cpu_baseline  # noqa: F401  (import check only: bench and tests share the fixtures)
+    from grid2op_amd.sharding import synthetic_lane_inputs
+    from oracle.pf_oracle_c import COracle
+    m = load_model("l2rpn_case14_sandbox")
+    ch = load_npz("l2rpn_case14_sandbox.chronics.npz")
+    B = 4096
+    eng = _engine(m, B)
+    tab = eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"])
+    T = tab.shape[0]
+    eng.upload_chronics(tab)
+    off, sc = synthetic_lane_inputs(m.n_load, T, np.arange(B))
+    eng.set_lane_chronics(lane_offset=off, lane_scale=sc)
+    eng.step(5, rebalance=1.02)
+    r = eng.results()
+    assert r.converged.all() and (r.n_iter <= 6).all()
+    out_a = r.out.copy()
+    # (1) KCL per substation (all elements on busbar 1 in this workload)
+    p_bus = np.zeros((B, m.n_sub))
+    q_bus = np.zeros((B, m.n_sub))
+    np.add.at(p_bus, (slice(None), m.line_or_sub), r.p_or.astype(np.float64))
+    np.add.at(p_bus, (slice(None), m.line_ex_sub), r.p_ex.astype(np.float64))
+    np.add.at(q_bus, (slice(None), m.line_or_sub), r.q_or.astype(np.float64))
+    np.add.at(q_bus, (slice(None), m.line_ex_sub), r.q_ex.astype(np.float64))
+    np.add.at(p_bus, (slice(None), m.load_sub), r.load_p.astype(np.float64))
+    np.add.at(q_bus, (slice(None), m.load_sub), r.load_q.astype(np.float64))
+    np.add.at(p_bus, (slice(None), m.gen_sub), -r.gen_p.astype(np.float64))
+    np.add.at(q_bus, (slice(None), m.gen_sub), -r.gen_q.astype(np.float64))
+    np.add.at(p_bus, (slice(None), m.shunt_sub), r.shunt_p.astype(np.float64))
+    np.add.at(q_bus, (slice(None), m.shunt_sub), r.shunt_q.astype(np.float64))
+    assert np.abs(p_bus).max() < 1e-2 and np.abs(q_bus).max() < 1e-2, (np.abs(p_bus).max(), np.abs(q_bus).max())
+    # (2) current identity, (3) losses
+    a_chk = np.sqrt(r.p_or.astype(np.float64) ** 2 + r.q_or.astype(np.float64) ** 2) * 1e3 / (np.sqrt(3.0) * r.v_or)
+    assert np.allclose(a_chk, r.a_or, rtol=2e-5, atol=1e-3)
+    assert ((r.p_or + r.p_ex).astype(np.float64) > -1e-3).all()
+    # (4) permutation invariance + (5) reproducibility: reverse the lane order and run again
+    eng.set_lane_chronics(lane_offset=off[::-1].copy(), lane_scale=sc[::-1].copy())
+    eng.step(5, rebalance=1.02)
+    out_b = eng.results().out[::-1]
+    assert np.allclose(out_a, out_b, rtol=1e-6, atol=1e-5)
+    # (6) spot check against the C oracle
+    orc = COracle(m)
+    lanes = np.random.default_rng(0).choice(B, 64, replace=False)
+    for k in lanes:
+        _, o, st = orc.step_batch(tab, off, sc, 1.02, 5, int(k), 1, want_out=True)
+        assert st[0, 0] == 0
+        assert np.allclose(out_a[k], o[0], rtol=5e-6, atol=2e-4), k
+    eng.close()
