@@ -33,6 +33,47 @@ from .grid_model import GridModel, load_grid_model
 __all__ = ["HipBackend"]
 
 
+class _LanePool:
+    """Backends of the same grid / device / busbar count share ONE engine and take one lane each.
+
+    ``Backend.copy`` is hammered by the reference (``ObservationSpace._create_backend_obs`` observationSpace.py:250-254,
+    ``N1Reward`` n1Reward.py:71, ``Simulator``): with the pool a copy costs no device allocation -- the façade pushes
+    its complete lane state before every power flow, so a copy only needs a free lane.  Engines are per process: a
+    forked child (Runner / multi-process envs) starts with an empty pool (HIP handles do not survive ``fork``)."""
+    LANES = 32
+    _pools = {}
+    _pid = None
+
+    @classmethod
+    def acquire(cls, key, factory):
+        if cls._pid != os.getpid():
+            cls._pools = {}
+            cls._pid = os.getpid()
+        for ent in cls._pools.setdefault(key, []):
+            if ent["free"]:
+                return ent["engine"], ent["free"].pop()
+        eng = factory(cls.LANES)
+        n = int(getattr(eng, "n_lanes", 1))
+        ent = {"engine": eng, "free": list(range(n - 1, 0, -1))}
+        cls._pools[key].append(ent)
+        return eng, 0
+
+    @classmethod
+    def release(cls, key, engine, lane):
+        if cls._pid != os.getpid():
+            return
+        ents = cls._pools.get(key, [])
+        for ent in ents:
+            if ent["engine"] is engine and lane not in ent["free"]:
+                ent["free"].append(lane)
+                if len(ent["free"]) == int(getattr(engine, "n_lanes", 1)):   # last user gone: free the device memory
+                    ents.remove(ent)
+                    engine.close()
+                    if not ents:
+                        cls._pools.pop(key, None)
+                return
+
+
 class HipBackend(Backend):
     """See module docstring.  Keyword arguments mirror ``PandaPowerBackend.__init__``
     (pandaPowerBackend.py:119-143) so that ``Runner`` can re-instantiate the class from ``_my_kwargs``
@@ -66,6 +107,7 @@ class HipBackend(Backend):
         self._m: Optional[GridModel] = None
         self._engine = None
         self._lane = 0
+        self._pool_key = None
         self.div_exception = None
         self.tol = 1e-5                     # storage "produces / absorbs anything" threshold (:864)
         self._topo_vect = None
@@ -73,10 +115,15 @@ class HipBackend(Backend):
         self.cst_1 = dt_float(1.0)
 
     # ------------------------------------------------------------------------------------------------------------
-    def _make_engine(self, model: GridModel, n_busbar: int):
+    def _make_engine(self, model: GridModel, n_busbar: int, n_lanes: int = 1):
         """Hook: the one place where the compute engine is created (tests swap in the CPU oracle here)."""
         from .engine import PowerFlowEngine
-        return PowerFlowEngine(model, n_lanes=1, device=self._device, n_busbar=n_busbar)
+        return PowerFlowEngine(model, n_lanes=n_lanes, device=self._device, n_busbar=n_busbar)
+
+    def _acquire_lane(self):
+        m, nbb = self._m, self.n_busbar_per_sub
+        self._pool_key = (type(self)._make_engine, id(m), self._device, nbb)
+        self._engine, self._lane = _LanePool.acquire(self._pool_key, lambda n: self._make_engine(m, nbb, n))
 
     # ---- load_grid (pandaPowerBackend.py:356-617 + 670-874) ------------------------------------------------------------
     def load_grid(self, path: Union[os.PathLike, str], filename: Optional[Union[os.PathLike, str]] = None) -> None:
@@ -86,8 +133,7 @@ class HipBackend(Backend):
         m = load_grid_model(full_path)
         self._m = m
         self._init_from_model(m)
-        self._engine = self._make_engine(m, self.n_busbar_per_sub)
-        self._lane = 0
+        self._acquire_lane()
 
     def _init_from_model(self, m: GridModel) -> None:
         self.n_line = m.n_line
@@ -422,7 +468,7 @@ class HipBackend(Backend):
             if hasattr(self, k):
                 setattr(res, k, getattr(self, k))
         # class-level grid description is shared through the (re-typed) class; instance-level arrays are copied
-        skip = {"_engine", "_m", "_my_kwargs"}
+        skip = {"_engine", "_m", "_my_kwargs", "_pool_key", "_lane"}
         for k, v in self.__dict__.items():
             if k in skip:
                 continue
@@ -443,13 +489,12 @@ class HipBackend(Backend):
         res.n_busbar_per_sub = self.n_busbar_per_sub
         res.detachment_is_allowed = self.detachment_is_allowed
         if self._engine is not None:
-            res._engine = res._make_engine(self._m, self.n_busbar_per_sub)
-            res._lane = 0
+            res._acquire_lane()        # same engine, another lane: no device allocation
         return res
 
     def close(self) -> None:
         if self._engine is not None:
-            self._engine.close()
+            _LanePool.release(self._pool_key, self._engine, self._lane)
         self._engine = None
 
     def save_file(self, full_path) -> None:

@@ -4,5 +4,5 @@ from oracle_engine import OracleEngine
 
 
 class OracleHipBackend(HipBackend):
-    def _make_engine(self, model, n_busbar):
-        return OracleEngine(model, n_lanes=1, n_busbar=n_busbar)
+    def _make_engine(self, model, n_busbar, n_lanes=1):
+        return OracleEngine(model, n_lanes=n_lanes, n_busbar=n_busbar)
