@@ -149,7 +149,10 @@ __device__ __forceinline__ bool block_inverse(const double (&D)[BS * BS], double
 // are combined with LDS f64 atomics.
 template <int BS>
 __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ prog, double* __restrict__ A,
-                                      double* __restrict__ rhs, int tid) {
+                                      double* __restrict__ rhs, int tid, double* dbg = nullptr) {
+#ifdef GPF_TIMING
+  const long long t_lu0 = __builtin_readcyclecounter();
+#endif
   constexpr int B2 = BS * BS;
   constexpr int CHB = (WAVE / B2) * B2;      // U-block items per chunk: whole blocks only
   constexpr int CHR = (WAVE / BS) * BS;
@@ -257,24 +260,29 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
     }
     __syncthreads();
   }
-  // back substitution, levels in reverse: x_p = b'_p - sum_j U'_pj x_j  (pivots of a level are independent)
+#ifdef GPF_TIMING
+  const long long t_lu1 = __builtin_readcyclecounter();
+#endif
+  // back substitution, levels in reverse: x_p = b'_p - sum_j U'_pj x_j.  Pivots of a level are independent and only
+  // depend on later levels, so every (pivot, U entry, row) item of a level runs in parallel and accumulates with
+  // ds_add_f64.
   for (int lv = S.n_levels - 1; lv >= 0; --lv) {
-    const int tab = prog[S.back_off + 2 * lv], n_piv = prog[S.back_off + 2 * lv + 1];
-    for (int it = tid; it < n_piv * BS; it += WAVE) {
-      const int q = it / BS, r = it % BS;
-      const int p = prog[tab + 3 * q], u_off = prog[tab + 3 * q + 1], nu = prog[tab + 3 * q + 2];
-      double acc = rhs[(size_t)p * BS + r];
-      for (int e = 0; e < nu; ++e) {
-        const unsigned w = (unsigned)prog[u_off + e];
-        const double* Au = A + (size_t)(w >> 16) * B2 + r * BS;
-        const double* xj = rhs + (size_t)(w & 0xffffu) * BS;
+    const int ent_off = prog[S.back_off + 2 * lv], n_ent = prog[S.back_off + 2 * lv + 1];
+    for (int it = tid; it < n_ent * BS; it += WAVE) {
+      const unsigned w = (unsigned)prog[ent_off + 2 * (it / BS)];      // u_slot | (u_col << 16)
+      const int p = prog[ent_off + 2 * (it / BS) + 1], r = it % BS;
+      const double* Au = A + (size_t)(w & 0xffffu) * B2 + r * BS;
+      const double* xj = rhs + (size_t)(w >> 16) * BS;
+      double acc = 0.0;
 #pragma unroll
-        for (int m = 0; m < BS; ++m) acc = fma(-Au[m], xj[m], acc);
-      }
-      rhs[(size_t)p * BS + r] = acc;
+      for (int m = 0; m < BS; ++m) acc = fma(Au[m], xj[m], acc);
+      atomicAdd(&rhs[(size_t)p * BS + r], -acc);
     }
     __syncthreads();
   }
+#ifdef GPF_TIMING
+  if (dbg && tid == 0) { dbg[0] = (double)(t_lu1 - t_lu0); dbg[1] = (double)((long long)__builtin_readcyclecounter() - t_lu1); }
+#endif
   return ok;
 }
 
@@ -473,7 +481,11 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
   __syncthreads();
   GPF_STAMPS(3);
   {
+#ifdef GPF_TIMING
+    bool ok = block_lu_solve<BS>(S, STAGE ? (const int*)c.prog : S.prog, c.A, c.rhs, tid, P->b.work + (size_t)inst * 32 + 20);
+#else
     bool ok = block_lu_solve<BS>(S, STAGE ? (const int*)c.prog : S.prog, c.A, c.rhs, tid);
+#endif
     for (int i = tid; i < nbus; i += WAVE) {
       const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
       const double th = c.rhs[(size_t)sub * BS + 2 * bi];

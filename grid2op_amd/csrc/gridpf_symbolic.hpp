@@ -33,9 +33,10 @@ struct Symbolic {
   //   b-items     : one int per U block          (pivot_sub << 16) | u_slot        -> U' = Dinv * A
   //   c-items     : two ints per trailing update  dst | (l_slot << 16), u_slot     -> A[dst] -= A[l] * U'[u]
   //   r-items     : two ints per L block          l_slot | (l_row << 16), pivot_sub -> rhs[l_row] -= A[l] * b'[p]
-  //   back headers: per level {bk_off, n_piv}; per pivot {sub, u_off, n_u}; u entries (u_slot << 16) | u_col
+  //   back section: level table [n_levels]{ent_off, n_ent}; entries two ints  u_slot | (u_col << 16), pivot_sub
+  //                 -> x[pivot] -= U'[u_slot] * x[u_col]   (all entries of a level run concurrently, LDS atomics)
   std::vector<int> prog;
-  int back_off = 0;                // offset of the back-substitution level table: [n_levels]{piv_tab_off, n_piv}
+  int back_off = 0;                // offset of the back-substitution level table
   int max_level_piv = 0;
 };
 
@@ -149,17 +150,17 @@ inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, co
   P.resize(P.size() + (size_t)2 * S.n_levels, 0);
   for (int lv = 0; lv < S.n_levels; ++lv) {
     const Level& L = levels[lv];
-    const int tab_off = (int)P.size();
-    P.resize(P.size() + (size_t)3 * L.piv.size(), 0);
-    for (size_t q = 0; q < L.piv.size(); ++q) {
-      const int u_off = (int)P.size();
-      P.insert(P.end(), L.u_entries[q].begin(), L.u_entries[q].end());
-      P[tab_off + 3 * q + 0] = L.piv[q];
-      P[tab_off + 3 * q + 1] = u_off;
-      P[tab_off + 3 * q + 2] = (int)L.u_entries[q].size();
-    }
-    P[S.back_off + 2 * lv + 0] = tab_off;
-    P[S.back_off + 2 * lv + 1] = (int)L.piv.size();
+    const int ent_off = (int)P.size();
+    int n_ent = 0;
+    for (size_t q = 0; q < L.piv.size(); ++q)
+      for (int ue : L.u_entries[q]) {
+        const int us = ue >> 16, col = ue & 0xffff;
+        P.push_back(us | (col << 16));
+        P.push_back(L.piv[q]);
+        ++n_ent;
+      }
+    P[S.back_off + 2 * lv + 0] = ent_off;
+    P[S.back_off + 2 * lv + 1] = n_ent;
   }
   return S;
 }

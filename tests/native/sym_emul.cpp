@@ -1,0 +1,93 @@
+// TEST INFRASTRUCTURE: host emulation of the device block-LU (gridpf_sparse.hpp: block_lu_solve) driven by the SAME
+// symbolic program that the product builds (grid2op_amd/csrc/gridpf_symbolic.hpp), so that the program layout and the
+// level scheduling are verified on CPU against a dense solve (tests/test_symbolic_program.py).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../grid2op_amd/csrc/gridpf_symbolic.hpp"
+
+extern "C" {
+
+// A_dense: [n*BS][n*BS] row-major (entries outside the fill pattern are ignored), rhs: [n*BS] -> x.
+// Returns the number of levels (>= 1) or a negative error code.
+int sym_emul_solve(int n_sub, int n_line, const int* line_or, const int* line_ex, int BS, const double* A_dense,
+                   const double* rhs_in, double* x_out, int* stats /* nslot_y, nslot, n_levels, n_prog */) {
+  gpf::Symbolic S = gpf::build_symbolic(n_sub, n_line, line_or, line_ex);
+  const int B2 = BS * BS, N = n_sub * BS;
+  std::vector<double> A((size_t)S.nslot * B2, 0.0), rhs(rhs_in, rhs_in + N);
+  for (int s = 0; s < S.nslot; ++s)
+    for (int r = 0; r < BS; ++r)
+      for (int q = 0; q < BS; ++q) A[(size_t)s * B2 + r * BS + q] = A_dense[(size_t)(S.slot_row[s] * BS + r) * N + S.slot_col[s] * BS + q];
+  const int* prog = S.prog.data();
+  auto inv = [&](const double* D, double* Di) -> bool {   // Gauss-Jordan with partial pivoting
+    std::vector<double> M((size_t)BS * 2 * BS);
+    for (int r = 0; r < BS; ++r) for (int q = 0; q < BS; ++q) { M[r * 2 * BS + q] = D[r * BS + q]; M[r * 2 * BS + BS + q] = r == q; }
+    for (int k = 0; k < BS; ++k) {
+      int p = k;
+      for (int r = k + 1; r < BS; ++r) if (std::fabs(M[r * 2 * BS + k]) > std::fabs(M[p * 2 * BS + k])) p = r;
+      if (p != k) for (int q = 0; q < 2 * BS; ++q) std::swap(M[k * 2 * BS + q], M[p * 2 * BS + q]);
+      const double pv = M[k * 2 * BS + k];
+      if (!(std::fabs(pv) > 1e-300)) return false;
+      for (int q = 0; q < 2 * BS; ++q) M[k * 2 * BS + q] /= pv;
+      for (int r = 0; r < BS; ++r) if (r != k) { const double m = M[r * 2 * BS + k]; for (int q = 0; q < 2 * BS; ++q) M[r * 2 * BS + q] -= m * M[k * 2 * BS + q]; }
+    }
+    for (int r = 0; r < BS; ++r) for (int q = 0; q < BS; ++q) Di[r * BS + q] = M[r * 2 * BS + BS + q];
+    return true;
+  };
+  for (int lv = 0; lv < S.n_levels; ++lv) {
+    const int* h = prog + 8 * lv;
+    const int piv_off = h[0], n_piv = h[1], b_off = h[2], n_b = h[3], c_off = h[4], n_c = h[5], r_off = h[6], n_r = h[7];
+    for (int q = 0; q < n_piv; ++q) {           // (a)
+      double* Ad = &A[(size_t)prog[piv_off + q] * B2];
+      std::vector<double> Di(B2);
+      if (!inv(Ad, Di.data())) return -1;
+      std::memcpy(Ad, Di.data(), sizeof(double) * B2);
+    }
+    for (int e = 0; e < n_b; ++e) {             // (b) U' = Dinv * A
+      const unsigned w = (unsigned)prog[b_off + e];
+      const double* Di = &A[(size_t)(w >> 16) * B2];
+      double* Au = &A[(size_t)(w & 0xffffu) * B2];
+      std::vector<double> T(B2, 0.0);
+      for (int r = 0; r < BS; ++r) for (int q = 0; q < BS; ++q) for (int m = 0; m < BS; ++m) T[r * BS + q] += Di[r * BS + m] * Au[m * BS + q];
+      std::memcpy(Au, T.data(), sizeof(double) * B2);
+    }
+    for (int q = 0; q < n_piv; ++q) {           //     b' = Dinv * b
+      const int p = prog[piv_off + q];
+      const double* Di = &A[(size_t)p * B2];
+      std::vector<double> t(BS, 0.0);
+      for (int r = 0; r < BS; ++r) for (int m = 0; m < BS; ++m) t[r] += Di[r * BS + m] * rhs[p * BS + m];
+      for (int r = 0; r < BS; ++r) rhs[p * BS + r] = t[r];
+    }
+    for (int o = 0; o < n_c; ++o) {             // (c) A[dst] -= A[l] * U'[u]
+      const unsigned w0 = (unsigned)prog[c_off + 2 * o];
+      const int u = prog[c_off + 2 * o + 1];
+      const double* Al = &A[(size_t)(w0 >> 16) * B2];
+      const double* Au = &A[(size_t)u * B2];
+      double* Ad = &A[(size_t)(w0 & 0xffffu) * B2];
+      for (int r = 0; r < BS; ++r) for (int q = 0; q < BS; ++q) { double acc = 0; for (int m = 0; m < BS; ++m) acc += Al[r * BS + m] * Au[m * BS + q]; Ad[r * BS + q] -= acc; }
+    }
+    for (int o = 0; o < n_r; ++o) {             //     rhs[row] -= A[l] * b'[p]
+      const unsigned w0 = (unsigned)prog[r_off + 2 * o];
+      const int p = prog[r_off + 2 * o + 1];
+      const double* Al = &A[(size_t)(w0 & 0xffffu) * B2];
+      for (int r = 0; r < BS; ++r) { double acc = 0; for (int m = 0; m < BS; ++m) acc += Al[r * BS + m] * rhs[p * BS + m]; rhs[(w0 >> 16) * BS + r] -= acc; }
+    }
+  }
+  for (int lv = S.n_levels - 1; lv >= 0; --lv) {   // back substitution
+    const int ent_off = prog[S.back_off + 2 * lv], n_ent = prog[S.back_off + 2 * lv + 1];
+    std::vector<double> delta((size_t)N, 0.0);
+    for (int e = 0; e < n_ent; ++e) {
+      const unsigned w = (unsigned)prog[ent_off + 2 * e];
+      const int p = prog[ent_off + 2 * e + 1];
+      const double* Au = &A[(size_t)(w & 0xffffu) * B2];
+      const double* xj = &rhs[(size_t)(w >> 16) * BS];
+      for (int r = 0; r < BS; ++r) { double acc = 0; for (int m = 0; m < BS; ++m) acc += Au[r * BS + m] * xj[m]; delta[p * BS + r] -= acc; }
+    }
+    for (int i = 0; i < N; ++i) rhs[i] += delta[i];
+  }
+  std::memcpy(x_out, rhs.data(), sizeof(double) * N);
+  if (stats) { stats[0] = S.nslot_y; stats[1] = S.nslot; stats[2] = S.n_levels; stats[3] = (int)S.prog.size(); }
+  return S.n_levels;
+}
+}

@@ -31,7 +31,7 @@ L = _capi.lib()
 buf = np.zeros((B, 32))
 L.gpf_debug_read_work.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int64]
 assert L.gpf_debug_read_work(eng._h, buf.ctypes.data_as(C.POINTER(C.c_double)), buf.size) == 0
-SPARSE = os.environ.get("GRIDPF_FORCE_SPARSE") == "1" or m.n_sub > 20
+SPARSE = os.environ.get("GRIDPF_DENSE") != "1"
 if SPARSE:
     names_s = {8: "kernel start", 0: "K9 chronics gather", 1: "K1 + bus types (atomics)", 2: "connectivity", 3: "Ybus + DC assembly",
                4: "DC block-LU solve", 5: "Newton loop total", 6: "results", 9: "back in step kernel"}
@@ -43,6 +43,7 @@ if SPARSE:
         print(f"  {names_s[k]:45s} {med[k] - prev:10.0f}")
         prev = med[k]
     print(f"  {'TOTAL':45s} {med[9] - med[8]:10.0f}")
+    print(f"  DC block-LU: elimination levels {med[20]:.0f}, back substitution {med[21]:.0f} cycles")
     sys.exit(0)
 names = {8: "kernel start", 0: "K9 chronics gather done / solve start", 1: "K1 topology", 2: "bus types+numbering", 3: "connectivity",
          4: "Ybus + B' assembly", 5: "DC solve", 10: "NR it1: sincos", 11: "NR it1: assembly+check (up to reload it2..)",
