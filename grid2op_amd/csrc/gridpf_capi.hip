@@ -448,7 +448,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     if (S.nslot > 65535 || g.n_sub > 32767) { gpf_destroy(e); return fail(GPF_E_CAPACITY, "grid too large for the 16-bit packed symbolic program"); }
     gpf::SymDev& D = e->sym_dev;
     const int* base = e->sym_buf.p;
-    D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.n_prog = (int)S.prog.size();
+    D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.scale_off = S.scale_off; D.n_scale = S.n_scale; D.n_prog = (int)S.prog.size();
     D.slot_row = base + o_sr; D.slot_col = base + o_sc; D.br_slot = base + o_br; D.prog = base + o_pr;
   }
   HIP_TRY(hipMemsetAsync(e->status.p, 0xFF, B * 4 * sizeof(int), e->stream));

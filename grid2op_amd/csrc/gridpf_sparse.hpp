@@ -16,7 +16,7 @@
 namespace gpf {
 
 struct SymDev {
-  int n, nslot, nslot_y, n_levels, back_off, n_prog;
+  int n, nslot, nslot_y, n_levels, back_off, n_prog, scale_off, n_scale;
   const int* slot_row;
   const int* slot_col;
   const int* br_slot;   // [n_line][4]
@@ -157,6 +157,61 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
   constexpr int CHB = (WAVE / B2) * B2;      // U-block items per chunk: whole blocks only
   constexpr int CHR = (WAVE / BS) * BS;
   bool ok = true;
+  if (BS == 2) {
+    // 2x2 blocks: ONE phase per level.  The pivot inverse is recomputed by every item from the (never overwritten)
+    // diagonal block, A[dst] -= A[l] * inv(D_p) * A[u] and rhs[row] -= A[l] * inv(D_p) * b_p; the scaling
+    // U' = inv(D) * A_u, b' = inv(D) * b needed by the back substitution is deferred to one fully parallel pass.
+    for (int lv = 0; lv < S.n_levels; ++lv) {
+      const int* h = prog + 8 * lv;
+      const int c_off = h[4], n_c = h[5], r_off = h[6], n_r = h[7];
+      for (int it = tid; it < n_c * 4; it += WAVE) {
+        const int o = it >> 2, r = (it >> 1) & 1, q = it & 1;
+        const unsigned w0 = (unsigned)prog[c_off + 2 * o], w1 = (unsigned)prog[c_off + 2 * o + 1];
+        const double* D = A + (size_t)(w1 >> 16) * 4;
+        const double* Al = A + (size_t)(w0 >> 16) * 4 + r * 2;
+        const double* Au = A + (size_t)(w1 & 0xffffu) * 4 + q;
+        const double d0 = D[0], d1 = D[1], d2 = D[2], d3 = D[3];
+        const double al0 = Al[0], al1 = Al[1], au0 = Au[0], au1 = Au[2];
+        const double rd = fast_rcp(fma(d0, d3, -d1 * d2));
+        const double t0 = fma(al0, d3, -al1 * d2), t1 = fma(al1, d0, -al0 * d1);
+        atomicAdd(&A[(size_t)(w0 & 0xffffu) * 4 + r * 2 + q], -fma(t0, au0, t1 * au1) * rd);
+      }
+      for (int it = tid; it < n_r * 2; it += WAVE) {
+        const int o = it >> 1, r = it & 1;
+        const unsigned w0 = (unsigned)prog[r_off + 2 * o];
+        const int p = prog[r_off + 2 * o + 1];
+        const double* D = A + (size_t)p * 4;
+        const double* Al = A + (size_t)(w0 & 0xffffu) * 4 + r * 2;
+        const double d0 = D[0], d1 = D[1], d2 = D[2], d3 = D[3];
+        const double al0 = Al[0], al1 = Al[1], b0 = rhs[(size_t)p * 2], b1 = rhs[(size_t)p * 2 + 1];
+        const double rd = fast_rcp(fma(d0, d3, -d1 * d2));
+        const double t0 = fma(al0, d3, -al1 * d2), t1 = fma(al1, d0, -al0 * d1);
+        atomicAdd(&rhs[(size_t)(w0 >> 16) * 2 + r], -fma(t0, b0, t1 * b1) * rd);
+      }
+      __syncthreads();
+    }
+    // deferred scaling (one item per block column / per pivot: no read-write overlap between items)
+    for (int it = tid; it < S.n_scale * 2; it += WAVE) {
+      const unsigned w = (unsigned)prog[S.scale_off + (it >> 1)];
+      const int q = it & 1;
+      const double* D = A + (size_t)(w >> 16) * 4;
+      double* Au = A + (size_t)(w & 0xffffu) * 4 + q;
+      const double d0 = D[0], d1 = D[1], d2 = D[2], d3 = D[3], a0 = Au[0], a1 = Au[2];
+      const double rd = fast_rcp(fma(d0, d3, -d1 * d2));
+      Au[0] = fma(d3, a0, -d1 * a1) * rd;
+      Au[2] = fma(d0, a1, -d2 * a0) * rd;
+    }
+    for (int p = tid; p < S.n; p += WAVE) {
+      const double* D = A + (size_t)p * 4;
+      const double d0 = D[0], d1 = D[1], d2 = D[2], d3 = D[3], b0 = rhs[(size_t)p * 2], b1 = rhs[(size_t)p * 2 + 1];
+      const double det = fma(d0, d3, -d1 * d2);
+      if (!(fabs(det) > 1e-300) || !(fabs(det) < 1e300)) ok = false;
+      const double rd = fast_rcp(det);
+      rhs[(size_t)p * 2] = fma(d3, b0, -d1 * b1) * rd;
+      rhs[(size_t)p * 2 + 1] = fma(d0, b1, -d2 * b0) * rd;
+    }
+    __syncthreads();
+  } else
   for (int lv = 0; lv < S.n_levels; ++lv) {
     const int* h = prog + 8 * lv;
     const int piv_off = h[0], n_piv = h[1], b_off = h[2], n_b = h[3], c_off = h[4], n_c = h[5], r_off = h[6], n_r = h[7];
@@ -239,7 +294,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
     for (int it = tid; it < n_c * B2; it += WAVE) {
       const int o = it / B2, r = (it % B2) / BS, q = it % BS;
       const unsigned w0 = (unsigned)prog[c_off + 2 * o];
-      const int u = prog[c_off + 2 * o + 1];
+      const int u = prog[c_off + 2 * o + 1] & 0xffff;
       const double* Al = A + (size_t)(w0 >> 16) * B2 + r * BS;
       const double* Au = A + (size_t)u * B2 + q;
       double acc = 0.0;

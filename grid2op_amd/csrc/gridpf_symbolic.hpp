@@ -31,11 +31,13 @@ struct Symbolic {
   //   prog[0 .. 8*n_levels)            level headers {piv_off, n_piv, b_off, n_b, c_off, n_c, r_off, n_r}
   //   pivots      : substation ids
   //   b-items     : one int per U block          (pivot_sub << 16) | u_slot        -> U' = Dinv * A
-  //   c-items     : two ints per trailing update  dst | (l_slot << 16), u_slot     -> A[dst] -= A[l] * U'[u]
+  //   c-items     : two ints per trailing update  dst | (l_slot << 16), u_slot | (pivot_sub << 16)
+  //                                                 -> A[dst] -= A[l] * Dinv[p] * A[u]
   //   r-items     : two ints per L block          l_slot | (l_row << 16), pivot_sub -> rhs[l_row] -= A[l] * b'[p]
   //   back section: level table [n_levels]{ent_off, n_ent}; entries two ints  u_slot | (u_col << 16), pivot_sub
   //                 -> x[pivot] -= U'[u_slot] * x[u_col]   (all entries of a level run concurrently, LDS atomics)
   std::vector<int> prog;
+  int scale_off = 0, n_scale = 0;  // all U blocks of all levels: (pivot_sub << 16) | u_slot  (deferred U' = Dinv * A pass)
   int back_off = 0;                // offset of the back-substitution level table
   int max_level_piv = 0;
 };
@@ -110,7 +112,7 @@ inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, co
         for (int j : nb) {
           const int dst = add_slot(i, j), ls = add_slot(i, p), us = add_slot(p, j);
           L.c_items.push_back(dst | (ls << 16));
-          L.c_items.push_back(us);
+          L.c_items.push_back(us | (p << 16));
         }
     }
     for (int p : L.piv) {
@@ -146,6 +148,9 @@ inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, co
     h[0] = piv_off; h[1] = (int)L.piv.size(); h[2] = b_off; h[3] = (int)L.b_items.size();
     h[4] = c_off; h[5] = (int)L.c_items.size() / 2; h[6] = r_off; h[7] = (int)L.r_items.size() / 2;
   }
+  S.scale_off = (int)P.size();
+  for (const Level& L : levels) P.insert(P.end(), L.b_items.begin(), L.b_items.end());
+  S.n_scale = (int)P.size() - S.scale_off;
   S.back_off = (int)P.size();
   P.resize(P.size() + (size_t)2 * S.n_levels, 0);
   for (int lv = 0; lv < S.n_levels; ++lv) {

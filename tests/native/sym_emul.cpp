@@ -12,7 +12,7 @@ extern "C" {
 // A_dense: [n*BS][n*BS] row-major (entries outside the fill pattern are ignored), rhs: [n*BS] -> x.
 // Returns the number of levels (>= 1) or a negative error code.
 int sym_emul_solve(int n_sub, int n_line, const int* line_or, const int* line_ex, int BS, const double* A_dense,
-                   const double* rhs_in, double* x_out, int* stats /* nslot_y, nslot, n_levels, n_prog */) {
+                   const double* rhs_in, double* x_out, int* stats /* nslot_y, nslot, n_levels, n_prog */, int fused) {
   gpf::Symbolic S = gpf::build_symbolic(n_sub, n_line, line_or, line_ex);
   const int B2 = BS * BS, N = n_sub * BS;
   std::vector<double> A((size_t)S.nslot * B2, 0.0), rhs(rhs_in, rhs_in + N);
@@ -35,6 +35,46 @@ int sym_emul_solve(int n_sub, int n_line, const int* line_or, const int* line_ex
     for (int r = 0; r < BS; ++r) for (int q = 0; q < BS; ++q) Di[r * BS + q] = M[r * 2 * BS + BS + q];
     return true;
   };
+  if (fused) {   // mirrors the BS == 2 device path: one phase per level, deferred scaling pass
+    for (int lv = 0; lv < S.n_levels; ++lv) {
+      const int* h = prog + 8 * lv;
+      const int c_off = h[4], n_c = h[5], r_off = h[6], n_r = h[7];
+      std::vector<double> dA(A.size(), 0.0), dr(rhs.size(), 0.0);      // all items of a level read the pre-level state
+      std::vector<double> Di(B2), T(B2);
+      for (int o = 0; o < n_c; ++o) {
+        const unsigned w0 = (unsigned)prog[c_off + 2 * o], w1 = (unsigned)prog[c_off + 2 * o + 1];
+        if (!inv(&A[(size_t)(w1 >> 16) * B2], Di.data())) return -1;
+        const double* Al = &A[(size_t)(w0 >> 16) * B2];
+        const double* Au = &A[(size_t)(w1 & 0xffffu) * B2];
+        for (int r = 0; r < BS; ++r) for (int q = 0; q < BS; ++q) { T[r * BS + q] = 0; for (int m = 0; m < BS; ++m) T[r * BS + q] += Al[r * BS + m] * Di[m * BS + q]; }
+        for (int r = 0; r < BS; ++r) for (int q = 0; q < BS; ++q) { double acc = 0; for (int m = 0; m < BS; ++m) acc += T[r * BS + m] * Au[m * BS + q]; dA[(size_t)(w0 & 0xffffu) * B2 + r * BS + q] -= acc; }
+      }
+      for (int o = 0; o < n_r; ++o) {
+        const unsigned w0 = (unsigned)prog[r_off + 2 * o];
+        const int p = prog[r_off + 2 * o + 1];
+        if (!inv(&A[(size_t)p * B2], Di.data())) return -1;
+        const double* Al = &A[(size_t)(w0 & 0xffffu) * B2];
+        for (int r = 0; r < BS; ++r) for (int q = 0; q < BS; ++q) { T[r * BS + q] = 0; for (int m = 0; m < BS; ++m) T[r * BS + q] += Al[r * BS + m] * Di[m * BS + q]; }
+        for (int r = 0; r < BS; ++r) { double acc = 0; for (int m = 0; m < BS; ++m) acc += T[r * BS + m] * rhs[p * BS + m]; dr[(w0 >> 16) * BS + r] -= acc; }
+      }
+      for (size_t i = 0; i < A.size(); ++i) A[i] += dA[i];
+      for (size_t i = 0; i < rhs.size(); ++i) rhs[i] += dr[i];
+    }
+    std::vector<double> Di(B2), T(B2);
+    for (int e = 0; e < S.n_scale; ++e) {
+      const unsigned w = (unsigned)prog[S.scale_off + e];
+      if (!inv(&A[(size_t)(w >> 16) * B2], Di.data())) return -1;
+      double* Au = &A[(size_t)(w & 0xffffu) * B2];
+      for (int r = 0; r < BS; ++r) for (int q = 0; q < BS; ++q) { T[r * BS + q] = 0; for (int m = 0; m < BS; ++m) T[r * BS + q] += Di[r * BS + m] * Au[m * BS + q]; }
+      std::memcpy(Au, T.data(), sizeof(double) * B2);
+    }
+    for (int p = 0; p < S.n; ++p) {
+      if (!inv(&A[(size_t)p * B2], Di.data())) return -1;
+      std::vector<double> t(BS, 0.0);
+      for (int r = 0; r < BS; ++r) for (int m = 0; m < BS; ++m) t[r] += Di[r * BS + m] * rhs[p * BS + m];
+      for (int r = 0; r < BS; ++r) rhs[p * BS + r] = t[r];
+    }
+  } else
   for (int lv = 0; lv < S.n_levels; ++lv) {
     const int* h = prog + 8 * lv;
     const int piv_off = h[0], n_piv = h[1], b_off = h[2], n_b = h[3], c_off = h[4], n_c = h[5], r_off = h[6], n_r = h[7];
@@ -61,7 +101,7 @@ int sym_emul_solve(int n_sub, int n_line, const int* line_or, const int* line_ex
     }
     for (int o = 0; o < n_c; ++o) {             // (c) A[dst] -= A[l] * U'[u]
       const unsigned w0 = (unsigned)prog[c_off + 2 * o];
-      const int u = prog[c_off + 2 * o + 1];
+      const int u = prog[c_off + 2 * o + 1] & 0xffff;
       const double* Al = &A[(size_t)(w0 >> 16) * B2];
       const double* Au = &A[(size_t)u * B2];
       double* Ad = &A[(size_t)(w0 & 0xffffu) * B2];

@@ -25,8 +25,8 @@ def emul():
 
 @pytest.mark.parametrize("name", ["rte_case5_example", "l2rpn_case14_sandbox", "l2rpn_neurips_2020_track1",
                                   "l2rpn_wcci_2022_dev"])
-@pytest.mark.parametrize("BS", [2, 4])
-def test_program_reproduces_dense_solve(emul, load_model, name, BS):
+@pytest.mark.parametrize("BS,fused", [(2, 0), (2, 1), (4, 0), (3, 1)])
+def test_program_reproduces_dense_solve(emul, load_model, name, BS, fused):
     m = load_model(name)
     n = m.n_sub
     N = n * BS
@@ -46,7 +46,7 @@ def test_program_reproduces_dense_solve(emul, load_model, name, BS):
     lex = np.ascontiguousarray(m.line_ex_sub, dtype=np.int32)
     ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
     rc = emul.sym_emul_solve(n, m.n_line, lor.ctypes.data_as(ip), lex.ctypes.data_as(ip), BS, A.ctypes.data_as(dp),
-                             rhs.ctypes.data_as(dp), x.ctypes.data_as(dp), stats.ctypes.data_as(ip))
+                             rhs.ctypes.data_as(dp), x.ctypes.data_as(dp), stats.ctypes.data_as(ip), fused)
     assert rc >= 1
     ref = np.linalg.solve(A, rhs)
     assert np.abs(x - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
