@@ -161,45 +161,73 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
     // 2x2 blocks: ONE phase per level.  The pivot inverse is recomputed by every item from the (never overwritten)
     // diagonal block, A[dst] -= A[l] * inv(D_p) * A[u] and rhs[row] -= A[l] * inv(D_p) * b_p; the scaling
     // U' = inv(D) * A_u, b' = inv(D) * b needed by the back substitution is deferred to one fully parallel pass.
-    for (int lv = 0; lv < S.n_levels; ++lv) {
-      const int* h = prog + 8 * lv;
-      const int c_off = h[4], n_c = h[5], r_off = h[6], n_r = h[7];
-      for (int it = tid; it < n_c * 4; it += WAVE) {
-        const int o = it >> 2, r = (it >> 1) & 1, q = it & 1;
-        const unsigned w0 = (unsigned)prog[c_off + 2 * o], w1 = (unsigned)prog[c_off + 2 * o + 1];
-        const double* D = A + (size_t)(w1 >> 16) * 4;
-        const double* Al = A + (size_t)(w0 >> 16) * 4 + r * 2;
-        const double* Au = A + (size_t)(w1 & 0xffffu) * 4 + q;
-        const double d0 = D[0], d1 = D[1], d2 = D[2], d3 = D[3];
-        const double al0 = Al[0], al1 = Al[1], au0 = Au[0], au1 = Au[2];
-        const double rd = fast_rcp(fma(d0, d3, -d1 * d2));
-        const double t0 = fma(al0, d3, -al1 * d2), t1 = fma(al1, d0, -al0 * d1);
-        atomicAdd(&A[(size_t)(w0 & 0xffffu) * 4 + r * 2 + q], -fma(t0, au0, t1 * au1) * rd);
+    // Every level is one barrier-delimited phase whose latency is a chain of dependent LDS round trips, so the chain is
+    // kept as short as possible: trailing updates (c) and right-hand-side updates (r) are ONE item list (r-items follow the
+    // c-items in the program), and the level header / the first item words of the NEXT levels are prefetched while the
+    // current level computes.  Per level: operand reads -> ~10 dependent f64 ops -> ds_add_f64 -> barrier.
+    const int n_levels = S.n_levels;
+    const int4* H = reinterpret_cast<const int4*>(prog);            // level lv: H[2 * lv + 1] = {c_off, n_c, r_off, n_r}
+    auto item_words = [&](const int4& h, int o, unsigned& w0, unsigned& w1) {
+      const bool on = o < h.y + h.w;
+      const int at = h.x + 2 * (on ? o : 0);
+      w0 = (unsigned)prog[at]; w1 = (unsigned)prog[at + 1];
+    };
+    auto do_item = [&](const int4& h, int o, unsigned w0, unsigned w1) {
+      if (o >= h.y + h.w) return;
+      const bool is_c = o < h.y;
+      const unsigned l = is_c ? (w0 >> 16) : (w0 & 0xffffu), dd = is_c ? (w0 & 0xffffu) : (w0 >> 16);
+      const unsigned p = is_c ? (w1 >> 16) : w1, u = w1 & 0xffffu;
+      const double2* D = reinterpret_cast<const double2*>(A + (size_t)p * 4);
+      const double2* Al = reinterpret_cast<const double2*>(A + (size_t)l * 4);
+      const double2* U = is_c ? reinterpret_cast<const double2*>(A + (size_t)u * 4) : reinterpret_cast<const double2*>(rhs + (size_t)p * 2);
+      const double2 dA = D[0], dB = D[1], lA = Al[0], lB = Al[1], uA = U[0];
+      double2 uB = make_double2(uA.y, 0.0);                       // r-item: the operand is the column vector b_p
+      if (is_c) uB = U[1];
+      const double rd = -fast_rcp(fma(dA.x, dB.y, -dA.y * dB.x));
+      // T = A_l * adj(D)
+      const double t00 = fma(lA.x, dB.y, -lA.y * dB.x), t01 = fma(lA.y, dA.x, -lA.x * dA.y);
+      const double t10 = fma(lB.x, dB.y, -lB.y * dB.x), t11 = fma(lB.y, dA.x, -lB.x * dA.y);
+      const double x0 = fma(t00, uA.x, t01 * uB.x) * rd, x1 = fma(t10, uA.x, t11 * uB.x) * rd;
+      if (is_c) {
+        double* dst = A + (size_t)dd * 4;
+        atomicAdd(&dst[0], x0);
+        atomicAdd(&dst[2], x1);
+        atomicAdd(&dst[1], fma(t00, uA.y, t01 * uB.y) * rd);
+        atomicAdd(&dst[3], fma(t10, uA.y, t11 * uB.y) * rd);
+      } else {
+        double* dst = rhs + (size_t)dd * 2;
+        atomicAdd(&dst[0], x0);
+        atomicAdd(&dst[1], x1);
       }
-      for (int it = tid; it < n_r * 2; it += WAVE) {
-        const int o = it >> 1, r = it & 1;
-        const unsigned w0 = (unsigned)prog[r_off + 2 * o];
-        const int p = prog[r_off + 2 * o + 1];
-        const double* D = A + (size_t)p * 4;
-        const double* Al = A + (size_t)(w0 & 0xffffu) * 4 + r * 2;
-        const double d0 = D[0], d1 = D[1], d2 = D[2], d3 = D[3];
-        const double al0 = Al[0], al1 = Al[1], b0 = rhs[(size_t)p * 2], b1 = rhs[(size_t)p * 2 + 1];
-        const double rd = fast_rcp(fma(d0, d3, -d1 * d2));
-        const double t0 = fma(al0, d3, -al1 * d2), t1 = fma(al1, d0, -al0 * d1);
-        atomicAdd(&rhs[(size_t)(w0 >> 16) * 2 + r], -fma(t0, b0, t1 * b1) * rd);
+    };
+    int4 h0 = H[1], h1 = n_levels > 1 ? H[3] : make_int4(0, 0, 0, 0);
+    unsigned w0, w1;
+    item_words(h0, tid, w0, w1);
+    for (int lv = 0; lv < n_levels; ++lv) {
+      const int4 h2 = lv + 2 < n_levels ? H[2 * (lv + 2) + 1] : make_int4(0, 0, 0, 0);
+      unsigned nw0, nw1;
+      item_words(h1, tid, nw0, nw1);                               // first-pass words of the next level
+      do_item(h0, tid, w0, w1);
+      for (int o = tid + WAVE; o < h0.y + h0.w; o += WAVE) {
+        unsigned v0, v1;
+        item_words(h0, o, v0, v1);
+        do_item(h0, o, v0, v1);
       }
       __syncthreads();
+#ifdef GPF_TIMING
+      if (dbg && tid == 0 && lv < 8) dbg[2 + lv] = (double)((long long)__builtin_readcyclecounter() - t_lu0);
+#endif
+      h0 = h1; h1 = h2; w0 = nw0; w1 = nw1;
     }
-    // deferred scaling (one item per block column / per pivot: no read-write overlap between items)
-    for (int it = tid; it < S.n_scale * 2; it += WAVE) {
-      const unsigned w = (unsigned)prog[S.scale_off + (it >> 1)];
-      const int q = it & 1;
-      const double* D = A + (size_t)(w >> 16) * 4;
-      double* Au = A + (size_t)(w & 0xffffu) * 4 + q;
-      const double d0 = D[0], d1 = D[1], d2 = D[2], d3 = D[3], a0 = Au[0], a1 = Au[2];
-      const double rd = fast_rcp(fma(d0, d3, -d1 * d2));
-      Au[0] = fma(d3, a0, -d1 * a1) * rd;
-      Au[2] = fma(d0, a1, -d2 * a0) * rd;
+    // deferred scaling (one item per U block / per pivot: no read-write overlap between items)
+    for (int e = tid; e < S.n_scale; e += WAVE) {
+      const unsigned w = (unsigned)prog[S.scale_off + e];
+      const double2* D = reinterpret_cast<const double2*>(A + (size_t)(w >> 16) * 4);
+      double2* Au = reinterpret_cast<double2*>(A + (size_t)(w & 0xffffu) * 4);
+      const double2 dA = D[0], dB = D[1], uA = Au[0], uB = Au[1];
+      const double rd = fast_rcp(fma(dA.x, dB.y, -dA.y * dB.x));
+      Au[0] = make_double2(fma(dB.y, uA.x, -dA.y * uB.x) * rd, fma(dB.y, uA.y, -dA.y * uB.y) * rd);
+      Au[1] = make_double2(fma(dA.x, uB.x, -dB.x * uA.x) * rd, fma(dA.x, uB.y, -dB.x * uA.y) * rd);
     }
     for (int p = tid; p < S.n; p += WAVE) {
       const double* D = A + (size_t)p * 4;

@@ -34,6 +34,8 @@ struct Symbolic {
   //   c-items     : two ints per trailing update  dst | (l_slot << 16), u_slot | (pivot_sub << 16)
   //                                                 -> A[dst] -= A[l] * Dinv[p] * A[u]
   //   r-items     : two ints per L block          l_slot | (l_row << 16), pivot_sub -> rhs[l_row] -= A[l] * b'[p]
+  //                 (the r-items of a level directly follow its c-items: r_off == c_off + 2 * n_c, the 2x2 device path
+  //                  walks both as one list)
   //   back section: level table [n_levels]{ent_off, n_ent}; entries two ints  u_slot | (u_col << 16), pivot_sub
   //                 -> x[pivot] -= U'[u_slot] * x[u_col]   (all entries of a level run concurrently, LDS atomics)
   std::vector<int> prog;

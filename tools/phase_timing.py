@@ -22,7 +22,7 @@ gold = os.path.join(ROOT, "tests", "golden")
 m = GridModel.load_npz(os.path.join(gold, f"{env}.grid.npz"))
 ch = dict(np.load(os.path.join(gold, f"{env}.chronics.npz")))
 eng = PowerFlowEngine(m, n_lanes=B)
-eng.upload_chronics(eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"] if "prod_v" in ch else None))
+eng.upload_chronics(eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch.get("prod_v", np.ones_like(ch["prod_p"]))))
 eng.set_lane_chronics(lane_offset=(7 * np.arange(B)) % ch["load_p"].shape[0])
 for t in range(5):
     eng.step(t, rebalance=1.02)
@@ -44,6 +44,7 @@ if SPARSE:
         prev = med[k]
     print(f"  {'TOTAL':45s} {med[9] - med[8]:10.0f}")
     print(f"  DC block-LU: elimination levels {med[20]:.0f}, back substitution {med[21]:.0f} cycles")
+    print("  DC block-LU cumulative cycles after forward level k:", [int(v) for v in med[22:30]])
     sys.exit(0)
 names = {8: "kernel start", 0: "K9 chronics gather done / solve start", 1: "K1 topology", 2: "bus types+numbering", 3: "connectivity",
          4: "Ybus + B' assembly", 5: "DC solve", 10: "NR it1: sincos", 11: "NR it1: assembly+check (up to reload it2..)",
