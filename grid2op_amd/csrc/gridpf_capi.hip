@@ -63,6 +63,8 @@ struct LaunchPlan {
   size_t lds;
   int small_nmax;   // 0: generic LDS kernels (v1); 24/32/48/64: register-resident kernels (v2)
   int sparse_nb;    // 0: no; 1..3: block-sparse kernel S with NB busbars per substation block
+  int minw;         // kernel S: __launch_bounds__ waves per SIMD (4 caps the kernel at 128 VGPRs: only worth it when LDS allows > 8 blocks per CU)
+  int ipw;          // kernel S: grid instances per wavefront (1, 2 or 4; > 1 only for NB == 1 on small grids)
   bool sparse_stage; // program staged in LDS (small grids) or streamed from L2 (keeps 3 instances per CU on 118-bus grids)
 };
 
@@ -106,6 +108,8 @@ struct gpf_engine {
   gpf::DevParamsS* d_params_s = nullptr;
   bool params_s_valid = false;
   bool force_sparse = false;   // GRIDPF_FORCE_SPARSE=1
+  int ipw_override = 0;        // GRIDPF_IPW=1|2|4 (developer override of the instances-per-wavefront heuristic)
+  int cap_lanes = 0;           // lane buffers are padded to a multiple of 4 lanes (instance groups of a wavefront)
   bool dense_small_64 = false; // GRIDPF_DENSE64=1: use the dense register kernels up to n = 64 (experiment)
   bool dense_small = false;    // GRIDPF_DENSE=1: dense register-resident kernels (gridpf_small.hpp) for n <= 32
   std::vector<int> lane_mb;    // max live busbars in one substation, per lane
@@ -199,6 +203,8 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
   p.nJ = (nj + 1) & ~1;
   p.small_nmax = 0;
   p.sparse_nb = 0;
+  p.ipw = 1;
+  p.minw = 2;
   p.sparse_stage = false;
   int mb = 1;
   for (int k = lane0; k < lane0 + n; ++k) mb = std::max(mb, e->lane_mb[k]);
@@ -212,7 +218,7 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
                                 : gpf::lds_bytes_small<64, 1>(e->g, p.nbc, p.nJ);
     if (l <= LDS_SMALL_LIMIT) {
 #ifdef GPF_TIMING
-      if (e->work.n < (size_t)e->n_lanes * 32) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->n_lanes * 32)); }
+      if (e->work.n < (size_t)e->cap_lanes * 32) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->cap_lanes * 32)); }
 #endif
       p.small_nmax = nmax;
       p.big = false;
@@ -223,9 +229,16 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
   if (!e->force_generic && e->g.n_sub * mb <= 32000 && e->g.n_busbar <= 3) {
     const int nbk = mb == 1 ? 1 : e->g.n_busbar;
     const int npr = (int)e->sym.prog.size();
+    // small grids do not have 64-wide work: several instances share a wavefront (instance groups, gridpf_sparse.hpp).
+    // Sub-ranges must be group-aligned (or end at the padded tail of the lane buffers).
+    int ipw = 1;
+    if (nbk == 1) {
+      ipw = e->ipw_override ? e->ipw_override : (e->g.n_sub <= 8 ? 4 : e->g.n_sub <= 24 ? 2 : 1);
+      while (ipw > 1 && !(lane0 % ipw == 0 && (n % ipw == 0 || lane0 + n == e->n_lanes))) ipw >>= 1;
+    }
     auto need = [&](int nprog) -> size_t {
       const bool st = nprog > 0;
-      return nbk == 1 ? gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, e->sym.nslot_y, nprog, st)
+      return nbk == 1 ? gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, e->sym.nslot_y, nprog, st, ipw)
            : nbk == 2 ? gpf::lds_bytes_sparse<2>(e->g, e->sym.nslot, e->sym.nslot_y, nprog, st)
                       : gpf::lds_bytes_sparse<3>(e->g, e->sym.nslot, e->sym.nslot_y, nprog, st);
     };
@@ -235,9 +248,11 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
     const size_t l = stage ? l_st : l_gl;
     if (l <= LDS_HARD_LIMIT) {
 #ifdef GPF_TIMING
-      if (e->work.n < (size_t)e->n_lanes * 32) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->n_lanes * 32)); }
+      if (e->work.n < (size_t)e->cap_lanes * 32) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->cap_lanes * 32)); }
 #endif
       p.sparse_nb = nbk;
+      p.ipw = ipw;
+      p.minw = (nbk == 1 && ipw == 1 && LDS_HARD_LIMIT / l >= 12) ? 4 : 2;
       p.sparse_stage = stage;
       p.big = false;
       p.lds = l;
@@ -317,6 +332,29 @@ int drain_events(gpf_engine* e) {
   return GPF_OK;
 }
 
+int reset_lanes_unchecked(gpf_engine* e, int lane0, int n) {
+  HIP_TRY(hipSetDevice(e->device));
+  const gpf::GridDev& g = e->g;
+  // replicate the pristine rows (host staging keeps this a plain strided copy)
+  std::vector<double> inj((size_t)n * g.n_inj);
+  std::vector<int> topo((size_t)n * g.dim_topo), sb((size_t)n * g.n_shunt);
+  for (int k = 0; k < n; ++k) {
+    std::copy(e->h_init_inj.begin(), e->h_init_inj.end(), inj.begin() + (size_t)k * g.n_inj);
+    std::copy(e->h_init_topo.begin(), e->h_init_topo.end(), topo.begin() + (size_t)k * g.dim_topo);
+    if (g.n_shunt) std::copy(e->h_init_shunt_bus.begin(), e->h_init_shunt_bus.end(), sb.begin() + (size_t)k * g.n_shunt);
+  }
+  HIP_TRY(hipMemcpyAsync(e->inj.p + (size_t)lane0 * g.n_inj, inj.data(), inj.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->topo.p + (size_t)lane0 * g.dim_topo, topo.data(), topo.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  if (g.n_shunt)
+    HIP_TRY(hipMemcpyAsync(e->shunt_bus.p + (size_t)lane0 * g.n_shunt, sb.data(), sb.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemsetAsync(e->overflow_count.p + (size_t)lane0 * g.n_line, 0, (size_t)n * g.n_line * sizeof(int), e->stream));
+  HIP_TRY(hipMemsetAsync(e->status.p + (size_t)lane0 * 4, 0xFF, (size_t)n * 4 * sizeof(int), e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (int k = lane0; k < lane0 + n; ++k) { e->lane_nb[k] = e->init_nb; e->lane_nj[k] = e->init_nj; e->lane_mb[k] = e->init_mb; }
+  e->plan_valid = false;
+  return GPF_OK;
+}
+
 bool check_range(gpf_engine* e, int lane0, int n) { return e && lane0 >= 0 && n >= 0 && lane0 + n <= e->n_lanes; }
 
 }  // namespace
@@ -343,6 +381,8 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     e->force_generic = fg && fg[0] == '1';
     const char* fs = std::getenv("GRIDPF_FORCE_SPARSE");
     e->force_sparse = fs && fs[0] == '1';
+    const char* iw = std::getenv("GRIDPF_IPW");
+    e->ipw_override = (iw && (iw[0] == '1' || iw[0] == '2' || iw[0] == '4')) ? iw[0] - '0' : 0;
     const char* dn = std::getenv("GRIDPF_DENSE");
     e->dense_small = dn && dn[0] == '1';
     const char* d64 = std::getenv("GRIDPF_DENSE64");
@@ -352,6 +392,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     e->lpr1 = l1 && l1[0] == '1';
   }
   e->n_lanes = n_lanes;
+  e->cap_lanes = (n_lanes + 3) & ~3;
   gpf::GridDev& g = e->g;
   g.n_sub = d->n_sub; g.n_busbar = d->n_busbar; g.nb_tot = d->n_sub * d->n_busbar;
   g.n_line = d->n_line; g.n_gen = d->n_gen; g.n_load = d->n_load; g.n_sto = d->n_storage; g.n_shunt = d->n_shunt;
@@ -422,7 +463,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   g.gen_slack = e->gen_slack.p; g.load_sub = e->load_sub.p; g.load_pos = e->load_pos.p; g.sto_sub = e->sto_sub.p;
   g.sto_pos = e->sto_pos.p; g.shunt_sub = e->shunt_sub.p; g.shunt_fact = e->shunt_fact.p;
 
-  const size_t B = (size_t)n_lanes;
+  const size_t B = (size_t)e->cap_lanes;   // padded: ghost lanes hold the pristine state and are never read back
   AL(inj, B * g.n_inj); AL(topo, B * g.dim_topo); AL(shunt_bus, B * nsh);
   AL(out, B * g.n_out); AL(topo_out, B * g.dim_topo); AL(shunt_bus_out, B * nsh); AL(line_status, B * nl);
   AL(status, B * 4); AL(bus_vm, B * g.nb_tot); AL(bus_va, B * g.nb_tot);
@@ -433,9 +474,9 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   hipError_t es = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
   if (es != hipSuccess) { gpf_destroy(e); return fail(GPF_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(es)); }
   count_lane(e, e->h_init_topo.data(), nsh ? e->h_init_shunt_bus.data() : nullptr, e->init_nb, e->init_nj, e->init_mb);
-  e->lane_nb.assign(n_lanes, e->init_nb);
-  e->lane_nj.assign(n_lanes, e->init_nj);
-  e->lane_mb.assign(n_lanes, e->init_mb);
+  e->lane_nb.assign(e->cap_lanes, e->init_nb);
+  e->lane_nj.assign(e->cap_lanes, e->init_nj);
+  e->lane_mb.assign(e->cap_lanes, e->init_mb);
   {
     // symbolic analysis of the substation graph for the block-sparse kernels (once per grid)
     e->sym = gpf::build_symbolic(g.n_sub, nl, e->h_line_or_sub.data(), e->h_line_ex_sub.data());
@@ -461,7 +502,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     HIP_TRY(hipStreamSynchronize(e->stream));
   }
   *out_h = e;
-  int rc = gpf_reset_lanes(e, 0, n_lanes);
+  int rc = reset_lanes_unchecked(e, 0, e->cap_lanes);
   if (rc != GPF_OK) { gpf_destroy(e); *out_h = nullptr; return rc; }
   HIP_TRY(hipStreamSynchronize(e->stream));
   return GPF_OK;
@@ -572,26 +613,7 @@ int gpf_disconnect_line(gpf_handle e, int32_t lane, int32_t line_id) {
 
 int gpf_reset_lanes(gpf_handle e, int32_t lane0, int32_t n) {
   if (!check_range(e, lane0, n)) return fail(GPF_E_INVALID, "gpf_reset_lanes: bad range");
-  HIP_TRY(hipSetDevice(e->device));
-  const gpf::GridDev& g = e->g;
-  // replicate the pristine rows (host staging keeps this a plain strided copy)
-  std::vector<double> inj((size_t)n * g.n_inj);
-  std::vector<int> topo((size_t)n * g.dim_topo), sb((size_t)n * g.n_shunt);
-  for (int k = 0; k < n; ++k) {
-    std::copy(e->h_init_inj.begin(), e->h_init_inj.end(), inj.begin() + (size_t)k * g.n_inj);
-    std::copy(e->h_init_topo.begin(), e->h_init_topo.end(), topo.begin() + (size_t)k * g.dim_topo);
-    if (g.n_shunt) std::copy(e->h_init_shunt_bus.begin(), e->h_init_shunt_bus.end(), sb.begin() + (size_t)k * g.n_shunt);
-  }
-  HIP_TRY(hipMemcpyAsync(e->inj.p + (size_t)lane0 * g.n_inj, inj.data(), inj.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipMemcpyAsync(e->topo.p + (size_t)lane0 * g.dim_topo, topo.data(), topo.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
-  if (g.n_shunt)
-    HIP_TRY(hipMemcpyAsync(e->shunt_bus.p + (size_t)lane0 * g.n_shunt, sb.data(), sb.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipMemsetAsync(e->overflow_count.p + (size_t)lane0 * g.n_line, 0, (size_t)n * g.n_line * sizeof(int), e->stream));
-  HIP_TRY(hipMemsetAsync(e->status.p + (size_t)lane0 * 4, 0xFF, (size_t)n * 4 * sizeof(int), e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
-  for (int k = lane0; k < lane0 + n; ++k) { e->lane_nb[k] = e->init_nb; e->lane_nj[k] = e->init_nj; e->lane_mb[k] = e->init_mb; }
-  e->plan_valid = false;
-  return GPF_OK;
+  return reset_lanes_unchecked(e, lane0, n);
 }
 
 int gpf_copy_lanes(gpf_handle e, int32_t src, int32_t dst, int32_t n) {
@@ -642,19 +664,25 @@ int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
   if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
   if (p.sparse_nb) { rc = upload_params_s(e, b); if (rc != GPF_OK) return rc; }
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
-#define LAUNCH_RUNPF_SPARSE(NBK, ST)                                                                                            \
+#define LAUNCH_RUNPF_SPARSE(NBK, ST, IPW, MW)                                                                                           \
   do {                                                                                                                      \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<NBK, ST>),                              \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<NBK, ST, IPW, MW>),                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                   \
-    hipLaunchKernelGGL((gpf::runpf_sparse_kernel<NBK, ST>), dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->d_params_s, lane0,     \
-                       is_dc, max_iter, tol_pu);                                                                            \
+    hipLaunchKernelGGL((gpf::runpf_sparse_kernel<NBK, ST, IPW, MW>), dim3((n + IPW - 1) / IPW), dim3(gpf::WAVE), p.lds, e->stream,  \
+                       e->d_params_s, lane0, is_dc, max_iter, tol_pu);                                                      \
   } while (0)
-  if (p.sparse_nb == 1 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(1, true);
-  else if (p.sparse_nb == 1) LAUNCH_RUNPF_SPARSE(1, false);
-  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(2, true);
-  else if (p.sparse_nb == 2) LAUNCH_RUNPF_SPARSE(2, false);
-  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(3, true);
-  else if (p.sparse_nb == 3) LAUNCH_RUNPF_SPARSE(3, false);
+  if (p.sparse_nb == 1 && p.sparse_stage && p.ipw == 4) LAUNCH_RUNPF_SPARSE(1, true, 4, 2);
+  else if (p.sparse_nb == 1 && p.sparse_stage && p.ipw == 2) LAUNCH_RUNPF_SPARSE(1, true, 2, 2);
+  else if (p.sparse_nb == 1 && p.sparse_stage && p.minw == 4) LAUNCH_RUNPF_SPARSE(1, true, 1, 4);
+  else if (p.sparse_nb == 1 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(1, true, 1, 2);
+  else if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_RUNPF_SPARSE(1, false, 4, 2);
+  else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_RUNPF_SPARSE(1, false, 2, 2);
+  else if (p.sparse_nb == 1 && p.minw == 4) LAUNCH_RUNPF_SPARSE(1, false, 1, 4);
+  else if (p.sparse_nb == 1) LAUNCH_RUNPF_SPARSE(1, false, 1, 2);
+  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(2, true, 1, 2);
+  else if (p.sparse_nb == 2) LAUNCH_RUNPF_SPARSE(2, false, 1, 2);
+  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(3, true, 1, 2);
+  else if (p.sparse_nb == 3) LAUNCH_RUNPF_SPARSE(3, false, 1, 2);
   else
 #define LAUNCH_RUNPF_SMALL(NM, LP)                                                                                              \
   hipLaunchKernelGGL((gpf::runpf_small_kernel<NM, LP>), dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, lane0, p.nbc,   \
@@ -716,7 +744,10 @@ int gpf_set_lane_chronics(gpf_handle e, const int32_t* lane_table, const int32_t
   }
   if (lane_offset) HIP_TRY(hipMemcpyAsync(e->lane_offset.p, lane_offset, B * sizeof(int), hipMemcpyHostToDevice, e->stream));
   if (lane_scale) {
-    if (!e->lane_scale.p) HIP_TRY(e->lane_scale.alloc(B * 2 * e->g.n_load));
+    if (!e->lane_scale.p) {
+      HIP_TRY(e->lane_scale.alloc((size_t)e->cap_lanes * 2 * e->g.n_load));
+      HIP_TRY(hipMemsetAsync(e->lane_scale.p, 0, (size_t)e->cap_lanes * 2 * e->g.n_load * sizeof(float), e->stream));
+    }
     HIP_TRY(hipMemcpyAsync(e->lane_scale.p, lane_scale, B * 2 * e->g.n_load * sizeof(float), hipMemcpyHostToDevice, e->stream));
     e->has_scale = true;
   } else {
@@ -752,19 +783,25 @@ int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double r
   if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
   if (p.sparse_nb) { rc = upload_params_s(e, b); if (rc != GPF_OK) return rc; }
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
-#define LAUNCH_STEP_SPARSE(NBK, ST)                                                                                             \
+#define LAUNCH_STEP_SPARSE(NBK, ST, IPW, MW)                                                                                           \
   do {                                                                                                                      \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<NBK, ST>),                               \
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<NBK, ST, IPW, MW>),                          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                   \
-    hipLaunchKernelGGL((gpf::step_sparse_kernel<NBK, ST>), dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->d_params_s,    \
-                       max_iter, tol_pu, sa);                                                                               \
+    hipLaunchKernelGGL((gpf::step_sparse_kernel<NBK, ST, IPW, MW>), dim3((e->n_lanes + IPW - 1) / IPW), dim3(gpf::WAVE), p.lds,     \
+                       e->stream, e->d_params_s, max_iter, tol_pu, sa);                                                     \
   } while (0)
-  if (p.sparse_nb == 1 && p.sparse_stage) LAUNCH_STEP_SPARSE(1, true);
-  else if (p.sparse_nb == 1) LAUNCH_STEP_SPARSE(1, false);
-  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_STEP_SPARSE(2, true);
-  else if (p.sparse_nb == 2) LAUNCH_STEP_SPARSE(2, false);
-  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_STEP_SPARSE(3, true);
-  else if (p.sparse_nb == 3) LAUNCH_STEP_SPARSE(3, false);
+  if (p.sparse_nb == 1 && p.sparse_stage && p.ipw == 4) LAUNCH_STEP_SPARSE(1, true, 4, 2);
+  else if (p.sparse_nb == 1 && p.sparse_stage && p.ipw == 2) LAUNCH_STEP_SPARSE(1, true, 2, 2);
+  else if (p.sparse_nb == 1 && p.sparse_stage && p.minw == 4) LAUNCH_STEP_SPARSE(1, true, 1, 4);
+  else if (p.sparse_nb == 1 && p.sparse_stage) LAUNCH_STEP_SPARSE(1, true, 1, 2);
+  else if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_STEP_SPARSE(1, false, 4, 2);
+  else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_STEP_SPARSE(1, false, 2, 2);
+  else if (p.sparse_nb == 1 && p.minw == 4) LAUNCH_STEP_SPARSE(1, false, 1, 4);
+  else if (p.sparse_nb == 1) LAUNCH_STEP_SPARSE(1, false, 1, 2);
+  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_STEP_SPARSE(2, true, 1, 2);
+  else if (p.sparse_nb == 2) LAUNCH_STEP_SPARSE(2, false, 1, 2);
+  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_STEP_SPARSE(3, true, 1, 2);
+  else if (p.sparse_nb == 3) LAUNCH_STEP_SPARSE(3, false, 1, 2);
   else
 #define LAUNCH_STEP_SMALL(NM, LP)                                                                                               \
   hipLaunchKernelGGL((gpf::step_small_kernel<NM, LP>), dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, p.nbc,   \

@@ -282,20 +282,21 @@ __device__ inline int build_topology(const GridDev& g, Carve& c, const int* __re
   return nb;
 }
 
+template <int GW = WAVE>
 __device__ inline void write_nan_results(const GridDev& g, const Bufs& b, int inst, int tid) {
   float* out = b.out + (size_t)inst * g.n_out;
   const float nanv = __builtin_nanf("");
-  for (int i = tid; i < g.n_out; i += WAVE) out[i] = nanv;
+  for (int i = tid; i < g.n_out; i += GW) out[i] = nanv;
   int* to = b.topo_out + (size_t)inst * g.dim_topo;
-  for (int i = tid; i < g.dim_topo; i += WAVE) to[i] = -1;
+  for (int i = tid; i < g.dim_topo; i += GW) to[i] = -1;
   int* so = b.shunt_bus_out + (size_t)inst * g.n_shunt;
-  for (int i = tid; i < g.n_shunt; i += WAVE) so[i] = -1;
+  for (int i = tid; i < g.n_shunt; i += GW) so[i] = -1;
   unsigned char* ls = b.line_status + (size_t)inst * g.n_line;
-  for (int i = tid; i < g.n_line; i += WAVE) ls[i] = 0;
+  for (int i = tid; i < g.n_line; i += GW) ls[i] = 0;
   const double nand = __builtin_nan("");
   double* bvm = b.bus_vm + (size_t)inst * g.nb_tot;
   double* bva = b.bus_va + (size_t)inst * g.nb_tot;
-  for (int i = tid; i < g.nb_tot; i += WAVE) { bvm[i] = nand; bva[i] = nand; }
+  for (int i = tid; i < g.nb_tot; i += GW) { bvm[i] = nand; bva[i] = nand; }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(GridDev g, Bufs b, OutOff oo
   while (true) {
     st = solve_instance(g, b, c, oo, inst, nbc, nJ, 0, max_iter, tol_pu, tid, n_iter, nb);
     __syncthreads();
-    if (st != 0 || !sa.cascade) break;
+    if (st != 0 || !sa.cascade || rounds >= sa.max_rounds) break;   // at most max_rounds re-solves
     // K7: Backend.next_grid_state (grid2op/Backend/backend.py:1476-1520)
     int any_disc = 0;
 #pragma unroll
@@ -795,7 +796,6 @@ __global__ __launch_bounds__(WAVE) void step_kernel(GridDev g, Bufs b, OutOff oo
     }
     __syncthreads();
     if (!__any(any_disc)) break;
-    if (rounds >= sa.max_rounds) break;
     ++rounds;
   }
   if (st != 0) write_nan_results(g, b, inst, tid);

@@ -917,7 +917,7 @@ __global__ __launch_bounds__(WAVE, GPF_MINW(NMAX)) void step_small_kernel(const 
   while (true) {
     st = solve_instance_small<NMAX, LPR>(P, c, inst, nbc, nrows, 0, max_iter, tol_pu, tid, true, n_iter, nb);
     __syncthreads();
-    if (st != 0 || !sa.cascade) break;
+    if (st != 0 || !sa.cascade || rounds >= sa.max_rounds) break;   // at most max_rounds re-solves
     int any_disc = 0;
 #pragma unroll
     for (int k = 0; k < MAXK; ++k) {
@@ -938,7 +938,6 @@ __global__ __launch_bounds__(WAVE, GPF_MINW(NMAX)) void step_small_kernel(const 
     }
     __syncthreads();
     if (!__any(any_disc)) break;
-    if (rounds >= sa.max_rounds) break;
     ++rounds;
   }
   GPF_STAMP(9);

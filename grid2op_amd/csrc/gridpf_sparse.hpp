@@ -55,27 +55,32 @@ struct CarveP {
   int* prog;      // [n_prog] LDS copy of the level-scheduled program
 };
 
+// LDS bytes of ONE instance (without the program copy, which is shared by the IPW instances of a block).
 template <int NB>
-__host__ __device__ inline size_t lds_bytes_sparse(const GridDev& g, int nslot, int nslot_y, int n_prog, bool stage_inj) {
+__host__ __device__ inline size_t lds_bytes_instance(const GridDev& g, int nslot, int nslot_y, bool stage_inj) {
   constexpr int BS = 2 * NB;
   const size_t nbus = (size_t)g.n_sub * NB;
   size_t a_d = (size_t)nslot * BS * BS;
-  const size_t topo_d = ((size_t)g.dim_topo + 1) / 2 + 1;
+  const size_t topo_d = (((size_t)g.dim_topo + 1) / 2 + 2) & ~(size_t)1;
   if (a_d < topo_d) a_d = topo_d;
   const size_t nd = a_d + (size_t)nslot_y * NB * NB * 2 + (size_t)g.n_sub * BS + 8 * nbus + (stage_inj ? (size_t)g.n_inj : 0);
-  const size_t ni = nbus + (((size_t)n_prog + 3) & ~(size_t)3);
+  const size_t ni = nbus;
   const size_t n16 = 2 * (size_t)g.n_line + g.n_gen + g.n_load + g.n_sto + g.n_shunt;
-  return nd * 8 + ni * 4 + ((n16 * 2 + g.n_sub + 15) & ~(size_t)15);
+  return (nd * 8 + ni * 4 + n16 * 2 + g.n_sub + 15) & ~(size_t)15;
+}
+// dynamic LDS of a block: IPW instances + (when staged) one copy of the program
+template <int NB>
+__host__ __device__ inline size_t lds_bytes_sparse(const GridDev& g, int nslot, int nslot_y, int n_prog, bool stage_inj, int ipw = 1) {
+  return (size_t)ipw * lds_bytes_instance<NB>(g, nslot, nslot_y, stage_inj) + ((((size_t)n_prog + 3) & ~(size_t)3) * 4);
 }
 
 template <int NB>
-__device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const GridDev& g, int nslot, int nslot_y, int n_prog,
-                                    bool stage_inj) {
+__device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const GridDev& g, int nslot, int nslot_y, bool stage_inj) {
   constexpr int BS = 2 * NB;
   const size_t nbus = (size_t)g.n_sub * NB;
   double* d = reinterpret_cast<double*>(base);
   size_t a_d = (size_t)nslot * BS * BS;
-  const size_t topo_d = ((size_t)g.dim_topo + 1) / 2 + 1;
+  const size_t topo_d = (((size_t)g.dim_topo + 1) / 2 + 2) & ~(size_t)1;
   if (a_d < topo_d) a_d = topo_d;
   c.A = d; c.topo = reinterpret_cast<int*>(d); d += a_d;
   c.Yb = d; d += (size_t)nslot_y * NB * NB * 2;
@@ -86,13 +91,30 @@ __device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const Gr
   c.Sim = d; c.vidx = reinterpret_cast<int*>(d); d += nbus;
   c.inj = d; if (stage_inj) d += g.n_inj;
   int* i = reinterpret_cast<int*>(d);
-  c.prog = i; i += ((size_t)n_prog + 3) & ~(size_t)3;          // 16-byte aligned: headers are read as int4
   c.btype = i; i += nbus;
   i16* q = reinterpret_cast<i16*>(i);
   c.lor_b = q; q += g.n_line; c.lex_b = q; q += g.n_line;
   c.gen_b = q; q += g.n_gen; c.load_b = q; q += g.n_load; c.sto_b = q; q += g.n_sto; c.sh_b = q; q += g.n_shunt;
   c.sub_bb = reinterpret_cast<i8*>(q);
+  c.prog = nullptr;
 }
+
+// Instance groups: a wavefront serves IPW instances, GW = 64 / IPW lanes each (small grids do not have 64-wide work).
+// All groups execute the same instruction stream (same grid, same symbolic program); collectives are scoped to the group.
+template <int IPW>
+struct Grp {
+  static constexpr int GW = WAVE / IPW;
+  static __device__ __forceinline__ unsigned long long mask() {
+    return IPW == 1 ? ~0ull : (((1ull << GW) - 1ull) << ((threadIdx.x / GW) * GW));
+  }
+  static __device__ __forceinline__ bool any(bool x) { return IPW == 1 ? (bool)__any(x) : ((__ballot(x) & mask()) != 0ull); }
+  static __device__ __forceinline__ int count(bool x) { return __popcll(__ballot(x) & mask()); }
+  static __device__ __forceinline__ double sum(double v) {
+#pragma unroll
+    for (int off = GW / 2; off; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+  }
+};
 
 constexpr int BT_OFF = -1;   // inactive bus
 
@@ -147,15 +169,15 @@ __device__ __forceinline__ bool block_inverse(const double (&D)[BS * BS], double
 // Level-scheduled block-sparse LU + solve, in place in LDS.  A: [nslot][BS*BS] blocks; rhs: [n][BS] right-hand
 // side -> solution.  All pivots of a level are eliminated concurrently; trailing updates that hit the same block
 // are combined with LDS f64 atomics.
-template <int BS>
+template <int BS, int GW = WAVE>
 __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ prog, double* __restrict__ A,
                                       double* __restrict__ rhs, int tid, double* dbg = nullptr) {
 #ifdef GPF_TIMING
   const long long t_lu0 = __builtin_readcyclecounter();
 #endif
   constexpr int B2 = BS * BS;
-  constexpr int CHB = (WAVE / B2) * B2;      // U-block items per chunk: whole blocks only
-  constexpr int CHR = (WAVE / BS) * BS;
+  constexpr int CHB = (GW / B2) * B2;      // U-block items per chunk: whole blocks only
+  constexpr int CHR = (GW / BS) * BS;
   bool ok = true;
   if (BS == 2) {
     // 2x2 blocks: ONE phase per level.  The pivot inverse is recomputed by every item from the (never overwritten)
@@ -208,7 +230,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
       unsigned nw0, nw1;
       item_words(h1, tid, nw0, nw1);                               // first-pass words of the next level
       do_item(h0, tid, w0, w1);
-      for (int o = tid + WAVE; o < h0.y + h0.w; o += WAVE) {
+      for (int o = tid + GW; o < h0.y + h0.w; o += GW) {
         unsigned v0, v1;
         item_words(h0, o, v0, v1);
         do_item(h0, o, v0, v1);
@@ -220,7 +242,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
       h0 = h1; h1 = h2; w0 = nw0; w1 = nw1;
     }
     // deferred scaling (one item per U block / per pivot: no read-write overlap between items)
-    for (int e = tid; e < S.n_scale; e += WAVE) {
+    for (int e = tid; e < S.n_scale; e += GW) {
       const unsigned w = (unsigned)prog[S.scale_off + e];
       const double2* D = reinterpret_cast<const double2*>(A + (size_t)(w >> 16) * 4);
       double2* Au = reinterpret_cast<double2*>(A + (size_t)(w & 0xffffu) * 4);
@@ -229,7 +251,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
       Au[0] = make_double2(fma(dB.y, uA.x, -dA.y * uB.x) * rd, fma(dB.y, uA.y, -dA.y * uB.y) * rd);
       Au[1] = make_double2(fma(dA.x, uB.x, -dB.x * uA.x) * rd, fma(dA.x, uB.y, -dB.x * uA.y) * rd);
     }
-    for (int p = tid; p < S.n; p += WAVE) {
+    for (int p = tid; p < S.n; p += GW) {
       const double* D = A + (size_t)p * 4;
       const double d0 = D[0], d1 = D[1], d2 = D[2], d3 = D[3], b0 = rhs[(size_t)p * 2], b1 = rhs[(size_t)p * 2 + 1];
       const double det = fma(d0, d3, -d1 * d2);
@@ -244,7 +266,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
     const int* h = prog + 8 * lv;
     const int piv_off = h[0], n_piv = h[1], b_off = h[2], n_b = h[3], c_off = h[4], n_c = h[5], r_off = h[6], n_r = h[7];
     // (a) invert the pivot blocks in place
-    for (int q = tid; q < n_piv; q += WAVE) {
+    for (int q = tid; q < n_piv; q += GW) {
       double* Ad = A + (size_t)prog[piv_off + q] * B2;      // diag slot of substation p is slot p
       double D[B2], Di[B2];
 #pragma unroll
@@ -256,7 +278,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
     __syncthreads();
     // (b) scale the pivot block rows and right-hand sides: U'_pj = Dinv_p * A_pj, b'_p = Dinv_p * b_p
     //     (items of one block read a whole block column: every pass reads first, then writes)
-    if (n_b * B2 + n_piv * BS <= WAVE) {
+    if (n_b * B2 + n_piv * BS <= GW) {
       const int nu = n_b * B2;
       double acc = 0.0;
       int dst = -1;            // >= 0: A element index; <= -2: rhs element index -(dst+2)
@@ -319,7 +341,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
     }
     }
     // (c) trailing updates A[dst] -= A[l] * U'[u] and rhs[row] -= A[l] * b'[p] (LDS atomics: blocks / rows may collide)
-    for (int it = tid; it < n_c * B2; it += WAVE) {
+    for (int it = tid; it < n_c * B2; it += GW) {
       const int o = it / B2, r = (it % B2) / BS, q = it % BS;
       const unsigned w0 = (unsigned)prog[c_off + 2 * o];
       const int u = prog[c_off + 2 * o + 1] & 0xffff;
@@ -330,7 +352,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
       for (int m = 0; m < BS; ++m) acc = fma(Al[m], Au[m * BS], acc);
       atomicAdd(&A[(size_t)(w0 & 0xffffu) * B2 + r * BS + q], -acc);
     }
-    for (int it = tid; it < n_r * BS; it += WAVE) {
+    for (int it = tid; it < n_r * BS; it += GW) {
       const int o = it / BS, r = it % BS;
       const unsigned w0 = (unsigned)prog[r_off + 2 * o];
       const int p = prog[r_off + 2 * o + 1];
@@ -351,7 +373,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
   // ds_add_f64.
   for (int lv = S.n_levels - 1; lv >= 0; --lv) {
     const int ent_off = prog[S.back_off + 2 * lv], n_ent = prog[S.back_off + 2 * lv + 1];
-    for (int it = tid; it < n_ent * BS; it += WAVE) {
+    for (int it = tid; it < n_ent * BS; it += GW) {
       const unsigned w = (unsigned)prog[ent_off + 2 * (it / BS)];      // u_slot | (u_col << 16)
       const int p = prog[ent_off + 2 * (it / BS) + 1], r = it % BS;
       const double* Au = A + (size_t)(w & 0xffffu) * B2 + r * BS;
@@ -370,9 +392,14 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int NB, bool STAGE>
+// One complete power flow of the IPW instances of a wavefront (tid = lane within the instance group).  Returns the GPF_ST_*
+// status of the caller's group.  Groups share the instruction stream: a group that has failed or finished keeps executing
+// (its state is frozen / its results are overwritten by the caller), so barriers stay wave-uniform.
+template <int NB, bool STAGE, int IPW>
 __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, CarveP<NB>& c, int inst, int is_dc, int max_iter,
                                             double tol_pu, int tid, bool inj_staged, int& n_iter_out, int& nb_out) {
+  typedef Grp<IPW> G;
+  constexpr int GW = G::GW;
   constexpr int BS = 2 * NB;
   constexpr int B2 = BS * BS;
   const GridDev& g = P->g;
@@ -389,22 +416,22 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
   GPF_STAMPS(0);
   const double* __restrict__ inj_g = b.inj + (size_t)inst * g.n_inj;
   if (STAGE && !inj_staged) {
-    for (int i = tid; i < g.n_inj; i += WAVE) c.inj[i] = inj_g[i];
+    for (int i = tid; i < g.n_inj; i += GW) c.inj[i] = inj_g[i];
   }
   const double* __restrict__ inj = STAGE ? (const double*)c.inj : inj_g;
   const double sn = g.sn_mva, inv_sn = 1.0 / sn;
 
   // ---- K1: element -> bus, bus activity / types / injections with LDS atomics from the element lanes ---------------------
-  for (int i = tid; i < g.dim_topo; i += WAVE) c.topo[i] = topo_g[i];
-  for (int i = tid; i < nbus; i += WAVE) {
+  for (int i = tid; i < g.dim_topo; i += GW) c.topo[i] = topo_g[i];
+  for (int i = tid; i < nbus; i += GW) {
     c.btype[i] = BT_OFF; c.vidx[i] = -1;
     c.Psp[i] = 0.0; c.Qsp[i] = 0.0; c.Gs[i] = 0.0;
   }
-  if (NB == 1) for (int i = tid; i < nsub; i += WAVE) c.sub_bb[i] = 1;
+  if (NB == 1) for (int i = tid; i < nsub; i += GW) c.sub_bb[i] = 1;
   __syncthreads();
   const int* topo = c.topo;
   auto bus_of = [&](int sub, int local) -> int { return (NB == 1) ? sub : sub * NB + (local - 1); };
-  for (int l = tid; l < g.n_line; l += WAVE) {
+  for (int l = tid; l < g.n_line; l += GW) {
     const int bo = topo[g.line_or_pos[l]], be = topo[g.line_ex_pos[l]];
     const bool on = (bo >= 1) && (be >= 1);
     const int so = g.line_or_sub[l], se = g.line_ex_sub[l];
@@ -418,7 +445,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       if (NB == 1) { c.sub_bb[so] = (i8)bo; c.sub_bb[se] = (i8)be; }
     }
   }
-  for (int i = tid; i < g.n_gen; i += WAVE) {
+  for (int i = tid; i < g.n_gen; i += GW) {
     const int lb = topo[g.gen_pos[i]];
     const int sb = g.gen_sub[i];
     const int bu = lb >= 1 ? bus_of(sb, lb) : -1;
@@ -431,7 +458,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       if (NB == 1) c.sub_bb[sb] = (i8)lb;
     }
   }
-  for (int i = tid; i < g.n_load; i += WAVE) {
+  for (int i = tid; i < g.n_load; i += GW) {
     const int lb = topo[g.load_pos[i]];
     const int sb = g.load_sub[i];
     const int bu = lb >= 1 ? bus_of(sb, lb) : -1;
@@ -443,7 +470,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       if (NB == 1) c.sub_bb[sb] = (i8)lb;
     }
   }
-  for (int i = tid; i < g.n_sto; i += WAVE) {
+  for (int i = tid; i < g.n_sto; i += GW) {
     const int lb = topo[g.sto_pos[i]];
     const int sb = g.sto_sub[i];
     const int bu = lb >= 1 ? bus_of(sb, lb) : -1;
@@ -455,7 +482,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       if (NB == 1) c.sub_bb[sb] = (i8)lb;
     }
   }
-  for (int i = tid; i < g.n_shunt; i += WAVE) {
+  for (int i = tid; i < g.n_shunt; i += GW) {
     const int lb = shb[i];
     const int sb = g.shunt_sub[i];
     const int bu = lb >= 1 ? bus_of(sb, lb) : -1;
@@ -468,7 +495,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
   }
   __syncthreads();
   int nb = 0, nref = 0;
-  for (int i0 = 0; i0 < nbus; i0 += WAVE) {
+  for (int i0 = 0; i0 < nbus; i0 += GW) {
     const int i = i0 + tid;
     const int bt = i < nbus ? c.btype[i] : BT_OFF;
     if (i < nbus) {
@@ -477,18 +504,19 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       c.vm[i] = (vi >= 0 && (bt == BT_PV || bt == BT_REF)) ? inj[oo.inj_gen_vm + vi] : 1.0;
       c.lab[i] = (bt == BT_REF) ? 1 : 0;
     }
-    nb += __popcll(__ballot(bt != BT_OFF));
-    nref += __popcll(__ballot(bt == BT_REF));
+    nb += G::count(bt != BT_OFF);
+    nref += G::count(bt == BT_REF);
   }
   nb_out = nb;
   __syncthreads();
-  if (nref == 0) return 3;
+  int status = (nref == 0) ? 3 : 0;           // first failure of this group (0 = alive)
+  if (__all(status != 0)) return status;
   GPF_STAMPS(1);
 
   // ---- connectivity ----------------------------------------------------------------------------------------------------
-  for (int sweep = 0; sweep < nb; ++sweep) {
+  for (int sweep = 0; sweep < nbus; ++sweep) {
     int changed = 0;
-    for (int l = tid; l < g.n_line; l += WAVE) {
+    for (int l = tid; l < g.n_line; l += GW) {
       const int f = c.lor_b[l], t = c.lex_b[l];
       if (f >= 0) {
         const int lf = c.lab[f], lt = c.lab[t];
@@ -496,21 +524,22 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       }
     }
     __syncthreads();
-    if (!__any(changed)) break;
+    if (!__any(changed)) break;             // extra sweeps of a settled group are idempotent
   }
   {
     int bad = 0;
-    for (int i = tid; i < nbus; i += WAVE) bad |= (c.btype[i] != BT_OFF && c.lab[i] == 0);
-    if (__any(bad)) return 2;
+    for (int i = tid; i < nbus; i += GW) bad |= (c.btype[i] != BT_OFF && c.lab[i] == 0);
+    if (status == 0 && G::any(bad)) status = 2;
+    if (__all(status != 0)) return status;
   }
   GPF_STAMPS(2);
 
   // ---- K2: block Ybus (original pattern) + K3: DC matrix in the block array, both with LDS atomics ----------------------------
-  for (int i = tid; i < S.nslot_y * NB * NB * 2; i += WAVE) c.Yb[i] = 0.0;
-  for (int i = tid; i < S.nslot * B2; i += WAVE) c.A[i] = 0.0;
+  for (int i = tid; i < S.nslot_y * NB * NB * 2; i += GW) c.Yb[i] = 0.0;
+  for (int i = tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
   __syncthreads();
   auto lidx = [&](int bus) -> int { return (NB == 1) ? 0 : bus % NB; };
-  for (int l = tid; l < g.n_line; l += WAVE) {
+  for (int l = tid; l < g.n_line; l += GW) {
     const int f = c.lor_b[l], t = c.lex_b[l];
     if (f < 0) continue;
     const int bi = lidx(f), bj = lidx(t);
@@ -537,7 +566,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     }
   }
   if (!is_dc) {
-    for (int s = tid; s < g.n_shunt; s += WAVE) {
+    for (int s = tid; s < g.n_shunt; s += GW) {
       const int bu = c.sh_b[s];
       if (bu >= 0) {
         const int bi = lidx(bu);
@@ -551,7 +580,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
   }
   __syncthreads();
   // identity rows (fixed variables) + DC right-hand side
-  for (int i = tid; i < nbus; i += WAVE) {
+  for (int i = tid; i < nbus; i += GW) {
     const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
     const int bt = c.btype[i];
     double* Ad = c.A + (size_t)sub * B2;
@@ -565,11 +594,11 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
   GPF_STAMPS(3);
   {
 #ifdef GPF_TIMING
-    bool ok = block_lu_solve<BS>(S, STAGE ? (const int*)c.prog : S.prog, c.A, c.rhs, tid, P->b.work + (size_t)inst * 32 + 20);
+    bool ok = block_lu_solve<BS, GW>(S, STAGE ? (const int*)c.prog : S.prog, c.A, c.rhs, tid, P->b.work + (size_t)inst * 32 + 20);
 #else
-    bool ok = block_lu_solve<BS>(S, STAGE ? (const int*)c.prog : S.prog, c.A, c.rhs, tid);
+    bool ok = block_lu_solve<BS, GW>(S, STAGE ? (const int*)c.prog : S.prog, c.A, c.rhs, tid);
 #endif
-    for (int i = tid; i < nbus; i += WAVE) {
+    for (int i = tid; i < nbus; i += GW) {
       const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
       const double th = c.rhs[(size_t)sub * BS + 2 * bi];
       const int bt = c.btype[i];
@@ -577,16 +606,18 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       if (bt != BT_OFF && !(fabs(th) < 1e300)) ok = false;
     }
     __syncthreads();
-    if (__any(!ok)) return 4;
+    if (status == 0 && G::any(!ok)) status = 4;
+    if (__all(status != 0)) return status;
   }
   GPF_STAMPS(4);
 
-  int status = 0, it = 0;
+  int it = 0;
   if (!is_dc) {
     bool converged = false;
+    bool done = status != 0;                  // this group takes no further Newton steps (state frozen)
     const int n_pairs = S.nslot_y * NB * NB;
     while (true) {
-      for (int i = tid; i < nbus; i += WAVE) {
+      for (int i = tid; i < nbus; i += GW) {
         double s, co;
         fast_sincos(c.va[i], s, co);
         const double vmi = c.vm[i];
@@ -595,10 +626,10 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
         c.Sre[i] = 0.0;
         c.Sim[i] = 0.0;
       }
-      for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += WAVE) c.A[i] = 0.0;     // fill blocks start at zero
+      for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;     // fill blocks start at zero
       __syncthreads();
       // Jacobian blocks from the Ybus blocks: T_ij = V_i conj(Y_ij V_j); S_i += T_ij (LDS atomics)
-      for (int pr = tid; pr < n_pairs; pr += WAVE) {
+      for (int pr = tid; pr < n_pairs; pr += GW) {
         const int slot = pr / (NB * NB), bi = (pr / NB) % NB, bj = pr % NB;
         const int si = S.slot_row[slot], sj = S.slot_col[slot];
         const int i = si * NB + bi, j = sj * NB + bj;
@@ -623,7 +654,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       __syncthreads();
       double fabs_mis = 0.0;
       bool bad = false;
-      for (int i = tid; i < nbus; i += WAVE) {
+      for (int i = tid; i < nbus; i += GW) {
         const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
         const int bt = c.btype[i];
         const bool rowP = (bt == BT_PQ || bt == BT_PV), rowQ = (bt == BT_PQ);
@@ -641,15 +672,19 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
         if (!(am <= 1e300)) bad = true;
         fabs_mis = fmax(fabs_mis, am);
       }
-      const bool any_ge = __any(!(fabs_mis < tol_pu));
-      if (__any(bad)) { status = 1; break; }
-      if (!any_ge) { converged = true; break; }
-      if (it >= max_iter) break;
-      ++it;
+      if (!done) {
+        const bool any_ge = G::any(!(fabs_mis < tol_pu));
+        if (G::any(bad)) { status = 1; done = true; }
+        else if (!any_ge) { converged = true; done = true; }
+        else if (it >= max_iter) done = true;
+        else ++it;
+      }
+      if (__all(done)) break;
       __syncthreads();
-      const bool ok = block_lu_solve<BS>(S, STAGE ? (const int*)c.prog : S.prog, c.A, c.rhs, tid);
+      const bool ok = block_lu_solve<BS, GW>(S, STAGE ? (const int*)c.prog : S.prog, c.A, c.rhs, tid);
       bool fin = true;
-      for (int i = tid; i < nbus; i += WAVE) {
+      if (!done)
+      for (int i = tid; i < nbus; i += GW) {
         const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
         const int bt = c.btype[i];
         if (bt == BT_OFF) continue;
@@ -664,12 +699,12 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
         c.vm[i] = vm;
       }
       __syncthreads();
-      if (__any(!ok) || __any(!fin)) { status = 4; break; }
+      if (!done && (G::any(!ok) || G::any(!fin))) { status = 4; done = true; }
     }
     if (status == 0 && !converged) status = 1;
   }
   n_iter_out = it;
-  if (status != 0) return status;
+  if (__all(status != 0)) return status;
   GPF_STAMPS(5);
 
   // ---- K6: results ---------------------------------------------------------------------------------------------------------
@@ -678,9 +713,9 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
   const double SQRT3 = 1.7320508075688772935;
   __syncthreads();
   if (is_dc) {
-    for (int i = tid; i < nbus; i += WAVE) { c.Sre[i] = c.Gs[i]; c.Sim[i] = 0.0; }
+    for (int i = tid; i < nbus; i += GW) { c.Sre[i] = c.Gs[i]; c.Sim[i] = 0.0; }
     __syncthreads();
-    for (int l = tid; l < g.n_line; l += WAVE) {
+    for (int l = tid; l < g.n_line; l += GW) {
       const int f = c.lor_b[l], t = c.lex_b[l];
       if (f < 0) continue;
       const double fl = (c.va[f] - c.va[t]) * g.br_bdc[l];
@@ -689,7 +724,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     }
     __syncthreads();
   }
-  for (int l = tid; l < g.n_line; l += WAVE) {
+  for (int l = tid; l < g.n_line; l += GW) {
     const int f = c.lor_b[l], t = c.lex_b[l];
     float p_or = 0.f, q_or = 0.f, v_or = 0.f, a_or = 0.f, th_or = 0.f;
     float p_ex = 0.f, q_ex = 0.f, v_ex = 0.f, a_ex = 0.f, th_ex = 0.f;
@@ -720,7 +755,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     out[oo.p_or + l] = p_or; out[oo.q_or + l] = q_or; out[oo.v_or + l] = v_or; out[oo.a_or + l] = a_or; out[oo.th_or + l] = th_or;
     out[oo.p_ex + l] = p_ex; out[oo.q_ex + l] = q_ex; out[oo.v_ex + l] = v_ex; out[oo.a_ex + l] = a_ex; out[oo.th_ex + l] = th_ex;
   }
-  for (int i = tid; i < g.n_load; i += WAVE) {
+  for (int i = tid; i < g.n_load; i += GW) {
     const int bu = c.load_b[i];
     const bool on = bu >= 0;
     out[oo.load_p + i] = on ? (float)inj[oo.inj_load_p + i] : 0.f;
@@ -728,7 +763,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     out[oo.load_v + i] = on ? (float)(c.vm[bu] * g.sub_vn_kv[g.load_sub[i]]) : 0.f;
     out[oo.load_th + i] = on ? (float)(c.va[bu] * RAD2DEG) : 0.f;
   }
-  for (int i = tid; i < g.n_sto; i += WAVE) {
+  for (int i = tid; i < g.n_sto; i += GW) {
     const int bu = c.sto_b[i];
     const bool on = bu >= 0;
     out[oo.sto_p + i] = on ? (float)inj[oo.inj_sto_p + i] : 0.f;
@@ -737,7 +772,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     out[oo.sto_th + i] = on ? (float)(c.va[bu] * RAD2DEG) : 0.f;
   }
   int* sbo = b.shunt_bus_out + (size_t)inst * g.n_shunt;
-  for (int i = tid; i < g.n_shunt; i += WAVE) {
+  for (int i = tid; i < g.n_shunt; i += GW) {
     const int bu = c.sh_b[i];
     const bool on = bu >= 0;
     const double v = on ? c.vm[bu] : 0.0;
@@ -755,9 +790,9 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     int* cnt = reinterpret_cast<int*>(c.A + 2 * (size_t)nbus);
     int* nsl = cnt + nbus;
     __syncthreads();
-    for (int i = tid; i < nbus; i += WAVE) { qmin_t[i] = 0.0; qmax_t[i] = 0.0; cnt[i] = 0; nsl[i] = 0; }
+    for (int i = tid; i < nbus; i += GW) { qmin_t[i] = 0.0; qmax_t[i] = 0.0; cnt[i] = 0; nsl[i] = 0; }
     __syncthreads();
-    for (int i = tid; i < g.n_gen; i += WAVE) {
+    for (int i = tid; i < g.n_gen; i += GW) {
       const int bu = c.gen_b[i];
       if (bu < 0) continue;
       atomicAdd(&cnt[bu], 1);
@@ -766,7 +801,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       if (g.gen_slack[i]) atomicAdd(&nsl[bu], 1);
     }
     __syncthreads();
-    for (int i = tid; i < g.n_gen; i += WAVE) {
+    for (int i = tid; i < g.n_gen; i += GW) {
       const int bu = c.gen_b[i];
       float gp = 0.f, gq = 0.f, gv = 0.f, gth = 0.f;
       if (bu >= 0) {
@@ -788,15 +823,15 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     }
   }
   int* to = b.topo_out + (size_t)inst * g.dim_topo;
-  for (int i = tid; i < g.dim_topo; i += WAVE) { const int v = topo_g[i]; to[i] = v >= 1 ? v : -1; }
+  for (int i = tid; i < g.dim_topo; i += GW) { const int v = topo_g[i]; to[i] = v >= 1 ? v : -1; }
   __syncthreads();
-  for (int l = tid; l < g.n_line; l += WAVE) {
+  for (int l = tid; l < g.n_line; l += GW) {
     if (c.lor_b[l] < 0) { to[g.line_or_pos[l]] = -1; to[g.line_ex_pos[l]] = -1; }
   }
   double* bvm = b.bus_vm + (size_t)inst * g.nb_tot;
   double* bva = b.bus_va + (size_t)inst * g.nb_tot;
   const double nand = __builtin_nan("");
-  for (int i = tid; i < g.nb_tot; i += WAVE) {
+  for (int i = tid; i < g.nb_tot; i += GW) {
     const int sub = i % nsub, lb = i / nsub + 1;            // global bus = sub + (local-1)*n_sub
     int bu;
     if (NB == 1) bu = (c.sub_bb[sub] == lb) ? sub : -1;
@@ -806,40 +841,47 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     bva[i] = on ? c.va[bu] * RAD2DEG : nand;
   }
   GPF_STAMPS(6);
-  return 0;
+  return status;
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int NB, bool STAGE>
-__global__ __launch_bounds__(WAVE, (NB == 1 ? 4 : 2)) void runpf_sparse_kernel(const DevParamsS* __restrict__ P, int lane0, int is_dc, int max_iter,
+template <int NB, bool STAGE, int IPW, int MINW>
+__global__ __launch_bounds__(WAVE, MINW) void runpf_sparse_kernel(const DevParamsS* __restrict__ P, int lane0, int is_dc, int max_iter,
                                                             double tol_pu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int inst = lane0 + blockIdx.x;
-  const int tid = threadIdx.x;
+  constexpr int GW = WAVE / IPW;
+  const int grp = threadIdx.x / GW, tid = threadIdx.x % GW;
+  const int inst = lane0 + blockIdx.x * IPW + grp;             // the host pads the lane buffers to a multiple of IPW
   CarveP<NB> c;
-  carve_sparse<NB>(c, smem, P->g, P->sym.nslot, P->sym.nslot_y, STAGE ? P->sym.n_prog : 0, STAGE);
+  const size_t per_inst = lds_bytes_instance<NB>(P->g, P->sym.nslot, P->sym.nslot_y, STAGE);
+  carve_sparse<NB>(c, smem + (size_t)grp * per_inst, P->g, P->sym.nslot, P->sym.nslot_y, STAGE);
+  c.prog = reinterpret_cast<int*>(smem + (size_t)IPW * per_inst);
   if (STAGE) for (int i = threadIdx.x; i < P->sym.n_prog; i += WAVE) c.prog[i] = P->sym.prog[i];   // visible after the first barrier
   int n_iter, nb;
-  const int st = solve_instance_sparse<NB, STAGE>(P, c, inst, is_dc, max_iter, tol_pu, tid, false, n_iter, nb);
+  const int st = solve_instance_sparse<NB, STAGE, IPW>(P, c, inst, is_dc, max_iter, tol_pu, tid, false, n_iter, nb);
   __syncthreads();
-  if (st != 0) write_nan_results(P->g, P->b, inst, tid);
+  if (st != 0) write_nan_results<GW>(P->g, P->b, inst, tid);
   if (tid == 0) {
     int* s = P->b.status + (size_t)inst * 4;
     s[0] = st; s[1] = n_iter; s[2] = nb; s[3] = 0;
   }
 }
 
-template <int NB, bool STAGE>
-__global__ __launch_bounds__(WAVE, (NB == 1 ? 4 : 2)) void step_sparse_kernel(const DevParamsS* __restrict__ P, int max_iter, double tol_pu,
+template <int NB, bool STAGE, int IPW, int MINW>
+__global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParamsS* __restrict__ P, int max_iter, double tol_pu,
                                                            StepArgs sa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef Grp<IPW> G;
+  constexpr int GW = G::GW;
   const GridDev& g = P->g;
   const Bufs& b = P->b;
   const OutOff& oo = P->oo;
-  const int inst = blockIdx.x;
-  const int tid = threadIdx.x;
+  const int grp = threadIdx.x / GW, tid = threadIdx.x % GW;
+  const int inst = blockIdx.x * IPW + grp;                     // the host pads the lane buffers to a multiple of IPW
   CarveP<NB> c;
-  carve_sparse<NB>(c, smem, g, P->sym.nslot, P->sym.nslot_y, STAGE ? P->sym.n_prog : 0, STAGE);
+  const size_t per_inst = lds_bytes_instance<NB>(g, P->sym.nslot, P->sym.nslot_y, STAGE);
+  carve_sparse<NB>(c, smem + (size_t)grp * per_inst, g, P->sym.nslot, P->sym.nslot_y, STAGE);
+  c.prog = reinterpret_cast<int*>(smem + (size_t)IPW * per_inst);
   if (STAGE) for (int i = threadIdx.x; i < P->sym.n_prog; i += WAVE) c.prog[i] = P->sym.prog[i];   // visible after the first barrier
   GPF_STAMPS(8);
   {
@@ -850,9 +892,9 @@ __global__ __launch_bounds__(WAVE, (NB == 1 ? 4 : 2)) void step_sparse_kernel(co
     const float* __restrict__ ch = b.chron + ((size_t)tab * sa.T + row) * g.n_chron;
     const float* __restrict__ sc = b.lane_scale ? b.lane_scale + (size_t)inst * 2 * g.n_load : nullptr;
     double* inj_g = b.inj + (size_t)inst * g.n_inj;
-    if (STAGE) for (int i = oo.inj_sto_p + tid; i < g.n_inj; i += WAVE) c.inj[i] = inj_g[i];
+    if (STAGE) for (int i = oo.inj_sto_p + tid; i < g.n_inj; i += GW) c.inj[i] = inj_g[i];
     double sum_load = 0.0, sum_prod = 0.0;
-    for (int i = tid; i < g.n_load; i += WAVE) {
+    for (int i = tid; i < g.n_load; i += GW) {
       float lp = ch[i], lq = ch[g.n_load + i];
       if (sc) { lp *= sc[i]; lq *= sc[g.n_load + i]; }
       if (STAGE) { c.inj[oo.inj_load_p + i] = (double)lp; c.inj[oo.inj_load_q + i] = (double)lq; }
@@ -860,15 +902,15 @@ __global__ __launch_bounds__(WAVE, (NB == 1 ? 4 : 2)) void step_sparse_kernel(co
       inj_g[oo.inj_load_q + i] = (double)lq;
       sum_load += (double)lp;
     }
-    for (int i = tid; i < g.n_gen; i += WAVE)
+    for (int i = tid; i < g.n_gen; i += GW)
       if (!g.gen_slack[i]) sum_prod += (double)ch[2 * g.n_load + i];
     float scale_p = 1.0f;
     if (sa.rebalance_on) {
-      sum_load = wave_sum(sum_load);
-      sum_prod = wave_sum(sum_prod);
+      sum_load = G::sum(sum_load);
+      sum_prod = G::sum(sum_prod);
       scale_p = (sum_prod > 0.0) ? (float)(sa.rebalance * sum_load / sum_prod) : 1.0f;
     }
-    for (int i = tid; i < g.n_gen; i += WAVE) {
+    for (int i = tid; i < g.n_gen; i += GW) {
       float pp = ch[2 * g.n_load + i];
       if (!g.gen_slack[i]) pp *= scale_p;
       const float pv_kv = ch[2 * g.n_load + g.n_gen + i];
@@ -886,18 +928,23 @@ __global__ __launch_bounds__(WAVE, (NB == 1 ? 4 : 2)) void step_sparse_kernel(co
   float* rho = b.rho + (size_t)inst * g.n_line;
   float* out = b.out + (size_t)inst * g.n_out;
   int* topo = b.topo + (size_t)inst * g.dim_topo;
-  for (int l = tid; l < g.n_line; l += WAVE) dround[l] = -1;
+  for (int l = tid; l < g.n_line; l += GW) dround[l] = -1;
   // Backend.next_grid_state keeps a LOCAL copy of the protection counters that is advanced at most once per line
   // and per call (backend.py:1476-1520): local value = ovc + (line already counted this call ? 1 : 0); the "already
   // counted" flag lives in bit 30 of disc_round's scratch twin (rho buffer reused as int scratch until the end).
   int* inc_flag = reinterpret_cast<int*>(rho);
-  if (sa.cascade) for (int l = tid; l < g.n_line; l += WAVE) inc_flag[l] = 0;
+  if (sa.cascade) for (int l = tid; l < g.n_line; l += GW) inc_flag[l] = 0;
+  bool more = true;                                           // this group still cascades
   while (true) {
-    st = solve_instance_sparse<NB, STAGE>(P, c, inst, 0, max_iter, tol_pu, tid, true, n_iter, nb);
+    // a group whose cascade has ended re-solves its unchanged state along with the others (same results)
+    int it_k = 0, nb_k = 0;
+    const int st_k = solve_instance_sparse<NB, STAGE, IPW>(P, c, inst, 0, max_iter, tol_pu, tid, true, it_k, nb_k);
     __syncthreads();
-    if (st != 0 || !sa.cascade) break;
+    if (more) { st = st_k; n_iter = it_k; nb = nb_k; }
+    if (st != 0 || !sa.cascade || rounds >= sa.max_rounds) more = false;   // at most max_rounds re-solves
     int any_disc = 0;
-    for (int l = tid; l < g.n_line; l += WAVE) {
+    if (more)
+    for (int l = tid; l < g.n_line; l += GW) {
       const float a = out[oo.a_or + l];
       const float lim = b.thermal_limit[l];
       const bool on = c.lor_b[l] >= 0;
@@ -913,14 +960,14 @@ __global__ __launch_bounds__(WAVE, (NB == 1 ? 4 : 2)) void step_sparse_kernel(co
       }
     }
     __syncthreads();
-    if (!__any(any_disc)) break;
-    if (rounds >= sa.max_rounds) break;
-    ++rounds;
+    if (more && !G::any(any_disc)) more = false;
+    if (!__any(more)) break;
+    if (more) ++rounds;
   }
   GPF_STAMPS(9);
-  if (st != 0) write_nan_results(g, b, inst, tid);
+  if (st != 0) write_nan_results<GW>(g, b, inst, tid);
   __syncthreads();
-  for (int l = tid; l < g.n_line; l += WAVE) {
+  for (int l = tid; l < g.n_line; l += GW) {
     const float lim = b.thermal_limit[l];
     const float a = out[oo.a_or + l];
     rho[l] = a / lim;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 #include "../grid2op_amd/csrc/gridpf_kernels.hpp"
 #include "../grid2op_amd/csrc/gridpf_sparse.hpp"
@@ -14,17 +15,18 @@ using namespace gpf;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-template <int BS>
+template <int BS, int IPW>
 __global__ __launch_bounds__(64, 4) void lu_kernel(SymDev S, const double* __restrict__ A0, const double* __restrict__ b0, int reps,
                                                     int do_solve, long long* cycles, double* xout) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
+  constexpr int GW = 64 / IPW;
+  const int tid = threadIdx.x, grp = tid / GW, t = tid % GW;
   constexpr int B2 = BS * BS;
-  double* A = reinterpret_cast<double*>(smem);
-  double* Ap = A + (size_t)S.nslot * B2;          // pristine copy
-  double* rhs = Ap + (size_t)S.nslot * B2;
-  double* bp = rhs + (size_t)S.n * BS;
-  int* prog = reinterpret_cast<int*>(bp + (size_t)S.n * BS);
+  double* Ap = reinterpret_cast<double*>(smem);                      // pristine copy (shared by the groups)
+  double* bp = Ap + (size_t)S.nslot * B2;
+  double* A = bp + (size_t)S.n * BS + (size_t)grp * ((size_t)S.nslot * B2 + (size_t)S.n * BS);
+  double* rhs = A + (size_t)S.nslot * B2;
+  int* prog = reinterpret_cast<int*>(bp + (size_t)S.n * BS + (size_t)IPW * ((size_t)S.nslot * B2 + (size_t)S.n * BS));
   for (int i = tid; i < S.nslot * B2; i += 64) Ap[i] = A0[i];
   for (int i = tid; i < S.n * BS; i += 64) bp[i] = b0[i];
   for (int i = tid; i < S.n_prog; i += 64) prog[i] = S.prog[i];
@@ -32,14 +34,42 @@ __global__ __launch_bounds__(64, 4) void lu_kernel(SymDev S, const double* __res
   bool ok = true;
   const long long t0 = __builtin_readcyclecounter();
   for (int r = 0; r < reps; ++r) {
-    for (int i = tid; i < S.nslot * B2; i += 64) A[i] = Ap[i];
-    for (int i = tid; i < S.n * BS; i += 64) rhs[i] = bp[i];
+    for (int i = t; i < S.nslot * B2; i += GW) A[i] = Ap[i];
+    for (int i = t; i < S.n * BS; i += GW) rhs[i] = bp[i];
     __syncthreads();
-    if (do_solve) ok &= block_lu_solve<BS>(S, prog, A, rhs, tid);
+    if (do_solve) ok &= block_lu_solve<BS, GW>(S, prog, A, rhs, t);
   }
   const long long t1 = __builtin_readcyclecounter();
   if (tid == 0) cycles[blockIdx.x] = (t1 - t0) + (ok ? 0 : 1000000000000LL);
-  if (blockIdx.x == 0) for (int i = tid; i < S.n * BS; i += 64) xout[i] = rhs[i];
+  if (blockIdx.x == 0 && grp == IPW - 1) for (int i = t; i < S.n * BS; i += GW) xout[i] = rhs[i];
+}
+
+template <int BS, int IPW>
+void run(const SymDev& D, const Symbolic& S, int n, int instances, int reps, const double* dA, const double* db, double* dx, long long* dcy,
+         double* med) {
+  constexpr int B2 = BS * BS;
+  const int blocks = instances / IPW;
+  const size_t lds = ((size_t)(1 + IPW) * ((size_t)S.nslot * B2 + (size_t)n * BS)) * 8 + S.prog.size() * 4 + 16;
+  CK(hipFuncSetAttribute((const void*)lu_kernel<BS, IPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  printf("IPW=%d: LDS %zu B/block, blocks=%d\n", IPW, lds, blocks);
+  for (int solve = 0; solve < 2; ++solve) {
+    for (int w = 0; w < 2; ++w) {
+      hipLaunchKernelGGL((lu_kernel<BS, IPW>), dim3(blocks), dim3(64), lds, 0, D, dA, db, reps, solve, dcy, dx);
+      CK(hipDeviceSynchronize());
+    }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((lu_kernel<BS, IPW>), dim3(blocks), dim3(64), lds, 0, D, dA, db, reps, solve, dcy, dx);
+    CK(hipEventRecord(e1, 0));
+    CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<long long> cy(blocks);
+    CK(hipMemcpy(cy.data(), dcy, (size_t)blocks * 8, hipMemcpyDeviceToHost));
+    std::sort(cy.begin(), cy.end());
+    med[solve] = (double)cy[blocks / 2] / reps;
+    med[2 + solve] = ms * 1000.0 / reps;
+  }
 }
 
 int main(int argc, char** argv) {
@@ -70,20 +100,12 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&db, b.size() * 8)); CK(hipMemcpy(db, b.data(), b.size() * 8, hipMemcpyHostToDevice));
   CK(hipMalloc(&dx, b.size() * 8)); CK(hipMalloc(&dcy, (size_t)blocks * 8));
   D.prog = dprog;
-  const size_t lds = ((size_t)2 * S.nslot * B2 + (size_t)2 * n * BS) * 8 + S.prog.size() * 4 + 16;
-  CK(hipFuncSetAttribute((const void*)lu_kernel<BS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  printf("n=%d nslot=%d levels=%d prog=%zu ints, LDS %zu B/block, blocks=%d reps=%d\n", n, S.nslot, S.n_levels, S.prog.size(), lds, blocks, reps);
-  double med[2];
-  for (int solve = 0; solve < 2; ++solve) {
-    for (int w = 0; w < 2; ++w) {
-      hipLaunchKernelGGL(lu_kernel<BS>, dim3(blocks), dim3(64), lds, 0, D, dA, db, reps, solve, dcy, dx);
-      CK(hipDeviceSynchronize());
-    }
-    std::vector<long long> cy(blocks);
-    CK(hipMemcpy(cy.data(), dcy, (size_t)blocks * 8, hipMemcpyDeviceToHost));
-    std::sort(cy.begin(), cy.end());
-    med[solve] = (double)cy[blocks / 2] / reps;
-  }
+  const int ipw = argc > 4 ? atoi(argv[4]) : 1;
+  printf("n=%d nslot=%d levels=%d prog=%zu ints, instances=%d reps=%d\n", n, S.nslot, S.n_levels, S.prog.size(), blocks, reps);
+  double med[4];
+  if (ipw == 1) run<BS, 1>(D, S, n, blocks, reps, dA, db, dx, dcy, med);
+  else if (ipw == 2) run<BS, 2>(D, S, n, blocks, reps, dA, db, dx, dcy, med);
+  else run<BS, 4>(D, S, n, blocks, reps, dA, db, dx, dcy, med);
   // check the solution of block 0 against a dense solve
   std::vector<double> x(b.size());
   CK(hipMemcpy(x.data(), dx, b.size() * 8, hipMemcpyDeviceToHost));
@@ -100,6 +122,7 @@ int main(int argc, char** argv) {
   }
   double err = 0;
   for (int i = 0; i < N; ++i) err = fmax(err, fabs(x[i] - M[(size_t)i * (N + 1) + N] / M[(size_t)i * (N + 1) + i]));
-  printf("cycles per rep: restore-only %.0f, restore+solve %.0f  => LU solve %.0f cycles   (max |x - dense| = %.2e)\n", med[0], med[1], med[1] - med[0], err);
+  printf("cycles per rep: restore-only %.0f, restore+solve %.0f  => LU solve %.0f cycles; launch us per rep: %.3f -> %.3f => %.3f us per batched solve  (max |x - dense| = %.2e)\n",
+         med[0], med[1], med[1] - med[0], med[2], med[3], med[3] - med[2], err);
   return 0;
 }
