@@ -30,10 +30,32 @@ struct DevParamsS {
   SymDev sym;
 };
 
+// -DGPF_TIMING developer build: cycle-counter stamps are kept in REGISTERS (a global store per stamp would be waited for
+// at the next barrier and distort the phases) and written to b.work[inst][32] once at the end of the kernel.
 #ifdef GPF_TIMING
-#define GPF_STAMPS(k) do { if (tid == 0) P->b.work[(size_t)inst * 32 + (k)] = (double)(long long)__builtin_readcyclecounter(); } while (0)
+struct Stamps { long long v[32]; };
+#define GPF_STAMPS(k) do { stamps.v[(k)] = (long long)__builtin_readcyclecounter(); } while (0)
+#define GPF_STAMPS_PARAM , Stamps& stamps
+#define GPF_STAMPS_ARG , stamps
+#define GPF_STAMPS_DECL Stamps stamps; for (int k_ = 0; k_ < 32; ++k_) stamps.v[k_] = 0
+#define GPF_STAMPS_FLUSH(inst_) do { if (tid == 0) for (int k_ = 0; k_ < 32; ++k_) P->b.work[(size_t)(inst_) * 32 + k_] = (double)stamps.v[k_]; } while (0)
 #else
 #define GPF_STAMPS(k) do {} while (0)
+#define GPF_STAMPS_PARAM
+#define GPF_STAMPS_ARG
+#define GPF_STAMPS_DECL do {} while (0)
+#define GPF_STAMPS_FLUSH(inst_) do {} while (0)
+#endif
+
+// Phase boundaries.  A block is exactly ONE wavefront and the LDS executes the operations of a wavefront in issue order,
+// so a boundary would only have to order LDS accesses in the COMPILER (wavefront-scope fences, no instruction; unlike
+// __syncthreads() that does not wait for the global stores of the results / injections still in flight)
+// (measured: no difference on MI355X, so __syncthreads() stays the default; -DGPF_WAVE_SYNC selects the fences).
+#ifndef GPF_WAVE_SYNC
+#define GPF_SYNC() __syncthreads()
+#else
+#define GPF_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #endif
 
 typedef short i16;
@@ -171,7 +193,7 @@ __device__ __forceinline__ bool block_inverse(const double (&D)[BS * BS], double
 // are combined with LDS f64 atomics.
 template <int BS, int GW = WAVE>
 __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ prog, double* __restrict__ A,
-                                      double* __restrict__ rhs, int tid, double* dbg = nullptr) {
+                                      double* __restrict__ rhs, int tid, long long* dbg = nullptr) {
 #ifdef GPF_TIMING
   const long long t_lu0 = __builtin_readcyclecounter();
 #endif
@@ -235,10 +257,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
         item_words(h0, o, v0, v1);
         do_item(h0, o, v0, v1);
       }
-      __syncthreads();
-#ifdef GPF_TIMING
-      if (dbg && tid == 0 && lv < 8) dbg[2 + lv] = (double)((long long)__builtin_readcyclecounter() - t_lu0);
-#endif
+      GPF_SYNC();
       h0 = h1; h1 = h2; w0 = nw0; w1 = nw1;
     }
     // deferred scaling (one item per U block / per pivot: no read-write overlap between items)
@@ -260,7 +279,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
       rhs[(size_t)p * 2] = fma(d3, b0, -d1 * b1) * rd;
       rhs[(size_t)p * 2 + 1] = fma(d0, b1, -d2 * b0) * rd;
     }
-    __syncthreads();
+    GPF_SYNC();
   } else
   for (int lv = 0; lv < S.n_levels; ++lv) {
     const int* h = prog + 8 * lv;
@@ -275,7 +294,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
 #pragma unroll
       for (int m = 0; m < B2; ++m) Ad[m] = Di[m];
     }
-    __syncthreads();
+    GPF_SYNC();
     // (b) scale the pivot block rows and right-hand sides: U'_pj = Dinv_p * A_pj, b'_p = Dinv_p * b_p
     //     (items of one block read a whole block column: every pass reads first, then writes)
     if (n_b * B2 + n_piv * BS <= GW) {
@@ -300,10 +319,10 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
         for (int m = 0; m < BS; ++m) acc = fma(Di[m], bp[m], acc);
         dst = -(p * BS + (it % BS)) - 2;
       }
-      __syncthreads();
+      GPF_SYNC();
       if (dst >= 0) A[dst] = acc;
       else if (dst <= -2) rhs[-(dst + 2)] = acc;
-      __syncthreads();
+      GPF_SYNC();
     } else {
     for (int base = 0; base < n_b * B2; base += CHB) {
       const int it = base + tid;
@@ -319,9 +338,9 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
 #pragma unroll
         for (int m = 0; m < BS; ++m) acc = fma(Di[m], Au[m * BS], acc);
       }
-      __syncthreads();
+      GPF_SYNC();
       if (on) A[(size_t)us * B2 + (it % B2)] = acc;
-      __syncthreads();
+      GPF_SYNC();
     }
     for (int base = 0; base < n_piv * BS; base += CHR) {
       const int it = base + tid;
@@ -335,9 +354,9 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
 #pragma unroll
         for (int m = 0; m < BS; ++m) acc = fma(Di[m], bp[m], acc);
       }
-      __syncthreads();
+      GPF_SYNC();
       if (on) rhs[(size_t)p * BS + (it % BS)] = acc;
-      __syncthreads();
+      GPF_SYNC();
     }
     }
     // (c) trailing updates A[dst] -= A[l] * U'[u] and rhs[row] -= A[l] * b'[p] (LDS atomics: blocks / rows may collide)
@@ -363,7 +382,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
       for (int m = 0; m < BS; ++m) acc = fma(Al[m], bp[m], acc);
       atomicAdd(&rhs[(size_t)(w0 >> 16) * BS + r], -acc);
     }
-    __syncthreads();
+    GPF_SYNC();
   }
 #ifdef GPF_TIMING
   const long long t_lu1 = __builtin_readcyclecounter();
@@ -383,10 +402,10 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
       for (int m = 0; m < BS; ++m) acc = fma(Au[m], xj[m], acc);
       atomicAdd(&rhs[(size_t)p * BS + r], -acc);
     }
-    __syncthreads();
+    GPF_SYNC();
   }
 #ifdef GPF_TIMING
-  if (dbg && tid == 0) { dbg[0] = (double)(t_lu1 - t_lu0); dbg[1] = (double)((long long)__builtin_readcyclecounter() - t_lu1); }
+  if (dbg) { dbg[0] = t_lu1 - t_lu0; dbg[1] = (long long)__builtin_readcyclecounter() - t_lu1; }
 #endif
   return ok;
 }
@@ -397,7 +416,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
 // (its state is frozen / its results are overwritten by the caller), so barriers stay wave-uniform.
 template <int NB, bool STAGE, int IPW>
 __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, CarveP<NB>& c, int inst, int is_dc, int max_iter,
-                                            double tol_pu, int tid, bool inj_staged, int& n_iter_out, int& nb_out) {
+                                            double tol_pu, int tid, bool inj_staged, int& n_iter_out, int& nb_out GPF_STAMPS_PARAM) {
   typedef Grp<IPW> G;
   constexpr int GW = G::GW;
   constexpr int BS = 2 * NB;
@@ -428,7 +447,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     c.Psp[i] = 0.0; c.Qsp[i] = 0.0; c.Gs[i] = 0.0;
   }
   if (NB == 1) for (int i = tid; i < nsub; i += GW) c.sub_bb[i] = 1;
-  __syncthreads();
+  GPF_SYNC();
+  GPF_STAMPS(27);
   const int* topo = c.topo;
   auto bus_of = [&](int sub, int local) -> int { return (NB == 1) ? sub : sub * NB + (local - 1); };
   for (int l = tid; l < g.n_line; l += GW) {
@@ -493,7 +513,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       if (NB == 1) c.sub_bb[sb] = (i8)lb;
     }
   }
-  __syncthreads();
+  GPF_SYNC();
+  GPF_STAMPS(28);
   int nb = 0, nref = 0;
   for (int i0 = 0; i0 < nbus; i0 += GW) {
     const int i = i0 + tid;
@@ -508,7 +529,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     nref += G::count(bt == BT_REF);
   }
   nb_out = nb;
-  __syncthreads();
+  GPF_SYNC();
   int status = (nref == 0) ? 3 : 0;           // first failure of this group (0 = alive)
   if (__all(status != 0)) return status;
   GPF_STAMPS(1);
@@ -523,7 +544,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
         if (lf != lt) { c.lab[f] = 1; c.lab[t] = 1; changed = 1; }
       }
     }
-    __syncthreads();
+    GPF_SYNC();
     if (!__any(changed)) break;             // extra sweeps of a settled group are idempotent
   }
   {
@@ -537,7 +558,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
   // ---- K2: block Ybus (original pattern) + K3: DC matrix in the block array, both with LDS atomics ----------------------------
   for (int i = tid; i < S.nslot_y * NB * NB * 2; i += GW) c.Yb[i] = 0.0;
   for (int i = tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
-  __syncthreads();
+  GPF_SYNC();
   auto lidx = [&](int bus) -> int { return (NB == 1) ? 0 : bus % NB; };
   for (int l = tid; l < g.n_line; l += GW) {
     const int f = c.lor_b[l], t = c.lex_b[l];
@@ -578,7 +599,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       }
     }
   }
-  __syncthreads();
+  GPF_SYNC();
   // identity rows (fixed variables) + DC right-hand side
   for (int i = tid; i < nbus; i += GW) {
     const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
@@ -590,11 +611,11 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     c.rhs[(size_t)sub * BS + 2 * bi] = th_live ? (c.Psp[i] - c.Gs[i]) : 0.0;
     c.rhs[(size_t)sub * BS + 2 * bi + 1] = 0.0;
   }
-  __syncthreads();
+  GPF_SYNC();
   GPF_STAMPS(3);
   {
 #ifdef GPF_TIMING
-    bool ok = block_lu_solve<BS, GW>(S, STAGE ? (const int*)c.prog : S.prog, c.A, c.rhs, tid, P->b.work + (size_t)inst * 32 + 20);
+    bool ok = block_lu_solve<BS, GW>(S, STAGE ? (const int*)c.prog : S.prog, c.A, c.rhs, tid, &stamps.v[20]);
 #else
     bool ok = block_lu_solve<BS, GW>(S, STAGE ? (const int*)c.prog : S.prog, c.A, c.rhs, tid);
 #endif
@@ -605,7 +626,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       c.va[i] = (bt == BT_PQ || bt == BT_PV) ? th : 0.0;
       if (bt != BT_OFF && !(fabs(th) < 1e300)) ok = false;
     }
-    __syncthreads();
+    GPF_SYNC();
     if (status == 0 && G::any(!ok)) status = 4;
     if (__all(status != 0)) return status;
   }
@@ -627,7 +648,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
         c.Sim[i] = 0.0;
       }
       for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;     // fill blocks start at zero
-      __syncthreads();
+      GPF_SYNC();
+      if (it == 0) GPF_STAMPS(10);
       // Jacobian blocks from the Ybus blocks: T_ij = V_i conj(Y_ij V_j); S_i += T_ij (LDS atomics)
       for (int pr = tid; pr < n_pairs; pr += GW) {
         const int slot = pr / (NB * NB), bi = (pr / NB) % NB, bj = pr % NB;
@@ -651,7 +673,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
         Ab[BS] = (rowQ && colT) ? -tr_ : 0.0;
         Ab[BS + 1] = (rowQ && colV) ? ti_ * ivmj : 0.0;
       }
-      __syncthreads();
+      GPF_SYNC();
+      if (it == 0) GPF_STAMPS(11);
       double fabs_mis = 0.0;
       bool bad = false;
       for (int i = tid; i < nbus; i += GW) {
@@ -680,8 +703,10 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
         else ++it;
       }
       if (__all(done)) break;
-      __syncthreads();
+      GPF_SYNC();
+      if (it == 1) GPF_STAMPS(12);
       const bool ok = block_lu_solve<BS, GW>(S, STAGE ? (const int*)c.prog : S.prog, c.A, c.rhs, tid);
+      if (it == 1) GPF_STAMPS(13);
       bool fin = true;
       if (!done)
       for (int i = tid; i < nbus; i += GW) {
@@ -698,8 +723,9 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
         c.va[i] = va;
         c.vm[i] = vm;
       }
-      __syncthreads();
+      GPF_SYNC();
       if (!done && (G::any(!ok) || G::any(!fin))) { status = 4; done = true; }
+      if (it == 1) GPF_STAMPS(14);
     }
     if (status == 0 && !converged) status = 1;
   }
@@ -711,10 +737,10 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
   float* out = b.out + (size_t)inst * g.n_out;
   const double RAD2DEG = 57.295779513082320877;
   const double SQRT3 = 1.7320508075688772935;
-  __syncthreads();
+  GPF_SYNC();
   if (is_dc) {
     for (int i = tid; i < nbus; i += GW) { c.Sre[i] = c.Gs[i]; c.Sim[i] = 0.0; }
-    __syncthreads();
+    GPF_SYNC();
     for (int l = tid; l < g.n_line; l += GW) {
       const int f = c.lor_b[l], t = c.lex_b[l];
       if (f < 0) continue;
@@ -722,7 +748,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       atomicAdd(&c.Sre[f], fl);
       atomicAdd(&c.Sre[t], -fl);
     }
-    __syncthreads();
+    GPF_SYNC();
   }
   for (int l = tid; l < g.n_line; l += GW) {
     const int f = c.lor_b[l], t = c.lex_b[l];
@@ -755,6 +781,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     out[oo.p_or + l] = p_or; out[oo.q_or + l] = q_or; out[oo.v_or + l] = v_or; out[oo.a_or + l] = a_or; out[oo.th_or + l] = th_or;
     out[oo.p_ex + l] = p_ex; out[oo.q_ex + l] = q_ex; out[oo.v_ex + l] = v_ex; out[oo.a_ex + l] = a_ex; out[oo.th_ex + l] = th_ex;
   }
+  GPF_STAMPS(22);
   for (int i = tid; i < g.n_load; i += GW) {
     const int bu = c.load_b[i];
     const bool on = bu >= 0;
@@ -784,14 +811,15 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
   // generators (pypower pfsoln): per-bus totals accumulated in LDS with atomics (the block array is dead by now and
   // serves as scratch), then a per-generator pass.  Bus balances: total generation at a bus = S_inj - (P,Q)_spec,
   // i.e. slack P = (Re S - Psp) * sn (Psp already holds +other generators -loads) and Q_gen,total = (Im S - Qsp) * sn.
+  GPF_STAMPS(23);
   {
     double* qmin_t = c.A;
     double* qmax_t = c.A + nbus;
     int* cnt = reinterpret_cast<int*>(c.A + 2 * (size_t)nbus);
     int* nsl = cnt + nbus;
-    __syncthreads();
+    GPF_SYNC();
     for (int i = tid; i < nbus; i += GW) { qmin_t[i] = 0.0; qmax_t[i] = 0.0; cnt[i] = 0; nsl[i] = 0; }
-    __syncthreads();
+    GPF_SYNC();
     for (int i = tid; i < g.n_gen; i += GW) {
       const int bu = c.gen_b[i];
       if (bu < 0) continue;
@@ -800,7 +828,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       atomicAdd(&qmax_t[bu], g.gen_max_q[i]);
       if (g.gen_slack[i]) atomicAdd(&nsl[bu], 1);
     }
-    __syncthreads();
+    GPF_SYNC();
+    GPF_STAMPS(24);
     for (int i = tid; i < g.n_gen; i += GW) {
       const int bu = c.gen_b[i];
       float gp = 0.f, gq = 0.f, gv = 0.f, gth = 0.f;
@@ -822,12 +851,14 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       out[oo.gen_p + i] = gp; out[oo.gen_q + i] = gq; out[oo.gen_v + i] = gv; out[oo.gen_th + i] = gth;
     }
   }
+  GPF_STAMPS(25);
   int* to = b.topo_out + (size_t)inst * g.dim_topo;
   for (int i = tid; i < g.dim_topo; i += GW) { const int v = topo_g[i]; to[i] = v >= 1 ? v : -1; }
-  __syncthreads();
+  GPF_SYNC();
   for (int l = tid; l < g.n_line; l += GW) {
     if (c.lor_b[l] < 0) { to[g.line_or_pos[l]] = -1; to[g.line_ex_pos[l]] = -1; }
   }
+  GPF_STAMPS(26);
   double* bvm = b.bus_vm + (size_t)inst * g.nb_tot;
   double* bva = b.bus_va + (size_t)inst * g.nb_tot;
   const double nand = __builtin_nan("");
@@ -858,8 +889,9 @@ __global__ __launch_bounds__(WAVE, MINW) void runpf_sparse_kernel(const DevParam
   c.prog = reinterpret_cast<int*>(smem + (size_t)IPW * per_inst);
   if (STAGE) for (int i = threadIdx.x; i < P->sym.n_prog; i += WAVE) c.prog[i] = P->sym.prog[i];   // visible after the first barrier
   int n_iter, nb;
-  const int st = solve_instance_sparse<NB, STAGE, IPW>(P, c, inst, is_dc, max_iter, tol_pu, tid, false, n_iter, nb);
-  __syncthreads();
+  GPF_STAMPS_DECL;
+  const int st = solve_instance_sparse<NB, STAGE, IPW>(P, c, inst, is_dc, max_iter, tol_pu, tid, false, n_iter, nb GPF_STAMPS_ARG);
+  GPF_SYNC();
   if (st != 0) write_nan_results<GW>(P->g, P->b, inst, tid);
   if (tid == 0) {
     int* s = P->b.status + (size_t)inst * 4;
@@ -883,6 +915,7 @@ __global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParams
   carve_sparse<NB>(c, smem + (size_t)grp * per_inst, g, P->sym.nslot, P->sym.nslot_y, STAGE);
   c.prog = reinterpret_cast<int*>(smem + (size_t)IPW * per_inst);
   if (STAGE) for (int i = threadIdx.x; i < P->sym.n_prog; i += WAVE) c.prog[i] = P->sym.prog[i];   // visible after the first barrier
+  GPF_STAMPS_DECL;
   GPF_STAMPS(8);
   {
     const int tab = b.lane_table ? b.lane_table[inst] : 0;
@@ -894,6 +927,7 @@ __global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParams
     double* inj_g = b.inj + (size_t)inst * g.n_inj;
     if (STAGE) for (int i = oo.inj_sto_p + tid; i < g.n_inj; i += GW) c.inj[i] = inj_g[i];
     double sum_load = 0.0, sum_prod = 0.0;
+    GPF_STAMPS(16);
     for (int i = tid; i < g.n_load; i += GW) {
       float lp = ch[i], lq = ch[g.n_load + i];
       if (sc) { lp *= sc[i]; lq *= sc[g.n_load + i]; }
@@ -905,11 +939,13 @@ __global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParams
     for (int i = tid; i < g.n_gen; i += GW)
       if (!g.gen_slack[i]) sum_prod += (double)ch[2 * g.n_load + i];
     float scale_p = 1.0f;
+    GPF_STAMPS(17);
     if (sa.rebalance_on) {
       sum_load = G::sum(sum_load);
       sum_prod = G::sum(sum_prod);
       scale_p = (sum_prod > 0.0) ? (float)(sa.rebalance * sum_load / sum_prod) : 1.0f;
     }
+    GPF_STAMPS(18);
     for (int i = tid; i < g.n_gen; i += GW) {
       float pp = ch[2 * g.n_load + i];
       if (!g.gen_slack[i]) pp *= scale_p;
@@ -920,7 +956,7 @@ __global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParams
       inj_g[oo.inj_gen_p + i] = (double)pp;
       inj_g[oo.inj_gen_vm + i] = vm_pu;
     }
-    __syncthreads();
+    GPF_SYNC();
   }
   int n_iter = 0, nb = 0, st = 0, rounds = 0;
   int* ovc = b.overflow_count + (size_t)inst * g.n_line;    // env._protection_counter (persistent)
@@ -938,8 +974,8 @@ __global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParams
   while (true) {
     // a group whose cascade has ended re-solves its unchanged state along with the others (same results)
     int it_k = 0, nb_k = 0;
-    const int st_k = solve_instance_sparse<NB, STAGE, IPW>(P, c, inst, 0, max_iter, tol_pu, tid, true, it_k, nb_k);
-    __syncthreads();
+    const int st_k = solve_instance_sparse<NB, STAGE, IPW>(P, c, inst, 0, max_iter, tol_pu, tid, true, it_k, nb_k GPF_STAMPS_ARG);
+    GPF_SYNC();
     if (more) { st = st_k; n_iter = it_k; nb = nb_k; }
     if (st != 0 || !sa.cascade || rounds >= sa.max_rounds) more = false;   // at most max_rounds re-solves
     int any_disc = 0;
@@ -959,14 +995,14 @@ __global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParams
         any_disc = 1;
       }
     }
-    __syncthreads();
+    GPF_SYNC();
     if (more && !G::any(any_disc)) more = false;
     if (!__any(more)) break;
     if (more) ++rounds;
   }
   GPF_STAMPS(9);
   if (st != 0) write_nan_results<GW>(g, b, inst, tid);
-  __syncthreads();
+  GPF_SYNC();
   for (int l = tid; l < g.n_line; l += GW) {
     const float lim = b.thermal_limit[l];
     const float a = out[oo.a_or + l];
@@ -977,6 +1013,8 @@ __global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParams
     int* s = b.status + (size_t)inst * 4;
     s[0] = st; s[1] = n_iter; s[2] = nb; s[3] = rounds;
   }
+  GPF_STAMPS(15);
+  GPF_STAMPS_FLUSH(inst);
 }
 
 }  // namespace gpf

@@ -376,3 +376,38 @@ def test_full_batch_properties_case14(load_model, load_npz):
         assert st[0, 0] == 0
         assert np.allclose(out_a[k], o[0], rtol=5e-6, atol=2e-4), k
     eng.close()
+
+
+@pytest.mark.parametrize("name,n", [("rte_case5_example", 7), ("l2rpn_case14_sandbox", 7), ("l2rpn_case14_sandbox", 1)])
+def test_instance_groups_ragged_ranges(name, n, load_model):
+    """Small grids run several instances per wavefront (instance groups): lane counts that are not a multiple of the
+    group count, unaligned sub-range solves (untouched neighbours must stay untouched) and wavefronts that mix
+    converging, islanded and diverging lanes must all give the per-lane oracle results."""
+    m = load_model(name)
+    rng = np.random.default_rng(100 + n)
+    states = random_states(m, n, rng)
+    eng = _engine(m, n)
+    inj, topo, sb = _pack(eng, states)
+    eng.set_injections(inj)
+    eng.set_topology(topo, sb)
+    eng.runpf()
+    r = eng.results()
+    ref = [solve(m, s) for s in states]
+    for k in range(n):
+        _compare(m, r, k, ref[k])
+    if n >= 4:
+        # re-solve an unaligned sub-range after changing ALL lanes' injections: only lanes 1..3 may change
+        states2 = random_states(m, n, rng)
+        inj2, topo2, sb2 = _pack(eng, states2)
+        eng.set_injections(inj2)
+        eng.set_topology(topo2, sb2)
+        eng.runpf(lane0=1, n=3)
+        r2 = eng.results()
+        for k in range(n):
+            if 1 <= k <= 3:
+                _compare(m, r2, k, solve(m, states2[k]))
+            else:
+                for f in F32_FIELDS:
+                    assert np.array_equal(getattr(r2, f)[k], getattr(r, f)[k], equal_nan=True), (k, f)
+                assert np.array_equal(r2.status[k], r.status[k])
+    eng.close()

@@ -34,17 +34,23 @@ assert L.gpf_debug_read_work(eng._h, buf.ctypes.data_as(C.POINTER(C.c_double)), 
 SPARSE = os.environ.get("GRIDPF_DENSE") != "1"
 if SPARSE:
     names_s = {8: "kernel start", 0: "K9 chronics gather", 1: "K1 + bus types (atomics)", 2: "connectivity", 3: "Ybus + DC assembly",
-               4: "DC block-LU solve", 5: "Newton loop total", 6: "results", 9: "back in step kernel"}
-    order_s = [8, 0, 1, 2, 3, 4, 5, 6, 9]
+               4: "DC block-LU solve", 5: "Newton loop total", 6: "results", 9: "cascade check / back in step kernel", 15: "rho + counters"}
+    order_s = [8, 0, 1, 2, 3, 4, 5, 6, 9, 15]
     med = np.median(buf, axis=0)
     print(f"[kernel S] {env} batch {B}: median cycle counts per phase")
     prev = med[8]
     for k in order_s[1:]:
         print(f"  {names_s[k]:45s} {med[k] - prev:10.0f}")
         prev = med[k]
-    print(f"  {'TOTAL':45s} {med[9] - med[8]:10.0f}")
-    print(f"  DC block-LU: elimination levels {med[20]:.0f}, back substitution {med[21]:.0f} cycles")
-    print("  DC block-LU cumulative cycles after forward level k:", [int(v) for v in med[22:30]])
+    print(f"  {'TOTAL':45s} {med[15] - med[8]:10.0f}")
+    print(f"  DC block-LU: elimination levels + scaling {med[20]:.0f}, back substitution {med[21]:.0f} cycles")
+    print(f"  first Newton iteration: sincos {med[10] - med[4]:.0f}, Jacobian blocks + S {med[11] - med[10]:.0f}, "
+          f"diag + mismatch + test {med[12] - med[11]:.0f}, block LU {med[13] - med[12]:.0f}, update {med[14] - med[13]:.0f}")
+    print(f"  K9 detail: row address {med[16] - med[8]:.0f}, load rows + sums {med[17] - med[16]:.0f}, reductions {med[18] - med[17]:.0f}, "
+          f"gens + stores {med[0] - med[18]:.0f}")
+    print(f"  K1 detail: topo row -> LDS {med[27] - med[0]:.0f}, element loops (atomics) {med[28] - med[27]:.0f}, types / counts {med[1] - med[28]:.0f}")
+    print(f"  results detail: line flows {med[22] - med[5]:.0f}, loads/storages/shunts {med[23] - med[22]:.0f}, gen accumulate {med[24] - med[23]:.0f}, "
+          f"gen write {med[25] - med[24]:.0f}, topo_out {med[26] - med[25]:.0f}, bus V {med[6] - med[26]:.0f}")
     sys.exit(0)
 names = {8: "kernel start", 0: "K9 chronics gather done / solve start", 1: "K1 topology", 2: "bus types+numbering", 3: "connectivity",
          4: "Ybus + B' assembly", 5: "DC solve", 10: "NR it1: sincos", 11: "NR it1: assembly+check (up to reload it2..)",
