@@ -65,7 +65,7 @@ struct LaunchPlan {
   int sparse_nb;    // 0: no; 1..3: block-sparse kernel S with NB busbars per substation block
   int minw;         // kernel S: __launch_bounds__ waves per SIMD (4 caps the kernel at 128 VGPRs: only worth it when LDS allows > 8 blocks per CU)
   int ipw;          // kernel S: grid instances per wavefront (1, 2 or 4; > 1 only for NB == 1 on small grids)
-  bool sparse_stage; // program staged in LDS (small grids) or streamed from L2 (keeps 3 instances per CU on 118-bus grids)
+  int sparse_stage;  // 0: static tables read in place (L2), 1: program + pair table + injection row in LDS, 2: everything in LDS // program staged in LDS (small grids) or streamed from L2 (keeps 3 instances per CU on 118-bus grids)
 };
 
 struct gpf_engine {
@@ -102,7 +102,8 @@ struct gpf_engine {
   bool force_generic = false;   // GRIDPF_FORCE_GENERIC=1: always use the generic (v1) kernels
   // block-sparse path (kernel S)
   gpf::Symbolic sym;
-  DevArr<int> sym_buf;
+  DevArr<double> stat_dbl;     // static blob of kernel S (gpf::StatOff)
+  DevArr<int> stat_int;
   gpf::SymDev sym_dev{};
   gpf::DevParamsS h_params_s{};
   gpf::DevParamsS* d_params_s = nullptr;
@@ -205,7 +206,7 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
   p.sparse_nb = 0;
   p.ipw = 1;
   p.minw = 2;
-  p.sparse_stage = false;
+  p.sparse_stage = 0;
   int mb = 1;
   for (int k = lane0; k < lane0 + n; ++k) mb = std::max(mb, e->lane_mb[k]);
   // dense register-resident kernels for tiny systems (n <= 32); block-sparse kernel S beyond (3x faster at n = 56)
@@ -228,7 +229,6 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
   }
   if (!e->force_generic && e->g.n_sub * mb <= 32000 && e->g.n_busbar <= 3) {
     const int nbk = mb == 1 ? 1 : e->g.n_busbar;
-    const int npr = (int)e->sym.prog.size();
     // small grids do not have 64-wide work: several instances share a wavefront (instance groups, gridpf_sparse.hpp).
     // Sub-ranges must be group-aligned (or end at the padded tail of the lane buffers).
     int ipw = 1;
@@ -236,16 +236,24 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
       ipw = e->ipw_override ? e->ipw_override : (e->g.n_sub <= 8 ? 4 : e->g.n_sub <= 24 ? 2 : 1);
       while (ipw > 1 && !(lane0 % ipw == 0 && (n % ipw == 0 || lane0 + n == e->n_lanes))) ipw >>= 1;
     }
-    auto need = [&](int nprog) -> size_t {
-      const bool st = nprog > 0;
-      return nbk == 1 ? gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, e->sym.nslot_y, nprog, st, ipw)
-           : nbk == 2 ? gpf::lds_bytes_sparse<2>(e->g, e->sym.nslot, e->sym.nslot_y, nprog, st)
-                      : gpf::lds_bytes_sparse<3>(e->g, e->sym.nslot, e->sym.nslot_y, nprog, st);
+    auto need = [&](int tier) -> size_t {
+      const size_t static_bytes = gpf::stat_bytes(e->sym_dev.so, tier);
+      const bool st = tier > 0;
+      return nbk == 1 ? gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, e->sym.nslot_y, static_bytes, st, ipw)
+           : nbk == 2 ? gpf::lds_bytes_sparse<2>(e->g, e->sym.nslot, e->sym.nslot_y, static_bytes, st)
+                      : gpf::lds_bytes_sparse<3>(e->g, e->sym.nslot, e->sym.nslot_y, static_bytes, st);
     };
-    // stage the program in LDS only when that does not cost occupancy (instances per CU = 160 KiB / footprint)
-    const size_t l_st = need(npr), l_gl = need(0);
-    const bool stage = l_st <= LDS_HARD_LIMIT && (LDS_HARD_LIMIT / l_st == LDS_HARD_LIMIT / l_gl || LDS_HARD_LIMIT / l_st >= 8);
-    const size_t l = stage ? l_st : l_gl;
+    // stage the static tables + the injection row in LDS only when that does not cost residency: blocks per CU
+    // (160 KiB / footprint) must still cover what the launch needs at once, or what the un-staged kernel would get
+    const size_t l_gl = need(0);
+    const size_t n_blocks = ((size_t)n + ipw - 1) / ipw;
+    const size_t want = std::min<size_t>(std::min<size_t>((n_blocks + 255) / 256, LDS_HARD_LIMIT / std::max<size_t>(l_gl, 1)), 8);
+    int stage = 0;
+    const int top_tier = nbk == 1 ? 2 : 1;
+    for (int tier = top_tier; tier >= 1 && !stage; --tier)
+      if (need(tier) <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / need(tier) >= want) stage = tier;
+    if (ipw > 1 && stage != 2) { ipw = 1; stage = 0; for (int tier = 2; tier >= 1 && !stage; --tier) if (need(tier) <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / need(tier) >= want) stage = tier; }
+    const size_t l = need(stage);
     if (l <= LDS_HARD_LIMIT) {
 #ifdef GPF_TIMING
       if (e->work.n < (size_t)e->cap_lanes * 32) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->cap_lanes * 32)); }
@@ -481,16 +489,33 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     // symbolic analysis of the substation graph for the block-sparse kernels (once per grid)
     e->sym = gpf::build_symbolic(g.n_sub, nl, e->h_line_or_sub.data(), e->h_line_ex_sub.data());
     const gpf::Symbolic& S = e->sym;
-    std::vector<int> flat;
-    auto put = [&flat](const std::vector<int>& v) { size_t off = flat.size(); flat.insert(flat.end(), v.begin(), v.end()); return off; };
-    const size_t o_sr = put(S.slot_row), o_sc = put(S.slot_col), o_br = put(S.br_slot), o_pr = put(S.prog);
-    hipError_t eu = e->sym_buf.upload(flat.data(), flat.size());
-    if (eu != hipSuccess) { gpf_destroy(e); return fail(GPF_E_DEVICE, std::string("upload symbolic: ") + hipGetErrorString(eu)); }
     if (S.nslot > 65535 || g.n_sub > 32767) { gpf_destroy(e); return fail(GPF_E_CAPACITY, "grid too large for the 16-bit packed symbolic program"); }
+    // the static blob of kernel S (layout: gpf::StatOff): doubles, then ints
     gpf::SymDev& D = e->sym_dev;
-    const int* base = e->sym_buf.p;
+    gpf::StatOff& so = D.so;
+    std::vector<double> fd;
+    std::vector<int> fi;
+    auto putd = [&fd](const double* v, size_t n) { int off = (int)fd.size(); fd.insert(fd.end(), v, v + n); if (fd.size() & 1) fd.push_back(0.0); return off; };
+    auto puti = [&fi](const int* v, size_t n) { int off = (int)fi.size(); fi.insert(fi.end(), v, v + n); while (fi.size() & 3) fi.push_back(0); return off; };
+    so.br_y = putd(d->br_y, (size_t)8 * nl); so.br_bdc = putd(d->br_bdc, nl); so.sub_vn_kv = putd(d->sub_vn_kv, g.n_sub);
+    so.shunt_fact = putd(d->shunt_fact, nsh); so.gen_min_q = putd(d->gen_min_q, ng); so.gen_max_q = putd(d->gen_max_q, ng);
+    so.prog = puti(S.prog.data(), S.prog.size());                // 16-byte aligned: level headers are read as int4
+    { std::vector<int> rc(S.nslot_y); for (int k = 0; k < S.nslot_y; ++k) rc[k] = S.slot_row[k] | (S.slot_col[k] << 16); so.pair_rc = puti(rc.data(), rc.size()); }
+    so.n_int_hot = (int)fi.size();
+    so.line_or_pos = puti(d->line_or_pos_topo_vect, nl); so.line_ex_pos = puti(d->line_ex_pos_topo_vect, nl);
+    so.line_or_sub = puti(d->line_or_sub, nl); so.line_ex_sub = puti(d->line_ex_sub, nl);
+    so.br_slot = puti(S.br_slot.data(), S.br_slot.size());
+    so.gen_pos = puti(d->gen_pos_topo_vect, ng); so.gen_sub = puti(d->gen_sub, ng);
+    { std::vector<int> sl(ng); for (size_t i = 0; i < ng; ++i) sl[i] = d->gen_slack[i] ? 1 : 0; so.gen_slack = puti(sl.data(), ng); }
+    so.load_pos = puti(d->load_pos_topo_vect, nd); so.load_sub = puti(d->load_sub, nd);
+    so.sto_pos = puti(d->storage_pos_topo_vect, ns); so.sto_sub = puti(d->storage_sub, ns);
+    so.shunt_sub = puti(d->shunt_sub, nsh);
+    so.n_dbl = (int)fd.size(); so.n_int = (int)fi.size();
+    hipError_t eu = e->stat_dbl.upload(fd.data(), fd.size());
+    if (eu == hipSuccess) eu = e->stat_int.upload(fi.data(), fi.size());
+    if (eu != hipSuccess) { gpf_destroy(e); return fail(GPF_E_DEVICE, std::string("upload static tables: ") + hipGetErrorString(eu)); }
     D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.scale_off = S.scale_off; D.n_scale = S.n_scale; D.n_prog = (int)S.prog.size();
-    D.slot_row = base + o_sr; D.slot_col = base + o_sc; D.br_slot = base + o_br; D.prog = base + o_pr;
+    D.stat_dbl = e->stat_dbl.p; D.stat_int = e->stat_int.p; D.prog = e->stat_int.p + so.prog;
   }
   HIP_TRY(hipMemsetAsync(e->status.p, 0xFF, B * 4 * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->overflow_count.p, 0, B * nl * sizeof(int), e->stream));
@@ -524,7 +549,8 @@ int gpf_destroy(gpf_handle e) {
   e->d_init_inj.release(); e->d_init_topo.release(); e->d_init_shunt_bus.release();
   if (e->d_params) (void)hipFree(e->d_params);
   if (e->d_params_s) (void)hipFree(e->d_params_s);
-  e->sym_buf.release();
+  e->stat_dbl.release();
+  e->stat_int.release();
   delete e;
   return GPF_OK;
 }
@@ -671,18 +697,18 @@ int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
     hipLaunchKernelGGL((gpf::runpf_sparse_kernel<NBK, ST, IPW, MW>), dim3((n + IPW - 1) / IPW), dim3(gpf::WAVE), p.lds, e->stream,  \
                        e->d_params_s, lane0, is_dc, max_iter, tol_pu);                                                      \
   } while (0)
-  if (p.sparse_nb == 1 && p.sparse_stage && p.ipw == 4) LAUNCH_RUNPF_SPARSE(1, true, 4, 2);
-  else if (p.sparse_nb == 1 && p.sparse_stage && p.ipw == 2) LAUNCH_RUNPF_SPARSE(1, true, 2, 2);
-  else if (p.sparse_nb == 1 && p.sparse_stage && p.minw == 4) LAUNCH_RUNPF_SPARSE(1, true, 1, 4);
-  else if (p.sparse_nb == 1 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(1, true, 1, 2);
-  else if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_RUNPF_SPARSE(1, false, 4, 2);
-  else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_RUNPF_SPARSE(1, false, 2, 2);
-  else if (p.sparse_nb == 1 && p.minw == 4) LAUNCH_RUNPF_SPARSE(1, false, 1, 4);
-  else if (p.sparse_nb == 1) LAUNCH_RUNPF_SPARSE(1, false, 1, 2);
-  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(2, true, 1, 2);
-  else if (p.sparse_nb == 2) LAUNCH_RUNPF_SPARSE(2, false, 1, 2);
-  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(3, true, 1, 2);
-  else if (p.sparse_nb == 3) LAUNCH_RUNPF_SPARSE(3, false, 1, 2);
+  if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_RUNPF_SPARSE(1, 2, 4, 2);
+  else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_RUNPF_SPARSE(1, 2, 2, 2);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 2 && p.minw == 4) LAUNCH_RUNPF_SPARSE(1, 2, 1, 4);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 2) LAUNCH_RUNPF_SPARSE(1, 2, 1, 2);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 1 && p.minw == 4) LAUNCH_RUNPF_SPARSE(1, 1, 1, 4);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 1) LAUNCH_RUNPF_SPARSE(1, 1, 1, 2);
+  else if (p.sparse_nb == 1 && p.minw == 4) LAUNCH_RUNPF_SPARSE(1, 0, 1, 4);
+  else if (p.sparse_nb == 1) LAUNCH_RUNPF_SPARSE(1, 0, 1, 2);
+  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(2, 1, 1, 2);
+  else if (p.sparse_nb == 2) LAUNCH_RUNPF_SPARSE(2, 0, 1, 2);
+  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(3, 1, 1, 2);
+  else if (p.sparse_nb == 3) LAUNCH_RUNPF_SPARSE(3, 0, 1, 2);
   else
 #define LAUNCH_RUNPF_SMALL(NM, LP)                                                                                              \
   hipLaunchKernelGGL((gpf::runpf_small_kernel<NM, LP>), dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, lane0, p.nbc,   \
@@ -790,18 +816,18 @@ int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double r
     hipLaunchKernelGGL((gpf::step_sparse_kernel<NBK, ST, IPW, MW>), dim3((e->n_lanes + IPW - 1) / IPW), dim3(gpf::WAVE), p.lds,     \
                        e->stream, e->d_params_s, max_iter, tol_pu, sa);                                                     \
   } while (0)
-  if (p.sparse_nb == 1 && p.sparse_stage && p.ipw == 4) LAUNCH_STEP_SPARSE(1, true, 4, 2);
-  else if (p.sparse_nb == 1 && p.sparse_stage && p.ipw == 2) LAUNCH_STEP_SPARSE(1, true, 2, 2);
-  else if (p.sparse_nb == 1 && p.sparse_stage && p.minw == 4) LAUNCH_STEP_SPARSE(1, true, 1, 4);
-  else if (p.sparse_nb == 1 && p.sparse_stage) LAUNCH_STEP_SPARSE(1, true, 1, 2);
-  else if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_STEP_SPARSE(1, false, 4, 2);
-  else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_STEP_SPARSE(1, false, 2, 2);
-  else if (p.sparse_nb == 1 && p.minw == 4) LAUNCH_STEP_SPARSE(1, false, 1, 4);
-  else if (p.sparse_nb == 1) LAUNCH_STEP_SPARSE(1, false, 1, 2);
-  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_STEP_SPARSE(2, true, 1, 2);
-  else if (p.sparse_nb == 2) LAUNCH_STEP_SPARSE(2, false, 1, 2);
-  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_STEP_SPARSE(3, true, 1, 2);
-  else if (p.sparse_nb == 3) LAUNCH_STEP_SPARSE(3, false, 1, 2);
+  if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_STEP_SPARSE(1, 2, 4, 2);
+  else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_STEP_SPARSE(1, 2, 2, 2);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 2 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 2, 1, 4);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 2) LAUNCH_STEP_SPARSE(1, 2, 1, 2);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 1 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 1, 1, 4);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 1) LAUNCH_STEP_SPARSE(1, 1, 1, 2);
+  else if (p.sparse_nb == 1 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 0, 1, 4);
+  else if (p.sparse_nb == 1) LAUNCH_STEP_SPARSE(1, 0, 1, 2);
+  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_STEP_SPARSE(2, 1, 1, 2);
+  else if (p.sparse_nb == 2) LAUNCH_STEP_SPARSE(2, 0, 1, 2);
+  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_STEP_SPARSE(3, 1, 1, 2);
+  else if (p.sparse_nb == 3) LAUNCH_STEP_SPARSE(3, 0, 1, 2);
   else
 #define LAUNCH_STEP_SMALL(NM, LP)                                                                                               \
   hipLaunchKernelGGL((gpf::step_small_kernel<NM, LP>), dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, p.nbc,   \

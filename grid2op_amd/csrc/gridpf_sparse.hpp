@@ -15,12 +15,43 @@
 
 namespace gpf {
 
+// Static (per grid) tables of kernel S live in ONE blob (doubles, then ints) so that a block can stage all of them in LDS
+// with one coalesced copy: every per-element loop of the kernel then starts from LDS reads instead of a chain of dependent
+// L2 / HBM loads.  Offsets are element offsets into the double / int section; the host builds the blob (gridpf_capi.hip).
+struct StatOff {
+  int n_dbl, n_int;
+  int n_int_hot;   // the int section starts with the tables of the Newton loop (prog, pair_rc): staging tier 1 copies only these
+  int br_y, br_bdc, sub_vn_kv, shunt_fact, gen_min_q, gen_max_q;
+  int line_or_pos, line_ex_pos, line_or_sub, line_ex_sub, br_slot, gen_pos, gen_sub, gen_slack, load_pos, load_sub, sto_pos,
+      sto_sub, shunt_sub, pair_rc, prog;
+};
+struct StatView {
+  const double *br_y, *br_bdc, *sub_vn_kv, *shunt_fact, *gen_min_q, *gen_max_q;
+  const int *line_or_pos, *line_ex_pos, *line_or_sub, *line_ex_sub, *br_slot, *gen_pos, *gen_sub, *gen_slack, *load_pos,
+      *load_sub, *sto_pos, *sto_sub, *shunt_sub;
+  const int* pair_rc;   // [nslot_y] slot_row | slot_col << 16 of the original-pattern blocks
+  const int* prog;      // level-scheduled program (layout: gridpf_symbolic.hpp)
+};
+__host__ __device__ inline void stat_view(StatView& v, const StatOff& o, const double* d, const int* i) {
+  v.br_y = d + o.br_y; v.br_bdc = d + o.br_bdc; v.sub_vn_kv = d + o.sub_vn_kv; v.shunt_fact = d + o.shunt_fact;
+  v.gen_min_q = d + o.gen_min_q; v.gen_max_q = d + o.gen_max_q;
+  v.line_or_pos = i + o.line_or_pos; v.line_ex_pos = i + o.line_ex_pos; v.line_or_sub = i + o.line_or_sub;
+  v.line_ex_sub = i + o.line_ex_sub; v.br_slot = i + o.br_slot; v.gen_pos = i + o.gen_pos; v.gen_sub = i + o.gen_sub;
+  v.gen_slack = i + o.gen_slack; v.load_pos = i + o.load_pos; v.load_sub = i + o.load_sub; v.sto_pos = i + o.sto_pos;
+  v.sto_sub = i + o.sto_sub; v.shunt_sub = i + o.shunt_sub; v.pair_rc = i + o.pair_rc; v.prog = i + o.prog;
+}
+// LDS bytes of the staged part of the blob.  tier 0: nothing; 1: the hot ints (+ the lane's injection row, per instance);
+// 2: everything
+__host__ __device__ inline size_t stat_bytes(const StatOff& o, int tier) {
+  return tier == 2 ? (((size_t)o.n_dbl * 8 + (size_t)o.n_int * 4 + 15) & ~(size_t)15) : tier == 1 ? (((size_t)o.n_int_hot * 4 + 15) & ~(size_t)15) : 0;
+}
+
 struct SymDev {
   int n, nslot, nslot_y, n_levels, back_off, n_prog, scale_off, n_scale;
-  const int* slot_row;
-  const int* slot_col;
-  const int* br_slot;   // [n_line][4]
-  const int* prog;      // level-scheduled program (layout: gridpf_symbolic.hpp)
+  const int* prog;          // level-scheduled program in global memory (tools/lu_bench; the kernels use StatView::prog)
+  const double* stat_dbl;   // the static blob: [so.n_dbl] doubles ...
+  const int* stat_int;      // ... and [so.n_int] ints
+  StatOff so;
 };
 
 struct DevParamsS {
@@ -74,7 +105,6 @@ struct CarveP {
   int* topo;      // alias of A during K1
   i16 *lor_b, *lex_b, *gen_b, *load_b, *sto_b, *sh_b;
   i8* sub_bb;     // [n_sub] live busbar (local id) of each substation (NB == 1)
-  int* prog;      // [n_prog] LDS copy of the level-scheduled program
 };
 
 // LDS bytes of ONE instance (without the program copy, which is shared by the IPW instances of a block).
@@ -90,10 +120,30 @@ __host__ __device__ inline size_t lds_bytes_instance(const GridDev& g, int nslot
   const size_t n16 = 2 * (size_t)g.n_line + g.n_gen + g.n_load + g.n_sto + g.n_shunt;
   return (nd * 8 + ni * 4 + n16 * 2 + g.n_sub + 15) & ~(size_t)15;
 }
-// dynamic LDS of a block: IPW instances + (when staged) one copy of the program
+// dynamic LDS of a block: IPW instances + (when staged) one copy of the static blob (stat_bytes, 0 when not staged)
 template <int NB>
-__host__ __device__ inline size_t lds_bytes_sparse(const GridDev& g, int nslot, int nslot_y, int n_prog, bool stage_inj, int ipw = 1) {
-  return (size_t)ipw * lds_bytes_instance<NB>(g, nslot, nslot_y, stage_inj) + ((((size_t)n_prog + 3) & ~(size_t)3) * 4);
+__host__ __device__ inline size_t lds_bytes_sparse(const GridDev& g, int nslot, int nslot_y, size_t static_bytes, bool stage_inj, int ipw = 1) {
+  return (size_t)ipw * lds_bytes_instance<NB>(g, nslot, nslot_y, stage_inj) + static_bytes;
+}
+
+// Stage the static blob in LDS (STAGE) or view it in place; visible to the block after the first barrier.
+template <int STAGE>
+__device__ inline void make_stat_view(StatView& sv, const SymDev& S, unsigned char* lds_static) {
+  if (STAGE == 2) {
+    double* sd = reinterpret_cast<double*>(lds_static);
+    int* si = reinterpret_cast<int*>(sd + S.so.n_dbl);
+    for (int i = threadIdx.x; i < S.so.n_dbl; i += WAVE) sd[i] = S.stat_dbl[i];
+    for (int i = threadIdx.x; i < S.so.n_int; i += WAVE) si[i] = S.stat_int[i];
+    stat_view(sv, S.so, sd, si);
+  } else {
+    stat_view(sv, S.so, S.stat_dbl, S.stat_int);
+    if (STAGE == 1) {
+      int* si = reinterpret_cast<int*>(lds_static);
+      for (int i = threadIdx.x; i < S.so.n_int_hot; i += WAVE) si[i] = S.stat_int[i];
+      sv.prog = si + S.so.prog;
+      sv.pair_rc = si + S.so.pair_rc;
+    }
+  }
 }
 
 template <int NB>
@@ -118,7 +168,6 @@ __device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const Gr
   c.lor_b = q; q += g.n_line; c.lex_b = q; q += g.n_line;
   c.gen_b = q; q += g.n_gen; c.load_b = q; q += g.n_load; c.sto_b = q; q += g.n_sto; c.sh_b = q; q += g.n_shunt;
   c.sub_bb = reinterpret_cast<i8*>(q);
-  c.prog = nullptr;
 }
 
 // Instance groups: a wavefront serves IPW instances, GW = 64 / IPW lanes each (small grids do not have 64-wide work).
@@ -414,9 +463,9 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
 // One complete power flow of the IPW instances of a wavefront (tid = lane within the instance group).  Returns the GPF_ST_*
 // status of the caller's group.  Groups share the instruction stream: a group that has failed or finished keeps executing
 // (its state is frozen / its results are overwritten by the caller), so barriers stay wave-uniform.
-template <int NB, bool STAGE, int IPW>
-__device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, CarveP<NB>& c, int inst, int is_dc, int max_iter,
-                                            double tol_pu, int tid, bool inj_staged, int& n_iter_out, int& nb_out GPF_STAMPS_PARAM) {
+template <int NB, int STAGE, int IPW>
+__device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, const StatView& sv, CarveP<NB>& c, int inst, int is_dc, int max_iter,
+                                            double tol_pu, int tid, bool inj_staged, bool topo_staged, int& n_iter_out, int& nb_out GPF_STAMPS_PARAM) {
   typedef Grp<IPW> G;
   constexpr int GW = G::GW;
   constexpr int BS = 2 * NB;
@@ -441,7 +490,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
   const double sn = g.sn_mva, inv_sn = 1.0 / sn;
 
   // ---- K1: element -> bus, bus activity / types / injections with LDS atomics from the element lanes ---------------------
-  for (int i = tid; i < g.dim_topo; i += GW) c.topo[i] = topo_g[i];
+  if (!topo_staged) for (int i = tid; i < g.dim_topo; i += GW) c.topo[i] = topo_g[i];
   for (int i = tid; i < nbus; i += GW) {
     c.btype[i] = BT_OFF; c.vidx[i] = -1;
     c.Psp[i] = 0.0; c.Qsp[i] = 0.0; c.Gs[i] = 0.0;
@@ -452,13 +501,12 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
   const int* topo = c.topo;
   auto bus_of = [&](int sub, int local) -> int { return (NB == 1) ? sub : sub * NB + (local - 1); };
   for (int l = tid; l < g.n_line; l += GW) {
-    const int bo = topo[g.line_or_pos[l]], be = topo[g.line_ex_pos[l]];
+    const int bo = topo[sv.line_or_pos[l]], be = topo[sv.line_ex_pos[l]];
     const bool on = (bo >= 1) && (be >= 1);
-    const int so = g.line_or_sub[l], se = g.line_ex_sub[l];
+    const int so = sv.line_or_sub[l], se = sv.line_ex_sub[l];
     const int fo = on ? bus_of(so, bo) : -1, fe = on ? bus_of(se, be) : -1;
     c.lor_b[l] = (i16)fo;
     c.lex_b[l] = (i16)fe;
-    lstat[l] = on ? 1 : 0;
     if (on) {
       atomicMax(&c.btype[fo], BT_PQ);
       atomicMax(&c.btype[fe], BT_PQ);
@@ -466,12 +514,12 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     }
   }
   for (int i = tid; i < g.n_gen; i += GW) {
-    const int lb = topo[g.gen_pos[i]];
-    const int sb = g.gen_sub[i];
+    const int lb = topo[sv.gen_pos[i]];
+    const int sb = sv.gen_sub[i];
     const int bu = lb >= 1 ? bus_of(sb, lb) : -1;
     c.gen_b[i] = (i16)bu;
     if (bu >= 0) {
-      const bool sl = g.gen_slack[i] != 0;
+      const bool sl = sv.gen_slack[i] != 0;
       atomicMax(&c.btype[bu], sl ? BT_REF : BT_PV);
       if (!sl) atomicAdd(&c.Psp[bu], inj[oo.inj_gen_p + i] * inv_sn);
       atomicMax(&c.vidx[bu], i);
@@ -479,8 +527,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     }
   }
   for (int i = tid; i < g.n_load; i += GW) {
-    const int lb = topo[g.load_pos[i]];
-    const int sb = g.load_sub[i];
+    const int lb = topo[sv.load_pos[i]];
+    const int sb = sv.load_sub[i];
     const int bu = lb >= 1 ? bus_of(sb, lb) : -1;
     c.load_b[i] = (i16)bu;
     if (bu >= 0) {
@@ -491,8 +539,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     }
   }
   for (int i = tid; i < g.n_sto; i += GW) {
-    const int lb = topo[g.sto_pos[i]];
-    const int sb = g.sto_sub[i];
+    const int lb = topo[sv.sto_pos[i]];
+    const int sb = sv.sto_sub[i];
     const int bu = lb >= 1 ? bus_of(sb, lb) : -1;
     c.sto_b[i] = (i16)bu;
     if (bu >= 0) {
@@ -504,12 +552,12 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
   }
   for (int i = tid; i < g.n_shunt; i += GW) {
     const int lb = shb[i];
-    const int sb = g.shunt_sub[i];
+    const int sb = sv.shunt_sub[i];
     const int bu = lb >= 1 ? bus_of(sb, lb) : -1;
     c.sh_b[i] = (i16)bu;
     if (bu >= 0) {
       atomicMax(&c.btype[bu], BT_PQ);
-      atomicAdd(&c.Gs[bu], inj[oo.inj_sh_p + i] * g.shunt_fact[i] * inv_sn);
+      atomicAdd(&c.Gs[bu], inj[oo.inj_sh_p + i] * sv.shunt_fact[i] * inv_sn);
       if (NB == 1) c.sub_bb[sb] = (i8)lb;
     }
   }
@@ -564,9 +612,9 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     const int f = c.lor_b[l], t = c.lex_b[l];
     if (f < 0) continue;
     const int bi = lidx(f), bj = lidx(t);
-    const int sff = S.br_slot[4 * l + 0], sft = S.br_slot[4 * l + 1], stf = S.br_slot[4 * l + 2], stt = S.br_slot[4 * l + 3];
+    const int sff = sv.br_slot[4 * l + 0], sft = sv.br_slot[4 * l + 1], stf = sv.br_slot[4 * l + 2], stt = sv.br_slot[4 * l + 3];
     if (!is_dc) {
-      const double4* y4 = reinterpret_cast<const double4*>(g.br_y + (size_t)8 * l);
+      const double4* y4 = reinterpret_cast<const double4*>(sv.br_y + (size_t)8 * l);
       const double4 ya = y4[0], yb = y4[1];
       double* y;
       y = c.Yb + ((size_t)sff * NB * NB + bi * NB + bi) * 2; atomicAdd(&y[0], ya.x); atomicAdd(&y[1], ya.y);
@@ -575,7 +623,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       y = c.Yb + ((size_t)stt * NB * NB + bj * NB + bj) * 2; atomicAdd(&y[0], yb.z); atomicAdd(&y[1], yb.w);
     }
     if (f != t) {
-      const double bb = g.br_bdc[l];
+      const double bb = sv.br_bdc[l];
       const bool ff_ = c.btype[f] != BT_REF, tf_ = c.btype[t] != BT_REF;     // theta row / column live?
       const int rf = 2 * bi, rt = 2 * bj;
       if (ff_) atomicAdd(&c.A[(size_t)sff * B2 + rf * BS + rf], bb);
@@ -592,7 +640,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       if (bu >= 0) {
         const int bi = lidx(bu);
         const int sub = (NB == 1) ? bu : bu / NB;
-        const double fct = g.shunt_fact[s] * inv_sn;
+        const double fct = sv.shunt_fact[s] * inv_sn;
         double* y = c.Yb + ((size_t)sub * NB * NB + bi * NB + bi) * 2;       // diag slot of a substation == its index
         atomicAdd(&y[0], inj[oo.inj_sh_p + s] * fct);
         atomicAdd(&y[1], -inj[oo.inj_sh_q + s] * fct);
@@ -615,9 +663,9 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
   GPF_STAMPS(3);
   {
 #ifdef GPF_TIMING
-    bool ok = block_lu_solve<BS, GW>(S, STAGE ? (const int*)c.prog : S.prog, c.A, c.rhs, tid, &stamps.v[20]);
+    bool ok = block_lu_solve<BS, GW>(S, sv.prog, c.A, c.rhs, tid, &stamps.v[20]);
 #else
-    bool ok = block_lu_solve<BS, GW>(S, STAGE ? (const int*)c.prog : S.prog, c.A, c.rhs, tid);
+    bool ok = block_lu_solve<BS, GW>(S, sv.prog, c.A, c.rhs, tid);
 #endif
     for (int i = tid; i < nbus; i += GW) {
       const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
@@ -637,41 +685,44 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     bool converged = false;
     bool done = status != 0;                  // this group takes no further Newton steps (state frozen)
     const int n_pairs = S.nslot_y * NB * NB;
+    // Every phase of the loop is "issue all LDS reads -> compute -> write": the latency of a phase is a chain of dependent
+    // LDS round trips, so read-modify-write sequences inside branches are avoided.  V = e + jf, S = 0 and zeroed fill
+    // blocks are prepared by the phase BEFORE the pair phase (here for the first iteration, then by the update phase).
+    for (int i = tid; i < nbus; i += GW) {
+      const double va = c.va[i], vmi = c.vm[i];
+      double sn_, co;
+      fast_sincos(va, sn_, co);
+      c.e[i] = vmi * co;
+      c.f[i] = vmi * sn_;
+      c.Sre[i] = 0.0;
+      c.Sim[i] = 0.0;
+    }
+    for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;     // fill blocks start at zero
+    GPF_SYNC();
+    GPF_STAMPS(10);
     while (true) {
-      for (int i = tid; i < nbus; i += GW) {
-        double s, co;
-        fast_sincos(c.va[i], s, co);
-        const double vmi = c.vm[i];
-        c.e[i] = vmi * co;
-        c.f[i] = vmi * s;
-        c.Sre[i] = 0.0;
-        c.Sim[i] = 0.0;
-      }
-      for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;     // fill blocks start at zero
-      GPF_SYNC();
-      if (it == 0) GPF_STAMPS(10);
       // Jacobian blocks from the Ybus blocks: T_ij = V_i conj(Y_ij V_j); S_i += T_ij (LDS atomics)
       for (int pr = tid; pr < n_pairs; pr += GW) {
         const int slot = pr / (NB * NB), bi = (pr / NB) % NB, bj = pr % NB;
-        const int si = S.slot_row[slot], sj = S.slot_col[slot];
+        const unsigned rc = (unsigned)sv.pair_rc[slot];
+        const double2 y = *reinterpret_cast<const double2*>(c.Yb + (size_t)pr * 2);
+        const int si = (int)(rc & 0xffffu), sj = (int)(rc >> 16);
         const int i = si * NB + bi, j = sj * NB + bj;
         const int bti = c.btype[i], btj = c.btype[j];
-        const double yr = c.Yb[(size_t)pr * 2], yi = c.Yb[(size_t)pr * 2 + 1];
-        const double ei = c.e[i], fi = c.f[i], ej = c.e[j], fj = c.f[j];
+        const double ei = c.e[i], fi = c.f[i], ej = c.e[j], fj = c.f[j], vmj = c.vm[j];
+        const double yr = y.x, yi = y.y;
         const double aa = yr * ej - yi * fj, bb = yr * fj + yi * ej;
         const double tr_ = ei * aa + fi * bb;
         const double ti_ = fi * aa - ei * bb;
         const bool act = (bti != BT_OFF) && (btj != BT_OFF);
-        if (act && (yr != 0.0 || yi != 0.0)) { atomicAdd(&c.Sre[i], tr_); atomicAdd(&c.Sim[i], ti_); }
         const bool rowP = (bti == BT_PQ || bti == BT_PV), rowQ = (bti == BT_PQ);
         const bool colT = (btj == BT_PQ || btj == BT_PV), colV = (btj == BT_PQ);
-        const double ivmj = fast_rcp(c.vm[j]);
+        const double ivmj = fast_rcp(vmj);
         double* Ab = c.A + (size_t)slot * B2 + (2 * bi) * BS + 2 * bj;
         // [dP/dth dP/dV; dQ/dth dQ/dV] = [Im T, Re T/|Vj|; -Re T, Im T/|Vj|]  (diagonal S-terms are added below)
-        Ab[0] = (rowP && colT) ? ti_ : 0.0;
-        Ab[1] = (rowP && colV) ? tr_ * ivmj : 0.0;
-        Ab[BS] = (rowQ && colT) ? -tr_ : 0.0;
-        Ab[BS + 1] = (rowQ && colV) ? ti_ * ivmj : 0.0;
+        *reinterpret_cast<double2*>(Ab) = make_double2((rowP && colT) ? ti_ : 0.0, (rowP && colV) ? tr_ * ivmj : 0.0);
+        *reinterpret_cast<double2*>(Ab + BS) = make_double2((rowQ && colT) ? -tr_ : 0.0, (rowQ && colV) ? ti_ * ivmj : 0.0);
+        if (act && (yr != 0.0 || yi != 0.0)) { atomicAdd(&c.Sre[i], tr_); atomicAdd(&c.Sim[i], ti_); }
       }
       GPF_SYNC();
       if (it == 0) GPF_STAMPS(11);
@@ -679,18 +730,18 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       bool bad = false;
       for (int i = tid; i < nbus; i += GW) {
         const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
-        const int bt = c.btype[i];
-        const bool rowP = (bt == BT_PQ || bt == BT_PV), rowQ = (bt == BT_PQ);
         double* Ad = c.A + (size_t)sub * B2 + (2 * bi) * BS + 2 * bi;
-        const double Sr = c.Sre[i], Si = c.Sim[i], ivmi = fast_rcp(c.vm[i]);
+        const int bt = c.btype[i];
+        const double Sr = c.Sre[i], Si = c.Sim[i], vmi = c.vm[i], psp = c.Psp[i], qsp = c.Qsp[i];
+        const double2 r0 = *reinterpret_cast<const double2*>(Ad), r1 = *reinterpret_cast<const double2*>(Ad + BS);
+        const bool rowP = (bt == BT_PQ || bt == BT_PV), rowQ = (bt == BT_PQ);
+        const double ivmi = fast_rcp(vmi);
         // dS/dVa_ii += j S_i ; dS/dVm_ii += S_i / |V_i| ; identity on the fixed variables
-        if (rowP) Ad[0] += -Si; else Ad[0] = 1.0;
-        if (rowQ) { Ad[1] += Sr * ivmi; Ad[BS] += Sr; Ad[BS + 1] += Si * ivmi; }
-        else { Ad[BS + 1] = 1.0; if (rowP) { /* PV: dP/dV column is fixed -> 0 */ } }
-        const double mp = rowP ? (Sr - c.Psp[i]) : 0.0;
-        const double mq = rowQ ? (Si - c.Qsp[i]) : 0.0;
-        c.rhs[(size_t)sub * BS + 2 * bi] = -mp;
-        c.rhs[(size_t)sub * BS + 2 * bi + 1] = -mq;
+        *reinterpret_cast<double2*>(Ad) = make_double2(rowP ? r0.x - Si : 1.0, rowQ ? fma(Sr, ivmi, r0.y) : r0.y);
+        *reinterpret_cast<double2*>(Ad + BS) = make_double2(rowQ ? r1.x + Sr : r1.x, rowQ ? fma(Si, ivmi, r1.y) : 1.0);
+        const double mp = rowP ? (Sr - psp) : 0.0;
+        const double mq = rowQ ? (Si - qsp) : 0.0;
+        *reinterpret_cast<double2*>(c.rhs + (size_t)sub * BS + 2 * bi) = make_double2(-mp, -mq);
         const double am = fmax(fabs(mp), fabs(mq));
         if (!(am <= 1e300)) bad = true;
         fabs_mis = fmax(fabs_mis, am);
@@ -705,24 +756,32 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       if (__all(done)) break;
       GPF_SYNC();
       if (it == 1) GPF_STAMPS(12);
-      const bool ok = block_lu_solve<BS, GW>(S, STAGE ? (const int*)c.prog : S.prog, c.A, c.rhs, tid);
+      const bool ok = block_lu_solve<BS, GW>(S, sv.prog, c.A, c.rhs, tid);
       if (it == 1) GPF_STAMPS(13);
+      // update (groups that are done keep their state) + preparation of the next pair phase (every group)
       bool fin = true;
-      if (!done)
       for (int i = tid; i < nbus; i += GW) {
         const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
         const int bt = c.btype[i];
-        if (bt == BT_OFF) continue;
         double va = c.va[i], vm = c.vm[i];
-        const double dth = c.rhs[(size_t)sub * BS + 2 * bi], dv = c.rhs[(size_t)sub * BS + 2 * bi + 1];
-        if (!(fabs(dth) < 1e300) || !(fabs(dv) < 1e300)) fin = false;
-        if (bt == BT_PQ || bt == BT_PV) va += dth;
-        if (bt == BT_PQ) vm += dv;
-        if (vm < 0.0) { vm = -vm; va += 3.14159265358979323846; }
-        if (fabs(va) > 3.14159265358979323846) va = remainder(va, 6.28318530717958647692);
-        c.va[i] = va;
-        c.vm[i] = vm;
+        const double2 dx = *reinterpret_cast<const double2*>(c.rhs + (size_t)sub * BS + 2 * bi);
+        if (!done && bt != BT_OFF) {
+          if (!(fabs(dx.x) < 1e300) || !(fabs(dx.y) < 1e300)) fin = false;
+          if (bt == BT_PQ || bt == BT_PV) va += dx.x;
+          if (bt == BT_PQ) vm += dx.y;
+          if (vm < 0.0) { vm = -vm; va += 3.14159265358979323846; }
+          if (fabs(va) > 3.14159265358979323846) va = remainder(va, 6.28318530717958647692);
+          c.va[i] = va;
+          c.vm[i] = vm;
+        }
+        double sn_, co;
+        fast_sincos(va, sn_, co);
+        c.e[i] = vm * co;
+        c.f[i] = vm * sn_;
+        c.Sre[i] = 0.0;
+        c.Sim[i] = 0.0;
       }
+      for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
       GPF_SYNC();
       if (!done && (G::any(!ok) || G::any(!fin))) { status = 4; done = true; }
       if (it == 1) GPF_STAMPS(14);
@@ -744,7 +803,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     for (int l = tid; l < g.n_line; l += GW) {
       const int f = c.lor_b[l], t = c.lex_b[l];
       if (f < 0) continue;
-      const double fl = (c.va[f] - c.va[t]) * g.br_bdc[l];
+      const double fl = (c.va[f] - c.va[t]) * sv.br_bdc[l];
       atomicAdd(&c.Sre[f], fl);
       atomicAdd(&c.Sre[t], -fl);
     }
@@ -752,17 +811,18 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
   }
   for (int l = tid; l < g.n_line; l += GW) {
     const int f = c.lor_b[l], t = c.lex_b[l];
+    lstat[l] = f >= 0 ? 1 : 0;
     float p_or = 0.f, q_or = 0.f, v_or = 0.f, a_or = 0.f, th_or = 0.f;
     float p_ex = 0.f, q_ex = 0.f, v_ex = 0.f, a_ex = 0.f, th_ex = 0.f;
     if (f >= 0) {
-      const double vnf = g.sub_vn_kv[g.line_or_sub[l]], vnt = g.sub_vn_kv[g.line_ex_sub[l]];
+      const double vnf = sv.sub_vn_kv[sv.line_or_sub[l]], vnt = sv.sub_vn_kv[sv.line_ex_sub[l]];
       const double vmf = c.vm[f], vmt = c.vm[t];
       double pf, qf, pt, qt;
       if (is_dc) {
-        pf = (c.va[f] - c.va[t]) * g.br_bdc[l] * sn;
+        pf = (c.va[f] - c.va[t]) * sv.br_bdc[l] * sn;
         pt = -pf; qf = 0.0; qt = 0.0;
       } else {
-        const double4* y4 = reinterpret_cast<const double4*>(g.br_y + (size_t)8 * l);
+        const double4* y4 = reinterpret_cast<const double4*>(sv.br_y + (size_t)8 * l);
         const double4 ya = y4[0], yb = y4[1];
         const double ef = c.e[f], ff = c.f[f], et = c.e[t], ft = c.f[t];
         const double ifr = ya.x * ef - ya.y * ff + ya.z * et - ya.w * ft;
@@ -787,7 +847,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     const bool on = bu >= 0;
     out[oo.load_p + i] = on ? (float)inj[oo.inj_load_p + i] : 0.f;
     out[oo.load_q + i] = (on && !is_dc) ? (float)inj[oo.inj_load_q + i] : 0.f;
-    out[oo.load_v + i] = on ? (float)(c.vm[bu] * g.sub_vn_kv[g.load_sub[i]]) : 0.f;
+    out[oo.load_v + i] = on ? (float)(c.vm[bu] * sv.sub_vn_kv[sv.load_sub[i]]) : 0.f;
     out[oo.load_th + i] = on ? (float)(c.va[bu] * RAD2DEG) : 0.f;
   }
   for (int i = tid; i < g.n_sto; i += GW) {
@@ -795,7 +855,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     const bool on = bu >= 0;
     out[oo.sto_p + i] = on ? (float)inj[oo.inj_sto_p + i] : 0.f;
     out[oo.sto_q + i] = (on && !is_dc) ? (float)inj[oo.inj_sto_q + i] : 0.f;
-    out[oo.sto_v + i] = on ? (float)(c.vm[bu] * g.sub_vn_kv[g.sto_sub[i]]) : 0.f;
+    out[oo.sto_v + i] = on ? (float)(c.vm[bu] * sv.sub_vn_kv[sv.sto_sub[i]]) : 0.f;
     out[oo.sto_th + i] = on ? (float)(c.va[bu] * RAD2DEG) : 0.f;
   }
   int* sbo = b.shunt_bus_out + (size_t)inst * g.n_shunt;
@@ -803,9 +863,9 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
     const int bu = c.sh_b[i];
     const bool on = bu >= 0;
     const double v = on ? c.vm[bu] : 0.0;
-    out[oo.sh_p + i] = on ? (float)(inj[oo.inj_sh_p + i] * g.shunt_fact[i] * v * v) : 0.f;
-    out[oo.sh_q + i] = (on && !is_dc) ? (float)(inj[oo.inj_sh_q + i] * g.shunt_fact[i] * v * v) : 0.f;
-    out[oo.sh_v + i] = on ? (float)(v * g.sub_vn_kv[g.shunt_sub[i]]) : 0.f;
+    out[oo.sh_p + i] = on ? (float)(inj[oo.inj_sh_p + i] * sv.shunt_fact[i] * v * v) : 0.f;
+    out[oo.sh_q + i] = (on && !is_dc) ? (float)(inj[oo.inj_sh_q + i] * sv.shunt_fact[i] * v * v) : 0.f;
+    out[oo.sh_v + i] = on ? (float)(v * sv.sub_vn_kv[sv.shunt_sub[i]]) : 0.f;
     sbo[i] = on ? shb[i] : -1;
   }
   // generators (pypower pfsoln): per-bus totals accumulated in LDS with atomics (the block array is dead by now and
@@ -824,9 +884,9 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       const int bu = c.gen_b[i];
       if (bu < 0) continue;
       atomicAdd(&cnt[bu], 1);
-      atomicAdd(&qmin_t[bu], g.gen_min_q[i]);
-      atomicAdd(&qmax_t[bu], g.gen_max_q[i]);
-      if (g.gen_slack[i]) atomicAdd(&nsl[bu], 1);
+      atomicAdd(&qmin_t[bu], sv.gen_min_q[i]);
+      atomicAdd(&qmax_t[bu], sv.gen_max_q[i]);
+      if (sv.gen_slack[i]) atomicAdd(&nsl[bu], 1);
     }
     GPF_SYNC();
     GPF_STAMPS(24);
@@ -836,16 +896,16 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
       if (bu >= 0) {
         const double qtot = (c.Sim[bu] - c.Qsp[bu]) * sn;
         const int cn = cnt[bu];
-        const double mn = g.gen_min_q[i], mx = g.gen_max_q[i];
+        const double mn = sv.gen_min_q[i], mx = sv.gen_max_q[i];
         double q;
         if (is_dc) q = 0.0;
         else if (cn == 1) q = qtot;
         else if (qmin_t[bu] == qmax_t[bu]) q = qtot / cn;
         else q = mn + (qtot - qmin_t[bu]) / (qmax_t[bu] - qmin_t[bu] + 2.220446049250313e-16) * (mx - mn);
         double p = inj[oo.inj_gen_p + i];
-        if (g.gen_slack[i]) p = (c.Sre[bu] - c.Psp[bu]) * sn / nsl[bu];
+        if (sv.gen_slack[i]) p = (c.Sre[bu] - c.Psp[bu]) * sn / nsl[bu];
         gp = (float)p; gq = (float)q;
-        gv = (float)(c.vm[bu] * g.sub_vn_kv[g.gen_sub[i]]);
+        gv = (float)(c.vm[bu] * sv.sub_vn_kv[sv.gen_sub[i]]);
         gth = (float)(c.va[bu] * RAD2DEG);
       }
       out[oo.gen_p + i] = gp; out[oo.gen_q + i] = gq; out[oo.gen_v + i] = gv; out[oo.gen_th + i] = gth;
@@ -856,7 +916,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
   for (int i = tid; i < g.dim_topo; i += GW) { const int v = topo_g[i]; to[i] = v >= 1 ? v : -1; }
   GPF_SYNC();
   for (int l = tid; l < g.n_line; l += GW) {
-    if (c.lor_b[l] < 0) { to[g.line_or_pos[l]] = -1; to[g.line_ex_pos[l]] = -1; }
+    if (c.lor_b[l] < 0) { to[sv.line_or_pos[l]] = -1; to[sv.line_ex_pos[l]] = -1; }
   }
   GPF_STAMPS(26);
   double* bvm = b.bus_vm + (size_t)inst * g.nb_tot;
@@ -876,7 +936,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, Ca
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int NB, bool STAGE, int IPW, int MINW>
+template <int NB, int STAGE, int IPW, int MINW>
 __global__ __launch_bounds__(WAVE, MINW) void runpf_sparse_kernel(const DevParamsS* __restrict__ P, int lane0, int is_dc, int max_iter,
                                                             double tol_pu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -884,13 +944,13 @@ __global__ __launch_bounds__(WAVE, MINW) void runpf_sparse_kernel(const DevParam
   const int grp = threadIdx.x / GW, tid = threadIdx.x % GW;
   const int inst = lane0 + blockIdx.x * IPW + grp;             // the host pads the lane buffers to a multiple of IPW
   CarveP<NB> c;
-  const size_t per_inst = lds_bytes_instance<NB>(P->g, P->sym.nslot, P->sym.nslot_y, STAGE);
-  carve_sparse<NB>(c, smem + (size_t)grp * per_inst, P->g, P->sym.nslot, P->sym.nslot_y, STAGE);
-  c.prog = reinterpret_cast<int*>(smem + (size_t)IPW * per_inst);
-  if (STAGE) for (int i = threadIdx.x; i < P->sym.n_prog; i += WAVE) c.prog[i] = P->sym.prog[i];   // visible after the first barrier
+  const size_t per_inst = lds_bytes_instance<NB>(P->g, P->sym.nslot, P->sym.nslot_y, STAGE != 0);
+  carve_sparse<NB>(c, smem + (size_t)grp * per_inst, P->g, P->sym.nslot, P->sym.nslot_y, STAGE != 0);
+  StatView sv;
+  make_stat_view<STAGE>(sv, P->sym, smem + (size_t)IPW * per_inst);
   int n_iter, nb;
   GPF_STAMPS_DECL;
-  const int st = solve_instance_sparse<NB, STAGE, IPW>(P, c, inst, is_dc, max_iter, tol_pu, tid, false, n_iter, nb GPF_STAMPS_ARG);
+  const int st = solve_instance_sparse<NB, STAGE, IPW>(P, sv, c, inst, is_dc, max_iter, tol_pu, tid, false, false, n_iter, nb GPF_STAMPS_ARG);
   GPF_SYNC();
   if (st != 0) write_nan_results<GW>(P->g, P->b, inst, tid);
   if (tid == 0) {
@@ -899,7 +959,7 @@ __global__ __launch_bounds__(WAVE, MINW) void runpf_sparse_kernel(const DevParam
   }
 }
 
-template <int NB, bool STAGE, int IPW, int MINW>
+template <int NB, int STAGE, int IPW, int MINW>
 __global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParamsS* __restrict__ P, int max_iter, double tol_pu,
                                                            StepArgs sa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -911,10 +971,11 @@ __global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParams
   const int grp = threadIdx.x / GW, tid = threadIdx.x % GW;
   const int inst = blockIdx.x * IPW + grp;                     // the host pads the lane buffers to a multiple of IPW
   CarveP<NB> c;
-  const size_t per_inst = lds_bytes_instance<NB>(g, P->sym.nslot, P->sym.nslot_y, STAGE);
-  carve_sparse<NB>(c, smem + (size_t)grp * per_inst, g, P->sym.nslot, P->sym.nslot_y, STAGE);
-  c.prog = reinterpret_cast<int*>(smem + (size_t)IPW * per_inst);
-  if (STAGE) for (int i = threadIdx.x; i < P->sym.n_prog; i += WAVE) c.prog[i] = P->sym.prog[i];   // visible after the first barrier
+  const size_t per_inst = lds_bytes_instance<NB>(g, P->sym.nslot, P->sym.nslot_y, STAGE != 0);
+  carve_sparse<NB>(c, smem + (size_t)grp * per_inst, g, P->sym.nslot, P->sym.nslot_y, STAGE != 0);
+  StatView sv;
+  make_stat_view<STAGE>(sv, P->sym, smem + (size_t)IPW * per_inst);
+  if (STAGE) GPF_SYNC();                                       // the static tables are read from here on
   GPF_STAMPS_DECL;
   GPF_STAMPS(8);
   {
@@ -925,19 +986,26 @@ __global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParams
     const float* __restrict__ ch = b.chron + ((size_t)tab * sa.T + row) * g.n_chron;
     const float* __restrict__ sc = b.lane_scale ? b.lane_scale + (size_t)inst * 2 * g.n_load : nullptr;
     double* inj_g = b.inj + (size_t)inst * g.n_inj;
+    // all global loads of the phase are issued up front (one round trip): the lane's topology row (first solve), the
+    // storage / shunt set-points, and the first pass of the generator columns of the chronics row
+    {
+      const int* __restrict__ topo_g = b.topo + (size_t)inst * g.dim_topo;
+      for (int i = tid; i < g.dim_topo; i += GW) c.topo[i] = topo_g[i];
+    }
     if (STAGE) for (int i = oo.inj_sto_p + tid; i < g.n_inj; i += GW) c.inj[i] = inj_g[i];
+    const float pp_pre = tid < g.n_gen ? ch[2 * g.n_load + tid] : 0.f;
+    const float pv_pre = tid < g.n_gen ? ch[2 * g.n_load + g.n_gen + tid] : 1.f;
     double sum_load = 0.0, sum_prod = 0.0;
     GPF_STAMPS(16);
     for (int i = tid; i < g.n_load; i += GW) {
       float lp = ch[i], lq = ch[g.n_load + i];
       if (sc) { lp *= sc[i]; lq *= sc[g.n_load + i]; }
-      if (STAGE) { c.inj[oo.inj_load_p + i] = (double)lp; c.inj[oo.inj_load_q + i] = (double)lq; }
-      inj_g[oo.inj_load_p + i] = (double)lp;
-      inj_g[oo.inj_load_q + i] = (double)lq;
+      if (STAGE) { c.inj[oo.inj_load_p + i] = (double)lp; c.inj[oo.inj_load_q + i] = (double)lq; }   // HBM copy: end of kernel
+      else { inj_g[oo.inj_load_p + i] = (double)lp; inj_g[oo.inj_load_q + i] = (double)lq; }
       sum_load += (double)lp;
     }
     for (int i = tid; i < g.n_gen; i += GW)
-      if (!g.gen_slack[i]) sum_prod += (double)ch[2 * g.n_load + i];
+      if (!sv.gen_slack[i]) sum_prod += (double)(i == tid ? pp_pre : ch[2 * g.n_load + i]);
     float scale_p = 1.0f;
     GPF_STAMPS(17);
     if (sa.rebalance_on) {
@@ -947,14 +1015,13 @@ __global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParams
     }
     GPF_STAMPS(18);
     for (int i = tid; i < g.n_gen; i += GW) {
-      float pp = ch[2 * g.n_load + i];
-      if (!g.gen_slack[i]) pp *= scale_p;
-      const float pv_kv = ch[2 * g.n_load + g.n_gen + i];
-      const float vn = (float)g.sub_vn_kv[g.gen_sub[i]];
+      float pp = (i == tid) ? pp_pre : ch[2 * g.n_load + i];
+      if (!sv.gen_slack[i]) pp *= scale_p;
+      const float pv_kv = (i == tid) ? pv_pre : ch[2 * g.n_load + g.n_gen + i];
+      const float vn = (float)sv.sub_vn_kv[sv.gen_sub[i]];
       const double vm_pu = (double)(pv_kv / vn);
       if (STAGE) { c.inj[oo.inj_gen_p + i] = (double)pp; c.inj[oo.inj_gen_vm + i] = vm_pu; }
-      inj_g[oo.inj_gen_p + i] = (double)pp;
-      inj_g[oo.inj_gen_vm + i] = vm_pu;
+      else { inj_g[oo.inj_gen_p + i] = (double)pp; inj_g[oo.inj_gen_vm + i] = vm_pu; }
     }
     GPF_SYNC();
   }
@@ -971,10 +1038,12 @@ __global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParams
   int* inc_flag = reinterpret_cast<int*>(rho);
   if (sa.cascade) for (int l = tid; l < g.n_line; l += GW) inc_flag[l] = 0;
   bool more = true;                                           // this group still cascades
+  bool first = true;
   while (true) {
     // a group whose cascade has ended re-solves its unchanged state along with the others (same results)
     int it_k = 0, nb_k = 0;
-    const int st_k = solve_instance_sparse<NB, STAGE, IPW>(P, c, inst, 0, max_iter, tol_pu, tid, true, it_k, nb_k GPF_STAMPS_ARG);
+    const int st_k = solve_instance_sparse<NB, STAGE, IPW>(P, sv, c, inst, 0, max_iter, tol_pu, tid, true, first, it_k, nb_k GPF_STAMPS_ARG);
+    first = false;
     GPF_SYNC();
     if (more) { st = st_k; n_iter = it_k; nb = nb_k; }
     if (st != 0 || !sa.cascade || rounds >= sa.max_rounds) more = false;   // at most max_rounds re-solves
@@ -989,8 +1058,8 @@ __global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParams
       if (on && (a > sa.soft_overflow * lim) && !inc) { inc = 1; inc_flag[l] = 1; }
       if (on && (ovc[l] + inc) > sa.nb_ts_allowed) disc = true;
       if (disc) {
-        topo[g.line_or_pos[l]] = -1;
-        topo[g.line_ex_pos[l]] = -1;
+        topo[sv.line_or_pos[l]] = -1;
+        topo[sv.line_ex_pos[l]] = -1;
         dround[l] = rounds;
         any_disc = 1;
       }
@@ -1001,6 +1070,10 @@ __global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParams
     if (more) ++rounds;
   }
   GPF_STAMPS(9);
+  if (STAGE) {                                                // the step's injection row -> HBM (gpf_get_injections, next launches)
+    double* inj_g = b.inj + (size_t)inst * g.n_inj;
+    for (int i = tid; i < oo.inj_sto_p; i += GW) inj_g[i] = c.inj[i];
+  }
   if (st != 0) write_nan_results<GW>(g, b, inst, tid);
   GPF_SYNC();
   for (int l = tid; l < g.n_line; l += GW) {

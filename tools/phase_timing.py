@@ -44,8 +44,8 @@ if SPARSE:
         prev = med[k]
     print(f"  {'TOTAL':45s} {med[15] - med[8]:10.0f}")
     print(f"  DC block-LU: elimination levels + scaling {med[20]:.0f}, back substitution {med[21]:.0f} cycles")
-    print(f"  first Newton iteration: sincos {med[10] - med[4]:.0f}, Jacobian blocks + S {med[11] - med[10]:.0f}, "
-          f"diag + mismatch + test {med[12] - med[11]:.0f}, block LU {med[13] - med[12]:.0f}, update {med[14] - med[13]:.0f}")
+    print(f"  first Newton iteration: initial sincos {med[10] - med[4]:.0f}, Jacobian blocks + S {med[11] - med[10]:.0f}, "
+          f"diag + mismatch + test {med[12] - med[11]:.0f}, block LU {med[13] - med[12]:.0f}, update + sincos {med[14] - med[13]:.0f}")
     print(f"  K9 detail: row address {med[16] - med[8]:.0f}, load rows + sums {med[17] - med[16]:.0f}, reductions {med[18] - med[17]:.0f}, "
           f"gens + stores {med[0] - med[18]:.0f}")
     print(f"  K1 detail: topo row -> LDS {med[27] - med[0]:.0f}, element loops (atomics) {med[28] - med[27]:.0f}, types / counts {med[1] - med[28]:.0f}")
