@@ -122,7 +122,10 @@ struct gpf_engine {
   bool plan_valid = false;      // cached launch plan of the whole batch (invalidated by every topology mutation)
   LaunchPlan plan_cached{};
   // profiling
-  bool profiling = false;
+  bool profiling = false;      // per-launch event pairs (gpf_set_profiling(h, 2))
+  bool window = false;         // one event pair around a window of launches (gpf_set_profiling(h, 1))
+  hipEvent_t win_a = nullptr, win_b = nullptr;
+  long long win_launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   double acc_ms = 0.0;
@@ -514,7 +517,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     hipError_t eu = e->stat_dbl.upload(fd.data(), fd.size());
     if (eu == hipSuccess) eu = e->stat_int.upload(fi.data(), fi.size());
     if (eu != hipSuccess) { gpf_destroy(e); return fail(GPF_E_DEVICE, std::string("upload static tables: ") + hipGetErrorString(eu)); }
-    D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.scale_off = S.scale_off; D.n_scale = S.n_scale; D.n_prog = (int)S.prog.size();
+    D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.back_first = S.back_first; D.scale_off = S.scale_off; D.n_scale = S.n_scale; D.n_prog = (int)S.prog.size();
     D.stat_dbl = e->stat_dbl.p; D.stat_int = e->stat_int.p; D.prog = e->stat_int.p + so.prog;
   }
   HIP_TRY(hipMemsetAsync(e->status.p, 0xFF, B * 4 * sizeof(int), e->stream));
@@ -537,6 +540,7 @@ int gpf_destroy(gpf_handle e) {
   if (!e) return GPF_OK;
   (void)hipSetDevice(e->device);
   if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
+  if (e->win_a) { (void)hipEventDestroy(e->win_a); (void)hipEventDestroy(e->win_b); }
   for (auto& pr : e->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   e->sub_vn_kv.release(); e->br_y.release(); e->br_bdc.release(); e->gen_min_q.release(); e->gen_max_q.release();
   e->shunt_fact.release(); e->line_or_sub.release(); e->line_ex_sub.release(); e->line_or_pos.release();
@@ -692,8 +696,12 @@ int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
 #define LAUNCH_RUNPF_SPARSE(NBK, ST, IPW, MW)                                                                                           \
   do {                                                                                                                      \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<NBK, ST, IPW, MW>),                         \
+    static size_t lds_set_[64] = {0};                                                                                       \
+    if (p.lds > lds_set_[e->device & 63]) {                                                                                  \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<NBK, ST, IPW, MW>),                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                   \
+      lds_set_[e->device & 63] = p.lds;                                                                                     \
+    }                                   \
     hipLaunchKernelGGL((gpf::runpf_sparse_kernel<NBK, ST, IPW, MW>), dim3((n + IPW - 1) / IPW), dim3(gpf::WAVE), p.lds, e->stream,  \
                        e->d_params_s, lane0, is_dc, max_iter, tol_pu);                                                      \
   } while (0)
@@ -729,6 +737,7 @@ int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
   }
   HIP_TRY(hipGetLastError());
   if (e->profiling) HIP_TRY(hipEventRecord(eb, e->stream));
+  if (e->window) ++e->win_launches;
   return GPF_OK;
 }
 
@@ -811,8 +820,12 @@ int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double r
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
 #define LAUNCH_STEP_SPARSE(NBK, ST, IPW, MW)                                                                                           \
   do {                                                                                                                      \
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<NBK, ST, IPW, MW>),                          \
+    static size_t lds_set_[64] = {0};                                                                                       \
+    if (p.lds > lds_set_[e->device & 63]) {                                                                                  \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<NBK, ST, IPW, MW>),                          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                   \
+      lds_set_[e->device & 63] = p.lds;                                                                                     \
+    }                                   \
     hipLaunchKernelGGL((gpf::step_sparse_kernel<NBK, ST, IPW, MW>), dim3((e->n_lanes + IPW - 1) / IPW), dim3(gpf::WAVE), p.lds,     \
                        e->stream, e->d_params_s, max_iter, tol_pu, sa);                                                     \
   } while (0)
@@ -848,6 +861,7 @@ int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double r
   }
   HIP_TRY(hipGetLastError());
   if (e->profiling) HIP_TRY(hipEventRecord(eb, e->stream));
+  if (e->window) ++e->win_launches;
   return GPF_OK;
 }
 
@@ -871,9 +885,36 @@ int gpf_sync(gpf_handle e) {
   return GPF_OK;
 }
 
-int gpf_set_profiling(gpf_handle e, int32_t enabled) {
+static int close_window(gpf_engine* e) {
+  if (!e->window) return GPF_OK;
+  if (e->win_launches > 0) {
+    HIP_TRY(hipEventRecord(e->win_b, e->stream));
+    HIP_TRY(hipEventSynchronize(e->win_b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->win_a, e->win_b));
+    e->acc_ms += ms;
+    e->acc_launches += e->win_launches;
+  }
+  e->win_launches = 0;
+  e->window = false;
+  return GPF_OK;
+}
+
+static int open_window(gpf_engine* e) {
+  if (!e->win_a) { HIP_TRY(hipEventCreate(&e->win_a)); HIP_TRY(hipEventCreate(&e->win_b)); }
+  HIP_TRY(hipEventRecord(e->win_a, e->stream));
+  e->win_launches = 0;
+  e->window = true;
+  return GPF_OK;
+}
+
+int gpf_set_profiling(gpf_handle e, int32_t mode) {
   if (!e) return fail(GPF_E_INVALID, "gpf_set_profiling: null");
-  e->profiling = enabled != 0;
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = close_window(e);
+  if (rc != GPF_OK) return rc;
+  e->profiling = mode == 2;
+  if (mode == 1) return open_window(e);
   return GPF_OK;
 }
 
@@ -882,6 +923,11 @@ int gpf_get_kernel_time(gpf_handle e, double* total_ms, int64_t* n_launches) {
   HIP_TRY(hipSetDevice(e->device));
   int rc = drain_events(e);
   if (rc != GPF_OK) return rc;
+  if (e->window) {                      // close the running window and open the next one
+    rc = close_window(e);
+    if (rc == GPF_OK) rc = open_window(e);
+    if (rc != GPF_OK) return rc;
+  }
   if (total_ms) *total_ms = e->acc_ms;
   if (n_launches) *n_launches = e->acc_launches;
   e->acc_ms = 0.0;

@@ -48,6 +48,7 @@ __host__ __device__ inline size_t stat_bytes(const StatOff& o, int tier) {
 
 struct SymDev {
   int n, nslot, nslot_y, n_levels, back_off, n_prog, scale_off, n_scale;
+  int back_first;           // highest level that has U entries (back substitution starts there)
   const int* prog;          // level-scheduled program in global memory (tools/lu_bench; the kernels use StatView::prog)
   const double* stat_dbl;   // the static blob: [so.n_dbl] doubles ...
   const int* stat_int;      // ... and [so.n_int] ints
@@ -439,6 +440,38 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
   // back substitution, levels in reverse: x_p = b'_p - sum_j U'_pj x_j.  Pivots of a level are independent and only
   // depend on later levels, so every (pivot, U entry, row) item of a level runs in parallel and accumulates with
   // ds_add_f64.
+  if (BS == 2) {
+    // one item per U entry (both rows); level table entry / first item words of the next levels are prefetched as in the
+    // forward sweep; levels above back_first have no U entries (the last level never has) and are skipped
+    auto hdr = [&](int lv) -> int2 { return lv >= 0 ? make_int2(prog[S.back_off + 2 * lv], prog[S.back_off + 2 * lv + 1]) : make_int2(0, 0); };
+    auto words = [&](const int2& h, int o, unsigned& w, int& p) {
+      const int at = h.x + 2 * (o < h.y ? o : 0);
+      w = (unsigned)prog[at]; p = prog[at + 1];
+    };
+    auto item = [&](const int2& h, int o, unsigned w, int p) {
+      if (o >= h.y) return;
+      const double2* U = reinterpret_cast<const double2*>(A + (size_t)(w & 0xffffu) * 4);
+      const double2 uA = U[0], uB = U[1], xj = *reinterpret_cast<const double2*>(rhs + (size_t)(w >> 16) * 2);
+      atomicAdd(&rhs[(size_t)p * 2], -fma(uA.x, xj.x, uA.y * xj.y));
+      atomicAdd(&rhs[(size_t)p * 2 + 1], -fma(uB.x, xj.x, uB.y * xj.y));
+    };
+    int2 h0 = hdr(S.back_first), h1 = hdr(S.back_first - 1);
+    unsigned w; int p;
+    words(h0, tid, w, p);
+    for (int lv = S.back_first; lv >= 0; --lv) {
+      const int2 h2 = hdr(lv - 2);
+      unsigned nw; int np;
+      words(h1, tid, nw, np);
+      item(h0, tid, w, p);
+      for (int o = tid + GW; o < h0.y; o += GW) {
+        unsigned v; int q;
+        words(h0, o, v, q);
+        item(h0, o, v, q);
+      }
+      GPF_SYNC();
+      h0 = h1; h1 = h2; w = nw; p = np;
+    }
+  } else
   for (int lv = S.n_levels - 1; lv >= 0; --lv) {
     const int ent_off = prog[S.back_off + 2 * lv], n_ent = prog[S.back_off + 2 * lv + 1];
     for (int it = tid; it < n_ent * BS; it += GW) {

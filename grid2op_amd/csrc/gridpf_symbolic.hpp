@@ -40,6 +40,7 @@ struct Symbolic {
   //                 -> x[pivot] -= U'[u_slot] * x[u_col]   (all entries of a level run concurrently, LDS atomics)
   std::vector<int> prog;
   int scale_off = 0, n_scale = 0;  // all U blocks of all levels: (pivot_sub << 16) | u_slot  (deferred U' = Dinv * A pass)
+  int back_first = -1;             // highest level with U entries (-1: none)
   int back_off = 0;                // offset of the back-substitution level table
   int max_level_piv = 0;
 };
@@ -168,6 +169,7 @@ inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, co
       }
     P[S.back_off + 2 * lv + 0] = ent_off;
     P[S.back_off + 2 * lv + 1] = n_ent;
+    if (n_ent > 0) S.back_first = lv;
   }
   return S;
 }

@@ -278,8 +278,10 @@ class PowerFlowEngine:
     def sync(self):
         check(self._lib.gpf_sync(self._h), "gpf_sync")
 
-    def set_profiling(self, enabled: bool):
-        check(self._lib.gpf_set_profiling(self._h, int(bool(enabled))), "gpf_set_profiling")
+    def set_profiling(self, mode):
+        """0/False: off; 1/True: one HIP event pair around the window of launches up to the next ``kernel_time()``;
+        2: an event pair per launch (exact per-kernel durations, costs ~7 us of stream time per launch)."""
+        check(self._lib.gpf_set_profiling(self._h, int(mode)), "gpf_set_profiling")
 
     def kernel_time(self) -> Tuple[float, int]:
         ms = C.c_double(0.0)

@@ -157,9 +157,14 @@ int gpf_get_step_outputs(gpf_handle h, int32_t lane0, int32_t n, float* rho, int
 
 /* ---- measurement ---------------------------------------------------------------------------------------- */
 int gpf_sync(gpf_handle h);
-/* When enabled every solver launch is bracketed by HIP events on the handle's stream. */
-int gpf_set_profiling(gpf_handle h, int32_t enabled);
-/* Sum of the event-measured durations (ms) and number of solver launches since the last call. */
+/* Event timing of the solver launches on the handle's stream.  mode 0: off.  mode 1 (window): ONE event pair around all
+ * launches issued until the next gpf_get_kernel_time / gpf_set_profiling call -- no per-launch events, so back-to-back
+ * launches stay back-to-back (a per-launch pair costs ~7 us of stream time per launch on MI355X); the window time divided
+ * by the launch count is the average launch duration when the stream never runs dry.  mode 2: every launch is bracketed
+ * by its own event pair (exact per-kernel durations, perturbs throughput). */
+int gpf_set_profiling(gpf_handle h, int32_t mode);
+/* Sum of the event-measured durations (ms) and number of solver launches since the last call (closes the running
+ * window of mode 1 and opens the next one). */
 int gpf_get_kernel_time(gpf_handle h, double* total_ms, int64_t* n_launches);
 /* Raw device pointers + the stream, for zero-copy interop (torch.as_tensor / DLPack on the Python side).
  * ptrs[0..7] = inj, topo, shunt_bus, out, topo_vect, line_status, status, chronics; stream = hipStream_t */

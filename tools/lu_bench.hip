@@ -93,7 +93,7 @@ int main(int argc, char** argv) {
   for (auto& v : b) v = rnd();
   SymDev D{};
   D.n = n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.n_prog = (int)S.prog.size();
-  D.scale_off = S.scale_off; D.n_scale = S.n_scale;
+  D.scale_off = S.scale_off; D.n_scale = S.n_scale; D.back_first = S.back_first;
   int* dprog; double *dA, *db, *dx; long long* dcy;
   CK(hipMalloc(&dprog, S.prog.size() * 4)); CK(hipMemcpy(dprog, S.prog.data(), S.prog.size() * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&dA, A.size() * 8)); CK(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice));
