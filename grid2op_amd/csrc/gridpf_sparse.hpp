@@ -492,6 +492,95 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
   return ok;
 }
 
+// Scalar variant for the DC system of the NB == 1 layout: B' theta = P only couples the theta entries, i.e. element [0] of
+// every 2x2 block and rhs[2p] (the |V| rows are identity), so the same program is run on scalars: a quarter of the LDS
+// traffic and a fraction of the arithmetic of the block solve.
+template <int GW>
+__device__ inline bool scalar_lu_solve(const SymDev& S, const int* __restrict__ prog, double* __restrict__ A,
+                                       double* __restrict__ rhs, int tid, long long* dbg = nullptr) {
+#ifdef GPF_TIMING
+  const long long t_lu0 = __builtin_readcyclecounter();
+#endif
+  bool ok = true;
+  const int n_levels = S.n_levels;
+  const int4* H = reinterpret_cast<const int4*>(prog);
+  auto item_words = [&](const int4& h, int o, unsigned& w0, unsigned& w1) {
+    const int at = h.x + 2 * (o < h.y + h.w ? o : 0);
+    w0 = (unsigned)prog[at]; w1 = (unsigned)prog[at + 1];
+  };
+  auto do_item = [&](const int4& h, int o, unsigned w0, unsigned w1) {
+    if (o >= h.y + h.w) return;
+    const bool is_c = o < h.y;
+    const unsigned l = is_c ? (w0 >> 16) : (w0 & 0xffffu), dd = is_c ? (w0 & 0xffffu) : (w0 >> 16);
+    const unsigned p = is_c ? (w1 >> 16) : w1, u = w1 & 0xffffu;
+    const double d = A[(size_t)p * 4], al = A[(size_t)l * 4];
+    const double x = is_c ? A[(size_t)u * 4] : rhs[(size_t)p * 2];
+    double* dst = is_c ? (A + (size_t)dd * 4) : (rhs + (size_t)dd * 2);
+    atomicAdd(dst, -(al * x) * fast_rcp(d));
+  };
+  int4 h0 = H[1], h1 = n_levels > 1 ? H[3] : make_int4(0, 0, 0, 0);
+  unsigned w0, w1;
+  item_words(h0, tid, w0, w1);
+  for (int lv = 0; lv < n_levels; ++lv) {
+    const int4 h2 = lv + 2 < n_levels ? H[2 * (lv + 2) + 1] : make_int4(0, 0, 0, 0);
+    unsigned nw0, nw1;
+    item_words(h1, tid, nw0, nw1);
+    do_item(h0, tid, w0, w1);
+    for (int o = tid + GW; o < h0.y + h0.w; o += GW) {
+      unsigned v0, v1;
+      item_words(h0, o, v0, v1);
+      do_item(h0, o, v0, v1);
+    }
+    GPF_SYNC();
+    h0 = h1; h1 = h2; w0 = nw0; w1 = nw1;
+  }
+  for (int e = tid; e < S.n_scale; e += GW) {
+    const unsigned w = (unsigned)prog[S.scale_off + e];
+    double* au = A + (size_t)(w & 0xffffu) * 4;
+    *au = *au * fast_rcp(A[(size_t)(w >> 16) * 4]);
+  }
+  for (int p = tid; p < S.n; p += GW) {
+    const double d = A[(size_t)p * 4];
+    if (!(fabs(d) > 1e-300) || !(fabs(d) < 1e300)) ok = false;
+    rhs[(size_t)p * 2] *= fast_rcp(d);
+  }
+  GPF_SYNC();
+#ifdef GPF_TIMING
+  const long long t_lu1 = __builtin_readcyclecounter();
+#endif
+  {
+    auto hdr = [&](int lv) -> int2 { return lv >= 0 ? make_int2(prog[S.back_off + 2 * lv], prog[S.back_off + 2 * lv + 1]) : make_int2(0, 0); };
+    auto words = [&](const int2& h, int o, unsigned& w, int& p) {
+      const int at = h.x + 2 * (o < h.y ? o : 0);
+      w = (unsigned)prog[at]; p = prog[at + 1];
+    };
+    auto item = [&](const int2& h, int o, unsigned w, int p) {
+      if (o >= h.y) return;
+      atomicAdd(&rhs[(size_t)p * 2], -A[(size_t)(w & 0xffffu) * 4] * rhs[(size_t)(w >> 16) * 2]);
+    };
+    int2 g0 = hdr(S.back_first), g1 = hdr(S.back_first - 1);
+    unsigned w; int p;
+    words(g0, tid, w, p);
+    for (int lv = S.back_first; lv >= 0; --lv) {
+      const int2 g2 = hdr(lv - 2);
+      unsigned nw; int np;
+      words(g1, tid, nw, np);
+      item(g0, tid, w, p);
+      for (int o = tid + GW; o < g0.y; o += GW) {
+        unsigned v; int q;
+        words(g0, o, v, q);
+        item(g0, o, v, q);
+      }
+      GPF_SYNC();
+      g0 = g1; g1 = g2; w = nw; p = np;
+    }
+  }
+#ifdef GPF_TIMING
+  if (dbg) { dbg[0] = t_lu1 - t_lu0; dbg[1] = (long long)__builtin_readcyclecounter() - t_lu1; }
+#endif
+  return ok;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // One complete power flow of the IPW instances of a wavefront (tid = lane within the instance group).  Returns the GPF_ST_*
 // status of the caller's group.  Groups share the instruction stream: a group that has failed or finished keeps executing
@@ -696,9 +785,10 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   GPF_STAMPS(3);
   {
 #ifdef GPF_TIMING
-    bool ok = block_lu_solve<BS, GW>(S, sv.prog, c.A, c.rhs, tid, &stamps.v[20]);
+    bool ok = (NB == 1) ? scalar_lu_solve<GW>(S, sv.prog, c.A, c.rhs, tid, &stamps.v[20])
+                        : block_lu_solve<BS, GW>(S, sv.prog, c.A, c.rhs, tid, &stamps.v[20]);
 #else
-    bool ok = block_lu_solve<BS, GW>(S, sv.prog, c.A, c.rhs, tid);
+    bool ok = (NB == 1) ? scalar_lu_solve<GW>(S, sv.prog, c.A, c.rhs, tid) : block_lu_solve<BS, GW>(S, sv.prog, c.A, c.rhs, tid);
 #endif
     for (int i = tid; i < nbus; i += GW) {
       const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);

@@ -1,7 +1,6 @@
 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-secondary 2>&1 | tail -1 | cut -c1-200
-python bench.py --env l2rpn_neurips_2020_track1 --steps 50 --warmup 10 --no-secondary --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
-python bench.py --env l2rpn_neurips_2020_track1 --batch 1024 --steps 50 --warmup 10 --no-secondary --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
-python bench.py --env rte_case5_example --steps 50 --warmup 10 --no-secondary --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
-python bench.py --env l2rpn_wcci_2022_dev --batch 1024 --steps 50 --warmup 10 --no-secondary --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
-export GRIDPF_LIB=$PWD/grid2op_amd/libgridpf_timing.so; python tools/phase_timing.py 4096
+python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-secondary 2>&1 | tail -1 | cut -c1-200
+python bench.py --env l2rpn_neurips_2020_track1 --steps 100 --warmup 10 --no-secondary --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
+python bench.py --env l2rpn_neurips_2020_track1 --batch 1024 --steps 100 --warmup 10 --no-secondary --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
+python bench.py --env rte_case5_example --steps 100 --warmup 10 --no-secondary --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
+python bench.py --env l2rpn_wcci_2022_dev --batch 1024 --steps 100 --warmup 10 --no-secondary --no-cpu-baseline 2>&1 | tail -1 | cut -c1-200
