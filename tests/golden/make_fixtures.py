@@ -123,7 +123,65 @@ def _known_answers(ref):
         txt = txt[txt.index("["):txt.rindex("]") + 1]
         return np.array([float(x) for x in re.findall(r"[-+]?\d+\.\d*(?:[eE][-+]?\d+)?", txt)])
 
-    return {"p_or_dc": grab(262, 287), "p_or_ac": grab(289, 319), "a_or_init": grab(1584, 1607)}
+    out = {"p_or_dc": grab(262, 287), "p_or_ac": grab(289, 319), "a_or_init": grab(1584, 1607)}
+    out.update(_observation_json_ref(ref))
+    return out
+
+
+def _observation_json_ref(ref):
+    """The complete observation after reset of rte_case14_test recorded with PandaPowerBackend that
+    grid2op/tests/test_Observation.py compares for EXACT float32 equality (``self.json_ref``, :307-...): only its
+    numeric vectors are kept (prefix ``obs14_``)."""
+    import ast
+    txt = open(os.path.join(ref, "grid2op/tests/test_Observation.py")).read()
+    a = txt.index("self.json_ref = {") + len("self.json_ref = ")
+    depth, b = 0, a
+    while True:
+        ch = txt[b]
+        depth += ch == "{"
+        depth -= ch == "}"
+        b += 1
+        if depth == 0:
+            break
+    d = ast.literal_eval(txt[a:b])
+    keep = ["gen_p", "gen_q", "gen_v", "load_p", "load_q", "load_v", "p_or", "q_or", "v_or", "a_or", "p_ex", "q_ex", "v_ex",
+            "a_ex", "rho", "line_status", "topo_vect", "theta_or", "theta_ex", "load_theta", "gen_theta"]
+    return {"obs14_" + k: np.asarray(d[k]) for k in keep if k in d}
+
+
+def _runner_trajectories(ref, versions=("1.9.8", "1.10.1", "1.10.5")):
+    """Trajectories recorded with PandaPowerBackend that grid2op/tests/test_Runner.py:426,540-585 loads
+    (data_test/runner_data/res_agent_<ver>/{00,01}: rte_case5_example, RandomAgent).  Every recorded observation holds
+    both the INPUTS of its power flow (load_p/q, gen_p, gen_v set-points, topo_vect after the random topology action)
+    and the pandapower RESULTS (flows, currents, gen_q), so each row is a self-contained golden vector.  Decoded with the
+    reference's own ObservationSpace (needs the reference importable: tests/_refshim); numbers only are kept."""
+    try:
+        sys.path.insert(0, os.path.join(HERE, "..", "_refshim"))
+        sys.path.insert(0, ref)
+        import json
+        import warnings
+        warnings.filterwarnings("ignore")
+        from grid2op.Observation import ObservationSpace
+    except Exception as exc:       # pragma: no cover
+        print("runner trajectories skipped:", exc)
+        return {}
+    out = {}
+    keys = ["load_p", "load_q", "gen_p", "gen_v", "gen_q", "topo_vect", "line_status", "p_or", "q_or", "v_or", "a_or", "p_ex", "q_ex",
+            "v_ex", "a_ex"]
+    for ver in versions:
+        base = os.path.join(ref, "grid2op/data_test/runner_data", f"res_agent_{ver}")
+        if not os.path.isdir(base):
+            continue
+        sp = ObservationSpace.from_dict(os.path.join(base, "dict_observation_space.json"))
+        for ep in ("00", "01"):
+            meta = json.load(open(os.path.join(base, ep, "episode_meta.json")))
+            n = int(meta["nb_timestep_played"])
+            data = np.load(os.path.join(base, ep, "observations.npz"))["data"]
+            rows = [sp.from_vect(data[t]) for t in range(n)]       # the row after the last played step is the game-over obs
+            tag = f"v{ver.replace('.', '_')}_{ep}_"
+            for k in keys:
+                out[tag + k] = np.stack([np.asarray(getattr(o, k)) for o in rows])
+    return out
 
 
 def main():
@@ -146,6 +204,10 @@ def main():
         if chron:
             np.savez_compressed(os.path.join(HERE, f"{name}.chronics.npz"), **chron)
         print(name, "n_sub", m.n_sub, "n_line", m.n_line, "res:", sorted(res)[:3], "chron:", {k: v.shape for k, v in chron.items()})
+    rt = _runner_trajectories(ref)
+    if rt:
+        np.savez_compressed(os.path.join(HERE, "runner_case5.npz"), **rt)
+        print("runner trajectories", {k: v.shape for k, v in rt.items() if k.endswith("p_or")})
     ka = _known_answers(ref)
     np.savez_compressed(os.path.join(HERE, "known_answers.npz"), **ka)
     print("known answers", {k: v.shape for k, v in ka.items()})

@@ -411,3 +411,55 @@ def test_instance_groups_ragged_ranges(name, n, load_model):
                     assert np.array_equal(getattr(r2, f)[k], getattr(r, f)[k], equal_nan=True), (k, f)
                 assert np.array_equal(r2.status[k], r.status[k])
     eng.close()
+
+
+def test_hip_matches_observations_recorded_with_pandapower(load_model, load_npz):
+    """The HIP path against the reference's OWN recordings (no oracle in between): the rte_case5_example RandomAgent
+    episodes of grid2op/data_test/runner_data (bus splits, line switches) and the rte_case14_test reset observation of
+    grid2op/tests/test_Observation.py (json_ref) -- fixtures tests/golden/runner_case5.npz / known_answers.npz."""
+    m = load_model("rte_case5_example")
+    rt = load_npz("runner_case5.npz")
+    tags = sorted({k[:-len("p_or")] for k in rt if k.endswith("_p_or")})
+    states, rows = [], []
+    for tag in tags:
+        for t in range(rt[tag + "p_or"].shape[0]):
+            st = LaneState.from_model(m)
+            st.topo = rt[tag + "topo_vect"][t].astype(np.int32)
+            st.load_p = rt[tag + "load_p"][t].astype(np.float64)
+            st.load_q = rt[tag + "load_q"][t].astype(np.float64)
+            st.gen_p = rt[tag + "gen_p"][t].astype(np.float64)
+            st.gen_vm = (rt[tag + "gen_v"][t].astype(np.float32) / m.sub_vn_kv[m.gen_sub].astype(np.float32)).astype(np.float64)
+            states.append(st)
+            rows.append((tag, t))
+    eng = _engine(m, len(states))
+    inj, topo, sb = _pack(eng, states)
+    eng.set_injections(inj)
+    eng.set_topology(topo, sb)
+    eng.runpf()
+    r = eng.results()
+    assert r.converged.all()
+    for k, (tag, t) in enumerate(rows):
+        assert np.array_equal(r.topo_vect[k], rt[tag + "topo_vect"][t])
+        for f, tol in [("p_or", 1e-4), ("q_or", 3e-4), ("p_ex", 1e-4), ("q_ex", 3e-4), ("v_or", 1e-4), ("v_ex", 1e-4)]:
+            assert np.abs(getattr(r, f)[k].astype(np.float64) - rt[tag + f][t]).max() < tol, (tag, t, f)
+        assert np.abs(r.gen_q[k].astype(np.float64) - rt[tag + "gen_q"][t]).max() < 3e-4
+    eng.close()
+
+    m = load_model("rte_case14_test")
+    ch = load_npz("rte_case14_test.chronics.npz")
+    ka = load_npz("known_answers.npz")
+    eng = _engine(m, 4)
+    eng.upload_chronics(eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"]))
+    eng.set_lane_chronics(lane_offset=np.zeros(4, dtype=np.int32))
+    eng.set_thermal_limits(ch["thermal_limits"])
+    eng.step(0)                                   # chronics row 0 through the device-side step (K9 + K1..K7)
+    r = eng.results()
+    rho, _, _ = eng.step_outputs()
+    assert r.converged.all()
+    for f, tol in [("p_or", 1e-4), ("q_or", 3e-4), ("p_ex", 1e-4), ("q_ex", 3e-4), ("v_or", 1e-4), ("v_ex", 1e-4), ("gen_q", 3e-4),
+                   ("load_v", 1e-4), ("gen_v", 1e-4)]:
+        assert np.abs(getattr(r, f)[0].astype(np.float64) - ka["obs14_" + f]).max() < tol, f
+    assert np.abs(r.a_or[0] / ka["obs14_a_or"] - 1).max() < 1e-5
+    assert np.abs(rho[0] - ka["obs14_rho"]).max() < 1e-5
+    assert np.array_equal(r.topo_vect[0], ka["obs14_topo_vect"].astype(np.int32))
+    eng.close()

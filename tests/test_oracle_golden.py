@@ -94,3 +94,70 @@ def test_islanded_grid_diverges_in_ac_and_dc(load_model):
         r = solve(m, st, is_dc=dc)
         assert not r.converged
         assert np.all(np.isnan(r.p_or)) and np.all(r.topo_vect == -1) and not r.line_status.any()
+
+
+def test_observation_recorded_with_pandapower_backend(load_model, load_npz):
+    """grid2op/tests/test_Observation.py:307-... (``json_ref``): the complete observation of rte_case14_test after reset,
+    recorded with PandaPowerBackend and compared there for exact float32 equality.  The oracle is fed row 0 of
+    chronics/0 the way ``_BackendAction`` hands it over (float32 set-points, float32 prod_v / vn_kv) and must reproduce
+    the recorded flows / voltages / reactive dispatch; integer vectors bit-exactly."""
+    m = load_model("rte_case14_test")
+    ch = load_npz("rte_case14_test.chronics.npz")
+    ka = load_npz("known_answers.npz")
+    st = LaneState.from_model(m)
+    st.load_p = ch["load_p"][0].astype(np.float64)
+    st.load_q = ch["load_q"][0].astype(np.float64)
+    st.gen_p = ch["prod_p"][0].astype(np.float64)
+    st.gen_vm = (ch["prod_v"][0] / m.sub_vn_kv[m.gen_sub].astype(np.float32)).astype(np.float64)
+    r = solve(m, st)
+    assert r.converged
+    assert np.array_equal(r.topo_vect, ka["obs14_topo_vect"].astype(np.int32))
+    assert np.array_equal(r.line_status.astype(bool), ka["obs14_line_status"].astype(bool))
+    for f, tol in [("p_or", 2e-5), ("q_or", 1e-4), ("p_ex", 2e-5), ("q_ex", 1e-4), ("v_or", 2e-5), ("v_ex", 2e-5)]:
+        assert np.abs(getattr(r, f) - ka["obs14_" + f]).max() < tol, f
+    assert np.abs(r.a_or / ka["obs14_a_or"] - 1).max() < 2e-6
+    assert np.abs(r.a_ex / ka["obs14_a_ex"] - 1).max() < 2e-6
+    assert np.abs(r.load_p - ka["obs14_load_p"]).max() < 1e-6 and np.abs(r.load_v - ka["obs14_load_v"]).max() < 2e-5
+    assert np.abs(r.gen_v - ka["obs14_gen_v"]).max() < 2e-5
+    assert np.abs(r.gen_q - ka["obs14_gen_q"]).max() < 1e-4
+    ns = ~m.gen_slack
+    assert np.abs(r.gen_p[ns] - ka["obs14_gen_p"][ns]).max() < 1e-6
+    assert np.abs(r.gen_p[m.gen_slack] - ka["obs14_gen_p"][m.gen_slack]).max() < 1e-4      # slack P = losses balance
+    assert np.abs(r.a_or / ch["thermal_limits"] - ka["obs14_rho"]).max() < 2e-6
+    for f in ("theta_or", "theta_ex", "load_theta", "gen_theta"):
+        if "obs14_" + f in ka:
+            d = np.abs(getattr(r, f) - ka["obs14_" + f])
+            assert np.minimum(d, 360 - d).max() < 2e-5, f
+
+
+def test_runner_trajectories_recorded_with_pandapower_backend(load_model, load_npz):
+    """grid2op/data_test/runner_data/res_agent_<ver>/{00,01} (loaded by grid2op/tests/test_Runner.py:426,540-585):
+    rte_case5_example episodes of a RandomAgent recorded with PandaPowerBackend.  Every observation row carries the
+    inputs of its power flow (injections, topo_vect after the random bus splits / line switches) and pandapower's
+    results, so each row pins the oracle on a DIFFERENT topology."""
+    m = load_model("rte_case5_example")
+    rt = load_npz("runner_case5.npz")
+    tags = sorted({k[:-len("p_or")] for k in rt if k.endswith("_p_or")})
+    assert len(tags) >= 4
+    n_rows = n_split = 0
+    for tag in tags:
+        for t in range(rt[tag + "p_or"].shape[0]):
+            topo = rt[tag + "topo_vect"][t].astype(np.int32)
+            st = LaneState.from_model(m)
+            st.topo = topo.copy()
+            st.load_p = rt[tag + "load_p"][t].astype(np.float64)
+            st.load_q = rt[tag + "load_q"][t].astype(np.float64)
+            st.gen_p = rt[tag + "gen_p"][t].astype(np.float64)
+            st.gen_vm = (rt[tag + "gen_v"][t].astype(np.float32) / m.sub_vn_kv[m.gen_sub].astype(np.float32)).astype(np.float64)
+            r = solve(m, st)
+            assert r.converged, (tag, t)
+            assert np.array_equal(r.topo_vect, topo), (tag, t)
+            assert np.array_equal(r.line_status.astype(bool), rt[tag + "line_status"][t].astype(bool))
+            for f, tol in [("p_or", 5e-5), ("q_or", 2e-4), ("p_ex", 5e-5), ("q_ex", 2e-4), ("v_or", 5e-5), ("v_ex", 5e-5)]:
+                assert np.abs(getattr(r, f) - rt[tag + f][t]).max() < tol, (tag, t, f)
+            on = rt[tag + "a_or"][t] > 0
+            assert np.abs(r.a_or[on] / rt[tag + "a_or"][t][on] - 1).max() < 5e-6
+            assert np.abs(r.gen_q - rt[tag + "gen_q"][t]).max() < 2e-4
+            n_rows += 1
+            n_split += int((topo == 2).any())
+    assert n_rows >= 15 and n_split >= 5
