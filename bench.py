@@ -217,7 +217,7 @@ def main():
                        "tol_mva": 1e-8, "parallelism": f"independent lanes, static shard x{world}, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": (measured_traffic_bytes() or {}).get("hbm_bytes_per_launch"),
-                         "kernel": "gpf::step_sparse_kernel<1, true>", "avg_launch_us": avg_launch_s * 1e6, "launches": int(n_launch),
+                         "kernel": (measured_traffic_bytes() or {}).get("kernel"), "avg_launch_us": avg_launch_s * 1e6, "launches": int(n_launch),
                          "algorithmic_bytes_per_step": bytes_step,
                          "note": "small dense FP64 factorisations dominate: the kernel is issue/latency bound, not HBM "
                                  "bound (SURVEY.md 8(d)); the FP64 figure below is the relevant ceiling",
@@ -265,8 +265,64 @@ def main():
                    "hbm_gbs": b2 * B2 / (k2 / max(n2, 1) * 1e-3) / 1e9 if k2 > 0 else 0.0,
                    "frac_converged": float(r2.converged.mean()), "mean_nr_iterations": float(r2.n_iter[r2.converged].mean())}
         eng2.close()
+    # ---- DC sensitivity path of BASELINE.json configs[4]: l2rpn_idf_2023, 2048 lanes, PTDF GEMM next to the AC solve ------------
+    ptdf = None
+    if not args.no_secondary and args.env == "l2rpn_case14_sandbox":
+        env3, B3 = "l2rpn_idf_2023", 2048
+        m3 = GridModel.load_npz(os.path.join(GOLD, f"{env3}.grid.npz"))
+        eng3 = PowerFlowEngine(m3, n_lanes=B3, device=local_rank)
+        l0, _ = lane_range(world * B3, world, rank)
+        inj3 = np.tile(eng3.get_injections(0, 1), (B3, 1))
+        lay = eng3.layout
+        for k in range(B3):                                   # +-5 % load jitter per lane, generators follow
+            f = 1.0 + 0.05 * np.random.default_rng(l0 + k).standard_normal(m3.n_load)
+            lp = inj3[k, lay.inj_load_p:lay.inj_load_p + m3.n_load]
+            gp = inj3[k, lay.inj_gen_p:lay.inj_gen_p + m3.n_gen]
+            gp *= (lp * f).sum() / lp.sum()
+            lp *= f
+        eng3.set_injections(inj3)
+        eng3.ptdf_build(0)
+        reps = max(20, args.steps)
+        for _ in range(3):
+            eng3.ptdf_flows(fetch=False)
+        eng3.sync()
+        if dist is not None:
+            dist.barrier()
+        eng3.set_profiling(1)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            eng3.ptdf_flows(fetch=False)
+        eng3.sync()
+        el3 = time.perf_counter() - t0
+        k3, n3 = eng3.kernel_time()
+        eng3.set_profiling(0)
+        el3 = max_over_ranks(el3, dist, device="cuda" if dist is not None else None)
+        flows = eng3.ptdf_flows()
+        eng3.runpf(is_dc=True)
+        eng3.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            eng3.runpf(is_dc=True)
+        eng3.sync()
+        dc_solve_s = (time.perf_counter() - t0) / 5
+        r3 = eng3.results()
+        if rank == 0:
+            nb_act = int(r3.status[0, 2])                     # active buses of the topology = K of the GEMM
+            nb_pad, line_pad = (nb_act + 3) // 4 * 4, (m3.n_line + 15) // 16 * 16
+            us = k3 / max(n3, 1) * 1e3
+            ptdf = {"workload": f"{env3} (118 substations) batch={B3} lanes per GPU: DC line flows of every lane as ONE FP64 MFMA GEMM "
+                                f"(flows = P_bus[{B3}x{nb_pad}] . PTDF^T[{nb_pad}x{line_pad}]) for a fixed topology",
+                    "value": world * B3 * reps / el3, "unit": "DC power flows/sec", "us_per_batch": us,
+                    "roofline": {"bound": "mfma", "achieved": 2.0 * B3 * nb_pad * line_pad / (us * 1e-6) / 1e12 if us > 0 else 0.0,
+                                 "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": (2.0 * B3 * nb_pad * line_pad / (us * 1e-6) / 1e12 / F64_PEAK_TFLOPS) if us > 0 else 0.0,
+                                 "note": "90 MFLOP per batch: launch/latency bound, two kernels (bus injections + GEMM)"},
+                    "per_lane_dc_solve_value": world * B3 / dc_solve_s, "per_lane_dc_solve_unit": "DC power flows/sec (kernel S, B' refactorised per lane)",
+                    "max_abs_diff_vs_per_lane_dc_solve_mw": float(np.abs(flows - r3.p_or).max())}
+        eng3.close()
     if rank == 0:
         res["secondary"] = sec
+        res["dc_ptdf"] = ptdf
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

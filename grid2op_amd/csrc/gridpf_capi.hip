@@ -16,6 +16,7 @@
 #include "gridpf_kernels.hpp"
 #include "gridpf_small.hpp"
 #include "gridpf_sparse.hpp"
+#include "gridpf_ptdf.hpp"
 #include "gridpf_symbolic.hpp"
 
 namespace {
@@ -102,6 +103,14 @@ struct gpf_engine {
   bool force_generic = false;   // GRIDPF_FORCE_GENERIC=1: always use the generic (v1) kernels
   // block-sparse path (kernel S)
   gpf::Symbolic sym;
+  // DC sensitivity path (gridpf_ptdf.hpp)
+  DevArr<int> ptdf_inj_bus;
+  DevArr<double> ptdf_inj_w, ptdf_t, ptdf_pbus;
+  DevArr<float> ptdf_flow;
+  std::vector<double> h_ptdf;      // [n_line][nb_tot]
+  std::vector<double> h_br_bdc, h_shunt_fact;
+  int ptdf_nb_pad = 0, ptdf_line_pad = 0;
+  bool ptdf_ready = false;
   DevArr<double> stat_dbl;     // static blob of kernel S (gpf::StatOff)
   DevArr<int> stat_int;
   gpf::SymDev sym_dev{};
@@ -435,6 +444,8 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   if (ns) { cp(e->h_sto_sub, d->storage_sub, ns); cp(e->h_sto_pos, d->storage_pos_topo_vect, ns); }
   if (nsh) cp(e->h_shunt_sub, d->shunt_sub, nsh);
   e->h_gen_slack.assign(d->gen_slack, d->gen_slack + ng);
+  e->h_br_bdc.assign(d->br_bdc, d->br_bdc + nl);
+  e->h_shunt_fact.assign(d->shunt_fact, d->shunt_fact + nsh);
   e->h_init_inj.assign(d->init_inj, d->init_inj + g.n_inj);
   e->h_init_topo.assign(d->init_topo, d->init_topo + g.dim_topo);
   if (nsh) e->h_init_shunt_bus.assign(d->init_shunt_bus, d->init_shunt_bus + nsh);
@@ -554,6 +565,7 @@ int gpf_destroy(gpf_handle e) {
   if (e->d_params) (void)hipFree(e->d_params);
   if (e->d_params_s) (void)hipFree(e->d_params_s);
   e->stat_dbl.release();
+  e->ptdf_inj_bus.release(); e->ptdf_inj_w.release(); e->ptdf_t.release(); e->ptdf_pbus.release(); e->ptdf_flow.release();
   e->stat_int.release();
   delete e;
   return GPF_OK;
@@ -932,6 +944,150 @@ int gpf_get_kernel_time(gpf_handle e, double* total_ms, int64_t* n_launches) {
   if (n_launches) *n_launches = e->acc_launches;
   e->acc_ms = 0.0;
   e->acc_launches = 0;
+  return GPF_OK;
+}
+
+
+/* ---- DC sensitivity (PTDF) path ------------------------------------------------------------------------------------ */
+int gpf_ptdf_build(gpf_handle e, int32_t lane) {
+  if (!check_range(e, lane, 1)) return fail(GPF_E_INVALID, "gpf_ptdf_build: bad lane");
+  HIP_TRY(hipSetDevice(e->device));
+  const gpf::GridDev& g = e->g;
+  const gpf::OutOff& oo = e->oo;
+  std::vector<int> topo(g.dim_topo), sb(std::max(g.n_shunt, 1));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(topo.data(), e->topo.p + (size_t)lane * g.dim_topo, (size_t)g.dim_topo * sizeof(int), hipMemcpyDeviceToHost));
+  if (g.n_shunt) HIP_TRY(hipMemcpy(sb.data(), e->shunt_bus.p + (size_t)lane * g.n_shunt, (size_t)g.n_shunt * sizeof(int), hipMemcpyDeviceToHost));
+  const int nbt = g.nb_tot;
+  auto bus_of = [&](int sub, int local) -> int { return (local >= 1 && local <= g.n_busbar) ? sub + (local - 1) * g.n_sub : -1; };
+  std::vector<char> act(nbt, 0), ref(nbt, 0);
+  std::vector<int> lf(g.n_line, -1), lt(g.n_line, -1);
+  for (int l = 0; l < g.n_line; ++l) {
+    const int bo = topo[e->h_line_or_pos[l]], be = topo[e->h_line_ex_pos[l]];
+    if (bo >= 1 && be >= 1) {
+      lf[l] = bus_of(e->h_line_or_sub[l], bo); lt[l] = bus_of(e->h_line_ex_sub[l], be);
+      if (lf[l] < 0 || lt[l] < 0) return fail(GPF_E_INVALID, "gpf_ptdf_build: bus id out of range");
+      act[lf[l]] = act[lt[l]] = 1;
+    }
+  }
+  std::vector<int> inj_bus(g.n_inj, -1);
+  std::vector<double> inj_w(g.n_inj, 0.0);
+  for (int i = 0; i < g.n_gen; ++i) {
+    const int b = bus_of(e->h_gen_sub[i], topo[e->h_gen_pos[i]]);
+    if (b < 0) continue;
+    act[b] = 1;
+    if (e->h_gen_slack[i]) ref[b] = 1; else { inj_bus[oo.inj_gen_p + i] = b; inj_w[oo.inj_gen_p + i] = 1.0; }
+  }
+  for (int i = 0; i < g.n_load; ++i) {
+    const int b = bus_of(e->h_load_sub[i], topo[e->h_load_pos[i]]);
+    if (b >= 0) { act[b] = 1; inj_bus[oo.inj_load_p + i] = b; inj_w[oo.inj_load_p + i] = -1.0; }
+  }
+  for (int i = 0; i < g.n_sto; ++i) {
+    const int b = bus_of(e->h_sto_sub[i], topo[e->h_sto_pos[i]]);
+    if (b >= 0) { act[b] = 1; inj_bus[oo.inj_sto_p + i] = b; inj_w[oo.inj_sto_p + i] = -1.0; }
+  }
+  for (int i = 0; i < g.n_shunt; ++i) {
+    const int b = bus_of(e->h_shunt_sub[i], sb[i]);
+    if (b >= 0) { act[b] = 1; inj_bus[oo.inj_sh_p + i] = b; inj_w[oo.inj_sh_p + i] = -e->h_shunt_fact[i]; }
+  }
+  // reduced B' over the active non-reference buses, inverted by Gauss-Jordan with partial pivoting (once per topology)
+  std::vector<int> idx(nbt, -1), buses;
+  bool any_ref = false;
+  for (int b = 0; b < nbt; ++b) { any_ref |= (act[b] && ref[b]); if (act[b] && !ref[b]) { idx[b] = (int)buses.size(); buses.push_back(b); } }
+  if (!any_ref) return fail(GPF_E_INVALID, "gpf_ptdf_build: no in-service slack generator in this topology");
+  const int nr = (int)buses.size();
+  std::vector<double> M((size_t)nr * 2 * nr, 0.0);
+  for (int r = 0; r < nr; ++r) M[(size_t)r * 2 * nr + nr + r] = 1.0;
+  for (int l = 0; l < g.n_line; ++l) {
+    if (lf[l] < 0 || lf[l] == lt[l]) continue;
+    const double bb = e->h_br_bdc[l];
+    const int a = idx[lf[l]], c = idx[lt[l]];
+    if (a >= 0) M[(size_t)a * 2 * nr + a] += bb;
+    if (c >= 0) M[(size_t)c * 2 * nr + c] += bb;
+    if (a >= 0 && c >= 0) { M[(size_t)a * 2 * nr + c] -= bb; M[(size_t)c * 2 * nr + a] -= bb; }
+  }
+  for (int k = 0; k < nr; ++k) {
+    int p = k;
+    for (int r = k + 1; r < nr; ++r) if (std::fabs(M[(size_t)r * 2 * nr + k]) > std::fabs(M[(size_t)p * 2 * nr + k])) p = r;
+    const double pv = M[(size_t)p * 2 * nr + k];
+    if (!(std::fabs(pv) > 1e-12)) return fail(GPF_E_INVALID, "gpf_ptdf_build: the topology is islanded (singular B')");
+    if (p != k) for (int q = 0; q < 2 * nr; ++q) std::swap(M[(size_t)k * 2 * nr + q], M[(size_t)p * 2 * nr + q]);
+    const double rp = 1.0 / pv;
+    for (int q = 0; q < 2 * nr; ++q) M[(size_t)k * 2 * nr + q] *= rp;
+    for (int r = 0; r < nr; ++r) {
+      if (r == k) continue;
+      const double mlt = M[(size_t)r * 2 * nr + k];
+      if (mlt == 0.0) continue;
+      for (int q = k; q < 2 * nr; ++q) M[(size_t)r * 2 * nr + q] -= mlt * M[(size_t)k * 2 * nr + q];
+    }
+  }
+  auto X = [&](int bus_row, int bus_col) -> double {
+    const int r = bus_row >= 0 ? idx[bus_row] : -1, c = idx[bus_col];
+    return (r >= 0 && c >= 0) ? M[(size_t)r * 2 * nr + nr + c] : 0.0;
+  };
+  e->h_ptdf.assign((size_t)g.n_line * nbt, 0.0);
+  // the device GEMM runs over the ACTIVE buses only (compact index: half of the n_sub * n_busbar ids are unused)
+  std::vector<int> compact(nbt, -1);
+  int n_act = 0;
+  for (int b = 0; b < nbt; ++b) if (act[b]) compact[b] = n_act++;
+  const int nb_pad = std::max(4, (n_act + 3) & ~3), line_pad = (g.n_line + 15) & ~15;
+  std::vector<double> pt((size_t)nb_pad * line_pad, 0.0);
+  for (int l = 0; l < g.n_line; ++l) {
+    if (lf[l] < 0 || lf[l] == lt[l]) continue;
+    for (int b = 0; b < nbt; ++b) {
+      if (idx[b] < 0) continue;
+      const double v = e->h_br_bdc[l] * (X(lf[l], b) - X(lt[l], b));
+      e->h_ptdf[(size_t)l * nbt + b] = v;
+      pt[(size_t)compact[b] * line_pad + l] = v;
+    }
+  }
+  for (int i = 0; i < g.n_inj; ++i) if (inj_bus[i] >= 0) inj_bus[i] = compact[inj_bus[i]];
+  e->ptdf_ready = false;
+  e->ptdf_inj_bus.release(); e->ptdf_inj_w.release(); e->ptdf_t.release();
+  HIP_TRY(e->ptdf_inj_bus.upload(inj_bus.data(), inj_bus.size()));
+  HIP_TRY(e->ptdf_inj_w.upload(inj_w.data(), inj_w.size()));
+  HIP_TRY(e->ptdf_t.upload(pt.data(), pt.size()));
+  if (e->ptdf_nb_pad != nb_pad || e->ptdf_line_pad != line_pad || !e->ptdf_pbus.p) {
+    e->ptdf_pbus.release(); e->ptdf_flow.release();
+    HIP_TRY(e->ptdf_pbus.alloc((size_t)e->cap_lanes * nb_pad));
+    HIP_TRY(e->ptdf_flow.alloc((size_t)e->cap_lanes * line_pad));
+  }
+  e->ptdf_nb_pad = nb_pad; e->ptdf_line_pad = line_pad;
+  e->ptdf_ready = true;
+  return GPF_OK;
+}
+
+int gpf_ptdf_get(gpf_handle e, double* ptdf) {
+  if (!e || !ptdf) return fail(GPF_E_INVALID, "gpf_ptdf_get: null");
+  if (!e->ptdf_ready) return fail(GPF_E_INVALID, "gpf_ptdf_get: call gpf_ptdf_build first");
+  std::copy(e->h_ptdf.begin(), e->h_ptdf.end(), ptdf);
+  return GPF_OK;
+}
+
+int gpf_ptdf_flows(gpf_handle e, int32_t lane0, int32_t n) {
+  if (!check_range(e, lane0, n)) return fail(GPF_E_INVALID, "gpf_ptdf_flows: bad range");
+  if (!e->ptdf_ready) return fail(GPF_E_INVALID, "gpf_ptdf_flows: call gpf_ptdf_build first");
+  if (n == 0) return GPF_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  gpf::PtdfDev P{};
+  P.n_inj = e->g.n_inj; P.nb_pad = e->ptdf_nb_pad; P.line_pad = e->ptdf_line_pad; P.n_line = e->g.n_line;
+  P.inj_bus = e->ptdf_inj_bus.p; P.inj_w = e->ptdf_inj_w.p; P.ptdf_t = e->ptdf_t.p;
+  hipLaunchKernelGGL(gpf::ptdf_bus_injection_kernel, dim3(n), dim3(gpf::WAVE), (size_t)P.nb_pad * sizeof(double), e->stream, P, e->inj.p,
+                     lane0, e->ptdf_pbus.p);
+  hipLaunchKernelGGL(gpf::ptdf_gemm_kernel, dim3((n + 15) / 16), dim3(256), 0, e->stream, P, e->ptdf_pbus.p, lane0, n, e->ptdf_flow.p);
+  HIP_TRY(hipGetLastError());
+  if (e->window) ++e->win_launches;
+  return GPF_OK;
+}
+
+int gpf_get_ptdf_flows(gpf_handle e, int32_t lane0, int32_t n, float* p_or) {
+  if (!check_range(e, lane0, n) || !p_or) return fail(GPF_E_INVALID, "gpf_get_ptdf_flows: bad arguments");
+  if (!e->ptdf_ready) return fail(GPF_E_INVALID, "gpf_get_ptdf_flows: call gpf_ptdf_build first");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpy2DAsync(p_or, (size_t)e->g.n_line * sizeof(float), e->ptdf_flow.p + (size_t)lane0 * e->ptdf_line_pad,
+                           (size_t)e->ptdf_line_pad * sizeof(float), (size_t)e->g.n_line * sizeof(float), (size_t)n,
+                           hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
   return GPF_OK;
 }
 

@@ -275,6 +275,28 @@ class PowerFlowEngine:
         return rho, oc, dr
 
     # ---- measurement -------------------------------------------------------------------------------------
+    # ---- DC sensitivity (PTDF) path: fixed topology, flows = PTDF * P_bus as one FP64 MFMA GEMM ----------------------
+    def ptdf_build(self, lane: int = 0):
+        """Factorise the DC system of the topology currently held by ``lane`` (once per topology)."""
+        check(self._lib.gpf_ptdf_build(self._h, int(lane)), "gpf_ptdf_build")
+
+    def ptdf(self) -> np.ndarray:
+        """PTDF [n_line, n_sub * n_busbar] (MW of origin-side flow per MW injected at the bus, slack-referenced)."""
+        out = np.empty((self.model.n_line, self.nb_total), dtype=np.float64)
+        check(self._lib.gpf_ptdf_get(self._h, ptr(out, C.c_double)), "gpf_ptdf_get")
+        return out
+
+    def ptdf_flows(self, lane0: int = 0, n: Optional[int] = None, fetch: bool = True) -> Optional[np.ndarray]:
+        """DC active-power flows (MW, float32 [n, n_line]) of the lanes' current injection rows (asynchronous launch;
+        ``fetch=False`` leaves the result on the device)."""
+        lane0, n = self._range(lane0, n)
+        check(self._lib.gpf_ptdf_flows(self._h, lane0, n), "gpf_ptdf_flows")
+        if not fetch:
+            return None
+        out = np.empty((n, self.model.n_line), dtype=np.float32)
+        check(self._lib.gpf_get_ptdf_flows(self._h, lane0, n, ptr(out, C.c_float)), "gpf_get_ptdf_flows")
+        return out
+
     def sync(self):
         check(self._lib.gpf_sync(self._h), "gpf_sync")
 

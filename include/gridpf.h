@@ -155,6 +155,19 @@ int gpf_step(gpf_handle h, int32_t t, int32_t max_iter, double tol_mva, double r
 int gpf_get_step_outputs(gpf_handle h, int32_t lane0, int32_t n, float* rho, int32_t* overflow_count,
                          int32_t* disc_round);
 
+/* ---- DC sensitivity (PTDF) path ------------------------------------------------------------------------------
+ * The reference solves B' theta = P from scratch on every DC power flow (pp.rundcpp, pandaPowerBackend.py:1090).
+ * For a FIXED topology the DC branch flows are linear in the bus injections: p_or = PTDF * P_bus.
+ * gpf_ptdf_build factorises the DC system of the topology currently held by `lane` (host side, once) and keeps the
+ * PTDF on the device; gpf_ptdf_flows evaluates lanes [lane0, lane0+n) from their current injection rows (as left
+ * by gpf_set_injections / gpf_step) with one FP64 MFMA GEMM (asynchronous); gpf_get_ptdf_flows copies the active
+ * power flows at the origin side (MW, float32 [n][n_line]; the extremity side is the negative, DC has no losses).
+ * Errors: no in-service slack generator / islanded topology -> GPF_E_INVALID. */
+int gpf_ptdf_build(gpf_handle h, int32_t lane);
+int gpf_ptdf_get(gpf_handle h, double* ptdf /* [n_line][n_sub*n_busbar] row-major, MW per MW */);
+int gpf_ptdf_flows(gpf_handle h, int32_t lane0, int32_t n);
+int gpf_get_ptdf_flows(gpf_handle h, int32_t lane0, int32_t n, float* p_or);
+
 /* ---- measurement ---------------------------------------------------------------------------------------- */
 int gpf_sync(gpf_handle h);
 /* Event timing of the solver launches on the handle's stream.  mode 0: off.  mode 1 (window): ONE event pair around all

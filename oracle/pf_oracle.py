@@ -464,3 +464,57 @@ def _results_dc(m, st, res, va_rad, vm, B, active, lor, lex, status, gbus, lbus,
                 res.gen_p[g] = p_slack / len(slacks)
     res.gen_v = _bus_lookup(gbus, vm) * m.sub_vn_kv[m.gen_sub]
     res.gen_theta = _bus_lookup(gbus, va)
+
+
+def ptdf(m, st: LaneState, n_busbar: int = 2):
+    """DC sensitivity matrix of the topology of ``st`` (test oracle of gpf_ptdf_build): PTDF [n_line, n_sub*n_busbar],
+    origin-side MW per MW injected at the bus, slack-referenced.  Same DC model as ``solve(..., is_dc=True)``
+    (pp.rundcpp, pandaPowerBackend.py:1090): flows = PTDF @ dc_bus_injection."""
+    nb_tot = m.n_sub * n_busbar
+    lor, lex, status, gbus, lbus, sbus, shbus = element_buses(m, st)
+    active = np.zeros(nb_tot, dtype=bool)
+    for arr in (lor, lex, gbus, lbus, sbus, shbus):
+        active[arr[arr >= 0]] = True
+    slack_on = (gbus >= 0) & m.gen_slack
+    if not slack_on.any():
+        raise ValueError("no in-service slack generator")
+    is_ref = np.zeros(nb_tot, bool)
+    is_ref[np.unique(gbus[slack_on])] = True
+    B = np.zeros((nb_tot, nb_tot))
+    for l in np.nonzero(status)[0]:
+        f, t = lor[l], lex[l]
+        if f == t:
+            continue
+        b = m.br_bdc[l]
+        B[f, f] += b
+        B[t, t] += b
+        B[f, t] -= b
+        B[t, f] -= b
+    free = np.nonzero(active & ~is_ref)[0]
+    X = np.zeros((nb_tot, nb_tot))
+    X[np.ix_(free, free)] = np.linalg.inv(B[np.ix_(free, free)])
+    out = np.zeros((m.n_line, nb_tot))
+    for l in np.nonzero(status)[0]:
+        f, t = lor[l], lex[l]
+        if f != t:
+            out[l] = m.br_bdc[l] * (X[f] - X[t])
+    return out
+
+
+def dc_bus_injection(m, st: LaneState, n_busbar: int = 2):
+    """Active-power injection per bus (MW) as the DC power flow sees it: generators except the slack, minus loads,
+    storages and the shunt conductances at 1 pu."""
+    nb_tot = m.n_sub * n_busbar
+    _, _, _, gbus, lbus, sbus, shbus = element_buses(m, st)
+    P = np.zeros(nb_tot)
+    for g in np.nonzero(gbus >= 0)[0]:
+        if not m.gen_slack[g]:
+            P[gbus[g]] += st.gen_p[g]
+    for i in np.nonzero(lbus >= 0)[0]:
+        P[lbus[i]] -= st.load_p[i]
+    for i in np.nonzero(sbus >= 0)[0]:
+        P[sbus[i]] -= st.storage_p[i]
+    for s in range(m.n_shunt):
+        if shbus[s] >= 0:
+            P[shbus[s]] -= st.shunt_p[s] * m.shunt_fact[s]
+    return P

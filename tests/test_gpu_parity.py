@@ -463,3 +463,67 @@ def test_hip_matches_observations_recorded_with_pandapower(load_model, load_npz)
     assert np.abs(rho[0] - ka["obs14_rho"]).max() < 1e-5
     assert np.array_equal(r.topo_vect[0], ka["obs14_topo_vect"].astype(np.int32))
     eng.close()
+
+
+@pytest.mark.parametrize("name,n", [("l2rpn_case14_sandbox", 50), ("l2rpn_neurips_2020_track1", 33), ("l2rpn_idf_2023", 40),
+                                    ("educ_case14_storage", 17)])
+def test_ptdf_path_matches_dc_power_flow(name, n, load_model):
+    """DC sensitivity path (gpf_ptdf_build / gpf_ptdf_flows, FP64 MFMA GEMM): the PTDF of a topology with a bus split
+    and a line outage equals the oracle's, and PTDF * P_bus reproduces the DC power flow of every lane -- the oracle's
+    (float64) and the device's own per-lane DC solve (kernel S)."""
+    from oracle.pf_oracle import dc_bus_injection, ptdf
+    m = load_model(name)
+    rng = np.random.default_rng(11)
+    base = LaneState.from_model(m)
+    pos_sub = np.empty(m.dim_topo, dtype=np.int64)
+    pos_sub[m.line_or_pos_topo_vect] = m.line_or_sub
+    pos_sub[m.line_ex_pos_topo_vect] = m.line_ex_sub
+    pos_sub[m.gen_pos_topo_vect] = m.gen_sub
+    pos_sub[m.load_pos_topo_vect] = m.load_sub
+    if m.n_storage:
+        pos_sub[m.storage_pos_topo_vect] = m.storage_sub
+    # one topology for the whole batch: a line out + (if the grid stays connected) a substation split
+    for attempt in range(50):
+        st0 = LaneState.from_model(m)
+        l_out = int(rng.integers(m.n_line))
+        st0.topo[m.line_or_pos_topo_vect[l_out]] = -1
+        st0.topo[m.line_ex_pos_topo_vect[l_out]] = -1
+        if attempt < 40:
+            s = int(rng.integers(m.n_sub))
+            pos = np.nonzero(pos_sub == s)[0]
+            if len(pos) >= 4:
+                st0.topo[pos[::2]] = np.where(st0.topo[pos[::2]] >= 1, 2, st0.topo[pos[::2]])
+        if solve(m, st0, is_dc=True).converged:
+            break
+    else:
+        st0 = base
+    states = []
+    for k in range(n):
+        st = LaneState.from_model(m)
+        st.topo = st0.topo.copy()
+        st.load_p = base.load_p * (1 + 0.2 * rng.standard_normal(m.n_load))
+        st.gen_p = base.gen_p * (1 + 0.2 * rng.standard_normal(m.n_gen))
+        if m.n_storage:
+            st.storage_p = rng.uniform(-2, 2, m.n_storage)
+        states.append(st)
+    eng = _engine(m, n)
+    inj, topo, sb = _pack(eng, states)
+    eng.set_injections(inj)
+    eng.set_topology(topo, sb)
+    eng.ptdf_build(lane=0)
+    T = eng.ptdf()
+    T_ref = ptdf(m, st0)
+    assert np.abs(T - T_ref).max() < 1e-10
+    flows = eng.ptdf_flows()
+    eng.runpf(is_dc=True)
+    r = eng.results()
+    assert r.converged.all()
+    for k, st in enumerate(states):
+        ref = T_ref @ dc_bus_injection(m, st)
+        tol = 2e-4 + 5e-6 * np.abs(ref)
+        assert np.all(np.abs(flows[k] - ref) <= tol), (k, np.abs(flows[k] - ref).max())
+        assert np.all(np.abs(flows[k] - r.p_or[k]) <= 2 * tol), k
+    # ragged sub-range
+    part = eng.ptdf_flows(lane0=3, n=5)
+    assert np.array_equal(part, flows[3:8])
+    eng.close()
