@@ -527,3 +527,36 @@ def test_ptdf_path_matches_dc_power_flow(name, n, load_model):
     part = eng.ptdf_flows(lane0=3, n=5)
     assert np.array_equal(part, flows[3:8])
     eng.close()
+
+
+@pytest.mark.parametrize("name,B", [("l2rpn_wcci_2022_dev", 1024), ("l2rpn_neurips_2020_track1", 4096)])
+def test_large_batches_at_bench_size_vs_c_oracle(name, B, load_model, load_npz):
+    """The bench-size launches of the larger grids pick other kernel variants than the small test batches (static tables
+    read in place / only the program staged in LDS, one instance per wavefront): every lane must converge, obey KCL and
+    a sample of lanes must match the C oracle."""
+    from grid2op_amd.sharding import synthetic_lane_inputs
+    from oracle.pf_oracle_c import COracle
+    m = load_model(name)
+    ch = load_npz(f"{name}.chronics.npz")
+    if "prod_v" not in ch:
+        ch = dict(ch)
+        ch["prod_v"] = np.tile((m.gen_vm0 * m.sub_vn_kv[m.gen_sub]).astype(np.float32), (ch["prod_p"].shape[0], 1))
+    eng = _engine(m, B)
+    tab = eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"])
+    eng.upload_chronics(tab)
+    off, sc = synthetic_lane_inputs(m.n_load, tab.shape[0], np.arange(B))
+    eng.set_lane_chronics(lane_offset=off, lane_scale=sc)
+    eng.step(3, rebalance=1.02)
+    r = eng.results()
+    assert r.converged.all()
+    p_bus = np.zeros((B, m.n_sub))
+    for sub, val in [(m.line_or_sub, r.p_or), (m.line_ex_sub, r.p_ex), (m.load_sub, r.load_p), (m.gen_sub, -r.gen_p),
+                     (m.shunt_sub, r.shunt_p)] + ([(m.storage_sub, r.storage_p)] if m.n_storage else []):
+        np.add.at(p_bus, (slice(None), sub), val.astype(np.float64))
+    assert np.abs(p_bus).max() < 1e-2
+    orc = COracle(m)
+    for k in np.random.default_rng(1).choice(B, 24, replace=False):
+        _, o, st = orc.step_batch(tab, off, sc, 1.02, 3, int(k), 1, want_out=True)
+        assert st[0, 0] == 0
+        assert np.allclose(r.out[k], o[0], rtol=5e-6, atol=2e-4), k
+    eng.close()
