@@ -247,6 +247,12 @@ def main():
         l0, _ = lane_range(world * B2, world, rank)
         off2, sc2 = synthetic_lane_inputs(m2.n_load, T2, l0 + np.arange(B2))
         eng2.set_lane_chronics(lane_offset=off2, lane_scale=sc2)
+        if m2.n_storage:                                      # BASELINE.json configs[3]: storage actions, U(-2, 2) MW per unit
+            inj2 = eng2.get_injections()
+            lay2 = eng2.layout
+            for k in range(B2):
+                inj2[k, lay2.inj_storage_p:lay2.inj_storage_p + m2.n_storage] = np.random.default_rng(l0 + k).uniform(-2.0, 2.0, m2.n_storage)
+            eng2.set_injections(inj2)
         steps2 = max(10, args.steps // 4)
 
         def sync2():
@@ -259,7 +265,7 @@ def main():
         r2 = eng2.results()
         if rank == 0:
             b2 = eng2.algorithmic_bytes_per_step()
-            sec = {"workload": f"{env2} (118 substations) AC NR DoNothing env.step, batch={B2} lanes per GPU", "value": world * B2 * steps2 / el2,
+            sec = {"workload": f"{env2} (118 substations) AC NR env.step with storage set-points U(-2,2) MW, batch={B2} lanes per GPU", "value": world * B2 * steps2 / el2,
                    "unit": "env steps/sec", "ms_per_step": el2 / steps2 * 1e3, "steps": steps2,
                    "avg_launch_us": k2 / max(n2, 1) * 1e3, "algorithmic_bytes_per_step": b2,
                    "hbm_gbs": b2 * B2 / (k2 / max(n2, 1) * 1e-3) / 1e9 if k2 > 0 else 0.0,

@@ -22,7 +22,7 @@ gold = os.path.join(ROOT, "tests", "golden")
 m = GridModel.load_npz(os.path.join(gold, f"{env}.grid.npz"))
 ch = dict(np.load(os.path.join(gold, f"{env}.chronics.npz")))
 eng = PowerFlowEngine(m, n_lanes=B)
-eng.upload_chronics(eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch.get("prod_v", np.ones_like(ch["prod_p"]))))
+eng.upload_chronics(eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch.get("prod_v", np.tile((m.gen_vm0 * m.sub_vn_kv[m.gen_sub]).astype(np.float32), (ch["prod_p"].shape[0], 1)))))
 eng.set_lane_chronics(lane_offset=(7 * np.arange(B)) % ch["load_p"].shape[0])
 for t in range(5):
     eng.step(t, rebalance=1.02)
