@@ -108,8 +108,8 @@ def run_workload(eng, steps, warmup, step_kw, sync_all):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--env", default="l2rpn_case14_sandbox")
     ap.add_argument("--batch", type=int, default=4096, help="lanes per GPU")
     ap.add_argument("--cascade", action="store_true", help="enable overflow disconnections (cascade loop)")
