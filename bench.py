@@ -219,8 +219,10 @@ def main():
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": (measured_traffic_bytes() or {}).get("hbm_bytes_per_launch"),
                          "kernel": (measured_traffic_bytes() or {}).get("kernel"), "avg_launch_us": avg_launch_s * 1e6, "launches": int(n_launch),
                          "algorithmic_bytes_per_step": bytes_step,
-                         "note": "small dense FP64 factorisations dominate: the kernel is issue/latency bound, not HBM "
-                                 "bound (SURVEY.md 8(d)); the FP64 figure below is the relevant ceiling",
+                         "lds_pipe_busy_frac": (measured_traffic_bytes() or {}).get("lds_pipe_busy_frac"),
+                         "note": "chains of small FP64 block factorisations in LDS dominate: the kernel is LDS-pipe / issue / latency "
+                                 "bound, not HBM bound (SURVEY.md 8(d), DESIGN.md 3); lds_pipe_busy_frac is the PMC figure of the "
+                                 "committed profile, f64 the dense-equivalent flop rate",
                          "f64": {"achieved_tflops": flops_pf * B / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0,
                                  "peak_tflops": F64_PEAK_TFLOPS, "algorithmic_flops_per_step": flops_pf, "J": J}},
             "frac_converged": frac_conv,
