@@ -65,6 +65,7 @@ struct LaunchPlan {
   int small_nmax;   // 0: generic LDS kernels (v1); 24/32/48/64: register-resident kernels (v2)
   int sparse_nb;    // 0: no; 1..3: block-sparse kernel S with NB busbars per substation block
   int minw;         // kernel S: __launch_bounds__ waves per SIMD (4 caps the kernel at 128 VGPRs: only worth it when LDS allows > 8 blocks per CU)
+  int wpi;          // kernel S: wavefronts per instance (1, 2 or 4; > 1 only for NB == 1, IPW == 1 on large grids)
   int ipw;          // kernel S: grid instances per wavefront (1, 2 or 4; > 1 only for NB == 1 on small grids)
   int sparse_stage;  // 0: static tables read in place (L2), 1: program + pair table + injection row in LDS, 2: everything in LDS // program staged in LDS (small grids) or streamed from L2 (keeps 3 instances per CU on 118-bus grids)
 };
@@ -119,6 +120,7 @@ struct gpf_engine {
   bool params_s_valid = false;
   bool force_sparse = false;   // GRIDPF_FORCE_SPARSE=1
   int ipw_override = 0;        // GRIDPF_IPW=1|2|4 (developer override of the instances-per-wavefront heuristic)
+  int wpi_override = 0;        // GRIDPF_WPI=1|2|4 (developer override of the wavefronts-per-instance heuristic)
   int cap_lanes = 0;           // lane buffers are padded to a multiple of 4 lanes (instance groups of a wavefront)
   bool dense_small_64 = false; // GRIDPF_DENSE64=1: use the dense register kernels up to n = 64 (experiment)
   bool dense_small = false;    // GRIDPF_DENSE=1: dense register-resident kernels (gridpf_small.hpp) for n <= 32
@@ -217,6 +219,7 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
   p.small_nmax = 0;
   p.sparse_nb = 0;
   p.ipw = 1;
+  p.wpi = 1;
   p.minw = 2;
   p.sparse_stage = 0;
   int mb = 1;
@@ -273,6 +276,9 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
       p.sparse_nb = nbk;
       p.ipw = ipw;
       p.minw = (nbk == 1 && ipw == 1 && LDS_HARD_LIMIT / l >= 12) ? 4 : 2;
+      // large grids: phases loop over hundreds of items -> several wavefronts per instance (block-wide barriers)
+      p.wpi = (nbk == 1 && ipw == 1) ? (e->wpi_override ? e->wpi_override : (e->g.n_sub >= 64 ? 2 : 1)) : 1;
+      if (p.wpi > 1) p.minw = 2;
       p.sparse_stage = stage;
       p.big = false;
       p.lds = l;
@@ -403,6 +409,8 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     e->force_sparse = fs && fs[0] == '1';
     const char* iw = std::getenv("GRIDPF_IPW");
     e->ipw_override = (iw && (iw[0] == '1' || iw[0] == '2' || iw[0] == '4')) ? iw[0] - '0' : 0;
+    const char* ww = std::getenv("GRIDPF_WPI");
+    e->wpi_override = (ww && (ww[0] == '1' || ww[0] == '2' || ww[0] == '4')) ? ww[0] - '0' : 0;
     const char* dn = std::getenv("GRIDPF_DENSE");
     e->dense_small = dn && dn[0] == '1';
     const char* d64 = std::getenv("GRIDPF_DENSE64");
@@ -706,29 +714,35 @@ int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
   if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
   if (p.sparse_nb) { rc = upload_params_s(e, b); if (rc != GPF_OK) return rc; }
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
-#define LAUNCH_RUNPF_SPARSE(NBK, ST, IPW, MW)                                                                                           \
+#define LAUNCH_RUNPF_SPARSE(NBK, ST, IPW, MW, WP)                                                                                           \
   do {                                                                                                                      \
     static size_t lds_set_[64] = {0};                                                                                       \
     if (p.lds > lds_set_[e->device & 63]) {                                                                                  \
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<NBK, ST, IPW, MW>),                         \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<NBK, ST, IPW, MW, WP>),                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                   \
       lds_set_[e->device & 63] = p.lds;                                                                                     \
     }                                   \
-    hipLaunchKernelGGL((gpf::runpf_sparse_kernel<NBK, ST, IPW, MW>), dim3((n + IPW - 1) / IPW), dim3(gpf::WAVE), p.lds, e->stream,  \
+    hipLaunchKernelGGL((gpf::runpf_sparse_kernel<NBK, ST, IPW, MW, WP>), dim3((n + IPW - 1) / IPW), dim3(gpf::WAVE * WP), p.lds, e->stream,  \
                        e->d_params_s, lane0, is_dc, max_iter, tol_pu);                                                      \
   } while (0)
-  if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_RUNPF_SPARSE(1, 2, 4, 2);
-  else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_RUNPF_SPARSE(1, 2, 2, 2);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 2 && p.minw == 4) LAUNCH_RUNPF_SPARSE(1, 2, 1, 4);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 2) LAUNCH_RUNPF_SPARSE(1, 2, 1, 2);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 1 && p.minw == 4) LAUNCH_RUNPF_SPARSE(1, 1, 1, 4);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 1) LAUNCH_RUNPF_SPARSE(1, 1, 1, 2);
-  else if (p.sparse_nb == 1 && p.minw == 4) LAUNCH_RUNPF_SPARSE(1, 0, 1, 4);
-  else if (p.sparse_nb == 1) LAUNCH_RUNPF_SPARSE(1, 0, 1, 2);
-  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(2, 1, 1, 2);
-  else if (p.sparse_nb == 2) LAUNCH_RUNPF_SPARSE(2, 0, 1, 2);
-  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(3, 1, 1, 2);
-  else if (p.sparse_nb == 3) LAUNCH_RUNPF_SPARSE(3, 0, 1, 2);
+  if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_RUNPF_SPARSE(1, 2, 4, 2, 1);
+  else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_RUNPF_SPARSE(1, 2, 2, 2, 1);
+  else if (p.sparse_nb == 1 && p.wpi == 2 && p.sparse_stage == 2) LAUNCH_RUNPF_SPARSE(1, 2, 1, 2, 2);
+  else if (p.sparse_nb == 1 && p.wpi == 2 && p.sparse_stage == 1) LAUNCH_RUNPF_SPARSE(1, 1, 1, 2, 2);
+  else if (p.sparse_nb == 1 && p.wpi == 2) LAUNCH_RUNPF_SPARSE(1, 0, 1, 2, 2);
+  else if (p.sparse_nb == 1 && p.wpi == 4 && p.sparse_stage == 2) LAUNCH_RUNPF_SPARSE(1, 2, 1, 2, 4);
+  else if (p.sparse_nb == 1 && p.wpi == 4 && p.sparse_stage == 1) LAUNCH_RUNPF_SPARSE(1, 1, 1, 2, 4);
+  else if (p.sparse_nb == 1 && p.wpi == 4) LAUNCH_RUNPF_SPARSE(1, 0, 1, 2, 4);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 2 && p.minw == 4) LAUNCH_RUNPF_SPARSE(1, 2, 1, 4, 1);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 2) LAUNCH_RUNPF_SPARSE(1, 2, 1, 2, 1);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 1 && p.minw == 4) LAUNCH_RUNPF_SPARSE(1, 1, 1, 4, 1);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 1) LAUNCH_RUNPF_SPARSE(1, 1, 1, 2, 1);
+  else if (p.sparse_nb == 1 && p.minw == 4) LAUNCH_RUNPF_SPARSE(1, 0, 1, 4, 1);
+  else if (p.sparse_nb == 1) LAUNCH_RUNPF_SPARSE(1, 0, 1, 2, 1);
+  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(2, 1, 1, 2, 1);
+  else if (p.sparse_nb == 2) LAUNCH_RUNPF_SPARSE(2, 0, 1, 2, 1);
+  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(3, 1, 1, 2, 1);
+  else if (p.sparse_nb == 3) LAUNCH_RUNPF_SPARSE(3, 0, 1, 2, 1);
   else
 #define LAUNCH_RUNPF_SMALL(NM, LP)                                                                                              \
   hipLaunchKernelGGL((gpf::runpf_small_kernel<NM, LP>), dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, lane0, p.nbc,   \
@@ -830,29 +844,35 @@ int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double r
   if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
   if (p.sparse_nb) { rc = upload_params_s(e, b); if (rc != GPF_OK) return rc; }
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
-#define LAUNCH_STEP_SPARSE(NBK, ST, IPW, MW)                                                                                           \
+#define LAUNCH_STEP_SPARSE(NBK, ST, IPW, MW, WP)                                                                                           \
   do {                                                                                                                      \
     static size_t lds_set_[64] = {0};                                                                                       \
     if (p.lds > lds_set_[e->device & 63]) {                                                                                  \
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<NBK, ST, IPW, MW>),                          \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<NBK, ST, IPW, MW, WP>),                          \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                   \
       lds_set_[e->device & 63] = p.lds;                                                                                     \
     }                                   \
-    hipLaunchKernelGGL((gpf::step_sparse_kernel<NBK, ST, IPW, MW>), dim3((e->n_lanes + IPW - 1) / IPW), dim3(gpf::WAVE), p.lds,     \
+    hipLaunchKernelGGL((gpf::step_sparse_kernel<NBK, ST, IPW, MW, WP>), dim3((e->n_lanes + IPW - 1) / IPW), dim3(gpf::WAVE * WP), p.lds,     \
                        e->stream, e->d_params_s, max_iter, tol_pu, sa);                                                     \
   } while (0)
-  if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_STEP_SPARSE(1, 2, 4, 2);
-  else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_STEP_SPARSE(1, 2, 2, 2);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 2 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 2, 1, 4);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 2) LAUNCH_STEP_SPARSE(1, 2, 1, 2);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 1 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 1, 1, 4);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 1) LAUNCH_STEP_SPARSE(1, 1, 1, 2);
-  else if (p.sparse_nb == 1 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 0, 1, 4);
-  else if (p.sparse_nb == 1) LAUNCH_STEP_SPARSE(1, 0, 1, 2);
-  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_STEP_SPARSE(2, 1, 1, 2);
-  else if (p.sparse_nb == 2) LAUNCH_STEP_SPARSE(2, 0, 1, 2);
-  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_STEP_SPARSE(3, 1, 1, 2);
-  else if (p.sparse_nb == 3) LAUNCH_STEP_SPARSE(3, 0, 1, 2);
+  if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_STEP_SPARSE(1, 2, 4, 2, 1);
+  else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_STEP_SPARSE(1, 2, 2, 2, 1);
+  else if (p.sparse_nb == 1 && p.wpi == 2 && p.sparse_stage == 2) LAUNCH_STEP_SPARSE(1, 2, 1, 2, 2);
+  else if (p.sparse_nb == 1 && p.wpi == 2 && p.sparse_stage == 1) LAUNCH_STEP_SPARSE(1, 1, 1, 2, 2);
+  else if (p.sparse_nb == 1 && p.wpi == 2) LAUNCH_STEP_SPARSE(1, 0, 1, 2, 2);
+  else if (p.sparse_nb == 1 && p.wpi == 4 && p.sparse_stage == 2) LAUNCH_STEP_SPARSE(1, 2, 1, 2, 4);
+  else if (p.sparse_nb == 1 && p.wpi == 4 && p.sparse_stage == 1) LAUNCH_STEP_SPARSE(1, 1, 1, 2, 4);
+  else if (p.sparse_nb == 1 && p.wpi == 4) LAUNCH_STEP_SPARSE(1, 0, 1, 2, 4);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 2 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 2, 1, 4, 1);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 2) LAUNCH_STEP_SPARSE(1, 2, 1, 2, 1);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 1 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 1, 1, 4, 1);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 1) LAUNCH_STEP_SPARSE(1, 1, 1, 2, 1);
+  else if (p.sparse_nb == 1 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 0, 1, 4, 1);
+  else if (p.sparse_nb == 1) LAUNCH_STEP_SPARSE(1, 0, 1, 2, 1);
+  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_STEP_SPARSE(2, 1, 1, 2, 1);
+  else if (p.sparse_nb == 2) LAUNCH_STEP_SPARSE(2, 0, 1, 2, 1);
+  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_STEP_SPARSE(3, 1, 1, 2, 1);
+  else if (p.sparse_nb == 3) LAUNCH_STEP_SPARSE(3, 0, 1, 2, 1);
   else
 #define LAUNCH_STEP_SMALL(NM, LP)                                                                                               \
   hipLaunchKernelGGL((gpf::step_small_kernel<NM, LP>), dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, p.nbc,   \

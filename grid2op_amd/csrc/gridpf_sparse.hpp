@@ -133,14 +133,14 @@ __device__ inline void make_stat_view(StatView& sv, const SymDev& S, unsigned ch
   if (STAGE == 2) {
     double* sd = reinterpret_cast<double*>(lds_static);
     int* si = reinterpret_cast<int*>(sd + S.so.n_dbl);
-    for (int i = threadIdx.x; i < S.so.n_dbl; i += WAVE) sd[i] = S.stat_dbl[i];
-    for (int i = threadIdx.x; i < S.so.n_int; i += WAVE) si[i] = S.stat_int[i];
+    for (int i = threadIdx.x; i < S.so.n_dbl; i += blockDim.x) sd[i] = S.stat_dbl[i];
+    for (int i = threadIdx.x; i < S.so.n_int; i += blockDim.x) si[i] = S.stat_int[i];
     stat_view(sv, S.so, sd, si);
   } else {
     stat_view(sv, S.so, S.stat_dbl, S.stat_int);
     if (STAGE == 1) {
       int* si = reinterpret_cast<int*>(lds_static);
-      for (int i = threadIdx.x; i < S.so.n_int_hot; i += WAVE) si[i] = S.stat_int[i];
+      for (int i = threadIdx.x; i < S.so.n_int_hot; i += blockDim.x) si[i] = S.stat_int[i];
       sv.prog = si + S.so.prog;
       sv.pair_rc = si + S.so.pair_rc;
     }
@@ -171,21 +171,47 @@ __device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const Gr
   c.sub_bb = reinterpret_cast<i8*>(q);
 }
 
-// Instance groups: a wavefront serves IPW instances, GW = 64 / IPW lanes each (small grids do not have 64-wide work).
-// All groups execute the same instruction stream (same grid, same symbolic program); collectives are scoped to the group.
-template <int IPW>
+// Instance groups: a wavefront serves IPW instances, GW = 64 / IPW lanes each (small grids do not have 64-wide work), or
+// -- large grids, whose phases loop over hundreds of items -- WPI wavefronts serve ONE instance (GW = 64 * WPI lanes, the
+// phase boundaries become real workgroup barriers).  All lanes execute the same instruction stream (same grid, same
+// symbolic program); collectives are scoped to the group.
+template <int IPW, int WPI = 1>
 struct Grp {
-  static constexpr int GW = WAVE / IPW;
+  static_assert(IPW == 1 || WPI == 1, "either several instances per wavefront or several wavefronts per instance");
+  static constexpr int GW = WPI > 1 ? WAVE * WPI : WAVE / IPW;
+  static constexpr int BLOCK = WAVE * WPI;
   static __device__ __forceinline__ unsigned long long mask() {
-    return IPW == 1 ? ~0ull : (((1ull << GW) - 1ull) << ((threadIdx.x / GW) * GW));
+    return IPW == 1 ? ~0ull : (((1ull << (GW & 63)) - 1ull) << ((threadIdx.x / GW) * GW));
   }
-  static __device__ __forceinline__ bool any(bool x) { return IPW == 1 ? (bool)__any(x) : ((__ballot(x) & mask()) != 0ull); }
-  static __device__ __forceinline__ int count(bool x) { return __popcll(__ballot(x) & mask()); }
+  // over the lanes of the caller's instance
+  static __device__ __forceinline__ bool any(bool x) {
+    if (WPI > 1) return __syncthreads_or(x) != 0;
+    return IPW == 1 ? (bool)__any(x) : ((__ballot(x) & mask()) != 0ull);
+  }
+  static __device__ __forceinline__ int count(bool x) {
+    if (WPI > 1) return __syncthreads_count(x);
+    return __popcll(__ballot(x) & mask());
+  }
   static __device__ __forceinline__ double sum(double v) {
+    if (WPI > 1) {
+      __shared__ double red_[WPI > 1 ? WPI : 1];
 #pragma unroll
-    for (int off = GW / 2; off; off >>= 1) v += __shfl_xor(v, off);
+      for (int off = WAVE / 2; off; off >>= 1) v += __shfl_xor(v, off);
+      __syncthreads();
+      if ((threadIdx.x & (WAVE - 1)) == 0) red_[threadIdx.x / WAVE] = v;
+      __syncthreads();
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < WPI; ++k) t += red_[k];
+      return t;
+    }
+#pragma unroll
+    for (int off = (GW < WAVE ? GW : WAVE) / 2; off; off >>= 1) v += __shfl_xor(v, off);
     return v;
   }
+  // over ALL lanes of the block (every instance of the wavefront / every wavefront of the instance)
+  static __device__ __forceinline__ bool block_any(bool x) { return WPI > 1 ? (__syncthreads_or(x) != 0) : (bool)__any(x); }
+  static __device__ __forceinline__ bool block_all(bool x) { return WPI > 1 ? (__syncthreads_and(x) != 0) : (bool)__all(x); }
 };
 
 constexpr int BT_OFF = -1;   // inactive bus
@@ -585,10 +611,10 @@ __device__ inline bool scalar_lu_solve(const SymDev& S, const int* __restrict__ 
 // One complete power flow of the IPW instances of a wavefront (tid = lane within the instance group).  Returns the GPF_ST_*
 // status of the caller's group.  Groups share the instruction stream: a group that has failed or finished keeps executing
 // (its state is frozen / its results are overwritten by the caller), so barriers stay wave-uniform.
-template <int NB, int STAGE, int IPW>
+template <int NB, int STAGE, int IPW, int WPI>
 __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, const StatView& sv, CarveP<NB>& c, int inst, int is_dc, int max_iter,
                                             double tol_pu, int tid, bool inj_staged, bool topo_staged, int& n_iter_out, int& nb_out GPF_STAMPS_PARAM) {
-  typedef Grp<IPW> G;
+  typedef Grp<IPW, WPI> G;
   constexpr int GW = G::GW;
   constexpr int BS = 2 * NB;
   constexpr int B2 = BS * BS;
@@ -701,7 +727,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   nb_out = nb;
   GPF_SYNC();
   int status = (nref == 0) ? 3 : 0;           // first failure of this group (0 = alive)
-  if (__all(status != 0)) return status;
+  if (G::block_all(status != 0)) return status;
   GPF_STAMPS(1);
 
   // ---- connectivity ----------------------------------------------------------------------------------------------------
@@ -715,13 +741,13 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       }
     }
     GPF_SYNC();
-    if (!__any(changed)) break;             // extra sweeps of a settled group are idempotent
+    if (!G::block_any(changed)) break;      // extra sweeps of a settled group are idempotent
   }
   {
     int bad = 0;
     for (int i = tid; i < nbus; i += GW) bad |= (c.btype[i] != BT_OFF && c.lab[i] == 0);
     if (status == 0 && G::any(bad)) status = 2;
-    if (__all(status != 0)) return status;
+    if (G::block_all(status != 0)) return status;
   }
   GPF_STAMPS(2);
 
@@ -799,7 +825,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     }
     GPF_SYNC();
     if (status == 0 && G::any(!ok)) status = 4;
-    if (__all(status != 0)) return status;
+    if (G::block_all(status != 0)) return status;
   }
   GPF_STAMPS(4);
 
@@ -876,7 +902,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         else if (it >= max_iter) done = true;
         else ++it;
       }
-      if (__all(done)) break;
+      if (G::block_all(done)) break;
       GPF_SYNC();
       if (it == 1) GPF_STAMPS(12);
       const bool ok = block_lu_solve<BS, GW>(S, sv.prog, c.A, c.rhs, tid);
@@ -912,7 +938,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     if (status == 0 && !converged) status = 1;
   }
   n_iter_out = it;
-  if (__all(status != 0)) return status;
+  if (G::block_all(status != 0)) return status;
   GPF_STAMPS(5);
 
   // ---- K6: results ---------------------------------------------------------------------------------------------------------
@@ -1059,11 +1085,11 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int NB, int STAGE, int IPW, int MINW>
-__global__ __launch_bounds__(WAVE, MINW) void runpf_sparse_kernel(const DevParamsS* __restrict__ P, int lane0, int is_dc, int max_iter,
+template <int NB, int STAGE, int IPW, int MINW, int WPI>
+__global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const DevParamsS* __restrict__ P, int lane0, int is_dc, int max_iter,
                                                             double tol_pu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int GW = WAVE / IPW;
+  constexpr int GW = Grp<IPW, WPI>::GW;
   const int grp = threadIdx.x / GW, tid = threadIdx.x % GW;
   const int inst = lane0 + blockIdx.x * IPW + grp;             // the host pads the lane buffers to a multiple of IPW
   CarveP<NB> c;
@@ -1073,7 +1099,7 @@ __global__ __launch_bounds__(WAVE, MINW) void runpf_sparse_kernel(const DevParam
   make_stat_view<STAGE>(sv, P->sym, smem + (size_t)IPW * per_inst);
   int n_iter, nb;
   GPF_STAMPS_DECL;
-  const int st = solve_instance_sparse<NB, STAGE, IPW>(P, sv, c, inst, is_dc, max_iter, tol_pu, tid, false, false, n_iter, nb GPF_STAMPS_ARG);
+  const int st = solve_instance_sparse<NB, STAGE, IPW, WPI>(P, sv, c, inst, is_dc, max_iter, tol_pu, tid, false, false, n_iter, nb GPF_STAMPS_ARG);
   GPF_SYNC();
   if (st != 0) write_nan_results<GW>(P->g, P->b, inst, tid);
   if (tid == 0) {
@@ -1082,11 +1108,11 @@ __global__ __launch_bounds__(WAVE, MINW) void runpf_sparse_kernel(const DevParam
   }
 }
 
-template <int NB, int STAGE, int IPW, int MINW>
-__global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParamsS* __restrict__ P, int max_iter, double tol_pu,
+template <int NB, int STAGE, int IPW, int MINW, int WPI>
+__global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const DevParamsS* __restrict__ P, int max_iter, double tol_pu,
                                                            StepArgs sa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  typedef Grp<IPW> G;
+  typedef Grp<IPW, WPI> G;
   constexpr int GW = G::GW;
   const GridDev& g = P->g;
   const Bufs& b = P->b;
@@ -1165,7 +1191,7 @@ __global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParams
   while (true) {
     // a group whose cascade has ended re-solves its unchanged state along with the others (same results)
     int it_k = 0, nb_k = 0;
-    const int st_k = solve_instance_sparse<NB, STAGE, IPW>(P, sv, c, inst, 0, max_iter, tol_pu, tid, true, first, it_k, nb_k GPF_STAMPS_ARG);
+    const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI>(P, sv, c, inst, 0, max_iter, tol_pu, tid, true, first, it_k, nb_k GPF_STAMPS_ARG);
     first = false;
     GPF_SYNC();
     if (more) { st = st_k; n_iter = it_k; nb = nb_k; }
@@ -1189,7 +1215,7 @@ __global__ __launch_bounds__(WAVE, MINW) void step_sparse_kernel(const DevParams
     }
     GPF_SYNC();
     if (more && !G::any(any_disc)) more = false;
-    if (!__any(more)) break;
+    if (!G::block_any(more)) break;
     if (more) ++rounds;
   }
   GPF_STAMPS(9);
