@@ -45,7 +45,7 @@ struct Symbolic {
   int max_level_piv = 0;
 };
 
-inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, const int* line_ex_sub) {
+inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, const int* line_ex_sub, int degree_slack = 1) {
   Symbolic S;
   S.n = n_sub;
   std::vector<std::set<int>> adj(n_sub);
@@ -86,9 +86,9 @@ inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, co
   while (remaining > 0) {
     size_t mind = (size_t)-1;
     for (int s = 0; s < n_sub; ++s) if (!done[s]) mind = std::min(mind, g[s].size());
-    // independent set of nodes of degree <= mind + 1, lowest degree first
+    // independent set of nodes of degree <= mind + degree_slack, lowest degree first
     std::vector<int> cand;
-    for (int s = 0; s < n_sub; ++s) if (!done[s] && g[s].size() <= mind + 1) cand.push_back(s);
+    for (int s = 0; s < n_sub; ++s) if (!done[s] && g[s].size() <= mind + (size_t)degree_slack) cand.push_back(s);
     std::stable_sort(cand.begin(), cand.end(), [&](int a, int b) { return g[a].size() < g[b].size(); });
     std::vector<char> blocked(n_sub, 0);
     Level L;

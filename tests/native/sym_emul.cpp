@@ -133,8 +133,9 @@ int sym_emul_solve(int n_sub, int n_line, const int* line_or, const int* line_ex
 }
 
 // level sizes of the program: out[4*lv + {0,1,2,3}] = n_piv, n_b, n_c, n_r; returns n_levels
-extern "C" int sym_level_sizes(int n_sub, int n_line, const int* line_or, const int* line_ex, int* out, int cap) {
-  gpf::Symbolic S = gpf::build_symbolic(n_sub, n_line, line_or, line_ex);
+extern "C" int sym_level_sizes(int n_sub, int n_line, const int* line_or, const int* line_ex, int* out, int cap, int slack) {
+  gpf::Symbolic S = gpf::build_symbolic(n_sub, n_line, line_or, line_ex, slack);
+  out[4 * cap] = S.nslot; out[4 * cap + 1] = S.nslot_y;
   for (int lv = 0; lv < S.n_levels && lv < cap; ++lv) {
     const int* h = S.prog.data() + 8 * lv;
     out[4 * lv] = h[1]; out[4 * lv + 1] = h[3]; out[4 * lv + 2] = h[5]; out[4 * lv + 3] = h[7];
