@@ -282,20 +282,27 @@ __device__ inline int build_topology(const GridDev& g, Carve& c, const int* __re
   return nb;
 }
 
+// Pointers read from a parameter block in memory are GENERIC to the compiler: every access becomes a flat_load /
+// flat_store, which counts on BOTH vmcnt and lgkmcnt -- an LDS wait then also waits for every result store in flight.
+// gptr() re-types such a pointer as global (address space 1) so that global_load / global_store are emitted.
+#define GPF_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ GPF_GLOBAL T* gptr(T* p) { return (GPF_GLOBAL T*)p; }
+
 template <int GW = WAVE>
 __device__ inline void write_nan_results(const GridDev& g, const Bufs& b, int inst, int tid) {
-  float* out = b.out + (size_t)inst * g.n_out;
+  auto out = gptr(b.out) + (size_t)inst * g.n_out;
   const float nanv = __builtin_nanf("");
   for (int i = tid; i < g.n_out; i += GW) out[i] = nanv;
-  int* to = b.topo_out + (size_t)inst * g.dim_topo;
+  auto to = gptr(b.topo_out) + (size_t)inst * g.dim_topo;
   for (int i = tid; i < g.dim_topo; i += GW) to[i] = -1;
-  int* so = b.shunt_bus_out + (size_t)inst * g.n_shunt;
+  auto so = gptr(b.shunt_bus_out) + (size_t)inst * g.n_shunt;
   for (int i = tid; i < g.n_shunt; i += GW) so[i] = -1;
-  unsigned char* ls = b.line_status + (size_t)inst * g.n_line;
+  auto ls = gptr(b.line_status) + (size_t)inst * g.n_line;
   for (int i = tid; i < g.n_line; i += GW) ls[i] = 0;
   const double nand = __builtin_nan("");
-  double* bvm = b.bus_vm + (size_t)inst * g.nb_tot;
-  double* bva = b.bus_va + (size_t)inst * g.nb_tot;
+  auto bvm = gptr(b.bus_vm) + (size_t)inst * g.nb_tot;
+  auto bva = gptr(b.bus_va) + (size_t)inst * g.nb_tot;
   for (int i = tid; i < g.nb_tot; i += GW) { bvm[i] = nand; bva[i] = nand; }
 }
 

@@ -25,20 +25,36 @@ struct StatOff {
   int line_or_pos, line_ex_pos, line_or_sub, line_ex_sub, br_slot, gen_pos, gen_sub, gen_slack, load_pos, load_sub, sto_pos,
       sto_sub, shunt_sub, pair_rc, prog;
 };
-struct StatView {
-  const double *br_y, *br_bdc, *sub_vn_kv, *shunt_fact, *gen_min_q, *gen_max_q;
-  const int *line_or_pos, *line_ex_pos, *line_or_sub, *line_ex_sub, *br_slot, *gen_pos, *gen_sub, *gen_slack, *load_pos,
-      *load_sub, *sto_pos, *sto_sub, *shunt_sub;
-  const int* pair_rc;   // [nslot_y] slot_row | slot_col << 16 of the original-pattern blocks
-  const int* prog;      // level-scheduled program (layout: gridpf_symbolic.hpp)
+// Pointer to a static table that is either staged in LDS or read in place: in place it is re-typed as a GLOBAL pointer
+// (gptr, gridpf_kernels.hpp) so that global_load is emitted instead of flat_load.
+template <class T, bool IN_LDS>
+struct SP {
+  const T* p;
+  __device__ __forceinline__ T operator[](int i) const { return IN_LDS ? p[i] : (T)gptr(p)[i]; }
+  __device__ __forceinline__ double4 ld4(size_t off) const {       // 4 consecutive doubles (32-byte aligned)
+    if (IN_LDS) return *reinterpret_cast<const double4*>(p + off);
+    typedef double v4d_ __attribute__((ext_vector_type(4)));
+    const v4d_ v = *(GPF_GLOBAL const v4d_*)(gptr(p) + off);
+    return make_double4(v.x, v.y, v.z, v.w);
+  }
 };
-__host__ __device__ inline void stat_view(StatView& v, const StatOff& o, const double* d, const int* i) {
-  v.br_y = d + o.br_y; v.br_bdc = d + o.br_bdc; v.sub_vn_kv = d + o.sub_vn_kv; v.shunt_fact = d + o.shunt_fact;
-  v.gen_min_q = d + o.gen_min_q; v.gen_max_q = d + o.gen_max_q;
-  v.line_or_pos = i + o.line_or_pos; v.line_ex_pos = i + o.line_ex_pos; v.line_or_sub = i + o.line_or_sub;
-  v.line_ex_sub = i + o.line_ex_sub; v.br_slot = i + o.br_slot; v.gen_pos = i + o.gen_pos; v.gen_sub = i + o.gen_sub;
-  v.gen_slack = i + o.gen_slack; v.load_pos = i + o.load_pos; v.load_sub = i + o.load_sub; v.sto_pos = i + o.sto_pos;
-  v.sto_sub = i + o.sto_sub; v.shunt_sub = i + o.shunt_sub; v.pair_rc = i + o.pair_rc; v.prog = i + o.prog;
+template <int STAGE>
+struct StatView {
+  static constexpr bool ALL = STAGE == 2, HOT = STAGE >= 1;
+  SP<double, ALL> br_y, br_bdc, sub_vn_kv, shunt_fact, gen_min_q, gen_max_q;
+  SP<int, ALL> line_or_pos, line_ex_pos, line_or_sub, line_ex_sub, br_slot, gen_pos, gen_sub, gen_slack, load_pos, load_sub,
+      sto_pos, sto_sub, shunt_sub;
+  SP<int, HOT> pair_rc;   // [nslot_y] slot_row | slot_col << 16 of the original-pattern blocks
+  SP<int, HOT> prog;      // level-scheduled program (layout: gridpf_symbolic.hpp)
+};
+template <int STAGE>
+__device__ inline void stat_view(StatView<STAGE>& v, const StatOff& o, const double* d, const int* i) {
+  v.br_y.p = d + o.br_y; v.br_bdc.p = d + o.br_bdc; v.sub_vn_kv.p = d + o.sub_vn_kv; v.shunt_fact.p = d + o.shunt_fact;
+  v.gen_min_q.p = d + o.gen_min_q; v.gen_max_q.p = d + o.gen_max_q;
+  v.line_or_pos.p = i + o.line_or_pos; v.line_ex_pos.p = i + o.line_ex_pos; v.line_or_sub.p = i + o.line_or_sub;
+  v.line_ex_sub.p = i + o.line_ex_sub; v.br_slot.p = i + o.br_slot; v.gen_pos.p = i + o.gen_pos; v.gen_sub.p = i + o.gen_sub;
+  v.gen_slack.p = i + o.gen_slack; v.load_pos.p = i + o.load_pos; v.load_sub.p = i + o.load_sub; v.sto_pos.p = i + o.sto_pos;
+  v.sto_sub.p = i + o.sto_sub; v.shunt_sub.p = i + o.shunt_sub; v.pair_rc.p = i + o.pair_rc; v.prog.p = i + o.prog;
 }
 // LDS bytes of the staged part of the blob.  tier 0: nothing; 1: the hot ints (+ the lane's injection row, per instance);
 // 2: everything
@@ -129,20 +145,22 @@ __host__ __device__ inline size_t lds_bytes_sparse(const GridDev& g, int nslot, 
 
 // Stage the static blob in LDS (STAGE) or view it in place; visible to the block after the first barrier.
 template <int STAGE>
-__device__ inline void make_stat_view(StatView& sv, const SymDev& S, unsigned char* lds_static) {
+__device__ inline void make_stat_view(StatView<STAGE>& sv, const SymDev& S, unsigned char* lds_static) {
+  const auto gd = gptr(S.stat_dbl);
+  const auto gi = gptr(S.stat_int);
   if (STAGE == 2) {
     double* sd = reinterpret_cast<double*>(lds_static);
     int* si = reinterpret_cast<int*>(sd + S.so.n_dbl);
-    for (int i = threadIdx.x; i < S.so.n_dbl; i += blockDim.x) sd[i] = S.stat_dbl[i];
-    for (int i = threadIdx.x; i < S.so.n_int; i += blockDim.x) si[i] = S.stat_int[i];
+    for (int i = threadIdx.x; i < S.so.n_dbl; i += blockDim.x) sd[i] = gd[i];
+    for (int i = threadIdx.x; i < S.so.n_int; i += blockDim.x) si[i] = gi[i];
     stat_view(sv, S.so, sd, si);
   } else {
     stat_view(sv, S.so, S.stat_dbl, S.stat_int);
     if (STAGE == 1) {
       int* si = reinterpret_cast<int*>(lds_static);
-      for (int i = threadIdx.x; i < S.so.n_int_hot; i += blockDim.x) si[i] = S.stat_int[i];
-      sv.prog = si + S.so.prog;
-      sv.pair_rc = si + S.so.pair_rc;
+      for (int i = threadIdx.x; i < S.so.n_int_hot; i += blockDim.x) si[i] = gi[i];
+      sv.prog.p = si + S.so.prog;
+      sv.pair_rc.p = si + S.so.pair_rc;
     }
   }
 }
@@ -267,8 +285,8 @@ __device__ __forceinline__ bool block_inverse(const double (&D)[BS * BS], double
 // Level-scheduled block-sparse LU + solve, in place in LDS.  A: [nslot][BS*BS] blocks; rhs: [n][BS] right-hand
 // side -> solution.  All pivots of a level are eliminated concurrently; trailing updates that hit the same block
 // are combined with LDS f64 atomics.
-template <int BS, int GW = WAVE>
-__device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ prog, double* __restrict__ A,
+template <int BS, int GW = WAVE, class PP = const int*>
+__device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restrict__ A,
                                       double* __restrict__ rhs, int tid, long long* dbg = nullptr) {
 #ifdef GPF_TIMING
   const long long t_lu0 = __builtin_readcyclecounter();
@@ -286,7 +304,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
     // c-items in the program), and the level header / the first item words of the NEXT levels are prefetched while the
     // current level computes.  Per level: operand reads -> ~10 dependent f64 ops -> ds_add_f64 -> barrier.
     const int n_levels = S.n_levels;
-    const int4* H = reinterpret_cast<const int4*>(prog);            // level lv: H[2 * lv + 1] = {c_off, n_c, r_off, n_r}
+    auto hdr4 = [&](int k) -> int4 { return make_int4(prog[4 * k], prog[4 * k + 1], prog[4 * k + 2], prog[4 * k + 3]); };   // level lv: hdr4(2 * lv + 1) = {c_off, n_c, r_off, n_r}
     auto item_words = [&](const int4& h, int o, unsigned& w0, unsigned& w1) {
       const bool on = o < h.y + h.w;
       const int at = h.x + 2 * (on ? o : 0);
@@ -320,11 +338,11 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
         atomicAdd(&dst[1], x1);
       }
     };
-    int4 h0 = H[1], h1 = n_levels > 1 ? H[3] : make_int4(0, 0, 0, 0);
+    int4 h0 = hdr4(1), h1 = n_levels > 1 ? hdr4(3) : make_int4(0, 0, 0, 0);
     unsigned w0, w1;
     item_words(h0, tid, w0, w1);
     for (int lv = 0; lv < n_levels; ++lv) {
-      const int4 h2 = lv + 2 < n_levels ? H[2 * (lv + 2) + 1] : make_int4(0, 0, 0, 0);
+      const int4 h2 = lv + 2 < n_levels ? hdr4(2 * (lv + 2) + 1) : make_int4(0, 0, 0, 0);
       unsigned nw0, nw1;
       item_words(h1, tid, nw0, nw1);                               // first-pass words of the next level
       do_item(h0, tid, w0, w1);
@@ -358,8 +376,8 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
     GPF_SYNC();
   } else
   for (int lv = 0; lv < S.n_levels; ++lv) {
-    const int* h = prog + 8 * lv;
-    const int piv_off = h[0], n_piv = h[1], b_off = h[2], n_b = h[3], c_off = h[4], n_c = h[5], r_off = h[6], n_r = h[7];
+    const int piv_off = prog[8 * lv], n_piv = prog[8 * lv + 1], b_off = prog[8 * lv + 2], n_b = prog[8 * lv + 3], c_off = prog[8 * lv + 4],
+              n_c = prog[8 * lv + 5], r_off = prog[8 * lv + 6], n_r = prog[8 * lv + 7];
     // (a) invert the pivot blocks in place
     for (int q = tid; q < n_piv; q += GW) {
       double* Ad = A + (size_t)prog[piv_off + q] * B2;      // diag slot of substation p is slot p
@@ -521,15 +539,15 @@ __device__ inline bool block_lu_solve(const SymDev& S, const int* __restrict__ p
 // Scalar variant for the DC system of the NB == 1 layout: B' theta = P only couples the theta entries, i.e. element [0] of
 // every 2x2 block and rhs[2p] (the |V| rows are identity), so the same program is run on scalars: a quarter of the LDS
 // traffic and a fraction of the arithmetic of the block solve.
-template <int GW>
-__device__ inline bool scalar_lu_solve(const SymDev& S, const int* __restrict__ prog, double* __restrict__ A,
+template <int GW, class PP = const int*>
+__device__ inline bool scalar_lu_solve(const SymDev& S, PP prog, double* __restrict__ A,
                                        double* __restrict__ rhs, int tid, long long* dbg = nullptr) {
 #ifdef GPF_TIMING
   const long long t_lu0 = __builtin_readcyclecounter();
 #endif
   bool ok = true;
   const int n_levels = S.n_levels;
-  const int4* H = reinterpret_cast<const int4*>(prog);
+  auto hdr4 = [&](int k) -> int4 { return make_int4(prog[4 * k], prog[4 * k + 1], prog[4 * k + 2], prog[4 * k + 3]); };
   auto item_words = [&](const int4& h, int o, unsigned& w0, unsigned& w1) {
     const int at = h.x + 2 * (o < h.y + h.w ? o : 0);
     w0 = (unsigned)prog[at]; w1 = (unsigned)prog[at + 1];
@@ -544,11 +562,11 @@ __device__ inline bool scalar_lu_solve(const SymDev& S, const int* __restrict__ 
     double* dst = is_c ? (A + (size_t)dd * 4) : (rhs + (size_t)dd * 2);
     atomicAdd(dst, -(al * x) * fast_rcp(d));
   };
-  int4 h0 = H[1], h1 = n_levels > 1 ? H[3] : make_int4(0, 0, 0, 0);
+  int4 h0 = hdr4(1), h1 = n_levels > 1 ? hdr4(3) : make_int4(0, 0, 0, 0);
   unsigned w0, w1;
   item_words(h0, tid, w0, w1);
   for (int lv = 0; lv < n_levels; ++lv) {
-    const int4 h2 = lv + 2 < n_levels ? H[2 * (lv + 2) + 1] : make_int4(0, 0, 0, 0);
+    const int4 h2 = lv + 2 < n_levels ? hdr4(2 * (lv + 2) + 1) : make_int4(0, 0, 0, 0);
     unsigned nw0, nw1;
     item_words(h1, tid, nw0, nw1);
     do_item(h0, tid, w0, w1);
@@ -612,7 +630,7 @@ __device__ inline bool scalar_lu_solve(const SymDev& S, const int* __restrict__ 
 // status of the caller's group.  Groups share the instruction stream: a group that has failed or finished keeps executing
 // (its state is frozen / its results are overwritten by the caller), so barriers stay wave-uniform.
 template <int NB, int STAGE, int IPW, int WPI>
-__device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, const StatView& sv, CarveP<NB>& c, int inst, int is_dc, int max_iter,
+__device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, const StatView<STAGE>& sv, CarveP<NB>& c, int inst, int is_dc, int max_iter,
                                             double tol_pu, int tid, bool inj_staged, bool topo_staged, int& n_iter_out, int& nb_out GPF_STAMPS_PARAM) {
   typedef Grp<IPW, WPI> G;
   constexpr int GW = G::GW;
@@ -624,17 +642,17 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   const SymDev& S = P->sym;
   const int nsub = g.n_sub;
   const int nbus = nsub * NB;
-  const int* __restrict__ topo_g = b.topo + (size_t)inst * g.dim_topo;
-  const int* __restrict__ shb = b.shunt_bus + (size_t)inst * g.n_shunt;
-  unsigned char* lstat = b.line_status + (size_t)inst * g.n_line;
+  const auto topo_g = gptr(b.topo) + (size_t)inst * g.dim_topo;            // lane rows in HBM: explicit global address space
+  const auto shb = gptr(b.shunt_bus) + (size_t)inst * g.n_shunt;
+  const auto lstat = gptr(b.line_status) + (size_t)inst * g.n_line;
   n_iter_out = 0;
   nb_out = 0;
   GPF_STAMPS(0);
-  const double* __restrict__ inj_g = b.inj + (size_t)inst * g.n_inj;
+  const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj;
   if (STAGE && !inj_staged) {
     for (int i = tid; i < g.n_inj; i += GW) c.inj[i] = inj_g[i];
   }
-  const double* __restrict__ inj = STAGE ? (const double*)c.inj : inj_g;
+#define GPF_INJ(i_) (STAGE ? c.inj[(i_)] : (double)inj_g[(i_)])      /* staged row in LDS, else the lane's row in HBM / L2 */
   const double sn = g.sn_mva, inv_sn = 1.0 / sn;
 
   // ---- K1: element -> bus, bus activity / types / injections with LDS atomics from the element lanes ---------------------
@@ -669,7 +687,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     if (bu >= 0) {
       const bool sl = sv.gen_slack[i] != 0;
       atomicMax(&c.btype[bu], sl ? BT_REF : BT_PV);
-      if (!sl) atomicAdd(&c.Psp[bu], inj[oo.inj_gen_p + i] * inv_sn);
+      if (!sl) atomicAdd(&c.Psp[bu], GPF_INJ(oo.inj_gen_p + i) * inv_sn);
       atomicMax(&c.vidx[bu], i);
       if (NB == 1) c.sub_bb[sb] = (i8)lb;
     }
@@ -681,8 +699,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     c.load_b[i] = (i16)bu;
     if (bu >= 0) {
       atomicMax(&c.btype[bu], BT_PQ);
-      atomicAdd(&c.Psp[bu], -inj[oo.inj_load_p + i] * inv_sn);
-      atomicAdd(&c.Qsp[bu], -inj[oo.inj_load_q + i] * inv_sn);
+      atomicAdd(&c.Psp[bu], -GPF_INJ(oo.inj_load_p + i) * inv_sn);
+      atomicAdd(&c.Qsp[bu], -GPF_INJ(oo.inj_load_q + i) * inv_sn);
       if (NB == 1) c.sub_bb[sb] = (i8)lb;
     }
   }
@@ -693,8 +711,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     c.sto_b[i] = (i16)bu;
     if (bu >= 0) {
       atomicMax(&c.btype[bu], BT_PQ);
-      atomicAdd(&c.Psp[bu], -inj[oo.inj_sto_p + i] * inv_sn);
-      atomicAdd(&c.Qsp[bu], -inj[oo.inj_sto_q + i] * inv_sn);
+      atomicAdd(&c.Psp[bu], -GPF_INJ(oo.inj_sto_p + i) * inv_sn);
+      atomicAdd(&c.Qsp[bu], -GPF_INJ(oo.inj_sto_q + i) * inv_sn);
       if (NB == 1) c.sub_bb[sb] = (i8)lb;
     }
   }
@@ -705,7 +723,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     c.sh_b[i] = (i16)bu;
     if (bu >= 0) {
       atomicMax(&c.btype[bu], BT_PQ);
-      atomicAdd(&c.Gs[bu], inj[oo.inj_sh_p + i] * sv.shunt_fact[i] * inv_sn);
+      atomicAdd(&c.Gs[bu], GPF_INJ(oo.inj_sh_p + i) * sv.shunt_fact[i] * inv_sn);
       if (NB == 1) c.sub_bb[sb] = (i8)lb;
     }
   }
@@ -718,7 +736,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     if (i < nbus) {
       const int vi = c.vidx[i];
       // initial |V|: set-point of the last in-service generator on PV / reference buses, 1 pu elsewhere
-      c.vm[i] = (vi >= 0 && (bt == BT_PV || bt == BT_REF)) ? inj[oo.inj_gen_vm + vi] : 1.0;
+      c.vm[i] = (vi >= 0 && (bt == BT_PV || bt == BT_REF)) ? GPF_INJ(oo.inj_gen_vm + vi) : 1.0;
       c.lab[i] = (bt == BT_REF) ? 1 : 0;
     }
     nb += G::count(bt != BT_OFF);
@@ -762,8 +780,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     const int bi = lidx(f), bj = lidx(t);
     const int sff = sv.br_slot[4 * l + 0], sft = sv.br_slot[4 * l + 1], stf = sv.br_slot[4 * l + 2], stt = sv.br_slot[4 * l + 3];
     if (!is_dc) {
-      const double4* y4 = reinterpret_cast<const double4*>(sv.br_y + (size_t)8 * l);
-      const double4 ya = y4[0], yb = y4[1];
+      const double4 ya = sv.br_y.ld4((size_t)8 * l), yb = sv.br_y.ld4((size_t)8 * l + 4);
       double* y;
       y = c.Yb + ((size_t)sff * NB * NB + bi * NB + bi) * 2; atomicAdd(&y[0], ya.x); atomicAdd(&y[1], ya.y);
       y = c.Yb + ((size_t)sft * NB * NB + bi * NB + bj) * 2; atomicAdd(&y[0], ya.z); atomicAdd(&y[1], ya.w);
@@ -790,8 +807,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         const int sub = (NB == 1) ? bu : bu / NB;
         const double fct = sv.shunt_fact[s] * inv_sn;
         double* y = c.Yb + ((size_t)sub * NB * NB + bi * NB + bi) * 2;       // diag slot of a substation == its index
-        atomicAdd(&y[0], inj[oo.inj_sh_p + s] * fct);
-        atomicAdd(&y[1], -inj[oo.inj_sh_q + s] * fct);
+        atomicAdd(&y[0], GPF_INJ(oo.inj_sh_p + s) * fct);
+        atomicAdd(&y[1], -GPF_INJ(oo.inj_sh_q + s) * fct);
       }
     }
   }
@@ -809,12 +826,21 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   }
   GPF_SYNC();
   GPF_STAMPS(3);
+  // the program is in LDS (tier >= 1) or read in place through a global-address-space pointer (tier 0)
+  auto lu_ac = [&](long long* dbg) -> bool {
+    if (STAGE >= 1) return block_lu_solve<BS, GW>(S, sv.prog.p, c.A, c.rhs, tid, dbg);
+    return block_lu_solve<BS, GW>(S, gptr(sv.prog.p), c.A, c.rhs, tid, dbg);
+  };
+  auto lu_dc = [&](long long* dbg) -> bool {
+    if (STAGE >= 1) return scalar_lu_solve<GW>(S, sv.prog.p, c.A, c.rhs, tid, dbg);
+    return scalar_lu_solve<GW>(S, gptr(sv.prog.p), c.A, c.rhs, tid, dbg);
+  };
   {
 #ifdef GPF_TIMING
-    bool ok = (NB == 1) ? scalar_lu_solve<GW>(S, sv.prog, c.A, c.rhs, tid, &stamps.v[20])
-                        : block_lu_solve<BS, GW>(S, sv.prog, c.A, c.rhs, tid, &stamps.v[20]);
+    bool ok = (NB == 1) ? lu_dc(&stamps.v[20])
+                        : lu_ac(&stamps.v[20]);
 #else
-    bool ok = (NB == 1) ? scalar_lu_solve<GW>(S, sv.prog, c.A, c.rhs, tid) : block_lu_solve<BS, GW>(S, sv.prog, c.A, c.rhs, tid);
+    bool ok = (NB == 1) ? lu_dc(nullptr) : lu_ac(nullptr);
 #endif
     for (int i = tid; i < nbus; i += GW) {
       const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
@@ -905,7 +931,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       if (G::block_all(done)) break;
       GPF_SYNC();
       if (it == 1) GPF_STAMPS(12);
-      const bool ok = block_lu_solve<BS, GW>(S, sv.prog, c.A, c.rhs, tid);
+      const bool ok = lu_ac(nullptr);
       if (it == 1) GPF_STAMPS(13);
       // update (groups that are done keep their state) + preparation of the next pair phase (every group)
       bool fin = true;
@@ -942,7 +968,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   GPF_STAMPS(5);
 
   // ---- K6: results ---------------------------------------------------------------------------------------------------------
-  float* out = b.out + (size_t)inst * g.n_out;
+  const auto out = gptr(b.out) + (size_t)inst * g.n_out;
   const double RAD2DEG = 57.295779513082320877;
   const double SQRT3 = 1.7320508075688772935;
   GPF_SYNC();
@@ -971,8 +997,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         pf = (c.va[f] - c.va[t]) * sv.br_bdc[l] * sn;
         pt = -pf; qf = 0.0; qt = 0.0;
       } else {
-        const double4* y4 = reinterpret_cast<const double4*>(sv.br_y + (size_t)8 * l);
-        const double4 ya = y4[0], yb = y4[1];
+        const double4 ya = sv.br_y.ld4((size_t)8 * l), yb = sv.br_y.ld4((size_t)8 * l + 4);
         const double ef = c.e[f], ff = c.f[f], et = c.e[t], ft = c.f[t];
         const double ifr = ya.x * ef - ya.y * ff + ya.z * et - ya.w * ft;
         const double ifi = ya.x * ff + ya.y * ef + ya.z * ft + ya.w * et;
@@ -994,26 +1019,26 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   for (int i = tid; i < g.n_load; i += GW) {
     const int bu = c.load_b[i];
     const bool on = bu >= 0;
-    out[oo.load_p + i] = on ? (float)inj[oo.inj_load_p + i] : 0.f;
-    out[oo.load_q + i] = (on && !is_dc) ? (float)inj[oo.inj_load_q + i] : 0.f;
+    out[oo.load_p + i] = on ? (float)GPF_INJ(oo.inj_load_p + i) : 0.f;
+    out[oo.load_q + i] = (on && !is_dc) ? (float)GPF_INJ(oo.inj_load_q + i) : 0.f;
     out[oo.load_v + i] = on ? (float)(c.vm[bu] * sv.sub_vn_kv[sv.load_sub[i]]) : 0.f;
     out[oo.load_th + i] = on ? (float)(c.va[bu] * RAD2DEG) : 0.f;
   }
   for (int i = tid; i < g.n_sto; i += GW) {
     const int bu = c.sto_b[i];
     const bool on = bu >= 0;
-    out[oo.sto_p + i] = on ? (float)inj[oo.inj_sto_p + i] : 0.f;
-    out[oo.sto_q + i] = (on && !is_dc) ? (float)inj[oo.inj_sto_q + i] : 0.f;
+    out[oo.sto_p + i] = on ? (float)GPF_INJ(oo.inj_sto_p + i) : 0.f;
+    out[oo.sto_q + i] = (on && !is_dc) ? (float)GPF_INJ(oo.inj_sto_q + i) : 0.f;
     out[oo.sto_v + i] = on ? (float)(c.vm[bu] * sv.sub_vn_kv[sv.sto_sub[i]]) : 0.f;
     out[oo.sto_th + i] = on ? (float)(c.va[bu] * RAD2DEG) : 0.f;
   }
-  int* sbo = b.shunt_bus_out + (size_t)inst * g.n_shunt;
+  const auto sbo = gptr(b.shunt_bus_out) + (size_t)inst * g.n_shunt;
   for (int i = tid; i < g.n_shunt; i += GW) {
     const int bu = c.sh_b[i];
     const bool on = bu >= 0;
     const double v = on ? c.vm[bu] : 0.0;
-    out[oo.sh_p + i] = on ? (float)(inj[oo.inj_sh_p + i] * sv.shunt_fact[i] * v * v) : 0.f;
-    out[oo.sh_q + i] = (on && !is_dc) ? (float)(inj[oo.inj_sh_q + i] * sv.shunt_fact[i] * v * v) : 0.f;
+    out[oo.sh_p + i] = on ? (float)(GPF_INJ(oo.inj_sh_p + i) * sv.shunt_fact[i] * v * v) : 0.f;
+    out[oo.sh_q + i] = (on && !is_dc) ? (float)(GPF_INJ(oo.inj_sh_q + i) * sv.shunt_fact[i] * v * v) : 0.f;
     out[oo.sh_v + i] = on ? (float)(v * sv.sub_vn_kv[sv.shunt_sub[i]]) : 0.f;
     sbo[i] = on ? shb[i] : -1;
   }
@@ -1051,7 +1076,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         else if (cn == 1) q = qtot;
         else if (qmin_t[bu] == qmax_t[bu]) q = qtot / cn;
         else q = mn + (qtot - qmin_t[bu]) / (qmax_t[bu] - qmin_t[bu] + 2.220446049250313e-16) * (mx - mn);
-        double p = inj[oo.inj_gen_p + i];
+        double p = GPF_INJ(oo.inj_gen_p + i);
         if (sv.gen_slack[i]) p = (c.Sre[bu] - c.Psp[bu]) * sn / nsl[bu];
         gp = (float)p; gq = (float)q;
         gv = (float)(c.vm[bu] * sv.sub_vn_kv[sv.gen_sub[i]]);
@@ -1061,15 +1086,15 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     }
   }
   GPF_STAMPS(25);
-  int* to = b.topo_out + (size_t)inst * g.dim_topo;
+  const auto to = gptr(b.topo_out) + (size_t)inst * g.dim_topo;
   for (int i = tid; i < g.dim_topo; i += GW) { const int v = topo_g[i]; to[i] = v >= 1 ? v : -1; }
   GPF_SYNC();
   for (int l = tid; l < g.n_line; l += GW) {
     if (c.lor_b[l] < 0) { to[sv.line_or_pos[l]] = -1; to[sv.line_ex_pos[l]] = -1; }
   }
   GPF_STAMPS(26);
-  double* bvm = b.bus_vm + (size_t)inst * g.nb_tot;
-  double* bva = b.bus_va + (size_t)inst * g.nb_tot;
+  const auto bvm = gptr(b.bus_vm) + (size_t)inst * g.nb_tot;
+  const auto bva = gptr(b.bus_va) + (size_t)inst * g.nb_tot;
   const double nand = __builtin_nan("");
   for (int i = tid; i < g.nb_tot; i += GW) {
     const int sub = i % nsub, lb = i / nsub + 1;            // global bus = sub + (local-1)*n_sub
@@ -1082,6 +1107,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   }
   GPF_STAMPS(6);
   return status;
+#undef GPF_INJ
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1095,7 +1121,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   CarveP<NB> c;
   const size_t per_inst = lds_bytes_instance<NB>(P->g, P->sym.nslot, P->sym.nslot_y, STAGE != 0);
   carve_sparse<NB>(c, smem + (size_t)grp * per_inst, P->g, P->sym.nslot, P->sym.nslot_y, STAGE != 0);
-  StatView sv;
+  StatView<STAGE> sv;
   make_stat_view<STAGE>(sv, P->sym, smem + (size_t)IPW * per_inst);
   int n_iter, nb;
   GPF_STAMPS_DECL;
@@ -1103,7 +1129,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   GPF_SYNC();
   if (st != 0) write_nan_results<GW>(P->g, P->b, inst, tid);
   if (tid == 0) {
-    int* s = P->b.status + (size_t)inst * 4;
+    const auto s = gptr(P->b.status) + (size_t)inst * 4;
     s[0] = st; s[1] = n_iter; s[2] = nb; s[3] = 0;
   }
 }
@@ -1122,23 +1148,24 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   CarveP<NB> c;
   const size_t per_inst = lds_bytes_instance<NB>(g, P->sym.nslot, P->sym.nslot_y, STAGE != 0);
   carve_sparse<NB>(c, smem + (size_t)grp * per_inst, g, P->sym.nslot, P->sym.nslot_y, STAGE != 0);
-  StatView sv;
+  StatView<STAGE> sv;
   make_stat_view<STAGE>(sv, P->sym, smem + (size_t)IPW * per_inst);
   if (STAGE) GPF_SYNC();                                       // the static tables are read from here on
   GPF_STAMPS_DECL;
   GPF_STAMPS(8);
   {
-    const int tab = b.lane_table ? b.lane_table[inst] : 0;
-    const int off = b.lane_offset ? b.lane_offset[inst] : 0;
+    const int tab = b.lane_table ? gptr(b.lane_table)[inst] : 0;
+    const int off = b.lane_offset ? gptr(b.lane_offset)[inst] : 0;
     int row = (sa.t + off) % sa.T;
     if (row < 0) row += sa.T;
-    const float* __restrict__ ch = b.chron + ((size_t)tab * sa.T + row) * g.n_chron;
-    const float* __restrict__ sc = b.lane_scale ? b.lane_scale + (size_t)inst * 2 * g.n_load : nullptr;
-    double* inj_g = b.inj + (size_t)inst * g.n_inj;
+    const auto ch = gptr(b.chron) + ((size_t)tab * sa.T + row) * g.n_chron;
+    const bool has_sc = b.lane_scale != nullptr;
+    const auto sc = gptr(b.lane_scale) + (size_t)inst * 2 * g.n_load;
+    const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj;
     // all global loads of the phase are issued up front (one round trip): the lane's topology row (first solve), the
     // storage / shunt set-points, and the first pass of the generator columns of the chronics row
     {
-      const int* __restrict__ topo_g = b.topo + (size_t)inst * g.dim_topo;
+      const auto topo_g = gptr(b.topo) + (size_t)inst * g.dim_topo;
       for (int i = tid; i < g.dim_topo; i += GW) c.topo[i] = topo_g[i];
     }
     if (STAGE) for (int i = oo.inj_sto_p + tid; i < g.n_inj; i += GW) c.inj[i] = inj_g[i];
@@ -1148,7 +1175,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
     GPF_STAMPS(16);
     for (int i = tid; i < g.n_load; i += GW) {
       float lp = ch[i], lq = ch[g.n_load + i];
-      if (sc) { lp *= sc[i]; lq *= sc[g.n_load + i]; }
+      if (has_sc) { lp *= sc[i]; lq *= sc[g.n_load + i]; }
       if (STAGE) { c.inj[oo.inj_load_p + i] = (double)lp; c.inj[oo.inj_load_q + i] = (double)lq; }   // HBM copy: end of kernel
       else { inj_g[oo.inj_load_p + i] = (double)lp; inj_g[oo.inj_load_q + i] = (double)lq; }
       sum_load += (double)lp;
@@ -1175,16 +1202,17 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
     GPF_SYNC();
   }
   int n_iter = 0, nb = 0, st = 0, rounds = 0;
-  int* ovc = b.overflow_count + (size_t)inst * g.n_line;    // env._protection_counter (persistent)
-  int* dround = b.disc_round + (size_t)inst * g.n_line;
-  float* rho = b.rho + (size_t)inst * g.n_line;
-  float* out = b.out + (size_t)inst * g.n_out;
-  int* topo = b.topo + (size_t)inst * g.dim_topo;
+  const auto ovc = gptr(b.overflow_count) + (size_t)inst * g.n_line;    // env._protection_counter (persistent)
+  const auto dround = gptr(b.disc_round) + (size_t)inst * g.n_line;
+  const auto rho = gptr(b.rho) + (size_t)inst * g.n_line;
+  const auto out = gptr(b.out) + (size_t)inst * g.n_out;
+  const auto topo = gptr(b.topo) + (size_t)inst * g.dim_topo;
+  const auto thermal_limit = gptr(b.thermal_limit);
   for (int l = tid; l < g.n_line; l += GW) dround[l] = -1;
   // Backend.next_grid_state keeps a LOCAL copy of the protection counters that is advanced at most once per line
   // and per call (backend.py:1476-1520): local value = ovc + (line already counted this call ? 1 : 0); the "already
   // counted" flag lives in bit 30 of disc_round's scratch twin (rho buffer reused as int scratch until the end).
-  int* inc_flag = reinterpret_cast<int*>(rho);
+  const auto inc_flag = (GPF_GLOBAL int*)rho;
   if (sa.cascade) for (int l = tid; l < g.n_line; l += GW) inc_flag[l] = 0;
   bool more = true;                                           // this group still cascades
   bool first = true;
@@ -1200,7 +1228,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
     if (more)
     for (int l = tid; l < g.n_line; l += GW) {
       const float a = out[oo.a_or + l];
-      const float lim = b.thermal_limit[l];
+      const float lim = thermal_limit[l];
       const bool on = c.lor_b[l] >= 0;
       bool disc = on && (a > sa.hard_overflow * lim);
       int inc = inc_flag[l];
@@ -1220,19 +1248,19 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   }
   GPF_STAMPS(9);
   if (STAGE) {                                                // the step's injection row -> HBM (gpf_get_injections, next launches)
-    double* inj_g = b.inj + (size_t)inst * g.n_inj;
+    const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj;
     for (int i = tid; i < oo.inj_sto_p; i += GW) inj_g[i] = c.inj[i];
   }
   if (st != 0) write_nan_results<GW>(g, b, inst, tid);
   GPF_SYNC();
   for (int l = tid; l < g.n_line; l += GW) {
-    const float lim = b.thermal_limit[l];
+    const float lim = thermal_limit[l];
     const float a = out[oo.a_or + l];
     rho[l] = a / lim;
     if (a > sa.soft_overflow * lim) ovc[l] += 1; else ovc[l] = 0;
   }
   if (tid == 0) {
-    int* s = b.status + (size_t)inst * 4;
+    const auto s = gptr(b.status) + (size_t)inst * 4;
     s[0] = st; s[1] = n_iter; s[2] = nb; s[3] = rounds;
   }
   GPF_STAMPS(15);
