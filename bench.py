@@ -228,7 +228,7 @@ def main():
             "frac_converged": frac_conv,
             "mean_nr_iterations": mean_iter,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 of the 1-GPU run only
             res["cpu_baseline"] = cpu_baseline(m, ch, T)
         else:
             res["cpu_baseline"] = None
