@@ -110,7 +110,7 @@ def lib() -> C.CDLL:
     L.gpf_upload_chronics.argtypes = [h, i32, i32, _fp]
     L.gpf_set_lane_chronics.argtypes = [h, _ip, _ip, _fp]
     L.gpf_set_thermal_limits.argtypes = [h, _fp]
-    L.gpf_step.argtypes = [h, i32, i32, C.c_double, C.c_double, i32, C.c_float, C.c_float, i32, i32]
+    L.gpf_step.argtypes = [h, i32, i32, C.c_double, C.c_double, i32, C.c_float, C.c_float, i32, i32, i32]
     L.gpf_get_step_outputs.argtypes = [h, i32, i32, _fp, _ip, _ip]
     L.gpf_sync.argtypes = [h]
     L.gpf_set_profiling.argtypes = [h, i32]

@@ -827,7 +827,7 @@ int gpf_set_thermal_limits(gpf_handle e, const float* limit_a) {
 }
 
 int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double rebalance, int32_t cascade, float hard_overflow,
-             float soft_overflow, int32_t nb_ts_allowed, int32_t max_rounds) {
+             float soft_overflow, int32_t nb_ts_allowed, int32_t max_rounds, int32_t is_dc) {
   if (!e) return fail(GPF_E_INVALID, "gpf_step: null");
   if (!e->chron.p || e->chron_T <= 0) return fail(GPF_E_INVALID, "gpf_step: no chronics uploaded");
   HIP_TRY(hipSetDevice(e->device));
@@ -838,6 +838,7 @@ int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double r
   b.work_stride = (long long)work_stride(p);
   gpf::StepArgs sa{};
   sa.t = t; sa.T = e->chron_T; sa.rebalance_on = rebalance > 0.0 ? 1 : 0; sa.rebalance = rebalance; sa.cascade = cascade;
+  sa.is_dc = is_dc ? 1 : 0;
   sa.nb_ts_allowed = nb_ts_allowed; sa.max_rounds = max_rounds; sa.hard_overflow = hard_overflow; sa.soft_overflow = soft_overflow;
   const double tol_pu = tol_mva / e->g.sn_mva;
   hipEvent_t ea = nullptr, eb = nullptr;

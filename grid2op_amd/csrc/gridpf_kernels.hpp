@@ -74,7 +74,7 @@ struct Bufs {
 };
 
 struct StepArgs {
-  int t, T, rebalance_on, cascade, nb_ts_allowed, max_rounds;
+  int t, T, rebalance_on, cascade, nb_ts_allowed, max_rounds, is_dc;
   double rebalance;
   float hard_overflow, soft_overflow;
 };
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(WAVE) void step_kernel(GridDev g, Bufs b, OutOff oo
     if (l < g.n_line) dround[l] = -1;
   }
   while (true) {
-    st = solve_instance(g, b, c, oo, inst, nbc, nJ, 0, max_iter, tol_pu, tid, n_iter, nb);
+    st = solve_instance(g, b, c, oo, inst, nbc, nJ, sa.is_dc, max_iter, tol_pu, tid, n_iter, nb);
     __syncthreads();
     if (st != 0 || !sa.cascade || rounds >= sa.max_rounds) break;   // at most max_rounds re-solves
     // K7: Backend.next_grid_state (grid2op/Backend/backend.py:1476-1520)

@@ -915,7 +915,7 @@ __global__ __launch_bounds__(WAVE, GPF_MINW(NMAX)) void step_small_kernel(const 
     if (l < g.n_line) dround[l] = -1;
   }
   while (true) {
-    st = solve_instance_small<NMAX, LPR>(P, c, inst, nbc, nrows, 0, max_iter, tol_pu, tid, true, n_iter, nb);
+    st = solve_instance_small<NMAX, LPR>(P, c, inst, nbc, nrows, sa.is_dc, max_iter, tol_pu, tid, true, n_iter, nb);
     __syncthreads();
     if (st != 0 || !sa.cascade || rounds >= sa.max_rounds) break;   // at most max_rounds re-solves
     int any_disc = 0;

@@ -1219,7 +1219,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   while (true) {
     // a group whose cascade has ended re-solves its unchanged state along with the others (same results)
     int it_k = 0, nb_k = 0;
-    const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI>(P, sv, c, inst, 0, max_iter, tol_pu, tid, true, first, it_k, nb_k GPF_STAMPS_ARG);
+    const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI>(P, sv, c, inst, sa.is_dc, max_iter, tol_pu, tid, true, first, it_k, nb_k GPF_STAMPS_ARG);
     first = false;
     GPF_SYNC();
     if (more) { st = st_k; n_iter = it_k; nb = nb_k; }

@@ -259,10 +259,12 @@ class PowerFlowEngine:
         check(self._lib.gpf_set_thermal_limits(self._h, ptr(lim, C.c_float)), "gpf_set_thermal_limits")
 
     def step(self, t: int, max_iter: int = 10, tol_mva: float = 1e-8, rebalance: float = 0.0, cascade: bool = False,
-             hard_overflow: float = 2.0, soft_overflow: float = 1.0, nb_ts_allowed: int = 2, max_rounds: int = 16):
+             hard_overflow: float = 2.0, soft_overflow: float = 1.0, nb_ts_allowed: int = 2, max_rounds: int = 16,
+             is_dc: bool = False):
         """One DoNothing ``env.step`` for every lane (asynchronous)."""
         check(self._lib.gpf_step(self._h, int(t), int(max_iter), float(tol_mva), float(rebalance), int(bool(cascade)),
-                                 float(hard_overflow), float(soft_overflow), int(nb_ts_allowed), int(max_rounds)), "gpf_step")
+                                 float(hard_overflow), float(soft_overflow), int(nb_ts_allowed), int(max_rounds), int(bool(is_dc))),
+              "gpf_step")
 
     def step_outputs(self, lane0: int = 0, n: Optional[int] = None):
         lane0, n = self._range(lane0, n)

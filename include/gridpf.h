@@ -148,9 +148,10 @@ int gpf_set_thermal_limits(gpf_handle h, const float* limit_a /* [n_line] */);
 /* One DoNothing env.step for every lane (Environment/baseEnv.py:3562 -> Backend.next_grid_state
  * backend.py:1433-1521): chronics row -> injections -> AC power flow -> results -> overflow counters;
  * when `cascade` != 0 lines above hard_overflow*limit (or soft-overflowed for more than nb_ts_allowed
- * steps) are tripped and the power flow re-run, at most max_rounds times. Asynchronous. */
+ * steps) are tripped and the power flow re-run, at most max_rounds times.  is_dc != 0 runs the DC power flow
+ * instead (Parameters.ENV_DC, grid2op/Parameters.py:273 -> runpf(is_dc=True)).  Asynchronous. */
 int gpf_step(gpf_handle h, int32_t t, int32_t max_iter, double tol_mva, double rebalance, int32_t cascade,
-             float hard_overflow, float soft_overflow, int32_t nb_ts_allowed, int32_t max_rounds);
+             float hard_overflow, float soft_overflow, int32_t nb_ts_allowed, int32_t max_rounds, int32_t is_dc);
 /* rho = a_or / thermal_limit (backend.py:1145-1168) and overflow counters of the last gpf_step. */
 int gpf_get_step_outputs(gpf_handle h, int32_t lane0, int32_t n, float* rho, int32_t* overflow_count,
                          int32_t* disc_round);

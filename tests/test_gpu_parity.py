@@ -560,3 +560,31 @@ def test_large_batches_at_bench_size_vs_c_oracle(name, B, load_model, load_npz):
         assert st[0, 0] == 0
         assert np.allclose(r.out[k], o[0], rtol=5e-6, atol=2e-4), k
     eng.close()
+
+
+def test_batched_step_dc_mode(load_model, load_npz):
+    """``gpf_step(..., is_dc=1)``: Parameters.ENV_DC (grid2op/Parameters.py:273 -> Backend.runpf(is_dc=True)) for the whole
+    batch: chronics row -> injections -> DC power flow -> rho."""
+    m = load_model("l2rpn_case14_sandbox")
+    ch = load_npz("l2rpn_case14_sandbox.chronics.npz")
+    B = 9
+    eng = _engine(m, B)
+    eng.upload_chronics(eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"]))
+    off = 5 * np.arange(B)
+    eng.set_lane_chronics(lane_offset=off)
+    eng.set_thermal_limits(ch["thermal_limits"])
+    eng.step(4, is_dc=True)
+    r = eng.results()
+    for k in range(B):
+        row = (4 + off[k]) % ch["load_p"].shape[0]
+        s = LaneState.from_model(m)
+        s.load_p, s.load_q = ch["load_p"][row].astype(np.float64), ch["load_q"][row].astype(np.float64)
+        s.gen_p = ch["prod_p"][row].astype(np.float64)
+        s.gen_vm = (ch["prod_v"][row] / m.sub_vn_kv[m.gen_sub].astype(np.float32)).astype(np.float64)
+        o = solve(m, s, is_dc=True)
+        assert o.converged and r.converged[k] and r.n_iter[k] == 0
+        assert np.allclose(r.p_or[k], o.p_or, rtol=5e-6, atol=2e-4)
+        assert np.allclose(r.p_ex[k], o.p_ex, rtol=5e-6, atol=2e-4)
+        assert np.all(r.q_or[k] == 0.0)
+        assert np.allclose(r.a_or[k], o.a_or, rtol=2e-5, atol=1e-3)
+    eng.close()
