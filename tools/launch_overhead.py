@@ -1,3 +1,4 @@
+"""Developer tool: host enqueue time and wall time per batched step with event timing off / window / off (GPU box)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.getcwd())
