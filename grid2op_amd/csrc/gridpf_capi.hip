@@ -536,7 +536,16 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     hipError_t eu = e->stat_dbl.upload(fd.data(), fd.size());
     if (eu == hipSuccess) eu = e->stat_int.upload(fi.data(), fi.size());
     if (eu != hipSuccess) { gpf_destroy(e); return fail(GPF_E_DEVICE, std::string("upload static tables: ") + hipGetErrorString(eu)); }
-    D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.back_first = S.back_first; D.scale_off = S.scale_off; D.n_scale = S.n_scale; D.n_prog = (int)S.prog.size();
+    D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.back_first = S.back_first;
+    {   // connectivity of the static substation graph (all lines in service): lets the kernel skip the label propagation
+      std::vector<int> comp(g.n_sub);
+      for (int i = 0; i < g.n_sub; ++i) comp[i] = i;
+      auto find = [&](int x) { while (comp[x] != x) { comp[x] = comp[comp[x]]; x = comp[x]; } return x; };
+      for (int l = 0; l < nl; ++l) comp[find(e->h_line_or_sub[l])] = find(e->h_line_ex_sub[l]);
+      int roots = 0;
+      for (int i = 0; i < g.n_sub; ++i) roots += (find(i) == i);
+      D.static_connected = roots == 1 ? 1 : 0;
+    } D.scale_off = S.scale_off; D.n_scale = S.n_scale; D.n_prog = (int)S.prog.size();
     D.stat_dbl = e->stat_dbl.p; D.stat_int = e->stat_int.p; D.prog = e->stat_int.p + so.prog;
   }
   HIP_TRY(hipMemsetAsync(e->status.p, 0xFF, B * 4 * sizeof(int), e->stream));

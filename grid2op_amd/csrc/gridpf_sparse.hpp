@@ -65,6 +65,7 @@ __host__ __device__ inline size_t stat_bytes(const StatOff& o, int tier) {
 struct SymDev {
   int n, nslot, nslot_y, n_levels, back_off, n_prog, scale_off, n_scale;
   int back_first;           // highest level that has U entries (back substitution starts there)
+  int static_connected;     // the substation graph with every line in service is connected (host check at gpf_create)
   const int* prog;          // level-scheduled program in global memory (tools/lu_bench; the kernels use StatView::prog)
   const double* stat_dbl;   // the static blob: [so.n_dbl] doubles ...
   const int* stat_int;      // ... and [so.n_int] ints
@@ -666,9 +667,11 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   GPF_STAMPS(27);
   const int* topo = c.topo;
   auto bus_of = [&](int sub, int local) -> int { return (NB == 1) ? sub : sub * NB + (local - 1); };
+  bool line_off = false;
   for (int l = tid; l < g.n_line; l += GW) {
     const int bo = topo[sv.line_or_pos[l]], be = topo[sv.line_ex_pos[l]];
     const bool on = (bo >= 1) && (be >= 1);
+    line_off |= !on;
     const int so = sv.line_or_sub[l], se = sv.line_ex_sub[l];
     const int fo = on ? bus_of(so, bo) : -1, fe = on ? bus_of(se, be) : -1;
     c.lor_b[l] = (i16)fo;
@@ -749,6 +752,11 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   GPF_STAMPS(1);
 
   // ---- connectivity ----------------------------------------------------------------------------------------------------
+  // With one live busbar per substation and every line in service the bus graph IS the static substation graph, whose
+  // connectivity the host checked at gpf_create: nothing to propagate (the DoNothing case).  Otherwise label propagation
+  // from the reference buses.
+  const bool conn_known = (NB == 1) && S.static_connected && !G::any(line_off);
+  if (!G::block_all(conn_known))
   for (int sweep = 0; sweep < nbus; ++sweep) {
     int changed = 0;
     for (int l = tid; l < g.n_line; l += GW) {
@@ -763,7 +771,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   }
   {
     int bad = 0;
-    for (int i = tid; i < nbus; i += GW) bad |= (c.btype[i] != BT_OFF && c.lab[i] == 0);
+    if (!conn_known) for (int i = tid; i < nbus; i += GW) bad |= (c.btype[i] != BT_OFF && c.lab[i] == 0);
     if (status == 0 && G::any(bad)) status = 2;
     if (G::block_all(status != 0)) return status;
   }
