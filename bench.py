@@ -314,6 +314,14 @@ def main():
         eng3.sync()
         dc_solve_s = (time.perf_counter() - t0) / 5
         r3 = eng3.results()
+        eng3.runpf()
+        eng3.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            eng3.runpf()
+        eng3.sync()
+        ac_solve_s = (time.perf_counter() - t0) / 5
+        r3ac = eng3.results()
         if rank == 0:
             nb_act = int(r3.status[0, 2])                     # active buses of the topology = K of the GEMM
             nb_pad, line_pad = (nb_act + 3) // 4 * 4, (m3.n_line + 15) // 16 * 16
@@ -326,7 +334,10 @@ def main():
                                  "frac": (2.0 * B3 * nb_pad * line_pad / (us * 1e-6) / 1e12 / F64_PEAK_TFLOPS) if us > 0 else 0.0,
                                  "note": "90 MFLOP per batch: launch/latency bound, two kernels (bus injections + GEMM)"},
                     "per_lane_dc_solve_value": world * B3 / dc_solve_s, "per_lane_dc_solve_unit": "DC power flows/sec (kernel S, B' refactorised per lane)",
-                    "max_abs_diff_vs_per_lane_dc_solve_mw": float(np.abs(flows - r3.p_or).max())}
+                    "max_abs_diff_vs_per_lane_dc_solve_mw": float(np.abs(flows - r3.p_or).max()),
+                    "ac_runpf_value": world * B3 / ac_solve_s, "ac_runpf_unit": "AC power flows/sec (same lanes, gpf_runpf)",
+                    "ac_frac_converged": float(r3ac.converged.mean()),
+                    "max_abs_dc_vs_ac_p_or_mw": float(np.abs(flows - r3ac.p_or)[r3ac.converged].max())}
         eng3.close()
     if rank == 0:
         res["secondary"] = sec
