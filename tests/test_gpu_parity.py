@@ -588,3 +588,32 @@ def test_batched_step_dc_mode(load_model, load_npz):
         assert np.all(r.q_or[k] == 0.0)
         assert np.allclose(r.a_or[k], o.a_or, rtol=2e-5, atol=1e-3)
     eng.close()
+
+
+@pytest.mark.parametrize("name,n", [("l2rpn_case14_sandbox", 384), ("rte_case5_example", 256), ("l2rpn_neurips_2020_track1", 96)])
+def test_single_busbar_batches_with_outages_instance_group_kernels(name, n, load_model):
+    """Batches WITHOUT bus splits run the single-busbar kernels (several instances per wavefront on the small grids):
+    random injections (some far outside the solvable range) and 1-3 line outages per lane give wavefronts that mix
+    converging, islanded, non-converging and all-lines-in-service lanes."""
+    m = load_model(name)
+    rng = np.random.default_rng(2024)
+    states = random_states(m, n, rng, p_split=0.0, p_line_off=0.6)
+    for s in states[::7]:                       # overloaded lanes: Newton does not converge
+        s.load_p = s.load_p * 6.0
+        s.load_q = s.load_q * 6.0
+    for s in states:                            # shunts stay on busbar 1 (no second busbar in this batch)
+        if m.n_shunt:
+            s.shunt_bus = np.where(s.shunt_bus == 2, 1, s.shunt_bus)
+    eng = _engine(m, n)
+    inj, topo, sb = _pack(eng, states)
+    eng.set_injections(inj)
+    eng.set_topology(topo, sb)
+    eng.runpf()
+    r = eng.results()
+    kinds = set()
+    for k, s in enumerate(states):
+        o = solve(m, s)
+        _compare(m, r, k, o)
+        kinds.add("ok" if o.converged else o.reason.split()[0])
+    assert "ok" in kinds and len(kinds) >= 3, kinds
+    eng.close()
