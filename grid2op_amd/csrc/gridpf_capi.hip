@@ -65,6 +65,8 @@ struct LaunchPlan {
   int small_nmax;   // 0: generic LDS kernels (v1); 24/32/48/64: register-resident kernels (v2)
   int sparse_nb;    // 0: no; 1..3: block-sparse kernel S with NB busbars per substation block
   int minw;         // kernel S: __launch_bounds__ waves per SIMD (4 caps the kernel at 128 VGPRs: only worth it when LDS allows > 8 blocks per CU)
+  int n_list;       // > 0: this plan covers n_list lanes given by a device index list (mixed batches), else a contiguous range
+  const int* list;  // device pointer (padded with a ghost lane to a multiple of ipw)
   int wpi;          // kernel S: wavefronts per instance (1, 2 or 4; > 1 only for NB == 1, IPW == 1 on large grids)
   int ipw;          // kernel S: grid instances per wavefront (1, 2 or 4; > 1 only for NB == 1 on small grids)
   int sparse_stage;  // 0: static tables read in place (L2), 1: program + pair table + injection row in LDS, 2: everything in LDS // program staged in LDS (small grids) or streamed from L2 (keeps 3 instances per CU on 118-bus grids)
@@ -119,6 +121,9 @@ struct gpf_engine {
   gpf::DevParamsS* d_params_s = nullptr;
   bool params_s_valid = false;
   bool force_sparse = false;   // GRIDPF_FORCE_SPARSE=1
+  // mixed batches: lanes without / with split substations are launched separately (single-busbar kernel / NB = n_busbar)
+  DevArr<int> list_a, list_b;
+  bool no_partition = false;     // GRIDPF_NO_PARTITION=1
   int ipw_override = 0;        // GRIDPF_IPW=1|2|4 (developer override of the instances-per-wavefront heuristic)
   int wpi_override = 0;        // GRIDPF_WPI=1|2|4 (developer override of the wavefronts-per-instance heuristic)
   int cap_lanes = 0;           // lane buffers are padded to a multiple of 4 lanes (instance groups of a wavefront)
@@ -131,7 +136,7 @@ struct gpf_engine {
   gpf::DevParams* d_params = nullptr;
   bool params_valid = false;
   bool plan_valid = false;      // cached launch plan of the whole batch (invalidated by every topology mutation)
-  LaunchPlan plan_cached{};
+  LaunchPlan plan_cached{}, plan_b_cached{};   // plan_b: the split lanes of a mixed batch (sparse_nb == 0: none)
   // profiling
   bool profiling = false;      // per-launch event pairs (gpf_set_profiling(h, 2))
   bool window = false;         // one event pair around a window of launches (gpf_set_profiling(h, 1))
@@ -198,17 +203,21 @@ void count_lane(const gpf_engine* e, const int* topo, const int* shunt_bus, int&
 constexpr size_t LDS_SMALL_LIMIT = 64 * 1024;   // above this Y and J move to an HBM/L2 workspace
 constexpr size_t LDS_HARD_LIMIT = 160 * 1024;
 
-int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p);
+int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchPlan& pb);
 
-int plan_launch(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
+// p: the plan of the range (or of its single-busbar lanes when the batch is mixed); pb.sparse_nb != 0: second launch for
+// the lanes that have a split substation (both then run from device lane lists)
+int plan_launch(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchPlan& pb) {
   const bool whole = (lane0 == 0 && n == e->n_lanes);
-  if (whole && e->plan_valid) { p = e->plan_cached; return GPF_OK; }
-  int rc = plan_launch_uncached(e, lane0, n, p);
-  if (rc == GPF_OK && whole) { e->plan_cached = p; e->plan_valid = true; }
+  if (whole && e->plan_valid) { p = e->plan_cached; pb = e->plan_b_cached; return GPF_OK; }
+  int rc = plan_launch_uncached(e, lane0, n, p, pb);
+  if (!whole && (p.n_list || pb.n_list)) e->plan_valid = false;     // the device lane lists were overwritten
+  if (rc == GPF_OK && whole) { e->plan_cached = p; e->plan_b_cached = pb; e->plan_valid = true; }
   return rc;
 }
 
-int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
+int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchPlan& pb) {
+  pb = LaunchPlan{};
   int nb = 1, nj = 1;
   for (int k = lane0; k < lane0 + n; ++k) {
     nb = std::max(nb, e->lane_nb[k]);
@@ -219,6 +228,8 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
   p.small_nmax = 0;
   p.sparse_nb = 0;
   p.ipw = 1;
+  p.n_list = 0;
+  p.list = nullptr;
   p.wpi = 1;
   p.minw = 2;
   p.sparse_stage = 0;
@@ -242,14 +253,14 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
       return GPF_OK;
     }
   }
-  if (!e->force_generic && e->g.n_sub * mb <= 32000 && e->g.n_busbar <= 3) {
-    const int nbk = mb == 1 ? 1 : e->g.n_busbar;
+  // kernel S plan of n lanes that all run with NBK busbars per substation block; listed: the lanes come from an index list
+  auto plan_sparse = [&](int nbk, int n_l, int lane0_l, bool listed, LaunchPlan& q) -> bool {
     // small grids do not have 64-wide work: several instances share a wavefront (instance groups, gridpf_sparse.hpp).
-    // Sub-ranges must be group-aligned (or end at the padded tail of the lane buffers).
+    // Contiguous sub-ranges must be group-aligned (or end at the padded tail of the lane buffers); lists are padded.
     int ipw = 1;
     if (nbk == 1) {
       ipw = e->ipw_override ? e->ipw_override : (e->g.n_sub <= 8 ? 4 : e->g.n_sub <= 24 ? 2 : 1);
-      while (ipw > 1 && !(lane0 % ipw == 0 && (n % ipw == 0 || lane0 + n == e->n_lanes))) ipw >>= 1;
+      while (!listed && ipw > 1 && !(lane0_l % ipw == 0 && (n_l % ipw == 0 || lane0_l + n_l == e->n_lanes))) ipw >>= 1;
     }
     auto need = [&](int tier) -> size_t {
       const size_t static_bytes = gpf::stat_bytes(e->sym_dev.so, tier);
@@ -261,7 +272,7 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
     // stage the static tables + the injection row in LDS only when that does not cost residency: blocks per CU
     // (160 KiB / footprint) must still cover what the launch needs at once, or what the un-staged kernel would get
     const size_t l_gl = need(0);
-    const size_t n_blocks = ((size_t)n + ipw - 1) / ipw;
+    const size_t n_blocks = ((size_t)n_l + ipw - 1) / ipw;
     const size_t want = std::min<size_t>(std::min<size_t>((n_blocks + 255) / 256, LDS_HARD_LIMIT / std::max<size_t>(l_gl, 1)), 8);
     int stage = 0;
     const int top_tier = nbk == 1 ? 2 : 1;
@@ -269,21 +280,45 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p) {
       if (need(tier) <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / need(tier) >= want) stage = tier;
     if (ipw > 1 && stage != 2) { ipw = 1; stage = 0; for (int tier = 2; tier >= 1 && !stage; --tier) if (need(tier) <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / need(tier) >= want) stage = tier; }
     const size_t l = need(stage);
-    if (l <= LDS_HARD_LIMIT) {
+    if (l > LDS_HARD_LIMIT) return false;
+    q.sparse_nb = nbk;
+    q.ipw = ipw;
+    q.minw = (nbk == 1 && ipw == 1 && LDS_HARD_LIMIT / l >= 12) ? 4 : 2;
+    // large grids: phases loop over hundreds of items -> several wavefronts per instance (block-wide barriers)
+    q.wpi = (nbk == 1 && ipw == 1) ? (e->wpi_override ? e->wpi_override : (e->g.n_sub >= 64 ? 2 : 1)) : 1;
+    if (q.wpi > 1) q.minw = 2;
+    q.sparse_stage = stage;
+    q.big = false;
+    q.lds = l;
+    return true;
+  };
+  if (!e->force_generic && e->g.n_sub * mb <= 32000 && e->g.n_busbar <= 3) {
 #ifdef GPF_TIMING
-      if (e->work.n < (size_t)e->cap_lanes * 32) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->cap_lanes * 32)); }
+    if (e->work.n < (size_t)e->cap_lanes * 32) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->cap_lanes * 32)); }
 #endif
-      p.sparse_nb = nbk;
-      p.ipw = ipw;
-      p.minw = (nbk == 1 && ipw == 1 && LDS_HARD_LIMIT / l >= 12) ? 4 : 2;
-      // large grids: phases loop over hundreds of items -> several wavefronts per instance (block-wide barriers)
-      p.wpi = (nbk == 1 && ipw == 1) ? (e->wpi_override ? e->wpi_override : (e->g.n_sub >= 64 ? 2 : 1)) : 1;
-      if (p.wpi > 1) p.minw = 2;
-      p.sparse_stage = stage;
-      p.big = false;
-      p.lds = l;
-      return GPF_OK;
+    // mixed batch: the lanes without a split substation keep the (much cheaper) single-busbar kernel
+    int n_single = 0;
+    for (int k = lane0; k < lane0 + n; ++k) n_single += (e->lane_mb[k] == 1);
+    if (mb > 1 && n_single > 0 && !e->no_partition) {
+      std::vector<int> la, lb;
+      la.reserve(n_single + 4); lb.reserve(n - n_single + 4);
+      for (int k = lane0; k < lane0 + n; ++k) (e->lane_mb[k] == 1 ? la : lb).push_back(k);
+      LaunchPlan qa = p, qb = p;
+      if (plan_sparse(1, (int)la.size(), 0, true, qa) && plan_sparse(e->g.n_busbar, (int)lb.size(), 0, true, qb)) {
+        qa.n_list = (int)la.size(); qb.n_list = (int)lb.size();
+        while (la.size() % 4) la.push_back(e->n_lanes);             // ghost lane (pristine state, never read back)
+        while (lb.size() % 4) lb.push_back(e->n_lanes);
+        if (e->list_a.n < la.size()) { e->list_a.release(); HIP_TRY(e->list_a.alloc(e->cap_lanes + 4)); }
+        if (e->list_b.n < lb.size()) { e->list_b.release(); HIP_TRY(e->list_b.alloc(e->cap_lanes + 4)); }
+        HIP_TRY(hipMemcpyAsync(e->list_a.p, la.data(), la.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->list_b.p, lb.data(), lb.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));                    // the host vectors go out of scope
+        qa.list = e->list_a.p; qb.list = e->list_b.p;
+        p = qa; pb = qb;
+        return GPF_OK;
+      }
     }
+    if (plan_sparse(mb == 1 ? 1 : e->g.n_busbar, n, lane0, false, p)) return GPF_OK;
   }
   size_t small = gpf::lds_bytes(e->g, p.nbc, p.nJ, false);
   p.big = small > LDS_SMALL_LIMIT;
@@ -407,6 +442,8 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     e->force_generic = fg && fg[0] == '1';
     const char* fs = std::getenv("GRIDPF_FORCE_SPARSE");
     e->force_sparse = fs && fs[0] == '1';
+    const char* np_ = std::getenv("GRIDPF_NO_PARTITION");
+    e->no_partition = np_ && np_[0] == '1';
     const char* iw = std::getenv("GRIDPF_IPW");
     e->ipw_override = (iw && (iw[0] == '1' || iw[0] == '2' || iw[0] == '4')) ? iw[0] - '0' : 0;
     const char* ww = std::getenv("GRIDPF_WPI");
@@ -420,7 +457,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     e->lpr1 = l1 && l1[0] == '1';
   }
   e->n_lanes = n_lanes;
-  e->cap_lanes = (n_lanes + 3) & ~3;
+  e->cap_lanes = (n_lanes + 7) & ~3;          // >= 4 ghost lanes (pristine state): padding of instance groups / lane lists
   gpf::GridDev& g = e->g;
   g.n_sub = d->n_sub; g.n_busbar = d->n_busbar; g.nb_tot = d->n_sub * d->n_busbar;
   g.n_line = d->n_line; g.n_gen = d->n_gen; g.n_load = d->n_load; g.n_sto = d->n_storage; g.n_shunt = d->n_shunt;
@@ -582,6 +619,7 @@ int gpf_destroy(gpf_handle e) {
   if (e->d_params) (void)hipFree(e->d_params);
   if (e->d_params_s) (void)hipFree(e->d_params_s);
   e->stat_dbl.release();
+  e->list_a.release(); e->list_b.release();
   e->ptdf_inj_bus.release(); e->ptdf_inj_w.release(); e->ptdf_t.release(); e->ptdf_pbus.release(); e->ptdf_flow.release();
   e->stat_int.release();
   delete e;
@@ -709,30 +747,20 @@ int gpf_fanout_n1(gpf_handle e, int32_t src, int32_t dst0, int32_t n_out, const 
   return GPF_OK;
 }
 
-int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max_iter, double tol_mva) {
-  if (!check_range(e, lane0, n)) return fail(GPF_E_INVALID, "gpf_runpf: bad range");
-  if (n == 0) return GPF_OK;
-  HIP_TRY(hipSetDevice(e->device));
-  LaunchPlan p;
-  int rc = plan_launch(e, lane0, n, p);
-  if (rc != GPF_OK) return rc;
-  gpf::Bufs b = e->bufs();
-  b.work_stride = (long long)work_stride(p);
-  const double tol_pu = tol_mva / e->g.sn_mva;
-  hipEvent_t ea = nullptr, eb = nullptr;
-  if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
-  if (p.sparse_nb) { rc = upload_params_s(e, b); if (rc != GPF_OK) return rc; }
-  if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
-#define LAUNCH_RUNPF_SPARSE(NBK, ST, IPW, MW, WP)                                                                                           \
-  do {                                                                                                                      \
-    static size_t lds_set_[64] = {0};                                                                                       \
-    if (p.lds > lds_set_[e->device & 63]) {                                                                                  \
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<NBK, ST, IPW, MW, WP>),                         \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                   \
-      lds_set_[e->device & 63] = p.lds;                                                                                     \
-    }                                   \
-    hipLaunchKernelGGL((gpf::runpf_sparse_kernel<NBK, ST, IPW, MW, WP>), dim3((n + IPW - 1) / IPW), dim3(gpf::WAVE * WP), p.lds, e->stream,  \
-                       e->d_params_s, lane0, is_dc, max_iter, tol_pu);                                                      \
+// kernel S dispatch (one launch for a contiguous range, or for the lanes of a device index list)
+static int launch_runpf_sparse(gpf_engine* e, const LaunchPlan& p, hipStream_t stream, int lane0, int n, int is_dc, int max_iter, double tol_pu) {
+  const int n_l = p.n_list ? p.n_list : n;
+  const int* list = p.n_list ? p.list : nullptr;
+#define LAUNCH_RUNPF_SPARSE(NBK, ST, IPW, MW, WP)                                                                                 \
+  do {                                                                                                                            \
+    static size_t lds_set_[64] = {0};                                                                                             \
+    if (p.lds > lds_set_[e->device & 63]) {                                                                                       \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<NBK, ST, IPW, MW, WP>),                 \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                       \
+      lds_set_[e->device & 63] = p.lds;                                                                                           \
+    }                                                                                                                             \
+    hipLaunchKernelGGL((gpf::runpf_sparse_kernel<NBK, ST, IPW, MW, WP>), dim3((n_l + IPW - 1) / IPW), dim3(gpf::WAVE * WP), p.lds, \
+                       stream, e->d_params_s, lane0, list, is_dc, max_iter, tol_pu);                                              \
   } while (0)
   if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_RUNPF_SPARSE(1, 2, 4, 2, 1);
   else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_RUNPF_SPARSE(1, 2, 2, 2, 1);
@@ -752,6 +780,68 @@ int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
   else if (p.sparse_nb == 2) LAUNCH_RUNPF_SPARSE(2, 0, 1, 2, 1);
   else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(3, 1, 1, 2, 1);
   else if (p.sparse_nb == 3) LAUNCH_RUNPF_SPARSE(3, 0, 1, 2, 1);
+#undef LAUNCH_RUNPF_SPARSE
+  HIP_TRY(hipGetLastError());
+  return GPF_OK;
+}
+
+static int launch_step_sparse(gpf_engine* e, const LaunchPlan& p, hipStream_t stream, int max_iter, double tol_pu, const gpf::StepArgs& sa) {
+  const int n_l = p.n_list ? p.n_list : e->n_lanes;
+  const int* list = p.n_list ? p.list : nullptr;
+#define LAUNCH_STEP_SPARSE(NBK, ST, IPW, MW, WP)                                                                                  \
+  do {                                                                                                                            \
+    static size_t lds_set_[64] = {0};                                                                                             \
+    if (p.lds > lds_set_[e->device & 63]) {                                                                                       \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<NBK, ST, IPW, MW, WP>),                  \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                       \
+      lds_set_[e->device & 63] = p.lds;                                                                                           \
+    }                                                                                                                             \
+    hipLaunchKernelGGL((gpf::step_sparse_kernel<NBK, ST, IPW, MW, WP>), dim3((n_l + IPW - 1) / IPW), dim3(gpf::WAVE * WP), p.lds,  \
+                       stream, e->d_params_s, list, max_iter, tol_pu, sa);                                                        \
+  } while (0)
+  if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_STEP_SPARSE(1, 2, 4, 2, 1);
+  else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_STEP_SPARSE(1, 2, 2, 2, 1);
+  else if (p.sparse_nb == 1 && p.wpi == 2 && p.sparse_stage == 2) LAUNCH_STEP_SPARSE(1, 2, 1, 2, 2);
+  else if (p.sparse_nb == 1 && p.wpi == 2 && p.sparse_stage == 1) LAUNCH_STEP_SPARSE(1, 1, 1, 2, 2);
+  else if (p.sparse_nb == 1 && p.wpi == 2) LAUNCH_STEP_SPARSE(1, 0, 1, 2, 2);
+  else if (p.sparse_nb == 1 && p.wpi == 4 && p.sparse_stage == 2) LAUNCH_STEP_SPARSE(1, 2, 1, 2, 4);
+  else if (p.sparse_nb == 1 && p.wpi == 4 && p.sparse_stage == 1) LAUNCH_STEP_SPARSE(1, 1, 1, 2, 4);
+  else if (p.sparse_nb == 1 && p.wpi == 4) LAUNCH_STEP_SPARSE(1, 0, 1, 2, 4);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 2 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 2, 1, 4, 1);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 2) LAUNCH_STEP_SPARSE(1, 2, 1, 2, 1);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 1 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 1, 1, 4, 1);
+  else if (p.sparse_nb == 1 && p.sparse_stage == 1) LAUNCH_STEP_SPARSE(1, 1, 1, 2, 1);
+  else if (p.sparse_nb == 1 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 0, 1, 4, 1);
+  else if (p.sparse_nb == 1) LAUNCH_STEP_SPARSE(1, 0, 1, 2, 1);
+  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_STEP_SPARSE(2, 1, 1, 2, 1);
+  else if (p.sparse_nb == 2) LAUNCH_STEP_SPARSE(2, 0, 1, 2, 1);
+  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_STEP_SPARSE(3, 1, 1, 2, 1);
+  else if (p.sparse_nb == 3) LAUNCH_STEP_SPARSE(3, 0, 1, 2, 1);
+#undef LAUNCH_STEP_SPARSE
+  HIP_TRY(hipGetLastError());
+  return GPF_OK;
+}
+
+int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max_iter, double tol_mva) {
+  if (!check_range(e, lane0, n)) return fail(GPF_E_INVALID, "gpf_runpf: bad range");
+  if (n == 0) return GPF_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  LaunchPlan p, pb;
+  int rc = plan_launch(e, lane0, n, p, pb);
+  if (rc != GPF_OK) return rc;
+  gpf::Bufs b = e->bufs();
+  b.work_stride = (long long)work_stride(p);
+  const double tol_pu = tol_mva / e->g.sn_mva;
+  hipEvent_t ea = nullptr, eb = nullptr;
+  if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
+  if (p.sparse_nb) { rc = upload_params_s(e, b); if (rc != GPF_OK) return rc; }
+  if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
+  if (p.sparse_nb) {
+    // (measured: forking the second launch onto its own stream costs more in cross-stream events than the overlap gains)
+    rc = launch_runpf_sparse(e, p, e->stream, lane0, n, is_dc, max_iter, tol_pu);
+    if (rc == GPF_OK && pb.sparse_nb) rc = launch_runpf_sparse(e, pb, e->stream, lane0, n, is_dc, max_iter, tol_pu);
+    if (rc != GPF_OK) return rc;
+  }
   else
 #define LAUNCH_RUNPF_SMALL(NM, LP)                                                                                              \
   hipLaunchKernelGGL((gpf::runpf_small_kernel<NM, LP>), dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, lane0, p.nbc,   \
@@ -840,8 +930,8 @@ int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double r
   if (!e) return fail(GPF_E_INVALID, "gpf_step: null");
   if (!e->chron.p || e->chron_T <= 0) return fail(GPF_E_INVALID, "gpf_step: no chronics uploaded");
   HIP_TRY(hipSetDevice(e->device));
-  LaunchPlan p;
-  int rc = plan_launch(e, 0, e->n_lanes, p);
+  LaunchPlan p, pb;
+  int rc = plan_launch(e, 0, e->n_lanes, p, pb);
   if (rc != GPF_OK) return rc;
   gpf::Bufs b = e->bufs();
   b.work_stride = (long long)work_stride(p);
@@ -854,35 +944,11 @@ int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double r
   if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
   if (p.sparse_nb) { rc = upload_params_s(e, b); if (rc != GPF_OK) return rc; }
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
-#define LAUNCH_STEP_SPARSE(NBK, ST, IPW, MW, WP)                                                                                           \
-  do {                                                                                                                      \
-    static size_t lds_set_[64] = {0};                                                                                       \
-    if (p.lds > lds_set_[e->device & 63]) {                                                                                  \
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<NBK, ST, IPW, MW, WP>),                          \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                   \
-      lds_set_[e->device & 63] = p.lds;                                                                                     \
-    }                                   \
-    hipLaunchKernelGGL((gpf::step_sparse_kernel<NBK, ST, IPW, MW, WP>), dim3((e->n_lanes + IPW - 1) / IPW), dim3(gpf::WAVE * WP), p.lds,     \
-                       e->stream, e->d_params_s, max_iter, tol_pu, sa);                                                     \
-  } while (0)
-  if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_STEP_SPARSE(1, 2, 4, 2, 1);
-  else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_STEP_SPARSE(1, 2, 2, 2, 1);
-  else if (p.sparse_nb == 1 && p.wpi == 2 && p.sparse_stage == 2) LAUNCH_STEP_SPARSE(1, 2, 1, 2, 2);
-  else if (p.sparse_nb == 1 && p.wpi == 2 && p.sparse_stage == 1) LAUNCH_STEP_SPARSE(1, 1, 1, 2, 2);
-  else if (p.sparse_nb == 1 && p.wpi == 2) LAUNCH_STEP_SPARSE(1, 0, 1, 2, 2);
-  else if (p.sparse_nb == 1 && p.wpi == 4 && p.sparse_stage == 2) LAUNCH_STEP_SPARSE(1, 2, 1, 2, 4);
-  else if (p.sparse_nb == 1 && p.wpi == 4 && p.sparse_stage == 1) LAUNCH_STEP_SPARSE(1, 1, 1, 2, 4);
-  else if (p.sparse_nb == 1 && p.wpi == 4) LAUNCH_STEP_SPARSE(1, 0, 1, 2, 4);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 2 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 2, 1, 4, 1);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 2) LAUNCH_STEP_SPARSE(1, 2, 1, 2, 1);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 1 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 1, 1, 4, 1);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 1) LAUNCH_STEP_SPARSE(1, 1, 1, 2, 1);
-  else if (p.sparse_nb == 1 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 0, 1, 4, 1);
-  else if (p.sparse_nb == 1) LAUNCH_STEP_SPARSE(1, 0, 1, 2, 1);
-  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_STEP_SPARSE(2, 1, 1, 2, 1);
-  else if (p.sparse_nb == 2) LAUNCH_STEP_SPARSE(2, 0, 1, 2, 1);
-  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_STEP_SPARSE(3, 1, 1, 2, 1);
-  else if (p.sparse_nb == 3) LAUNCH_STEP_SPARSE(3, 0, 1, 2, 1);
+  if (p.sparse_nb) {
+    rc = launch_step_sparse(e, p, e->stream, max_iter, tol_pu, sa);
+    if (rc == GPF_OK && pb.sparse_nb) rc = launch_step_sparse(e, pb, e->stream, max_iter, tol_pu, sa);
+    if (rc != GPF_OK) return rc;
+  }
   else
 #define LAUNCH_STEP_SMALL(NM, LP)                                                                                               \
   hipLaunchKernelGGL((gpf::step_small_kernel<NM, LP>), dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, p.nbc,   \

@@ -1120,12 +1120,13 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
 
 // ---------------------------------------------------------------------------------------------------
 template <int NB, int STAGE, int IPW, int MINW, int WPI>
-__global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const DevParamsS* __restrict__ P, int lane0, int is_dc, int max_iter,
+__global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const DevParamsS* __restrict__ P, int lane0, const int* __restrict__ lane_list, int is_dc, int max_iter,
                                                             double tol_pu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int GW = Grp<IPW, WPI>::GW;
   const int grp = threadIdx.x / GW, tid = threadIdx.x % GW;
-  const int inst = lane0 + blockIdx.x * IPW + grp;             // the host pads the lane buffers to a multiple of IPW
+  // contiguous range, or (mixed batches) a device list of lanes; both padded by the host with ghost lanes to a multiple of IPW
+  const int inst = lane_list ? gptr(lane_list)[blockIdx.x * IPW + grp] : lane0 + blockIdx.x * IPW + grp;
   CarveP<NB> c;
   const size_t per_inst = lds_bytes_instance<NB>(P->g, P->sym.nslot, P->sym.nslot_y, STAGE != 0);
   carve_sparse<NB>(c, smem + (size_t)grp * per_inst, P->g, P->sym.nslot, P->sym.nslot_y, STAGE != 0);
@@ -1143,7 +1144,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
 }
 
 template <int NB, int STAGE, int IPW, int MINW, int WPI>
-__global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const DevParamsS* __restrict__ P, int max_iter, double tol_pu,
+__global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const DevParamsS* __restrict__ P, const int* __restrict__ lane_list, int max_iter, double tol_pu,
                                                            StepArgs sa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef Grp<IPW, WPI> G;
@@ -1152,7 +1153,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   const Bufs& b = P->b;
   const OutOff& oo = P->oo;
   const int grp = threadIdx.x / GW, tid = threadIdx.x % GW;
-  const int inst = blockIdx.x * IPW + grp;                     // the host pads the lane buffers to a multiple of IPW
+  const int inst = lane_list ? gptr(lane_list)[blockIdx.x * IPW + grp] : blockIdx.x * IPW + grp;   // ghost-padded by the host
   CarveP<NB> c;
   const size_t per_inst = lds_bytes_instance<NB>(g, P->sym.nslot, P->sym.nslot_y, STAGE != 0);
   carve_sparse<NB>(c, smem + (size_t)grp * per_inst, g, P->sym.nslot, P->sym.nslot_y, STAGE != 0);
