@@ -285,7 +285,8 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
     q.ipw = ipw;
     q.minw = (nbk == 1 && ipw == 1 && LDS_HARD_LIMIT / l >= 12) ? 4 : 2;
     // large grids: phases loop over hundreds of items -> several wavefronts per instance (block-wide barriers)
-    q.wpi = (nbk == 1 && ipw == 1) ? (e->wpi_override ? e->wpi_override : (e->g.n_sub >= 64 ? 2 : 1)) : 1;
+    q.wpi = (nbk == 1 && ipw == 1) ? (e->wpi_override ? e->wpi_override : (e->g.n_sub >= 64 ? 2 : 1))
+          : (nbk == 2 && (e->wpi_override ? e->wpi_override == 2 : e->g.n_sub >= 64)) ? 2 : 1;
     if (q.wpi > 1) q.minw = 2;
     q.sparse_stage = stage;
     q.big = false;
@@ -776,6 +777,8 @@ static int launch_runpf_sparse(gpf_engine* e, const LaunchPlan& p, hipStream_t s
   else if (p.sparse_nb == 1 && p.sparse_stage == 1) LAUNCH_RUNPF_SPARSE(1, 1, 1, 2, 1);
   else if (p.sparse_nb == 1 && p.minw == 4) LAUNCH_RUNPF_SPARSE(1, 0, 1, 4, 1);
   else if (p.sparse_nb == 1) LAUNCH_RUNPF_SPARSE(1, 0, 1, 2, 1);
+  else if (p.sparse_nb == 2 && p.wpi == 2 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(2, 1, 1, 2, 2);
+  else if (p.sparse_nb == 2 && p.wpi == 2) LAUNCH_RUNPF_SPARSE(2, 0, 1, 2, 2);
   else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(2, 1, 1, 2, 1);
   else if (p.sparse_nb == 2) LAUNCH_RUNPF_SPARSE(2, 0, 1, 2, 1);
   else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(3, 1, 1, 2, 1);
@@ -813,6 +816,8 @@ static int launch_step_sparse(gpf_engine* e, const LaunchPlan& p, hipStream_t st
   else if (p.sparse_nb == 1 && p.sparse_stage == 1) LAUNCH_STEP_SPARSE(1, 1, 1, 2, 1);
   else if (p.sparse_nb == 1 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 0, 1, 4, 1);
   else if (p.sparse_nb == 1) LAUNCH_STEP_SPARSE(1, 0, 1, 2, 1);
+  else if (p.sparse_nb == 2 && p.wpi == 2 && p.sparse_stage) LAUNCH_STEP_SPARSE(2, 1, 1, 2, 2);
+  else if (p.sparse_nb == 2 && p.wpi == 2) LAUNCH_STEP_SPARSE(2, 0, 1, 2, 2);
   else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_STEP_SPARSE(2, 1, 1, 2, 1);
   else if (p.sparse_nb == 2) LAUNCH_STEP_SPARSE(2, 0, 1, 2, 1);
   else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_STEP_SPARSE(3, 1, 1, 2, 1);
