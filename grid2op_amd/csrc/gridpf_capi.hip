@@ -201,7 +201,7 @@ void count_lane(const gpf_engine* e, const int* topo, const int* shunt_bus, int&
 
 
 constexpr size_t LDS_SMALL_LIMIT = 64 * 1024;   // above this Y and J move to an HBM/L2 workspace
-constexpr size_t LDS_HARD_LIMIT = 160 * 1024;
+constexpr size_t LDS_HARD_LIMIT = 160 * 1024 - 256;   // dynamic LDS budget (a few static bytes: block-wide reductions)
 
 int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchPlan& pb);
 
