@@ -17,6 +17,8 @@
 #include "gridpf_small.hpp"
 #include "gridpf_sparse.hpp"
 #include "gridpf_ptdf.hpp"
+#include <string>
+#include <unordered_map>
 #include "gridpf_symbolic.hpp"
 
 namespace {
@@ -65,6 +67,9 @@ struct LaunchPlan {
   int small_nmax;   // 0: generic LDS kernels (v1); 24/32/48/64: register-resident kernels (v2)
   int sparse_nb;    // 0: no; 1..3: block-sparse kernel S with NB busbars per substation block
   int minw;         // kernel S: __launch_bounds__ waves per SIMD (4 caps the kernel at 128 VGPRs: only worth it when LDS allows > 8 blocks per CU)
+  bool tc;          // topology-class launch: single-busbar kernel on the bus-level graph of each lane's class (cls_list)
+  const int* cls_list;
+  int tc_rows, tc_nslot, tc_nslot_y;
   int n_list;       // > 0: this plan covers n_list lanes given by a device index list (mixed batches), else a contiguous range
   const int* list;  // device pointer (padded with a ghost lane to a multiple of ipw)
   int wpi;          // kernel S: wavefronts per instance (1, 2 or 4; > 1 only for NB == 1, IPW == 1 on large grids)
@@ -122,7 +127,15 @@ struct gpf_engine {
   bool params_s_valid = false;
   bool force_sparse = false;   // GRIDPF_FORCE_SPARSE=1
   // mixed batches: lanes without / with split substations are launched separately (single-busbar kernel / NB = n_busbar)
-  DevArr<int> list_a, list_b;
+  DevArr<int> list_a, list_b, list_c;   // list_c: topology class of every lane of list_b
+  // topology classes (gpf::TopoClassDev): bus-level graphs of the split topologies seen so far, each with its own symbolic program
+  struct TopoClassHost { DevArr<int> tables; gpf::TopoClassDev dev; int n_nodes, nslot, nslot_y; };
+  std::vector<TopoClassHost*> classes;
+  std::unordered_map<std::string, int> class_of_key;
+  std::vector<int> lane_class;          // per lane: topology class (-1: no split substation / classes disabled)
+  DevArr<gpf::TopoClassDev> d_classes;  // device copy of classes[*].dev
+  size_t d_classes_count = 0;
+  bool no_classes = false;              // GRIDPF_NO_CLASSES=1: split lanes run the NB = n_busbar kernel
   bool no_partition = false;     // GRIDPF_NO_PARTITION=1
   int ipw_override = 0;        // GRIDPF_IPW=1|2|4 (developer override of the instances-per-wavefront heuristic)
   int wpi_override = 0;        // GRIDPF_WPI=1|2|4 (developer override of the wavefronts-per-instance heuristic)
@@ -200,6 +213,67 @@ void count_lane(const gpf_engine* e, const int* topo, const int* shunt_bus, int&
 }
 
 
+
+// Topology class of a lane whose substations are split (gridpf_sparse.hpp: TopoClassDev).  Key = busbar of every line end
+// (an open end counts as busbar 1) + which busbars >= 2 carry any element; classes are built on first sight and cached.
+// Returns the class id, or -1 (classes disabled / capacity) -> the lane falls back to the NB = n_busbar kernel.
+int topo_class_of(gpf_engine* e, const int* topo, const int* shunt_bus) {
+  const gpf::GridDev& g = e->g;
+  if (e->no_classes || g.n_busbar < 2 || e->classes.size() >= 8192) return -1;
+  const int nbb = g.n_busbar;
+  std::string key((size_t)2 * g.n_line + (size_t)g.n_sub * nbb, '\0');
+  auto bb = [&](int v) { return v >= 2 && v <= nbb ? v : 1; };
+  for (int l = 0; l < g.n_line; ++l) {
+    key[2 * l] = (char)bb(topo[e->h_line_or_pos[l]]);
+    key[2 * l + 1] = (char)bb(topo[e->h_line_ex_pos[l]]);
+  }
+  char* used = &key[(size_t)2 * g.n_line];                  // [sub][busbar-1]: the busbar carries an element
+  auto mark = [&](int sub, int v) { if (v >= 1 && v <= nbb) used[(size_t)sub * nbb + (v - 1)] = 1; };
+  for (int l = 0; l < g.n_line; ++l) { mark(e->h_line_or_sub[l], key[2 * l]); mark(e->h_line_ex_sub[l], key[2 * l + 1]); }
+  for (int i = 0; i < g.n_gen; ++i) mark(e->h_gen_sub[i], topo[e->h_gen_pos[i]]);
+  for (int i = 0; i < g.n_load; ++i) mark(e->h_load_sub[i], topo[e->h_load_pos[i]]);
+  for (int i = 0; i < g.n_sto; ++i) mark(e->h_sto_sub[i], topo[e->h_sto_pos[i]]);
+  if (shunt_bus) for (int i = 0; i < g.n_shunt; ++i) mark(e->h_shunt_sub[i], shunt_bus[i]);
+  for (int s_ = 0; s_ < g.n_sub; ++s_) used[(size_t)s_ * nbb] = 1;      // the busbar-1 node always exists
+  auto it = e->class_of_key.find(key);
+  if (it != e->class_of_key.end()) return it->second;
+  // nodes: (sub, busbar 1) -> sub; used busbars >= 2 -> n_sub, n_sub + 1, ...
+  std::vector<int> node_of((size_t)g.n_sub * nbb, -1);
+  int n_nodes = g.n_sub;
+  for (int s_ = 0; s_ < g.n_sub; ++s_) node_of[(size_t)s_ * nbb] = s_;
+  for (int s_ = 0; s_ < g.n_sub; ++s_)
+    for (int k = 1; k < nbb; ++k) if (used[(size_t)s_ * nbb + k]) node_of[(size_t)s_ * nbb + k] = n_nodes++;
+  if (n_nodes > 32767) return -1;
+  std::vector<int> lo(g.n_line), le(g.n_line);
+  for (int l = 0; l < g.n_line; ++l) {
+    lo[l] = node_of[(size_t)e->h_line_or_sub[l] * nbb + (key[2 * l] - 1)];
+    le[l] = node_of[(size_t)e->h_line_ex_sub[l] * nbb + (key[2 * l + 1] - 1)];
+  }
+  gpf::Symbolic S = gpf::build_symbolic(n_nodes, g.n_line, lo.data(), le.data());
+  if (S.nslot > 65535) return -1;
+  auto* c = new gpf_engine::TopoClassHost();
+  std::vector<int> fi;
+  auto puti = [&fi](const int* v, size_t n) { int off = (int)fi.size(); fi.insert(fi.end(), v, v + n); while (fi.size() & 3) fi.push_back(0); return off; };
+  const int o_prog = puti(S.prog.data(), S.prog.size());
+  std::vector<int> rc(S.nslot_y);
+  for (int k = 0; k < S.nslot_y; ++k) rc[k] = S.slot_row[k] | (S.slot_col[k] << 16);
+  const int o_rc = puti(rc.data(), rc.size());
+  const int o_br = puti(S.br_slot.data(), S.br_slot.size());
+  const int o_no = puti(node_of.data(), node_of.size());
+  if (c->tables.upload(fi.data(), fi.size()) != hipSuccess) { delete c; return -1; }
+  c->n_nodes = n_nodes; c->nslot = S.nslot; c->nslot_y = S.nslot_y;
+  gpf::SymDev& D = c->dev.sym;
+  D = e->sym_dev;                                            // the grid's static blob pointers / offsets
+  D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.back_first = S.back_first;
+  D.scale_off = S.scale_off; D.n_scale = S.n_scale; D.n_prog = (int)S.prog.size(); D.static_connected = 0;
+  D.prog = c->tables.p + o_prog;
+  c->dev.pair_rc = c->tables.p + o_rc; c->dev.br_slot = c->tables.p + o_br; c->dev.node_of = c->tables.p + o_no;
+  const int id = (int)e->classes.size();
+  e->classes.push_back(c);
+  e->class_of_key.emplace(std::move(key), id);
+  return id;
+}
+
 constexpr size_t LDS_SMALL_LIMIT = 64 * 1024;   // above this Y and J move to an HBM/L2 workspace
 constexpr size_t LDS_HARD_LIMIT = 160 * 1024 - 256;   // dynamic LDS budget (a few static bytes: block-wide reductions)
 
@@ -230,6 +304,9 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
   p.ipw = 1;
   p.n_list = 0;
   p.list = nullptr;
+  p.tc = false;
+  p.cls_list = nullptr;
+  p.tc_rows = p.tc_nslot = p.tc_nslot_y = 0;
   p.wpi = 1;
   p.minw = 2;
   p.sparse_stage = 0;
@@ -297,25 +374,56 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
 #ifdef GPF_TIMING
     if (e->work.n < (size_t)e->cap_lanes * 32) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->cap_lanes * 32)); }
 #endif
-    // mixed batch: the lanes without a split substation keep the (much cheaper) single-busbar kernel
-    int n_single = 0;
-    for (int k = lane0; k < lane0 + n; ++k) n_single += (e->lane_mb[k] == 1);
-    if (mb > 1 && n_single > 0 && !e->no_partition) {
-      std::vector<int> la, lb;
-      la.reserve(n_single + 4); lb.reserve(n - n_single + 4);
-      for (int k = lane0; k < lane0 + n; ++k) (e->lane_mb[k] == 1 ? la : lb).push_back(k);
+    // lanes with split substations: (1) topology classes -- the single-busbar kernel on the lane's bus-level graph --, else
+    // (2) the NB = n_busbar kernel; the lanes without a split keep the plain single-busbar kernel (mixed batch: two launches)
+    if (mb > 1 && !e->no_partition) {
+      std::vector<int> la, lb, lc;
+      bool all_classed = true;
+      // grids without instance groups (> 24 substations): ONE topology-class launch for the whole mixed batch (the lanes
+      // without a split run their own class at the same speed); small grids keep their lanes without a split on the
+      // instance-group kernel
+      bool everyone = e->g.n_sub > 24 && !e->ipw_override;
+      for (int k = lane0; k < lane0 + n && everyone; ++k) everyone = e->lane_class[k] >= 0;
+      for (int k = lane0; k < lane0 + n; ++k) {
+        if (e->lane_mb[k] == 1 && !everyone) la.push_back(k);
+        else { lb.push_back(k); lc.push_back(e->lane_class[k]); all_classed &= (e->lane_class[k] >= 0); }
+      }
       LaunchPlan qa = p, qb = p;
-      if (plan_sparse(1, (int)la.size(), 0, true, qa) && plan_sparse(e->g.n_busbar, (int)lb.size(), 0, true, qb)) {
+      bool ok_b;
+      if (all_classed) {
+        qb.tc = true; qb.sparse_nb = 1; qb.ipw = 1; qb.sparse_stage = 0; qb.minw = 2; qb.big = false;
+        qb.wpi = e->wpi_override ? (e->wpi_override >= 2 ? 2 : 1) : (e->g.n_sub >= 64 ? 2 : 1);
+        for (int cid : lc) {
+          const auto* c = e->classes[cid];
+          qb.tc_rows = std::max(qb.tc_rows, c->n_nodes); qb.tc_nslot = std::max(qb.tc_nslot, c->nslot); qb.tc_nslot_y = std::max(qb.tc_nslot_y, c->nslot_y);
+        }
+        qb.lds = gpf::lds_bytes_sparse<1>(e->g, qb.tc_nslot, qb.tc_nslot_y, 0, false, 1, qb.tc_rows);
+        ok_b = qb.lds <= LDS_HARD_LIMIT;
+        if (ok_b && e->d_classes_count != e->classes.size()) {
+          std::vector<gpf::TopoClassDev> hc(e->classes.size());
+          for (size_t i = 0; i < hc.size(); ++i) hc[i] = e->classes[i]->dev;
+          e->d_classes.release();
+          HIP_TRY(e->d_classes.upload(hc.data(), hc.size()));
+          e->d_classes_count = hc.size();
+        }
+      } else {
+        ok_b = plan_sparse(e->g.n_busbar, (int)lb.size(), 0, true, qb);
+      }
+      const bool ok_a = la.empty() || plan_sparse(1, (int)la.size(), 0, true, qa);
+      if (ok_a && ok_b) {
         qa.n_list = (int)la.size(); qb.n_list = (int)lb.size();
         while (la.size() % 4) la.push_back(e->n_lanes);             // ghost lane (pristine state, never read back)
-        while (lb.size() % 4) lb.push_back(e->n_lanes);
-        if (e->list_a.n < la.size()) { e->list_a.release(); HIP_TRY(e->list_a.alloc(e->cap_lanes + 4)); }
-        if (e->list_b.n < lb.size()) { e->list_b.release(); HIP_TRY(e->list_b.alloc(e->cap_lanes + 4)); }
-        HIP_TRY(hipMemcpyAsync(e->list_a.p, la.data(), la.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        while (lb.size() % 4) { lb.push_back(e->n_lanes); lc.push_back(lc.empty() ? 0 : lc.back()); }
+        if (e->list_a.n < la.size() + 4) { e->list_a.release(); HIP_TRY(e->list_a.alloc(e->cap_lanes + 8)); }
+        if (e->list_b.n < lb.size() + 4) { e->list_b.release(); HIP_TRY(e->list_b.alloc(e->cap_lanes + 8)); }
+        if (e->list_c.n < lc.size() + 4) { e->list_c.release(); HIP_TRY(e->list_c.alloc(e->cap_lanes + 8)); }
+        if (!la.empty()) HIP_TRY(hipMemcpyAsync(e->list_a.p, la.data(), la.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
         HIP_TRY(hipMemcpyAsync(e->list_b.p, lb.data(), lb.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->list_c.p, lc.data(), lc.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));                    // the host vectors go out of scope
-        qa.list = e->list_a.p; qb.list = e->list_b.p;
-        p = qa; pb = qb;
+        qa.list = e->list_a.p; qb.list = e->list_b.p; qb.cls_list = e->list_c.p;
+        if (qa.n_list == 0) { p = qb; }                              // every lane is split: one launch
+        else { p = qa; pb = qb; }
         return GPF_OK;
       }
     }
@@ -351,12 +459,14 @@ int upload_params(gpf_engine* e, const gpf::Bufs& b) {
   return GPF_OK;
 }
 
-int upload_params_s(gpf_engine* e, const gpf::Bufs& b) {
+int upload_params_s(gpf_engine* e, const gpf::Bufs& b, const LaunchPlan* tc = nullptr) {
   gpf::DevParamsS hp{};
   hp.g = e->g;
   hp.b = b;
   hp.oo = e->oo;
   hp.sym = e->sym_dev;
+  hp.classes = e->d_classes.p;
+  hp.tc_rows = tc ? tc->tc_rows : 0; hp.tc_nslot = tc ? tc->tc_nslot : 0; hp.tc_nslot_y = tc ? tc->tc_nslot_y : 0;
   if (!e->d_params_s) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_params_s), sizeof(gpf::DevParamsS)));
   if (!e->params_s_valid || std::memcmp(&hp, &e->h_params_s, sizeof(hp)) != 0) {
     e->h_params_s = hp;
@@ -412,7 +522,8 @@ int reset_lanes_unchecked(gpf_engine* e, int lane0, int n) {
   HIP_TRY(hipMemsetAsync(e->overflow_count.p + (size_t)lane0 * g.n_line, 0, (size_t)n * g.n_line * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->status.p + (size_t)lane0 * 4, 0xFF, (size_t)n * 4 * sizeof(int), e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  for (int k = lane0; k < lane0 + n; ++k) { e->lane_nb[k] = e->init_nb; e->lane_nj[k] = e->init_nj; e->lane_mb[k] = e->init_mb; }
+  const int init_class = topo_class_of(e, e->h_init_topo.data(), g.n_shunt ? e->h_init_shunt_bus.data() : nullptr);
+  for (int k = lane0; k < lane0 + n; ++k) { e->lane_nb[k] = e->init_nb; e->lane_nj[k] = e->init_nj; e->lane_mb[k] = e->init_mb; e->lane_class[k] = init_class; }
   e->plan_valid = false;
   return GPF_OK;
 }
@@ -445,6 +556,8 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     e->force_sparse = fs && fs[0] == '1';
     const char* np_ = std::getenv("GRIDPF_NO_PARTITION");
     e->no_partition = np_ && np_[0] == '1';
+    const char* nc_ = std::getenv("GRIDPF_NO_CLASSES");
+    e->no_classes = nc_ && nc_[0] == '1';
     const char* iw = std::getenv("GRIDPF_IPW");
     e->ipw_override = (iw && (iw[0] == '1' || iw[0] == '2' || iw[0] == '4')) ? iw[0] - '0' : 0;
     const char* ww = std::getenv("GRIDPF_WPI");
@@ -545,6 +658,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   e->lane_nb.assign(e->cap_lanes, e->init_nb);
   e->lane_nj.assign(e->cap_lanes, e->init_nj);
   e->lane_mb.assign(e->cap_lanes, e->init_mb);
+  e->lane_class.assign(e->cap_lanes, -1);
   {
     // symbolic analysis of the substation graph for the block-sparse kernels (once per grid)
     e->sym = gpf::build_symbolic(g.n_sub, nl, e->h_line_or_sub.data(), e->h_line_ex_sub.data());
@@ -620,7 +734,9 @@ int gpf_destroy(gpf_handle e) {
   if (e->d_params) (void)hipFree(e->d_params);
   if (e->d_params_s) (void)hipFree(e->d_params_s);
   e->stat_dbl.release();
-  e->list_a.release(); e->list_b.release();
+  e->list_a.release(); e->list_b.release(); e->list_c.release(); e->d_classes.release();
+  for (auto* c : e->classes) { c->tables.release(); delete c; }
+  e->classes.clear();
   e->ptdf_inj_bus.release(); e->ptdf_inj_w.release(); e->ptdf_t.release(); e->ptdf_pbus.release(); e->ptdf_flow.release();
   e->stat_int.release();
   delete e;
@@ -671,6 +787,7 @@ int gpf_set_topology(gpf_handle e, int32_t lane0, int32_t n, const int32_t* topo
     const int* sb = nullptr;
     if (g.n_shunt) sb = shunt_bus ? shunt_bus + (size_t)k * g.n_shunt : sb_host.data() + (size_t)k * g.n_shunt;
     count_lane(e, topo + (size_t)k * g.dim_topo, sb, e->lane_nb[lane0 + k], e->lane_nj[lane0 + k], e->lane_mb[lane0 + k]);
+    e->lane_class[lane0 + k] = topo_class_of(e, topo + (size_t)k * g.dim_topo, sb);
   }
   e->plan_valid = false;
   return GPF_OK;
@@ -728,7 +845,7 @@ int gpf_copy_lanes(gpf_handle e, int32_t src, int32_t dst, int32_t n) {
   CP(shunt_bus_out, g.n_shunt); CP(line_status, g.n_line); CP(status, 4); CP(bus_vm, g.nb_tot); CP(bus_va, g.nb_tot);
   CP(overflow_count, g.n_line); CP(disc_round, g.n_line); CP(rho, g.n_line);
 #undef CP
-  for (int k = 0; k < n; ++k) { e->lane_nb[dst + k] = e->lane_nb[src + k]; e->lane_nj[dst + k] = e->lane_nj[src + k]; e->lane_mb[dst + k] = e->lane_mb[src + k]; }
+  for (int k = 0; k < n; ++k) { e->lane_nb[dst + k] = e->lane_nb[src + k]; e->lane_nj[dst + k] = e->lane_nj[src + k]; e->lane_mb[dst + k] = e->lane_mb[src + k]; e->lane_class[dst + k] = e->lane_class[src + k]; }
   e->plan_valid = false;
   return GPF_OK;
 }
@@ -743,7 +860,7 @@ int gpf_fanout_n1(gpf_handle e, int32_t src, int32_t dst0, int32_t n_out, const 
   hipLaunchKernelGGL(gpf::fanout_kernel, dim3(n_out), dim3(64), 0, e->stream, e->g, e->bufs(), src, dst0, n_out, e->tmp_lines.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(e->stream));   // out_lines may be reused by the caller
-  for (int k = 0; k < n_out; ++k) { e->lane_nb[dst0 + k] = e->lane_nb[src]; e->lane_nj[dst0 + k] = e->lane_nj[src]; e->lane_mb[dst0 + k] = e->lane_mb[src]; }
+  for (int k = 0; k < n_out; ++k) { e->lane_nb[dst0 + k] = e->lane_nb[src]; e->lane_nj[dst0 + k] = e->lane_nj[src]; e->lane_mb[dst0 + k] = e->lane_mb[src]; e->lane_class[dst0 + k] = e->lane_class[src]; }
   e->plan_valid = false;
   return GPF_OK;
 }
@@ -761,8 +878,18 @@ static int launch_runpf_sparse(gpf_engine* e, const LaunchPlan& p, hipStream_t s
       lds_set_[e->device & 63] = p.lds;                                                                                           \
     }                                                                                                                             \
     hipLaunchKernelGGL((gpf::runpf_sparse_kernel<NBK, ST, IPW, MW, WP>), dim3((n_l + IPW - 1) / IPW), dim3(gpf::WAVE * WP), p.lds, \
-                       stream, e->d_params_s, lane0, list, is_dc, max_iter, tol_pu);                                              \
+                       stream, e->d_params_s, lane0, list, p.cls_list, is_dc, max_iter, tol_pu);                                  \
   } while (0)
+  if (p.tc) {
+    static size_t lds_tc_[64] = {0};
+    if (p.wpi == 2) {
+      if (p.lds > lds_tc_[e->device & 63]) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<1, 0, 1, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<1, 0, 1, 2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); lds_tc_[e->device & 63] = p.lds; }
+      hipLaunchKernelGGL((gpf::runpf_sparse_kernel<1, 0, 1, 2, 2, true>), dim3(n_l), dim3(gpf::WAVE * 2), p.lds, stream, e->d_params_s, lane0, list, p.cls_list, is_dc, max_iter, tol_pu);
+    } else {
+      if (p.lds > lds_tc_[e->device & 63]) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<1, 0, 1, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<1, 0, 1, 2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); lds_tc_[e->device & 63] = p.lds; }
+      hipLaunchKernelGGL((gpf::runpf_sparse_kernel<1, 0, 1, 2, 1, true>), dim3(n_l), dim3(gpf::WAVE), p.lds, stream, e->d_params_s, lane0, list, p.cls_list, is_dc, max_iter, tol_pu);
+    }
+  } else
   if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_RUNPF_SPARSE(1, 2, 4, 2, 1);
   else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_RUNPF_SPARSE(1, 2, 2, 2, 1);
   else if (p.sparse_nb == 1 && p.wpi == 2 && p.sparse_stage == 2) LAUNCH_RUNPF_SPARSE(1, 2, 1, 2, 2);
@@ -800,8 +927,14 @@ static int launch_step_sparse(gpf_engine* e, const LaunchPlan& p, hipStream_t st
       lds_set_[e->device & 63] = p.lds;                                                                                           \
     }                                                                                                                             \
     hipLaunchKernelGGL((gpf::step_sparse_kernel<NBK, ST, IPW, MW, WP>), dim3((n_l + IPW - 1) / IPW), dim3(gpf::WAVE * WP), p.lds,  \
-                       stream, e->d_params_s, list, max_iter, tol_pu, sa);                                                        \
+                       stream, e->d_params_s, list, p.cls_list, max_iter, tol_pu, sa);                                            \
   } while (0)
+  if (p.tc) {
+    static size_t lds_tc_[64] = {0};
+    if (p.lds > lds_tc_[e->device & 63]) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<1, 0, 1, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<1, 0, 1, 2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); lds_tc_[e->device & 63] = p.lds; }
+    if (p.wpi == 2) hipLaunchKernelGGL((gpf::step_sparse_kernel<1, 0, 1, 2, 2, true>), dim3(n_l), dim3(gpf::WAVE * 2), p.lds, stream, e->d_params_s, list, p.cls_list, max_iter, tol_pu, sa);
+    else hipLaunchKernelGGL((gpf::step_sparse_kernel<1, 0, 1, 2, 1, true>), dim3(n_l), dim3(gpf::WAVE), p.lds, stream, e->d_params_s, list, p.cls_list, max_iter, tol_pu, sa);
+  } else
   if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_STEP_SPARSE(1, 2, 4, 2, 1);
   else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_STEP_SPARSE(1, 2, 2, 2, 1);
   else if (p.sparse_nb == 1 && p.wpi == 2 && p.sparse_stage == 2) LAUNCH_STEP_SPARSE(1, 2, 1, 2, 2);
@@ -839,7 +972,7 @@ int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
   const double tol_pu = tol_mva / e->g.sn_mva;
   hipEvent_t ea = nullptr, eb = nullptr;
   if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
-  if (p.sparse_nb) { rc = upload_params_s(e, b); if (rc != GPF_OK) return rc; }
+  if (p.sparse_nb) { rc = upload_params_s(e, b, p.tc ? &p : (pb.tc ? &pb : nullptr)); if (rc != GPF_OK) return rc; }
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
   if (p.sparse_nb) {
     // (measured: forking the second launch onto its own stream costs more in cross-stream events than the overlap gains)
@@ -947,7 +1080,7 @@ int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double r
   const double tol_pu = tol_mva / e->g.sn_mva;
   hipEvent_t ea = nullptr, eb = nullptr;
   if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
-  if (p.sparse_nb) { rc = upload_params_s(e, b); if (rc != GPF_OK) return rc; }
+  if (p.sparse_nb) { rc = upload_params_s(e, b, p.tc ? &p : (pb.tc ? &pb : nullptr)); if (rc != GPF_OK) return rc; }
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
   if (p.sparse_nb) {
     rc = launch_step_sparse(e, p, e->stream, max_iter, tol_pu, sa);

@@ -46,6 +46,7 @@ struct StatView {
       sto_pos, sto_sub, shunt_sub;
   SP<int, HOT> pair_rc;   // [nslot_y] slot_row | slot_col << 16 of the original-pattern blocks
   SP<int, HOT> prog;      // level-scheduled program (layout: gridpf_symbolic.hpp)
+  SP<int, false> node_of; // topology-class launches only (TopoClassDev::node_of)
 };
 template <int STAGE>
 __device__ inline void stat_view(StatView<STAGE>& v, const StatOff& o, const double* d, const int* i) {
@@ -55,6 +56,7 @@ __device__ inline void stat_view(StatView<STAGE>& v, const StatOff& o, const dou
   v.line_ex_sub.p = i + o.line_ex_sub; v.br_slot.p = i + o.br_slot; v.gen_pos.p = i + o.gen_pos; v.gen_sub.p = i + o.gen_sub;
   v.gen_slack.p = i + o.gen_slack; v.load_pos.p = i + o.load_pos; v.load_sub.p = i + o.load_sub; v.sto_pos.p = i + o.sto_pos;
   v.sto_sub.p = i + o.sto_sub; v.shunt_sub.p = i + o.shunt_sub; v.pair_rc.p = i + o.pair_rc; v.prog.p = i + o.prog;
+  v.node_of.p = nullptr;
 }
 // LDS bytes of the staged part of the blob.  tier 0: nothing; 1: the hot ints (+ the lane's injection row, per instance);
 // 2: everything
@@ -72,11 +74,26 @@ struct SymDev {
   StatOff so;
 };
 
+// Topology class (gridpf_capi.hip: build_topo_class): lanes whose substations are SPLIT do not fall back to NB = n_busbar
+// blocks -- their bus-level graph (one node per live busbar: node = substation for busbar 1, extra nodes behind) gets its
+// own symbolic analysis, cached per distinct line-end / busbar assignment, and the single-busbar kernel runs on it with
+// 2x2 blocks.  A class carries what depends on the graph: program, pair table, branch slots and the (substation, busbar)
+// -> node table; everything else is the grid's static blob.
+struct TopoClassDev {
+  SymDev sym;             // n = number of nodes; prog -> this class's program; stat_* / so: the grid's
+  const int* pair_rc;     // [nslot_y]
+  const int* br_slot;     // [n_line][4]
+  const int* node_of;     // [n_sub][n_busbar] node of a (substation, local busbar - 1), -1: that busbar has no element
+};
+
 struct DevParamsS {
   GridDev g;
   Bufs b;
   OutOff oo;
   SymDev sym;
+  const TopoClassDev* classes;   // device array (topology-class launches), else nullptr
+  int tc_rows;                   // LDS sizing of a topology-class launch: max number of nodes ...
+  int tc_nslot, tc_nslot_y;      // ... blocks incl. fill / original-pattern blocks over the classes of the launch
 };
 
 // -DGPF_TIMING developer build: cycle-counter stamps are kept in REGISTERS (a global store per stamp would be waited for
@@ -127,21 +144,23 @@ struct CarveP {
 
 // LDS bytes of ONE instance (without the program copy, which is shared by the IPW instances of a block).
 template <int NB>
-__host__ __device__ inline size_t lds_bytes_instance(const GridDev& g, int nslot, int nslot_y, bool stage_inj) {
+__host__ __device__ inline size_t lds_bytes_instance(const GridDev& g, int nslot, int nslot_y, bool stage_inj, int n_rows = -1) {
   constexpr int BS = 2 * NB;
-  const size_t nbus = (size_t)g.n_sub * NB;
+  const size_t rows = n_rows > 0 ? (size_t)n_rows : (size_t)g.n_sub;      // block rows: substations, or nodes of a topology class
+  const size_t nbus = rows * NB;
   size_t a_d = (size_t)nslot * BS * BS;
   const size_t topo_d = (((size_t)g.dim_topo + 1) / 2 + 2) & ~(size_t)1;
   if (a_d < topo_d) a_d = topo_d;
-  const size_t nd = a_d + (size_t)nslot_y * NB * NB * 2 + (size_t)g.n_sub * BS + 8 * nbus + (stage_inj ? (size_t)g.n_inj : 0);
+  const size_t nd = a_d + (size_t)nslot_y * NB * NB * 2 + rows * BS + 8 * nbus + (stage_inj ? (size_t)g.n_inj : 0);
   const size_t ni = nbus;
   const size_t n16 = 2 * (size_t)g.n_line + g.n_gen + g.n_load + g.n_sto + g.n_shunt;
   return (nd * 8 + ni * 4 + n16 * 2 + g.n_sub + 15) & ~(size_t)15;
 }
 // dynamic LDS of a block: IPW instances + (when staged) one copy of the static blob (stat_bytes, 0 when not staged)
 template <int NB>
-__host__ __device__ inline size_t lds_bytes_sparse(const GridDev& g, int nslot, int nslot_y, size_t static_bytes, bool stage_inj, int ipw = 1) {
-  return (size_t)ipw * lds_bytes_instance<NB>(g, nslot, nslot_y, stage_inj) + static_bytes;
+__host__ __device__ inline size_t lds_bytes_sparse(const GridDev& g, int nslot, int nslot_y, size_t static_bytes, bool stage_inj, int ipw = 1,
+                                                   int n_rows = -1) {
+  return (size_t)ipw * lds_bytes_instance<NB>(g, nslot, nslot_y, stage_inj, n_rows) + static_bytes;
 }
 
 // Stage the static blob in LDS (STAGE) or view it in place; visible to the block after the first barrier.
@@ -167,16 +186,18 @@ __device__ inline void make_stat_view(StatView<STAGE>& sv, const SymDev& S, unsi
 }
 
 template <int NB>
-__device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const GridDev& g, int nslot, int nslot_y, bool stage_inj) {
+__device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const GridDev& g, int nslot, int nslot_y, bool stage_inj,
+                                    int n_rows = -1) {
   constexpr int BS = 2 * NB;
-  const size_t nbus = (size_t)g.n_sub * NB;
+  const size_t rows = n_rows > 0 ? (size_t)n_rows : (size_t)g.n_sub;
+  const size_t nbus = rows * NB;
   double* d = reinterpret_cast<double*>(base);
   size_t a_d = (size_t)nslot * BS * BS;
   const size_t topo_d = (((size_t)g.dim_topo + 1) / 2 + 2) & ~(size_t)1;
   if (a_d < topo_d) a_d = topo_d;
   c.A = d; c.topo = reinterpret_cast<int*>(d); d += a_d;
   c.Yb = d; d += (size_t)nslot_y * NB * NB * 2;
-  c.rhs = d; d += (size_t)g.n_sub * BS;
+  c.rhs = d; d += rows * BS;
   c.vm = d; d += nbus; c.va = d; d += nbus; c.e = d; c.Gs = d; d += nbus; c.f = d; d += nbus;
   c.Psp = d; d += nbus; c.Qsp = d; d += nbus;
   c.Sre = d; c.lab = reinterpret_cast<int*>(d); d += nbus;
@@ -630,8 +651,8 @@ __device__ inline bool scalar_lu_solve(const SymDev& S, PP prog, double* __restr
 // One complete power flow of the IPW instances of a wavefront (tid = lane within the instance group).  Returns the GPF_ST_*
 // status of the caller's group.  Groups share the instruction stream: a group that has failed or finished keeps executing
 // (its state is frozen / its results are overwritten by the caller), so barriers stay wave-uniform.
-template <int NB, int STAGE, int IPW, int WPI>
-__device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, const StatView<STAGE>& sv, CarveP<NB>& c, int inst, int is_dc, int max_iter,
+template <int NB, int STAGE, int IPW, int WPI, bool TC>
+__device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, const SymDev& S, const StatView<STAGE>& sv, CarveP<NB>& c, int inst, int is_dc, int max_iter,
                                             double tol_pu, int tid, bool inj_staged, bool topo_staged, int& n_iter_out, int& nb_out GPF_STAMPS_PARAM) {
   typedef Grp<IPW, WPI> G;
   constexpr int GW = G::GW;
@@ -640,9 +661,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   const GridDev& g = P->g;
   const Bufs& b = P->b;
   const OutOff& oo = P->oo;
-  const SymDev& S = P->sym;
   const int nsub = g.n_sub;
-  const int nbus = nsub * NB;
+  const int nbus = TC ? S.n : nsub * NB;               // block rows x NB: substations, or the nodes of the topology class
   const auto topo_g = gptr(b.topo) + (size_t)inst * g.dim_topo;            // lane rows in HBM: explicit global address space
   const auto shb = gptr(b.shunt_bus) + (size_t)inst * g.n_shunt;
   const auto lstat = gptr(b.line_status) + (size_t)inst * g.n_line;
@@ -662,11 +682,14 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     c.btype[i] = BT_OFF; c.vidx[i] = -1;
     c.Psp[i] = 0.0; c.Qsp[i] = 0.0; c.Gs[i] = 0.0;
   }
-  if (NB == 1) for (int i = tid; i < nsub; i += GW) c.sub_bb[i] = 1;
+  if (NB == 1 && !TC) for (int i = tid; i < nsub; i += GW) c.sub_bb[i] = 1;
   GPF_SYNC();
   GPF_STAMPS(27);
   const int* topo = c.topo;
-  auto bus_of = [&](int sub, int local) -> int { return (NB == 1) ? sub : sub * NB + (local - 1); };
+  auto bus_of = [&](int sub, int local) -> int {
+    if (TC) return sv.node_of[sub * g.n_busbar + (local - 1)];
+    return (NB == 1) ? sub : sub * NB + (local - 1);
+  };
   bool line_off = false;
   for (int l = tid; l < g.n_line; l += GW) {
     const int bo = topo[sv.line_or_pos[l]], be = topo[sv.line_ex_pos[l]];
@@ -679,7 +702,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     if (on) {
       atomicMax(&c.btype[fo], BT_PQ);
       atomicMax(&c.btype[fe], BT_PQ);
-      if (NB == 1) { c.sub_bb[so] = (i8)bo; c.sub_bb[se] = (i8)be; }
+      if (NB == 1 && !TC) { c.sub_bb[so] = (i8)bo; c.sub_bb[se] = (i8)be; }
     }
   }
   for (int i = tid; i < g.n_gen; i += GW) {
@@ -692,7 +715,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       atomicMax(&c.btype[bu], sl ? BT_REF : BT_PV);
       if (!sl) atomicAdd(&c.Psp[bu], GPF_INJ(oo.inj_gen_p + i) * inv_sn);
       atomicMax(&c.vidx[bu], i);
-      if (NB == 1) c.sub_bb[sb] = (i8)lb;
+      if (NB == 1 && !TC) c.sub_bb[sb] = (i8)lb;
     }
   }
   for (int i = tid; i < g.n_load; i += GW) {
@@ -704,7 +727,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       atomicMax(&c.btype[bu], BT_PQ);
       atomicAdd(&c.Psp[bu], -GPF_INJ(oo.inj_load_p + i) * inv_sn);
       atomicAdd(&c.Qsp[bu], -GPF_INJ(oo.inj_load_q + i) * inv_sn);
-      if (NB == 1) c.sub_bb[sb] = (i8)lb;
+      if (NB == 1 && !TC) c.sub_bb[sb] = (i8)lb;
     }
   }
   for (int i = tid; i < g.n_sto; i += GW) {
@@ -716,7 +739,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       atomicMax(&c.btype[bu], BT_PQ);
       atomicAdd(&c.Psp[bu], -GPF_INJ(oo.inj_sto_p + i) * inv_sn);
       atomicAdd(&c.Qsp[bu], -GPF_INJ(oo.inj_sto_q + i) * inv_sn);
-      if (NB == 1) c.sub_bb[sb] = (i8)lb;
+      if (NB == 1 && !TC) c.sub_bb[sb] = (i8)lb;
     }
   }
   for (int i = tid; i < g.n_shunt; i += GW) {
@@ -727,7 +750,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     if (bu >= 0) {
       atomicMax(&c.btype[bu], BT_PQ);
       atomicAdd(&c.Gs[bu], GPF_INJ(oo.inj_sh_p + i) * sv.shunt_fact[i] * inv_sn);
-      if (NB == 1) c.sub_bb[sb] = (i8)lb;
+      if (NB == 1 && !TC) c.sub_bb[sb] = (i8)lb;
     }
   }
   GPF_SYNC();
@@ -755,7 +778,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   // With one live busbar per substation and every line in service the bus graph IS the static substation graph, whose
   // connectivity the host checked at gpf_create: nothing to propagate (the DoNothing case).  Otherwise label propagation
   // from the reference buses.
-  const bool conn_known = (NB == 1) && S.static_connected && !G::any(line_off);
+  const bool conn_known = (NB == 1) && !TC && S.static_connected && !G::any(line_off);
   if (!G::block_all(conn_known))
   for (int sweep = 0; sweep < nbus; ++sweep) {
     int changed = 0;
@@ -1107,7 +1130,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   for (int i = tid; i < g.nb_tot; i += GW) {
     const int sub = i % nsub, lb = i / nsub + 1;            // global bus = sub + (local-1)*n_sub
     int bu;
-    if (NB == 1) bu = (c.sub_bb[sub] == lb) ? sub : -1;
+    if (TC) bu = lb <= g.n_busbar ? sv.node_of[sub * g.n_busbar + (lb - 1)] : -1;
+    else if (NB == 1) bu = (c.sub_bb[sub] == lb) ? sub : -1;
     else bu = (lb <= NB) ? sub * NB + (lb - 1) : -1;
     const bool on = bu >= 0 && c.btype[bu] != BT_OFF;
     bvm[i] = on ? c.vm[bu] : nand;
@@ -1119,8 +1143,27 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
 }
 
 // ---------------------------------------------------------------------------------------------------
-template <int NB, int STAGE, int IPW, int MINW, int WPI>
-__global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const DevParamsS* __restrict__ P, int lane0, const int* __restrict__ lane_list, int is_dc, int max_iter,
+// LDS carve + static view + symbolic header of a block.  Topology-class launches (TC): the header and the graph-dependent
+// tables come from the class of the block's lane (all lanes of a block share it: IPW == 1), LDS is sized for the largest
+// class of the launch.
+#define GPF_CARVE_AND_VIEW(G_)                                                                                                   \
+  SymDev S_tc;                                                                                                                   \
+  if (TC) S_tc = P->classes[gptr(lane_class)[blockIdx.x * IPW + grp]].sym;                                                        \
+  const SymDev& S = TC ? S_tc : P->sym;                                                                                          \
+  const int lds_rows = TC ? P->tc_rows : -1, lds_nslot = TC ? P->tc_nslot : P->sym.nslot,                                        \
+            lds_nslot_y = TC ? P->tc_nslot_y : P->sym.nslot_y;                                                                   \
+  const size_t per_inst = lds_bytes_instance<NB>(G_, lds_nslot, lds_nslot_y, STAGE != 0, lds_rows);                              \
+  carve_sparse<NB>(c, smem + (size_t)grp * per_inst, G_, lds_nslot, lds_nslot_y, STAGE != 0, lds_rows);                          \
+  StatView<STAGE> sv;                                                                                                            \
+  make_stat_view<STAGE>(sv, P->sym, smem + (size_t)IPW * per_inst);                                                              \
+  if (TC) {                                                                                                                      \
+    const TopoClassDev& tc_ = P->classes[gptr(lane_class)[blockIdx.x * IPW + grp]];                                              \
+    sv.prog.p = tc_.sym.prog; sv.pair_rc.p = tc_.pair_rc; sv.br_slot.p = tc_.br_slot; sv.node_of.p = tc_.node_of;                \
+  }
+
+template <int NB, int STAGE, int IPW, int MINW, int WPI, bool TC = false>
+__global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const DevParamsS* __restrict__ P, int lane0, const int* __restrict__ lane_list,
+                                                            const int* __restrict__ lane_class, int is_dc, int max_iter,
                                                             double tol_pu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int GW = Grp<IPW, WPI>::GW;
@@ -1128,13 +1171,10 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   // contiguous range, or (mixed batches) a device list of lanes; both padded by the host with ghost lanes to a multiple of IPW
   const int inst = lane_list ? gptr(lane_list)[blockIdx.x * IPW + grp] : lane0 + blockIdx.x * IPW + grp;
   CarveP<NB> c;
-  const size_t per_inst = lds_bytes_instance<NB>(P->g, P->sym.nslot, P->sym.nslot_y, STAGE != 0);
-  carve_sparse<NB>(c, smem + (size_t)grp * per_inst, P->g, P->sym.nslot, P->sym.nslot_y, STAGE != 0);
-  StatView<STAGE> sv;
-  make_stat_view<STAGE>(sv, P->sym, smem + (size_t)IPW * per_inst);
+  GPF_CARVE_AND_VIEW(P->g);
   int n_iter, nb;
   GPF_STAMPS_DECL;
-  const int st = solve_instance_sparse<NB, STAGE, IPW, WPI>(P, sv, c, inst, is_dc, max_iter, tol_pu, tid, false, false, n_iter, nb GPF_STAMPS_ARG);
+  const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC>(P, S, sv, c, inst, is_dc, max_iter, tol_pu, tid, false, false, n_iter, nb GPF_STAMPS_ARG);
   GPF_SYNC();
   if (st != 0) write_nan_results<GW>(P->g, P->b, inst, tid);
   if (tid == 0) {
@@ -1143,8 +1183,9 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   }
 }
 
-template <int NB, int STAGE, int IPW, int MINW, int WPI>
-__global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const DevParamsS* __restrict__ P, const int* __restrict__ lane_list, int max_iter, double tol_pu,
+template <int NB, int STAGE, int IPW, int MINW, int WPI, bool TC = false>
+__global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const DevParamsS* __restrict__ P, const int* __restrict__ lane_list,
+                                                           const int* __restrict__ lane_class, int max_iter, double tol_pu,
                                                            StepArgs sa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef Grp<IPW, WPI> G;
@@ -1155,10 +1196,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   const int grp = threadIdx.x / GW, tid = threadIdx.x % GW;
   const int inst = lane_list ? gptr(lane_list)[blockIdx.x * IPW + grp] : blockIdx.x * IPW + grp;   // ghost-padded by the host
   CarveP<NB> c;
-  const size_t per_inst = lds_bytes_instance<NB>(g, P->sym.nslot, P->sym.nslot_y, STAGE != 0);
-  carve_sparse<NB>(c, smem + (size_t)grp * per_inst, g, P->sym.nslot, P->sym.nslot_y, STAGE != 0);
-  StatView<STAGE> sv;
-  make_stat_view<STAGE>(sv, P->sym, smem + (size_t)IPW * per_inst);
+  GPF_CARVE_AND_VIEW(g);
   if (STAGE) GPF_SYNC();                                       // the static tables are read from here on
   GPF_STAMPS_DECL;
   GPF_STAMPS(8);
@@ -1228,7 +1266,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   while (true) {
     // a group whose cascade has ended re-solves its unchanged state along with the others (same results)
     int it_k = 0, nb_k = 0;
-    const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI>(P, sv, c, inst, sa.is_dc, max_iter, tol_pu, tid, true, first, it_k, nb_k GPF_STAMPS_ARG);
+    const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI, TC>(P, S, sv, c, inst, sa.is_dc, max_iter, tol_pu, tid, true, first, it_k, nb_k GPF_STAMPS_ARG);
     first = false;
     GPF_SYNC();
     if (more) { st = st_k; n_iter = it_k; nb = nb_k; }
