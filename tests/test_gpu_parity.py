@@ -617,3 +617,33 @@ def test_single_busbar_batches_with_outages_instance_group_kernels(name, n, load
         kinds.add("ok" if o.converged else o.reason.split()[0])
     assert "ok" in kinds and len(kinds) >= 3, kinds
     eng.close()
+
+
+@pytest.mark.parametrize("name,n", [("l2rpn_neurips_2020_track1", 160), ("l2rpn_wcci_2022_dev", 64), ("l2rpn_case14_sandbox", 200)])
+def test_many_distinct_split_topologies(name, n, load_model):
+    """Topology classes: most lanes carry a DIFFERENT split topology (each gets its own bus-level symbolic program on the
+    host), mixed with unsplit lanes, line outages and shunts moved to busbar 2; then the topologies are shuffled between
+    the lanes (class cache hits, new lane -> class lists) and solved again."""
+    m = load_model(name)
+    rng = np.random.default_rng(77)
+    states = random_states(m, n, rng, p_split=0.75, p_line_off=0.3)
+    eng = _engine(m, n)
+    inj, topo, sb = _pack(eng, states)
+    eng.set_injections(inj)
+    eng.set_topology(topo, sb)
+    eng.runpf()
+    r = eng.results()
+    ref = [solve(m, s) for s in states]
+    n_split = 0
+    for k in range(n):
+        _compare(m, r, k, ref[k])
+        n_split += int((states[k].topo == 2).any())
+    assert n_split > n // 2
+    perm = rng.permutation(n)
+    eng.set_injections(inj[perm])
+    eng.set_topology(topo[perm], sb[perm] if m.n_shunt else None)
+    eng.runpf()
+    r2 = eng.results()
+    for k in range(n):
+        _compare(m, r2, k, ref[perm[k]])
+    eng.close()
