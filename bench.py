@@ -232,6 +232,26 @@ def main():
             res["cpu_baseline"] = cpu_baseline(m, ch, T)
         else:
             res["cpu_baseline"] = None
+    # ---- same workload with topology actions: 10 % of the lanes with a split substation (topology classes) --------
+    split = None
+    if not args.no_secondary and args.env == "l2rpn_case14_sandbox" and not args.n1:
+        topo = np.tile(m.initial_topo_vect(), (B, 1))
+        sub = int(np.argmax(m.sub_info))
+        start = int(np.concatenate(([0], np.cumsum(m.sub_info)))[sub])
+        ends = set(m.line_or_pos_topo_vect.tolist()) | set(m.line_ex_pos_topo_vect.tolist())
+        line_pos = [q for q in range(start, start + int(m.sub_info[sub])) if q in ends]
+        pick = np.random.default_rng(lane0).random(B) < 0.10
+        for q in line_pos[::2][:max(1, len(line_pos) // 2 - 1)]:
+            topo[pick, q] = 2
+        eng.set_topology(topo)
+        el_s, k_s, n_s = run_workload(eng, max(20, args.steps // 4), max(2, args.warmup // 4), step_kw, sync_all)
+        el_s = max_over_ranks(el_s, dist, device="cuda" if dist is not None else None)
+        conv_s = float(eng.results().converged.mean())
+        if rank == 0:
+            split = {"workload": f"{args.env}, batch={B}: substation {sub} split (lines alternating between its two busbars) in "
+                                 f"{100.0 * pick.mean():.0f} % of the lanes",
+                     "value": world * B * max(20, args.steps // 4) / el_s, "unit": "env steps/sec",
+                     "us_per_step": k_s / max(n_s, 1) * 1e3, "frac_converged": conv_s}
     eng.close()
 
     # ---- secondary workload: the 118-substation grid of BASELINE.json configs[3] (1024 lanes per GPU) -------------------
@@ -342,6 +362,7 @@ def main():
     if rank == 0:
         res["secondary"] = sec
         res["dc_ptdf"] = ptdf
+        res["split_topologies"] = split
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()
