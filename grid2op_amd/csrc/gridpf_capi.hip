@@ -379,25 +379,37 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
     if (mb > 1 && !e->no_partition) {
       std::vector<int> la, lb, lc;
       bool all_classed = true;
-      // grids without instance groups (> 24 substations): ONE topology-class launch for the whole mixed batch (the lanes
-      // without a split run their own class at the same speed); small grids keep their lanes without a split on the
-      // instance-group kernel
-      bool everyone = e->g.n_sub > 24 && !e->ipw_override;
+      // ONE topology-class launch serves the whole mixed batch when every lane has a class (the lanes without a split run
+      // their own class at the same speed); on small grids the lanes are packed by class into instance groups
+      bool everyone = true;
       for (int k = lane0; k < lane0 + n && everyone; ++k) everyone = e->lane_class[k] >= 0;
+      const int tc_ipw = e->ipw_override ? e->ipw_override : (e->g.n_sub <= 8 ? 4 : e->g.n_sub <= 24 ? 2 : 1);
+      if (everyone) {
+        std::vector<int> order(n);
+        for (int k = 0; k < n; ++k) order[k] = lane0 + k;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return e->lane_class[a] < e->lane_class[b]; });
+        for (size_t i = 0; i < order.size();) {
+          const int cid = e->lane_class[order[i]];
+          size_t j = i;
+          while (j < order.size() && e->lane_class[order[j]] == cid) { lb.push_back(order[j]); lc.push_back(cid); ++j; }
+          while (lb.size() % tc_ipw) { lb.push_back(e->n_lanes); lc.push_back(cid); }      // ghost lanes complete the group
+          i = j;
+        }
+      } else
       for (int k = lane0; k < lane0 + n; ++k) {
-        if (e->lane_mb[k] == 1 && !everyone) la.push_back(k);
+        if (e->lane_mb[k] == 1) la.push_back(k);
         else { lb.push_back(k); lc.push_back(e->lane_class[k]); all_classed &= (e->lane_class[k] >= 0); }
       }
       LaunchPlan qa = p, qb = p;
       bool ok_b;
       if (all_classed) {
-        qb.tc = true; qb.sparse_nb = 1; qb.ipw = 1; qb.sparse_stage = 0; qb.minw = 2; qb.big = false;
-        qb.wpi = e->wpi_override ? (e->wpi_override >= 2 ? 2 : 1) : (e->g.n_sub >= 64 ? 2 : 1);
+        qb.tc = true; qb.sparse_nb = 1; qb.ipw = everyone ? tc_ipw : 1; qb.sparse_stage = 0; qb.minw = 2; qb.big = false;
+        qb.wpi = qb.ipw > 1 ? 1 : (e->wpi_override ? (e->wpi_override >= 2 ? 2 : 1) : (e->g.n_sub >= 64 ? 2 : 1));
         for (int cid : lc) {
           const auto* c = e->classes[cid];
           qb.tc_rows = std::max(qb.tc_rows, c->n_nodes); qb.tc_nslot = std::max(qb.tc_nslot, c->nslot); qb.tc_nslot_y = std::max(qb.tc_nslot_y, c->nslot_y);
         }
-        qb.lds = gpf::lds_bytes_sparse<1>(e->g, qb.tc_nslot, qb.tc_nslot_y, 0, false, 1, qb.tc_rows);
+        qb.lds = gpf::lds_bytes_sparse<1>(e->g, qb.tc_nslot, qb.tc_nslot_y, 0, false, qb.ipw, qb.tc_rows);
         ok_b = qb.lds <= LDS_HARD_LIMIT;
         if (ok_b && e->d_classes_count != e->classes.size()) {
           std::vector<gpf::TopoClassDev> hc(e->classes.size());
@@ -414,9 +426,12 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
         qa.n_list = (int)la.size(); qb.n_list = (int)lb.size();
         while (la.size() % 4) la.push_back(e->n_lanes);             // ghost lane (pristine state, never read back)
         while (lb.size() % 4) { lb.push_back(e->n_lanes); lc.push_back(lc.empty() ? 0 : lc.back()); }
-        if (e->list_a.n < la.size() + 4) { e->list_a.release(); HIP_TRY(e->list_a.alloc(e->cap_lanes + 8)); }
-        if (e->list_b.n < lb.size() + 4) { e->list_b.release(); HIP_TRY(e->list_b.alloc(e->cap_lanes + 8)); }
-        if (e->list_c.n < lc.size() + 4) { e->list_c.release(); HIP_TRY(e->list_c.alloc(e->cap_lanes + 8)); }
+        auto fit = [&](DevArr<int>& d, size_t need_n) -> hipError_t {
+          if (d.n >= need_n) return hipSuccess;
+          d.release();
+          return d.alloc(std::max<size_t>(need_n, (size_t)e->cap_lanes + 8) * 2);
+        };
+        HIP_TRY(fit(e->list_a, la.size() + 4)); HIP_TRY(fit(e->list_b, lb.size() + 4)); HIP_TRY(fit(e->list_c, lc.size() + 4));
         if (!la.empty()) HIP_TRY(hipMemcpyAsync(e->list_a.p, la.data(), la.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
         HIP_TRY(hipMemcpyAsync(e->list_b.p, lb.data(), lb.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
         HIP_TRY(hipMemcpyAsync(e->list_c.p, lc.data(), lc.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
@@ -881,14 +896,22 @@ static int launch_runpf_sparse(gpf_engine* e, const LaunchPlan& p, hipStream_t s
                        stream, e->d_params_s, lane0, list, p.cls_list, is_dc, max_iter, tol_pu);                                  \
   } while (0)
   if (p.tc) {
-    static size_t lds_tc_[64] = {0};
-    if (p.wpi == 2) {
-      if (p.lds > lds_tc_[e->device & 63]) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<1, 0, 1, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<1, 0, 1, 2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); lds_tc_[e->device & 63] = p.lds; }
-      hipLaunchKernelGGL((gpf::runpf_sparse_kernel<1, 0, 1, 2, 2, true>), dim3(n_l), dim3(gpf::WAVE * 2), p.lds, stream, e->d_params_s, lane0, list, p.cls_list, is_dc, max_iter, tol_pu);
-    } else {
-      if (p.lds > lds_tc_[e->device & 63]) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<1, 0, 1, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<1, 0, 1, 2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); lds_tc_[e->device & 63] = p.lds; }
-      hipLaunchKernelGGL((gpf::runpf_sparse_kernel<1, 0, 1, 2, 1, true>), dim3(n_l), dim3(gpf::WAVE), p.lds, stream, e->d_params_s, lane0, list, p.cls_list, is_dc, max_iter, tol_pu);
-    }
+#define LAUNCH_RUNPF_TC(IPW, WP)                                                                                                  \
+    do {                                                                                                                          \
+      static size_t lds_set_[64] = {0};                                                                                           \
+      if (p.lds > lds_set_[e->device & 63]) {                                                                                     \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<1, 0, IPW, 2, WP, true>),            \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                     \
+        lds_set_[e->device & 63] = p.lds;                                                                                         \
+      }                                                                                                                           \
+      hipLaunchKernelGGL((gpf::runpf_sparse_kernel<1, 0, IPW, 2, WP, true>), dim3((n_l + IPW - 1) / IPW), dim3(gpf::WAVE * WP),  \
+                         p.lds, stream, e->d_params_s, lane0, list, p.cls_list, is_dc, max_iter, tol_pu);                         \
+    } while (0)
+    if (p.ipw == 4) LAUNCH_RUNPF_TC(4, 1);
+    else if (p.ipw == 2) LAUNCH_RUNPF_TC(2, 1);
+    else if (p.wpi == 2) LAUNCH_RUNPF_TC(1, 2);
+    else LAUNCH_RUNPF_TC(1, 1);
+#undef LAUNCH_RUNPF_TC
   } else
   if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_RUNPF_SPARSE(1, 2, 4, 2, 1);
   else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_RUNPF_SPARSE(1, 2, 2, 2, 1);
@@ -930,10 +953,22 @@ static int launch_step_sparse(gpf_engine* e, const LaunchPlan& p, hipStream_t st
                        stream, e->d_params_s, list, p.cls_list, max_iter, tol_pu, sa);                                            \
   } while (0)
   if (p.tc) {
-    static size_t lds_tc_[64] = {0};
-    if (p.lds > lds_tc_[e->device & 63]) { HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<1, 0, 1, 2, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<1, 0, 1, 2, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds)); lds_tc_[e->device & 63] = p.lds; }
-    if (p.wpi == 2) hipLaunchKernelGGL((gpf::step_sparse_kernel<1, 0, 1, 2, 2, true>), dim3(n_l), dim3(gpf::WAVE * 2), p.lds, stream, e->d_params_s, list, p.cls_list, max_iter, tol_pu, sa);
-    else hipLaunchKernelGGL((gpf::step_sparse_kernel<1, 0, 1, 2, 1, true>), dim3(n_l), dim3(gpf::WAVE), p.lds, stream, e->d_params_s, list, p.cls_list, max_iter, tol_pu, sa);
+#define LAUNCH_STEP_TC(IPW, WP)                                                                                                   \
+    do {                                                                                                                          \
+      static size_t lds_set_[64] = {0};                                                                                           \
+      if (p.lds > lds_set_[e->device & 63]) {                                                                                     \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<1, 0, IPW, 2, WP, true>),             \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                     \
+        lds_set_[e->device & 63] = p.lds;                                                                                         \
+      }                                                                                                                           \
+      hipLaunchKernelGGL((gpf::step_sparse_kernel<1, 0, IPW, 2, WP, true>), dim3((n_l + IPW - 1) / IPW), dim3(gpf::WAVE * WP),   \
+                         p.lds, stream, e->d_params_s, list, p.cls_list, max_iter, tol_pu, sa);                                   \
+    } while (0)
+    if (p.ipw == 4) LAUNCH_STEP_TC(4, 1);
+    else if (p.ipw == 2) LAUNCH_STEP_TC(2, 1);
+    else if (p.wpi == 2) LAUNCH_STEP_TC(1, 2);
+    else LAUNCH_STEP_TC(1, 1);
+#undef LAUNCH_STEP_TC
   } else
   if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_STEP_SPARSE(1, 2, 4, 2, 1);
   else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_STEP_SPARSE(1, 2, 2, 2, 1);

@@ -1144,11 +1144,11 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
 
 // ---------------------------------------------------------------------------------------------------
 // LDS carve + static view + symbolic header of a block.  Topology-class launches (TC): the header and the graph-dependent
-// tables come from the class of the block's lane (all lanes of a block share it: IPW == 1), LDS is sized for the largest
-// class of the launch.
+// tables come from the class of the block's lanes (the host packs lanes of ONE class into a block), LDS is sized for the
+// largest class of the launch.
 #define GPF_CARVE_AND_VIEW(G_)                                                                                                   \
   SymDev S_tc;                                                                                                                   \
-  if (TC) S_tc = P->classes[gptr(lane_class)[blockIdx.x * IPW + grp]].sym;                                                        \
+  if (TC) S_tc = P->classes[gptr(lane_class)[blockIdx.x * IPW]].sym;                                                        \
   const SymDev& S = TC ? S_tc : P->sym;                                                                                          \
   const int lds_rows = TC ? P->tc_rows : -1, lds_nslot = TC ? P->tc_nslot : P->sym.nslot,                                        \
             lds_nslot_y = TC ? P->tc_nslot_y : P->sym.nslot_y;                                                                   \
@@ -1157,7 +1157,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   StatView<STAGE> sv;                                                                                                            \
   make_stat_view<STAGE>(sv, P->sym, smem + (size_t)IPW * per_inst);                                                              \
   if (TC) {                                                                                                                      \
-    const TopoClassDev& tc_ = P->classes[gptr(lane_class)[blockIdx.x * IPW + grp]];                                              \
+    const TopoClassDev& tc_ = P->classes[gptr(lane_class)[blockIdx.x * IPW]];                                              \
     sv.prog.p = tc_.sym.prog; sv.pair_rc.p = tc_.pair_rc; sv.br_slot.p = tc_.br_slot; sv.node_of.p = tc_.node_of;                \
   }
 
