@@ -234,6 +234,7 @@ int topo_class_of(gpf_engine* e, const int* topo, const int* shunt_bus) {
   for (int i = 0; i < g.n_load; ++i) mark(e->h_load_sub[i], topo[e->h_load_pos[i]]);
   for (int i = 0; i < g.n_sto; ++i) mark(e->h_sto_sub[i], topo[e->h_sto_pos[i]]);
   if (shunt_bus) for (int i = 0; i < g.n_shunt; ++i) mark(e->h_shunt_sub[i], shunt_bus[i]);
+  std::string elem(used, (size_t)g.n_sub * nbb);                        // busbars that really carry an element
   for (int s_ = 0; s_ < g.n_sub; ++s_) used[(size_t)s_ * nbb] = 1;      // the busbar-1 node always exists
   auto it = e->class_of_key.find(key);
   if (it != e->class_of_key.end()) return it->second;
@@ -265,7 +266,23 @@ int topo_class_of(gpf_engine* e, const int* topo, const int* shunt_bus) {
   gpf::SymDev& D = c->dev.sym;
   D = e->sym_dev;                                            // the grid's static blob pointers / offsets
   D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.back_first = S.back_first;
-  D.scale_off = S.scale_off; D.n_scale = S.n_scale; D.n_prog = (int)S.prog.size(); D.static_connected = 0;
+  D.scale_off = S.scale_off; D.n_scale = S.n_scale; D.n_prog = (int)S.prog.size();
+  {   // with every line in service the bus graph of a lane of this class is exactly this graph: connected <=> one component
+      // over the nodes that carry an element (an element-only node without a line is an island)
+    std::vector<int> comp(n_nodes);
+    for (int i = 0; i < n_nodes; ++i) comp[i] = i;
+    auto find = [&](int x) { while (comp[x] != x) { comp[x] = comp[comp[x]]; x = comp[x]; } return x; };
+    for (int l = 0; l < g.n_line; ++l) comp[find(lo[l])] = find(le[l]);
+    int root = -1;
+    bool one = true;
+    for (int s_ = 0; s_ < g.n_sub && one; ++s_)
+      for (int k = 0; k < nbb && one; ++k)
+        if (elem[(size_t)s_ * nbb + k]) {
+          const int r = find(node_of[(size_t)s_ * nbb + k]);
+          if (root < 0) root = r; else one = (r == root);
+        }
+    D.static_connected = one ? 1 : 0;
+  }
   D.prog = c->tables.p + o_prog;
   c->dev.pair_rc = c->tables.p + o_rc; c->dev.br_slot = c->tables.p + o_br; c->dev.node_of = c->tables.p + o_no;
   const int id = (int)e->classes.size();

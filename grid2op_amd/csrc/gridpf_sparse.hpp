@@ -778,7 +778,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   // With one live busbar per substation and every line in service the bus graph IS the static substation graph, whose
   // connectivity the host checked at gpf_create: nothing to propagate (the DoNothing case).  Otherwise label propagation
   // from the reference buses.
-  const bool conn_known = (NB == 1) && !TC && S.static_connected && !G::any(line_off);
+  const bool conn_known = (NB == 1) && S.static_connected && !G::any(line_off);
   if (!G::block_all(conn_known))
   for (int sweep = 0; sweep < nbus; ++sweep) {
     int changed = 0;
