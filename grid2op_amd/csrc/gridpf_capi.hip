@@ -1360,7 +1360,8 @@ int gpf_ptdf_flows(gpf_handle e, int32_t lane0, int32_t n) {
   P.inj_bus = e->ptdf_inj_bus.p; P.inj_w = e->ptdf_inj_w.p; P.ptdf_t = e->ptdf_t.p;
   hipLaunchKernelGGL(gpf::ptdf_bus_injection_kernel, dim3(n), dim3(gpf::WAVE), (size_t)P.nb_pad * sizeof(double), e->stream, P, e->inj.p,
                      lane0, e->ptdf_pbus.p);
-  hipLaunchKernelGGL(gpf::ptdf_gemm_kernel, dim3((n + 15) / 16), dim3(256), 0, e->stream, P, e->ptdf_pbus.p, lane0, n, e->ptdf_flow.p);
+  hipLaunchKernelGGL(gpf::ptdf_gemm_kernel, dim3((n + 15) / 16, (P.line_pad / 16 + 3) / 4), dim3(256), 0, e->stream, P, e->ptdf_pbus.p, lane0, n,
+                     e->ptdf_flow.p);
   HIP_TRY(hipGetLastError());
   if (e->window) ++e->win_launches;
   return GPF_OK;

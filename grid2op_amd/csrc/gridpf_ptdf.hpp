@@ -40,7 +40,7 @@ __global__ __launch_bounds__(WAVE) void ptdf_bus_injection_kernel(PtdfDev P, con
   for (int b = tid; b < P.nb_pad; b += WAVE) out[b] = acc[b];
 }
 
-// K_G: flow[16 lanes][all lines] per block of 4 wavefronts; wavefront w owns the line tiles w, w+4, ...
+// K_G: block (x, y) of 4 wavefronts: 16 lanes x the line tiles 4y .. 4y+3 (one 16 x 16 tile per wavefront)
 // MFMA operand layout (64 lanes, l = lane id): A[i = l % 16][k = l / 16], B[k = l / 16][j = l % 16],
 // D[i = 4 * v + l / 16][j = l % 16] for the 4 result registers v.
 __global__ __launch_bounds__(256) void ptdf_gemm_kernel(PtdfDev P, const double* __restrict__ pbus, int lane0, int n_lanes,
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void ptdf_gemm_kernel(PtdfDev P, const double*
   const int my_row = row0 + (l & 15);
   const double* arow = pbus + (size_t)(lane0 + (my_row < n_lanes ? my_row : n_lanes - 1)) * P.nb_pad + (l >> 4);
   const int n_tiles = P.line_pad / 16;
-  for (int t = w; t < n_tiles; t += 4) {
+  for (int t = blockIdx.y * 4 + w; t < n_tiles; t += 4 * gridDim.y) {      // one 16 x 16 tile per wavefront when gridDim.y covers the tiles
     v4d c = {0.0, 0.0, 0.0, 0.0};
     const double* bcol = P.ptdf_t + (size_t)(l >> 4) * P.line_pad + t * 16 + (l & 15);
     int s = 0;
