@@ -326,6 +326,11 @@ def main():
         eng3.set_profiling(0)
         el3 = max_over_ranks(el3, dist, device="cuda" if dist is not None else None)
         flows = eng3.ptdf_flows()
+        eng3.lodf_screen(0, 8)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            worst = eng3.lodf_screen()                          # synchronous: includes the copy of [B3, n_line] floats to the host
+        lodf_s = (time.perf_counter() - t0) / 5
         eng3.runpf(is_dc=True)
         eng3.sync()
         t0 = time.perf_counter()
@@ -355,6 +360,9 @@ def main():
                                  "note": "90 MFLOP per batch: launch/latency bound, two kernels (bus injections + GEMM)"},
                     "per_lane_dc_solve_value": world * B3 / dc_solve_s, "per_lane_dc_solve_unit": "DC power flows/sec (kernel S, B' refactorised per lane)",
                     "max_abs_diff_vs_per_lane_dc_solve_mw": float(np.abs(flows - r3.p_or).max()),
+                    "lodf_n1_value": world * B3 * m3.n_line / lodf_s, "lodf_n1_unit": "DC contingency cases/sec (every single-line outage of "
+                    "every lane: worst post-outage flow via LODF, result copied to the host)",
+                    "lodf_n1_frac_islanding": float(np.isinf(worst).mean()),
                     "ac_runpf_value": world * B3 / ac_solve_s, "ac_runpf_unit": "AC power flows/sec (same lanes, gpf_runpf)",
                     "ac_frac_converged": float(r3ac.converged.mean()),
                     "max_abs_dc_vs_ac_p_or_mw": float(np.abs(flows - r3ac.p_or)[r3ac.converged].max())}

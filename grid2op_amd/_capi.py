@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "gpf_reset_lanes", "gpf_copy_lanes", "gpf_fanout_n1", "gpf_runpf", "gpf_get_results", "gpf_upload_chronics",
     "gpf_set_lane_chronics", "gpf_set_thermal_limits", "gpf_step", "gpf_get_step_outputs", "gpf_sync",
     "gpf_set_profiling", "gpf_get_kernel_time", "gpf_device_pointers",
-    "gpf_ptdf_build", "gpf_ptdf_get", "gpf_ptdf_flows", "gpf_get_ptdf_flows",
+    "gpf_ptdf_build", "gpf_ptdf_get", "gpf_ptdf_flows", "gpf_get_ptdf_flows", "gpf_lodf_screen",
 ]
 
 
@@ -120,6 +120,7 @@ def lib() -> C.CDLL:
     L.gpf_ptdf_get.argtypes = [h, _dp]
     L.gpf_ptdf_flows.argtypes = [h, i32, i32]
     L.gpf_get_ptdf_flows.argtypes = [h, i32, i32, _fp]
+    L.gpf_lodf_screen.argtypes = [h, i32, i32, _fp, _fp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if name not in ("gpf_last_error",):

@@ -114,7 +114,8 @@ struct gpf_engine {
   // DC sensitivity path (gridpf_ptdf.hpp)
   DevArr<int> ptdf_inj_bus;
   DevArr<double> ptdf_inj_w, ptdf_t, ptdf_pbus;
-  DevArr<float> ptdf_flow;
+  DevArr<float> ptdf_flow, lodf_worst, lodf_inv_cap;
+  DevArr<double> lodf;             // [n_line][line_pad] line outage distribution factors of the PTDF topology (NaN column: islanding outage)
   std::vector<double> h_ptdf;      // [n_line][nb_tot]
   std::vector<double> h_br_bdc, h_shunt_fact;
   int ptdf_nb_pad = 0, ptdf_line_pad = 0;
@@ -770,6 +771,7 @@ int gpf_destroy(gpf_handle e) {
   for (auto* c : e->classes) { c->tables.release(); delete c; }
   e->classes.clear();
   e->ptdf_inj_bus.release(); e->ptdf_inj_w.release(); e->ptdf_t.release(); e->ptdf_pbus.release(); e->ptdf_flow.release();
+  e->lodf.release(); e->lodf_worst.release(); e->lodf_inv_cap.release();
   e->stat_int.release();
   delete e;
   return GPF_OK;
@@ -1338,6 +1340,22 @@ int gpf_ptdf_build(gpf_handle e, int32_t lane) {
     HIP_TRY(e->ptdf_pbus.alloc((size_t)e->cap_lanes * nb_pad));
     HIP_TRY(e->ptdf_flow.alloc((size_t)e->cap_lanes * line_pad));
   }
+  {   // LODF[l][k] = H[l][k] / (1 - H[k][k]), H[l][k] = PTDF[l][from_k] - PTDF[l][to_k]; LODF[k][k] = -1
+    std::vector<double> lo_((size_t)g.n_line * line_pad, 0.0);
+    for (int k = 0; k < g.n_line; ++k) {
+      if (lf[k] < 0 || lf[k] == lt[k]) continue;                 // an open line: its outage changes nothing
+      const double hkk = e->h_ptdf[(size_t)k * nbt + lf[k]] - e->h_ptdf[(size_t)k * nbt + lt[k]];
+      const double den = 1.0 - hkk;
+      for (int l = 0; l < g.n_line; ++l) {
+        const double hlk = e->h_ptdf[(size_t)l * nbt + lf[k]] - e->h_ptdf[(size_t)l * nbt + lt[k]];
+        lo_[(size_t)l * line_pad + k] = std::fabs(den) < 1e-8 ? std::nan("") : (l == k ? -1.0 : hlk / den);
+      }
+    }
+    e->lodf.release();
+    HIP_TRY(e->lodf.upload(lo_.data(), lo_.size()));
+    e->lodf_worst.release();
+    HIP_TRY(e->lodf_worst.alloc((size_t)e->cap_lanes * line_pad));
+  }
   e->ptdf_nb_pad = nb_pad; e->ptdf_line_pad = line_pad;
   e->ptdf_ready = true;
   return GPF_OK;
@@ -1374,6 +1392,32 @@ int gpf_get_ptdf_flows(gpf_handle e, int32_t lane0, int32_t n, float* p_or) {
   HIP_TRY(hipMemcpy2DAsync(p_or, (size_t)e->g.n_line * sizeof(float), e->ptdf_flow.p + (size_t)lane0 * e->ptdf_line_pad,
                            (size_t)e->ptdf_line_pad * sizeof(float), (size_t)e->g.n_line * sizeof(float), (size_t)n,
                            hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_lodf_screen(gpf_handle e, int32_t lane0, int32_t n, const float* cap_mw, float* worst) {
+  if (!check_range(e, lane0, n) || !worst) return fail(GPF_E_INVALID, "gpf_lodf_screen: bad arguments");
+  if (!e->ptdf_ready) return fail(GPF_E_INVALID, "gpf_lodf_screen: call gpf_ptdf_build and gpf_ptdf_flows first");
+  if (n == 0) return GPF_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  const int nl = e->g.n_line, lp = e->ptdf_line_pad;
+  const float* ic = nullptr;
+  if (cap_mw) {
+    std::vector<float> inv(nl);
+    for (int l = 0; l < nl; ++l) inv[l] = cap_mw[l] > 0.f ? 1.0f / cap_mw[l] : 0.f;
+    if (!e->lodf_inv_cap.p) HIP_TRY(e->lodf_inv_cap.alloc(nl));
+    HIP_TRY(hipMemcpyAsync(e->lodf_inv_cap.p, inv.data(), (size_t)nl * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    ic = e->lodf_inv_cap.p;
+  }
+  const size_t lds = ((size_t)gpf::LODF_LPW + 1) * lp * sizeof(float);
+  hipLaunchKernelGGL(gpf::lodf_screen_kernel, dim3((n + gpf::LODF_LPW - 1) / gpf::LODF_LPW), dim3(gpf::WAVE), lds, e->stream, nl, lp, e->lodf.p, ic,
+                     e->ptdf_flow.p, lane0, n, e->lodf_worst.p + (size_t)lane0 * lp);
+  HIP_TRY(hipGetLastError());
+  if (e->window) ++e->win_launches;
+  HIP_TRY(hipMemcpy2DAsync(worst, (size_t)nl * sizeof(float), e->lodf_worst.p + (size_t)lane0 * lp, (size_t)lp * sizeof(float),
+                           (size_t)nl * sizeof(float), (size_t)n, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return GPF_OK;
 }

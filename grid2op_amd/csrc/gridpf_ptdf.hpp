@@ -71,4 +71,41 @@ __global__ __launch_bounds__(256) void ptdf_gemm_kernel(PtdfDev P, const double*
   }
 }
 
+// K_L: DC N-1 screening.  Post-outage flows are f_l + LODF[l][k] * f_k (rank-1 update of the pre-outage flows), so for
+// every lane and every single-line outage k the worst loading max_l |f_l + LODF[l][k] f_k| * inv_cap[l] needs no solve.
+// One wavefront serves LODF_LPW lanes (each LODF element fetched from L2 is used for all of them); a thread owns the
+// outages k = tid, tid + 64, ... and walks the monitored lines l: no cross-lane reduction at all.
+constexpr int LODF_LPW = 4;
+__global__ __launch_bounds__(WAVE) void lodf_screen_kernel(int n_line, int line_pad, const double* __restrict__ lodf /* [n_line][line_pad] */,
+                                                           const float* __restrict__ inv_cap /* [n_line] or nullptr */,
+                                                           const float* __restrict__ flow, int lane0, int n_lanes,
+                                                           float* __restrict__ worst /* [n_lanes][line_pad] */) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* f = reinterpret_cast<float*>(smem);                     // [LODF_LPW][line_pad]
+  float* ic = f + (size_t)LODF_LPW * line_pad;                   // [line_pad]
+  const int tid = threadIdx.x, r0 = blockIdx.x * LODF_LPW;
+  for (int i = tid; i < LODF_LPW * line_pad; i += WAVE) {
+    const int r = r0 + i / line_pad, l = i % line_pad;
+    f[i] = (r < n_lanes && l < n_line) ? flow[(size_t)(lane0 + r) * line_pad + l] : 0.f;
+  }
+  for (int l = tid; l < line_pad; l += WAVE) ic[l] = l < n_line ? (inv_cap ? inv_cap[l] : 1.f) : 0.f;
+  __syncthreads();
+  for (int k = tid; k < n_line; k += WAVE) {
+    double fk[LODF_LPW], m[LODF_LPW];
+#pragma unroll
+    for (int r = 0; r < LODF_LPW; ++r) { fk[r] = (double)f[r * line_pad + k]; m[r] = 0.0; }
+    bool island = false;
+    for (int l = 0; l < n_line; ++l) {
+      const double d = lodf[(size_t)l * line_pad + k];
+      island |= (d != d);
+      const double w = (double)ic[l];
+#pragma unroll
+      for (int r = 0; r < LODF_LPW; ++r) m[r] = fmax(m[r], fabs(fma(d, fk[r], (double)f[r * line_pad + l])) * w);
+    }
+#pragma unroll
+    for (int r = 0; r < LODF_LPW; ++r)
+      if (r0 + r < n_lanes) worst[(size_t)(r0 + r) * line_pad + k] = island ? __builtin_inff() : (float)m[r];
+  }
+}
+
 }  // namespace gpf

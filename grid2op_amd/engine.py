@@ -299,6 +299,16 @@ class PowerFlowEngine:
         check(self._lib.gpf_get_ptdf_flows(self._h, lane0, n, ptr(out, C.c_float)), "gpf_get_ptdf_flows")
         return out
 
+    def lodf_screen(self, lane0: int = 0, n: Optional[int] = None, cap_mw: Optional[np.ndarray] = None) -> np.ndarray:
+        """DC N-1 screening from the flows of the last ``ptdf_flows``: [n, n_line] largest post-outage loading
+        max_l |f_l + LODF[l, k] f_k| / cap_mw[l] for every single-line outage k (MW if ``cap_mw`` is None; inf: the
+        outage islands the grid)."""
+        lane0, n = self._range(lane0, n)
+        out = np.empty((n, self.model.n_line), dtype=np.float32)
+        cap = None if cap_mw is None else np.ascontiguousarray(cap_mw, dtype=np.float32)
+        check(self._lib.gpf_lodf_screen(self._h, lane0, n, ptr(cap, C.c_float), ptr(out, C.c_float)), "gpf_lodf_screen")
+        return out
+
     def sync(self):
         check(self._lib.gpf_sync(self._h), "gpf_sync")
 

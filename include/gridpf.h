@@ -168,6 +168,12 @@ int gpf_ptdf_build(gpf_handle h, int32_t lane);
 int gpf_ptdf_get(gpf_handle h, double* ptdf /* [n_line][n_sub*n_busbar] row-major, MW per MW */);
 int gpf_ptdf_flows(gpf_handle h, int32_t lane0, int32_t n);
 int gpf_get_ptdf_flows(gpf_handle h, int32_t lane0, int32_t n, float* p_or);
+/* DC N-1 screening on top of the PTDF path (what N1Reward / obs.simulate loops do one contingency at a time,
+ * grid2op/Reward/n1Reward.py:70-99): post-outage flows are f_l + LODF[l][k] * f_k, so for every lane of the range and
+ * every single-line outage k this returns the largest post-outage loading max_l |f_l + LODF[l][k] f_k| / cap_mw[l]
+ * (cap_mw NULL: the largest |flow| in MW), computed from the flows left by the last gpf_ptdf_flows; outages that island
+ * the grid give +inf.  Synchronous; worst is [n][n_line]. */
+int gpf_lodf_screen(gpf_handle h, int32_t lane0, int32_t n, const float* cap_mw, float* worst);
 
 /* ---- measurement ---------------------------------------------------------------------------------------- */
 int gpf_sync(gpf_handle h);

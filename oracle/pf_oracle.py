@@ -518,3 +518,26 @@ def dc_bus_injection(m, st: LaneState, n_busbar: int = 2):
         if shbus[s] >= 0:
             P[shbus[s]] -= st.shunt_p[s] * m.shunt_fact[s]
     return P
+
+
+def dc_n1_worst_loading(m, st: LaneState, cap_mw=None, n_busbar: int = 2):
+    """Test oracle of gpf_lodf_screen: for every single-line outage k, re-solve the DC power flow with line k forced off
+    (what ``N1Reward`` / ``obs.simulate`` do, one contingency at a time) and return max_l |p_or[l]| / cap_mw[l]
+    (MW if ``cap_mw`` is None); +inf when the outage makes the DC power flow fail (islanding)."""
+    out = np.empty(m.n_line)
+    for k in range(m.n_line):
+        s2 = LaneState.from_model(m)
+        s2.topo = st.topo.copy()
+        s2.shunt_bus = st.shunt_bus.copy()
+        s2.load_p, s2.load_q, s2.gen_p, s2.gen_vm = st.load_p, st.load_q, st.gen_p, st.gen_vm
+        s2.storage_p, s2.storage_q = st.storage_p, st.storage_q
+        s2.shunt_p, s2.shunt_q = st.shunt_p, st.shunt_q
+        s2.topo[m.line_or_pos_topo_vect[k]] = -1
+        s2.topo[m.line_ex_pos_topo_vect[k]] = -1
+        r = solve(m, s2, is_dc=True, n_busbar=n_busbar)
+        if not r.converged:
+            out[k] = np.inf
+        else:
+            f = np.abs(r.p_or)
+            out[k] = (f if cap_mw is None else f / np.asarray(cap_mw)).max()
+    return out

@@ -647,3 +647,37 @@ def test_many_distinct_split_topologies(name, n, load_model):
     for k in range(n):
         _compare(m, r2, k, ref[perm[k]])
     eng.close()
+
+
+@pytest.mark.parametrize("name,n", [("l2rpn_case14_sandbox", 10), ("l2rpn_neurips_2020_track1", 6), ("rte_case5_example", 5)])
+def test_lodf_screening_matches_brute_force_dc_n1(name, n, load_model, load_npz):
+    """gpf_lodf_screen (post-outage flows f + LODF[:, k] f_k, no solve) against the brute-force DC N-1 of the oracle: one DC
+    power flow per (lane, outage), islanding outages -> inf."""
+    from oracle.pf_oracle import dc_n1_worst_loading
+    m = load_model(name)
+    rng = np.random.default_rng(5)
+    base = LaneState.from_model(m)
+    states = []
+    for k in range(n):
+        st = LaneState.from_model(m)
+        st.load_p = base.load_p * (1 + 0.2 * rng.standard_normal(m.n_load))
+        st.gen_p = base.gen_p * (1 + 0.2 * rng.standard_normal(m.n_gen))
+        states.append(st)
+    ch = load_npz(f"{name}.chronics.npz")
+    lim = np.asarray(ch["thermal_limits"], dtype=np.float64) if "thermal_limits" in ch else np.full(m.n_line, 400.0)
+    cap = np.sqrt(3.0) * m.sub_vn_kv[m.line_or_sub] * lim / 1000.0        # MW at 1 pu
+    eng = _engine(m, n)
+    inj, topo, sb = _pack(eng, states)
+    eng.set_injections(inj)
+    eng.set_topology(topo, sb)
+    eng.ptdf_build(0)
+    eng.ptdf_flows(fetch=False)
+    for caps in (None, cap):
+        w = eng.lodf_screen(cap_mw=caps)
+        for k, st in enumerate(states):
+            ref = dc_n1_worst_loading(m, st, caps)
+            assert np.array_equal(np.isinf(w[k]), np.isinf(ref)), k
+            ok = np.isfinite(ref)
+            assert np.allclose(w[k][ok], ref[ok], rtol=2e-5, atol=2e-4 if caps is None else 2e-6), (k, np.abs(w[k][ok] - ref[ok]).max())
+    assert np.isinf(w).any() or name != "l2rpn_case14_sandbox"        # case14 has a radial generator bus: its line islands it
+    eng.close()
