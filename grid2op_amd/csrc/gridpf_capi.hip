@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <climits>
 #include <string>
 #include <vector>
 
@@ -133,6 +134,9 @@ struct gpf_engine {
   struct TopoClassHost { DevArr<int> tables; gpf::TopoClassDev dev; int n_nodes, nslot, nslot_y; };
   std::vector<TopoClassHost*> classes;
   std::unordered_map<std::string, int> class_of_key;
+  // host mirror of the topology last SENT for every lane (gpf_set_topology skips the per-lane bookkeeping when a lane is
+  // re-sent unchanged: agents resend whole batches with few changes); first entry INT_MIN = unknown
+  std::vector<int> h_lane_topo, h_lane_sb;
   std::vector<int> lane_class;          // per lane: topology class (-1: no split substation / classes disabled)
   DevArr<gpf::TopoClassDev> d_classes;  // device copy of classes[*].dev
   size_t d_classes_count = 0;
@@ -556,7 +560,11 @@ int reset_lanes_unchecked(gpf_engine* e, int lane0, int n) {
   HIP_TRY(hipMemsetAsync(e->status.p + (size_t)lane0 * 4, 0xFF, (size_t)n * 4 * sizeof(int), e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   const int init_class = topo_class_of(e, e->h_init_topo.data(), g.n_shunt ? e->h_init_shunt_bus.data() : nullptr);
-  for (int k = lane0; k < lane0 + n; ++k) { e->lane_nb[k] = e->init_nb; e->lane_nj[k] = e->init_nj; e->lane_mb[k] = e->init_mb; e->lane_class[k] = init_class; }
+  for (int k = lane0; k < lane0 + n; ++k) {
+    e->lane_nb[k] = e->init_nb; e->lane_nj[k] = e->init_nj; e->lane_mb[k] = e->init_mb; e->lane_class[k] = init_class;
+    std::copy(e->h_init_topo.begin(), e->h_init_topo.end(), e->h_lane_topo.begin() + (size_t)k * g.dim_topo);
+    if (g.n_shunt) std::copy(e->h_init_shunt_bus.begin(), e->h_init_shunt_bus.end(), e->h_lane_sb.begin() + (size_t)k * g.n_shunt);
+  }
   e->plan_valid = false;
   return GPF_OK;
 }
@@ -692,6 +700,8 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   e->lane_nj.assign(e->cap_lanes, e->init_nj);
   e->lane_mb.assign(e->cap_lanes, e->init_mb);
   e->lane_class.assign(e->cap_lanes, -1);
+  e->h_lane_topo.assign((size_t)e->cap_lanes * g.dim_topo, INT_MIN);
+  e->h_lane_sb.assign((size_t)e->cap_lanes * std::max(g.n_shunt, 1), INT_MIN);
   {
     // symbolic analysis of the substation graph for the block-sparse kernels (once per grid)
     e->sym = gpf::build_symbolic(g.n_sub, nl, e->h_line_or_sub.data(), e->h_line_ex_sub.data());
@@ -817,13 +827,22 @@ int gpf_set_topology(gpf_handle e, int32_t lane0, int32_t n, const int32_t* topo
                            hipMemcpyDeviceToHost, e->stream));
   }
   HIP_TRY(hipStreamSynchronize(e->stream));
+  bool changed = false;
   for (int k = 0; k < n; ++k) {
+    const int* t = topo + (size_t)k * g.dim_topo;
     const int* sb = nullptr;
     if (g.n_shunt) sb = shunt_bus ? shunt_bus + (size_t)k * g.n_shunt : sb_host.data() + (size_t)k * g.n_shunt;
-    count_lane(e, topo + (size_t)k * g.dim_topo, sb, e->lane_nb[lane0 + k], e->lane_nj[lane0 + k], e->lane_mb[lane0 + k]);
-    e->lane_class[lane0 + k] = topo_class_of(e, topo + (size_t)k * g.dim_topo, sb);
+    int* mt = e->h_lane_topo.data() + (size_t)(lane0 + k) * g.dim_topo;
+    int* ms = e->h_lane_sb.data() + (size_t)(lane0 + k) * std::max(g.n_shunt, 1);
+    if (std::memcmp(mt, t, (size_t)g.dim_topo * sizeof(int)) == 0 && (!g.n_shunt || std::memcmp(ms, sb, (size_t)g.n_shunt * sizeof(int)) == 0))
+      continue;                                              // re-sent unchanged: counts and topology class stay
+    std::memcpy(mt, t, (size_t)g.dim_topo * sizeof(int));
+    if (g.n_shunt) std::memcpy(ms, sb, (size_t)g.n_shunt * sizeof(int));
+    count_lane(e, t, sb, e->lane_nb[lane0 + k], e->lane_nj[lane0 + k], e->lane_mb[lane0 + k]);
+    e->lane_class[lane0 + k] = topo_class_of(e, t, sb);
+    changed = true;
   }
-  e->plan_valid = false;
+  if (changed) e->plan_valid = false;
   return GPF_OK;
 }
 
@@ -857,6 +876,7 @@ int gpf_disconnect_line(gpf_handle e, int32_t lane, int32_t line_id) {
   HIP_TRY(hipMemcpyAsync(row + e->h_line_or_pos[line_id], &m1, sizeof(int), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipMemcpyAsync(row + e->h_line_ex_pos[line_id], &m1, sizeof(int), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  e->h_lane_topo[(size_t)lane * e->g.dim_topo] = INT_MIN;          // host mirror of the sent topology: unknown from now on
   return GPF_OK;   // removing a branch never increases the bus / unknown counts: capacity bookkeeping unchanged
 }
 
@@ -879,7 +899,9 @@ int gpf_copy_lanes(gpf_handle e, int32_t src, int32_t dst, int32_t n) {
   CP(shunt_bus_out, g.n_shunt); CP(line_status, g.n_line); CP(status, 4); CP(bus_vm, g.nb_tot); CP(bus_va, g.nb_tot);
   CP(overflow_count, g.n_line); CP(disc_round, g.n_line); CP(rho, g.n_line);
 #undef CP
-  for (int k = 0; k < n; ++k) { e->lane_nb[dst + k] = e->lane_nb[src + k]; e->lane_nj[dst + k] = e->lane_nj[src + k]; e->lane_mb[dst + k] = e->lane_mb[src + k]; e->lane_class[dst + k] = e->lane_class[src + k]; }
+  for (int k = 0; k < n; ++k) { e->lane_nb[dst + k] = e->lane_nb[src + k]; e->lane_nj[dst + k] = e->lane_nj[src + k]; e->lane_mb[dst + k] = e->lane_mb[src + k]; e->lane_class[dst + k] = e->lane_class[src + k];
+    std::copy_n(e->h_lane_topo.begin() + (size_t)(src + k) * g.dim_topo, g.dim_topo, e->h_lane_topo.begin() + (size_t)(dst + k) * g.dim_topo);
+    if (g.n_shunt) std::copy_n(e->h_lane_sb.begin() + (size_t)(src + k) * g.n_shunt, g.n_shunt, e->h_lane_sb.begin() + (size_t)(dst + k) * g.n_shunt); }
   e->plan_valid = false;
   return GPF_OK;
 }
@@ -894,7 +916,8 @@ int gpf_fanout_n1(gpf_handle e, int32_t src, int32_t dst0, int32_t n_out, const 
   hipLaunchKernelGGL(gpf::fanout_kernel, dim3(n_out), dim3(64), 0, e->stream, e->g, e->bufs(), src, dst0, n_out, e->tmp_lines.p);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(e->stream));   // out_lines may be reused by the caller
-  for (int k = 0; k < n_out; ++k) { e->lane_nb[dst0 + k] = e->lane_nb[src]; e->lane_nj[dst0 + k] = e->lane_nj[src]; e->lane_mb[dst0 + k] = e->lane_mb[src]; e->lane_class[dst0 + k] = e->lane_class[src]; }
+  for (int k = 0; k < n_out; ++k) { e->lane_nb[dst0 + k] = e->lane_nb[src]; e->lane_nj[dst0 + k] = e->lane_nj[src]; e->lane_mb[dst0 + k] = e->lane_mb[src]; e->lane_class[dst0 + k] = e->lane_class[src];
+    e->h_lane_topo[(size_t)(dst0 + k) * e->g.dim_topo] = INT_MIN; }     // a line was forced off on the device: mirror unknown
   e->plan_valid = false;
   return GPF_OK;
 }
