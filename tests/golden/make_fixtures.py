@@ -52,6 +52,14 @@ GRIDS = {
     "l2rpn_2019": ("data/l2rpn_2019/grid.json", None, None),
     "rte_case14_test": ("data/rte_case14_test/grid.json", "data/rte_case14_test/chronics/0", "data/rte_case14_test/config.py"),
     "test_case14": ("data_test/test_PandaPower/test_case14.json", None, None),
+    # the other grids the reference ships (embedded pandapower results pin the oracle on each of them)
+    "rte_case118_example": ("data/rte_case118_example/grid.json", None, None),
+    "l2rpn_wcci_2020": ("data/l2rpn_wcci_2020/grid.json", None, None),
+    "l2rpn_icaps_2021": ("data/l2rpn_icaps_2021/grid.json", None, None),
+    "l2rpn_neurips_2020_track2_x1": ("data/l2rpn_neurips_2020_track2/x1/grid.json", None, None),
+    "rte_case14_realistic": ("data/rte_case14_realistic/grid.json", None, None),
+    "educ_case14_redisp": ("data/educ_case14_redisp/grid.json", None, None),
+    "l2rpn_case14_sandbox_diff_grid": ("data/l2rpn_case14_sandbox_diff_grid/grid.json", None, None),
 }
 MAX_ROWS = 600
 

@@ -20,7 +20,8 @@ def _row_fields(orc, m):
 
 
 @pytest.mark.parametrize("name", ["rte_case5_example", "l2rpn_case14_sandbox", "educ_case14_storage", "test_case14",
-                                  "l2rpn_neurips_2020_track1", "l2rpn_wcci_2022_dev"])
+                                  "l2rpn_neurips_2020_track1", "l2rpn_wcci_2022_dev", "rte_case118_example", "l2rpn_wcci_2020",
+                                  "l2rpn_icaps_2021"])
 def test_c_oracle_equals_numpy_oracle(name, load_model):
     m = load_model(name)
     orc = COracle(m)

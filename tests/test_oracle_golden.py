@@ -9,7 +9,8 @@ import pytest
 
 from oracle.pf_oracle import LaneState, solve
 
-FULL_GOLDEN = ["rte_case5_example", "l2rpn_neurips_2020_track1", "l2rpn_wcci_2022_dev", "l2rpn_2019"]
+FULL_GOLDEN = ["rte_case5_example", "l2rpn_neurips_2020_track1", "l2rpn_wcci_2022_dev", "l2rpn_2019", "l2rpn_wcci_2020",
+               "l2rpn_icaps_2021"]
 
 
 @pytest.mark.parametrize("name", FULL_GOLDEN)
@@ -49,11 +50,13 @@ def test_ac_solution_matches_embedded_pandapower_results(name, load_model, load_
         assert abs(r.gen_q[-1] - g["ext_grid_q_mvar"][0]) < tol
 
 
-def test_branch_level_consistency_on_idf2023(load_model, load_npz):
-    """l2rpn_idf_2023/grid.json: the embedded results belong to another injection state (SURVEY.md
-    fact table) -> only check V -> branch flow consistency: impose the golden bus voltages."""
-    m = load_model("l2rpn_idf_2023")
-    g = load_npz("l2rpn_idf_2023.res.npz")
+@pytest.mark.parametrize("name", ["l2rpn_idf_2023", "rte_case118_example", "l2rpn_neurips_2020_track2_x1"])
+def test_branch_level_consistency_when_embedded_results_are_of_another_state(name, load_model, load_npz):
+    """l2rpn_idf_2023, rte_case118_example (IEEE 118) and l2rpn_neurips_2020_track2: the embedded results belong to another
+    injection state -> only check V -> branch flow consistency (line and transformer models):
+    impose the golden bus voltages."""
+    m = load_model(name)
+    g = load_npz(f"{name}.res.npz")
     V = g["bus_vm_pu"] * np.exp(1j * np.radians(g["bus_va_degree"]))
     f, t = m.line_or_sub, m.line_ex_sub
     Sf = V[f] * np.conj(m.br_yff * V[f] + m.br_yft * V[t]) * m.sn_mva
