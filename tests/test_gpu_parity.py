@@ -683,3 +683,59 @@ def test_lodf_screening_matches_brute_force_dc_n1(name, n, load_model, load_npz)
             assert np.allclose(w[k][ok], ref[ok], rtol=2e-5, atol=2e-4 if caps is None else 2e-6), (k, np.abs(w[k][ok] - ref[ok]).max())
     assert np.isinf(w).any() or name != "l2rpn_case14_sandbox"        # case14 has a radial generator bus: its line islands it
     eng.close()
+
+
+def test_device_cascade_reproduces_reference_next_grid_state_answers(load_model, load_npz):
+    """grid2op/tests/BaseBackendTest.py:1700-1800 (test_next_grid_state_multiple_iteration_no_cooldown / _cooldown) on
+    test_case14, through the DEVICE cascade of gpf_step: HARD_OVERFLOW_THRESHOLD = 1.5, thermal limits 30 x a_or except
+    line 10 (half its flow: trips in round 0), line 2 (18849.43 / 1.6: trips in round 1 after the flows moved) and line 0
+    (600 A: stays / 650 A with 2 steps of overflow already counted and 2 allowed: trips in round 1)."""
+    m = load_model("test_case14")
+    ka = load_npz("known_answers.npz")
+    a_or = ka["a_or_init"]
+    st = LaneState.from_model(m)
+    chron = dict(load_p=st.load_p[None].astype(np.float32), load_q=st.load_q[None].astype(np.float32),
+                 prod_p=st.gen_p[None].astype(np.float32),
+                 prod_v=(st.gen_vm * m.sub_vn_kv[m.gen_sub])[None].astype(np.float32))
+
+    def limits(l0):
+        th = 30.0 * a_or
+        th[0] = l0
+        th[10] = a_or[10] / 2.0
+        th[2] = 18849.43 / 1.6
+        return th.astype(np.float32)
+
+    # no cooldown: NB_TIMESTEP_OVERFLOW_ALLOWED = 1, counters at 0
+    eng = _engine(m, 3)
+    eng.upload_chronics(eng.pack_chronics(chron["load_p"], chron["load_q"], chron["prod_p"], chron["prod_v"]))
+    eng.set_lane_chronics(lane_offset=np.zeros(3, dtype=np.int32))
+    eng.set_thermal_limits(limits(600.0))
+    eng.step(0, cascade=True, hard_overflow=1.5, soft_overflow=1.0, nb_ts_allowed=1)
+    r = eng.results()
+    _, _, disco = eng.step_outputs()
+    assert r.converged.all()
+    for k in range(3):
+        assert disco[k, 10] == 0 and disco[k, 2] == 1 and disco[k, 0] == -1
+        assert r.a_or[k, 0] > 0.0 and abs(r.a_or[k, 10]) <= 1e-8 and abs(r.a_or[k, 2]) <= 1e-8
+    eng.close()
+
+    # cooldown: line 0 has already spent 2 steps on overflow (NB_TIMESTEP_OVERFLOW_ALLOWED = 2) -> trips in round 1
+    eng = _engine(m, 3)
+    eng.upload_chronics(eng.pack_chronics(chron["load_p"], chron["load_q"], chron["prod_p"], chron["prod_v"]))
+    eng.set_lane_chronics(lane_offset=np.zeros(3, dtype=np.int32))
+    pre = np.full(m.n_line, 1e9, dtype=np.float32)
+    pre[0] = 1.0                                   # two plain steps with line 0 above its (tiny) limit: counter[0] = 2
+    eng.set_thermal_limits(pre)
+    eng.step(0)
+    eng.step(0)
+    _, oc, _ = eng.step_outputs()
+    assert (oc[:, 0] == 2).all() and (oc[:, 1:] == 0).all()
+    eng.set_thermal_limits(limits(650.0))
+    eng.step(0, cascade=True, hard_overflow=1.5, soft_overflow=1.0, nb_ts_allowed=2)
+    r = eng.results()
+    _, _, disco = eng.step_outputs()
+    assert r.converged.all()
+    for k in range(3):
+        assert disco[k, 10] == 0 and disco[k, 2] == 1 and disco[k, 0] == 1
+        assert abs(r.a_or[k, 0]) <= 1e-8
+    eng.close()
