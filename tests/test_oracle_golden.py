@@ -164,3 +164,16 @@ def test_runner_trajectories_recorded_with_pandapower_backend(load_model, load_n
             n_rows += 1
             n_split += int((topo == 2).any())
     assert n_rows >= 15 and n_split >= 5
+
+
+@pytest.mark.parametrize("name,sizes", [
+    ("l2rpn_neurips_2020_track1", (36, 59, 37, 22, 0)), ("l2rpn_icaps_2021", (36, 59, 37, 22, 0)),
+    ("l2rpn_neurips_2020_track2_x1", (118, 186, 99, 62, 0)), ("l2rpn_case14_sandbox", (14, 20, 11, 6, 0)),
+    ("educ_case14_redisp", (14, 20, 11, 6, 0)), ("educ_case14_storage", (14, 20, 11, 6, 2)),
+    ("l2rpn_wcci_2022_dev", (118, 186, 91, 62, 7)), ("l2rpn_idf_2023", (118, 186, 99, 62, 7))])
+def test_grid_sizes_asserted_by_the_reference(name, sizes, load_model):
+    """grid2op/tests/test_attached_envs.py:30-50, 76-80, 125-129, 169-173, 260-264, 305-309, 350-354, 398-402:
+    (n_sub, n_line, n_load, n_gen, n_storage) of the attached environments, exact."""
+    m = load_model(name)
+    assert (m.n_sub, m.n_line, m.n_load, m.n_gen, m.n_storage) == sizes
+    assert m.dim_topo == 2 * m.n_line + m.n_gen + m.n_load + m.n_storage
