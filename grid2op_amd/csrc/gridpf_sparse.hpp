@@ -317,6 +317,10 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
   constexpr int CHB = (GW / B2) * B2;      // U-block items per chunk: whole blocks only
   constexpr int CHR = (GW / BS) * BS;
   bool ok = true;
+  // 2x2 blocks are stored SPLIT BY ROW: row 0 of every block in [0, HS_), row 1 of every block behind.  A b128 read of one
+  // row of 8 different blocks then spans 8 distinct bank groups instead of 4 (blocks of 32 contiguous bytes put every
+  // row-0 read on the even 16-byte positions): -13 % on the case14 solve, measured with tools/lu_bench.
+  const size_t HS_ = (size_t)S.nslot * 2;
   if (BS == 2) {
     // 2x2 blocks: ONE phase per level.  The pivot inverse is recomputed by every item from the (never overwritten)
     // diagonal block, A[dst] -= A[l] * inv(D_p) * A[u] and rhs[row] -= A[l] * inv(D_p) * b_p; the scaling
@@ -326,6 +330,9 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
     // c-items in the program), and the level header / the first item words of the NEXT levels are prefetched while the
     // current level computes.  Per level: operand reads -> ~10 dependent f64 ops -> ds_add_f64 -> barrier.
     const int n_levels = S.n_levels;
+#define R0_(slot) (A + (size_t)(slot) * 2)
+#define R1_(slot) (A + HS_ + (size_t)(slot) * 2)
+#define LD2_(ptr) (*reinterpret_cast<const double2*>(ptr))
     auto hdr4 = [&](int k) -> int4 { return make_int4(prog[4 * k], prog[4 * k + 1], prog[4 * k + 2], prog[4 * k + 3]); };   // level lv: hdr4(2 * lv + 1) = {c_off, n_c, r_off, n_r}
     auto item_words = [&](const int4& h, int o, unsigned& w0, unsigned& w1) {
       const bool on = o < h.y + h.w;
@@ -337,23 +344,22 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
       const bool is_c = o < h.y;
       const unsigned l = is_c ? (w0 >> 16) : (w0 & 0xffffu), dd = is_c ? (w0 & 0xffffu) : (w0 >> 16);
       const unsigned p = is_c ? (w1 >> 16) : w1, u = w1 & 0xffffu;
-      const double2* D = reinterpret_cast<const double2*>(A + (size_t)p * 4);
-      const double2* Al = reinterpret_cast<const double2*>(A + (size_t)l * 4);
-      const double2* U = is_c ? reinterpret_cast<const double2*>(A + (size_t)u * 4) : reinterpret_cast<const double2*>(rhs + (size_t)p * 2);
-      const double2 dA = D[0], dB = D[1], lA = Al[0], lB = Al[1], uA = U[0];
+      const double2 dA = LD2_(R0_(p)), dB = LD2_(R1_(p)), lA = LD2_(R0_(l)), lB = LD2_(R1_(l));
+      const double2 uA = is_c ? LD2_(R0_(u)) : LD2_(rhs + (size_t)p * 2);
       double2 uB = make_double2(uA.y, 0.0);                       // r-item: the operand is the column vector b_p
-      if (is_c) uB = U[1];
+      if (is_c) uB = LD2_(R1_(u));
       const double rd = -fast_rcp(fma(dA.x, dB.y, -dA.y * dB.x));
       // T = A_l * adj(D)
       const double t00 = fma(lA.x, dB.y, -lA.y * dB.x), t01 = fma(lA.y, dA.x, -lA.x * dA.y);
       const double t10 = fma(lB.x, dB.y, -lB.y * dB.x), t11 = fma(lB.y, dA.x, -lB.x * dA.y);
       const double x0 = fma(t00, uA.x, t01 * uB.x) * rd, x1 = fma(t10, uA.x, t11 * uB.x) * rd;
       if (is_c) {
-        double* dst = A + (size_t)dd * 4;
-        atomicAdd(&dst[0], x0);
-        atomicAdd(&dst[2], x1);
-        atomicAdd(&dst[1], fma(t00, uA.y, t01 * uB.y) * rd);
-        atomicAdd(&dst[3], fma(t10, uA.y, t11 * uB.y) * rd);
+        double* d0_ = R0_(dd);
+        double* d1_ = R1_(dd);
+        atomicAdd(&d0_[0], x0);
+        atomicAdd(&d1_[0], x1);
+        atomicAdd(&d0_[1], fma(t00, uA.y, t01 * uB.y) * rd);
+        atomicAdd(&d1_[1], fma(t10, uA.y, t11 * uB.y) * rd);
       } else {
         double* dst = rhs + (size_t)dd * 2;
         atomicAdd(&dst[0], x0);
@@ -379,16 +385,14 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
     // deferred scaling (one item per U block / per pivot: no read-write overlap between items)
     for (int e = tid; e < S.n_scale; e += GW) {
       const unsigned w = (unsigned)prog[S.scale_off + e];
-      const double2* D = reinterpret_cast<const double2*>(A + (size_t)(w >> 16) * 4);
-      double2* Au = reinterpret_cast<double2*>(A + (size_t)(w & 0xffffu) * 4);
-      const double2 dA = D[0], dB = D[1], uA = Au[0], uB = Au[1];
+      const double2 dA = LD2_(R0_(w >> 16)), dB = LD2_(R1_(w >> 16)), uA = LD2_(R0_(w & 0xffffu)), uB = LD2_(R1_(w & 0xffffu));
       const double rd = fast_rcp(fma(dA.x, dB.y, -dA.y * dB.x));
-      Au[0] = make_double2(fma(dB.y, uA.x, -dA.y * uB.x) * rd, fma(dB.y, uA.y, -dA.y * uB.y) * rd);
-      Au[1] = make_double2(fma(dA.x, uB.x, -dB.x * uA.x) * rd, fma(dA.x, uB.y, -dB.x * uA.y) * rd);
+      *reinterpret_cast<double2*>(R0_(w & 0xffffu)) = make_double2(fma(dB.y, uA.x, -dA.y * uB.x) * rd, fma(dB.y, uA.y, -dA.y * uB.y) * rd);
+      *reinterpret_cast<double2*>(R1_(w & 0xffffu)) = make_double2(fma(dA.x, uB.x, -dB.x * uA.x) * rd, fma(dA.x, uB.y, -dB.x * uA.y) * rd);
     }
     for (int p = tid; p < S.n; p += GW) {
-      const double* D = A + (size_t)p * 4;
-      const double d0 = D[0], d1 = D[1], d2 = D[2], d3 = D[3], b0 = rhs[(size_t)p * 2], b1 = rhs[(size_t)p * 2 + 1];
+      const double2 dA_ = LD2_(R0_(p)), dB_ = LD2_(R1_(p));
+      const double d0 = dA_.x, d1 = dA_.y, d2 = dB_.x, d3 = dB_.y, b0 = rhs[(size_t)p * 2], b1 = rhs[(size_t)p * 2 + 1];
       const double det = fma(d0, d3, -d1 * d2);
       if (!(fabs(det) > 1e-300) || !(fabs(det) < 1e300)) ok = false;
       const double rd = fast_rcp(det);
@@ -516,8 +520,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
     };
     auto item = [&](const int2& h, int o, unsigned w, int p) {
       if (o >= h.y) return;
-      const double2* U = reinterpret_cast<const double2*>(A + (size_t)(w & 0xffffu) * 4);
-      const double2 uA = U[0], uB = U[1], xj = *reinterpret_cast<const double2*>(rhs + (size_t)(w >> 16) * 2);
+      const double2 uA = LD2_(R0_(w & 0xffffu)), uB = LD2_(R1_(w & 0xffffu)), xj = LD2_(rhs + (size_t)(w >> 16) * 2);
       atomicAdd(&rhs[(size_t)p * 2], -fma(uA.x, xj.x, uA.y * xj.y));
       atomicAdd(&rhs[(size_t)p * 2 + 1], -fma(uB.x, xj.x, uB.y * xj.y));
     };
@@ -558,8 +561,8 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
   return ok;
 }
 
-// Scalar variant for the DC system of the NB == 1 layout: B' theta = P only couples the theta entries, i.e. element [0] of
-// every 2x2 block and rhs[2p] (the |V| rows are identity), so the same program is run on scalars: a quarter of the LDS
+// Scalar variant for the DC system of the NB == 1 layout: B' theta = P only couples the theta entries, i.e. element [0][0] of
+// every 2x2 block (A[2 * slot] in the split-row layout of block_lu_solve) and rhs[2p] (the |V| rows are identity), so the same program is run on scalars: a quarter of the LDS
 // traffic and a fraction of the arithmetic of the block solve.
 template <int GW, class PP = const int*>
 __device__ inline bool scalar_lu_solve(const SymDev& S, PP prog, double* __restrict__ A,
@@ -579,9 +582,9 @@ __device__ inline bool scalar_lu_solve(const SymDev& S, PP prog, double* __restr
     const bool is_c = o < h.y;
     const unsigned l = is_c ? (w0 >> 16) : (w0 & 0xffffu), dd = is_c ? (w0 & 0xffffu) : (w0 >> 16);
     const unsigned p = is_c ? (w1 >> 16) : w1, u = w1 & 0xffffu;
-    const double d = A[(size_t)p * 4], al = A[(size_t)l * 4];
-    const double x = is_c ? A[(size_t)u * 4] : rhs[(size_t)p * 2];
-    double* dst = is_c ? (A + (size_t)dd * 4) : (rhs + (size_t)dd * 2);
+    const double d = A[(size_t)p * 2], al = A[(size_t)l * 2];
+    const double x = is_c ? A[(size_t)u * 2] : rhs[(size_t)p * 2];
+    double* dst = is_c ? (A + (size_t)dd * 2) : (rhs + (size_t)dd * 2);
     atomicAdd(dst, -(al * x) * fast_rcp(d));
   };
   int4 h0 = hdr4(1), h1 = n_levels > 1 ? hdr4(3) : make_int4(0, 0, 0, 0);
@@ -602,11 +605,11 @@ __device__ inline bool scalar_lu_solve(const SymDev& S, PP prog, double* __restr
   }
   for (int e = tid; e < S.n_scale; e += GW) {
     const unsigned w = (unsigned)prog[S.scale_off + e];
-    double* au = A + (size_t)(w & 0xffffu) * 4;
-    *au = *au * fast_rcp(A[(size_t)(w >> 16) * 4]);
+    double* au = A + (size_t)(w & 0xffffu) * 2;
+    *au = *au * fast_rcp(A[(size_t)(w >> 16) * 2]);
   }
   for (int p = tid; p < S.n; p += GW) {
-    const double d = A[(size_t)p * 4];
+    const double d = A[(size_t)p * 2];
     if (!(fabs(d) > 1e-300) || !(fabs(d) < 1e300)) ok = false;
     rhs[(size_t)p * 2] *= fast_rcp(d);
   }
@@ -622,7 +625,7 @@ __device__ inline bool scalar_lu_solve(const SymDev& S, PP prog, double* __restr
     };
     auto item = [&](const int2& h, int o, unsigned w, int p) {
       if (o >= h.y) return;
-      atomicAdd(&rhs[(size_t)p * 2], -A[(size_t)(w & 0xffffu) * 4] * rhs[(size_t)(w >> 16) * 2]);
+      atomicAdd(&rhs[(size_t)p * 2], -A[(size_t)(w & 0xffffu) * 2] * rhs[(size_t)(w >> 16) * 2]);
     };
     int2 g0 = hdr(S.back_first), g1 = hdr(S.back_first - 1);
     unsigned w; int p;
@@ -663,6 +666,11 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   const OutOff& oo = P->oo;
   const int nsub = g.n_sub;
   const int nbus = TC ? S.n : nsub * NB;               // block rows x NB: substations, or the nodes of the topology class
+  // element (r, col) of block `slot`: 2x2 blocks are stored split by row (see block_lu_solve), larger blocks contiguously
+  const size_t HS = (size_t)S.nslot * 2;
+  auto bel = [&](int slot, int r, int col) -> double* {
+    return BS == 2 ? c.A + (size_t)r * HS + (size_t)slot * 2 + col : c.A + (size_t)slot * B2 + r * BS + col;
+  };
   const auto topo_g = gptr(b.topo) + (size_t)inst * g.dim_topo;            // lane rows in HBM: explicit global address space
   const auto shb = gptr(b.shunt_bus) + (size_t)inst * g.n_shunt;
   const auto lstat = gptr(b.line_status) + (size_t)inst * g.n_line;
@@ -822,11 +830,11 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       const double bb = sv.br_bdc[l];
       const bool ff_ = c.btype[f] != BT_REF, tf_ = c.btype[t] != BT_REF;     // theta row / column live?
       const int rf = 2 * bi, rt = 2 * bj;
-      if (ff_) atomicAdd(&c.A[(size_t)sff * B2 + rf * BS + rf], bb);
-      if (tf_) atomicAdd(&c.A[(size_t)stt * B2 + rt * BS + rt], bb);
+      if (ff_) atomicAdd(bel(sff, rf, rf), bb);
+      if (tf_) atomicAdd(bel(stt, rt, rt), bb);
       if (ff_ && tf_) {
-        atomicAdd(&c.A[(size_t)sft * B2 + rf * BS + rt], -bb);
-        atomicAdd(&c.A[(size_t)stf * B2 + rt * BS + rf], -bb);
+        atomicAdd(bel(sft, rf, rt), -bb);
+        atomicAdd(bel(stf, rt, rf), -bb);
       }
     }
   }
@@ -848,10 +856,9 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   for (int i = tid; i < nbus; i += GW) {
     const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
     const int bt = c.btype[i];
-    double* Ad = c.A + (size_t)sub * B2;
     const bool th_live = (bt == BT_PQ || bt == BT_PV);
-    if (!th_live) Ad[(2 * bi) * BS + 2 * bi] = 1.0;
-    Ad[(2 * bi + 1) * BS + 2 * bi + 1] = 1.0;                    // |V| rows are identity in the DC system
+    if (!th_live) *bel(sub, 2 * bi, 2 * bi) = 1.0;
+    *bel(sub, 2 * bi + 1, 2 * bi + 1) = 1.0;                     // |V| rows are identity in the DC system
     c.rhs[(size_t)sub * BS + 2 * bi] = th_live ? (c.Psp[i] - c.Gs[i]) : 0.0;
     c.rhs[(size_t)sub * BS + 2 * bi + 1] = 0.0;
   }
@@ -903,7 +910,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       c.Sre[i] = 0.0;
       c.Sim[i] = 0.0;
     }
-    for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;     // fill blocks start at zero
+    if (BS == 2) { for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; } }
+    else for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;     // fill blocks start at zero
     GPF_SYNC();
     GPF_STAMPS(10);
     while (true) {
@@ -924,10 +932,9 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         const bool rowP = (bti == BT_PQ || bti == BT_PV), rowQ = (bti == BT_PQ);
         const bool colT = (btj == BT_PQ || btj == BT_PV), colV = (btj == BT_PQ);
         const double ivmj = fast_rcp(vmj);
-        double* Ab = c.A + (size_t)slot * B2 + (2 * bi) * BS + 2 * bj;
         // [dP/dth dP/dV; dQ/dth dQ/dV] = [Im T, Re T/|Vj|; -Re T, Im T/|Vj|]  (diagonal S-terms are added below)
-        *reinterpret_cast<double2*>(Ab) = make_double2((rowP && colT) ? ti_ : 0.0, (rowP && colV) ? tr_ * ivmj : 0.0);
-        *reinterpret_cast<double2*>(Ab + BS) = make_double2((rowQ && colT) ? -tr_ : 0.0, (rowQ && colV) ? ti_ * ivmj : 0.0);
+        *reinterpret_cast<double2*>(bel(slot, 2 * bi, 2 * bj)) = make_double2((rowP && colT) ? ti_ : 0.0, (rowP && colV) ? tr_ * ivmj : 0.0);
+        *reinterpret_cast<double2*>(bel(slot, 2 * bi + 1, 2 * bj)) = make_double2((rowQ && colT) ? -tr_ : 0.0, (rowQ && colV) ? ti_ * ivmj : 0.0);
         if (act && (yr != 0.0 || yi != 0.0)) { atomicAdd(&c.Sre[i], tr_); atomicAdd(&c.Sim[i], ti_); }
       }
       GPF_SYNC();
@@ -936,15 +943,16 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       bool bad = false;
       for (int i = tid; i < nbus; i += GW) {
         const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
-        double* Ad = c.A + (size_t)sub * B2 + (2 * bi) * BS + 2 * bi;
+        double* Ad0 = bel(sub, 2 * bi, 2 * bi);
+        double* Ad1 = bel(sub, 2 * bi + 1, 2 * bi);
         const int bt = c.btype[i];
         const double Sr = c.Sre[i], Si = c.Sim[i], vmi = c.vm[i], psp = c.Psp[i], qsp = c.Qsp[i];
-        const double2 r0 = *reinterpret_cast<const double2*>(Ad), r1 = *reinterpret_cast<const double2*>(Ad + BS);
+        const double2 r0 = *reinterpret_cast<const double2*>(Ad0), r1 = *reinterpret_cast<const double2*>(Ad1);
         const bool rowP = (bt == BT_PQ || bt == BT_PV), rowQ = (bt == BT_PQ);
         const double ivmi = fast_rcp(vmi);
         // dS/dVa_ii += j S_i ; dS/dVm_ii += S_i / |V_i| ; identity on the fixed variables
-        *reinterpret_cast<double2*>(Ad) = make_double2(rowP ? r0.x - Si : 1.0, rowQ ? fma(Sr, ivmi, r0.y) : r0.y);
-        *reinterpret_cast<double2*>(Ad + BS) = make_double2(rowQ ? r1.x + Sr : r1.x, rowQ ? fma(Si, ivmi, r1.y) : 1.0);
+        *reinterpret_cast<double2*>(Ad0) = make_double2(rowP ? r0.x - Si : 1.0, rowQ ? fma(Sr, ivmi, r0.y) : r0.y);
+        *reinterpret_cast<double2*>(Ad1) = make_double2(rowQ ? r1.x + Sr : r1.x, rowQ ? fma(Si, ivmi, r1.y) : 1.0);
         const double mp = rowP ? (Sr - psp) : 0.0;
         const double mq = rowQ ? (Si - qsp) : 0.0;
         *reinterpret_cast<double2*>(c.rhs + (size_t)sub * BS + 2 * bi) = make_double2(-mp, -mq);
@@ -987,7 +995,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         c.Sre[i] = 0.0;
         c.Sim[i] = 0.0;
       }
-      for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
+      if (BS == 2) { for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; } }
+    else for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
       GPF_SYNC();
       if (!done && (G::any(!ok) || G::any(!fin))) { status = 4; done = true; }
       if (it == 1) GPF_STAMPS(14);

@@ -34,7 +34,8 @@ __global__ __launch_bounds__(64, 4) void lu_kernel(SymDev S, const double* __res
   bool ok = true;
   const long long t0 = __builtin_readcyclecounter();
   for (int r = 0; r < reps; ++r) {
-    for (int i = t; i < S.nslot * B2; i += GW) A[i] = Ap[i];
+    // 2x2 blocks are stored split by row (block_lu_solve): row 0 of every block first, row 1 behind
+    for (int i = t; i < S.nslot * B2; i += GW) { const int slot = i / B2, e = i % B2; A[(e / BS) * S.nslot * BS + slot * BS + (e % BS)] = Ap[i]; }
     for (int i = t; i < S.n * BS; i += GW) rhs[i] = bp[i];
     __syncthreads();
     if (do_solve) ok &= block_lu_solve<BS, GW>(S, prog, A, rhs, t);
