@@ -228,10 +228,7 @@ def main():
             "frac_converged": frac_conv,
             "mean_nr_iterations": mean_iter,
         }
-        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is timed on rank 0 of the 1-GPU run only
-            res["cpu_baseline"] = cpu_baseline(m, ch, T)
-        else:
-            res["cpu_baseline"] = None
+        res["cpu_baseline"] = None
     # ---- same workload with topology actions: 10 % of the lanes with a split substation (topology classes) --------
     split = None
     if not args.no_secondary and args.env == "l2rpn_case14_sandbox" and not args.n1:
@@ -368,6 +365,10 @@ def main():
                     "max_abs_dc_vs_ac_p_or_mw": float(np.abs(flows - r3ac.p_or)[r3ac.converged].max())}
         eng3.close()
     if rank == 0:
+        # the CPU baseline is timed LAST (rank 0 of the 1-GPU run only): 12 s of host-only work in the middle of the run would
+        # let the GPU clocks drop before the secondary workloads
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(m, ch, T)
         res["secondary"] = sec
         res["dc_ptdf"] = ptdf
         res["split_topologies"] = split
