@@ -87,6 +87,11 @@ def measured_traffic_bytes():
 
 def run_workload(eng, steps, warmup, step_kw, sync_all):
     t = 0
+    # untimed pre-roll before the W warm-up steps: an idle MI355X needs tens of milliseconds of work to reach its clocks
+    # (measured: 2.7x slower steps right after a 12 s host-only phase with a 12-step warm-up)
+    for _ in range(max(0, 400 - warmup)):
+        eng.step(t, **step_kw)
+        t += 1
     for _ in range(warmup):
         eng.step(t, **step_kw)
         t += 1
