@@ -576,7 +576,15 @@ bool check_range(gpf_engine* e, int lane0, int n) { return e && lane0 >= 0 && n 
 extern "C" {
 
 const char* gpf_last_error(void) { return g_err.c_str(); }
-int gpf_version(void) { return 100; }
+int gpf_version(void) { return 200; }
+
+int gpf_device_count(int32_t* n_devices) {
+  if (!n_devices) return fail(GPF_E_INVALID, "gpf_device_count: null");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+  *n_devices = n;
+  return GPF_OK;
+}
 
 int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_handle* out_h) {
   if (!d || !out_h || n_lanes <= 0) return fail(GPF_E_INVALID, "gpf_create: bad arguments");

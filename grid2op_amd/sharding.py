@@ -10,7 +10,7 @@ from typing import Tuple
 
 import numpy as np
 
-__all__ = ["lane_range", "synthetic_lane_inputs", "max_over_ranks", "sum_over_ranks"]
+__all__ = ["lane_range", "synthetic_lane_inputs", "max_over_ranks", "sum_over_ranks", "visible_devices", "ShardedEngine"]
 
 
 def lane_range(total_lanes: int, world: int, rank: int) -> Tuple[int, int]:
@@ -52,3 +52,135 @@ def sum_over_ranks(value: float, dist=None, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def visible_devices() -> int:
+    """Number of HIP devices this process sees (``gpf_device_count``; raises when the library is not built)."""
+    import ctypes as C
+    from . import _capi
+    n = C.c_int32(0)
+    _capi.check(_capi.lib().gpf_device_count(C.byref(n)), "gpf_device_count")
+    return int(n.value)
+
+
+class ShardedEngine:
+    """Single-process multi-GPU engine: one `PowerFlowEngine` (own HIP stream) per device, the global lane batch cut
+    into the contiguous blocks of `lane_range`.  Lanes never communicate, so there is no cross-device operation: every
+    call is forwarded to the engines that own the addressed lanes (asynchronous calls stay asynchronous, i.e. one host
+    thread keeps all the devices busy) and results are concatenated in global lane order.
+
+    Counterpart in the reference: its only parallelism is one process per environment -- ``Runner._run_parrallel``
+    (grid2op/Runner/runner.py:1071-1253, a ``multiprocessing.Pool`` over episodes) and ``BaseMultiProcessEnvironment``
+    (grid2op/Environment/baseMultiProcessEnv.py:22, 293, one worker process per environment copy).  ``bench.py``
+    uses the other form (one PROCESS per GPU, `lane_range` of the global batch per rank)."""
+
+    def __init__(self, model, n_lanes: int, devices=None, n_busbar: int = 2, engine_factory=None):
+        if devices is None:
+            devices = list(range(visible_devices()))
+        devices = [int(d) for d in devices]
+        if not devices:
+            raise RuntimeError("ShardedEngine: no HIP device visible (there is no CPU fallback)")
+        if n_lanes < len(devices):
+            raise ValueError("ShardedEngine: fewer lanes than devices")
+        if engine_factory is None:
+            from .engine import PowerFlowEngine
+            engine_factory = lambda m, n, dev, nbb: PowerFlowEngine(m, n_lanes=n, device=dev, n_busbar=nbb)  # noqa: E731
+        self.model = model
+        self.n_lanes = int(n_lanes)
+        self.devices = devices
+        self.blocks = [lane_range(self.n_lanes, len(devices), r) for r in range(len(devices))]
+        self.engines = [engine_factory(model, n, dev, n_busbar) for dev, (_, n) in zip(devices, self.blocks)]
+        e0 = self.engines[0]
+        for k in ("n_inj", "n_out", "n_chron", "nb_total", "layout", "out_slices", "inj_slices", "init_inj"):
+            if hasattr(e0, k):
+                setattr(self, k, getattr(e0, k))
+
+    # ---- routing ------------------------------------------------------------------------------------------------------
+    def _parts(self, lane0: int = 0, n=None):
+        """(engine, local lane0, count, offset into the caller's rows) of the shards that intersect [lane0, lane0+n)."""
+        if n is None:
+            n = self.n_lanes - lane0
+        if lane0 < 0 or n < 0 or lane0 + n > self.n_lanes:
+            raise ValueError("ShardedEngine: lane range out of bounds")
+        out = []
+        for eng, (b0, bn) in zip(self.engines, self.blocks):
+            a, b = max(lane0, b0), min(lane0 + n, b0 + bn)
+            if a < b:
+                out.append((eng, a - b0, b - a, a - lane0))
+        return out
+
+    def owner(self, lane: int):
+        (eng, l0, _, _), = self._parts(lane, 1)
+        return eng, l0
+
+    # ---- state ----------------------------------------------------------------------------------------------------------
+    def pack_injections(self, n: int = 1, **fields):
+        return self.engines[0].pack_injections(n, **fields)
+
+    def pack_chronics(self, *a):
+        return self.engines[0].pack_chronics(*a)
+
+    def set_injections(self, inj, lane0: int = 0):
+        inj = np.asarray(inj).reshape(-1, self.n_inj)
+        for eng, l0, n, off in self._parts(lane0, inj.shape[0]):
+            eng.set_injections(inj[off:off + n], lane0=l0)
+
+    def get_injections(self, lane0: int = 0, n=None):
+        return np.concatenate([eng.get_injections(l0, k) for eng, l0, k, _ in self._parts(lane0, n)])
+
+    def set_topology(self, topo, shunt_bus=None, lane0: int = 0):
+        topo = np.asarray(topo).reshape(-1, self.model.dim_topo)
+        sb = None if shunt_bus is None or not self.model.n_shunt else np.asarray(shunt_bus).reshape(-1, self.model.n_shunt)
+        for eng, l0, n, off in self._parts(lane0, topo.shape[0]):
+            eng.set_topology(topo[off:off + n], None if sb is None else sb[off:off + n], lane0=l0)
+
+    def reset(self, lane0: int = 0, n=None):
+        for eng, l0, k, _ in self._parts(lane0, n):
+            eng.reset(l0, k)
+
+    def disconnect_line(self, lane: int, line_id: int):
+        eng, l0 = self.owner(lane)
+        eng.disconnect_line(l0, line_id)
+
+    def upload_chronics(self, tables):
+        for eng in self.engines:                     # every device holds its own copy of the (small) tables
+            eng.upload_chronics(tables)
+        self.chron_T = self.engines[0].chron_T
+
+    def set_lane_chronics(self, lane_table=None, lane_offset=None, lane_scale=None):
+        for eng, (b0, bn) in zip(self.engines, self.blocks):
+            cut = lambda a: None if a is None else np.asarray(a)[b0:b0 + bn]  # noqa: E731
+            eng.set_lane_chronics(cut(lane_table), cut(lane_offset), cut(lane_scale))
+
+    def set_thermal_limits(self, limit_a):
+        for eng in self.engines:
+            eng.set_thermal_limits(limit_a)
+
+    # ---- solve (asynchronous: queued on every device's stream) ----------------------------------------------------------------
+    def runpf(self, lane0: int = 0, n=None, **kw):
+        for eng, l0, k, _ in self._parts(lane0, n):
+            eng.runpf(l0, k, **kw)
+
+    def step(self, t: int, **kw):
+        for eng in self.engines:
+            eng.step(t, **kw)
+
+    def sync(self):
+        for eng in self.engines:
+            eng.sync()
+
+    def results(self, lane0: int = 0, n=None, with_bus: bool = True):
+        from .engine import LaneResults
+        rs = [eng.results(l0, k, with_bus=with_bus) for eng, l0, k, _ in self._parts(lane0, n)]
+        cat = lambda f: None if getattr(rs[0], f) is None else np.concatenate([getattr(r, f) for r in rs])  # noqa: E731
+        return LaneResults(out=cat("out"), topo_vect=cat("topo_vect"), shunt_bus=cat("shunt_bus"), line_status=cat("line_status"),
+                           status=cat("status"), bus_vm=cat("bus_vm"), bus_va=cat("bus_va"), _slices=rs[0]._slices)
+
+    def step_outputs(self, lane0: int = 0, n=None):
+        parts = [eng.step_outputs(l0, k) for eng, l0, k, _ in self._parts(lane0, n)]
+        return tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
+
+    def close(self):
+        for eng in self.engines:
+            eng.close()
+        self.engines = []

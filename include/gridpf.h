@@ -94,6 +94,10 @@ typedef struct gpf_layout {
 
 const char* gpf_last_error(void);
 int gpf_version(void);
+/* Number of HIP devices visible to this process (0 and GPF_OK when there is none): what a single-process caller
+ * shards its lane batch over (grid2op_amd/sharding.py ShardedEngine; the reference's own parallelism is one process per
+ * environment, Runner/runner.py:1071-1253, Environment/baseMultiProcessEnv.py:293). */
+int gpf_device_count(int32_t* n_devices);
 
 /* load_grid (pandaPowerBackend.py:356): build an engine with `n_lanes` lanes on HIP device `device`.
  * Every lane starts in the pristine state. */

@@ -135,3 +135,51 @@ def time_steps(m, ch, T, budget_s=12.0, chunk=512):
         n_total += chunk
         k0 += chunk
     return n_total, spent
+
+
+def _all_cores_worker(args):
+    """One process of `time_steps_all_cores`: worker `w` of `n` solves lanes w, w+n, w+2n, ... of the same global batch."""
+    grid_npz, chron_npz, w, n_workers, budget_s, start_at = args
+    import sys
+    root = os.path.dirname(_HERE)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from grid2op_amd.grid_model import GridModel
+    m = GridModel.load_npz(grid_npz)
+    ch = dict(np.load(chron_npz))
+    if "prod_v" not in ch:
+        ch["prod_v"] = np.tile((m.gen_vm0 * m.sub_vn_kv[m.gen_sub]).astype(np.float32), (ch["prod_p"].shape[0], 1))
+    T = ch["load_p"].shape[0]
+    orc = COracle(m)
+    tab = np.ascontiguousarray(np.concatenate([ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"]], axis=-1), np.float32)
+    chunk = 128
+    while time.time() < start_at:            # common start (the slowest interpreter start-up is not part of the sample)
+        time.sleep(0.005)
+    t_begin = time.time()
+    n_total, k0 = 0, 0
+    while time.time() - t_begin < budget_s:
+        lanes = w + n_workers * np.arange(k0, k0 + chunk)
+        off = (7 * lanes) % T
+        sc = np.empty((chunk, 2 * m.n_load), np.float32)
+        for i, k in enumerate(lanes):
+            sc[i] = 1.0 + 0.05 * np.random.default_rng(int(k)).standard_normal(2 * m.n_load)
+        orc.step_batch(tab, off, sc, 1.02, 0, 0, chunk)
+        n_total += chunk
+        k0 += chunk
+    return n_total, t_begin, time.time()
+
+
+def time_steps_all_cores(grid_npz, chron_npz, n_workers, budget_s=10.0, startup_s=None):
+    """bench.py cpu_baseline leg, all host cores: `n_workers` single-thread processes (spawned -- the parent has initialised
+    HIP, which must not be forked) split the lanes of the same synthetic workload between them.  Returns (lane-steps,
+    wall seconds from the common start to the last worker's end); the jitter generation IS inside this wall time."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    if startup_s is None:
+        startup_s = 4.0 + 0.03 * n_workers
+    start_at = time.time() + startup_s
+    with ProcessPoolExecutor(max_workers=n_workers, mp_context=mp.get_context("spawn")) as ex:
+        rs = list(ex.map(_all_cores_worker, [(grid_npz, chron_npz, w, n_workers, budget_s, start_at) for w in range(n_workers)]))
+    total = sum(r[0] for r in rs)
+    wall = max(r[2] for r in rs) - min(r[1] for r in rs)
+    return total, wall
