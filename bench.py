@@ -94,8 +94,8 @@ def cpu_baseline(env_name, m, ch, T, budget_s=10.0):
         tot, wall = pf_oracle_c.time_steps_all_cores(os.path.join(GOLD, f"{env_name}.grid.npz"),
                                                      os.path.join(GOLD, f"{env_name}.chronics.npz"), ncores, budget_s)
         res["all_cores"] = {"value": tot / wall, "unit": "env steps/sec", "cores": ncores,
-                            "sample": f"{tot} lane-steps by {ncores} processes (one per host core, lanes split between them) in "
-                                      f"{wall:.1f} s of wall time incl. their start-up barrier; total {time.perf_counter() - t0:.1f} s"}
+                            "sample": f"{tot} lane-steps by {ncores} processes (one per host core, 256 lanes each, stepped through t = 0, 1, ...) in "
+                                      f"{wall:.1f} s of wall time after their common start; total {time.perf_counter() - t0:.1f} s"}
     return res
 
 

@@ -152,34 +152,50 @@ def _all_cores_worker(args):
     T = ch["load_p"].shape[0]
     orc = COracle(m)
     tab = np.ascontiguousarray(np.concatenate([ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"]], axis=-1), np.float32)
-    chunk = 128
-    while time.time() < start_at:            # common start (the slowest interpreter start-up is not part of the sample)
+    chunk = 256                              # this worker's lanes: w, w + n, w + 2n, ... stepped through t = 0, 1, 2, ...
+    lanes = w + n_workers * np.arange(chunk)
+    off = (7 * lanes) % T
+    sc = np.empty((chunk, 2 * m.n_load), np.float32)
+    for i, k in enumerate(lanes):
+        sc[i] = 1.0 + 0.05 * np.random.default_rng(int(k)).standard_normal(2 * m.n_load)
+    while time.time() < start_at:            # common start (interpreter start-up / input generation are not part of the sample)
         time.sleep(0.005)
     t_begin = time.time()
-    n_total, k0 = 0, 0
+    n_total, t = 0, 0
     while time.time() - t_begin < budget_s:
-        lanes = w + n_workers * np.arange(k0, k0 + chunk)
-        off = (7 * lanes) % T
-        sc = np.empty((chunk, 2 * m.n_load), np.float32)
-        for i, k in enumerate(lanes):
-            sc[i] = 1.0 + 0.05 * np.random.default_rng(int(k)).standard_normal(2 * m.n_load)
-        orc.step_batch(tab, off, sc, 1.02, 0, 0, chunk)
+        orc.step_batch(tab, off, sc, 1.02, t, 0, chunk)
         n_total += chunk
-        k0 += chunk
+        t += 1
     return n_total, t_begin, time.time()
 
 
 def time_steps_all_cores(grid_npz, chron_npz, n_workers, budget_s=10.0, startup_s=None):
-    """bench.py cpu_baseline leg, all host cores: `n_workers` single-thread processes (spawned -- the parent has initialised
-    HIP, which must not be forked) split the lanes of the same synthetic workload between them.  Returns (lane-steps,
-    wall seconds from the common start to the last worker's end); the jitter generation IS inside this wall time."""
-    import multiprocessing as mp
-    from concurrent.futures import ProcessPoolExecutor
+    """bench.py cpu_baseline leg, all host cores: `n_workers` single-thread processes (fresh interpreters -- the parent has
+    initialised HIP, which must not be forked) split the lanes of the same synthetic workload between them.  Returns
+    (lane-steps, wall seconds from the common start to the last worker's end)."""
+    import json
+    import sys
     if startup_s is None:
         startup_s = 4.0 + 0.03 * n_workers
     start_at = time.time() + startup_s
-    with ProcessPoolExecutor(max_workers=n_workers, mp_context=mp.get_context("spawn")) as ex:
-        rs = list(ex.map(_all_cores_worker, [(grid_npz, chron_npz, w, n_workers, budget_s, start_at) for w in range(n_workers)]))
+    root = os.path.dirname(_HERE)
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.pf_oracle_c", grid_npz, chron_npz, str(w), str(n_workers), str(budget_s),
+                               repr(start_at)], cwd=root, stdout=subprocess.PIPE, text=True,
+                              env=dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1"))
+             for w in range(n_workers)]
+    rs = []
+    for p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("cpu baseline worker failed")
+        rs.append(json.loads(out.strip().splitlines()[-1]))
     total = sum(r[0] for r in rs)
     wall = max(r[2] for r in rs) - min(r[1] for r in rs)
     return total, wall
+
+
+if __name__ == "__main__":
+    import json
+    import sys
+    a = sys.argv[1:]
+    print(json.dumps(_all_cores_worker((a[0], a[1], int(a[2]), int(a[3]), float(a[4]), float(a[5])))))
