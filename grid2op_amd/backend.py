@@ -20,6 +20,7 @@ from __future__ import annotations
 import copy
 import os
 import time
+import weakref
 from typing import Optional, Tuple, Union
 
 import numpy as np
@@ -33,13 +34,18 @@ from .grid_model import GridModel, load_grid_model
 __all__ = ["HipBackend"]
 
 
+_MODEL_CACHE = {}      # (real path, mtime) -> GridModel: the parsed grid file is immutable, re-loads reuse it (and its engine)
+
+
 class _LanePool:
     """Backends of the same grid / device / busbar count share ONE engine and take one lane each.
 
     ``Backend.copy`` is hammered by the reference (``ObservationSpace._create_backend_obs`` observationSpace.py:250-254,
     ``N1Reward`` n1Reward.py:71, ``Simulator``): with the pool a copy costs no device allocation -- the façade pushes
     its complete lane state before every power flow, so a copy only needs a free lane.  Engines are per process: a
-    forked child (Runner / multi-process envs) starts with an empty pool (HIP handles do not survive ``fork``)."""
+    forked child starts with an empty pool and never touches the parent's handles (`PowerFlowEngine.close` is a no-op in a
+    process that did not create the engine).  ROCm cannot be used in a child forked AFTER the parent initialised HIP: run
+    ``Runner(..., nb_process > 1)`` / multi-process environments with the ``spawn`` start method."""
     LANES = 32
     _pools = {}
     _pid = None
@@ -108,6 +114,7 @@ class HipBackend(Backend):
         self._engine = None
         self._lane = 0
         self._pool_key = None
+        self._lane_finalizer = None
         self.div_exception = None
         self.tol = 1e-5                     # storage "produces / absorbs anything" threshold (:864)
         self._topo_vect = None
@@ -121,16 +128,38 @@ class HipBackend(Backend):
         return PowerFlowEngine(model, n_lanes=n_lanes, device=self._device, n_busbar=n_busbar)
 
     def _acquire_lane(self):
+        self._release_lane()
         m, nbb = self._m, self.n_busbar_per_sub
-        self._pool_key = (type(self)._make_engine, id(m), self._device, nbb)
+        # backends of the same grid FILE share an engine: copies, and the fresh instances ``Runner`` loads per episode
+        self._pool_key = (type(self)._make_engine, getattr(m, "_source_key", None) or id(m), self._device, nbb)
         self._engine, self._lane = _LanePool.acquire(self._pool_key, lambda n: self._make_engine(m, nbb, n))
+        # a backend that is simply dropped (the reference never closes the copies ``next_grid_state`` appends to its infos,
+        # backend.py:1490-1492, nor do users close ``env.copy()``) must give its lane back like a closed one
+        self._lane_finalizer = weakref.finalize(self, _LanePool.release, self._pool_key, self._engine, self._lane)
+
+    def _release_lane(self):
+        fin = getattr(self, "_lane_finalizer", None)
+        if fin is not None:
+            fin()                      # runs _LanePool.release at most once
+        self._lane_finalizer = None
+        self._engine = None
 
     # ---- load_grid (pandaPowerBackend.py:356-617 + 670-874) ------------------------------------------------------------
     def load_grid(self, path: Union[os.PathLike, str], filename: Optional[Union[os.PathLike, str]] = None) -> None:
         self.can_handle_more_than_2_busbar()
         self.can_handle_detachment()
         full_path = self.make_complete_path(path, filename)
-        m = load_grid_model(full_path)
+        src = (os.path.realpath(str(full_path)), os.path.getmtime(str(full_path)))
+        m = _MODEL_CACHE.get(src)
+        if m is None:
+            if str(full_path).endswith(".npz"):      # a grid description saved by ``save_file`` / tests/golden/*.grid.npz
+                m = GridModel.load_npz(str(full_path))
+            else:
+                m = load_grid_model(full_path)
+            m._source_key = src
+            if len(_MODEL_CACHE) >= 16:
+                _MODEL_CACHE.pop(next(iter(_MODEL_CACHE)))
+            _MODEL_CACHE[src] = m
         self._m = m
         self._init_from_model(m)
         self._acquire_lane()
@@ -403,18 +432,39 @@ class HipBackend(Backend):
             self.storage_v[:] = f32(r.storage_v)
             g_st = m.storage_sub + (self._bus_sto - 1) * n_sub
             vm_st = r.bus_vm[0][g_st]
-            self.storage_theta[:] = np.nan_to_num(vm_st, nan=0.0).astype(dt_float) * self.storage_pu_to_kv
+            if is_dc:
+                vm_st = np.full(m.n_storage, np.nan)          # res_bus.vm_pu is NaN in DC (:1137-1139)
+            self.storage_theta[:] = (vm_st * self.storage_pu_to_kv).astype(dt_float)
+            # a storage unit whose voltage is not finite is switched off FOR GOOD (:1197-1201: p = q = v = 0 and
+            # storage["in_service"] = False) -- in DC mode that is every unit
             dead = ~np.isfinite(vm_st) & self._act_sto
             self.storage_p[dead] = 0.0
             self.storage_q[dead] = 0.0
+            self.storage_v[dead] = 0.0
+            self._act_sto[dead] = False
+        self._shunt_res = (f32(r.shunt_p).copy(), f32(r.shunt_q).copy(), f32(r.shunt_v).copy(),
+                           np.asarray(r.shunt_bus[0], dtype=dt_int).copy())
         if is_dc:
+            # pandapower leaves res_bus.vm_pu / res_line.vm_*_pu NaN in DC mode.  What PandaPowerBackend makes of it:
+            # * load_v = nominal kV, or the prod_v of the first generator of the same substation that sits on the same
+            #   busbar; 0 for an out-of-service load (:1137-1156)
+            # * v_or = v_ex = 0 (NaN -> 0, :1161-1181)
+            # * every q is 0 (:1212-1218)
+            self.load_v[:] = self.load_pu_to_kv
+            tv = self._topo_vect
+            for l_id in range(m.n_load):
+                for g_id in np.nonzero(m.gen_sub == m.load_sub[l_id])[0]:
+                    if tv[m.load_pos_topo_vect[l_id]] == tv[m.gen_pos_topo_vect[g_id]]:
+                        self.load_v[l_id] = self.prod_v[g_id]
+                        break
+            self.load_v[~self._act_load] = 0.0
+            self.v_or[:] = 0.0
+            self.v_ex[:] = 0.0
             self.prod_q[:] = 0.0
             self.load_q[:] = 0.0
             self.storage_q[:] = 0.0
             self.q_or[:] = 0.0
             self.q_ex[:] = 0.0
-        self._shunt_res = (f32(r.shunt_p).copy(), f32(r.shunt_q).copy(), f32(r.shunt_v).copy(),
-                           np.asarray(r.shunt_bus[0], dtype=dt_int).copy())
 
     def _reset_all_nan(self) -> None:
         """pandaPowerBackend.py:1257-1287."""
@@ -468,7 +518,7 @@ class HipBackend(Backend):
             if hasattr(self, k):
                 setattr(res, k, getattr(self, k))
         # class-level grid description is shared through the (re-typed) class; instance-level arrays are copied
-        skip = {"_engine", "_m", "_my_kwargs", "_pool_key", "_lane"}
+        skip = {"_engine", "_m", "_my_kwargs", "_pool_key", "_lane", "_lane_finalizer"}
         for k, v in self.__dict__.items():
             if k in skip:
                 continue
@@ -493,9 +543,7 @@ class HipBackend(Backend):
         return res
 
     def close(self) -> None:
-        if self._engine is not None:
-            _LanePool.release(self._pool_key, self._engine, self._lane)
-        self._engine = None
+        self._release_lane()
 
     def save_file(self, full_path) -> None:
         """The reference dumps its pandapower net (``pp.to_json``, :1425-1437); here the grid description and

@@ -816,17 +816,17 @@ int gpf_set_topology(gpf_handle e, int32_t lane0, int32_t n, const int32_t* topo
   if (!check_range(e, lane0, n) || !topo) return fail(GPF_E_INVALID, "gpf_set_topology: bad range");
   HIP_TRY(hipSetDevice(e->device));
   const gpf::GridDev& g = e->g;
-  for (int k = 0; k < n; ++k) {
-    const int* t = topo + (size_t)k * g.dim_topo;
-    for (int i = 0; i < g.dim_topo; ++i)
-      if (t[i] > g.n_busbar) return fail(GPF_E_INVALID, "gpf_set_topology: local bus id > n_busbar");
-  }
+  // validate BOTH arrays before anything is queued: a rejected call leaves the device state and the host mirror untouched
+  auto bad_bus = [&g](int v) { return v == 0 || v < -1 || v > g.n_busbar; };
+  for (size_t i = 0; i < (size_t)n * g.dim_topo; ++i)
+    if (bad_bus(topo[i])) return fail(GPF_E_INVALID, "gpf_set_topology: local bus ids must be -1 or 1..n_busbar");
+  if (shunt_bus && g.n_shunt)
+    for (size_t i = 0; i < (size_t)n * g.n_shunt; ++i)
+      if (bad_bus(shunt_bus[i])) return fail(GPF_E_INVALID, "gpf_set_topology: shunt bus ids must be -1 or 1..n_busbar");
   HIP_TRY(hipMemcpyAsync(e->topo.p + (size_t)lane0 * g.dim_topo, topo, (size_t)n * g.dim_topo * sizeof(int),
                          hipMemcpyHostToDevice, e->stream));
   std::vector<int> sb_host;
   if (shunt_bus && g.n_shunt) {
-    for (size_t i = 0; i < (size_t)n * g.n_shunt; ++i)
-      if (shunt_bus[i] > g.n_busbar) return fail(GPF_E_INVALID, "gpf_set_topology: shunt bus id > n_busbar");
     HIP_TRY(hipMemcpyAsync(e->shunt_bus.p + (size_t)lane0 * g.n_shunt, shunt_bus, (size_t)n * g.n_shunt * sizeof(int),
                            hipMemcpyHostToDevice, e->stream));
   } else if (g.n_shunt) {
@@ -1112,6 +1112,15 @@ int gpf_upload_chronics(gpf_handle e, int32_t n_tables, int32_t T, const float* 
   e->chron.release();
   HIP_TRY(e->chron.upload(data, (size_t)n_tables * T * e->g.n_chron));
   e->chron_T = T;
+  if (n_tables < e->chron_tables) {
+    // fewer tables than before: lanes that pointed past the new end fall back to table 0 (the kernel indexes the buffer
+    // with lane_table unchecked)
+    std::vector<int> lt(e->cap_lanes);
+    HIP_TRY(hipMemcpy(lt.data(), e->lane_table.p, lt.size() * sizeof(int), hipMemcpyDeviceToHost));
+    bool fix = false;
+    for (int& v : lt) if (v < 0 || v >= n_tables) { v = 0; fix = true; }
+    if (fix) HIP_TRY(hipMemcpy(e->lane_table.p, lt.data(), lt.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   e->chron_tables = n_tables;
   return GPF_OK;
 }

@@ -10,6 +10,7 @@ the batched stepping API (`upload_chronics` / `step`) is what ``bench.py`` measu
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -121,6 +122,7 @@ class PowerFlowEngine:
         d.init_topo = ptr(keep["init_topo"], C.c_int32)
         d.init_shunt_bus = ptr(keep["init_shunt_bus"], C.c_int32)
         check(self._lib.gpf_create(C.byref(d), int(n_lanes), int(device), C.byref(self._h)), "gpf_create")
+        self._pid = os.getpid()          # HIP handles belong to the creating process (a forked child must not destroy them)
         self.n_lanes = int(n_lanes)
         self.device = int(device)
         lay = GpfLayout()
@@ -142,7 +144,8 @@ class PowerFlowEngine:
     # ------------------------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            self._lib.gpf_destroy(self._h)
+            if getattr(self, "_pid", None) == os.getpid():
+                self._lib.gpf_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

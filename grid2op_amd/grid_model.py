@@ -266,6 +266,19 @@ def load_grid_model(path: str) -> GridModel:
     T = net["tables"]
     bus, line, trafo, gen, load, sto, shunt, ext = (T[k] for k in
                                                     ("bus", "line", "trafo", "gen", "load", "storage", "shunt", "ext_grid"))
+    # Elements pandapower includes in the power flow but this engine does not model: refuse the file instead of returning
+    # converged-but-different results (the reference only warns, pandaPowerBackend.py:253-276, because pandapower itself
+    # still solves them).
+    unsupported = [t for t in ("sgen", "trafo3w", "impedance", "ward", "xward", "dcline", "motor", "asymmetric_load",
+                               "asymmetric_sgen") if t in T and T[t].n]
+    if trafo.n and (np.any(trafo.f64("shift_degree", 0.0) != 0.0) or np.any(trafo.boolean("tap_phase_shifter", False))):
+        unsupported.append("trafo.shift_degree / tap_phase_shifter")
+    for tn, tb in (("load", load), ("gen", gen), ("storage", sto)):
+        if tb.n and np.any(tb.f64("scaling", 1.0) != 1.0):
+            unsupported.append(f"{tn}.scaling != 1")
+    if unsupported:
+        raise ValueError(f"{path}: grid elements not modelled by the HIP engine: {', '.join(unsupported)} "
+                         f"(pandapower would include them in the power flow; results would silently differ)")
     m = GridModel()
     m.sn_mva = net["sn_mva"]
     m.f_hz = net["f_hz"]

@@ -52,3 +52,40 @@ _cls = globals().get("TestLoadingBackendPandaPower_HipBackend")
 if _cls is not None:
     _cls.get_backend = lambda self, detailed_infos_for_cascading_failures=True: OracleHipBackend(
         detailed_infos_for_cascading_failures=detailed_infos_for_cascading_failures)
+
+
+# ---- lane pool hygiene: dropped / re-loaded backends give their engine lane back ---------------------------------
+def test_dropped_copies_do_not_leak_engine_lanes():
+    import gc
+    from grid2op_amd.backend import _LanePool
+    path = os.path.join(REFERENCE, "grid2op", "data", "rte_case5_example")
+    bk = OracleHipBackend()
+    bk.load_grid(path, "grid.json")
+    key = bk._pool_key
+    for _ in range(3 * _LanePool.LANES):                 # copies that are never closed (Backend.next_grid_state's infos,
+        c = bk.copy()                                    # env.copy() users): garbage collection must release their lane
+        assert c._lane != bk._lane
+        del c
+        gc.collect()
+    assert len(_LanePool._pools[key]) == 1
+    held = [bk.copy() for _ in range(_LanePool.LANES + 3)]          # more live copies than one engine has lanes
+    assert len(_LanePool._pools[key]) == 2
+    assert len({(id(h._engine), h._lane) for h in held + [bk]}) == len(held) + 1
+    for h in held:
+        h.close()
+    lane0 = bk._lane
+    bk.load_grid(path, "grid.json")                       # a second load_grid releases the previous lane first
+    assert sum(len(e["free"]) for e in _LanePool._pools[bk._pool_key]) == _LanePool.LANES - 1
+    bk.close()
+    bk.close()                                            # idempotent
+    assert key not in _LanePool._pools or all(len(e["free"]) == _LanePool.LANES for e in _LanePool._pools[key])
+    assert lane0 >= 0
+
+
+def test_unsupported_pandapower_elements_are_refused():
+    from grid2op_amd.grid_model import load_grid_model
+    p = os.path.join(REFERENCE, "grid2op", "data_test", "5bus_modif_grid", "grid.json")
+    if not os.path.exists(p):
+        pytest.skip("fixture grid absent")
+    with pytest.raises(ValueError, match="not modelled"):
+        load_grid_model(p)
