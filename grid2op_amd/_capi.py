@@ -12,7 +12,7 @@ from typing import Optional
 
 import numpy as np
 
-__all__ = ["lib", "GridPFError", "GpfGridDesc", "GpfLayout", "library_path", "EXPORTED_SYMBOLS"]
+__all__ = ["lib", "GridPFError", "GpfGridDesc", "GpfLayout", "GpfStepOpts", "library_path", "EXPORTED_SYMBOLS"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libgridpf.so"
@@ -21,7 +21,8 @@ EXPORTED_SYMBOLS = [
     "gpf_last_error", "gpf_version", "gpf_device_count", "gpf_create", "gpf_destroy", "gpf_get_layout", "gpf_n_lanes",
     "gpf_set_injections", "gpf_set_topology", "gpf_get_injections", "gpf_get_topology", "gpf_disconnect_line",
     "gpf_reset_lanes", "gpf_copy_lanes", "gpf_fanout_n1", "gpf_runpf", "gpf_get_results", "gpf_upload_chronics",
-    "gpf_set_lane_chronics", "gpf_set_thermal_limits", "gpf_step", "gpf_get_step_outputs", "gpf_sync",
+    "gpf_set_lane_chronics", "gpf_set_thermal_limits", "gpf_step", "gpf_step_n", "gpf_set_lane_redispatch", "gpf_set_trajectory",
+    "gpf_get_trajectory", "gpf_get_episode", "gpf_lane_capacity", "gpf_get_step_outputs", "gpf_sync",
     "gpf_set_profiling", "gpf_get_kernel_time", "gpf_device_pointers",
     "gpf_ptdf_build", "gpf_ptdf_get", "gpf_ptdf_flows", "gpf_get_ptdf_flows", "gpf_lodf_screen",
 ]
@@ -71,6 +72,12 @@ class GpfLayout(C.Structure):
         "n_chron", "chron_load_p", "chron_load_q", "chron_prod_p", "chron_prod_v", "nb_total")]
 
 
+class GpfStepOpts(C.Structure):
+    _fields_ = [("max_iter", C.c_int32), ("tol_mva", C.c_double), ("rebalance", C.c_double), ("cascade", C.c_int32),
+                ("hard_overflow", C.c_float), ("soft_overflow", C.c_float), ("nb_ts_allowed", C.c_int32), ("max_rounds", C.c_int32),
+                ("is_dc", C.c_int32), ("auto_reset", C.c_int32)]
+
+
 _lib: Optional[C.CDLL] = None
 
 
@@ -84,6 +91,16 @@ def lib() -> C.CDLL:
         raise GridPFError(
             f"{path} not found: the HIP engine is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             f"(there is no CPU fallback).")
+    # PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64.  Two HIP runtimes cannot share a process: whichever
+    # is loaded first serves both (same SONAME), and torch finds no GPU when it is the system one (measured on the MI355X box:
+    # "No HIP GPUs are available" as soon as libgridpf.so was loaded before ``import torch``).  So when torch is installed it is
+    # imported first and libgridpf.so binds to the runtime torch ships -- zero-copy views (PowerFlowEngine.device_views),
+    # torch.distributed / RCCL and the engine then live on the same runtime.  GRIDPF_NO_TORCH_PRELOAD=1 skips this.
+    if os.environ.get("GRIDPF_NO_TORCH_PRELOAD", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     try:
         L = C.CDLL(path)
     except OSError as exc:
@@ -112,6 +129,12 @@ def lib() -> C.CDLL:
     L.gpf_set_lane_chronics.argtypes = [h, _ip, _ip, _fp]
     L.gpf_set_thermal_limits.argtypes = [h, _fp]
     L.gpf_step.argtypes = [h, i32, i32, C.c_double, C.c_double, i32, C.c_float, C.c_float, i32, i32, i32]
+    L.gpf_step_n.argtypes = [h, i32, i32, C.POINTER(GpfStepOpts)]
+    L.gpf_set_lane_redispatch.argtypes = [h, _fp]
+    L.gpf_set_trajectory.argtypes = [h, i32]
+    L.gpf_get_trajectory.argtypes = [h, i32, i32, i32, i32, _fp, C.POINTER(C.c_int8)]
+    L.gpf_get_episode.argtypes = [h, i32, i32, _bp, _ip]
+    L.gpf_lane_capacity.argtypes = [h]
     L.gpf_get_step_outputs.argtypes = [h, i32, i32, _fp, _ip, _ip]
     L.gpf_sync.argtypes = [h]
     L.gpf_set_profiling.argtypes = [h, i32]

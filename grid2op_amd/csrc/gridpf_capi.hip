@@ -1,6 +1,6 @@
 // gridpf_capi.hip -- host side of libgridpf.so: the C ABI declared in include/gridpf.h.
 // Owns the device buffers of one engine (static grid tables + lane-major per-lane state), one HIP
-// stream, and launches the kernels of gridpf_kernels.hpp.  gfx950 only; no fallback path: if HIP is
+// stream, and launches the kernels of gridpf_sparse.hpp / gridpf_ptdf.hpp.  gfx950 only; no fallback path: if HIP is
 // unavailable every entry point fails with GPF_E_DEVICE.
 #include <hip/hip_runtime.h>
 
@@ -14,13 +14,38 @@
 #include <vector>
 
 #include "../../include/gridpf.h"
-#include "gridpf_kernels.hpp"
-#include "gridpf_small.hpp"
+#include "gridpf_common.hpp"
 #include "gridpf_sparse.hpp"
+#include "gridpf_host.hpp"
 #include "gridpf_ptdf.hpp"
 #include <string>
 #include <unordered_map>
 #include "gridpf_symbolic.hpp"
+
+namespace gpf {
+// device-side lane utilities ------------------------------------------------------------------------------------------
+__global__ void fanout_kernel(GridDev g, Bufs b, int src, int dst0, int n_dst, const int* __restrict__ out_lines) {
+  const int k = blockIdx.x;
+  if (k >= n_dst) return;
+  const int dst = dst0 + k;
+  const int tid = threadIdx.x;
+  const double* sinj = b.inj + (size_t)src * g.n_inj;
+  double* dinj = b.inj + (size_t)dst * g.n_inj;
+  for (int i = tid; i < g.n_inj; i += blockDim.x) dinj[i] = sinj[i];
+  const int* st = b.topo + (size_t)src * g.dim_topo;
+  int* dt = b.topo + (size_t)dst * g.dim_topo;
+  const int ol = out_lines ? out_lines[k] : -1;
+  const int po = (ol >= 0 && ol < g.n_line) ? g.line_or_pos[ol] : -1;
+  const int pe = (ol >= 0 && ol < g.n_line) ? g.line_ex_pos[ol] : -1;
+  int* d0 = const_cast<int*>(b.topo0) + (size_t)dst * g.dim_topo;
+  for (int i = tid; i < g.dim_topo; i += blockDim.x) { const int v = (i == po || i == pe) ? -1 : st[i]; dt[i] = v; d0[i] = v; }
+  const int* ss = b.shunt_bus + (size_t)src * g.n_shunt;
+  int* ds = b.shunt_bus + (size_t)dst * g.n_shunt;
+  for (int i = tid; i < g.n_shunt; i += blockDim.x) ds[i] = ss[i];
+}
+
+
+}  // namespace gpf
 
 namespace {
 
@@ -61,23 +86,6 @@ struct DevArr {
 
 }  // namespace
 
-struct LaunchPlan {
-  int nbc, nJ;
-  bool big;
-  size_t lds;
-  int small_nmax;   // 0: generic LDS kernels (v1); 24/32/48/64: register-resident kernels (v2)
-  int sparse_nb;    // 0: no; 1..3: block-sparse kernel S with NB busbars per substation block
-  int minw;         // kernel S: __launch_bounds__ waves per SIMD (4 caps the kernel at 128 VGPRs: only worth it when LDS allows > 8 blocks per CU)
-  bool tc;          // topology-class launch: single-busbar kernel on the bus-level graph of each lane's class (cls_list)
-  const int* cls_list;
-  int tc_rows, tc_nslot, tc_nslot_y;
-  int n_list;       // > 0: this plan covers n_list lanes given by a device index list (mixed batches), else a contiguous range
-  const int* list;  // device pointer (padded with a ghost lane to a multiple of ipw)
-  int wpi;          // kernel S: wavefronts per instance (1, 2 or 4; > 1 only for NB == 1, IPW == 1 on large grids)
-  int ipw;          // kernel S: grid instances per wavefront (1, 2 or 4; > 1 only for NB == 1 on small grids)
-  int sparse_stage;  // 0: static tables read in place (L2), 1: program + pair table + injection row in LDS, 2: everything in LDS // program staged in LDS (small grids) or streamed from L2 (keeps 3 instances per CU on 118-bus grids)
-};
-
 struct gpf_engine {
   int device = 0;
   int n_lanes = 0;
@@ -100,7 +108,13 @@ struct gpf_engine {
   DevArr<double> inj, bus_vm, bus_va, work;
   DevArr<int> topo, shunt_bus, topo_out, shunt_bus_out, status, overflow_count, disc_round, lane_table, lane_offset, tmp_lines;
   DevArr<float> out, chron, lane_scale, thermal_limit, rho;
-  DevArr<unsigned char> line_status;
+  DevArr<unsigned char> line_status, done;
+  DevArr<int> topo0, episode;           // topology last sent by the host (auto-reset target); {steps survived, resets} per lane
+  DevArr<float> lane_gen_delta, traj_rho;
+  DevArr<signed char> traj_status;
+  int traj_cap = 0;
+  bool has_delta = false;
+  int dcf = 0;                          // the NB == 1 LDS layout has room for the factored DC matrix (decided once at gpf_create)
   DevArr<double> d_init_inj;
   DevArr<int> d_init_topo, d_init_shunt_bus;
   int chron_T = 0, chron_tables = 0;
@@ -108,8 +122,6 @@ struct gpf_engine {
   // per-lane capacity bookkeeping (host): number of active buses / NR unknowns of each lane
   std::vector<int> lane_nb, lane_nj;
   int init_nb = 0, init_nj = 0;
-  bool lpr1 = false;            // GRIDPF_LPR1=1: one lane per Jacobian row for n <= 24 (experiment)
-  bool force_generic = false;   // GRIDPF_FORCE_GENERIC=1: always use the generic (v1) kernels
   // block-sparse path (kernel S)
   gpf::Symbolic sym;
   // DC sensitivity path (gridpf_ptdf.hpp)
@@ -127,7 +139,6 @@ struct gpf_engine {
   gpf::DevParamsS h_params_s{};
   gpf::DevParamsS* d_params_s = nullptr;
   bool params_s_valid = false;
-  bool force_sparse = false;   // GRIDPF_FORCE_SPARSE=1
   // mixed batches: lanes without / with split substations are launched separately (single-busbar kernel / NB = n_busbar)
   DevArr<int> list_a, list_b, list_c;   // list_c: topology class of every lane of list_b
   // topology classes (gpf::TopoClassDev): bus-level graphs of the split topologies seen so far, each with its own symbolic program
@@ -145,14 +156,8 @@ struct gpf_engine {
   int ipw_override = 0;        // GRIDPF_IPW=1|2|4 (developer override of the instances-per-wavefront heuristic)
   int wpi_override = 0;        // GRIDPF_WPI=1|2|4 (developer override of the wavefronts-per-instance heuristic)
   int cap_lanes = 0;           // lane buffers are padded to a multiple of 4 lanes (instance groups of a wavefront)
-  bool dense_small_64 = false; // GRIDPF_DENSE64=1: use the dense register kernels up to n = 64 (experiment)
-  bool dense_small = false;    // GRIDPF_DENSE=1: dense register-resident kernels (gridpf_small.hpp) for n <= 32
   std::vector<int> lane_mb;    // max live busbars in one substation, per lane
   int init_mb = 1;
-  // device-resident kernel parameter block (kernel v2 takes ONE pointer)
-  gpf::DevParams h_params{};
-  gpf::DevParams* d_params = nullptr;
-  bool params_valid = false;
   bool plan_valid = false;      // cached launch plan of the whole batch (invalidated by every topology mutation)
   LaunchPlan plan_cached{}, plan_b_cached{};   // plan_b: the split lanes of a mixed batch (sparse_nb == 0: none)
   // profiling
@@ -173,6 +178,10 @@ struct gpf_engine {
     b.chron = chron.p; b.lane_table = lane_table.p; b.lane_offset = lane_offset.p;
     b.lane_scale = has_scale ? lane_scale.p : nullptr;
     b.thermal_limit = thermal_limit.p; b.rho = rho.p; b.overflow_count = overflow_count.p; b.disc_round = disc_round.p;
+    b.lane_gen_delta = has_delta ? lane_gen_delta.p : nullptr;
+    b.topo0 = topo0.p; b.done = done.p; b.episode = episode.p;
+    b.traj_rho = traj_cap ? traj_rho.p : nullptr; b.traj_status = traj_cap ? traj_status.p : nullptr; b.traj_cap = traj_cap;
+    b.lane_stride = cap_lanes; b.n_real_lanes = n_lanes;
     return b;
   }
 };
@@ -314,44 +323,12 @@ int plan_launch(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchPlan& pb) 
 
 int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchPlan& pb) {
   pb = LaunchPlan{};
-  int nb = 1, nj = 1;
-  for (int k = lane0; k < lane0 + n; ++k) {
-    nb = std::max(nb, e->lane_nb[k]);
-    nj = std::max(nj, e->lane_nj[k]);
-  }
-  p.nbc = (nb + 1) & ~1;
-  p.nJ = (nj + 1) & ~1;
-  p.small_nmax = 0;
-  p.sparse_nb = 0;
+  p = LaunchPlan{};
   p.ipw = 1;
-  p.n_list = 0;
-  p.list = nullptr;
-  p.tc = false;
-  p.cls_list = nullptr;
-  p.tc_rows = p.tc_nslot = p.tc_nslot_y = 0;
   p.wpi = 1;
   p.minw = 2;
-  p.sparse_stage = 0;
   int mb = 1;
   for (int k = lane0; k < lane0 + n; ++k) mb = std::max(mb, e->lane_mb[k]);
-  // dense register-resident kernels for tiny systems (n <= 32); block-sparse kernel S beyond (3x faster at n = 56)
-  const int small_max_n = e->dense_small_64 ? 64 : 32;
-  if (!e->force_generic && !e->force_sparse && e->dense_small && p.nJ <= small_max_n && p.nbc <= 64 && e->g.nb_tot <= 127) {
-    const int nmax = p.nJ <= 24 ? 24 : p.nJ <= 32 ? 32 : p.nJ <= 48 ? 48 : 64;
-    const size_t l = nmax == 24 ? (e->lpr1 ? gpf::lds_bytes_small<24, 1>(e->g, p.nbc, p.nJ) : gpf::lds_bytes_small<24, 2>(e->g, p.nbc, p.nJ))
-                   : nmax == 32 ? gpf::lds_bytes_small<32, 2>(e->g, p.nbc, p.nJ)
-                   : nmax == 48 ? gpf::lds_bytes_small<48, 1>(e->g, p.nbc, p.nJ)
-                                : gpf::lds_bytes_small<64, 1>(e->g, p.nbc, p.nJ);
-    if (l <= LDS_SMALL_LIMIT) {
-#ifdef GPF_TIMING
-      if (e->work.n < (size_t)e->cap_lanes * 32) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->cap_lanes * 32)); }
-#endif
-      p.small_nmax = nmax;
-      p.big = false;
-      p.lds = l;
-      return GPF_OK;
-    }
-  }
   // kernel S plan of n lanes that all run with NBK busbars per substation block; listed: the lanes come from an index list
   auto plan_sparse = [&](int nbk, int n_l, int lane0_l, bool listed, LaunchPlan& q) -> bool {
     // small grids do not have 64-wide work: several instances share a wavefront (instance groups, gridpf_sparse.hpp).
@@ -364,9 +341,10 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
     auto need = [&](int tier) -> size_t {
       const size_t static_bytes = gpf::stat_bytes(e->sym_dev.so, tier);
       const bool st = tier > 0;
-      return nbk == 1 ? gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, e->sym.nslot_y, static_bytes, st, ipw)
-           : nbk == 2 ? gpf::lds_bytes_sparse<2>(e->g, e->sym.nslot, e->sym.nslot_y, static_bytes, st)
-                      : gpf::lds_bytes_sparse<3>(e->g, e->sym.nslot, e->sym.nslot_y, static_bytes, st);
+      const bool dcf = e->dcf != 0;
+      return nbk == 1 ? gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, e->sym.nslot_y, static_bytes, st, ipw, -1, dcf)
+           : nbk == 2 ? gpf::lds_bytes_sparse<2>(e->g, e->sym.nslot, e->sym.nslot_y, static_bytes, st, 1, -1, dcf)
+                      : gpf::lds_bytes_sparse<3>(e->g, e->sym.nslot, e->sym.nslot_y, static_bytes, st, 1, -1, dcf);
     };
     // stage the static tables + the injection row in LDS only when that does not cost residency: blocks per CU
     // (160 KiB / footprint) must still cover what the launch needs at once, or what the un-staged kernel would get
@@ -382,17 +360,16 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
     if (l > LDS_HARD_LIMIT) return false;
     q.sparse_nb = nbk;
     q.ipw = ipw;
-    q.minw = (nbk == 1 && ipw == 1 && LDS_HARD_LIMIT / l >= 12) ? 4 : 2;
+    q.minw = 2;
     // large grids: phases loop over hundreds of items -> several wavefronts per instance (block-wide barriers)
-    q.wpi = (nbk == 1 && ipw == 1) ? (e->wpi_override ? e->wpi_override : (e->g.n_sub >= 64 ? 2 : 1))
+    q.wpi = (nbk == 1 && ipw == 1) ? (e->wpi_override ? std::min(e->wpi_override, 2) : (e->g.n_sub >= 64 ? 2 : 1))
           : (nbk == 2 && (e->wpi_override ? e->wpi_override == 2 : e->g.n_sub >= 64)) ? 2 : 1;
     if (q.wpi > 1) q.minw = 2;
     q.sparse_stage = stage;
-    q.big = false;
     q.lds = l;
     return true;
   };
-  if (!e->force_generic && e->g.n_sub * mb <= 32000 && e->g.n_busbar <= 3) {
+  if (e->g.n_sub * mb <= 32000 && e->g.n_busbar <= 3) {
 #ifdef GPF_TIMING
     if (e->work.n < (size_t)e->cap_lanes * 32) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->cap_lanes * 32)); }
 #endif
@@ -425,7 +402,7 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
       LaunchPlan qa = p, qb = p;
       bool ok_b;
       if (all_classed) {
-        qb.tc = true; qb.sparse_nb = 1; qb.ipw = everyone ? tc_ipw : 1; qb.sparse_stage = 0; qb.minw = 2; qb.big = false;
+        qb.tc = true; qb.sparse_nb = 1; qb.ipw = everyone ? tc_ipw : 1; qb.sparse_stage = 0; qb.minw = 2;
         qb.wpi = qb.ipw > 1 ? 1 : (e->wpi_override ? (e->wpi_override >= 2 ? 2 : 1) : (e->g.n_sub >= 64 ? 2 : 1));
         for (int cid : lc) {
           const auto* c = e->classes[cid];
@@ -466,34 +443,7 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
     }
     if (plan_sparse(mb == 1 ? 1 : e->g.n_busbar, n, lane0, false, p)) return GPF_OK;
   }
-  size_t small = gpf::lds_bytes(e->g, p.nbc, p.nJ, false);
-  p.big = small > LDS_SMALL_LIMIT;
-  p.lds = gpf::lds_bytes(e->g, p.nbc, p.nJ, p.big);
-  if (p.lds > LDS_HARD_LIMIT) return fail(GPF_E_CAPACITY, "grid too large: per-instance LDS footprint exceeds 160 KiB");
-  if (p.big) {
-    size_t stride = (size_t)2 * p.nbc * p.nbc + (size_t)p.nJ * (p.nJ + 1);
-    size_t need = stride * (size_t)e->n_lanes;
-    if (e->work.n < need) {
-      HIP_TRY(hipStreamSynchronize(e->stream));
-      e->work.release();
-      HIP_TRY(e->work.alloc(need));
-    }
-  }
-  return GPF_OK;
-}
-
-int upload_params(gpf_engine* e, const gpf::Bufs& b) {
-  gpf::DevParams hp{};
-  hp.g = e->g;
-  hp.b = b;
-  hp.oo = e->oo;
-  if (!e->d_params) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_params), sizeof(gpf::DevParams)));
-  if (!e->params_valid || std::memcmp(&hp, &e->h_params, sizeof(hp)) != 0) {
-    e->h_params = hp;
-    HIP_TRY(hipMemcpyAsync(e->d_params, &e->h_params, sizeof(hp), hipMemcpyHostToDevice, e->stream));
-    e->params_valid = true;
-  }
-  return GPF_OK;
+  return fail(GPF_E_CAPACITY, "grid too large: per-instance LDS footprint of the block-sparse kernel exceeds 160 KiB");
 }
 
 int upload_params_s(gpf_engine* e, const gpf::Bufs& b, const LaunchPlan* tc = nullptr) {
@@ -504,6 +454,7 @@ int upload_params_s(gpf_engine* e, const gpf::Bufs& b, const LaunchPlan* tc = nu
   hp.sym = e->sym_dev;
   hp.classes = e->d_classes.p;
   hp.tc_rows = tc ? tc->tc_rows : 0; hp.tc_nslot = tc ? tc->tc_nslot : 0; hp.tc_nslot_y = tc ? tc->tc_nslot_y : 0;
+  hp.dcf = e->dcf;
   if (!e->d_params_s) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_params_s), sizeof(gpf::DevParamsS)));
   if (!e->params_s_valid || std::memcmp(&hp, &e->h_params_s, sizeof(hp)) != 0) {
     e->h_params_s = hp;
@@ -512,8 +463,6 @@ int upload_params_s(gpf_engine* e, const gpf::Bufs& b, const LaunchPlan* tc = nu
   }
   return GPF_OK;
 }
-
-size_t work_stride(const LaunchPlan& p) { return (size_t)2 * p.nbc * p.nbc + (size_t)p.nJ * (p.nJ + 1); }
 
 int prof_begin(gpf_engine* e, hipEvent_t& a, hipEvent_t& b) {
   if (e->ev_used == e->ev_pool.size()) {
@@ -554,9 +503,12 @@ int reset_lanes_unchecked(gpf_engine* e, int lane0, int n) {
   }
   HIP_TRY(hipMemcpyAsync(e->inj.p + (size_t)lane0 * g.n_inj, inj.data(), inj.size() * sizeof(double), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipMemcpyAsync(e->topo.p + (size_t)lane0 * g.dim_topo, topo.data(), topo.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->topo0.p + (size_t)lane0 * g.dim_topo, topo.data(), topo.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
   if (g.n_shunt)
     HIP_TRY(hipMemcpyAsync(e->shunt_bus.p + (size_t)lane0 * g.n_shunt, sb.data(), sb.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipMemsetAsync(e->overflow_count.p + (size_t)lane0 * g.n_line, 0, (size_t)n * g.n_line * sizeof(int), e->stream));
+  HIP_TRY(hipMemsetAsync(e->done.p + lane0, 0, (size_t)n, e->stream));
+  HIP_TRY(hipMemsetAsync(e->episode.p + (size_t)lane0 * 2, 0, (size_t)n * 2 * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->status.p + (size_t)lane0 * 4, 0xFF, (size_t)n * 4 * sizeof(int), e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   const int init_class = topo_class_of(e, e->h_init_topo.data(), g.n_shunt ? e->h_init_shunt_bus.data() : nullptr);
@@ -599,10 +551,6 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   gpf_engine* e = new gpf_engine();
   e->device = device;
   {
-    const char* fg = std::getenv("GRIDPF_FORCE_GENERIC");
-    e->force_generic = fg && fg[0] == '1';
-    const char* fs = std::getenv("GRIDPF_FORCE_SPARSE");
-    e->force_sparse = fs && fs[0] == '1';
     const char* np_ = std::getenv("GRIDPF_NO_PARTITION");
     e->no_partition = np_ && np_[0] == '1';
     const char* nc_ = std::getenv("GRIDPF_NO_CLASSES");
@@ -611,13 +559,6 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     e->ipw_override = (iw && (iw[0] == '1' || iw[0] == '2' || iw[0] == '4')) ? iw[0] - '0' : 0;
     const char* ww = std::getenv("GRIDPF_WPI");
     e->wpi_override = (ww && (ww[0] == '1' || ww[0] == '2' || ww[0] == '4')) ? ww[0] - '0' : 0;
-    const char* dn = std::getenv("GRIDPF_DENSE");
-    e->dense_small = dn && dn[0] == '1';
-    const char* d64 = std::getenv("GRIDPF_DENSE64");
-    e->dense_small_64 = d64 && d64[0] == '1';
-    if (e->dense_small_64) e->dense_small = true;
-    const char* l1 = std::getenv("GRIDPF_LPR1");
-    e->lpr1 = l1 && l1[0] == '1';
   }
   e->n_lanes = n_lanes;
   e->cap_lanes = (n_lanes + 7) & ~3;          // >= 4 ghost lanes (pristine state): padding of instance groups / lane lists
@@ -698,6 +639,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   AL(out, B * g.n_out); AL(topo_out, B * g.dim_topo); AL(shunt_bus_out, B * nsh); AL(line_status, B * nl);
   AL(status, B * 4); AL(bus_vm, B * g.nb_tot); AL(bus_va, B * g.nb_tot);
   AL(overflow_count, B * nl); AL(disc_round, B * nl); AL(rho, B * nl);
+  AL(topo0, B * g.dim_topo); AL(done, B); AL(episode, B * 2);
   AL(lane_table, B); AL(lane_offset, B); AL(thermal_limit, nl); AL(tmp_lines, std::max<size_t>(B, 1));
 #undef UP
 #undef AL
@@ -751,8 +693,22 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     } D.scale_off = S.scale_off; D.n_scale = S.n_scale; D.n_prog = (int)S.prog.size();
     D.stat_dbl = e->stat_dbl.p; D.stat_int = e->stat_int.p; D.prog = e->stat_int.p + so.prog;
   }
+  {
+    // keep the factored DC matrix in LDS across the steps of a launch when that does not cost residency: the blocks per CU
+    // the whole batch needs at once must still fit (GRIDPF_DCF=0|1 overrides)
+    const int ipw = e->ipw_override ? e->ipw_override : (g.n_sub <= 8 ? 4 : g.n_sub <= 24 ? 2 : 1);
+    const size_t stat2 = gpf::stat_bytes(e->sym_dev.so, 2);
+    const size_t with = gpf::lds_bytes_sparse<1>(g, e->sym.nslot, e->sym.nslot_y, stat2, true, ipw, -1, true);
+    const size_t n_blocks = ((size_t)n_lanes + ipw - 1) / ipw;
+    const size_t want = std::min<size_t>((n_blocks + 255) / 256, 8);
+    e->dcf = (with <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / with >= want) ? 1 : 0;
+    const char* dv = std::getenv("GRIDPF_DCF");
+    if (dv && (dv[0] == '0' || dv[0] == '1')) e->dcf = dv[0] - '0';
+  }
   HIP_TRY(hipMemsetAsync(e->status.p, 0xFF, B * 4 * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->overflow_count.p, 0, B * nl * sizeof(int), e->stream));
+  HIP_TRY(hipMemsetAsync(e->done.p, 0, B, e->stream));
+  HIP_TRY(hipMemsetAsync(e->episode.p, 0, B * 2 * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->lane_table.p, 0, B * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->lane_offset.p, 0, B * sizeof(int), e->stream));
   {
@@ -782,7 +738,7 @@ int gpf_destroy(gpf_handle e) {
   e->lane_table.release(); e->lane_offset.release(); e->tmp_lines.release(); e->out.release(); e->chron.release();
   e->lane_scale.release(); e->thermal_limit.release(); e->rho.release(); e->line_status.release();
   e->d_init_inj.release(); e->d_init_topo.release(); e->d_init_shunt_bus.release();
-  if (e->d_params) (void)hipFree(e->d_params);
+  e->topo0.release(); e->done.release(); e->episode.release(); e->lane_gen_delta.release(); e->traj_rho.release(); e->traj_status.release();
   if (e->d_params_s) (void)hipFree(e->d_params_s);
   e->stat_dbl.release();
   e->list_a.release(); e->list_b.release(); e->list_c.release(); e->d_classes.release();
@@ -802,6 +758,7 @@ int gpf_get_layout(gpf_handle e, gpf_layout* out) {
 }
 
 int gpf_n_lanes(gpf_handle e) { return e ? e->n_lanes : GPF_E_INVALID; }
+int gpf_lane_capacity(gpf_handle e) { return e ? e->cap_lanes : GPF_E_INVALID; }
 
 int gpf_set_injections(gpf_handle e, int32_t lane0, int32_t n, const double* inj) {
   if (!check_range(e, lane0, n) || !inj) return fail(GPF_E_INVALID, "gpf_set_injections: bad range");
@@ -824,6 +781,8 @@ int gpf_set_topology(gpf_handle e, int32_t lane0, int32_t n, const int32_t* topo
     for (size_t i = 0; i < (size_t)n * g.n_shunt; ++i)
       if (bad_bus(shunt_bus[i])) return fail(GPF_E_INVALID, "gpf_set_topology: shunt bus ids must be -1 or 1..n_busbar");
   HIP_TRY(hipMemcpyAsync(e->topo.p + (size_t)lane0 * g.dim_topo, topo, (size_t)n * g.dim_topo * sizeof(int),
+                         hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->topo0.p + (size_t)lane0 * g.dim_topo, topo, (size_t)n * g.dim_topo * sizeof(int),
                          hipMemcpyHostToDevice, e->stream));
   std::vector<int> sb_host;
   if (shunt_bus && g.n_shunt) {
@@ -881,8 +840,11 @@ int gpf_disconnect_line(gpf_handle e, int32_t lane, int32_t line_id) {
   HIP_TRY(hipSetDevice(e->device));
   const int m1 = -1;
   int* row = e->topo.p + (size_t)lane * e->g.dim_topo;
+  int* row0 = e->topo0.p + (size_t)lane * e->g.dim_topo;
   HIP_TRY(hipMemcpyAsync(row + e->h_line_or_pos[line_id], &m1, sizeof(int), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipMemcpyAsync(row + e->h_line_ex_pos[line_id], &m1, sizeof(int), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(row0 + e->h_line_or_pos[line_id], &m1, sizeof(int), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(row0 + e->h_line_ex_pos[line_id], &m1, sizeof(int), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->h_lane_topo[(size_t)lane * e->g.dim_topo] = INT_MIN;          // host mirror of the sent topology: unknown from now on
   return GPF_OK;   // removing a branch never increases the bus / unknown counts: capacity bookkeeping unchanged
@@ -905,7 +867,7 @@ int gpf_copy_lanes(gpf_handle e, int32_t src, int32_t dst, int32_t n) {
                          (size_t)n * (stride) * sizeof(*e->arr.p), hipMemcpyDeviceToDevice, e->stream))
   CP(inj, g.n_inj); CP(topo, g.dim_topo); CP(shunt_bus, g.n_shunt); CP(out, g.n_out); CP(topo_out, g.dim_topo);
   CP(shunt_bus_out, g.n_shunt); CP(line_status, g.n_line); CP(status, 4); CP(bus_vm, g.nb_tot); CP(bus_va, g.nb_tot);
-  CP(overflow_count, g.n_line); CP(disc_round, g.n_line); CP(rho, g.n_line);
+  CP(overflow_count, g.n_line); CP(disc_round, g.n_line); CP(rho, g.n_line); CP(topo0, g.dim_topo); CP(done, 1); CP(episode, 2);
 #undef CP
   for (int k = 0; k < n; ++k) { e->lane_nb[dst + k] = e->lane_nb[src + k]; e->lane_nj[dst + k] = e->lane_nj[src + k]; e->lane_mb[dst + k] = e->lane_mb[src + k]; e->lane_class[dst + k] = e->lane_class[src + k];
     std::copy_n(e->h_lane_topo.begin() + (size_t)(src + k) * g.dim_topo, g.dim_topo, e->h_lane_topo.begin() + (size_t)(dst + k) * g.dim_topo);
@@ -930,121 +892,6 @@ int gpf_fanout_n1(gpf_handle e, int32_t src, int32_t dst0, int32_t n_out, const 
   return GPF_OK;
 }
 
-// kernel S dispatch (one launch for a contiguous range, or for the lanes of a device index list)
-static int launch_runpf_sparse(gpf_engine* e, const LaunchPlan& p, hipStream_t stream, int lane0, int n, int is_dc, int max_iter, double tol_pu) {
-  const int n_l = p.n_list ? p.n_list : n;
-  const int* list = p.n_list ? p.list : nullptr;
-#define LAUNCH_RUNPF_SPARSE(NBK, ST, IPW, MW, WP)                                                                                 \
-  do {                                                                                                                            \
-    static size_t lds_set_[64] = {0};                                                                                             \
-    if (p.lds > lds_set_[e->device & 63]) {                                                                                       \
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<NBK, ST, IPW, MW, WP>),                 \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                       \
-      lds_set_[e->device & 63] = p.lds;                                                                                           \
-    }                                                                                                                             \
-    hipLaunchKernelGGL((gpf::runpf_sparse_kernel<NBK, ST, IPW, MW, WP>), dim3((n_l + IPW - 1) / IPW), dim3(gpf::WAVE * WP), p.lds, \
-                       stream, e->d_params_s, lane0, list, p.cls_list, is_dc, max_iter, tol_pu);                                  \
-  } while (0)
-  if (p.tc) {
-#define LAUNCH_RUNPF_TC(IPW, WP)                                                                                                  \
-    do {                                                                                                                          \
-      static size_t lds_set_[64] = {0};                                                                                           \
-      if (p.lds > lds_set_[e->device & 63]) {                                                                                     \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_sparse_kernel<1, 0, IPW, 2, WP, true>),            \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                     \
-        lds_set_[e->device & 63] = p.lds;                                                                                         \
-      }                                                                                                                           \
-      hipLaunchKernelGGL((gpf::runpf_sparse_kernel<1, 0, IPW, 2, WP, true>), dim3((n_l + IPW - 1) / IPW), dim3(gpf::WAVE * WP),  \
-                         p.lds, stream, e->d_params_s, lane0, list, p.cls_list, is_dc, max_iter, tol_pu);                         \
-    } while (0)
-    if (p.ipw == 4) LAUNCH_RUNPF_TC(4, 1);
-    else if (p.ipw == 2) LAUNCH_RUNPF_TC(2, 1);
-    else if (p.wpi == 2) LAUNCH_RUNPF_TC(1, 2);
-    else LAUNCH_RUNPF_TC(1, 1);
-#undef LAUNCH_RUNPF_TC
-  } else
-  if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_RUNPF_SPARSE(1, 2, 4, 2, 1);
-  else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_RUNPF_SPARSE(1, 2, 2, 2, 1);
-  else if (p.sparse_nb == 1 && p.wpi == 2 && p.sparse_stage == 2) LAUNCH_RUNPF_SPARSE(1, 2, 1, 2, 2);
-  else if (p.sparse_nb == 1 && p.wpi == 2 && p.sparse_stage == 1) LAUNCH_RUNPF_SPARSE(1, 1, 1, 2, 2);
-  else if (p.sparse_nb == 1 && p.wpi == 2) LAUNCH_RUNPF_SPARSE(1, 0, 1, 2, 2);
-  else if (p.sparse_nb == 1 && p.wpi == 4 && p.sparse_stage == 2) LAUNCH_RUNPF_SPARSE(1, 2, 1, 2, 4);
-  else if (p.sparse_nb == 1 && p.wpi == 4 && p.sparse_stage == 1) LAUNCH_RUNPF_SPARSE(1, 1, 1, 2, 4);
-  else if (p.sparse_nb == 1 && p.wpi == 4) LAUNCH_RUNPF_SPARSE(1, 0, 1, 2, 4);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 2 && p.minw == 4) LAUNCH_RUNPF_SPARSE(1, 2, 1, 4, 1);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 2) LAUNCH_RUNPF_SPARSE(1, 2, 1, 2, 1);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 1 && p.minw == 4) LAUNCH_RUNPF_SPARSE(1, 1, 1, 4, 1);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 1) LAUNCH_RUNPF_SPARSE(1, 1, 1, 2, 1);
-  else if (p.sparse_nb == 1 && p.minw == 4) LAUNCH_RUNPF_SPARSE(1, 0, 1, 4, 1);
-  else if (p.sparse_nb == 1) LAUNCH_RUNPF_SPARSE(1, 0, 1, 2, 1);
-  else if (p.sparse_nb == 2 && p.wpi == 2 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(2, 1, 1, 2, 2);
-  else if (p.sparse_nb == 2 && p.wpi == 2) LAUNCH_RUNPF_SPARSE(2, 0, 1, 2, 2);
-  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(2, 1, 1, 2, 1);
-  else if (p.sparse_nb == 2) LAUNCH_RUNPF_SPARSE(2, 0, 1, 2, 1);
-  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_RUNPF_SPARSE(3, 1, 1, 2, 1);
-  else if (p.sparse_nb == 3) LAUNCH_RUNPF_SPARSE(3, 0, 1, 2, 1);
-#undef LAUNCH_RUNPF_SPARSE
-  HIP_TRY(hipGetLastError());
-  return GPF_OK;
-}
-
-static int launch_step_sparse(gpf_engine* e, const LaunchPlan& p, hipStream_t stream, int max_iter, double tol_pu, const gpf::StepArgs& sa) {
-  const int n_l = p.n_list ? p.n_list : e->n_lanes;
-  const int* list = p.n_list ? p.list : nullptr;
-#define LAUNCH_STEP_SPARSE(NBK, ST, IPW, MW, WP)                                                                                  \
-  do {                                                                                                                            \
-    static size_t lds_set_[64] = {0};                                                                                             \
-    if (p.lds > lds_set_[e->device & 63]) {                                                                                       \
-      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<NBK, ST, IPW, MW, WP>),                  \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                       \
-      lds_set_[e->device & 63] = p.lds;                                                                                           \
-    }                                                                                                                             \
-    hipLaunchKernelGGL((gpf::step_sparse_kernel<NBK, ST, IPW, MW, WP>), dim3((n_l + IPW - 1) / IPW), dim3(gpf::WAVE * WP), p.lds,  \
-                       stream, e->d_params_s, list, p.cls_list, max_iter, tol_pu, sa);                                            \
-  } while (0)
-  if (p.tc) {
-#define LAUNCH_STEP_TC(IPW, WP)                                                                                                   \
-    do {                                                                                                                          \
-      static size_t lds_set_[64] = {0};                                                                                           \
-      if (p.lds > lds_set_[e->device & 63]) {                                                                                     \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_sparse_kernel<1, 0, IPW, 2, WP, true>),             \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));                                     \
-        lds_set_[e->device & 63] = p.lds;                                                                                         \
-      }                                                                                                                           \
-      hipLaunchKernelGGL((gpf::step_sparse_kernel<1, 0, IPW, 2, WP, true>), dim3((n_l + IPW - 1) / IPW), dim3(gpf::WAVE * WP),   \
-                         p.lds, stream, e->d_params_s, list, p.cls_list, max_iter, tol_pu, sa);                                   \
-    } while (0)
-    if (p.ipw == 4) LAUNCH_STEP_TC(4, 1);
-    else if (p.ipw == 2) LAUNCH_STEP_TC(2, 1);
-    else if (p.wpi == 2) LAUNCH_STEP_TC(1, 2);
-    else LAUNCH_STEP_TC(1, 1);
-#undef LAUNCH_STEP_TC
-  } else
-  if (p.sparse_nb == 1 && p.ipw == 4) LAUNCH_STEP_SPARSE(1, 2, 4, 2, 1);
-  else if (p.sparse_nb == 1 && p.ipw == 2) LAUNCH_STEP_SPARSE(1, 2, 2, 2, 1);
-  else if (p.sparse_nb == 1 && p.wpi == 2 && p.sparse_stage == 2) LAUNCH_STEP_SPARSE(1, 2, 1, 2, 2);
-  else if (p.sparse_nb == 1 && p.wpi == 2 && p.sparse_stage == 1) LAUNCH_STEP_SPARSE(1, 1, 1, 2, 2);
-  else if (p.sparse_nb == 1 && p.wpi == 2) LAUNCH_STEP_SPARSE(1, 0, 1, 2, 2);
-  else if (p.sparse_nb == 1 && p.wpi == 4 && p.sparse_stage == 2) LAUNCH_STEP_SPARSE(1, 2, 1, 2, 4);
-  else if (p.sparse_nb == 1 && p.wpi == 4 && p.sparse_stage == 1) LAUNCH_STEP_SPARSE(1, 1, 1, 2, 4);
-  else if (p.sparse_nb == 1 && p.wpi == 4) LAUNCH_STEP_SPARSE(1, 0, 1, 2, 4);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 2 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 2, 1, 4, 1);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 2) LAUNCH_STEP_SPARSE(1, 2, 1, 2, 1);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 1 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 1, 1, 4, 1);
-  else if (p.sparse_nb == 1 && p.sparse_stage == 1) LAUNCH_STEP_SPARSE(1, 1, 1, 2, 1);
-  else if (p.sparse_nb == 1 && p.minw == 4) LAUNCH_STEP_SPARSE(1, 0, 1, 4, 1);
-  else if (p.sparse_nb == 1) LAUNCH_STEP_SPARSE(1, 0, 1, 2, 1);
-  else if (p.sparse_nb == 2 && p.wpi == 2 && p.sparse_stage) LAUNCH_STEP_SPARSE(2, 1, 1, 2, 2);
-  else if (p.sparse_nb == 2 && p.wpi == 2) LAUNCH_STEP_SPARSE(2, 0, 1, 2, 2);
-  else if (p.sparse_nb == 2 && p.sparse_stage) LAUNCH_STEP_SPARSE(2, 1, 1, 2, 1);
-  else if (p.sparse_nb == 2) LAUNCH_STEP_SPARSE(2, 0, 1, 2, 1);
-  else if (p.sparse_nb == 3 && p.sparse_stage) LAUNCH_STEP_SPARSE(3, 1, 1, 2, 1);
-  else if (p.sparse_nb == 3) LAUNCH_STEP_SPARSE(3, 0, 1, 2, 1);
-#undef LAUNCH_STEP_SPARSE
-  HIP_TRY(hipGetLastError());
-  return GPF_OK;
-}
-
 int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max_iter, double tol_mva) {
   if (!check_range(e, lane0, n)) return fail(GPF_E_INVALID, "gpf_runpf: bad range");
   if (n == 0) return GPF_OK;
@@ -1053,36 +900,14 @@ int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
   int rc = plan_launch(e, lane0, n, p, pb);
   if (rc != GPF_OK) return rc;
   gpf::Bufs b = e->bufs();
-  b.work_stride = (long long)work_stride(p);
   const double tol_pu = tol_mva / e->g.sn_mva;
   hipEvent_t ea = nullptr, eb = nullptr;
-  if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
-  if (p.sparse_nb) { rc = upload_params_s(e, b, p.tc ? &p : (pb.tc ? &pb : nullptr)); if (rc != GPF_OK) return rc; }
+  rc = upload_params_s(e, b, p.tc ? &p : (pb.tc ? &pb : nullptr));
+  if (rc != GPF_OK) return rc;
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
-  if (p.sparse_nb) {
-    // (measured: forking the second launch onto its own stream costs more in cross-stream events than the overlap gains)
-    rc = launch_runpf_sparse(e, p, e->stream, lane0, n, is_dc, max_iter, tol_pu);
-    if (rc == GPF_OK && pb.sparse_nb) rc = launch_runpf_sparse(e, pb, e->stream, lane0, n, is_dc, max_iter, tol_pu);
-    if (rc != GPF_OK) return rc;
-  }
-  else
-#define LAUNCH_RUNPF_SMALL(NM, LP)                                                                                              \
-  hipLaunchKernelGGL((gpf::runpf_small_kernel<NM, LP>), dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, lane0, p.nbc,   \
-                     p.nJ, is_dc, max_iter, tol_pu)
-  if (p.small_nmax == 24 && e->lpr1) LAUNCH_RUNPF_SMALL(24, 1);
-  else if (p.small_nmax == 24) LAUNCH_RUNPF_SMALL(24, 2);
-  else if (p.small_nmax == 32) LAUNCH_RUNPF_SMALL(32, 2);
-  else if (p.small_nmax == 48) LAUNCH_RUNPF_SMALL(48, 1);
-  else if (p.small_nmax == 64) LAUNCH_RUNPF_SMALL(64, 1);
-  else if (p.big) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
-    hipLaunchKernelGGL(gpf::runpf_kernel<true>, dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->g, b, e->oo, lane0, p.nbc, p.nJ,
-                       is_dc, max_iter, tol_pu);
-  } else {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::runpf_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
-    hipLaunchKernelGGL(gpf::runpf_kernel<false>, dim3(n), dim3(gpf::WAVE), p.lds, e->stream, e->g, b, e->oo, lane0, p.nbc, p.nJ,
-                       is_dc, max_iter, tol_pu);
-  }
+  // (measured: forking the second launch onto its own stream costs more in cross-stream events than the overlap gains)
+  HIP_TRY(gpf_launch_runpf_sparse(p, e->device, e->d_params_s, e->stream, lane0, n, is_dc, max_iter, tol_pu));
+  if (pb.sparse_nb) HIP_TRY(gpf_launch_runpf_sparse(pb, e->device, e->d_params_s, e->stream, lane0, n, is_dc, max_iter, tol_pu));
   HIP_TRY(hipGetLastError());
   if (e->profiling) HIP_TRY(hipEventRecord(eb, e->stream));
   if (e->window) ++e->win_launches;
@@ -1157,51 +982,92 @@ int gpf_set_thermal_limits(gpf_handle e, const float* limit_a) {
   return GPF_OK;
 }
 
-int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double rebalance, int32_t cascade, float hard_overflow,
-             float soft_overflow, int32_t nb_ts_allowed, int32_t max_rounds, int32_t is_dc) {
-  if (!e) return fail(GPF_E_INVALID, "gpf_step: null");
-  if (!e->chron.p || e->chron_T <= 0) return fail(GPF_E_INVALID, "gpf_step: no chronics uploaded");
+int gpf_step_n(gpf_handle e, int32_t t0, int32_t n_steps, const gpf_step_opts* o) {
+  if (!e || !o) return fail(GPF_E_INVALID, "gpf_step_n: null");
+  if (n_steps <= 0) return fail(GPF_E_INVALID, "gpf_step_n: n_steps must be positive");
+  if (!e->chron.p || e->chron_T <= 0) return fail(GPF_E_INVALID, "gpf_step_n: no chronics uploaded");
   HIP_TRY(hipSetDevice(e->device));
   LaunchPlan p, pb;
   int rc = plan_launch(e, 0, e->n_lanes, p, pb);
   if (rc != GPF_OK) return rc;
+  if (n_steps > 1 && pb.sparse_nb)
+    return fail(GPF_E_INVALID, "gpf_step_n: multi-step launches need a batch that runs as ONE launch (mixed split / unsplit lanes "
+                               "without topology classes run as two): use n_steps = 1");
   gpf::Bufs b = e->bufs();
-  b.work_stride = (long long)work_stride(p);
   gpf::StepArgs sa{};
-  sa.t = t; sa.T = e->chron_T; sa.rebalance_on = rebalance > 0.0 ? 1 : 0; sa.rebalance = rebalance; sa.cascade = cascade;
-  sa.is_dc = is_dc ? 1 : 0;
-  sa.nb_ts_allowed = nb_ts_allowed; sa.max_rounds = max_rounds; sa.hard_overflow = hard_overflow; sa.soft_overflow = soft_overflow;
-  const double tol_pu = tol_mva / e->g.sn_mva;
+  sa.t = t0; sa.T = e->chron_T; sa.rebalance_on = o->rebalance > 0.0 ? 1 : 0; sa.rebalance = o->rebalance; sa.cascade = o->cascade;
+  sa.is_dc = o->is_dc ? 1 : 0; sa.n_steps = n_steps; sa.auto_reset = o->auto_reset ? 1 : 0;
+  sa.nb_ts_allowed = o->nb_ts_allowed; sa.max_rounds = o->max_rounds; sa.hard_overflow = o->hard_overflow; sa.soft_overflow = o->soft_overflow;
+  const double tol_pu = o->tol_mva / e->g.sn_mva;
   hipEvent_t ea = nullptr, eb = nullptr;
-  if (p.small_nmax) { rc = upload_params(e, b); if (rc != GPF_OK) return rc; }
-  if (p.sparse_nb) { rc = upload_params_s(e, b, p.tc ? &p : (pb.tc ? &pb : nullptr)); if (rc != GPF_OK) return rc; }
+  rc = upload_params_s(e, b, p.tc ? &p : (pb.tc ? &pb : nullptr));
+  if (rc != GPF_OK) return rc;
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
-  if (p.sparse_nb) {
-    rc = launch_step_sparse(e, p, e->stream, max_iter, tol_pu, sa);
-    if (rc == GPF_OK && pb.sparse_nb) rc = launch_step_sparse(e, pb, e->stream, max_iter, tol_pu, sa);
-    if (rc != GPF_OK) return rc;
-  }
-  else
-#define LAUNCH_STEP_SMALL(NM, LP)                                                                                               \
-  hipLaunchKernelGGL((gpf::step_small_kernel<NM, LP>), dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->d_params, p.nbc,   \
-                     p.nJ, max_iter, tol_pu, sa)
-  if (p.small_nmax == 24 && e->lpr1) LAUNCH_STEP_SMALL(24, 1);
-  else if (p.small_nmax == 24) LAUNCH_STEP_SMALL(24, 2);
-  else if (p.small_nmax == 32) LAUNCH_STEP_SMALL(32, 2);
-  else if (p.small_nmax == 48) LAUNCH_STEP_SMALL(48, 1);
-  else if (p.small_nmax == 64) LAUNCH_STEP_SMALL(64, 1);
-  else if (p.big) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
-    hipLaunchKernelGGL(gpf::step_kernel<true>, dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->g, b, e->oo, p.nbc, p.nJ,
-                       max_iter, tol_pu, sa);
-  } else {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::step_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
-    hipLaunchKernelGGL(gpf::step_kernel<false>, dim3(e->n_lanes), dim3(gpf::WAVE), p.lds, e->stream, e->g, b, e->oo, p.nbc, p.nJ,
-                       max_iter, tol_pu, sa);
-  }
+  HIP_TRY(gpf_launch_step_sparse(p, e->device, e->d_params_s, e->stream, e->n_lanes, o->max_iter, tol_pu, sa));
+  if (pb.sparse_nb) HIP_TRY(gpf_launch_step_sparse(pb, e->device, e->d_params_s, e->stream, e->n_lanes, o->max_iter, tol_pu, sa));
   HIP_TRY(hipGetLastError());
   if (e->profiling) HIP_TRY(hipEventRecord(eb, e->stream));
   if (e->window) ++e->win_launches;
+  return GPF_OK;
+}
+
+int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double rebalance, int32_t cascade, float hard_overflow,
+             float soft_overflow, int32_t nb_ts_allowed, int32_t max_rounds, int32_t is_dc) {
+  gpf_step_opts o{};
+  o.max_iter = max_iter; o.tol_mva = tol_mva; o.rebalance = rebalance; o.cascade = cascade; o.hard_overflow = hard_overflow;
+  o.soft_overflow = soft_overflow; o.nb_ts_allowed = nb_ts_allowed; o.max_rounds = max_rounds; o.is_dc = is_dc; o.auto_reset = 0;
+  return gpf_step_n(e, t, 1, &o);
+}
+
+int gpf_set_lane_redispatch(gpf_handle e, const float* delta_mw) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_set_lane_redispatch: null");
+  HIP_TRY(hipSetDevice(e->device));
+  if (!delta_mw) { e->has_delta = false; return GPF_OK; }
+  const size_t n = (size_t)e->cap_lanes * e->g.n_gen;
+  if (!e->lane_gen_delta.p) { HIP_TRY(e->lane_gen_delta.alloc(n)); HIP_TRY(hipMemsetAsync(e->lane_gen_delta.p, 0, n * sizeof(float), e->stream)); }
+  HIP_TRY(hipMemcpyAsync(e->lane_gen_delta.p, delta_mw, (size_t)e->n_lanes * e->g.n_gen * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->has_delta = true;
+  return GPF_OK;
+}
+
+int gpf_set_trajectory(gpf_handle e, int32_t n_steps_cap) {
+  if (!e || n_steps_cap < 0) return fail(GPF_E_INVALID, "gpf_set_trajectory: bad arguments");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->traj_rho.release(); e->traj_status.release();
+  e->traj_cap = 0;
+  if (n_steps_cap > 0) {
+    HIP_TRY(e->traj_rho.alloc((size_t)n_steps_cap * e->cap_lanes * e->g.n_line));
+    HIP_TRY(e->traj_status.alloc((size_t)n_steps_cap * e->cap_lanes));
+    HIP_TRY(hipMemset(e->traj_status.p, 0xFF, (size_t)n_steps_cap * e->cap_lanes));
+    e->traj_cap = n_steps_cap;
+  }
+  return GPF_OK;
+}
+
+int gpf_get_trajectory(gpf_handle e, int32_t step0, int32_t n_steps, int32_t lane0, int32_t n, float* rho, int8_t* status) {
+  if (!check_range(e, lane0, n) || step0 < 0 || n_steps < 0 || step0 + n_steps > e->traj_cap)
+    return fail(GPF_E_INVALID, "gpf_get_trajectory: bad range (gpf_set_trajectory sizes the buffer)");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t nl = e->g.n_line, B = e->cap_lanes;
+  if (rho)
+    HIP_TRY(hipMemcpy2DAsync(rho, (size_t)n * nl * sizeof(float), e->traj_rho.p + ((size_t)step0 * B + lane0) * nl, B * nl * sizeof(float),
+                             (size_t)n * nl * sizeof(float), (size_t)n_steps, hipMemcpyDeviceToHost, e->stream));
+  if (status)
+    HIP_TRY(hipMemcpy2DAsync(status, (size_t)n, e->traj_status.p + (size_t)step0 * B + lane0, B, (size_t)n, (size_t)n_steps,
+                             hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_get_episode(gpf_handle e, int32_t lane0, int32_t n, uint8_t* done, int32_t* steps_and_resets) {
+  if (!check_range(e, lane0, n)) return fail(GPF_E_INVALID, "gpf_get_episode: bad range");
+  HIP_TRY(hipSetDevice(e->device));
+  if (done) HIP_TRY(hipMemcpyAsync(done, e->done.p + lane0, (size_t)n, hipMemcpyDeviceToHost, e->stream));
+  if (steps_and_resets)
+    HIP_TRY(hipMemcpyAsync(steps_and_resets, e->episode.p + (size_t)lane0 * 2, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
   return GPF_OK;
 }
 
@@ -1475,6 +1341,8 @@ int gpf_device_pointers(gpf_handle e, void** ptrs, void** stream) {
   if (!e || !ptrs) return fail(GPF_E_INVALID, "gpf_device_pointers: null");
   ptrs[0] = e->inj.p; ptrs[1] = e->topo.p; ptrs[2] = e->shunt_bus.p; ptrs[3] = e->out.p; ptrs[4] = e->topo_out.p;
   ptrs[5] = e->line_status.p; ptrs[6] = e->status.p; ptrs[7] = e->chron.p;
+  ptrs[8] = e->rho.p; ptrs[9] = e->overflow_count.p; ptrs[10] = e->done.p; ptrs[11] = e->episode.p; ptrs[12] = e->bus_vm.p;
+  ptrs[13] = e->bus_va.p; ptrs[14] = e->shunt_bus_out.p; ptrs[15] = e->disc_round.p;
   if (stream) *stream = e->stream;
   return GPF_OK;
 }

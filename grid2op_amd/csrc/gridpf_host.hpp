@@ -1,0 +1,28 @@
+// gridpf_host.hpp -- host-side declarations shared by the translation units of libgridpf.so: the launch plan of kernel S and
+// the two dispatchers (the template instantiations of the power-flow kernel and of the step kernel are compiled in
+// separate translation units so that they build in parallel).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gridpf_sparse.hpp"
+
+struct LaunchPlan {
+  size_t lds;
+  int sparse_nb;    // 0: no launch; 1..3: block-sparse kernel S with NB busbars per substation block
+  int minw;         // kernel S: __launch_bounds__ waves per SIMD (4 caps the kernel at 128 VGPRs: only worth it when LDS allows > 8 blocks per CU)
+  bool tc;          // topology-class launch: single-busbar kernel on the bus-level graph of each lane's class (cls_list)
+  const int* cls_list;
+  int tc_rows, tc_nslot, tc_nslot_y;
+  int n_list;       // > 0: this plan covers n_list lanes given by a device index list (mixed batches), else a contiguous range
+  const int* list;  // device pointer (padded with a ghost lane to a multiple of ipw)
+  int wpi;          // kernel S: wavefronts per instance (1, 2 or 4; > 1 only for NB == 1, IPW == 1 on large grids)
+  int ipw;          // kernel S: grid instances per wavefront (1, 2 or 4; > 1 only for NB == 1 on small grids)
+  int sparse_stage;  // 0: static tables read in place (L2), 1: program + pair table + injection row in LDS, 2: everything in LDS // program staged in LDS (small grids) or streamed from L2 (keeps 3 instances per CU on 118-bus grids)
+};
+
+
+// dispatch of the kernel-S variants (gridpf_launch_runpf.hip / gridpf_launch_step.hip); they return the HIP status of the launch
+hipError_t gpf_launch_runpf_sparse(const LaunchPlan& p, int device, const gpf::DevParamsS* d_params, hipStream_t stream, int lane0, int n,
+                                   int is_dc, int max_iter, double tol_pu);
+hipError_t gpf_launch_step_sparse(const LaunchPlan& p, int device, const gpf::DevParamsS* d_params, hipStream_t stream, int n_lanes,
+                                  int max_iter, double tol_pu, const gpf::StepArgs& sa);

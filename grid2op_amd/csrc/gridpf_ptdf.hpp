@@ -7,7 +7,7 @@
 // -- the one GEMM-shaped operation of this code base, on the FP64 matrix cores (v_mfma_f64_16x16x4_f64; the lane
 // layout of its operands / results was probed on gfx950 with tools/mfma_probe.hip).
 #pragma once
-#include "gridpf_kernels.hpp"
+#include "gridpf_common.hpp"
 
 namespace gpf {
 

@@ -11,7 +11,7 @@
 // array.  Assembly uses native LDS f64 atomics from branch / element lanes; the pipeline (K9, K1..K7) and the
 // arithmetic conventions are those of gridpf_kernels.hpp / gridpf_small.hpp.
 #pragma once
-#include "gridpf_small.hpp"
+#include "gridpf_common.hpp"
 
 namespace gpf {
 
@@ -26,7 +26,7 @@ struct StatOff {
       sto_sub, shunt_sub, pair_rc, prog;
 };
 // Pointer to a static table that is either staged in LDS or read in place: in place it is re-typed as a GLOBAL pointer
-// (gptr, gridpf_kernels.hpp) so that global_load is emitted instead of flat_load.
+// (gptr, gridpf_common.hpp) so that global_load is emitted instead of flat_load.
 template <class T, bool IN_LDS>
 struct SP {
   const T* p;
@@ -94,6 +94,7 @@ struct DevParamsS {
   const TopoClassDev* classes;   // device array (topology-class launches), else nullptr
   int tc_rows;                   // LDS sizing of a topology-class launch: max number of nodes ...
   int tc_nslot, tc_nslot_y;      // ... blocks incl. fill / original-pattern blocks over the classes of the launch
+  int dcf;                       // the LDS layout has room for the factored DC matrix (CarveP::Adc): the step kernel keeps it across steps
 };
 
 // -DGPF_TIMING developer build: cycle-counter stamps are kept in REGISTERS (a global store per stamp would be waited for
@@ -135,8 +136,10 @@ struct CarveP {
   double *vm, *va, *e, *f, *Psp, *Qsp, *Sre, *Sim;   // [nbus]
   double* Gs;     // [nbus] aliases e (shunt conductance: only needed before the Newton loop and by the DC results)
   double* inj;    // [n_inj] staged injection row (only when STAGE; otherwise the lane's row in HBM/L2 is read directly)
+  double* Adc;    // [nslot] factored scalar DC matrix kept across the solves of a launch (only when the plan says so, NB == 1)
   int* btype;     // [nbus]
-  int *lab, *vidx;   // [nbus] alias Sre / Sim (connectivity labels, last-generator index: dead before the Newton loop)
+  int* vidx;      // [nbus] last in-service generator of a bus (voltage set-point), -1: none; kept across the solves of a launch
+  int* lab;       // [nbus] aliases Sre (connectivity labels: dead before the Newton loop)
   int* topo;      // alias of A during K1
   i16 *lor_b, *lex_b, *gen_b, *load_b, *sto_b, *sh_b;
   i8* sub_bb;     // [n_sub] live busbar (local id) of each substation (NB == 1)
@@ -144,23 +147,23 @@ struct CarveP {
 
 // LDS bytes of ONE instance (without the program copy, which is shared by the IPW instances of a block).
 template <int NB>
-__host__ __device__ inline size_t lds_bytes_instance(const GridDev& g, int nslot, int nslot_y, bool stage_inj, int n_rows = -1) {
+__host__ __device__ inline size_t lds_bytes_instance(const GridDev& g, int nslot, int nslot_y, bool stage_inj, int n_rows = -1, bool dcf = false) {
   constexpr int BS = 2 * NB;
   const size_t rows = n_rows > 0 ? (size_t)n_rows : (size_t)g.n_sub;      // block rows: substations, or nodes of a topology class
   const size_t nbus = rows * NB;
   size_t a_d = (size_t)nslot * BS * BS;
   const size_t topo_d = (((size_t)g.dim_topo + 1) / 2 + 2) & ~(size_t)1;
   if (a_d < topo_d) a_d = topo_d;
-  const size_t nd = a_d + (size_t)nslot_y * NB * NB * 2 + rows * BS + 8 * nbus + (stage_inj ? (size_t)g.n_inj : 0);
-  const size_t ni = nbus;
+  const size_t nd = a_d + (size_t)nslot_y * NB * NB * 2 + rows * BS + 8 * nbus + (stage_inj ? (size_t)g.n_inj : 0) + (dcf ? (size_t)nslot : 0);
+  const size_t ni = 2 * nbus;
   const size_t n16 = 2 * (size_t)g.n_line + g.n_gen + g.n_load + g.n_sto + g.n_shunt;
   return (nd * 8 + ni * 4 + n16 * 2 + g.n_sub + 15) & ~(size_t)15;
 }
 // dynamic LDS of a block: IPW instances + (when staged) one copy of the static blob (stat_bytes, 0 when not staged)
 template <int NB>
 __host__ __device__ inline size_t lds_bytes_sparse(const GridDev& g, int nslot, int nslot_y, size_t static_bytes, bool stage_inj, int ipw = 1,
-                                                   int n_rows = -1) {
-  return (size_t)ipw * lds_bytes_instance<NB>(g, nslot, nslot_y, stage_inj, n_rows) + static_bytes;
+                                                   int n_rows = -1, bool dcf = false) {
+  return (size_t)ipw * lds_bytes_instance<NB>(g, nslot, nslot_y, stage_inj, n_rows, dcf) + static_bytes;
 }
 
 // Stage the static blob in LDS (STAGE) or view it in place; visible to the block after the first barrier.
@@ -187,7 +190,7 @@ __device__ inline void make_stat_view(StatView<STAGE>& sv, const SymDev& S, unsi
 
 template <int NB>
 __device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const GridDev& g, int nslot, int nslot_y, bool stage_inj,
-                                    int n_rows = -1) {
+                                    int n_rows = -1, bool dcf = false) {
   constexpr int BS = 2 * NB;
   const size_t rows = n_rows > 0 ? (size_t)n_rows : (size_t)g.n_sub;
   const size_t nbus = rows * NB;
@@ -201,10 +204,12 @@ __device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const Gr
   c.vm = d; d += nbus; c.va = d; d += nbus; c.e = d; c.Gs = d; d += nbus; c.f = d; d += nbus;
   c.Psp = d; d += nbus; c.Qsp = d; d += nbus;
   c.Sre = d; c.lab = reinterpret_cast<int*>(d); d += nbus;
-  c.Sim = d; c.vidx = reinterpret_cast<int*>(d); d += nbus;
+  c.Sim = d; d += nbus;
   c.inj = d; if (stage_inj) d += g.n_inj;
+  c.Adc = d; if (dcf) d += nslot;
   int* i = reinterpret_cast<int*>(d);
   c.btype = i; i += nbus;
+  c.vidx = i; i += nbus;
   i16* q = reinterpret_cast<i16*>(i);
   c.lor_b = q; q += g.n_line; c.lex_b = q; q += g.n_line;
   c.gen_b = q; q += g.n_gen; c.load_b = q; q += g.n_load; c.sto_b = q; q += g.n_sto; c.sh_b = q; q += g.n_shunt;
@@ -562,9 +567,12 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
 }
 
 // Scalar variant for the DC system of the NB == 1 layout: B' theta = P only couples the theta entries, i.e. element [0][0] of
-// every 2x2 block (A[2 * slot] in the split-row layout of block_lu_solve) and rhs[2p] (the |V| rows are identity), so the same program is run on scalars: a quarter of the LDS
-// traffic and a fraction of the arithmetic of the block solve.
-template <int GW, class PP = const int*>
+// every 2x2 block (A[2 * slot] in the split-row layout of block_lu_solve, STRIDE = 2) and rhs[2p] (the |V| rows are identity),
+// so the same program is run on scalars: a quarter of the LDS traffic and a fraction of the arithmetic of the block solve.
+// FACTOR = false: A already holds the FACTORED matrix of an earlier solve with the same topology (L and D as left by the
+// forward sweep, U scaled by the deferred pass -- the forward sweep never reads U', the back substitution never reads L), so only
+// the right-hand-side items, the pivot scaling and the back substitution run (STRIDE = 1: the compact copy CarveP::Adc).
+template <int GW, int STRIDE, bool FACTOR, class PP = const int*>
 __device__ inline bool scalar_lu_solve(const SymDev& S, PP prog, double* __restrict__ A,
                                        double* __restrict__ rhs, int tid, long long* dbg = nullptr) {
 #ifdef GPF_TIMING
@@ -573,44 +581,46 @@ __device__ inline bool scalar_lu_solve(const SymDev& S, PP prog, double* __restr
   bool ok = true;
   const int n_levels = S.n_levels;
   auto hdr4 = [&](int k) -> int4 { return make_int4(prog[4 * k], prog[4 * k + 1], prog[4 * k + 2], prog[4 * k + 3]); };
+  auto first = [&](const int4& h) -> int { return FACTOR ? 0 : h.y; };       // r-items follow the c-items
   auto item_words = [&](const int4& h, int o, unsigned& w0, unsigned& w1) {
     const int at = h.x + 2 * (o < h.y + h.w ? o : 0);
     w0 = (unsigned)prog[at]; w1 = (unsigned)prog[at + 1];
   };
   auto do_item = [&](const int4& h, int o, unsigned w0, unsigned w1) {
     if (o >= h.y + h.w) return;
-    const bool is_c = o < h.y;
+    const bool is_c = FACTOR && o < h.y;
     const unsigned l = is_c ? (w0 >> 16) : (w0 & 0xffffu), dd = is_c ? (w0 & 0xffffu) : (w0 >> 16);
     const unsigned p = is_c ? (w1 >> 16) : w1, u = w1 & 0xffffu;
-    const double d = A[(size_t)p * 2], al = A[(size_t)l * 2];
-    const double x = is_c ? A[(size_t)u * 2] : rhs[(size_t)p * 2];
-    double* dst = is_c ? (A + (size_t)dd * 2) : (rhs + (size_t)dd * 2);
+    const double d = A[(size_t)p * STRIDE], al = A[(size_t)l * STRIDE];
+    const double x = is_c ? A[(size_t)u * STRIDE] : rhs[(size_t)p * 2];
+    double* dst = is_c ? (A + (size_t)dd * STRIDE) : (rhs + (size_t)dd * 2);
     atomicAdd(dst, -(al * x) * fast_rcp(d));
   };
   int4 h0 = hdr4(1), h1 = n_levels > 1 ? hdr4(3) : make_int4(0, 0, 0, 0);
   unsigned w0, w1;
-  item_words(h0, tid, w0, w1);
+  item_words(h0, first(h0) + tid, w0, w1);
   for (int lv = 0; lv < n_levels; ++lv) {
     const int4 h2 = lv + 2 < n_levels ? hdr4(2 * (lv + 2) + 1) : make_int4(0, 0, 0, 0);
     unsigned nw0, nw1;
-    item_words(h1, tid, nw0, nw1);
-    do_item(h0, tid, w0, w1);
-    for (int o = tid + GW; o < h0.y + h0.w; o += GW) {
+    item_words(h1, first(h1) + tid, nw0, nw1);
+    do_item(h0, first(h0) + tid, w0, w1);
+    for (int o = first(h0) + tid + GW; o < h0.y + h0.w; o += GW) {
       unsigned v0, v1;
       item_words(h0, o, v0, v1);
       do_item(h0, o, v0, v1);
     }
-    GPF_SYNC();
+    if (FACTOR || h0.w > 0) GPF_SYNC();               // (h0 is uniform over the block)
     h0 = h1; h1 = h2; w0 = nw0; w1 = nw1;
   }
+  if (FACTOR)
   for (int e = tid; e < S.n_scale; e += GW) {
     const unsigned w = (unsigned)prog[S.scale_off + e];
-    double* au = A + (size_t)(w & 0xffffu) * 2;
-    *au = *au * fast_rcp(A[(size_t)(w >> 16) * 2]);
+    double* au = A + (size_t)(w & 0xffffu) * STRIDE;
+    *au = *au * fast_rcp(A[(size_t)(w >> 16) * STRIDE]);
   }
   for (int p = tid; p < S.n; p += GW) {
-    const double d = A[(size_t)p * 2];
-    if (!(fabs(d) > 1e-300) || !(fabs(d) < 1e300)) ok = false;
+    const double d = A[(size_t)p * STRIDE];
+    if (FACTOR && (!(fabs(d) > 1e-300) || !(fabs(d) < 1e300))) ok = false;
     rhs[(size_t)p * 2] *= fast_rcp(d);
   }
   GPF_SYNC();
@@ -625,7 +635,7 @@ __device__ inline bool scalar_lu_solve(const SymDev& S, PP prog, double* __restr
     };
     auto item = [&](const int2& h, int o, unsigned w, int p) {
       if (o >= h.y) return;
-      atomicAdd(&rhs[(size_t)p * 2], -A[(size_t)(w & 0xffffu) * 2] * rhs[(size_t)(w >> 16) * 2]);
+      atomicAdd(&rhs[(size_t)p * 2], -A[(size_t)(w & 0xffffu) * STRIDE] * rhs[(size_t)(w >> 16) * 2]);
     };
     int2 g0 = hdr(S.back_first), g1 = hdr(S.back_first - 1);
     unsigned w; int p;
@@ -650,13 +660,28 @@ __device__ inline bool scalar_lu_solve(const SymDev& S, PP prog, double* __restr
   return ok;
 }
 
+// What a solve may take over from the previous solve of the same block (multi-step launches, cascade rounds).
+struct SolveCtl {
+  bool inj_staged;    // the injection row is already in CarveP::inj
+  bool topo_staged;   // the topology row is already in CarveP::topo
+  bool reuse;         // BLOCK-UNIFORM: same topology as the previous solve of this block -> the element->bus maps, bus types,
+                      // connectivity verdict and Ybus blocks in LDS are valid (and the DC factors when dcf)
+  bool dcf;           // CarveP::Adc holds / receives the factored DC matrix (NB == 1)
+  bool write_bus;     // write the float64 bus voltages (parity checks, the facade's stale-bus angles)
+};
+// per-group results of the topology phases, kept by the caller across solves
+struct TopoState {
+  int status;         // 0, GPF_ST_NOSLACK or GPF_ST_ISLANDED
+  int nb;             // number of active buses
+};
+
 // ---------------------------------------------------------------------------------------------------
 // One complete power flow of the IPW instances of a wavefront (tid = lane within the instance group).  Returns the GPF_ST_*
 // status of the caller's group.  Groups share the instruction stream: a group that has failed or finished keeps executing
 // (its state is frozen / its results are overwritten by the caller), so barriers stay wave-uniform.
 template <int NB, int STAGE, int IPW, int WPI, bool TC>
 __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, const SymDev& S, const StatView<STAGE>& sv, CarveP<NB>& c, int inst, int is_dc, int max_iter,
-                                            double tol_pu, int tid, bool inj_staged, bool topo_staged, int& n_iter_out, int& nb_out GPF_STAMPS_PARAM) {
+                                            double tol_pu, int tid, const SolveCtl& ctl, TopoState& ts, int& n_iter_out, int& nb_out GPF_STAMPS_PARAM) {
   typedef Grp<IPW, WPI> G;
   constexpr int GW = G::GW;
   constexpr int BS = 2 * NB;
@@ -678,19 +703,22 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   nb_out = 0;
   GPF_STAMPS(0);
   const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj;
-  if (STAGE && !inj_staged) {
+  if (STAGE && !ctl.inj_staged) {
     for (int i = tid; i < g.n_inj; i += GW) c.inj[i] = inj_g[i];
   }
+  const bool reuse = ctl.reuse;
+  const bool dc_kept = reuse && ctl.dcf && NB == 1;        // the factored DC matrix of the previous solve is still valid
 #define GPF_INJ(i_) (STAGE ? c.inj[(i_)] : (double)inj_g[(i_)])      /* staged row in LDS, else the lane's row in HBM / L2 */
   const double sn = g.sn_mva, inv_sn = 1.0 / sn;
 
   // ---- K1: element -> bus, bus activity / types / injections with LDS atomics from the element lanes ---------------------
-  if (!topo_staged) for (int i = tid; i < g.dim_topo; i += GW) c.topo[i] = topo_g[i];
+  // (reuse: the maps and types of the previous solve stand, only the injection sums are rebuilt)
+  if (!reuse && !ctl.topo_staged) for (int i = tid; i < g.dim_topo; i += GW) c.topo[i] = topo_g[i];
   for (int i = tid; i < nbus; i += GW) {
-    c.btype[i] = BT_OFF; c.vidx[i] = -1;
+    if (!reuse) { c.btype[i] = BT_OFF; c.vidx[i] = -1; }
     c.Psp[i] = 0.0; c.Qsp[i] = 0.0; c.Gs[i] = 0.0;
   }
-  if (NB == 1 && !TC) for (int i = tid; i < nsub; i += GW) c.sub_bb[i] = 1;
+  if (NB == 1 && !TC && !reuse) for (int i = tid; i < nsub; i += GW) c.sub_bb[i] = 1;
   GPF_SYNC();
   GPF_STAMPS(27);
   const int* topo = c.topo;
@@ -699,6 +727,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     return (NB == 1) ? sub : sub * NB + (local - 1);
   };
   bool line_off = false;
+  if (!reuse)
   for (int l = tid; l < g.n_line; l += GW) {
     const int bo = topo[sv.line_or_pos[l]], be = topo[sv.line_ex_pos[l]];
     const bool on = (bo >= 1) && (be >= 1);
@@ -714,52 +743,68 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     }
   }
   for (int i = tid; i < g.n_gen; i += GW) {
-    const int lb = topo[sv.gen_pos[i]];
-    const int sb = sv.gen_sub[i];
-    const int bu = lb >= 1 ? bus_of(sb, lb) : -1;
-    c.gen_b[i] = (i16)bu;
-    if (bu >= 0) {
-      const bool sl = sv.gen_slack[i] != 0;
-      atomicMax(&c.btype[bu], sl ? BT_REF : BT_PV);
-      if (!sl) atomicAdd(&c.Psp[bu], GPF_INJ(oo.inj_gen_p + i) * inv_sn);
-      atomicMax(&c.vidx[bu], i);
-      if (NB == 1 && !TC) c.sub_bb[sb] = (i8)lb;
-    }
+    int bu;
+    const bool sl = sv.gen_slack[i] != 0;
+    if (!reuse) {
+      const int lb = topo[sv.gen_pos[i]];
+      const int sb = sv.gen_sub[i];
+      bu = lb >= 1 ? bus_of(sb, lb) : -1;
+      c.gen_b[i] = (i16)bu;
+      if (bu >= 0) {
+        atomicMax(&c.btype[bu], sl ? BT_REF : BT_PV);
+        atomicMax(&c.vidx[bu], i);
+        if (NB == 1 && !TC) c.sub_bb[sb] = (i8)lb;
+      }
+    } else bu = c.gen_b[i];
+    if (bu >= 0 && !sl) atomicAdd(&c.Psp[bu], GPF_INJ(oo.inj_gen_p + i) * inv_sn);
   }
   for (int i = tid; i < g.n_load; i += GW) {
-    const int lb = topo[sv.load_pos[i]];
-    const int sb = sv.load_sub[i];
-    const int bu = lb >= 1 ? bus_of(sb, lb) : -1;
-    c.load_b[i] = (i16)bu;
+    int bu;
+    if (!reuse) {
+      const int lb = topo[sv.load_pos[i]];
+      const int sb = sv.load_sub[i];
+      bu = lb >= 1 ? bus_of(sb, lb) : -1;
+      c.load_b[i] = (i16)bu;
+      if (bu >= 0) {
+        atomicMax(&c.btype[bu], BT_PQ);
+        if (NB == 1 && !TC) c.sub_bb[sb] = (i8)lb;
+      }
+    } else bu = c.load_b[i];
     if (bu >= 0) {
-      atomicMax(&c.btype[bu], BT_PQ);
       atomicAdd(&c.Psp[bu], -GPF_INJ(oo.inj_load_p + i) * inv_sn);
       atomicAdd(&c.Qsp[bu], -GPF_INJ(oo.inj_load_q + i) * inv_sn);
-      if (NB == 1 && !TC) c.sub_bb[sb] = (i8)lb;
     }
   }
   for (int i = tid; i < g.n_sto; i += GW) {
-    const int lb = topo[sv.sto_pos[i]];
-    const int sb = sv.sto_sub[i];
-    const int bu = lb >= 1 ? bus_of(sb, lb) : -1;
-    c.sto_b[i] = (i16)bu;
+    int bu;
+    if (!reuse) {
+      const int lb = topo[sv.sto_pos[i]];
+      const int sb = sv.sto_sub[i];
+      bu = lb >= 1 ? bus_of(sb, lb) : -1;
+      c.sto_b[i] = (i16)bu;
+      if (bu >= 0) {
+        atomicMax(&c.btype[bu], BT_PQ);
+        if (NB == 1 && !TC) c.sub_bb[sb] = (i8)lb;
+      }
+    } else bu = c.sto_b[i];
     if (bu >= 0) {
-      atomicMax(&c.btype[bu], BT_PQ);
       atomicAdd(&c.Psp[bu], -GPF_INJ(oo.inj_sto_p + i) * inv_sn);
       atomicAdd(&c.Qsp[bu], -GPF_INJ(oo.inj_sto_q + i) * inv_sn);
-      if (NB == 1 && !TC) c.sub_bb[sb] = (i8)lb;
     }
   }
   for (int i = tid; i < g.n_shunt; i += GW) {
-    const int lb = shb[i];
-    const int sb = sv.shunt_sub[i];
-    const int bu = lb >= 1 ? bus_of(sb, lb) : -1;
-    c.sh_b[i] = (i16)bu;
-    if (bu >= 0) {
-      atomicMax(&c.btype[bu], BT_PQ);
-      atomicAdd(&c.Gs[bu], GPF_INJ(oo.inj_sh_p + i) * sv.shunt_fact[i] * inv_sn);
-      if (NB == 1 && !TC) c.sub_bb[sb] = (i8)lb;
-    }
+    int bu;
+    if (!reuse) {
+      const int lb = shb[i];
+      const int sb = sv.shunt_sub[i];
+      bu = lb >= 1 ? bus_of(sb, lb) : -1;
+      c.sh_b[i] = (i16)bu;
+      if (bu >= 0) {
+        atomicMax(&c.btype[bu], BT_PQ);
+        if (NB == 1 && !TC) c.sub_bb[sb] = (i8)lb;
+      }
+    } else bu = c.sh_b[i];
+    if (bu >= 0) atomicAdd(&c.Gs[bu], GPF_INJ(oo.inj_sh_p + i) * sv.shunt_fact[i] * inv_sn);
   }
   GPF_SYNC();
   GPF_STAMPS(28);
@@ -771,14 +816,18 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       const int vi = c.vidx[i];
       // initial |V|: set-point of the last in-service generator on PV / reference buses, 1 pu elsewhere
       c.vm[i] = (vi >= 0 && (bt == BT_PV || bt == BT_REF)) ? GPF_INJ(oo.inj_gen_vm + vi) : 1.0;
-      c.lab[i] = (bt == BT_REF) ? 1 : 0;
+      if (!reuse) c.lab[i] = (bt == BT_REF) ? 1 : 0;
     }
-    nb += G::count(bt != BT_OFF);
-    nref += G::count(bt == BT_REF);
+    if (!reuse) {
+      nb += G::count(bt != BT_OFF);
+      nref += G::count(bt == BT_REF);
+    }
   }
+  if (reuse) nb = ts.nb;
   nb_out = nb;
   GPF_SYNC();
-  int status = (nref == 0) ? 3 : 0;           // first failure of this group (0 = alive)
+  int status = reuse ? ts.status : ((nref == 0) ? 3 : 0);           // first failure of this group (0 = alive)
+  if (!reuse) { ts.status = status; ts.nb = nb; }
   if (G::block_all(status != 0)) return status;
   GPF_STAMPS(1);
 
@@ -786,6 +835,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   // With one live busbar per substation and every line in service the bus graph IS the static substation graph, whose
   // connectivity the host checked at gpf_create: nothing to propagate (the DoNothing case).  Otherwise label propagation
   // from the reference buses.
+  if (!reuse) {
   const bool conn_known = (NB == 1) && S.static_connected && !G::any(line_off);
   if (!G::block_all(conn_known))
   for (int sweep = 0; sweep < nbus; ++sweep) {
@@ -804,21 +854,26 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     int bad = 0;
     if (!conn_known) for (int i = tid; i < nbus; i += GW) bad |= (c.btype[i] != BT_OFF && c.lab[i] == 0);
     if (status == 0 && G::any(bad)) status = 2;
+    ts.status = status;
     if (G::block_all(status != 0)) return status;
+  }
   }
   GPF_STAMPS(2);
 
   // ---- K2: block Ybus (original pattern) + K3: DC matrix in the block array, both with LDS atomics ----------------------------
-  for (int i = tid; i < S.nslot_y * NB * NB * 2; i += GW) c.Yb[i] = 0.0;
-  for (int i = tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
-  GPF_SYNC();
+  // (reuse: the Ybus blocks stand; the DC matrix is rebuilt unless its factors were kept)
+  const bool do_y = !reuse && !is_dc;
   auto lidx = [&](int bus) -> int { return (NB == 1) ? 0 : bus % NB; };
+  if (!dc_kept || do_y) {
+  if (do_y) for (int i = tid; i < S.nslot_y * NB * NB * 2; i += GW) c.Yb[i] = 0.0;
+  if (!dc_kept) for (int i = tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
+  GPF_SYNC();
   for (int l = tid; l < g.n_line; l += GW) {
     const int f = c.lor_b[l], t = c.lex_b[l];
     if (f < 0) continue;
     const int bi = lidx(f), bj = lidx(t);
     const int sff = sv.br_slot[4 * l + 0], sft = sv.br_slot[4 * l + 1], stf = sv.br_slot[4 * l + 2], stt = sv.br_slot[4 * l + 3];
-    if (!is_dc) {
+    if (do_y) {
       const double4 ya = sv.br_y.ld4((size_t)8 * l), yb = sv.br_y.ld4((size_t)8 * l + 4);
       double* y;
       y = c.Yb + ((size_t)sff * NB * NB + bi * NB + bi) * 2; atomicAdd(&y[0], ya.x); atomicAdd(&y[1], ya.y);
@@ -826,7 +881,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       y = c.Yb + ((size_t)stf * NB * NB + bj * NB + bi) * 2; atomicAdd(&y[0], yb.x); atomicAdd(&y[1], yb.y);
       y = c.Yb + ((size_t)stt * NB * NB + bj * NB + bj) * 2; atomicAdd(&y[0], yb.z); atomicAdd(&y[1], yb.w);
     }
-    if (f != t) {
+    if (f != t && !dc_kept) {
       const double bb = sv.br_bdc[l];
       const bool ff_ = c.btype[f] != BT_REF, tf_ = c.btype[t] != BT_REF;     // theta row / column live?
       const int rf = 2 * bi, rt = 2 * bj;
@@ -838,7 +893,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       }
     }
   }
-  if (!is_dc) {
+  if (do_y) {
     for (int s = tid; s < g.n_shunt; s += GW) {
       const int bu = c.sh_b[s];
       if (bu >= 0) {
@@ -852,13 +907,16 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     }
   }
   GPF_SYNC();
+  }
   // identity rows (fixed variables) + DC right-hand side
   for (int i = tid; i < nbus; i += GW) {
     const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
     const int bt = c.btype[i];
     const bool th_live = (bt == BT_PQ || bt == BT_PV);
-    if (!th_live) *bel(sub, 2 * bi, 2 * bi) = 1.0;
-    *bel(sub, 2 * bi + 1, 2 * bi + 1) = 1.0;                     // |V| rows are identity in the DC system
+    if (!dc_kept) {
+      if (!th_live) *bel(sub, 2 * bi, 2 * bi) = 1.0;
+      *bel(sub, 2 * bi + 1, 2 * bi + 1) = 1.0;                   // |V| rows are identity in the DC system
+    }
     c.rhs[(size_t)sub * BS + 2 * bi] = th_live ? (c.Psp[i] - c.Gs[i]) : 0.0;
     c.rhs[(size_t)sub * BS + 2 * bi + 1] = 0.0;
   }
@@ -870,8 +928,12 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     return block_lu_solve<BS, GW>(S, gptr(sv.prog.p), c.A, c.rhs, tid, dbg);
   };
   auto lu_dc = [&](long long* dbg) -> bool {
-    if (STAGE >= 1) return scalar_lu_solve<GW>(S, sv.prog.p, c.A, c.rhs, tid, dbg);
-    return scalar_lu_solve<GW>(S, gptr(sv.prog.p), c.A, c.rhs, tid, dbg);
+    if (dc_kept) {
+      if (STAGE >= 1) return scalar_lu_solve<GW, 1, false>(S, sv.prog.p, c.Adc, c.rhs, tid, dbg);
+      return scalar_lu_solve<GW, 1, false>(S, gptr(sv.prog.p), c.Adc, c.rhs, tid, dbg);
+    }
+    if (STAGE >= 1) return scalar_lu_solve<GW, 2, true>(S, sv.prog.p, c.A, c.rhs, tid, dbg);
+    return scalar_lu_solve<GW, 2, true>(S, gptr(sv.prog.p), c.A, c.rhs, tid, dbg);
   };
   {
 #ifdef GPF_TIMING
@@ -887,6 +949,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       c.va[i] = (bt == BT_PQ || bt == BT_PV) ? th : 0.0;
       if (bt != BT_OFF && !(fabs(th) < 1e300)) ok = false;
     }
+    if (NB == 1 && ctl.dcf && !dc_kept)                            // keep the factors for the next solves of this launch
+      for (int q = tid; q < S.nslot; q += GW) c.Adc[q] = c.A[(size_t)q * 2];
     GPF_SYNC();
     if (status == 0 && G::any(!ok)) status = 4;
     if (G::block_all(status != 0)) return status;
@@ -1026,7 +1090,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   }
   for (int l = tid; l < g.n_line; l += GW) {
     const int f = c.lor_b[l], t = c.lex_b[l];
-    lstat[l] = f >= 0 ? 1 : 0;
+    if (!reuse) lstat[l] = f >= 0 ? 1 : 0;
     float p_or = 0.f, q_or = 0.f, v_or = 0.f, a_or = 0.f, th_or = 0.f;
     float p_ex = 0.f, q_ex = 0.f, v_ex = 0.f, a_ex = 0.f, th_ex = 0.f;
     if (f >= 0) {
@@ -1080,7 +1144,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     out[oo.sh_p + i] = on ? (float)(GPF_INJ(oo.inj_sh_p + i) * sv.shunt_fact[i] * v * v) : 0.f;
     out[oo.sh_q + i] = (on && !is_dc) ? (float)(GPF_INJ(oo.inj_sh_q + i) * sv.shunt_fact[i] * v * v) : 0.f;
     out[oo.sh_v + i] = on ? (float)(v * sv.sub_vn_kv[sv.shunt_sub[i]]) : 0.f;
-    sbo[i] = on ? shb[i] : -1;
+    if (!reuse) sbo[i] = on ? shb[i] : -1;
   }
   // generators (pypower pfsoln): per-bus totals accumulated in LDS with atomics (the block array is dead by now and
   // serves as scratch), then a per-generator pass.  Bus balances: total generation at a bus = S_inj - (P,Q)_spec,
@@ -1126,13 +1190,16 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     }
   }
   GPF_STAMPS(25);
-  const auto to = gptr(b.topo_out) + (size_t)inst * g.dim_topo;
-  for (int i = tid; i < g.dim_topo; i += GW) { const int v = topo_g[i]; to[i] = v >= 1 ? v : -1; }
-  GPF_SYNC();
-  for (int l = tid; l < g.n_line; l += GW) {
-    if (c.lor_b[l] < 0) { to[sv.line_or_pos[l]] = -1; to[sv.line_ex_pos[l]] = -1; }
+  if (!reuse) {                          // topo_vect only depends on the topology: it stands when the topology does
+    const auto to = gptr(b.topo_out) + (size_t)inst * g.dim_topo;
+    for (int i = tid; i < g.dim_topo; i += GW) { const int v = topo_g[i]; to[i] = v >= 1 ? v : -1; }
+    GPF_SYNC();
+    for (int l = tid; l < g.n_line; l += GW) {
+      if (c.lor_b[l] < 0) { to[sv.line_or_pos[l]] = -1; to[sv.line_ex_pos[l]] = -1; }
+    }
   }
   GPF_STAMPS(26);
+  if (ctl.write_bus) {
   const auto bvm = gptr(b.bus_vm) + (size_t)inst * g.nb_tot;
   const auto bva = gptr(b.bus_va) + (size_t)inst * g.nb_tot;
   const double nand = __builtin_nan("");
@@ -1145,6 +1212,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     const bool on = bu >= 0 && c.btype[bu] != BT_OFF;
     bvm[i] = on ? c.vm[bu] : nand;
     bva[i] = on ? c.va[bu] * RAD2DEG : nand;
+  }
   }
   GPF_STAMPS(6);
   return status;
@@ -1161,8 +1229,9 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   const SymDev& S = TC ? S_tc : P->sym;                                                                                          \
   const int lds_rows = TC ? P->tc_rows : -1, lds_nslot = TC ? P->tc_nslot : P->sym.nslot,                                        \
             lds_nslot_y = TC ? P->tc_nslot_y : P->sym.nslot_y;                                                                   \
-  const size_t per_inst = lds_bytes_instance<NB>(G_, lds_nslot, lds_nslot_y, STAGE != 0, lds_rows);                              \
-  carve_sparse<NB>(c, smem + (size_t)grp * per_inst, G_, lds_nslot, lds_nslot_y, STAGE != 0, lds_rows);                          \
+  const bool lds_dcf = !TC && P->dcf != 0;                                                                                       \
+  const size_t per_inst = lds_bytes_instance<NB>(G_, lds_nslot, lds_nslot_y, STAGE != 0, lds_rows, lds_dcf);                     \
+  carve_sparse<NB>(c, smem + (size_t)grp * per_inst, G_, lds_nslot, lds_nslot_y, STAGE != 0, lds_rows, lds_dcf);                 \
   StatView<STAGE> sv;                                                                                                            \
   make_stat_view<STAGE>(sv, P->sym, smem + (size_t)IPW * per_inst);                                                              \
   if (TC) {                                                                                                                      \
@@ -1183,7 +1252,11 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   GPF_CARVE_AND_VIEW(P->g);
   int n_iter, nb;
   GPF_STAMPS_DECL;
-  const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC>(P, S, sv, c, inst, is_dc, max_iter, tol_pu, tid, false, false, n_iter, nb GPF_STAMPS_ARG);
+  SolveCtl ctl;
+  ctl.inj_staged = false; ctl.topo_staged = false; ctl.reuse = false; ctl.dcf = false; ctl.write_bus = true;
+  TopoState ts;
+  ts.status = 0; ts.nb = 0;
+  const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC>(P, S, sv, c, inst, is_dc, max_iter, tol_pu, tid, ctl, ts, n_iter, nb GPF_STAMPS_ARG);
   GPF_SYNC();
   if (st != 0) write_nan_results<GW>(P->g, P->b, inst, tid);
   if (tid == 0) {
@@ -1192,6 +1265,11 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   }
 }
 
+// Batched environment steps: n_steps consecutive DoNothing env.step of every lane in ONE launch.  Per step: chronics row
+// (+ jitter, rebalancing, redispatch delta) -> injections -> power flow -> results row -> overflow counters / cascade (K7) ->
+// rho, status, episode bookkeeping, all written to HBM.  What does NOT change from one step to the next stays in LDS / registers:
+// the static tables, the lane's chronics cursor and -- as long as no line tripped and no lane failed -- everything that only
+// depends on the topology (element -> bus maps, bus types, connectivity verdict, Ybus blocks, the factored DC matrix).
 template <int NB, int STAGE, int IPW, int MINW, int WPI, bool TC = false>
 __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const DevParamsS* __restrict__ P, const int* __restrict__ lane_list,
                                                            const int* __restrict__ lane_class, int max_iter, double tol_pu,
@@ -1204,120 +1282,163 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   const OutOff& oo = P->oo;
   const int grp = threadIdx.x / GW, tid = threadIdx.x % GW;
   const int inst = lane_list ? gptr(lane_list)[blockIdx.x * IPW + grp] : blockIdx.x * IPW + grp;   // ghost-padded by the host
+  const bool ghost = inst >= (int)b.n_real_lanes;               // padding lane of an instance group: computes, never mutates state
   CarveP<NB> c;
   GPF_CARVE_AND_VIEW(g);
   if (STAGE) GPF_SYNC();                                       // the static tables are read from here on
   GPF_STAMPS_DECL;
   GPF_STAMPS(8);
-  {
-    const int tab = b.lane_table ? gptr(b.lane_table)[inst] : 0;
-    const int off = b.lane_offset ? gptr(b.lane_offset)[inst] : 0;
-    int row = (sa.t + off) % sa.T;
-    if (row < 0) row += sa.T;
-    const auto ch = gptr(b.chron) + ((size_t)tab * sa.T + row) * g.n_chron;
-    const bool has_sc = b.lane_scale != nullptr;
-    const auto sc = gptr(b.lane_scale) + (size_t)inst * 2 * g.n_load;
-    const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj;
-    // all global loads of the phase are issued up front (one round trip): the lane's topology row (first solve), the
-    // storage / shunt set-points, and the first pass of the generator columns of the chronics row
-    {
-      const auto topo_g = gptr(b.topo) + (size_t)inst * g.dim_topo;
-      for (int i = tid; i < g.dim_topo; i += GW) c.topo[i] = topo_g[i];
-    }
-    if (STAGE) for (int i = oo.inj_sto_p + tid; i < g.n_inj; i += GW) c.inj[i] = inj_g[i];
-    const float pp_pre = tid < g.n_gen ? ch[2 * g.n_load + tid] : 0.f;
-    const float pv_pre = tid < g.n_gen ? ch[2 * g.n_load + g.n_gen + tid] : 1.f;
-    double sum_load = 0.0, sum_prod = 0.0;
-    GPF_STAMPS(16);
-    for (int i = tid; i < g.n_load; i += GW) {
-      float lp = ch[i], lq = ch[g.n_load + i];
-      if (has_sc) { lp *= sc[i]; lq *= sc[g.n_load + i]; }
-      if (STAGE) { c.inj[oo.inj_load_p + i] = (double)lp; c.inj[oo.inj_load_q + i] = (double)lq; }   // HBM copy: end of kernel
-      else { inj_g[oo.inj_load_p + i] = (double)lp; inj_g[oo.inj_load_q + i] = (double)lq; }
-      sum_load += (double)lp;
-    }
-    for (int i = tid; i < g.n_gen; i += GW)
-      if (!sv.gen_slack[i]) sum_prod += (double)(i == tid ? pp_pre : ch[2 * g.n_load + i]);
-    float scale_p = 1.0f;
-    GPF_STAMPS(17);
-    if (sa.rebalance_on) {
-      sum_load = G::sum(sum_load);
-      sum_prod = G::sum(sum_prod);
-      scale_p = (sum_prod > 0.0) ? (float)(sa.rebalance * sum_load / sum_prod) : 1.0f;
-    }
-    GPF_STAMPS(18);
-    for (int i = tid; i < g.n_gen; i += GW) {
-      float pp = (i == tid) ? pp_pre : ch[2 * g.n_load + i];
-      if (!sv.gen_slack[i]) pp *= scale_p;
-      const float pv_kv = (i == tid) ? pv_pre : ch[2 * g.n_load + g.n_gen + i];
-      const float vn = (float)sv.sub_vn_kv[sv.gen_sub[i]];
-      const double vm_pu = (double)(pv_kv / vn);
-      if (STAGE) { c.inj[oo.inj_gen_p + i] = (double)pp; c.inj[oo.inj_gen_vm + i] = vm_pu; }
-      else { inj_g[oo.inj_gen_p + i] = (double)pp; inj_g[oo.inj_gen_vm + i] = vm_pu; }
-    }
-    GPF_SYNC();
-  }
-  int n_iter = 0, nb = 0, st = 0, rounds = 0;
+  // ---- per-lane constants of the launch --------------------------------------------------------------------------------------
+  const int tab = b.lane_table ? gptr(b.lane_table)[inst] : 0;
+  const int off = b.lane_offset ? gptr(b.lane_offset)[inst] : 0;
+  int row = (sa.t + off) % sa.T;
+  if (row < 0) row += sa.T;
+  const auto ch_tab = gptr(b.chron) + (size_t)tab * sa.T * g.n_chron;
+  const bool has_sc = b.lane_scale != nullptr;
+  const auto sc = gptr(b.lane_scale) + (size_t)inst * 2 * g.n_load;
+  const bool has_delta = b.lane_gen_delta != nullptr;
+  const auto gdelta = gptr(b.lane_gen_delta) + (size_t)inst * g.n_gen;
+  const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj;
   const auto ovc = gptr(b.overflow_count) + (size_t)inst * g.n_line;    // env._protection_counter (persistent)
   const auto dround = gptr(b.disc_round) + (size_t)inst * g.n_line;
   const auto rho = gptr(b.rho) + (size_t)inst * g.n_line;
   const auto out = gptr(b.out) + (size_t)inst * g.n_out;
   const auto topo = gptr(b.topo) + (size_t)inst * g.dim_topo;
   const auto thermal_limit = gptr(b.thermal_limit);
-  for (int l = tid; l < g.n_line; l += GW) dround[l] = -1;
-  // Backend.next_grid_state keeps a LOCAL copy of the protection counters that is advanced at most once per line
-  // and per call (backend.py:1476-1520): local value = ovc + (line already counted this call ? 1 : 0); the "already
-  // counted" flag lives in bit 30 of disc_round's scratch twin (rho buffer reused as int scratch until the end).
-  const auto inc_flag = (GPF_GLOBAL int*)rho;
-  if (sa.cascade) for (int l = tid; l < g.n_line; l += GW) inc_flag[l] = 0;
-  bool more = true;                                           // this group still cascades
-  bool first = true;
-  while (true) {
-    // a group whose cascade has ended re-solves its unchanged state along with the others (same results)
-    int it_k = 0, nb_k = 0;
-    const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI, TC>(P, S, sv, c, inst, sa.is_dc, max_iter, tol_pu, tid, true, first, it_k, nb_k GPF_STAMPS_ARG);
-    first = false;
+  // jitter factors and redispatch delta of the elements this thread handles first stay in registers for the whole launch
+  const float sc_p0 = (has_sc && tid < g.n_load) ? sc[tid] : 1.f, sc_q0 = (has_sc && tid < g.n_load) ? sc[g.n_load + tid] : 1.f;
+  const float gd0 = (has_delta && tid < g.n_gen) ? gdelta[tid] : 0.f;
+  if (STAGE) for (int i = oo.inj_sto_p + tid; i < g.n_inj; i += GW) c.inj[i] = inj_g[i];      // storage / shunt set-points
+  TopoState ts;
+  ts.status = 0; ts.nb = 0;
+  bool reuse = false;                                         // block-uniform
+  int n_iter = 0, nb = 0, st = 0, rounds = 0;
+  int ep_steps = 0, ep_resets = 0;
+  if (tid == 0 && !ghost) { ep_steps = gptr(b.episode)[2 * (size_t)inst]; ep_resets = gptr(b.episode)[2 * (size_t)inst + 1]; }
+  for (int step = 0; step < sa.n_steps; ++step) {
+    const bool last = step + 1 == sa.n_steps;
+    // ---- K9: chronics row -> injections -----------------------------------------------------------------------------------
+    {
+      const auto ch = ch_tab + (size_t)row * g.n_chron;
+      // all global loads of the phase are issued up front (one round trip): the lane's topology row (when the topology phases
+      // run again) and the first pass of the chronics row
+      if (!reuse) for (int i = tid; i < g.dim_topo; i += GW) c.topo[i] = topo[i];
+      const float pp_pre = tid < g.n_gen ? ch[2 * g.n_load + tid] : 0.f;
+      const float pv_pre = tid < g.n_gen ? ch[2 * g.n_load + g.n_gen + tid] : 1.f;
+      double sum_load = 0.0, sum_prod = 0.0;
+      GPF_STAMPS(16);
+      for (int i = tid; i < g.n_load; i += GW) {
+        float lp = ch[i], lq = ch[g.n_load + i];
+        if (has_sc) { lp *= (i == tid) ? sc_p0 : sc[i]; lq *= (i == tid) ? sc_q0 : sc[g.n_load + i]; }
+        if (STAGE) { c.inj[oo.inj_load_p + i] = (double)lp; c.inj[oo.inj_load_q + i] = (double)lq; }   // HBM copy: end of kernel
+        else { inj_g[oo.inj_load_p + i] = (double)lp; inj_g[oo.inj_load_q + i] = (double)lq; }
+        sum_load += (double)lp;
+      }
+      for (int i = tid; i < g.n_gen; i += GW)
+        if (!sv.gen_slack[i]) sum_prod += (double)(i == tid ? pp_pre : ch[2 * g.n_load + i]);
+      float scale_p = 1.0f;
+      GPF_STAMPS(17);
+      if (sa.rebalance_on) {
+        sum_load = G::sum(sum_load);
+        sum_prod = G::sum(sum_prod);
+        scale_p = (sum_prod > 0.0) ? (float)(sa.rebalance * sum_load / sum_prod) : 1.0f;
+      }
+      GPF_STAMPS(18);
+      for (int i = tid; i < g.n_gen; i += GW) {
+        float pp = (i == tid) ? pp_pre : ch[2 * g.n_load + i];
+        if (!sv.gen_slack[i]) pp *= scale_p;
+        if (has_delta) pp += (i == tid) ? gd0 : gdelta[i];
+        const float pv_kv = (i == tid) ? pv_pre : ch[2 * g.n_load + g.n_gen + i];
+        const float vn = (float)sv.sub_vn_kv[sv.gen_sub[i]];
+        const double vm_pu = (double)(pv_kv / vn);
+        if (STAGE) { c.inj[oo.inj_gen_p + i] = (double)pp; c.inj[oo.inj_gen_vm + i] = vm_pu; }
+        else { inj_g[oo.inj_gen_p + i] = (double)pp; inj_g[oo.inj_gen_vm + i] = vm_pu; }
+      }
+      GPF_SYNC();
+    }
+    // ---- power flow + K7 (Backend.next_grid_state) --------------------------------------------------------------------------
+    n_iter = 0; nb = 0; st = 0; rounds = 0;
+    for (int l = tid; l < g.n_line; l += GW) dround[l] = -1;
+    // Backend.next_grid_state keeps a LOCAL copy of the protection counters that is advanced at most once per line
+    // and per call (backend.py:1476-1520): local value = ovc + (line already counted this call ? 1 : 0); the "already
+    // counted" flag lives in the rho buffer, reused as int scratch until the end of the step.
+    const auto inc_flag = (GPF_GLOBAL int*)rho;
+    if (sa.cascade) for (int l = tid; l < g.n_line; l += GW) inc_flag[l] = 0;
+    bool more = true;                                           // this group still cascades
+    bool first = true;
+    bool tripped = false;                                       // this group tripped a line during this step
+    while (true) {
+      // a group whose cascade has ended re-solves its unchanged state along with the others (same results)
+      int it_k = 0, nb_k = 0;
+      SolveCtl ctl;
+      ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && !TC; ctl.write_bus = last;
+      const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI, TC>(P, S, sv, c, inst, sa.is_dc, max_iter, tol_pu, tid, ctl, ts, it_k, nb_k GPF_STAMPS_ARG);
+      first = false;
+      GPF_SYNC();
+      if (more) { st = st_k; n_iter = it_k; nb = nb_k; }
+      if (st != 0 || !sa.cascade || rounds >= sa.max_rounds) more = false;   // at most max_rounds re-solves
+      int any_disc = 0;
+      if (more && !ghost)
+      for (int l = tid; l < g.n_line; l += GW) {
+        const float a = out[oo.a_or + l];
+        const float lim = thermal_limit[l];
+        const bool on = c.lor_b[l] >= 0;
+        bool disc = on && (a > sa.hard_overflow * lim);
+        int inc = inc_flag[l];
+        if (on && (a > sa.soft_overflow * lim) && !inc) { inc = 1; inc_flag[l] = 1; }
+        if (on && (ovc[l] + inc) > sa.nb_ts_allowed) disc = true;
+        if (disc) {
+          topo[sv.line_or_pos[l]] = -1;
+          topo[sv.line_ex_pos[l]] = -1;
+          dround[l] = rounds;
+          any_disc = 1;
+        }
+      }
+      GPF_SYNC();
+      if (more && !G::any(any_disc)) more = false;
+      if (more) tripped = true;
+      if (!G::block_any(more)) break;
+      if (more) ++rounds;
+    }
+    GPF_STAMPS(9);
+    // ---- per-step outputs -----------------------------------------------------------------------------------------------------
+    if (st != 0) write_nan_results<GW>(g, b, inst, tid);
     GPF_SYNC();
-    if (more) { st = st_k; n_iter = it_k; nb = nb_k; }
-    if (st != 0 || !sa.cascade || rounds >= sa.max_rounds) more = false;   // at most max_rounds re-solves
-    int any_disc = 0;
-    if (more)
+    GPF_GLOBAL float* traj = nullptr;
+    if (b.traj_rho && step < b.traj_cap) traj = gptr(b.traj_rho) + ((size_t)step * b.lane_stride + inst) * g.n_line;
     for (int l = tid; l < g.n_line; l += GW) {
-      const float a = out[oo.a_or + l];
       const float lim = thermal_limit[l];
-      const bool on = c.lor_b[l] >= 0;
-      bool disc = on && (a > sa.hard_overflow * lim);
-      int inc = inc_flag[l];
-      if (on && (a > sa.soft_overflow * lim) && !inc) { inc = 1; inc_flag[l] = 1; }
-      if (on && (ovc[l] + inc) > sa.nb_ts_allowed) disc = true;
-      if (disc) {
-        topo[sv.line_or_pos[l]] = -1;
-        topo[sv.line_ex_pos[l]] = -1;
-        dround[l] = rounds;
-        any_disc = 1;
+      const float a = out[oo.a_or + l];
+      const float r_ = a / lim;
+      rho[l] = r_;
+      if (traj) traj[l] = r_;
+      if (!ghost) { if (a > sa.soft_overflow * lim) ovc[l] += 1; else ovc[l] = 0; }
+    }
+    const bool failed = st != 0;
+    if (tid == 0) {
+      const auto s = gptr(b.status) + (size_t)inst * 4;
+      s[0] = st; s[1] = n_iter; s[2] = nb; s[3] = rounds;
+      if (!ghost) {
+        gptr(b.done)[inst] = failed ? 1 : 0;
+        if (b.traj_status && step < b.traj_cap) gptr(b.traj_status)[(size_t)step * b.lane_stride + inst] = (signed char)st;
+        if (failed) { if (sa.auto_reset) { ep_steps = 0; ++ep_resets; } } else ++ep_steps;
       }
     }
-    GPF_SYNC();
-    if (more && !G::any(any_disc)) more = false;
-    if (!G::block_any(more)) break;
-    if (more) ++rounds;
+    // game over + auto-reset: the lane restarts from the topology the host sent last, protection counters cleared (the
+    // chronics cursor keeps running: the next step is the first of a new episode)
+    if (failed && sa.auto_reset && !ghost) {
+      const auto t0 = gptr(b.topo0) + (size_t)inst * g.dim_topo;
+      for (int i = tid; i < g.dim_topo; i += GW) topo[i] = t0[i];
+      for (int l = tid; l < g.n_line; l += GW) ovc[l] = 0;
+    }
+    // the topology-derived state stands for the next step only if NO group of the block changed or lost its topology
+    reuse = !G::block_any(failed || tripped);
+    if (++row >= sa.T) row = 0;
+    if (!last) GPF_SYNC();
   }
-  GPF_STAMPS(9);
-  if (STAGE) {                                                // the step's injection row -> HBM (gpf_get_injections, next launches)
-    const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj;
+  if (tid == 0 && !ghost) { gptr(b.episode)[2 * (size_t)inst] = ep_steps; gptr(b.episode)[2 * (size_t)inst + 1] = ep_resets; }
+  if (STAGE && !ghost) {                                      // the last step's injection row -> HBM (gpf_get_injections, next launches)
     for (int i = tid; i < oo.inj_sto_p; i += GW) inj_g[i] = c.inj[i];
-  }
-  if (st != 0) write_nan_results<GW>(g, b, inst, tid);
-  GPF_SYNC();
-  for (int l = tid; l < g.n_line; l += GW) {
-    const float lim = thermal_limit[l];
-    const float a = out[oo.a_or + l];
-    rho[l] = a / lim;
-    if (a > sa.soft_overflow * lim) ovc[l] += 1; else ovc[l] = 0;
-  }
-  if (tid == 0) {
-    const auto s = gptr(b.status) + (size_t)inst * 4;
-    s[0] = st; s[1] = n_iter; s[2] = nb; s[3] = rounds;
   }
   GPF_STAMPS(15);
   GPF_STAMPS_FLUSH(inst);

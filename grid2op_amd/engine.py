@@ -17,7 +17,7 @@ from typing import Dict, Optional, Tuple
 import numpy as np
 
 from . import _capi
-from ._capi import GpfGridDesc, GpfLayout, GridPFError, check, ptr
+from ._capi import GpfGridDesc, GpfLayout, GpfStepOpts, GridPFError, check, ptr
 from .grid_model import GridModel
 
 __all__ = ["PowerFlowEngine", "LaneResults", "GridPFError", "ST_CONVERGED", "STATUS_TEXT"]
@@ -263,11 +263,73 @@ class PowerFlowEngine:
 
     def step(self, t: int, max_iter: int = 10, tol_mva: float = 1e-8, rebalance: float = 0.0, cascade: bool = False,
              hard_overflow: float = 2.0, soft_overflow: float = 1.0, nb_ts_allowed: int = 2, max_rounds: int = 16,
-             is_dc: bool = False):
-        """One DoNothing ``env.step`` for every lane (asynchronous)."""
-        check(self._lib.gpf_step(self._h, int(t), int(max_iter), float(tol_mva), float(rebalance), int(bool(cascade)),
-                                 float(hard_overflow), float(soft_overflow), int(nb_ts_allowed), int(max_rounds), int(bool(is_dc))),
-              "gpf_step")
+             is_dc: bool = False, n_steps: int = 1, auto_reset: bool = False):
+        """``n_steps`` consecutive DoNothing ``env.step`` (t, t+1, ...) for every lane in ONE launch (asynchronous).  Every step
+        writes its results; the getters return the last one, `trajectory` the rho / status of each when requested."""
+        o = GpfStepOpts(int(max_iter), float(tol_mva), float(rebalance), int(bool(cascade)), float(hard_overflow), float(soft_overflow),
+                        int(nb_ts_allowed), int(max_rounds), int(bool(is_dc)), int(bool(auto_reset)))
+        check(self._lib.gpf_step_n(self._h, int(t), int(n_steps), C.byref(o)), "gpf_step_n")
+
+    def set_lane_redispatch(self, delta_mw):
+        """Per-lane additive generator set-point delta (MW, ``[n_lanes, n_gen]``; None switches it off): the redispatch the
+        environment adds to the chronics' prod_p."""
+        d = None if delta_mw is None else np.ascontiguousarray(delta_mw, dtype=np.float32)
+        if d is not None:
+            assert d.shape == (self.n_lanes, self.model.n_gen)
+        check(self._lib.gpf_set_lane_redispatch(self._h, ptr(d, C.c_float)), "gpf_set_lane_redispatch")
+
+    def set_trajectory(self, n_steps_cap: int):
+        check(self._lib.gpf_set_trajectory(self._h, int(n_steps_cap)), "gpf_set_trajectory")
+
+    def trajectory(self, n_steps: int, step0: int = 0, lane0: int = 0, n: Optional[int] = None):
+        """(rho ``[n_steps, n, n_line]`` float32, status ``[n_steps, n]`` int8) of the steps of the last multi-step launch."""
+        lane0, n = self._range(lane0, n)
+        rho = np.empty((n_steps, n, self.model.n_line), dtype=np.float32)
+        st = np.empty((n_steps, n), dtype=np.int8)
+        check(self._lib.gpf_get_trajectory(self._h, int(step0), int(n_steps), lane0, n, ptr(rho, C.c_float), ptr(st, C.c_int8)),
+              "gpf_get_trajectory")
+        return rho, st
+
+    def episode(self, lane0: int = 0, n: Optional[int] = None):
+        """(done ``[n]`` bool, steps survived since the last reset ``[n]``, auto-resets ``[n]``)."""
+        lane0, n = self._range(lane0, n)
+        done = np.empty(n, dtype=np.uint8)
+        sr = np.empty((n, 2), dtype=np.int32)
+        check(self._lib.gpf_get_episode(self._h, lane0, n, ptr(done, C.c_uint8), ptr(sr, C.c_int32)), "gpf_get_episode")
+        return done.astype(bool), sr[:, 0].copy(), sr[:, 1].copy()
+
+    # ---- zero-copy device views ------------------------------------------------------------------------------------------
+    def device_views(self):
+        """The engine's result buffers as torch tensors that ALIAS the device memory (no copy, no PCIe): ``out`` float32
+        ``[n_lanes, n_out]`` (columns: `out_slices`), ``rho`` ``[n_lanes, n_line]``, ``status`` int32 ``[n_lanes, 4]``,
+        ``topo_vect``, ``line_status`` uint8, ``overflow_count``, ``done`` uint8, ``episode`` int32 ``[n_lanes, 2]``, ``inj``
+        float64, ``bus_vm`` / ``bus_va`` float64.  The engine works on its own HIP stream: call `sync` (or make the consumer's
+        stream wait on ``views["stream"]``, a ``torch.cuda.ExternalStream``) before reading."""
+        import torch
+        ptrs = (C.c_void_p * 16)()
+        stream = C.c_void_p()
+        check(self._lib.gpf_device_pointers(self._h, ptrs, C.byref(stream)), "gpf_device_pointers")
+        cap = self._lib.gpf_lane_capacity(self._h)
+        m = self.model
+        dev = torch.device("cuda", self.device)
+
+        class _Arr:                          # __cuda_array_interface__ v2: torch.as_tensor wraps it without a copy
+            def __init__(self, p, shape, typestr):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(p), False), "version": 2,
+                                                 "strides": None}
+
+        def view(idx, cols, typestr):
+            if cols == 0 or not ptrs[idx]:
+                return None
+            t = torch.as_tensor(_Arr(ptrs[idx], (cap, cols), typestr), device=dev)
+            return t[:self.n_lanes]
+        v = {"inj": view(0, self.n_inj, "<f8"), "topo": view(1, m.dim_topo, "<i4"), "out": view(3, self.n_out, "<f4"),
+             "topo_vect": view(4, m.dim_topo, "<i4"), "line_status": view(5, m.n_line, "|u1"), "status": view(6, 4, "<i4"),
+             "rho": view(8, m.n_line, "<f4"), "overflow_count": view(9, m.n_line, "<i4"), "done": view(10, 1, "|u1"),
+             "episode": view(11, 2, "<i4"), "bus_vm": view(12, self.nb_total, "<f8"), "bus_va": view(13, self.nb_total, "<f8"),
+             "disc_round": view(15, m.n_line, "<i4")}
+        v["stream"] = torch.cuda.ExternalStream(stream.value, device=dev)
+        return v
 
     def step_outputs(self, lane0: int = 0, n: Optional[int] = None):
         lane0, n = self._range(lane0, n)

@@ -165,6 +165,14 @@ class ShardedEngine:
         for eng in self.engines:
             eng.step(t, **kw)
 
+    def set_lane_redispatch(self, delta_mw):
+        for eng, (b0, bn) in zip(self.engines, self.blocks):
+            eng.set_lane_redispatch(None if delta_mw is None else np.asarray(delta_mw)[b0:b0 + bn])
+
+    def episode(self, lane0: int = 0, n=None):
+        parts = [eng.episode(l0, k) for eng, l0, k, _ in self._parts(lane0, n)]
+        return tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
+
     def sync(self):
         for eng in self.engines:
             eng.sync()

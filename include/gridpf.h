@@ -106,6 +106,8 @@ int gpf_create(const gpf_grid_desc* desc, int32_t n_lanes, int32_t device, gpf_h
 int gpf_destroy(gpf_handle h);
 int gpf_get_layout(gpf_handle h, gpf_layout* out);
 int gpf_n_lanes(gpf_handle h);
+/* Lane capacity of the per-lane device buffers (n_lanes rounded up, plus padding lanes the kernels use for instance groups). */
+int gpf_lane_capacity(gpf_handle h);
 
 /* apply_action, injection half (pandaPowerBackend.py:925-969): overwrite rows lane0..lane0+n-1.
  * inj is [n][n_inj] double. */
@@ -156,6 +158,36 @@ int gpf_set_thermal_limits(gpf_handle h, const float* limit_a /* [n_line] */);
  * instead (Parameters.ENV_DC, grid2op/Parameters.py:273 -> runpf(is_dc=True)).  Asynchronous. */
 int gpf_step(gpf_handle h, int32_t t, int32_t max_iter, double tol_mva, double rebalance, int32_t cascade,
              float hard_overflow, float soft_overflow, int32_t nb_ts_allowed, int32_t max_rounds, int32_t is_dc);
+/* Options of gpf_step_n (the arguments of gpf_step, plus auto_reset). */
+typedef struct gpf_step_opts {
+  int32_t max_iter;
+  double tol_mva;
+  double rebalance;
+  int32_t cascade;
+  float hard_overflow, soft_overflow;
+  int32_t nb_ts_allowed, max_rounds;
+  int32_t is_dc;
+  int32_t auto_reset;    /* != 0: a lane whose step fails (game over: BaseEnv.step sets done when the backend diverges,
+                            Environment/baseEnv.py:3847-3931) restarts at the next step from the topology the host sent last
+                            (gpf_set_topology / gpf_reset_lanes), overflow counters cleared -- what env.reset() does to the
+                            backend (Environment/environment.py:1418 reset_grid); the chronics cursor keeps running */
+} gpf_step_opts;
+/* n_steps consecutive DoNothing env.step (t0, t0+1, ...) of every lane in ONE launch.  Every step does the whole of gpf_step and
+ * writes its results row, rho, status and counters; between the steps of a launch the lane state stays on chip and whatever only
+ * depends on the topology (element->bus maps, bus types, Ybus, the factored DC matrix) is kept until a line trips or a lane
+ * fails.  After the call the getters return the LAST step; gpf_get_trajectory returns rho / status of every step when a
+ * trajectory buffer was requested.  Asynchronous. */
+int gpf_step_n(gpf_handle h, int32_t t0, int32_t n_steps, const gpf_step_opts* opts);
+/* Per-lane additive generator set-point delta in MW, [n_lanes][n_gen] (NULL: none): the redispatch the environment adds to the
+ * chronics' prod_p every step (actual_dispatch, Environment/baseEnv.py:2211-2470, 3650-3700). */
+int gpf_set_lane_redispatch(gpf_handle h, const float* delta_mw);
+/* Trajectory buffer of multi-step launches: rho [n_steps_cap][n_lanes][n_line] and status [n_steps_cap][n_lanes] of the steps of
+ * the last gpf_step_n (0 releases it). */
+int gpf_set_trajectory(gpf_handle h, int32_t n_steps_cap);
+int gpf_get_trajectory(gpf_handle h, int32_t step0, int32_t n_steps, int32_t lane0, int32_t n, float* rho, int8_t* status);
+/* Episode bookkeeping of the batched steps: done [n] (1: the lane's last step ended its episode), steps_and_resets [n][2]
+ * {steps survived since the last (auto-)reset, number of auto-resets}. */
+int gpf_get_episode(gpf_handle h, int32_t lane0, int32_t n, uint8_t* done, int32_t* steps_and_resets);
 /* rho = a_or / thermal_limit (backend.py:1145-1168) and overflow counters of the last gpf_step. */
 int gpf_get_step_outputs(gpf_handle h, int32_t lane0, int32_t n, float* rho, int32_t* overflow_count,
                          int32_t* disc_round);
@@ -190,8 +222,9 @@ int gpf_set_profiling(gpf_handle h, int32_t mode);
 /* Sum of the event-measured durations (ms) and number of solver launches since the last call (closes the running
  * window of mode 1 and opens the next one). */
 int gpf_get_kernel_time(gpf_handle h, double* total_ms, int64_t* n_launches);
-/* Raw device pointers + the stream, for zero-copy interop (torch.as_tensor / DLPack on the Python side).
- * ptrs[0..7] = inj, topo, shunt_bus, out, topo_vect, line_status, status, chronics; stream = hipStream_t */
+/* Raw device pointers + the stream, for zero-copy interop (grid2op_amd/engine.py: PowerFlowEngine.device_views wraps them as
+ * torch tensors).  ptrs[0..15] = inj, topo, shunt_bus, out, topo_vect, line_status, status, chronics, rho, overflow_count, done,
+ * episode, bus_vm, bus_va, shunt_bus_out, disc_round (rows are padded to gpf_lane_capacity lanes); stream = hipStream_t */
 int gpf_device_pointers(gpf_handle h, void** ptrs, void** stream);
 
 #ifdef __cplusplus

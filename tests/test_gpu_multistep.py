@@ -1,0 +1,279 @@
+"""GPU tests of the multi-step launch (gpf_step_n): n consecutive env steps in one launch must reproduce n single-step
+launches (integers bit-exact, floats to rounding of the LDS atomics' summation order), with and without line trips, in DC
+mode, with a redispatch delta, with failing lanes and auto-reset; plus the zero-copy device views and the episode counters.
+The single-step path itself is checked against the oracle in tests/test_gpu_parity.py."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.pf_oracle import LaneState, solve
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_parity import _compare  # noqa: E402
+
+
+def _setup(load_model, load_npz, name, B, seed=0, env=None):
+    from grid2op_amd.engine import PowerFlowEngine
+    m = load_model(name)
+    ch = dict(load_npz(f"{name}.chronics.npz"))
+    if "load_p" not in ch:               # no chronics fixture for this grid: 40 jittered copies of the stored state
+        rg = np.random.default_rng(99)
+        j = lambda v: (np.asarray(v, np.float64)[None, :] * (1 + 0.03 * rg.standard_normal((40, len(v))))).astype(np.float32)  # noqa: E731
+        ch.update(load_p=j(m.load_p0), load_q=j(m.load_q0), prod_p=j(m.gen_p0))
+    if "prod_v" not in ch:
+        ch["prod_v"] = np.tile((m.gen_vm0 * m.sub_vn_kv[m.gen_sub]).astype(np.float32), (ch["prod_p"].shape[0], 1))
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        eng = PowerFlowEngine(m, n_lanes=B, device=0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    tab = eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"])
+    eng.upload_chronics(tab)
+    rng = np.random.default_rng(seed)
+    off = (11 * np.arange(B)) % tab.shape[0]
+    scale = (1 + 0.05 * rng.standard_normal((B, 2 * m.n_load))).astype(np.float32)
+    eng.set_lane_chronics(lane_offset=off, lane_scale=scale)
+    if "thermal_limits" in ch:
+        eng.set_thermal_limits(ch["thermal_limits"])
+    return m, ch, eng, tab, off, scale
+
+
+def _snapshot(eng):
+    r = eng.results()
+    rho, ovc, dr = eng.step_outputs()
+    return dict(out=r.out.copy(), status=r.status.copy(), topo=r.topo_vect.copy(), ls=r.line_status.copy(), rho=rho, ovc=ovc, dr=dr,
+                bus_vm=r.bus_vm.copy(), inj=eng.get_injections(), sb=r.shunt_bus.copy())
+
+
+def _same(a, b, what):
+    for k in ("status", "topo", "ls", "ovc", "dr", "sb"):
+        assert np.array_equal(a[k], b[k]), (what, k)
+    assert np.array_equal(np.isnan(a["out"]), np.isnan(b["out"])), what
+    assert np.allclose(a["out"], b["out"], rtol=2e-6, atol=2e-5, equal_nan=True), (what, np.nanmax(np.abs(a["out"] - b["out"])))
+    assert np.allclose(a["rho"], b["rho"], rtol=2e-6, atol=1e-6, equal_nan=True), what
+    assert np.allclose(a["bus_vm"], b["bus_vm"], rtol=0, atol=1e-11, equal_nan=True), what
+    assert np.array_equal(a["inj"], b["inj"]), what
+
+
+@pytest.mark.parametrize("name,B,kw", [
+    ("rte_case5_example", 37, dict(rebalance=1.02)),                       # 4 instances per wavefront, ragged tail
+    ("l2rpn_case14_sandbox", 66, dict(rebalance=1.02)),                    # 2 instances per wavefront
+    ("l2rpn_case14_sandbox", 64, dict(rebalance=1.02, is_dc=True)),
+    ("l2rpn_neurips_2020_track1", 33, dict(rebalance=1.02)),               # 1 instance per wavefront
+    ("l2rpn_wcci_2022_dev", 8, dict(rebalance=1.02)),                      # 2 wavefronts per instance, no room for the DC factors
+    ("educ_case14_storage", 16, dict(rebalance=1.0)),
+])
+def test_multi_step_launch_equals_single_steps(name, B, kw, load_model, load_npz):
+    m, ch, e1, tab, off, scale = _setup(load_model, load_npz, name, B)
+    _, _, e2, _, _, _ = _setup(load_model, load_npz, name, B)
+    n = 7
+    e2.set_trajectory(n)
+    snaps = []
+    for t in range(3, 3 + n):
+        e1.step(t, **kw)
+        snaps.append(_snapshot(e1))
+    e2.step(3, n_steps=n, **kw)
+    _same(_snapshot(e2), snaps[-1], name)
+    rho, st = e2.trajectory(n)
+    for k in range(n):
+        assert np.array_equal(st[k], snaps[k]["status"][:, 0]), k
+        assert np.allclose(rho[k], snaps[k]["rho"], rtol=2e-6, atol=1e-6, equal_nan=True), k
+    assert (snaps[-1]["status"][:, 0] == 0).all()
+    # a second multi-step launch continues from the state the first one left (injection rows, counters)
+    e1.step(3 + n, **kw)
+    e1.step(4 + n, **kw)
+    e2.step(3 + n, n_steps=2, **kw)
+    _same(_snapshot(e2), _snapshot(e1), name + " second launch")
+    done, steps, resets = e2.episode()
+    assert not done.any() and (steps == n + 2).all() and (resets == 0).all()
+    e1.close()
+    e2.close()
+
+
+def test_multi_step_last_step_matches_oracle(load_model, load_npz):
+    m, ch, eng, tab, off, scale = _setup(load_model, load_npz, "l2rpn_case14_sandbox", 32)
+    T = tab.shape[0]
+    eng.step(5, n_steps=4, rebalance=1.02)
+    r = eng.results()
+    t = 8
+    for k in range(32):
+        row = (t + off[k]) % T
+        s = LaneState.from_model(m)
+        lp = ch["load_p"][row] * scale[k, :m.n_load]
+        lq = ch["load_q"][row] * scale[k, m.n_load:]
+        pp = ch["prod_p"][row].copy()
+        ns = ~m.gen_slack
+        pp[ns] = pp[ns] * np.float32(1.02 * lp.astype(np.float64).sum() / pp[ns].astype(np.float64).sum())
+        s.load_p, s.load_q, s.gen_p = lp.astype(np.float64), lq.astype(np.float64), pp.astype(np.float64)
+        s.gen_vm = (ch["prod_v"][row] / m.sub_vn_kv[m.gen_sub].astype(np.float32)).astype(np.float64)
+        _compare(m, r, k, solve(m, s))
+    eng.close()
+
+
+@pytest.mark.parametrize("name,B", [("l2rpn_case14_sandbox", 24), ("l2rpn_neurips_2020_track1", 9)])
+def test_multi_step_with_cascade_equals_single_steps(name, B, load_model, load_npz):
+    """Tight thermal limits: lines trip at different steps in different lanes (soft overflows counted over steps, hard
+    overflows at once), some lanes end islanded.  The topology-derived state kept on chip must be dropped exactly then."""
+    m, ch, e1, tab, off, scale = _setup(load_model, load_npz, name, B)
+    _, _, e2, _, _, _ = _setup(load_model, load_npz, name, B)
+    e1.step(0, rebalance=1.02)
+    a0 = e1.results().a_or.copy()
+    lim = (np.median(a0, axis=0) * 1.02).astype(np.float32) + 1.0          # about half of the lanes overflow softly on every line
+    hot = np.argsort(-np.median(a0, axis=0))[:2]
+    lim[hot] = np.median(a0, axis=0)[hot] * 0.45                           # hard overflows
+    kw = dict(rebalance=1.02, cascade=True, hard_overflow=2.0, soft_overflow=1.0, nb_ts_allowed=2)
+    n = 6
+    for e in (e1, e2):
+        e.set_thermal_limits(lim)
+        e.reset()
+    e2.set_trajectory(n)
+    snaps = []
+    for t in range(n):
+        e1.step(t, **kw)
+        snaps.append(_snapshot(e1))
+    e2.step(0, n_steps=n, **kw)
+    _same(_snapshot(e2), snaps[-1], name)
+    _, st = e2.trajectory(n)
+    for k in range(n):
+        assert np.array_equal(st[k], snaps[k]["status"][:, 0]), k
+    tripped = (~snaps[-1]["ls"]).any(axis=1)
+    assert tripped.any() and not tripped.all() or (snaps[-1]["status"][:, 0] != 0).any()
+    t1, _ = e1.get_topology()
+    t2, _ = e2.get_topology()
+    assert np.array_equal(t1, t2)
+    e1.close()
+    e2.close()
+
+
+def test_failing_lanes_done_flags_and_auto_reset(load_model, load_npz):
+    m, ch, eng, tab, off, scale = _setup(load_model, load_npz, "l2rpn_case14_sandbox", 16)
+    # lanes 3 and 10: loads x 6 -> the Newton iteration cannot converge (game over for these lanes)
+    scale2 = scale.copy()
+    scale2[[3, 10]] *= 6.0
+    eng.set_lane_chronics(lane_offset=off, lane_scale=scale2)
+    # every lane starts an episode with line 2 out of service (the topology an auto-reset must come back to)
+    topo = np.tile(m.initial_topo_vect(), (16, 1))
+    topo[:, m.line_or_pos_topo_vect[2]] = -1
+    topo[:, m.line_ex_pos_topo_vect[2]] = -1
+    eng.set_topology(topo)
+    eng.set_trajectory(5)
+    eng.step(0, n_steps=5, rebalance=1.02, auto_reset=True)
+    r = eng.results()
+    done, steps, resets = eng.episode()
+    bad = np.zeros(16, bool)
+    bad[[3, 10]] = True
+    assert np.array_equal(done, bad) and np.array_equal(r.converged, ~bad)
+    assert (steps[~bad] == 5).all() and (steps[bad] == 0).all() and (resets[bad] == 5).all() and (resets[~bad] == 0).all()
+    assert np.isnan(r.out[bad]).all() and (r.topo_vect[bad] == -1).all() and not np.isnan(r.out[~bad]).any()
+    _, st = eng.trajectory(5)
+    assert (st[:, bad] != 0).all() and (st[:, ~bad] == 0).all()
+    t_dev, _ = eng.get_topology()
+    assert np.array_equal(t_dev, topo)                                  # restored for the failed lanes, untouched for the others
+    # the healthy lanes are not disturbed by their failing neighbours (same wavefront): compare with a clean engine
+    _, _, ref, _, _, _ = _setup(load_model, load_npz, "l2rpn_case14_sandbox", 16)
+    ref.set_lane_chronics(lane_offset=off, lane_scale=scale)
+    ref.set_topology(topo)
+    ref.step(0, n_steps=5, rebalance=1.02)
+    rr = ref.results()
+    assert np.allclose(r.out[~bad], rr.out[~bad], rtol=2e-6, atol=2e-5)
+    # once the overload is gone the reset lanes converge again and survive
+    eng.set_lane_chronics(lane_offset=off, lane_scale=scale)
+    eng.step(5, n_steps=3, rebalance=1.02, auto_reset=True)
+    done, steps, resets = eng.episode()
+    assert not done.any() and (steps[bad] == 3).all() and (steps[~bad] == 8).all()
+    eng.close()
+    ref.close()
+
+
+def test_redispatch_delta_matches_oracle(load_model, load_npz):
+    m, ch, eng, tab, off, scale = _setup(load_model, load_npz, "l2rpn_wcci_2022_dev", 6)
+    rng = np.random.default_rng(3)
+    disp = np.nonzero(~m.gen_slack)[0]
+    delta = np.zeros((6, m.n_gen), np.float32)
+    for k in range(6):
+        a, b = rng.choice(disp, 2, replace=False)
+        delta[k, a], delta[k, b] = 1.0, -1.0
+    eng.set_lane_redispatch(delta)
+    eng.step(2, n_steps=2)
+    r = eng.results()
+    T = tab.shape[0]
+    for k in range(6):
+        row = (3 + off[k]) % T
+        s = LaneState.from_model(m)
+        s.load_p = (ch["load_p"][row] * scale[k, :m.n_load]).astype(np.float64)
+        s.load_q = (ch["load_q"][row] * scale[k, m.n_load:]).astype(np.float64)
+        s.gen_p = (ch["prod_p"][row] + delta[k]).astype(np.float64)
+        s.gen_vm = (ch["prod_v"][row] / m.sub_vn_kv[m.gen_sub].astype(np.float32)).astype(np.float64)
+        _compare(m, r, k, solve(m, s))
+    eng.set_lane_redispatch(None)
+    eng.step(3)
+    assert np.abs(eng.results().gen_p - r.gen_p)[:, ~m.gen_slack].max() > 0.5
+    eng.close()
+
+
+def test_zero_copy_device_views(load_model, load_npz):
+    import torch
+    m, ch, eng, tab, off, scale = _setup(load_model, load_npz, "l2rpn_case14_sandbox", 130)
+    eng.step(1, n_steps=3, rebalance=1.02)
+    v = eng.device_views()
+    eng.sync()
+    r = eng.results()
+    rho, ovc, _ = eng.step_outputs()
+    assert v["out"].is_cuda and v["out"].shape == (130, eng.n_out)
+    assert np.array_equal(v["out"].cpu().numpy(), r.out)
+    assert np.array_equal(v["rho"].cpu().numpy(), rho) and np.array_equal(v["overflow_count"].cpu().numpy(), ovc)
+    assert np.array_equal(v["status"].cpu().numpy(), r.status) and np.array_equal(v["topo_vect"].cpu().numpy(), r.topo_vect)
+    assert np.array_equal(v["line_status"].cpu().numpy().astype(bool), r.line_status)
+    assert np.array_equal(v["inj"].cpu().numpy(), eng.get_injections())
+    # the views alias the engine's memory: the next launch shows through without any copy
+    before = v["rho"].clone()
+    eng.step(40, rebalance=1.02)
+    with torch.cuda.stream(v["stream"]):
+        pass
+    eng.sync()
+    assert not torch.equal(before, v["rho"])
+    assert np.array_equal(v["rho"].cpu().numpy(), eng.step_outputs()[0])
+    # a consumer that never leaves the device: worst loading per lane
+    worst = v["rho"].max(dim=1).values
+    assert torch.allclose(worst.cpu(), torch.from_numpy(eng.step_outputs()[0].max(axis=1)))
+    eng.close()
+
+
+@pytest.mark.parametrize("mode", ["GRIDPF_NO_CLASSES", "GRIDPF_NO_PARTITION", "GRIDPF_DCF0"])
+def test_split_batches_in_every_kernel_mode(mode, load_model, load_npz):
+    """A batch with split substations stepped through the fallback kernel modes (NB = n_busbar blocks instead of topology
+    classes, one launch instead of a partition, DC factors not kept) must agree with the default mode."""
+    env = {"GRIDPF_DCF": "0"} if mode == "GRIDPF_DCF0" else {mode: "1"}
+    name, B = "l2rpn_case14_sandbox", 40
+    m, ch, e1, tab, off, scale = _setup(load_model, load_npz, name, B)
+    _, _, e2, _, _, _ = _setup(load_model, load_npz, name, B, env=env)
+    topo = np.tile(m.initial_topo_vect(), (B, 1))
+    sub = int(np.argmax(m.sub_info))
+    start = int(np.concatenate(([0], np.cumsum(m.sub_info)))[sub])
+    pos = np.arange(start, start + m.sub_info[sub])
+    split = np.random.default_rng(1).random(B) < (1.0 if mode == "GRIDPF_NO_PARTITION" else 0.4)
+    for q in pos[::2]:
+        topo[split, q] = 2
+    for e in (e1, e2):
+        e.set_topology(topo)
+    n = 1 if mode == "GRIDPF_NO_CLASSES" else 3           # two launches per step (split / unsplit lanes): single steps only
+    for t in range(3):
+        e1.step(t, n_steps=n, rebalance=1.02)
+        e2.step(t, n_steps=n, rebalance=1.02)
+        _same(_snapshot(e2), _snapshot(e1), (mode, t))
+    assert (e1.results().status[:, 0] == 0).all()
+    if mode == "GRIDPF_NO_CLASSES":
+        from grid2op_amd.engine import GridPFError
+        with pytest.raises(GridPFError):
+            e2.step(0, n_steps=2)
+    e1.close()
+    e2.close()
