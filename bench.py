@@ -197,22 +197,30 @@ def setup_engine(ctx, m, ch, n_envs, fan=1):
     return eng, T, lane0
 
 
-def preroll(eng, step_kw, n):
+def run_steps(eng, t, n, step_kw, spl):
+    """``n`` env steps starting at time index ``t``, ``spl`` steps per launch (the last launch takes the remainder)."""
+    done = 0
+    while done < n:
+        k = min(spl, n - done)
+        eng.step(t + done, n_steps=k, **step_kw)
+        done += k
+    return t + n
+
+
+def preroll(eng, step_kw, n, spl=1):
     """untimed: an idle MI355X needs tens of milliseconds of work to reach its clocks (measured: 2.7x slower steps right
     after a 12 s host-only phase with a 12-step warm-up)"""
-    for t in range(n):
-        eng.step(t, **step_kw)
+    run_steps(eng, 0, n, step_kw, spl)
     eng.sync()
 
 
-def timed_windows(ctx, eng, steps, warmup, step_kw, n_windows, t0=0, preroll_steps=400):
-    """W warm-up steps, then ``n_windows`` windows of exactly ``steps`` steps; returns the per-window (elapsed seconds
-    MAX-reduced over the ranks, kernel ms, launches) and the next time index."""
+def timed_windows(ctx, eng, steps, warmup, step_kw, n_windows, t0=0, preroll_steps=400, spl=None):
+    """W warm-up steps, then ``n_windows`` windows of exactly ``steps`` steps (``spl`` env steps per launch); returns the
+    per-window (elapsed seconds MAX-reduced over the ranks, kernel ms, launches) and the next time index."""
+    spl = ctx.args.steps_per_launch if spl is None else spl
     t = t0
-    preroll(eng, step_kw, max(0, preroll_steps - warmup))
-    for _ in range(warmup):
-        eng.step(t, **step_kw)
-        t += 1
+    preroll(eng, step_kw, max(0, preroll_steps - warmup), spl)
+    t = run_steps(eng, t, warmup, step_kw, spl)
     out = []
     for _ in range(n_windows):
         eng.sync()
@@ -220,9 +228,7 @@ def timed_windows(ctx, eng, steps, warmup, step_kw, n_windows, t0=0, preroll_ste
         ctx.sync_all(eng)
         eng.set_profiling(1)     # ONE HIP event pair on the engine's stream around the K timed launches (no per-launch events)
         w0 = time.perf_counter()
-        for _ in range(steps):
-            eng.step(t, **step_kw)
-            t += 1
+        t = run_steps(eng, t, steps, step_kw, spl)
         ctx.sync_all(eng)
         el = time.perf_counter() - w0
         k_ms, n_l = eng.kernel_time()
@@ -250,6 +256,9 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each (the median one is reported)")
+    ap.add_argument("--steps-per-launch", type=int, default=16,
+                    help="env steps per kernel launch (gpf_step_n): every step does the full work and writes its results; between "
+                         "the steps of a launch the lane state stays on chip (1 = one launch per step, also reported)")
     ap.add_argument("--env", default="l2rpn_case14_sandbox")
     ap.add_argument("--batch", type=int, default=4096, help="lanes per GPU")
     ap.add_argument("--cascade", action="store_true", help="headline with overflow disconnections (cascade loop) enabled")
@@ -324,7 +333,7 @@ def main():
             "config": {"workload": f"{args.env} AC Newton-Raphson DoNothing env.step, batch={B} lanes per GPU "
                                    f"(row (t+7k) mod {T}, loads x (1+0.05 N(0,1)), prod_p rebalanced to 1.02 sum(load))",
                        "env": args.env, "lanes_per_gpu": B, "envs_per_gpu": n_envs, "total_lanes": world * B, "n1_fanout": fan,
-                       "cascade": bool(args.cascade), "max_iter": 10, "tol_mva": 1e-8,
+                       "cascade": bool(args.cascade), "max_iter": 10, "tol_mva": 1e-8, "env_steps_per_launch": args.steps_per_launch,
                        "parallelism": f"independent lanes, static shard x{world} (one process per GPU), no collective"},
             "windows": dict(summarize(wins, total_steps), steps_each=args.steps,
                             note="value / ms_per_step are those of the median window; each window is bracketed by barrier + sync"),
@@ -349,6 +358,13 @@ def main():
     secondary = not args.no_secondary and args.env == "l2rpn_case14_sandbox" and not args.n1 and not args.stub_engine
     k_sec = max(20, args.steps // 4)
     w_sec = max(2, args.warmup // 4)
+
+    # ---- the same workload, ONE launch per env step (a consumer that reads every step's full observation from HBM) -----------
+    if secondary and args.steps_per_launch != 1:
+        w, _ = timed_windows(ctx, eng, k_sec, w_sec, step_kw, 3, preroll_steps=0, spl=1)
+        if rank == 0:
+            res["one_launch_per_step"] = dict(summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec,
+                                              us_per_step=median_window(w)[0] / k_sec * 1e6)
 
     # ---- the same workload with the reference's DEFAULT parameters: overflow disconnections (cascade) on ---------------------
     if secondary and not args.cascade:

@@ -125,7 +125,26 @@ struct Stamps { long long v[32]; };
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #endif
 
+// LIGHT phase boundary for phases that only exchange data through LDS.  The LDS executes the DS instructions of ONE
+// wavefront in issue order (reads, writes and atomics alike), so inside a single-wavefront instance a read issued after
+// another lane's write / atomic of an earlier phase sees it WITHOUT any s_waitcnt in between: only the COMPILER must be kept
+// from moving LDS accesses across the boundary.  __syncthreads() / wavefront-scope fences cost an "s_waitcnt lgkmcnt(0)" per
+// phase -- a full LDS round trip (~100+ cycles) on each of the ~150 phases of a step.  Instances served by several wavefronts
+// (GW > WAVE) keep the real workgroup barrier.  -DGPF_HARD_SYNC restores __syncthreads() everywhere.
+#ifndef GPF_HARD_SYNC
+#define GPF_LSYNC() do { if (GW > WAVE) __syncthreads(); else { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } } while (0)
+#else
+#define GPF_LSYNC() GPF_SYNC()
+#endif
+
 typedef short i16;
+
+// Uniform launch constants (grid sizes, offsets of the symbolic program) reach the kernel through a parameter block in memory.
+// Under SGPR pressure the compiler does not keep them in registers: it RE-LOADS them (s_load_dword + s_waitcnt lgkmcnt(0)) right
+// where they are used -- inside the phases of the LU, where that wait also drains every LDS operation in flight.  Passing a
+// value through pin_sgpr makes it opaque (no longer "a load the compiler may repeat"): it then lives in an SGPR or is spilled to
+// a VGPR lane (v_readlane, no memory wait).
+__device__ __forceinline__ void pin_sgpr(int& x) { x = __builtin_amdgcn_readfirstlane(x); asm volatile("" : "+s"(x)); }
 
 template <int NB>
 struct CarveP {
@@ -384,7 +403,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
         item_words(h0, o, v0, v1);
         do_item(h0, o, v0, v1);
       }
-      GPF_SYNC();
+      GPF_LSYNC();
       h0 = h1; h1 = h2; w0 = nw0; w1 = nw1;
     }
     // deferred scaling (one item per U block / per pivot: no read-write overlap between items)
@@ -404,7 +423,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
       rhs[(size_t)p * 2] = fma(d3, b0, -d1 * b1) * rd;
       rhs[(size_t)p * 2 + 1] = fma(d0, b1, -d2 * b0) * rd;
     }
-    GPF_SYNC();
+    GPF_LSYNC();
   } else
   for (int lv = 0; lv < S.n_levels; ++lv) {
     const int piv_off = prog[8 * lv], n_piv = prog[8 * lv + 1], b_off = prog[8 * lv + 2], n_b = prog[8 * lv + 3], c_off = prog[8 * lv + 4],
@@ -419,7 +438,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
 #pragma unroll
       for (int m = 0; m < B2; ++m) Ad[m] = Di[m];
     }
-    GPF_SYNC();
+    GPF_LSYNC();
     // (b) scale the pivot block rows and right-hand sides: U'_pj = Dinv_p * A_pj, b'_p = Dinv_p * b_p
     //     (items of one block read a whole block column: every pass reads first, then writes)
     if (n_b * B2 + n_piv * BS <= GW) {
@@ -444,10 +463,10 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
         for (int m = 0; m < BS; ++m) acc = fma(Di[m], bp[m], acc);
         dst = -(p * BS + (it % BS)) - 2;
       }
-      GPF_SYNC();
+      GPF_LSYNC();
       if (dst >= 0) A[dst] = acc;
       else if (dst <= -2) rhs[-(dst + 2)] = acc;
-      GPF_SYNC();
+      GPF_LSYNC();
     } else {
     for (int base = 0; base < n_b * B2; base += CHB) {
       const int it = base + tid;
@@ -463,9 +482,9 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
 #pragma unroll
         for (int m = 0; m < BS; ++m) acc = fma(Di[m], Au[m * BS], acc);
       }
-      GPF_SYNC();
+      GPF_LSYNC();
       if (on) A[(size_t)us * B2 + (it % B2)] = acc;
-      GPF_SYNC();
+      GPF_LSYNC();
     }
     for (int base = 0; base < n_piv * BS; base += CHR) {
       const int it = base + tid;
@@ -479,9 +498,9 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
 #pragma unroll
         for (int m = 0; m < BS; ++m) acc = fma(Di[m], bp[m], acc);
       }
-      GPF_SYNC();
+      GPF_LSYNC();
       if (on) rhs[(size_t)p * BS + (it % BS)] = acc;
-      GPF_SYNC();
+      GPF_LSYNC();
     }
     }
     // (c) trailing updates A[dst] -= A[l] * U'[u] and rhs[row] -= A[l] * b'[p] (LDS atomics: blocks / rows may collide)
@@ -507,7 +526,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
       for (int m = 0; m < BS; ++m) acc = fma(Al[m], bp[m], acc);
       atomicAdd(&rhs[(size_t)(w0 >> 16) * BS + r], -acc);
     }
-    GPF_SYNC();
+    GPF_LSYNC();
   }
 #ifdef GPF_TIMING
   const long long t_lu1 = __builtin_readcyclecounter();
@@ -542,7 +561,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
         words(h0, o, v, q);
         item(h0, o, v, q);
       }
-      GPF_SYNC();
+      GPF_LSYNC();
       h0 = h1; h1 = h2; w = nw; p = np;
     }
   } else
@@ -558,7 +577,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
       for (int m = 0; m < BS; ++m) acc = fma(Au[m], xj[m], acc);
       atomicAdd(&rhs[(size_t)p * BS + r], -acc);
     }
-    GPF_SYNC();
+    GPF_LSYNC();
   }
 #ifdef GPF_TIMING
   if (dbg) { dbg[0] = t_lu1 - t_lu0; dbg[1] = (long long)__builtin_readcyclecounter() - t_lu1; }
@@ -609,7 +628,7 @@ __device__ inline bool scalar_lu_solve(const SymDev& S, PP prog, double* __restr
       item_words(h0, o, v0, v1);
       do_item(h0, o, v0, v1);
     }
-    if (FACTOR || h0.w > 0) GPF_SYNC();               // (h0 is uniform over the block)
+    if (FACTOR || h0.w > 0) GPF_LSYNC();               // (h0 is uniform over the block)
     h0 = h1; h1 = h2; w0 = nw0; w1 = nw1;
   }
   if (FACTOR)
@@ -623,7 +642,7 @@ __device__ inline bool scalar_lu_solve(const SymDev& S, PP prog, double* __restr
     if (FACTOR && (!(fabs(d) > 1e-300) || !(fabs(d) < 1e300))) ok = false;
     rhs[(size_t)p * 2] *= fast_rcp(d);
   }
-  GPF_SYNC();
+  GPF_LSYNC();
 #ifdef GPF_TIMING
   const long long t_lu1 = __builtin_readcyclecounter();
 #endif
@@ -650,7 +669,7 @@ __device__ inline bool scalar_lu_solve(const SymDev& S, PP prog, double* __restr
         words(g0, o, v, q);
         item(g0, o, v, q);
       }
-      GPF_SYNC();
+      GPF_LSYNC();
       g0 = g1; g1 = g2; w = nw; p = np;
     }
   }
@@ -686,7 +705,10 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   constexpr int GW = G::GW;
   constexpr int BS = 2 * NB;
   constexpr int B2 = BS * BS;
-  const GridDev& g = P->g;
+  GridDev g_loc = P->g;                                  // sizes pinned in registers (see pin_sgpr)
+  pin_sgpr(g_loc.n_sub); pin_sgpr(g_loc.n_line); pin_sgpr(g_loc.n_gen); pin_sgpr(g_loc.n_load); pin_sgpr(g_loc.n_sto);
+  pin_sgpr(g_loc.n_shunt); pin_sgpr(g_loc.dim_topo); pin_sgpr(g_loc.nb_tot);
+  const GridDev& g = g_loc;
   const Bufs& b = P->b;
   const OutOff& oo = P->oo;
   const int nsub = g.n_sub;
@@ -719,7 +741,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     c.Psp[i] = 0.0; c.Qsp[i] = 0.0; c.Gs[i] = 0.0;
   }
   if (NB == 1 && !TC && !reuse) for (int i = tid; i < nsub; i += GW) c.sub_bb[i] = 1;
-  GPF_SYNC();
+  GPF_LSYNC();
   GPF_STAMPS(27);
   const int* topo = c.topo;
   auto bus_of = [&](int sub, int local) -> int {
@@ -806,7 +828,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     } else bu = c.sh_b[i];
     if (bu >= 0) atomicAdd(&c.Gs[bu], GPF_INJ(oo.inj_sh_p + i) * sv.shunt_fact[i] * inv_sn);
   }
-  GPF_SYNC();
+  GPF_LSYNC();
   GPF_STAMPS(28);
   int nb = 0, nref = 0;
   for (int i0 = 0; i0 < nbus; i0 += GW) {
@@ -825,7 +847,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   }
   if (reuse) nb = ts.nb;
   nb_out = nb;
-  GPF_SYNC();
+  GPF_LSYNC();
   int status = reuse ? ts.status : ((nref == 0) ? 3 : 0);           // first failure of this group (0 = alive)
   if (!reuse) { ts.status = status; ts.nb = nb; }
   if (G::block_all(status != 0)) return status;
@@ -847,7 +869,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         if (lf != lt) { c.lab[f] = 1; c.lab[t] = 1; changed = 1; }
       }
     }
-    GPF_SYNC();
+    GPF_LSYNC();
     if (!G::block_any(changed)) break;      // extra sweeps of a settled group are idempotent
   }
   {
@@ -867,7 +889,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   if (!dc_kept || do_y) {
   if (do_y) for (int i = tid; i < S.nslot_y * NB * NB * 2; i += GW) c.Yb[i] = 0.0;
   if (!dc_kept) for (int i = tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
-  GPF_SYNC();
+  GPF_LSYNC();
   for (int l = tid; l < g.n_line; l += GW) {
     const int f = c.lor_b[l], t = c.lex_b[l];
     if (f < 0) continue;
@@ -906,7 +928,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       }
     }
   }
-  GPF_SYNC();
+  GPF_LSYNC();
   }
   // identity rows (fixed variables) + DC right-hand side
   for (int i = tid; i < nbus; i += GW) {
@@ -920,7 +942,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     c.rhs[(size_t)sub * BS + 2 * bi] = th_live ? (c.Psp[i] - c.Gs[i]) : 0.0;
     c.rhs[(size_t)sub * BS + 2 * bi + 1] = 0.0;
   }
-  GPF_SYNC();
+  GPF_LSYNC();
   GPF_STAMPS(3);
   // the program is in LDS (tier >= 1) or read in place through a global-address-space pointer (tier 0)
   auto lu_ac = [&](long long* dbg) -> bool {
@@ -951,7 +973,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     }
     if (NB == 1 && ctl.dcf && !dc_kept)                            // keep the factors for the next solves of this launch
       for (int q = tid; q < S.nslot; q += GW) c.Adc[q] = c.A[(size_t)q * 2];
-    GPF_SYNC();
+    GPF_LSYNC();
     if (status == 0 && G::any(!ok)) status = 4;
     if (G::block_all(status != 0)) return status;
   }
@@ -976,7 +998,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     }
     if (BS == 2) { for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; } }
     else for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;     // fill blocks start at zero
-    GPF_SYNC();
+    GPF_LSYNC();
     GPF_STAMPS(10);
     while (true) {
       // Jacobian blocks from the Ybus blocks: T_ij = V_i conj(Y_ij V_j); S_i += T_ij (LDS atomics)
@@ -1001,7 +1023,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         *reinterpret_cast<double2*>(bel(slot, 2 * bi + 1, 2 * bj)) = make_double2((rowQ && colT) ? -tr_ : 0.0, (rowQ && colV) ? ti_ * ivmj : 0.0);
         if (act && (yr != 0.0 || yi != 0.0)) { atomicAdd(&c.Sre[i], tr_); atomicAdd(&c.Sim[i], ti_); }
       }
-      GPF_SYNC();
+      GPF_LSYNC();
       if (it == 0) GPF_STAMPS(11);
       double fabs_mis = 0.0;
       bool bad = false;
@@ -1032,7 +1054,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         else ++it;
       }
       if (G::block_all(done)) break;
-      GPF_SYNC();
+      GPF_LSYNC();
       if (it == 1) GPF_STAMPS(12);
       const bool ok = lu_ac(nullptr);
       if (it == 1) GPF_STAMPS(13);
@@ -1061,7 +1083,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       }
       if (BS == 2) { for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; } }
     else for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
-      GPF_SYNC();
+      GPF_LSYNC();
       if (!done && (G::any(!ok) || G::any(!fin))) { status = 4; done = true; }
       if (it == 1) GPF_STAMPS(14);
     }
@@ -1075,10 +1097,10 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   const auto out = gptr(b.out) + (size_t)inst * g.n_out;
   const double RAD2DEG = 57.295779513082320877;
   const double SQRT3 = 1.7320508075688772935;
-  GPF_SYNC();
+  GPF_LSYNC();
   if (is_dc) {
     for (int i = tid; i < nbus; i += GW) { c.Sre[i] = c.Gs[i]; c.Sim[i] = 0.0; }
-    GPF_SYNC();
+    GPF_LSYNC();
     for (int l = tid; l < g.n_line; l += GW) {
       const int f = c.lor_b[l], t = c.lex_b[l];
       if (f < 0) continue;
@@ -1086,7 +1108,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       atomicAdd(&c.Sre[f], fl);
       atomicAdd(&c.Sre[t], -fl);
     }
-    GPF_SYNC();
+    GPF_LSYNC();
   }
   for (int l = tid; l < g.n_line; l += GW) {
     const int f = c.lor_b[l], t = c.lex_b[l];
@@ -1155,9 +1177,9 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     double* qmax_t = c.A + nbus;
     int* cnt = reinterpret_cast<int*>(c.A + 2 * (size_t)nbus);
     int* nsl = cnt + nbus;
-    GPF_SYNC();
+    GPF_LSYNC();
     for (int i = tid; i < nbus; i += GW) { qmin_t[i] = 0.0; qmax_t[i] = 0.0; cnt[i] = 0; nsl[i] = 0; }
-    GPF_SYNC();
+    GPF_LSYNC();
     for (int i = tid; i < g.n_gen; i += GW) {
       const int bu = c.gen_b[i];
       if (bu < 0) continue;
@@ -1166,7 +1188,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       atomicAdd(&qmax_t[bu], sv.gen_max_q[i]);
       if (sv.gen_slack[i]) atomicAdd(&nsl[bu], 1);
     }
-    GPF_SYNC();
+    GPF_LSYNC();
     GPF_STAMPS(24);
     for (int i = tid; i < g.n_gen; i += GW) {
       const int bu = c.gen_b[i];
@@ -1224,9 +1246,11 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
 // tables come from the class of the block's lanes (the host packs lanes of ONE class into a block), LDS is sized for the
 // largest class of the launch.
 #define GPF_CARVE_AND_VIEW(G_)                                                                                                   \
-  SymDev S_tc;                                                                                                                   \
-  if (TC) S_tc = P->classes[gptr(lane_class)[blockIdx.x * IPW]].sym;                                                        \
-  const SymDev& S = TC ? S_tc : P->sym;                                                                                          \
+  SymDev S_loc = P->sym;                                                                                                         \
+  if (TC) S_loc = P->classes[gptr(lane_class)[blockIdx.x * IPW]].sym;                                                            \
+  pin_sgpr(S_loc.n); pin_sgpr(S_loc.nslot); pin_sgpr(S_loc.nslot_y); pin_sgpr(S_loc.n_levels); pin_sgpr(S_loc.back_off);         \
+  pin_sgpr(S_loc.scale_off); pin_sgpr(S_loc.n_scale); pin_sgpr(S_loc.back_first); pin_sgpr(S_loc.static_connected);              \
+  const SymDev& S = S_loc;                                                                                                       \
   const int lds_rows = TC ? P->tc_rows : -1, lds_nslot = TC ? P->tc_nslot : P->sym.nslot,                                        \
             lds_nslot_y = TC ? P->tc_nslot_y : P->sym.nslot_y;                                                                   \
   const bool lds_dcf = !TC && P->dcf != 0;                                                                                       \
@@ -1280,8 +1304,9 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   const GridDev& g = P->g;
   const Bufs& b = P->b;
   const OutOff& oo = P->oo;
-  const int grp = threadIdx.x / GW, tid = threadIdx.x % GW;
-  const int inst = lane_list ? gptr(lane_list)[blockIdx.x * IPW + grp] : blockIdx.x * IPW + grp;   // ghost-padded by the host
+  const int grp0 = threadIdx.x / GW, tid0 = threadIdx.x % GW;
+  const int inst0 = lane_list ? gptr(lane_list)[blockIdx.x * IPW + grp0] : blockIdx.x * IPW + grp0;   // ghost-padded by the host
+  int grp = grp0, tid = tid0, inst = inst0;
   const bool ghost = inst >= (int)b.n_real_lanes;               // padding lane of an instance group: computes, never mutates state
   CarveP<NB> c;
   GPF_CARVE_AND_VIEW(g);
@@ -1293,36 +1318,42 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   const int off = b.lane_offset ? gptr(b.lane_offset)[inst] : 0;
   int row = (sa.t + off) % sa.T;
   if (row < 0) row += sa.T;
-  const auto ch_tab = gptr(b.chron) + (size_t)tab * sa.T * g.n_chron;
   const bool has_sc = b.lane_scale != nullptr;
-  const auto sc = gptr(b.lane_scale) + (size_t)inst * 2 * g.n_load;
   const bool has_delta = b.lane_gen_delta != nullptr;
-  const auto gdelta = gptr(b.lane_gen_delta) + (size_t)inst * g.n_gen;
-  const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj;
-  const auto ovc = gptr(b.overflow_count) + (size_t)inst * g.n_line;    // env._protection_counter (persistent)
-  const auto dround = gptr(b.disc_round) + (size_t)inst * g.n_line;
-  const auto rho = gptr(b.rho) + (size_t)inst * g.n_line;
-  const auto out = gptr(b.out) + (size_t)inst * g.n_out;
-  const auto topo = gptr(b.topo) + (size_t)inst * g.dim_topo;
-  const auto thermal_limit = gptr(b.thermal_limit);
   // jitter factors and redispatch delta of the elements this thread handles first stay in registers for the whole launch
-  const float sc_p0 = (has_sc && tid < g.n_load) ? sc[tid] : 1.f, sc_q0 = (has_sc && tid < g.n_load) ? sc[g.n_load + tid] : 1.f;
-  const float gd0 = (has_delta && tid < g.n_gen) ? gdelta[tid] : 0.f;
-  if (STAGE) for (int i = oo.inj_sto_p + tid; i < g.n_inj; i += GW) c.inj[i] = inj_g[i];      // storage / shunt set-points
+  float sc_p0 = 1.f, sc_q0 = 1.f, gd0 = 0.f;
+  if (has_sc && tid < g.n_load) { const auto sc = gptr(b.lane_scale) + (size_t)inst * 2 * g.n_load; sc_p0 = sc[tid]; sc_q0 = sc[g.n_load + tid]; }
+  if (has_delta && tid < g.n_gen) gd0 = gptr(b.lane_gen_delta)[(size_t)inst * g.n_gen + tid];
+  if (STAGE) { const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj; for (int i = oo.inj_sto_p + tid; i < g.n_inj; i += GW) c.inj[i] = inj_g[i]; }   // storage / shunt set-points
   TopoState ts;
   ts.status = 0; ts.nb = 0;
   bool reuse = false;                                         // block-uniform
   int n_iter = 0, nb = 0, st = 0, rounds = 0;
   int ep_steps = 0, ep_resets = 0;
   if (tid == 0 && !ghost) { ep_steps = gptr(b.episode)[2 * (size_t)inst]; ep_resets = gptr(b.episode)[2 * (size_t)inst + 1]; }
+  // Every step (and every cascade round) runs the same code on the same addresses, so the compiler would hoist each per-thread
+  // pointer, offset and table entry it finds out of the loops (loop-invariant code motion) and keep them live for the whole
+  // launch: > 250 VGPRs plus scratch spills.  GPF_REDERIVE makes the thread's coordinates opaque and re-derives the LDS carve
+  // from them, so that what is live at a loop head is only what the loop really carries.
+#define GPF_REDERIVE()                                                                                              \
+  do {                                                                                                              \
+    grp = grp0; tid = tid0; inst = inst0;                                                                           \
+    asm volatile("" : "+v"(grp), "+v"(tid), "+v"(inst));                                                            \
+    carve_sparse<NB>(c, smem + (size_t)grp * per_inst, g, lds_nslot, lds_nslot_y, STAGE != 0, lds_rows, lds_dcf);   \
+  } while (0)
   for (int step = 0; step < sa.n_steps; ++step) {
+    GPF_REDERIVE();
     const bool last = step + 1 == sa.n_steps;
+    GPF_STAMPS(19);
     // ---- K9: chronics row -> injections -----------------------------------------------------------------------------------
     {
-      const auto ch = ch_tab + (size_t)row * g.n_chron;
+      const auto ch = gptr(b.chron) + ((size_t)tab * sa.T + row) * g.n_chron;
+      const auto sc = gptr(b.lane_scale) + (size_t)inst * 2 * g.n_load;
+      const auto gdelta = gptr(b.lane_gen_delta) + (size_t)inst * g.n_gen;
+      const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj;
       // all global loads of the phase are issued up front (one round trip): the lane's topology row (when the topology phases
       // run again) and the first pass of the chronics row
-      if (!reuse) for (int i = tid; i < g.dim_topo; i += GW) c.topo[i] = topo[i];
+      if (!reuse) { const auto topo = gptr(b.topo) + (size_t)inst * g.dim_topo; for (int i = tid; i < g.dim_topo; i += GW) c.topo[i] = topo[i]; }
       const float pp_pre = tid < g.n_gen ? ch[2 * g.n_load + tid] : 0.f;
       const float pv_pre = tid < g.n_gen ? ch[2 * g.n_load + g.n_gen + tid] : 1.f;
       double sum_load = 0.0, sum_prod = 0.0;
@@ -1358,16 +1389,20 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
     }
     // ---- power flow + K7 (Backend.next_grid_state) --------------------------------------------------------------------------
     n_iter = 0; nb = 0; st = 0; rounds = 0;
-    for (int l = tid; l < g.n_line; l += GW) dround[l] = -1;
-    // Backend.next_grid_state keeps a LOCAL copy of the protection counters that is advanced at most once per line
-    // and per call (backend.py:1476-1520): local value = ovc + (line already counted this call ? 1 : 0); the "already
-    // counted" flag lives in the rho buffer, reused as int scratch until the end of the step.
-    const auto inc_flag = (GPF_GLOBAL int*)rho;
-    if (sa.cascade) for (int l = tid; l < g.n_line; l += GW) inc_flag[l] = 0;
+    {
+      const auto dround = gptr(b.disc_round) + (size_t)inst * g.n_line;
+      for (int l = tid; l < g.n_line; l += GW) dround[l] = -1;
+      // Backend.next_grid_state keeps a LOCAL copy of the protection counters that is advanced at most once per line
+      // and per call (backend.py:1476-1520): local value = ovc + (line already counted this call ? 1 : 0); the "already
+      // counted" flag lives in the rho buffer, reused as int scratch until the end of the step.
+      const auto inc_flag = (GPF_GLOBAL int*)(gptr(b.rho) + (size_t)inst * g.n_line);
+      if (sa.cascade) for (int l = tid; l < g.n_line; l += GW) inc_flag[l] = 0;
+    }
     bool more = true;                                           // this group still cascades
     bool first = true;
     bool tripped = false;                                       // this group tripped a line during this step
     while (true) {
+      GPF_REDERIVE();
       // a group whose cascade has ended re-solves its unchanged state along with the others (same results)
       int it_k = 0, nb_k = 0;
       SolveCtl ctl;
@@ -1378,20 +1413,27 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       if (more) { st = st_k; n_iter = it_k; nb = nb_k; }
       if (st != 0 || !sa.cascade || rounds >= sa.max_rounds) more = false;   // at most max_rounds re-solves
       int any_disc = 0;
-      if (more && !ghost)
-      for (int l = tid; l < g.n_line; l += GW) {
-        const float a = out[oo.a_or + l];
-        const float lim = thermal_limit[l];
-        const bool on = c.lor_b[l] >= 0;
-        bool disc = on && (a > sa.hard_overflow * lim);
-        int inc = inc_flag[l];
-        if (on && (a > sa.soft_overflow * lim) && !inc) { inc = 1; inc_flag[l] = 1; }
-        if (on && (ovc[l] + inc) > sa.nb_ts_allowed) disc = true;
-        if (disc) {
-          topo[sv.line_or_pos[l]] = -1;
-          topo[sv.line_ex_pos[l]] = -1;
-          dround[l] = rounds;
-          any_disc = 1;
+      if (more && !ghost) {
+        const auto out = gptr(b.out) + (size_t)inst * g.n_out;
+        const auto ovc = gptr(b.overflow_count) + (size_t)inst * g.n_line;
+        const auto dround = gptr(b.disc_round) + (size_t)inst * g.n_line;
+        const auto inc_flag = (GPF_GLOBAL int*)(gptr(b.rho) + (size_t)inst * g.n_line);
+        const auto topo = gptr(b.topo) + (size_t)inst * g.dim_topo;
+        const auto thermal_limit = gptr(b.thermal_limit);
+        for (int l = tid; l < g.n_line; l += GW) {
+          const float a = out[oo.a_or + l];
+          const float lim = thermal_limit[l];
+          const bool on = c.lor_b[l] >= 0;
+          bool disc = on && (a > sa.hard_overflow * lim);
+          int inc = inc_flag[l];
+          if (on && (a > sa.soft_overflow * lim) && !inc) { inc = 1; inc_flag[l] = 1; }
+          if (on && (ovc[l] + inc) > sa.nb_ts_allowed) disc = true;
+          if (disc) {
+            topo[sv.line_or_pos[l]] = -1;
+            topo[sv.line_ex_pos[l]] = -1;
+            dround[l] = rounds;
+            any_disc = 1;
+          }
         }
       }
       GPF_SYNC();
@@ -1401,18 +1443,25 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       if (more) ++rounds;
     }
     GPF_STAMPS(9);
+    GPF_REDERIVE();
     // ---- per-step outputs -----------------------------------------------------------------------------------------------------
     if (st != 0) write_nan_results<GW>(g, b, inst, tid);
     GPF_SYNC();
-    GPF_GLOBAL float* traj = nullptr;
-    if (b.traj_rho && step < b.traj_cap) traj = gptr(b.traj_rho) + ((size_t)step * b.lane_stride + inst) * g.n_line;
-    for (int l = tid; l < g.n_line; l += GW) {
-      const float lim = thermal_limit[l];
-      const float a = out[oo.a_or + l];
-      const float r_ = a / lim;
-      rho[l] = r_;
-      if (traj) traj[l] = r_;
-      if (!ghost) { if (a > sa.soft_overflow * lim) ovc[l] += 1; else ovc[l] = 0; }
+    {
+      const auto out = gptr(b.out) + (size_t)inst * g.n_out;
+      const auto ovc = gptr(b.overflow_count) + (size_t)inst * g.n_line;
+      const auto rho = gptr(b.rho) + (size_t)inst * g.n_line;
+      const auto thermal_limit = gptr(b.thermal_limit);
+      GPF_GLOBAL float* traj = nullptr;
+      if (b.traj_rho && step < b.traj_cap) traj = gptr(b.traj_rho) + ((size_t)step * b.lane_stride + inst) * g.n_line;
+      for (int l = tid; l < g.n_line; l += GW) {
+        const float lim = thermal_limit[l];
+        const float a = out[oo.a_or + l];
+        const float r_ = a / lim;
+        rho[l] = r_;
+        if (traj) traj[l] = r_;
+        if (!ghost) { if (a > sa.soft_overflow * lim) ovc[l] += 1; else ovc[l] = 0; }
+      }
     }
     const bool failed = st != 0;
     if (tid == 0) {
@@ -1428,16 +1477,22 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
     // chronics cursor keeps running: the next step is the first of a new episode)
     if (failed && sa.auto_reset && !ghost) {
       const auto t0 = gptr(b.topo0) + (size_t)inst * g.dim_topo;
+      const auto topo = gptr(b.topo) + (size_t)inst * g.dim_topo;
+      const auto ovc = gptr(b.overflow_count) + (size_t)inst * g.n_line;
       for (int i = tid; i < g.dim_topo; i += GW) topo[i] = t0[i];
       for (int l = tid; l < g.n_line; l += GW) ovc[l] = 0;
     }
     // the topology-derived state stands for the next step only if NO group of the block changed or lost its topology
     reuse = !G::block_any(failed || tripped);
+    GPF_STAMPS(7);
     if (++row >= sa.T) row = 0;
     if (!last) GPF_SYNC();
   }
+#undef GPF_REDERIVE
+  grp = grp0; tid = tid0; inst = inst0;
   if (tid == 0 && !ghost) { gptr(b.episode)[2 * (size_t)inst] = ep_steps; gptr(b.episode)[2 * (size_t)inst + 1] = ep_resets; }
   if (STAGE && !ghost) {                                      // the last step's injection row -> HBM (gpf_get_injections, next launches)
+    const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj;
     for (int i = tid; i < oo.inj_sto_p; i += GW) inj_g[i] = c.inj[i];
   }
   GPF_STAMPS(15);

@@ -76,8 +76,8 @@ class StubEngine:
     def runpf(self, lane0=0, n=None, **kw):
         self.n_runpf += 1
 
-    def step(self, t, **kw):
-        self.n_steps += 1
+    def step(self, t, n_steps=1, **kw):
+        self.n_steps += n_steps
 
     def sync(self):
         pass

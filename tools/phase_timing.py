@@ -24,8 +24,9 @@ ch = dict(np.load(os.path.join(gold, f"{env}.chronics.npz")))
 eng = PowerFlowEngine(m, n_lanes=B)
 eng.upload_chronics(eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch.get("prod_v", np.tile((m.gen_vm0 * m.sub_vn_kv[m.gen_sub]).astype(np.float32), (ch["prod_p"].shape[0], 1)))))
 eng.set_lane_chronics(lane_offset=(7 * np.arange(B)) % ch["load_p"].shape[0])
+NS = int(os.environ.get("NSTEPS", "1"))
 for t in range(5):
-    eng.step(t, rebalance=1.02)
+    eng.step(t * NS, rebalance=1.02, n_steps=NS)
 eng.sync()
 L = _capi.lib()
 buf = np.zeros((B, 32))
@@ -37,16 +38,22 @@ if SPARSE:
                4: "DC block-LU solve", 5: "Newton loop total", 6: "results", 9: "cascade check / back in step kernel", 15: "rho + counters"}
     order_s = [8, 0, 1, 2, 3, 4, 5, 6, 9, 15]
     med = np.median(buf, axis=0)
-    print(f"[kernel S] {env} batch {B}: median cycle counts per phase")
+    print(f"[kernel S] {env} batch {B}, {NS} step(s) per launch: median cycle counts per phase (LAST step of the launch)")
+    print(f"  launch prologue (carve, static staging, lane constants) {med[19] - med[8]:10.0f}" if NS == 1 else
+          f"  whole launch {med[15] - med[8]:.0f} cycles = {(med[15] - med[8]) / NS:.0f} per step")
+    med[8] = med[19]
+    names_s[9] = "cascade check"
+    names_s[7] = "rho + counters + episode"
+    order_s = [8, 0, 1, 2, 3, 4, 5, 6, 9, 7]
     prev = med[8]
     for k in order_s[1:]:
         print(f"  {names_s[k]:45s} {med[k] - prev:10.0f}")
         prev = med[k]
-    print(f"  {'TOTAL':45s} {med[15] - med[8]:10.0f}")
+    print(f"  {'TOTAL (one step)':45s} {med[7] - med[8]:10.0f}")
     print(f"  DC block-LU: elimination levels + scaling {med[20]:.0f}, back substitution {med[21]:.0f} cycles")
     print(f"  first Newton iteration: initial sincos {med[10] - med[4]:.0f}, Jacobian blocks + S {med[11] - med[10]:.0f}, "
           f"diag + mismatch + test {med[12] - med[11]:.0f}, block LU {med[13] - med[12]:.0f}, update + sincos {med[14] - med[13]:.0f}")
-    print(f"  K9 detail: row address {med[16] - med[8]:.0f}, load rows + sums {med[17] - med[16]:.0f}, reductions {med[18] - med[17]:.0f}, "
+    print(f"  K9 detail: topo row + first loads {med[16] - med[8]:.0f}, load rows + sums {med[17] - med[16]:.0f}, reductions {med[18] - med[17]:.0f}, "
           f"gens + stores {med[0] - med[18]:.0f}")
     print(f"  K1 detail: topo row -> LDS {med[27] - med[0]:.0f}, element loops (atomics) {med[28] - med[27]:.0f}, types / counts {med[1] - med[28]:.0f}")
     print(f"  results detail: line flows {med[22] - med[5]:.0f}, loads/storages/shunts {med[23] - med[22]:.0f}, gen accumulate {med[24] - med[23]:.0f}, "
