@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libgridpf.so"
 
 EXPORTED_SYMBOLS = [
-    "gpf_last_error", "gpf_version", "gpf_device_count", "gpf_create", "gpf_destroy", "gpf_get_layout", "gpf_n_lanes",
+    "gpf_last_error", "gpf_version", "gpf_set_deterministic", "gpf_device_count", "gpf_create", "gpf_destroy", "gpf_get_layout", "gpf_n_lanes",
     "gpf_set_injections", "gpf_set_topology", "gpf_get_injections", "gpf_get_topology", "gpf_disconnect_line",
     "gpf_reset_lanes", "gpf_copy_lanes", "gpf_fanout_n1", "gpf_runpf", "gpf_get_results", "gpf_upload_chronics",
     "gpf_set_lane_chronics", "gpf_set_thermal_limits", "gpf_step", "gpf_step_n", "gpf_set_lane_redispatch", "gpf_set_trajectory",
@@ -111,6 +111,7 @@ def lib() -> C.CDLL:
     L.gpf_last_error.argtypes = []
     L.gpf_version.restype = C.c_int
     L.gpf_device_count.argtypes = [_ip]
+    L.gpf_set_deterministic.argtypes = [h, i32]
     L.gpf_create.argtypes = [C.POINTER(GpfGridDesc), i32, i32, C.POINTER(h)]
     L.gpf_destroy.argtypes = [h]
     L.gpf_get_layout.argtypes = [h, C.POINTER(GpfLayout)]

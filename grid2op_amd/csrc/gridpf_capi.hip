@@ -154,7 +154,8 @@ struct gpf_engine {
   bool no_classes = false;              // GRIDPF_NO_CLASSES=1: split lanes run the NB = n_busbar kernel
   bool no_partition = false;     // GRIDPF_NO_PARTITION=1
   int ipw_override = 0;        // GRIDPF_IPW=1|2|4 (developer override of the instances-per-wavefront heuristic)
-  int wpi_override = 0;        // GRIDPF_WPI=1|2|4 (developer override of the wavefronts-per-instance heuristic)
+  int wpi_override = 0;        // GRIDPF_WPI=1|2 (developer override of the wavefronts-per-instance heuristic); 1 = deterministic
+  int wpi_env = 0;
   int cap_lanes = 0;           // lane buffers are padded to a multiple of 4 lanes (instance groups of a wavefront)
   std::vector<int> lane_mb;    // max live busbars in one substation, per lane
   int init_mb = 1;
@@ -558,7 +559,10 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     const char* iw = std::getenv("GRIDPF_IPW");
     e->ipw_override = (iw && (iw[0] == '1' || iw[0] == '2' || iw[0] == '4')) ? iw[0] - '0' : 0;
     const char* ww = std::getenv("GRIDPF_WPI");
-    e->wpi_override = (ww && (ww[0] == '1' || ww[0] == '2' || ww[0] == '4')) ? ww[0] - '0' : 0;
+    e->wpi_override = (ww && (ww[0] == '1' || ww[0] == '2')) ? ww[0] - '0' : 0;
+    const char* det = std::getenv("GRIDPF_DETERMINISTIC");
+    if (det && det[0] == '1') e->wpi_override = 1;
+    e->wpi_env = e->wpi_override;
   }
   e->n_lanes = n_lanes;
   e->cap_lanes = (n_lanes + 7) & ~3;          // >= 4 ghost lanes (pristine state): padding of instance groups / lane lists
@@ -754,6 +758,13 @@ int gpf_destroy(gpf_handle e) {
 int gpf_get_layout(gpf_handle e, gpf_layout* out) {
   if (!e || !out) return fail(GPF_E_INVALID, "gpf_get_layout: null");
   *out = e->layout;
+  return GPF_OK;
+}
+
+int gpf_set_deterministic(gpf_handle e, int32_t flag) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_set_deterministic: null");
+  e->wpi_override = flag ? 1 : e->wpi_env;
+  e->plan_valid = false;
   return GPF_OK;
 }
 

@@ -73,7 +73,7 @@ class LaneResults:
 
 
 class PowerFlowEngine:
-    def __init__(self, model: GridModel, n_lanes: int = 1, device: int = 0, n_busbar: int = 2):
+    def __init__(self, model: GridModel, n_lanes: int = 1, device: int = 0, n_busbar: int = 2, deterministic: bool = False):
         self.model = model
         self.n_busbar = int(n_busbar)
         self._lib = _capi.lib()
@@ -123,6 +123,8 @@ class PowerFlowEngine:
         d.init_shunt_bus = ptr(keep["init_shunt_bus"], C.c_int32)
         check(self._lib.gpf_create(C.byref(d), int(n_lanes), int(device), C.byref(self._h)), "gpf_create")
         self._pid = os.getpid()          # HIP handles belong to the creating process (a forked child must not destroy them)
+        if deterministic:
+            self.set_deterministic(True)
         self.n_lanes = int(n_lanes)
         self.device = int(device)
         lay = GpfLayout()
@@ -153,6 +155,11 @@ class PowerFlowEngine:
             self.close()
         except Exception:
             pass
+
+    def set_deterministic(self, flag: bool = True):
+        """Bit-identical results from run to run on grids with >= 64 substations too (one wavefront per lane instead of two,
+        ~7 % slower there); small grids always are."""
+        check(self._lib.gpf_set_deterministic(self._h, int(bool(flag))), "gpf_set_deterministic")
 
     def _range(self, lane0, n):
         if n is None:
