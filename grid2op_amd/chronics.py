@@ -7,6 +7,11 @@ step (reader in the reference: grid2op/Chronics/gridStateFromFile.py).  Columns 
 BY NAME (optionally through the ``names_chronics_to_backend`` mapping of the environment,
 grid2op/Environment/environment.py:431-437).  Environments without ``prod_v.csv`` take the voltage set-points from the
 ``V`` column of ``prods_charac.csv`` (kV) -- what ``ControlVoltageFromFile`` ends up applying every step.
+``maintenance.csv`` / ``hazards.csv`` (0/1 per line and row, header = LINE names) are read when present.
+
+`load_chronics_multifolder` does what ``grid2op.Chronics.Multifolder`` (grid2op/Chronics/multiFolder.py) does at
+``initialize``: every sub-folder of the chronics directory is one scenario, taken in SORTED order; the result is one stacked
+table per quantity, ``[n_scenarios, T, n]``, i.e. the ``n_tables`` the engine indexes per lane (``lane_table``).
 """
 from __future__ import annotations
 
@@ -20,7 +25,7 @@ import numpy as np
 
 from .grid_model import GridModel
 
-__all__ = ["load_chronics_folder", "chronics_table"]
+__all__ = ["load_chronics_folder", "load_chronics_multifolder", "chronics_table"]
 
 
 def _read_csv(path: str):
@@ -64,6 +69,13 @@ def load_chronics_folder(folder: str, model: GridModel, names_chronics_to_backen
         header, data = _read_csv(path)
         idx = _columns(header, names, mp.get(sub))
         out[key] = np.ascontiguousarray(data[:max_rows, idx], dtype=np.float32)
+    for key in ("maintenance", "hazards"):
+        path = _find(folder, key)
+        if path is None:
+            continue
+        header, data = _read_csv(path)
+        idx = _columns(header, m.name_line, mp.get("lines"))
+        out[key] = np.ascontiguousarray(data[:max_rows, idx] != 0, dtype=np.uint8)
     if "prod_v" not in out:
         T = out["prod_p"].shape[0]
         v = (m.gen_vm0 * m.sub_vn_kv[m.gen_sub]).astype(np.float32)       # grid-file set-points (kV)
@@ -78,7 +90,29 @@ def load_chronics_folder(folder: str, model: GridModel, names_chronics_to_backen
     return out
 
 
+def load_chronics_multifolder(chronics_dir: str, model: GridModel, names_chronics_to_backend: Optional[dict] = None,
+                              prods_charac: Optional[str] = None, max_rows: Optional[int] = None, truncate: bool = False):
+    """Every scenario of a chronics directory (sub-folders in sorted order, as ``Multifolder`` lists them).  Returns
+    ``(scenario names, {"load_p", "load_q", "prod_p", "prod_v"[, "maintenance", "hazards"]: [n_scenarios, T, n]})``.  Scenarios
+    of different lengths are an error unless ``truncate`` (then all are cut to the shortest)."""
+    names = sorted(d for d in os.listdir(chronics_dir) if os.path.isdir(os.path.join(chronics_dir, d)))
+    if not names:
+        raise FileNotFoundError(f"no scenario folder under {chronics_dir}")
+    per = [load_chronics_folder(os.path.join(chronics_dir, n), model, names_chronics_to_backend, prods_charac, max_rows) for n in names]
+    lens = [p["load_p"].shape[0] for p in per]
+    T = min(lens)
+    if len(set(lens)) > 1 and not truncate:
+        raise ValueError(f"scenarios of different lengths {dict(zip(names, lens))}: pass truncate=True to cut them to {T} rows")
+    out = {}
+    for key in ("load_p", "load_q", "prod_p", "prod_v", "maintenance", "hazards"):
+        if any(key in p for p in per):
+            n_col = next(p[key].shape[1] for p in per if key in p)
+            dt = next(p[key].dtype for p in per if key in p)
+            out[key] = np.stack([p[key][:T] if key in p else np.zeros((T, n_col), dt) for p in per])
+    return names, out
+
+
 def chronics_table(ch: Dict[str, np.ndarray]) -> np.ndarray:
-    """``[T, 2*n_load + 2*n_gen]`` float32 table in the engine's chronics row layout (gpf_layout.chron_*)."""
+    """``[..., T, 2*n_load + 2*n_gen]`` float32 table(s) in the engine's chronics row layout (gpf_layout.chron_*)."""
     return np.ascontiguousarray(np.concatenate([ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"]], axis=-1),
                                 dtype=np.float32)

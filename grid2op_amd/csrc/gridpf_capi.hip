@@ -111,6 +111,7 @@ struct gpf_engine {
   DevArr<unsigned char> line_status, done;
   DevArr<int> topo0, episode;           // topology last sent by the host (auto-reset target); {steps survived, resets} per lane
   DevArr<float> lane_gen_delta, traj_rho;
+  DevArr<unsigned char> maint;          // [chron_tables][chron_T][n_line] scheduled maintenance, or empty
   DevArr<signed char> traj_status;
   int traj_cap = 0;
   bool has_delta = false;
@@ -180,6 +181,7 @@ struct gpf_engine {
     b.lane_scale = has_scale ? lane_scale.p : nullptr;
     b.thermal_limit = thermal_limit.p; b.rho = rho.p; b.overflow_count = overflow_count.p; b.disc_round = disc_round.p;
     b.lane_gen_delta = has_delta ? lane_gen_delta.p : nullptr;
+    b.maint = maint.n ? maint.p : nullptr;
     b.topo0 = topo0.p; b.done = done.p; b.episode = episode.p;
     b.traj_rho = traj_cap ? traj_rho.p : nullptr; b.traj_status = traj_cap ? traj_status.p : nullptr; b.traj_cap = traj_cap;
     b.lane_stride = cap_lanes; b.n_real_lanes = n_lanes;
@@ -742,6 +744,7 @@ int gpf_destroy(gpf_handle e) {
   e->lane_table.release(); e->lane_offset.release(); e->tmp_lines.release(); e->out.release(); e->chron.release();
   e->lane_scale.release(); e->thermal_limit.release(); e->rho.release(); e->line_status.release();
   e->d_init_inj.release(); e->d_init_topo.release(); e->d_init_shunt_bus.release();
+  e->maint.release();
   e->topo0.release(); e->done.release(); e->episode.release(); e->lane_gen_delta.release(); e->traj_rho.release(); e->traj_status.release();
   if (e->d_params_s) (void)hipFree(e->d_params_s);
   e->stat_dbl.release();
@@ -946,6 +949,7 @@ int gpf_upload_chronics(gpf_handle e, int32_t n_tables, int32_t T, const float* 
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->chron.release();
+  e->maint.release();                       // belongs to the previous tables
   HIP_TRY(e->chron.upload(data, (size_t)n_tables * T * e->g.n_chron));
   e->chron_T = T;
   if (n_tables < e->chron_tables) {
@@ -958,6 +962,18 @@ int gpf_upload_chronics(gpf_handle e, int32_t n_tables, int32_t T, const float* 
     if (fix) HIP_TRY(hipMemcpy(e->lane_table.p, lt.data(), lt.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   e->chron_tables = n_tables;
+  return GPF_OK;
+}
+
+int gpf_upload_maintenance(gpf_handle e, int32_t n_tables, int32_t T, const uint8_t* data) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_upload_maintenance: null");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->maint.release();
+  if (!data) return GPF_OK;
+  if (n_tables != e->chron_tables || T != e->chron_T)
+    return fail(GPF_E_INVALID, "gpf_upload_maintenance: shape must match the uploaded chronics tables (n_tables, T)");
+  HIP_TRY(e->maint.upload(data, (size_t)n_tables * T * e->g.n_line));
   return GPF_OK;
 }
 

@@ -69,6 +69,7 @@ struct Bufs {
   int* overflow_count;         // [B][n_line]
   int* disc_round;             // [B][n_line]
   const float* lane_gen_delta; // [B][n_gen] MW added to prod_p after the chronics (redispatch, baseEnv.py:2211-2470), or nullptr
+  const unsigned char* maint;  // [n_tab][T][n_line] 1: the line is in maintenance at that chronics row (forced out of service), or nullptr
   const int* topo0;            // [B][dim_topo] topology last SENT by the host (what an auto-reset restores)
   unsigned char* done;         // [B] 1: the lane's last step ended its episode (power flow diverged / grid islanded)
   int* episode;                // [B][2] {steps survived since the last reset, number of auto-resets}

@@ -1353,7 +1353,24 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj;
       // all global loads of the phase are issued up front (one round trip): the lane's topology row (when the topology phases
       // run again) and the first pass of the chronics row
+      // scheduled maintenance (Chronics/gridStateFromFile.py maintenance.csv -> the environment's "maintenance" modification,
+      // Action/baseAction.py: the line's status is set to -1 at every step of the outage; nothing reconnects it afterwards)
+      bool any_maint = false;
+      const auto mrow = gptr(b.maint) + ((size_t)tab * sa.T + row) * g.n_line;
+      if (b.maint) {
+        const auto topo = gptr(b.topo) + (size_t)inst * g.dim_topo;
+        bool hit = false;
+        if (!ghost)
+        for (int l = tid; l < g.n_line; l += GW)
+          if (mrow[l] && topo[sv.line_or_pos[l]] != -1) { topo[sv.line_or_pos[l]] = -1; topo[sv.line_ex_pos[l]] = -1; hit = true; }
+        any_maint = G::block_any(hit);
+        if (any_maint) reuse = false;
+      }
       if (!reuse) { const auto topo = gptr(b.topo) + (size_t)inst * g.dim_topo; for (int i = tid; i < g.dim_topo; i += GW) c.topo[i] = topo[i]; }
+      if (any_maint) {                       // the LDS copy may have been read before the stores above landed: same fix-up there
+        GPF_SYNC();
+        for (int l = tid; l < g.n_line; l += GW) if (mrow[l]) { c.topo[sv.line_or_pos[l]] = -1; c.topo[sv.line_ex_pos[l]] = -1; }
+      }
       const float pp_pre = tid < g.n_gen ? ch[2 * g.n_load + tid] : 0.f;
       const float pv_pre = tid < g.n_gen ? ch[2 * g.n_load + g.n_gen + tid] : 1.f;
       double sum_load = 0.0, sum_prod = 0.0;

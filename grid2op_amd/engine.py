@@ -250,6 +250,17 @@ class PowerFlowEngine:
               "gpf_upload_chronics")
         self.chron_T = tables.shape[1]
 
+    def upload_maintenance(self, maintenance):
+        """Scheduled maintenance of the uploaded tables: ``[n_tables, T, n_line]`` (or ``[T, n_line]``) 0/1; None removes it."""
+        if maintenance is None:
+            check(self._lib.gpf_upload_maintenance(self._h, 0, 0, None), "gpf_upload_maintenance")
+            return
+        mt = np.ascontiguousarray(maintenance, dtype=np.uint8)
+        if mt.ndim == 2:
+            mt = mt[None]
+        assert mt.shape[2] == self.model.n_line
+        check(self._lib.gpf_upload_maintenance(self._h, mt.shape[0], mt.shape[1], ptr(mt, C.c_uint8)), "gpf_upload_maintenance")
+
     def set_lane_chronics(self, lane_table=None, lane_offset=None, lane_scale=None):
         lt = None if lane_table is None else np.ascontiguousarray(lane_table, dtype=np.int32)
         lo = None if lane_offset is None else np.ascontiguousarray(lane_offset, dtype=np.int32)

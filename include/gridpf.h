@@ -155,6 +155,11 @@ int gpf_get_results(gpf_handle h, int32_t lane0, int32_t n, float* out, int32_t*
  * (NULL = 1); if `rebalance` != 0 the non-slack prod_p are rescaled so that sum(prod_p) =
  * rebalance * sum(load_p) (Environment/baseEnv.py:2516-2563 feeds these 4 vectors each step). */
 int gpf_upload_chronics(gpf_handle h, int32_t n_tables, int32_t T, const float* data);
+/* Scheduled maintenance of the uploaded chronics tables: [n_tables][T][n_line] uint8, 1 = the line is in maintenance at that
+ * row (maintenance.csv, grid2op/Chronics/gridStateFromFile.py:520-600 -> the "maintenance" modification the environment applies
+ * every step, Environment/baseEnv.py:2516-2563): gpf_step / gpf_step_n force such a line out of service; it stays out afterwards
+ * (nothing reconnects it for a DoNothing agent).  NULL removes the table. */
+int gpf_upload_maintenance(gpf_handle h, int32_t n_tables, int32_t T, const uint8_t* data);
 int gpf_set_lane_chronics(gpf_handle h, const int32_t* lane_table, const int32_t* lane_offset, const float* lane_scale);
 int gpf_set_thermal_limits(gpf_handle h, const float* limit_a /* [n_line] */);
 /* One DoNothing env.step for every lane (Environment/baseEnv.py:3562 -> Backend.next_grid_state

@@ -1,4 +1,5 @@
-"""The batched chronics loader against the committed fixtures (which were cut from the same reference folders)."""
+"""The batched chronics loader against the REFERENCE's own readers (grid2op.Chronics.GridStateFromFile / Multifolder, imported
+from the read-only checkout) and against the committed fixtures."""
 import os
 
 import numpy as np
@@ -40,3 +41,49 @@ def test_name_mapping(load_model):
     assert all(np.array_equal(a[k], b[k]) for k in a)
     with pytest.raises(KeyError):
         load_chronics_folder(folder, m, names_chronics_to_backend={"loads": {str(m.name_load[0]): "nope"}}, max_rows=3)
+
+
+def _reference_multifolder(env, m):
+    import test_backend_conformance  # noqa: F401  (puts the reference + the pandapower stand-in on sys.path)
+    from grid2op.Chronics import GridStateFromFile, Multifolder
+    mf = Multifolder(path=os.path.join(REFERENCE, "grid2op", "data", env, "chronics"), gridvalueClass=GridStateFromFile, max_iter=-1,
+                     chunk_size=None)
+    mf.initialize([str(x) for x in m.name_load], [str(x) for x in m.name_gen], [str(x) for x in m.name_line],
+                  [str(x) for x in m.name_sub], names_chronics_to_backend=None)
+    return mf
+
+
+@pytest.mark.parametrize("env", ["l2rpn_case14_sandbox", "l2rpn_neurips_2020_track1", "l2rpn_wcci_2022_dev", "rte_case5_example",
+                                 "educ_case14_storage"])
+def test_multifolder_equals_the_reference_readers(env, load_model):
+    """Scenario order, every row of load_p / load_q / prod_p / prod_v and the maintenance / hazards tables, as
+    ``Multifolder`` + ``GridStateFromFile`` (grid2op/Chronics/multiFolder.py, gridStateFromFile.py) decode them."""
+    from grid2op_amd.chronics import chronics_table, load_chronics_multifolder
+    m = load_model(env)
+    base = os.path.join(REFERENCE, "grid2op", "data", env)
+    names, ch = load_chronics_multifolder(os.path.join(base, "chronics"), m, prods_charac=os.path.join(base, "prods_charac.csv"),
+                                          truncate=True)
+    mf = _reference_multifolder(env, m)
+    assert names == [os.path.basename(p) for p in mf.subpaths]                 # sorted scenario order
+    T = ch["load_p"].shape[1]
+    for k, name in enumerate(names):
+        mf.tell_id(k - 1 if k > 0 else len(names) - 1)                          # Multifolder.next_chronics advances to id + 1
+        mf.next_chronics()
+        mf.initialize([str(x) for x in m.name_load], [str(x) for x in m.name_gen], [str(x) for x in m.name_line],
+                      [str(x) for x in m.name_sub], names_chronics_to_backend=None)
+        d = mf.data
+        assert os.path.basename(d.path) == name
+        for key in ("load_p", "load_q", "prod_p"):
+            assert np.array_equal(ch[key][k], getattr(d, key)[:T].astype(np.float32)), (name, key)
+        if d.prod_v is not None:
+            assert np.array_equal(ch["prod_v"][k], d.prod_v[:T].astype(np.float32)), name
+        for key in ("maintenance", "hazards"):
+            ref = getattr(d, key)
+            if ref is not None and key in ch:
+                assert np.array_equal(ch[key][k].astype(bool), np.asarray(ref)[:T].astype(bool)), (name, key)
+            elif ref is not None:
+                assert not np.asarray(ref).any()
+    tab = chronics_table(ch)
+    assert tab.shape == (len(names), T, 2 * m.n_load + 2 * m.n_gen) and tab.dtype == np.float32
+    if env == "l2rpn_neurips_2020_track1":
+        assert "maintenance" in ch and ch["maintenance"].sum() > 0

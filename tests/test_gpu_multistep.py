@@ -277,3 +277,49 @@ def test_split_batches_in_every_kernel_mode(mode, load_model, load_npz):
             e2.step(0, n_steps=2)
     e1.close()
     e2.close()
+
+
+@pytest.mark.parametrize("name", ["l2rpn_case14_sandbox", "l2rpn_neurips_2020_track1"])
+def test_device_rollout_reproduces_the_reference_environment(name, load_model, load_npz):
+    """A DoNothing rollout of the UNMODIFIED reference Environment (default parameters: overflow disconnections on; all the
+    scenarios of its chronics folder, scheduled maintenance included) recorded by tests/golden/make_rollout_fixtures.py, against ONE
+    multi-step launch of the engine with one lane per scenario: rho of every step, final line status and overflow counters."""
+    from grid2op_amd.engine import PowerFlowEngine
+    from grid2op_amd.chronics import chronics_table
+    m = load_model(name)
+    fx = load_npz(f"rollout_{name}.npz")
+    n_scen, n_steps = fx["rho"].shape[:2]
+    reps = 5                                              # every scenario on several lanes (different wavefront positions)
+    B = n_scen * reps
+    eng = PowerFlowEngine(m, n_lanes=B, device=0)
+    ch = {k[len("chron_"):]: fx[k] for k in fx if k.startswith("chron_")}
+    eng.upload_chronics(chronics_table(ch))
+    if "maintenance" in ch:
+        eng.upload_maintenance(ch["maintenance"])
+    eng.set_lane_chronics(lane_table=np.tile(np.arange(n_scen), reps), lane_offset=np.ones(B, np.int32))   # env step k reads row k
+    eng.set_thermal_limits(fx["thermal_limit"])
+    eng.set_trajectory(n_steps)
+    eng.step(0, n_steps=n_steps, cascade=True, hard_overflow=float(fx["hard_overflow"]), nb_ts_allowed=int(fx["nb_ts_allowed"]))
+    rho, st = eng.trajectory(n_steps)
+    r = eng.results()
+    _, ovc, _ = eng.step_outputs()
+    assert (fx["done_at"] < 0).all() and (st == 0).all()
+    for lane in range(B):
+        k = lane % n_scen
+        assert np.allclose(rho[:, lane], fx["rho"][k], rtol=2e-5, atol=2e-6), (lane, np.abs(rho[:, lane] - fx["rho"][k]).max())
+        assert np.array_equal(r.line_status[lane], fx["line_status"][k, -1]), lane
+        assert np.array_equal(ovc[lane], fx["timestep_overflow"][k, -1]), lane
+    if "maintenance" in ch:
+        assert (~r.line_status).any()                     # the scheduled outage really happened
+    # the same rollout one launch per step, and in launches of 7
+    for spl in (1, 7):
+        eng.reset()
+        eng.set_lane_chronics(lane_table=np.tile(np.arange(n_scen), reps), lane_offset=np.ones(B, np.int32))
+        t = 0
+        while t < n_steps:
+            k = min(spl, n_steps - t)
+            eng.step(t, n_steps=k, cascade=True, hard_overflow=float(fx["hard_overflow"]), nb_ts_allowed=int(fx["nb_ts_allowed"]))
+            t += k
+        r2 = eng.results()
+        assert np.array_equal(r2.line_status, r.line_status) and np.allclose(r2.out, r.out, rtol=2e-6, atol=2e-5)
+    eng.close()
