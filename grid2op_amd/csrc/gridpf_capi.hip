@@ -18,6 +18,7 @@
 #include "gridpf_sparse.hpp"
 #include "gridpf_host.hpp"
 #include "gridpf_ptdf.hpp"
+#include "gridpf_redispatch.hpp"
 #include <string>
 #include <unordered_map>
 #include "gridpf_symbolic.hpp"
@@ -115,6 +116,11 @@ struct gpf_engine {
   DevArr<signed char> traj_status;
   int traj_cap = 0;
   bool has_delta = false;
+  DevArr<double> rd_pmin, rd_pmax, rd_ru, rd_rd, rd_in;      // generator limits + staging of gpf_redispatch
+  DevArr<unsigned char> rd_redisp, rd_u8;
+  DevArr<float> rd_after;
+  double rd_eps = 1e-4;
+  bool rd_ready = false;
   int dcf = 0;                          // the NB == 1 LDS layout has room for the factored DC matrix (decided once at gpf_create)
   DevArr<double> d_init_inj;
   DevArr<int> d_init_topo, d_init_shunt_bus;
@@ -745,6 +751,8 @@ int gpf_destroy(gpf_handle e) {
   e->lane_scale.release(); e->thermal_limit.release(); e->rho.release(); e->line_status.release();
   e->d_init_inj.release(); e->d_init_topo.release(); e->d_init_shunt_bus.release();
   e->maint.release();
+  e->rd_pmin.release(); e->rd_pmax.release(); e->rd_ru.release(); e->rd_rd.release(); e->rd_in.release(); e->rd_redisp.release();
+  e->rd_u8.release(); e->rd_after.release();
   e->topo0.release(); e->done.release(); e->episode.release(); e->lane_gen_delta.release(); e->traj_rho.release(); e->traj_status.release();
   if (e->d_params_s) (void)hipFree(e->d_params_s);
   e->stat_dbl.release();
@@ -1055,6 +1063,58 @@ int gpf_set_lane_redispatch(gpf_handle e, const float* delta_mw) {
   HIP_TRY(hipMemcpyAsync(e->lane_gen_delta.p, delta_mw, (size_t)e->n_lanes * e->g.n_gen * sizeof(float), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->has_delta = true;
+  return GPF_OK;
+}
+
+int gpf_set_gen_limits(gpf_handle e, const double* pmin, const double* pmax, const double* ramp_up, const double* ramp_down,
+                       const uint8_t* redispatchable, double eps_poly) {
+  if (!e || !pmin || !pmax || !ramp_up || !ramp_down || !redispatchable) return fail(GPF_E_INVALID, "gpf_set_gen_limits: null");
+  if (e->g.n_gen > gpf::RD_PER_LANE * gpf::WAVE) return fail(GPF_E_CAPACITY, "gpf_set_gen_limits: more than 256 generators");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const size_t ng = e->g.n_gen;
+  e->rd_pmin.release(); e->rd_pmax.release(); e->rd_ru.release(); e->rd_rd.release(); e->rd_redisp.release();
+  HIP_TRY(e->rd_pmin.upload(pmin, ng)); HIP_TRY(e->rd_pmax.upload(pmax, ng)); HIP_TRY(e->rd_ru.upload(ramp_up, ng));
+  HIP_TRY(e->rd_rd.upload(ramp_down, ng)); HIP_TRY(e->rd_redisp.upload(redispatchable, ng));
+  e->rd_eps = eps_poly;
+  e->rd_ready = true;
+  return GPF_OK;
+}
+
+int gpf_redispatch(gpf_handle e, int32_t lane0, int32_t n, const double* new_p, const double* prev_p, const double* actual,
+                   const double* target, const uint8_t* modified, const double* rhs, int32_t apply, uint8_t* ok, float* actual_after) {
+  if (!check_range(e, lane0, n) || !new_p || !prev_p || !actual || !target || !modified || !rhs)
+    return fail(GPF_E_INVALID, "gpf_redispatch: bad arguments");
+  if (!e->rd_ready) return fail(GPF_E_INVALID, "gpf_redispatch: call gpf_set_gen_limits first");
+  if (n == 0) return GPF_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t ng = e->g.n_gen, row = (size_t)n * ng;
+  if (e->rd_in.n < 4 * row + (size_t)n) { e->rd_in.release(); HIP_TRY(e->rd_in.alloc(4 * row + n)); }
+  if (e->rd_u8.n < row + (size_t)n) { e->rd_u8.release(); HIP_TRY(e->rd_u8.alloc(row + n)); }
+  if (e->rd_after.n < row) { e->rd_after.release(); HIP_TRY(e->rd_after.alloc(row)); }
+  double* d = e->rd_in.p;
+  HIP_TRY(hipMemcpyAsync(d, new_p, row * 8, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(d + row, prev_p, row * 8, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(d + 2 * row, actual, row * 8, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(d + 3 * row, target, row * 8, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(d + 4 * row, rhs, (size_t)n * 8, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->rd_u8.p, modified, row, hipMemcpyHostToDevice, e->stream));
+  float* delta = nullptr;
+  if (apply) {
+    const size_t nd = (size_t)e->cap_lanes * ng;
+    if (!e->lane_gen_delta.p) { HIP_TRY(e->lane_gen_delta.alloc(nd)); HIP_TRY(hipMemsetAsync(e->lane_gen_delta.p, 0, nd * sizeof(float), e->stream)); }
+    delta = e->lane_gen_delta.p + (size_t)lane0 * ng;
+    e->has_delta = true;
+  }
+  gpf::RedispDev R{};
+  R.n_gen = (int)ng; R.eps_poly = e->rd_eps; R.pmin = e->rd_pmin.p; R.pmax = e->rd_pmax.p; R.ramp_up = e->rd_ru.p; R.ramp_down = e->rd_rd.p;
+  R.redispatchable = e->rd_redisp.p;
+  hipLaunchKernelGGL(gpf::redispatch_kernel, dim3(n), dim3(gpf::WAVE), 0, e->stream, R, n, d, d + row, d + 2 * row, d + 3 * row, e->rd_u8.p,
+                     d + 4 * row, e->rd_u8.p + row, e->rd_after.p, delta);
+  HIP_TRY(hipGetLastError());
+  if (ok) HIP_TRY(hipMemcpyAsync(ok, e->rd_u8.p + row, (size_t)n, hipMemcpyDeviceToHost, e->stream));
+  if (actual_after) HIP_TRY(hipMemcpyAsync(actual_after, e->rd_after.p, row * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
   return GPF_OK;
 }
 

@@ -296,6 +296,33 @@ class PowerFlowEngine:
             assert d.shape == (self.n_lanes, self.model.n_gen)
         check(self._lib.gpf_set_lane_redispatch(self._h, ptr(d, C.c_float)), "gpf_set_lane_redispatch")
 
+    def set_gen_limits(self, pmin, pmax, ramp_up, ramp_down, redispatchable, eps_poly: float = 1e-4):
+        """Generator characteristics (``prods_charac.csv``: Pmin, Pmax, max_ramp_up, max_ramp_down, redispatchable) for
+        `redispatch`."""
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        a = [f64(pmin), f64(pmax), f64(ramp_up), f64(ramp_down)]
+        r = np.ascontiguousarray(redispatchable, dtype=np.uint8)
+        assert all(x.size == self.model.n_gen for x in a) and r.size == self.model.n_gen
+        check(self._lib.gpf_set_gen_limits(self._h, *[ptr(x, C.c_double) for x in a], ptr(r, C.c_uint8), float(eps_poly)),
+              "gpf_set_gen_limits")
+
+    def redispatch(self, new_p, prev_p, actual, target, modified, rhs, lane0: int = 0, apply: bool = False):
+        """The environment's redispatching automaton for a batch of lanes (``BaseEnv._compute_dispatch_vect``): rows
+        ``[n, n_gen]`` of new_p / prev_p / actual dispatch / target dispatch / modified mask, ``rhs[n]`` = storage - curtailment
+        + detached MW.  Returns ``(ok[n] bool, actual_dispatch_after[n, n_gen] float32)``; ``apply`` also installs the result as
+        the lanes' redispatch delta for the next `step`."""
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64).reshape(-1, self.model.n_gen)  # noqa: E731
+        new_p, prev_p, actual, target = f64(new_p), f64(prev_p), f64(actual), f64(target)
+        n = new_p.shape[0]
+        mod = np.ascontiguousarray(modified, dtype=np.uint8).reshape(n, self.model.n_gen)
+        rhs = np.ascontiguousarray(np.broadcast_to(np.asarray(rhs, dtype=np.float64), (n,)))
+        ok = np.empty(n, dtype=np.uint8)
+        after = np.empty((n, self.model.n_gen), dtype=np.float32)
+        check(self._lib.gpf_redispatch(self._h, int(lane0), n, ptr(new_p, C.c_double), ptr(prev_p, C.c_double), ptr(actual, C.c_double),
+                                       ptr(target, C.c_double), ptr(mod, C.c_uint8), ptr(rhs, C.c_double), int(bool(apply)),
+                                       ptr(ok, C.c_uint8), ptr(after, C.c_float)), "gpf_redispatch")
+        return ok.astype(bool), after
+
     def set_trajectory(self, n_steps_cap: int):
         check(self._lib.gpf_set_trajectory(self._h, int(n_steps_cap)), "gpf_set_trajectory")
 

@@ -192,6 +192,19 @@ int gpf_step_n(gpf_handle h, int32_t t0, int32_t n_steps, const gpf_step_opts* o
 /* Per-lane additive generator set-point delta in MW, [n_lanes][n_gen] (NULL: none): the redispatch the environment adds to the
  * chronics' prod_p every step (actual_dispatch, Environment/baseEnv.py:2211-2470, 3650-3700). */
 int gpf_set_lane_redispatch(gpf_handle h, const float* delta_mw);
+/* The environment's redispatching automaton (BaseEnv._compute_dispatch_vect, Environment/baseEnv.py:2211-2470), batched: for
+ * every lane the redispatch the agents ask for is projected on pmin / pmax / ramp limits under the zero-sum constraint
+ * sum(x) = rhs (rhs = storage power - curtailment + detached MW, :2335-2340) and added to the actual dispatch.
+ * gpf_set_gen_limits: the generator characteristics of prods_charac.csv ([n_gen] each), eps_poly as BaseEnv._epsilon_poly.
+ * gpf_redispatch: rows of lanes lane0..lane0+n-1, [n][n_gen]: new_p (chronics set-points of the step), prev_p (set-points of
+ * the previous step incl. dispatch, BaseEnv._gen_activeprod_t_redisp), actual / target dispatch, modified (generators touched
+ * by an action this step); ok[n] = 0 where the reference raises ImpossibleRedispatching (the row is then returned unchanged);
+ * actual_after [n][n_gen] float.  apply != 0 also stores the result as the lanes' redispatch delta (gpf_set_lane_redispatch)
+ * for the following gpf_step.  Synchronous. */
+int gpf_set_gen_limits(gpf_handle h, const double* pmin, const double* pmax, const double* ramp_up, const double* ramp_down,
+                       const uint8_t* redispatchable, double eps_poly);
+int gpf_redispatch(gpf_handle h, int32_t lane0, int32_t n, const double* new_p, const double* prev_p, const double* actual,
+                   const double* target, const uint8_t* modified, const double* rhs, int32_t apply, uint8_t* ok, float* actual_after);
 /* Trajectory buffer of multi-step launches: rho [n_steps_cap][n_lanes][n_line] and status [n_steps_cap][n_lanes] of the steps of
  * the last gpf_step_n (0 releases it). */
 int gpf_set_trajectory(gpf_handle h, int32_t n_steps_cap);
