@@ -133,7 +133,7 @@ struct gpf_engine {
   gpf::Symbolic sym;
   // DC sensitivity path (gridpf_ptdf.hpp)
   DevArr<int> ptdf_inj_bus;
-  DevArr<double> ptdf_inj_w, ptdf_t, ptdf_pbus;
+  DevArr<double> ptdf_inj_w, ptdf_t;
   DevArr<float> ptdf_flow, lodf_worst, lodf_inv_cap;
   DevArr<double> lodf;             // [n_line][line_pad] line outage distribution factors of the PTDF topology (NaN column: islanding outage)
   std::vector<double> h_ptdf;      // [n_line][nb_tot]
@@ -759,7 +759,7 @@ int gpf_destroy(gpf_handle e) {
   e->list_a.release(); e->list_b.release(); e->list_c.release(); e->d_classes.release();
   for (auto* c : e->classes) { c->tables.release(); delete c; }
   e->classes.clear();
-  e->ptdf_inj_bus.release(); e->ptdf_inj_w.release(); e->ptdf_t.release(); e->ptdf_pbus.release(); e->ptdf_flow.release();
+  e->ptdf_inj_bus.release(); e->ptdf_inj_w.release(); e->ptdf_t.release(); e->ptdf_flow.release();
   e->lodf.release(); e->lodf_worst.release(); e->lodf_inv_cap.release();
   e->stat_int.release();
   delete e;
@@ -1328,9 +1328,8 @@ int gpf_ptdf_build(gpf_handle e, int32_t lane) {
   HIP_TRY(e->ptdf_inj_bus.upload(inj_bus.data(), inj_bus.size()));
   HIP_TRY(e->ptdf_inj_w.upload(inj_w.data(), inj_w.size()));
   HIP_TRY(e->ptdf_t.upload(pt.data(), pt.size()));
-  if (e->ptdf_nb_pad != nb_pad || e->ptdf_line_pad != line_pad || !e->ptdf_pbus.p) {
-    e->ptdf_pbus.release(); e->ptdf_flow.release();
-    HIP_TRY(e->ptdf_pbus.alloc((size_t)e->cap_lanes * nb_pad));
+  if (e->ptdf_nb_pad != nb_pad || e->ptdf_line_pad != line_pad || !e->ptdf_flow.p) {
+    e->ptdf_flow.release();
     HIP_TRY(e->ptdf_flow.alloc((size_t)e->cap_lanes * line_pad));
   }
   {   // LODF[l][k] = H[l][k] / (1 - H[k][k]), H[l][k] = PTDF[l][from_k] - PTDF[l][to_k]; LODF[k][k] = -1
@@ -1369,9 +1368,8 @@ int gpf_ptdf_flows(gpf_handle e, int32_t lane0, int32_t n) {
   gpf::PtdfDev P{};
   P.n_inj = e->g.n_inj; P.nb_pad = e->ptdf_nb_pad; P.line_pad = e->ptdf_line_pad; P.n_line = e->g.n_line;
   P.inj_bus = e->ptdf_inj_bus.p; P.inj_w = e->ptdf_inj_w.p; P.ptdf_t = e->ptdf_t.p;
-  hipLaunchKernelGGL(gpf::ptdf_bus_injection_kernel, dim3(n), dim3(gpf::WAVE), (size_t)P.nb_pad * sizeof(double), e->stream, P, e->inj.p,
-                     lane0, e->ptdf_pbus.p);
-  hipLaunchKernelGGL(gpf::ptdf_gemm_kernel, dim3((n + 15) / 16, (P.line_pad / 16 + 3) / 4), dim3(256), 0, e->stream, P, e->ptdf_pbus.p, lane0, n,
+  const size_t lds_a = (size_t)16 * gpf::ptdf_a_stride(P.nb_pad) * sizeof(double);
+  hipLaunchKernelGGL(gpf::ptdf_flows_kernel, dim3((n + 15) / 16, (P.line_pad / 16 + 3) / 4), dim3(256), lds_a, e->stream, P, e->inj.p, lane0, n,
                      e->ptdf_flow.p);
   HIP_TRY(hipGetLastError());
   if (e->window) ++e->win_launches;
@@ -1404,8 +1402,8 @@ int gpf_lodf_screen(gpf_handle e, int32_t lane0, int32_t n, const float* cap_mw,
     HIP_TRY(hipStreamSynchronize(e->stream));
     ic = e->lodf_inv_cap.p;
   }
-  const size_t lds = ((size_t)gpf::LODF_LPW + 1) * lp * sizeof(float);
-  hipLaunchKernelGGL(gpf::lodf_screen_kernel, dim3((n + gpf::LODF_LPW - 1) / gpf::LODF_LPW), dim3(gpf::WAVE), lds, e->stream, nl, lp, e->lodf.p, ic,
+  const size_t lds = ((size_t)5 * gpf::LODF_LPW + 1) * lp * sizeof(float);
+  hipLaunchKernelGGL(gpf::lodf_screen_kernel, dim3((n + gpf::LODF_LPW - 1) / gpf::LODF_LPW), dim3(256), lds, e->stream, nl, lp, e->lodf.p, ic,
                      e->ptdf_flow.p, lane0, n, e->lodf_worst.p + (size_t)lane0 * lp);
   HIP_TRY(hipGetLastError());
   if (e->window) ++e->win_launches;
