@@ -66,6 +66,8 @@ __host__ __device__ inline size_t stat_bytes(const StatOff& o, int tier) {
 
 struct SymDev {
   int n, nslot, nslot_y, n_levels, back_off, n_prog, scale_off, n_scale;
+  int n_fwd;                // levels the 2x2 / scalar forward sweeps visit: the trailing levels without any update item (the last
+                            // pivot never has one) are skipped -- each would cost a whole barrier-delimited phase per solve
   int back_first;           // highest level that has U entries (back substitution starts there)
   int static_connected;     // the substation graph with every line in service is connected (host check at gpf_create)
   const int* prog;          // level-scheduled program in global memory (tools/lu_bench; the kernels use StatView::prog)
@@ -353,7 +355,7 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
     // kept as short as possible: trailing updates (c) and right-hand-side updates (r) are ONE item list (r-items follow the
     // c-items in the program), and the level header / the first item words of the NEXT levels are prefetched while the
     // current level computes.  Per level: operand reads -> ~10 dependent f64 ops -> ds_add_f64 -> barrier.
-    const int n_levels = S.n_levels;
+    const int n_levels = S.n_fwd;
 #define R0_(slot) (A + (size_t)(slot) * 2)
 #define R1_(slot) (A + HS_ + (size_t)(slot) * 2)
 #define LD2_(ptr) (*reinterpret_cast<const double2*>(ptr))
@@ -598,7 +600,7 @@ __device__ inline bool scalar_lu_solve(const SymDev& S, PP prog, double* __restr
   const long long t_lu0 = __builtin_readcyclecounter();
 #endif
   bool ok = true;
-  const int n_levels = S.n_levels;
+  const int n_levels = S.n_fwd;
   auto hdr4 = [&](int k) -> int4 { return make_int4(prog[4 * k], prog[4 * k + 1], prog[4 * k + 2], prog[4 * k + 3]); };
   auto first = [&](const int4& h) -> int { return FACTOR ? 0 : h.y; };       // r-items follow the c-items
   auto item_words = [&](const int4& h, int o, unsigned& w0, unsigned& w1) {
@@ -1248,7 +1250,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
 #define GPF_CARVE_AND_VIEW(G_)                                                                                                   \
   SymDev S_loc = P->sym;                                                                                                         \
   if (TC) S_loc = P->classes[gptr(lane_class)[blockIdx.x * IPW]].sym;                                                            \
-  pin_sgpr(S_loc.n); pin_sgpr(S_loc.nslot); pin_sgpr(S_loc.nslot_y); pin_sgpr(S_loc.n_levels); pin_sgpr(S_loc.back_off);         \
+  pin_sgpr(S_loc.n); pin_sgpr(S_loc.nslot); pin_sgpr(S_loc.nslot_y); pin_sgpr(S_loc.n_fwd); pin_sgpr(S_loc.back_off);          \
   pin_sgpr(S_loc.scale_off); pin_sgpr(S_loc.n_scale); pin_sgpr(S_loc.back_first); pin_sgpr(S_loc.static_connected);              \
   const SymDev& S = S_loc;                                                                                                       \
   const int lds_rows = TC ? P->tc_rows : -1, lds_nslot = TC ? P->tc_nslot : P->sym.nslot,                                        \
