@@ -323,3 +323,36 @@ def test_device_rollout_reproduces_the_reference_environment(name, load_model, l
         r2 = eng.results()
         assert np.array_equal(r2.line_status, r.line_status) and np.allclose(r2.out, r.out, rtol=2e-6, atol=2e-5)
     eng.close()
+
+
+def test_sharded_engine_on_real_engines(load_model, load_npz):
+    """`ShardedEngine` with two REAL engines (both on device 0: the routing, not the device count, is what is checked): a
+    stepped and solved batch equals the same batch on one engine, lane for lane."""
+    from grid2op_amd.sharding import ShardedEngine
+    m, ch, one, tab, off, scale = _setup(load_model, load_npz, "l2rpn_case14_sandbox", 70)
+    se = ShardedEngine(m, 70, devices=[0, 0])
+    assert [e.n_lanes for e in se.engines] == [35, 35]
+    se.upload_chronics(tab)
+    se.set_lane_chronics(lane_offset=off, lane_scale=scale)
+    se.set_thermal_limits(ch["thermal_limits"])
+    topo = np.tile(m.initial_topo_vect(), (6, 1))
+    topo[:, m.line_or_pos_topo_vect[4]] = -1
+    topo[:, m.line_ex_pos_topo_vect[4]] = -1
+    for e in (one, se):
+        e.set_topology(topo, lane0=32)                     # lanes 32..37 straddle the shard boundary
+        e.step(2, n_steps=5, rebalance=1.02)
+    a, b = one.results(), se.results()
+    assert np.array_equal(a.status, b.status) and np.array_equal(a.topo_vect, b.topo_vect)
+    assert np.array_equal(a.out, b.out, equal_nan=True)
+    assert np.array_equal(one.step_outputs()[0], se.step_outputs()[0])
+    inj = one.get_injections(30, 10)
+    inj[:, :m.n_gen] *= 1.01
+    for e in (one, se):
+        e.set_injections(inj, lane0=30)
+        e.runpf(30, 10)
+    assert np.array_equal(one.results(28, 14).out, se.results(28, 14).out, equal_nan=True)
+    d1, s1, r1 = one.episode()
+    d2, s2, r2 = se.episode()
+    assert np.array_equal(s1, s2) and (s2 == 5).all()
+    one.close()
+    se.close()
