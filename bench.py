@@ -447,6 +447,14 @@ def main():
         # let the GPU clocks drop before the secondary workloads
         if not args.no_cpu_baseline and world == 1 and not args.stub_engine:
             res["cpu_baseline"] = cpu_baseline(args.env, m, ch, T)
+            try:    # the reference Environment.step loop itself (profiler_do_nothing.py:42-65) cannot run on the GPU box (grid2op is
+                    # not installable there): figure measured in the build container, committed, quoted -- not measured in this run
+                with open(os.path.join(ROOT, "profiles", "r02_framework_loop_cpu.json")) as f:
+                    res["cpu_baseline"]["reference_environment_step_loop"] = dict(
+                        json.load(f), source="committed profiles/r02_framework_loop_cpu.json (tools/framework_loop.py, build container "
+                                             "CPU, NOT measured in this run)")
+            except Exception:
+                pass
         print(json.dumps(res), flush=True)
     if ctx.dist is not None:
         ctx.dist.barrier()

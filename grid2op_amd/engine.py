@@ -214,6 +214,51 @@ class PowerFlowEngine:
         ol = np.ascontiguousarray(out_lines, dtype=np.int32)
         check(self._lib.gpf_fanout_n1(self._h, src_lane, dst_lane0, ol.size, ptr(ol, C.c_int32)), "gpf_fanout_n1")
 
+    def candidate_topologies(self, base_topo, actions) -> np.ndarray:
+        """``[len(actions), dim_topo]`` topology rows = ``base_topo`` modified by each candidate action, described as grid2op
+        describes them (Action/baseAction.py ``set_bus`` / ``set_line_status`` / ``change_bus``): a dict with any of
+        ``"set_bus": {topo_vect position: bus}``, ``"lines_or_bus" / "lines_ex_bus" / "loads_bus" / "gens_bus" / "storages_bus":
+        [(element id, bus)]``, ``"set_line_status": [(line id, +1 | -1)]`` (reconnection puts both ends on busbar 1 unless a bus is
+        given as well), ``"change_bus": [positions]`` (1 <-> 2).  An empty dict is the do-nothing candidate."""
+        m = self.model
+        base = np.asarray(base_topo, dtype=np.int32).reshape(m.dim_topo)
+        pos_of = {"lines_or_bus": m.line_or_pos_topo_vect, "lines_ex_bus": m.line_ex_pos_topo_vect, "loads_bus": m.load_pos_topo_vect,
+                  "gens_bus": m.gen_pos_topo_vect, "storages_bus": m.storage_pos_topo_vect}
+        out = np.tile(base, (len(actions), 1))
+        for k, act in enumerate(actions):
+            row = out[k]
+            for line, st in act.get("set_line_status", ()):
+                po, pe = m.line_or_pos_topo_vect[line], m.line_ex_pos_topo_vect[line]
+                if st < 0:
+                    row[po] = row[pe] = -1
+                elif st > 0 and (row[po] < 1 or row[pe] < 1):
+                    row[po] = row[pe] = 1
+            for key, pos in pos_of.items():
+                for el, bus in act.get(key, ()):
+                    row[pos[el]] = bus
+            for p_, bus in dict(act.get("set_bus", {})).items():
+                row[p_] = bus
+            for p_ in act.get("change_bus", ()):
+                if row[p_] >= 1:
+                    row[p_] = 2 if row[p_] == 1 else 1
+        return out
+
+    def simulate_candidates(self, src_lane: int, dst_lane0: int, actions=None, topologies=None, is_dc: bool = False,
+                            max_iter: int = 10, tol_mva: float = 1e-8) -> int:
+        """Batched ``obs.simulate`` (Observation/_obsEnv.py:321-503, Reward/n1Reward.py:70-99): lanes ``dst_lane0 ...`` become
+        copies of ``src_lane`` (injections, shunts) with one candidate topology each -- built from ``actions``
+        (`candidate_topologies`) or given as rows -- and are solved in ONE launch (asynchronous; read them with `results`).
+        Returns the number of candidate lanes."""
+        if topologies is None:
+            base, _ = self.get_topology(src_lane, 1)
+            topologies = self.candidate_topologies(base[0], actions)
+        topologies = np.ascontiguousarray(topologies, dtype=np.int32).reshape(-1, self.model.dim_topo)
+        n = topologies.shape[0]
+        self.fanout_n1(src_lane, dst_lane0, np.full(n, -1, dtype=np.int32))      # device-side copy of the source lane's state
+        self.set_topology(topologies, lane0=dst_lane0)
+        self.runpf(dst_lane0, n, is_dc=is_dc, max_iter=max_iter, tol_mva=tol_mva)
+        return n
+
     # ---- solve --------------------------------------------------------------------------------------
     def runpf(self, lane0: int = 0, n: Optional[int] = None, is_dc: bool = False, max_iter: int = 10,
               tol_mva: float = 1e-8):
