@@ -56,13 +56,19 @@ def _columns(header, names, mapping: Optional[Dict[str, str]]):
 
 
 def load_chronics_folder(folder: str, model: GridModel, names_chronics_to_backend: Optional[dict] = None,
-                         prods_charac: Optional[str] = None, max_rows: Optional[int] = None) -> Dict[str, np.ndarray]:
-    """``{"load_p","load_q","prod_p","prod_v"}`` float32 ``[T, n]`` arrays in the GridModel's element order."""
+                         prods_charac: Optional[str] = None, max_rows: Optional[int] = None,
+                         forecasts: bool = False) -> Dict[str, np.ndarray]:
+    """``{"load_p","load_q","prod_p","prod_v"}`` float32 ``[T, n]`` arrays in the GridModel's element order (plus
+    ``maintenance`` / ``hazards`` uint8 ``[T, n_line]`` when the folder has them, and -- ``forecasts=True`` -- the
+    ``*_forecasted`` tables ``obs.simulate`` injects, grid2op/Chronics/gridStateFromFileWithForecasts.py)."""
     m = model
     mp = names_chronics_to_backend or {}
     out = {}
-    for key, names, sub in (("load_p", m.name_load, "loads"), ("load_q", m.name_load, "loads"),
-                            ("prod_p", m.name_gen, "prods"), ("prod_v", m.name_gen, "prods")):
+    todo = [("load_p", m.name_load, "loads"), ("load_q", m.name_load, "loads"), ("prod_p", m.name_gen, "prods"),
+            ("prod_v", m.name_gen, "prods")]
+    if forecasts:
+        todo += [(k + "_forecasted", n, s_) for k, n, s_ in todo]
+    for key, names, sub in todo:
         path = _find(folder, key)
         if path is None:
             continue
@@ -91,20 +97,24 @@ def load_chronics_folder(folder: str, model: GridModel, names_chronics_to_backen
 
 
 def load_chronics_multifolder(chronics_dir: str, model: GridModel, names_chronics_to_backend: Optional[dict] = None,
-                              prods_charac: Optional[str] = None, max_rows: Optional[int] = None, truncate: bool = False):
+                              prods_charac: Optional[str] = None, max_rows: Optional[int] = None, truncate: bool = False,
+                              forecasts: bool = False):
     """Every scenario of a chronics directory (sub-folders in sorted order, as ``Multifolder`` lists them).  Returns
     ``(scenario names, {"load_p", "load_q", "prod_p", "prod_v"[, "maintenance", "hazards"]: [n_scenarios, T, n]})``.  Scenarios
     of different lengths are an error unless ``truncate`` (then all are cut to the shortest)."""
     names = sorted(d for d in os.listdir(chronics_dir) if os.path.isdir(os.path.join(chronics_dir, d)))
     if not names:
         raise FileNotFoundError(f"no scenario folder under {chronics_dir}")
-    per = [load_chronics_folder(os.path.join(chronics_dir, n), model, names_chronics_to_backend, prods_charac, max_rows) for n in names]
+    per = [load_chronics_folder(os.path.join(chronics_dir, n), model, names_chronics_to_backend, prods_charac, max_rows, forecasts)
+           for n in names]
     lens = [p["load_p"].shape[0] for p in per]
     T = min(lens)
     if len(set(lens)) > 1 and not truncate:
         raise ValueError(f"scenarios of different lengths {dict(zip(names, lens))}: pass truncate=True to cut them to {T} rows")
     out = {}
-    for key in ("load_p", "load_q", "prod_p", "prod_v", "maintenance", "hazards"):
+    keys = ["load_p", "load_q", "prod_p", "prod_v", "maintenance", "hazards"]
+    keys += [k + "_forecasted" for k in keys[:4]]
+    for key in keys:
         if any(key in p for p in per):
             n_col = next(p[key].shape[1] for p in per if key in p)
             dt = next(p[key].dtype for p in per if key in p)

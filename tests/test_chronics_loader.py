@@ -87,3 +87,22 @@ def test_multifolder_equals_the_reference_readers(env, load_model):
     assert tab.shape == (len(names), T, 2 * m.n_load + 2 * m.n_gen) and tab.dtype == np.float32
     if env == "l2rpn_neurips_2020_track1":
         assert "maintenance" in ch and ch["maintenance"].sum() > 0
+
+
+def test_forecast_tables_equal_the_reference_reader(load_model):
+    """``GridStateFromFileWithForecasts`` (grid2op/Chronics/gridStateFromFileWithForecasts.py): the *_forecasted tables that
+    ``obs.simulate`` injects."""
+    import test_backend_conformance  # noqa: F401
+    from grid2op.Chronics import GridStateFromFileWithForecasts
+    from grid2op_amd.chronics import load_chronics_folder
+    env, scen = "l2rpn_case14_sandbox", "0000"
+    m = load_model(env)
+    folder = os.path.join(REFERENCE, "grid2op", "data", env, "chronics", scen)
+    ch = load_chronics_folder(folder, m, forecasts=True)
+    ref = GridStateFromFileWithForecasts(path=folder, max_iter=-1, chunk_size=None)
+    ref.initialize([str(x) for x in m.name_load], [str(x) for x in m.name_gen], [str(x) for x in m.name_line],
+                   [str(x) for x in m.name_sub], names_chronics_to_backend=None)
+    for key, attr in (("load_p_forecasted", "load_p_forecast"), ("load_q_forecasted", "load_q_forecast"),
+                      ("prod_p_forecasted", "prod_p_forecast"), ("prod_v_forecasted", "prod_v_forecast")):
+        got, want = ch[key], getattr(ref, attr)
+        assert got.shape == want.shape and np.array_equal(got, want.astype(np.float32)), key

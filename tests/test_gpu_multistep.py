@@ -394,3 +394,57 @@ def test_batched_simulate_of_candidate_actions(name, load_model):
         n_conv += int(o.converged)
     assert n_conv >= n - 2
     eng.close()
+
+
+def test_api_error_paths_and_edge_cases(load_model, load_npz):
+    """Bad arguments are refused with GPF_E_INVALID and leave the engine state untouched; odd shapes work: a 1-lane engine, more
+    steps per launch than the chronics table has rows (the cursor wraps), a trajectory buffer shorter than the launch."""
+    from grid2op_amd.engine import GridPFError, PowerFlowEngine
+    m, ch, eng, tab, off, scale = _setup(load_model, load_npz, "l2rpn_case14_sandbox", 5)
+    eng.step(0, rebalance=1.02)
+    before = _snapshot(eng)
+    t_before, sb_before = eng.get_topology()
+    bad = np.tile(m.initial_topo_vect(), (5, 1))
+    bad[3, 7] = 0                                            # local bus ids are -1 or 1..n_busbar
+    with pytest.raises(GridPFError):
+        eng.set_topology(bad)
+    bad[3, 7] = 3
+    with pytest.raises(GridPFError):
+        eng.set_topology(bad)
+    good = np.tile(m.initial_topo_vect(), (5, 1))
+    with pytest.raises(GridPFError):
+        eng.set_topology(good, np.full((5, m.n_shunt), 5, np.int32))
+    t_after, sb_after = eng.get_topology()
+    assert np.array_equal(t_before, t_after) and np.array_equal(sb_before, sb_after)      # nothing was half-applied
+    with pytest.raises(GridPFError):
+        eng.step(0, n_steps=0)
+    with pytest.raises(GridPFError):
+        eng.runpf(3, 10)                                      # range past the last lane
+    with pytest.raises(GridPFError):
+        eng.upload_maintenance(np.zeros((1, 7, m.n_line), np.uint8))          # shape must match the chronics tables
+    with pytest.raises(GridPFError):
+        eng.redispatch(np.zeros((5, m.n_gen)), np.zeros((5, m.n_gen)), np.zeros((5, m.n_gen)), np.zeros((5, m.n_gen)),
+                       np.zeros((5, m.n_gen), bool), np.zeros(5))             # generator limits not set
+    with pytest.raises(GridPFError):
+        eng.trajectory(1)                                     # no trajectory buffer requested
+    eng.step(0, rebalance=1.02)
+    _same(_snapshot(eng), before, "state after the refused calls")
+    # the chronics cursor wraps inside a launch: T + 3 steps from row 0 end on row 2
+    T = tab.shape[0]
+    eng.set_lane_chronics(lane_offset=np.zeros(5, np.int32), lane_scale=scale)
+    eng.set_trajectory(4)                                     # shorter than the launch: only the first 4 steps are kept
+    eng.step(0, n_steps=T + 3, rebalance=1.02)
+    a = _snapshot(eng)
+    rho4, st4 = eng.trajectory(4)
+    eng.step(2, rebalance=1.02)
+    b = _snapshot(eng)
+    assert np.allclose(a["out"], b["out"], rtol=2e-6, atol=2e-5) and np.array_equal(a["status"], b["status"])
+    eng.step(3, rebalance=1.02)
+    assert np.allclose(rho4[3], eng.step_outputs()[0], rtol=2e-6, atol=1e-6)
+    eng.close()
+    one = PowerFlowEngine(m, n_lanes=1, device=0)             # a single lane (what a HipBackend without copies uses)
+    one.upload_chronics(tab)
+    one.step(5, n_steps=2)
+    one.runpf()
+    assert one.results().converged.all()
+    one.close()
