@@ -241,6 +241,33 @@ __device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const Gr
 // -- large grids, whose phases loop over hundreds of items -- WPI wavefronts serve ONE instance (GW = 64 * WPI lanes, the
 // phase boundaries become real workgroup barriers).  All lanes execute the same instruction stream (same grid, same
 // symbolic program); collectives are scoped to the group.
+// v + (v moved across lanes by a DPP control): cross-lane adds in the VALU instead of ds_bpermute round trips (~100 cycles each)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// sum over aligned groups of GWS = 16 / 32 / 64 lanes of a wavefront, returned to every lane of the group
+template <int GWS>
+__device__ __forceinline__ double dpp_group_sum(double v) {
+  v = dpp_add_f64<0xB1, 0xF>(v);                 // quad_perm [1,0,3,2]
+  v = dpp_add_f64<0x4E, 0xF>(v);                 // quad_perm [2,3,0,1]
+  v = dpp_add_f64<0x141, 0xF>(v);                // row_half_mirror
+  v = dpp_add_f64<0x140, 0xF>(v);                // row_mirror: every lane of a 16-lane row holds the row sum
+  if (GWS == 16) return v;
+  v = dpp_add_f64<0x142, 0xA>(v);                // row_bcast15 into rows 1 and 3: they hold the sums of rows 0+1 / 2+3
+  if (GWS == 32) {
+    const double s0 = readlane_f64(v, 31), s1 = readlane_f64(v, 63);
+    return (threadIdx.x & 32) ? s1 : s0;
+  }
+  v = dpp_add_f64<0x143, 0xC>(v);                // row_bcast31 into rows 2 and 3: lane 63 holds the wavefront sum
+  return readlane_f64(v, 63);
+}
+
 template <int IPW, int WPI = 1>
 struct Grp {
   static_assert(IPW == 1 || WPI == 1, "either several instances per wavefront or several wavefronts per instance");
@@ -271,9 +298,7 @@ struct Grp {
       for (int k = 0; k < WPI; ++k) t += red_[k];
       return t;
     }
-#pragma unroll
-    for (int off = (GW < WAVE ? GW : WAVE) / 2; off; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    return dpp_group_sum<(GW < WAVE ? GW : WAVE)>(v);
   }
   // over ALL lanes of the block (every instance of the wavefront / every wavefront of the instance)
   static __device__ __forceinline__ bool block_any(bool x) { return WPI > 1 ? (__syncthreads_or(x) != 0) : (bool)__any(x); }
@@ -1425,7 +1450,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       // a group whose cascade has ended re-solves its unchanged state along with the others (same results)
       int it_k = 0, nb_k = 0;
       SolveCtl ctl;
-      ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && !TC; ctl.write_bus = last;
+      ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && !TC && sa.n_steps > 1; ctl.write_bus = last;
       const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI, TC>(P, S, sv, c, inst, sa.is_dc, max_iter, tol_pu, tid, ctl, ts, it_k, nb_k GPF_STAMPS_ARG);
       first = false;
       GPF_SYNC();
