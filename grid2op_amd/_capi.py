@@ -20,7 +20,7 @@ _LIB_NAME = "libgridpf.so"
 EXPORTED_SYMBOLS = [
     "gpf_last_error", "gpf_version", "gpf_set_deterministic", "gpf_device_count", "gpf_create", "gpf_destroy", "gpf_get_layout", "gpf_n_lanes",
     "gpf_set_injections", "gpf_set_topology", "gpf_get_injections", "gpf_get_topology", "gpf_disconnect_line",
-    "gpf_reset_lanes", "gpf_copy_lanes", "gpf_fanout_n1", "gpf_runpf", "gpf_get_results", "gpf_upload_chronics",
+    "gpf_reset_lanes", "gpf_copy_lanes", "gpf_fanout_n1", "gpf_runpf", "gpf_solve_lane", "gpf_get_results", "gpf_upload_chronics",
     "gpf_upload_maintenance", "gpf_set_lane_chronics", "gpf_set_thermal_limits", "gpf_step", "gpf_step_n", "gpf_set_lane_redispatch", "gpf_set_gen_limits", "gpf_redispatch", "gpf_set_trajectory",
     "gpf_get_trajectory", "gpf_get_episode", "gpf_lane_capacity", "gpf_get_step_outputs", "gpf_sync",
     "gpf_set_profiling", "gpf_get_kernel_time", "gpf_device_pointers",
@@ -126,6 +126,7 @@ def lib() -> C.CDLL:
     L.gpf_fanout_n1.argtypes = [h, i32, i32, i32, _ip]
     L.gpf_runpf.argtypes = [h, i32, i32, i32, i32, C.c_double]
     L.gpf_get_results.argtypes = [h, i32, i32, _fp, _ip, _ip, _bp, _ip, _dp, _dp]
+    L.gpf_solve_lane.argtypes = [h, i32, _dp, _ip, _ip, i32, i32, C.c_double, _fp, _ip, _ip, _bp, _ip, _dp, _dp]
     L.gpf_upload_chronics.argtypes = [h, i32, i32, _fp]
     L.gpf_upload_maintenance.argtypes = [h, i32, i32, _bp]
     L.gpf_set_lane_chronics.argtypes = [h, _ip, _ip, _fp]

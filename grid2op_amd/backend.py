@@ -388,11 +388,8 @@ class HipBackend(Backend):
         inj = np.concatenate((self._gen_p, self._gen_vm, self._load_p, self._load_q, self._sto_p, self._sto_q,
                               self._sh_p, self._sh_q))
         shunt_bus = np.where(self._act_shunt, self._bus_shunt, -1).astype(np.int32)
-        eng.set_injections(inj[None, :], lane0=self._lane)
-        eng.set_topology(self._topo_vect.astype(np.int32)[None, :], shunt_bus[None, :] if m.n_shunt else None,
-                         lane0=self._lane)
-        eng.runpf(self._lane, 1, is_dc=bool(is_dc), max_iter=self._max_iter, tol_mva=self._tol_mva)
-        r = eng.results(self._lane, 1)
+        r = eng.solve_lane(self._lane, inj, self._topo_vect, shunt_bus if m.n_shunt else None, is_dc=bool(is_dc),
+                           max_iter=self._max_iter, tol_mva=self._tol_mva)      # push state + solve + read back: one call, one sync
         self.comp_time += time.perf_counter() - beg
         st = int(r.status[0, 0])
         if st != 0:

@@ -121,6 +121,8 @@ struct gpf_engine {
   DevArr<float> rd_after;
   double rd_eps = 1e-4;
   bool rd_ready = false;
+  unsigned char* pin = nullptr;         // pinned host staging of gpf_solve_lane (one lane in, one lane out)
+  size_t pin_bytes = 0;
   int dcf = 0;                          // the NB == 1 LDS layout has room for the factored DC matrix (decided once at gpf_create)
   DevArr<double> d_init_inj;
   DevArr<int> d_init_topo, d_init_shunt_bus;
@@ -760,6 +762,7 @@ int gpf_destroy(gpf_handle e) {
   e->lane_table.release(); e->lane_offset.release(); e->tmp_lines.release(); e->out.release(); e->chron.release();
   e->lane_scale.release(); e->thermal_limit.release(); e->rho.release(); e->line_status.release();
   e->d_init_inj.release(); e->d_init_topo.release(); e->d_init_shunt_bus.release();
+  if (e->pin) (void)hipHostFree(e->pin);
   e->maint.release();
   e->rd_pmin.release(); e->rd_pmax.release(); e->rd_ru.release(); e->rd_rd.release(); e->rd_in.release(); e->rd_redisp.release();
   e->rd_u8.release(); e->rd_after.release();
@@ -943,6 +946,77 @@ int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
   HIP_TRY(hipGetLastError());
   if (e->profiling) HIP_TRY(hipEventRecord(eb, e->stream));
   if (e->window) ++e->win_launches;
+  return GPF_OK;
+}
+
+// The whole of HipBackend.runpf for ONE lane in a single call: push the lane's injections and topology (apply_action's
+// scatter, pandaPowerBackend.py:920-975), solve (runpf -> pp.runpp / rundcpp, :1078-1120), read every result buffer back
+// (the getters, :1566-1619) -- everything queued on the stream through one pinned staging block, ONE synchronisation.
+int gpf_solve_lane(gpf_handle e, int32_t lane, const double* inj, const int32_t* topo, const int32_t* shunt_bus, int32_t is_dc,
+                   int32_t max_iter, double tol_mva, float* out, int32_t* topo_vect, int32_t* shunt_bus_out, uint8_t* line_status,
+                   int32_t* status, double* bus_vm, double* bus_va) {
+  if (!check_range(e, lane, 1) || !inj || !topo) return fail(GPF_E_INVALID, "gpf_solve_lane: bad arguments");
+  const gpf::GridDev& g = e->g;
+  if (g.n_shunt && !shunt_bus) return fail(GPF_E_INVALID, "gpf_solve_lane: shunt_bus is required on a grid with shunts");
+  auto bad_bus = [&g](int v) { return v == 0 || v < -1 || v > g.n_busbar; };
+  for (int i = 0; i < g.dim_topo; ++i) if (bad_bus(topo[i])) return fail(GPF_E_INVALID, "gpf_solve_lane: local bus ids must be -1 or 1..n_busbar");
+  for (int i = 0; i < g.n_shunt; ++i) if (bad_bus(shunt_bus[i])) return fail(GPF_E_INVALID, "gpf_solve_lane: shunt bus ids must be -1 or 1..n_busbar");
+  HIP_TRY(hipSetDevice(e->device));
+  // staging layout (16-byte aligned pieces): in: inj | topo | shunt_bus    out: out | topo_vect | shunt_bus_out | line_status | status | bus_vm | bus_va
+  auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  const size_t o_inj = 0, o_topo = o_inj + al((size_t)g.n_inj * 8), o_sb = o_topo + al((size_t)g.dim_topo * 4);
+  const size_t o_out = o_sb + al((size_t)g.n_shunt * 4), o_tv = o_out + al((size_t)g.n_out * 4), o_sbo = o_tv + al((size_t)g.dim_topo * 4);
+  const size_t o_ls = o_sbo + al((size_t)g.n_shunt * 4), o_st = o_ls + al((size_t)g.n_line), o_vm = o_st + 16, o_va = o_vm + al((size_t)g.nb_tot * 8);
+  const size_t total = o_va + al((size_t)g.nb_tot * 8);
+  if (e->pin_bytes < total) {
+    if (e->pin) (void)hipHostFree(e->pin);
+    e->pin = nullptr; e->pin_bytes = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->pin), total, hipHostMallocDefault));
+    e->pin_bytes = total;
+  }
+  unsigned char* P = e->pin;
+  std::memcpy(P + o_inj, inj, (size_t)g.n_inj * 8);
+  std::memcpy(P + o_topo, topo, (size_t)g.dim_topo * 4);
+  if (g.n_shunt) std::memcpy(P + o_sb, shunt_bus, (size_t)g.n_shunt * 4);
+  hipStream_t st = e->stream;
+  HIP_TRY(hipMemcpyAsync(e->inj.p + (size_t)lane * g.n_inj, P + o_inj, (size_t)g.n_inj * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(e->topo.p + (size_t)lane * g.dim_topo, P + o_topo, (size_t)g.dim_topo * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(e->topo0.p + (size_t)lane * g.dim_topo, P + o_topo, (size_t)g.dim_topo * 4, hipMemcpyHostToDevice, st));
+  if (g.n_shunt) HIP_TRY(hipMemcpyAsync(e->shunt_bus.p + (size_t)lane * g.n_shunt, P + o_sb, (size_t)g.n_shunt * 4, hipMemcpyHostToDevice, st));
+  {   // host bookkeeping of the lane's topology (as gpf_set_topology)
+    int* mt = e->h_lane_topo.data() + (size_t)lane * g.dim_topo;
+    int* ms = e->h_lane_sb.data() + (size_t)lane * std::max(g.n_shunt, 1);
+    if (!(std::memcmp(mt, topo, (size_t)g.dim_topo * sizeof(int)) == 0 &&
+          (!g.n_shunt || std::memcmp(ms, shunt_bus, (size_t)g.n_shunt * sizeof(int)) == 0))) {
+      std::memcpy(mt, topo, (size_t)g.dim_topo * sizeof(int));
+      if (g.n_shunt) std::memcpy(ms, shunt_bus, (size_t)g.n_shunt * sizeof(int));
+      count_lane(e, topo, g.n_shunt ? shunt_bus : nullptr, e->lane_nb[lane], e->lane_nj[lane], e->lane_mb[lane]);
+      e->lane_class[lane] = topo_class_of(e, topo, g.n_shunt ? shunt_bus : nullptr);
+      e->plan_valid = false;
+    }
+  }
+  LaunchPlan p, pb;
+  int rc = plan_launch(e, lane, 1, p, pb);
+  if (rc != GPF_OK) return rc;
+  rc = upload_params_s(e, e->bufs(), p.tc ? &p : (pb.tc ? &pb : nullptr));
+  if (rc != GPF_OK) return rc;
+  const double tol_pu = tol_mva / g.sn_mva;
+  HIP_TRY(gpf_launch_runpf_sparse(p, e->device, e->d_params_s, st, lane, 1, is_dc, max_iter, tol_pu));
+  if (pb.sparse_nb) HIP_TRY(gpf_launch_runpf_sparse(pb, e->device, e->d_params_s, st, lane, 1, is_dc, max_iter, tol_pu));
+  if (e->window) ++e->win_launches;
+#define DL1(off, arr, stride, bytes_per) \
+  if ((stride) > 0) HIP_TRY(hipMemcpyAsync(P + (off), e->arr.p + (size_t)lane * (stride), (size_t)(stride) * (bytes_per), hipMemcpyDeviceToHost, st))
+  DL1(o_out, out, g.n_out, 4); DL1(o_tv, topo_out, g.dim_topo, 4); DL1(o_sbo, shunt_bus_out, g.n_shunt, 4); DL1(o_ls, line_status, g.n_line, 1);
+  DL1(o_st, status, 4, 4); DL1(o_vm, bus_vm, g.nb_tot, 8); DL1(o_va, bus_va, g.nb_tot, 8);
+#undef DL1
+  HIP_TRY(hipStreamSynchronize(st));
+  if (out) std::memcpy(out, P + o_out, (size_t)g.n_out * 4);
+  if (topo_vect) std::memcpy(topo_vect, P + o_tv, (size_t)g.dim_topo * 4);
+  if (shunt_bus_out && g.n_shunt) std::memcpy(shunt_bus_out, P + o_sbo, (size_t)g.n_shunt * 4);
+  if (line_status) std::memcpy(line_status, P + o_ls, (size_t)g.n_line);
+  if (status) std::memcpy(status, P + o_st, 16);
+  if (bus_vm) std::memcpy(bus_vm, P + o_vm, (size_t)g.nb_tot * 8);
+  if (bus_va) std::memcpy(bus_va, P + o_va, (size_t)g.nb_tot * 8);
   return GPF_OK;
 }
 

@@ -265,6 +265,28 @@ class PowerFlowEngine:
         lane0, n = self._range(lane0, n)
         check(self._lib.gpf_runpf(self._h, lane0, n, int(bool(is_dc)), int(max_iter), float(tol_mva)), "gpf_runpf")
 
+    def solve_lane(self, lane: int, inj: np.ndarray, topo: np.ndarray, shunt_bus: Optional[np.ndarray] = None, is_dc: bool = False,
+                   max_iter: int = 10, tol_mva: float = 1e-8) -> LaneResults:
+        """`set_injections` + `set_topology` + `runpf` + `results` of ONE lane in one C call with a single synchronisation: the
+        whole of a Backend's ``runpf`` (what `HipBackend` uses)."""
+        m = self.model
+        inj = np.ascontiguousarray(inj, dtype=np.float64).reshape(self.n_inj)
+        topo = np.ascontiguousarray(topo, dtype=np.int32).reshape(m.dim_topo)
+        sb_in = None if not m.n_shunt else np.ascontiguousarray(shunt_bus, dtype=np.int32).reshape(m.n_shunt)
+        out = np.empty((1, self.n_out), dtype=np.float32)
+        tv = np.empty((1, m.dim_topo), dtype=np.int32)
+        sb = np.empty((1, m.n_shunt), dtype=np.int32)
+        ls = np.empty((1, m.n_line), dtype=np.uint8)
+        st = np.empty((1, 4), dtype=np.int32)
+        bvm = np.empty((1, self.nb_total), dtype=np.float64)
+        bva = np.empty((1, self.nb_total), dtype=np.float64)
+        check(self._lib.gpf_solve_lane(self._h, int(lane), ptr(inj, C.c_double), ptr(topo, C.c_int32), ptr(sb_in, C.c_int32),
+                                       int(bool(is_dc)), int(max_iter), float(tol_mva), ptr(out, C.c_float), ptr(tv, C.c_int32),
+                                       ptr(sb, C.c_int32), ptr(ls, C.c_uint8), ptr(st, C.c_int32), ptr(bvm, C.c_double),
+                                       ptr(bva, C.c_double)), "gpf_solve_lane")
+        return LaneResults(out=out, topo_vect=tv, shunt_bus=sb, line_status=ls.astype(bool), status=st, bus_vm=bvm, bus_va=bva,
+                           _slices=self.out_slices)
+
     def results(self, lane0: int = 0, n: Optional[int] = None, with_bus: bool = True) -> LaneResults:
         lane0, n = self._range(lane0, n)
         m = self.model

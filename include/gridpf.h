@@ -138,6 +138,15 @@ int gpf_fanout_n1(gpf_handle h, int32_t src_lane, int32_t dst_lane0, int32_t n_o
  * result extraction of _fetch_data_pf_converged.  Asynchronous (queued on the handle's stream). */
 int gpf_runpf(gpf_handle h, int32_t lane0, int32_t n, int32_t is_dc, int32_t max_iter, double tol_mva);
 
+/* The single-environment plugin path in ONE call (what HipBackend.runpf does per power flow): gpf_set_injections +
+ * gpf_set_topology + gpf_runpf + gpf_get_results for one lane, staged through pinned host memory and synchronised once
+ * (apply_action pandaPowerBackend.py:902-975, runpf :1220-1255, getters :1566-1619).  inj [n_inj], topo [dim_topo],
+ * shunt_bus [n_shunt] (required when the grid has shunts); output pointers as in gpf_get_results (any may be NULL).
+ * Synchronous. */
+int gpf_solve_lane(gpf_handle h, int32_t lane, const double* inj, const int32_t* topo, const int32_t* shunt_bus, int32_t is_dc,
+                   int32_t max_iter, double tol_mva, float* out, int32_t* topo_vect, int32_t* shunt_bus_out, uint8_t* line_status,
+                   int32_t* status, double* bus_vm, double* bus_va);
+
 /* Getters (pandaPowerBackend.py:1566-1619, 278-301, 1439-1462, 1486): synchronise, then copy rows
  * lane0..lane0+n-1.  Any pointer may be NULL.
  *   out         [n][n_out]    float   (NaN everywhere when the lane did not converge, :1257-1287)

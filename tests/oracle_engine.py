@@ -59,5 +59,11 @@ class OracleEngine:
                            line_status=st("line_status", bool), status=st("status", np.int32), bus_vm=st("bus_vm", np.float64),
                            bus_va=st("bus_va", np.float64), _slices=self.out_slices)
 
+    def solve_lane(self, lane, inj, topo, shunt_bus=None, is_dc=False, max_iter=10, tol_mva=1e-8):
+        self.set_injections(np.asarray(inj)[None, :], lane0=lane)
+        self.set_topology(np.asarray(topo)[None, :], None if shunt_bus is None else np.asarray(shunt_bus)[None, :], lane0=lane)
+        self.runpf(lane, 1, is_dc=is_dc, max_iter=max_iter, tol_mva=tol_mva)
+        return self.results(lane, 1)
+
     def close(self):
         pass

@@ -448,3 +448,27 @@ def test_api_error_paths_and_edge_cases(load_model, load_npz):
     one.runpf()
     assert one.results().converged.all()
     one.close()
+
+
+def test_solve_lane_equals_the_four_call_sequence(load_model):
+    """`gpf_solve_lane` (one call, pinned staging, one sync) against set_injections + set_topology + runpf + results on another
+    lane of the same engine, for random states incl. splits, outages, diverging lanes and DC mode."""
+    from grid2op_amd.engine import PowerFlowEngine
+    from helpers import pack_states, random_states
+    m = load_model("educ_case14_storage")
+    eng = PowerFlowEngine(m, n_lanes=5, device=0)
+    rng = np.random.default_rng(9)
+    for s in [LaneState.from_model(m)] + random_states(m, 25, rng):
+        inj, topo, sb = pack_states(m, [s])
+        for dc in (False, True):
+            a = eng.solve_lane(3, inj[0], topo[0], sb[0], is_dc=dc)
+            eng.set_injections(inj, lane0=1)
+            eng.set_topology(topo, sb, lane0=1)
+            eng.runpf(1, 1, is_dc=dc)
+            b = eng.results(1, 1)
+            assert np.array_equal(a.status, b.status) and np.array_equal(a.topo_vect, b.topo_vect)
+            assert np.array_equal(a.line_status, b.line_status) and np.array_equal(a.shunt_bus, b.shunt_bus)
+            assert np.array_equal(a.out, b.out, equal_nan=True)
+            assert np.array_equal(a.bus_vm, b.bus_vm, equal_nan=True) and np.array_equal(a.bus_va, b.bus_va, equal_nan=True)
+            assert np.array_equal(eng.get_injections(3, 1), inj) and np.array_equal(eng.get_topology(3, 1)[0], topo)
+    eng.close()
