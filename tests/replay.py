@@ -85,7 +85,13 @@ def replay(tr, factory, grid_path, env_dir=None):
         k, bid, arg, row = int(k), int(bid), int(arg), int(row)
         if k == EV_LOAD:
             bk = factory()
-            bk.set_env_name("replay_" + os.path.basename(grid_path).split(".")[0])   # one grid class per grid (environment.py:300)
+            n_busbar = int(tr["meta_n_busbar"]) if "meta_n_busbar" in tr else 2
+            cls = type(bk)                                       # what grid2op.make(..., n_busbar=N) does before load_grid
+            if hasattr(cls, "set_n_busbar_per_sub"):
+                cls.set_n_busbar_per_sub(n_busbar)
+            else:
+                cls.n_busbar_per_sub = n_busbar
+            bk.set_env_name("replay_" + os.path.basename(grid_path).split(".")[0] + (f"_{n_busbar}bb" if n_busbar != 2 else ""))   # one grid class per grid (environment.py:300)
             bk.load_grid(grid_path)
             if env_dir is not None and bk.n_storage > 0:         # real grid2op: storage characteristics are part of the grid class
                 bk.load_storage_data(env_dir)
