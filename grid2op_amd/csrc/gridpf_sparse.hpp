@@ -1,4 +1,4 @@
-// gridpf_sparse.hpp -- kernel S: block-sparse Newton-Raphson for LARGE grids (e.g. the 118-substation grids).
+// gridpf_sparse.hpp -- kernel S: block-sparse Newton-Raphson power flow + batched environment step, every grid size.
 //
 // One wavefront per grid instance, everything in LDS, but the linear algebra is a right-looking BLOCK-SPARSE LU on the
 // substation graph (host-side symbolic analysis: gridpf_symbolic.hpp).  A block couples the NB busbars x {theta, |V|}
@@ -8,8 +8,8 @@
 //
 // Work per factorisation is O(sum_k deg_k^2 * BS^3) (~10^4 FMA for 118 substations) instead of 2/3 n^3 = 4.6e6 for
 // the dense Jacobian, and the 0.3 MB dense matrix (which cannot live in the 160 KB LDS) shrinks to a ~25 KB block
-// array.  Assembly uses native LDS f64 atomics from branch / element lanes; the pipeline (K9, K1..K7) and the
-// arithmetic conventions are those of gridpf_kernels.hpp / gridpf_small.hpp.
+// array.  Assembly uses native LDS f64 atomics from branch / element lanes; the pipeline (K9, K1..K7) and its reference
+// counterparts are listed in gridpf_common.hpp.
 #pragma once
 #include "gridpf_common.hpp"
 

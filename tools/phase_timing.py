@@ -32,7 +32,7 @@ L = _capi.lib()
 buf = np.zeros((B, 32))
 L.gpf_debug_read_work.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int64]
 assert L.gpf_debug_read_work(eng._h, buf.ctypes.data_as(C.POINTER(C.c_double)), buf.size) == 0
-SPARSE = os.environ.get("GRIDPF_DENSE") != "1"
+SPARSE = True
 if SPARSE:
     names_s = {8: "kernel start", 0: "K9 chronics gather", 1: "K1 + bus types (atomics)", 2: "connectivity", 3: "Ybus + DC assembly",
                4: "DC block-LU solve", 5: "Newton loop total", 6: "results", 9: "cascade check / back in step kernel", 15: "rho + counters"}
@@ -59,15 +59,3 @@ if SPARSE:
     print(f"  results detail: line flows {med[22] - med[5]:.0f}, loads/storages/shunts {med[23] - med[22]:.0f}, gen accumulate {med[24] - med[23]:.0f}, "
           f"gen write {med[25] - med[24]:.0f}, topo_out {med[26] - med[25]:.0f}, bus V {med[6] - med[26]:.0f}")
     sys.exit(0)
-names = {8: "kernel start", 0: "K9 chronics gather done / solve start", 1: "K1 topology", 2: "bus types+numbering", 3: "connectivity",
-         4: "Ybus + B' assembly", 5: "DC solve", 10: "NR it1: sincos", 11: "NR it1: assembly+check (up to reload it2..)",
-         12: "NR it2: reload+GJ", 6: "Newton loop total", 7: "results", 9: "back in step kernel"}
-order = [8, 0, 1, 2, 3, 4, 5, 6, 7, 9]
-med = np.median(buf, axis=0)
-print(f"batch {B}: median cycle counts per phase (s_memtime ticks)")
-prev = med[8]
-for k in order[1:]:
-    print(f"  {names[k]:45s} {med[k] - prev:10.0f}")
-    prev = med[k]
-print(f"  {'TOTAL':45s} {med[9] - med[8]:10.0f}")
-print("  inside Newton: sincos(it1 start..)->", med[10] - med[5], " assembly it1..reload it2:", med[11] - med[10], " GJ it2:", med[12] - med[11])
