@@ -383,6 +383,20 @@ def main():
             res["one_launch_per_step"] = dict(summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec,
                                               us_per_step=median_window(w)[0] / k_sec * 1e6)
 
+    # ---- OPT-IN, NOT the reference's algorithm (never the headline): Newton warm-started from the previous step -----------------
+    if secondary and args.steps_per_launch != 1:
+        eng.reset()
+        w, _ = timed_windows(ctx, eng, k_sec, w_sec, dict(step_kw, warm_start=True), 3, preroll_steps=0)
+        rw = eng.results()
+        if rank == 0:
+            res["warm_start_opt_in"] = dict(summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec,
+                                            note="gpf_step_opts.warm_start=1: steps 2..n of a launch start Newton from the previous "
+                                                 "step's voltages instead of pandapower's per-call DC initialisation; same solution "
+                                                 "within tol_mva, n_iter differs from the reference's; NOT used for `value`",
+                                            mean_nr_iterations=float(rw.n_iter[rw.converged].mean()) if rw.converged.any() else None,
+                                            frac_converged=float(rw.converged.mean()))
+        eng.reset()
+
     # ---- the same workload with the reference's DEFAULT parameters: overflow disconnections (cascade) on ---------------------
     if secondary and not args.cascade:
         eng.reset()

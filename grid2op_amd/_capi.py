@@ -75,7 +75,7 @@ class GpfLayout(C.Structure):
 class GpfStepOpts(C.Structure):
     _fields_ = [("max_iter", C.c_int32), ("tol_mva", C.c_double), ("rebalance", C.c_double), ("cascade", C.c_int32),
                 ("hard_overflow", C.c_float), ("soft_overflow", C.c_float), ("nb_ts_allowed", C.c_int32), ("max_rounds", C.c_int32),
-                ("is_dc", C.c_int32), ("auto_reset", C.c_int32)]
+                ("is_dc", C.c_int32), ("auto_reset", C.c_int32), ("warm_start", C.c_int32)]
 
 
 _lib: Optional[C.CDLL] = None

@@ -1115,7 +1115,7 @@ int gpf_step_n(gpf_handle e, int32_t t0, int32_t n_steps, const gpf_step_opts* o
   gpf::Bufs b = e->bufs();
   gpf::StepArgs sa{};
   sa.t = t0; sa.T = e->chron_T; sa.rebalance_on = o->rebalance > 0.0 ? 1 : 0; sa.rebalance = o->rebalance; sa.cascade = o->cascade;
-  sa.is_dc = o->is_dc ? 1 : 0; sa.n_steps = n_steps; sa.auto_reset = o->auto_reset ? 1 : 0;
+  sa.is_dc = o->is_dc ? 1 : 0; sa.n_steps = n_steps; sa.auto_reset = o->auto_reset ? 1 : 0; sa.warm_start = o->warm_start ? 1 : 0;
   sa.nb_ts_allowed = o->nb_ts_allowed; sa.max_rounds = o->max_rounds; sa.hard_overflow = o->hard_overflow; sa.soft_overflow = o->soft_overflow;
   const double tol_pu = o->tol_mva / e->g.sn_mva;
   hipEvent_t ea = nullptr, eb = nullptr;
@@ -1134,7 +1134,7 @@ int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double r
              float soft_overflow, int32_t nb_ts_allowed, int32_t max_rounds, int32_t is_dc) {
   gpf_step_opts o{};
   o.max_iter = max_iter; o.tol_mva = tol_mva; o.rebalance = rebalance; o.cascade = cascade; o.hard_overflow = hard_overflow;
-  o.soft_overflow = soft_overflow; o.nb_ts_allowed = nb_ts_allowed; o.max_rounds = max_rounds; o.is_dc = is_dc; o.auto_reset = 0;
+  o.soft_overflow = soft_overflow; o.nb_ts_allowed = nb_ts_allowed; o.max_rounds = max_rounds; o.is_dc = is_dc; o.auto_reset = 0; o.warm_start = 0;
   return gpf_step_n(e, t, 1, &o);
 }
 

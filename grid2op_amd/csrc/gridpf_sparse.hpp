@@ -714,6 +714,8 @@ struct SolveCtl {
                       // connectivity verdict and Ybus blocks in LDS are valid (and the DC factors when dcf)
   bool dcf;           // CarveP::Adc holds / receives the factored DC matrix (NB == 1)
   bool write_bus;     // write the float64 bus voltages (parity checks, the facade's stale-bus angles)
+  bool warm;          // OPT-IN, not the reference's algorithm: with `reuse`, Newton starts from the previous solve's voltages
+                      // (CarveP::va / vm still hold them) instead of the DC initialisation pandapower does on every call
 };
 // per-group results of the topology phases, kept by the caller across solves
 struct TopoState {
@@ -757,6 +759,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   }
   const bool reuse = ctl.reuse;
   const bool dc_kept = reuse && ctl.dcf && NB == 1;        // the factored DC matrix of the previous solve is still valid
+  const bool warm = reuse && ctl.warm && !is_dc;            // block-uniform: skip the DC initialisation, keep va / |V| of PQ buses
 #define GPF_INJ(i_) (STAGE ? c.inj[(i_)] : (double)inj_g[(i_)])      /* staged row in LDS, else the lane's row in HBM / L2 */
   const double sn = g.sn_mva, inv_sn = 1.0 / sn;
 
@@ -864,7 +867,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     if (i < nbus) {
       const int vi = c.vidx[i];
       // initial |V|: set-point of the last in-service generator on PV / reference buses, 1 pu elsewhere
-      c.vm[i] = (vi >= 0 && (bt == BT_PV || bt == BT_REF)) ? GPF_INJ(oo.inj_gen_vm + vi) : 1.0;
+      const double vm_pq = warm ? c.vm[i] : 1.0;
+      c.vm[i] = (vi >= 0 && (bt == BT_PV || bt == BT_REF)) ? GPF_INJ(oo.inj_gen_vm + vi) : vm_pq;
       if (!reuse) c.lab[i] = (bt == BT_REF) ? 1 : 0;
     }
     if (!reuse) {
@@ -913,6 +917,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   // (reuse: the Ybus blocks stand; the DC matrix is rebuilt unless its factors were kept)
   const bool do_y = !reuse && !is_dc;
   auto lidx = [&](int bus) -> int { return (NB == 1) ? 0 : bus % NB; };
+  if (!warm) {
   if (!dc_kept || do_y) {
   if (do_y) for (int i = tid; i < S.nslot_y * NB * NB * 2; i += GW) c.Yb[i] = 0.0;
   if (!dc_kept) for (int i = tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
@@ -970,6 +975,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     c.rhs[(size_t)sub * BS + 2 * bi + 1] = 0.0;
   }
   GPF_LSYNC();
+  }
   GPF_STAMPS(3);
   // the program is in LDS (tier >= 1) or read in place through a global-address-space pointer (tier 0)
   auto lu_ac = [&](long long* dbg) -> bool {
@@ -984,7 +990,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     if (STAGE >= 1) return scalar_lu_solve<GW, 2, true>(S, sv.prog.p, c.A, c.rhs, tid, dbg);
     return scalar_lu_solve<GW, 2, true>(S, gptr(sv.prog.p), c.A, c.rhs, tid, dbg);
   };
-  {
+  if (!warm) {
 #ifdef GPF_TIMING
     bool ok = (NB == 1) ? lu_dc(&stamps.v[20])
                         : lu_ac(&stamps.v[20]);
@@ -1304,7 +1310,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   int n_iter, nb;
   GPF_STAMPS_DECL;
   SolveCtl ctl;
-  ctl.inj_staged = false; ctl.topo_staged = false; ctl.reuse = false; ctl.dcf = false; ctl.write_bus = true;
+  ctl.inj_staged = false; ctl.topo_staged = false; ctl.reuse = false; ctl.dcf = false; ctl.write_bus = true; ctl.warm = false;
   TopoState ts;
   ts.status = 0; ts.nb = 0;
   const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC>(P, S, sv, c, inst, is_dc, max_iter, tol_pu, tid, ctl, ts, n_iter, nb GPF_STAMPS_ARG);
@@ -1450,7 +1456,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       // a group whose cascade has ended re-solves its unchanged state along with the others (same results)
       int it_k = 0, nb_k = 0;
       SolveCtl ctl;
-      ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && !TC && sa.n_steps > 1; ctl.write_bus = last;
+      ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && !TC && sa.n_steps > 1; ctl.write_bus = last; ctl.warm = sa.warm_start != 0;
       const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI, TC>(P, S, sv, c, inst, sa.is_dc, max_iter, tol_pu, tid, ctl, ts, it_k, nb_k GPF_STAMPS_ARG);
       first = false;
       GPF_SYNC();

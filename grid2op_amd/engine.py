@@ -348,11 +348,13 @@ class PowerFlowEngine:
 
     def step(self, t: int, max_iter: int = 10, tol_mva: float = 1e-8, rebalance: float = 0.0, cascade: bool = False,
              hard_overflow: float = 2.0, soft_overflow: float = 1.0, nb_ts_allowed: int = 2, max_rounds: int = 16,
-             is_dc: bool = False, n_steps: int = 1, auto_reset: bool = False):
+             is_dc: bool = False, n_steps: int = 1, auto_reset: bool = False, warm_start: bool = False):
         """``n_steps`` consecutive DoNothing ``env.step`` (t, t+1, ...) for every lane in ONE launch (asynchronous).  Every step
-        writes its results; the getters return the last one, `trajectory` the rho / status of each when requested."""
+        writes its results; the getters return the last one, `trajectory` the rho / status of each when requested.
+        ``warm_start`` (opt-in, NOT the reference's algorithm) starts Newton of steps 2..n from the previous step's voltages
+        while a lane's topology stands: same solution within ``tol_mva``, fewer iterations, ``n_iter`` differs."""
         o = GpfStepOpts(int(max_iter), float(tol_mva), float(rebalance), int(bool(cascade)), float(hard_overflow), float(soft_overflow),
-                        int(nb_ts_allowed), int(max_rounds), int(bool(is_dc)), int(bool(auto_reset)))
+                        int(nb_ts_allowed), int(max_rounds), int(bool(is_dc)), int(bool(auto_reset)), int(bool(warm_start)))
         check(self._lib.gpf_step_n(self._h, int(t), int(n_steps), C.byref(o)), "gpf_step_n")
 
     def set_lane_redispatch(self, delta_mw):

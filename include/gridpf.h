@@ -191,6 +191,11 @@ typedef struct gpf_step_opts {
                             Environment/baseEnv.py:3847-3931) restarts at the next step from the topology the host sent last
                             (gpf_set_topology / gpf_reset_lanes), overflow counters cleared -- what env.reset() does to the
                             backend (Environment/environment.py:1418 reset_grid); the chronics cursor keeps running */
+  int32_t warm_start;    /* != 0 (OPT-IN, NOT what PandaPowerBackend does): steps 2..n of a launch start Newton from the previous
+                            step's voltages while the lane's topology stands, instead of the DC initialisation pandapower
+                            performs on every runpf (pandaPowerBackend.py:1086 _pf_init = "dc"; LightSimBackend-style warm start).
+                            Same solution within the solver tolerance, fewer iterations: n_iter and the last digits differ
+                            from the reference's.  Default 0 = the reference's algorithm. */
 } gpf_step_opts;
 /* n_steps consecutive DoNothing env.step (t0, t0+1, ...) of every lane in ONE launch.  Every step does the whole of gpf_step and
  * writes its results row, rho, status and counters; between the steps of a launch the lane state stays on chip and whatever only

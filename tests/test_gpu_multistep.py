@@ -99,6 +99,43 @@ def test_multi_step_launch_equals_single_steps(name, B, kw, load_model, load_npz
     e2.close()
 
 
+@pytest.mark.parametrize("name,B,kw", [
+    ("rte_case5_example", 20, dict(rebalance=1.02)),
+    ("l2rpn_case14_sandbox", 66, dict(rebalance=1.02)),
+    ("l2rpn_case14_sandbox", 32, dict(rebalance=1.02, cascade=True, hard_overflow=1.05, nb_ts_allowed=1)),
+    ("l2rpn_neurips_2020_track1", 17, dict(rebalance=1.02)),
+    ("l2rpn_wcci_2022_dev", 8, dict(rebalance=1.02)),
+])
+def test_warm_start_option_same_solution_fewer_iterations(name, B, kw, load_model, load_npz):
+    """The opt-in warm start (NOT the reference's algorithm: pandapower re-initialises from the DC solution on every call)
+    converges to the same power flow within the solver tolerance, in fewer Newton iterations."""
+    m, ch, e1, tab, off, scale = _setup(load_model, load_npz, name, B)
+    _, _, e2, _, _, _ = _setup(load_model, load_npz, name, B)
+    n = 6
+    e1.set_trajectory(n)
+    e2.set_trajectory(n)
+    e1.step(3, n_steps=n, **kw)
+    e2.step(3, n_steps=n, warm_start=True, **kw)
+    a, b = _snapshot(e1), _snapshot(e2)
+    for k in ("topo", "ls", "ovc", "dr", "sb"):
+        assert np.array_equal(a[k], b[k]), (name, k)
+    assert np.array_equal(a["status"][:, [0, 2, 3]], b["status"][:, [0, 2, 3]])      # column 1 is n_iter
+    ok = a["status"][:, 0] == 0
+    assert ok.sum() >= B // 2
+    err = np.abs(a["out"] - b["out"])
+    assert np.array_equal(np.isnan(a["out"]), np.isnan(b["out"]))
+    assert np.all(err[~np.isnan(err)] <= (2e-4 + 5e-6 * np.abs(a["out"]))[~np.isnan(err)]), np.nanmax(err)
+    assert np.allclose(a["bus_vm"], b["bus_vm"], rtol=0, atol=1e-8, equal_nan=True)     # pu: both within tol_mva = 1e-8 of the solution
+    ra, sa_ = e1.trajectory(n)
+    rb, sb_ = e2.trajectory(n)
+    assert np.array_equal(sa_, sb_)
+    assert np.allclose(ra, rb, rtol=1e-5, atol=1e-6, equal_nan=True)
+    it_cold, it_warm = a["status"][ok, 1], b["status"][ok, 1]
+    assert (it_warm <= it_cold).all() and it_warm.mean() < it_cold.mean() - 0.5, (it_cold.mean(), it_warm.mean())
+    e1.close()
+    e2.close()
+
+
 def test_multi_step_last_step_matches_oracle(load_model, load_npz):
     m, ch, eng, tab, off, scale = _setup(load_model, load_npz, "l2rpn_case14_sandbox", 32)
     T = tab.shape[0]
