@@ -1,5 +1,6 @@
 // gridpf_launch_step.hip -- template instantiations + dispatch of gpf::step_sparse_kernel (kernel S, batched env steps).
 #include "gridpf_host.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -7,13 +8,15 @@ template <int NB, int ST, int IPW, int WP, bool TC>
 hipError_t launch(const LaunchPlan& p, int device, const gpf::DevParamsS* d_params, hipStream_t stream, int n_l, const int* list,
                   int max_iter, double tol_pu, const gpf::StepArgs& sa) {
   static size_t lds_set[64] = {0};
+  static const size_t pad = getenv("GRIDPF_LDS_PAD") ? (size_t)atoi(getenv("GRIDPF_LDS_PAD")) : 0;   // occupancy experiments only
   auto kern = &gpf::step_sparse_kernel<NB, ST, IPW, 2, WP, TC>;
-  if (p.lds > lds_set[device & 63]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
+  const size_t lds = p.lds + pad;
+  if (lds > lds_set[device & 63]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    lds_set[device & 63] = p.lds;
+    lds_set[device & 63] = lds;
   }
-  hipLaunchKernelGGL(kern, dim3((n_l + IPW - 1) / IPW), dim3(gpf::WAVE * WP), p.lds, stream, d_params, list, p.cls_list, max_iter, tol_pu,
+  hipLaunchKernelGGL(kern, dim3((n_l + IPW - 1) / IPW), dim3(gpf::WAVE * WP), lds, stream, d_params, list, p.cls_list, max_iter, tol_pu,
                      sa);
   return hipGetLastError();
 }
