@@ -144,6 +144,7 @@ struct gpf_engine {
   bool ptdf_ready = false;
   DevArr<double> stat_dbl;     // static blob of kernel S (gpf::StatOff)
   DevArr<int> stat_int;
+  DevArr<int> flat_prog;       // flat programs of the substation graph (4 group widths)
   gpf::SymDev sym_dev{};
   gpf::DevParamsS h_params_s{};
   gpf::DevParamsS* d_params_s = nullptr;
@@ -151,7 +152,7 @@ struct gpf_engine {
   // mixed batches: lanes without / with split substations are launched separately (single-busbar kernel / NB = n_busbar)
   DevArr<int> list_a, list_b, list_c;   // list_c: topology class of every lane of list_b
   // topology classes (gpf::TopoClassDev): bus-level graphs of the split topologies seen so far, each with its own symbolic program
-  struct TopoClassHost { DevArr<int> tables; gpf::TopoClassDev dev; int n_nodes, nslot, nslot_y; };
+  struct TopoClassHost { DevArr<int> tables, flat; gpf::TopoClassDev dev; int n_nodes, nslot, nslot_y; };
   std::vector<TopoClassHost*> classes;
   std::unordered_map<std::string, int> class_of_key;
   // host mirror of the topology last SENT for every lane (gpf_set_topology skips the per-lane bookkeeping when a lane is
@@ -247,6 +248,27 @@ int fwd_levels(const gpf::Symbolic& S) {
   return n;
 }
 
+// flat programs (gridpf_symbolic.hpp: FlatProg) of one graph for the four group widths, in one device buffer; false: upload
+// failed.  A graph too large for the 16-bit byte-offset fields gets none (fl[k].n_words == 0: it would not fit the LDS either).
+bool upload_flats(const gpf::Symbolic& S, DevArr<int>& buf, gpf::SymDev& D) {
+  D.rslot0 = S.rslot0;
+  for (int k = 0; k < 4; ++k) { D.flat[k] = nullptr; D.fl[k] = gpf::FlatDev{}; }
+  if (!gpf::flat_fits(S)) return true;
+  std::vector<int> all;
+  size_t off[4];
+  for (int k = 0; k < 4; ++k) {
+    const gpf::FlatProg F = gpf::build_flat(S, 16 << k);
+    off[k] = all.size();
+    all.insert(all.end(), F.words.begin(), F.words.end());
+    gpf::FlatDev& f = D.fl[k];
+    f.n_fwd = F.n_fwd; f.n_scale = F.n_scale; f.n_scale_rhs = F.n_scale_rhs; f.n_back = F.n_back; f.scale_off = F.scale_off;
+    f.back_off = F.back_off; f.rhs_field0 = F.rhs_field0; f.n_words = (int)F.words.size();
+  }
+  if (buf.upload(all.data(), all.size()) != hipSuccess) return false;
+  for (int k = 0; k < 4; ++k) D.flat[k] = buf.p + off[k];
+  return true;
+}
+
 // Topology class of a lane whose substations are split (gridpf_sparse.hpp: TopoClassDev).  Key = busbar of every line end
 // (an open end counts as busbar 1) + which busbars >= 2 carry any element; classes are built on first sight and cached.
 // Returns the class id, or -1 (classes disabled / capacity) -> the lane falls back to the NB = n_busbar kernel.
@@ -284,7 +306,7 @@ int topo_class_of(gpf_engine* e, const int* topo, const int* shunt_bus) {
     le[l] = node_of[(size_t)e->h_line_ex_sub[l] * nbb + (key[2 * l + 1] - 1)];
   }
   gpf::Symbolic S = gpf::build_symbolic(n_nodes, g.n_line, lo.data(), le.data());
-  if (S.nslot > 65535) return -1;
+  if (S.nslot > 65535 || !gpf::flat_fits(S)) return -1;
   auto* c = new gpf_engine::TopoClassHost();
   std::vector<int> fi;
   auto puti = [&fi](const int* v, size_t n) { int off = (int)fi.size(); fi.insert(fi.end(), v, v + n); while (fi.size() & 3) fi.push_back(0); return off; };
@@ -318,6 +340,7 @@ int topo_class_of(gpf_engine* e, const int* topo, const int* shunt_bus) {
     D.static_connected = one ? 1 : 0;
   }
   D.prog = c->tables.p + o_prog;
+  if (!upload_flats(S, c->flat, D)) { c->tables.release(); c->flat.release(); delete c; return -1; }
   c->dev.pair_rc = c->tables.p + o_rc; c->dev.br_slot = c->tables.p + o_br; c->dev.node_of = c->tables.p + o_no;
   const int id = (int)e->classes.size();
   e->classes.push_back(c);
@@ -359,7 +382,8 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
       while (!listed && ipw > 1 && !(lane0_l % ipw == 0 && (n_l % ipw == 0 || lane0_l + n_l == e->n_lanes))) ipw >>= 1;
     }
     auto need = [&](int tier) -> size_t {
-      const size_t static_bytes = gpf::stat_bytes(e->sym_dev.so, tier);
+      const int wpi_n = (nbk == 1 && ipw == 1) ? (e->wpi_override ? std::min(e->wpi_override, 2) : (e->g.n_sub >= 64 ? 2 : 1)) : 1;
+      const size_t static_bytes = gpf::stat_bytes(e->sym_dev.so, tier, nbk == 1, e->sym_dev.fl[gpf::gw_index(64 / ipw * wpi_n)].n_words);
       const bool st = tier > 0;
       const bool dcf = e->dcf != 0;
       return nbk == 1 ? gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, e->sym.nslot_y, static_bytes, st, ipw, -1, dcf)
@@ -378,6 +402,7 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
     if (ipw > 1 && stage != 2) { ipw = 1; stage = 0; for (int tier = 2; tier >= 1 && !stage; --tier) if (need(tier) <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / need(tier) >= want) stage = tier; }
     const size_t l = need(stage);
     if (l > LDS_HARD_LIMIT) return false;
+    if (nbk == 1 && !e->sym_dev.flat[0]) return false;           // no flat program: graph beyond the 16-bit slot fields
     q.sparse_nb = nbk;
     q.ipw = ipw;
     q.minw = 2;
@@ -716,12 +741,14 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
       D.static_connected = roots == 1 ? 1 : 0;
     } D.scale_off = S.scale_off; D.n_scale = S.n_scale; D.n_prog = (int)S.prog.size();
     D.stat_dbl = e->stat_dbl.p; D.stat_int = e->stat_int.p; D.prog = e->stat_int.p + so.prog;
+    if (!upload_flats(S, e->flat_prog, D)) { gpf_destroy(e); return fail(GPF_E_DEVICE, "upload flat programs"); }
   }
   {
     // keep the factored DC matrix in LDS across the steps of a launch when that does not cost residency: the blocks per CU
     // the whole batch needs at once must still fit (GRIDPF_DCF=0|1 overrides)
     const int ipw = e->ipw_override ? e->ipw_override : (g.n_sub <= 8 ? 4 : g.n_sub <= 24 ? 2 : 1);
-    const size_t stat2 = gpf::stat_bytes(e->sym_dev.so, 2);
+    const int wpi0 = e->wpi_override ? std::min(e->wpi_override, 2) : (g.n_sub >= 64 ? 2 : 1);
+    const size_t stat2 = gpf::stat_bytes(e->sym_dev.so, 2, true, e->sym_dev.fl[gpf::gw_index(64 / ipw * (ipw == 1 ? wpi0 : 1))].n_words);
     const size_t with = gpf::lds_bytes_sparse<1>(g, e->sym.nslot, e->sym.nslot_y, stat2, true, ipw, -1, true);
     const size_t n_blocks = ((size_t)n_lanes + ipw - 1) / ipw;
     const size_t want = std::min<size_t>((n_blocks + 255) / 256, 8);
@@ -770,11 +797,12 @@ int gpf_destroy(gpf_handle e) {
   if (e->d_params_s) (void)hipFree(e->d_params_s);
   e->stat_dbl.release();
   e->list_a.release(); e->list_b.release(); e->list_c.release(); e->d_classes.release();
-  for (auto* c : e->classes) { c->tables.release(); delete c; }
+  for (auto* c : e->classes) { c->tables.release(); c->flat.release(); delete c; }
   e->classes.clear();
   e->ptdf_inj_bus.release(); e->ptdf_inj_w.release(); e->ptdf_t.release(); e->ptdf_flow.release();
   e->lodf.release(); e->lodf_worst.release(); e->lodf_inv_cap.release();
   e->stat_int.release();
+  e->flat_prog.release();
   delete e;
   return GPF_OK;
 }

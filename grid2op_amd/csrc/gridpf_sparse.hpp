@@ -58,14 +58,29 @@ __device__ inline void stat_view(StatView<STAGE>& v, const StatOff& o, const dou
   v.sto_sub.p = i + o.sto_sub; v.shunt_sub.p = i + o.shunt_sub; v.pair_rc.p = i + o.pair_rc; v.prog.p = i + o.prog;
   v.node_of.p = nullptr;
 }
-// LDS bytes of the staged part of the blob.  tier 0: nothing; 1: the hot ints (+ the lane's injection row, per instance);
-// 2: everything
-__host__ __device__ inline size_t stat_bytes(const StatOff& o, int tier) {
-  return tier == 2 ? (((size_t)o.n_dbl * 8 + (size_t)o.n_int * 4 + 15) & ~(size_t)15) : tier == 1 ? (((size_t)o.n_int_hot * 4 + 15) & ~(size_t)15) : 0;
+// LDS bytes of the staged part of the static data.  Single-busbar kernels (nb1; the old level-header program at the head of the
+// int section is not theirs): tier 1 = pair_rc + the flat program of the kernel's group width (n_flat ints), tier 2 = doubles +
+// every int table from pair_rc on + the flat program.  NB > 1 kernels: tier 1 = the hot prefix of the int section
+// (level-header program + pair_rc).  tier 0: nothing.
+__host__ __device__ inline size_t stat_bytes(const StatOff& o, int tier, bool nb1, int n_flat) {
+  if (tier == 0) return 0;
+  if (!nb1) return ((size_t)o.n_int_hot * 4 + 15) & ~(size_t)15;
+  const size_t ints = (size_t)((tier == 2 ? o.n_int : o.n_int_hot) - o.pair_rc) + (size_t)n_flat;
+  return ((tier == 2 ? (size_t)o.n_dbl * 8 : 0) + ints * 4 + 15) & ~(size_t)15;
 }
+
+// Device view of a FlatProg (gridpf_symbolic.hpp): pass counts and section offsets (ints) of ONE group-width variant.
+struct FlatDev {
+  int n_fwd, n_scale, n_scale_rhs, n_back, scale_off, back_off, rhs_field0, n_words;
+};
+// group width (threads per instance) -> index of its flat-program variant: 16, 32, 64, 128 -> 0 .. 3
+__host__ __device__ constexpr int gw_index(int gw) { return gw >= 128 ? 3 : gw >= 64 ? 2 : gw >= 32 ? 1 : 0; }
 
 struct SymDev {
   int n, nslot, nslot_y, n_levels, back_off, n_prog, scale_off, n_scale;
+  int rslot0;               // first right-hand-side pseudo-slot of the single-busbar block array (Symbolic::rslot0)
+  const int* flat[4];       // flat programs of the single-busbar kernels, one per group width (gw_index), global memory
+  FlatDev fl[4];
   int n_fwd;                // levels the 2x2 / scalar forward sweeps visit: the trailing levels without any update item (the last
                             // pivot never has one) are skipped -- each would cost a whole barrier-delimited phase per solve
   int back_first;           // highest level that has U entries (back substitution starts there)
@@ -153,14 +168,15 @@ struct CarveP {
   static constexpr int BS = 2 * NB;
   double* A;      // [nslot][BS*BS] row-major blocks
   double* Yb;     // [nslot_y][NB*NB][2]
-  double* rhs;    // [n_sub][BS]
-  double *vm, *va, *e, *f, *Psp, *Qsp, *Sre, *Sim;   // [nbus]
+  double* rhs;    // NB > 1: [n_sub][BS].  NB == 1: the right-hand side is pseudo-slot rslot0 + p of A (rows (b0, Re S), (b1, Im S))
+  double *vm, *va, *e, *f, *Psp, *Qsp;   // [nbus]
+  double *Sre, *Sim;                     // NB > 1: [nbus] bus injections S; NB == 1: the second column of the pseudo-slots
   double* Gs;     // [nbus] aliases e (shunt conductance: only needed before the Newton loop and by the DC results)
   double* inj;    // [n_inj] staged injection row (only when STAGE; otherwise the lane's row in HBM/L2 is read directly)
   double* Adc;    // [nslot] factored scalar DC matrix kept across the solves of a launch (only when the plan says so, NB == 1)
   int* btype;     // [nbus]
   int* vidx;      // [nbus] last in-service generator of a bus (voltage set-point), -1: none; kept across the solves of a launch
-  int* lab;       // [nbus] aliases Sre (connectivity labels: dead before the Newton loop)
+  int* lab;       // [nbus] aliases f (connectivity labels: dead before the Newton loop)
   int* topo;      // alias of A during K1
   i16 *lor_b, *lex_b, *gen_b, *load_b, *sto_b, *sh_b;
   i8* sub_bb;     // [n_sub] live busbar (local id) of each substation (NB == 1)
@@ -172,10 +188,14 @@ __host__ __device__ inline size_t lds_bytes_instance(const GridDev& g, int nslot
   constexpr int BS = 2 * NB;
   const size_t rows = n_rows > 0 ? (size_t)n_rows : (size_t)g.n_sub;      // block rows: substations, or nodes of a topology class
   const size_t nbus = rows * NB;
-  size_t a_d = (size_t)nslot * BS * BS;
+  // NB == 1: the block array also holds the right-hand side and the bus injections S as `rows` pseudo-slots behind slot
+  // rslot0 = max(nslot, ceil(1.5 rows)) (Symbolic::rslot0; the K6 scratch at the head of the array stays below them)
+  const size_t rs0 = (size_t)nslot > (3 * rows + 1) / 2 ? (size_t)nslot : (3 * rows + 1) / 2;
+  size_t a_d = NB == 1 ? (rs0 + rows) * 4 : (size_t)nslot * BS * BS;
   const size_t topo_d = (((size_t)g.dim_topo + 1) / 2 + 2) & ~(size_t)1;
   if (a_d < topo_d) a_d = topo_d;
-  const size_t nd = a_d + (size_t)nslot_y * NB * NB * 2 + rows * BS + 8 * nbus + (stage_inj ? (size_t)g.n_inj : 0) + (dcf ? (size_t)nslot : 0);
+  const size_t nd = a_d + (size_t)nslot_y * NB * NB * 2 + (NB == 1 ? 6 * nbus : rows * BS + 8 * nbus) + (stage_inj ? (size_t)g.n_inj : 0) +
+                    (dcf ? (size_t)nslot : 0);
   const size_t ni = 2 * nbus;
   const size_t n16 = 2 * (size_t)g.n_line + g.n_gen + g.n_load + g.n_sto + g.n_shunt;
   return (nd * 8 + ni * 4 + n16 * 2 + g.n_sub + 15) & ~(size_t)15;
@@ -187,26 +207,33 @@ __host__ __device__ inline size_t lds_bytes_sparse(const GridDev& g, int nslot, 
   return (size_t)ipw * lds_bytes_instance<NB>(g, nslot, nslot_y, stage_inj, n_rows, dcf) + static_bytes;
 }
 
-// Stage the static blob in LDS (STAGE) or view it in place; visible to the block after the first barrier.
-template <int STAGE>
-__device__ inline void make_stat_view(StatView<STAGE>& sv, const SymDev& S, unsigned char* lds_static) {
+// Stage the static data in LDS (STAGE, see stat_bytes) or view it in place; visible to the block after the first barrier.
+// NB1: single-busbar kernel -- its program is the flat program `flat` (n_flat ints, global memory) of the kernel's group width.
+template <int STAGE, bool NB1>
+__device__ inline void make_stat_view(StatView<STAGE>& sv, const SymDev& S, unsigned char* lds_static, const int* flat, int n_flat) {
   const auto gd = gptr(S.stat_dbl);
   const auto gi = gptr(S.stat_int);
-  if (STAGE == 2) {
-    double* sd = reinterpret_cast<double*>(lds_static);
-    int* si = reinterpret_cast<int*>(sd + S.so.n_dbl);
-    for (int i = threadIdx.x; i < S.so.n_dbl; i += blockDim.x) sd[i] = gd[i];
-    for (int i = threadIdx.x; i < S.so.n_int; i += blockDim.x) si[i] = gi[i];
-    stat_view(sv, S.so, sd, si);
-  } else {
-    stat_view(sv, S.so, S.stat_dbl, S.stat_int);
-    if (STAGE == 1) {
-      int* si = reinterpret_cast<int*>(lds_static);
-      for (int i = threadIdx.x; i < S.so.n_int_hot; i += blockDim.x) si[i] = gi[i];
-      sv.prog.p = si + S.so.prog;
-      sv.pair_rc.p = si + S.so.pair_rc;
-    }
+  stat_view(sv, S.so, S.stat_dbl, S.stat_int);
+  if (NB1) sv.prog.p = flat;
+  if (STAGE == 0) return;
+  if (!NB1) {                                                     // tier 1 of the NB > 1 kernels: [level-header program][pair_rc]
+    int* si = reinterpret_cast<int*>(lds_static);
+    for (int i = threadIdx.x; i < S.so.n_int_hot; i += blockDim.x) si[i] = gi[i];
+    sv.prog.p = si + S.so.prog;
+    sv.pair_rc.p = si + S.so.pair_rc;
+    return;
   }
+  double* sd = reinterpret_cast<double*>(lds_static);
+  int* si = reinterpret_cast<int*>(STAGE == 2 ? sd + S.so.n_dbl : sd);
+  const int i0 = S.so.pair_rc, i1 = STAGE == 2 ? S.so.n_int : S.so.n_int_hot;       // int tables [pair_rc .. )
+  if (STAGE == 2) for (int i = threadIdx.x; i < S.so.n_dbl; i += blockDim.x) sd[i] = gd[i];
+  for (int i = threadIdx.x; i < i1 - i0; i += blockDim.x) si[i] = gi[i0 + i];
+  int* sp = si + (i1 - i0);
+  const auto gf = gptr(flat);
+  for (int i = threadIdx.x; i < n_flat; i += blockDim.x) sp[i] = gf[i];
+  if (STAGE == 2) stat_view(sv, S.so, sd, si - i0);
+  sv.pair_rc.p = si;
+  sv.prog.p = sp;
 }
 
 template <int NB>
@@ -216,16 +243,17 @@ __device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const Gr
   const size_t rows = n_rows > 0 ? (size_t)n_rows : (size_t)g.n_sub;
   const size_t nbus = rows * NB;
   double* d = reinterpret_cast<double*>(base);
-  size_t a_d = (size_t)nslot * BS * BS;
+  const size_t rs0 = (size_t)nslot > (3 * rows + 1) / 2 ? (size_t)nslot : (3 * rows + 1) / 2;
+  size_t a_d = NB == 1 ? (rs0 + rows) * 4 : (size_t)nslot * BS * BS;
   const size_t topo_d = (((size_t)g.dim_topo + 1) / 2 + 2) & ~(size_t)1;
   if (a_d < topo_d) a_d = topo_d;
   c.A = d; c.topo = reinterpret_cast<int*>(d); d += a_d;
   c.Yb = d; d += (size_t)nslot_y * NB * NB * 2;
-  c.rhs = d; d += rows * BS;
-  c.vm = d; d += nbus; c.va = d; d += nbus; c.e = d; c.Gs = d; d += nbus; c.f = d; d += nbus;
+  c.rhs = d; if (NB > 1) d += rows * BS;
+  c.vm = d; d += nbus; c.va = d; d += nbus; c.e = d; c.Gs = d; d += nbus; c.f = d; c.lab = reinterpret_cast<int*>(d); d += nbus;
   c.Psp = d; d += nbus; c.Qsp = d; d += nbus;
-  c.Sre = d; c.lab = reinterpret_cast<int*>(d); d += nbus;
-  c.Sim = d; d += nbus;
+  c.Sre = d; if (NB > 1) d += nbus;
+  c.Sim = d; if (NB > 1) d += nbus;
   c.inj = d; if (stage_inj) d += g.n_inj;
   c.Adc = d; if (dcf) d += nslot;
   int* i = reinterpret_cast<int*>(d);
@@ -355,9 +383,9 @@ __device__ __forceinline__ bool block_inverse(const double (&D)[BS * BS], double
   return ok;
 }
 
-// Level-scheduled block-sparse LU + solve, in place in LDS.  A: [nslot][BS*BS] blocks; rhs: [n][BS] right-hand
-// side -> solution.  All pivots of a level are eliminated concurrently; trailing updates that hit the same block
-// are combined with LDS f64 atomics.
+// Level-scheduled block-sparse LU + solve, in place in LDS, for the NB > 1 kernels (blocks of 4x4 / 6x6; the single-busbar
+// kernels run block_lu_flat below).  A: [nslot][BS*BS] blocks; rhs: [n][BS] right-hand side -> solution.  All pivots of a
+// level are eliminated concurrently; trailing updates that hit the same block are combined with LDS f64 atomics.
 template <int BS, int GW = WAVE, class PP = const int*>
 __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restrict__ A,
                                       double* __restrict__ rhs, int tid, long long* dbg = nullptr) {
@@ -368,90 +396,6 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
   constexpr int CHB = (GW / B2) * B2;      // U-block items per chunk: whole blocks only
   constexpr int CHR = (GW / BS) * BS;
   bool ok = true;
-  // 2x2 blocks are stored SPLIT BY ROW: row 0 of every block in [0, HS_), row 1 of every block behind.  A b128 read of one
-  // row of 8 different blocks then spans 8 distinct bank groups instead of 4 (blocks of 32 contiguous bytes put every
-  // row-0 read on the even 16-byte positions): -13 % on the case14 solve, measured with tools/lu_bench.
-  const size_t HS_ = (size_t)S.nslot * 2;
-  if (BS == 2) {
-    // 2x2 blocks: ONE phase per level.  The pivot inverse is recomputed by every item from the (never overwritten)
-    // diagonal block, A[dst] -= A[l] * inv(D_p) * A[u] and rhs[row] -= A[l] * inv(D_p) * b_p; the scaling
-    // U' = inv(D) * A_u, b' = inv(D) * b needed by the back substitution is deferred to one fully parallel pass.
-    // Every level is one barrier-delimited phase whose latency is a chain of dependent LDS round trips, so the chain is
-    // kept as short as possible: trailing updates (c) and right-hand-side updates (r) are ONE item list (r-items follow the
-    // c-items in the program), and the level header / the first item words of the NEXT levels are prefetched while the
-    // current level computes.  Per level: operand reads -> ~10 dependent f64 ops -> ds_add_f64 -> barrier.
-    const int n_levels = S.n_fwd;
-#define R0_(slot) (A + (size_t)(slot) * 2)
-#define R1_(slot) (A + HS_ + (size_t)(slot) * 2)
-#define LD2_(ptr) (*reinterpret_cast<const double2*>(ptr))
-    auto hdr4 = [&](int k) -> int4 { return make_int4(prog[4 * k], prog[4 * k + 1], prog[4 * k + 2], prog[4 * k + 3]); };   // level lv: hdr4(2 * lv + 1) = {c_off, n_c, r_off, n_r}
-    auto item_words = [&](const int4& h, int o, unsigned& w0, unsigned& w1) {
-      const bool on = o < h.y + h.w;
-      const int at = h.x + 2 * (on ? o : 0);
-      w0 = (unsigned)prog[at]; w1 = (unsigned)prog[at + 1];
-    };
-    auto do_item = [&](const int4& h, int o, unsigned w0, unsigned w1) {
-      if (o >= h.y + h.w) return;
-      const bool is_c = o < h.y;
-      const unsigned l = is_c ? (w0 >> 16) : (w0 & 0xffffu), dd = is_c ? (w0 & 0xffffu) : (w0 >> 16);
-      const unsigned p = is_c ? (w1 >> 16) : w1, u = w1 & 0xffffu;
-      const double2 dA = LD2_(R0_(p)), dB = LD2_(R1_(p)), lA = LD2_(R0_(l)), lB = LD2_(R1_(l));
-      const double2 uA = is_c ? LD2_(R0_(u)) : LD2_(rhs + (size_t)p * 2);
-      double2 uB = make_double2(uA.y, 0.0);                       // r-item: the operand is the column vector b_p
-      if (is_c) uB = LD2_(R1_(u));
-      const double rd = -fast_rcp(fma(dA.x, dB.y, -dA.y * dB.x));
-      // T = A_l * adj(D)
-      const double t00 = fma(lA.x, dB.y, -lA.y * dB.x), t01 = fma(lA.y, dA.x, -lA.x * dA.y);
-      const double t10 = fma(lB.x, dB.y, -lB.y * dB.x), t11 = fma(lB.y, dA.x, -lB.x * dA.y);
-      const double x0 = fma(t00, uA.x, t01 * uB.x) * rd, x1 = fma(t10, uA.x, t11 * uB.x) * rd;
-      if (is_c) {
-        double* d0_ = R0_(dd);
-        double* d1_ = R1_(dd);
-        atomicAdd(&d0_[0], x0);
-        atomicAdd(&d1_[0], x1);
-        atomicAdd(&d0_[1], fma(t00, uA.y, t01 * uB.y) * rd);
-        atomicAdd(&d1_[1], fma(t10, uA.y, t11 * uB.y) * rd);
-      } else {
-        double* dst = rhs + (size_t)dd * 2;
-        atomicAdd(&dst[0], x0);
-        atomicAdd(&dst[1], x1);
-      }
-    };
-    int4 h0 = hdr4(1), h1 = n_levels > 1 ? hdr4(3) : make_int4(0, 0, 0, 0);
-    unsigned w0, w1;
-    item_words(h0, tid, w0, w1);
-    for (int lv = 0; lv < n_levels; ++lv) {
-      const int4 h2 = lv + 2 < n_levels ? hdr4(2 * (lv + 2) + 1) : make_int4(0, 0, 0, 0);
-      unsigned nw0, nw1;
-      item_words(h1, tid, nw0, nw1);                               // first-pass words of the next level
-      do_item(h0, tid, w0, w1);
-      for (int o = tid + GW; o < h0.y + h0.w; o += GW) {
-        unsigned v0, v1;
-        item_words(h0, o, v0, v1);
-        do_item(h0, o, v0, v1);
-      }
-      GPF_LSYNC();
-      h0 = h1; h1 = h2; w0 = nw0; w1 = nw1;
-    }
-    // deferred scaling (one item per U block / per pivot: no read-write overlap between items)
-    for (int e = tid; e < S.n_scale; e += GW) {
-      const unsigned w = (unsigned)prog[S.scale_off + e];
-      const double2 dA = LD2_(R0_(w >> 16)), dB = LD2_(R1_(w >> 16)), uA = LD2_(R0_(w & 0xffffu)), uB = LD2_(R1_(w & 0xffffu));
-      const double rd = fast_rcp(fma(dA.x, dB.y, -dA.y * dB.x));
-      *reinterpret_cast<double2*>(R0_(w & 0xffffu)) = make_double2(fma(dB.y, uA.x, -dA.y * uB.x) * rd, fma(dB.y, uA.y, -dA.y * uB.y) * rd);
-      *reinterpret_cast<double2*>(R1_(w & 0xffffu)) = make_double2(fma(dA.x, uB.x, -dB.x * uA.x) * rd, fma(dA.x, uB.y, -dB.x * uA.y) * rd);
-    }
-    for (int p = tid; p < S.n; p += GW) {
-      const double2 dA_ = LD2_(R0_(p)), dB_ = LD2_(R1_(p));
-      const double d0 = dA_.x, d1 = dA_.y, d2 = dB_.x, d3 = dB_.y, b0 = rhs[(size_t)p * 2], b1 = rhs[(size_t)p * 2 + 1];
-      const double det = fma(d0, d3, -d1 * d2);
-      if (!(fabs(det) > 1e-300) || !(fabs(det) < 1e300)) ok = false;
-      const double rd = fast_rcp(det);
-      rhs[(size_t)p * 2] = fma(d3, b0, -d1 * b1) * rd;
-      rhs[(size_t)p * 2 + 1] = fma(d0, b1, -d2 * b0) * rd;
-    }
-    GPF_LSYNC();
-  } else
   for (int lv = 0; lv < S.n_levels; ++lv) {
     const int piv_off = prog[8 * lv], n_piv = prog[8 * lv + 1], b_off = prog[8 * lv + 2], n_b = prog[8 * lv + 3], c_off = prog[8 * lv + 4],
               n_c = prog[8 * lv + 5], r_off = prog[8 * lv + 6], n_r = prog[8 * lv + 7];
@@ -561,37 +505,6 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
   // back substitution, levels in reverse: x_p = b'_p - sum_j U'_pj x_j.  Pivots of a level are independent and only
   // depend on later levels, so every (pivot, U entry, row) item of a level runs in parallel and accumulates with
   // ds_add_f64.
-  if (BS == 2) {
-    // one item per U entry (both rows); level table entry / first item words of the next levels are prefetched as in the
-    // forward sweep; levels above back_first have no U entries (the last level never has) and are skipped
-    auto hdr = [&](int lv) -> int2 { return lv >= 0 ? make_int2(prog[S.back_off + 2 * lv], prog[S.back_off + 2 * lv + 1]) : make_int2(0, 0); };
-    auto words = [&](const int2& h, int o, unsigned& w, int& p) {
-      const int at = h.x + 2 * (o < h.y ? o : 0);
-      w = (unsigned)prog[at]; p = prog[at + 1];
-    };
-    auto item = [&](const int2& h, int o, unsigned w, int p) {
-      if (o >= h.y) return;
-      const double2 uA = LD2_(R0_(w & 0xffffu)), uB = LD2_(R1_(w & 0xffffu)), xj = LD2_(rhs + (size_t)(w >> 16) * 2);
-      atomicAdd(&rhs[(size_t)p * 2], -fma(uA.x, xj.x, uA.y * xj.y));
-      atomicAdd(&rhs[(size_t)p * 2 + 1], -fma(uB.x, xj.x, uB.y * xj.y));
-    };
-    int2 h0 = hdr(S.back_first), h1 = hdr(S.back_first - 1);
-    unsigned w; int p;
-    words(h0, tid, w, p);
-    for (int lv = S.back_first; lv >= 0; --lv) {
-      const int2 h2 = hdr(lv - 2);
-      unsigned nw; int np;
-      words(h1, tid, nw, np);
-      item(h0, tid, w, p);
-      for (int o = tid + GW; o < h0.y; o += GW) {
-        unsigned v; int q;
-        words(h0, o, v, q);
-        item(h0, o, v, q);
-      }
-      GPF_LSYNC();
-      h0 = h1; h1 = h2; w = nw; p = np;
-    }
-  } else
   for (int lv = S.n_levels - 1; lv >= 0; --lv) {
     const int ent_off = prog[S.back_off + 2 * lv], n_ent = prog[S.back_off + 2 * lv + 1];
     for (int it = tid; it < n_ent * BS; it += GW) {
@@ -612,92 +525,80 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
   return ok;
 }
 
-// Scalar variant for the DC system of the NB == 1 layout: B' theta = P only couples the theta entries, i.e. element [0][0] of
-// every 2x2 block (A[2 * slot] in the split-row layout of block_lu_solve, STRIDE = 2) and rhs[2p] (the |V| rows are identity),
-// so the same program is run on scalars: a quarter of the LDS traffic and a fraction of the arithmetic of the block solve.
-// FACTOR = false: A already holds the FACTORED matrix of an earlier solve with the same topology (L and D as left by the
-// forward sweep, U scaled by the deferred pass -- the forward sweep never reads U', the back substitution never reads L), so only
-// the right-hand-side items, the pivot scaling and the back substitution run (STRIDE = 1: the compact copy CarveP::Adc).
-template <int GW, int STRIDE, bool FACTOR, class PP = const int*>
-__device__ inline bool scalar_lu_solve(const SymDev& S, PP prog, double* __restrict__ A,
-                                       double* __restrict__ rhs, int tid, long long* dbg = nullptr) {
+// ---- flat-program sweeps (gridpf_symbolic.hpp: FlatProg) -------------------------------------------------------------------
+// Block LU + solve with 2x2 blocks on the flat program.  A: row 0 of every (pseudo-)slot at A + slot * 2, row 1 at
+// A + HS + slot * 2 (HS = (rslot0 + n) * 2 doubles); the right-hand side lives in the pseudo-slots and holds the solution on
+// return.  Same arithmetic, item by item, as the level-header version it replaces (block_lu_solve, BS == 2): the pivot inverse
+// is recomputed by every item from the never-overwritten diagonal block, the scaling U' = inv(D) U, b' = inv(D) b is deferred
+// to one parallel pass, the back substitution accumulates with ds_add_f64.  What changed is the instruction count of a phase:
+// no level headers, no bounds / clamps, no "trailing update or right-hand side?" selects, byte offsets instead of slot indices.
+template <int GW, class PP = const int*>
+__device__ inline bool block_lu_flat(const FlatDev& F, PP prog, double* __restrict__ A, size_t HS, int tid, long long* dbg = nullptr) {
 #ifdef GPF_TIMING
   const long long t_lu0 = __builtin_readcyclecounter();
 #endif
   bool ok = true;
-  const int n_levels = S.n_fwd;
-  auto hdr4 = [&](int k) -> int4 { return make_int4(prog[4 * k], prog[4 * k + 1], prog[4 * k + 2], prog[4 * k + 3]); };
-  auto first = [&](const int4& h) -> int { return FACTOR ? 0 : h.y; };       // r-items follow the c-items
-  auto item_words = [&](const int4& h, int o, unsigned& w0, unsigned& w1) {
-    const int at = h.x + 2 * (o < h.y + h.w ? o : 0);
-    w0 = (unsigned)prog[at]; w1 = (unsigned)prog[at + 1];
-  };
-  auto do_item = [&](const int4& h, int o, unsigned w0, unsigned w1) {
-    if (o >= h.y + h.w) return;
-    const bool is_c = FACTOR && o < h.y;
-    const unsigned l = is_c ? (w0 >> 16) : (w0 & 0xffffu), dd = is_c ? (w0 & 0xffffu) : (w0 >> 16);
-    const unsigned p = is_c ? (w1 >> 16) : w1, u = w1 & 0xffffu;
-    const double d = A[(size_t)p * STRIDE], al = A[(size_t)l * STRIDE];
-    const double x = is_c ? A[(size_t)u * STRIDE] : rhs[(size_t)p * 2];
-    double* dst = is_c ? (A + (size_t)dd * STRIDE) : (rhs + (size_t)dd * 2);
-    atomicAdd(dst, -(al * x) * fast_rcp(d));
-  };
-  int4 h0 = hdr4(1), h1 = n_levels > 1 ? hdr4(3) : make_int4(0, 0, 0, 0);
-  unsigned w0, w1;
-  item_words(h0, first(h0) + tid, w0, w1);
-  for (int lv = 0; lv < n_levels; ++lv) {
-    const int4 h2 = lv + 2 < n_levels ? hdr4(2 * (lv + 2) + 1) : make_int4(0, 0, 0, 0);
-    unsigned nw0, nw1;
-    item_words(h1, first(h1) + tid, nw0, nw1);
-    do_item(h0, first(h0) + tid, w0, w1);
-    for (int o = first(h0) + tid + GW; o < h0.y + h0.w; o += GW) {
-      unsigned v0, v1;
-      item_words(h0, o, v0, v1);
-      do_item(h0, o, v0, v1);
+  char* const a0 = reinterpret_cast<char*>(A);
+  char* const a1 = a0 + HS * 8;
+#define FL_LD2(base, f) (*reinterpret_cast<const double2*>((base) + (f)))
+#define FL_D(base, f) (reinterpret_cast<double*>((base) + (f)))
+  {
+    int at = 2 * tid;
+    unsigned w0 = (unsigned)prog[at], w1 = (unsigned)prog[at + 1];
+    for (int k = 0; k < F.n_fwd; ++k) {
+      at += 2 * GW;
+      const unsigned n0 = (unsigned)prog[at], n1 = (unsigned)prog[at + 1];     // words of the next pass
+      if (w0 != 0xffffffffu) {
+        const unsigned fd = w0 & 0xffffu, fl = w0 >> 16, fu = w1 & 0xffffu, fp = w1 >> 16;
+        const double2 dA = FL_LD2(a0, fp), dB = FL_LD2(a1, fp), lA = FL_LD2(a0, fl), lB = FL_LD2(a1, fl);
+        const double2 uA = FL_LD2(a0, fu), uB = FL_LD2(a1, fu);
+        const double rd = -fast_rcp(fma(dA.x, dB.y, -dA.y * dB.x));
+        // T = A_l * adj(D)
+        const double t00 = fma(lA.x, dB.y, -lA.y * dB.x), t01 = fma(lA.y, dA.x, -lA.x * dA.y);
+        const double t10 = fma(lB.x, dB.y, -lB.y * dB.x), t11 = fma(lB.y, dA.x, -lB.x * dA.y);
+        double* d0_ = FL_D(a0, fd);
+        double* d1_ = FL_D(a1, fd);
+        atomicAdd(&d0_[0], fma(t00, uA.x, t01 * uB.x) * rd);
+        atomicAdd(&d1_[0], fma(t10, uA.x, t11 * uB.x) * rd);
+        atomicAdd(&d0_[1], fma(t00, uA.y, t01 * uB.y) * rd);
+        atomicAdd(&d1_[1], fma(t10, uA.y, t11 * uB.y) * rd);
+      }
+      GPF_LSYNC();
+      w0 = n0; w1 = n1;
     }
-    if (FACTOR || h0.w > 0) GPF_LSYNC();               // (h0 is uniform over the block)
-    h0 = h1; h1 = h2; w0 = nw0; w1 = nw1;
   }
-  if (FACTOR)
-  for (int e = tid; e < S.n_scale; e += GW) {
-    const unsigned w = (unsigned)prog[S.scale_off + e];
-    double* au = A + (size_t)(w & 0xffffu) * STRIDE;
-    *au = *au * fast_rcp(A[(size_t)(w >> 16) * STRIDE]);
-  }
-  for (int p = tid; p < S.n; p += GW) {
-    const double d = A[(size_t)p * STRIDE];
-    if (FACTOR && (!(fabs(d) > 1e-300) || !(fabs(d) < 1e300))) ok = false;
-    rhs[(size_t)p * 2] *= fast_rcp(d);
+  // deferred scaling U' = inv(D) U and b' = inv(D) b (one item per block: no read-write overlap between items)
+  for (int k = 0; k < F.n_scale; ++k) {
+    const unsigned w = (unsigned)prog[F.scale_off + k * GW + tid];
+    if (w == 0xffffffffu) continue;
+    const unsigned fu = w & 0xffffu, fp = w >> 16;
+    const double2 dA = FL_LD2(a0, fp), dB = FL_LD2(a1, fp), uA = FL_LD2(a0, fu), uB = FL_LD2(a1, fu);
+    const double det = fma(dA.x, dB.y, -dA.y * dB.x);
+    if ((int)fu >= F.rhs_field0 && (!(fabs(det) > 1e-300) || !(fabs(det) < 1e300))) ok = false;
+    const double rd = fast_rcp(det);
+    *reinterpret_cast<double2*>(a0 + fu) = make_double2(fma(dB.y, uA.x, -dA.y * uB.x) * rd, fma(dB.y, uA.y, -dA.y * uB.y) * rd);
+    *reinterpret_cast<double2*>(a1 + fu) = make_double2(fma(dA.x, uB.x, -dB.x * uA.x) * rd, fma(dA.x, uB.y, -dB.x * uA.y) * rd);
   }
   GPF_LSYNC();
 #ifdef GPF_TIMING
   const long long t_lu1 = __builtin_readcyclecounter();
 #endif
+  // back substitution: x_p -= U'_pj x_j, levels in reverse, every entry of a level concurrently
   {
-    auto hdr = [&](int lv) -> int2 { return lv >= 0 ? make_int2(prog[S.back_off + 2 * lv], prog[S.back_off + 2 * lv + 1]) : make_int2(0, 0); };
-    auto words = [&](const int2& h, int o, unsigned& w, int& p) {
-      const int at = h.x + 2 * (o < h.y ? o : 0);
-      w = (unsigned)prog[at]; p = prog[at + 1];
-    };
-    auto item = [&](const int2& h, int o, unsigned w, int p) {
-      if (o >= h.y) return;
-      atomicAdd(&rhs[(size_t)p * 2], -A[(size_t)(w & 0xffffu) * STRIDE] * rhs[(size_t)(w >> 16) * 2]);
-    };
-    int2 g0 = hdr(S.back_first), g1 = hdr(S.back_first - 1);
-    unsigned w; int p;
-    words(g0, tid, w, p);
-    for (int lv = S.back_first; lv >= 0; --lv) {
-      const int2 g2 = hdr(lv - 2);
-      unsigned nw; int np;
-      words(g1, tid, nw, np);
-      item(g0, tid, w, p);
-      for (int o = tid + GW; o < g0.y; o += GW) {
-        unsigned v; int q;
-        words(g0, o, v, q);
-        item(g0, o, v, q);
+    int at = F.back_off + 2 * tid;
+    unsigned w0 = (unsigned)prog[at], w1 = (unsigned)prog[at + 1];
+    for (int k = 0; k < F.n_back; ++k) {
+      at += 2 * GW;
+      const unsigned n0 = (unsigned)prog[at], n1 = (unsigned)prog[at + 1];
+      if (w0 != 0xffffffffu) {
+        const unsigned fu = w0 & 0xffffu, fj = w0 >> 16;
+        const double2 uA = FL_LD2(a0, fu), uB = FL_LD2(a1, fu);
+        const double x0 = *FL_D(a0, fj), x1 = *FL_D(a1, fj);
+        atomicAdd(FL_D(a0, w1), -fma(uA.x, x0, uA.y * x1));
+        atomicAdd(FL_D(a1, w1), -fma(uB.x, x0, uB.y * x1));
       }
       GPF_LSYNC();
-      g0 = g1; g1 = g2; w = nw; p = np;
+      w0 = n0; w1 = n1;
     }
   }
 #ifdef GPF_TIMING
@@ -705,6 +606,75 @@ __device__ inline bool scalar_lu_solve(const SymDev& S, PP prog, double* __restr
 #endif
   return ok;
 }
+
+// Scalar variant for the DC system of the single-busbar layout: B' theta = P only couples element [0][0] of every block and the
+// first entry of every right-hand-side pseudo-slot (the |V| rows are identity), so the same flat program runs on scalars.
+// FACTOR = false: `fac` holds the FACTORED matrix of an earlier solve with the same topology (L and D as left by the forward
+// sweep, U scaled), COMPACT: as one double per slot (CarveP::Adc) instead of element [0][0] of the row-0 half; only the
+// right-hand-side items, the pivot scaling of the right-hand side and the back substitution run.
+template <int GW, bool FACTOR, bool COMPACT, class PP = const int*>
+__device__ inline bool scalar_lu_flat(const FlatDev& F, PP prog, double* __restrict__ A, double* __restrict__ fac, int tid,
+                                      long long* dbg = nullptr) {
+#ifdef GPF_TIMING
+  const long long t_lu0 = __builtin_readcyclecounter();
+#endif
+  bool ok = true;
+  char* const a0 = reinterpret_cast<char*>(A);
+  char* const fb = reinterpret_cast<char*>(fac);
+  auto facp = [&](unsigned f) -> double* { return reinterpret_cast<double*>(fb + (COMPACT ? (f >> 1) : f)); };
+  {
+    int at = 2 * tid;
+    unsigned w0 = (unsigned)prog[at], w1 = (unsigned)prog[at + 1];
+    for (int k = 0; k < F.n_fwd; ++k) {
+      at += 2 * GW;
+      const unsigned n0 = (unsigned)prog[at], n1 = (unsigned)prog[at + 1];
+      const unsigned fd = w0 & 0xffffu, fl = w0 >> 16, fu = w1 & 0xffffu, fp = w1 >> 16;
+      const bool is_r = (int)fd >= F.rhs_field0;
+      if (w0 != 0xffffffffu && (FACTOR || is_r)) {
+        const double d = *facp(fp), al = *facp(fl);
+        const double x = is_r ? *FL_D(a0, fu) : *facp(fu);
+        double* dst = is_r ? FL_D(a0, fd) : facp(fd);
+        atomicAdd(dst, -(al * x) * fast_rcp(d));
+      }
+      GPF_LSYNC();
+      w0 = n0; w1 = n1;
+    }
+  }
+  for (int k = 0; k < (FACTOR ? F.n_scale : F.n_scale_rhs); ++k) {
+    const unsigned w = (unsigned)prog[F.scale_off + k * GW + tid];
+    if (w == 0xffffffffu) continue;
+    const unsigned fu = w & 0xffffu, fp = w >> 16;
+    const double d = *facp(fp);
+    if ((int)fu >= F.rhs_field0) {
+      if (FACTOR && (!(fabs(d) > 1e-300) || !(fabs(d) < 1e300))) ok = false;
+      *FL_D(a0, fu) *= fast_rcp(d);
+    } else {
+      double* au = facp(fu);
+      *au = *au * fast_rcp(d);
+    }
+  }
+  GPF_LSYNC();
+#ifdef GPF_TIMING
+  const long long t_lu1 = __builtin_readcyclecounter();
+#endif
+  {
+    int at = F.back_off + 2 * tid;
+    unsigned w0 = (unsigned)prog[at], w1 = (unsigned)prog[at + 1];
+    for (int k = 0; k < F.n_back; ++k) {
+      at += 2 * GW;
+      const unsigned n0 = (unsigned)prog[at], n1 = (unsigned)prog[at + 1];
+      if (w0 != 0xffffffffu) atomicAdd(FL_D(a0, w1), -*facp(w0 & 0xffffu) * *FL_D(a0, w0 >> 16));
+      GPF_LSYNC();
+      w0 = n0; w1 = n1;
+    }
+  }
+#ifdef GPF_TIMING
+  if (dbg) { dbg[0] = t_lu1 - t_lu0; dbg[1] = (long long)__builtin_readcyclecounter() - t_lu1; }
+#endif
+  return ok;
+}
+#undef FL_LD2
+#undef FL_D
 
 // What a solve may take over from the previous solve of the same block (multi-step launches, cascade rounds).
 struct SolveCtl {
@@ -728,7 +698,7 @@ struct TopoState {
 // status of the caller's group.  Groups share the instruction stream: a group that has failed or finished keeps executing
 // (its state is frozen / its results are overwritten by the caller), so barriers stay wave-uniform.
 template <int NB, int STAGE, int IPW, int WPI, bool TC>
-__device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, const SymDev& S, const StatView<STAGE>& sv, CarveP<NB>& c, int inst, int is_dc, int max_iter,
+__device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, const SymDev& S, const FlatDev& FL, const StatView<STAGE>& sv, CarveP<NB>& c, int inst, int is_dc, int max_iter,
                                             double tol_pu, int tid, const SolveCtl& ctl, TopoState& ts, int& n_iter_out, int& nb_out GPF_STAMPS_PARAM) {
   typedef Grp<IPW, WPI> G;
   constexpr int GW = G::GW;
@@ -743,10 +713,16 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   const int nsub = g.n_sub;
   const int nbus = TC ? S.n : nsub * NB;               // block rows x NB: substations, or the nodes of the topology class
   // element (r, col) of block `slot`: 2x2 blocks are stored split by row (see block_lu_solve), larger blocks contiguously
-  const size_t HS = (size_t)S.nslot * 2;
+  const size_t HS = ((size_t)S.rslot0 + S.n) * 2;         // doubles per row half (single-busbar layout: slots + right-hand-side pseudo-slots)
   auto bel = [&](int slot, int r, int col) -> double* {
     return BS == 2 ? c.A + (size_t)r * HS + (size_t)slot * 2 + col : c.A + (size_t)slot * B2 + r * BS + col;
   };
+  // right-hand side / solution (theta, |V| entries) and bus injection S of bus i.  Single-busbar layout: pseudo-slot rslot0 + i of
+  // the block array, rows (b_theta, Re S) and (b_V, Im S); NB > 1: the separate arrays
+  auto rhsT = [&](int i) -> double* { return BS == 2 ? c.A + ((size_t)S.rslot0 + i) * 2 : c.rhs + (size_t)(i / NB) * BS + 2 * (i % NB); };
+  auto rhsV = [&](int i) -> double* { return BS == 2 ? c.A + HS + ((size_t)S.rslot0 + i) * 2 : c.rhs + (size_t)(i / NB) * BS + 2 * (i % NB) + 1; };
+  auto SreP = [&](int i) -> double* { return BS == 2 ? c.A + ((size_t)S.rslot0 + i) * 2 + 1 : c.Sre + i; };
+  auto SimP = [&](int i) -> double* { return BS == 2 ? c.A + HS + ((size_t)S.rslot0 + i) * 2 + 1 : c.Sim + i; };
   const auto topo_g = gptr(b.topo) + (size_t)inst * g.dim_topo;            // lane rows in HBM: explicit global address space
   const auto shb = gptr(b.shunt_bus) + (size_t)inst * g.n_shunt;
   const auto lstat = gptr(b.line_status) + (size_t)inst * g.n_line;
@@ -971,24 +947,28 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       if (!th_live) *bel(sub, 2 * bi, 2 * bi) = 1.0;
       *bel(sub, 2 * bi + 1, 2 * bi + 1) = 1.0;                   // |V| rows are identity in the DC system
     }
-    c.rhs[(size_t)sub * BS + 2 * bi] = th_live ? (c.Psp[i] - c.Gs[i]) : 0.0;
-    c.rhs[(size_t)sub * BS + 2 * bi + 1] = 0.0;
+    *rhsT(i) = th_live ? (c.Psp[i] - c.Gs[i]) : 0.0;
+    *rhsV(i) = 0.0;
   }
   GPF_LSYNC();
   }
   GPF_STAMPS(3);
   // the program is in LDS (tier >= 1) or read in place through a global-address-space pointer (tier 0)
   auto lu_ac = [&](long long* dbg) -> bool {
+    if (BS == 2) {
+      if (STAGE >= 1) return block_lu_flat<GW>(FL, sv.prog.p, c.A, HS, tid, dbg);
+      return block_lu_flat<GW>(FL, gptr(sv.prog.p), c.A, HS, tid, dbg);
+    }
     if (STAGE >= 1) return block_lu_solve<BS, GW>(S, sv.prog.p, c.A, c.rhs, tid, dbg);
     return block_lu_solve<BS, GW>(S, gptr(sv.prog.p), c.A, c.rhs, tid, dbg);
   };
-  auto lu_dc = [&](long long* dbg) -> bool {
+  auto lu_dc = [&](long long* dbg) -> bool {       // single-busbar layout only
     if (dc_kept) {
-      if (STAGE >= 1) return scalar_lu_solve<GW, 1, false>(S, sv.prog.p, c.Adc, c.rhs, tid, dbg);
-      return scalar_lu_solve<GW, 1, false>(S, gptr(sv.prog.p), c.Adc, c.rhs, tid, dbg);
+      if (STAGE >= 1) return scalar_lu_flat<GW, false, true>(FL, sv.prog.p, c.A, c.Adc, tid, dbg);
+      return scalar_lu_flat<GW, false, true>(FL, gptr(sv.prog.p), c.A, c.Adc, tid, dbg);
     }
-    if (STAGE >= 1) return scalar_lu_solve<GW, 2, true>(S, sv.prog.p, c.A, c.rhs, tid, dbg);
-    return scalar_lu_solve<GW, 2, true>(S, gptr(sv.prog.p), c.A, c.rhs, tid, dbg);
+    if (STAGE >= 1) return scalar_lu_flat<GW, true, false>(FL, sv.prog.p, c.A, c.A, tid, dbg);
+    return scalar_lu_flat<GW, true, false>(FL, gptr(sv.prog.p), c.A, c.A, tid, dbg);
   };
   if (!warm) {
 #ifdef GPF_TIMING
@@ -999,7 +979,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
 #endif
     for (int i = tid; i < nbus; i += GW) {
       const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
-      const double th = c.rhs[(size_t)sub * BS + 2 * bi];
+      const double th = *rhsT(i);
       const int bt = c.btype[i];
       c.va[i] = (bt == BT_PQ || bt == BT_PV) ? th : 0.0;
       if (bt != BT_OFF && !(fabs(th) < 1e300)) ok = false;
@@ -1026,8 +1006,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       fast_sincos(va, sn_, co);
       c.e[i] = vmi * co;
       c.f[i] = vmi * sn_;
-      c.Sre[i] = 0.0;
-      c.Sim[i] = 0.0;
+      *SreP(i) = 0.0;
+      *SimP(i) = 0.0;
     }
     if (BS == 2) { for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; } }
     else for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;     // fill blocks start at zero
@@ -1054,7 +1034,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         // [dP/dth dP/dV; dQ/dth dQ/dV] = [Im T, Re T/|Vj|; -Re T, Im T/|Vj|]  (diagonal S-terms are added below)
         *reinterpret_cast<double2*>(bel(slot, 2 * bi, 2 * bj)) = make_double2((rowP && colT) ? ti_ : 0.0, (rowP && colV) ? tr_ * ivmj : 0.0);
         *reinterpret_cast<double2*>(bel(slot, 2 * bi + 1, 2 * bj)) = make_double2((rowQ && colT) ? -tr_ : 0.0, (rowQ && colV) ? ti_ * ivmj : 0.0);
-        if (act && (yr != 0.0 || yi != 0.0)) { atomicAdd(&c.Sre[i], tr_); atomicAdd(&c.Sim[i], ti_); }
+        if (act && (yr != 0.0 || yi != 0.0)) { atomicAdd(SreP(i), tr_); atomicAdd(SimP(i), ti_); }
       }
       GPF_LSYNC();
       if (it == 0) GPF_STAMPS(11);
@@ -1065,7 +1045,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         double* Ad0 = bel(sub, 2 * bi, 2 * bi);
         double* Ad1 = bel(sub, 2 * bi + 1, 2 * bi);
         const int bt = c.btype[i];
-        const double Sr = c.Sre[i], Si = c.Sim[i], vmi = c.vm[i], psp = c.Psp[i], qsp = c.Qsp[i];
+        const double Sr = *SreP(i), Si = *SimP(i), vmi = c.vm[i], psp = c.Psp[i], qsp = c.Qsp[i];
         const double2 r0 = *reinterpret_cast<const double2*>(Ad0), r1 = *reinterpret_cast<const double2*>(Ad1);
         const bool rowP = (bt == BT_PQ || bt == BT_PV), rowQ = (bt == BT_PQ);
         const double ivmi = fast_rcp(vmi);
@@ -1074,7 +1054,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         *reinterpret_cast<double2*>(Ad1) = make_double2(rowQ ? r1.x + Sr : r1.x, rowQ ? fma(Si, ivmi, r1.y) : 1.0);
         const double mp = rowP ? (Sr - psp) : 0.0;
         const double mq = rowQ ? (Si - qsp) : 0.0;
-        *reinterpret_cast<double2*>(c.rhs + (size_t)sub * BS + 2 * bi) = make_double2(-mp, -mq);
+        if (BS == 2) { *rhsT(i) = -mp; *rhsV(i) = -mq; }
+        else *reinterpret_cast<double2*>(c.rhs + (size_t)sub * BS + 2 * bi) = make_double2(-mp, -mq);
         const double am = fmax(fabs(mp), fabs(mq));
         if (!(am <= 1e300)) bad = true;
         fabs_mis = fmax(fabs_mis, am);
@@ -1097,7 +1078,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
         const int bt = c.btype[i];
         double va = c.va[i], vm = c.vm[i];
-        const double2 dx = *reinterpret_cast<const double2*>(c.rhs + (size_t)sub * BS + 2 * bi);
+        const double2 dx = make_double2(*rhsT(i), *rhsV(i));
         if (!done && bt != BT_OFF) {
           if (!(fabs(dx.x) < 1e300) || !(fabs(dx.y) < 1e300)) fin = false;
           if (bt == BT_PQ || bt == BT_PV) va += dx.x;
@@ -1111,8 +1092,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         fast_sincos(va, sn_, co);
         c.e[i] = vm * co;
         c.f[i] = vm * sn_;
-        c.Sre[i] = 0.0;
-        c.Sim[i] = 0.0;
+        *SreP(i) = 0.0;
+        *SimP(i) = 0.0;
       }
       if (BS == 2) { for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; } }
     else for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
@@ -1132,14 +1113,14 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   const double SQRT3 = 1.7320508075688772935;
   GPF_LSYNC();
   if (is_dc) {
-    for (int i = tid; i < nbus; i += GW) { c.Sre[i] = c.Gs[i]; c.Sim[i] = 0.0; }
+    for (int i = tid; i < nbus; i += GW) { *SreP(i) = c.Gs[i]; *SimP(i) = 0.0; }
     GPF_LSYNC();
     for (int l = tid; l < g.n_line; l += GW) {
       const int f = c.lor_b[l], t = c.lex_b[l];
       if (f < 0) continue;
       const double fl = (c.va[f] - c.va[t]) * sv.br_bdc[l];
-      atomicAdd(&c.Sre[f], fl);
-      atomicAdd(&c.Sre[t], -fl);
+      atomicAdd(SreP(f), fl);
+      atomicAdd(SreP(t), -fl);
     }
     GPF_LSYNC();
   }
@@ -1227,7 +1208,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       const int bu = c.gen_b[i];
       float gp = 0.f, gq = 0.f, gv = 0.f, gth = 0.f;
       if (bu >= 0) {
-        const double qtot = (c.Sim[bu] - c.Qsp[bu]) * sn;
+        const double qtot = (*SimP(bu) - c.Qsp[bu]) * sn;
         const int cn = cnt[bu];
         const double mn = sv.gen_min_q[i], mx = sv.gen_max_q[i];
         double q;
@@ -1236,7 +1217,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         else if (qmin_t[bu] == qmax_t[bu]) q = qtot / cn;
         else q = mn + (qtot - qmin_t[bu]) / (qmax_t[bu] - qmin_t[bu] + 2.220446049250313e-16) * (mx - mn);
         double p = GPF_INJ(oo.inj_gen_p + i);
-        if (sv.gen_slack[i]) p = (c.Sre[bu] - c.Psp[bu]) * sn / nsl[bu];
+        if (sv.gen_slack[i]) p = (*SreP(bu) - c.Psp[bu]) * sn / nsl[bu];
         gp = (float)p; gq = (float)q;
         gv = (float)(c.vm[bu] * sv.sub_vn_kv[sv.gen_sub[i]]);
         gth = (float)(c.va[bu] * RAD2DEG);
@@ -1283,17 +1264,23 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   if (TC) S_loc = P->classes[gptr(lane_class)[blockIdx.x * IPW]].sym;                                                            \
   pin_sgpr(S_loc.n); pin_sgpr(S_loc.nslot); pin_sgpr(S_loc.nslot_y); pin_sgpr(S_loc.n_fwd); pin_sgpr(S_loc.back_off);          \
   pin_sgpr(S_loc.scale_off); pin_sgpr(S_loc.n_scale); pin_sgpr(S_loc.back_first); pin_sgpr(S_loc.static_connected);              \
+  pin_sgpr(S_loc.rslot0);                                                                                                        \
   const SymDev& S = S_loc;                                                                                                       \
   const int lds_rows = TC ? P->tc_rows : -1, lds_nslot = TC ? P->tc_nslot : P->sym.nslot,                                        \
             lds_nslot_y = TC ? P->tc_nslot_y : P->sym.nslot_y;                                                                   \
   const bool lds_dcf = !TC && P->dcf != 0;                                                                                       \
   const size_t per_inst = lds_bytes_instance<NB>(G_, lds_nslot, lds_nslot_y, STAGE != 0, lds_rows, lds_dcf);                     \
   carve_sparse<NB>(c, smem + (size_t)grp * per_inst, G_, lds_nslot, lds_nslot_y, STAGE != 0, lds_rows, lds_dcf);                 \
+  constexpr int GWI = gw_index(Grp<IPW, WPI>::GW);                                                                               \
+  FlatDev F_loc = S_loc.fl[GWI];                                                                                                 \
+  pin_sgpr(F_loc.n_fwd); pin_sgpr(F_loc.n_scale); pin_sgpr(F_loc.n_scale_rhs); pin_sgpr(F_loc.n_back); pin_sgpr(F_loc.scale_off); \
+  pin_sgpr(F_loc.back_off); pin_sgpr(F_loc.rhs_field0);                                                                          \
+  const FlatDev& FL = F_loc;                                                                                                     \
   StatView<STAGE> sv;                                                                                                            \
-  make_stat_view<STAGE>(sv, P->sym, smem + (size_t)IPW * per_inst);                                                              \
+  make_stat_view<STAGE, NB == 1>(sv, P->sym, smem + (size_t)IPW * per_inst, S_loc.flat[GWI], F_loc.n_words);                     \
   if (TC) {                                                                                                                      \
     const TopoClassDev& tc_ = P->classes[gptr(lane_class)[blockIdx.x * IPW]];                                              \
-    sv.prog.p = tc_.sym.prog; sv.pair_rc.p = tc_.pair_rc; sv.br_slot.p = tc_.br_slot; sv.node_of.p = tc_.node_of;                \
+    sv.pair_rc.p = tc_.pair_rc; sv.br_slot.p = tc_.br_slot; sv.node_of.p = tc_.node_of;                                          \
   }
 
 template <int NB, int STAGE, int IPW, int MINW, int WPI, bool TC = false>
@@ -1313,7 +1300,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   ctl.inj_staged = false; ctl.topo_staged = false; ctl.reuse = false; ctl.dcf = false; ctl.write_bus = true; ctl.warm = false;
   TopoState ts;
   ts.status = 0; ts.nb = 0;
-  const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC>(P, S, sv, c, inst, is_dc, max_iter, tol_pu, tid, ctl, ts, n_iter, nb GPF_STAMPS_ARG);
+  const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC>(P, S, FL, sv, c, inst, is_dc, max_iter, tol_pu, tid, ctl, ts, n_iter, nb GPF_STAMPS_ARG);
   GPF_SYNC();
   if (st != 0) write_nan_results<GW>(P->g, P->b, inst, tid);
   if (tid == 0) {
@@ -1457,7 +1444,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       int it_k = 0, nb_k = 0;
       SolveCtl ctl;
       ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && !TC && sa.n_steps > 1; ctl.write_bus = last; ctl.warm = sa.warm_start != 0;
-      const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI, TC>(P, S, sv, c, inst, sa.is_dc, max_iter, tol_pu, tid, ctl, ts, it_k, nb_k GPF_STAMPS_ARG);
+      const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI, TC>(P, S, FL, sv, c, inst, sa.is_dc, max_iter, tol_pu, tid, ctl, ts, it_k, nb_k GPF_STAMPS_ARG);
       first = false;
       GPF_SYNC();
       if (more) { st = st_k; n_iter = it_k; nb = nb_k; }

@@ -43,6 +43,26 @@ struct Symbolic {
   int back_first = -1;             // highest level with U entries (-1: none)
   int back_off = 0;                // offset of the back-substitution level table
   int max_level_piv = 0;
+  int rslot0 = 0;                  // first right-hand-side pseudo-slot of the flat program (FlatProg): max(nslot, ceil(1.5 n))
+};
+
+// FLAT program of the 2x2 / scalar sweeps for one group width GW (threads per instance).  The block array of an instance holds
+// the right-hand side as n extra PSEUDO-SLOTS (slot rslot0 + p: rows (b_p[0], pad) and (b_p[1], pad)), so that a right-hand-side
+// update is the same item as a trailing update (A[dst] -= A[l] * inv(D_p) * A[u] with dst / u pseudo-slots: the pad column only
+// ever feeds pad columns) and b' = inv(D) b is one more scaling item.  Every sweep is a list of PASSES of exactly GW items --
+// lane t of the instance executes item t of every pass, a level that has more than GW items takes several passes, short levels
+// are padded with 0xFFFFFFFF words -- so the device walks `words + pass * stride + t` without level headers, bounds or
+// item-kind selects.  Slot fields are BYTE offsets (slot * 16) into one row half of the block array.
+//   forward : 2 words per item  dst | (l << 16), u | (pivot << 16)            (a barrier-delimited phase per pass)
+//   scale   : 1 word per item   u | (pivot << 16): first the n right-hand-side pseudo-slots, then every U block   (one phase)
+//   back    : 2 words per item  u | (x_col pseudo-slot << 16), dst pseudo-slot (a phase per pass, levels in reverse)
+// The forward and back sections end with one extra all-invalid pass (the device prefetches the words of the next pass).
+struct FlatProg {
+  int gw = 0;
+  int n_fwd = 0, n_scale = 0, n_scale_rhs = 0, n_back = 0;     // passes
+  int scale_off = 0, back_off = 0;                             // int offsets of the sections (forward starts at 0)
+  int rhs_field0 = 0;                                          // rslot0 * 16: fields >= this are right-hand-side pseudo-slots
+  std::vector<int> words;
 };
 
 inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, const int* line_ex_sub, int degree_slack = 1) {
@@ -132,6 +152,7 @@ inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, co
     levels.push_back(std::move(L));
   }
   S.nslot = (int)S.slot_row.size();
+  S.rslot0 = std::max(S.nslot, (3 * n_sub + 1) / 2);
   S.n_levels = (int)levels.size();
   // ---- flatten -------------------------------------------------------------------------------------------------------
   std::vector<int>& P = S.prog;
@@ -172,6 +193,75 @@ inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, co
     if (n_ent > 0) S.back_first = lv;
   }
   return S;
+}
+
+// false: the grid has too many blocks for 16-bit byte-offset fields (it would not fit the LDS either)
+inline bool flat_fits(const Symbolic& S) { return (size_t)(S.rslot0 + S.n) * 16 <= 65536; }
+
+inline FlatProg build_flat(const Symbolic& S, int gw) {
+  FlatProg F;
+  F.gw = gw;
+  F.rhs_field0 = S.rslot0 * 16;
+  const unsigned INV = 0xffffffffu;
+  auto fld = [](int slot) -> unsigned { return (unsigned)slot * 16u; };
+  auto rfld = [&](int row) -> unsigned { return (unsigned)(S.rslot0 + row) * 16u; };
+  std::vector<int>& W = F.words;
+  auto pad2 = [&](size_t start_items, size_t n_items) {       // pad a list of 2-word items to whole passes
+    const size_t rem = n_items % gw;
+    if (rem) for (size_t k = rem; k < (size_t)gw; ++k) { W.push_back((int)INV); W.push_back((int)INV); }
+    (void)start_items;
+    return (int)((n_items + gw - 1) / gw);
+  };
+  // forward
+  for (int lv = 0; lv < S.n_levels; ++lv) {
+    const int* h = S.prog.data() + (size_t)8 * lv;
+    const int c_off = h[4], n_c = h[5], r_off = h[6], n_r = h[7];
+    if (n_c + n_r == 0) continue;
+    for (int o = 0; o < n_c; ++o) {
+      const unsigned w0 = (unsigned)S.prog[c_off + 2 * o], w1 = (unsigned)S.prog[c_off + 2 * o + 1];
+      W.push_back((int)(fld(w0 & 0xffffu) | (fld(w0 >> 16) << 16)));
+      W.push_back((int)(fld(w1 & 0xffffu) | (fld(w1 >> 16) << 16)));
+    }
+    for (int o = 0; o < n_r; ++o) {
+      const unsigned w0 = (unsigned)S.prog[r_off + 2 * o];
+      const int p = S.prog[r_off + 2 * o + 1];
+      W.push_back((int)(rfld((int)(w0 >> 16)) | (fld(w0 & 0xffffu) << 16)));
+      W.push_back((int)(rfld(p) | (fld(p) << 16)));
+    }
+    F.n_fwd += pad2(0, (size_t)n_c + n_r);
+  }
+  for (int k = 0; k < gw; ++k) { W.push_back((int)INV); W.push_back((int)INV); }
+  // scale: right-hand sides first (the scalar solve with kept factors only runs these), then the U blocks
+  F.scale_off = (int)W.size();
+  {
+    int n_it = 0;
+    for (int p = 0; p < S.n; ++p, ++n_it) W.push_back((int)(rfld(p) | (fld(p) << 16)));
+    while (n_it % gw) { W.push_back((int)INV); ++n_it; }
+    F.n_scale_rhs = n_it / gw;
+    for (int e = 0; e < S.n_scale; ++e, ++n_it) {
+      const unsigned w = (unsigned)S.prog[S.scale_off + e];
+      W.push_back((int)(fld(w & 0xffffu) | (fld(w >> 16) << 16)));
+    }
+    while (n_it % gw) { W.push_back((int)INV); ++n_it; }
+    F.n_scale = n_it / gw;
+  }
+  if (W.size() & 1) W.push_back((int)INV);                     // 8-byte alignment of the back section
+  // back substitution, levels in reverse
+  F.back_off = (int)W.size();
+  for (int lv = S.back_first; lv >= 0; --lv) {
+    const int ent_off = S.prog[S.back_off + 2 * lv], n_ent = S.prog[S.back_off + 2 * lv + 1];
+    if (n_ent == 0) continue;
+    for (int o = 0; o < n_ent; ++o) {
+      const unsigned w = (unsigned)S.prog[ent_off + 2 * o];
+      const int p = S.prog[ent_off + 2 * o + 1];
+      W.push_back((int)(fld(w & 0xffffu) | (rfld((int)(w >> 16)) << 16)));
+      W.push_back((int)rfld(p));
+    }
+    F.n_back += pad2(0, (size_t)n_ent);
+  }
+  for (int k = 0; k < gw; ++k) { W.push_back((int)INV); W.push_back((int)INV); }
+  while (W.size() & 3) W.push_back((int)INV);
+  return F;
 }
 
 }  // namespace gpf

@@ -1,4 +1,4 @@
-// Developer tool: micro-benchmark of the in-LDS block-sparse LU of kernel S (gridpf_sparse.hpp: block_lu_solve) on the
+// Developer tool: micro-benchmark of the in-LDS block-sparse LU of kernel S (gridpf_sparse.hpp: block_lu_flat) on the
 // substation graph of a grid, one wavefront per block, REPS solves per launch, cycle counts per solve.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/lu_bench.hip -o tools/_build/lu_bench
 //   tools/_build/lu_bench graph.txt [blocks=4096] [reps=50]        (graph.txt: "n_sub n_line" then "or ex" per line)
@@ -16,52 +16,58 @@ using namespace gpf;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 template <int BS, int IPW>
-__global__ __launch_bounds__(64, 4) void lu_kernel(SymDev S, const double* __restrict__ A0, const double* __restrict__ b0, int reps,
-                                                    int do_solve, long long* cycles, double* xout) {
+__global__ __launch_bounds__(64, 4) void lu_kernel(SymDev S, FlatDev F, const int* __restrict__ fprog, int rslot0, const double* __restrict__ A0,
+                                                    const double* __restrict__ b0, int reps, int do_solve, long long* cycles, double* xout) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int GW = 64 / IPW;
   const int tid = threadIdx.x, grp = tid / GW, t = tid % GW;
   constexpr int B2 = BS * BS;
+  const size_t NS = (size_t)rslot0 + S.n, HS = NS * 2;
   double* Ap = reinterpret_cast<double*>(smem);                      // pristine copy (shared by the groups)
   double* bp = Ap + (size_t)S.nslot * B2;
-  double* A = bp + (size_t)S.n * BS + (size_t)grp * ((size_t)S.nslot * B2 + (size_t)S.n * BS);
-  double* rhs = A + (size_t)S.nslot * B2;
-  int* prog = reinterpret_cast<int*>(bp + (size_t)S.n * BS + (size_t)IPW * ((size_t)S.nslot * B2 + (size_t)S.n * BS));
+  double* A = bp + (size_t)S.n * BS + (size_t)grp * (NS * B2);
+  int* prog = reinterpret_cast<int*>(bp + (size_t)S.n * BS + (size_t)IPW * (NS * B2));
   for (int i = tid; i < S.nslot * B2; i += 64) Ap[i] = A0[i];
   for (int i = tid; i < S.n * BS; i += 64) bp[i] = b0[i];
-  for (int i = tid; i < S.n_prog; i += 64) prog[i] = S.prog[i];
+  for (int i = tid; i < F.n_words; i += 64) prog[i] = fprog[i];
   __syncthreads();
   bool ok = true;
   const long long t0 = __builtin_readcyclecounter();
   for (int r = 0; r < reps; ++r) {
-    // 2x2 blocks are stored split by row (block_lu_solve): row 0 of every block first, row 1 behind
-    for (int i = t; i < S.nslot * B2; i += GW) { const int slot = i / B2, e = i % B2; A[(e / BS) * S.nslot * BS + slot * BS + (e % BS)] = Ap[i]; }
-    for (int i = t; i < S.n * BS; i += GW) rhs[i] = bp[i];
+    // 2x2 blocks are stored split by row: row 0 of every (pseudo-)slot first, row 1 behind; right-hand side in the pseudo-slots
+    for (int i = t; i < S.nslot * B2; i += GW) { const int slot = i / B2, e = i % B2; A[(e / BS) * HS + slot * BS + (e % BS)] = Ap[i]; }
+    for (int i = t; i < S.n * BS; i += GW) A[(i % BS) * HS + ((size_t)rslot0 + i / BS) * 2] = bp[i];
     __syncthreads();
-    if (do_solve) ok &= block_lu_solve<BS, GW>(S, prog, A, rhs, t);
+    if (do_solve) ok &= block_lu_flat<GW>(F, prog, A, HS, t);
   }
   const long long t1 = __builtin_readcyclecounter();
   if (tid == 0) cycles[blockIdx.x] = (t1 - t0) + (ok ? 0 : 1000000000000LL);
-  if (blockIdx.x == 0 && grp == IPW - 1) for (int i = t; i < S.n * BS; i += GW) xout[i] = rhs[i];
+  if (blockIdx.x == 0 && grp == IPW - 1) for (int i = t; i < S.n * BS; i += GW) xout[i] = A[(i % BS) * HS + ((size_t)rslot0 + i / BS) * 2];
 }
 
 template <int BS, int IPW>
 void run(const SymDev& D, const Symbolic& S, int n, int instances, int reps, const double* dA, const double* db, double* dx, long long* dcy,
          double* med) {
+  FlatProg FP = build_flat(S, 64 / IPW);
+  FlatDev F{};
+  F.n_fwd = FP.n_fwd; F.n_scale = FP.n_scale; F.n_scale_rhs = FP.n_scale_rhs; F.n_back = FP.n_back; F.scale_off = FP.scale_off;
+  F.back_off = FP.back_off; F.rhs_field0 = FP.rhs_field0; F.n_words = (int)FP.words.size();
+  int* dfp; CK(hipMalloc(&dfp, FP.words.size() * 4)); CK(hipMemcpy(dfp, FP.words.data(), FP.words.size() * 4, hipMemcpyHostToDevice));
+  printf("flat program GW=%d: %d forward + %d back passes, %d scale passes, %zu ints\n", 64 / IPW, F.n_fwd, F.n_back, F.n_scale, FP.words.size());
   constexpr int B2 = BS * BS;
   const int blocks = instances / IPW;
-  const size_t lds = ((size_t)(1 + IPW) * ((size_t)S.nslot * B2 + (size_t)n * BS)) * 8 + S.prog.size() * 4 + 16;
+  const size_t lds = ((size_t)S.nslot * B2 + (size_t)n * BS + (size_t)IPW * ((size_t)S.rslot0 + n) * B2) * 8 + FP.words.size() * 4 + 16;
   CK(hipFuncSetAttribute((const void*)lu_kernel<BS, IPW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   printf("IPW=%d: LDS %zu B/block, blocks=%d\n", IPW, lds, blocks);
   for (int solve = 0; solve < 2; ++solve) {
     for (int w = 0; w < 2; ++w) {
-      hipLaunchKernelGGL((lu_kernel<BS, IPW>), dim3(blocks), dim3(64), lds, 0, D, dA, db, reps, solve, dcy, dx);
+      hipLaunchKernelGGL((lu_kernel<BS, IPW>), dim3(blocks), dim3(64), lds, 0, D, F, dfp, S.rslot0, dA, db, reps, solve, dcy, dx);
       CK(hipDeviceSynchronize());
     }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL((lu_kernel<BS, IPW>), dim3(blocks), dim3(64), lds, 0, D, dA, db, reps, solve, dcy, dx);
+    hipLaunchKernelGGL((lu_kernel<BS, IPW>), dim3(blocks), dim3(64), lds, 0, D, F, dfp, S.rslot0, dA, db, reps, solve, dcy, dx);
     CK(hipEventRecord(e1, 0));
     CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
