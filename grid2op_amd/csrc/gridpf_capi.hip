@@ -714,6 +714,16 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     auto puti = [&fi](const int* v, size_t n) { int off = (int)fi.size(); fi.insert(fi.end(), v, v + n); while (fi.size() & 3) fi.push_back(0); return off; };
     so.br_y = putd(d->br_y, (size_t)8 * nl); so.br_bdc = putd(d->br_bdc, nl); so.sub_vn_kv = putd(d->sub_vn_kv, g.n_sub);
     so.shunt_fact = putd(d->shunt_fact, nsh); so.gen_min_q = putd(d->gen_min_q, ng); so.gen_max_q = putd(d->gen_max_q, ng);
+    {
+      auto vn_of = [&](const int* sub, size_t n) { std::vector<double> v(n); for (size_t i = 0; i < n; ++i) v[i] = d->sub_vn_kv[sub[i]]; return v; };
+      std::vector<double> lv((size_t)2 * nl);
+      for (int l = 0; l < nl; ++l) { lv[2 * (size_t)l] = d->sub_vn_kv[d->line_or_sub[l]]; lv[2 * (size_t)l + 1] = d->sub_vn_kv[d->line_ex_sub[l]]; }
+      so.line_vn = putd(lv.data(), lv.size());
+      { auto v = vn_of(d->load_sub, nd); so.load_vn = putd(v.data(), v.size()); }
+      { auto v = vn_of(d->gen_sub, ng); so.gen_vn = putd(v.data(), v.size()); }
+      { auto v = vn_of(d->storage_sub, ns); so.sto_vn = putd(v.data(), v.size()); }
+      { auto v = vn_of(d->shunt_sub, nsh); so.shunt_vn = putd(v.data(), v.size()); }
+    }
     so.prog = puti(S.prog.data(), S.prog.size());                // 16-byte aligned: level headers are read as int4
     { std::vector<int> rc(S.nslot_y); for (int k = 0; k < S.nslot_y; ++k) rc[k] = S.slot_row[k] | (S.slot_col[k] << 16); so.pair_rc = puti(rc.data(), rc.size()); }
     so.n_int_hot = (int)fi.size();

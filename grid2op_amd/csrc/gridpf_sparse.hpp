@@ -22,6 +22,7 @@ struct StatOff {
   int n_dbl, n_int;
   int n_int_hot;   // the int section starts with the tables of the Newton loop (prog, pair_rc): staging tier 1 copies only these
   int br_y, br_bdc, sub_vn_kv, shunt_fact, gen_min_q, gen_max_q;
+  int line_vn, load_vn, gen_vn, sto_vn, shunt_vn;   // nominal kV of the substation of every element (line: [n_line][2] = or, ex)
   int line_or_pos, line_ex_pos, line_or_sub, line_ex_sub, br_slot, gen_pos, gen_sub, gen_slack, load_pos, load_sub, sto_pos,
       sto_sub, shunt_sub, pair_rc, prog;
 };
@@ -41,7 +42,7 @@ struct SP {
 template <int STAGE>
 struct StatView {
   static constexpr bool ALL = STAGE == 2, HOT = STAGE >= 1;
-  SP<double, ALL> br_y, br_bdc, sub_vn_kv, shunt_fact, gen_min_q, gen_max_q;
+  SP<double, ALL> br_y, br_bdc, sub_vn_kv, shunt_fact, gen_min_q, gen_max_q, line_vn, load_vn, gen_vn, sto_vn, shunt_vn;
   SP<int, ALL> line_or_pos, line_ex_pos, line_or_sub, line_ex_sub, br_slot, gen_pos, gen_sub, gen_slack, load_pos, load_sub,
       sto_pos, sto_sub, shunt_sub;
   SP<int, HOT> pair_rc;   // [nslot_y] slot_row | slot_col << 16 of the original-pattern blocks
@@ -52,6 +53,7 @@ template <int STAGE>
 __device__ inline void stat_view(StatView<STAGE>& v, const StatOff& o, const double* d, const int* i) {
   v.br_y.p = d + o.br_y; v.br_bdc.p = d + o.br_bdc; v.sub_vn_kv.p = d + o.sub_vn_kv; v.shunt_fact.p = d + o.shunt_fact;
   v.gen_min_q.p = d + o.gen_min_q; v.gen_max_q.p = d + o.gen_max_q;
+  v.line_vn.p = d + o.line_vn; v.load_vn.p = d + o.load_vn; v.gen_vn.p = d + o.gen_vn; v.sto_vn.p = d + o.sto_vn; v.shunt_vn.p = d + o.shunt_vn;
   v.line_or_pos.p = i + o.line_or_pos; v.line_ex_pos.p = i + o.line_ex_pos; v.line_or_sub.p = i + o.line_or_sub;
   v.line_ex_sub.p = i + o.line_ex_sub; v.br_slot.p = i + o.br_slot; v.gen_pos.p = i + o.gen_pos; v.gen_sub.p = i + o.gen_sub;
   v.gen_slack.p = i + o.gen_slack; v.load_pos.p = i + o.load_pos; v.load_sub.p = i + o.load_sub; v.sto_pos.p = i + o.sto_pos;
@@ -1013,11 +1015,18 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     else for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;     // fill blocks start at zero
     GPF_LSYNC();
     GPF_STAMPS(10);
+    // tier 0 (pair table in global memory): the word of the first pass stays in a register for the whole Newton loop and the
+    // word of pass k + 1 is fetched before pass k computes -- an L2 round trip per pass is otherwise the longest link of the phase
+    unsigned rc_first = 0;
+    if (STAGE == 0 && tid < n_pairs) rc_first = (unsigned)sv.pair_rc[tid / (NB * NB)];
     while (true) {
       // Jacobian blocks from the Ybus blocks: T_ij = V_i conj(Y_ij V_j); S_i += T_ij (LDS atomics)
+      unsigned rc_pf = rc_first;
       for (int pr = tid; pr < n_pairs; pr += GW) {
         const int slot = pr / (NB * NB), bi = (pr / NB) % NB, bj = pr % NB;
-        const unsigned rc = (unsigned)sv.pair_rc[slot];
+        unsigned rc;
+        if (STAGE == 0) { rc = rc_pf; if (pr + GW < n_pairs) rc_pf = (unsigned)sv.pair_rc[(pr + GW) / (NB * NB)]; }
+        else rc = (unsigned)sv.pair_rc[slot];
         const double2 y = *reinterpret_cast<const double2*>(c.Yb + (size_t)pr * 2);
         const int si = (int)(rc & 0xffffu), sj = (int)(rc >> 16);
         const int i = si * NB + bi, j = sj * NB + bj;
@@ -1130,7 +1139,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     float p_or = 0.f, q_or = 0.f, v_or = 0.f, a_or = 0.f, th_or = 0.f;
     float p_ex = 0.f, q_ex = 0.f, v_ex = 0.f, a_ex = 0.f, th_ex = 0.f;
     if (f >= 0) {
-      const double vnf = sv.sub_vn_kv[sv.line_or_sub[l]], vnt = sv.sub_vn_kv[sv.line_ex_sub[l]];
+      const double vnf = sv.line_vn[2 * l], vnt = sv.line_vn[2 * l + 1];
       const double vmf = c.vm[f], vmt = c.vm[t];
       double pf, qf, pt, qt;
       if (is_dc) {
@@ -1161,7 +1170,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     const bool on = bu >= 0;
     out[oo.load_p + i] = on ? (float)GPF_INJ(oo.inj_load_p + i) : 0.f;
     out[oo.load_q + i] = (on && !is_dc) ? (float)GPF_INJ(oo.inj_load_q + i) : 0.f;
-    out[oo.load_v + i] = on ? (float)(c.vm[bu] * sv.sub_vn_kv[sv.load_sub[i]]) : 0.f;
+    out[oo.load_v + i] = on ? (float)(c.vm[bu] * sv.load_vn[i]) : 0.f;
     out[oo.load_th + i] = on ? (float)(c.va[bu] * RAD2DEG) : 0.f;
   }
   for (int i = tid; i < g.n_sto; i += GW) {
@@ -1169,7 +1178,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     const bool on = bu >= 0;
     out[oo.sto_p + i] = on ? (float)GPF_INJ(oo.inj_sto_p + i) : 0.f;
     out[oo.sto_q + i] = (on && !is_dc) ? (float)GPF_INJ(oo.inj_sto_q + i) : 0.f;
-    out[oo.sto_v + i] = on ? (float)(c.vm[bu] * sv.sub_vn_kv[sv.sto_sub[i]]) : 0.f;
+    out[oo.sto_v + i] = on ? (float)(c.vm[bu] * sv.sto_vn[i]) : 0.f;
     out[oo.sto_th + i] = on ? (float)(c.va[bu] * RAD2DEG) : 0.f;
   }
   const auto sbo = gptr(b.shunt_bus_out) + (size_t)inst * g.n_shunt;
@@ -1179,7 +1188,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     const double v = on ? c.vm[bu] : 0.0;
     out[oo.sh_p + i] = on ? (float)(GPF_INJ(oo.inj_sh_p + i) * sv.shunt_fact[i] * v * v) : 0.f;
     out[oo.sh_q + i] = (on && !is_dc) ? (float)(GPF_INJ(oo.inj_sh_q + i) * sv.shunt_fact[i] * v * v) : 0.f;
-    out[oo.sh_v + i] = on ? (float)(v * sv.sub_vn_kv[sv.shunt_sub[i]]) : 0.f;
+    out[oo.sh_v + i] = on ? (float)(v * sv.shunt_vn[i]) : 0.f;
     if (!reuse) sbo[i] = on ? shb[i] : -1;
   }
   // generators (pypower pfsoln): per-bus totals accumulated in LDS with atomics (the block array is dead by now and
@@ -1219,7 +1228,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         double p = GPF_INJ(oo.inj_gen_p + i);
         if (sv.gen_slack[i]) p = (*SreP(bu) - c.Psp[bu]) * sn / nsl[bu];
         gp = (float)p; gq = (float)q;
-        gv = (float)(c.vm[bu] * sv.sub_vn_kv[sv.gen_sub[i]]);
+        gv = (float)(c.vm[bu] * sv.gen_vn[i]);
         gth = (float)(c.va[bu] * RAD2DEG);
       }
       out[oo.gen_p + i] = gp; out[oo.gen_q + i] = gq; out[oo.gen_v + i] = gv; out[oo.gen_th + i] = gth;
@@ -1417,7 +1426,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
         if (!sv.gen_slack[i]) pp *= scale_p;
         if (has_delta) pp += (i == tid) ? gd0 : gdelta[i];
         const float pv_kv = (i == tid) ? pv_pre : ch[2 * g.n_load + g.n_gen + i];
-        const float vn = (float)sv.sub_vn_kv[sv.gen_sub[i]];
+        const float vn = (float)sv.gen_vn[i];
         const double vm_pu = (double)(pv_kv / vn);
         if (STAGE) { c.inj[oo.inj_gen_p + i] = (double)pp; c.inj[oo.inj_gen_vm + i] = vm_pu; }
         else { inj_g[oo.inj_gen_p + i] = (double)pp; inj_g[oo.inj_gen_vm + i] = vm_pu; }
