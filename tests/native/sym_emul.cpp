@@ -142,3 +142,77 @@ extern "C" int sym_level_sizes(int n_sub, int n_line, const int* line_or, const 
   }
   return S.n_levels;
 }
+
+// Host emulation of the FLAT-program sweeps (gridpf_sparse.hpp: block_lu_flat; gridpf_symbolic.hpp: build_flat) for one group
+// width: 2x2 blocks split by row, right-hand side in the pseudo-slots behind rslot0, every pass of exactly gw items whose
+// updates are applied together (the device combines them with LDS atomics).  A_dense: [2n][2n] row-major.  Returns the number
+// of passes (forward + back), or a negative error (-2: a field out of range, -3: a padding word inside the valid prefix, ...).
+extern "C" int sym_emul_solve_flat(int n_sub, int n_line, const int* line_or, const int* line_ex, int gw, const double* A_dense,
+                                   const double* rhs_in, double* x_out, int* stats /* n_fwd, n_scale, n_back, n_words */) {
+  gpf::Symbolic S = gpf::build_symbolic(n_sub, n_line, line_or, line_ex);
+  if (!gpf::flat_fits(S)) return -10;
+  const gpf::FlatProg F = gpf::build_flat(S, gw);
+  const int N = n_sub * 2;
+  const size_t NS = (size_t)S.rslot0 + n_sub, HS = NS * 2;
+  std::vector<double> A(2 * HS, 0.0);                                     // row 0 of every (pseudo-)slot, then row 1
+  for (int s = 0; s < S.nslot; ++s)
+    for (int r = 0; r < 2; ++r)
+      for (int q = 0; q < 2; ++q) A[r * HS + (size_t)s * 2 + q] = A_dense[(size_t)(S.slot_row[s] * 2 + r) * N + S.slot_col[s] * 2 + q];
+  for (int p = 0; p < n_sub; ++p)
+    for (int r = 0; r < 2; ++r) { A[r * HS + ((size_t)S.rslot0 + p) * 2] = rhs_in[p * 2 + r]; A[r * HS + ((size_t)S.rslot0 + p) * 2 + 1] = 12345.678; }   // pad column: garbage on purpose
+  const unsigned INV = 0xffffffffu;
+  auto ok_field = [&](unsigned f) { return f % 16 == 0 && f / 16 < NS; };
+  auto el = [&](unsigned f, int r, int q) -> double& { return A[r * HS + (size_t)(f / 16) * 2 + q]; };
+  const int* W = F.words.data();
+  if (F.scale_off != 2 * gw * (F.n_fwd + 1)) return -4;                   // forward section + its padding pass
+  for (int k = 0; k < F.n_fwd; ++k) {
+    std::vector<double> d(A.size(), 0.0);
+    bool seen_inv = false;
+    for (int t = 0; t < gw; ++t) {
+      const unsigned w0 = (unsigned)W[2 * (k * gw + t)], w1 = (unsigned)W[2 * (k * gw + t) + 1];
+      if (w0 == INV) { seen_inv = true; continue; }
+      if (seen_inv) return -3;
+      const unsigned fd = w0 & 0xffffu, fl = w0 >> 16, fu = w1 & 0xffffu, fp = w1 >> 16;
+      if (!ok_field(fd) || !ok_field(fl) || !ok_field(fu) || !ok_field(fp)) return -2;
+      const double d00 = el(fp, 0, 0), d01 = el(fp, 0, 1), d10 = el(fp, 1, 0), d11 = el(fp, 1, 1);
+      const double det = d00 * d11 - d01 * d10;
+      if (!(std::fabs(det) > 1e-300)) return -1;
+      const double i00 = d11 / det, i01 = -d01 / det, i10 = -d10 / det, i11 = d00 / det;
+      double T[2][2];
+      for (int r = 0; r < 2; ++r) { T[r][0] = el(fl, r, 0) * i00 + el(fl, r, 1) * i10; T[r][1] = el(fl, r, 0) * i01 + el(fl, r, 1) * i11; }
+      for (int r = 0; r < 2; ++r)
+        for (int q = 0; q < 2; ++q) d[r * HS + (size_t)(fd / 16) * 2 + q] -= T[r][0] * el(fu, 0, q) + T[r][1] * el(fu, 1, q);
+    }
+    for (size_t i = 0; i < A.size(); ++i) A[i] += d[i];
+  }
+  for (int t = 0; t < gw; ++t) if ((unsigned)W[2 * (F.n_fwd * gw + t)] != INV) return -5;      // the padding pass
+  if (F.n_scale_rhs * gw < n_sub) return -6;
+  for (int k = 0; k < F.n_scale; ++k)
+    for (int t = 0; t < gw; ++t) {
+      const unsigned w = (unsigned)W[F.scale_off + k * gw + t];
+      if (w == INV) continue;
+      const unsigned fu = w & 0xffffu, fp = w >> 16;
+      if (!ok_field(fu) || !ok_field(fp)) return -2;
+      if ((k < F.n_scale_rhs) != ((int)fu >= F.rhs_field0)) return -7;    // right-hand sides first, then the U blocks
+      const double d00 = el(fp, 0, 0), d01 = el(fp, 0, 1), d10 = el(fp, 1, 0), d11 = el(fp, 1, 1);
+      const double det = d00 * d11 - d01 * d10;
+      const double u00 = el(fu, 0, 0), u01 = el(fu, 0, 1), u10 = el(fu, 1, 0), u11 = el(fu, 1, 1);
+      el(fu, 0, 0) = (d11 * u00 - d01 * u10) / det; el(fu, 0, 1) = (d11 * u01 - d01 * u11) / det;
+      el(fu, 1, 0) = (d00 * u10 - d10 * u00) / det; el(fu, 1, 1) = (d00 * u11 - d10 * u01) / det;
+    }
+  if (F.back_off % 2) return -8;
+  for (int k = 0; k < F.n_back; ++k) {
+    std::vector<double> d(A.size(), 0.0);
+    for (int t = 0; t < gw; ++t) {
+      const unsigned w0 = (unsigned)W[F.back_off + 2 * (k * gw + t)], w1 = (unsigned)W[F.back_off + 2 * (k * gw + t) + 1];
+      if (w0 == INV) continue;
+      const unsigned fu = w0 & 0xffffu, fj = w0 >> 16;
+      if (!ok_field(fu) || !ok_field(fj) || !ok_field(w1) || (int)fj < F.rhs_field0 || (int)w1 < F.rhs_field0) return -2;
+      for (int r = 0; r < 2; ++r) d[r * HS + (size_t)(w1 / 16) * 2] -= el(fu, r, 0) * el(fj, 0, 0) + el(fu, r, 1) * el(fj, 1, 0);
+    }
+    for (size_t i = 0; i < A.size(); ++i) A[i] += d[i];
+  }
+  for (int p = 0; p < n_sub; ++p) for (int r = 0; r < 2; ++r) x_out[p * 2 + r] = A[r * HS + ((size_t)S.rslot0 + p) * 2];
+  if (stats) { stats[0] = F.n_fwd; stats[1] = F.n_scale; stats[2] = F.n_back; stats[3] = (int)F.words.size(); }
+  return F.n_fwd + F.n_back;
+}

@@ -53,3 +53,38 @@ def test_program_reproduces_dense_solve(emul, load_model, name, BS, fused):
     nslot_y, nslot, n_levels, _ = stats
     assert n_levels < n or n <= 2                      # level scheduling really groups pivots
     assert nslot >= nslot_y >= n
+
+
+@pytest.mark.parametrize("name", ["rte_case5_example", "l2rpn_case14_sandbox", "l2rpn_neurips_2020_track1",
+                                  "l2rpn_wcci_2022_dev"])
+@pytest.mark.parametrize("gw", [16, 32, 64, 128])
+def test_flat_program_reproduces_dense_solve(emul, load_model, name, gw):
+    """The flat program of the single-busbar kernels (build_flat: passes of exactly gw items, byte-offset fields, right-hand
+    side as pseudo-slots whose pad column holds garbage) solves the same random block-sparse systems."""
+    m = load_model(name)
+    n, BS = m.n_sub, 2
+    N = n * BS
+    rng = np.random.default_rng(n * 100 + gw)
+    A = np.zeros((N, N))
+    for a, b in zip(m.line_or_sub, m.line_ex_sub):
+        A[a * BS:(a + 1) * BS, b * BS:(b + 1) * BS] += rng.standard_normal((BS, BS))
+        A[b * BS:(b + 1) * BS, a * BS:(a + 1) * BS] += rng.standard_normal((BS, BS))
+    for s in range(n):
+        A[s * BS:(s + 1) * BS, s * BS:(s + 1) * BS] += rng.standard_normal((BS, BS)) + (4.0 + np.abs(A[s * BS:(s + 1) * BS]).sum() / BS) * np.eye(BS)
+    rhs = rng.standard_normal(N)
+    x = np.zeros(N)
+    stats = np.zeros(4, dtype=np.int32)
+    lor = np.ascontiguousarray(m.line_or_sub, dtype=np.int32)
+    lex = np.ascontiguousarray(m.line_ex_sub, dtype=np.int32)
+    ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    rc = emul.sym_emul_solve_flat(n, m.n_line, lor.ctypes.data_as(ip), lex.ctypes.data_as(ip), gw, A.ctypes.data_as(dp),
+                                  rhs.ctypes.data_as(dp), x.ctypes.data_as(dp), stats.ctypes.data_as(ip))
+    assert rc >= 1, rc
+    ref = np.linalg.solve(A, rhs)
+    assert np.abs(x - ref).max() < 1e-9 * max(1.0, np.abs(ref).max())
+    n_fwd, n_scale, n_back, n_words = stats
+    lv = np.zeros(4 * 64 + 2, dtype=np.int32)
+    n_levels = emul.sym_level_sizes(n, m.n_line, lor.ctypes.data_as(ip), lex.ctypes.data_as(ip), lv.ctypes.data_as(ip), 64, 1)
+    items = [int(lv[4 * k + 2] + lv[4 * k + 3]) for k in range(n_levels)]
+    assert n_fwd == sum(-(-i // gw) for i in items if i > 0)          # a level takes ceil(items / gw) passes
+    assert n_words % 4 == 0
