@@ -330,9 +330,50 @@ struct Grp {
     }
     return dpp_group_sum<(GW < WAVE ? GW : WAVE)>(v);
   }
+  // two flags at once (bit 0 = any(a), bit 1 = any(b)).  Several wavefronts per instance: ONE exchange through LDS and ONE
+  // barrier instead of two __syncthreads_or (two barriers each); BUF selects the exchange buffer -- two calls with the same BUF
+  // must be separated by at least one other workgroup barrier (the slower wavefront may still be reading).
+  template <int BUF>
+  static __device__ __forceinline__ unsigned any2(bool a, bool b) {
+    if (WPI > 1) {
+      __shared__ unsigned redb_[4][WPI > 1 ? WPI : 1];
+      const unsigned w = (__ballot(a) != 0ull ? 1u : 0u) | (__ballot(b) != 0ull ? 2u : 0u);
+      if ((threadIdx.x & (WAVE - 1)) == 0) redb_[BUF][threadIdx.x / WAVE] = w;
+      __syncthreads();
+      unsigned r = 0;
+#pragma unroll
+      for (int k = 0; k < WPI; ++k) r |= redb_[BUF][k];
+      return r;
+    }
+    if (IPW == 1) return (__any(a) ? 1u : 0u) | (__any(b) ? 2u : 0u);
+    const unsigned long long m = mask();
+    return ((__ballot(a) & m) != 0ull ? 1u : 0u) | ((__ballot(b) & m) != 0ull ? 2u : 0u);
+  }
+  // two sums at once (several wavefronts per instance: one exchange, one barrier; same BUF rule as any2)
+  template <int BUF>
+  static __device__ __forceinline__ void sum2(double& a, double& b) {
+    if (WPI > 1) {
+      __shared__ double reds_[2][2 * (WPI > 1 ? WPI : 1)];
+#pragma unroll
+      for (int off = WAVE / 2; off; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
+      if ((threadIdx.x & (WAVE - 1)) == 0) { reds_[BUF][2 * (threadIdx.x / WAVE)] = a; reds_[BUF][2 * (threadIdx.x / WAVE) + 1] = b; }
+      __syncthreads();
+      double ta = 0.0, tb = 0.0;
+#pragma unroll
+      for (int k = 0; k < WPI; ++k) { ta += reds_[BUF][2 * k]; tb += reds_[BUF][2 * k + 1]; }
+      a = ta; b = tb;
+      return;
+    }
+    a = dpp_group_sum<(GW < WAVE ? GW : WAVE)>(a);
+    b = dpp_group_sum<(GW < WAVE ? GW : WAVE)>(b);
+  }
   // over ALL lanes of the block (every instance of the wavefront / every wavefront of the instance)
   static __device__ __forceinline__ bool block_any(bool x) { return WPI > 1 ? (__syncthreads_or(x) != 0) : (bool)__any(x); }
   static __device__ __forceinline__ bool block_all(bool x) { return WPI > 1 ? (__syncthreads_and(x) != 0) : (bool)__all(x); }
+  // the same for a value that is already uniform over the caller's instance (the result of a group collective, a loop counter):
+  // with one instance per block there is nothing to reduce
+  static __device__ __forceinline__ bool block_any_u(bool x) { return IPW == 1 ? x : (bool)__any(x); }
+  static __device__ __forceinline__ bool block_all_u(bool x) { return IPW == 1 ? x : (bool)__all(x); }
 };
 
 constexpr int BT_OFF = -1;   // inactive bus
@@ -859,7 +900,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   GPF_LSYNC();
   int status = reuse ? ts.status : ((nref == 0) ? 3 : 0);           // first failure of this group (0 = alive)
   if (!reuse) { ts.status = status; ts.nb = nb; }
-  if (G::block_all(status != 0)) return status;
+  if (G::block_all_u(status != 0)) return status;
   GPF_STAMPS(1);
 
   // ---- connectivity ----------------------------------------------------------------------------------------------------
@@ -886,7 +927,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     if (!conn_known) for (int i = tid; i < nbus; i += GW) bad |= (c.btype[i] != BT_OFF && c.lab[i] == 0);
     if (status == 0 && G::any(bad)) status = 2;
     ts.status = status;
-    if (G::block_all(status != 0)) return status;
+    if (G::block_all_u(status != 0)) return status;
   }
   }
   GPF_STAMPS(2);
@@ -990,7 +1031,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       for (int q = tid; q < S.nslot; q += GW) c.Adc[q] = c.A[(size_t)q * 2];
     GPF_LSYNC();
     if (status == 0 && G::any(!ok)) status = 4;
-    if (G::block_all(status != 0)) return status;
+    if (G::block_all_u(status != 0)) return status;
   }
   GPF_STAMPS(4);
 
@@ -1070,13 +1111,13 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         fabs_mis = fmax(fabs_mis, am);
       }
       if (!done) {
-        const bool any_ge = G::any(!(fabs_mis < tol_pu));
-        if (G::any(bad)) { status = 1; done = true; }
-        else if (!any_ge) { converged = true; done = true; }
+        const unsigned fl = G::template any2<0>(!(fabs_mis < tol_pu), bad);
+        if (fl & 2u) { status = 1; done = true; }
+        else if (!(fl & 1u)) { converged = true; done = true; }
         else if (it >= max_iter) done = true;
         else ++it;
       }
-      if (G::block_all(done)) break;
+      if (G::block_all_u(done)) break;
       GPF_LSYNC();
       if (it == 1) GPF_STAMPS(12);
       const bool ok = lu_ac(nullptr);
@@ -1107,13 +1148,13 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       if (BS == 2) { for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; } }
     else for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
       GPF_LSYNC();
-      if (!done && (G::any(!ok) || G::any(!fin))) { status = 4; done = true; }
+      if (!done && G::template any2<1>(!ok, !fin) != 0u) { status = 4; done = true; }
       if (it == 1) GPF_STAMPS(14);
     }
     if (status == 0 && !converged) status = 1;
   }
   n_iter_out = it;
-  if (G::block_all(status != 0)) return status;
+  if (G::block_all_u(status != 0)) return status;
   GPF_STAMPS(5);
 
   // ---- K6: results ---------------------------------------------------------------------------------------------------------
@@ -1416,8 +1457,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       float scale_p = 1.0f;
       GPF_STAMPS(17);
       if (sa.rebalance_on) {
-        sum_load = G::sum(sum_load);
-        sum_prod = G::sum(sum_prod);
+        G::template sum2<0>(sum_load, sum_prod);
         scale_p = (sum_prod > 0.0) ? (float)(sa.rebalance * sum_load / sum_prod) : 1.0f;
       }
       GPF_STAMPS(18);
@@ -1485,7 +1525,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       GPF_SYNC();
       if (more && !G::any(any_disc)) more = false;
       if (more) tripped = true;
-      if (!G::block_any(more)) break;
+      if (!G::block_any_u(more)) break;
       if (more) ++rounds;
     }
     GPF_STAMPS(9);
@@ -1529,7 +1569,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       for (int l = tid; l < g.n_line; l += GW) ovc[l] = 0;
     }
     // the topology-derived state stands for the next step only if NO group of the block changed or lost its topology
-    reuse = !G::block_any(failed || tripped);
+    reuse = !G::block_any_u(failed || tripped);
     GPF_STAMPS(7);
     if (++row >= sa.T) row = 0;
     if (!last) GPF_SYNC();
