@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "gpf_reset_lanes", "gpf_copy_lanes", "gpf_fanout_n1", "gpf_runpf", "gpf_solve_lane", "gpf_get_results", "gpf_upload_chronics",
     "gpf_upload_maintenance", "gpf_set_lane_chronics", "gpf_set_thermal_limits", "gpf_step", "gpf_step_n", "gpf_set_lane_redispatch", "gpf_set_gen_limits", "gpf_redispatch", "gpf_set_trajectory",
     "gpf_get_trajectory", "gpf_get_episode", "gpf_lane_capacity", "gpf_get_step_outputs", "gpf_sync",
-    "gpf_set_profiling", "gpf_get_kernel_time", "gpf_device_pointers",
+    "gpf_set_profiling", "gpf_get_kernel_time", "gpf_get_plan", "gpf_device_pointers",
     "gpf_ptdf_build", "gpf_ptdf_get", "gpf_ptdf_flows", "gpf_get_ptdf_flows", "gpf_lodf_screen",
 ]
 
@@ -144,6 +144,7 @@ def lib() -> C.CDLL:
     L.gpf_sync.argtypes = [h]
     L.gpf_set_profiling.argtypes = [h, i32]
     L.gpf_get_kernel_time.argtypes = [h, _dp, C.POINTER(C.c_int64)]
+    L.gpf_get_plan.argtypes = [h, C.POINTER(C.c_int32)]
     L.gpf_device_pointers.argtypes = [h, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.gpf_ptdf_build.argtypes = [h, i32]
     L.gpf_ptdf_get.argtypes = [h, _dp]

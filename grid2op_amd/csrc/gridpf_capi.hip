@@ -166,6 +166,9 @@ struct gpf_engine {
   int ipw_override = 0;        // GRIDPF_IPW=1|2|4 (developer override of the instances-per-wavefront heuristic)
   int wpi_override = 0;        // GRIDPF_WPI=1|2 (developer override of the wavefronts-per-instance heuristic); 1 = deterministic
   int wpi_env = 0;
+  bool no_yreg = false;        // GRIDPF_YREG=0: never keep the Ybus blocks in registers
+  int stage_max = 2;           // GRIDPF_STAGE=0|1|2: highest static-table staging tier the planner may pick (developer / tests)
+  int dcf_env = -1;            // GRIDPF_DCF=0|1 (-1: not set)
   int cap_lanes = 0;           // lane buffers are padded to a multiple of 4 lanes (instance groups of a wavefront)
   std::vector<int> lane_mb;    // max live busbars in one substation, per lane
   int init_mb = 1;
@@ -396,10 +399,10 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
     const size_t n_blocks = ((size_t)n_l + ipw - 1) / ipw;
     const size_t want = std::min<size_t>(std::min<size_t>((n_blocks + 255) / 256, LDS_HARD_LIMIT / std::max<size_t>(l_gl, 1)), 8);
     int stage = 0;
-    const int top_tier = nbk == 1 ? 2 : 1;
+    const int top_tier = std::min(nbk == 1 ? 2 : 1, e->stage_max);
     for (int tier = top_tier; tier >= 1 && !stage; --tier)
       if (need(tier) <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / need(tier) >= want) stage = tier;
-    if (ipw > 1 && stage != 2) { ipw = 1; stage = 0; for (int tier = 2; tier >= 1 && !stage; --tier) if (need(tier) <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / need(tier) >= want) stage = tier; }
+    if (ipw > 1 && stage != 2) { ipw = 1; stage = 0; for (int tier = top_tier; tier >= 1 && !stage; --tier) if (need(tier) <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / need(tier) >= want) stage = tier; }
     const size_t l = need(stage);
     if (l > LDS_HARD_LIMIT) return false;
     if (nbk == 1 && !e->sym_dev.flat[0]) return false;           // no flat program: graph beyond the 16-bit slot fields
@@ -412,6 +415,14 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
     if (q.wpi > 1) q.minw = 2;
     q.sparse_stage = stage;
     q.lds = l;
+    q.dcf = e->dcf;
+    q.yreg = false;
+    // Ybus blocks in registers (2 wavefronts per instance, tables in global memory, at most 4 pairs per lane): when the LDS they
+    // free holds the factored DC matrix without costing a block per CU, every step of a launch skips the DC assembly + factorisation
+    if (nbk == 1 && !listed && ipw == 1 && q.wpi == 2 && stage == 0 && !e->no_yreg && e->dcf_env != 0 && e->sym.nslot_y <= 4 * 128) {
+      const size_t ly = gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, 0, 0, false, 1, -1, true);
+      if (ly <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / ly >= std::min<size_t>(LDS_HARD_LIMIT / l, want)) { q.yreg = true; q.dcf = 1; q.lds = ly; }
+    }
     return true;
   };
   if (e->g.n_sub * mb <= 32000 && e->g.n_busbar <= 3) {
@@ -491,7 +502,7 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
   return fail(GPF_E_CAPACITY, "grid too large: per-instance LDS footprint of the block-sparse kernel exceeds 160 KiB");
 }
 
-int upload_params_s(gpf_engine* e, const gpf::Bufs& b, const LaunchPlan* tc = nullptr) {
+int upload_params_s(gpf_engine* e, const gpf::Bufs& b, const LaunchPlan* tc, int dcf) {
   gpf::DevParamsS hp{};
   hp.g = e->g;
   hp.b = b;
@@ -499,7 +510,7 @@ int upload_params_s(gpf_engine* e, const gpf::Bufs& b, const LaunchPlan* tc = nu
   hp.sym = e->sym_dev;
   hp.classes = e->d_classes.p;
   hp.tc_rows = tc ? tc->tc_rows : 0; hp.tc_nslot = tc ? tc->tc_nslot : 0; hp.tc_nslot_y = tc ? tc->tc_nslot_y : 0;
-  hp.dcf = e->dcf;
+  hp.dcf = dcf;
   if (!e->d_params_s) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_params_s), sizeof(gpf::DevParamsS)));
   if (!e->params_s_valid || std::memcmp(&hp, &e->h_params_s, sizeof(hp)) != 0) {
     e->h_params_s = hp;
@@ -764,7 +775,11 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     const size_t want = std::min<size_t>((n_blocks + 255) / 256, 8);
     e->dcf = (with <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / with >= want) ? 1 : 0;
     const char* dv = std::getenv("GRIDPF_DCF");
-    if (dv && (dv[0] == '0' || dv[0] == '1')) e->dcf = dv[0] - '0';
+    if (dv && (dv[0] == '0' || dv[0] == '1')) { e->dcf = dv[0] - '0'; e->dcf_env = e->dcf; }
+    const char* yv = std::getenv("GRIDPF_YREG");
+    e->no_yreg = yv && yv[0] == '0';
+    const char* sv_ = std::getenv("GRIDPF_STAGE");
+    if (sv_ && sv_[0] >= '0' && sv_[0] <= '2') e->stage_max = sv_[0] - '0';
   }
   HIP_TRY(hipMemsetAsync(e->status.p, 0xFF, B * 4 * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->overflow_count.p, 0, B * nl * sizeof(int), e->stream));
@@ -975,7 +990,7 @@ int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
   gpf::Bufs b = e->bufs();
   const double tol_pu = tol_mva / e->g.sn_mva;
   hipEvent_t ea = nullptr, eb = nullptr;
-  rc = upload_params_s(e, b, p.tc ? &p : (pb.tc ? &pb : nullptr));
+  rc = upload_params_s(e, b, p.tc ? &p : (pb.tc ? &pb : nullptr), p.dcf);
   if (rc != GPF_OK) return rc;
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
   // (measured: forking the second launch onto its own stream costs more in cross-stream events than the overlap gains)
@@ -1036,7 +1051,7 @@ int gpf_solve_lane(gpf_handle e, int32_t lane, const double* inj, const int32_t*
   LaunchPlan p, pb;
   int rc = plan_launch(e, lane, 1, p, pb);
   if (rc != GPF_OK) return rc;
-  rc = upload_params_s(e, e->bufs(), p.tc ? &p : (pb.tc ? &pb : nullptr));
+  rc = upload_params_s(e, e->bufs(), p.tc ? &p : (pb.tc ? &pb : nullptr), p.dcf);
   if (rc != GPF_OK) return rc;
   const double tol_pu = tol_mva / g.sn_mva;
   HIP_TRY(gpf_launch_runpf_sparse(p, e->device, e->d_params_s, st, lane, 1, is_dc, max_iter, tol_pu));
@@ -1157,7 +1172,7 @@ int gpf_step_n(gpf_handle e, int32_t t0, int32_t n_steps, const gpf_step_opts* o
   sa.nb_ts_allowed = o->nb_ts_allowed; sa.max_rounds = o->max_rounds; sa.hard_overflow = o->hard_overflow; sa.soft_overflow = o->soft_overflow;
   const double tol_pu = o->tol_mva / e->g.sn_mva;
   hipEvent_t ea = nullptr, eb = nullptr;
-  rc = upload_params_s(e, b, p.tc ? &p : (pb.tc ? &pb : nullptr));
+  rc = upload_params_s(e, b, p.tc ? &p : (pb.tc ? &pb : nullptr), p.dcf);
   if (rc != GPF_OK) return rc;
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
   HIP_TRY(gpf_launch_step_sparse(p, e->device, e->d_params_s, e->stream, e->n_lanes, o->max_iter, tol_pu, sa));
@@ -1543,6 +1558,16 @@ int gpf_debug_read_work(gpf_handle e, double* out, int64_t n) {
   return GPF_OK;
 }
 #endif
+
+int gpf_get_plan(gpf_handle e, int32_t out[8]) {
+  if (!e || !out) return fail(GPF_E_INVALID, "gpf_get_plan: null");
+  LaunchPlan p, pb;
+  int rc = plan_launch(e, 0, e->n_lanes, p, pb);
+  if (rc != GPF_OK) return rc;
+  out[0] = p.sparse_nb; out[1] = p.ipw; out[2] = p.wpi; out[3] = p.sparse_stage; out[4] = p.yreg ? 1 : 0; out[5] = p.dcf;
+  out[6] = (int32_t)p.lds; out[7] = p.tc ? 1 : 0;
+  return GPF_OK;
+}
 
 int gpf_device_pointers(gpf_handle e, void** ptrs, void** stream) {
   if (!e || !ptrs) return fail(GPF_E_INVALID, "gpf_device_pointers: null");

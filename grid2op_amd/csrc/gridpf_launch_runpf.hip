@@ -3,11 +3,11 @@
 
 namespace {
 
-template <int NB, int ST, int IPW, int WP, bool TC>
+template <int NB, int ST, int IPW, int WP, bool TC, bool YR = false>
 hipError_t launch(const LaunchPlan& p, int device, const gpf::DevParamsS* d_params, hipStream_t stream, int lane0, int n_l,
                   const int* list, int is_dc, int max_iter, double tol_pu) {
   static size_t lds_set[64] = {0};
-  auto kern = &gpf::runpf_sparse_kernel<NB, ST, IPW, 2, WP, TC>;
+  auto kern = &gpf::runpf_sparse_kernel<NB, ST, IPW, 2, WP, TC, YR>;
   if (p.lds > lds_set[device & 63]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);
     if (e != hipSuccess) return e;
@@ -25,7 +25,8 @@ hipError_t gpf_launch_runpf_sparse(const LaunchPlan& p, int device, const gpf::D
                                    int is_dc, int max_iter, double tol_pu) {
   const int n_l = p.n_list ? p.n_list : n;
   const int* list = p.n_list ? p.list : nullptr;
-#define GO(NB, ST, IPW, WP, TC) return launch<NB, ST, IPW, WP, TC>(p, device, d_params, stream, lane0, n_l, list, is_dc, max_iter, tol_pu)
+#define LAUNCH_ARGS p, device, d_params, stream, lane0, n_l, list, is_dc, max_iter, tol_pu
+#define GO(NB, ST, IPW, WP, TC) return launch<NB, ST, IPW, WP, TC>(LAUNCH_ARGS)
   if (p.tc) {
     if (p.ipw == 4) GO(1, 0, 4, 1, true);
     if (p.ipw == 2) GO(1, 0, 2, 1, true);
@@ -38,6 +39,7 @@ hipError_t gpf_launch_runpf_sparse(const LaunchPlan& p, int device, const gpf::D
     if (p.wpi == 2) {
       if (p.sparse_stage == 2) GO(1, 2, 1, 2, false);
       if (p.sparse_stage == 1) GO(1, 1, 1, 2, false);
+      if (p.yreg) return launch<1, 0, 1, 2, false, true>(LAUNCH_ARGS);
       GO(1, 0, 1, 2, false);
     }
     if (p.sparse_stage == 2) GO(1, 2, 1, 1, false);
@@ -54,5 +56,6 @@ hipError_t gpf_launch_runpf_sparse(const LaunchPlan& p, int device, const gpf::D
     GO(3, 0, 1, 1, false);
   }
 #undef GO
+#undef LAUNCH_ARGS
   return hipErrorInvalidValue;
 }

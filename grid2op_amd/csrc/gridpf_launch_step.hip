@@ -4,12 +4,12 @@
 
 namespace {
 
-template <int NB, int ST, int IPW, int WP, bool TC>
+template <int NB, int ST, int IPW, int WP, bool TC, bool YR = false>
 hipError_t launch(const LaunchPlan& p, int device, const gpf::DevParamsS* d_params, hipStream_t stream, int n_l, const int* list,
                   int max_iter, double tol_pu, const gpf::StepArgs& sa) {
   static size_t lds_set[64] = {0};
   static const size_t pad = getenv("GRIDPF_LDS_PAD") ? (size_t)atoi(getenv("GRIDPF_LDS_PAD")) : 0;   // occupancy experiments only
-  auto kern = &gpf::step_sparse_kernel<NB, ST, IPW, 2, WP, TC>;
+  auto kern = &gpf::step_sparse_kernel<NB, ST, IPW, 2, WP, TC, YR>;
   const size_t lds = p.lds + pad;
   if (lds > lds_set[device & 63]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -28,7 +28,8 @@ hipError_t gpf_launch_step_sparse(const LaunchPlan& p, int device, const gpf::De
                                   int max_iter, double tol_pu, const gpf::StepArgs& sa) {
   const int n_l = p.n_list ? p.n_list : n_lanes;
   const int* list = p.n_list ? p.list : nullptr;
-#define GO(NB, ST, IPW, WP, TC) return launch<NB, ST, IPW, WP, TC>(p, device, d_params, stream, n_l, list, max_iter, tol_pu, sa)
+#define LAUNCH_ARGS p, device, d_params, stream, n_l, list, max_iter, tol_pu, sa
+#define GO(NB, ST, IPW, WP, TC) return launch<NB, ST, IPW, WP, TC>(LAUNCH_ARGS)
   if (p.tc) {
     if (p.ipw == 4) GO(1, 0, 4, 1, true);
     if (p.ipw == 2) GO(1, 0, 2, 1, true);
@@ -41,6 +42,7 @@ hipError_t gpf_launch_step_sparse(const LaunchPlan& p, int device, const gpf::De
     if (p.wpi == 2) {
       if (p.sparse_stage == 2) GO(1, 2, 1, 2, false);
       if (p.sparse_stage == 1) GO(1, 1, 1, 2, false);
+      if (p.yreg) return launch<1, 0, 1, 2, false, true>(LAUNCH_ARGS);
       GO(1, 0, 1, 2, false);
     }
     if (p.sparse_stage == 2) GO(1, 2, 1, 1, false);
@@ -57,5 +59,6 @@ hipError_t gpf_launch_step_sparse(const LaunchPlan& p, int device, const gpf::De
     GO(3, 0, 1, 1, false);
   }
 #undef GO
+#undef LAUNCH_ARGS
   return hipErrorInvalidValue;
 }

@@ -740,8 +740,13 @@ struct TopoState {
 // One complete power flow of the IPW instances of a wavefront (tid = lane within the instance group).  Returns the GPF_ST_*
 // status of the caller's group.  Groups share the instruction stream: a group that has failed or finished keeps executing
 // (its state is frozen / its results are overwritten by the caller), so barriers stay wave-uniform.
-template <int NB, int STAGE, int IPW, int WPI, bool TC>
-__device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, const SymDev& S, const FlatDev& FL, const StatView<STAGE>& sv, CarveP<NB>& c, int inst, int is_dc, int max_iter,
+// YR (large single-busbar grids, 2 wavefronts per instance, tables in global memory): the Ybus blocks and pair-table words of the
+// (at most YR_PASSES * GW) pairs stay in REGISTERS of the lane that owns the pair (yreg / rcreg, owned by the kernel so that they
+// survive from one solve to the next like the LDS copy does); the 7.6 KB of LDS this frees on a 118-substation grid hold the
+// factored DC matrix (CarveP::Adc) instead, which no longer has to be rebuilt and refactored by every step of a launch.
+constexpr int YR_PASSES = 4;
+template <int NB, int STAGE, int IPW, int WPI, bool TC, bool YR = false>
+__device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, const SymDev& S, const FlatDev& FL, const StatView<STAGE>& sv, CarveP<NB>& c, double2* yreg, unsigned* rcreg, int inst, int is_dc, int max_iter,
                                             double tol_pu, int tid, const SolveCtl& ctl, TopoState& ts, int& n_iter_out, int& nb_out GPF_STAMPS_PARAM) {
   typedef Grp<IPW, WPI> G;
   constexpr int GW = G::GW;
@@ -938,8 +943,10 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   auto lidx = [&](int bus) -> int { return (NB == 1) ? 0 : bus % NB; };
   if (!warm) {
   if (!dc_kept || do_y) {
-  if (do_y) for (int i = tid; i < S.nslot_y * NB * NB * 2; i += GW) c.Yb[i] = 0.0;
+  // YR: the Ybus blocks are assembled in the (still unused) row-1 half of the block array and then moved to registers
+  double* const ydst = YR ? c.A + HS : c.Yb;
   if (!dc_kept) for (int i = tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
+  if (do_y) for (int i = tid; i < S.nslot_y * NB * NB * 2; i += GW) ydst[i] = 0.0;
   GPF_LSYNC();
   for (int l = tid; l < g.n_line; l += GW) {
     const int f = c.lor_b[l], t = c.lex_b[l];
@@ -949,10 +956,10 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     if (do_y) {
       const double4 ya = sv.br_y.ld4((size_t)8 * l), yb = sv.br_y.ld4((size_t)8 * l + 4);
       double* y;
-      y = c.Yb + ((size_t)sff * NB * NB + bi * NB + bi) * 2; atomicAdd(&y[0], ya.x); atomicAdd(&y[1], ya.y);
-      y = c.Yb + ((size_t)sft * NB * NB + bi * NB + bj) * 2; atomicAdd(&y[0], ya.z); atomicAdd(&y[1], ya.w);
-      y = c.Yb + ((size_t)stf * NB * NB + bj * NB + bi) * 2; atomicAdd(&y[0], yb.x); atomicAdd(&y[1], yb.y);
-      y = c.Yb + ((size_t)stt * NB * NB + bj * NB + bj) * 2; atomicAdd(&y[0], yb.z); atomicAdd(&y[1], yb.w);
+      y = ydst + ((size_t)sff * NB * NB + bi * NB + bi) * 2; atomicAdd(&y[0], ya.x); atomicAdd(&y[1], ya.y);
+      y = ydst + ((size_t)sft * NB * NB + bi * NB + bj) * 2; atomicAdd(&y[0], ya.z); atomicAdd(&y[1], ya.w);
+      y = ydst + ((size_t)stf * NB * NB + bj * NB + bi) * 2; atomicAdd(&y[0], yb.x); atomicAdd(&y[1], yb.y);
+      y = ydst + ((size_t)stt * NB * NB + bj * NB + bj) * 2; atomicAdd(&y[0], yb.z); atomicAdd(&y[1], yb.w);
     }
     if (f != t && !dc_kept) {
       const double bb = sv.br_bdc[l];
@@ -973,13 +980,22 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         const int bi = lidx(bu);
         const int sub = (NB == 1) ? bu : bu / NB;
         const double fct = sv.shunt_fact[s] * inv_sn;
-        double* y = c.Yb + ((size_t)sub * NB * NB + bi * NB + bi) * 2;       // diag slot of a substation == its index
+        double* y = ydst + ((size_t)sub * NB * NB + bi * NB + bi) * 2;       // diag slot of a substation == its index
         atomicAdd(&y[0], GPF_INJ(oo.inj_sh_p + s) * fct);
         atomicAdd(&y[1], -GPF_INJ(oo.inj_sh_q + s) * fct);
       }
     }
   }
   GPF_LSYNC();
+  if (YR && do_y) {
+#pragma unroll
+    for (int k = 0; k < YR_PASSES; ++k) {
+      const int pr = tid + k * GW;
+      yreg[k] = pr < S.nslot_y ? *reinterpret_cast<const double2*>(ydst + (size_t)pr * 2) : make_double2(0.0, 0.0);
+      rcreg[k] = pr < S.nslot_y ? (unsigned)sv.pair_rc[pr] : 0u;
+    }
+    GPF_LSYNC();                                   // the identity rows below overwrite the scratch
+  }
   }
   // identity rows (fixed variables) + DC right-hand side
   for (int i = tid; i < nbus; i += GW) {
@@ -1059,16 +1075,11 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     // tier 0 (pair table in global memory): the word of the first pass stays in a register for the whole Newton loop and the
     // word of pass k + 1 is fetched before pass k computes -- an L2 round trip per pass is otherwise the longest link of the phase
     unsigned rc_first = 0;
-    if (STAGE == 0 && tid < n_pairs) rc_first = (unsigned)sv.pair_rc[tid / (NB * NB)];
+    if (STAGE == 0 && !YR && tid < n_pairs) rc_first = (unsigned)sv.pair_rc[tid / (NB * NB)];
     while (true) {
       // Jacobian blocks from the Ybus blocks: T_ij = V_i conj(Y_ij V_j); S_i += T_ij (LDS atomics)
-      unsigned rc_pf = rc_first;
-      for (int pr = tid; pr < n_pairs; pr += GW) {
+      auto pair_item = [&](int pr, const double2 y, const unsigned rc) {
         const int slot = pr / (NB * NB), bi = (pr / NB) % NB, bj = pr % NB;
-        unsigned rc;
-        if (STAGE == 0) { rc = rc_pf; if (pr + GW < n_pairs) rc_pf = (unsigned)sv.pair_rc[(pr + GW) / (NB * NB)]; }
-        else rc = (unsigned)sv.pair_rc[slot];
-        const double2 y = *reinterpret_cast<const double2*>(c.Yb + (size_t)pr * 2);
         const int si = (int)(rc & 0xffffu), sj = (int)(rc >> 16);
         const int i = si * NB + bi, j = sj * NB + bj;
         const int bti = c.btype[i], btj = c.btype[j];
@@ -1085,6 +1096,18 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         *reinterpret_cast<double2*>(bel(slot, 2 * bi, 2 * bj)) = make_double2((rowP && colT) ? ti_ : 0.0, (rowP && colV) ? tr_ * ivmj : 0.0);
         *reinterpret_cast<double2*>(bel(slot, 2 * bi + 1, 2 * bj)) = make_double2((rowQ && colT) ? -tr_ : 0.0, (rowQ && colV) ? ti_ * ivmj : 0.0);
         if (act && (yr != 0.0 || yi != 0.0)) { atomicAdd(SreP(i), tr_); atomicAdd(SimP(i), ti_); }
+      };
+      if (YR) {
+#pragma unroll
+        for (int k = 0; k < YR_PASSES; ++k) { const int pr = tid + k * GW; if (pr < n_pairs) pair_item(pr, yreg[k], rcreg[k]); }
+      } else {
+        unsigned rc_pf = rc_first;
+        for (int pr = tid; pr < n_pairs; pr += GW) {
+          unsigned rc;
+          if (STAGE == 0) { rc = rc_pf; if (pr + GW < n_pairs) rc_pf = (unsigned)sv.pair_rc[(pr + GW) / (NB * NB)]; }
+          else rc = (unsigned)sv.pair_rc[pr / (NB * NB)];
+          pair_item(pr, *reinterpret_cast<const double2*>(c.Yb + (size_t)pr * 2), rc);
+        }
       }
       GPF_LSYNC();
       if (it == 0) GPF_STAMPS(11);
@@ -1317,7 +1340,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   pin_sgpr(S_loc.rslot0);                                                                                                        \
   const SymDev& S = S_loc;                                                                                                       \
   const int lds_rows = TC ? P->tc_rows : -1, lds_nslot = TC ? P->tc_nslot : P->sym.nslot,                                        \
-            lds_nslot_y = TC ? P->tc_nslot_y : P->sym.nslot_y;                                                                   \
+            lds_nslot_y = YR ? 0 : TC ? P->tc_nslot_y : P->sym.nslot_y;      /* YR: the Ybus blocks live in registers */          \
   const bool lds_dcf = !TC && P->dcf != 0;                                                                                       \
   const size_t per_inst = lds_bytes_instance<NB>(G_, lds_nslot, lds_nslot_y, STAGE != 0, lds_rows, lds_dcf);                     \
   carve_sparse<NB>(c, smem + (size_t)grp * per_inst, G_, lds_nslot, lds_nslot_y, STAGE != 0, lds_rows, lds_dcf);                 \
@@ -1333,7 +1356,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     sv.pair_rc.p = tc_.pair_rc; sv.br_slot.p = tc_.br_slot; sv.node_of.p = tc_.node_of;                                          \
   }
 
-template <int NB, int STAGE, int IPW, int MINW, int WPI, bool TC = false>
+template <int NB, int STAGE, int IPW, int MINW, int WPI, bool TC = false, bool YR = false>
 __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const DevParamsS* __restrict__ P, int lane0, const int* __restrict__ lane_list,
                                                             const int* __restrict__ lane_class, int is_dc, int max_iter,
                                                             double tol_pu) {
@@ -1344,13 +1367,15 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   const int inst = lane_list ? gptr(lane_list)[blockIdx.x * IPW + grp] : lane0 + blockIdx.x * IPW + grp;
   CarveP<NB> c;
   GPF_CARVE_AND_VIEW(P->g);
+  double2 yreg[YR_PASSES];
+  unsigned rcreg[YR_PASSES];
   int n_iter, nb;
   GPF_STAMPS_DECL;
   SolveCtl ctl;
   ctl.inj_staged = false; ctl.topo_staged = false; ctl.reuse = false; ctl.dcf = false; ctl.write_bus = true; ctl.warm = false;
   TopoState ts;
   ts.status = 0; ts.nb = 0;
-  const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC>(P, S, FL, sv, c, inst, is_dc, max_iter, tol_pu, tid, ctl, ts, n_iter, nb GPF_STAMPS_ARG);
+  const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, is_dc, max_iter, tol_pu, tid, ctl, ts, n_iter, nb GPF_STAMPS_ARG);
   GPF_SYNC();
   if (st != 0) write_nan_results<GW>(P->g, P->b, inst, tid);
   if (tid == 0) {
@@ -1364,7 +1389,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
 // rho, status, episode bookkeeping, all written to HBM.  What does NOT change from one step to the next stays in LDS / registers:
 // the static tables, the lane's chronics cursor and -- as long as no line tripped and no lane failed -- everything that only
 // depends on the topology (element -> bus maps, bus types, connectivity verdict, Ybus blocks, the factored DC matrix).
-template <int NB, int STAGE, int IPW, int MINW, int WPI, bool TC = false>
+template <int NB, int STAGE, int IPW, int MINW, int WPI, bool TC = false, bool YR = false>
 __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const DevParamsS* __restrict__ P, const int* __restrict__ lane_list,
                                                            const int* __restrict__ lane_class, int max_iter, double tol_pu,
                                                            StepArgs sa) {
@@ -1380,6 +1405,8 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   const bool ghost = inst >= (int)b.n_real_lanes;               // padding lane of an instance group: computes, never mutates state
   CarveP<NB> c;
   GPF_CARVE_AND_VIEW(g);
+  double2 yreg[YR_PASSES];
+  unsigned rcreg[YR_PASSES];
   if (STAGE) GPF_SYNC();                                       // the static tables are read from here on
   GPF_STAMPS_DECL;
   GPF_STAMPS(8);
@@ -1493,7 +1520,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       int it_k = 0, nb_k = 0;
       SolveCtl ctl;
       ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && !TC && sa.n_steps > 1; ctl.write_bus = last; ctl.warm = sa.warm_start != 0;
-      const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI, TC>(P, S, FL, sv, c, inst, sa.is_dc, max_iter, tol_pu, tid, ctl, ts, it_k, nb_k GPF_STAMPS_ARG);
+      const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, sa.is_dc, max_iter, tol_pu, tid, ctl, ts, it_k, nb_k GPF_STAMPS_ARG);
       first = false;
       GPF_SYNC();
       if (more) { st = st_k; n_iter = it_k; nb = nb_k; }

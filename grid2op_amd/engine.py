@@ -502,6 +502,14 @@ class PowerFlowEngine:
         check(self._lib.gpf_get_kernel_time(self._h, C.byref(ms), C.byref(n)), "gpf_get_kernel_time")
         return ms.value, n.value
 
+    def plan(self) -> dict:
+        """Diagnostics: the kernel configuration a launch over all lanes would use right now (gpf_get_plan)."""
+        out = (C.c_int32 * 8)()
+        check(self._lib.gpf_get_plan(self._h, out), "gpf_get_plan")
+        keys = ("busbars_per_block", "instances_per_wavefront", "wavefronts_per_instance", "staging_tier", "ybus_in_registers",
+                "dc_factors_kept", "lds_bytes", "topology_classes")
+        return dict(zip(keys, [int(v) for v in out]))
+
     def algorithmic_bytes_per_step(self) -> int:
         """inputs at API dtype + outputs at API dtype, topology unchanged."""
         m = self.model

@@ -260,6 +260,12 @@ int gpf_set_profiling(gpf_handle h, int32_t mode);
 /* Sum of the event-measured durations (ms) and number of solver launches since the last call (closes the running
  * window of mode 1 and opens the next one). */
 int gpf_get_kernel_time(gpf_handle h, double* total_ms, int64_t* n_launches);
+/* Diagnostics (no reference counterpart): the kernel configuration a launch over ALL lanes would use right now.
+ * out[0] busbars per block (1: single-busbar kernel; 2, 3: NB = n_busbar kernel), out[1] instances per wavefront,
+ * out[2] wavefronts per instance, out[3] static-table staging tier (0 global memory, 1 program + pair table in LDS, 2 all),
+ * out[4] Ybus blocks in registers, out[5] LDS layout keeps the factored DC matrix, out[6] dynamic LDS bytes per block,
+ * out[7] topology-class launch. */
+int gpf_get_plan(gpf_handle h, int32_t out[8]);
 /* Raw device pointers + the stream, for zero-copy interop (grid2op_amd/engine.py: PowerFlowEngine.device_views wraps them as
  * torch tensors).  ptrs[0..15] = inj, topo, shunt_bus, out, topo_vect, line_status, status, chronics, rho, overflow_count, done,
  * episode, bus_vm, bus_va, shunt_bus_out, disc_round (rows are padded to gpf_lane_capacity lanes); stream = hipStream_t */

@@ -136,6 +136,54 @@ def test_warm_start_option_same_solution_fewer_iterations(name, B, kw, load_mode
     e2.close()
 
 
+def test_ybus_in_registers_variant(load_model, load_npz):
+    """118 substations with the tables left in global memory (what a 1 024-lane batch runs; GRIDPF_STAGE=0 forces it on a small
+    one): the Ybus blocks live in registers and the freed LDS keeps the factored DC matrix across the steps of a launch.  Same
+    results as the LDS variant (GRIDPF_YREG=0), multi-step and single-step, and as the oracle."""
+    name, B, kw = "l2rpn_wcci_2022_dev", 10, dict(rebalance=1.02)
+    m, ch, e_lds, tab, off, scale = _setup(load_model, load_npz, name, B, env={"GRIDPF_STAGE": "0", "GRIDPF_YREG": "0"})
+    _, _, e_reg, _, _, _ = _setup(load_model, load_npz, name, B, env={"GRIDPF_STAGE": "0"})
+    _, _, e_one, _, _, _ = _setup(load_model, load_npz, name, B, env={"GRIDPF_STAGE": "0"})
+    pl, pr_ = e_lds.plan(), e_reg.plan()
+    assert pl["staging_tier"] == 0 and pl["wavefronts_per_instance"] == 2 and not pl["ybus_in_registers"]
+    assert pr_["staging_tier"] == 0 and pr_["ybus_in_registers"] == 1 and pr_["dc_factors_kept"] == 1 and pr_["lds_bytes"] < pl["lds_bytes"]
+    n = 5
+    e_lds.step(2, n_steps=n, **kw)
+    e_reg.step(2, n_steps=n, **kw)
+    for t in range(2, 2 + n):
+        e_one.step(t, **kw)
+    a, b, c1 = _snapshot(e_lds), _snapshot(e_reg), _snapshot(e_one)
+    _same(b, a, "registers vs LDS")
+    _same(b, c1, "registers: multi-step vs single steps")
+    assert (b["status"][:, 0] == 0).all()
+    # a topology change in the middle of a launch sequence rebuilds the register copy
+    topo = np.tile(m.initial_topo_vect(), (B, 1))
+    l_out = 3
+    topo[:, m.line_or_pos_topo_vect[l_out]] = -1
+    topo[:, m.line_ex_pos_topo_vect[l_out]] = -1
+    for e in (e_lds, e_reg):
+        e.set_topology(topo)
+        e.step(2 + n, n_steps=3, **kw)
+    _same(_snapshot(e_reg), _snapshot(e_lds), "registers vs LDS after a line outage")
+    T = tab.shape[0]
+    r = e_reg.results()
+    t = 2 + n + 2
+    for k in (0, B - 1):
+        row = (t + off[k]) % T
+        s = LaneState.from_model(m)
+        s.topo = topo[k].copy()
+        lp = ch["load_p"][row] * scale[k, :m.n_load]
+        lq = ch["load_q"][row] * scale[k, m.n_load:]
+        pp = ch["prod_p"][row].copy()
+        ns = ~m.gen_slack
+        pp[ns] = pp[ns] * np.float32(1.02 * lp.astype(np.float64).sum() / pp[ns].astype(np.float64).sum())
+        s.load_p, s.load_q, s.gen_p = lp.astype(np.float64), lq.astype(np.float64), pp.astype(np.float64)
+        s.gen_vm = (ch["prod_v"][row] / m.sub_vn_kv[m.gen_sub].astype(np.float32)).astype(np.float64)
+        _compare(m, r, k, solve(m, s))
+    for e in (e_lds, e_reg, e_one):
+        e.close()
+
+
 def test_multi_step_last_step_matches_oracle(load_model, load_npz):
     m, ch, eng, tab, off, scale = _setup(load_model, load_npz, "l2rpn_case14_sandbox", 32)
     T = tab.shape[0]
