@@ -735,6 +735,44 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
       { auto v = vn_of(d->storage_sub, ns); so.sto_vn = putd(v.data(), v.size()); }
       { auto v = vn_of(d->shunt_sub, nsh); so.shunt_vn = putd(v.data(), v.size()); }
     }
+    so.dc_inv = -1;
+    if (g.n_sub <= 24 && !std::getenv("GRIDPF_NO_DCINV")) {
+      // inverse of the DC matrix of the reference topology (every line in service, reference buses = substations of the slack
+      // generators), exactly as K3 assembles it: rows / columns of the reference buses are identity.  Column-major.
+      const int n = g.n_sub;
+      std::vector<char> is_ref(n, 0);
+      for (int i = 0; i < ng; ++i) if (d->gen_slack[i]) is_ref[d->gen_sub[i]] = 1;
+      std::vector<double> M((size_t)n * 2 * n, 0.0);
+      std::vector<char> touched(n, 0);
+      for (int l = 0; l < nl; ++l) {
+        const int f = d->line_or_sub[l], t = d->line_ex_sub[l];
+        touched[f] = touched[t] = 1;
+        if (f == t) continue;
+        const double bb = d->br_bdc[l];
+        if (!is_ref[f]) M[(size_t)f * 2 * n + f] += bb;
+        if (!is_ref[t]) M[(size_t)t * 2 * n + t] += bb;
+        if (!is_ref[f] && !is_ref[t]) { M[(size_t)f * 2 * n + t] -= bb; M[(size_t)t * 2 * n + f] -= bb; }
+      }
+      bool ok = true;
+      for (int i = 0; i < n; ++i) { if (is_ref[i]) M[(size_t)i * 2 * n + i] = 1.0; if (!touched[i]) ok = false; M[(size_t)i * 2 * n + n + i] = 1.0; }
+      for (int k = 0; k < n && ok; ++k) {                          // Gauss-Jordan, partial pivoting
+        int pv = k;
+        for (int r = k + 1; r < n; ++r) if (std::fabs(M[(size_t)r * 2 * n + k]) > std::fabs(M[(size_t)pv * 2 * n + k])) pv = r;
+        if (!(std::fabs(M[(size_t)pv * 2 * n + k]) > 1e-12)) { ok = false; break; }
+        if (pv != k) for (int q = 0; q < 2 * n; ++q) std::swap(M[(size_t)k * 2 * n + q], M[(size_t)pv * 2 * n + q]);
+        const double piv = M[(size_t)k * 2 * n + k];
+        for (int q = 0; q < 2 * n; ++q) M[(size_t)k * 2 * n + q] /= piv;
+        for (int r = 0; r < n; ++r) if (r != k) {
+          const double m = M[(size_t)r * 2 * n + k];
+          if (m != 0.0) for (int q = 0; q < 2 * n; ++q) M[(size_t)r * 2 * n + q] -= m * M[(size_t)k * 2 * n + q];
+        }
+      }
+      if (ok) {
+        std::vector<double> cm((size_t)n * n);
+        for (int i = 0; i < n; ++i) for (int k = 0; k < n; ++k) cm[(size_t)k * n + i] = M[(size_t)i * 2 * n + n + k];
+        so.dc_inv = putd(cm.data(), cm.size());
+      }
+    }
     so.prog = puti(S.prog.data(), S.prog.size());                // 16-byte aligned: level headers are read as int4
     { std::vector<int> rc(S.nslot_y); for (int k = 0; k < S.nslot_y; ++k) rc[k] = S.slot_row[k] | (S.slot_col[k] << 16); so.pair_rc = puti(rc.data(), rc.size()); }
     so.n_int_hot = (int)fi.size();

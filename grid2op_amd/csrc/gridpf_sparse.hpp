@@ -23,6 +23,8 @@ struct StatOff {
   int n_int_hot;   // the int section starts with the tables of the Newton loop (prog, pair_rc): staging tier 1 copies only these
   int br_y, br_bdc, sub_vn_kv, shunt_fact, gen_min_q, gen_max_q;
   int line_vn, load_vn, gen_vn, sto_vn, shunt_vn;   // nominal kV of the substation of every element (line: [n_line][2] = or, ex)
+  int dc_inv;      // >= 0: [n_sub][n_sub] COLUMN-major inverse of the DC matrix B' of the reference topology (every line in service,
+                   // every slack generator connected; reference / fixed rows are identity), small grids only; -1: none
   int line_or_pos, line_ex_pos, line_or_sub, line_ex_sub, br_slot, gen_pos, gen_sub, gen_slack, load_pos, load_sub, sto_pos,
       sto_sub, shunt_sub, pair_rc, prog;
 };
@@ -42,7 +44,7 @@ struct SP {
 template <int STAGE>
 struct StatView {
   static constexpr bool ALL = STAGE == 2, HOT = STAGE >= 1;
-  SP<double, ALL> br_y, br_bdc, sub_vn_kv, shunt_fact, gen_min_q, gen_max_q, line_vn, load_vn, gen_vn, sto_vn, shunt_vn;
+  SP<double, ALL> br_y, br_bdc, sub_vn_kv, shunt_fact, gen_min_q, gen_max_q, line_vn, load_vn, gen_vn, sto_vn, shunt_vn, dc_inv;
   SP<int, ALL> line_or_pos, line_ex_pos, line_or_sub, line_ex_sub, br_slot, gen_pos, gen_sub, gen_slack, load_pos, load_sub,
       sto_pos, sto_sub, shunt_sub;
   SP<int, HOT> pair_rc;   // [nslot_y] slot_row | slot_col << 16 of the original-pattern blocks
@@ -53,6 +55,7 @@ template <int STAGE>
 __device__ inline void stat_view(StatView<STAGE>& v, const StatOff& o, const double* d, const int* i) {
   v.br_y.p = d + o.br_y; v.br_bdc.p = d + o.br_bdc; v.sub_vn_kv.p = d + o.sub_vn_kv; v.shunt_fact.p = d + o.shunt_fact;
   v.gen_min_q.p = d + o.gen_min_q; v.gen_max_q.p = d + o.gen_max_q;
+  v.dc_inv.p = d + (o.dc_inv >= 0 ? o.dc_inv : 0);
   v.line_vn.p = d + o.line_vn; v.load_vn.p = d + o.load_vn; v.gen_vn.p = d + o.gen_vn; v.sto_vn.p = d + o.sto_vn; v.shunt_vn.p = d + o.shunt_vn;
   v.line_or_pos.p = i + o.line_or_pos; v.line_ex_pos.p = i + o.line_ex_pos; v.line_or_sub.p = i + o.line_or_sub;
   v.line_ex_sub.p = i + o.line_ex_sub; v.br_slot.p = i + o.br_slot; v.gen_pos.p = i + o.gen_pos; v.gen_sub.p = i + o.gen_sub;
@@ -734,6 +737,7 @@ struct SolveCtl {
 struct TopoState {
   int status;         // 0, GPF_ST_NOSLACK or GPF_ST_ISLANDED
   int nb;             // number of active buses
+  bool dc_base;       // the DC matrix of this topology is the reference one (StatOff::dc_inv applies)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -802,7 +806,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     if (TC) return sv.node_of[sub * g.n_busbar + (local - 1)];
     return (NB == 1) ? sub : sub * NB + (local - 1);
   };
-  bool line_off = false;
+  bool line_off = false, slack_off = false;
   if (!reuse)
   for (int l = tid; l < g.n_line; l += GW) {
     const int bo = topo[sv.line_or_pos[l]], be = topo[sv.line_ex_pos[l]];
@@ -826,6 +830,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       const int sb = sv.gen_sub[i];
       bu = lb >= 1 ? bus_of(sb, lb) : -1;
       c.gen_b[i] = (i16)bu;
+      slack_off |= sl && bu < 0;
       if (bu >= 0) {
         atomicMax(&c.btype[bu], sl ? BT_REF : BT_PV);
         atomicMax(&c.vidx[bu], i);
@@ -913,7 +918,10 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   // connectivity the host checked at gpf_create: nothing to propagate (the DoNothing case).  Otherwise label propagation
   // from the reference buses.
   if (!reuse) {
-  const bool conn_known = (NB == 1) && S.static_connected && !G::any(line_off);
+  const unsigned off_bits = G::template any2<2>(line_off, slack_off);
+  // the DC matrix only depends on which lines are in service and where the reference buses are
+  ts.dc_base = NB == 1 && !TC && S.so.dc_inv >= 0 && off_bits == 0u;
+  const bool conn_known = (NB == 1) && S.static_connected && !(off_bits & 1u);
   if (!G::block_all(conn_known))
   for (int sweep = 0; sweep < nbus; ++sweep) {
     int changed = 0;
@@ -940,12 +948,17 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   // ---- K2: block Ybus (original pattern) + K3: DC matrix in the block array, both with LDS atomics ----------------------------
   // (reuse: the Ybus blocks stand; the DC matrix is rebuilt unless its factors were kept)
   const bool do_y = !reuse && !is_dc;
+  // reference topology on a small grid: theta = inv(B') P with the static inverse (one matrix-vector phase instead of assembling,
+  // factoring and sweeping the DC system); takes precedence over kept factors.  Uniform over the block: a wavefront whose
+  // groups differ takes the LU path for all of them.
+  const bool dc_inv = NB == 1 && !TC && G::block_all_u(ts.dc_base);
+  const bool dc_skip = dc_kept || dc_inv;              // no DC matrix to assemble
   auto lidx = [&](int bus) -> int { return (NB == 1) ? 0 : bus % NB; };
   if (!warm) {
-  if (!dc_kept || do_y) {
+  if (!dc_skip || do_y) {
   // YR: the Ybus blocks are assembled in the (still unused) row-1 half of the block array and then moved to registers
   double* const ydst = YR ? c.A + HS : c.Yb;
-  if (!dc_kept) for (int i = tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
+  if (!dc_skip) for (int i = tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
   if (do_y) for (int i = tid; i < S.nslot_y * NB * NB * 2; i += GW) ydst[i] = 0.0;
   GPF_LSYNC();
   for (int l = tid; l < g.n_line; l += GW) {
@@ -961,7 +974,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       y = ydst + ((size_t)stf * NB * NB + bj * NB + bi) * 2; atomicAdd(&y[0], yb.x); atomicAdd(&y[1], yb.y);
       y = ydst + ((size_t)stt * NB * NB + bj * NB + bj) * 2; atomicAdd(&y[0], yb.z); atomicAdd(&y[1], yb.w);
     }
-    if (f != t && !dc_kept) {
+    if (f != t && !dc_skip) {
       const double bb = sv.br_bdc[l];
       const bool ff_ = c.btype[f] != BT_REF, tf_ = c.btype[t] != BT_REF;     // theta row / column live?
       const int rf = 2 * bi, rt = 2 * bj;
@@ -1002,7 +1015,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
     const int bt = c.btype[i];
     const bool th_live = (bt == BT_PQ || bt == BT_PV);
-    if (!dc_kept) {
+    if (!dc_skip) {
       if (!th_live) *bel(sub, 2 * bi, 2 * bi) = 1.0;
       *bel(sub, 2 * bi + 1, 2 * bi + 1) = 1.0;                   // |V| rows are identity in the DC system
     }
@@ -1031,19 +1044,28 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   };
   if (!warm) {
 #ifdef GPF_TIMING
-    bool ok = (NB == 1) ? lu_dc(&stamps.v[20])
-                        : lu_ac(&stamps.v[20]);
+    bool ok = dc_inv ? true : (NB == 1) ? lu_dc(&stamps.v[20])
+                                        : lu_ac(&stamps.v[20]);
 #else
-    bool ok = (NB == 1) ? lu_dc(nullptr) : lu_ac(nullptr);
+    bool ok = dc_inv ? true : (NB == 1) ? lu_dc(nullptr) : lu_ac(nullptr);
 #endif
     for (int i = tid; i < nbus; i += GW) {
-      const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
-      const double th = *rhsT(i);
+      double th;
+      if (dc_inv) {                                                 // row i of inv(B') (column-major table) times the right-hand side
+        double t0 = 0.0, t1 = 0.0;                                  // two chains: half the dependent-FMA depth
+        int k = 0;
+        for (; k + 1 < nbus; k += 2) {
+          t0 = fma(sv.dc_inv[k * nbus + i], *rhsT(k), t0);
+          t1 = fma(sv.dc_inv[(k + 1) * nbus + i], *rhsT(k + 1), t1);
+        }
+        if (k < nbus) t0 = fma(sv.dc_inv[k * nbus + i], *rhsT(k), t0);
+        th = t0 + t1;
+      } else th = *rhsT(i);
       const int bt = c.btype[i];
       c.va[i] = (bt == BT_PQ || bt == BT_PV) ? th : 0.0;
       if (bt != BT_OFF && !(fabs(th) < 1e300)) ok = false;
     }
-    if (NB == 1 && ctl.dcf && !dc_kept)                            // keep the factors for the next solves of this launch
+    if (NB == 1 && ctl.dcf && !dc_skip)                            // keep the factors for the next solves of this launch
       for (int q = tid; q < S.nslot; q += GW) c.Adc[q] = c.A[(size_t)q * 2];
     GPF_LSYNC();
     if (status == 0 && G::any(!ok)) status = 4;

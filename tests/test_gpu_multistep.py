@@ -364,6 +364,35 @@ def test_split_batches_in_every_kernel_mode(mode, load_model, load_npz):
     e2.close()
 
 
+@pytest.mark.parametrize("name,B", [("l2rpn_case14_sandbox", 26), ("rte_case5_example", 12), ("educ_case14_storage", 8)])
+def test_static_dc_inverse_equals_the_dc_solve(name, B, load_model, load_npz):
+    """Small grids: lanes in the reference topology get their DC initialisation from the static inverse of B' (one
+    matrix-vector phase), the others -- here every third lane has a line out, so that wavefronts mix both kinds -- from the DC
+    factorisation.  GRIDPF_NO_DCINV=1 (always factorise) must give the same power flows."""
+    m, ch, e1, tab, off, scale = _setup(load_model, load_npz, name, B)
+    _, _, e2, _, _, _ = _setup(load_model, load_npz, name, B, env={"GRIDPF_NO_DCINV": "1"})
+    topo = np.tile(m.initial_topo_vect(), (B, 1))
+    for k in range(0, B, 3):
+        l = (k // 3) % m.n_line
+        topo[k, m.line_or_pos_topo_vect[l]] = -1
+        topo[k, m.line_ex_pos_topo_vect[l]] = -1
+    for e in (e1, e2):
+        e.set_topology(topo)
+    for t, n in ((0, 1), (1, 4), (5, 1), (6, 3)):
+        e1.step(t, n_steps=n, rebalance=1.02)
+        e2.step(t, n_steps=n, rebalance=1.02)
+        _same(_snapshot(e1), _snapshot(e2), (name, t))
+    st = e1.results().status
+    assert (st[np.arange(B) % 3 != 0, 0] == 0).all()                # (some single-line outages may island a bus: those lanes may fail in both)
+    e1.runpf(0, B, is_dc=True)
+    e2.runpf(0, B, is_dc=True)
+    a, b = e1.results(), e2.results()
+    assert np.array_equal(a.status[:, 0], b.status[:, 0])
+    assert np.allclose(a.out, b.out, rtol=2e-6, atol=2e-5, equal_nan=True)
+    e1.close()
+    e2.close()
+
+
 @pytest.mark.parametrize("name", ["l2rpn_case14_sandbox", "l2rpn_neurips_2020_track1"])
 def test_device_rollout_reproduces_the_reference_environment(name, load_model, load_npz):
     """A DoNothing rollout of the UNMODIFIED reference Environment (default parameters: overflow disconnections on; all the
