@@ -140,6 +140,7 @@ struct gpf_engine {
   DevArr<double> lodf;             // [n_line][line_pad] line outage distribution factors of the PTDF topology (NaN column: islanding outage)
   std::vector<double> h_ptdf;      // [n_line][nb_tot]
   std::vector<double> h_br_bdc, h_shunt_fact;
+  std::vector<int> h_gen_cnt;
   int ptdf_nb_pad = 0, ptdf_line_pad = 0;
   bool ptdf_ready = false;
   DevArr<double> stat_dbl;     // static blob of kernel S (gpf::StatOff)
@@ -735,6 +736,18 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
       { auto v = vn_of(d->storage_sub, ns); so.sto_vn = putd(v.data(), v.size()); }
       { auto v = vn_of(d->shunt_sub, nsh); so.shunt_vn = putd(v.data(), v.size()); }
     }
+    {   // per-generator totals over the generators of its substation (pfsoln's reactive split when every generator is connected)
+      std::vector<double> qmn(g.n_sub, 0.0), qmx(g.n_sub, 0.0), a(ng), b(ng);
+      std::vector<int> cn(g.n_sub, 0), nsl(g.n_sub, 0), w(ng);
+      for (int i = 0; i < ng; ++i) {
+        const int sb = d->gen_sub[i];
+        cn[sb] += 1; qmn[sb] += d->gen_min_q[i]; qmx[sb] += d->gen_max_q[i];
+        if (d->gen_slack[i]) nsl[sb] += 1;
+      }
+      for (int i = 0; i < ng; ++i) { const int sb = d->gen_sub[i]; a[i] = qmn[sb]; b[i] = qmx[sb]; w[i] = cn[sb] | (nsl[sb] << 16); }
+      so.gen_qmin_tot = putd(a.data(), a.size()); so.gen_qmax_tot = putd(b.data(), b.size());
+      e->h_gen_cnt = w;
+    }
     so.dc_inv = -1;
     if (g.n_sub <= 24 && !std::getenv("GRIDPF_NO_DCINV")) {
       // inverse of the DC matrix of the reference topology (every line in service, reference buses = substations of the slack
@@ -784,6 +797,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     so.load_pos = puti(d->load_pos_topo_vect, nd); so.load_sub = puti(d->load_sub, nd);
     so.sto_pos = puti(d->storage_pos_topo_vect, ns); so.sto_sub = puti(d->storage_sub, ns);
     so.shunt_sub = puti(d->shunt_sub, nsh);
+    so.gen_cnt = puti(e->h_gen_cnt.data(), e->h_gen_cnt.size());
     so.n_dbl = (int)fd.size(); so.n_int = (int)fi.size();
     hipError_t eu = e->stat_dbl.upload(fd.data(), fd.size());
     if (eu == hipSuccess) eu = e->stat_int.upload(fi.data(), fi.size());

@@ -23,6 +23,9 @@ struct StatOff {
   int n_int_hot;   // the int section starts with the tables of the Newton loop (prog, pair_rc): staging tier 1 copies only these
   int br_y, br_bdc, sub_vn_kv, shunt_fact, gen_min_q, gen_max_q;
   int line_vn, load_vn, gen_vn, sto_vn, shunt_vn;   // nominal kV of the substation of every element (line: [n_line][2] = or, ex)
+  int gen_qmin_tot, gen_qmax_tot;   // [n_gen] sum of min_q / max_q over the generators of the generator's substation (every generator
+                                    // connected, single busbar): what pfsoln's reactive split needs, per generator
+  int gen_cnt;     // (int section) [n_gen] generators | slack generators << 16 of the generator's substation, same assumption
   int dc_inv;      // >= 0: [n_sub][n_sub] COLUMN-major inverse of the DC matrix B' of the reference topology (every line in service,
                    // every slack generator connected; reference / fixed rows are identity), small grids only; -1: none
   int line_or_pos, line_ex_pos, line_or_sub, line_ex_sub, br_slot, gen_pos, gen_sub, gen_slack, load_pos, load_sub, sto_pos,
@@ -44,9 +47,9 @@ struct SP {
 template <int STAGE>
 struct StatView {
   static constexpr bool ALL = STAGE == 2, HOT = STAGE >= 1;
-  SP<double, ALL> br_y, br_bdc, sub_vn_kv, shunt_fact, gen_min_q, gen_max_q, line_vn, load_vn, gen_vn, sto_vn, shunt_vn, dc_inv;
+  SP<double, ALL> br_y, br_bdc, sub_vn_kv, shunt_fact, gen_min_q, gen_max_q, line_vn, load_vn, gen_vn, sto_vn, shunt_vn, dc_inv, gen_qmin_tot, gen_qmax_tot;
   SP<int, ALL> line_or_pos, line_ex_pos, line_or_sub, line_ex_sub, br_slot, gen_pos, gen_sub, gen_slack, load_pos, load_sub,
-      sto_pos, sto_sub, shunt_sub;
+      sto_pos, sto_sub, shunt_sub, gen_cnt;
   SP<int, HOT> pair_rc;   // [nslot_y] slot_row | slot_col << 16 of the original-pattern blocks
   SP<int, HOT> prog;      // level-scheduled program (layout: gridpf_symbolic.hpp)
   SP<int, false> node_of; // topology-class launches only (TopoClassDev::node_of)
@@ -56,6 +59,7 @@ __device__ inline void stat_view(StatView<STAGE>& v, const StatOff& o, const dou
   v.br_y.p = d + o.br_y; v.br_bdc.p = d + o.br_bdc; v.sub_vn_kv.p = d + o.sub_vn_kv; v.shunt_fact.p = d + o.shunt_fact;
   v.gen_min_q.p = d + o.gen_min_q; v.gen_max_q.p = d + o.gen_max_q;
   v.dc_inv.p = d + (o.dc_inv >= 0 ? o.dc_inv : 0);
+  v.gen_qmin_tot.p = d + o.gen_qmin_tot; v.gen_qmax_tot.p = d + o.gen_qmax_tot; v.gen_cnt.p = i + o.gen_cnt;
   v.line_vn.p = d + o.line_vn; v.load_vn.p = d + o.load_vn; v.gen_vn.p = d + o.gen_vn; v.sto_vn.p = d + o.sto_vn; v.shunt_vn.p = d + o.shunt_vn;
   v.line_or_pos.p = i + o.line_or_pos; v.line_ex_pos.p = i + o.line_ex_pos; v.line_or_sub.p = i + o.line_or_sub;
   v.line_ex_sub.p = i + o.line_ex_sub; v.br_slot.p = i + o.br_slot; v.gen_pos.p = i + o.gen_pos; v.gen_sub.p = i + o.gen_sub;
@@ -336,11 +340,19 @@ struct Grp {
   // two flags at once (bit 0 = any(a), bit 1 = any(b)).  Several wavefronts per instance: ONE exchange through LDS and ONE
   // barrier instead of two __syncthreads_or (two barriers each); BUF selects the exchange buffer -- two calls with the same BUF
   // must be separated by at least one other workgroup barrier (the slower wavefront may still be reading).
-  template <int BUF>
-  static __device__ __forceinline__ unsigned any2(bool a, bool b) {
+  template <int BUF, int N>
+  static __device__ __forceinline__ unsigned any_bits(unsigned lane_bits) {      // bit k of the result = any lane has bit k set
+    unsigned w = 0;
+    if (WPI > 1 || IPW == 1) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) w |= (__ballot((lane_bits >> k) & 1u) != 0ull ? 1u : 0u) << k;
+    } else {
+      const unsigned long long m = mask();
+#pragma unroll
+      for (int k = 0; k < N; ++k) w |= ((__ballot((lane_bits >> k) & 1u) & m) != 0ull ? 1u : 0u) << k;
+    }
     if (WPI > 1) {
       __shared__ unsigned redb_[4][WPI > 1 ? WPI : 1];
-      const unsigned w = (__ballot(a) != 0ull ? 1u : 0u) | (__ballot(b) != 0ull ? 2u : 0u);
       if ((threadIdx.x & (WAVE - 1)) == 0) redb_[BUF][threadIdx.x / WAVE] = w;
       __syncthreads();
       unsigned r = 0;
@@ -348,10 +360,10 @@ struct Grp {
       for (int k = 0; k < WPI; ++k) r |= redb_[BUF][k];
       return r;
     }
-    if (IPW == 1) return (__any(a) ? 1u : 0u) | (__any(b) ? 2u : 0u);
-    const unsigned long long m = mask();
-    return ((__ballot(a) & m) != 0ull ? 1u : 0u) | ((__ballot(b) & m) != 0ull ? 2u : 0u);
+    return w;
   }
+  template <int BUF>
+  static __device__ __forceinline__ unsigned any2(bool a, bool b) { return any_bits<BUF, 2>((a ? 1u : 0u) | (b ? 2u : 0u)); }
   // two sums at once (several wavefronts per instance: one exchange, one barrier; same BUF rule as any2)
   template <int BUF>
   static __device__ __forceinline__ void sum2(double& a, double& b) {
@@ -738,6 +750,7 @@ struct TopoState {
   int status;         // 0, GPF_ST_NOSLACK or GPF_ST_ISLANDED
   int nb;             // number of active buses
   bool dc_base;       // the DC matrix of this topology is the reference one (StatOff::dc_inv applies)
+  bool gen_base;      // every generator is connected (single-busbar layout): the static per-generator bus totals apply
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -806,7 +819,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     if (TC) return sv.node_of[sub * g.n_busbar + (local - 1)];
     return (NB == 1) ? sub : sub * NB + (local - 1);
   };
-  bool line_off = false, slack_off = false;
+  bool line_off = false, slack_off = false, gen_off = false;
   if (!reuse)
   for (int l = tid; l < g.n_line; l += GW) {
     const int bo = topo[sv.line_or_pos[l]], be = topo[sv.line_ex_pos[l]];
@@ -831,6 +844,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       bu = lb >= 1 ? bus_of(sb, lb) : -1;
       c.gen_b[i] = (i16)bu;
       slack_off |= sl && bu < 0;
+      gen_off |= bu < 0;
       if (bu >= 0) {
         atomicMax(&c.btype[bu], sl ? BT_REF : BT_PV);
         atomicMax(&c.vidx[bu], i);
@@ -918,9 +932,10 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   // connectivity the host checked at gpf_create: nothing to propagate (the DoNothing case).  Otherwise label propagation
   // from the reference buses.
   if (!reuse) {
-  const unsigned off_bits = G::template any2<2>(line_off, slack_off);
+  const unsigned off_bits = G::template any_bits<2, 3>((line_off ? 1u : 0u) | (slack_off ? 2u : 0u) | (gen_off ? 4u : 0u));
+  ts.gen_base = NB == 1 && !TC && !(off_bits & 4u);
   // the DC matrix only depends on which lines are in service and where the reference buses are
-  ts.dc_base = NB == 1 && !TC && S.so.dc_inv >= 0 && off_bits == 0u;
+  ts.dc_base = NB == 1 && !TC && S.so.dc_inv >= 0 && (off_bits & 3u) == 0u;
   const bool conn_known = (NB == 1) && S.static_connected && !(off_bits & 1u);
   if (!G::block_all(conn_known))
   for (int sweep = 0; sweep < nbus; ++sweep) {
@@ -1286,33 +1301,40 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     double* qmax_t = c.A + nbus;
     int* cnt = reinterpret_cast<int*>(c.A + 2 * (size_t)nbus);
     int* nsl = cnt + nbus;
-    GPF_LSYNC();
-    for (int i = tid; i < nbus; i += GW) { qmin_t[i] = 0.0; qmax_t[i] = 0.0; cnt[i] = 0; nsl[i] = 0; }
-    GPF_LSYNC();
-    for (int i = tid; i < g.n_gen; i += GW) {
-      const int bu = c.gen_b[i];
-      if (bu < 0) continue;
-      atomicAdd(&cnt[bu], 1);
-      atomicAdd(&qmin_t[bu], sv.gen_min_q[i]);
-      atomicAdd(&qmax_t[bu], sv.gen_max_q[i]);
-      if (sv.gen_slack[i]) atomicAdd(&nsl[bu], 1);
+    // every generator connected (single-busbar layout): the per-bus totals are the static per-generator tables of the grid
+    const bool gen_static = NB == 1 && !TC && G::block_all_u(ts.gen_base);
+    if (!gen_static) {
+      GPF_LSYNC();
+      for (int i = tid; i < nbus; i += GW) { qmin_t[i] = 0.0; qmax_t[i] = 0.0; cnt[i] = 0; nsl[i] = 0; }
+      GPF_LSYNC();
+      for (int i = tid; i < g.n_gen; i += GW) {
+        const int bu = c.gen_b[i];
+        if (bu < 0) continue;
+        atomicAdd(&cnt[bu], 1);
+        atomicAdd(&qmin_t[bu], sv.gen_min_q[i]);
+        atomicAdd(&qmax_t[bu], sv.gen_max_q[i]);
+        if (sv.gen_slack[i]) atomicAdd(&nsl[bu], 1);
+      }
+      GPF_LSYNC();
     }
-    GPF_LSYNC();
     GPF_STAMPS(24);
     for (int i = tid; i < g.n_gen; i += GW) {
       const int bu = c.gen_b[i];
       float gp = 0.f, gq = 0.f, gv = 0.f, gth = 0.f;
       if (bu >= 0) {
         const double qtot = (*SimP(bu) - c.Qsp[bu]) * sn;
-        const int cn = cnt[bu];
+        int cn, ns;
+        double qmn, qmx;
+        if (gen_static) { const int w = sv.gen_cnt[i]; cn = w & 0xffff; ns = w >> 16; qmn = sv.gen_qmin_tot[i]; qmx = sv.gen_qmax_tot[i]; }
+        else { cn = cnt[bu]; ns = nsl[bu]; qmn = qmin_t[bu]; qmx = qmax_t[bu]; }
         const double mn = sv.gen_min_q[i], mx = sv.gen_max_q[i];
         double q;
         if (is_dc) q = 0.0;
         else if (cn == 1) q = qtot;
-        else if (qmin_t[bu] == qmax_t[bu]) q = qtot / cn;
-        else q = mn + (qtot - qmin_t[bu]) / (qmax_t[bu] - qmin_t[bu] + 2.220446049250313e-16) * (mx - mn);
+        else if (qmn == qmx) q = qtot / cn;
+        else q = mn + (qtot - qmn) / (qmx - qmn + 2.220446049250313e-16) * (mx - mn);
         double p = GPF_INJ(oo.inj_gen_p + i);
-        if (sv.gen_slack[i]) p = (*SreP(bu) - c.Psp[bu]) * sn / nsl[bu];
+        if (sv.gen_slack[i]) p = (*SreP(bu) - c.Psp[bu]) * sn / ns;
         gp = (float)p; gq = (float)q;
         gv = (float)(c.vm[bu] * sv.gen_vn[i]);
         gth = (float)(c.va[bu] * RAD2DEG);
@@ -1396,7 +1418,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   SolveCtl ctl;
   ctl.inj_staged = false; ctl.topo_staged = false; ctl.reuse = false; ctl.dcf = false; ctl.write_bus = true; ctl.warm = false;
   TopoState ts;
-  ts.status = 0; ts.nb = 0;
+  ts.status = 0; ts.nb = 0; ts.dc_base = false; ts.gen_base = false;
   const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, is_dc, max_iter, tol_pu, tid, ctl, ts, n_iter, nb GPF_STAMPS_ARG);
   GPF_SYNC();
   if (st != 0) write_nan_results<GW>(P->g, P->b, inst, tid);
@@ -1445,7 +1467,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   if (has_delta && tid < g.n_gen) gd0 = gptr(b.lane_gen_delta)[(size_t)inst * g.n_gen + tid];
   if (STAGE) { const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj; for (int i = oo.inj_sto_p + tid; i < g.n_inj; i += GW) c.inj[i] = inj_g[i]; }   // storage / shunt set-points
   TopoState ts;
-  ts.status = 0; ts.nb = 0;
+  ts.status = 0; ts.nb = 0; ts.dc_base = false; ts.gen_base = false;
   bool reuse = false;                                         // block-uniform
   int n_iter = 0, nb = 0, st = 0, rounds = 0;
   int ep_steps = 0, ep_resets = 0;
