@@ -742,6 +742,8 @@ struct SolveCtl {
                       // connectivity verdict and Ybus blocks in LDS are valid (and the DC factors when dcf)
   bool dcf;           // CarveP::Adc holds / receives the factored DC matrix (NB == 1)
   bool write_bus;     // write the float64 bus voltages (parity checks, the facade's stale-bus angles)
+  bool sums_done;     // (with reuse) the caller already accumulated the bus injections Psp / Qsp / Gs of this solve (step kernel: K9
+                      // scatters every element's new set-point as it computes it)
   bool warm;          // OPT-IN, not the reference's algorithm: with `reuse`, Newton starts from the previous solve's voltages
                       // (CarveP::va / vm still hold them) instead of the DC initialisation pandapower does on every call
 };
@@ -807,12 +809,15 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   // ---- K1: element -> bus, bus activity / types / injections with LDS atomics from the element lanes ---------------------
   // (reuse: the maps and types of the previous solve stand, only the injection sums are rebuilt)
   if (!reuse && !ctl.topo_staged) for (int i = tid; i < g.dim_topo; i += GW) c.topo[i] = topo_g[i];
+  const bool sums_done = reuse && ctl.sums_done;
+  if (!sums_done) {
   for (int i = tid; i < nbus; i += GW) {
     if (!reuse) { c.btype[i] = BT_OFF; c.vidx[i] = -1; }
     c.Psp[i] = 0.0; c.Qsp[i] = 0.0; c.Gs[i] = 0.0;
   }
   if (NB == 1 && !TC && !reuse) for (int i = tid; i < nsub; i += GW) c.sub_bb[i] = 1;
   GPF_LSYNC();
+  }
   GPF_STAMPS(27);
   const int* topo = c.topo;
   auto bus_of = [&](int sub, int local) -> int {
@@ -820,6 +825,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     return (NB == 1) ? sub : sub * NB + (local - 1);
   };
   bool line_off = false, slack_off = false, gen_off = false;
+  if (!sums_done) {
   if (!reuse)
   for (int l = tid; l < g.n_line; l += GW) {
     const int bo = topo[sv.line_or_pos[l]], be = topo[sv.line_ex_pos[l]];
@@ -900,6 +906,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       }
     } else bu = c.sh_b[i];
     if (bu >= 0) atomicAdd(&c.Gs[bu], GPF_INJ(oo.inj_sh_p + i) * sv.shunt_fact[i] * inv_sn);
+  }
   }
   GPF_LSYNC();
   GPF_STAMPS(28);
@@ -1416,7 +1423,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   int n_iter, nb;
   GPF_STAMPS_DECL;
   SolveCtl ctl;
-  ctl.inj_staged = false; ctl.topo_staged = false; ctl.reuse = false; ctl.dcf = false; ctl.write_bus = true; ctl.warm = false;
+  ctl.inj_staged = false; ctl.topo_staged = false; ctl.reuse = false; ctl.dcf = false; ctl.write_bus = true; ctl.warm = false; ctl.sums_done = false;
   TopoState ts;
   ts.status = 0; ts.nb = 0; ts.dc_base = false; ts.gen_base = false;
   const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, is_dc, max_iter, tol_pu, tid, ctl, ts, n_iter, nb GPF_STAMPS_ARG);
@@ -1487,6 +1494,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
     const bool last = step + 1 == sa.n_steps;
     GPF_STAMPS(19);
     // ---- K9: chronics row -> injections -----------------------------------------------------------------------------------
+    bool sums_in_k9 = false;
     {
       const auto ch = gptr(b.chron) + ((size_t)tab * sa.T + row) * g.n_chron;
       const auto sc = gptr(b.lane_scale) + (size_t)inst * 2 * g.n_load;
@@ -1515,6 +1523,15 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       const float pp_pre = tid < g.n_gen ? ch[2 * g.n_load + tid] : 0.f;
       const float pv_pre = tid < g.n_gen ? ch[2 * g.n_load + g.n_gen + tid] : 1.f;
       double sum_load = 0.0, sum_prod = 0.0;
+      // The element -> bus maps stand (reuse): every element adds its new set-point to the bus sums Psp / Qsp / Gs right here
+      // (the same LDS atomics K1 would issue from four more loops over the injection row, SolveCtl::sums_done)
+      sums_in_k9 = reuse;
+      const double inv_sn9 = 1.0 / g.sn_mva;
+      if (sums_in_k9) {
+        const int nbus9 = TC ? S.n : g.n_sub * NB;
+        for (int i = tid; i < nbus9; i += GW) { c.Psp[i] = 0.0; c.Qsp[i] = 0.0; c.Gs[i] = 0.0; }
+        GPF_LSYNC();
+      }
       GPF_STAMPS(16);
       for (int i = tid; i < g.n_load; i += GW) {
         float lp = ch[i], lq = ch[g.n_load + i];
@@ -1522,6 +1539,10 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
         if (STAGE) { c.inj[oo.inj_load_p + i] = (double)lp; c.inj[oo.inj_load_q + i] = (double)lq; }   // HBM copy: end of kernel
         else { inj_g[oo.inj_load_p + i] = (double)lp; inj_g[oo.inj_load_q + i] = (double)lq; }
         sum_load += (double)lp;
+        if (sums_in_k9) {
+          const int bu = c.load_b[i];
+          if (bu >= 0) { atomicAdd(&c.Psp[bu], -(double)lp * inv_sn9); atomicAdd(&c.Qsp[bu], -(double)lq * inv_sn9); }
+        }
       }
       for (int i = tid; i < g.n_gen; i += GW)
         if (!sv.gen_slack[i]) sum_prod += (double)(i == tid ? pp_pre : ch[2 * g.n_load + i]);
@@ -1541,6 +1562,28 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
         const double vm_pu = (double)(pv_kv / vn);
         if (STAGE) { c.inj[oo.inj_gen_p + i] = (double)pp; c.inj[oo.inj_gen_vm + i] = vm_pu; }
         else { inj_g[oo.inj_gen_p + i] = (double)pp; inj_g[oo.inj_gen_vm + i] = vm_pu; }
+        if (sums_in_k9) {
+          const int bu = c.gen_b[i];
+          if (bu >= 0 && !sv.gen_slack[i]) atomicAdd(&c.Psp[bu], (double)pp * inv_sn9);
+        }
+      }
+      if (sums_in_k9) {                              // storage and shunt set-points do not change during a launch
+        for (int i = tid; i < g.n_sto; i += GW) {
+          const int bu = c.sto_b[i];
+          if (bu >= 0) {
+            const double sp = STAGE ? c.inj[oo.inj_sto_p + i] : (double)inj_g[oo.inj_sto_p + i];
+            const double sq = STAGE ? c.inj[oo.inj_sto_q + i] : (double)inj_g[oo.inj_sto_q + i];
+            atomicAdd(&c.Psp[bu], -sp * inv_sn9);
+            atomicAdd(&c.Qsp[bu], -sq * inv_sn9);
+          }
+        }
+        for (int i = tid; i < g.n_shunt; i += GW) {
+          const int bu = c.sh_b[i];
+          if (bu >= 0) {
+            const double hp = STAGE ? c.inj[oo.inj_sh_p + i] : (double)inj_g[oo.inj_sh_p + i];
+            atomicAdd(&c.Gs[bu], hp * sv.shunt_fact[i] * inv_sn9);
+          }
+        }
       }
       GPF_SYNC();
     }
@@ -1563,7 +1606,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       // a group whose cascade has ended re-solves its unchanged state along with the others (same results)
       int it_k = 0, nb_k = 0;
       SolveCtl ctl;
-      ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && !TC && sa.n_steps > 1; ctl.write_bus = last; ctl.warm = sa.warm_start != 0;
+      ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && !TC && sa.n_steps > 1; ctl.write_bus = last; ctl.warm = sa.warm_start != 0; ctl.sums_done = first && sums_in_k9;
       const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, sa.is_dc, max_iter, tol_pu, tid, ctl, ts, it_k, nb_k GPF_STAMPS_ARG);
       first = false;
       GPF_SYNC();
