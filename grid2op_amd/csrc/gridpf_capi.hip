@@ -318,6 +318,8 @@ int topo_class_of(gpf_engine* e, const int* topo, const int* shunt_bus) {
   std::vector<int> rc(S.nslot_y);
   for (int k = 0; k < S.nslot_y; ++k) rc[k] = S.slot_row[k] | (S.slot_col[k] << 16);
   const int o_rc = puti(rc.data(), rc.size());
+  const std::vector<int> upv = gpf::build_upairs(S);
+  const int o_up = puti(upv.data(), upv.size());
   const int o_br = puti(S.br_slot.data(), S.br_slot.size());
   const int o_no = puti(node_of.data(), node_of.size());
   if (c->tables.upload(fi.data(), fi.size()) != hipSuccess) { delete c; return -1; }
@@ -345,7 +347,8 @@ int topo_class_of(gpf_engine* e, const int* topo, const int* shunt_bus) {
   }
   D.prog = c->tables.p + o_prog;
   if (!upload_flats(S, c->flat, D)) { c->tables.release(); c->flat.release(); delete c; return -1; }
-  c->dev.pair_rc = c->tables.p + o_rc; c->dev.br_slot = c->tables.p + o_br; c->dev.node_of = c->tables.p + o_no;
+  c->dev.pair_rc = c->tables.p + o_rc; c->dev.up = c->tables.p + o_up; c->dev.br_slot = c->tables.p + o_br; c->dev.node_of = c->tables.p + o_no;
+  D.n_up = (int)upv.size() / 2;
   const int id = (int)e->classes.size();
   e->classes.push_back(c);
   e->class_of_key.emplace(std::move(key), id);
@@ -420,7 +423,7 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
     q.yreg = false;
     // Ybus blocks in registers (2 wavefronts per instance, tables in global memory, at most 4 pairs per lane): when the LDS they
     // free holds the factored DC matrix without costing a block per CU, every step of a launch skips the DC assembly + factorisation
-    if (nbk == 1 && !listed && ipw == 1 && q.wpi == 2 && stage == 0 && !e->no_yreg && e->dcf_env != 0 && e->sym.nslot_y <= 4 * 128) {
+    if (nbk == 1 && !listed && ipw == 1 && q.wpi == 2 && stage == 0 && !e->no_yreg && e->dcf_env != 0 && (e->sym.nslot_y - e->g.n_sub) / 2 <= 4 * 128 && e->g.n_sub <= 128) {
       const size_t ly = gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, 0, 0, false, 1, -1, true);
       if (ly <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / ly >= std::min<size_t>(LDS_HARD_LIMIT / l, want)) { q.yreg = true; q.dcf = 1; q.lds = ly; }
     }
@@ -788,6 +791,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     }
     so.prog = puti(S.prog.data(), S.prog.size());                // 16-byte aligned: level headers are read as int4
     { std::vector<int> rc(S.nslot_y); for (int k = 0; k < S.nslot_y; ++k) rc[k] = S.slot_row[k] | (S.slot_col[k] << 16); so.pair_rc = puti(rc.data(), rc.size()); }
+    { const std::vector<int> upv = gpf::build_upairs(S); so.up = puti(upv.data(), upv.size()); D.n_up = (int)upv.size() / 2; }
     so.n_int_hot = (int)fi.size();
     so.line_or_pos = puti(d->line_or_pos_topo_vect, nl); so.line_ex_pos = puti(d->line_ex_pos_topo_vect, nl);
     so.line_or_sub = puti(d->line_or_sub, nl); so.line_ex_sub = puti(d->line_ex_sub, nl);

@@ -29,7 +29,7 @@ struct StatOff {
   int dc_inv;      // >= 0: [n_sub][n_sub] COLUMN-major inverse of the DC matrix B' of the reference topology (every line in service,
                    // every slack generator connected; reference / fixed rows are identity), small grids only; -1: none
   int line_or_pos, line_ex_pos, line_or_sub, line_ex_sub, br_slot, gen_pos, gen_sub, gen_slack, load_pos, load_sub, sto_pos,
-      sto_sub, shunt_sub, pair_rc, prog;
+      sto_sub, shunt_sub, pair_rc, up, prog;
 };
 // Pointer to a static table that is either staged in LDS or read in place: in place it is re-typed as a GLOBAL pointer
 // (gptr, gridpf_common.hpp) so that global_load is emitted instead of flat_load.
@@ -51,6 +51,7 @@ struct StatView {
   SP<int, ALL> line_or_pos, line_ex_pos, line_or_sub, line_ex_sub, br_slot, gen_pos, gen_sub, gen_slack, load_pos, load_sub,
       sto_pos, sto_sub, shunt_sub, gen_cnt;
   SP<int, HOT> pair_rc;   // [nslot_y] slot_row | slot_col << 16 of the original-pattern blocks
+  SP<int, HOT> up;        // [n_up][2] undirected off-diagonal pairs (gridpf_symbolic.hpp: build_upairs), single-busbar Newton loop
   SP<int, HOT> prog;      // level-scheduled program (layout: gridpf_symbolic.hpp)
   SP<int, false> node_of; // topology-class launches only (TopoClassDev::node_of)
 };
@@ -64,7 +65,7 @@ __device__ inline void stat_view(StatView<STAGE>& v, const StatOff& o, const dou
   v.line_or_pos.p = i + o.line_or_pos; v.line_ex_pos.p = i + o.line_ex_pos; v.line_or_sub.p = i + o.line_or_sub;
   v.line_ex_sub.p = i + o.line_ex_sub; v.br_slot.p = i + o.br_slot; v.gen_pos.p = i + o.gen_pos; v.gen_sub.p = i + o.gen_sub;
   v.gen_slack.p = i + o.gen_slack; v.load_pos.p = i + o.load_pos; v.load_sub.p = i + o.load_sub; v.sto_pos.p = i + o.sto_pos;
-  v.sto_sub.p = i + o.sto_sub; v.shunt_sub.p = i + o.shunt_sub; v.pair_rc.p = i + o.pair_rc; v.prog.p = i + o.prog;
+  v.sto_sub.p = i + o.sto_sub; v.shunt_sub.p = i + o.shunt_sub; v.pair_rc.p = i + o.pair_rc; v.up.p = i + o.up; v.prog.p = i + o.prog;
   v.node_of.p = nullptr;
 }
 // LDS bytes of the staged part of the static data.  Single-busbar kernels (nb1; the old level-header program at the head of the
@@ -87,6 +88,7 @@ __host__ __device__ constexpr int gw_index(int gw) { return gw >= 128 ? 3 : gw >
 
 struct SymDev {
   int n, nslot, nslot_y, n_levels, back_off, n_prog, scale_off, n_scale;
+  int n_up;                 // undirected off-diagonal pairs of the original pattern ((nslot_y - n) / 2)
   int rslot0;               // first right-hand-side pseudo-slot of the single-busbar block array (Symbolic::rslot0)
   const int* flat[4];       // flat programs of the single-busbar kernels, one per group width (gw_index), global memory
   FlatDev fl[4];
@@ -108,6 +110,7 @@ struct SymDev {
 struct TopoClassDev {
   SymDev sym;             // n = number of nodes; prog -> this class's program; stat_* / so: the grid's
   const int* pair_rc;     // [nslot_y]
+  const int* up;          // [sym.n_up][2]
   const int* br_slot;     // [n_line][4]
   const int* node_of;     // [n_sub][n_busbar] node of a (substation, local busbar - 1), -1: that busbar has no element
 };
@@ -230,6 +233,7 @@ __device__ inline void make_stat_view(StatView<STAGE>& sv, const SymDev& S, unsi
     for (int i = threadIdx.x; i < S.so.n_int_hot; i += blockDim.x) si[i] = gi[i];
     sv.prog.p = si + S.so.prog;
     sv.pair_rc.p = si + S.so.pair_rc;
+    sv.up.p = si + S.so.up;
     return;
   }
   double* sd = reinterpret_cast<double*>(lds_static);
@@ -242,6 +246,7 @@ __device__ inline void make_stat_view(StatView<STAGE>& sv, const SymDev& S, unsi
   for (int i = threadIdx.x; i < n_flat; i += blockDim.x) sp[i] = gf[i];
   if (STAGE == 2) stat_view(sv, S.so, sd, si - i0);
   sv.pair_rc.p = si;
+  sv.up.p = si + (S.so.up - i0);
   sv.prog.p = sp;
 }
 
@@ -1026,9 +1031,12 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
 #pragma unroll
     for (int k = 0; k < YR_PASSES; ++k) {
       const int pr = tid + k * GW;
-      yreg[k] = pr < S.nslot_y ? *reinterpret_cast<const double2*>(ydst + (size_t)pr * 2) : make_double2(0.0, 0.0);
-      rcreg[k] = pr < S.nslot_y ? (unsigned)sv.pair_rc[pr] : 0u;
+      const unsigned w0 = pr < S.n_up ? (unsigned)sv.up[2 * pr] : 0u, w1 = pr < S.n_up ? (unsigned)sv.up[2 * pr + 1] : 0u;
+      rcreg[2 * k] = w0; rcreg[2 * k + 1] = w1;
+      yreg[2 * k] = pr < S.n_up ? *reinterpret_cast<const double2*>(ydst + (size_t)(w1 & 0xffffu) * 2) : make_double2(0.0, 0.0);
+      yreg[2 * k + 1] = pr < S.n_up ? *reinterpret_cast<const double2*>(ydst + (size_t)(w1 >> 16) * 2) : make_double2(0.0, 0.0);
     }
+    yreg[2 * YR_PASSES] = tid < nbus ? *reinterpret_cast<const double2*>(ydst + (size_t)tid * 2) : make_double2(0.0, 0.0);   // diagonal block of bus tid
     GPF_LSYNC();                                   // the identity rows below overwrite the scratch
   }
   }
@@ -1116,35 +1124,72 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     else for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;     // fill blocks start at zero
     GPF_LSYNC();
     GPF_STAMPS(10);
-    // tier 0 (pair table in global memory): the word of the first pass stays in a register for the whole Newton loop and the
-    // word of pass k + 1 is fetched before pass k computes -- an L2 round trip per pass is otherwise the longest link of the phase
-    unsigned rc_first = 0;
-    if (STAGE == 0 && !YR && tid < n_pairs) rc_first = (unsigned)sv.pair_rc[tid / (NB * NB)];
+    // Single-busbar layout: ONE lane per undirected pair (u, v) of connected substations computes both Jacobian blocks (u, v) and
+    // (v, u) -- they share every operand but the Ybus block --, and the diagonal block of bus i is built by bus i's lane in the
+    // mismatch phase (which needs S_i anyway): half the passes of one lane per block of the original pattern.
+    // Tier 0 (tables in global memory): the words of the first pass stay in registers for the whole Newton loop and those of pass
+    // k + 1 are fetched before pass k computes -- an L2 round trip per pass is otherwise the longest link of the phase.
+    unsigned rc_first = 0, rc_first1 = 0;
+    if (STAGE == 0 && !YR) {
+      if (NB == 1) { if (tid < S.n_up) { rc_first = (unsigned)sv.up[2 * tid]; rc_first1 = (unsigned)sv.up[2 * tid + 1]; } }
+      else if (tid < n_pairs) rc_first = (unsigned)sv.pair_rc[tid / (NB * NB)];
+    }
+    // T = V_i conj(Y V_j) and the masked block [dP/dth dP/dV; dQ/dth dQ/dV] = [Im T, Re T/|Vj|; -Re T, Im T/|Vj|] of (i, j)
+    auto t_of = [&](const double2 y, double ei, double fi, double ej, double fj, double& tr_, double& ti_) {
+      const double aa = y.x * ej - y.y * fj, bb = y.x * fj + y.y * ej;
+      tr_ = ei * aa + fi * bb;
+      ti_ = fi * aa - ei * bb;
+    };
     while (true) {
       // Jacobian blocks from the Ybus blocks: T_ij = V_i conj(Y_ij V_j); S_i += T_ij (LDS atomics)
-      auto pair_item = [&](int pr, const double2 y, const unsigned rc) {
-        const int slot = pr / (NB * NB), bi = (pr / NB) % NB, bj = pr % NB;
-        const int si = (int)(rc & 0xffffu), sj = (int)(rc >> 16);
-        const int i = si * NB + bi, j = sj * NB + bj;
-        const int bti = c.btype[i], btj = c.btype[j];
-        const double ei = c.e[i], fi = c.f[i], ej = c.e[j], fj = c.f[j], vmj = c.vm[j];
-        const double yr = y.x, yi = y.y;
-        const double aa = yr * ej - yi * fj, bb = yr * fj + yi * ej;
-        const double tr_ = ei * aa + fi * bb;
-        const double ti_ = fi * aa - ei * bb;
-        const bool act = (bti != BT_OFF) && (btj != BT_OFF);
-        const bool rowP = (bti == BT_PQ || bti == BT_PV), rowQ = (bti == BT_PQ);
-        const bool colT = (btj == BT_PQ || btj == BT_PV), colV = (btj == BT_PQ);
-        const double ivmj = fast_rcp(vmj);
-        // [dP/dth dP/dV; dQ/dth dQ/dV] = [Im T, Re T/|Vj|; -Re T, Im T/|Vj|]  (diagonal S-terms are added below)
-        *reinterpret_cast<double2*>(bel(slot, 2 * bi, 2 * bj)) = make_double2((rowP && colT) ? ti_ : 0.0, (rowP && colV) ? tr_ * ivmj : 0.0);
-        *reinterpret_cast<double2*>(bel(slot, 2 * bi + 1, 2 * bj)) = make_double2((rowQ && colT) ? -tr_ : 0.0, (rowQ && colV) ? ti_ * ivmj : 0.0);
-        if (act && (yr != 0.0 || yi != 0.0)) { atomicAdd(SreP(i), tr_); atomicAdd(SimP(i), ti_); }
-      };
-      if (YR) {
+      if (NB == 1) {
+        auto upair_item = [&](const unsigned w0, const unsigned w1, const double2 yuv, const double2 yvu) {
+          const int u = (int)(w0 & 0xffffu), v = (int)(w0 >> 16), suv = (int)(w1 & 0xffffu), svu = (int)(w1 >> 16);
+          const int btu = c.btype[u], btv = c.btype[v];
+          const double eu = c.e[u], fu = c.f[u], vmu = c.vm[u], ev = c.e[v], fv = c.f[v], vmv = c.vm[v];
+          double tr_, ti_, sr_, si_;
+          t_of(yuv, eu, fu, ev, fv, tr_, ti_);
+          t_of(yvu, ev, fv, eu, fu, sr_, si_);
+          const bool act = (btu != BT_OFF) && (btv != BT_OFF);
+          const bool uP = (btu == BT_PQ || btu == BT_PV), uQ = (btu == BT_PQ), vP = (btv == BT_PQ || btv == BT_PV), vQ = (btv == BT_PQ);
+          const double ivmu = fast_rcp(vmu), ivmv = fast_rcp(vmv);
+          *reinterpret_cast<double2*>(bel(suv, 0, 0)) = make_double2((uP && vP) ? ti_ : 0.0, (uP && vQ) ? tr_ * ivmv : 0.0);
+          *reinterpret_cast<double2*>(bel(suv, 1, 0)) = make_double2((uQ && vP) ? -tr_ : 0.0, (uQ && vQ) ? ti_ * ivmv : 0.0);
+          *reinterpret_cast<double2*>(bel(svu, 0, 0)) = make_double2((vP && uP) ? si_ : 0.0, (vP && uQ) ? sr_ * ivmu : 0.0);
+          *reinterpret_cast<double2*>(bel(svu, 1, 0)) = make_double2((vQ && uP) ? -sr_ : 0.0, (vQ && uQ) ? si_ * ivmu : 0.0);
+          if (act && (yuv.x != 0.0 || yuv.y != 0.0)) { atomicAdd(SreP(u), tr_); atomicAdd(SimP(u), ti_); }
+          if (act && (yvu.x != 0.0 || yvu.y != 0.0)) { atomicAdd(SreP(v), sr_); atomicAdd(SimP(v), si_); }
+        };
+        if (YR) {
 #pragma unroll
-        for (int k = 0; k < YR_PASSES; ++k) { const int pr = tid + k * GW; if (pr < n_pairs) pair_item(pr, yreg[k], rcreg[k]); }
+          for (int k = 0; k < YR_PASSES; ++k) if (tid + k * GW < S.n_up) upair_item(rcreg[2 * k], rcreg[2 * k + 1], yreg[2 * k], yreg[2 * k + 1]);
+        } else {
+          unsigned p0 = rc_first, p1 = rc_first1;
+          for (int k = tid; k < S.n_up; k += GW) {
+            unsigned w0, w1;
+            if (STAGE == 0) { w0 = p0; w1 = p1; if (k + GW < S.n_up) { p0 = (unsigned)sv.up[2 * (k + GW)]; p1 = (unsigned)sv.up[2 * (k + GW) + 1]; } }
+            else { w0 = (unsigned)sv.up[2 * k]; w1 = (unsigned)sv.up[2 * k + 1]; }
+            upair_item(w0, w1, *reinterpret_cast<const double2*>(c.Yb + (size_t)(w1 & 0xffffu) * 2),
+                       *reinterpret_cast<const double2*>(c.Yb + (size_t)(w1 >> 16) * 2));
+          }
+        }
       } else {
+        auto pair_item = [&](int pr, const double2 y, const unsigned rc) {
+          const int slot = pr / (NB * NB), bi = (pr / NB) % NB, bj = pr % NB;
+          const int si = (int)(rc & 0xffffu), sj = (int)(rc >> 16);
+          const int i = si * NB + bi, j = sj * NB + bj;
+          const int bti = c.btype[i], btj = c.btype[j];
+          const double ei = c.e[i], fi = c.f[i], ej = c.e[j], fj = c.f[j], vmj = c.vm[j];
+          double tr_, ti_;
+          t_of(y, ei, fi, ej, fj, tr_, ti_);
+          const bool act = (bti != BT_OFF) && (btj != BT_OFF);
+          const bool rowP = (bti == BT_PQ || bti == BT_PV), rowQ = (bti == BT_PQ);
+          const bool colT = (btj == BT_PQ || btj == BT_PV), colV = (btj == BT_PQ);
+          const double ivmj = fast_rcp(vmj);
+          *reinterpret_cast<double2*>(bel(slot, 2 * bi, 2 * bj)) = make_double2((rowP && colT) ? ti_ : 0.0, (rowP && colV) ? tr_ * ivmj : 0.0);
+          *reinterpret_cast<double2*>(bel(slot, 2 * bi + 1, 2 * bj)) = make_double2((rowQ && colT) ? -tr_ : 0.0, (rowQ && colV) ? ti_ * ivmj : 0.0);
+          if (act && (y.x != 0.0 || y.y != 0.0)) { atomicAdd(SreP(i), tr_); atomicAdd(SimP(i), ti_); }
+        };
         unsigned rc_pf = rc_first;
         for (int pr = tid; pr < n_pairs; pr += GW) {
           unsigned rc;
@@ -1162,10 +1207,21 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         double* Ad0 = bel(sub, 2 * bi, 2 * bi);
         double* Ad1 = bel(sub, 2 * bi + 1, 2 * bi);
         const int bt = c.btype[i];
-        const double Sr = *SreP(i), Si = *SimP(i), vmi = c.vm[i], psp = c.Psp[i], qsp = c.Qsp[i];
-        const double2 r0 = *reinterpret_cast<const double2*>(Ad0), r1 = *reinterpret_cast<const double2*>(Ad1);
+        double Sr = *SreP(i), Si = *SimP(i);
+        const double vmi = c.vm[i], psp = c.Psp[i], qsp = c.Qsp[i];
         const bool rowP = (bt == BT_PQ || bt == BT_PV), rowQ = (bt == BT_PQ);
         const double ivmi = fast_rcp(vmi);
+        double2 r0, r1;
+        if (NB == 1) {                           // the diagonal block (i, i) is built here: T_ii joins S_i last
+          const double2 y = YR ? yreg[2 * YR_PASSES] : *reinterpret_cast<const double2*>(c.Yb + (size_t)i * 2);
+          const double ei = c.e[i], fi = c.f[i];
+          double tr_, ti_;
+          t_of(y, ei, fi, ei, fi, tr_, ti_);
+          if (bt != BT_OFF && (y.x != 0.0 || y.y != 0.0)) { Sr += tr_; Si += ti_; }
+          *SreP(i) = Sr; *SimP(i) = Si;          // K6 reads the bus injections of the converged state
+          r0 = make_double2(rowP ? ti_ : 0.0, (rowP && rowQ) ? tr_ * ivmi : 0.0);
+          r1 = make_double2((rowQ && rowP) ? -tr_ : 0.0, rowQ ? ti_ * ivmi : 0.0);
+        } else { r0 = *reinterpret_cast<const double2*>(Ad0); r1 = *reinterpret_cast<const double2*>(Ad1); }
         // dS/dVa_ii += j S_i ; dS/dVm_ii += S_i / |V_i| ; identity on the fixed variables
         *reinterpret_cast<double2*>(Ad0) = make_double2(rowP ? r0.x - Si : 1.0, rowQ ? fma(Sr, ivmi, r0.y) : r0.y);
         *reinterpret_cast<double2*>(Ad1) = make_double2(rowQ ? r1.x + Sr : r1.x, rowQ ? fma(Si, ivmi, r1.y) : 1.0);
@@ -1388,7 +1444,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   if (TC) S_loc = P->classes[gptr(lane_class)[blockIdx.x * IPW]].sym;                                                            \
   pin_sgpr(S_loc.n); pin_sgpr(S_loc.nslot); pin_sgpr(S_loc.nslot_y); pin_sgpr(S_loc.n_fwd); pin_sgpr(S_loc.back_off);          \
   pin_sgpr(S_loc.scale_off); pin_sgpr(S_loc.n_scale); pin_sgpr(S_loc.back_first); pin_sgpr(S_loc.static_connected);              \
-  pin_sgpr(S_loc.rslot0);                                                                                                        \
+  pin_sgpr(S_loc.rslot0); pin_sgpr(S_loc.n_up);                                                                                                        \
   const SymDev& S = S_loc;                                                                                                       \
   const int lds_rows = TC ? P->tc_rows : -1, lds_nslot = TC ? P->tc_nslot : P->sym.nslot,                                        \
             lds_nslot_y = YR ? 0 : TC ? P->tc_nslot_y : P->sym.nslot_y;      /* YR: the Ybus blocks live in registers */          \
@@ -1404,7 +1460,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   make_stat_view<STAGE, NB == 1>(sv, P->sym, smem + (size_t)IPW * per_inst, S_loc.flat[GWI], F_loc.n_words);                     \
   if (TC) {                                                                                                                      \
     const TopoClassDev& tc_ = P->classes[gptr(lane_class)[blockIdx.x * IPW]];                                              \
-    sv.pair_rc.p = tc_.pair_rc; sv.br_slot.p = tc_.br_slot; sv.node_of.p = tc_.node_of;                                          \
+    sv.pair_rc.p = tc_.pair_rc; sv.up.p = tc_.up; sv.br_slot.p = tc_.br_slot; sv.node_of.p = tc_.node_of;                        \
   }
 
 template <int NB, int STAGE, int IPW, int MINW, int WPI, bool TC = false, bool YR = false>
@@ -1418,8 +1474,8 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   const int inst = lane_list ? gptr(lane_list)[blockIdx.x * IPW + grp] : lane0 + blockIdx.x * IPW + grp;
   CarveP<NB> c;
   GPF_CARVE_AND_VIEW(P->g);
-  double2 yreg[YR_PASSES];
-  unsigned rcreg[YR_PASSES];
+  double2 yreg[2 * YR_PASSES + 1];
+  unsigned rcreg[2 * YR_PASSES];
   int n_iter, nb;
   GPF_STAMPS_DECL;
   SolveCtl ctl;
@@ -1456,8 +1512,8 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   const bool ghost = inst >= (int)b.n_real_lanes;               // padding lane of an instance group: computes, never mutates state
   CarveP<NB> c;
   GPF_CARVE_AND_VIEW(g);
-  double2 yreg[YR_PASSES];
-  unsigned rcreg[YR_PASSES];
+  double2 yreg[2 * YR_PASSES + 1];
+  unsigned rcreg[2 * YR_PASSES];
   if (STAGE) GPF_SYNC();                                       // the static tables are read from here on
   GPF_STAMPS_DECL;
   GPF_STAMPS(8);

@@ -195,6 +195,22 @@ inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, co
   return S;
 }
 
+// Undirected off-diagonal pairs of the original pattern (single-busbar Newton loop: ONE lane computes the Jacobian blocks (u, v)
+// and (v, u) of a pair of connected substations): [n_up][2] ints = { u | v << 16, slot(u, v) | slot(v, u) << 16 }, u < v.
+inline std::vector<int> build_upairs(const Symbolic& S) {
+  std::vector<int> up;
+  for (int s = S.n; s < S.nslot_y; ++s) {
+    const int r = S.slot_row[s], c = S.slot_col[s];
+    if (r >= c) continue;
+    int back = -1;
+    for (int t = S.n; t < S.nslot_y; ++t) if (S.slot_row[t] == c && S.slot_col[t] == r) { back = t; break; }
+    if (back < 0) continue;                               // (cannot happen: the pattern is symmetric)
+    up.push_back(r | (c << 16));
+    up.push_back(s | (back << 16));
+  }
+  return up;
+}
+
 // false: the grid has too many blocks for 16-bit byte-offset fields (it would not fit the LDS either)
 inline bool flat_fits(const Symbolic& S) { return (size_t)(S.rslot0 + S.n) * 16 <= 65536; }
 

@@ -216,3 +216,20 @@ extern "C" int sym_emul_solve_flat(int n_sub, int n_line, const int* line_or, co
   if (stats) { stats[0] = F.n_fwd; stats[1] = F.n_scale; stats[2] = F.n_back; stats[3] = (int)F.words.size(); }
   return F.n_fwd + F.n_back;
 }
+
+// undirected off-diagonal pairs (build_upairs): out[4k + {0,1,2,3}] = u, v, row/col check flags; returns n_up or a negative error
+extern "C" int sym_upairs_check(int n_sub, int n_line, const int* line_or, const int* line_ex) {
+  gpf::Symbolic S = gpf::build_symbolic(n_sub, n_line, line_or, line_ex);
+  const std::vector<int> up = gpf::build_upairs(S);
+  const int n_up = (int)up.size() / 2;
+  if (2 * n_up != S.nslot_y - S.n) return -1;                    // every off-diagonal block of the pattern belongs to one pair
+  std::vector<char> seen(S.nslot_y, 0);
+  for (int k = 0; k < n_up; ++k) {
+    const int u = up[2 * k] & 0xffff, v = (int)((unsigned)up[2 * k] >> 16), suv = up[2 * k + 1] & 0xffff, svu = (int)((unsigned)up[2 * k + 1] >> 16);
+    if (!(u < v) || suv < S.n || svu < S.n || suv >= S.nslot_y || svu >= S.nslot_y) return -2;
+    if (S.slot_row[suv] != u || S.slot_col[suv] != v || S.slot_row[svu] != v || S.slot_col[svu] != u) return -3;
+    if (seen[suv] || seen[svu]) return -4;
+    seen[suv] = seen[svu] = 1;
+  }
+  return n_up;
+}

@@ -21,22 +21,37 @@ def _engine(model, n_lanes):
     return PowerFlowEngine(model, n_lanes=n_lanes, device=0)
 
 
-def _run(m, states):
+def _run(m, states, tol_mva=1e-8):
     eng = _engine(m, len(states))
     inj, topo, sb = pack_states(m, states)
     eng.set_injections(inj)
     eng.set_topology(topo, sb)
-    eng.runpf()
+    eng.runpf(tol_mva=tol_mva)
     r = eng.results()
     eng.close()
     return r
 
 
-def _check(m, r, states, v_tol):
-    """verdict and iteration count bit-exact; voltages within v_tol (pu)"""
+def _check(m, r, states, v_tol, noise_limited_tol_mva=None):
+    """verdict and iteration count bit-exact; voltages within v_tol (pu).
+
+    noise_limited_tol_mva: the case sits where the rounding noise of the mismatch (|Y| * eps) reaches the 1e-8 MVA tolerance, so
+    whether the last iterate passes the test is decided by the summation order of either implementation.  A lane on which the
+    two verdicts differ is then re-run by BOTH at this looser tolerance, where both must converge to the same voltages."""
     n_conv = 0
+    relaxed = None
     for k, s in enumerate(states):
         o = solve(m, s)
+        if noise_limited_tol_mva is not None and bool(r.converged[k]) != bool(o.converged):
+            if relaxed is None:
+                relaxed = _run(m, states, tol_mva=noise_limited_tol_mva)
+            o2 = solve(m, s, tol_mva=noise_limited_tol_mva)
+            assert o2.converged and relaxed.converged[k], (k, o2.reason, relaxed.status[k])
+            act = ~np.isnan(o2.bus_vm)
+            assert np.abs(relaxed.bus_vm[k][act] - o2.bus_vm[act]).max() < v_tol, k
+            if r.converged[k]:                                   # the strict GPU answer is that solution too
+                assert np.abs(r.bus_vm[k][act] - o2.bus_vm[act]).max() < v_tol, k
+            continue
         assert bool(r.converged[k]) == bool(o.converged), (k, r.status[k], o.reason, o.n_iter)
         if not o.converged:
             assert np.isnan(r.out[k]).all()
@@ -100,7 +115,8 @@ def test_lines_with_almost_zero_reactance(name, x_pu, load_model):
     states.append(s)
     r = _run(m, states)
     # voltages across a 1e-8 pu line are determined to ~1e-16 / 1e-8 relative: the tolerance follows the conditioning
-    _check(m, r, states, v_tol=max(1e-9, 1e-14 / x_pu))
+    # 1e6 pu admittances: |Y| * eps = 2e-10 pu is above the 1e-10 pu tolerance -> the verdict of a lane may be a matter of rounding
+    _check(m, r, states, v_tol=max(1e-9, 1e-14 / x_pu), noise_limited_tol_mva=1e-6 if x_pu <= 1e-6 else None)
 
 
 def test_heavily_loaded_radial_feeder(load_model):

@@ -88,3 +88,15 @@ def test_flat_program_reproduces_dense_solve(emul, load_model, name, gw):
     items = [int(lv[4 * k + 2] + lv[4 * k + 3]) for k in range(n_levels)]
     assert n_fwd == sum(-(-i // gw) for i in items if i > 0)          # a level takes ceil(items / gw) passes
     assert n_words % 4 == 0
+
+
+@pytest.mark.parametrize("name", ["rte_case5_example", "l2rpn_case14_sandbox", "l2rpn_neurips_2020_track1", "l2rpn_wcci_2022_dev"])
+def test_undirected_pair_table(emul, load_model, name):
+    """build_upairs: every off-diagonal block of the original pattern belongs to exactly one pair (u < v) with both its slots."""
+    m = load_model(name)
+    lor = np.ascontiguousarray(m.line_or_sub, dtype=np.int32)
+    lex = np.ascontiguousarray(m.line_ex_sub, dtype=np.int32)
+    ip = C.POINTER(C.c_int32)
+    n_up = emul.sym_upairs_check(m.n_sub, m.n_line, lor.ctypes.data_as(ip), lex.ctypes.data_as(ip))
+    distinct = {(min(a, b), max(a, b)) for a, b in zip(m.line_or_sub.tolist(), m.line_ex_sub.tolist()) if a != b}
+    assert n_up == len(distinct)
