@@ -166,6 +166,12 @@ struct Stamps { long long v[32]; };
 #define GPF_LSYNC() GPF_SYNC()
 #endif
 
+// Boundary after which lanes read what OTHER lanes of the block wrote to GLOBAL memory (`cond`, block-uniform): a workgroup
+// barrier that also drains the vector-memory counter.  A single-wavefront block whose lanes only read back their own global
+// stores needs neither (same-lane ordering is the hardware's): the stores of the result row then drain behind the next phases
+// instead of being waited for -- a full store round trip, three or four times per environment step.
+#define GPF_SYNC_IF(cond) do { if (GW > WAVE || (cond)) GPF_SYNC(); else GPF_LSYNC(); } while (0)
+
 typedef short i16;
 
 // Uniform launch constants (grid sizes, offsets of the symbolic program) reach the kernel through a parameter block in memory.
@@ -771,7 +777,7 @@ struct TopoState {
 constexpr int YR_PASSES = 4;
 template <int NB, int STAGE, int IPW, int WPI, bool TC, bool YR = false>
 __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, const SymDev& S, const FlatDev& FL, const StatView<STAGE>& sv, CarveP<NB>& c, double2* yreg, unsigned* rcreg, int inst, int is_dc, int max_iter,
-                                            double tol_pu, int tid, const SolveCtl& ctl, TopoState& ts, int& n_iter_out, int& nb_out GPF_STAMPS_PARAM) {
+                                            double tol_pu, int tid, const SolveCtl& ctl, TopoState& ts, int& n_iter_out, int& nb_out, float& a_or_first GPF_STAMPS_PARAM) {
   typedef Grp<IPW, WPI> G;
   constexpr int GW = G::GW;
   constexpr int BS = 2 * NB;
@@ -1326,6 +1332,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       th_or = (float)(c.va[f] * RAD2DEG); th_ex = (float)(c.va[t] * RAD2DEG);
     }
     out[oo.p_or + l] = p_or; out[oo.q_or + l] = q_or; out[oo.v_or + l] = v_or; out[oo.a_or + l] = a_or; out[oo.th_or + l] = th_or;
+    if (l == tid) a_or_first = a_or;                 // the step kernel derives rho / the protection counters of this line from it
     out[oo.p_ex + l] = p_ex; out[oo.q_ex + l] = q_ex; out[oo.v_ex + l] = v_ex; out[oo.a_ex + l] = a_ex; out[oo.th_ex + l] = th_ex;
   }
   GPF_STAMPS(22);
@@ -1477,12 +1484,13 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   double2 yreg[2 * YR_PASSES + 1];
   unsigned rcreg[2 * YR_PASSES];
   int n_iter, nb;
+  float a_first = 0.f;
   GPF_STAMPS_DECL;
   SolveCtl ctl;
   ctl.inj_staged = false; ctl.topo_staged = false; ctl.reuse = false; ctl.dcf = false; ctl.write_bus = true; ctl.warm = false; ctl.sums_done = false;
   TopoState ts;
   ts.status = 0; ts.nb = 0; ts.dc_base = false; ts.gen_base = false;
-  const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, is_dc, max_iter, tol_pu, tid, ctl, ts, n_iter, nb GPF_STAMPS_ARG);
+  const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, is_dc, max_iter, tol_pu, tid, ctl, ts, n_iter, nb, a_first GPF_STAMPS_ARG);
   GPF_SYNC();
   if (st != 0) write_nan_results<GW>(P->g, P->b, inst, tid);
   if (tid == 0) {
@@ -1641,10 +1649,11 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
           }
         }
       }
-      GPF_SYNC();
+      GPF_SYNC_IF(!STAGE);                         // tier 0: the injection row went to global memory and is read back from there
     }
     // ---- power flow + K7 (Backend.next_grid_state) --------------------------------------------------------------------------
     n_iter = 0; nb = 0; st = 0; rounds = 0;
+    float a_first = 0.f;                                        // a_or of line `tid` from the last solve of this step
     {
       const auto dround = gptr(b.disc_round) + (size_t)inst * g.n_line;
       for (int l = tid; l < g.n_line; l += GW) dround[l] = -1;
@@ -1663,9 +1672,9 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       int it_k = 0, nb_k = 0;
       SolveCtl ctl;
       ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && !TC && sa.n_steps > 1; ctl.write_bus = last; ctl.warm = sa.warm_start != 0; ctl.sums_done = first && sums_in_k9;
-      const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, sa.is_dc, max_iter, tol_pu, tid, ctl, ts, it_k, nb_k GPF_STAMPS_ARG);
+      const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, sa.is_dc, max_iter, tol_pu, tid, ctl, ts, it_k, nb_k, a_first GPF_STAMPS_ARG);
       first = false;
-      GPF_SYNC();
+      GPF_SYNC_IF(sa.cascade != 0);                // the overflow check reads result rows and counters other lanes wrote
       if (more) { st = st_k; n_iter = it_k; nb = nb_k; }
       if (st != 0 || !sa.cascade || rounds >= sa.max_rounds) more = false;   // at most max_rounds re-solves
       int any_disc = 0;
@@ -1692,7 +1701,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
           }
         }
       }
-      GPF_SYNC();
+      GPF_SYNC_IF(sa.cascade != 0);
       if (more && !G::any(any_disc)) more = false;
       if (more) tripped = true;
       if (!G::block_any_u(more)) break;
@@ -1701,8 +1710,8 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
     GPF_STAMPS(9);
     GPF_REDERIVE();
     // ---- per-step outputs -----------------------------------------------------------------------------------------------------
-    if (st != 0) write_nan_results<GW>(g, b, inst, tid);
-    GPF_SYNC();
+    if (st != 0) { write_nan_results<GW>(g, b, inst, tid); a_first = __builtin_nanf(""); }
+    GPF_SYNC_IF(G::block_any_u(st != 0));          // NaN rows are written with another lane mapping than the line loop's
     {
       const auto out = gptr(b.out) + (size_t)inst * g.n_out;
       const auto ovc = gptr(b.overflow_count) + (size_t)inst * g.n_line;
@@ -1712,7 +1721,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       if (b.traj_rho && step < b.traj_cap) traj = gptr(b.traj_rho) + ((size_t)step * b.lane_stride + inst) * g.n_line;
       for (int l = tid; l < g.n_line; l += GW) {
         const float lim = thermal_limit[l];
-        const float a = out[oo.a_or + l];
+        const float a = (l == tid) ? a_first : (float)out[oo.a_or + l];       // (this lane wrote out[a_or + l] itself)
         const float r_ = a / lim;
         rho[l] = r_;
         if (traj) traj[l] = r_;
@@ -1742,7 +1751,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
     reuse = !G::block_any_u(failed || tripped);
     GPF_STAMPS(7);
     if (++row >= sa.T) row = 0;
-    if (!last) GPF_SYNC();
+    if (!last) GPF_SYNC_IF(G::block_any_u(failed && sa.auto_reset != 0));   // auto-reset rewrote topology rows with another lane mapping
   }
 #undef GPF_REDERIVE
   grp = grp0; tid = tid0; inst = inst0;
