@@ -1541,6 +1541,11 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   ts.status = 0; ts.nb = 0; ts.dc_base = false; ts.gen_base = false;
   bool reuse = false;                                         // block-uniform
   int n_iter = 0, nb = 0, st = 0, rounds = 0;
+  // state of the lane's OWN line (line `tid`: the line loops all map line l to lane l % GW) kept in registers for the launch:
+  // thermal limit, protection counter (written back by every step) and the "already counted in this call" flag of K7
+  float lim_first = 1e30f;
+  int ovc_first = 0, inc_first = 0;
+  if (tid < g.n_line) { lim_first = gptr(b.thermal_limit)[tid]; ovc_first = gptr(b.overflow_count)[(size_t)inst * g.n_line + tid]; }
   int ep_steps = 0, ep_resets = 0;
   if (tid == 0 && !ghost) { ep_steps = gptr(b.episode)[2 * (size_t)inst]; ep_resets = gptr(b.episode)[2 * (size_t)inst + 1]; }
   // Every step (and every cascade round) runs the same code on the same addresses, so the compiler would hoist each per-thread
@@ -1661,7 +1666,8 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       // and per call (backend.py:1476-1520): local value = ovc + (line already counted this call ? 1 : 0); the "already
       // counted" flag lives in the rho buffer, reused as int scratch until the end of the step.
       const auto inc_flag = (GPF_GLOBAL int*)(gptr(b.rho) + (size_t)inst * g.n_line);
-      if (sa.cascade) for (int l = tid; l < g.n_line; l += GW) inc_flag[l] = 0;
+      if (sa.cascade) for (int l = tid + GW; l < g.n_line; l += GW) inc_flag[l] = 0;      // (line tid: inc_first)
+      inc_first = 0;
     }
     bool more = true;                                           // this group still cascades
     bool first = true;
@@ -1674,7 +1680,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && !TC && sa.n_steps > 1; ctl.write_bus = last; ctl.warm = sa.warm_start != 0; ctl.sums_done = first && sums_in_k9;
       const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, sa.is_dc, max_iter, tol_pu, tid, ctl, ts, it_k, nb_k, a_first GPF_STAMPS_ARG);
       first = false;
-      GPF_SYNC_IF(sa.cascade != 0);                // the overflow check reads result rows and counters other lanes wrote
+      GPF_SYNC_IF(sa.cascade != 0 && g.n_line > GW);   // (every line loop maps line l to lane l % GW: lanes read their own rows)
       if (more) { st = st_k; n_iter = it_k; nb = nb_k; }
       if (st != 0 || !sa.cascade || rounds >= sa.max_rounds) more = false;   // at most max_rounds re-solves
       int any_disc = 0;
@@ -1686,13 +1692,14 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
         const auto topo = gptr(b.topo) + (size_t)inst * g.dim_topo;
         const auto thermal_limit = gptr(b.thermal_limit);
         for (int l = tid; l < g.n_line; l += GW) {
-          const float a = out[oo.a_or + l];
-          const float lim = thermal_limit[l];
+          const bool own = l == tid;
+          const float a = own ? a_first : (float)out[oo.a_or + l];
+          const float lim = own ? lim_first : (float)thermal_limit[l];
           const bool on = c.lor_b[l] >= 0;
           bool disc = on && (a > sa.hard_overflow * lim);
-          int inc = inc_flag[l];
-          if (on && (a > sa.soft_overflow * lim) && !inc) { inc = 1; inc_flag[l] = 1; }
-          if (on && (ovc[l] + inc) > sa.nb_ts_allowed) disc = true;
+          int inc = own ? inc_first : (int)inc_flag[l];
+          if (on && (a > sa.soft_overflow * lim) && !inc) { inc = 1; if (own) inc_first = 1; else inc_flag[l] = 1; }
+          if (on && ((own ? ovc_first : (int)ovc[l]) + inc) > sa.nb_ts_allowed) disc = true;
           if (disc) {
             topo[sv.line_or_pos[l]] = -1;
             topo[sv.line_ex_pos[l]] = -1;
@@ -1701,8 +1708,9 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
           }
         }
       }
-      GPF_SYNC_IF(sa.cascade != 0);
-      if (more && !G::any(any_disc)) more = false;
+      const bool anyd = more && G::any(any_disc);
+      GPF_SYNC_IF(G::block_any_u(anyd));           // a tripped line rewrote the topology row the next round stages with another lane mapping
+      if (more && !anyd) more = false;
       if (more) tripped = true;
       if (!G::block_any_u(more)) break;
       if (more) ++rounds;
@@ -1720,12 +1728,18 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       GPF_GLOBAL float* traj = nullptr;
       if (b.traj_rho && step < b.traj_cap) traj = gptr(b.traj_rho) + ((size_t)step * b.lane_stride + inst) * g.n_line;
       for (int l = tid; l < g.n_line; l += GW) {
-        const float lim = thermal_limit[l];
-        const float a = (l == tid) ? a_first : (float)out[oo.a_or + l];       // (this lane wrote out[a_or + l] itself)
+        const bool own = l == tid;
+        const float lim = own ? lim_first : (float)thermal_limit[l];
+        const float a = own ? a_first : (float)out[oo.a_or + l];              // (this lane wrote out[a_or + l] itself)
         const float r_ = a / lim;
         rho[l] = r_;
         if (traj) traj[l] = r_;
-        if (!ghost) { if (a > sa.soft_overflow * lim) ovc[l] += 1; else ovc[l] = 0; }
+        if (!ghost) {
+          const int prev = own ? ovc_first : (int)ovc[l];
+          const int now = (a > sa.soft_overflow * lim) ? prev + 1 : 0;
+          if (own) ovc_first = now;
+          ovc[l] = now;
+        }
       }
     }
     const bool failed = st != 0;
@@ -1746,6 +1760,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       const auto ovc = gptr(b.overflow_count) + (size_t)inst * g.n_line;
       for (int i = tid; i < g.dim_topo; i += GW) topo[i] = t0[i];
       for (int l = tid; l < g.n_line; l += GW) ovc[l] = 0;
+      ovc_first = 0;
     }
     // the topology-derived state stands for the next step only if NO group of the block changed or lost its topology
     reuse = !G::block_any_u(failed || tripped);
