@@ -244,14 +244,6 @@ void count_lane(const gpf_engine* e, const int* topo, const int* shunt_bus, int&
 
 
 
-// number of leading levels that have at least one update item (SymDev::n_fwd)
-int fwd_levels(const gpf::Symbolic& S) {
-  int n = 0;
-  for (int lv = 0; lv < S.n_levels; ++lv)
-    if (S.prog[(size_t)8 * lv + 5] + S.prog[(size_t)8 * lv + 7] > 0) n = lv + 1;
-  return n;
-}
-
 // flat programs (gridpf_symbolic.hpp: FlatProg) of one graph for the four group widths, in one device buffer; false: upload
 // failed.  A graph too large for the 16-bit byte-offset fields gets none (fl[k].n_words == 0: it would not fit the LDS either).
 bool upload_flats(const gpf::Symbolic& S, DevArr<int>& buf, gpf::SymDev& D) {
@@ -327,7 +319,6 @@ int topo_class_of(gpf_engine* e, const int* topo, const int* shunt_bus) {
   gpf::SymDev& D = c->dev.sym;
   D = e->sym_dev;                                            // the grid's static blob pointers / offsets
   D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.back_first = S.back_first;
-  D.n_fwd = fwd_levels(S);
   D.scale_off = S.scale_off; D.n_scale = S.n_scale; D.n_prog = (int)S.prog.size();
   {   // with every line in service the bus graph of a lane of this class is exactly this graph: connected <=> one component
       // over the nodes that carry an element (an element-only node without a line is an island)
@@ -807,8 +798,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     if (eu == hipSuccess) eu = e->stat_int.upload(fi.data(), fi.size());
     if (eu != hipSuccess) { gpf_destroy(e); return fail(GPF_E_DEVICE, std::string("upload static tables: ") + hipGetErrorString(eu)); }
     D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.back_first = S.back_first;
-    D.n_fwd = fwd_levels(S);
-    {   // connectivity of the static substation graph (all lines in service): lets the kernel skip the label propagation
+      {   // connectivity of the static substation graph (all lines in service): lets the kernel skip the label propagation
       std::vector<int> comp(g.n_sub);
       for (int i = 0; i < g.n_sub; ++i) comp[i] = i;
       auto find = [&](int x) { while (comp[x] != x) { comp[x] = comp[comp[x]]; x = comp[x]; } return x; };

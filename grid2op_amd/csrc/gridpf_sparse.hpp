@@ -92,8 +92,6 @@ struct SymDev {
   int rslot0;               // first right-hand-side pseudo-slot of the single-busbar block array (Symbolic::rslot0)
   const int* flat[4];       // flat programs of the single-busbar kernels, one per group width (gw_index), global memory
   FlatDev fl[4];
-  int n_fwd;                // levels the 2x2 / scalar forward sweeps visit: the trailing levels without any update item (the last
-                            // pivot never has one) are skipped -- each would cost a whole barrier-delimited phase per solve
   int back_first;           // highest level that has U entries (back substitution starts there)
   int static_connected;     // the substation graph with every line in service is connected (host check at gpf_create)
   const int* prog;          // level-scheduled program in global memory (tools/lu_bench; the kernels use StatView::prog)
@@ -1449,9 +1447,9 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
 #define GPF_CARVE_AND_VIEW(G_)                                                                                                   \
   SymDev S_loc = P->sym;                                                                                                         \
   if (TC) S_loc = P->classes[gptr(lane_class)[blockIdx.x * IPW]].sym;                                                            \
-  pin_sgpr(S_loc.n); pin_sgpr(S_loc.nslot); pin_sgpr(S_loc.nslot_y); pin_sgpr(S_loc.n_fwd); pin_sgpr(S_loc.back_off);          \
+  pin_sgpr(S_loc.n); pin_sgpr(S_loc.nslot); pin_sgpr(S_loc.nslot_y); pin_sgpr(S_loc.back_off);                                  \
   pin_sgpr(S_loc.scale_off); pin_sgpr(S_loc.n_scale); pin_sgpr(S_loc.back_first); pin_sgpr(S_loc.static_connected);              \
-  pin_sgpr(S_loc.rslot0); pin_sgpr(S_loc.n_up);                                                                                                        \
+  pin_sgpr(S_loc.rslot0); pin_sgpr(S_loc.n_up);                                                                                 \
   const SymDev& S = S_loc;                                                                                                       \
   const int lds_rows = TC ? P->tc_rows : -1, lds_nslot = TC ? P->tc_nslot : P->sym.nslot,                                        \
             lds_nslot_y = YR ? 0 : TC ? P->tc_nslot_y : P->sym.nslot_y;      /* YR: the Ybus blocks live in registers */          \

@@ -101,8 +101,6 @@ int main(int argc, char** argv) {
   SymDev D{};
   D.n = n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.n_prog = (int)S.prog.size();
   D.scale_off = S.scale_off; D.n_scale = S.n_scale; D.back_first = S.back_first;
-  D.n_fwd = 0;
-  for (int lv = 0; lv < S.n_levels; ++lv) if (S.prog[(size_t)8 * lv + 5] + S.prog[(size_t)8 * lv + 7] > 0) D.n_fwd = lv + 1;
   int* dprog; double *dA, *db, *dx; long long* dcy;
   CK(hipMalloc(&dprog, S.prog.size() * 4)); CK(hipMemcpy(dprog, S.prog.data(), S.prog.size() * 4, hipMemcpyHostToDevice));
   CK(hipMalloc(&dA, A.size() * 8)); CK(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice));
