@@ -400,14 +400,19 @@ def main():
     # ---- the same workload with the reference's DEFAULT parameters: overflow disconnections (cascade) on ---------------------
     if secondary and not args.cascade:
         eng.reset()
-        w, _ = timed_windows(ctx, eng, k_sec, w_sec, dict(rebalance=1.02, cascade=True), 3, preroll_steps=0)
+        w, _ = timed_windows(ctx, eng, k_sec, w_sec, dict(rebalance=1.02, cascade=True, auto_reset=True), 3, preroll_steps=0)
         rc = eng.results()
+        _, _, n_resets = eng.episode()
         if rank == 0:
             res["cascade_on"] = dict(summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec,
                                      workload="same lanes, Parameters.NO_OVERFLOW_DISCONNECTION=False (hard_overflow 2.0, "
-                                              "NB_TIMESTEP_OVERFLOW_ALLOWED 2): lines trip and the power flow is re-run inside the step",
+                                              "NB_TIMESTEP_OVERFLOW_ALLOWED 2): lines trip and the power flow is re-run inside the step; "
+                                              "a lane whose step fails (game over) restarts at the next step like env.reset() "
+                                              "(auto_reset: without it the dead lanes re-diverge at every step and, the batch being "
+                                              "exactly one residency round, their blocks set the duration of every launch)",
                                      frac_converged=float(rc.converged.mean()),
-                                     frac_lanes_with_a_tripped_line=float((~rc.line_status).any(axis=1).mean()))
+                                     frac_lanes_with_a_tripped_line=float((~rc.line_status).any(axis=1).mean()),
+                                     lane_resets=int(np.asarray(n_resets).sum()))
         eng.reset()
 
     # ---- same workload with topology actions: 10 % of the lanes with a split substation (topology classes) ------

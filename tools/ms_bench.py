@@ -7,7 +7,7 @@ from grid2op_amd.engine import PowerFlowEngine
 env = sys.argv[1] if len(sys.argv) > 1 else "l2rpn_case14_sandbox"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 ns = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 4, 8, 16, 32, 64]
-kw = dict(rebalance=1.02, cascade=bool(int(os.environ.get("CASCADE", "0"))))
+kw = dict(rebalance=1.02, cascade=bool(int(os.environ.get("CASCADE", "0"))), auto_reset=bool(int(os.environ.get("AUTO_RESET", "0"))))
 m = GridModel.load_npz(f"tests/golden/{env}.grid.npz")
 ch = dict(np.load(f"tests/golden/{env}.chronics.npz"))
 if "prod_v" not in ch:
@@ -17,7 +17,7 @@ eng.upload_chronics(eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], 
 T = ch["load_p"].shape[0]
 rng = np.random.default_rng(0)
 eng.set_lane_chronics(lane_offset=(7 * np.arange(B)) % T, lane_scale=(1 + 0.05 * rng.standard_normal((B, 2 * m.n_load))).astype(np.float32))
-if "thermal_limits" in ch: eng.set_thermal_limits(ch["thermal_limits"])
+if "thermal_limits" in ch: eng.set_thermal_limits(ch["thermal_limits"] * float(os.environ.get("LIMIT_SCALE", "1")))
 for t in range(300): eng.step(t, **kw)
 eng.sync()
 for n in ns:
