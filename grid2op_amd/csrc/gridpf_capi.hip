@@ -459,7 +459,16 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
           const auto* c = e->classes[cid];
           qb.tc_rows = std::max(qb.tc_rows, c->n_nodes); qb.tc_nslot = std::max(qb.tc_nslot, c->nslot); qb.tc_nslot_y = std::max(qb.tc_nslot_y, c->nslot_y);
         }
-        qb.lds = gpf::lds_bytes_sparse<1>(e->g, qb.tc_nslot, qb.tc_nslot_y, 0, false, qb.ipw, qb.tc_rows);
+        // DC factors kept across the steps of a launch: alone (every lane has a class: ONE launch, its own parameter block) when
+        // that does not cost residency; next to a launch of unsplit lanes the shared parameter block carries that plan's setting
+        auto lds_tc = [&](bool dcf_) { return gpf::lds_bytes_sparse<1>(e->g, qb.tc_nslot, qb.tc_nslot_y, 0, false, qb.ipw, qb.tc_rows, dcf_); };
+        qb.dcf = everyone ? 0 : e->dcf;
+        qb.lds = lds_tc(qb.dcf != 0);
+        if (everyone && e->dcf_env != 0) {
+          const size_t nblk = (lb.size() + qb.ipw - 1) / qb.ipw, with = lds_tc(true);
+          const size_t want_tc = std::min<size_t>(std::min<size_t>((nblk + 255) / 256, LDS_HARD_LIMIT / std::max<size_t>(qb.lds, 1)), 8);
+          if (with <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / with >= want_tc) { qb.dcf = 1; qb.lds = with; }
+        }
         ok_b = qb.lds <= LDS_HARD_LIMIT;
         if (ok_b && e->d_classes_count != e->classes.size()) {
           std::vector<gpf::TopoClassDev> hc(e->classes.size());

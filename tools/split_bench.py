@@ -15,12 +15,13 @@ if "prod_v" not in ch:
 eng = PowerFlowEngine(m, n_lanes=B)
 eng.upload_chronics(eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"]))
 eng.set_lane_chronics(lane_offset=(7 * np.arange(B)) % ch["load_p"].shape[0])
+NS = int(os.environ.get("NSTEPS", "1"))              # environment steps per launch
 def run(label):
-    for t in range(10): eng.step(t, rebalance=1.02)
+    for t in range(10): eng.step(t * NS, rebalance=1.02, n_steps=NS)
     eng.sync(); t0 = time.perf_counter()
     N = 100
-    for t in range(N): eng.step(t, rebalance=1.02)
-    eng.sync(); dt = (time.perf_counter() - t0) / N
+    for t in range(N): eng.step(t * NS, rebalance=1.02, n_steps=NS)
+    eng.sync(); dt = (time.perf_counter() - t0) / (N * NS)
     r = eng.results()
     print(f"{label}: {dt*1e6:.1f} us/step = {B/dt/1e6:.2f} M steps/s, converged {r.converged.mean():.3f}")
 run("no split")
