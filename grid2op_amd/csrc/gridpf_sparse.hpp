@@ -225,6 +225,21 @@ __host__ __device__ inline size_t lds_bytes_sparse(const GridDev& g, int nslot, 
 
 // Stage the static data in LDS (STAGE, see stat_bytes) or view it in place; visible to the block after the first barrier.
 // NB1: single-busbar kernel -- its program is the flat program `flat` (n_flat ints, global memory) of the kernel's group width.
+// global -> LDS copy of n16 16-byte chunks (both 16-byte aligned) with four loads in flight per lane: a plain element loop waits
+// for one L2 round trip per iteration, which made the static staging the longest part of a one-step launch's prologue
+__device__ __forceinline__ void stage_copy16(void* dst_lds, const void* src_global, int n16) {
+  typedef int v4i_ __attribute__((ext_vector_type(4)));
+  v4i_* d = reinterpret_cast<v4i_*>(dst_lds);
+  const auto s = (GPF_GLOBAL const v4i_*)src_global;
+  const int st = blockDim.x;
+  int i = threadIdx.x;
+  for (; i + 3 * st < n16; i += 4 * st) {
+    const v4i_ t0 = s[i], t1 = s[i + st], t2 = s[i + 2 * st], t3 = s[i + 3 * st];
+    d[i] = t0; d[i + st] = t1; d[i + 2 * st] = t2; d[i + 3 * st] = t3;
+  }
+  for (; i < n16; i += st) d[i] = s[i];
+}
+
 template <int STAGE, bool NB1>
 __device__ inline void make_stat_view(StatView<STAGE>& sv, const SymDev& S, unsigned char* lds_static, const int* flat, int n_flat) {
   const auto gd = gptr(S.stat_dbl);
@@ -243,11 +258,11 @@ __device__ inline void make_stat_view(StatView<STAGE>& sv, const SymDev& S, unsi
   double* sd = reinterpret_cast<double*>(lds_static);
   int* si = reinterpret_cast<int*>(STAGE == 2 ? sd + S.so.n_dbl : sd);
   const int i0 = S.so.pair_rc, i1 = STAGE == 2 ? S.so.n_int : S.so.n_int_hot;       // int tables [pair_rc .. )
-  if (STAGE == 2) for (int i = threadIdx.x; i < S.so.n_dbl; i += blockDim.x) sd[i] = gd[i];
-  for (int i = threadIdx.x; i < i1 - i0; i += blockDim.x) si[i] = gi[i0 + i];
+  // (every table of the blob is padded to 16 bytes: doubles to an even count, ints to a multiple of 4; the flat programs too)
+  if (STAGE == 2) stage_copy16(sd, S.stat_dbl, S.so.n_dbl / 2);
+  stage_copy16(si, S.stat_int + i0, (i1 - i0) / 4);
   int* sp = si + (i1 - i0);
-  const auto gf = gptr(flat);
-  for (int i = threadIdx.x; i < n_flat; i += blockDim.x) sp[i] = gf[i];
+  stage_copy16(sp, flat, n_flat / 4);
   if (STAGE == 2) stat_view(sv, S.so, sd, si - i0);
   sv.pair_rc.p = si;
   sv.up.p = si + (S.so.up - i0);
