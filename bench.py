@@ -21,6 +21,14 @@ barrier and the max-over-ranks timing.  ``python bench.py --gpus N`` without a t
 the N ranks itself (``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1``)
 and FAILS when fewer than N devices are visible; under torchrun ``--gpus`` must equal WORLD_SIZE.
 
+Observations: the reference returns one observation per ``env.step``.  The headline therefore runs its multi-step launches
+(``--steps-per-launch``, default 16) with the per-step observation trajectory ON (``gpf_set_trajectory(.., GPF_TRAJ_OBS)``):
+every one of the 16 steps of a launch writes its complete backend observation (results row, topo_vect, shunt buses, line
+status, rho, status) to its own rows in HBM.  The cheaper contracts are labelled secondaries: ``rollout_last_observation_only``
+(16 steps per launch, each step overwrites the lane's single row: only the last observation of a launch exists) and
+``one_launch_per_step``.  After each timed workload a sample of lanes is re-solved by the C oracle (checker only, outside
+every timed region): ``max_abs_err_vs_oracle``.
+
 Timing: W warm-up steps, then ``--windows`` (default 5) timed windows of EXACTLY K steps each, every window
 bracketed by barrier + synchronize on both sides and MAX-reduced over the ranks; ``value`` / ``ms_per_step``
 are those of the MEDIAN window, min / max are reported in ``windows``.
@@ -45,7 +53,8 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 F64_PEAK_TFLOPS = 78.6         # MI355X FP64 vector == FP64 matrix peak (spec)
-TRAFFIC_PROFILE = os.path.join("profiles", "r02_traffic.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r03_traffic.json")
+CASCADE_LIMIT_SCALE = 0.85     # `cascade_tripping` secondary: thermal limits x 0.85 -> ~20 % of the lane-steps overflow softly
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -60,7 +69,7 @@ def _free_port() -> int:
 
 def self_launch(args, argv) -> int:
     """``--gpus N`` (N > 1) outside torchrun: start one rank per GPU and pass its single JSON line through."""
-    if not args.stub_engine:
+    if not args.stub_engine and not args.share_device:
         from grid2op_amd.sharding import visible_devices
         n_dev = visible_devices()
         if n_dev < args.gpus:
@@ -120,7 +129,7 @@ def traffic_profile():
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC run (FETCH_SIZE and WRITE_SIZE collected
     in separate --pmc passes of this same command, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950).  Not
     measured in this run: the JSON says so (``traffic_source``)."""
-    for rel in (TRAFFIC_PROFILE, os.path.join("profiles", "r01_traffic.json")):
+    for rel in (TRAFFIC_PROFILE,):
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 d = json.load(f)
@@ -140,6 +149,7 @@ class Ctx:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = 0 if args.share_device else self.local_rank      # --share-device: every rank drives device 0
         self.dist = None
         self.torch = None
         self.red_dev = None
@@ -154,8 +164,8 @@ class Ctx:
             import torch.distributed as dist
             self.dist = dist
             if args.dist_backend == "nccl":
-                self.torch.cuda.set_device(self.local_rank)
-                dist.init_process_group(backend="nccl", device_id=self.torch.device("cuda", self.local_rank))
+                self.torch.cuda.set_device(self.device)
+                dist.init_process_group(backend="nccl", device_id=self.torch.device("cuda", self.device))
                 self.red_dev = "cuda"
             else:
                 dist.init_process_group(backend=args.dist_backend)
@@ -180,9 +190,9 @@ class Ctx:
         if self.args.stub_engine:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from stub_engine import StubEngine           # launcher test hook (CPU): no arithmetic, see tests/stub_engine.py
-            return StubEngine(m, n_lanes=n_lanes, device=self.local_rank)
+            return StubEngine(m, n_lanes=n_lanes, device=self.device)
         from grid2op_amd.engine import PowerFlowEngine
-        return PowerFlowEngine(m, n_lanes=n_lanes, device=self.local_rank)
+        return PowerFlowEngine(m, n_lanes=n_lanes, device=self.device)
 
 
 def load_env(name):
@@ -211,14 +221,40 @@ def setup_engine(ctx, m, ch, n_envs, fan=1):
     eng.set_lane_chronics(lane_offset=offsets, lane_scale=scale)
     if "thermal_limits" in ch:
         eng.set_thermal_limits(ch["thermal_limits"])
+    eng.bench_inputs = (tab, offsets, scale)            # for the oracle spot check after the timed region
     return eng, T, lane0
+
+
+def oracle_spot_check(ctx, eng, n_lanes=32, t_last=None, rebalance=1.02, is_dc=False, seed=0):
+    """CHECKER leg (never timed, never the product): re-solve a sample of lanes with the C oracle and compare with what the engine
+    holds after the timed workload.  `t_last` given (DoNothing workloads without trips): the oracle recomputes the step from the
+    chronics table (covers the device-side chronics gather); otherwise from the injection / topology rows the lanes hold."""
+    if ctx.args.stub_engine or ctx.args.no_oracle_check:
+        return None
+    try:
+        from oracle import spot_check
+        lanes = np.sort(np.random.default_rng(seed).choice(eng.n_lanes, min(n_lanes, eng.n_lanes), replace=False))
+        if t_last is not None:
+            tab, off, sc = eng.bench_inputs
+            r = eng.results(with_bus=False)
+            res = spot_check.check_step(eng.model, tab, off, sc, rebalance, t_last, lanes, r.out[lanes], r.status[lanes])
+            res["against"] = "oracle/pf_oracle.c, step recomputed from the chronics table"
+        else:
+            res = spot_check.check_lanes(eng, lanes, is_dc=is_dc)
+            res["against"] = "oracle/pf_oracle.c, re-solve of the injection / topology rows the lanes hold"
+        res["max_abs_err_vs_oracle"] = res.pop("max_abs_err")
+        res["tolerance"] = "2e-4 + 5e-6 |x| (MW, MVAr, kV, A, deg); status and n_iter bit-exact"
+        return res
+    except Exception as exc:                      # the checker must never take the measurement down
+        return {"error": repr(exc)[:300]}
 
 
 def run_steps(eng, t, n, step_kw, spl):
     """``n`` env steps starting at time index ``t``, ``spl`` steps per launch (the last launch takes the remainder)."""
+    n_launch = -(-n // spl)                       # balanced: 20 steps at 16 per launch = 10 + 10, not 16 + 4
     done = 0
-    while done < n:
-        k = min(spl, n - done)
+    for i in range(n_launch):
+        k = (n - done) // (n_launch - i)
         eng.step(t + done, n_steps=k, **step_kw)
         done += k
     return t + n
@@ -284,7 +320,15 @@ def main():
     ap.add_argument("--n1", action="store_true",
                     help="headline = BASELINE.json configs[2] shape: every env copy is stepped together with its N-1 contingencies "
                          "(one extra lane per line, that line forced off), all fused into the same launch")
-    ap.add_argument("--dist-backend", default="nccl", help=argparse.SUPPRESS)       # CPU launcher test: gloo
+    ap.add_argument("--last-obs-only", action="store_true",
+                    help="headline WITHOUT the per-step observation trajectory: each step of a launch overwrites the lane's result "
+                         "row, only the last observation of a launch reaches HBM (the round-2 headline; now a labelled secondary)")
+    ap.add_argument("--no-oracle-check", action="store_true", help="skip the oracle spot checks after the timed workloads")
+    ap.add_argument("--share-device", action="store_true",
+                    help="every rank drives HIP device 0 (with --dist-backend gloo: the REAL multi-rank path -- init, per-rank lane "
+                         "blocks, barrier, max-reduce, JSON aggregation -- on a box with one GPU; not a scaling measurement)")
+    ap.add_argument("--dump-results", default=None, help="rank r writes its lanes' final result rows to <path>.rank<r>.npz")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo")
     ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)   # CPU launcher test: no arithmetic
     args = ap.parse_args()
     if args.gpus < 1:
@@ -313,10 +357,16 @@ def main():
             topo[c::fan, m.line_ex_pos_topo_vect[c - 1]] = -1
         eng.set_topology(topo)
     step_kw = dict(rebalance=1.02, cascade=args.cascade)
+    obs_every_step = args.steps_per_launch > 1 and not args.last_obs_only and not args.stub_engine
+    if obs_every_step:
+        eng.set_trajectory(args.steps_per_launch, eng.TRAJ_OBS)     # every step of a launch writes its observation to HBM
 
     wins, t_next = timed_windows(ctx, eng, args.steps, args.warmup, step_kw, args.windows)
     elapsed, kern_ms, n_launch = median_window(wins)
     r = eng.results()
+    check = oracle_spot_check(ctx, eng, 32, t_last=None if (args.cascade or args.n1) else t_next - 1) if rank == 0 else None
+    if args.dump_results:
+        np.savez(f"{args.dump_results}.rank{rank}.npz", out=r.out, status=r.status, topo_vect=r.topo_vect, lane0=lane0, t_last=t_next - 1)
     frac_conv = float(r.converged.mean())
     mean_iter = float(r.n_iter[r.converged].mean()) if r.converged.any() else float("nan")
     total_steps = world * n_envs * args.steps
@@ -351,11 +401,24 @@ def main():
                                    f"(row (t+7k) mod {T}, loads x (1+0.05 N(0,1)), prod_p rebalanced to 1.02 sum(load))",
                        "env": args.env, "lanes_per_gpu": B, "envs_per_gpu": n_envs, "total_lanes": world * B, "n1_fanout": fan,
                        "cascade": bool(args.cascade), "max_iter": 10, "tol_mva": 1e-8, "env_steps_per_launch": args.steps_per_launch,
+                       "observations": ("every env step: each of the steps of a launch writes its complete backend observation "
+                                        "(results row, topo_vect, shunt buses, line status, rho, status) to its own rows in HBM "
+                                        "(gpf_set_trajectory GPF_TRAJ_OBS)") if obs_every_step else
+                                       ("every env step (one launch per step)" if args.steps_per_launch == 1 else
+                                        "LAST step of each launch only (each step overwrites the lane's result row)"),
+                       "share_device": bool(args.share_device), "dist_backend": args.dist_backend if ctx.dist is not None else None,
                        "parallelism": f"independent lanes, static shard x{world} (one process per GPU), no collective"},
             "windows": dict(summarize(wins, total_steps), steps_each=args.steps,
                             note="value / ms_per_step are those of the median window; each window is bracketed by barrier + sync"),
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": tp.get("hbm_bytes_per_launch"),
+                         "achieved_is": "ALGORITHMIC bytes per launch (SURVEY.md 8(d): inputs + outputs of one env step at API dtype, x "
+                                        "lanes x steps per launch) / average launch duration" +
+                                        ("; with the observation trajectory on every step's output row IS written to HBM" if obs_every_step
+                                         else "; NOTE only the last step's rows of a launch reach HBM in this mode"),
+                         "counter_gbs": (tp.get("hbm_bytes_per_launch") / (tp.get("avg_launch_us") * 1e-6) / 1e9)
+                                        if tp.get("hbm_bytes_per_launch") and tp.get("avg_launch_us") else None,
+                         "traffic_over_algorithmic": tp.get("traffic_over_algorithmic"),
                          "traffic_source": (f"committed profile {tp.get('_file')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                             f"command; NOT measured in this run)") if tp else None,
                          "kernel": tp.get("kernel"), "avg_launch_us": avg_launch_s * 1e6, "launches": int(n_launch),
@@ -369,6 +432,8 @@ def main():
                                  "peak_tflops": F64_PEAK_TFLOPS, "algorithmic_flops_per_step": flops_pf, "J": J}},
             "frac_converged": frac_conv,
             "mean_nr_iterations": mean_iter,
+            "oracle_check": check,
+            "max_abs_err_vs_oracle": check.get("max_abs_err_vs_oracle") if check else None,
             "cpu_baseline": None,
         }
 
@@ -376,12 +441,24 @@ def main():
     k_sec = max(20, args.steps // 4)
     w_sec = max(2, args.warmup // 4)
 
-    # ---- the same workload, ONE launch per env step (a consumer that reads every step's full observation from HBM) -----------
+    # ---- the same workload WITHOUT the observation trajectory: only the last observation of each launch exists in HBM --------
+    if secondary and obs_every_step:
+        eng.set_trajectory(0)
+        w, _ = timed_windows(ctx, eng, k_sec, w_sec, step_kw, 3, preroll_steps=0)
+        if rank == 0:
+            res["rollout_last_observation_only"] = dict(
+                summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec, us_per_step=median_window(w)[0] / k_sec * 1e6,
+                note=f"{args.steps_per_launch} env steps per launch, every step overwrites the lane's result row: a rollout that only "
+                     "consumes rho / status (or nothing) between launches; NOT the reference's env.step contract, never `value`")
+
+    # ---- the same workload, ONE launch per env step (an agent that acts between any two steps) -----------------------------
     if secondary and args.steps_per_launch != 1:
-        w, _ = timed_windows(ctx, eng, k_sec, w_sec, step_kw, 3, preroll_steps=0, spl=1)
+        eng.set_trajectory(0)
+        w, t_l = timed_windows(ctx, eng, k_sec, w_sec, step_kw, 3, preroll_steps=0, spl=1)
         if rank == 0:
             res["one_launch_per_step"] = dict(summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec,
-                                              us_per_step=median_window(w)[0] / k_sec * 1e6)
+                                              us_per_step=median_window(w)[0] / k_sec * 1e6,
+                                              oracle_check=oracle_spot_check(ctx, eng, 32, t_last=t_l - 1, seed=1))
 
     # ---- OPT-IN, NOT the reference's algorithm (never the headline): Newton warm-started from the previous step -----------------
     if secondary and args.steps_per_launch != 1:
@@ -414,6 +491,26 @@ def main():
                                      frac_lanes_with_a_tripped_line=float((~rc.line_status).any(axis=1).mean()),
                                      lane_resets=int(np.asarray(n_resets).sum()))
         eng.reset()
+        # ... and with thermal limits x CASCADE_LIMIT_SCALE, so that lines really trip and the power flow is re-run inside the step
+        if "thermal_limits" in ch:
+            eng.set_thermal_limits(ch["thermal_limits"] * np.float32(CASCADE_LIMIT_SCALE))
+            eng.set_trajectory(args.steps_per_launch, eng.TRAJ_RHO)
+            w, _ = timed_windows(ctx, eng, k_sec, w_sec, dict(rebalance=1.02, cascade=True, auto_reset=True), 3, preroll_steps=0)
+            rc = eng.results()
+            _, _, n_resets = eng.episode()
+            rounds = rc.status[:, 3]
+            if rank == 0:
+                res["cascade_tripping"] = dict(
+                    summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec,
+                    workload=f"as cascade_on with thermal limits x {CASCADE_LIMIT_SCALE}: soft overflows accumulate, lines trip, the "
+                             "power flow is re-solved inside the step, lanes that end islanded / diverged restart (auto_reset)",
+                    frac_converged=float(rc.converged.mean()),
+                    frac_lanes_with_a_tripped_line=float((~rc.line_status).any(axis=1).mean()),
+                    frac_lanes_resolved_in_last_step=float((rounds > 0).mean()), lane_resets=int(np.asarray(n_resets).sum()),
+                    oracle_check=oracle_spot_check(ctx, eng, 32, seed=2))
+            eng.set_trajectory(0)
+            eng.set_thermal_limits(ch["thermal_limits"])
+        eng.reset()
 
     # ---- same workload with topology actions: 10 % of the lanes with a split substation (topology classes) ------
     if secondary:
@@ -430,6 +527,7 @@ def main():
         conv_s = float(eng.results().converged.mean())
         if rank == 0:
             res["split_topologies"] = dict(summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec,
+                                           oracle_check=oracle_spot_check(ctx, eng, 32, seed=3),
                                            workload=f"{args.env}, batch={B}: substation {sub} split (lines alternating between its two "
                                                     f"busbars) in {100.0 * pick.mean():.0f} % of the lanes", frac_converged=conv_s)
     eng.close()
@@ -498,7 +596,8 @@ def workload_n1(ctx, env, n_envs, k_sec):
            "value": ctx.world * n_envs * k_sec / med, "unit": "env steps/sec (each with its full N-1 screening)",
            "lane_power_flows_per_sec": ctx.world * B * k_sec / med, "ms_per_step": med / k_sec * 1e3, "steps_each": k_sec,
            "windows": summarize(w, ctx.world * n_envs * k_sec), "frac_converged": float(r.converged.mean()),
-           "frac_contingencies_diverged_or_islanding": float(1.0 - r.converged.reshape(n_envs, fan)[:, 1:].mean())}
+           "frac_contingencies_diverged_or_islanding": float(1.0 - r.converged.reshape(n_envs, fan)[:, 1:].mean()),
+           "oracle_check": oracle_spot_check(ctx, eng, 64, seed=4)}
     eng.close()
     return out
 
@@ -535,7 +634,8 @@ def workload_wcci(ctx, env, n_envs, k_sec, w_sec, cascade):
                "value": ctx.world * B * k_sec / med, "unit": "env steps/sec", "ms_per_step": med / k_sec * 1e3, "steps_each": k_sec,
                "windows": summarize(w, ctx.world * B * k_sec), "avg_launch_us": us, "algorithmic_bytes_per_step": b2,
                "hbm_gbs": b2 * B * (k_sec / max(n_l, 1)) / (us * 1e-6) / 1e9 if us > 0 else 0.0,
-               "frac_converged": float(r.converged.mean()), "mean_nr_iterations": float(r.n_iter[r.converged].mean())}
+               "frac_converged": float(r.converged.mean()), "mean_nr_iterations": float(r.n_iter[r.converged].mean()),
+               "oracle_check": oracle_spot_check(ctx, eng, 32, seed=5)}
     eng.close()
     return out
 
@@ -566,6 +666,19 @@ def workload_ptdf(ctx, env, B, reps):
     k_ms, n_l = eng.kernel_time()
     eng.set_profiling(0)
     flows = eng.ptdf_flows()
+    ptdf_check = None
+    if not ctx.args.no_oracle_check and not ctx.args.stub_engine:
+        try:                                              # CHECKER leg: 32 lanes vs the C oracle's DC power flow (pp.rundcpp restated)
+            from oracle.pf_oracle_c import COracle
+            ls_ = np.sort(np.random.default_rng(6).choice(B, 32, replace=False))
+            topo_, sb_ = eng.get_topology(0, 1)
+            ref = COracle(m).solve_rows(inj[ls_], np.tile(topo_, (32, 1)), np.tile(sb_, (32, 1)) if m.n_shunt else None, is_dc=True)
+            p_ref = ref["out"][:, lay.out_p_or:lay.out_p_or + m.n_line]
+            ptdf_check = {"n": 32, "max_abs_err_vs_oracle": float(np.abs(flows[ls_] - p_ref).max()),
+                          "ok": bool(np.all(np.abs(flows[ls_] - p_ref) <= 2e-4 + 5e-6 * np.abs(p_ref))),
+                          "against": "oracle/pf_oracle.c DC power flow of the same injection rows"}
+        except Exception as exc:
+            ptdf_check = {"error": repr(exc)[:300]}
     eng.lodf_screen(0, 8)
     t0 = time.perf_counter()
     for _ in range(5):
@@ -613,7 +726,7 @@ def workload_ptdf(ctx, env, B, reps):
     out = {"workload": f"{env} (118 substations) batch={B} lanes per GPU: DC line flows of every lane as ONE FP64 MFMA GEMM "
                        f"(flows = P_bus[{B}x{nb_pad}] . PTDF^T[{nb_pad}x{line_pad}], P_bus built in LDS from the injection rows in the "
                        f"same launch) for a fixed topology",
-           "large_batch": big,
+           "large_batch": big, "oracle_check": ptdf_check,
            "value": B * reps / el, "unit": "DC power flows/sec", "us_per_batch": us, "launches_per_batch": n_l / max(reps, 1),
            "roofline": {"bound": "mfma", "achieved": tf, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_PEAK_TFLOPS,
                         "hbm_gbs": hbm_bytes / (us * 1e-6) / 1e9 if us > 0 else 0.0,

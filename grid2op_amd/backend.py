@@ -35,6 +35,7 @@ __all__ = ["HipBackend"]
 
 
 _MODEL_CACHE = {}      # (real path, mtime) -> GridModel: the parsed grid file is immutable, re-loads reuse it (and its engine)
+MAX_BUSBAR_PER_SUB = 3   # include/gridpf.h GPF_MAX_BUSBAR: busbars per substation the compiled HIP kernels cover
 
 
 class _LanePool:
@@ -161,6 +162,12 @@ class HipBackend(Backend):
                 _MODEL_CACHE.pop(next(iter(_MODEL_CACHE)))
             _MODEL_CACHE[src] = m
         self._m = m
+        if self.n_busbar_per_sub > MAX_BUSBAR_PER_SUB:
+            # PandaPowerBackend takes any n_busbar_per_sub (pandaPowerBackend.py:356-372 duplicates the buses n times); the HIP
+            # kernels are compiled for 1..3 busbars per substation (include/gridpf.h GPF_MAX_BUSBAR): refuse at load time,
+            # with the reason, instead of failing at the first power flow
+            raise BackendError(f"HipBackend supports at most {MAX_BUSBAR_PER_SUB} busbars per substation "
+                               f"(n_busbar_per_sub={self.n_busbar_per_sub} requested)")
         self._init_from_model(m)
         self._acquire_lane()
 

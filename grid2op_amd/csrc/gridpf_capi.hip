@@ -114,7 +114,12 @@ struct gpf_engine {
   DevArr<float> lane_gen_delta, traj_rho;
   DevArr<unsigned char> maint;          // [chron_tables][chron_T][n_line] scheduled maintenance, or empty
   DevArr<signed char> traj_status;
+  DevArr<float> traj_out;               // per-step observation trajectory (GPF_TRAJ_OBS): [traj_cap][cap_lanes][n_out] ...
+  DevArr<int> traj_topo, traj_shb;
+  DevArr<unsigned char> traj_lstat;
   int traj_cap = 0;
+  int traj_what = 0;                    // GPF_TRAJ_* bits of the current buffers
+  int traj_valid = 0;                   // steps of the trajectory written by the last gpf_step_n
   bool has_delta = false;
   DevArr<double> rd_pmin, rd_pmax, rd_ru, rd_rd, rd_in;      // generator limits + staging of gpf_redispatch
   DevArr<unsigned char> rd_redisp, rd_u8;
@@ -197,6 +202,9 @@ struct gpf_engine {
     b.maint = maint.n ? maint.p : nullptr;
     b.topo0 = topo0.p; b.done = done.p; b.episode = episode.p;
     b.traj_rho = traj_cap ? traj_rho.p : nullptr; b.traj_status = traj_cap ? traj_status.p : nullptr; b.traj_cap = traj_cap;
+    const bool obs = traj_cap && (traj_what & GPF_TRAJ_OBS);
+    b.traj_out = obs ? traj_out.p : nullptr; b.traj_topo = obs ? traj_topo.p : nullptr; b.traj_shb = obs ? traj_shb.p : nullptr;
+    b.traj_lstat = obs ? traj_lstat.p : nullptr;
     b.lane_stride = cap_lanes; b.n_real_lanes = n_lanes;
     return b;
   }
@@ -602,6 +610,8 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   if (!d || !out_h || n_lanes <= 0) return fail(GPF_E_INVALID, "gpf_create: bad arguments");
   if (d->n_sub <= 0 || d->n_busbar <= 0 || d->n_line < 0 || d->n_gen <= 0) return fail(GPF_E_INVALID, "gpf_create: bad sizes");
   if (d->n_line > 256) return fail(GPF_E_CAPACITY, "gpf_create: n_line > 256 not supported by the step kernel");
+  if (d->n_busbar > GPF_MAX_BUSBAR)
+    return fail(GPF_E_CAPACITY, "gpf_create: n_busbar > 3 is not supported (the compiled kernels cover 1..3 busbars per substation)");
   int ndev = 0;
   hipError_t e0 = hipGetDeviceCount(&ndev);
   if (e0 != hipSuccess || ndev == 0)
@@ -802,6 +812,11 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     so.sto_pos = puti(d->storage_pos_topo_vect, ns); so.sto_sub = puti(d->storage_sub, ns);
     so.shunt_sub = puti(d->shunt_sub, nsh);
     so.gen_cnt = puti(e->h_gen_cnt.data(), e->h_gen_cnt.size());
+    {
+      std::vector<int> pl(g.dim_topo, -1);
+      for (int l = 0; l < nl; ++l) { pl[d->line_or_pos_topo_vect[l]] = l; pl[d->line_ex_pos_topo_vect[l]] = l; }
+      so.pos_line = puti(pl.data(), pl.size());
+    }
     so.n_dbl = (int)fd.size(); so.n_int = (int)fi.size();
     hipError_t eu = e->stat_dbl.upload(fd.data(), fd.size());
     if (eu == hipSuccess) eu = e->stat_int.upload(fi.data(), fi.size());
@@ -874,6 +889,7 @@ int gpf_destroy(gpf_handle e) {
   e->rd_pmin.release(); e->rd_pmax.release(); e->rd_ru.release(); e->rd_rd.release(); e->rd_in.release(); e->rd_redisp.release();
   e->rd_u8.release(); e->rd_after.release();
   e->topo0.release(); e->done.release(); e->episode.release(); e->lane_gen_delta.release(); e->traj_rho.release(); e->traj_status.release();
+  e->traj_out.release(); e->traj_topo.release(); e->traj_shb.release(); e->traj_lstat.release();
   if (e->d_params_s) (void)hipFree(e->d_params_s);
   e->stat_dbl.release();
   e->list_a.release(); e->list_b.release(); e->list_c.release(); e->d_classes.release();
@@ -1087,27 +1103,36 @@ int gpf_solve_lane(gpf_handle e, int32_t lane, const double* inj, const int32_t*
   std::memcpy(P + o_topo, topo, (size_t)g.dim_topo * 4);
   if (g.n_shunt) std::memcpy(P + o_sb, shunt_bus, (size_t)g.n_shunt * 4);
   hipStream_t st = e->stream;
-  HIP_TRY(hipMemcpyAsync(e->inj.p + (size_t)lane * g.n_inj, P + o_inj, (size_t)g.n_inj * 8, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(e->topo.p + (size_t)lane * g.dim_topo, P + o_topo, (size_t)g.dim_topo * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(e->topo0.p + (size_t)lane * g.dim_topo, P + o_topo, (size_t)g.dim_topo * 4, hipMemcpyHostToDevice, st));
-  if (g.n_shunt) HIP_TRY(hipMemcpyAsync(e->shunt_bus.p + (size_t)lane * g.n_shunt, P + o_sb, (size_t)g.n_shunt * 4, hipMemcpyHostToDevice, st));
-  {   // host bookkeeping of the lane's topology (as gpf_set_topology)
+  // Host bookkeeping of the lane's topology (as gpf_set_topology) and launch planning come FIRST: both can fail (capacity), and a
+  // rejected call must leave the device rows and the host mirror untouched -- the old bookkeeping is restored on failure.
+  LaunchPlan p, pb;
+  {
     int* mt = e->h_lane_topo.data() + (size_t)lane * g.dim_topo;
     int* ms = e->h_lane_sb.data() + (size_t)lane * std::max(g.n_shunt, 1);
-    if (!(std::memcmp(mt, topo, (size_t)g.dim_topo * sizeof(int)) == 0 &&
-          (!g.n_shunt || std::memcmp(ms, shunt_bus, (size_t)g.n_shunt * sizeof(int)) == 0))) {
-      std::memcpy(mt, topo, (size_t)g.dim_topo * sizeof(int));
-      if (g.n_shunt) std::memcpy(ms, shunt_bus, (size_t)g.n_shunt * sizeof(int));
+    const bool same = std::memcmp(mt, topo, (size_t)g.dim_topo * sizeof(int)) == 0 &&
+                      (!g.n_shunt || std::memcmp(ms, shunt_bus, (size_t)g.n_shunt * sizeof(int)) == 0);
+    const int o_nb = e->lane_nb[lane], o_nj = e->lane_nj[lane], o_mb = e->lane_mb[lane], o_cls = e->lane_class[lane];
+    if (!same) {
       count_lane(e, topo, g.n_shunt ? shunt_bus : nullptr, e->lane_nb[lane], e->lane_nj[lane], e->lane_mb[lane]);
       e->lane_class[lane] = topo_class_of(e, topo, g.n_shunt ? shunt_bus : nullptr);
       e->plan_valid = false;
     }
+    int rc = plan_launch(e, lane, 1, p, pb);
+    if (rc == GPF_OK) rc = upload_params_s(e, e->bufs(), p.tc ? &p : (pb.tc ? &pb : nullptr), p.dcf);
+    if (rc != GPF_OK) {
+      e->lane_nb[lane] = o_nb; e->lane_nj[lane] = o_nj; e->lane_mb[lane] = o_mb; e->lane_class[lane] = o_cls;
+      e->plan_valid = false;
+      return rc;
+    }
+    if (!same) {
+      std::memcpy(mt, topo, (size_t)g.dim_topo * sizeof(int));
+      if (g.n_shunt) std::memcpy(ms, shunt_bus, (size_t)g.n_shunt * sizeof(int));
+    }
   }
-  LaunchPlan p, pb;
-  int rc = plan_launch(e, lane, 1, p, pb);
-  if (rc != GPF_OK) return rc;
-  rc = upload_params_s(e, e->bufs(), p.tc ? &p : (pb.tc ? &pb : nullptr), p.dcf);
-  if (rc != GPF_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(e->inj.p + (size_t)lane * g.n_inj, P + o_inj, (size_t)g.n_inj * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(e->topo.p + (size_t)lane * g.dim_topo, P + o_topo, (size_t)g.dim_topo * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(e->topo0.p + (size_t)lane * g.dim_topo, P + o_topo, (size_t)g.dim_topo * 4, hipMemcpyHostToDevice, st));
+  if (g.n_shunt) HIP_TRY(hipMemcpyAsync(e->shunt_bus.p + (size_t)lane * g.n_shunt, P + o_sb, (size_t)g.n_shunt * 4, hipMemcpyHostToDevice, st));
   const double tol_pu = tol_mva / g.sn_mva;
   HIP_TRY(gpf_launch_runpf_sparse(p, e->device, e->d_params_s, st, lane, 1, is_dc, max_iter, tol_pu));
   if (pb.sparse_nb) HIP_TRY(gpf_launch_runpf_sparse(pb, e->device, e->d_params_s, st, lane, 1, is_dc, max_iter, tol_pu));
@@ -1213,6 +1238,8 @@ int gpf_step_n(gpf_handle e, int32_t t0, int32_t n_steps, const gpf_step_opts* o
   if (!e || !o) return fail(GPF_E_INVALID, "gpf_step_n: null");
   if (n_steps <= 0) return fail(GPF_E_INVALID, "gpf_step_n: n_steps must be positive");
   if (!e->chron.p || e->chron_T <= 0) return fail(GPF_E_INVALID, "gpf_step_n: no chronics uploaded");
+  if (e->traj_cap && n_steps > e->traj_cap)
+    return fail(GPF_E_INVALID, "gpf_step_n: n_steps exceeds the trajectory buffer (gpf_set_trajectory sizes it; 0 releases it)");
   HIP_TRY(hipSetDevice(e->device));
   LaunchPlan p, pb;
   int rc = plan_launch(e, 0, e->n_lanes, p, pb);
@@ -1235,6 +1262,7 @@ int gpf_step_n(gpf_handle e, int32_t t0, int32_t n_steps, const gpf_step_opts* o
   HIP_TRY(hipGetLastError());
   if (e->profiling) HIP_TRY(hipEventRecord(eb, e->stream));
   if (e->window) ++e->win_launches;
+  e->traj_valid = e->traj_cap ? n_steps : 0;
   return GPF_OK;
 }
 
@@ -1310,32 +1338,67 @@ int gpf_redispatch(gpf_handle e, int32_t lane0, int32_t n, const double* new_p, 
   return GPF_OK;
 }
 
-int gpf_set_trajectory(gpf_handle e, int32_t n_steps_cap) {
-  if (!e || n_steps_cap < 0) return fail(GPF_E_INVALID, "gpf_set_trajectory: bad arguments");
+int gpf_set_trajectory(gpf_handle e, int32_t n_steps_cap, int32_t what) {
+  if (!e || n_steps_cap < 0 || (what & ~(GPF_TRAJ_RHO | GPF_TRAJ_OBS))) return fail(GPF_E_INVALID, "gpf_set_trajectory: bad arguments");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->traj_rho.release(); e->traj_status.release();
-  e->traj_cap = 0;
-  if (n_steps_cap > 0) {
-    HIP_TRY(e->traj_rho.alloc((size_t)n_steps_cap * e->cap_lanes * e->g.n_line));
-    HIP_TRY(e->traj_status.alloc((size_t)n_steps_cap * e->cap_lanes));
-    HIP_TRY(hipMemset(e->traj_status.p, 0xFF, (size_t)n_steps_cap * e->cap_lanes));
+  e->traj_out.release(); e->traj_topo.release(); e->traj_shb.release(); e->traj_lstat.release();
+  e->traj_cap = 0; e->traj_what = 0; e->traj_valid = 0;
+  if (n_steps_cap > 0 && what) {
+    const size_t rows = (size_t)n_steps_cap * e->cap_lanes;
+    const gpf::GridDev& g = e->g;
+    HIP_TRY(e->traj_rho.alloc(rows * g.n_line));
+    HIP_TRY(e->traj_status.alloc(rows));
+    HIP_TRY(hipMemset(e->traj_status.p, 0xFF, rows));
+    if (what & GPF_TRAJ_OBS) {
+      HIP_TRY(e->traj_out.alloc(rows * g.n_out)); HIP_TRY(e->traj_topo.alloc(rows * g.dim_topo));
+      HIP_TRY(e->traj_shb.alloc(rows * std::max(g.n_shunt, 1))); HIP_TRY(e->traj_lstat.alloc(rows * g.n_line));
+    }
     e->traj_cap = n_steps_cap;
+    e->traj_what = what | GPF_TRAJ_RHO;
   }
   return GPF_OK;
 }
 
+}  // extern "C"
+namespace {
+// rows [step0, step0 + n_steps) x lanes [lane0, lane0 + n) of a [cap][cap_lanes][stride] device buffer -> dense host array
+template <class T>
+int traj_copy(gpf_engine* e, T* dst, const T* src, size_t stride, int step0, int n_steps, int lane0, int n) {
+  if (!dst || stride == 0 || n == 0 || n_steps == 0) return GPF_OK;
+  const size_t B = e->cap_lanes;
+  HIP_TRY(hipMemcpy2DAsync(dst, (size_t)n * stride * sizeof(T), src + ((size_t)step0 * B + lane0) * stride, B * stride * sizeof(T),
+                           (size_t)n * stride * sizeof(T), (size_t)n_steps, hipMemcpyDeviceToHost, e->stream));
+  return GPF_OK;
+}
+}  // namespace
+extern "C" {
+
 int gpf_get_trajectory(gpf_handle e, int32_t step0, int32_t n_steps, int32_t lane0, int32_t n, float* rho, int8_t* status) {
-  if (!check_range(e, lane0, n) || step0 < 0 || n_steps < 0 || step0 + n_steps > e->traj_cap)
-    return fail(GPF_E_INVALID, "gpf_get_trajectory: bad range (gpf_set_trajectory sizes the buffer)");
+  if (!check_range(e, lane0, n) || step0 < 0 || n_steps < 0 || step0 + n_steps > e->traj_valid)
+    return fail(GPF_E_INVALID, "gpf_get_trajectory: bad range (only the steps of the last gpf_step_n are retrievable)");
   HIP_TRY(hipSetDevice(e->device));
-  const size_t nl = e->g.n_line, B = e->cap_lanes;
-  if (rho)
-    HIP_TRY(hipMemcpy2DAsync(rho, (size_t)n * nl * sizeof(float), e->traj_rho.p + ((size_t)step0 * B + lane0) * nl, B * nl * sizeof(float),
-                             (size_t)n * nl * sizeof(float), (size_t)n_steps, hipMemcpyDeviceToHost, e->stream));
-  if (status)
-    HIP_TRY(hipMemcpy2DAsync(status, (size_t)n, e->traj_status.p + (size_t)step0 * B + lane0, B, (size_t)n, (size_t)n_steps,
-                             hipMemcpyDeviceToHost, e->stream));
+  int rc = traj_copy(e, rho, e->traj_rho.p, (size_t)e->g.n_line, step0, n_steps, lane0, n);
+  if (rc == GPF_OK) rc = traj_copy(e, reinterpret_cast<signed char*>(status), e->traj_status.p, 1, step0, n_steps, lane0, n);
+  if (rc != GPF_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_get_trajectory_obs(gpf_handle e, int32_t step0, int32_t n_steps, int32_t lane0, int32_t n, float* out, int32_t* topo_vect,
+                           int32_t* shunt_bus, uint8_t* line_status) {
+  if (!check_range(e, lane0, n) || step0 < 0 || n_steps < 0 || step0 + n_steps > e->traj_valid)
+    return fail(GPF_E_INVALID, "gpf_get_trajectory_obs: bad range (only the steps of the last gpf_step_n are retrievable)");
+  if (!(e->traj_what & GPF_TRAJ_OBS))
+    return fail(GPF_E_INVALID, "gpf_get_trajectory_obs: no observation trajectory (gpf_set_trajectory(.., GPF_TRAJ_OBS))");
+  HIP_TRY(hipSetDevice(e->device));
+  const gpf::GridDev& g = e->g;
+  int rc = traj_copy(e, out, e->traj_out.p, (size_t)g.n_out, step0, n_steps, lane0, n);
+  if (rc == GPF_OK) rc = traj_copy(e, topo_vect, e->traj_topo.p, (size_t)g.dim_topo, step0, n_steps, lane0, n);
+  if (rc == GPF_OK) rc = traj_copy(e, shunt_bus, e->traj_shb.p, (size_t)g.n_shunt, step0, n_steps, lane0, n);
+  if (rc == GPF_OK) rc = traj_copy(e, line_status, e->traj_lstat.p, (size_t)g.n_line, step0, n_steps, lane0, n);
+  if (rc != GPF_OK) return rc;
   HIP_TRY(hipStreamSynchronize(e->stream));
   return GPF_OK;
 }
@@ -1630,6 +1693,10 @@ int gpf_device_pointers(gpf_handle e, void** ptrs, void** stream) {
   ptrs[5] = e->line_status.p; ptrs[6] = e->status.p; ptrs[7] = e->chron.p;
   ptrs[8] = e->rho.p; ptrs[9] = e->overflow_count.p; ptrs[10] = e->done.p; ptrs[11] = e->episode.p; ptrs[12] = e->bus_vm.p;
   ptrs[13] = e->bus_va.p; ptrs[14] = e->shunt_bus_out.p; ptrs[15] = e->disc_round.p;
+  ptrs[16] = e->traj_cap ? e->traj_rho.p : nullptr; ptrs[17] = e->traj_cap ? e->traj_status.p : nullptr;
+  const bool obs = e->traj_cap && (e->traj_what & GPF_TRAJ_OBS);
+  ptrs[18] = obs ? e->traj_out.p : nullptr; ptrs[19] = obs ? e->traj_topo.p : nullptr; ptrs[20] = obs ? e->traj_shb.p : nullptr;
+  ptrs[21] = obs ? e->traj_lstat.p : nullptr;
   if (stream) *stream = e->stream;
   return GPF_OK;
 }

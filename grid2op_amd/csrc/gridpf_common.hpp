@@ -75,6 +75,13 @@ struct Bufs {
   int* episode;                // [B][2] {steps survived since the last reset, number of auto-resets}
   float* traj_rho;             // [traj_cap][B][n_line] rho of every step of the last multi-step launch, or nullptr
   signed char* traj_status;    // [traj_cap][B] GPF_ST_* of every step of the last multi-step launch
+  // complete backend observation of EVERY step of a multi-step launch (gpf_set_trajectory(.., GPF_TRAJ_OBS)), or nullptr: the
+  // step kernel then writes each step's results row / topo_vect / shunt buses / line status into row [step][lane] of these
+  // buffers instead of overwriting the lane's single row, and copies the last step's rows to out / topo_out / ... at the end
+  float* traj_out;             // [traj_cap][B][n_out]
+  int* traj_topo;              // [traj_cap][B][dim_topo]
+  int* traj_shb;               // [traj_cap][B][n_shunt]
+  unsigned char* traj_lstat;   // [traj_cap][B][n_line]
   int traj_cap;
   long long lane_stride;       // B (padded lane count): stride of the trajectory buffers
   long long n_real_lanes;      // lanes >= this index are padding (ghost lanes of instance groups / lane lists)
@@ -124,16 +131,18 @@ typedef signed char i8;
 template <class T>
 __device__ __forceinline__ GPF_GLOBAL T* gptr(T* p) { return (GPF_GLOBAL T*)p; }
 
+// Rows the results of one solve go to: the lane's own row of out / topo_out / shunt_bus_out / line_status (orow = lane), or row
+// orow = step * lane_stride + lane of the per-step observation trajectory (otraj).
 template <int GW = WAVE>
-__device__ inline void write_nan_results(const GridDev& g, const Bufs& b, int inst, int tid) {
-  auto out = gptr(b.out) + (size_t)inst * g.n_out;
+__device__ inline void write_nan_results(const GridDev& g, const Bufs& b, int inst, int tid, int orow, bool otraj) {
+  auto out = gptr(otraj ? b.traj_out : b.out) + (size_t)orow * g.n_out;
   const float nanv = __builtin_nanf("");
   for (int i = tid; i < g.n_out; i += GW) out[i] = nanv;
-  auto to = gptr(b.topo_out) + (size_t)inst * g.dim_topo;
+  auto to = gptr(otraj ? b.traj_topo : b.topo_out) + (size_t)orow * g.dim_topo;
   for (int i = tid; i < g.dim_topo; i += GW) to[i] = -1;
-  auto so = gptr(b.shunt_bus_out) + (size_t)inst * g.n_shunt;
+  auto so = gptr(otraj ? b.traj_shb : b.shunt_bus_out) + (size_t)orow * g.n_shunt;
   for (int i = tid; i < g.n_shunt; i += GW) so[i] = -1;
-  auto ls = gptr(b.line_status) + (size_t)inst * g.n_line;
+  auto ls = gptr(otraj ? b.traj_lstat : b.line_status) + (size_t)orow * g.n_line;
   for (int i = tid; i < g.n_line; i += GW) ls[i] = 0;
   const double nand = __builtin_nan("");
   auto bvm = gptr(b.bus_vm) + (size_t)inst * g.nb_tot;

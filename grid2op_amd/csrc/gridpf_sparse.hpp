@@ -30,6 +30,7 @@ struct StatOff {
                    // every slack generator connected; reference / fixed rows are identity), small grids only; -1: none
   int line_or_pos, line_ex_pos, line_or_sub, line_ex_sub, br_slot, gen_pos, gen_sub, gen_slack, load_pos, load_sub, sto_pos,
       sto_sub, shunt_sub, pair_rc, up, prog;
+  int pos_line;    // (int section) [dim_topo] line whose end sits at that topo_vect position, -1: the position of a generator / load / storage unit
 };
 // Pointer to a static table that is either staged in LDS or read in place: in place it is re-typed as a GLOBAL pointer
 // (gptr, gridpf_common.hpp) so that global_load is emitted instead of flat_load.
@@ -49,7 +50,7 @@ struct StatView {
   static constexpr bool ALL = STAGE == 2, HOT = STAGE >= 1;
   SP<double, ALL> br_y, br_bdc, sub_vn_kv, shunt_fact, gen_min_q, gen_max_q, line_vn, load_vn, gen_vn, sto_vn, shunt_vn, dc_inv, gen_qmin_tot, gen_qmax_tot;
   SP<int, ALL> line_or_pos, line_ex_pos, line_or_sub, line_ex_sub, br_slot, gen_pos, gen_sub, gen_slack, load_pos, load_sub,
-      sto_pos, sto_sub, shunt_sub, gen_cnt;
+      sto_pos, sto_sub, shunt_sub, gen_cnt, pos_line;
   SP<int, HOT> pair_rc;   // [nslot_y] slot_row | slot_col << 16 of the original-pattern blocks
   SP<int, HOT> up;        // [n_up][2] undirected off-diagonal pairs (gridpf_symbolic.hpp: build_upairs), single-busbar Newton loop
   SP<int, HOT> prog;      // level-scheduled program (layout: gridpf_symbolic.hpp)
@@ -65,7 +66,7 @@ __device__ inline void stat_view(StatView<STAGE>& v, const StatOff& o, const dou
   v.line_or_pos.p = i + o.line_or_pos; v.line_ex_pos.p = i + o.line_ex_pos; v.line_or_sub.p = i + o.line_or_sub;
   v.line_ex_sub.p = i + o.line_ex_sub; v.br_slot.p = i + o.br_slot; v.gen_pos.p = i + o.gen_pos; v.gen_sub.p = i + o.gen_sub;
   v.gen_slack.p = i + o.gen_slack; v.load_pos.p = i + o.load_pos; v.load_sub.p = i + o.load_sub; v.sto_pos.p = i + o.sto_pos;
-  v.sto_sub.p = i + o.sto_sub; v.shunt_sub.p = i + o.shunt_sub; v.pair_rc.p = i + o.pair_rc; v.up.p = i + o.up; v.prog.p = i + o.prog;
+  v.sto_sub.p = i + o.sto_sub; v.shunt_sub.p = i + o.shunt_sub; v.pos_line.p = i + o.pos_line; v.pair_rc.p = i + o.pair_rc; v.up.p = i + o.up; v.prog.p = i + o.prog;
   v.node_of.p = nullptr;
 }
 // LDS bytes of the staged part of the static data.  Single-busbar kernels (nb1; the old level-header program at the head of the
@@ -770,6 +771,10 @@ struct SolveCtl {
                       // scatters every element's new set-point as it computes it)
   bool warm;          // OPT-IN, not the reference's algorithm: with `reuse`, Newton starts from the previous solve's voltages
                       // (CarveP::va / vm still hold them) instead of the DC initialisation pandapower does on every call
+  bool otraj;         // the results go to row `orow` of the per-step observation trajectory (Bufs::traj_out ...) instead of the
+  int orow;           // lane's own row `orow` = lane of out / topo_out / shunt_bus_out / line_status (see write_nan_results)
+  bool write_topo;    // write the topology-only outputs (topo_vect, line status, shunt buses) even when `reuse` says they stand:
+                      // every row of the observation trajectory is complete
 };
 // per-group results of the topology phases, kept by the caller across solves
 struct TopoState {
@@ -816,7 +821,6 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   auto SimP = [&](int i) -> double* { return BS == 2 ? c.A + HS + ((size_t)S.rslot0 + i) * 2 + 1 : c.Sim + i; };
   const auto topo_g = gptr(b.topo) + (size_t)inst * g.dim_topo;            // lane rows in HBM: explicit global address space
   const auto shb = gptr(b.shunt_bus) + (size_t)inst * g.n_shunt;
-  const auto lstat = gptr(b.line_status) + (size_t)inst * g.n_line;
   n_iter_out = 0;
   nb_out = 0;
   GPF_STAMPS(0);
@@ -1300,7 +1304,9 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   GPF_STAMPS(5);
 
   // ---- K6: results ---------------------------------------------------------------------------------------------------------
-  const auto out = gptr(b.out) + (size_t)inst * g.n_out;
+  const auto out = gptr(ctl.otraj ? b.traj_out : b.out) + (size_t)ctl.orow * g.n_out;
+  const auto lstat = gptr(ctl.otraj ? b.traj_lstat : b.line_status) + (size_t)ctl.orow * g.n_line;
+  const bool wtopo = !reuse || ctl.write_topo;
   const double RAD2DEG = 57.295779513082320877;
   const double SQRT3 = 1.7320508075688772935;
   GPF_LSYNC();
@@ -1318,7 +1324,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   }
   for (int l = tid; l < g.n_line; l += GW) {
     const int f = c.lor_b[l], t = c.lex_b[l];
-    if (!reuse) lstat[l] = f >= 0 ? 1 : 0;
+    if (wtopo) lstat[l] = f >= 0 ? 1 : 0;
     float p_or = 0.f, q_or = 0.f, v_or = 0.f, a_or = 0.f, th_or = 0.f;
     float p_ex = 0.f, q_ex = 0.f, v_ex = 0.f, a_ex = 0.f, th_ex = 0.f;
     if (f >= 0) {
@@ -1365,7 +1371,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     out[oo.sto_v + i] = on ? (float)(c.vm[bu] * sv.sto_vn[i]) : 0.f;
     out[oo.sto_th + i] = on ? (float)(c.va[bu] * RAD2DEG) : 0.f;
   }
-  const auto sbo = gptr(b.shunt_bus_out) + (size_t)inst * g.n_shunt;
+  const auto sbo = gptr(ctl.otraj ? b.traj_shb : b.shunt_bus_out) + (size_t)ctl.orow * g.n_shunt;
   for (int i = tid; i < g.n_shunt; i += GW) {
     const int bu = c.sh_b[i];
     const bool on = bu >= 0;
@@ -1373,7 +1379,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     out[oo.sh_p + i] = on ? (float)(GPF_INJ(oo.inj_sh_p + i) * sv.shunt_fact[i] * v * v) : 0.f;
     out[oo.sh_q + i] = (on && !is_dc) ? (float)(GPF_INJ(oo.inj_sh_q + i) * sv.shunt_fact[i] * v * v) : 0.f;
     out[oo.sh_v + i] = on ? (float)(v * sv.shunt_vn[i]) : 0.f;
-    if (!reuse) sbo[i] = on ? shb[i] : -1;
+    if (wtopo) sbo[i] = on ? shb[i] : -1;
   }
   // generators (pypower pfsoln): per-bus totals accumulated in LDS with atomics (the block array is dead by now and
   // serves as scratch), then a per-generator pass.  Bus balances: total generation at a bus = S_inj - (P,Q)_spec,
@@ -1426,12 +1432,14 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     }
   }
   GPF_STAMPS(25);
-  if (!reuse) {                          // topo_vect only depends on the topology: it stands when the topology does
-    const auto to = gptr(b.topo_out) + (size_t)inst * g.dim_topo;
-    for (int i = tid; i < g.dim_topo; i += GW) { const int v = topo_g[i]; to[i] = v >= 1 ? v : -1; }
-    GPF_SYNC();
-    for (int l = tid; l < g.n_line; l += GW) {
-      if (c.lor_b[l] < 0) { to[sv.line_or_pos[l]] = -1; to[sv.line_ex_pos[l]] = -1; }
+  if (wtopo) {                           // topo_vect only depends on the topology: it stands when the topology does
+    // one pass, every position written once by one lane: an element's bus, -1 for both ends of a line that is out of service
+    // (StatOff::pos_line names the line of a position)
+    const auto to = gptr(ctl.otraj ? b.traj_topo : b.topo_out) + (size_t)ctl.orow * g.dim_topo;
+    for (int i = tid; i < g.dim_topo; i += GW) {
+      const int v = topo_g[i], pl = sv.pos_line[i];
+      const bool line_out = pl >= 0 && c.lor_b[pl] < 0;
+      to[i] = (v >= 1 && !line_out) ? v : -1;
     }
   }
   GPF_STAMPS(26);
@@ -1501,11 +1509,12 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   GPF_STAMPS_DECL;
   SolveCtl ctl;
   ctl.inj_staged = false; ctl.topo_staged = false; ctl.reuse = false; ctl.dcf = false; ctl.write_bus = true; ctl.warm = false; ctl.sums_done = false;
+  ctl.otraj = false; ctl.orow = inst; ctl.write_topo = true;
   TopoState ts;
   ts.status = 0; ts.nb = 0; ts.dc_base = false; ts.gen_base = false;
   const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, is_dc, max_iter, tol_pu, tid, ctl, ts, n_iter, nb, a_first GPF_STAMPS_ARG);
   GPF_SYNC();
-  if (st != 0) write_nan_results<GW>(P->g, P->b, inst, tid);
+  if (st != 0) write_nan_results<GW>(P->g, P->b, inst, tid, inst, false);
   if (tid == 0) {
     const auto s = gptr(P->b.status) + (size_t)inst * 4;
     s[0] = st; s[1] = n_iter; s[2] = nb; s[3] = 0;
@@ -1571,9 +1580,13 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
     asm volatile("" : "+v"(grp), "+v"(tid), "+v"(inst));                                                            \
     carve_sparse<NB>(c, smem + (size_t)grp * per_inst, g, lds_nslot, lds_nslot_y, STAGE != 0, lds_rows, lds_dcf);   \
   } while (0)
+  // per-step observation trajectory (block-uniform): every step's rows go to [step][lane] of Bufs::traj_*, else to the lane's rows
+  const bool tobs = b.traj_out != nullptr;
   for (int step = 0; step < sa.n_steps; ++step) {
     GPF_REDERIVE();
     const bool last = step + 1 == sa.n_steps;
+    const bool otraj = tobs && step < b.traj_cap;
+    int orow = otraj ? step * (int)b.lane_stride + inst : inst;
     GPF_STAMPS(19);
     // ---- K9: chronics row -> injections -----------------------------------------------------------------------------------
     bool sums_in_k9 = false;
@@ -1691,6 +1704,8 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       int it_k = 0, nb_k = 0;
       SolveCtl ctl;
       ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && sa.n_steps > 1; ctl.write_bus = last; ctl.warm = sa.warm_start != 0; ctl.sums_done = first && sums_in_k9;
+      orow = otraj ? step * (int)b.lane_stride + inst : inst;          // (re-derived: see GPF_REDERIVE)
+      ctl.otraj = otraj; ctl.orow = orow; ctl.write_topo = otraj;
       const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, sa.is_dc, max_iter, tol_pu, tid, ctl, ts, it_k, nb_k, a_first GPF_STAMPS_ARG);
       first = false;
       GPF_SYNC_IF(sa.cascade != 0 && g.n_line > GW);   // (every line loop maps line l to lane l % GW: lanes read their own rows)
@@ -1698,7 +1713,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       if (st != 0 || !sa.cascade || rounds >= sa.max_rounds) more = false;   // at most max_rounds re-solves
       int any_disc = 0;
       if (more && !ghost) {
-        const auto out = gptr(b.out) + (size_t)inst * g.n_out;
+        const auto out = gptr(otraj ? b.traj_out : b.out) + (size_t)orow * g.n_out;
         const auto ovc = gptr(b.overflow_count) + (size_t)inst * g.n_line;
         const auto dround = gptr(b.disc_round) + (size_t)inst * g.n_line;
         const auto inc_flag = (GPF_GLOBAL int*)(gptr(b.rho) + (size_t)inst * g.n_line);
@@ -1730,11 +1745,12 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
     }
     GPF_STAMPS(9);
     GPF_REDERIVE();
+    orow = otraj ? step * (int)b.lane_stride + inst : inst;
     // ---- per-step outputs -----------------------------------------------------------------------------------------------------
-    if (st != 0) { write_nan_results<GW>(g, b, inst, tid); a_first = __builtin_nanf(""); }
+    if (st != 0) { write_nan_results<GW>(g, b, inst, tid, orow, otraj); a_first = __builtin_nanf(""); }
     GPF_SYNC_IF(G::block_any_u(st != 0));          // NaN rows are written with another lane mapping than the line loop's
     {
-      const auto out = gptr(b.out) + (size_t)inst * g.n_out;
+      const auto out = gptr(otraj ? b.traj_out : b.out) + (size_t)orow * g.n_out;
       const auto ovc = gptr(b.overflow_count) + (size_t)inst * g.n_line;
       const auto rho = gptr(b.rho) + (size_t)inst * g.n_line;
       const auto thermal_limit = gptr(b.thermal_limit);
@@ -1783,6 +1799,16 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   }
 #undef GPF_REDERIVE
   grp = grp0; tid = tid0; inst = inst0;
+  if (tobs) {
+    // the getters / device views of the lane's own rows return the LAST step: copy its trajectory rows there
+    const int ls = sa.n_steps <= b.traj_cap ? sa.n_steps - 1 : b.traj_cap - 1;
+    const size_t r = (size_t)ls * b.lane_stride + inst;
+    GPF_SYNC();                                    // rows written with the element / line lane mappings, read back coalesced
+    { const auto s_ = gptr(b.traj_out) + r * g.n_out; const auto d_ = gptr(b.out) + (size_t)inst * g.n_out; for (int i = tid; i < g.n_out; i += GW) d_[i] = s_[i]; }
+    { const auto s_ = gptr(b.traj_topo) + r * g.dim_topo; const auto d_ = gptr(b.topo_out) + (size_t)inst * g.dim_topo; for (int i = tid; i < g.dim_topo; i += GW) d_[i] = s_[i]; }
+    { const auto s_ = gptr(b.traj_shb) + r * g.n_shunt; const auto d_ = gptr(b.shunt_bus_out) + (size_t)inst * g.n_shunt; for (int i = tid; i < g.n_shunt; i += GW) d_[i] = s_[i]; }
+    { const auto s_ = gptr(b.traj_lstat) + r * g.n_line; const auto d_ = gptr(b.line_status) + (size_t)inst * g.n_line; for (int i = tid; i < g.n_line; i += GW) d_[i] = s_[i]; }
+  }
   if (tid == 0 && !ghost) { gptr(b.episode)[2 * (size_t)inst] = ep_steps; gptr(b.episode)[2 * (size_t)inst + 1] = ep_resets; }
   if (STAGE && !ghost) {                                      // the last step's injection row -> HBM (gpf_get_injections, next launches)
     const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj;

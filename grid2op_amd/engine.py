@@ -214,14 +214,17 @@ class PowerFlowEngine:
         ol = np.ascontiguousarray(out_lines, dtype=np.int32)
         check(self._lib.gpf_fanout_n1(self._h, src_lane, dst_lane0, ol.size, ptr(ol, C.c_int32)), "gpf_fanout_n1")
 
-    def candidate_topologies(self, base_topo, actions) -> np.ndarray:
+    def candidate_topologies(self, base_topo, actions, last_bus=None) -> np.ndarray:
         """``[len(actions), dim_topo]`` topology rows = ``base_topo`` modified by each candidate action, described as grid2op
         describes them (Action/baseAction.py ``set_bus`` / ``set_line_status`` / ``change_bus``): a dict with any of
         ``"set_bus": {topo_vect position: bus}``, ``"lines_or_bus" / "lines_ex_bus" / "loads_bus" / "gens_bus" / "storages_bus":
-        [(element id, bus)]``, ``"set_line_status": [(line id, +1 | -1)]`` (reconnection puts both ends on busbar 1 unless a bus is
-        given as well), ``"change_bus": [positions]`` (1 <-> 2).  An empty dict is the do-nothing candidate."""
+        [(element id, bus)]``, ``"set_line_status": [(line id, +1 | -1)]``, ``"change_bus": [positions]`` (1 <-> 2; refused with
+        more than 2 busbars per substation, as grid2op refuses it).  A reconnection without an explicit bus puts each end back on
+        its LAST KNOWN busbar (``last_bus``: the ``[dim_topo]`` row _BackendAction keeps in ``last_topo_registered``,
+        Action/_backendAction.py; busbar 1 where it is unknown or not given).  An empty dict is the do-nothing candidate."""
         m = self.model
         base = np.asarray(base_topo, dtype=np.int32).reshape(m.dim_topo)
+        last = None if last_bus is None else np.asarray(last_bus, dtype=np.int32).reshape(m.dim_topo)
         pos_of = {"lines_or_bus": m.line_or_pos_topo_vect, "lines_ex_bus": m.line_ex_pos_topo_vect, "loads_bus": m.load_pos_topo_vect,
                   "gens_bus": m.gen_pos_topo_vect, "storages_bus": m.storage_pos_topo_vect}
         out = np.tile(base, (len(actions), 1))
@@ -232,12 +235,16 @@ class PowerFlowEngine:
                 if st < 0:
                     row[po] = row[pe] = -1
                 elif st > 0 and (row[po] < 1 or row[pe] < 1):
-                    row[po] = row[pe] = 1
+                    for p_ in (po, pe):
+                        if row[p_] < 1:
+                            row[p_] = last[p_] if (last is not None and last[p_] >= 1) else 1
             for key, pos in pos_of.items():
                 for el, bus in act.get(key, ()):
                     row[pos[el]] = bus
             for p_, bus in dict(act.get("set_bus", {})).items():
                 row[p_] = bus
+            if act.get("change_bus", ()) and self.n_busbar > 2:
+                raise ValueError("change_bus is only defined for 2 busbars per substation (grid2op refuses it otherwise)")
             for p_ in act.get("change_bus", ()):
                 if row[p_] >= 1:
                     row[p_] = 2 if row[p_] == 1 else 1
@@ -392,8 +399,14 @@ class PowerFlowEngine:
                                        ptr(ok, C.c_uint8), ptr(after, C.c_float)), "gpf_redispatch")
         return ok.astype(bool), after
 
-    def set_trajectory(self, n_steps_cap: int):
-        check(self._lib.gpf_set_trajectory(self._h, int(n_steps_cap)), "gpf_set_trajectory")
+    TRAJ_RHO, TRAJ_OBS = 1, 2
+
+    def set_trajectory(self, n_steps_cap: int, what: int = 1):
+        """Trajectory buffers of multi-step launches: ``what`` = `TRAJ_RHO` (rho + status of every step) or `TRAJ_OBS` (in
+        addition the complete backend observation of every step: results row, topo_vect, shunt buses, line status).
+        ``n_steps_cap = 0`` releases them."""
+        check(self._lib.gpf_set_trajectory(self._h, int(n_steps_cap), int(what)), "gpf_set_trajectory")
+        self._traj_cap = int(n_steps_cap) if what else 0
 
     def trajectory(self, n_steps: int, step0: int = 0, lane0: int = 0, n: Optional[int] = None):
         """(rho ``[n_steps, n, n_line]`` float32, status ``[n_steps, n]`` int8) of the steps of the last multi-step launch."""
@@ -403,6 +416,26 @@ class PowerFlowEngine:
         check(self._lib.gpf_get_trajectory(self._h, int(step0), int(n_steps), lane0, n, ptr(rho, C.c_float), ptr(st, C.c_int8)),
               "gpf_get_trajectory")
         return rho, st
+
+    def trajectory_obs(self, n_steps: int, step0: int = 0, lane0: int = 0, n: Optional[int] = None):
+        """The backend observation of every step of the last multi-step launch (`set_trajectory(cap, TRAJ_OBS)`): a list of
+        `LaneResults` (one per step; ``status`` column 0 from the status trajectory, bus voltages are not part of it)."""
+        lane0, n = self._range(lane0, n)
+        m = self.model
+        out = np.empty((n_steps, n, self.n_out), dtype=np.float32)
+        tv = np.empty((n_steps, n, m.dim_topo), dtype=np.int32)
+        sb = np.empty((n_steps, n, m.n_shunt), dtype=np.int32)
+        ls = np.empty((n_steps, n, m.n_line), dtype=np.uint8)
+        check(self._lib.gpf_get_trajectory_obs(self._h, int(step0), int(n_steps), lane0, n, ptr(out, C.c_float), ptr(tv, C.c_int32),
+                                               ptr(sb, C.c_int32), ptr(ls, C.c_uint8)), "gpf_get_trajectory_obs")
+        _, st = self.trajectory(n_steps, step0, lane0, n)
+        res = []
+        for k in range(n_steps):
+            st4 = np.full((n, 4), -1, dtype=np.int32)
+            st4[:, 0] = st[k]
+            res.append(LaneResults(out=out[k], topo_vect=tv[k], shunt_bus=sb[k], line_status=ls[k].astype(bool), status=st4,
+                                   bus_vm=None, bus_va=None, _slices=self.out_slices))
+        return res
 
     def episode(self, lane0: int = 0, n: Optional[int] = None):
         """(done ``[n]`` bool, steps survived since the last reset ``[n]``, auto-resets ``[n]``)."""
@@ -420,7 +453,7 @@ class PowerFlowEngine:
         float64, ``bus_vm`` / ``bus_va`` float64.  The engine works on its own HIP stream: call `sync` (or make the consumer's
         stream wait on ``views["stream"]``, a ``torch.cuda.ExternalStream``) before reading."""
         import torch
-        ptrs = (C.c_void_p * 16)()
+        ptrs = (C.c_void_p * 22)()
         stream = C.c_void_p()
         check(self._lib.gpf_device_pointers(self._h, ptrs, C.byref(stream)), "gpf_device_pointers")
         cap = self._lib.gpf_lane_capacity(self._h)
@@ -442,6 +475,15 @@ class PowerFlowEngine:
              "rho": view(8, m.n_line, "<f4"), "overflow_count": view(9, m.n_line, "<i4"), "done": view(10, 1, "|u1"),
              "episode": view(11, 2, "<i4"), "bus_vm": view(12, self.nb_total, "<f8"), "bus_va": view(13, self.nb_total, "<f8"),
              "disc_round": view(15, m.n_line, "<i4")}
+
+        def tview(idx, cols, typestr):       # trajectory buffers: [cap_steps][cap][cols]
+            if cols == 0 or not ptrs[idx] or not getattr(self, "_traj_cap", 0):
+                return None
+            t = torch.as_tensor(_Arr(ptrs[idx], (self._traj_cap, cap, cols), typestr), device=dev)
+            return t[:, :self.n_lanes]
+        v.update({"traj_rho": tview(16, m.n_line, "<f4"), "traj_status": tview(17, 1, "|i1"), "traj_out": tview(18, self.n_out, "<f4"),
+                  "traj_topo_vect": tview(19, m.dim_topo, "<i4"), "traj_shunt_bus": tview(20, m.n_shunt, "<i4"),
+                  "traj_line_status": tview(21, m.n_line, "|u1")})
         v["stream"] = torch.cuda.ExternalStream(stream.value, device=dev)
         return v
 

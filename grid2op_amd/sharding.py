@@ -188,6 +188,92 @@ class ShardedEngine:
         parts = [eng.step_outputs(l0, k) for eng, l0, k, _ in self._parts(lane0, n)]
         return tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
 
+    # ---- the rest of the batched API: per-table calls go to every device, per-lane calls are cut by block ---------------------
+    TRAJ_RHO, TRAJ_OBS = 1, 2
+
+    def upload_maintenance(self, maintenance):
+        for eng in self.engines:
+            eng.upload_maintenance(maintenance)
+
+    def set_deterministic(self, flag: bool = True):
+        for eng in self.engines:
+            eng.set_deterministic(flag)
+
+    def set_gen_limits(self, *a, **kw):
+        for eng in self.engines:
+            eng.set_gen_limits(*a, **kw)
+
+    def redispatch(self, new_p, prev_p, actual, target, modified, rhs, lane0: int = 0, apply: bool = False):
+        ng = self.model.n_gen
+        rows = [np.asarray(a).reshape(-1, ng) for a in (new_p, prev_p, actual, target, modified)]
+        n = rows[0].shape[0]
+        rhs = np.broadcast_to(np.asarray(rhs, dtype=np.float64), (n,))
+        oks, afters = [], []
+        for eng, l0, k, off in self._parts(lane0, n):
+            ok, after = eng.redispatch(*[r[off:off + k] for r in rows], rhs[off:off + k], lane0=l0, apply=apply)
+            oks.append(ok)
+            afters.append(after)
+        return np.concatenate(oks), np.concatenate(afters)
+
+    def set_trajectory(self, n_steps_cap: int, what: int = 1):
+        for eng in self.engines:
+            eng.set_trajectory(n_steps_cap, what)
+
+    def trajectory(self, n_steps: int, step0: int = 0, lane0: int = 0, n=None):
+        parts = [eng.trajectory(n_steps, step0, l0, k) for eng, l0, k, _ in self._parts(lane0, n)]
+        return np.concatenate([p[0] for p in parts], axis=1), np.concatenate([p[1] for p in parts], axis=1)
+
+    def trajectory_obs(self, n_steps: int, step0: int = 0, lane0: int = 0, n=None):
+        from .engine import LaneResults
+        parts = [eng.trajectory_obs(n_steps, step0, l0, k) for eng, l0, k, _ in self._parts(lane0, n)]
+        out = []
+        for s in range(n_steps):
+            rs = [p[s] for p in parts]
+            cat = lambda f: np.concatenate([getattr(r, f) for r in rs])  # noqa: E731
+            out.append(LaneResults(out=cat("out"), topo_vect=cat("topo_vect"), shunt_bus=cat("shunt_bus"), line_status=cat("line_status"),
+                                   status=cat("status"), bus_vm=None, bus_va=None, _slices=rs[0]._slices))
+        return out
+
+    def copy_lanes(self, src: int, dst: int, n: int = 1):
+        """Device-side copy inside one shard; a copy that crosses devices goes through the host (inputs only: the results of the
+        destination lanes are those of their next solve)."""
+        ps, pd = self._parts(src, n), self._parts(dst, n)
+        if len(ps) == 1 and len(pd) == 1 and ps[0][0] is pd[0][0]:
+            ps[0][0].copy_lanes(ps[0][1], pd[0][1], n)
+            return
+        topo, sb = self.get_topology(src, n)
+        self.set_injections(self.get_injections(src, n), lane0=dst)
+        self.set_topology(topo, sb, lane0=dst)
+
+    def get_topology(self, lane0: int = 0, n=None):
+        parts = [eng.get_topology(l0, k) for eng, l0, k, _ in self._parts(lane0, n)]
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+    def fanout_n1(self, src_lane: int, dst_lane0: int, out_lines):
+        """N-1 fan-out of one source lane; source and destinations must live on the same device (the contingencies of an
+        environment sit next to it: SURVEY.md 8(e))."""
+        ol = np.asarray(out_lines, dtype=np.int32)
+        (es, ls, _, _), = self._parts(src_lane, 1)
+        pd = self._parts(dst_lane0, ol.size)
+        if len(pd) != 1 or pd[0][0] is not es:
+            raise ValueError("ShardedEngine.fanout_n1: the source lane and its contingency lanes must be on the same device")
+        es.fanout_n1(ls, pd[0][1], ol)
+
+    def simulate_candidates(self, src_lane: int, dst_lane0: int, actions=None, topologies=None, **kw):
+        (es, ls, _, _), = self._parts(src_lane, 1)
+        n = len(actions) if topologies is None else np.asarray(topologies).reshape(-1, self.model.dim_topo).shape[0]
+        pd = self._parts(dst_lane0, n)
+        if len(pd) != 1 or pd[0][0] is not es:
+            raise ValueError("ShardedEngine.simulate_candidates: the source lane and its candidate lanes must be on the same device")
+        return es.simulate_candidates(ls, pd[0][1], actions=actions, topologies=topologies, **kw)
+
+    def device_views(self):
+        """One dict of zero-copy torch views per device (global lane order = concatenation over the list)."""
+        return [eng.device_views() for eng in self.engines]
+
+    def plan(self):
+        return [eng.plan() for eng in self.engines]
+
     def close(self):
         for eng in self.engines:
             eng.close()

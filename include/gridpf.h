@@ -40,6 +40,8 @@ extern "C" {
 #define GPF_ST_CAPACITY 5    /* more active buses than the handle was sized for           */
 #define GPF_ST_NOTRUN (-1)
 
+#define GPF_MAX_BUSBAR 3     /* busbars per substation the compiled kernels cover (gpf_create refuses more: GPF_E_CAPACITY) */
+
 typedef struct gpf_engine* gpf_handle;
 
 /* Static description of one grid = what PandaPowerBackend.load_grid + _init_private_attrs derive
@@ -197,11 +199,15 @@ typedef struct gpf_step_opts {
                             Same solution within the solver tolerance, fewer iterations: n_iter and the last digits differ
                             from the reference's.  Default 0 = the reference's algorithm. */
 } gpf_step_opts;
-/* n_steps consecutive DoNothing env.step (t0, t0+1, ...) of every lane in ONE launch.  Every step does the whole of gpf_step and
- * writes its results row, rho, status and counters; between the steps of a launch the lane state stays on chip and whatever only
- * depends on the topology (element->bus maps, bus types, Ybus, the factored DC matrix) is kept until a line trips or a lane
- * fails.  After the call the getters return the LAST step; gpf_get_trajectory returns rho / status of every step when a
- * trajectory buffer was requested.  Asynchronous. */
+/* n_steps consecutive DoNothing env.step (t0, t0+1, ...) of every lane in ONE launch.  Every step does the whole of gpf_step;
+ * between the steps of a launch the lane state stays on chip and whatever only depends on the topology (element->bus maps, bus
+ * types, Ybus, the factored DC matrix) is kept until a line trips or a lane fails.
+ * What is retrievable afterwards: the getters (gpf_get_results, gpf_get_step_outputs, device views) return the LAST step only --
+ * without a trajectory buffer each step overwrites the lane's result row, so the observations of the earlier steps never exist in
+ * HBM.  gpf_set_trajectory(h, cap, GPF_TRAJ_OBS) keeps the complete backend observation of EVERY step (what BaseEnv.step hands
+ * to the observation after each env.step: Environment/baseEnv.py:3562-3931 -> Observation/completeObservation.py:140-211 reads
+ * the backend's flows / voltages / injections, topo_vect and line status); GPF_TRAJ_RHO keeps rho + status only.
+ * n_steps must not exceed the capacity of a trajectory buffer that is set.  Asynchronous. */
 int gpf_step_n(gpf_handle h, int32_t t0, int32_t n_steps, const gpf_step_opts* opts);
 /* Per-lane additive generator set-point delta in MW, [n_lanes][n_gen] (NULL: none): the redispatch the environment adds to the
  * chronics' prod_p every step (actual_dispatch, Environment/baseEnv.py:2211-2470, 3650-3700). */
@@ -219,10 +225,20 @@ int gpf_set_gen_limits(gpf_handle h, const double* pmin, const double* pmax, con
                        const uint8_t* redispatchable, double eps_poly);
 int gpf_redispatch(gpf_handle h, int32_t lane0, int32_t n, const double* new_p, const double* prev_p, const double* actual,
                    const double* target, const uint8_t* modified, const double* rhs, int32_t apply, uint8_t* ok, float* actual_after);
-/* Trajectory buffer of multi-step launches: rho [n_steps_cap][n_lanes][n_line] and status [n_steps_cap][n_lanes] of the steps of
- * the last gpf_step_n (0 releases it). */
-int gpf_set_trajectory(gpf_handle h, int32_t n_steps_cap);
+/* Trajectory buffers of multi-step launches (n_steps_cap = 0 or what = 0 releases them).
+ *   GPF_TRAJ_RHO: rho [cap][n_lanes][n_line] and status [cap][n_lanes] of every step of the last gpf_step_n.
+ *   GPF_TRAJ_OBS: in addition the complete backend observation of every step -- results row out [cap][n_lanes][n_out]
+ *                 (layout of gpf_get_results), topo_vect [..][dim_topo], shunt_bus [..][n_shunt], line_status [..][n_line]:
+ *                 every step of the launch then writes its rows to HBM (1 observation per env.step, as the reference
+ *                 returns one per BaseEnv.step); the lane's own rows still return the last step.
+ * gpf_get_trajectory / gpf_get_trajectory_obs copy steps [step0, step0+n_steps) of lanes [lane0, lane0+n) -- only steps written
+ * by the LAST gpf_step_n are retrievable (GPF_E_INVALID beyond).  Any output pointer may be NULL. */
+#define GPF_TRAJ_RHO 1
+#define GPF_TRAJ_OBS 2
+int gpf_set_trajectory(gpf_handle h, int32_t n_steps_cap, int32_t what);
 int gpf_get_trajectory(gpf_handle h, int32_t step0, int32_t n_steps, int32_t lane0, int32_t n, float* rho, int8_t* status);
+int gpf_get_trajectory_obs(gpf_handle h, int32_t step0, int32_t n_steps, int32_t lane0, int32_t n, float* out, int32_t* topo_vect,
+                           int32_t* shunt_bus, uint8_t* line_status);
 /* Episode bookkeeping of the batched steps: done [n] (1: the lane's last step ended its episode), steps_and_resets [n][2]
  * {steps survived since the last (auto-)reset, number of auto-resets}. */
 int gpf_get_episode(gpf_handle h, int32_t lane0, int32_t n, uint8_t* done, int32_t* steps_and_resets);
@@ -267,8 +283,10 @@ int gpf_get_kernel_time(gpf_handle h, double* total_ms, int64_t* n_launches);
  * out[7] topology-class launch. */
 int gpf_get_plan(gpf_handle h, int32_t out[8]);
 /* Raw device pointers + the stream, for zero-copy interop (grid2op_amd/engine.py: PowerFlowEngine.device_views wraps them as
- * torch tensors).  ptrs[0..15] = inj, topo, shunt_bus, out, topo_vect, line_status, status, chronics, rho, overflow_count, done,
- * episode, bus_vm, bus_va, shunt_bus_out, disc_round (rows are padded to gpf_lane_capacity lanes); stream = hipStream_t */
+ * torch tensors).  ptrs[0..21] = inj, topo, shunt_bus, out, topo_vect, line_status, status, chronics, rho, overflow_count, done,
+ * episode, bus_vm, bus_va, shunt_bus_out, disc_round, then the trajectory buffers (NULL when not set): traj_rho, traj_status,
+ * traj_out, traj_topo_vect, traj_shunt_bus, traj_line_status (rows are padded to gpf_lane_capacity lanes; trajectory buffers are
+ * [cap][gpf_lane_capacity][row]); stream = hipStream_t */
 int gpf_device_pointers(gpf_handle h, void** ptrs, void** stream);
 
 #ifdef __cplusplus

@@ -63,3 +63,32 @@ def test_layout_struct_matches_header():
     desc = re.sub(r"/\*.*?\*/", "", desc, flags=re.S)
     dnames = re.findall(r"\*?\s*([a-z_0-9]+)\s*[,;]", desc.split("{", 1)[1])
     assert dnames == [f[0] for f in GpfGridDesc._fields_]
+
+
+def test_more_than_three_busbars_is_refused_with_the_reason(load_model):
+    """gpf_create validates n_busbar before it touches the device: the compiled kernels cover 1..3 busbars per substation
+    (the reference takes any n_busbar_per_sub); the refusal names the limit instead of a misleading LDS-capacity error later."""
+    from grid2op_amd.engine import PowerFlowEngine, GridPFError
+    m = load_model("rte_case5_example")
+    with pytest.raises(GridPFError, match="n_busbar > 3"):
+        PowerFlowEngine(m, n_lanes=2, n_busbar=4)
+
+
+def test_bench_uses_the_oracle_only_as_checker_or_cpu_baseline():
+    """bench.py may call the oracle in its cpu_baseline leg and in the spot checks that run AFTER a timed workload -- nowhere
+    else (the measured path must be the HIP engine)."""
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    allowed = {"cpu_baseline", "oracle_spot_check", "workload_ptdf"}
+    found = set()
+    for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
+        for n in ast.walk(fn):
+            if isinstance(n, (ast.Import, ast.ImportFrom)):
+                names = [a.name for a in n.names] if isinstance(n, ast.Import) else [n.module or ""]
+                if any(x == "oracle" or x.startswith("oracle.") for x in names):
+                    found.add(fn.name)
+    for n in tree.body:                                   # no module-level import either
+        if isinstance(n, (ast.Import, ast.ImportFrom)):
+            names = [a.name for a in n.names] if isinstance(n, ast.Import) else [n.module or ""]
+            assert not any(x == "oracle" or x.startswith("oracle.") for x in names)
+    assert found and found <= allowed, found

@@ -470,6 +470,36 @@ def test_sharded_engine_on_real_engines(load_model, load_npz):
     d1, s1, r1 = one.episode()
     d2, s2, r2 = se.episode()
     assert np.array_equal(s1, s2) and (s2 == 5).all()
+    # the rest of the batched API is forwarded too: observation trajectory, maintenance, redispatch delta, fan-out, copies
+    maint = np.zeros((1, tab.shape[0], m.n_line), np.uint8)
+    maint[0, 9:12, 7] = 1
+    delta = np.zeros((70, m.n_gen), np.float32)
+    delta[:, 1], delta[:, 2] = 0.5, -0.5
+    for e in (one, se):
+        e.reset()
+        e.upload_maintenance(maint)
+        e.set_lane_redispatch(delta)
+        e.set_trajectory(6, e.TRAJ_OBS)
+        e.step(7, n_steps=6, rebalance=1.02)
+    oa, ob = one.trajectory_obs(6), se.trajectory_obs(6)
+    ra, rb = one.trajectory(6), se.trajectory(6)
+    assert np.array_equal(ra[0], rb[0], equal_nan=True) and np.array_equal(ra[1], rb[1])
+    for k in range(6):
+        assert np.array_equal(oa[k].out, ob[k].out, equal_nan=True) and np.array_equal(oa[k].line_status, ob[k].line_status)
+    assert not ob[5].line_status[:, 7].any() and ob[0].line_status[:, 7].any()       # the maintenance reached both shards
+    part = se.trajectory_obs(2, step0=1, lane0=33, n=4)                              # lanes straddling the shard boundary
+    assert np.array_equal(part[1].out, oa[2].out[33:37], equal_nan=True)
+    for e in (one, se):
+        e.set_trajectory(0)
+        e.upload_maintenance(None)
+        e.fanout_n1(36, 40, [0, 3, -1])
+        e.copy_lanes(2, 60, 3)                                                        # crosses devices on the sharded engine
+        e.runpf()
+    assert np.array_equal(one.results().out, se.results().out, equal_nan=True)
+    assert np.array_equal(one.get_topology()[0], se.get_topology()[0])
+    with pytest.raises(ValueError):
+        se.fanout_n1(2, 50, [1])                                                      # source and destinations on different devices
+    assert len(se.device_views()) == 2 and len(se.plan()) == 2
     one.close()
     se.close()
 
@@ -548,10 +578,21 @@ def test_api_error_paths_and_edge_cases(load_model, load_npz):
     # the chronics cursor wraps inside a launch: T + 3 steps from row 0 end on row 2
     T = tab.shape[0]
     eng.set_lane_chronics(lane_offset=np.zeros(5, np.int32), lane_scale=scale)
-    eng.set_trajectory(4)                                     # shorter than the launch: only the first 4 steps are kept
+    eng.set_trajectory(4)                                     # shorter than the launch: refused (steps would be dropped silently)
+    with pytest.raises(GridPFError):
+        eng.step(0, n_steps=T + 3, rebalance=1.02)
+    eng.set_trajectory(T + 3)
+    with pytest.raises(GridPFError):
+        eng.trajectory(1)                                     # nothing written yet by a launch into the new buffer
     eng.step(0, n_steps=T + 3, rebalance=1.02)
     a = _snapshot(eng)
     rho4, st4 = eng.trajectory(4)
+    eng.step(5, n_steps=2, rebalance=1.02)
+    with pytest.raises(GridPFError):
+        eng.trajectory(4)                                     # only the 2 steps of the LAST launch are retrievable
+    with pytest.raises(GridPFError):
+        eng.trajectory_obs(1)                                 # no observation trajectory requested
+    eng.set_trajectory(0)
     eng.step(2, rebalance=1.02)
     b = _snapshot(eng)
     assert np.allclose(a["out"], b["out"], rtol=2e-6, atol=2e-5) and np.array_equal(a["status"], b["status"])
@@ -587,4 +628,94 @@ def test_solve_lane_equals_the_four_call_sequence(load_model):
             assert np.array_equal(a.out, b.out, equal_nan=True)
             assert np.array_equal(a.bus_vm, b.bus_vm, equal_nan=True) and np.array_equal(a.bus_va, b.bus_va, equal_nan=True)
             assert np.array_equal(eng.get_injections(3, 1), inj) and np.array_equal(eng.get_topology(3, 1)[0], topo)
+    eng.close()
+
+
+def _tight_limits(e1, others, kw0):
+    """thermal limits that make about half of the lanes overflow softly on every line and two lines overflow hard"""
+    e1.step(0, **kw0)
+    a0 = e1.results().a_or.copy()
+    lim = (np.median(a0, axis=0) * 1.02).astype(np.float32) + 1.0
+    hot = np.argsort(-np.median(a0, axis=0))[:2]
+    lim[hot] = np.median(a0, axis=0)[hot] * 0.45
+    for e in [e1] + list(others):
+        e.set_thermal_limits(lim)
+        e.reset()
+
+
+@pytest.mark.parametrize("name,B,kw,tight", [
+    ("rte_case5_example", 37, dict(rebalance=1.02), False),                # 4 instances per wavefront, ragged tail
+    ("l2rpn_case14_sandbox", 66, dict(rebalance=1.02), False),             # 2 instances per wavefront
+    ("l2rpn_case14_sandbox", 24, dict(rebalance=1.02, cascade=True, hard_overflow=2.0, soft_overflow=1.0, nb_ts_allowed=2), True),
+    ("l2rpn_case14_sandbox", 64, dict(rebalance=1.02, is_dc=True), False),
+    ("l2rpn_neurips_2020_track1", 33, dict(rebalance=1.02), False),        # 1 instance per wavefront
+    ("l2rpn_neurips_2020_track1", 9, dict(rebalance=1.02, cascade=True, hard_overflow=2.0, soft_overflow=1.0, nb_ts_allowed=2), True),
+    ("l2rpn_wcci_2022_dev", 8, dict(rebalance=1.02), False),               # 2 wavefronts per instance, Ybus in registers
+    ("educ_case14_storage", 16, dict(rebalance=1.0), False),
+])
+def test_observation_trajectory_holds_every_step(name, B, kw, tight, load_model, load_npz):
+    """gpf_set_trajectory(.., GPF_TRAJ_OBS): EVERY step of a multi-step launch leaves its complete backend observation in HBM
+    (what BaseEnv.step hands to the observation after each env.step, Environment/baseEnv.py:3562-3931) -- equal to what n
+    single-step launches return one after the other (integers bit-exact), incl. steps in which lines trip; the lane's own rows
+    still hold the last step."""
+    m, ch, e1, tab, off, scale = _setup(load_model, load_npz, name, B)
+    _, _, e2, _, _, _ = _setup(load_model, load_npz, name, B)
+    if tight:
+        _tight_limits(e1, [e2], dict(rebalance=1.02))
+    n = 6
+    e2.set_trajectory(n, e2.TRAJ_OBS)
+    snaps = []
+    for t in range(2, 2 + n):
+        e1.step(t, **kw)
+        snaps.append(_snapshot(e1))
+    e2.step(2, n_steps=n, **kw)
+    _same(_snapshot(e2), snaps[-1], name)
+    obs = e2.trajectory_obs(n)
+    rho, st = e2.trajectory(n)
+    v = e2.device_views()
+    e2.sync()
+    for k in range(n):
+        a = snaps[k]
+        assert np.array_equal(st[k], a["status"][:, 0]), k
+        assert np.array_equal(obs[k].topo_vect, a["topo"]) and np.array_equal(obs[k].line_status, a["ls"]), k
+        assert np.array_equal(obs[k].shunt_bus, a["sb"]), k
+        assert np.array_equal(np.isnan(obs[k].out), np.isnan(a["out"])), k
+        assert np.allclose(obs[k].out, a["out"], rtol=2e-6, atol=2e-5, equal_nan=True), (k, np.nanmax(np.abs(obs[k].out - a["out"])))
+        assert np.allclose(rho[k], a["rho"], rtol=2e-6, atol=1e-6, equal_nan=True), k
+        assert np.array_equal(v["traj_out"][k].cpu().numpy(), obs[k].out, equal_nan=True)        # zero-copy view of the same rows
+        assert np.array_equal(v["traj_topo_vect"][k].cpu().numpy(), obs[k].topo_vect)
+        assert np.array_equal(v["traj_line_status"][k].cpu().numpy().astype(bool), obs[k].line_status)
+    if tight:
+        assert (~snaps[-1]["ls"]).any(), "the scenario is meant to trip lines"
+        assert any(not np.array_equal(snaps[k]["ls"], snaps[k + 1]["ls"]) for k in range(n - 1))   # ... at different steps
+    # a sub-range of steps / lanes
+    part = e2.trajectory_obs(2, step0=3, lane0=1, n=3)
+    assert np.array_equal(part[1].out, obs[4].out[1:4], equal_nan=True) and np.array_equal(part[0].topo_vect, obs[3].topo_vect[1:4])
+    # without the buffer the same launch gives the same last step (the trajectory only adds stores)
+    e2.set_trajectory(0)
+    e2.reset(); e1.reset()
+    e2.step(2, n_steps=n, **kw)
+    e1.set_trajectory(n, e1.TRAJ_OBS)
+    e1.step(2, n_steps=n, **kw)
+    _same(_snapshot(e2), _snapshot(e1), name + " with / without trajectory")
+    e1.close()
+    e2.close()
+
+
+def test_observation_trajectory_failing_lanes_and_auto_reset(load_model, load_npz):
+    """A lane whose step fails leaves an all-NaN observation (topo_vect -1) for THAT step only; after the auto-reset its next
+    steps are regular observations again."""
+    m, ch, eng, tab, off, scale = _setup(load_model, load_npz, "l2rpn_case14_sandbox", 16)
+    scale2 = scale.copy()
+    scale2[[3, 10]] *= 6.0
+    eng.set_lane_chronics(lane_offset=off, lane_scale=scale2)
+    eng.set_trajectory(5, eng.TRAJ_OBS)
+    eng.step(0, n_steps=5, rebalance=1.02, auto_reset=True)
+    obs = eng.trajectory_obs(5)
+    _, st = eng.trajectory(5)
+    for k in range(5):
+        bad = st[k] != 0
+        assert bad[[3, 10]].all() and bad.sum() == 2
+        assert np.isnan(obs[k].out[bad]).all() and (obs[k].topo_vect[bad] == -1).all() and not obs[k].line_status[bad].any()
+        assert not np.isnan(obs[k].out[~bad]).any() and (obs[k].topo_vect[~bad] >= 1).all()
     eng.close()
