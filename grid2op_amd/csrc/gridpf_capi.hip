@@ -174,6 +174,7 @@ struct gpf_engine {
   int wpi_env = 0;
   bool no_yreg = false;        // GRIDPF_YREG=0: never keep the Ybus blocks in registers
   int stage_max = 2;           // GRIDPF_STAGE=0|1|2: highest static-table staging tier the planner may pick (developer / tests)
+  int stage_force = -1;        // GRIDPF_FORCE_STAGE=0|1|2: take that tier whenever it fits the LDS, whatever it costs in residency (experiments)
   int dcf_env = -1;            // GRIDPF_DCF=0|1 (-1: not set)
   int cap_lanes = 0;           // lane buffers are padded to a multiple of 4 lanes (instance groups of a wavefront)
   std::vector<int> lane_mb;    // max live busbars in one substation, per lane
@@ -405,6 +406,7 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
     const int top_tier = std::min(nbk == 1 ? 2 : 1, e->stage_max);
     for (int tier = top_tier; tier >= 1 && !stage; --tier)
       if (need(tier) <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / need(tier) >= want) stage = tier;
+    if (e->stage_force >= 0 && e->stage_force <= top_tier && need(e->stage_force) <= LDS_HARD_LIMIT) stage = e->stage_force;
     if (ipw > 1 && stage != 2) { ipw = 1; stage = 0; for (int tier = top_tier; tier >= 1 && !stage; --tier) if (need(tier) <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / need(tier) >= want) stage = tier; }
     const size_t l = need(stage);
     if (l > LDS_HARD_LIMIT) return false;
@@ -850,6 +852,8 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     e->no_yreg = yv && yv[0] == '0';
     const char* sv_ = std::getenv("GRIDPF_STAGE");
     if (sv_ && sv_[0] >= '0' && sv_[0] <= '2') e->stage_max = sv_[0] - '0';
+    const char* fs_ = std::getenv("GRIDPF_FORCE_STAGE");
+    if (fs_ && fs_[0] >= '0' && fs_[0] <= '2') e->stage_force = fs_[0] - '0';
   }
   HIP_TRY(hipMemsetAsync(e->status.p, 0xFF, B * 4 * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->overflow_count.p, 0, B * nl * sizeof(int), e->stream));

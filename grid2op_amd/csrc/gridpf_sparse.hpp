@@ -610,11 +610,12 @@ __device__ inline bool block_lu_solve(const SymDev& S, PP prog, double* __restri
 
 // ---- flat-program sweeps (gridpf_symbolic.hpp: FlatProg) -------------------------------------------------------------------
 // Block LU + solve with 2x2 blocks on the flat program.  A: row 0 of every (pseudo-)slot at A + slot * 2, row 1 at
-// A + HS + slot * 2 (HS = (rslot0 + n) * 2 doubles); the right-hand side lives in the pseudo-slots and holds the solution on
-// return.  Same arithmetic, item by item, as the level-header version it replaces (block_lu_solve, BS == 2): the pivot inverse
-// is recomputed by every item from the never-overwritten diagonal block, the scaling U' = inv(D) U, b' = inv(D) b is deferred
-// to one parallel pass, the back substitution accumulates with ds_add_f64.  What changed is the instruction count of a phase:
-// no level headers, no bounds / clamps, no "trailing update or right-hand side?" selects, byte offsets instead of slot indices.
+// A + HS + slot * 2 (HS = (rslot0 + n) * 2 doubles); the right-hand side lives in the pseudo-slots and holds s = D x on return
+// (the solution is x_p = inv(D_p) s_p with the factored diagonal block D_p left in slot p).  The pivot inverse
+// is recomputed by every item from the never-overwritten diagonal block; U and the right-hand side are NEVER scaled (round 3: the
+// deferred scaling pass is gone): the back substitution accumulates s_p -= A_pj inv(D_j) s_j with ds_add_f64 and the caller forms
+// x_p = inv(D_p) s_p where it consumes the solution (flat_solution).  What a phase costs is its instruction count: no level headers,
+// no bounds / clamps, no "trailing update or right-hand side?" selects, byte offsets instead of slot indices.
 template <int GW, class PP = const int*>
 __device__ inline bool block_lu_flat(const FlatDev& F, PP prog, double* __restrict__ A, size_t HS, int tid, long long* dbg = nullptr) {
 #ifdef GPF_TIMING
@@ -650,23 +651,12 @@ __device__ inline bool block_lu_flat(const FlatDev& F, PP prog, double* __restri
       w0 = n0; w1 = n1;
     }
   }
-  // deferred scaling U' = inv(D) U and b' = inv(D) b (one item per block: no read-write overlap between items)
-  for (int k = 0; k < F.n_scale; ++k) {
-    const unsigned w = (unsigned)prog[F.scale_off + k * GW + tid];
-    if (w == 0xffffffffu) continue;
-    const unsigned fu = w & 0xffffu, fp = w >> 16;
-    const double2 dA = FL_LD2(a0, fp), dB = FL_LD2(a1, fp), uA = FL_LD2(a0, fu), uB = FL_LD2(a1, fu);
-    const double det = fma(dA.x, dB.y, -dA.y * dB.x);
-    if ((int)fu >= F.rhs_field0 && (!(fabs(det) > 1e-300) || !(fabs(det) < 1e300))) ok = false;
-    const double rd = fast_rcp(det);
-    *reinterpret_cast<double2*>(a0 + fu) = make_double2(fma(dB.y, uA.x, -dA.y * uB.x) * rd, fma(dB.y, uA.y, -dA.y * uB.y) * rd);
-    *reinterpret_cast<double2*>(a1 + fu) = make_double2(fma(dA.x, uB.x, -dB.x * uA.x) * rd, fma(dA.x, uB.y, -dB.x * uA.y) * rd);
-  }
-  GPF_LSYNC();
 #ifdef GPF_TIMING
   const long long t_lu1 = __builtin_readcyclecounter();
 #endif
-  // back substitution: x_p -= U'_pj x_j, levels in reverse, every entry of a level concurrently
+  // back substitution, levels in reverse, every entry of a level concurrently: s_p -= A_pj x_j with x_j = inv(D_j) s_j formed by
+  // the item itself from the column's accumulated right-hand side (complete: j was eliminated after p, its own entries ran in an
+  // earlier pass) -- U and the right-hand side are never scaled, so there is no scaling pass between the two sweeps
   {
     int at = F.back_off + 2 * tid;
     unsigned w0 = (unsigned)prog[at], w1 = (unsigned)prog[at + 1];
@@ -674,9 +664,11 @@ __device__ inline bool block_lu_flat(const FlatDev& F, PP prog, double* __restri
       at += 2 * GW;
       const unsigned n0 = (unsigned)prog[at], n1 = (unsigned)prog[at + 1];
       if (w0 != 0xffffffffu) {
-        const unsigned fu = w0 & 0xffffu, fj = w0 >> 16;
-        const double2 uA = FL_LD2(a0, fu), uB = FL_LD2(a1, fu);
-        const double x0 = *FL_D(a0, fj), x1 = *FL_D(a1, fj);
+        const unsigned fu = w0 & 0xffffu, fj = w0 >> 16, fdj = fj - (unsigned)F.rhs_field0;
+        const double2 uA = FL_LD2(a0, fu), uB = FL_LD2(a1, fu), dA = FL_LD2(a0, fdj), dB = FL_LD2(a1, fdj);
+        const double s0 = *FL_D(a0, fj), s1 = *FL_D(a1, fj);
+        const double rd = fast_rcp(fma(dA.x, dB.y, -dA.y * dB.x));
+        const double x0 = fma(dB.y, s0, -dA.y * s1) * rd, x1 = fma(dA.x, s1, -dB.x * s0) * rd;
         atomicAdd(FL_D(a0, w1), -fma(uA.x, x0, uA.y * x1));
         atomicAdd(FL_D(a1, w1), -fma(uB.x, x0, uB.y * x1));
       }
@@ -692,9 +684,10 @@ __device__ inline bool block_lu_flat(const FlatDev& F, PP prog, double* __restri
 
 // Scalar variant for the DC system of the single-busbar layout: B' theta = P only couples element [0][0] of every block and the
 // first entry of every right-hand-side pseudo-slot (the |V| rows are identity), so the same flat program runs on scalars.
-// FACTOR = false: `fac` holds the FACTORED matrix of an earlier solve with the same topology (L and D as left by the forward
-// sweep, U scaled), COMPACT: as one double per slot (CarveP::Adc) instead of element [0][0] of the row-0 half; only the
-// right-hand-side items, the pivot scaling of the right-hand side and the back substitution run.
+// FACTOR = false: `fac` holds the FACTORED matrix of an earlier solve with the same topology (L, D and the unscaled U as left by
+// the forward sweep), COMPACT: as one double per slot (CarveP::Adc) instead of element [0][0] of the row-0 half; only the
+// right-hand-side items of the forward sweep and the back substitution run.  On return the first entry of pseudo-slot p holds
+// s_p = d_p * theta_p (the caller divides by the pivot, like the 2x2 sweep's callers apply inv(D_p)).
 template <int GW, bool FACTOR, bool COMPACT, class PP = const int*>
 __device__ inline bool scalar_lu_flat(const FlatDev& F, PP prog, double* __restrict__ A, double* __restrict__ fac, int tid,
                                       long long* dbg = nullptr) {
@@ -723,20 +716,6 @@ __device__ inline bool scalar_lu_flat(const FlatDev& F, PP prog, double* __restr
       w0 = n0; w1 = n1;
     }
   }
-  for (int k = 0; k < (FACTOR ? F.n_scale : F.n_scale_rhs); ++k) {
-    const unsigned w = (unsigned)prog[F.scale_off + k * GW + tid];
-    if (w == 0xffffffffu) continue;
-    const unsigned fu = w & 0xffffu, fp = w >> 16;
-    const double d = *facp(fp);
-    if ((int)fu >= F.rhs_field0) {
-      if (FACTOR && (!(fabs(d) > 1e-300) || !(fabs(d) < 1e300))) ok = false;
-      *FL_D(a0, fu) *= fast_rcp(d);
-    } else {
-      double* au = facp(fu);
-      *au = *au * fast_rcp(d);
-    }
-  }
-  GPF_LSYNC();
 #ifdef GPF_TIMING
   const long long t_lu1 = __builtin_readcyclecounter();
 #endif
@@ -746,7 +725,10 @@ __device__ inline bool scalar_lu_flat(const FlatDev& F, PP prog, double* __restr
     for (int k = 0; k < F.n_back; ++k) {
       at += 2 * GW;
       const unsigned n0 = (unsigned)prog[at], n1 = (unsigned)prog[at + 1];
-      if (w0 != 0xffffffffu) atomicAdd(FL_D(a0, w1), -*facp(w0 & 0xffffu) * *FL_D(a0, w0 >> 16));
+      if (w0 != 0xffffffffu) {
+        const unsigned fj = w0 >> 16;
+        atomicAdd(FL_D(a0, w1), -(*facp(w0 & 0xffffu) * *FL_D(a0, fj)) * fast_rcp(*facp(fj - (unsigned)F.rhs_field0)));
+      }
       GPF_LSYNC();
       w0 = n0; w1 = n1;
     }
@@ -1113,6 +1095,10 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         }
         if (k < nbus) t0 = fma(sv.dc_inv[k * nbus + i], *rhsT(k), t0);
         th = t0 + t1;
+      } else if (NB == 1) {                                         // flat sweeps leave s_i = d_i theta_i (scalar_lu_flat)
+        const double d = dc_kept ? c.Adc[i] : c.A[(size_t)i * 2];
+        if (!(fabs(d) > 1e-300) || !(fabs(d) < 1e300)) ok = false;
+        th = *rhsT(i) * fast_rcp(d);
       } else th = *rhsT(i);
       const int bt = c.btype[i];
       c.va[i] = (bt == BT_PQ || bt == BT_PV) ? th : 0.0;
@@ -1269,12 +1255,19 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       const bool ok = lu_ac(nullptr);
       if (it == 1) GPF_STAMPS(13);
       // update (groups that are done keep their state) + preparation of the next pair phase (every group)
-      bool fin = true;
+      bool fin = true, piv_ok = true;
       for (int i = tid; i < nbus; i += GW) {
         const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
         const int bt = c.btype[i];
         double va = c.va[i], vm = c.vm[i];
-        const double2 dx = make_double2(*rhsT(i), *rhsV(i));
+        double2 dx = make_double2(*rhsT(i), *rhsV(i));
+        if (BS == 2) {                         // flat sweeps leave s_i = D_i x_i with the factored diagonal block in slot i
+          const double2 dA = *reinterpret_cast<const double2*>(bel(sub, 0, 0)), dB = *reinterpret_cast<const double2*>(bel(sub, 1, 0));
+          const double det = fma(dA.x, dB.y, -dA.y * dB.x);
+          if (!(fabs(det) > 1e-300) || !(fabs(det) < 1e300)) piv_ok = false;
+          const double rd = fast_rcp(det);
+          dx = make_double2(fma(dB.y, dx.x, -dA.y * dx.y) * rd, fma(dA.x, dx.y, -dB.x * dx.x) * rd);
+        }
         if (!done && bt != BT_OFF) {
           if (!(fabs(dx.x) < 1e300) || !(fabs(dx.y) < 1e300)) fin = false;
           if (bt == BT_PQ || bt == BT_PV) va += dx.x;
@@ -1294,7 +1287,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       if (BS == 2) { for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; } }
     else for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
       GPF_LSYNC();
-      if (!done && G::template any2<1>(!ok, !fin) != 0u) { status = 4; done = true; }
+      if (!done && G::template any2<1>(!ok || !piv_ok, !fin) != 0u) { status = 4; done = true; }
       if (it == 1) GPF_STAMPS(14);
     }
     if (status == 0 && !converged) status = 1;

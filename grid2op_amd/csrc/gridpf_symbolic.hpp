@@ -54,8 +54,11 @@ struct Symbolic {
 // are padded with 0xFFFFFFFF words -- so the device walks `words + pass * stride + t` without level headers, bounds or
 // item-kind selects.  Slot fields are BYTE offsets (slot * 16) into one row half of the block array.
 //   forward : 2 words per item  dst | (l << 16), u | (pivot << 16)            (a barrier-delimited phase per pass)
-//   scale   : 1 word per item   u | (pivot << 16): first the n right-hand-side pseudo-slots, then every U block   (one phase)
-//   back    : 2 words per item  u | (x_col pseudo-slot << 16), dst pseudo-slot (a phase per pass, levels in reverse)
+//   back    : 2 words per item  u | (x_col pseudo-slot << 16), dst pseudo-slot (a phase per pass, levels in reverse):
+//             s_dst -= A_u * inv(D_col) * s_col  -- U and the right-hand side are never scaled: the item applies the inverse of the
+//             column's pivot block (slot `col`: field - rhs_field0) to the column's ACCUMULATED right-hand side s_col itself, as
+//             every forward item recomputes its pivot inverse; the solution x_p = inv(D_p) s_p is formed by whoever consumes it
+//             (the Newton update / the DC angle extraction of gridpf_sparse.hpp).  No scaling pass: two phases less per solve.
 // The forward and back sections end with one extra all-invalid pass (the device prefetches the words of the next pass).
 struct FlatProg {
   int gw = 0;
@@ -247,20 +250,11 @@ inline FlatProg build_flat(const Symbolic& S, int gw) {
     F.n_fwd += pad2(0, (size_t)n_c + n_r);
   }
   for (int k = 0; k < gw; ++k) { W.push_back((int)INV); W.push_back((int)INV); }
-  // scale: right-hand sides first (the scalar solve with kept factors only runs these), then the U blocks
+  // (no scaling pass: the U blocks and the right-hand side stay UNSCALED -- the back substitution is
+  //  x_p = inv(D_p) (s_p - sum_j A_pj x_j) and every consumer of x_j applies inv(D_j) to the accumulated s_j itself)
   F.scale_off = (int)W.size();
-  {
-    int n_it = 0;
-    for (int p = 0; p < S.n; ++p, ++n_it) W.push_back((int)(rfld(p) | (fld(p) << 16)));
-    while (n_it % gw) { W.push_back((int)INV); ++n_it; }
-    F.n_scale_rhs = n_it / gw;
-    for (int e = 0; e < S.n_scale; ++e, ++n_it) {
-      const unsigned w = (unsigned)S.prog[S.scale_off + e];
-      W.push_back((int)(fld(w & 0xffffu) | (fld(w >> 16) << 16)));
-    }
-    while (n_it % gw) { W.push_back((int)INV); ++n_it; }
-    F.n_scale = n_it / gw;
-  }
+  F.n_scale = 0;
+  F.n_scale_rhs = 0;
   if (W.size() & 1) W.push_back((int)INV);                     // 8-byte alignment of the back section
   // back substitution, levels in reverse
   F.back_off = (int)W.size();

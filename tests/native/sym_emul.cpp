@@ -186,21 +186,14 @@ extern "C" int sym_emul_solve_flat(int n_sub, int n_line, const int* line_or, co
     for (size_t i = 0; i < A.size(); ++i) A[i] += d[i];
   }
   for (int t = 0; t < gw; ++t) if ((unsigned)W[2 * (F.n_fwd * gw + t)] != INV) return -5;      // the padding pass
-  if (F.n_scale_rhs * gw < n_sub) return -6;
-  for (int k = 0; k < F.n_scale; ++k)
-    for (int t = 0; t < gw; ++t) {
-      const unsigned w = (unsigned)W[F.scale_off + k * gw + t];
-      if (w == INV) continue;
-      const unsigned fu = w & 0xffffu, fp = w >> 16;
-      if (!ok_field(fu) || !ok_field(fp)) return -2;
-      if ((k < F.n_scale_rhs) != ((int)fu >= F.rhs_field0)) return -7;    // right-hand sides first, then the U blocks
-      const double d00 = el(fp, 0, 0), d01 = el(fp, 0, 1), d10 = el(fp, 1, 0), d11 = el(fp, 1, 1);
-      const double det = d00 * d11 - d01 * d10;
-      const double u00 = el(fu, 0, 0), u01 = el(fu, 0, 1), u10 = el(fu, 1, 0), u11 = el(fu, 1, 1);
-      el(fu, 0, 0) = (d11 * u00 - d01 * u10) / det; el(fu, 0, 1) = (d11 * u01 - d01 * u11) / det;
-      el(fu, 1, 0) = (d00 * u10 - d10 * u00) / det; el(fu, 1, 1) = (d00 * u11 - d10 * u01) / det;
-    }
+  if (F.n_scale != 0 || F.n_scale_rhs != 0) return -6;                    // no scaling pass: U and the right-hand side stay unscaled
   if (F.back_off % 2) return -8;
+  auto inv_apply = [&](unsigned fd, double s0, double s1, double& x0, double& x1) {       // x = inv(D) s, D = block at field fd
+    const double d00 = el(fd, 0, 0), d01 = el(fd, 0, 1), d10 = el(fd, 1, 0), d11 = el(fd, 1, 1);
+    const double det = d00 * d11 - d01 * d10;
+    x0 = (d11 * s0 - d01 * s1) / det;
+    x1 = (d00 * s1 - d10 * s0) / det;
+  };
   for (int k = 0; k < F.n_back; ++k) {
     std::vector<double> d(A.size(), 0.0);
     for (int t = 0; t < gw; ++t) {
@@ -208,11 +201,17 @@ extern "C" int sym_emul_solve_flat(int n_sub, int n_line, const int* line_or, co
       if (w0 == INV) continue;
       const unsigned fu = w0 & 0xffffu, fj = w0 >> 16;
       if (!ok_field(fu) || !ok_field(fj) || !ok_field(w1) || (int)fj < F.rhs_field0 || (int)w1 < F.rhs_field0) return -2;
-      for (int r = 0; r < 2; ++r) d[r * HS + (size_t)(w1 / 16) * 2] -= el(fu, r, 0) * el(fj, 0, 0) + el(fu, r, 1) * el(fj, 1, 0);
+      double x0, x1;
+      inv_apply(fj - (unsigned)F.rhs_field0, el(fj, 0, 0), el(fj, 1, 0), x0, x1);       // the item applies inv(D_col) itself
+      for (int r = 0; r < 2; ++r) d[r * HS + (size_t)(w1 / 16) * 2] -= el(fu, r, 0) * x0 + el(fu, r, 1) * x1;
     }
     for (size_t i = 0; i < A.size(); ++i) A[i] += d[i];
   }
-  for (int p = 0; p < n_sub; ++p) for (int r = 0; r < 2; ++r) x_out[p * 2 + r] = A[r * HS + ((size_t)S.rslot0 + p) * 2];
+  for (int p = 0; p < n_sub; ++p) {                                       // the consumer forms x_p = inv(D_p) s_p
+    double x0, x1;
+    inv_apply((unsigned)p * 16u, A[((size_t)S.rslot0 + p) * 2], A[HS + ((size_t)S.rslot0 + p) * 2], x0, x1);
+    x_out[p * 2] = x0; x_out[p * 2 + 1] = x1;
+  }
   if (stats) { stats[0] = F.n_fwd; stats[1] = F.n_scale; stats[2] = F.n_back; stats[3] = (int)F.words.size(); }
   return F.n_fwd + F.n_back;
 }
