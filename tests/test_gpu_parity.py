@@ -448,8 +448,9 @@ def test_instance_groups_ragged_ranges(name, n, load_model):
 
 
 def test_hip_matches_observations_recorded_with_pandapower(load_model, load_npz):
-    """The HIP path against the reference's OWN recordings (no oracle in between): the rte_case5_example RandomAgent
-    episodes of grid2op/data_test/runner_data (bus splits, line switches) and the rte_case14_test reset observation of
+    """The HIP path against the reference's OWN recordings (no oracle in between): the 389 observations of the 90
+    rte_case5_example RandomAgent episodes of grid2op/data_test/runner_data (45 grid2op releases; 260 rows with bus splits, 51
+    with switched-off lines), one lane per recorded row, and the rte_case14_test reset observation of
     grid2op/tests/test_Observation.py (json_ref) -- fixtures tests/golden/runner_case5.npz / known_answers.npz."""
     m = load_model("rte_case5_example")
     rt = load_npz("runner_case5.npz")

@@ -134,14 +134,15 @@ def test_observation_recorded_with_pandapower_backend(load_model, load_npz):
 
 
 def test_runner_trajectories_recorded_with_pandapower_backend(load_model, load_npz):
-    """grid2op/data_test/runner_data/res_agent_<ver>/{00,01} (loaded by grid2op/tests/test_Runner.py:426,540-585):
-    rte_case5_example episodes of a RandomAgent recorded with PandaPowerBackend.  Every observation row carries the
-    inputs of its power flow (injections, topo_vect after the random bus splits / line switches) and pandapower's
-    results, so each row pins the oracle on a DIFFERENT topology."""
+    """grid2op/data_test/runner_data/res_agent_<ver>/{00,01} (loaded by grid2op/tests/test_Runner.py:426,540-585): the
+    rte_case5_example RandomAgent episodes recorded with PandaPowerBackend by EVERY grid2op release the reference keeps
+    (45 of the 46 version folders -- 1.9.0's vectors do not match its own observation-space file --, 90 episodes, 389
+    observations).  Every observation row carries the inputs of its power flow (injections, topo_vect after the random bus
+    splits / line switches) and pandapower's results, so each row pins the oracle on a DIFFERENT topology."""
     m = load_model("rte_case5_example")
     rt = load_npz("runner_case5.npz")
     tags = sorted({k[:-len("p_or")] for k in rt if k.endswith("_p_or")})
-    assert len(tags) >= 4
+    assert len(tags) >= 90
     n_rows = n_split = 0
     for tag in tags:
         for t in range(rt[tag + "p_or"].shape[0]):
@@ -158,12 +159,13 @@ def test_runner_trajectories_recorded_with_pandapower_backend(load_model, load_n
             assert np.array_equal(r.line_status.astype(bool), rt[tag + "line_status"][t].astype(bool))
             for f, tol in [("p_or", 5e-5), ("q_or", 2e-4), ("p_ex", 5e-5), ("q_ex", 2e-4), ("v_or", 5e-5), ("v_ex", 5e-5)]:
                 assert np.abs(getattr(r, f) - rt[tag + f][t]).max() < tol, (tag, t, f)
-            on = rt[tag + "a_or"][t] > 0
+            on = rt[tag + "a_or"][t] > 1e-6        # (a line whose ends hang alone on a busbar carries 1e-11 A of rounding noise)
             assert np.abs(r.a_or[on] / rt[tag + "a_or"][t][on] - 1).max() < 5e-6
+            assert np.abs(r.a_or[~on]).max(initial=0.0) < 1e-6
             assert np.abs(r.gen_q - rt[tag + "gen_q"][t]).max() < 2e-4
             n_rows += 1
             n_split += int((topo == 2).any())
-    assert n_rows >= 15 and n_split >= 5
+    assert n_rows >= 380 and n_split >= 250
 
 
 @pytest.mark.parametrize("name,sizes", [
