@@ -267,7 +267,7 @@ bool upload_flats(const gpf::Symbolic& S, DevArr<int>& buf, gpf::SymDev& D) {
     all.insert(all.end(), F.words.begin(), F.words.end());
     gpf::FlatDev& f = D.fl[k];
     f.n_fwd = F.n_fwd; f.n_scale = F.n_scale; f.n_scale_rhs = F.n_scale_rhs; f.n_back = F.n_back; f.scale_off = F.scale_off;
-    f.back_off = F.back_off; f.rhs_field0 = F.rhs_field0; f.n_words = (int)F.words.size();
+    f.back_off = F.back_off; f.rhs_field0 = F.rhs_field0; f.n_words = (int)F.words.size(); f.wave_closed = F.wave_closed ? 1 : 0;
   }
   if (buf.upload(all.data(), all.size()) != hipSuccess) return false;
   for (int k = 0; k < 4; ++k) D.flat[k] = buf.p + off[k];
@@ -346,7 +346,7 @@ int topo_class_of(gpf_engine* e, const int* topo, const int* shunt_bus) {
     D.static_connected = one ? 1 : 0;
   }
   D.prog = c->tables.p + o_prog;
-  if (!upload_flats(S, c->flat, D)) { c->tables.release(); c->flat.release(); delete c; return -1; }
+  if (!upload_flats(S, c->flat, D) || !D.fl[3].wave_closed) { c->tables.release(); c->flat.release(); delete c; return -1; }
   c->dev.pair_rc = c->tables.p + o_rc; c->dev.up = c->tables.p + o_up; c->dev.br_slot = c->tables.p + o_br; c->dev.node_of = c->tables.p + o_no;
   D.n_up = (int)upv.size() / 2;
   const int id = (int)e->classes.size();
@@ -389,7 +389,7 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
       while (!listed && ipw > 1 && !(lane0_l % ipw == 0 && (n_l % ipw == 0 || lane0_l + n_l == e->n_lanes))) ipw >>= 1;
     }
     auto need = [&](int tier) -> size_t {
-      const int wpi_n = (nbk == 1 && ipw == 1) ? (e->wpi_override ? std::min(e->wpi_override, 2) : (e->g.n_sub >= 64 ? 2 : 1)) : 1;
+      const int wpi_n = (nbk == 1 && ipw == 1) ? (e->wpi_override ? std::min(e->wpi_override, 2) : (e->g.n_sub >= 64 && e->sym_dev.fl[3].wave_closed ? 2 : 1)) : 1;
       const size_t static_bytes = gpf::stat_bytes(e->sym_dev.so, tier, nbk == 1, e->sym_dev.fl[gpf::gw_index(64 / ipw * wpi_n)].n_words);
       const bool st = tier > 0;
       const bool dcf = e->dcf != 0;
@@ -415,8 +415,11 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
     q.ipw = ipw;
     q.minw = 2;
     // large grids: phases loop over hundreds of items -> several wavefronts per instance (block-wide barriers)
-    q.wpi = (nbk == 1 && ipw == 1) ? (e->wpi_override ? std::min(e->wpi_override, 2) : (e->g.n_sub >= 64 ? 2 : 1))
-          : (nbk == 2 && (e->wpi_override ? e->wpi_override == 2 : e->g.n_sub >= 64)) ? 2 : 1;
+    // (2 wavefronts per instance need a flat program whose passes keep every destination inside one wavefront -- bitwise
+    //  reproducibility; the NB = n_busbar kernels use the level-header program, which is not packed that way: one wavefront
+    //  unless GRIDPF_WPI=2 asks for the faster, not bit-reproducible variant)
+    q.wpi = (nbk == 1 && ipw == 1) ? (e->wpi_override ? std::min(e->wpi_override, 2) : (e->g.n_sub >= 64 && e->sym_dev.fl[3].wave_closed ? 2 : 1))
+          : (nbk == 2 && e->wpi_override == 2) ? 2 : 1;
     if (q.wpi > 1) q.minw = 2;
     q.sparse_stage = stage;
     q.lds = l;

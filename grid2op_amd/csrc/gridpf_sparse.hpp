@@ -83,6 +83,7 @@ __host__ __device__ inline size_t stat_bytes(const StatOff& o, int tier, bool nb
 // Device view of a FlatProg (gridpf_symbolic.hpp): pass counts and section offsets (ints) of ONE group-width variant.
 struct FlatDev {
   int n_fwd, n_scale, n_scale_rhs, n_back, scale_off, back_off, rhs_field0, n_words;
+  int wave_closed;   // (group width 128) every destination of a pass is accumulated by ONE wavefront (FlatProg::wave_closed)
 };
 // group width (threads per instance) -> index of its flat-program variant: 16, 32, 64, 128 -> 0 .. 3
 __host__ __device__ constexpr int gw_index(int gw) { return gw >= 128 ? 3 : gw >= 64 ? 2 : gw >= 32 ? 1 : 0; }
@@ -790,6 +791,16 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   const OutOff& oo = P->oo;
   const int nsub = g.n_sub;
   const int nbus = TC ? S.n : nsub * NB;               // block rows x NB: substations, or the nodes of the topology class
+  // BITWISE REPRODUCIBILITY with several wavefronts per instance.  The LDS applies the f64 atomics of ONE wavefront in issue order,
+  // those of two wavefronts in a timing-dependent order -- and floating-point addition is not associative.  So (1) the loops in
+  // which element / line lanes accumulate into bus or block sums run on wavefront 0 alone (GWA lanes: they are short and, but for
+  // the injection sums, only run when the topology changed), (2) the flat LU programs keep all items of a destination inside one
+  // wavefront per pass (gridpf_symbolic.hpp: build_flat), (3) the Newton loop's S_i = sum_j T_ij is accumulated per wavefront --
+  // wavefront 0 in the S column of the pseudo-slots, wavefront 1 in their (then unused) right-hand-side column -- and the two
+  // partial sums are added in a fixed order by the mismatch phase.  Single-wavefront instances: GWA = GW, nothing changes.
+  constexpr int GWA = WPI > 1 ? WAVE : GW;
+  const bool acc_lane = WPI == 1 || tid < WAVE;
+  const bool wave1 = WPI > 1 && tid >= WAVE;
   // element (r, col) of block `slot`: 2x2 blocks are stored split by row (see block_lu_solve), larger blocks contiguously
   const size_t HS = ((size_t)S.rslot0 + S.n) * 2;         // doubles per row half (single-busbar layout: slots + right-hand-side pseudo-slots)
   auto bel = [&](int slot, int r, int col) -> double* {
@@ -851,7 +862,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       if (NB == 1 && !TC) { c.sub_bb[so] = (i8)bo; c.sub_bb[se] = (i8)be; }
     }
   }
-  for (int i = tid; i < g.n_gen; i += GW) {
+  if (acc_lane)
+  for (int i = tid; i < g.n_gen; i += GWA) {
     int bu;
     const bool sl = sv.gen_slack[i] != 0;
     if (!reuse) {
@@ -869,7 +881,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     } else bu = c.gen_b[i];
     if (bu >= 0 && !sl) atomicAdd(&c.Psp[bu], GPF_INJ(oo.inj_gen_p + i) * inv_sn);
   }
-  for (int i = tid; i < g.n_load; i += GW) {
+  if (acc_lane)
+  for (int i = tid; i < g.n_load; i += GWA) {
     int bu;
     if (!reuse) {
       const int lb = topo[sv.load_pos[i]];
@@ -886,7 +899,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       atomicAdd(&c.Qsp[bu], -GPF_INJ(oo.inj_load_q + i) * inv_sn);
     }
   }
-  for (int i = tid; i < g.n_sto; i += GW) {
+  if (acc_lane)
+  for (int i = tid; i < g.n_sto; i += GWA) {
     int bu;
     if (!reuse) {
       const int lb = topo[sv.sto_pos[i]];
@@ -903,7 +917,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       atomicAdd(&c.Qsp[bu], -GPF_INJ(oo.inj_sto_q + i) * inv_sn);
     }
   }
-  for (int i = tid; i < g.n_shunt; i += GW) {
+  if (acc_lane)
+  for (int i = tid; i < g.n_shunt; i += GWA) {
     int bu;
     if (!reuse) {
       const int lb = shb[i];
@@ -993,7 +1008,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   if (!dc_skip) for (int i = tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
   if (do_y) for (int i = tid; i < S.nslot_y * NB * NB * 2; i += GW) ydst[i] = 0.0;
   GPF_LSYNC();
-  for (int l = tid; l < g.n_line; l += GW) {
+  if (acc_lane)
+  for (int l = tid; l < g.n_line; l += GWA) {
     const int f = c.lor_b[l], t = c.lex_b[l];
     if (f < 0) continue;
     const int bi = lidx(f), bj = lidx(t);
@@ -1018,8 +1034,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       }
     }
   }
-  if (do_y) {
-    for (int s = tid; s < g.n_shunt; s += GW) {
+  if (do_y && acc_lane) {
+    for (int s = tid; s < g.n_shunt; s += GWA) {
       const int bu = c.sh_b[s];
       if (bu >= 0) {
         const int bi = lidx(bu);
@@ -1128,6 +1144,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       c.f[i] = vmi * sn_;
       *SreP(i) = 0.0;
       *SimP(i) = 0.0;
+      if (WPI > 1) { *rhsT(i) = 0.0; *rhsV(i) = 0.0; }      // wavefront 1's partial sums of S (see acc_lane above)
     }
     if (BS == 2) { for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; } }
     else for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;     // fill blocks start at zero
@@ -1166,8 +1183,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
           *reinterpret_cast<double2*>(bel(suv, 1, 0)) = make_double2((uQ && vP) ? -tr_ : 0.0, (uQ && vQ) ? ti_ * ivmv : 0.0);
           *reinterpret_cast<double2*>(bel(svu, 0, 0)) = make_double2((vP && uP) ? si_ : 0.0, (vP && uQ) ? sr_ * ivmu : 0.0);
           *reinterpret_cast<double2*>(bel(svu, 1, 0)) = make_double2((vQ && uP) ? -sr_ : 0.0, (vQ && uQ) ? si_ * ivmu : 0.0);
-          if (act && (yuv.x != 0.0 || yuv.y != 0.0)) { atomicAdd(SreP(u), tr_); atomicAdd(SimP(u), ti_); }
-          if (act && (yvu.x != 0.0 || yvu.y != 0.0)) { atomicAdd(SreP(v), sr_); atomicAdd(SimP(v), si_); }
+          if (act && (yuv.x != 0.0 || yuv.y != 0.0)) { atomicAdd(wave1 ? rhsT(u) : SreP(u), tr_); atomicAdd(wave1 ? rhsV(u) : SimP(u), ti_); }
+          if (act && (yvu.x != 0.0 || yvu.y != 0.0)) { atomicAdd(wave1 ? rhsT(v) : SreP(v), sr_); atomicAdd(wave1 ? rhsV(v) : SimP(v), si_); }
         };
         if (YR) {
 #pragma unroll
@@ -1197,7 +1214,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
           const double ivmj = fast_rcp(vmj);
           *reinterpret_cast<double2*>(bel(slot, 2 * bi, 2 * bj)) = make_double2((rowP && colT) ? ti_ : 0.0, (rowP && colV) ? tr_ * ivmj : 0.0);
           *reinterpret_cast<double2*>(bel(slot, 2 * bi + 1, 2 * bj)) = make_double2((rowQ && colT) ? -tr_ : 0.0, (rowQ && colV) ? ti_ * ivmj : 0.0);
-          if (act && (y.x != 0.0 || y.y != 0.0)) { atomicAdd(SreP(i), tr_); atomicAdd(SimP(i), ti_); }
+          if (act && (y.x != 0.0 || y.y != 0.0)) { atomicAdd(wave1 ? rhsT(i) : SreP(i), tr_); atomicAdd(wave1 ? rhsV(i) : SimP(i), ti_); }
         };
         unsigned rc_pf = rc_first;
         for (int pr = tid; pr < n_pairs; pr += GW) {
@@ -1217,6 +1234,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         double* Ad1 = bel(sub, 2 * bi + 1, 2 * bi);
         const int bt = c.btype[i];
         double Sr = *SreP(i), Si = *SimP(i);
+        if (WPI > 1) { Sr += *rhsT(i); Si += *rhsV(i); }       // + wavefront 1's partial sums, always in this order
         const double vmi = c.vm[i], psp = c.Psp[i], qsp = c.Qsp[i];
         const bool rowP = (bt == BT_PQ || bt == BT_PV), rowQ = (bt == BT_PQ);
         const double ivmi = fast_rcp(vmi);
@@ -1283,6 +1301,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         c.f[i] = vm * sn_;
         *SreP(i) = 0.0;
         *SimP(i) = 0.0;
+        if (WPI > 1) { *rhsT(i) = 0.0; *rhsV(i) = 0.0; }
       }
       if (BS == 2) { for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; } }
     else for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
@@ -1306,7 +1325,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   if (is_dc) {
     for (int i = tid; i < nbus; i += GW) { *SreP(i) = c.Gs[i]; *SimP(i) = 0.0; }
     GPF_LSYNC();
-    for (int l = tid; l < g.n_line; l += GW) {
+    if (acc_lane)
+    for (int l = tid; l < g.n_line; l += GWA) {
       const int f = c.lor_b[l], t = c.lex_b[l];
       if (f < 0) continue;
       const double fl = (c.va[f] - c.va[t]) * sv.br_bdc[l];
@@ -1389,7 +1409,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       GPF_LSYNC();
       for (int i = tid; i < nbus; i += GW) { qmin_t[i] = 0.0; qmax_t[i] = 0.0; cnt[i] = 0; nsl[i] = 0; }
       GPF_LSYNC();
-      for (int i = tid; i < g.n_gen; i += GW) {
+      if (acc_lane)
+      for (int i = tid; i < g.n_gen; i += GWA) {
         const int bu = c.gen_b[i];
         if (bu < 0) continue;
         atomicAdd(&cnt[bu], 1);
@@ -1621,7 +1642,12 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
         GPF_LSYNC();
       }
       GPF_STAMPS(16);
-      for (int i = tid; i < g.n_load; i += GW) {
+      // several wavefronts per instance: the loops below (which also accumulate the bus sums when the maps stand) run on wavefront 0
+      // alone -- fixed order of the LDS atomics and of the load / generation totals: bitwise reproducibility, see solve_instance_sparse
+      constexpr int gw9 = WPI > 1 ? WAVE : GW;
+      const bool lane9 = tid < gw9;
+      if (lane9)
+      for (int i = tid; i < g.n_load; i += gw9) {
         float lp = ch[i], lq = ch[g.n_load + i];
         if (has_sc) { lp *= (i == tid) ? sc_p0 : sc[i]; lq *= (i == tid) ? sc_q0 : sc[g.n_load + i]; }
         if (STAGE) { c.inj[oo.inj_load_p + i] = (double)lp; c.inj[oo.inj_load_q + i] = (double)lq; }   // HBM copy: end of kernel
@@ -1632,7 +1658,8 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
           if (bu >= 0) { atomicAdd(&c.Psp[bu], -(double)lp * inv_sn9); atomicAdd(&c.Qsp[bu], -(double)lq * inv_sn9); }
         }
       }
-      for (int i = tid; i < g.n_gen; i += GW)
+      if (lane9)
+      for (int i = tid; i < g.n_gen; i += gw9)
         if (!sv.gen_slack[i]) sum_prod += (double)(i == tid ? pp_pre : ch[2 * g.n_load + i]);
       float scale_p = 1.0f;
       GPF_STAMPS(17);
@@ -1641,7 +1668,8 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
         scale_p = (sum_prod > 0.0) ? (float)(sa.rebalance * sum_load / sum_prod) : 1.0f;
       }
       GPF_STAMPS(18);
-      for (int i = tid; i < g.n_gen; i += GW) {
+      if (lane9)
+      for (int i = tid; i < g.n_gen; i += gw9) {
         float pp = (i == tid) ? pp_pre : ch[2 * g.n_load + i];
         if (!sv.gen_slack[i]) pp *= scale_p;
         if (has_delta) pp += (i == tid) ? gd0 : gdelta[i];
@@ -1655,8 +1683,8 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
           if (bu >= 0 && !sv.gen_slack[i]) atomicAdd(&c.Psp[bu], (double)pp * inv_sn9);
         }
       }
-      if (sums_in_k9) {                              // storage and shunt set-points do not change during a launch
-        for (int i = tid; i < g.n_sto; i += GW) {
+      if (sums_in_k9 && lane9) {                     // storage and shunt set-points do not change during a launch
+        for (int i = tid; i < g.n_sto; i += gw9) {
           const int bu = c.sto_b[i];
           if (bu >= 0) {
             const double sp = STAGE ? c.inj[oo.inj_sto_p + i] : (double)inj_g[oo.inj_sto_p + i];
@@ -1665,7 +1693,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
             atomicAdd(&c.Qsp[bu], -sq * inv_sn9);
           }
         }
-        for (int i = tid; i < g.n_shunt; i += GW) {
+        for (int i = tid; i < g.n_shunt; i += gw9) {
           const int bu = c.sh_b[i];
           if (bu >= 0) {
             const double hp = STAGE ? c.inj[oo.inj_sh_p + i] : (double)inj_g[oo.inj_sh_p + i];

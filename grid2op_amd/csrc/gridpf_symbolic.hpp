@@ -62,6 +62,7 @@ struct Symbolic {
 // The forward and back sections end with one extra all-invalid pass (the device prefetches the words of the next pass).
 struct FlatProg {
   int gw = 0;
+  bool wave_closed = true;                                     // gw > 64: every destination of a pass is written by ONE wavefront (below)
   int n_fwd = 0, n_scale = 0, n_scale_rhs = 0, n_back = 0;     // passes
   int scale_off = 0, back_off = 0;                             // int offsets of the sections (forward starts at 0)
   int rhs_field0 = 0;                                          // rslot0 * 16: fields >= this are right-hand-side pseudo-slots
@@ -225,29 +226,47 @@ inline FlatProg build_flat(const Symbolic& S, int gw) {
   auto fld = [](int slot) -> unsigned { return (unsigned)slot * 16u; };
   auto rfld = [&](int row) -> unsigned { return (unsigned)(S.rslot0 + row) * 16u; };
   std::vector<int>& W = F.words;
-  auto pad2 = [&](size_t start_items, size_t n_items) {       // pad a list of 2-word items to whole passes
-    const size_t rem = n_items % gw;
-    if (rem) for (size_t k = rem; k < (size_t)gw; ++k) { W.push_back((int)INV); W.push_back((int)INV); }
-    (void)start_items;
-    return (int)((n_items + gw - 1) / gw);
+  // Several wavefronts per instance (gw > 64): the items of a pass that accumulate into the SAME destination (ds_add_f64) must all
+  // run in ONE wavefront -- the LDS applies the atomics of a wavefront in a fixed order, those of two wavefronts in a timing-dependent
+  // one, and floating-point addition is not associative.  The items of a level are therefore grouped by destination and a group
+  // never straddles the boundary between the two 64-lane halves of a pass (it may continue in the NEXT pass: a barrier separates
+  // them); invalid items pad the gap.  Returns the number of passes the items took.  gw <= 64: plain sequential packing.
+  auto emit_items = [&](std::vector<std::pair<unsigned, std::pair<unsigned, unsigned>>>& items) -> int {   // (destination key, (w0, w1))
+    if (items.empty()) return 0;
+    size_t pos = 0;                                            // items emitted for this level, padding included
+    auto put = [&](unsigned a, unsigned b) { W.push_back((int)a); W.push_back((int)b); ++pos; };
+    if (gw > 64) {
+      std::stable_sort(items.begin(), items.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+      for (size_t i = 0; i < items.size();) {
+        size_t j = i;
+        while (j < items.size() && items[j].first == items[i].first) ++j;
+        const size_t g = j - i, in_half = pos % 64;
+        const bool first_half = (pos / 64) % 2 == 0 || gw != 128;        // (gw = 128: halves alternate wavefront 0 / 1)
+        if (g > 64) F.wave_closed = false;
+        else if (in_half + g > 64 && first_half) while (pos % 64) put(INV, INV);
+        for (; i < j; ++i) put(items[i].second.first, items[i].second.second);
+      }
+    } else
+      for (auto& it : items) put(it.second.first, it.second.second);
+    while (pos % gw) put(INV, INV);
+    return (int)(pos / gw);
   };
   // forward
   for (int lv = 0; lv < S.n_levels; ++lv) {
     const int* h = S.prog.data() + (size_t)8 * lv;
     const int c_off = h[4], n_c = h[5], r_off = h[6], n_r = h[7];
     if (n_c + n_r == 0) continue;
+    std::vector<std::pair<unsigned, std::pair<unsigned, unsigned>>> items;
     for (int o = 0; o < n_c; ++o) {
       const unsigned w0 = (unsigned)S.prog[c_off + 2 * o], w1 = (unsigned)S.prog[c_off + 2 * o + 1];
-      W.push_back((int)(fld(w0 & 0xffffu) | (fld(w0 >> 16) << 16)));
-      W.push_back((int)(fld(w1 & 0xffffu) | (fld(w1 >> 16) << 16)));
+      items.push_back({fld(w0 & 0xffffu), {fld(w0 & 0xffffu) | (fld(w0 >> 16) << 16), fld(w1 & 0xffffu) | (fld(w1 >> 16) << 16)}});
     }
     for (int o = 0; o < n_r; ++o) {
       const unsigned w0 = (unsigned)S.prog[r_off + 2 * o];
       const int p = S.prog[r_off + 2 * o + 1];
-      W.push_back((int)(rfld((int)(w0 >> 16)) | (fld(w0 & 0xffffu) << 16)));
-      W.push_back((int)(rfld(p) | (fld(p) << 16)));
+      items.push_back({rfld((int)(w0 >> 16)), {rfld((int)(w0 >> 16)) | (fld(w0 & 0xffffu) << 16), rfld(p) | (fld(p) << 16)}});
     }
-    F.n_fwd += pad2(0, (size_t)n_c + n_r);
+    F.n_fwd += emit_items(items);
   }
   for (int k = 0; k < gw; ++k) { W.push_back((int)INV); W.push_back((int)INV); }
   // (no scaling pass: the U blocks and the right-hand side stay UNSCALED -- the back substitution is
@@ -261,13 +280,13 @@ inline FlatProg build_flat(const Symbolic& S, int gw) {
   for (int lv = S.back_first; lv >= 0; --lv) {
     const int ent_off = S.prog[S.back_off + 2 * lv], n_ent = S.prog[S.back_off + 2 * lv + 1];
     if (n_ent == 0) continue;
+    std::vector<std::pair<unsigned, std::pair<unsigned, unsigned>>> items;
     for (int o = 0; o < n_ent; ++o) {
       const unsigned w = (unsigned)S.prog[ent_off + 2 * o];
       const int p = S.prog[ent_off + 2 * o + 1];
-      W.push_back((int)(fld(w & 0xffffu) | (rfld((int)(w >> 16)) << 16)));
-      W.push_back((int)rfld(p));
+      items.push_back({rfld(p), {fld(w & 0xffffu) | (rfld((int)(w >> 16)) << 16), rfld(p)}});
     }
-    F.n_back += pad2(0, (size_t)n_ent);
+    F.n_back += emit_items(items);
   }
   for (int k = 0; k < gw; ++k) { W.push_back((int)INV); W.push_back((int)INV); }
   while (W.size() & 3) W.push_back((int)INV);

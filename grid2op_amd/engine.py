@@ -157,8 +157,8 @@ class PowerFlowEngine:
             pass
 
     def set_deterministic(self, flag: bool = True):
-        """Bit-identical results from run to run on grids with >= 64 substations too (one wavefront per lane instead of two,
-        ~7 % slower there); small grids always are."""
+        """Results are bit-identical from run to run on every grid by default; ``True`` additionally forces one wavefront per lane
+        on grids with >= 64 substations (cross-check variant, ~20 % slower there)."""
         check(self._lib.gpf_set_deterministic(self._h, int(bool(flag))), "gpf_set_deterministic")
 
     def _range(self, lane0, n):

@@ -96,11 +96,14 @@ typedef struct gpf_layout {
 
 const char* gpf_last_error(void);
 int gpf_version(void);
-/* Bitwise run-to-run reproducibility.  Grids with >= 64 substations are solved by 2 wavefronts per lane whose LDS atomics
- * interleave in a timing-dependent order: results are reproducible to ~1e-13 relative, not bit for bit.  flag != 0 keeps
- * every lane on ONE wavefront (the order of the atomics of a single wavefront is fixed): bit-identical results from run to
- * run and independent of the lane's position in the batch, ~7 % slower on 118 substations.  Small grids are always bitwise
- * reproducible.  (grid2op's determinism contract: same seeds -> same episode, grid2op/Environment/baseEnv.py seed()). */
+/* Bitwise run-to-run reproducibility is the DEFAULT on every grid: the same lane inputs give bit-identical results from run to
+ * run and whatever the lane's position in the batch (grid2op's determinism contract: same seeds -> same episode,
+ * grid2op/Environment/baseEnv.py seed()).  Small grids are solved by one wavefront per lane (the LDS applies the atomics of a
+ * wavefront in a fixed order); grids with >= 64 substations by 2 wavefronts per lane whose accumulations are arranged so that no
+ * sum depends on the interleaving of the two (accumulation loops on wavefront 0, every destination of an LU pass owned by one
+ * wavefront, per-wavefront partial sums added in a fixed order).  flag != 0 additionally forces ONE wavefront per lane on the
+ * large grids (~20 % slower there; kept for cross-checks -- its results differ from the 2-wavefront kernel's in the last bits,
+ * each variant being reproducible in itself). */
 int gpf_set_deterministic(gpf_handle h, int32_t flag);
 /* Number of HIP devices visible to this process (0 and GPF_OK when there is none): what a single-process caller
  * shards its lane batch over (grid2op_amd/sharding.py ShardedEngine; the reference's own parallelism is one process per

@@ -3,6 +3,7 @@
 // level scheduling are verified on CPU against a dense solve (tests/test_symbolic_program.py).
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "../../grid2op_amd/csrc/gridpf_symbolic.hpp"
@@ -165,14 +166,21 @@ extern "C" int sym_emul_solve_flat(int n_sub, int n_line, const int* line_or, co
   auto el = [&](unsigned f, int r, int q) -> double& { return A[r * HS + (size_t)(f / 16) * 2 + q]; };
   const int* W = F.words.data();
   if (F.scale_off != 2 * gw * (F.n_fwd + 1)) return -4;                   // forward section + its padding pass
+  if (!F.wave_closed) return -11;
   for (int k = 0; k < F.n_fwd; ++k) {
     std::vector<double> d(A.size(), 0.0);
     bool seen_inv = false;
+    std::map<unsigned, int> dst_half;
     for (int t = 0; t < gw; ++t) {
       const unsigned w0 = (unsigned)W[2 * (k * gw + t)], w1 = (unsigned)W[2 * (k * gw + t) + 1];
       if (w0 == INV) { seen_inv = true; continue; }
-      if (seen_inv) return -3;
+      if (seen_inv && gw <= 64) return -3;                  // (gw > 64: padding keeps a destination's items inside one wavefront)
       const unsigned fd = w0 & 0xffffu, fl = w0 >> 16, fu = w1 & 0xffffu, fp = w1 >> 16;
+      if (gw > 64) {                                        // wave-closed: every destination of a pass belongs to ONE 64-lane half
+        auto it = dst_half.find(fd);
+        if (it != dst_half.end() && it->second != t / 64) return -9;
+        dst_half[fd] = t / 64;
+      }
       if (!ok_field(fd) || !ok_field(fl) || !ok_field(fu) || !ok_field(fp)) return -2;
       const double d00 = el(fp, 0, 0), d01 = el(fp, 0, 1), d10 = el(fp, 1, 0), d11 = el(fp, 1, 1);
       const double det = d00 * d11 - d01 * d10;
@@ -196,11 +204,17 @@ extern "C" int sym_emul_solve_flat(int n_sub, int n_line, const int* line_or, co
   };
   for (int k = 0; k < F.n_back; ++k) {
     std::vector<double> d(A.size(), 0.0);
+    std::map<unsigned, int> dst_half;
     for (int t = 0; t < gw; ++t) {
       const unsigned w0 = (unsigned)W[F.back_off + 2 * (k * gw + t)], w1 = (unsigned)W[F.back_off + 2 * (k * gw + t) + 1];
       if (w0 == INV) continue;
       const unsigned fu = w0 & 0xffffu, fj = w0 >> 16;
       if (!ok_field(fu) || !ok_field(fj) || !ok_field(w1) || (int)fj < F.rhs_field0 || (int)w1 < F.rhs_field0) return -2;
+      if (gw > 64) {
+        auto it = dst_half.find(w1);
+        if (it != dst_half.end() && it->second != t / 64) return -9;
+        dst_half[w1] = t / 64;
+      }
       double x0, x1;
       inv_apply(fj - (unsigned)F.rhs_field0, el(fj, 0, 0), el(fj, 1, 0), x0, x1);       // the item applies inv(D_col) itself
       for (int r = 0; r < 2; ++r) d[r * HS + (size_t)(w1 / 16) * 2] -= el(fu, r, 0) * x0 + el(fu, r, 1) * x1;

@@ -86,7 +86,10 @@ def test_flat_program_reproduces_dense_solve(emul, load_model, name, gw):
     lv = np.zeros(4 * 64 + 2, dtype=np.int32)
     n_levels = emul.sym_level_sizes(n, m.n_line, lor.ctypes.data_as(ip), lex.ctypes.data_as(ip), lv.ctypes.data_as(ip), 64, 1)
     items = [int(lv[4 * k + 2] + lv[4 * k + 3]) for k in range(n_levels)]
-    assert n_fwd == sum(-(-i // gw) for i in items if i > 0)          # a level takes ceil(items / gw) passes
+    if gw <= 64:
+        assert n_fwd == sum(-(-i // gw) for i in items if i > 0)      # a level takes ceil(items / gw) passes
+    else:                                                             # (wave-closed packing may pad: never fewer, at most one more per level)
+        assert sum(-(-i // gw) for i in items if i > 0) <= n_fwd <= sum(-(-i // gw) + 1 for i in items if i > 0)
     assert n_words % 4 == 0
 
 
