@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "gpf_set_injections", "gpf_set_topology", "gpf_get_injections", "gpf_get_topology", "gpf_disconnect_line",
     "gpf_reset_lanes", "gpf_copy_lanes", "gpf_fanout_n1", "gpf_runpf", "gpf_solve_lane", "gpf_get_results", "gpf_upload_chronics",
     "gpf_upload_maintenance", "gpf_set_lane_chronics", "gpf_set_thermal_limits", "gpf_step", "gpf_step_n", "gpf_set_lane_redispatch", "gpf_set_gen_limits", "gpf_redispatch", "gpf_set_trajectory",
-    "gpf_get_trajectory", "gpf_get_trajectory_obs", "gpf_get_episode", "gpf_lane_capacity", "gpf_get_step_outputs", "gpf_sync",
+    "gpf_get_trajectory", "gpf_get_trajectory_obs", "gpf_upload_forecasts", "gpf_simulate_batch", "gpf_set_overflow_count", "gpf_get_episode", "gpf_lane_capacity", "gpf_get_step_outputs", "gpf_sync",
     "gpf_set_profiling", "gpf_get_kernel_time", "gpf_get_plan", "gpf_device_pointers",
     "gpf_ptdf_build", "gpf_ptdf_get", "gpf_ptdf_flows", "gpf_get_ptdf_flows", "gpf_lodf_screen",
 ]
@@ -139,6 +139,9 @@ def lib() -> C.CDLL:
     L.gpf_set_trajectory.argtypes = [h, i32, i32]
     L.gpf_get_trajectory_obs.argtypes = [h, i32, i32, i32, i32, _fp, _ip, _ip, _bp]
     L.gpf_get_trajectory.argtypes = [h, i32, i32, i32, i32, _fp, C.POINTER(C.c_int8)]
+    L.gpf_upload_forecasts.argtypes = [h, i32, i32, i32, _fp]
+    L.gpf_simulate_batch.argtypes = [h, i32, i32, i32, _ip, i32, _ip, _ip, _ip, i32, C.POINTER(GpfStepOpts)]
+    L.gpf_set_overflow_count.argtypes = [h, i32, i32, _ip]
     L.gpf_get_episode.argtypes = [h, i32, i32, _bp, _ip]
     L.gpf_lane_capacity.argtypes = [h]
     L.gpf_get_step_outputs.argtypes = [h, i32, i32, _fp, _ip, _ip]

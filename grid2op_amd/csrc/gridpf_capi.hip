@@ -45,6 +45,37 @@ __global__ void fanout_kernel(GridDev g, Bufs b, int src, int dst0, int n_dst, c
   for (int i = tid; i < g.n_shunt; i += blockDim.x) ds[i] = ss[i];
 }
 
+// gpf_simulate_batch: topology / shunt rows of the source lanes -> one dense staging buffer (a single device-to-host copy)
+__global__ void gather_topo_kernel(GridDev g, Bufs b, const int* __restrict__ src_lanes, int n_src, int* __restrict__ dst) {
+  const int k = blockIdx.x;
+  if (k >= n_src) return;
+  const int src = src_lanes[k];
+  const int w = g.dim_topo + g.n_shunt;
+  for (int i = threadIdx.x; i < g.dim_topo; i += blockDim.x) dst[(size_t)k * w + i] = b.topo[(size_t)src * g.dim_topo + i];
+  for (int i = threadIdx.x; i < g.n_shunt; i += blockDim.x) dst[(size_t)k * w + g.dim_topo + i] = b.shunt_bus[(size_t)src * g.n_shunt + i];
+}
+
+// gpf_simulate_batch: destination lane d = dst0 + b * n_act + k takes over everything of source lane b that is not topology
+// (injection row, protection counters, chronics table / jitter / redispatch delta) and gets the chronics-table row to step on:
+// the source's current row idx = (t_obs + offset) mod T for time_step 0, else forecast row n_h * idx + time_step - 1.
+__global__ void simulate_prepare_kernel(GridDev g, Bufs b, const int* __restrict__ src_lanes, int n_act, int n_dst, int dst0, int t_obs,
+                                        int T, int n_h, int time_step, int* __restrict__ lane_table, int* __restrict__ lane_offset,
+                                        float* __restrict__ lane_scale, float* __restrict__ lane_gen_delta) {
+  const int q = blockIdx.x;
+  if (q >= n_dst) return;
+  const int src = src_lanes[q / n_act], dst = dst0 + q, tid = threadIdx.x;
+  for (int i = tid; i < g.n_inj; i += blockDim.x) b.inj[(size_t)dst * g.n_inj + i] = b.inj[(size_t)src * g.n_inj + i];
+  for (int i = tid; i < g.n_line; i += blockDim.x) b.overflow_count[(size_t)dst * g.n_line + i] = b.overflow_count[(size_t)src * g.n_line + i];
+  if (lane_scale) for (int i = tid; i < 2 * g.n_load; i += blockDim.x) lane_scale[(size_t)dst * 2 * g.n_load + i] = lane_scale[(size_t)src * 2 * g.n_load + i];
+  if (lane_gen_delta) for (int i = tid; i < g.n_gen; i += blockDim.x) lane_gen_delta[(size_t)dst * g.n_gen + i] = lane_gen_delta[(size_t)src * g.n_gen + i];
+  if (tid == 0) {
+    lane_table[dst] = lane_table[src];
+    int idx = (t_obs + lane_offset[src]) % T;
+    if (idx < 0) idx += T;
+    lane_offset[dst] = time_step == 0 ? idx : n_h * idx + (time_step - 1);
+    b.done[dst] = 0;
+  }
+}
 
 }  // namespace gpf
 
@@ -113,6 +144,9 @@ struct gpf_engine {
   DevArr<int> topo0, episode;           // topology last sent by the host (auto-reset target); {steps survived, resets} per lane
   DevArr<float> lane_gen_delta, traj_rho;
   DevArr<unsigned char> maint;          // [chron_tables][chron_T][n_line] scheduled maintenance, or empty
+  DevArr<float> forecast;               // [chron_tables][chron_T][fc_h][n_chron] *_forecasted tables (gpf_upload_forecasts), or empty
+  int fc_h = 0;
+  DevArr<int> sim_src, sim_rows;        // gpf_simulate_batch staging: source lane list, gathered topology rows
   DevArr<signed char> traj_status;
   DevArr<float> traj_out;               // per-step observation trajectory (GPF_TRAJ_OBS): [traj_cap][cap_lanes][n_out] ...
   DevArr<int> traj_topo, traj_shb;
@@ -892,7 +926,7 @@ int gpf_destroy(gpf_handle e) {
   e->lane_scale.release(); e->thermal_limit.release(); e->rho.release(); e->line_status.release();
   e->d_init_inj.release(); e->d_init_topo.release(); e->d_init_shunt_bus.release();
   if (e->pin) (void)hipHostFree(e->pin);
-  e->maint.release();
+  e->maint.release(); e->forecast.release(); e->sim_src.release(); e->sim_rows.release();
   e->rd_pmin.release(); e->rd_pmax.release(); e->rd_ru.release(); e->rd_rd.release(); e->rd_in.release(); e->rd_redisp.release();
   e->rd_u8.release(); e->rd_after.release();
   e->topo0.release(); e->done.release(); e->episode.release(); e->lane_gen_delta.release(); e->traj_rho.release(); e->traj_status.release();
@@ -1182,6 +1216,7 @@ int gpf_upload_chronics(gpf_handle e, int32_t n_tables, int32_t T, const float* 
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->chron.release();
   e->maint.release();                       // belongs to the previous tables
+  e->forecast.release(); e->fc_h = 0;
   HIP_TRY(e->chron.upload(data, (size_t)n_tables * T * e->g.n_chron));
   e->chron_T = T;
   if (n_tables < e->chron_tables) {
@@ -1241,6 +1276,69 @@ int gpf_set_thermal_limits(gpf_handle e, const float* limit_a) {
   return GPF_OK;
 }
 
+}  // extern "C"
+namespace {
+// n_steps env steps of lanes [lane0, lane0 + n) from time index t0 (T rows per chronics table in `b.chron`)
+int step_range(gpf_engine* e, const gpf::Bufs& b, int lane0, int n, int t0, int T, int n_steps, const gpf_step_opts* o, const char* who) {
+  LaunchPlan p, pb;
+  int rc = plan_launch(e, lane0, n, p, pb);
+  if (rc != GPF_OK) return rc;
+  if (n_steps > 1 && pb.sparse_nb)
+    return fail(GPF_E_INVALID, std::string(who) + ": multi-step launches need a batch that runs as ONE launch (mixed split / unsplit lanes "
+                               "without topology classes run as two): use n_steps = 1");
+  gpf::StepArgs sa{};
+  sa.t = t0; sa.T = T; sa.rebalance_on = o->rebalance > 0.0 ? 1 : 0; sa.rebalance = o->rebalance; sa.cascade = o->cascade;
+  sa.is_dc = o->is_dc ? 1 : 0; sa.n_steps = n_steps; sa.auto_reset = o->auto_reset ? 1 : 0; sa.warm_start = o->warm_start ? 1 : 0;
+  sa.nb_ts_allowed = o->nb_ts_allowed; sa.max_rounds = o->max_rounds; sa.hard_overflow = o->hard_overflow; sa.soft_overflow = o->soft_overflow;
+  sa.lane0 = lane0;
+  const double tol_pu = o->tol_mva / e->g.sn_mva;
+  hipEvent_t ea = nullptr, eb = nullptr;
+  rc = upload_params_s(e, b, p.tc ? &p : (pb.tc ? &pb : nullptr), p.dcf);
+  if (rc != GPF_OK) return rc;
+  if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
+  HIP_TRY(gpf_launch_step_sparse(p, e->device, e->d_params_s, e->stream, n, o->max_iter, tol_pu, sa));
+  if (pb.sparse_nb) HIP_TRY(gpf_launch_step_sparse(pb, e->device, e->d_params_s, e->stream, n, o->max_iter, tol_pu, sa));
+  HIP_TRY(hipGetLastError());
+  if (e->profiling) HIP_TRY(hipEventRecord(eb, e->stream));
+  if (e->window) ++e->win_launches;
+  return GPF_OK;
+}
+
+// _BackendAction.__iadd__ restricted to topology (Action/_backendAction.py:836-919; ValueStore.set_status / change_status / set_val /
+// change_val :140-234, _aux_iadd_reconcile_disco_reco :738-765) on one topology row; items = {kind, id, value} triples
+void apply_topo_action(const gpf_engine* e, int* row, int* sb, const int* last, const int32_t* items, int n_items) {
+  const gpf::GridDev& g = e->g;
+  auto old = [&](int pos) { return (last && last[pos] >= 1) ? last[pos] : 1; };
+  auto reco = [&](int l) { const int po = e->h_line_or_pos[l], pe = e->h_line_ex_pos[l]; if (row[po] < 0) row[po] = old(po); if (row[pe] < 0) row[pe] = old(pe); };
+  auto disco = [&](int l) { row[e->h_line_or_pos[l]] = -1; row[e->h_line_ex_pos[l]] = -1; };
+  // III line status: change_status, then set_status (a reconnected end goes back to its last known busbar)
+  for (int k = 0; k < n_items; ++k) if (items[3 * k] == GPF_ACT_CHANGE_LINE_STATUS) {
+    const int l = items[3 * k + 1];
+    if (row[e->h_line_or_pos[l]] > 0 || row[e->h_line_ex_pos[l]] > 0) disco(l); else reco(l);
+  }
+  for (int k = 0; k < n_items; ++k) if (items[3 * k] == GPF_ACT_SET_LINE_STATUS) {
+    const int l = items[3 * k + 1], v = items[3 * k + 2];
+    if (v < 0) disco(l); else if (v > 0) reco(l);
+  }
+  std::vector<int> or_before(g.n_line), ex_before(g.n_line);
+  for (int l = 0; l < g.n_line; ++l) { or_before[l] = row[e->h_line_or_pos[l]]; ex_before[l] = row[e->h_line_ex_pos[l]]; }
+  // IV change_bus, then set_bus
+  bool bus_modif = false;
+  for (int k = 0; k < n_items; ++k) if (items[3 * k] == GPF_ACT_CHANGE_BUS) { int& v = row[items[3 * k + 1]]; if (v > 0) v = (1 - v) + 2; bus_modif = true; }
+  for (int k = 0; k < n_items; ++k) if (items[3 * k] == GPF_ACT_SET_BUS && items[3 * k + 2] != 0) { row[items[3 * k + 1]] = items[3 * k + 2]; bus_modif = true; }
+  // V a line with an open end is open; a line that was open and got a bus on one end is reconnected (other end: last known busbar)
+  if (bus_modif)
+    for (int l = 0; l < g.n_line; ++l) {
+      const int o_ = row[e->h_line_or_pos[l]], x_ = row[e->h_line_ex_pos[l]];
+      const bool d_now = or_before[l] == -1 || o_ == -1 || ex_before[l] == -1 || x_ == -1;
+      const bool r_now = or_before[l] == -1 && (o_ >= 1 || x_ >= 1);
+      if (r_now) reco(l); else if (d_now) disco(l);
+    }
+  for (int k = 0; k < n_items; ++k) if (items[3 * k] == GPF_ACT_SET_SHUNT_BUS && sb && items[3 * k + 2] != 0) sb[items[3 * k + 1]] = items[3 * k + 2];
+}
+}  // namespace
+extern "C" {
+
 int gpf_step_n(gpf_handle e, int32_t t0, int32_t n_steps, const gpf_step_opts* o) {
   if (!e || !o) return fail(GPF_E_INVALID, "gpf_step_n: null");
   if (n_steps <= 0) return fail(GPF_E_INVALID, "gpf_step_n: n_steps must be positive");
@@ -1248,29 +1346,89 @@ int gpf_step_n(gpf_handle e, int32_t t0, int32_t n_steps, const gpf_step_opts* o
   if (e->traj_cap && n_steps > e->traj_cap)
     return fail(GPF_E_INVALID, "gpf_step_n: n_steps exceeds the trajectory buffer (gpf_set_trajectory sizes it; 0 releases it)");
   HIP_TRY(hipSetDevice(e->device));
-  LaunchPlan p, pb;
-  int rc = plan_launch(e, 0, e->n_lanes, p, pb);
+  int rc = step_range(e, e->bufs(), 0, e->n_lanes, t0, e->chron_T, n_steps, o, "gpf_step_n");
   if (rc != GPF_OK) return rc;
-  if (n_steps > 1 && pb.sparse_nb)
-    return fail(GPF_E_INVALID, "gpf_step_n: multi-step launches need a batch that runs as ONE launch (mixed split / unsplit lanes "
-                               "without topology classes run as two): use n_steps = 1");
-  gpf::Bufs b = e->bufs();
-  gpf::StepArgs sa{};
-  sa.t = t0; sa.T = e->chron_T; sa.rebalance_on = o->rebalance > 0.0 ? 1 : 0; sa.rebalance = o->rebalance; sa.cascade = o->cascade;
-  sa.is_dc = o->is_dc ? 1 : 0; sa.n_steps = n_steps; sa.auto_reset = o->auto_reset ? 1 : 0; sa.warm_start = o->warm_start ? 1 : 0;
-  sa.nb_ts_allowed = o->nb_ts_allowed; sa.max_rounds = o->max_rounds; sa.hard_overflow = o->hard_overflow; sa.soft_overflow = o->soft_overflow;
-  const double tol_pu = o->tol_mva / e->g.sn_mva;
-  hipEvent_t ea = nullptr, eb = nullptr;
-  rc = upload_params_s(e, b, p.tc ? &p : (pb.tc ? &pb : nullptr), p.dcf);
-  if (rc != GPF_OK) return rc;
-  if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
-  HIP_TRY(gpf_launch_step_sparse(p, e->device, e->d_params_s, e->stream, e->n_lanes, o->max_iter, tol_pu, sa));
-  if (pb.sparse_nb) HIP_TRY(gpf_launch_step_sparse(pb, e->device, e->d_params_s, e->stream, e->n_lanes, o->max_iter, tol_pu, sa));
-  HIP_TRY(hipGetLastError());
-  if (e->profiling) HIP_TRY(hipEventRecord(eb, e->stream));
-  if (e->window) ++e->win_launches;
   e->traj_valid = e->traj_cap ? n_steps : 0;
   return GPF_OK;
+}
+
+int gpf_upload_forecasts(gpf_handle e, int32_t n_tables, int32_t T, int32_t n_horizons, const float* data) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_upload_forecasts: null");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->forecast.release(); e->fc_h = 0;
+  if (!data) return GPF_OK;
+  if (n_horizons <= 0 || n_tables != e->chron_tables || T != e->chron_T)
+    return fail(GPF_E_INVALID, "gpf_upload_forecasts: shape must match the uploaded chronics tables (n_tables, T), n_horizons >= 1");
+  HIP_TRY(e->forecast.upload(data, (size_t)n_tables * T * n_horizons * e->g.n_chron));
+  e->fc_h = n_horizons;
+  return GPF_OK;
+}
+
+int gpf_simulate_batch(gpf_handle e, int32_t t_obs, int32_t time_step, int32_t n_src, const int32_t* src_lanes, int32_t n_act,
+                       const int32_t* act_off, const int32_t* act_items, const int32_t* last_bus, int32_t dst_lane0,
+                       const gpf_step_opts* o) {
+  if (!e || !o || !src_lanes || !act_off || n_src <= 0 || n_act <= 0) return fail(GPF_E_INVALID, "gpf_simulate_batch: bad arguments");
+  if (!e->chron.p || e->chron_T <= 0) return fail(GPF_E_INVALID, "gpf_simulate_batch: no chronics uploaded");
+  if (time_step < 0 || (time_step > 0 && (!e->forecast.p || time_step > e->fc_h)))
+    return fail(GPF_E_INVALID, "gpf_simulate_batch: no forecast for that horizon (gpf_upload_forecasts; NoForecastAvailable in the reference)");
+  const gpf::GridDev& g = e->g;
+  const long long n_dst = (long long)n_src * n_act;
+  if (n_dst > e->n_lanes || !check_range(e, dst_lane0, (int)n_dst)) return fail(GPF_E_INVALID, "gpf_simulate_batch: destination range out of bounds");
+  for (int b = 0; b < n_src; ++b)
+    if (src_lanes[b] < 0 || src_lanes[b] >= e->n_lanes || (src_lanes[b] >= dst_lane0 && src_lanes[b] < dst_lane0 + n_dst))
+      return fail(GPF_E_INVALID, "gpf_simulate_batch: source lane out of range or inside the destination range");
+  const int n_items_total = act_off[n_act];
+  if (act_off[0] != 0 || (n_items_total > 0 && !act_items)) return fail(GPF_E_INVALID, "gpf_simulate_batch: bad action offsets");
+  for (int k = 0; k < n_act; ++k) if (act_off[k + 1] < act_off[k]) return fail(GPF_E_INVALID, "gpf_simulate_batch: bad action offsets");
+  for (int q = 0; q < n_items_total; ++q) {
+    const int kind = act_items[3 * q], id = act_items[3 * q + 1], v = act_items[3 * q + 2];
+    const bool pos_kind = kind == GPF_ACT_SET_BUS || kind == GPF_ACT_CHANGE_BUS, line_kind = kind == GPF_ACT_SET_LINE_STATUS || kind == GPF_ACT_CHANGE_LINE_STATUS;
+    if (!(pos_kind || line_kind || kind == GPF_ACT_SET_SHUNT_BUS) || id < 0 || (pos_kind && id >= g.dim_topo) || (line_kind && id >= g.n_line) ||
+        (kind == GPF_ACT_SET_SHUNT_BUS && id >= g.n_shunt) || ((kind == GPF_ACT_SET_BUS || kind == GPF_ACT_SET_SHUNT_BUS) && (v < -1 || v > g.n_busbar)) ||
+        (kind == GPF_ACT_CHANGE_BUS && g.n_busbar != 2))
+      return fail(GPF_E_INVALID, "gpf_simulate_batch: bad action item (kind, id or bus; change_bus needs exactly 2 busbars per substation)");
+  }
+  HIP_TRY(hipSetDevice(e->device));
+  // 1. the source lanes' topology / shunt rows as they are on the device NOW (trips and maintenance included) -> host
+  const int w = g.dim_topo + g.n_shunt;
+  if (e->sim_src.n < (size_t)n_src) { e->sim_src.release(); HIP_TRY(e->sim_src.alloc((size_t)n_src)); }
+  if (e->sim_rows.n < (size_t)n_src * w) { e->sim_rows.release(); HIP_TRY(e->sim_rows.alloc((size_t)n_src * w)); }
+  HIP_TRY(hipMemcpyAsync(e->sim_src.p, src_lanes, (size_t)n_src * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(gpf::gather_topo_kernel, dim3(n_src), dim3(64), 0, e->stream, e->g, e->bufs(), e->sim_src.p, n_src, e->sim_rows.p);
+  HIP_TRY(hipGetLastError());
+  std::vector<int> rows((size_t)n_src * w);
+  HIP_TRY(hipMemcpyAsync(rows.data(), e->sim_rows.p, rows.size() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  // 2. candidate topologies on the host (the launch planner needs them anyway: busbars per substation, topology classes)
+  std::vector<int> topo((size_t)n_dst * g.dim_topo), sb((size_t)n_dst * std::max(g.n_shunt, 1));
+  for (int b = 0; b < n_src; ++b)
+    for (int k = 0; k < n_act; ++k) {
+      int* row = topo.data() + ((size_t)b * n_act + k) * g.dim_topo;
+      int* srow = sb.data() + ((size_t)b * n_act + k) * std::max(g.n_shunt, 1);
+      std::memcpy(row, rows.data() + (size_t)b * w, (size_t)g.dim_topo * sizeof(int));
+      if (g.n_shunt) std::memcpy(srow, rows.data() + (size_t)b * w + g.dim_topo, (size_t)g.n_shunt * sizeof(int));
+      apply_topo_action(e, row, g.n_shunt ? srow : nullptr, last_bus ? last_bus + (size_t)b * g.dim_topo : nullptr,
+                        act_items + 3 * (size_t)act_off[k], act_off[k + 1] - act_off[k]);
+    }
+  int rc = gpf_set_topology(e, dst_lane0, (int)n_dst, topo.data(), g.n_shunt ? sb.data() : nullptr);
+  if (rc != GPF_OK) return rc;
+  // 3. everything else of the source lanes + the chronics / forecast row to step on, on the device
+  const bool fc = time_step > 0;
+  const int T_eff = fc ? e->chron_T * e->fc_h : e->chron_T;
+  if (e->has_scale && !e->lane_scale.p) return fail(GPF_E_INVALID, "gpf_simulate_batch: internal (lane_scale)");
+  hipLaunchKernelGGL(gpf::simulate_prepare_kernel, dim3((unsigned)n_dst), dim3(64), 0, e->stream, e->g, e->bufs(), e->sim_src.p, n_act, (int)n_dst,
+                     dst_lane0, t_obs, e->chron_T, fc ? e->fc_h : 1, time_step, e->lane_table.p, e->lane_offset.p,
+                     e->has_scale ? e->lane_scale.p : nullptr, e->has_delta ? e->lane_gen_delta.p : nullptr);
+  HIP_TRY(hipGetLastError());
+  // 4. ONE step of the destination range on the forecast tables (no trajectory rows: these are scratch lanes)
+  gpf::Bufs b = e->bufs();
+  if (fc) b.chron = e->forecast.p;
+  b.maint = nullptr;
+  b.traj_rho = nullptr; b.traj_status = nullptr; b.traj_out = nullptr; b.traj_topo = nullptr; b.traj_shb = nullptr; b.traj_lstat = nullptr; b.traj_cap = 0;
+  gpf_step_opts oo = *o;
+  oo.auto_reset = 0; oo.warm_start = 0;
+  return step_range(e, b, dst_lane0, (int)n_dst, 0, T_eff, 1, &oo, "gpf_simulate_batch");
 }
 
 int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double rebalance, int32_t cascade, float hard_overflow,
@@ -1416,6 +1574,16 @@ int gpf_get_episode(gpf_handle e, int32_t lane0, int32_t n, uint8_t* done, int32
   if (done) HIP_TRY(hipMemcpyAsync(done, e->done.p + lane0, (size_t)n, hipMemcpyDeviceToHost, e->stream));
   if (steps_and_resets)
     HIP_TRY(hipMemcpyAsync(steps_and_resets, e->episode.p + (size_t)lane0 * 2, (size_t)n * 2 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_set_overflow_count(gpf_handle e, int32_t lane0, int32_t n, const int32_t* overflow_count) {
+  if (!check_range(e, lane0, n) || !overflow_count) return fail(GPF_E_INVALID, "gpf_set_overflow_count: bad arguments");
+  for (size_t i = 0; i < (size_t)n * e->g.n_line; ++i) if (overflow_count[i] < 0) return fail(GPF_E_INVALID, "gpf_set_overflow_count: negative counter");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(e->overflow_count.p + (size_t)lane0 * e->g.n_line, overflow_count, (size_t)n * e->g.n_line * sizeof(int),
+                         hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return GPF_OK;
 }

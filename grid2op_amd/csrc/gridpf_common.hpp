@@ -89,6 +89,7 @@ struct Bufs {
 
 struct StepArgs {
   int t, T, rebalance_on, cascade, nb_ts_allowed, max_rounds, is_dc;
+  int lane0;         // first lane of a contiguous launch (gpf_simulate_batch steps a sub-range; 0 for gpf_step_n)
   int n_steps;       // env steps per launch (t, t+1, ...): lane state and topology-derived tables stay in LDS in between
   int warm_start;    // opt-in: Newton starts from the previous step's voltages while the topology stands (see SolveCtl::warm)
   int auto_reset;    // a lane whose step failed restarts from the topology last sent by the host, counters cleared

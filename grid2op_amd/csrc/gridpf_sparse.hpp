@@ -1551,7 +1551,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   const Bufs& b = P->b;
   const OutOff& oo = P->oo;
   const int grp0 = threadIdx.x / GW, tid0 = threadIdx.x % GW;
-  const int inst0 = lane_list ? gptr(lane_list)[blockIdx.x * IPW + grp0] : blockIdx.x * IPW + grp0;   // ghost-padded by the host
+  const int inst0 = lane_list ? gptr(lane_list)[blockIdx.x * IPW + grp0] : sa.lane0 + blockIdx.x * IPW + grp0;   // ghost-padded by the host
   int grp = grp0, tid = tid0, inst = inst0;
   const bool ghost = inst >= (int)b.n_real_lanes;               // padding lane of an instance group: computes, never mutates state
   CarveP<NB> c;

@@ -266,6 +266,68 @@ class PowerFlowEngine:
         self.runpf(dst_lane0, n, is_dc=is_dc, max_iter=max_iter, tol_mva=tol_mva)
         return n
 
+    ACT_SET_BUS, ACT_SET_LINE_STATUS, ACT_CHANGE_BUS, ACT_CHANGE_LINE_STATUS, ACT_SET_SHUNT_BUS = 0, 1, 2, 3, 4
+
+    def upload_forecasts(self, tables):
+        """The ``*_forecasted`` tables of the uploaded chronics (`grid2op_amd.chronics` loads them with ``forecasts=True``;
+        `pack_chronics` packs them like the chronics): ``[n_tables, T, n_chron]`` (one horizon, the reference's default) or
+        ``[n_tables, T, n_horizons, n_chron]``; None removes them.  Row ``r`` holds the forecast made at chronics row ``r``
+        (Chronics/gridStateFromFileWithForecasts.py:311-353)."""
+        if tables is None:
+            check(self._lib.gpf_upload_forecasts(self._h, 0, 0, 0, None), "gpf_upload_forecasts")
+            return
+        t = np.ascontiguousarray(tables, dtype=np.float32)
+        if t.ndim == 2:
+            t = t[None]
+        if t.ndim == 3:
+            t = t[:, :, None, :]
+        assert t.ndim == 4 and t.shape[3] == self.n_chron, t.shape
+        check(self._lib.gpf_upload_forecasts(self._h, t.shape[0], t.shape[1], t.shape[2], ptr(t, C.c_float)), "gpf_upload_forecasts")
+
+    def pack_actions(self, actions):
+        """Candidate actions (dicts as `candidate_topologies` takes them, plus ``"change_line_status": [line ids]`` and
+        ``"shunts_bus": [(shunt id, bus)]``) -> (offsets ``[n + 1]``, items ``[n_items, 3]``) of `gpf_simulate_batch`."""
+        m = self.model
+        pos_of = {"lines_or_bus": m.line_or_pos_topo_vect, "lines_ex_bus": m.line_ex_pos_topo_vect, "loads_bus": m.load_pos_topo_vect,
+                  "gens_bus": m.gen_pos_topo_vect, "storages_bus": m.storage_pos_topo_vect}
+        off, items = [0], []
+        for act in actions:
+            for line, st in act.get("set_line_status", ()):
+                items.append((self.ACT_SET_LINE_STATUS, int(line), int(st)))
+            for line in act.get("change_line_status", ()):
+                items.append((self.ACT_CHANGE_LINE_STATUS, int(line), 0))
+            for key, pos in pos_of.items():
+                for el, bus in act.get(key, ()):
+                    items.append((self.ACT_SET_BUS, int(pos[el]), int(bus)))
+            for p_, bus in dict(act.get("set_bus", {})).items():
+                items.append((self.ACT_SET_BUS, int(p_), int(bus)))
+            for p_ in act.get("change_bus", ()):
+                items.append((self.ACT_CHANGE_BUS, int(p_), 0))
+            for sh, bus in act.get("shunts_bus", ()):
+                items.append((self.ACT_SET_SHUNT_BUS, int(sh), int(bus)))
+            off.append(len(items))
+        return np.asarray(off, dtype=np.int32), np.asarray(items, dtype=np.int32).reshape(-1, 3)
+
+    def simulate_batch(self, t_obs: int, src_lanes, actions, dst_lane0: int, time_step: int = 1, last_bus=None, max_iter: int = 10,
+                       tol_mva: float = 1e-8, rebalance: float = 0.0, cascade: bool = False, hard_overflow: float = 2.0,
+                       soft_overflow: float = 1.0, nb_ts_allowed: int = 2, max_rounds: int = 16, is_dc: bool = False) -> int:
+        """Batched ``obs.simulate(action, time_step)`` (Observation/baseObservation.py:3365-3670): for every source lane ``b``
+        (an environment whose current observation is the step at time index ``t_obs``) and every candidate action ``k``, lane
+        ``dst_lane0 + b * len(actions) + k`` becomes a copy of lane ``b`` with the action applied as ``_BackendAction`` applies it
+        and is stepped ONCE on the injections forecast ``time_step`` steps ahead (0: the observation's own injections) -- all
+        ``len(src_lanes) * len(actions)`` candidates in one launch (asynchronous).  Read them with `results` / `step_outputs`
+        on the destination range.  ``last_bus``: ``[len(src_lanes), dim_topo]`` last known busbars (reconnections), default 1.
+        Returns the number of destination lanes."""
+        src = np.ascontiguousarray(src_lanes, dtype=np.int32).reshape(-1)
+        off, items = self.pack_actions(actions)
+        lb = None if last_bus is None else np.ascontiguousarray(last_bus, dtype=np.int32).reshape(src.size, self.model.dim_topo)
+        o = GpfStepOpts(int(max_iter), float(tol_mva), float(rebalance), int(bool(cascade)), float(hard_overflow), float(soft_overflow),
+                        int(nb_ts_allowed), int(max_rounds), int(bool(is_dc)), 0, 0)
+        check(self._lib.gpf_simulate_batch(self._h, int(t_obs), int(time_step), src.size, ptr(src, C.c_int32), len(actions),
+                                           ptr(off, C.c_int32), ptr(items if items.size else None, C.c_int32), ptr(lb, C.c_int32),
+                                           int(dst_lane0), C.byref(o)), "gpf_simulate_batch")
+        return src.size * len(actions)
+
     # ---- solve --------------------------------------------------------------------------------------
     def runpf(self, lane0: int = 0, n: Optional[int] = None, is_dc: bool = False, max_iter: int = 10,
               tol_mva: float = 1e-8):
@@ -486,6 +548,12 @@ class PowerFlowEngine:
                   "traj_line_status": tview(21, m.n_line, "|u1")})
         v["stream"] = torch.cuda.ExternalStream(stream.value, device=dev)
         return v
+
+    def set_overflow_count(self, counts, lane0: int = 0):
+        """The protection counters (consecutive steps above the thermal limit, ``obs.timestep_overflow``) of lanes
+        ``lane0 ...``: ``[n, n_line]`` ints."""
+        c = np.ascontiguousarray(counts, dtype=np.int32).reshape(-1, self.model.n_line)
+        check(self._lib.gpf_set_overflow_count(self._h, int(lane0), c.shape[0], ptr(c, C.c_int32)), "gpf_set_overflow_count")
 
     def step_outputs(self, lane0: int = 0, n: Optional[int] = None):
         lane0, n = self._range(lane0, n)

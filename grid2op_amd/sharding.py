@@ -267,6 +267,26 @@ class ShardedEngine:
             raise ValueError("ShardedEngine.simulate_candidates: the source lane and its candidate lanes must be on the same device")
         return es.simulate_candidates(ls, pd[0][1], actions=actions, topologies=topologies, **kw)
 
+    def set_overflow_count(self, counts, lane0: int = 0):
+        c = np.asarray(counts).reshape(-1, self.model.n_line)
+        for eng, l0, n, off in self._parts(lane0, c.shape[0]):
+            eng.set_overflow_count(c[off:off + n], lane0=l0)
+
+    def upload_forecasts(self, tables):
+        for eng in self.engines:
+            eng.upload_forecasts(tables)
+
+    def simulate_batch(self, t_obs: int, src_lanes, actions, dst_lane0: int, **kw):
+        """`PowerFlowEngine.simulate_batch`; the source lanes and their candidate lanes must live on ONE device."""
+        src = np.asarray(src_lanes, dtype=np.int64).reshape(-1)
+        owners = {id(self.owner(int(k))[0]) for k in src}
+        pd = self._parts(dst_lane0, src.size * len(actions))
+        if len(owners) != 1 or len(pd) != 1 or id(pd[0][0]) not in owners:
+            raise ValueError("ShardedEngine.simulate_batch: the source lanes and their candidate lanes must be on the same device")
+        eng = pd[0][0]
+        b0 = self.blocks[self.engines.index(eng)][0]
+        return eng.simulate_batch(t_obs, src - b0, actions, pd[0][1], **kw)
+
     def device_views(self):
         """One dict of zero-copy torch views per device (global lane order = concatenation over the list)."""
         return [eng.device_views() for eng in self.engines]

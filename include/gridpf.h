@@ -228,6 +228,35 @@ int gpf_set_gen_limits(gpf_handle h, const double* pmin, const double* pmax, con
                        const uint8_t* redispatchable, double eps_poly);
 int gpf_redispatch(gpf_handle h, int32_t lane0, int32_t n, const double* new_p, const double* prev_p, const double* actual,
                    const double* target, const uint8_t* modified, const double* rhs, int32_t apply, uint8_t* ok, float* actual_after);
+/* ---- batched obs.simulate (Observation/baseObservation.py:3365-3670 simulate -> Environment/_obsEnv.py: the forecast
+ * injections of `time_step` steps ahead + a candidate action on a copy of the observation's grid state, one env.step of that copy) --
+ * gpf_upload_forecasts: the *_forecasted tables of the uploaded chronics (Chronics/gridStateFromFileWithForecasts.py:311-353:
+ * forecast h_id of chronics row r is row n_horizons * r + h_id), [n_tables][T][n_horizons][n_chron] float, same row layout as
+ * the chronics; NULL removes them.
+ * gpf_simulate_batch: for each of the n_src source lanes (environments whose current observation is the step at time index t_obs)
+ * and each of the n_act candidate actions, lane dst_lane0 + b * n_act + k becomes a copy of source lane b (topology, shunts,
+ * storage / shunt set-points, redispatch delta, jitter, protection counters) with action k applied to the topology as
+ * _BackendAction.__iadd__ applies it (Action/_backendAction.py:836-919: line status first -- a reconnected end goes back to its
+ * last known busbar, `last_bus` [n_src][dim_topo] or NULL = busbar 1 --, then change_bus, then set_bus, then lines with one open
+ * end are opened / lines reconnected by a bus assignment get their other end back), and ONE launch steps all n_src * n_act lanes
+ * with the injections of the forecast `time_step` steps ahead (time_step = 0: the current chronics row, i.e. the observation's own
+ * injections) under `opts` (cascade, thermal limits, is_dc ... as gpf_step_n; one step).  Results: the getters on the
+ * destination range (gpf_get_results, gpf_get_step_outputs -> rho).  The destination lanes are scratch lanes: their chronics
+ * cursor and counters are overwritten.  Actions: act_off[n_act + 1] offsets into act_items[][3] = {kind, id, value}:
+ *   GPF_ACT_SET_BUS {topo_vect position, bus (-1 | 1..n_busbar)}   GPF_ACT_CHANGE_BUS {topo_vect position, -}
+ *   GPF_ACT_SET_LINE_STATUS {line id, +1 | -1}                      GPF_ACT_CHANGE_LINE_STATUS {line id, -}
+ *   GPF_ACT_SET_SHUNT_BUS {shunt id, bus}
+ * Asynchronous launch (the topology bookkeeping before it synchronises once). */
+#define GPF_ACT_SET_BUS 0
+#define GPF_ACT_SET_LINE_STATUS 1
+#define GPF_ACT_CHANGE_BUS 2
+#define GPF_ACT_CHANGE_LINE_STATUS 3
+#define GPF_ACT_SET_SHUNT_BUS 4
+int gpf_upload_forecasts(gpf_handle h, int32_t n_tables, int32_t T, int32_t n_horizons, const float* data);
+int gpf_simulate_batch(gpf_handle h, int32_t t_obs, int32_t time_step, int32_t n_src, const int32_t* src_lanes, int32_t n_act,
+                       const int32_t* act_off, const int32_t* act_items, const int32_t* last_bus, int32_t dst_lane0,
+                       const gpf_step_opts* opts);
+
 /* Trajectory buffers of multi-step launches (n_steps_cap = 0 or what = 0 releases them).
  *   GPF_TRAJ_RHO: rho [cap][n_lanes][n_line] and status [cap][n_lanes] of every step of the last gpf_step_n.
  *   GPF_TRAJ_OBS: in addition the complete backend observation of every step -- results row out [cap][n_lanes][n_out]
@@ -245,6 +274,10 @@ int gpf_get_trajectory_obs(gpf_handle h, int32_t step0, int32_t n_steps, int32_t
 /* Episode bookkeeping of the batched steps: done [n] (1: the lane's last step ended its episode), steps_and_resets [n][2]
  * {steps survived since the last (auto-)reset, number of auto-resets}. */
 int gpf_get_episode(gpf_handle h, int32_t lane0, int32_t n, uint8_t* done, int32_t* steps_and_resets);
+/* The environment's protection counters of lanes lane0..lane0+n-1 (BaseEnv._timestep_overflow, Environment/baseEnv.py:3346-3370:
+ * consecutive steps each line has spent above its thermal limit), [n][n_line]: what an environment restored from an observation
+ * hands over (Environment/_obsEnv.py init copies obs.timestep_overflow).  gpf_step / gpf_step_n maintain them on the device. */
+int gpf_set_overflow_count(gpf_handle h, int32_t lane0, int32_t n, const int32_t* overflow_count);
 /* rho = a_or / thermal_limit (backend.py:1145-1168) and overflow counters of the last gpf_step. */
 int gpf_get_step_outputs(gpf_handle h, int32_t lane0, int32_t n, float* rho, int32_t* overflow_count,
                          int32_t* disc_round);

@@ -1,0 +1,131 @@
+"""CPU restatement of the pieces of the reference ENVIRONMENT that the batched engine reproduces on the device.  TEST
+INFRASTRUCTURE (like everything under oracle/): only tests/ may import it.
+
+* `apply_topo_action`  -- `_BackendAction.__iadd__` restricted to topology (grid2op/Action/_backendAction.py:836-919;
+  ValueStore.change_status / set_status / set_val / change_val :140-234; `_aux_iadd_reconcile_disco_reco` :738-765).
+* `next_grid_state`    -- `Backend.next_grid_state` (grid2op/Backend/backend.py:1433-1521): overflow disconnections until the grid
+  is stable, on top of `pf_oracle.solve`.
+* `simulate`           -- what `obs.simulate(action, time_step)` asks of the backend (grid2op/Observation/baseObservation.py:3365-3670
+  -> Environment/_obsEnv.py init / simulate -> BaseEnv.step): forecast injections in float32 as PandaPowerBackend applies them
+  (pandaPowerBackend.py:925-969), the candidate topology, one protected power flow.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .pf_oracle import LaneState, solve
+
+
+def apply_topo_action(m, topo, act, last_bus=None, shunt_bus=None):
+    """`act`: dict with any of set_line_status [(line, +-1)], change_line_status [lines], set_bus {pos: bus}, lines_or_bus /
+    lines_ex_bus / loads_bus / gens_bus / storages_bus [(id, bus)], change_bus [positions], shunts_bus [(id, bus)].
+    Returns the new topology row (and mutates `shunt_bus` in place when given)."""
+    row = np.array(topo, dtype=np.int32).copy()
+    lor, lex = np.asarray(m.line_or_pos_topo_vect), np.asarray(m.line_ex_pos_topo_vect)
+
+    def old(pos):
+        return int(last_bus[pos]) if (last_bus is not None and last_bus[pos] >= 1) else 1
+
+    def reco(l):
+        for p_ in (lor[l], lex[l]):
+            if row[p_] < 0:
+                row[p_] = old(p_)
+
+    def disco(l):
+        row[lor[l]] = row[lex[l]] = -1
+    # III line status: change_status (:168-198) then set_status (:200-231)
+    for l in act.get("change_line_status", ()):
+        if row[lor[l]] > 0 or row[lex[l]] > 0:
+            disco(l)
+        else:
+            reco(l)
+    for l, v in act.get("set_line_status", ()):
+        if v < 0:
+            disco(l)
+        elif v > 0:
+            reco(l)
+    or_before, ex_before = row[lor].copy(), row[lex].copy()
+    # IV change_bus (:156-159) then set_bus (:151-154)
+    modif = False
+    for p_ in act.get("change_bus", ()):
+        if row[p_] > 0:
+            row[p_] = (1 - row[p_]) + 2
+        modif = True
+    pos_of = {"lines_or_bus": lor, "lines_ex_bus": lex, "loads_bus": m.load_pos_topo_vect, "gens_bus": m.gen_pos_topo_vect,
+              "storages_bus": m.storage_pos_topo_vect}
+    for key, pos in pos_of.items():
+        for el, bus in act.get(key, ()):
+            if bus != 0:
+                row[pos[el]] = bus
+                modif = True
+    for p_, bus in dict(act.get("set_bus", {})).items():
+        if bus != 0:
+            row[int(p_)] = bus
+            modif = True
+    # V reconcile (:738-765): a line with an open end is open; an open line that got a bus is reconnected
+    if modif:
+        for l in range(m.n_line):
+            o_, x_ = row[lor[l]], row[lex[l]]
+            d_now = or_before[l] == -1 or o_ == -1 or ex_before[l] == -1 or x_ == -1
+            r_now = or_before[l] == -1 and (o_ >= 1 or x_ >= 1)
+            if r_now:
+                reco(l)
+            elif d_now:
+                disco(l)
+    if shunt_bus is not None:
+        for sh, bus in act.get("shunts_bus", ()):
+            if bus != 0:
+                shunt_bus[sh] = bus
+    return row
+
+
+def next_grid_state(m, st: LaneState, thermal_limit, timestep_overflow, hard_overflow=2.0, soft_overflow=1.0, nb_ts_allowed=2,
+                    cascade=True, is_dc=False, max_rounds=64):
+    """backend.py:1476-1520.  Returns (result of the last power flow, LaneState with the tripped lines open, updated protection
+    counters as BaseEnv keeps them after the step: baseEnv.py:3346-3370)."""
+    st = LaneState(**{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in st.__dict__.items()})
+    lor, lex = np.asarray(m.line_or_pos_topo_vect), np.asarray(m.line_ex_pos_topo_vect)
+    ts = np.asarray(timestep_overflow, dtype=np.int64).copy()
+    counted = np.zeros(m.n_line, bool)
+    lim = np.asarray(thermal_limit, dtype=np.float32)
+    res = None
+    for _ in range(max_rounds + 1):
+        res = solve(m, st, is_dc=is_dc)
+        if not res.converged or not cascade:
+            break
+        a = res.a_or.astype(np.float32)
+        on = res.line_status.astype(bool)
+        over_soft = on & (a > np.float32(soft_overflow) * lim)
+        newly = over_soft & ~counted
+        counted |= newly
+        local = ts + counted.astype(np.int64)
+        to_disc = on & ((a > np.float32(hard_overflow) * lim) | (local > nb_ts_allowed))
+        if not to_disc.any():
+            break
+        st.topo[lor[to_disc]] = -1
+        st.topo[lex[to_disc]] = -1
+    if res.converged:
+        a = res.a_or.astype(np.float32)
+        ts = np.where(a > np.float32(soft_overflow) * lim, ts + 1, 0)
+    return res, st, ts
+
+
+def forecast_state(m, base: LaneState, row):
+    """chronics / forecast row [load_p | load_q | prod_p | prod_v(kV)] -> injections, float32 arithmetic as the reference"""
+    st = LaneState(**{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in base.__dict__.items()})
+    nl, ng = m.n_load, m.n_gen
+    row = np.asarray(row, dtype=np.float32)
+    st.load_p = row[:nl].astype(np.float64)
+    st.load_q = row[nl:2 * nl].astype(np.float64)
+    st.gen_p = row[2 * nl:2 * nl + ng].astype(np.float64)
+    st.gen_vm = (row[2 * nl + ng:2 * nl + 2 * ng] / m.sub_vn_kv[m.gen_sub].astype(np.float32)).astype(np.float64)
+    return st
+
+
+def simulate(m, base: LaneState, row, act, thermal_limit, timestep_overflow, last_bus=None, **kw):
+    st = forecast_state(m, base, row)
+    sb = st.shunt_bus.copy() if m.n_shunt else None
+    st.topo = apply_topo_action(m, st.topo, act, last_bus, sb)
+    if sb is not None:
+        st.shunt_bus = sb
+    return next_grid_state(m, st, thermal_limit, timestep_overflow, **kw)

@@ -1,0 +1,127 @@
+"""GPU tests of the batched obs.simulate (gpf_simulate_batch): B source lanes x K candidate actions x forecast horizon in ONE
+launch, against (1) simulations recorded inside the UNMODIFIED reference environment (tests/golden/simulate_case14.npz, made by
+tests/golden/make_simulate_fixtures.py: Observation/baseObservation.py:3365-3670 -> Environment/_obsEnv.py) and (2) the oracle's
+restatement of the same path (oracle/env_oracle.py, itself pinned to those recordings on CPU) on other grids / states."""
+import numpy as np
+import pytest
+
+from oracle.env_oracle import simulate
+from oracle.pf_oracle import LaneState
+
+from test_oracle_simulate import sim_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def test_recorded_reference_simulations_in_one_call_per_horizon(load_model, load_npz):
+    from grid2op_amd.engine import PowerFlowEngine
+    m = load_model("l2rpn_case14_sandbox")
+    fx = load_npz("simulate_case14.npz")
+    cands = sim_cases(fx)
+    S, K = fx["row"].shape[0], len(cands)
+    eng = PowerFlowEngine(m, n_lanes=S + S * K, device=0)
+    eng.upload_chronics(eng.pack_chronics(fx["ch_load_p"], fx["ch_load_q"], fx["ch_prod_p"], fx["ch_prod_v"]))
+    eng.upload_forecasts(eng.pack_chronics(fx["fc_load_p"], fx["fc_load_q"], fx["fc_prod_p"], fx["fc_prod_v"]))
+    eng.set_thermal_limits(fx["thermal_limit"])
+    # source lane s = the environment after recorded step s: topology, chronics cursor (row = t_obs + offset), protection counters
+    off = np.zeros(S + S * K, np.int32)
+    off[:S] = fx["row"]
+    eng.set_lane_chronics(lane_offset=off)
+    eng.set_topology(fx["topo_vect"].astype(np.int32), lane0=0)
+    eng.set_overflow_count(fx["timestep_overflow"], lane0=0)
+    kw = dict(cascade=True, hard_overflow=float(fx["hard_overflow"]), nb_ts_allowed=int(fx["nb_ts_allowed"]))
+    n_done = 0
+    for ts in (0, 1):
+        n = eng.simulate_batch(0, np.arange(S), cands, dst_lane0=S, time_step=ts, last_bus=fx["last_bus"], **kw)
+        assert n == S * K
+        r = eng.results(S, n)
+        rho, _, _ = eng.step_outputs(S, n)
+        for s in range(S):
+            for k in range(K):
+                q = s * K + k
+                done = bool(fx[f"sim{ts}_done"][s, k])
+                assert (not r.converged[q]) == done, (ts, s, k, r.status[q])
+                n_done += done
+                if done:
+                    continue
+                assert np.array_equal(r.topo_vect[q], fx[f"sim{ts}_topo_vect"][s, k]), (ts, s, k)
+                assert np.array_equal(r.line_status[q], fx[f"sim{ts}_line_status"][s, k]), (ts, s, k)
+                for f, tol in [("p_or", 3e-4), ("q_or", 4e-4), ("p_ex", 3e-4), ("v_or", 3e-4), ("a_or", 2e-3), ("gen_p", 3e-4), ("gen_q", 4e-4),
+                               ("load_p", 1e-5), ("load_v", 3e-4)]:
+                    assert np.abs(getattr(r, f)[q].astype(np.float64) - fx[f"sim{ts}_{f}"][s, k]).max() < tol, (ts, s, k, f)
+                assert np.abs(rho[q] - fx[f"sim{ts}_rho"][s, k]).max() < 3e-5, (ts, s, k)
+    assert n_done >= 20
+    # the source lanes were not touched
+    t_src, _ = eng.get_topology(0, S)
+    assert np.array_equal(t_src, fx["topo_vect"])
+    eng.close()
+
+
+@pytest.mark.parametrize("name,B", [("l2rpn_neurips_2020_track1", 5), ("l2rpn_wcci_2022_dev", 3), ("educ_case14_storage", 6)])
+def test_simulate_batch_vs_oracle_restatement(name, B, load_model, load_npz):
+    """Other grids (1 wavefront per lane, 2 wavefronts per lane, storage units), source lanes in different states (open lines, a
+    split substation, their own chronics rows), 9 candidates each incl. reconnections and bus changes; synthetic forecasts."""
+    from grid2op_amd.engine import PowerFlowEngine
+    m = load_model(name)
+    ch = dict(load_npz(f"{name}.chronics.npz"))
+    if "load_p" not in ch:               # no chronics fixture for this grid: 48 jittered copies of the stored state
+        rg = np.random.default_rng(99)
+        j = lambda v: (np.asarray(v, np.float64)[None, :] * (1 + 0.03 * rg.standard_normal((48, len(v))))).astype(np.float32)  # noqa: E731
+        ch.update(load_p=j(m.load_p0), load_q=j(m.load_q0), prod_p=j(m.gen_p0))
+    if "prod_v" not in ch:
+        ch["prod_v"] = np.tile((m.gen_vm0 * m.sub_vn_kv[m.gen_sub]).astype(np.float32), (ch["prod_p"].shape[0], 1))
+    rng = np.random.default_rng(len(name))
+    cands = [{}, {"set_line_status": [(1, -1)]}, {"set_line_status": [(2, +1)]}, {"change_line_status": [4]},
+             {"lines_or_bus": [(2, 2)]}, {"lines_ex_bus": [(5, -1)]}, {"loads_bus": [(0, 2)]},
+             {"change_bus": [int(m.line_or_pos_topo_vect[6]), int(m.gen_pos_topo_vect[1])]}, {"set_line_status": [(0, -1), (3, -1)]}]
+    K = len(cands)
+    eng = PowerFlowEngine(m, n_lanes=B + B * K, device=0)
+    tab = eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"])[:48]
+    fc = np.stack([tab * np.float32(1.01), tab * np.float32(0.98)], axis=1)            # 2 horizons [T, 2, n_chron]
+    eng.upload_chronics(tab)
+    eng.upload_forecasts(fc[None])
+    lim = ch.get("thermal_limits")
+    if lim is not None:
+        eng.set_thermal_limits(lim)
+    off = np.zeros(B + B * K, np.int32)
+    off[:B] = rng.integers(0, 40, B)
+    eng.set_lane_chronics(lane_offset=off)
+    topo = np.tile(m.initial_topo_vect(), (B, 1))
+    last = np.ones((B, m.dim_topo), np.int32)
+    for b in range(1, B):
+        l = int(rng.integers(0, m.n_line))
+        topo[b, m.line_or_pos_topo_vect[l]] = topo[b, m.line_ex_pos_topo_vect[l]] = -1
+        last[b, m.line_or_pos_topo_vect[l]] = 2
+    topo[1, m.line_or_pos_topo_vect[2]] = topo[1, m.line_ex_pos_topo_vect[2]] = -1       # candidate 2 reconnects it (origin end -> busbar 2)
+    last[1, m.line_or_pos_topo_vect[2]] = 2
+    eng.set_topology(topo, lane0=0)
+    ovc = rng.integers(0, 2, (B, m.n_line)).astype(np.int32)
+    eng.set_overflow_count(ovc, lane0=0)
+    t_obs = 3
+    for ts in (0, 2):
+        eng.simulate_batch(t_obs, np.arange(B), cands, dst_lane0=B, time_step=ts, last_bus=last, cascade=lim is not None)
+        r = eng.results(B, B * K)
+        for b in range(B):
+            idx = (t_obs + off[b]) % tab.shape[0]
+            row = tab[idx] if ts == 0 else fc[idx, ts - 1]
+            base = LaneState.from_model(m)
+            base.topo = topo[b].copy()
+            for k, act in enumerate(cands):
+                res, st, _ = simulate(m, base, row, act, lim if lim is not None else np.full(m.n_line, 1e30, np.float32), ovc[b],
+                                      last_bus=last[b], cascade=lim is not None)
+                q = b * K + k
+                assert bool(r.converged[q]) == bool(res.converged), (ts, b, k, r.status[q], res.reason)
+                if not res.converged:
+                    continue
+                assert np.array_equal(r.topo_vect[q], res.topo_vect) and np.array_equal(r.line_status[q], res.line_status.astype(bool)), (ts, b, k)
+                for f in ("p_or", "q_or", "a_or", "v_or", "gen_p", "gen_q", "load_v"):
+                    ref = getattr(res, f)
+                    assert np.all(np.abs(getattr(r, f)[q] - ref) <= 2e-4 + 5e-6 * np.abs(ref)), (ts, b, k, f)
+    from grid2op_amd.engine import GridPFError
+    with pytest.raises(GridPFError):
+        eng.simulate_batch(t_obs, np.arange(B), cands, dst_lane0=B, time_step=3)          # only 2 horizons uploaded
+    with pytest.raises(GridPFError):
+        eng.simulate_batch(t_obs, [B + 1], cands, dst_lane0=B)                            # source inside the destination range
+    with pytest.raises(GridPFError):
+        eng.simulate_batch(t_obs, np.arange(B), [{"set_bus": {0: 7}}], dst_lane0=B)       # bus id beyond n_busbar
+    eng.close()
