@@ -143,7 +143,16 @@ struct gpf_engine {
   DevArr<unsigned char> line_status, done;
   DevArr<int> topo0, episode;           // topology last sent by the host (auto-reset target); {steps survived, resets} per lane
   DevArr<float> lane_gen_delta, traj_rho;
-  DevArr<unsigned char> maint;          // [chron_tables][chron_T][n_line] scheduled maintenance, or empty
+  DevArr<unsigned char> maint;          // [chron_tables][chron_T][n_line] scheduled maintenance OR hazards (forced outages), or empty
+  std::vector<unsigned char> h_maint, h_hazard;   // host copies of the two tables (the device holds their union)
+  // injection dynamics of the environment (gpf::EnvDyn)
+  bool env_on = false, env_hold = false, env_act_r = false, env_act_s = false, sto_ready = false;
+  int env_loss_on = 1;
+  double env_coeff = 300.0 / 3600.0, env_tol = 1e-2;
+  DevArr<float> env_target, env_actual, env_prev, env_charge, env_amount_prev, env_act_redisp, env_act_storage, sto_charge0;
+  DevArr<unsigned char> env_already, env_fresh;
+  DevArr<double> sto_emax, sto_emin, sto_loss, sto_effc, sto_effd;
+  std::vector<float> h_charge0;
   DevArr<float> forecast;               // [chron_tables][chron_T][fc_h][n_chron] *_forecasted tables (gpf_upload_forecasts), or empty
   int fc_h = 0;
   DevArr<int> sim_src, sim_rows;        // gpf_simulate_batch staging: source lane list, gathered topology rows
@@ -442,6 +451,7 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
       if (need(tier) <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / need(tier) >= want) stage = tier;
     if (e->stage_force >= 0 && e->stage_force <= top_tier && need(e->stage_force) <= LDS_HARD_LIMIT) stage = e->stage_force;
     if (ipw > 1 && stage != 2) { ipw = 1; stage = 0; for (int tier = top_tier; tier >= 1 && !stage; --tier) if (need(tier) <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / need(tier) >= want) stage = tier; }
+    if (e->env_on && ipw == 1) stage = 0;                       // the ENV step kernels exist for tier 0 (and tier 2 with instance groups)
     const size_t l = need(stage);
     if (l > LDS_HARD_LIMIT) return false;
     if (nbk == 1 && !e->sym_dev.flat[0]) return false;           // no flat program: graph beyond the 16-bit slot fields
@@ -461,7 +471,7 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
     q.yreg = false;
     // Ybus blocks in registers (2 wavefronts per instance, tables in global memory, at most 4 pairs per lane): when the LDS they
     // free holds the factored DC matrix without costing a block per CU, every step of a launch skips the DC assembly + factorisation
-    if (nbk == 1 && !listed && ipw == 1 && q.wpi == 2 && stage == 0 && !e->no_yreg && e->dcf_env != 0 && (e->sym.nslot_y - e->g.n_sub) / 2 <= 4 * 128 && e->g.n_sub <= 128) {
+    if (nbk == 1 && !listed && ipw == 1 && q.wpi == 2 && stage == 0 && !e->no_yreg && !e->env_on && e->dcf_env != 0 && (e->sym.nslot_y - e->g.n_sub) / 2 <= 4 * 128 && e->g.n_sub <= 128) {
       const size_t ly = gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, 0, 0, false, 1, -1, true);
       if (ly <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / ly >= std::min<size_t>(LDS_HARD_LIMIT / l, want)) { q.yreg = true; q.dcf = 1; q.lds = ly; }
     }
@@ -562,6 +572,15 @@ int upload_params_s(gpf_engine* e, const gpf::Bufs& b, const LaunchPlan* tc, int
   hp.classes = e->d_classes.p;
   hp.tc_rows = tc ? tc->tc_rows : 0; hp.tc_nslot = tc ? tc->tc_nslot : 0; hp.tc_nslot_y = tc ? tc->tc_nslot_y : 0;
   hp.dcf = dcf;
+  if (e->env_on) {
+    gpf::EnvDyn& E = hp.env;
+    E.on = 1; E.hold_storage = e->env_hold ? 1 : 0; E.loss_on = e->env_loss_on; E.coeff = e->env_coeff; E.eps_poly = e->rd_eps; E.tol_poly = e->env_tol;
+    E.target = e->env_target.p; E.actual = e->env_actual.p; E.prev_p = e->env_prev.p; E.already = e->env_already.p; E.charge = e->env_charge.p;
+    E.amount_prev = e->env_amount_prev.p; E.fresh = e->env_fresh.p;
+    E.act_redisp = e->env_act_r ? e->env_act_redisp.p : nullptr; E.act_storage = e->env_act_s ? e->env_act_storage.p : nullptr;
+    E.pmin = e->rd_pmin.p; E.pmax = e->rd_pmax.p; E.ramp_up = e->rd_ru.p; E.ramp_down = e->rd_rd.p; E.redispatchable = e->rd_redisp.p;
+    E.Emax = e->sto_emax.p; E.Emin = e->sto_emin.p; E.loss = e->sto_loss.p; E.eff_c = e->sto_effc.p; E.eff_d = e->sto_effd.p; E.charge0 = e->sto_charge0.p;
+  }
   if (!e->d_params_s) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->d_params_s), sizeof(gpf::DevParamsS)));
   if (!e->params_s_valid || std::memcmp(&hp, &e->h_params_s, sizeof(hp)) != 0) {
     e->h_params_s = hp;
@@ -597,6 +616,24 @@ int drain_events(gpf_engine* e) {
   return GPF_OK;
 }
 
+// env dynamics of lanes [lane0, lane0 + n) back to the state after env.reset(): no dispatch, initial state of charge
+int reset_env_state(gpf_engine* e, int lane0, int n) {
+  const size_t ng = e->g.n_gen, ns = e->g.n_sto;
+  HIP_TRY(hipMemsetAsync(e->env_target.p + lane0 * ng, 0, n * ng * sizeof(float), e->stream));
+  HIP_TRY(hipMemsetAsync(e->env_actual.p + lane0 * ng, 0, n * ng * sizeof(float), e->stream));
+  HIP_TRY(hipMemsetAsync(e->env_prev.p + lane0 * ng, 0, n * ng * sizeof(float), e->stream));
+  HIP_TRY(hipMemsetAsync(e->env_already.p + lane0 * ng, 0, n * ng, e->stream));
+  HIP_TRY(hipMemsetAsync(e->env_amount_prev.p + lane0, 0, (size_t)n * sizeof(float), e->stream));
+  HIP_TRY(hipMemsetAsync(e->env_fresh.p + lane0, 1, (size_t)n, e->stream));
+  if (ns) {
+    std::vector<float> c((size_t)n * ns);
+    for (int k = 0; k < n; ++k) std::copy(e->h_charge0.begin(), e->h_charge0.end(), c.begin() + (size_t)k * ns);
+    HIP_TRY(hipMemcpyAsync(e->env_charge.p + lane0 * ns, c.data(), c.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
+  return GPF_OK;
+}
+
 int reset_lanes_unchecked(gpf_engine* e, int lane0, int n) {
   HIP_TRY(hipSetDevice(e->device));
   const gpf::GridDev& g = e->g;
@@ -617,6 +654,7 @@ int reset_lanes_unchecked(gpf_engine* e, int lane0, int n) {
   HIP_TRY(hipMemsetAsync(e->done.p + lane0, 0, (size_t)n, e->stream));
   HIP_TRY(hipMemsetAsync(e->episode.p + (size_t)lane0 * 2, 0, (size_t)n * 2 * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->status.p + (size_t)lane0 * 4, 0xFF, (size_t)n * 4 * sizeof(int), e->stream));
+  if (e->env_on) { int rc_e = reset_env_state(e, lane0, n); if (rc_e != GPF_OK) return rc_e; }
   HIP_TRY(hipStreamSynchronize(e->stream));
   const int init_class = topo_class_of(e, e->h_init_topo.data(), g.n_shunt ? e->h_init_shunt_bus.data() : nullptr);
   for (int k = lane0; k < lane0 + n; ++k) {
@@ -927,6 +965,9 @@ int gpf_destroy(gpf_handle e) {
   e->d_init_inj.release(); e->d_init_topo.release(); e->d_init_shunt_bus.release();
   if (e->pin) (void)hipHostFree(e->pin);
   e->maint.release(); e->forecast.release(); e->sim_src.release(); e->sim_rows.release();
+  e->env_target.release(); e->env_actual.release(); e->env_prev.release(); e->env_charge.release(); e->env_amount_prev.release();
+  e->env_act_redisp.release(); e->env_act_storage.release(); e->sto_charge0.release(); e->env_already.release(); e->env_fresh.release();
+  e->sto_emax.release(); e->sto_emin.release(); e->sto_loss.release(); e->sto_effc.release(); e->sto_effd.release();
   e->rd_pmin.release(); e->rd_pmax.release(); e->rd_ru.release(); e->rd_rd.release(); e->rd_in.release(); e->rd_redisp.release();
   e->rd_u8.release(); e->rd_after.release();
   e->topo0.release(); e->done.release(); e->episode.release(); e->lane_gen_delta.release(); e->traj_rho.release(); e->traj_status.release();
@@ -1216,6 +1257,7 @@ int gpf_upload_chronics(gpf_handle e, int32_t n_tables, int32_t T, const float* 
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->chron.release();
   e->maint.release();                       // belongs to the previous tables
+  e->h_maint.clear(); e->h_hazard.clear();
   e->forecast.release(); e->fc_h = 0;
   HIP_TRY(e->chron.upload(data, (size_t)n_tables * T * e->g.n_chron));
   e->chron_T = T;
@@ -1232,16 +1274,38 @@ int gpf_upload_chronics(gpf_handle e, int32_t n_tables, int32_t T, const float* 
   return GPF_OK;
 }
 
-int gpf_upload_maintenance(gpf_handle e, int32_t n_tables, int32_t T, const uint8_t* data) {
-  if (!e) return fail(GPF_E_INVALID, "gpf_upload_maintenance: null");
+}  // extern "C"
+namespace {
+// maintenance.csv and hazards.csv both force a line out of service while flagged (the environment's "maintenance" / "hazards"
+// modifications, Environment/baseEnv.py:2516-2563): the device holds the union of the two tables
+int upload_outage_tables(gpf_engine* e) {
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->maint.release();
-  if (!data) return GPF_OK;
-  if (n_tables != e->chron_tables || T != e->chron_T)
-    return fail(GPF_E_INVALID, "gpf_upload_maintenance: shape must match the uploaded chronics tables (n_tables, T)");
-  HIP_TRY(e->maint.upload(data, (size_t)n_tables * T * e->g.n_line));
+  if (e->h_maint.empty() && e->h_hazard.empty()) return GPF_OK;
+  std::vector<unsigned char> u = e->h_maint.empty() ? e->h_hazard : e->h_maint;
+  if (!e->h_maint.empty() && !e->h_hazard.empty()) for (size_t i = 0; i < u.size(); ++i) u[i] = (u[i] || e->h_hazard[i]) ? 1 : 0;
+  HIP_TRY(e->maint.upload(u.data(), u.size()));
   return GPF_OK;
+}
+int set_outage_table(gpf_engine* e, std::vector<unsigned char>& dst, int n_tables, int T, const uint8_t* data, const char* who) {
+  if (!data) { dst.clear(); return upload_outage_tables(e); }
+  if (n_tables != e->chron_tables || T != e->chron_T)
+    return fail(GPF_E_INVALID, std::string(who) + ": shape must match the uploaded chronics tables (n_tables, T)");
+  dst.assign(data, data + (size_t)n_tables * T * e->g.n_line);
+  return upload_outage_tables(e);
+}
+}  // namespace
+extern "C" {
+
+int gpf_upload_maintenance(gpf_handle e, int32_t n_tables, int32_t T, const uint8_t* data) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_upload_maintenance: null");
+  return set_outage_table(e, e->h_maint, n_tables, T, data, "gpf_upload_maintenance");
+}
+
+int gpf_upload_hazards(gpf_handle e, int32_t n_tables, int32_t T, const uint8_t* data) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_upload_hazards: null");
+  return set_outage_table(e, e->h_hazard, n_tables, T, data, "gpf_upload_hazards");
 }
 
 int gpf_set_lane_chronics(gpf_handle e, const int32_t* lane_table, const int32_t* lane_offset, const float* lane_scale) {
@@ -1296,6 +1360,7 @@ int step_range(gpf_engine* e, const gpf::Bufs& b, int lane0, int n, int t0, int 
   rc = upload_params_s(e, b, p.tc ? &p : (pb.tc ? &pb : nullptr), p.dcf);
   if (rc != GPF_OK) return rc;
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
+  p.env = pb.env = e->env_on && b.chron == e->chron.p;         // (gpf_simulate_batch steps scratch lanes on the forecast tables: no dynamics)
   HIP_TRY(gpf_launch_step_sparse(p, e->device, e->d_params_s, e->stream, n, o->max_iter, tol_pu, sa));
   if (pb.sparse_nb) HIP_TRY(gpf_launch_step_sparse(pb, e->device, e->d_params_s, e->stream, n, o->max_iter, tol_pu, sa));
   HIP_TRY(hipGetLastError());
@@ -1346,9 +1411,107 @@ int gpf_step_n(gpf_handle e, int32_t t0, int32_t n_steps, const gpf_step_opts* o
   if (e->traj_cap && n_steps > e->traj_cap)
     return fail(GPF_E_INVALID, "gpf_step_n: n_steps exceeds the trajectory buffer (gpf_set_trajectory sizes it; 0 releases it)");
   HIP_TRY(hipSetDevice(e->device));
+  if (e->env_on) {
+    LaunchPlan p, pb;
+    int rc_p = plan_launch(e, 0, e->n_lanes, p, pb);
+    if (rc_p != GPF_OK) return rc_p;
+    const int lanes = p.wpi > 1 ? 64 : 64 / std::max(p.ipw, 1);
+    if (e->g.n_gen > lanes || e->g.n_sto > lanes || pb.sparse_nb || p.sparse_nb != 1)
+      return fail(GPF_E_CAPACITY, "gpf_step_n: the environment dynamics need n_gen and n_storage <= the lanes of an instance (16 / 32 / 64) "
+                                  "and a batch that runs as one launch");
+  }
   int rc = step_range(e, e->bufs(), 0, e->n_lanes, t0, e->chron_T, n_steps, o, "gpf_step_n");
   if (rc != GPF_OK) return rc;
   e->traj_valid = e->traj_cap ? n_steps : 0;
+  if (e->env_on) {                          // the actions were consumed by this launch (a held storage action stays)
+    if (e->env_act_r) { HIP_TRY(hipMemsetAsync(e->env_act_redisp.p, 0, e->env_act_redisp.n * sizeof(float), e->stream)); e->env_act_r = false; }
+    if (e->env_act_s && !e->env_hold) { HIP_TRY(hipMemsetAsync(e->env_act_storage.p, 0, e->env_act_storage.n * sizeof(float), e->stream)); e->env_act_s = false; }
+  }
+  return GPF_OK;
+}
+
+int gpf_set_storage_params(gpf_handle e, const double* emax, const double* emin, const double* loss, const double* eff_charge,
+                           const double* eff_discharge, const float* charge0, double delta_time_seconds, int32_t activate_loss) {
+  if (!e || delta_time_seconds <= 0.0) return fail(GPF_E_INVALID, "gpf_set_storage_params: bad arguments");
+  const size_t ns = e->g.n_sto;
+  if (ns && (!emax || !emin || !loss || !eff_charge || !eff_discharge || !charge0)) return fail(GPF_E_INVALID, "gpf_set_storage_params: null");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->sto_emax.release(); e->sto_emin.release(); e->sto_loss.release(); e->sto_effc.release(); e->sto_effd.release(); e->sto_charge0.release();
+  HIP_TRY(e->sto_emax.upload(emax, ns)); HIP_TRY(e->sto_emin.upload(emin, ns)); HIP_TRY(e->sto_loss.upload(loss, ns));
+  HIP_TRY(e->sto_effc.upload(eff_charge, ns)); HIP_TRY(e->sto_effd.upload(eff_discharge, ns)); HIP_TRY(e->sto_charge0.upload(charge0, ns));
+  e->h_charge0.assign(charge0, charge0 + ns);
+  e->env_coeff = delta_time_seconds / 3600.0;
+  e->env_loss_on = activate_loss ? 1 : 0;
+  e->sto_ready = true;
+  e->params_s_valid = false;
+  return GPF_OK;
+}
+
+int gpf_set_env_dynamics(gpf_handle e, int32_t on, double tol_poly) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_set_env_dynamics: null");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->plan_valid = false;
+  if (!on) { e->env_on = false; e->params_s_valid = false; return GPF_OK; }
+  if (!e->rd_ready) return fail(GPF_E_INVALID, "gpf_set_env_dynamics: call gpf_set_gen_limits first");
+  if (e->g.n_sto && !e->sto_ready) return fail(GPF_E_INVALID, "gpf_set_env_dynamics: call gpf_set_storage_params first (the grid has storage units)");
+  if (e->g.n_gen > 64 || e->g.n_sto > 64) return fail(GPF_E_CAPACITY, "gpf_set_env_dynamics: more than 64 generators or storage units");
+  const size_t B = e->cap_lanes, ng = e->g.n_gen, ns = std::max(e->g.n_sto, 1);
+  if (!e->env_target.p) {
+    HIP_TRY(e->env_target.alloc(B * ng)); HIP_TRY(e->env_actual.alloc(B * ng)); HIP_TRY(e->env_prev.alloc(B * ng)); HIP_TRY(e->env_already.alloc(B * ng));
+    HIP_TRY(e->env_charge.alloc(B * ns)); HIP_TRY(e->env_amount_prev.alloc(B)); HIP_TRY(e->env_fresh.alloc(B));
+    HIP_TRY(e->env_act_redisp.alloc(B * ng)); HIP_TRY(e->env_act_storage.alloc(B * ns));
+    HIP_TRY(hipMemset(e->env_act_redisp.p, 0, B * ng * sizeof(float))); HIP_TRY(hipMemset(e->env_act_storage.p, 0, B * ns * sizeof(float)));
+    HIP_TRY(hipMemset(e->env_charge.p, 0, B * ns * sizeof(float)));
+  }
+  e->env_on = true;
+  e->env_tol = tol_poly > 0.0 ? tol_poly : 1e-2;
+  e->env_act_r = e->env_act_s = false; e->env_hold = false;
+  e->params_s_valid = false;
+  return reset_env_state(e, 0, e->cap_lanes);
+}
+
+int gpf_set_lane_actions(gpf_handle e, const float* redispatch, const float* storage_power, int32_t hold_storage) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_set_lane_actions: null");
+  if (!e->env_on) return fail(GPF_E_INVALID, "gpf_set_lane_actions: the environment dynamics are off (gpf_set_env_dynamics)");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t B = e->n_lanes, ng = e->g.n_gen, ns = e->g.n_sto;
+  if (redispatch) { HIP_TRY(hipMemcpyAsync(e->env_act_redisp.p, redispatch, B * ng * sizeof(float), hipMemcpyHostToDevice, e->stream)); e->env_act_r = true; }
+  else if (e->env_act_r) { HIP_TRY(hipMemsetAsync(e->env_act_redisp.p, 0, e->env_act_redisp.n * sizeof(float), e->stream)); e->env_act_r = false; }
+  if (storage_power && ns) { HIP_TRY(hipMemcpyAsync(e->env_act_storage.p, storage_power, B * ns * sizeof(float), hipMemcpyHostToDevice, e->stream)); e->env_act_s = true; }
+  else if (e->env_act_s) { HIP_TRY(hipMemsetAsync(e->env_act_storage.p, 0, e->env_act_storage.n * sizeof(float), e->stream)); e->env_act_s = false; }
+  e->env_hold = hold_storage != 0;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_get_env_state(gpf_handle e, int32_t lane0, int32_t n, float* target, float* actual, float* prev_p, uint8_t* already_modified,
+                      float* charge, float* amount_prev) {
+  if (!check_range(e, lane0, n)) return fail(GPF_E_INVALID, "gpf_get_env_state: bad range");
+  if (!e->env_on) return fail(GPF_E_INVALID, "gpf_get_env_state: the environment dynamics are off");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t ng = e->g.n_gen, ns = e->g.n_sto;
+#define DLE(dst, arr, stride) if ((dst) && (stride) > 0) HIP_TRY(hipMemcpyAsync(dst, e->arr.p + (size_t)lane0 * (stride), (size_t)n * (stride) * sizeof(*e->arr.p), hipMemcpyDeviceToHost, e->stream))
+  DLE(target, env_target, ng); DLE(actual, env_actual, ng); DLE(prev_p, env_prev, ng); DLE(already_modified, env_already, ng);
+  DLE(charge, env_charge, ns); DLE(amount_prev, env_amount_prev, 1);
+#undef DLE
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_set_env_state(gpf_handle e, int32_t lane0, int32_t n, const float* target, const float* actual, const float* prev_p,
+                      const uint8_t* already_modified, const float* charge, const float* amount_prev) {
+  if (!check_range(e, lane0, n)) return fail(GPF_E_INVALID, "gpf_set_env_state: bad range");
+  if (!e->env_on) return fail(GPF_E_INVALID, "gpf_set_env_state: the environment dynamics are off");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t ng = e->g.n_gen, ns = e->g.n_sto;
+#define ULE(src, arr, stride) if ((src) && (stride) > 0) HIP_TRY(hipMemcpyAsync(e->arr.p + (size_t)lane0 * (stride), src, (size_t)n * (stride) * sizeof(*e->arr.p), hipMemcpyHostToDevice, e->stream))
+  ULE(target, env_target, ng); ULE(actual, env_actual, ng); ULE(prev_p, env_prev, ng); ULE(already_modified, env_already, ng);
+  ULE(charge, env_charge, ns); ULE(amount_prev, env_amount_prev, 1);
+#undef ULE
+  if (prev_p) HIP_TRY(hipMemsetAsync(e->env_fresh.p + lane0, 0, (size_t)n, e->stream));     // previous set-points given: not a fresh episode
+  HIP_TRY(hipStreamSynchronize(e->stream));
   return GPF_OK;
 }
 

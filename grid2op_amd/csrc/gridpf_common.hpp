@@ -87,6 +87,32 @@ struct Bufs {
   long long n_real_lanes;      // lanes >= this index are padding (ghost lanes of instance groups / lane lists)
 };
 
+// Injection dynamics of the environment (opt-in, gpf_set_env_dynamics): what BaseEnv.step does to the generator / storage
+// set-points between the chronics and the backend -- storage state of charge (baseEnv.py:2829-2905, 2777-2790), accumulation of
+// the agents' redispatch (:2101-2115), the _make_redisp gate (:2188-2209) and the ramp-limited projection
+// (_compute_dispatch_vect :2211-2470, the exact separable-QP solution of gridpf_redispatch.hpp) -- evaluated by the step kernel at
+// every step of a launch.  State arrays are float32 like the reference's (dt_float).
+struct EnvDyn {
+  int on;                        // 0: off (every pointer below may be null)
+  int hold_storage;              // the storage action is applied at every step of the launch (else at its first step only)
+  int loss_on;                   // Parameters.ACTIVATE_STORAGE_LOSS
+  double coeff;                  // delta_time_seconds / 3600
+  double eps_poly, tol_poly;     // BaseEnv._epsilon_poly / _tol_poly
+  // per-lane state [B][n_gen] / [B][n_storage] / [B]
+  float *target, *actual, *prev_p;      // _target_dispatch, _actual_dispatch, _gen_activeprod_t_redisp
+  unsigned char* already;               // _already_modified_gen
+  float* charge;                        // _storage_current_charge (MWh)
+  float* amount_prev;                   // _amount_storage_prev
+  unsigned char* fresh;                 // [B] 1: no step since the reset (nb_time_step == 0: prev_p := the step's own set-points)
+  // per-lane actions of the NEXT launch [B][n_gen] / [B][n_storage]: redispatch is consumed by the first step
+  const float *act_redisp, *act_storage;
+  // characteristics [n_gen] / [n_storage]
+  const double *pmin, *pmax, *ramp_up, *ramp_down;
+  const unsigned char* redispatchable;
+  const double *Emax, *Emin, *loss, *eff_c, *eff_d;
+  const float* charge0;                 // [n_storage] state of charge after a reset
+};
+
 struct StepArgs {
   int t, T, rebalance_on, cascade, nb_ts_allowed, max_rounds, is_dc;
   int lane0;         // first lane of a contiguous launch (gpf_simulate_batch steps a sub-range; 0 for gpf_step_n)

@@ -17,6 +17,7 @@ struct LaunchPlan {
   const int* list;  // device pointer (padded with a ghost lane to a multiple of ipw)
   int wpi;          // kernel S: wavefronts per instance (1, 2 or 4; > 1 only for NB == 1, IPW == 1 on large grids)
   int ipw;          // kernel S: grid instances per wavefront (1, 2 or 4; > 1 only for NB == 1 on small grids)
+  bool env;          // step launches: the ENV instantiation (environment injection dynamics on): tables in global memory unless instance groups
   bool yreg;         // Ybus blocks in registers (gridpf_sparse.hpp: YR): NB == 1, 2 wavefronts per instance, tables in global memory
   int dcf;           // the LDS layout of this launch has room for the factored DC matrix (DevParamsS::dcf)
   int sparse_stage;  // 0: static tables read in place (L2), 1: program + pair table + injection row in LDS, 2: everything in LDS // program staged in LDS (small grids) or streamed from L2 (keeps 3 instances per CU on 118-bus grids)

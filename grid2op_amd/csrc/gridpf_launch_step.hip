@@ -4,12 +4,12 @@
 
 namespace {
 
-template <int NB, int ST, int IPW, int WP, bool TC, bool YR = false>
+template <int NB, int ST, int IPW, int WP, bool TC, bool YR = false, bool ENV = false>
 hipError_t launch(const LaunchPlan& p, int device, const gpf::DevParamsS* d_params, hipStream_t stream, int n_l, const int* list,
                   int max_iter, double tol_pu, const gpf::StepArgs& sa) {
   static size_t lds_set[64] = {0};
   static const size_t pad = getenv("GRIDPF_LDS_PAD") ? (size_t)atoi(getenv("GRIDPF_LDS_PAD")) : 0;   // occupancy experiments only
-  auto kern = &gpf::step_sparse_kernel<NB, ST, IPW, 2, WP, TC, YR>;
+  auto kern = &gpf::step_sparse_kernel<NB, ST, IPW, 2, WP, TC, YR, ENV>;
   const size_t lds = p.lds + pad;
   if (lds > lds_set[device & 63]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -30,6 +30,20 @@ hipError_t gpf_launch_step_sparse(const LaunchPlan& p, int device, const gpf::De
   const int* list = p.n_list ? p.list : nullptr;
 #define LAUNCH_ARGS p, device, d_params, stream, n_l, list, max_iter, tol_pu, sa
 #define GO(NB, ST, IPW, WP, TC) return launch<NB, ST, IPW, WP, TC>(LAUNCH_ARGS)
+#define GOE(ST, IPW, WP, TC) return launch<1, ST, IPW, WP, TC, false, true>(LAUNCH_ARGS)
+  if (p.env) {          // environment injection dynamics: single-busbar kernels, tables in LDS only with instance groups (plan_launch)
+    if (p.sparse_nb != 1) return hipErrorInvalidValue;
+    if (p.tc) {
+      if (p.ipw == 4) GOE(0, 4, 1, true);
+      if (p.ipw == 2) GOE(0, 2, 1, true);
+      if (p.wpi == 2) GOE(0, 1, 2, true);
+      GOE(0, 1, 1, true);
+    }
+    if (p.ipw == 4) GOE(2, 4, 1, false);
+    if (p.ipw == 2) GOE(2, 2, 1, false);
+    if (p.wpi == 2) GOE(0, 1, 2, false);
+    GOE(0, 1, 1, false);
+  }
   if (p.tc) {
     if (p.ipw == 4) GO(1, 0, 4, 1, true);
     if (p.ipw == 2) GO(1, 0, 2, 1, true);
@@ -59,6 +73,7 @@ hipError_t gpf_launch_step_sparse(const LaunchPlan& p, int device, const gpf::De
     GO(3, 0, 1, 1, false);
   }
 #undef GO
+#undef GOE
 #undef LAUNCH_ARGS
   return hipErrorInvalidValue;
 }

@@ -124,6 +124,7 @@ struct DevParamsS {
   int tc_rows;                   // LDS sizing of a topology-class launch: max number of nodes ...
   int tc_nslot, tc_nslot_y;      // ... blocks incl. fill / original-pattern blocks over the classes of the launch
   int dcf;                       // the LDS layout has room for the factored DC matrix (CarveP::Adc): the step kernel keeps it across steps
+  EnvDyn env;                    // injection dynamics of the environment (EnvDyn::on == 0: off)
 };
 
 // -DGPF_TIMING developer build: cycle-counter stamps are kept in REGISTERS (a global store per stamp would be waited for
@@ -1535,12 +1536,168 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   }
 }
 
+// ---- environment injection dynamics (EnvDyn) ----------------------------------------------------------------------------------
+// One lane of an aligned group of LW lanes (a power of two <= 64, inside one wavefront) per generator / storage unit; reductions
+// over the group by xor-butterflies (lanes of other groups of the wavefront run their own instance).
+template <int LW>
+__device__ __forceinline__ double env_gsum(double v) {
+#pragma unroll
+  for (int off = LW / 2; off; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+template <int LW>
+__device__ __forceinline__ double env_gmin(double v) {
+#pragma unroll
+  for (int off = LW / 2; off; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+  return v;
+}
+template <int LW>
+__device__ __forceinline__ double env_gmax(double v) {
+#pragma unroll
+  for (int off = LW / 2; off; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+  return v;
+}
+// per-lane registers of the dynamics (lane k = generator k and storage unit k of the instance)
+struct EnvRegs {
+  float target, actual, prev_p, charge, amount_prev;
+  bool already, fresh;
+};
+// One env step of the dynamics for the caller's instance.  new_p: chronics set-point of generator `k` (after the environment's own
+// modifications); act_r / act_s: the agent's redispatch / storage action of this step for generator / unit k (0 = none).
+// Returns the storage power of unit k (MW, load convention) in `sto_power`, false when the reference would end the episode
+// (ImpossibleRedispatching, baseEnv.py:3227-3247).  Follows oracle/env_oracle.py InjectionDynamics.step line by line.
+template <int LW>
+__device__ inline bool env_dynamics_step(const EnvDyn& E, int k, int n_gen, int n_sto, float new_p_f, float act_r, float act_s,
+                                         EnvRegs& R, float& sto_power) {
+  const bool is_gen = k < n_gen, is_sto = k < n_sto;
+  // ---- _compute_storage (:2829-2905) + _withdraw_storage_losses (:2777-2790)
+  double amount = 0.0;
+  sto_power = 0.f;
+  if (n_sto > 0) {
+    float pw = 0.f;
+    bool any_act = false;
+    if (is_sto && fabsf(act_s) >= 1e-7f) {
+      any_act = true;
+      double eff = 1.0;
+      if (E.loss_on) eff = act_s > 0.f ? E.eff_c[k] : 1.0 / E.eff_d[k];
+      R.charge += (float)((double)act_s * E.coeff * eff);
+      pw = act_s;
+      const double emax = E.Emax[k], emin = E.Emin[k];
+      if ((double)R.charge > emax) {
+        double t_ = (1.0 / E.coeff) * ((double)R.charge - emax);
+        if (E.loss_on) t_ /= E.eff_c[k];
+        pw -= (float)t_;
+        R.charge = (float)emax;
+      }
+      if ((double)R.charge < emin) {
+        double t_ = (1.0 / E.coeff) * ((double)R.charge - emin);
+        if (E.loss_on) t_ *= E.eff_d[k];
+        pw -= (float)t_;
+        R.charge = (float)emin;
+      }
+      R.charge = fmaxf(R.charge, (float)emin);
+    }
+    const bool some = env_gmax<LW>(any_act ? 1.0 : 0.0) > 0.0;
+    amount = some ? (double)(float)env_gsum<LW>((double)pw) : 0.0;       // (the reference sums a float32 array)
+    const double tmp = amount;
+    amount -= (double)R.amount_prev;
+    R.amount_prev = (float)tmp;
+    if (E.loss_on && is_sto) R.charge = fmaxf(R.charge - (float)(E.loss[k] * E.coeff), 0.f);
+    sto_power = pw;
+  }
+  // ---- _get_already_modified_gen (:2101-2115)
+  if (is_gen && fabsf(act_r) > 1e-7f) {
+    R.target = R.already ? R.target + act_r : R.actual + act_r;
+    R.already = true;
+  }
+  // ---- _make_redisp gate (:2198-2209)
+  const double tol = E.tol_poly;
+  const double s_act = env_gsum<LW>(is_gen ? (double)R.actual : 0.0);
+  const double m_mis = env_gmax<LW>(is_gen ? fabs((double)R.actual - (double)R.target) : 0.0);
+  bool ok = true;
+  if (fabs((double)(float)s_act) >= tol || m_mis >= tol || fabs(amount) >= tol) {
+    // ---- _compute_dispatch_vect (:2211-2470): the separable QP of gridpf_redispatch.hpp, one generator per lane
+    const double np_ = (double)new_p_f, a = (double)R.actual, t = (double)R.target;
+    const double pv = R.fresh ? np_ : (double)R.prev_p;
+    bool part = false, mod = false;
+    double lo = 0.0, hi = 0.0, w = 0.0, tv = 0.0, x = 0.0;
+    double s_incr = 0.0, s_up = 0.0, s_down = 0.0, s_coef = 0.0;
+    const double added = 0.5 * E.eps_poly;
+    if (is_gen) {
+      const double pmin = E.pmin[k], pmax = E.pmax[k], ru = E.ramp_up[k], rd = E.ramp_down[k];
+      part = ((np_ > 0.0) || (fabs(a) >= 1e-7) || (t != a)) && E.redispatchable[k];
+      const double incr = np_ - (pv - a);
+      if (part) {
+        s_incr = incr; s_down = fmax(pmin - pv, -rd); s_up = fmin(pmax - pv, ru);
+        const double pth = np_ + a;
+        lo = fmax(pmin - pth, -rd - incr) - added;
+        hi = fmin(pmax - pth, ru - incr) + added;
+        w = 1.0 / (ru + rd + E.eps_poly);
+        s_coef = w;
+        tv = t - a;
+        mod = R.already;
+      }
+    }
+    s_incr = env_gsum<LW>(s_incr); s_up = env_gsum<LW>(s_up); s_down = env_gsum<LW>(s_down); s_coef = env_gsum<LW>(s_coef);
+    const int n_mod = (int)env_gsum<LW>(part && mod ? 1.0 : 0.0);
+    const double rhs = amount;
+    const double sum_move = s_incr + rhs;
+    if (sum_move > s_up || sum_move < s_down) ok = false;
+    if (part) { w /= s_coef; if (n_mod == 0) mod = true; }
+    const double s_lo = env_gsum<LW>(part ? lo : 0.0), s_hi = env_gsum<LW>(part ? hi : 0.0);
+    if (rhs < s_lo || rhs > s_hi) ok = false;
+    if (ok) {
+      const bool pm = part && mod, pf = part && !mod;
+      const double f_lo = env_gsum<LW>(pf ? lo : 0.0), f_hi = env_gsum<LW>(pf ? hi : 0.0);
+      const double lam_lo = env_gmin<LW>(pm ? 2.0 * w * (tv - hi) : 1e300), lam_hi = env_gmax<LW>(pm ? 2.0 * w * (tv - lo) : -1e300);
+      auto sum_mod = [&](double lam) -> double { return env_gsum<LW>(pm ? fmin(fmax(tv - lam / (2.0 * w), lo), hi) : 0.0); };
+      const double s0 = sum_mod(0.0);
+      double lam = 0.0;
+      int free_at = 0;
+      if (rhs - s0 > f_hi) { free_at = 1; double a_ = lam_lo, b_ = 0.0;
+        for (int it = 0; it < 64; ++it) { const double mid = 0.5 * (a_ + b_); if (sum_mod(mid) + f_hi > rhs) a_ = mid; else b_ = mid; }
+        lam = 0.5 * (a_ + b_);
+      } else if (rhs - s0 < f_lo) { free_at = -1; double a_ = 0.0, b_ = lam_hi;
+        for (int it = 0; it < 64; ++it) { const double mid = 0.5 * (a_ + b_); if (sum_mod(mid) + f_lo > rhs) a_ = mid; else b_ = mid; }
+        lam = 0.5 * (a_ + b_);
+      }
+      if (pm) x = fmin(fmax(tv - lam / (2.0 * w), lo), hi);
+      const double got = env_gsum<LW>(pm ? x : 0.0);
+      if (free_at != 0) {
+        if (pf) x = free_at > 0 ? hi : lo;
+        const double rest = rhs - got - (free_at > 0 ? f_hi : f_lo);
+        const bool inside = pm && x > lo && x < hi;
+        const int n_in = (int)env_gsum<LW>(inside ? 1.0 : 0.0);
+        if (n_in > 0 && inside) x += rest / n_in;
+      } else {
+        const double r = rhs - got;
+        double a_ = env_gmin<LW>(pf ? fmin(lo * w, hi * w) : 1e300), b_ = env_gmax<LW>(pf ? fmax(lo * w, hi * w) : -1e300);
+        if (a_ <= b_) {
+          for (int it = 0; it < 64; ++it) {
+            const double mid = 0.5 * (a_ + b_);
+            const double sm = env_gsum<LW>(pf ? fmin(fmax(mid / w, lo), hi) : 0.0);
+            if (sm < r) a_ = mid; else b_ = mid;
+          }
+          const double alpha = 0.5 * (a_ + b_);
+          if (pf) x = fmin(fmax(alpha / w, lo), hi);
+        }
+      }
+      if (part) R.actual = (float)(a + x);
+    }
+  }
+  if (ok && is_gen) { R.prev_p = new_p_f + R.actual; }
+  if (ok) R.fresh = false;
+  return ok;
+}
+
 // Batched environment steps: n_steps consecutive DoNothing env.step of every lane in ONE launch.  Per step: chronics row
 // (+ jitter, rebalancing, redispatch delta) -> injections -> power flow -> results row -> overflow counters / cascade (K7) ->
 // rho, status, episode bookkeeping, all written to HBM.  What does NOT change from one step to the next stays in LDS / registers:
 // the static tables, the lane's chronics cursor and -- as long as no line tripped and no lane failed -- everything that only
 // depends on the topology (element -> bus maps, bus types, connectivity verdict, Ybus blocks, the factored DC matrix).
-template <int NB, int STAGE, int IPW, int MINW, int WPI, bool TC = false, bool YR = false>
+// ENV: the kernel also evaluates the environment's injection dynamics (EnvDyn) at every step -- a separate instantiation, so that
+// the plain DoNothing kernels do not carry its registers and code (measured: -2.5 % on the 14-substation headline otherwise).
+template <int NB, int STAGE, int IPW, int MINW, int WPI, bool TC = false, bool YR = false, bool ENV = false>
 __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const DevParamsS* __restrict__ P, const int* __restrict__ lane_list,
                                                            const int* __restrict__ lane_class, int max_iter, double tol_pu,
                                                            StepArgs sa) {
@@ -1584,6 +1741,27 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   if (tid < g.n_line) { lim_first = gptr(b.thermal_limit)[tid]; ovc_first = gptr(b.overflow_count)[(size_t)inst * g.n_line + tid]; }
   int ep_steps = 0, ep_resets = 0;
   if (tid == 0 && !ghost) { ep_steps = gptr(b.episode)[2 * (size_t)inst]; ep_resets = gptr(b.episode)[2 * (size_t)inst + 1]; }
+  // environment injection dynamics (opt-in): lane k of the instance's first LWE lanes carries generator k and storage unit k
+  constexpr int LWE = GW < WAVE ? GW : WAVE;
+  constexpr bool env_on = ENV && NB == 1;                       // single-busbar kernels (incl. topology classes) only
+  EnvRegs er;
+  er.target = er.actual = er.prev_p = er.charge = er.amount_prev = 0.f; er.already = false; er.fresh = true;
+  float env_ar0 = 0.f, env_as0 = 0.f;
+  if (env_on && tid < LWE) {
+    const EnvDyn& E = P->env;
+    if (tid < g.n_gen) {
+      const size_t q = (size_t)inst * g.n_gen + tid;
+      er.target = gptr(E.target)[q]; er.actual = gptr(E.actual)[q]; er.prev_p = gptr(E.prev_p)[q]; er.already = gptr(E.already)[q] != 0;
+      if (E.act_redisp) env_ar0 = gptr(E.act_redisp)[q];
+    }
+    if (tid < g.n_sto) {
+      er.charge = gptr(E.charge)[(size_t)inst * g.n_sto + tid];
+      if (E.act_storage) env_as0 = gptr(E.act_storage)[(size_t)inst * g.n_sto + tid];
+    }
+    er.amount_prev = gptr(E.amount_prev)[inst];
+    er.fresh = gptr(E.fresh)[inst] != 0;
+  }
+  bool env_fail = false;                                       // this group's dynamics ended the episode in the current step
   // Every step (and every cascade round) runs the same code on the same addresses, so the compiler would hoist each per-thread
   // pointer, offset and table entry it finds out of the loops (loop-invariant code motion) and keep them live for the whole
   // launch: > 250 VGPRs plus scratch spills.  GPF_REDERIVE makes the thread's coordinates opaque and re-derives the LDS carve
@@ -1668,10 +1846,24 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
         scale_p = (sum_prod > 0.0) ? (float)(sa.rebalance * sum_load / sum_prod) : 1.0f;
       }
       GPF_STAMPS(18);
+      env_fail = false;
+      if (env_on && (WPI == 1 || tid < WAVE)) {                  // (wavefront-uniform: the whole wavefront takes part in the reductions)
+        float np_k = tid < g.n_gen ? pp_pre : 0.f;
+        if (tid < g.n_gen && !sv.gen_slack[tid]) np_k *= scale_p;
+        float sto_pw = 0.f;
+        const bool ok_e = env_dynamics_step<LWE>(P->env, tid, g.n_gen, g.n_sto, np_k, step == 0 ? env_ar0 : 0.f,
+                                                 (step == 0 || P->env.hold_storage) ? env_as0 : 0.f, er, sto_pw);
+        env_fail = !ok_e;
+        if (tid < g.n_sto) {                                      // the storage power the backend gets (set_storage, baseEnv.py:3831)
+          if (STAGE) c.inj[oo.inj_sto_p + tid] = (double)sto_pw;
+          else inj_g[oo.inj_sto_p + tid] = (double)sto_pw;
+        }
+      }
       if (lane9)
       for (int i = tid; i < g.n_gen; i += gw9) {
         float pp = (i == tid) ? pp_pre : ch[2 * g.n_load + i];
         if (!sv.gen_slack[i]) pp *= scale_p;
+        if (env_on) pp += er.actual;                              // set_redispatch (:3830): chronics + actual dispatch, float32 (n_gen <= lanes: i == tid)
         if (has_delta) pp += (i == tid) ? gd0 : gdelta[i];
         const float pv_kv = (i == tid) ? pv_pre : ch[2 * g.n_load + g.n_gen + i];
         const float vn = (float)sv.gen_vn[i];
@@ -1766,6 +1958,10 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
     }
     GPF_STAMPS(9);
     GPF_REDERIVE();
+    if (env_on) {                                              // ImpossibleRedispatching ends the episode (baseEnv.py:3227-3247)
+      const bool ef = WPI > 1 ? (__syncthreads_or(env_fail) != 0) : env_fail;
+      if (ef && st == 0) st = 6;
+    }
     orow = otraj ? step * (int)b.lane_stride + inst : inst;
     // ---- per-step outputs -----------------------------------------------------------------------------------------------------
     if (st != 0) { write_nan_results<GW>(g, b, inst, tid, orow, otraj); a_first = __builtin_nanf(""); }
@@ -1811,6 +2007,10 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       for (int i = tid; i < g.dim_topo; i += GW) topo[i] = t0[i];
       for (int l = tid; l < g.n_line; l += GW) ovc[l] = 0;
       ovc_first = 0;
+      if (env_on) {                                              // env.reset(): dispatch cleared, storage back to its initial charge
+        er.target = er.actual = er.prev_p = er.amount_prev = 0.f; er.already = false; er.fresh = true;
+        er.charge = (tid < g.n_sto && P->env.charge0) ? gptr(P->env.charge0)[tid] : 0.f;
+      }
     }
     // the topology-derived state stands for the next step only if NO group of the block changed or lost its topology
     reuse = !G::block_any_u(failed || tripped);
@@ -1833,7 +2033,17 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   if (tid == 0 && !ghost) { gptr(b.episode)[2 * (size_t)inst] = ep_steps; gptr(b.episode)[2 * (size_t)inst + 1] = ep_resets; }
   if (STAGE && !ghost) {                                      // the last step's injection row -> HBM (gpf_get_injections, next launches)
     const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj;
-    for (int i = tid; i < oo.inj_sto_p; i += GW) inj_g[i] = c.inj[i];
+    const int n_wb = env_on ? oo.inj_sto_q : oo.inj_sto_p;    // (the dynamics also move the storage power)
+    for (int i = tid; i < n_wb; i += GW) inj_g[i] = c.inj[i];
+  }
+  if (env_on && tid < LWE && !ghost) {
+    const EnvDyn& E = P->env;
+    if (tid < g.n_gen) {
+      const size_t q = (size_t)inst * g.n_gen + tid;
+      gptr(E.target)[q] = er.target; gptr(E.actual)[q] = er.actual; gptr(E.prev_p)[q] = er.prev_p; gptr(E.already)[q] = er.already ? 1 : 0;
+    }
+    if (tid < g.n_sto) gptr(E.charge)[(size_t)inst * g.n_sto + tid] = er.charge;
+    if (tid == 0) { gptr(E.amount_prev)[inst] = er.amount_prev; gptr(E.fresh)[inst] = er.fresh ? 1 : 0; }
   }
   GPF_STAMPS(15);
   GPF_STAMPS_FLUSH(inst);

@@ -30,6 +30,7 @@ STATUS_TEXT = {
     3: "no in-service slack generator",
     4: "singular matrix",
     5: "engine capacity exceeded",
+    6: "infeasible redispatching (ImpossibleRedispatching: game over)",
     -1: "power flow not run",
 }
 
@@ -397,6 +398,18 @@ class PowerFlowEngine:
         assert mt.shape[2] == self.model.n_line
         check(self._lib.gpf_upload_maintenance(self._h, mt.shape[0], mt.shape[1], ptr(mt, C.c_uint8)), "gpf_upload_maintenance")
 
+    def upload_hazards(self, hazards):
+        """Hazards of the uploaded tables (``hazards.csv``: unplanned outages): ``[n_tables, T, n_line]`` (or ``[T, n_line]``) 0/1; None
+        removes them.  Independent of the maintenance table; a line is out of service where either flags it."""
+        if hazards is None:
+            check(self._lib.gpf_upload_hazards(self._h, 0, 0, None), "gpf_upload_hazards")
+            return
+        hz = np.ascontiguousarray(hazards, dtype=np.uint8)
+        if hz.ndim == 2:
+            hz = hz[None]
+        assert hz.shape[2] == self.model.n_line
+        check(self._lib.gpf_upload_hazards(self._h, hz.shape[0], hz.shape[1], ptr(hz, C.c_uint8)), "gpf_upload_hazards")
+
     def set_lane_chronics(self, lane_table=None, lane_offset=None, lane_scale=None):
         lt = None if lane_table is None else np.ascontiguousarray(lane_table, dtype=np.int32)
         lo = None if lane_offset is None else np.ascontiguousarray(lane_offset, dtype=np.int32)
@@ -462,6 +475,56 @@ class PowerFlowEngine:
         return ok.astype(bool), after
 
     TRAJ_RHO, TRAJ_OBS = 1, 2
+
+    # ---- injection dynamics of the environment (storage state of charge, redispatch projection) inside the stepped batch ------
+    def set_storage_params(self, emax, emin, loss, eff_charge, eff_discharge, charge0, delta_time_seconds: float = 300.0,
+                           activate_loss: bool = True):
+        """Storage characteristics (``storage_Emax / Emin / loss / charging_efficiency / discharging_efficiency``, initial charge
+        in MWh), the step length and ``Parameters.ACTIVATE_STORAGE_LOSS``."""
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64).reshape(self.model.n_storage)  # noqa: E731
+        a = [f64(emax), f64(emin), f64(loss), f64(eff_charge), f64(eff_discharge)]
+        c0 = np.ascontiguousarray(charge0, dtype=np.float32).reshape(self.model.n_storage)
+        check(self._lib.gpf_set_storage_params(self._h, *[ptr(x, C.c_double) for x in a], ptr(c0, C.c_float), float(delta_time_seconds),
+                                               int(bool(activate_loss))), "gpf_set_storage_params")
+
+    def set_env_dynamics(self, on: bool = True, tol_poly: float = 1e-2):
+        """Switch the environment's injection dynamics on: every step of `step` then evolves the storage state of charge and
+        re-solves the ramp-limited redispatch (BaseEnv.step's path between the chronics and the backend); needs `set_gen_limits`
+        (and `set_storage_params` on a grid with storage units).  Resets the dynamics of every lane."""
+        check(self._lib.gpf_set_env_dynamics(self._h, int(bool(on)), float(tol_poly)), "gpf_set_env_dynamics")
+
+    def set_lane_actions(self, redispatch=None, storage_power=None, hold_storage: bool = False):
+        """The agents' actions of the NEXT launch: redispatch ``[n_lanes, n_gen]`` MW (consumed by its first step), storage power
+        ``[n_lanes, n_storage]`` MW (first step only, or every step until replaced with ``hold_storage``)."""
+        r = None if redispatch is None else np.ascontiguousarray(redispatch, dtype=np.float32).reshape(self.n_lanes, self.model.n_gen)
+        s_ = None if storage_power is None or not self.model.n_storage else \
+            np.ascontiguousarray(storage_power, dtype=np.float32).reshape(self.n_lanes, self.model.n_storage)
+        check(self._lib.gpf_set_lane_actions(self._h, ptr(r, C.c_float), ptr(s_, C.c_float), int(bool(hold_storage))), "gpf_set_lane_actions")
+
+    def env_state(self, lane0: int = 0, n: Optional[int] = None) -> dict:
+        """``target`` / ``actual`` dispatch, ``prev_p``, ``already_modified`` ``[n, n_gen]``, ``charge`` ``[n, n_storage]``,
+        ``amount_prev`` ``[n]`` of the lanes' environment dynamics."""
+        lane0, n = self._range(lane0, n)
+        ng, ns = self.model.n_gen, self.model.n_storage
+        d = dict(target=np.empty((n, ng), np.float32), actual=np.empty((n, ng), np.float32), prev_p=np.empty((n, ng), np.float32),
+                 already_modified=np.empty((n, ng), np.uint8), charge=np.empty((n, ns), np.float32), amount_prev=np.empty(n, np.float32))
+        check(self._lib.gpf_get_env_state(self._h, lane0, n, ptr(d["target"], C.c_float), ptr(d["actual"], C.c_float),
+                                          ptr(d["prev_p"], C.c_float), ptr(d["already_modified"], C.c_uint8),
+                                          ptr(d["charge"] if ns else None, C.c_float), ptr(d["amount_prev"], C.c_float)), "gpf_get_env_state")
+        d["already_modified"] = d["already_modified"].astype(bool)
+        return d
+
+    def set_env_state(self, lane0: int = 0, target=None, actual=None, prev_p=None, already_modified=None, charge=None, amount_prev=None):
+        """Overwrite (parts of) the lanes' environment dynamics, e.g. to restore them from an observation."""
+        f = lambda a, w: None if a is None else np.ascontiguousarray(a, dtype=np.float32).reshape(-1, w)  # noqa: E731
+        ng, ns = self.model.n_gen, max(self.model.n_storage, 1)
+        arrs = [f(target, ng), f(actual, ng), f(prev_p, ng)]
+        am = None if already_modified is None else np.ascontiguousarray(already_modified, dtype=np.uint8).reshape(-1, ng)
+        ch = None if charge is None or not self.model.n_storage else f(charge, ns)
+        ap = None if amount_prev is None else np.ascontiguousarray(amount_prev, dtype=np.float32).reshape(-1)
+        n = next(x.shape[0] for x in arrs + [am, ch, ap] if x is not None)
+        check(self._lib.gpf_set_env_state(self._h, int(lane0), n, ptr(arrs[0], C.c_float), ptr(arrs[1], C.c_float), ptr(arrs[2], C.c_float),
+                                          ptr(am, C.c_uint8), ptr(ch, C.c_float), ptr(ap, C.c_float)), "gpf_set_env_state")
 
     def set_trajectory(self, n_steps_cap: int, what: int = 1):
         """Trajectory buffers of multi-step launches: ``what`` = `TRAJ_RHO` (rho + status of every step) or `TRAJ_OBS` (in

@@ -195,6 +195,10 @@ class ShardedEngine:
         for eng in self.engines:
             eng.upload_maintenance(maintenance)
 
+    def upload_hazards(self, hazards):
+        for eng in self.engines:
+            eng.upload_hazards(hazards)
+
     def set_deterministic(self, flag: bool = True):
         for eng in self.engines:
             eng.set_deterministic(flag)
@@ -266,6 +270,23 @@ class ShardedEngine:
         if len(pd) != 1 or pd[0][0] is not es:
             raise ValueError("ShardedEngine.simulate_candidates: the source lane and its candidate lanes must be on the same device")
         return es.simulate_candidates(ls, pd[0][1], actions=actions, topologies=topologies, **kw)
+
+    def set_storage_params(self, *a, **kw):
+        for eng in self.engines:
+            eng.set_storage_params(*a, **kw)
+
+    def set_env_dynamics(self, *a, **kw):
+        for eng in self.engines:
+            eng.set_env_dynamics(*a, **kw)
+
+    def set_lane_actions(self, redispatch=None, storage_power=None, hold_storage: bool = False):
+        for eng, (b0, bn) in zip(self.engines, self.blocks):
+            cut = lambda a: None if a is None else np.asarray(a)[b0:b0 + bn]  # noqa: E731
+            eng.set_lane_actions(cut(redispatch), cut(storage_power), hold_storage)
+
+    def env_state(self, lane0: int = 0, n=None) -> dict:
+        parts = [eng.env_state(l0, k) for eng, l0, k, _ in self._parts(lane0, n)]
+        return {key: np.concatenate([p[key] for p in parts]) for key in parts[0]}
 
     def set_overflow_count(self, counts, lane0: int = 0):
         c = np.asarray(counts).reshape(-1, self.model.n_line)

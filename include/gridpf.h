@@ -174,6 +174,10 @@ int gpf_upload_chronics(gpf_handle h, int32_t n_tables, int32_t T, const float* 
  * every step, Environment/baseEnv.py:2516-2563): gpf_step / gpf_step_n force such a line out of service; it stays out afterwards
  * (nothing reconnects it for a DoNothing agent).  NULL removes the table. */
 int gpf_upload_maintenance(gpf_handle h, int32_t n_tables, int32_t T, const uint8_t* data);
+/* Hazards of the uploaded chronics tables (hazards.csv, Chronics/gridStateFromFile.py:478-490: unplanned outages), same shape and
+ * same effect on the backend as the maintenance table -- the line is forced out of service at the rows where it is flagged (the
+ * "hazards" modification the environment applies every step); the two tables are independent, the device applies their union. */
+int gpf_upload_hazards(gpf_handle h, int32_t n_tables, int32_t T, const uint8_t* data);
 int gpf_set_lane_chronics(gpf_handle h, const int32_t* lane_table, const int32_t* lane_offset, const float* lane_scale);
 int gpf_set_thermal_limits(gpf_handle h, const float* limit_a /* [n_line] */);
 /* One DoNothing env.step for every lane (Environment/baseEnv.py:3562 -> Backend.next_grid_state
@@ -228,6 +232,38 @@ int gpf_set_gen_limits(gpf_handle h, const double* pmin, const double* pmax, con
                        const uint8_t* redispatchable, double eps_poly);
 int gpf_redispatch(gpf_handle h, int32_t lane0, int32_t n, const double* new_p, const double* prev_p, const double* actual,
                    const double* target, const uint8_t* modified, const double* rhs, int32_t apply, uint8_t* ok, float* actual_after);
+/* ---- injection dynamics of the environment inside the stepped batch (BASELINE configs[3]: storage + redispatch actions) ------
+ * What BaseEnv.step does to the generator / storage set-points between the chronics and the backend, evaluated by gpf_step_n at
+ * EVERY step of a launch: the storage state of charge with its efficiencies, Emin / Emax clamping and losses
+ * (Environment/baseEnv.py:2829-2905 _compute_storage, :2777-2790 _withdraw_storage_losses), the accumulation of the agents'
+ * redispatch into the target dispatch (:2101-2115), the _make_redisp gate (:2188-2209) and the ramp- / pmin- / pmax-limited
+ * zero-sum projection (:2211-2470 _compute_dispatch_vect; exact solution of the separable QP, as gpf_redispatch), then
+ * prod_p = chronics + actual dispatch (:3830 set_redispatch) and the storage power (:3831 set_storage).  A lane whose projection is
+ * infeasible ends its episode (status GPF_ST_REDISPATCH; ImpossibleRedispatching :3227-3247).  Not modelled: curtailment,
+ * detachment, generator up / down times, the cancellation of illegal redispatch actions (:2140-2173).
+ *   gpf_set_storage_params : storage_Emax / Emin / loss / charging & discharging efficiency / initial charge [n_storage], the
+ *                            step length and Parameters.ACTIVATE_STORAGE_LOSS.
+ *   gpf_set_env_dynamics   : on != 0 switches the dynamics on (needs gpf_set_gen_limits, and gpf_set_storage_params on a grid
+ *                            with storage units) and resets the state of every lane (dispatch 0, initial charge); tol_poly as
+ *                            BaseEnv._tol_poly.  Needs n_gen and n_storage <= the lanes an instance owns (16 / 32 / 64).
+ *   gpf_set_lane_actions   : the agents' actions of the NEXT launch: redispatch [n_lanes][n_gen] MW (added to the target dispatch
+ *                            by the launch's first step, then consumed) and storage power [n_lanes][n_storage] MW (applied by the
+ *                            first step only -- grid2op's semantics of a storage action -- or, hold_storage != 0, by every step
+ *                            until replaced); NULL = none.
+ *   gpf_get/set_env_state  : target / actual dispatch, previous set-points (_gen_activeprod_t_redisp), already-modified mask
+ *                            [n][n_gen], state of charge [n][n_storage], previous storage amount [n] (what an environment
+ *                            restored from an observation hands over, baseEnv.py:4879-4882); any pointer may be NULL.
+ * gpf_reset_lanes also resets the dynamics of the lanes. */
+#define GPF_ST_REDISPATCH 6   /* the redispatch projection is infeasible: game over (ImpossibleRedispatching) */
+int gpf_set_storage_params(gpf_handle h, const double* emax, const double* emin, const double* loss, const double* eff_charge,
+                           const double* eff_discharge, const float* charge0, double delta_time_seconds, int32_t activate_loss);
+int gpf_set_env_dynamics(gpf_handle h, int32_t on, double tol_poly);
+int gpf_set_lane_actions(gpf_handle h, const float* redispatch, const float* storage_power, int32_t hold_storage);
+int gpf_get_env_state(gpf_handle h, int32_t lane0, int32_t n, float* target, float* actual, float* prev_p, uint8_t* already_modified,
+                      float* charge, float* amount_prev);
+int gpf_set_env_state(gpf_handle h, int32_t lane0, int32_t n, const float* target, const float* actual, const float* prev_p,
+                      const uint8_t* already_modified, const float* charge, const float* amount_prev);
+
 /* ---- batched obs.simulate (Observation/baseObservation.py:3365-3670 simulate -> Environment/_obsEnv.py: the forecast
  * injections of `time_step` steps ahead + a candidate action on a copy of the observation's grid state, one env.step of that copy) --
  * gpf_upload_forecasts: the *_forecasted tables of the uploaded chronics (Chronics/gridStateFromFileWithForecasts.py:311-353:

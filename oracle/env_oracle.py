@@ -129,3 +129,100 @@ def simulate(m, base: LaneState, row, act, thermal_limit, timestep_overflow, las
     if sb is not None:
         st.shunt_bus = sb
     return next_grid_state(m, st, thermal_limit, timestep_overflow, **kw)
+
+
+class InjectionDynamics:
+    """What BaseEnv.step does to the generator / storage set-points between the chronics and the backend, for an agent that hands
+    over a redispatch vector and a storage-power vector per step (zeros = do nothing): `_compute_storage` (baseEnv.py:2829-2905) +
+    `_withdraw_storage_losses` (:2777-2790), `_get_already_modified_gen` (:2101-2115), the `_make_redisp` gate (:2188-2209) and
+    `_compute_dispatch_vect` (:2211-2470, restated in oracle/redispatch_oracle.py with the reference's own solver), the set-points
+    of `set_redispatch` / `set_storage` (:3829-3831) and `_gen_activeprod_t_redisp` (:3439).  State arrays are float32 like the
+    reference's (dt_float).  Not restated: curtailment, detachment, generator up / down times, the cancellation of illegal
+    redispatch actions (`_prepare_redisp` :2140-2173: the tests only hand over legal ones)."""
+
+    def __init__(self, lim, n_gen, sto=None, delta_time_seconds=300.0, storage_charge0=None, activate_storage_loss=True, exact=False):
+        self.lim = lim
+        self.exact = bool(exact)       # the exact minimiser of the projection instead of SLSQP's approximate one (what the device computes)
+        f32 = np.float32
+        self.target = np.zeros(n_gen, f32)
+        self.actual = np.zeros(n_gen, f32)
+        self.prev_p = np.zeros(n_gen, f32)                    # _gen_activeprod_t_redisp
+        self.already = np.zeros(n_gen, bool)
+        self.sto = sto
+        self.coeff = delta_time_seconds / 3600.0
+        self.loss_on = bool(activate_storage_loss)
+        n_sto = 0 if sto is None else len(sto["Emax"])
+        self.charge = np.zeros(n_sto, f32) if storage_charge0 is None else np.asarray(storage_charge0, f32).copy()
+        self.power = np.zeros(n_sto, f32)
+        self.amount = 0.0
+        self.amount_prev = 0.0
+        self.fresh = True                                     # no step yet since the reset: the previous set-points are the step's own
+                                                              # (nb_time_step == 0, baseEnv.py:2218-2219); assigning prev_p clears it
+
+    def _compute_storage(self, act):
+        s = self.sto
+        act = np.asarray(act, np.float32)
+        sel = np.isfinite(act) & (np.abs(act) >= 1e-7)
+        self.power[:] = 0.0
+        if sel.any():
+            a = act[sel]
+            eff = np.ones(int(sel.sum()))
+            if self.loss_on:
+                eff[a > 0.0] *= s["charging_efficiency"][sel][a > 0.0]
+                eff[a < 0.0] /= s["discharging_efficiency"][sel][a < 0.0]
+            self.charge[sel] += (a * self.coeff * eff).astype(np.float32)
+            self.power[sel] = a
+            hi = self.charge > s["Emax"]
+            if hi.any():
+                t_ = (1.0 / self.coeff) * (self.charge[hi] - s["Emax"][hi])
+                if self.loss_on:
+                    t_ = t_ / s["charging_efficiency"][hi]
+                self.power[hi] -= t_.astype(np.float32)
+                self.charge[hi] = s["Emax"][hi]
+            lo = self.charge < s["Emin"]
+            if lo.any():
+                t_ = (1.0 / self.coeff) * (self.charge[lo] - s["Emin"][lo])
+                if self.loss_on:
+                    t_ = t_ * s["discharging_efficiency"][lo]
+                self.power[lo] -= t_.astype(np.float32)
+                self.charge[lo] = s["Emin"][lo]
+            self.charge[:] = np.maximum(self.charge, s["Emin"])
+            self.amount = float(self.power.sum())
+        else:
+            self.amount = 0.0
+        tmp = self.amount
+        self.amount -= self.amount_prev
+        self.amount_prev = tmp
+        if self.loss_on:
+            self.charge -= (s["loss"] * self.coeff).astype(np.float32)
+            self.charge[:] = np.maximum(self.charge, 0.0)
+
+    def step(self, new_p, act_redisp=None, act_storage=None):
+        """-> (ok, generator set-points float32 [n_gen] = chronics + actual dispatch, storage power float32 [n_storage])"""
+        from .redispatch_oracle import compute_dispatch, compute_dispatch_exact
+        if self.exact:
+            compute_dispatch = compute_dispatch_exact
+        new_p = np.asarray(new_p, np.float32)
+        if self.sto is not None:
+            self._compute_storage(np.zeros(len(self.power), np.float32) if act_storage is None else act_storage)
+        if act_redisp is not None and (np.asarray(act_redisp) != 0).any():
+            act = np.asarray(act_redisp, np.float32)
+            is_red = np.abs(act) > 1e-7
+            self.target[self.already] += act[self.already]
+            first_mod = (~self.already) & is_red
+            self.target[first_mod] = self.actual[first_mod] + act[first_mod]
+            self.already[is_red] = True
+        tol = self.lim["tol_poly"]
+        ok = True
+        if self.fresh and not self.prev_p.any():
+            self.prev_p[:] = new_p
+        self.fresh = False
+        if (abs(float(self.actual.sum())) >= tol or float(np.abs(self.actual - self.target).max()) >= tol or abs(self.amount) >= tol):
+            ok, after = compute_dispatch(new_p.astype(np.float64), self.prev_p.astype(np.float64), self.actual.astype(np.float64),
+                                         self.target.astype(np.float64), self.already.copy(), self.amount, 0.0, 0.0, self.lim, first=False)
+            if ok:
+                self.actual[:] = after.astype(np.float32)
+        gen = (new_p + self.actual).astype(np.float32)
+        if ok:
+            self.prev_p[:] = gen
+        return ok, gen, self.power.copy()

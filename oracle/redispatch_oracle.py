@@ -94,3 +94,60 @@ def compute_dispatch(new_p, prev_p, actual, target, modified, storage, curtail, 
 def objective_mw(q, x):
     """weighted squared distance to the agents' targets (MW^2) of a candidate x (MW, participating generators)"""
     return float((q["w"][q["mod"]] * (x[q["mod"]] - q["tv"][q["mod"]]) ** 2).sum())
+
+
+def solve_exact(q, eps_poly):
+    """EXACT minimiser of the program of `qp_terms` (the reference's SLSQP stops at ftol on a scaled objective and sits up to a few
+    tenths of a MW away from it): the program is separable with one coupling constraint, so x_i(lambda) = clip(t_i - lambda / (2 w_i))
+    on the generators of M, the generators of G \\ M sit at a bound when lambda != 0 and share the remainder in proportion to
+    1 / w_i when lambda = 0 -- the point the reference starts SLSQP from.  Plain numpy bisection (200 halvings), written
+    independently of the device kernel (gridpf_redispatch.hpp / env_dynamics_step) it is the reference for.  -> x [participating]"""
+    lo, hi, w, mod, tv, rhs = q["lo"] - 0.5 * eps_poly, q["hi"] + 0.5 * eps_poly, q["w"], q["mod"], q["tv"], q["rhs"]
+    free = ~mod
+    x = np.zeros(len(lo))
+
+    def xm(lam):
+        return np.clip(tv[mod] - lam / (2.0 * w[mod]), lo[mod], hi[mod])
+    s0 = xm(0.0).sum()
+    f_lo, f_hi = lo[free].sum(), hi[free].sum()
+    if rhs - s0 > f_hi or rhs - s0 < f_lo:
+        up = rhs - s0 > f_hi
+        fb = f_hi if up else f_lo
+        a, b = ((2.0 * w[mod] * (tv[mod] - hi[mod])).min(), 0.0) if up else (0.0, (2.0 * w[mod] * (tv[mod] - lo[mod])).max())
+        for _ in range(200):
+            mid = 0.5 * (a + b)
+            if xm(mid).sum() + fb > rhs:
+                a = mid
+            else:
+                b = mid
+        x[mod] = xm(0.5 * (a + b))
+        x[free] = hi[free] if up else lo[free]
+        inside = mod & (x > lo) & (x < hi)
+        if inside.any():
+            x[inside] += (rhs - x.sum()) / inside.sum()
+    else:
+        x[mod] = xm(0.0)
+        if free.any():
+            r = rhs - s0
+            a, b = np.minimum(lo[free] * w[free], hi[free] * w[free]).min(), np.maximum(lo[free] * w[free], hi[free] * w[free]).max()
+            for _ in range(200):
+                mid = 0.5 * (a + b)
+                if np.clip(mid / w[free], lo[free], hi[free]).sum() < r:
+                    a = mid
+                else:
+                    b = mid
+            x[free] = np.clip(0.5 * (a + b) / w[free], lo[free], hi[free])
+    return x
+
+
+def compute_dispatch_exact(new_p, prev_p, actual, target, modified, storage, curtail, detached, lim, first=False):
+    """As `compute_dispatch`, with the exact minimiser instead of SLSQP's approximate one.  -> (ok, actual_dispatch after)"""
+    q = qp_terms(new_p, prev_p, actual, target, modified, storage, curtail, detached, lim, first)
+    if q is None:
+        return False, actual.copy()
+    added = 0.5 * lim["eps_poly"]
+    if q["rhs"] < (q["lo"] - added).sum() or q["rhs"] > (q["hi"] + added).sum():
+        return False, actual.copy()
+    out = actual.copy()
+    out[q["part"]] += solve_exact(q, lim["eps_poly"])
+    return True, out

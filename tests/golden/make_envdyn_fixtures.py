@@ -1,0 +1,121 @@
+#!/usr/bin/env python
+"""Record the INJECTION DYNAMICS of the unmodified reference environment under redispatch + storage actions (build container).
+
+    python tests/golden/make_envdyn_fixtures.py        # -> tests/golden/envdyn_<env>.npz
+
+What BaseEnv.step does to the injections between the chronics and the backend (grid2op/Environment/baseEnv.py): the storage
+state of charge / clamping / losses (`_compute_storage` :2829-2905, `_withdraw_storage_losses` :2777-2790), the accumulation of the
+agents' redispatch into `_target_dispatch` (`_get_already_modified_gen` :2101-2115, `_prepare_redisp` :2117-2186), the gate and the
+ramp-limited projection (`_make_redisp` :2188-2209 -> `_compute_dispatch_vect` :2211-2470), and the set-points handed to the
+backend (`set_redispatch` / `set_storage`, :3829-3831).  The environment -- façade over the CPU oracle, NO_OVERFLOW_DISCONNECTION so
+that the episode is long -- is driven by an agent that acts every few steps and does nothing in between; per step the internal
+state after the step and the observation are recorded, plus the generator / storage characteristics and the chronics rows.
+Pins oracle/env_oracle.py (`InjectionDynamics`, CPU test) and is replayed by multi-step launches on the GPU."""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REFERENCE = os.environ.get("GRID2OP_REFERENCE", "/root/reference")
+for p in (ROOT, os.path.join(ROOT, "tests"), REFERENCE, os.path.join(ROOT, "tests", "_refshim")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("_GRID2OP_FORCE_TEST", "1")
+warnings.filterwarnings("ignore")
+
+import grid2op  # noqa: E402
+from grid2op.Action import DontAct  # noqa: E402
+from grid2op.Opponent import BaseOpponent  # noqa: E402
+from grid2op.Parameters import Parameters  # noqa: E402
+
+from conformance_backend import OracleHipBackend  # noqa: E402
+
+
+def record(env_name, n_steps, every, seed):
+    p = Parameters()
+    p.NO_OVERFLOW_DISCONNECTION = True
+    env = grid2op.make(env_name, test=True, backend=OracleHipBackend(), param=p, opponent_class=BaseOpponent,
+                       opponent_action_class=DontAct, opponent_init_budget=0.0, opponent_budget_per_ts=0.0)
+    cls = type(env)
+    env.seed(seed)
+    env.set_id(0)
+    obs = env.reset()
+    rng = np.random.default_rng(seed)
+    disp = np.nonzero(cls.gen_redispatchable)[0]
+    keys = ["row", "act_redisp", "act_storage", "new_p", "target", "actual", "prev_p", "already_modified", "storage_power", "storage_charge",
+            "amount_storage", "gen_p", "gen_v", "load_p", "load_q", "p_or", "a_or", "rho", "obs_storage_power", "obs_storage_charge",
+            "obs_actual_dispatch", "obs_target_dispatch", "failed_redisp"]
+    rec = {k: [] for k in keys}
+    data = env.chronics_handler.real_data.data
+    out0 = dict(storage_charge0=np.array(env._storage_current_charge, np.float64))
+    for t in range(n_steps):
+        red = np.zeros(cls.n_gen, np.float32)
+        sto = np.zeros(cls.n_storage, np.float32)
+        if t % every == 0:
+            k = rng.choice(disp, size=min(len(disp), 2), replace=False)
+            amp = cls.gen_max_ramp_up[k] * rng.uniform(0.2, 0.7, len(k)) * np.array([1.0, -1.0])[:len(k)]
+            red[k] = amp
+            if cls.n_storage:
+                sto[:] = rng.uniform(-4.0, 4.0, cls.n_storage)
+        act = {}
+        if (red != 0).any():
+            act["redispatch"] = [(int(g), float(red[g])) for g in np.nonzero(red)[0]]
+        if (sto != 0).any():
+            act["set_storage"] = [(int(i), float(sto[i])) for i in np.nonzero(sto)[0]]
+        obs, _, done, info = env.step(env.action_space(act))
+        assert not done, (t, info["exception"])
+        rec["row"].append(int(data.current_index))
+        rec["act_redisp"].append(red.copy())
+        rec["act_storage"].append(sto.copy())
+        rec["new_p"].append(np.array(data.prod_p[data.current_index], np.float32))
+        rec["target"].append(np.array(env._target_dispatch, np.float64))
+        rec["actual"].append(np.array(env._actual_dispatch, np.float64))
+        rec["prev_p"].append(np.array(env._gen_activeprod_t_redisp, np.float64))
+        rec["already_modified"].append(np.array(env._already_modified_gen, bool))
+        rec["storage_power"].append(np.array(env._storage_power, np.float64))
+        rec["storage_charge"].append(np.array(env._storage_current_charge, np.float64))
+        rec["amount_storage"].append(float(env._amount_storage))
+        rec["failed_redisp"].append(bool(info["failed_redispatching"]))
+        for f in ("gen_p", "gen_v", "load_p", "load_q", "p_or", "a_or", "rho"):
+            rec[f].append(np.asarray(getattr(obs, f)).copy())
+        rec["obs_storage_power"].append(np.asarray(obs.storage_power).copy())
+        rec["obs_storage_charge"].append(np.asarray(obs.storage_charge).copy())
+        rec["obs_actual_dispatch"].append(np.asarray(obs.actual_dispatch).copy())
+        rec["obs_target_dispatch"].append(np.asarray(obs.target_dispatch).copy())
+    out = {k: np.stack(v) if np.ndim(v[0]) else np.asarray(v) for k, v in rec.items()}
+    out.update(out0)
+    out.update(pmin=cls.gen_pmin.astype(np.float64), pmax=cls.gen_pmax.astype(np.float64), ramp_up=cls.gen_max_ramp_up.astype(np.float64),
+               ramp_down=cls.gen_max_ramp_down.astype(np.float64), redispatchable=cls.gen_redispatchable.astype(bool),
+               eps_poly=np.float64(env._epsilon_poly), tol_poly=np.float64(env._tol_poly), delta_time_seconds=np.float64(env.delta_time_seconds),
+               thermal_limit=np.asarray(env.get_thermal_limit(), np.float32),
+               activate_storage_loss=np.bool_(env.parameters.ACTIVATE_STORAGE_LOSS))
+    if cls.n_storage:
+        out.update(storage_Emax=cls.storage_Emax.astype(np.float64), storage_Emin=cls.storage_Emin.astype(np.float64),
+                   storage_loss=cls.storage_loss.astype(np.float64), storage_charging_efficiency=cls.storage_charging_efficiency.astype(np.float64),
+                   storage_discharging_efficiency=cls.storage_discharging_efficiency.astype(np.float64),
+                   storage_max_p_prod=cls.storage_max_p_prod.astype(np.float64), storage_max_p_absorb=cls.storage_max_p_absorb.astype(np.float64))
+    # chronics rows of the scenario as grid2op_amd.chronics reads them
+    from grid2op_amd.chronics import load_chronics_folder
+    from grid2op_amd.grid_model import GridModel
+    m = GridModel.load_npz(os.path.join(HERE, f"{env_name}.grid.npz"))
+    ch = load_chronics_folder(env.chronics_handler.get_id(), m, max_rows=n_steps + 4)
+    for k in ("load_p", "load_q", "prod_p", "prod_v"):
+        out["ch_" + k] = ch[k]
+    assert np.array_equal(out["new_p"], ch["prod_p"][out["row"]]), "chronics reader vs environment"
+    np.savez_compressed(os.path.join(HERE, f"envdyn_{env_name}.npz"), **out)
+    print(env_name, "steps", n_steps, "max |actual|", float(np.abs(out["actual"]).max()), "storage power range",
+          (float(out["storage_power"].min()), float(out["storage_power"].max())) if cls.n_storage else None,
+          "failed_redisp", int(out["failed_redisp"].sum()))
+    env.close()
+
+
+def main():
+    record("educ_case14_storage", 24, 4, 5)
+    record("l2rpn_wcci_2022_dev", 16, 4, 6)
+
+
+if __name__ == "__main__":
+    main()

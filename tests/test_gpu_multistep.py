@@ -720,3 +720,35 @@ def test_observation_trajectory_failing_lanes_and_auto_reset(load_model, load_np
         assert np.isnan(obs[k].out[bad]).all() and (obs[k].topo_vect[bad] == -1).all() and not obs[k].line_status[bad].any()
         assert not np.isnan(obs[k].out[~bad]).any() and (obs[k].topo_vect[~bad] >= 1).all()
     eng.close()
+
+
+def test_hazards_table_forces_lines_out_like_maintenance(load_model, load_npz):
+    """gpf_upload_hazards (hazards.csv, Chronics/gridStateFromFile.py:478-490): the union of the hazards and maintenance tables is
+    applied; each table can be replaced / removed independently."""
+    m, ch, eng, tab, off, scale = _setup(load_model, load_npz, "l2rpn_case14_sandbox", 8)
+    T = tab.shape[0]
+    eng.set_lane_chronics(lane_offset=np.zeros(8, np.int32), lane_scale=scale)
+    maint = np.zeros((1, T, m.n_line), np.uint8)
+    haz = np.zeros((1, T, m.n_line), np.uint8)
+    maint[0, 3:5, 4] = 1
+    haz[0, 4:6, 9] = 1
+    eng.upload_maintenance(maint)
+    eng.upload_hazards(haz)
+    eng.set_trajectory(8, eng.TRAJ_OBS)
+    eng.step(0, n_steps=8, rebalance=1.02)
+    obs = eng.trajectory_obs(8)
+    for t in range(8):
+        ls = obs[t].line_status
+        assert (ls[:, 4] == (t < 3)).all(), t            # out from its maintenance on (nothing reconnects it for a DoNothing agent)
+        assert (ls[:, 9] == (t < 4)).all(), t            # out from its hazard on
+        assert ls[:, [l for l in range(m.n_line) if l not in (4, 9)]].all()
+    eng.reset()
+    eng.upload_maintenance(None)                         # only the hazards are left
+    eng.step(0, n_steps=8, rebalance=1.02)
+    ls = eng.results().line_status
+    assert ls[:, 4].all() and not ls[:, 9].any()
+    eng.reset()
+    eng.upload_hazards(None)
+    eng.step(0, n_steps=8, rebalance=1.02)
+    assert eng.results().line_status.all()
+    eng.close()
