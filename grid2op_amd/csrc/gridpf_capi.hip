@@ -298,14 +298,26 @@ void count_lane(const gpf_engine* e, const int* topo, const int* shunt_bus, int&
 
 // flat programs (gridpf_symbolic.hpp: FlatProg) of one graph for the four group widths, in one device buffer; false: upload
 // failed.  A graph too large for the 16-bit byte-offset fields gets none (fl[k].n_words == 0: it would not fit the LDS either).
-bool upload_flats(const gpf::Symbolic& S, DevArr<int>& buf, gpf::SymDev& D) {
+bool upload_flats(const gpf::Symbolic& S, DevArr<int>& buf, gpf::SymDev& D, int lane_opt = 0) {
   D.rslot0 = S.rslot0;
   for (int k = 0; k < 4; ++k) { D.flat[k] = nullptr; D.fl[k] = gpf::FlatDev{}; }
   if (!gpf::flat_fits(S)) return true;
   std::vector<int> all;
   size_t off[4];
   for (int k = 0; k < 4; ++k) {
-    const gpf::FlatProg F = gpf::build_flat(S, 16 << k);
+    // (the lane assignment is a pure function of the graph: engines of the same grid -- every HipBackend copy pool, every test --
+    //  share one build per process)
+    static std::unordered_map<std::string, gpf::FlatProg> cache;
+    std::string key;
+    if (lane_opt > 0) {
+      key.assign(reinterpret_cast<const char*>(S.slot_row.data()), S.slot_row.size() * sizeof(int));
+      key.append(reinterpret_cast<const char*>(S.slot_col.data()), S.slot_col.size() * sizeof(int));
+      key.append(reinterpret_cast<const char*>(S.prog.data()), S.prog.size() * sizeof(int));
+      key += "/" + std::to_string(16 << k) + "/" + std::to_string(lane_opt);
+    }
+    auto hit = lane_opt > 0 ? cache.find(key) : cache.end();
+    const gpf::FlatProg F = hit != cache.end() ? hit->second : gpf::build_flat(S, 16 << k, lane_opt);
+    if (lane_opt > 0 && hit == cache.end() && cache.size() < 64) cache.emplace(key, F);
     off[k] = all.size();
     all.insert(all.end(), F.words.begin(), F.words.end());
     gpf::FlatDev& f = D.fl[k];
@@ -909,7 +921,11 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
       D.static_connected = roots == 1 ? 1 : 0;
     } D.scale_off = S.scale_off; D.n_scale = S.n_scale; D.n_prog = (int)S.prog.size();
     D.stat_dbl = e->stat_dbl.p; D.stat_int = e->stat_int.p; D.prog = e->stat_int.p + so.prog;
-    if (!upload_flats(S, e->flat_prog, D)) { gpf_destroy(e); return fail(GPF_E_DEVICE, "upload flat programs"); }
+    // the grid's own programs get the bank-conflict-aware lane assignment (a local search per pass, ~0.1-1 s once per engine;
+    // GRIDPF_LANE_OPT=<iterations> overrides, 0 = sequential assignment); topology classes are built inside a step and skip it
+    int lane_opt = 3000;
+    if (const char* lo_ = std::getenv("GRIDPF_LANE_OPT")) lane_opt = std::max(0, atoi(lo_));
+    if (!upload_flats(S, e->flat_prog, D, lane_opt)) { gpf_destroy(e); return fail(GPF_E_DEVICE, "upload flat programs"); }
   }
   {
     // keep the factored DC matrix in LDS across the steps of a launch when that does not cost residency: the blocks per CU

@@ -218,7 +218,80 @@ inline std::vector<int> build_upairs(const Symbolic& S) {
 // false: the grid has too many blocks for 16-bit byte-offset fields (it would not fit the LDS either)
 inline bool flat_fits(const Symbolic& S) { return (size_t)(S.rslot0 + S.n) * 16 <= 65536; }
 
-inline FlatProg build_flat(const Symbolic& S, int gw) {
+// ---- LDS bank model of one pass (MI355X: 64 banks x 4 B) -------------------------------------------------------------------------
+// ds_read_b128 is served in 4 groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 --, one LDS cycle per
+// group when the 16-byte chunks fall on distinct bank quads ((addr / 16) mod 16), identical addresses broadcast; every further
+// distinct address on a busy quad costs a cycle.  The 8-byte accesses (ds_add_f64, ds_read_b64 of the accumulated right-hand side) go
+// in groups of 16 contiguous lanes over bank pairs ((addr / 8) mod 16); atomics on one address serialise.  The two row halves of the
+// block array are a constant apart, so row 1 repeats the pattern of row 0.  `flat_pass_cost` = modelled LDS-array cycles of one pass
+// for a given item -> lane assignment; `flat_assign_lanes` lowers it by swapping items between lanes (deterministic local search:
+// the assignment only decides which lane executes an item and in which order a wavefront's atomics land -- still a fixed order).
+struct FlatAcc { unsigned rd[3]; int n_rd; unsigned at[2]; int n_at; unsigned r8; bool has_r8; bool valid; };
+inline int flat_b128_group(int lane) { const int l = lane & 31; return ((l < 4 || (l >= 12 && l < 16) || (l >= 20 && l < 28)) ? 0 : 1) + 2 * ((lane >> 5) & 1); }
+inline int flat_pass_cost(const std::vector<FlatAcc>& it, int gw) {
+  int cost = 0;
+  unsigned seen[16][8];
+  int cnt[16];
+  for (int base = 0; base < gw; base += 64) {
+    for (int f = 0; f < 3; ++f)
+      for (int g = 0; g < 4; ++g) {
+        for (int q = 0; q < 16; ++q) cnt[q] = 0;
+        int mx = 0;
+        for (int l = 0; l < 64 && base + l < gw; ++l) {
+          const FlatAcc& a = it[base + l];
+          if (!a.valid || f >= a.n_rd || flat_b128_group(l) != g) continue;
+          const unsigned ad = a.rd[f];
+          const int q = (ad / 16) % 16;
+          bool dup = false;
+          for (int k = 0; k < cnt[q] && k < 8; ++k) dup |= seen[q][k] == ad;
+          if (!dup) { if (cnt[q] < 8) seen[q][cnt[q]] = ad; ++cnt[q]; mx = std::max(mx, cnt[q]); }
+        }
+        cost += 2 * mx;                                    // rows 0 and 1
+      }
+    for (int g = 0; g < 4; ++g) {                          // 8-byte accesses: 16 contiguous lanes
+      for (int f = 0; f < 3; ++f) {
+        for (int q = 0; q < 16; ++q) cnt[q] = 0;
+        int mx = 0;
+        for (int l = 16 * g; l < 16 * g + 16 && base + l < gw; ++l) {
+          const FlatAcc& a = it[base + l];
+          if (!a.valid) continue;
+          unsigned ad;
+          if (f < 2) { if (f >= a.n_at) continue; ad = a.at[f]; }
+          else { if (!a.has_r8) continue; ad = a.r8; }
+          const int q = (ad / 8) % 16;
+          if (f < 2) { ++cnt[q]; mx = std::max(mx, cnt[q]); }       // atomics: every access counts
+          else {
+            bool dup = false;
+            for (int k = 0; k < cnt[q] && k < 8; ++k) dup |= seen[q][k] == ad;
+            if (!dup) { if (cnt[q] < 8) seen[q][cnt[q]] = ad; ++cnt[q]; mx = std::max(mx, cnt[q]); }
+          }
+        }
+        cost += 2 * mx;
+      }
+    }
+  }
+  return cost;
+}
+// items of ONE pass (it.size() == gw, invalid = padding); perm_unit: lanes may only be exchanged inside blocks of this many lanes
+// (64 when several wavefronts share the pass: an item must stay in its wavefront, see the wave-closed packing below)
+inline void flat_assign_lanes(std::vector<FlatAcc>& it, std::vector<std::pair<unsigned, unsigned>>& words, int gw, int perm_unit, int iters) {
+  int cost = flat_pass_cost(it, gw);
+  unsigned long long rng = 0x9E3779B97F4A7C15ull;                   // fixed seed: the program is a pure function of the grid
+  auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (unsigned)(rng >> 32); };
+  for (int k = 0; k < iters && cost > 0; ++k) {
+    const int x = (int)(next() % (unsigned)gw);
+    const int y = (x / perm_unit) * perm_unit + (int)(next() % (unsigned)perm_unit);
+    if (x == y || (!it[x].valid && !it[y].valid)) continue;
+    std::swap(it[x], it[y]);
+    const int c1 = flat_pass_cost(it, gw);
+    if (c1 <= cost) { cost = c1; std::swap(words[x], words[y]); }
+    else std::swap(it[x], it[y]);
+  }
+}
+
+// lane_opt: iterations of the bank-conflict local search per pass (0: keep the sequential assignment -- topology classes are built
+// at run time, inside a step, and skip it)
+inline FlatProg build_flat(const Symbolic& S, int gw, int lane_opt = 0) {
   FlatProg F;
   F.gw = gw;
   F.rhs_field0 = S.rslot0 * 16;
@@ -231,25 +304,58 @@ inline FlatProg build_flat(const Symbolic& S, int gw) {
   // one, and floating-point addition is not associative.  The items of a level are therefore grouped by destination and a group
   // never straddles the boundary between the two 64-lane halves of a pass (it may continue in the NEXT pass: a barrier separates
   // them); invalid items pad the gap.  Returns the number of passes the items took.  gw <= 64: plain sequential packing.
-  auto emit_items = [&](std::vector<std::pair<unsigned, std::pair<unsigned, unsigned>>>& items) -> int {   // (destination key, (w0, w1))
+  const unsigned rhs0 = (unsigned)F.rhs_field0;
+  auto emit_items = [&](std::vector<std::pair<unsigned, std::pair<unsigned, unsigned>>>& items, bool back) -> int {   // (destination key, (w0, w1))
     if (items.empty()) return 0;
-    size_t pos = 0;                                            // items emitted for this level, padding included
-    auto put = [&](unsigned a, unsigned b) { W.push_back((int)a); W.push_back((int)b); ++pos; };
+    std::vector<std::pair<unsigned, unsigned>> seq;            // the level's items in lane order, padding included
+    auto put = [&](unsigned a, unsigned b) { seq.push_back({a, b}); };
     if (gw > 64) {
       std::stable_sort(items.begin(), items.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
       for (size_t i = 0; i < items.size();) {
         size_t j = i;
         while (j < items.size() && items[j].first == items[i].first) ++j;
-        const size_t g = j - i, in_half = pos % 64;
-        const bool first_half = (pos / 64) % 2 == 0 || gw != 128;        // (gw = 128: halves alternate wavefront 0 / 1)
+        const size_t g = j - i, in_half = seq.size() % 64;
+        const bool first_half = (seq.size() / 64) % 2 == 0 || gw != 128;        // (gw = 128: halves alternate wavefront 0 / 1)
         if (g > 64) F.wave_closed = false;
-        else if (in_half + g > 64 && first_half) while (pos % 64) put(INV, INV);
+        else if (in_half + g > 64 && first_half) while (seq.size() % 64) put(INV, INV);
         for (; i < j; ++i) put(items[i].second.first, items[i].second.second);
       }
-    } else
-      for (auto& it : items) put(it.second.first, it.second.second);
-    while (pos % gw) put(INV, INV);
-    return (int)(pos / gw);
+    } else {
+      // a level that needs several passes is split EVENLY between them (the bank model says why: the cost of a pass grows faster than
+      // its item count, and a pass costs its latency whatever it holds)
+      const size_t n_pass = (items.size() + gw - 1) / gw, per = (items.size() + n_pass - 1) / n_pass;
+      size_t i = 0;
+      for (size_t pz = 0; pz < n_pass; ++pz) {
+        for (size_t k = 0; k < per && i < items.size(); ++k, ++i) put(items[i].second.first, items[i].second.second);
+        while (seq.size() % gw) put(INV, INV);
+      }
+    }
+    while (seq.size() % gw) put(INV, INV);
+    const int n_pass = (int)(seq.size() / gw);
+    if (lane_opt > 0)
+      for (int pz = 0; pz < n_pass; ++pz) {
+        std::vector<std::pair<unsigned, unsigned>> words(seq.begin() + (size_t)pz * gw, seq.begin() + (size_t)(pz + 1) * gw);
+        std::vector<FlatAcc> acc(gw);
+        for (int t = 0; t < gw; ++t) {
+          FlatAcc& a = acc[t];
+          const unsigned w0 = words[t].first, w1 = words[t].second;
+          a = FlatAcc{};
+          a.valid = w0 != INV;
+          if (!a.valid) continue;
+          if (!back) {                                         // reads D_p, A_l, A_u (2 rows each); 4 atomics on the rows of dst
+            a.rd[0] = w1 >> 16; a.rd[1] = w0 >> 16; a.rd[2] = w1 & 0xffffu; a.n_rd = 3;
+            a.at[0] = w0 & 0xffffu; a.at[1] = (w0 & 0xffffu) + 8; a.n_at = 2;
+          } else {                                             // reads A_u, D_col (2 rows), s_col (8 bytes per row); 2 atomics on s_dst
+            a.rd[0] = w0 & 0xffffu; a.rd[1] = (w0 >> 16) - rhs0; a.n_rd = 2;
+            a.r8 = w0 >> 16; a.has_r8 = true;
+            a.at[0] = w1; a.n_at = 1;
+          }
+        }
+        flat_assign_lanes(acc, words, gw, gw > 64 ? 64 : gw, lane_opt);
+        std::copy(words.begin(), words.end(), seq.begin() + (size_t)pz * gw);
+      }
+    for (auto& w : seq) { W.push_back((int)w.first); W.push_back((int)w.second); }
+    return n_pass;
   };
   // forward
   for (int lv = 0; lv < S.n_levels; ++lv) {
@@ -266,7 +372,7 @@ inline FlatProg build_flat(const Symbolic& S, int gw) {
       const int p = S.prog[r_off + 2 * o + 1];
       items.push_back({rfld((int)(w0 >> 16)), {rfld((int)(w0 >> 16)) | (fld(w0 & 0xffffu) << 16), rfld(p) | (fld(p) << 16)}});
     }
-    F.n_fwd += emit_items(items);
+    F.n_fwd += emit_items(items, false);
   }
   for (int k = 0; k < gw; ++k) { W.push_back((int)INV); W.push_back((int)INV); }
   // (no scaling pass: the U blocks and the right-hand side stay UNSCALED -- the back substitution is
@@ -286,7 +392,7 @@ inline FlatProg build_flat(const Symbolic& S, int gw) {
       const int p = S.prog[ent_off + 2 * o + 1];
       items.push_back({rfld(p), {fld(w & 0xffffu) | (rfld((int)(w >> 16)) << 16), rfld(p)}});
     }
-    F.n_back += emit_items(items);
+    F.n_back += emit_items(items, true);
   }
   for (int k = 0; k < gw; ++k) { W.push_back((int)INV); W.push_back((int)INV); }
   while (W.size() & 3) W.push_back((int)INV);

@@ -152,7 +152,7 @@ extern "C" int sym_emul_solve_flat(int n_sub, int n_line, const int* line_or, co
                                    const double* rhs_in, double* x_out, int* stats /* n_fwd, n_scale, n_back, n_words */) {
   gpf::Symbolic S = gpf::build_symbolic(n_sub, n_line, line_or, line_ex);
   if (!gpf::flat_fits(S)) return -10;
-  const gpf::FlatProg F = gpf::build_flat(S, gw);
+  const gpf::FlatProg F = gpf::build_flat(S, gw, 400);      // with the bank-conflict-aware lane assignment
   const int N = n_sub * 2;
   const size_t NS = (size_t)S.rslot0 + n_sub, HS = NS * 2;
   std::vector<double> A(2 * HS, 0.0);                                     // row 0 of every (pseudo-)slot, then row 1
@@ -174,7 +174,7 @@ extern "C" int sym_emul_solve_flat(int n_sub, int n_line, const int* line_or, co
     for (int t = 0; t < gw; ++t) {
       const unsigned w0 = (unsigned)W[2 * (k * gw + t)], w1 = (unsigned)W[2 * (k * gw + t) + 1];
       if (w0 == INV) { seen_inv = true; continue; }
-      if (seen_inv && gw <= 64) return -3;                  // (gw > 64: padding keeps a destination's items inside one wavefront)
+      (void)seen_inv;                                       // (padding may sit anywhere in a pass: balanced splitting, wave-closed packing, lane assignment)
       const unsigned fd = w0 & 0xffffu, fl = w0 >> 16, fu = w1 & 0xffffu, fp = w1 >> 16;
       if (gw > 64) {                                        // wave-closed: every destination of a pass belongs to ONE 64-lane half
         auto it = dst_half.find(fd);
