@@ -445,7 +445,8 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
     }
     auto need = [&](int tier) -> size_t {
       const int wpi_n = (nbk == 1 && ipw == 1) ? (e->wpi_override ? std::min(e->wpi_override, 2) : (e->g.n_sub >= 64 && e->sym_dev.fl[3].wave_closed ? 2 : 1)) : 1;
-      const size_t static_bytes = gpf::stat_bytes(e->sym_dev.so, tier, nbk == 1, e->sym_dev.fl[gpf::gw_index(64 / ipw * wpi_n)].n_words);
+      // (instance-group kernels stream the flat program from global memory: gridpf_sparse.hpp lu_ac)
+      const size_t static_bytes = gpf::stat_bytes(e->sym_dev.so, tier, nbk == 1, ipw > 1 ? 0 : e->sym_dev.fl[gpf::gw_index(64 / ipw * wpi_n)].n_words);
       const bool st = tier > 0;
       const bool dcf = e->dcf != 0;
       return nbk == 1 ? gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, e->sym.nslot_y, static_bytes, st, ipw, -1, dcf)
@@ -932,7 +933,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     // the whole batch needs at once must still fit (GRIDPF_DCF=0|1 overrides)
     const int ipw = e->ipw_override ? e->ipw_override : (g.n_sub <= 8 ? 4 : g.n_sub <= 24 ? 2 : 1);
     const int wpi0 = e->wpi_override ? std::min(e->wpi_override, 2) : (g.n_sub >= 64 ? 2 : 1);
-    const size_t stat2 = gpf::stat_bytes(e->sym_dev.so, 2, true, e->sym_dev.fl[gpf::gw_index(64 / ipw * (ipw == 1 ? wpi0 : 1))].n_words);
+    const size_t stat2 = gpf::stat_bytes(e->sym_dev.so, 2, true, ipw > 1 ? 0 : e->sym_dev.fl[gpf::gw_index(64 / ipw * (ipw == 1 ? wpi0 : 1))].n_words);
     const size_t with = gpf::lds_bytes_sparse<1>(g, e->sym.nslot, e->sym.nslot_y, stat2, true, ipw, -1, true);
     const size_t n_blocks = ((size_t)n_lanes + ipw - 1) / ipw;
     const size_t want = std::min<size_t>((n_blocks + 255) / 256, 8);

@@ -1078,21 +1078,30 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   }
   GPF_STAMPS(3);
   // the program is in LDS (tier >= 1) or read in place through a global-address-space pointer (tier 0)
+  // Instance-group kernels (IPW > 1: the small grids) stream the flat program from global memory (L1 / L2 resident, a few KB shared
+  // by every block), one pass ahead, although their other static tables are staged in LDS: item words that come back through the LDS
+  // share its in-order counter with the pass's atomics, and the wait for them at the end of a pass (s_waitcnt lgkmcnt(0): the two
+  // paths of the "valid item?" branch issue different numbers of LDS operations, so the compiler cannot count) drains the atomics of
+  // every pass; global loads wait on vmcnt and leave the LDS queue alone (+1.2 % on 14 substations, and 2.8 KB of LDS per block).
+  // One instance per wavefront (36+ substations): the passes are too short to hide an L2 round trip per pass -- measured -13 % at
+  // 4 096 lanes -- so a staged program (tier >= 1) is read from LDS there.
+  const int* const flat_g = STAGE == 0 ? sv.prog.p : S.flat[gw_index(GW)];     // (tier 0: the view already points at the global copy)
+  constexpr bool PROG_LDS = STAGE >= 1 && IPW == 1;
   auto lu_ac = [&](long long* dbg) -> bool {
     if (BS == 2) {
-      if (STAGE >= 1) return block_lu_flat<GW>(FL, sv.prog.p, c.A, HS, tid, dbg);
-      return block_lu_flat<GW>(FL, gptr(sv.prog.p), c.A, HS, tid, dbg);
+      if (PROG_LDS) return block_lu_flat<GW>(FL, sv.prog.p, c.A, HS, tid, dbg);
+      return block_lu_flat<GW>(FL, gptr(flat_g), c.A, HS, tid, dbg);
     }
     if (STAGE >= 1) return block_lu_solve<BS, GW>(S, sv.prog.p, c.A, c.rhs, tid, dbg);
     return block_lu_solve<BS, GW>(S, gptr(sv.prog.p), c.A, c.rhs, tid, dbg);
   };
   auto lu_dc = [&](long long* dbg) -> bool {       // single-busbar layout only
     if (dc_kept) {
-      if (STAGE >= 1) return scalar_lu_flat<GW, false, true>(FL, sv.prog.p, c.A, c.Adc, tid, dbg);
-      return scalar_lu_flat<GW, false, true>(FL, gptr(sv.prog.p), c.A, c.Adc, tid, dbg);
+      if (PROG_LDS) return scalar_lu_flat<GW, false, true>(FL, sv.prog.p, c.A, c.Adc, tid, dbg);
+      return scalar_lu_flat<GW, false, true>(FL, gptr(flat_g), c.A, c.Adc, tid, dbg);
     }
-    if (STAGE >= 1) return scalar_lu_flat<GW, true, false>(FL, sv.prog.p, c.A, c.A, tid, dbg);
-    return scalar_lu_flat<GW, true, false>(FL, gptr(sv.prog.p), c.A, c.A, tid, dbg);
+    if (PROG_LDS) return scalar_lu_flat<GW, true, false>(FL, sv.prog.p, c.A, c.A, tid, dbg);
+    return scalar_lu_flat<GW, true, false>(FL, gptr(flat_g), c.A, c.A, tid, dbg);
   };
   if (!warm) {
 #ifdef GPF_TIMING
@@ -1500,7 +1509,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   pin_sgpr(F_loc.back_off); pin_sgpr(F_loc.rhs_field0);                                                                          \
   const FlatDev& FL = F_loc;                                                                                                     \
   StatView<STAGE> sv;                                                                                                            \
-  make_stat_view<STAGE, NB == 1>(sv, P->sym, smem + (size_t)IPW * per_inst, S_loc.flat[GWI], F_loc.n_words);                     \
+  make_stat_view<STAGE, NB == 1>(sv, P->sym, smem + (size_t)IPW * per_inst, S_loc.flat[GWI], IPW > 1 ? 0 : F_loc.n_words);        \
   if (TC) {                                                                                                                      \
     const TopoClassDev& tc_ = P->classes[gptr(lane_class)[blockIdx.x * IPW]];                                              \
     sv.pair_rc.p = tc_.pair_rc; sv.up.p = tc_.up; sv.br_slot.p = tc_.br_slot; sv.node_of.p = tc_.node_of;                        \
