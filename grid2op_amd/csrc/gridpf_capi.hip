@@ -1360,10 +1360,12 @@ int gpf_set_thermal_limits(gpf_handle e, const float* limit_a) {
 }  // extern "C"
 namespace {
 // n_steps env steps of lanes [lane0, lane0 + n) from time index t0 (T rows per chronics table in `b.chron`)
-int step_range(gpf_engine* e, const gpf::Bufs& b, int lane0, int n, int t0, int T, int n_steps, const gpf_step_opts* o, const char* who) {
+int step_range(gpf_engine* e, const gpf::Bufs& b_in, int lane0, int n, int t0, int T, int n_steps, const gpf_step_opts* o, const char* who) {
   LaunchPlan p, pb;
   int rc = plan_launch(e, lane0, n, p, pb);
   if (rc != GPF_OK) return rc;
+  gpf::Bufs b = b_in;
+  b.work = e->work.p;                 // (developer timing build: the stamp buffer is allocated by the planner)
   if (n_steps > 1 && pb.sparse_nb)
     return fail(GPF_E_INVALID, std::string(who) + ": multi-step launches need a batch that runs as ONE launch (mixed split / unsplit lanes "
                                "without topology classes run as two): use n_steps = 1");

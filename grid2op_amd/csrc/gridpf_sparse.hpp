@@ -189,6 +189,8 @@ struct CarveP {
   double* Yb;     // [nslot_y][NB*NB][2]
   double* rhs;    // NB > 1: [n_sub][BS].  NB == 1: the right-hand side is pseudo-slot rslot0 + p of A (rows (b0, Re S), (b1, Im S))
   double *vm, *va, *e, *f, *Psp, *Qsp;   // [nbus]
+  double* ivm;    // [nbus] 1 / |V| of the current iterate (NB == 1: written with e / f, so that the pair and mismatch phases of the
+                  // Newton loop read it instead of running a reciprocal chain per pair / bus)
   double *Sre, *Sim;                     // NB > 1: [nbus] bus injections S; NB == 1: the second column of the pseudo-slots
   double* Gs;     // [nbus] aliases e (shunt conductance: only needed before the Newton loop and by the DC results)
   double* inj;    // [n_inj] staged injection row (only when STAGE; otherwise the lane's row in HBM/L2 is read directly)
@@ -213,7 +215,7 @@ __host__ __device__ inline size_t lds_bytes_instance(const GridDev& g, int nslot
   size_t a_d = NB == 1 ? (rs0 + rows) * 4 : (size_t)nslot * BS * BS;
   const size_t topo_d = (((size_t)g.dim_topo + 1) / 2 + 2) & ~(size_t)1;
   if (a_d < topo_d) a_d = topo_d;
-  const size_t nd = a_d + (size_t)nslot_y * NB * NB * 2 + (NB == 1 ? 6 * nbus : rows * BS + 8 * nbus) + (stage_inj ? (size_t)g.n_inj : 0) +
+  const size_t nd = a_d + (size_t)nslot_y * NB * NB * 2 + (NB == 1 ? 7 * nbus : rows * BS + 8 * nbus) + (stage_inj ? (size_t)g.n_inj : 0) +
                     (dcf ? (size_t)nslot : 0);
   const size_t ni = 2 * nbus;
   const size_t n16 = 2 * (size_t)g.n_line + g.n_gen + g.n_load + g.n_sto + g.n_shunt;
@@ -288,6 +290,7 @@ __device__ inline void carve_sparse(CarveP<NB>& c, unsigned char* base, const Gr
   c.rhs = d; if (NB > 1) d += rows * BS;
   c.vm = d; d += nbus; c.va = d; d += nbus; c.e = d; c.Gs = d; d += nbus; c.f = d; c.lab = reinterpret_cast<int*>(d); d += nbus;
   c.Psp = d; d += nbus; c.Qsp = d; d += nbus;
+  c.ivm = d; if (NB == 1) d += nbus;
   c.Sre = d; if (NB > 1) d += nbus;
   c.Sim = d; if (NB > 1) d += nbus;
   c.inj = d; if (stage_inj) d += g.n_inj;
@@ -1152,6 +1155,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       fast_sincos(va, sn_, co);
       c.e[i] = vmi * co;
       c.f[i] = vmi * sn_;
+      if (NB == 1) c.ivm[i] = fast_rcp(vmi);
       *SreP(i) = 0.0;
       *SimP(i) = 0.0;
       if (WPI > 1) { *rhsT(i) = 0.0; *rhsV(i) = 0.0; }      // wavefront 1's partial sums of S (see acc_lane above)
@@ -1182,13 +1186,12 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         auto upair_item = [&](const unsigned w0, const unsigned w1, const double2 yuv, const double2 yvu) {
           const int u = (int)(w0 & 0xffffu), v = (int)(w0 >> 16), suv = (int)(w1 & 0xffffu), svu = (int)(w1 >> 16);
           const int btu = c.btype[u], btv = c.btype[v];
-          const double eu = c.e[u], fu = c.f[u], vmu = c.vm[u], ev = c.e[v], fv = c.f[v], vmv = c.vm[v];
+          const double eu = c.e[u], fu = c.f[u], ivmu = c.ivm[u], ev = c.e[v], fv = c.f[v], ivmv = c.ivm[v];
           double tr_, ti_, sr_, si_;
           t_of(yuv, eu, fu, ev, fv, tr_, ti_);
           t_of(yvu, ev, fv, eu, fu, sr_, si_);
           const bool act = (btu != BT_OFF) && (btv != BT_OFF);
           const bool uP = (btu == BT_PQ || btu == BT_PV), uQ = (btu == BT_PQ), vP = (btv == BT_PQ || btv == BT_PV), vQ = (btv == BT_PQ);
-          const double ivmu = fast_rcp(vmu), ivmv = fast_rcp(vmv);
           *reinterpret_cast<double2*>(bel(suv, 0, 0)) = make_double2((uP && vP) ? ti_ : 0.0, (uP && vQ) ? tr_ * ivmv : 0.0);
           *reinterpret_cast<double2*>(bel(suv, 1, 0)) = make_double2((uQ && vP) ? -tr_ : 0.0, (uQ && vQ) ? ti_ * ivmv : 0.0);
           *reinterpret_cast<double2*>(bel(svu, 0, 0)) = make_double2((vP && uP) ? si_ : 0.0, (vP && uQ) ? sr_ * ivmu : 0.0);
@@ -1247,7 +1250,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         if (WPI > 1) { Sr += *rhsT(i); Si += *rhsV(i); }       // + wavefront 1's partial sums, always in this order
         const double vmi = c.vm[i], psp = c.Psp[i], qsp = c.Qsp[i];
         const bool rowP = (bt == BT_PQ || bt == BT_PV), rowQ = (bt == BT_PQ);
-        const double ivmi = fast_rcp(vmi);
+        const double ivmi = NB == 1 ? c.ivm[i] : fast_rcp(vmi);
         double2 r0, r1;
         if (NB == 1) {                           // the diagonal block (i, i) is built here: T_ii joins S_i last
           const double2 y = YR ? yreg[2 * YR_PASSES] : *reinterpret_cast<const double2*>(c.Yb + (size_t)i * 2);
@@ -1309,6 +1312,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         fast_sincos(va, sn_, co);
         c.e[i] = vm * co;
         c.f[i] = vm * sn_;
+        if (NB == 1) c.ivm[i] = fast_rcp(vm);
         *SreP(i) = 0.0;
         *SimP(i) = 0.0;
         if (WPI > 1) { *rhsT(i) = 0.0; *rhsV(i) = 0.0; }
