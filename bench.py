@@ -225,7 +225,7 @@ def setup_engine(ctx, m, ch, n_envs, fan=1):
     return eng, T, lane0
 
 
-def oracle_spot_check(ctx, eng, n_lanes=32, t_last=None, rebalance=1.02, is_dc=False, seed=0):
+def oracle_spot_check(ctx, eng, n_lanes=32, t_last=None, rebalance=1.02, is_dc=False, seed=0, alive_only=False):
     """CHECKER leg (never timed, never the product): re-solve a sample of lanes with the C oracle and compare with what the engine
     holds after the timed workload.  `t_last` given (DoNothing workloads without trips): the oracle recomputes the step from the
     chronics table (covers the device-side chronics gather); otherwise from the injection / topology rows the lanes hold."""
@@ -233,7 +233,10 @@ def oracle_spot_check(ctx, eng, n_lanes=32, t_last=None, rebalance=1.02, is_dc=F
         return None
     try:
         from oracle import spot_check
-        lanes = np.sort(np.random.default_rng(seed).choice(eng.n_lanes, min(n_lanes, eng.n_lanes), replace=False))
+        pool = np.arange(eng.n_lanes)
+        if alive_only:       # auto_reset workloads: a lane whose LAST step failed already holds its reset topology (results NaN): not comparable
+            pool = np.nonzero(eng.results(with_bus=False).status[:, 0] == 0)[0]
+        lanes = np.sort(np.random.default_rng(seed).choice(pool, min(n_lanes, pool.size), replace=False))
         if t_last is not None:
             tab, off, sc = eng.bench_inputs
             r = eng.results(with_bus=False)
@@ -507,7 +510,7 @@ def main():
                     frac_converged=float(rc.converged.mean()),
                     frac_lanes_with_a_tripped_line=float((~rc.line_status).any(axis=1).mean()),
                     frac_lanes_resolved_in_last_step=float((rounds > 0).mean()), lane_resets=int(np.asarray(n_resets).sum()),
-                    oracle_check=oracle_spot_check(ctx, eng, 32, seed=2))
+                    oracle_check=oracle_spot_check(ctx, eng, 32, seed=2, alive_only=True))
             eng.set_trajectory(0)
             eng.set_thermal_limits(ch["thermal_limits"])
         eng.reset()
@@ -554,6 +557,17 @@ def main():
         sec = workload_wcci(ctx, "l2rpn_wcci_2022_dev", 1024, k_sec, w_sec, args.cascade)
         if rank == 0:
             res["secondary"] = sec
+
+    # ---- configs[3] with the environment's injection dynamics evolving INSIDE the launch (storage state of charge, ramp-limited
+    #      redispatch re-solved at every step) -- what "storage + redispatch actions" means for agents that act
+    if secondary:
+        dyn = workload_wcci_dynamics(ctx, "l2rpn_wcci_2022_dev", 1024, k_sec, w_sec)
+        if rank == 0:
+            res["secondary_env_dynamics"] = dyn
+
+    # ---- batched obs.simulate: B environments x K candidate actions on the 1-step-ahead forecast, one call --------------------
+    if secondary and world == 1:
+        res["simulate_batch"] = workload_simulate(ctx, args.env, 256, 16)
 
     # ---- DC sensitivity path of BASELINE.json configs[4]: l2rpn_idf_2023, 2048 lanes, PTDF GEMM next to the AC solve ------------
     if secondary and world == 1:
@@ -636,6 +650,102 @@ def workload_wcci(ctx, env, n_envs, k_sec, w_sec, cascade):
                "hbm_gbs": b2 * B * (k_sec / max(n_l, 1)) / (us * 1e-6) / 1e9 if us > 0 else 0.0,
                "frac_converged": float(r.converged.mean()), "mean_nr_iterations": float(r.n_iter[r.converged].mean()),
                "oracle_check": oracle_spot_check(ctx, eng, 32, seed=5)}
+    eng.close()
+    return out
+
+
+def workload_wcci_dynamics(ctx, env, n_envs, k_sec, w_sec):
+    """configs[3] with gpf_set_env_dynamics: every lane holds a storage action U(-2, 2) MW per unit over the launch and starts it with a
+    zero-sum +-1 MW redispatch on two generators; the kernel evolves the state of charge and re-solves the ramp-limited dispatch
+    (BaseEnv._compute_dispatch_vect) at every step.  Generator / storage characteristics: tests/golden/envdyn_<env>.npz (recorded from
+    the reference environment)."""
+    m, ch = load_env(env)
+    fxp = os.path.join(GOLD, f"envdyn_{env}.npz")
+    if not os.path.exists(fxp) or ctx.args.stub_engine:
+        return None
+    fx = dict(np.load(fxp))
+    eng, T, l0 = setup_engine(ctx, m, ch, n_envs)
+    B = n_envs
+    eng.set_gen_limits(fx["pmin"], fx["pmax"], fx["ramp_up"], fx["ramp_down"], fx["redispatchable"], eps_poly=float(fx["eps_poly"]))
+    eng.set_storage_params(fx["storage_Emax"], fx["storage_Emin"], fx["storage_loss"], fx["storage_charging_efficiency"],
+                           fx["storage_discharging_efficiency"], fx["storage_charge0"], float(fx["delta_time_seconds"]),
+                           bool(fx["activate_storage_loss"]))
+    eng.set_env_dynamics(True, tol_poly=float(fx["tol_poly"]))
+    disp = np.nonzero(fx["redispatchable"] & ~m.gen_slack)[0]
+    red = np.zeros((B, m.n_gen), np.float32)
+    sto = np.zeros((B, m.n_storage), np.float32)
+    for k in range(B):
+        rg = np.random.default_rng(20_000_000 + l0 + k)
+        a, b = rg.choice(disp, size=2, replace=False)
+        red[k, a], red[k, b] = 1.0, -1.0
+        sto[k] = rg.uniform(-2.0, 2.0, m.n_storage)
+    spl = ctx.args.steps_per_launch
+    kw = dict(rebalance=1.02, auto_reset=True)
+
+    def run(t, n):
+        done = 0
+        while done < n:
+            k = min(spl, n - done)
+            eng.set_lane_actions(red, sto, hold_storage=True)      # the agents act at every launch boundary
+            eng.step(t + done, n_steps=k, **kw)
+            done += k
+        return t + n
+    t = run(0, max(w_sec, spl))
+    wins = []
+    for _ in range(3):
+        ctx.sync_all(eng)
+        w0 = time.perf_counter()
+        t = run(t, k_sec)
+        ctx.sync_all(eng)
+        wins.append((ctx.max(time.perf_counter() - w0), 0.0, 0))
+    med = median_window(wins)[0]
+    r = eng.results()
+    st = eng.env_state()
+    out = None
+    if ctx.rank == 0:
+        out = {"workload": f"{env} (118 substations), batch={B} lanes per GPU, environment injection dynamics ON (gpf_set_env_dynamics): per lane a "
+                           f"held storage action U(-2,2) MW per unit and a zero-sum +-1 MW redispatch at every launch boundary ({spl} steps); the "
+                           "state of charge and the ramp-limited dispatch (BaseEnv._compute_dispatch_vect, exact QP) evolve at every step "
+                           "inside the launch (BASELINE.json configs[3]: storage + redispatch actions); actions uploaded from the host per launch",
+               "value": ctx.world * B * k_sec / med, "unit": "env steps/sec", "ms_per_step": med / k_sec * 1e3, "steps_each": k_sec,
+               "windows": summarize(wins, ctx.world * B * k_sec), "frac_converged": float(r.converged.mean()),
+               "frac_infeasible_redispatch": float((r.status[:, 0] == 6).mean()),
+               "mean_abs_actual_dispatch_mw": float(np.abs(st["actual"]).mean()), "mean_state_of_charge_mwh": float(st["charge"].mean()),
+               "oracle_check": oracle_spot_check(ctx, eng, 32, seed=7, alive_only=True)}
+    eng.close()
+    return out
+
+
+def workload_simulate(ctx, env, n_envs, n_act):
+    """Batched obs.simulate (gpf_simulate_batch): `n_envs` environments x `n_act` candidate actions (do nothing + single-line
+    disconnections) on the 1-step-ahead forecast, ONE call = host topology bookkeeping + device copy + one launch.  Synthetic forecast
+    tables: the next chronics row."""
+    if ctx.args.stub_engine:
+        return None
+    m, ch = load_env(env)
+    eng, T, l0 = setup_engine(ctx, m, ch, n_envs * (1 + n_act))          # lanes [0, n_envs) = environments, the rest scratch
+    tab = eng.bench_inputs[0]
+    eng.upload_forecasts(np.roll(tab, -1, axis=0)[None])
+    cands = [{}] + [{"set_line_status": [(l, -1)]} for l in range(min(n_act - 1, m.n_line))]
+    eng.step(0, n_steps=4, rebalance=1.02)
+    src = np.arange(n_envs)
+    kw = dict(rebalance=1.02, cascade=True)
+    for _ in range(3):
+        eng.simulate_batch(3, src, cands, dst_lane0=n_envs, time_step=1, **kw)
+    eng.sync()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.simulate_batch(3, src, cands, dst_lane0=n_envs, time_step=1, **kw)
+    eng.sync()
+    el = time.perf_counter() - t0
+    r = eng.results(n_envs, n_envs * len(cands), with_bus=False)
+    out = {"workload": f"{env}: {n_envs} environments x {len(cands)} candidate actions (do nothing + single-line disconnections), forecast "
+                       "1 step ahead, overflow cascade on: one gpf_simulate_batch call per batch (obs.simulate, "
+                       "Observation/baseObservation.py:3365-3670)",
+           "value": n_envs * len(cands) * reps / el, "unit": "simulated (environment, action) pairs/sec, wall clock incl. the host-side "
+           "topology bookkeeping of every call", "ms_per_call": el / reps * 1e3, "frac_converged": float(r.converged.mean()),
+           "oracle_check": oracle_spot_check(ctx, eng, 32, seed=8)}
     eng.close()
     return out
 

@@ -1551,25 +1551,37 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
 
 // ---- environment injection dynamics (EnvDyn) ----------------------------------------------------------------------------------
 // One lane of an aligned group of LW lanes (a power of two <= 64, inside one wavefront) per generator / storage unit; reductions
-// over the group by xor-butterflies (lanes of other groups of the wavefront run their own instance).
-template <int LW>
-__device__ __forceinline__ double env_gsum(double v) {
-#pragma unroll
-  for (int off = LW / 2; off; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+// over the group with DPP moves (lanes of other groups of the wavefront run their own instance).
+// (DPP cross-lane moves in the VALU: a ds_bpermute butterfly costs an LDS round trip per step, and the projection below runs ~100
+//  reductions per env step.)  KIND 0: sum, 1: min, 2: max.  Lanes that a DPP control leaves untouched keep `old`: the identity of the
+// operation (0 for the sum, the lane's own value for min / max).
+template <int KIND, int CTRL, int ROW_MASK>
+__device__ __forceinline__ double env_dpp_step(double v) {
+  const int lo_ = __double2loint(v), hi_ = __double2hiint(v);
+  const int lo = __builtin_amdgcn_update_dpp(KIND == 0 ? 0 : lo_, lo_, CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(KIND == 0 ? 0 : hi_, hi_, CTRL, ROW_MASK, 0xF, false);
+  const double o = __hiloint2double(hi, lo);
+  return KIND == 0 ? v + o : KIND == 1 ? fmin(v, o) : fmax(v, o);
 }
-template <int LW>
-__device__ __forceinline__ double env_gmin(double v) {
-#pragma unroll
-  for (int off = LW / 2; off; off >>= 1) v = fmin(v, __shfl_xor(v, off));
-  return v;
+template <int LW, int KIND>
+__device__ __forceinline__ double env_greduce(double v) {
+  v = env_dpp_step<KIND, 0xB1, 0xF>(v);                // quad_perm [1,0,3,2]
+  v = env_dpp_step<KIND, 0x4E, 0xF>(v);                // quad_perm [2,3,0,1]
+  v = env_dpp_step<KIND, 0x141, 0xF>(v);               // row_half_mirror
+  v = env_dpp_step<KIND, 0x140, 0xF>(v);               // row_mirror: every lane of a 16-lane row holds the row's result
+  if (LW == 16) return v;
+  v = env_dpp_step<KIND, 0x142, 0xA>(v);               // row_bcast15 into rows 1 and 3: lanes of rows 1 / 3 hold rows 0+1 / 2+3
+  if (LW == 32) {
+    const double s0 = readlane_f64(v, 31), s1 = readlane_f64(v, 63);
+    return (threadIdx.x & 32) ? s1 : s0;
+  }
+  v = env_dpp_step<KIND, 0x143, 0xC>(v);               // row_bcast31 into rows 2 and 3: lane 63 holds the wavefront's result
+  return readlane_f64(v, 63);
 }
-template <int LW>
-__device__ __forceinline__ double env_gmax(double v) {
-#pragma unroll
-  for (int off = LW / 2; off; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-  return v;
-}
+template <int LW> __device__ __forceinline__ double env_gsum(double v) { return env_greduce<LW, 0>(v); }
+template <int LW> __device__ __forceinline__ double env_gmin(double v) { return env_greduce<LW, 1>(v); }
+template <int LW> __device__ __forceinline__ double env_gmax(double v) { return env_greduce<LW, 2>(v); }
+constexpr int ENV_BISECT = 52;    // halvings of the multiplier bracket: 2^-52 of a bracket of a few hundred MW is below the float32 state
 // per-lane registers of the dynamics (lane k = generator k and storage unit k of the instance)
 struct EnvRegs {
   float target, actual, prev_p, charge, amount_prev;
@@ -1668,10 +1680,10 @@ __device__ inline bool env_dynamics_step(const EnvDyn& E, int k, int n_gen, int 
       double lam = 0.0;
       int free_at = 0;
       if (rhs - s0 > f_hi) { free_at = 1; double a_ = lam_lo, b_ = 0.0;
-        for (int it = 0; it < 64; ++it) { const double mid = 0.5 * (a_ + b_); if (sum_mod(mid) + f_hi > rhs) a_ = mid; else b_ = mid; }
+        for (int it = 0; it < ENV_BISECT; ++it) { const double mid = 0.5 * (a_ + b_); if (sum_mod(mid) + f_hi > rhs) a_ = mid; else b_ = mid; }
         lam = 0.5 * (a_ + b_);
       } else if (rhs - s0 < f_lo) { free_at = -1; double a_ = 0.0, b_ = lam_hi;
-        for (int it = 0; it < 64; ++it) { const double mid = 0.5 * (a_ + b_); if (sum_mod(mid) + f_lo > rhs) a_ = mid; else b_ = mid; }
+        for (int it = 0; it < ENV_BISECT; ++it) { const double mid = 0.5 * (a_ + b_); if (sum_mod(mid) + f_lo > rhs) a_ = mid; else b_ = mid; }
         lam = 0.5 * (a_ + b_);
       }
       if (pm) x = fmin(fmax(tv - lam / (2.0 * w), lo), hi);
@@ -1686,7 +1698,7 @@ __device__ inline bool env_dynamics_step(const EnvDyn& E, int k, int n_gen, int 
         const double r = rhs - got;
         double a_ = env_gmin<LW>(pf ? fmin(lo * w, hi * w) : 1e300), b_ = env_gmax<LW>(pf ? fmax(lo * w, hi * w) : -1e300);
         if (a_ <= b_) {
-          for (int it = 0; it < 64; ++it) {
+          for (int it = 0; it < ENV_BISECT; ++it) {
             const double mid = 0.5 * (a_ + b_);
             const double sm = env_gsum<LW>(pf ? fmin(fmax(mid / w, lo), hi) : 0.0);
             if (sm < r) a_ = mid; else b_ = mid;

@@ -3,6 +3,7 @@ FETCH_SIZE / WRITE_SIZE PMC passes, LDS pipe figures).  usage: python tools/make
 import json, re, sys
 txt = open(sys.argv[1]).read()
 steps_per_launch = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+alg_bytes_per_launch = float(sys.argv[3]) if len(sys.argv) > 3 else None      # algorithmic bytes of one launch (bench.py: bytes/step x lanes x steps)
 def ctr(name):
     m = re.search(rf"^\s*{name} =\s+([0-9.]+)\s+\(n=\d+, avg dispatch ([0-9.]+) us\)\s+(.*)$", txt, re.M)
     return (float(m.group(1)), float(m.group(2)), m.group(3).strip()) if m else (None, None, None)
@@ -18,7 +19,9 @@ avg_us = int(geo.group(2)) / 1e3
 clk_ghz = 2.4
 out = {
     "source": sys.argv[1], "kernel": kern, "env_steps_per_launch": steps_per_launch,
-    "kernel_trace_avg_us": avg_us, "lds_bytes_per_block": int(geo.group(3)), "vgpr": int(geo.group(4)),
+    "kernel_trace_avg_us": avg_us, "avg_launch_us": avg_us,
+    "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+    "traffic_over_algorithmic": ((2.0 * fetch + write) * 1024.0 / alg_bytes_per_launch) if alg_bytes_per_launch else None, "lds_bytes_per_block": int(geo.group(3)), "vgpr": int(geo.group(4)),
     "fetch_size_kib": fetch, "write_size_kib": write,
     # MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read -> doubled; WRITE_SIZE as reported
     "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
