@@ -484,7 +484,7 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
     q.yreg = false;
     // Ybus blocks in registers (2 wavefronts per instance, tables in global memory, at most 4 pairs per lane): when the LDS they
     // free holds the factored DC matrix without costing a block per CU, every step of a launch skips the DC assembly + factorisation
-    if (nbk == 1 && !listed && ipw == 1 && q.wpi == 2 && stage == 0 && !e->no_yreg && !e->env_on && e->dcf_env != 0 && (e->sym.nslot_y - e->g.n_sub) / 2 <= 4 * 128 && e->g.n_sub <= 128) {
+    if (nbk == 1 && !listed && ipw == 1 && q.wpi == 2 && stage == 0 && !e->no_yreg && e->dcf_env != 0 && (e->sym.nslot_y - e->g.n_sub) / 2 <= 4 * 128 && e->g.n_sub <= 128) {
       const size_t ly = gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, 0, 0, false, 1, -1, true);
       if (ly <= LDS_HARD_LIMIT && LDS_HARD_LIMIT / ly >= std::min<size_t>(LDS_HARD_LIMIT / l, want)) { q.yreg = true; q.dcf = 1; q.lds = ly; }
     }

@@ -41,7 +41,10 @@ hipError_t gpf_launch_step_sparse(const LaunchPlan& p, int device, const gpf::De
     }
     if (p.ipw == 4) GOE(2, 4, 1, false);
     if (p.ipw == 2) GOE(2, 2, 1, false);
-    if (p.wpi == 2) GOE(0, 1, 2, false);
+    if (p.wpi == 2) {
+      if (p.yreg) return launch<1, 0, 1, 2, false, true, true>(LAUNCH_ARGS);
+      GOE(0, 1, 2, false);
+    }
     GOE(0, 1, 1, false);
   }
   if (p.tc) {
