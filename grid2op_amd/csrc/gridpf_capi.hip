@@ -150,7 +150,9 @@ struct gpf_engine {
   int env_loss_on = 1;
   double env_coeff = 300.0 / 3600.0, env_tol = 1e-2;
   DevArr<float> env_target, env_actual, env_prev, env_charge, env_amount_prev, env_act_redisp, env_act_storage, sto_charge0;
-  DevArr<unsigned char> env_already, env_fresh;
+  DevArr<float> env_limit, env_curt_prev, env_act_curtail;
+  DevArr<unsigned char> env_already, env_fresh, env_renewable;
+  bool env_act_c = false, env_has_ren = false;
   DevArr<double> sto_emax, sto_emin, sto_loss, sto_effc, sto_effd;
   std::vector<float> h_charge0;
   DevArr<float> forecast;               // [chron_tables][chron_T][fc_h][n_chron] *_forecasted tables (gpf_upload_forecasts), or empty
@@ -591,6 +593,8 @@ int upload_params_s(gpf_engine* e, const gpf::Bufs& b, const LaunchPlan* tc, int
     E.target = e->env_target.p; E.actual = e->env_actual.p; E.prev_p = e->env_prev.p; E.already = e->env_already.p; E.charge = e->env_charge.p;
     E.amount_prev = e->env_amount_prev.p; E.fresh = e->env_fresh.p;
     E.act_redisp = e->env_act_r ? e->env_act_redisp.p : nullptr; E.act_storage = e->env_act_s ? e->env_act_storage.p : nullptr;
+    E.limit = e->env_limit.p; E.curt_prev = e->env_curt_prev.p; E.act_curtail = e->env_act_c ? e->env_act_curtail.p : nullptr;
+    E.renewable = e->env_has_ren ? e->env_renewable.p : nullptr;
     E.pmin = e->rd_pmin.p; E.pmax = e->rd_pmax.p; E.ramp_up = e->rd_ru.p; E.ramp_down = e->rd_rd.p; E.redispatchable = e->rd_redisp.p;
     E.Emax = e->sto_emax.p; E.Emin = e->sto_emin.p; E.loss = e->sto_loss.p; E.eff_c = e->sto_effc.p; E.eff_d = e->sto_effd.p; E.charge0 = e->sto_charge0.p;
   }
@@ -637,6 +641,12 @@ int reset_env_state(gpf_engine* e, int lane0, int n) {
   HIP_TRY(hipMemsetAsync(e->env_prev.p + lane0 * ng, 0, n * ng * sizeof(float), e->stream));
   HIP_TRY(hipMemsetAsync(e->env_already.p + lane0 * ng, 0, n * ng, e->stream));
   HIP_TRY(hipMemsetAsync(e->env_amount_prev.p + lane0, 0, (size_t)n * sizeof(float), e->stream));
+  HIP_TRY(hipMemsetAsync(e->env_curt_prev.p + lane0, 0, (size_t)n * sizeof(float), e->stream));
+  {
+    std::vector<float> ones((size_t)n * ng, 1.0f);
+    HIP_TRY(hipMemcpyAsync(e->env_limit.p + lane0 * ng, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+  }
   HIP_TRY(hipMemsetAsync(e->env_fresh.p + lane0, 1, (size_t)n, e->stream));
   if (ns) {
     std::vector<float> c((size_t)n * ns);
@@ -985,6 +995,7 @@ int gpf_destroy(gpf_handle e) {
   e->env_target.release(); e->env_actual.release(); e->env_prev.release(); e->env_charge.release(); e->env_amount_prev.release();
   e->env_act_redisp.release(); e->env_act_storage.release(); e->sto_charge0.release(); e->env_already.release(); e->env_fresh.release();
   e->sto_emax.release(); e->sto_emin.release(); e->sto_loss.release(); e->sto_effc.release(); e->sto_effd.release();
+  e->env_limit.release(); e->env_curt_prev.release(); e->env_act_curtail.release(); e->env_renewable.release();
   e->rd_pmin.release(); e->rd_pmax.release(); e->rd_ru.release(); e->rd_rd.release(); e->rd_in.release(); e->rd_redisp.release();
   e->rd_u8.release(); e->rd_after.release();
   e->topo0.release(); e->done.release(); e->episode.release(); e->lane_gen_delta.release(); e->traj_rho.release(); e->traj_status.release();
@@ -1445,6 +1456,7 @@ int gpf_step_n(gpf_handle e, int32_t t0, int32_t n_steps, const gpf_step_opts* o
   if (e->env_on) {                          // the actions were consumed by this launch (a held storage action stays)
     if (e->env_act_r) { HIP_TRY(hipMemsetAsync(e->env_act_redisp.p, 0, e->env_act_redisp.n * sizeof(float), e->stream)); e->env_act_r = false; }
     if (e->env_act_s && !e->env_hold) { HIP_TRY(hipMemsetAsync(e->env_act_storage.p, 0, e->env_act_storage.n * sizeof(float), e->stream)); e->env_act_s = false; }
+    e->env_act_c = false;                   // (the curtailment limits live on in the lanes' state)
   }
   return GPF_OK;
 }
@@ -1481,12 +1493,13 @@ int gpf_set_env_dynamics(gpf_handle e, int32_t on, double tol_poly) {
     HIP_TRY(e->env_target.alloc(B * ng)); HIP_TRY(e->env_actual.alloc(B * ng)); HIP_TRY(e->env_prev.alloc(B * ng)); HIP_TRY(e->env_already.alloc(B * ng));
     HIP_TRY(e->env_charge.alloc(B * ns)); HIP_TRY(e->env_amount_prev.alloc(B)); HIP_TRY(e->env_fresh.alloc(B));
     HIP_TRY(e->env_act_redisp.alloc(B * ng)); HIP_TRY(e->env_act_storage.alloc(B * ns));
+    HIP_TRY(e->env_limit.alloc(B * ng)); HIP_TRY(e->env_curt_prev.alloc(B)); HIP_TRY(e->env_act_curtail.alloc(B * ng));
     HIP_TRY(hipMemset(e->env_act_redisp.p, 0, B * ng * sizeof(float))); HIP_TRY(hipMemset(e->env_act_storage.p, 0, B * ns * sizeof(float)));
     HIP_TRY(hipMemset(e->env_charge.p, 0, B * ns * sizeof(float)));
   }
   e->env_on = true;
   e->env_tol = tol_poly > 0.0 ? tol_poly : 1e-2;
-  e->env_act_r = e->env_act_s = false; e->env_hold = false;
+  e->env_act_r = e->env_act_s = e->env_act_c = false; e->env_hold = false;
   e->params_s_valid = false;
   return reset_env_state(e, 0, e->cap_lanes);
 }
@@ -1505,29 +1518,54 @@ int gpf_set_lane_actions(gpf_handle e, const float* redispatch, const float* sto
   return GPF_OK;
 }
 
+int gpf_set_gen_renewable(gpf_handle e, const uint8_t* renewable) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_set_gen_renewable: null");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->env_renewable.release();
+  e->env_has_ren = false;
+  if (renewable) { HIP_TRY(e->env_renewable.upload(renewable, (size_t)e->g.n_gen)); e->env_has_ren = true; }
+  e->params_s_valid = false;
+  return GPF_OK;
+}
+
+int gpf_set_lane_curtailment(gpf_handle e, const float* limit) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_set_lane_curtailment: null");
+  if (!e->env_on || !e->env_has_ren) return fail(GPF_E_INVALID, "gpf_set_lane_curtailment: needs gpf_set_env_dynamics and gpf_set_gen_renewable");
+  HIP_TRY(hipSetDevice(e->device));
+  if (!limit) { e->env_act_c = false; return GPF_OK; }
+  const size_t n = (size_t)e->n_lanes * e->g.n_gen;
+  for (size_t i = 0; i < n; ++i) if (!(limit[i] == -1.0f || (limit[i] >= 0.0f && limit[i] <= 1.0f))) return fail(GPF_E_INVALID, "gpf_set_lane_curtailment: limits are ratios in [0, 1], -1 = no change");
+  HIP_TRY(hipMemcpyAsync(e->env_act_curtail.p, limit, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->env_act_c = true;
+  return GPF_OK;
+}
+
 int gpf_get_env_state(gpf_handle e, int32_t lane0, int32_t n, float* target, float* actual, float* prev_p, uint8_t* already_modified,
-                      float* charge, float* amount_prev) {
+                      float* charge, float* amount_prev, float* curtail_limit, float* curtail_prev) {
   if (!check_range(e, lane0, n)) return fail(GPF_E_INVALID, "gpf_get_env_state: bad range");
   if (!e->env_on) return fail(GPF_E_INVALID, "gpf_get_env_state: the environment dynamics are off");
   HIP_TRY(hipSetDevice(e->device));
   const size_t ng = e->g.n_gen, ns = e->g.n_sto;
 #define DLE(dst, arr, stride) if ((dst) && (stride) > 0) HIP_TRY(hipMemcpyAsync(dst, e->arr.p + (size_t)lane0 * (stride), (size_t)n * (stride) * sizeof(*e->arr.p), hipMemcpyDeviceToHost, e->stream))
   DLE(target, env_target, ng); DLE(actual, env_actual, ng); DLE(prev_p, env_prev, ng); DLE(already_modified, env_already, ng);
-  DLE(charge, env_charge, ns); DLE(amount_prev, env_amount_prev, 1);
+  DLE(charge, env_charge, ns); DLE(amount_prev, env_amount_prev, 1); DLE(curtail_limit, env_limit, ng); DLE(curtail_prev, env_curt_prev, 1);
 #undef DLE
   HIP_TRY(hipStreamSynchronize(e->stream));
   return GPF_OK;
 }
 
 int gpf_set_env_state(gpf_handle e, int32_t lane0, int32_t n, const float* target, const float* actual, const float* prev_p,
-                      const uint8_t* already_modified, const float* charge, const float* amount_prev) {
+                      const uint8_t* already_modified, const float* charge, const float* amount_prev, const float* curtail_limit,
+                      const float* curtail_prev) {
   if (!check_range(e, lane0, n)) return fail(GPF_E_INVALID, "gpf_set_env_state: bad range");
   if (!e->env_on) return fail(GPF_E_INVALID, "gpf_set_env_state: the environment dynamics are off");
   HIP_TRY(hipSetDevice(e->device));
   const size_t ng = e->g.n_gen, ns = e->g.n_sto;
 #define ULE(src, arr, stride) if ((src) && (stride) > 0) HIP_TRY(hipMemcpyAsync(e->arr.p + (size_t)lane0 * (stride), src, (size_t)n * (stride) * sizeof(*e->arr.p), hipMemcpyHostToDevice, e->stream))
   ULE(target, env_target, ng); ULE(actual, env_actual, ng); ULE(prev_p, env_prev, ng); ULE(already_modified, env_already, ng);
-  ULE(charge, env_charge, ns); ULE(amount_prev, env_amount_prev, 1);
+  ULE(charge, env_charge, ns); ULE(amount_prev, env_amount_prev, 1); ULE(curtail_limit, env_limit, ng); ULE(curtail_prev, env_curt_prev, 1);
 #undef ULE
   if (prev_p) HIP_TRY(hipMemsetAsync(e->env_fresh.p + lane0, 0, (size_t)n, e->stream));     // previous set-points given: not a fresh episode
   HIP_TRY(hipStreamSynchronize(e->stream));

@@ -103,9 +103,13 @@ struct EnvDyn {
   unsigned char* already;               // _already_modified_gen
   float* charge;                        // _storage_current_charge (MWh)
   float* amount_prev;                   // _amount_storage_prev
+  float* limit;                         // [B][n_gen] _limit_curtailment (ratio of pmax, 1 = not curtailed)
+  float* curt_prev;                     // [B] _sum_curtailment_mw_prev
   unsigned char* fresh;                 // [B] 1: no step since the reset (nb_time_step == 0: prev_p := the step's own set-points)
   // per-lane actions of the NEXT launch [B][n_gen] / [B][n_storage]: redispatch is consumed by the first step
   const float *act_redisp, *act_storage;
+  const float* act_curtail;             // [B][n_gen] curtailment action (ratio of pmax; -1 = no change), consumed by the first step
+  const unsigned char* renewable;       // [n_gen] gen_renewable (null: no curtailment)
   // characteristics [n_gen] / [n_storage]
   const double *pmin, *pmax, *ramp_up, *ramp_down;
   const unsigned char* redispatchable;

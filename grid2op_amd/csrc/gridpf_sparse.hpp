@@ -1584,7 +1584,7 @@ template <int LW> __device__ __forceinline__ double env_gmax(double v) { return 
 constexpr int ENV_BISECT = 52;    // halvings of the multiplier bracket: 2^-52 of a bracket of a few hundred MW is below the float32 state
 // per-lane registers of the dynamics (lane k = generator k and storage unit k of the instance)
 struct EnvRegs {
-  float target, actual, prev_p, charge, amount_prev;
+  float target, actual, prev_p, charge, amount_prev, limit, curt_prev;
   bool already, fresh;
 };
 // One env step of the dynamics for the caller's instance.  new_p: chronics set-point of generator `k` (after the environment's own
@@ -1592,7 +1592,7 @@ struct EnvRegs {
 // Returns the storage power of unit k (MW, load convention) in `sto_power`, false when the reference would end the episode
 // (ImpossibleRedispatching, baseEnv.py:3227-3247).  Follows oracle/env_oracle.py InjectionDynamics.step line by line.
 template <int LW>
-__device__ inline bool env_dynamics_step(const EnvDyn& E, int k, int n_gen, int n_sto, float new_p_f, float act_r, float act_s,
+__device__ inline bool env_dynamics_step(const EnvDyn& E, int k, int n_gen, int n_sto, float& new_p_f, float act_r, float act_s, float act_c,
                                          EnvRegs& R, float& sto_power) {
   const bool is_gen = k < n_gen, is_sto = k < n_sto;
   // ---- _compute_storage (:2829-2905) + _withdraw_storage_losses (:2777-2790)
@@ -1630,6 +1630,27 @@ __device__ inline bool env_dynamics_step(const EnvDyn& E, int k, int n_gen, int 
     if (E.loss_on && is_sto) R.charge = fmaxf(R.charge - (float)(E.loss[k] * E.coeff), 0.f);
     sto_power = pw;
   }
+  // ---- _aux_handle_curtailment_without_limit (:2956-2982): renewable generators capped at limit * pmax; the change of the curtailed
+  //      total against the previous step joins the right-hand side of the projection.  new_p_f comes back curtailed.
+  double sum_curt = 0.0;
+  if (E.renewable) {
+    const bool ren = is_gen && E.renewable[k] != 0;
+    const bool has_act = env_gmax<LW>((ren && act_c != -1.0f) ? 1.0 : 0.0) > 0.0;
+    const bool any_lim = env_gmax<LW>((is_gen && fabsf(R.limit - 1.0f) >= 1e-7f) ? 1.0 : 0.0) > 0.0;
+    if (has_act || any_lim) {
+      if (ren && act_c != -1.0f) R.limit = act_c;
+      const bool gc = is_gen && fabsf(R.limit - 1.0f) >= 1e-7f;
+      const float before = new_p_f;
+      if (gc) new_p_f = fminf((float)(E.pmax[k] * (double)R.limit), new_p_f);
+      const double s_new = env_gsum<LW>(gc ? (double)new_p_f : 0.0), s_old = env_gsum<LW>(gc ? (double)before : 0.0);
+      const float tmp = (float)((double)(float)s_new - (double)(float)s_old);
+      sum_curt = (double)tmp - (double)R.curt_prev;
+      R.curt_prev = tmp;
+    } else {
+      sum_curt = -(double)R.curt_prev;
+      R.curt_prev = 0.f;
+    }
+  }
   // ---- _get_already_modified_gen (:2101-2115)
   if (is_gen && fabsf(act_r) > 1e-7f) {
     R.target = R.already ? R.target + act_r : R.actual + act_r;
@@ -1640,7 +1661,7 @@ __device__ inline bool env_dynamics_step(const EnvDyn& E, int k, int n_gen, int 
   const double s_act = env_gsum<LW>(is_gen ? (double)R.actual : 0.0);
   const double m_mis = env_gmax<LW>(is_gen ? fabs((double)R.actual - (double)R.target) : 0.0);
   bool ok = true;
-  if (fabs((double)(float)s_act) >= tol || m_mis >= tol || fabs(amount) >= tol) {
+  if (fabs((double)(float)s_act) >= tol || m_mis >= tol || fabs(amount) >= tol || fabs(sum_curt) >= tol) {
     // ---- _compute_dispatch_vect (:2211-2470): the separable QP of gridpf_redispatch.hpp, one generator per lane
     const double np_ = (double)new_p_f, a = (double)R.actual, t = (double)R.target;
     const double pv = R.fresh ? np_ : (double)R.prev_p;
@@ -1665,7 +1686,7 @@ __device__ inline bool env_dynamics_step(const EnvDyn& E, int k, int n_gen, int 
     }
     s_incr = env_gsum<LW>(s_incr); s_up = env_gsum<LW>(s_up); s_down = env_gsum<LW>(s_down); s_coef = env_gsum<LW>(s_coef);
     const int n_mod = (int)env_gsum<LW>(part && mod ? 1.0 : 0.0);
-    const double rhs = amount;
+    const double rhs = amount - sum_curt;                      // storage - curtailment (+ detached: not modelled) (:2335-2340)
     const double sum_move = s_incr + rhs;
     if (sum_move > s_up || sum_move < s_down) ok = false;
     if (part) { w /= s_coef; if (n_mod == 0) mod = true; }
@@ -1770,20 +1791,23 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   constexpr int LWE = GW < WAVE ? GW : WAVE;
   constexpr bool env_on = ENV && NB == 1;                       // single-busbar kernels (incl. topology classes) only
   EnvRegs er;
-  er.target = er.actual = er.prev_p = er.charge = er.amount_prev = 0.f; er.already = false; er.fresh = true;
-  float env_ar0 = 0.f, env_as0 = 0.f;
+  er.target = er.actual = er.prev_p = er.charge = er.amount_prev = er.curt_prev = 0.f; er.limit = 1.f; er.already = false; er.fresh = true;
+  float env_ar0 = 0.f, env_as0 = 0.f, env_ac0 = -1.f;
   if (env_on && tid < LWE) {
     const EnvDyn& E = P->env;
     if (tid < g.n_gen) {
       const size_t q = (size_t)inst * g.n_gen + tid;
       er.target = gptr(E.target)[q]; er.actual = gptr(E.actual)[q]; er.prev_p = gptr(E.prev_p)[q]; er.already = gptr(E.already)[q] != 0;
       if (E.act_redisp) env_ar0 = gptr(E.act_redisp)[q];
+      er.limit = gptr(E.limit)[q];
+      if (E.act_curtail) env_ac0 = gptr(E.act_curtail)[q];
     }
     if (tid < g.n_sto) {
       er.charge = gptr(E.charge)[(size_t)inst * g.n_sto + tid];
       if (E.act_storage) env_as0 = gptr(E.act_storage)[(size_t)inst * g.n_sto + tid];
     }
     er.amount_prev = gptr(E.amount_prev)[inst];
+    er.curt_prev = gptr(E.curt_prev)[inst];
     er.fresh = gptr(E.fresh)[inst] != 0;
   }
   bool env_fail = false;                                       // this group's dynamics ended the episode in the current step
@@ -1872,13 +1896,15 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       }
       GPF_STAMPS(18);
       env_fail = false;
+      float env_np = 0.f;
       if (env_on && (WPI == 1 || tid < WAVE)) {                  // (wavefront-uniform: the whole wavefront takes part in the reductions)
         float np_k = tid < g.n_gen ? pp_pre : 0.f;
         if (tid < g.n_gen && !sv.gen_slack[tid]) np_k *= scale_p;
         float sto_pw = 0.f;
         const bool ok_e = env_dynamics_step<LWE>(P->env, tid, g.n_gen, g.n_sto, np_k, step == 0 ? env_ar0 : 0.f,
-                                                 (step == 0 || P->env.hold_storage) ? env_as0 : 0.f, er, sto_pw);
+                                                 (step == 0 || P->env.hold_storage) ? env_as0 : 0.f, step == 0 ? env_ac0 : -1.f, er, sto_pw);
         env_fail = !ok_e;
+        env_np = np_k;                                            // the (curtailed) chronics set-point of generator tid
         if (tid < g.n_sto) {                                      // the storage power the backend gets (set_storage, baseEnv.py:3831)
           if (STAGE) c.inj[oo.inj_sto_p + tid] = (double)sto_pw;
           else inj_g[oo.inj_sto_p + tid] = (double)sto_pw;
@@ -1888,7 +1914,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       for (int i = tid; i < g.n_gen; i += gw9) {
         float pp = (i == tid) ? pp_pre : ch[2 * g.n_load + i];
         if (!sv.gen_slack[i]) pp *= scale_p;
-        if (env_on) pp += er.actual;                              // set_redispatch (:3830): chronics + actual dispatch, float32 (n_gen <= lanes: i == tid)
+        if (env_on) pp = env_np + er.actual;                              // set_redispatch (:3830): chronics + actual dispatch, float32 (n_gen <= lanes: i == tid)
         if (has_delta) pp += (i == tid) ? gd0 : gdelta[i];
         const float pv_kv = (i == tid) ? pv_pre : ch[2 * g.n_load + g.n_gen + i];
         const float vn = (float)sv.gen_vn[i];
@@ -2033,7 +2059,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       for (int l = tid; l < g.n_line; l += GW) ovc[l] = 0;
       ovc_first = 0;
       if (env_on) {                                              // env.reset(): dispatch cleared, storage back to its initial charge
-        er.target = er.actual = er.prev_p = er.amount_prev = 0.f; er.already = false; er.fresh = true;
+        er.target = er.actual = er.prev_p = er.amount_prev = er.curt_prev = 0.f; er.limit = 1.f; er.already = false; er.fresh = true;
         er.charge = (tid < g.n_sto && P->env.charge0) ? gptr(P->env.charge0)[tid] : 0.f;
       }
     }
@@ -2066,9 +2092,10 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
     if (tid < g.n_gen) {
       const size_t q = (size_t)inst * g.n_gen + tid;
       gptr(E.target)[q] = er.target; gptr(E.actual)[q] = er.actual; gptr(E.prev_p)[q] = er.prev_p; gptr(E.already)[q] = er.already ? 1 : 0;
+      gptr(E.limit)[q] = er.limit;
     }
     if (tid < g.n_sto) gptr(E.charge)[(size_t)inst * g.n_sto + tid] = er.charge;
-    if (tid == 0) { gptr(E.amount_prev)[inst] = er.amount_prev; gptr(E.fresh)[inst] = er.fresh ? 1 : 0; }
+    if (tid == 0) { gptr(E.amount_prev)[inst] = er.amount_prev; gptr(E.curt_prev)[inst] = er.curt_prev; gptr(E.fresh)[inst] = er.fresh ? 1 : 0; }
   }
   GPF_STAMPS(15);
   GPF_STAMPS_FLUSH(inst);

@@ -501,20 +501,34 @@ class PowerFlowEngine:
             np.ascontiguousarray(storage_power, dtype=np.float32).reshape(self.n_lanes, self.model.n_storage)
         check(self._lib.gpf_set_lane_actions(self._h, ptr(r, C.c_float), ptr(s_, C.c_float), int(bool(hold_storage))), "gpf_set_lane_actions")
 
+    def set_gen_renewable(self, renewable):
+        """``gen_renewable`` mask (curtailment only acts on these generators); None switches curtailment off."""
+        r = None if renewable is None else np.ascontiguousarray(renewable, dtype=np.uint8).reshape(self.model.n_gen)
+        check(self._lib.gpf_set_gen_renewable(self._h, ptr(r, C.c_uint8)), "gpf_set_gen_renewable")
+
+    def set_lane_curtailment(self, limit):
+        """Curtailment action of the NEXT launch: ``[n_lanes, n_gen]`` ratios of pmax in [0, 1], -1 = no change (consumed by the
+        launch's first step; the limits then stay in the lanes' state until changed)."""
+        a = None if limit is None else np.ascontiguousarray(limit, dtype=np.float32).reshape(self.n_lanes, self.model.n_gen)
+        check(self._lib.gpf_set_lane_curtailment(self._h, ptr(a, C.c_float)), "gpf_set_lane_curtailment")
+
     def env_state(self, lane0: int = 0, n: Optional[int] = None) -> dict:
         """``target`` / ``actual`` dispatch, ``prev_p``, ``already_modified`` ``[n, n_gen]``, ``charge`` ``[n, n_storage]``,
         ``amount_prev`` ``[n]`` of the lanes' environment dynamics."""
         lane0, n = self._range(lane0, n)
         ng, ns = self.model.n_gen, self.model.n_storage
         d = dict(target=np.empty((n, ng), np.float32), actual=np.empty((n, ng), np.float32), prev_p=np.empty((n, ng), np.float32),
-                 already_modified=np.empty((n, ng), np.uint8), charge=np.empty((n, ns), np.float32), amount_prev=np.empty(n, np.float32))
+                 already_modified=np.empty((n, ng), np.uint8), charge=np.empty((n, ns), np.float32), amount_prev=np.empty(n, np.float32),
+                 curtail_limit=np.empty((n, ng), np.float32), curtail_prev=np.empty(n, np.float32))
         check(self._lib.gpf_get_env_state(self._h, lane0, n, ptr(d["target"], C.c_float), ptr(d["actual"], C.c_float),
                                           ptr(d["prev_p"], C.c_float), ptr(d["already_modified"], C.c_uint8),
-                                          ptr(d["charge"] if ns else None, C.c_float), ptr(d["amount_prev"], C.c_float)), "gpf_get_env_state")
+                                          ptr(d["charge"] if ns else None, C.c_float), ptr(d["amount_prev"], C.c_float),
+                                          ptr(d["curtail_limit"], C.c_float), ptr(d["curtail_prev"], C.c_float)), "gpf_get_env_state")
         d["already_modified"] = d["already_modified"].astype(bool)
         return d
 
-    def set_env_state(self, lane0: int = 0, target=None, actual=None, prev_p=None, already_modified=None, charge=None, amount_prev=None):
+    def set_env_state(self, lane0: int = 0, target=None, actual=None, prev_p=None, already_modified=None, charge=None, amount_prev=None,
+                      curtail_limit=None, curtail_prev=None):
         """Overwrite (parts of) the lanes' environment dynamics, e.g. to restore them from an observation."""
         f = lambda a, w: None if a is None else np.ascontiguousarray(a, dtype=np.float32).reshape(-1, w)  # noqa: E731
         ng, ns = self.model.n_gen, max(self.model.n_storage, 1)
@@ -522,9 +536,12 @@ class PowerFlowEngine:
         am = None if already_modified is None else np.ascontiguousarray(already_modified, dtype=np.uint8).reshape(-1, ng)
         ch = None if charge is None or not self.model.n_storage else f(charge, ns)
         ap = None if amount_prev is None else np.ascontiguousarray(amount_prev, dtype=np.float32).reshape(-1)
-        n = next(x.shape[0] for x in arrs + [am, ch, ap] if x is not None)
+        cl = f(curtail_limit, ng)
+        cp = None if curtail_prev is None else np.ascontiguousarray(curtail_prev, dtype=np.float32).reshape(-1)
+        n = next(x.shape[0] for x in arrs + [am, ch, ap, cl, cp] if x is not None)
         check(self._lib.gpf_set_env_state(self._h, int(lane0), n, ptr(arrs[0], C.c_float), ptr(arrs[1], C.c_float), ptr(arrs[2], C.c_float),
-                                          ptr(am, C.c_uint8), ptr(ch, C.c_float), ptr(ap, C.c_float)), "gpf_set_env_state")
+                                          ptr(am, C.c_uint8), ptr(ch, C.c_float), ptr(ap, C.c_float), ptr(cl, C.c_float), ptr(cp, C.c_float)),
+              "gpf_set_env_state")
 
     def set_trajectory(self, n_steps_cap: int, what: int = 1):
         """Trajectory buffers of multi-step launches: ``what`` = `TRAJ_RHO` (rho + status of every step) or `TRAJ_OBS` (in

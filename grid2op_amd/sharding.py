@@ -284,6 +284,14 @@ class ShardedEngine:
             cut = lambda a: None if a is None else np.asarray(a)[b0:b0 + bn]  # noqa: E731
             eng.set_lane_actions(cut(redispatch), cut(storage_power), hold_storage)
 
+    def set_gen_renewable(self, renewable):
+        for eng in self.engines:
+            eng.set_gen_renewable(renewable)
+
+    def set_lane_curtailment(self, limit):
+        for eng, (b0, bn) in zip(self.engines, self.blocks):
+            eng.set_lane_curtailment(None if limit is None else np.asarray(limit)[b0:b0 + bn])
+
     def env_state(self, lane0: int = 0, n=None) -> dict:
         parts = [eng.env_state(l0, k) for eng, l0, k, _ in self._parts(lane0, n)]
         return {key: np.concatenate([p[key] for p in parts]) for key in parts[0]}

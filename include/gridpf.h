@@ -239,8 +239,10 @@ int gpf_redispatch(gpf_handle h, int32_t lane0, int32_t n, const double* new_p, 
  * redispatch into the target dispatch (:2101-2115), the _make_redisp gate (:2188-2209) and the ramp- / pmin- / pmax-limited
  * zero-sum projection (:2211-2470 _compute_dispatch_vect; exact solution of the separable QP, as gpf_redispatch), then
  * prod_p = chronics + actual dispatch (:3830 set_redispatch) and the storage power (:3831 set_storage).  A lane whose projection is
- * infeasible ends its episode (status GPF_ST_REDISPATCH; ImpossibleRedispatching :3227-3247).  Not modelled: curtailment,
- * detachment, generator up / down times, the cancellation of illegal redispatch actions (:2140-2173).
+ * infeasible ends its episode (status GPF_ST_REDISPATCH; ImpossibleRedispatching :3227-3247).  Curtailment
+ * (_aux_handle_curtailment_without_limit, :2956-2982): renewable generators are capped at limit * pmax, the change of the curtailed
+ * total joins the right-hand side of the projection.  Not modelled: detachment, generator up / down times, the cancellation of
+ * illegal redispatch actions (:2140-2173), LIMIT_INFEASIBLE_CURTAILMENT_STORAGE_ACTION.
  *   gpf_set_storage_params : storage_Emax / Emin / loss / charging & discharging efficiency / initial charge [n_storage], the
  *                            step length and Parameters.ACTIVATE_STORAGE_LOSS.
  *   gpf_set_env_dynamics   : on != 0 switches the dynamics on (needs gpf_set_gen_limits, and gpf_set_storage_params on a grid
@@ -250,19 +252,26 @@ int gpf_redispatch(gpf_handle h, int32_t lane0, int32_t n, const double* new_p, 
  *                            by the launch's first step, then consumed) and storage power [n_lanes][n_storage] MW (applied by the
  *                            first step only -- grid2op's semantics of a storage action -- or, hold_storage != 0, by every step
  *                            until replaced); NULL = none.
+ *   gpf_set_gen_renewable  : gen_renewable [n_gen] (NULL: no curtailment);  gpf_set_lane_curtailment: the curtailment action of
+ *                            the NEXT launch, [n_lanes][n_gen] ratios of pmax in [0, 1], -1 = no change (consumed by the first
+ *                            step; the limits then live in the lanes' state, like BaseEnv._limit_curtailment).
  *   gpf_get/set_env_state  : target / actual dispatch, previous set-points (_gen_activeprod_t_redisp), already-modified mask
- *                            [n][n_gen], state of charge [n][n_storage], previous storage amount [n] (what an environment
- *                            restored from an observation hands over, baseEnv.py:4879-4882); any pointer may be NULL.
+ *                            [n][n_gen], state of charge [n][n_storage], previous storage amount [n], curtailment limits
+ *                            [n][n_gen], previous curtailed total [n] (what an environment restored from an observation hands
+ *                            over, baseEnv.py:4879-4882); any pointer may be NULL.
  * gpf_reset_lanes also resets the dynamics of the lanes. */
 #define GPF_ST_REDISPATCH 6   /* the redispatch projection is infeasible: game over (ImpossibleRedispatching) */
 int gpf_set_storage_params(gpf_handle h, const double* emax, const double* emin, const double* loss, const double* eff_charge,
                            const double* eff_discharge, const float* charge0, double delta_time_seconds, int32_t activate_loss);
 int gpf_set_env_dynamics(gpf_handle h, int32_t on, double tol_poly);
 int gpf_set_lane_actions(gpf_handle h, const float* redispatch, const float* storage_power, int32_t hold_storage);
+int gpf_set_gen_renewable(gpf_handle h, const uint8_t* renewable);
+int gpf_set_lane_curtailment(gpf_handle h, const float* limit);
 int gpf_get_env_state(gpf_handle h, int32_t lane0, int32_t n, float* target, float* actual, float* prev_p, uint8_t* already_modified,
-                      float* charge, float* amount_prev);
+                      float* charge, float* amount_prev, float* curtail_limit, float* curtail_prev);
 int gpf_set_env_state(gpf_handle h, int32_t lane0, int32_t n, const float* target, const float* actual, const float* prev_p,
-                      const uint8_t* already_modified, const float* charge, const float* amount_prev);
+                      const uint8_t* already_modified, const float* charge, const float* amount_prev, const float* curtail_limit,
+                      const float* curtail_prev);
 
 /* ---- batched obs.simulate (Observation/baseObservation.py:3365-3670 simulate -> Environment/_obsEnv.py: the forecast
  * injections of `time_step` steps ahead + a candidate action on a copy of the observation's grid state, one env.step of that copy) --

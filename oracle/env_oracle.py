@@ -156,6 +156,9 @@ class InjectionDynamics:
         self.power = np.zeros(n_sto, f32)
         self.amount = 0.0
         self.amount_prev = 0.0
+        self.limit = np.ones(n_gen, f32)                      # _limit_curtailment (ratio of pmax; 1 = not curtailed)
+        self.sum_curt = 0.0                                   # _sum_curtailment_mw (change against the previous step)
+        self.sum_curt_prev = 0.0
         self.fresh = True                                     # no step yet since the reset: the previous set-points are the step's own
                                                               # (nb_time_step == 0, baseEnv.py:2218-2219); assigning prev_p clears it
 
@@ -197,14 +200,39 @@ class InjectionDynamics:
             self.charge -= (s["loss"] * self.coeff).astype(np.float32)
             self.charge[:] = np.maximum(self.charge, 0.0)
 
-    def step(self, new_p, act_redisp=None, act_storage=None):
-        """-> (ok, generator set-points float32 [n_gen] = chronics + actual dispatch, storage power float32 [n_storage])"""
+    def _curtail(self, new_p, act_curtail):
+        """_aux_handle_curtailment_without_limit (baseEnv.py:2956-2982): renewable generators are capped at limit * pmax, the change
+        of the curtailed total against the previous step goes to the right-hand side of the redispatch projection"""
+        ren = self.lim.get("renewable")
+        if ren is None:
+            return new_p
+        has_act = act_curtail is not None and (np.asarray(act_curtail) != -1.0).any()
+        if has_act or (np.abs(self.limit - 1.0) >= 1e-7).any():
+            if has_act:
+                a = np.asarray(act_curtail, np.float32)
+                sel = (a != -1.0) & ren
+                self.limit[sel] = a[sel]
+            gc = np.abs(self.limit - 1.0) >= 1e-7
+            before = new_p.copy()
+            new_p = new_p.copy()
+            new_p[gc] = np.minimum((self.lim["pmax"][gc] * self.limit[gc]).astype(np.float32), new_p[gc])
+            tmp = float(np.float32(new_p[gc].sum() - before[gc].sum()))
+            self.sum_curt = tmp - self.sum_curt_prev
+            self.sum_curt_prev = tmp
+        else:
+            self.sum_curt = -self.sum_curt_prev
+            self.sum_curt_prev = 0.0
+        return new_p
+
+    def step(self, new_p, act_redisp=None, act_storage=None, act_curtail=None):
+        """-> (ok, generator set-points float32 [n_gen] = (curtailed) chronics + actual dispatch, storage power float32 [n_storage])"""
         from .redispatch_oracle import compute_dispatch, compute_dispatch_exact
         if self.exact:
             compute_dispatch = compute_dispatch_exact
         new_p = np.asarray(new_p, np.float32)
         if self.sto is not None:
             self._compute_storage(np.zeros(len(self.power), np.float32) if act_storage is None else act_storage)
+        new_p = self._curtail(new_p, act_curtail)
         if act_redisp is not None and (np.asarray(act_redisp) != 0).any():
             act = np.asarray(act_redisp, np.float32)
             is_red = np.abs(act) > 1e-7
@@ -217,9 +245,10 @@ class InjectionDynamics:
         if self.fresh and not self.prev_p.any():
             self.prev_p[:] = new_p
         self.fresh = False
-        if (abs(float(self.actual.sum())) >= tol or float(np.abs(self.actual - self.target).max()) >= tol or abs(self.amount) >= tol):
+        if (abs(float(self.actual.sum())) >= tol or float(np.abs(self.actual - self.target).max()) >= tol or abs(self.amount) >= tol or
+                abs(self.sum_curt) >= tol):
             ok, after = compute_dispatch(new_p.astype(np.float64), self.prev_p.astype(np.float64), self.actual.astype(np.float64),
-                                         self.target.astype(np.float64), self.already.copy(), self.amount, 0.0, 0.0, self.lim, first=False)
+                                         self.target.astype(np.float64), self.already.copy(), self.amount, self.sum_curt, 0.0, self.lim, first=False)
             if ok:
                 self.actual[:] = after.astype(np.float32)
         gen = (new_p + self.actual).astype(np.float32)

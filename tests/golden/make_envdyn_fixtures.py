@@ -34,7 +34,7 @@ from grid2op.Parameters import Parameters  # noqa: E402
 from conformance_backend import OracleHipBackend  # noqa: E402
 
 
-def record(env_name, n_steps, every, seed):
+def record(env_name, n_steps, every, seed, curtail=False):
     p = Parameters()
     p.NO_OVERFLOW_DISCONNECTION = True
     env = grid2op.make(env_name, test=True, backend=OracleHipBackend(), param=p, opponent_class=BaseOpponent,
@@ -45,7 +45,7 @@ def record(env_name, n_steps, every, seed):
     obs = env.reset()
     rng = np.random.default_rng(seed)
     disp = np.nonzero(cls.gen_redispatchable)[0]
-    keys = ["row", "act_redisp", "act_storage", "new_p", "target", "actual", "prev_p", "already_modified", "storage_power", "storage_charge",
+    keys = ["row", "act_redisp", "act_storage", "act_curtail", "limit_curtailment", "sum_curtailment", "new_p", "target", "actual", "prev_p", "already_modified", "storage_power", "storage_charge",
             "amount_storage", "gen_p", "gen_v", "load_p", "load_q", "p_or", "a_or", "rho", "obs_storage_power", "obs_storage_charge",
             "obs_actual_dispatch", "obs_target_dispatch", "failed_redisp"]
     rec = {k: [] for k in keys}
@@ -54,6 +54,12 @@ def record(env_name, n_steps, every, seed):
     for t in range(n_steps):
         red = np.zeros(cls.n_gen, np.float32)
         sto = np.zeros(cls.n_storage, np.float32)
+        cur = np.full(cls.n_gen, -1.0, np.float32)
+        if curtail and t % every == 2:                   # curtail two renewable generators (and release them later)
+            ren = np.nonzero(cls.gen_renewable)[0]
+            ratio = np.asarray(data.prod_p[data.current_index + 1])[ren] / cls.gen_pmax[ren]      # the two renewables producing most
+            k = ren[np.argsort(-ratio)[(t // every) % 2 * 2:(t // every) % 2 * 2 + 2]]
+            cur[k] = 1.0 if t >= 10 else (ratio[np.isin(ren, k)] * rng.uniform(0.85, 0.95, 2)).astype(np.float32)
         if t % every == 0:
             k = rng.choice(disp, size=min(len(disp), 2), replace=False)
             amp = cls.gen_max_ramp_up[k] * rng.uniform(0.2, 0.7, len(k)) * np.array([1.0, -1.0])[:len(k)]
@@ -65,11 +71,16 @@ def record(env_name, n_steps, every, seed):
             act["redispatch"] = [(int(g), float(red[g])) for g in np.nonzero(red)[0]]
         if (sto != 0).any():
             act["set_storage"] = [(int(i), float(sto[i])) for i in np.nonzero(sto)[0]]
+        if (cur != -1).any():
+            act["curtail"] = [(int(g), float(cur[g])) for g in np.nonzero(cur != -1)[0]]
         obs, _, done, info = env.step(env.action_space(act))
         assert not done, (t, info["exception"])
         rec["row"].append(int(data.current_index))
         rec["act_redisp"].append(red.copy())
         rec["act_storage"].append(sto.copy())
+        rec["act_curtail"].append(cur.copy())
+        rec["limit_curtailment"].append(np.array(env._limit_curtailment, np.float64))
+        rec["sum_curtailment"].append(float(env._sum_curtailment_mw))
         rec["new_p"].append(np.array(data.prod_p[data.current_index], np.float32))
         rec["target"].append(np.array(env._target_dispatch, np.float64))
         rec["actual"].append(np.array(env._actual_dispatch, np.float64))
@@ -89,6 +100,7 @@ def record(env_name, n_steps, every, seed):
     out.update(out0)
     out.update(pmin=cls.gen_pmin.astype(np.float64), pmax=cls.gen_pmax.astype(np.float64), ramp_up=cls.gen_max_ramp_up.astype(np.float64),
                ramp_down=cls.gen_max_ramp_down.astype(np.float64), redispatchable=cls.gen_redispatchable.astype(bool),
+               renewable=cls.gen_renewable.astype(bool),
                eps_poly=np.float64(env._epsilon_poly), tol_poly=np.float64(env._tol_poly), delta_time_seconds=np.float64(env.delta_time_seconds),
                thermal_limit=np.asarray(env.get_thermal_limit(), np.float32),
                activate_storage_loss=np.bool_(env.parameters.ACTIVATE_STORAGE_LOSS))
@@ -114,7 +126,7 @@ def record(env_name, n_steps, every, seed):
 
 def main():
     record("educ_case14_storage", 24, 4, 5)
-    record("l2rpn_wcci_2022_dev", 16, 4, 6)
+    record("l2rpn_wcci_2022_dev", 16, 4, 6, curtail=True)
 
 
 if __name__ == "__main__":

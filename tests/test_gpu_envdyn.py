@@ -25,6 +25,8 @@ def _engine(m, fx, B):
                                fx["storage_discharging_efficiency"], fx["storage_charge0"], float(fx["delta_time_seconds"]),
                                bool(fx["activate_storage_loss"]))
     eng.set_env_dynamics(True, tol_poly=float(fx["tol_poly"]))
+    if "renewable" in fx:
+        eng.set_gen_renewable(fx["renewable"])
     return eng
 
 
@@ -39,7 +41,7 @@ def test_recorded_reference_episode_in_multi_step_launches(name, load_model, loa
     B = 3                                                  # three lanes play the same episode (a wavefront shared by 2 instances on 14 substations)
     eng = _engine(m, fx, B)
     n = fx["row"].shape[0]
-    acts = [t for t in range(n) if (fx["act_redisp"][t] != 0).any() or (fx["act_storage"][t] != 0).any()]
+    acts = [t for t in range(n) if (fx["act_redisp"][t] != 0).any() or (fx["act_storage"][t] != 0).any() or (fx["act_curtail"][t] != -1).any()]
     assert acts and acts[0] == 0
     row0 = int(fx["row"][0])
     # the reset step left _gen_activeprod_t_redisp = the set-points of the row before the first recorded step
@@ -65,12 +67,14 @@ def test_recorded_reference_episode_in_multi_step_launches(name, load_model, loa
             if m.n_storage:
                 ex.charge[:], ex.amount_prev = fx["storage_charge"][a - 1], float(ap)
         eng.set_lane_actions(np.tile(fx["act_redisp"][a], (B, 1)), np.tile(fx["act_storage"][a], (B, 1)) if m.n_storage else None)
+        if (fx["act_curtail"][a] != -1).any():
+            eng.set_lane_curtailment(np.tile(fx["act_curtail"][a], (B, 1)))
         eng.step(row0 + a, n_steps=b_ - a)                 # ONE launch from this action up to the next one
         obs = eng.trajectory_obs(b_ - a)
         st = eng.env_state()
         gens = []
         for t in range(a, b_):
-            ok, gen, spw = ex.step(fx["new_p"][t], fx["act_redisp"][t], fx["act_storage"][t])
+            ok, gen, spw = ex.step(fx["new_p"][t], fx["act_redisp"][t], fx["act_storage"][t], fx["act_curtail"][t])
             assert ok
             gens.append((gen, spw))
         for k in range(B):
@@ -78,6 +82,8 @@ def test_recorded_reference_episode_in_multi_step_launches(name, load_model, loa
             assert np.abs(st["target"][k] - ex.target).max() < 1e-4, (a, k)
             assert np.abs(st["actual"][k] - ex.actual).max() < 2e-3, (a, k, np.abs(st["actual"][k] - ex.actual).max())
             assert np.array_equal(st["already_modified"][k], ex.already), (a, k)
+            assert np.abs(st["curtail_limit"][k] - fx["limit_curtailment"][b_ - 1]).max() < 1e-6, (a, k)
+            assert abs(st["curtail_prev"][k] - ex.sum_curt_prev) < 2e-3, (a, k, st["curtail_prev"][k], ex.sum_curt_prev)
             assert np.abs(st["prev_p"][k] - ex.prev_p).max() < 2e-3, (a, k)
             # the reference environment's recorded state after step b_ - 1
             # (a generator redispatched for the first time gets target = actual + action, :2110-2112: it inherits the gap of `actual`)

@@ -10,6 +10,8 @@ from oracle.env_oracle import InjectionDynamics
 def dyn_from_fixture(fx, exact=False):
     lim = {k: fx[k] for k in ("pmin", "pmax", "ramp_up", "ramp_down", "redispatchable")}
     lim["eps_poly"], lim["tol_poly"] = float(fx["eps_poly"]), float(fx["tol_poly"])
+    if "renewable" in fx:
+        lim["renewable"] = fx["renewable"]
     sto = None
     if "storage_Emax" in fx:
         sto = {"Emax": fx["storage_Emax"], "Emin": fx["storage_Emin"], "loss": fx["storage_loss"],
@@ -27,8 +29,9 @@ def test_injection_dynamics_reproduce_the_reference_environment(name, load_npz):
     for t in range(n):
         if t == 0:                      # the reset step left _gen_activeprod_t_redisp = set-points of row 0 (no dispatch yet)
             dyn.prev_p[:] = fx["ch_prod_p"][fx["row"][0] - 1]
-        ok, gen, sto = dyn.step(fx["new_p"][t], fx["act_redisp"][t], fx["act_storage"][t])
+        ok, gen, sto = dyn.step(fx["new_p"][t], fx["act_redisp"][t], fx["act_storage"][t], fx["act_curtail"][t])
         assert ok
+        assert np.abs(dyn.limit - fx["limit_curtailment"][t]).max() < 1e-6 and abs(dyn.sum_curt - fx["sum_curtailment"][t]) < 1e-4, t
         assert np.abs(dyn.target - fx["target"][t]).max() < 1e-5, t
         assert np.abs(dyn.actual - fx["actual"][t]).max() < 2e-4, (t, np.abs(dyn.actual - fx["actual"][t]).max())
         assert np.array_equal(dyn.already, fx["already_modified"][t]), t
@@ -61,13 +64,15 @@ def test_exact_projection_stays_close_to_the_reference_and_is_never_worse(name, 
             ex.target[:], ex.actual[:], ex.prev_p[:], ex.already[:] = ref.target, ref.actual, ref.prev_p, ref.already
             ex.charge[:], ex.amount_prev = ref.charge, ref.amount_prev
         a0, t0_, p0, al0 = ref.actual.copy(), ref.target.copy(), ref.prev_p.copy(), ref.already.copy()
-        ok_e, gen_e, _ = ex.step(fx["new_p"][t], fx["act_redisp"][t], fx["act_storage"][t])
-        ok_r, gen_r, _ = ref.step(fx["new_p"][t], fx["act_redisp"][t], fx["act_storage"][t])
+        if t > 0:
+            ex.limit[:], ex.sum_curt_prev = ref.limit, ref.sum_curt_prev
+        ok_e, gen_e, _ = ex.step(fx["new_p"][t], fx["act_redisp"][t], fx["act_storage"][t], fx["act_curtail"][t])
+        ok_r, gen_r, _ = ref.step(fx["new_p"][t], fx["act_redisp"][t], fx["act_storage"][t], fx["act_curtail"][t])
         assert ok_e and ok_r
         worst = max(worst, float(np.abs(ex.actual - ref.actual).max()))
         assert np.abs(ex.actual - ref.actual).max() < 1.0, (t, np.abs(ex.actual - ref.actual).max())     # sanity bound (tests/test_redispatch.py)
         q = qp_terms(fx["new_p"][t].astype(np.float64), p0.astype(np.float64), a0.astype(np.float64), ref.target.astype(np.float64),
-                     ref.already.copy(), ref.amount, 0.0, 0.0, ref.lim)
+                     ref.already.copy(), ref.amount, ref.sum_curt, 0.0, ref.lim)
         if q is not None and (np.abs(ex.actual - a0).max() > 0 or np.abs(ref.actual - a0).max() > 0):
             xe, xr = (ex.actual - a0)[q["part"]].astype(np.float64), (ref.actual - a0)[q["part"]].astype(np.float64)
             assert objective_mw(q, xe) <= objective_mw(q, xr) + 1e-3, (t, objective_mw(q, xe), objective_mw(q, xr))
