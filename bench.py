@@ -340,6 +340,8 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args, sys.argv[1:]))
     ctx = Ctx(args)
+    if args.steps_per_launch > 1 and args.steps_per_launch < args.steps <= 2 * args.steps_per_launch:
+        args.steps_per_launch = args.steps     # a timed window of K <= 32 steps is ONE launch of K steps (not two half-size ones); reported in config
     if ctx.world != args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ctx.world}: launch with --nproc-per-node {args.gpus} "
                          f"(or without torchrun: bench.py starts the ranks itself)\n")
