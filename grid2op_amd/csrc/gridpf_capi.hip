@@ -77,6 +77,20 @@ __global__ void simulate_prepare_kernel(GridDev g, Bufs b, const int* __restrict
   }
 }
 
+// the environment-dynamics state of the source lane -> the scratch lane (simulate: _ObsEnv starts from the environment's own
+// _target_dispatch / _actual_dispatch / _gen_activeprod_t_redisp / storage charge / curtailment limits, Environment/_obsEnv.py)
+__global__ void simulate_env_copy_kernel(EnvDyn E, int n_gen, int n_sto, const int* __restrict__ src_lanes, int n_act, int n_dst, int dst0) {
+  const int q = blockIdx.x;
+  if (q >= n_dst) return;
+  const int src = src_lanes[q / n_act], dst = dst0 + q, tid = threadIdx.x;
+  for (int i = tid; i < n_gen; i += blockDim.x) {
+    const size_t s_ = (size_t)src * n_gen + i, d_ = (size_t)dst * n_gen + i;
+    E.target[d_] = E.target[s_]; E.actual[d_] = E.actual[s_]; E.prev_p[d_] = E.prev_p[s_]; E.already[d_] = E.already[s_]; E.limit[d_] = E.limit[s_];
+  }
+  for (int i = tid; i < n_sto; i += blockDim.x) E.charge[(size_t)dst * n_sto + i] = E.charge[(size_t)src * n_sto + i];
+  if (tid == 0) { E.amount_prev[dst] = E.amount_prev[src]; E.curt_prev[dst] = E.curt_prev[src]; E.fresh[dst] = E.fresh[src]; }
+}
+
 }  // namespace gpf
 
 namespace {
@@ -1375,6 +1389,12 @@ int step_range(gpf_engine* e, const gpf::Bufs& b_in, int lane0, int n, int t0, i
   LaunchPlan p, pb;
   int rc = plan_launch(e, lane0, n, p, pb);
   if (rc != GPF_OK) return rc;
+  if (e->env_on) {
+    const int lanes = p.wpi > 1 ? 64 : 64 / std::max(p.ipw, 1);
+    if (e->g.n_gen > lanes || e->g.n_sto > lanes || pb.sparse_nb || p.sparse_nb != 1)
+      return fail(GPF_E_CAPACITY, std::string(who) + ": the environment dynamics need n_gen and n_storage <= the lanes of an instance (16 / 32 / 64) "
+                                  "and a batch that runs as one launch");
+  }
   gpf::Bufs b = b_in;
   b.work = e->work.p;                 // (developer timing build: the stamp buffer is allocated by the planner)
   if (n_steps > 1 && pb.sparse_nb)
@@ -1390,7 +1410,7 @@ int step_range(gpf_engine* e, const gpf::Bufs& b_in, int lane0, int n, int t0, i
   rc = upload_params_s(e, b, p.tc ? &p : (pb.tc ? &pb : nullptr), p.dcf);
   if (rc != GPF_OK) return rc;
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
-  p.env = pb.env = e->env_on && b.chron == e->chron.p;         // (gpf_simulate_batch steps scratch lanes on the forecast tables: no dynamics)
+  p.env = pb.env = e->env_on;
   HIP_TRY(gpf_launch_step_sparse(p, e->device, e->d_params_s, e->stream, n, o->max_iter, tol_pu, sa));
   if (pb.sparse_nb) HIP_TRY(gpf_launch_step_sparse(pb, e->device, e->d_params_s, e->stream, n, o->max_iter, tol_pu, sa));
   HIP_TRY(hipGetLastError());
@@ -1441,15 +1461,6 @@ int gpf_step_n(gpf_handle e, int32_t t0, int32_t n_steps, const gpf_step_opts* o
   if (e->traj_cap && n_steps > e->traj_cap)
     return fail(GPF_E_INVALID, "gpf_step_n: n_steps exceeds the trajectory buffer (gpf_set_trajectory sizes it; 0 releases it)");
   HIP_TRY(hipSetDevice(e->device));
-  if (e->env_on) {
-    LaunchPlan p, pb;
-    int rc_p = plan_launch(e, 0, e->n_lanes, p, pb);
-    if (rc_p != GPF_OK) return rc_p;
-    const int lanes = p.wpi > 1 ? 64 : 64 / std::max(p.ipw, 1);
-    if (e->g.n_gen > lanes || e->g.n_sto > lanes || pb.sparse_nb || p.sparse_nb != 1)
-      return fail(GPF_E_CAPACITY, "gpf_step_n: the environment dynamics need n_gen and n_storage <= the lanes of an instance (16 / 32 / 64) "
-                                  "and a batch that runs as one launch");
-  }
   int rc = step_range(e, e->bufs(), 0, e->n_lanes, t0, e->chron_T, n_steps, o, "gpf_step_n");
   if (rc != GPF_OK) return rc;
   e->traj_valid = e->traj_cap ? n_steps : 0;
@@ -1641,6 +1652,21 @@ int gpf_simulate_batch(gpf_handle e, int32_t t_obs, int32_t time_step, int32_t n
                      dst_lane0, t_obs, e->chron_T, fc ? e->fc_h : 1, time_step, e->lane_table.p, e->lane_offset.p,
                      e->has_scale ? e->lane_scale.p : nullptr, e->has_delta ? e->lane_gen_delta.p : nullptr);
   HIP_TRY(hipGetLastError());
+  // with the injection dynamics on, the scratch lanes start from their source's dispatch / storage / curtailment state and take
+  // ONE do-nothing step of the dynamics on the forecast (the candidates are topology actions: no redispatch / storage part)
+  struct ActGuard {
+    gpf_engine* e; bool r, s, c;
+    explicit ActGuard(gpf_engine* e_) : e(e_), r(e_->env_act_r), s(e_->env_act_s), c(e_->env_act_c) { e->env_act_r = e->env_act_s = e->env_act_c = false; }
+    ~ActGuard() { e->env_act_r = r; e->env_act_s = s; e->env_act_c = c; }
+  } act_guard(e);
+  if (e->env_on) {
+    gpf::EnvDyn E{};
+    E.target = e->env_target.p; E.actual = e->env_actual.p; E.prev_p = e->env_prev.p; E.already = e->env_already.p; E.charge = e->env_charge.p;
+    E.amount_prev = e->env_amount_prev.p; E.fresh = e->env_fresh.p; E.limit = e->env_limit.p; E.curt_prev = e->env_curt_prev.p;
+    hipLaunchKernelGGL(gpf::simulate_env_copy_kernel, dim3((unsigned)n_dst), dim3(64), 0, e->stream, E, g.n_gen, g.n_sto, e->sim_src.p, n_act,
+                       (int)n_dst, dst_lane0);
+    HIP_TRY(hipGetLastError());
+  }
   // 4. ONE step of the destination range on the forecast tables (no trajectory rows: these are scratch lanes)
   gpf::Bufs b = e->bufs();
   if (fc) b.chron = e->forecast.p;

@@ -291,6 +291,9 @@ int gpf_set_env_state(gpf_handle h, int32_t lane0, int32_t n, const float* targe
  *   GPF_ACT_SET_BUS {topo_vect position, bus (-1 | 1..n_busbar)}   GPF_ACT_CHANGE_BUS {topo_vect position, -}
  *   GPF_ACT_SET_LINE_STATUS {line id, +1 | -1}                      GPF_ACT_CHANGE_LINE_STATUS {line id, -}
  *   GPF_ACT_SET_SHUNT_BUS {shunt id, bus}
+ * With the injection dynamics on (gpf_set_env_dynamics) every scratch lane also inherits its source's dispatch / storage /
+ * curtailment state (what _ObsEnv is initialised with) and takes ONE do-nothing step of the dynamics on the simulated injections
+ * (the candidates are topology actions); the sources' state and the per-lane actions waiting for the next gpf_step_n are untouched.
  * Asynchronous launch (the topology bookkeeping before it synchronises once). */
 #define GPF_ACT_SET_BUS 0
 #define GPF_ACT_SET_LINE_STATUS 1

@@ -170,3 +170,63 @@ def test_batch_of_lanes_with_different_actions_vs_oracle(load_model, load_npz):
     for k in range(B):
         assert np.abs(r.gen_p[k][ns] - fx["ch_prod_p"][(3 + off[k]) % T][ns]).max() < 1e-5
     eng.close()
+
+
+def test_simulate_batch_starts_from_the_sources_dynamics_state(load_model, load_npz):
+    """obs.simulate with the injection dynamics on: the scratch lanes inherit their source's dispatch / storage / curtailment state
+    (what _ObsEnv is initialised with, Environment/_obsEnv.py) and take ONE do-nothing step of the dynamics on the simulated
+    injections; the sources' own state is untouched and pending per-lane actions are not consumed."""
+    import copy
+    name = "educ_case14_storage"
+    m = load_model(name)
+    fx = load_npz(f"envdyn_{name}.npz")
+    B = 6
+    eng = _engine(m, fx, B)
+    T = fx["ch_prod_p"].shape[0]
+    disp = np.nonzero(fx["redispatchable"])[0]
+    dyns = [dyn_from_fixture(fx, exact=True) for _ in range(2)]
+    red = np.zeros((B, m.n_gen), np.float32)
+    sto = np.zeros((B, m.n_storage), np.float32)
+    red[0, disp[0]], red[0, disp[1]] = 3.0, -3.0
+    red[1, disp[1]], red[1, disp[2 % len(disp)]] = -2.0, 2.0
+    sto[0], sto[1] = 3.0, -2.0
+    eng.set_lane_actions(red, sto)
+    eng.step(1, n_steps=4)
+    for k in range(2):
+        for j in range(4):
+            ok, gen, spw = dyns[k].step(fx["ch_prod_p"][(1 + j) % T], red[k] if j == 0 else None, sto[k] if j == 0 else None)
+            assert ok
+    before = eng.env_state()
+    assert np.abs(before["actual"][:2]).max() > 0.5
+    pending = np.zeros((B, m.n_gen), np.float32)
+    pending[0, disp[0]] = 1.0                                  # an action waiting for the next real step: simulate must not eat it
+    pending[0, disp[1]] = -1.0
+    eng.set_lane_actions(pending, None)
+    t_obs = 4
+    n_dst = eng.simulate_batch(t_obs, [0, 1], [{}, {"set_line_status": [(3, -1)]}], dst_lane0=2, time_step=0)
+    assert n_dst == 4
+    r = eng.results(2, 4)
+    after = eng.env_state()
+    ns = ~m.gen_slack
+    for b in range(2):
+        sim = copy.deepcopy(dyns[b])
+        ok, gen, spw = sim.step(fx["ch_prod_p"][t_obs % T], None, None)
+        assert ok
+        for k in range(2):
+            q = 2 * b + k
+            assert r.converged[q], (b, k, r.status[q])
+            assert np.abs(r.gen_p[q][ns] - gen[ns]).max() < 3e-3, (b, k, np.abs(r.gen_p[q][ns] - gen[ns]).max())
+            assert np.abs(r.storage_p[q]).max() < 1e-6, (b, k)          # do-nothing: no storage power in the simulated step
+            assert np.abs(after["actual"][2 + q] - sim.actual).max() < 2e-3, (b, k)
+            assert np.abs(after["charge"][2 + q] - sim.charge).max() < 1e-4, (b, k)
+        assert r.line_status[2 * b + 1][3] == 0 and r.line_status[2 * b][3] == 1
+        for key in ("target", "actual", "prev_p", "charge"):
+            assert np.array_equal(after[key][b], before[key][b]), (b, key)
+    # the pending action is applied by the next real step
+    eng.step(5)
+    ok, _, _ = dyns[0].step(fx["ch_prod_p"][5 % T], pending[0], None)
+    assert ok
+    st = eng.env_state()
+    assert np.abs(st["target"][0] - dyns[0].target).max() < 1e-4
+    assert np.abs(st["actual"][0] - dyns[0].actual).max() < 2e-3
+    eng.close()
