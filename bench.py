@@ -332,6 +332,8 @@ def main():
                          "blocks, barrier, max-reduce, JSON aggregation -- on a box with one GPU; not a scaling measurement)")
     ap.add_argument("--dump-results", default=None, help="rank r writes its lanes' final result rows to <path>.rank<r>.npz")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo")
+    ap.add_argument("--only-env-dynamics", action="store_true",
+                    help="developer (profiling): run only the 118-substation workload with the injection dynamics on and print its record")
     ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)   # CPU launcher test: no arithmetic
     args = ap.parse_args()
     if args.gpus < 1:
@@ -348,6 +350,11 @@ def main():
         sys.exit(2)
     world, rank = ctx.world, ctx.rank
 
+    if args.only_env_dynamics:
+        dyn = workload_wcci_dynamics(ctx, "l2rpn_wcci_2022_dev", 1024, max(16, args.steps), max(16, args.warmup))
+        if rank == 0:
+            print(json.dumps(dyn))
+        return
     m, ch = load_env(args.env)
     n_envs = args.batch
     fan = 1 + m.n_line if args.n1 else 1
@@ -571,6 +578,10 @@ def main():
     if secondary and world == 1:
         res["simulate_batch"] = workload_simulate(ctx, args.env, 256, 16)
 
+    # ---- the drop-in boundary at batch 1: what ONE environment's Backend.runpf costs (HipBackend.runpf = one gpf_solve_lane call) ----
+    if secondary and world == 1:
+        res["single_env_runpf"] = workload_single_env(ctx, args.env, 2000)
+
     # ---- DC sensitivity path of BASELINE.json configs[4]: l2rpn_idf_2023, 2048 lanes, PTDF GEMM next to the AC solve ------------
     if secondary and world == 1:
         res["dc_ptdf"] = workload_ptdf(ctx, "l2rpn_idf_2023", 2048, max(20, args.steps // 2))
@@ -750,6 +761,44 @@ def workload_simulate(ctx, env, n_envs, n_act):
            "oracle_check": oracle_spot_check(ctx, eng, 32, seed=8)}
     eng.close()
     return out
+
+
+def workload_single_env(ctx, env, reps):
+    """ONE environment behind the reference's Backend interface: `HipBackend.runpf` (grid2op_amd/backend.py) is ONE `gpf_solve_lane`
+    call = injections + topology to the device, one launch of the power flow, results back, a single synchronisation.  Wall clock per
+    call on a 1-lane engine (the latency a user who only swaps the backend of a single `grid2op.make` environment gets; the batched
+    engine is the product, this is its floor)."""
+    if ctx.args.stub_engine:
+        return None
+    m, ch = load_env(env)
+    eng = ctx.make_engine(m, 1)
+    inj0 = eng.get_injections(0, 1)[0]
+    topo = np.ones(m.dim_topo, np.int32)
+    sb = np.ones(m.n_shunt, np.int32) if m.n_shunt else None
+    lay = eng.layout
+    rng = np.random.default_rng(5)
+    injs = np.tile(inj0, (16, 1))
+    for k in range(16):                                   # 16 different operating points (loads +- 3 %), cycled
+        f = 1.0 + 0.03 * rng.standard_normal(m.n_load)
+        injs[k, lay.inj_load_p:lay.inj_load_p + m.n_load] *= f
+        injs[k, lay.inj_load_q:lay.inj_load_q + m.n_load] *= f
+    for k in range(20):
+        r = eng.solve_lane(0, injs[k % 16], topo, sb)
+    t0 = time.perf_counter()
+    ok = 0
+    for k in range(reps):
+        r = eng.solve_lane(0, injs[k % 16], topo, sb)
+        ok += int(r.converged[0])
+    el = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    for k in range(reps):
+        r = eng.solve_lane(0, injs[k % 16], topo, sb, is_dc=True)
+    el_dc = time.perf_counter() - t1
+    eng.close()
+    return {"workload": f"{env}: 1 lane, {reps} sequential gpf_solve_lane calls (= HipBackend.runpf: set injections + topology, one AC "
+                        "power flow launch, results to the host, one synchronisation) on 16 cycled operating points",
+            "us_per_call_ac": el / reps * 1e6, "us_per_call_dc": el_dc / reps * 1e6, "value": reps / el, "unit": "runpf calls/sec (one environment)",
+            "frac_converged": ok / reps}
 
 
 def workload_ptdf(ctx, env, B, reps):

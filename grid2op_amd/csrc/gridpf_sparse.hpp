@@ -1582,6 +1582,39 @@ template <int LW> __device__ __forceinline__ double env_gsum(double v) { return 
 template <int LW> __device__ __forceinline__ double env_gmin(double v) { return env_greduce<LW, 1>(v); }
 template <int LW> __device__ __forceinline__ double env_gmax(double v) { return env_greduce<LW, 2>(v); }
 constexpr int ENV_BISECT = 52;    // halvings of the multiplier bracket: 2^-52 of a bracket of a few hundred MW is below the float32 state
+constexpr int ENV_BISECT_COARSE = 14;   // halvings before the closed-form attempt of env_root
+// Root s in [a_, b_] of  f(s) = sum over the group's active lanes of clip(c + s * g, lo, hi) = target  (f monotone: decreasing if
+// `dec`, else increasing; one generator per lane).  f is piecewise linear with at most 2 breakpoints per lane: a few bisection steps
+// isolate a bracket that (almost always) holds none, where the root is the solution of ONE linear equation -- accepted when every
+// lane is in the same piece (at its lower bound / inside / at its upper bound) at the candidate as at the bracket's midpoint;
+// otherwise the bisection runs on to ENV_BISECT halvings (what oracle/redispatch_oracle.py solve_exact does throughout).
+template <int LW>
+__device__ inline double env_root(bool act, double c, double gi, double lo, double hi, double target, double a_, double b_, bool dec) {
+  auto val = [&](double s_) -> double { return fmin(fmax(fma(s_, gi, c), lo), hi); };
+  auto piece = [&](double s_) -> int { const double v = fma(s_, gi, c); return v <= lo ? -1 : (v >= hi ? 1 : 0); };
+  int it = 0;
+  for (; it < ENV_BISECT_COARSE; ++it) {
+    const double mid = 0.5 * (a_ + b_);
+    const double fm = env_gsum<LW>(act ? val(mid) : 0.0);
+    if (dec ? fm > target : fm < target) a_ = mid; else b_ = mid;
+  }
+  {
+    const double mid = 0.5 * (a_ + b_);
+    const int pc = act ? piece(mid) : 2;
+    const double s_clip = env_gsum<LW>(pc == -1 ? lo : (pc == 1 ? hi : 0.0));
+    const double s_g = env_gsum<LW>(pc == 0 ? gi : 0.0), s_c = env_gsum<LW>(pc == 0 ? c : 0.0);
+    if (s_g == 0.0) return mid;                                   // every lane at a bound: f is constant over the bracket
+    const double cand = (target - s_clip - s_c) / s_g;
+    const bool same = env_gmax<LW>((act && piece(cand) != pc) ? 1.0 : 0.0) == 0.0;
+    if (same && cand >= a_ && cand <= b_) return cand;
+  }
+  for (; it < ENV_BISECT; ++it) {
+    const double mid = 0.5 * (a_ + b_);
+    const double fm = env_gsum<LW>(act ? val(mid) : 0.0);
+    if (dec ? fm > target : fm < target) a_ = mid; else b_ = mid;
+  }
+  return 0.5 * (a_ + b_);
+}
 // per-lane registers of the dynamics (lane k = generator k and storage unit k of the instance)
 struct EnvRegs {
   float target, actual, prev_p, charge, amount_prev, limit, curt_prev;
@@ -1696,18 +1729,13 @@ __device__ inline bool env_dynamics_step(const EnvDyn& E, int k, int n_gen, int 
       const bool pm = part && mod, pf = part && !mod;
       const double f_lo = env_gsum<LW>(pf ? lo : 0.0), f_hi = env_gsum<LW>(pf ? hi : 0.0);
       const double lam_lo = env_gmin<LW>(pm ? 2.0 * w * (tv - hi) : 1e300), lam_hi = env_gmax<LW>(pm ? 2.0 * w * (tv - lo) : -1e300);
-      auto sum_mod = [&](double lam) -> double { return env_gsum<LW>(pm ? fmin(fmax(tv - lam / (2.0 * w), lo), hi) : 0.0); };
-      const double s0 = sum_mod(0.0);
+      const double g_mod = pm ? -0.5 / w : 0.0, g_free = pf ? 1.0 / w : 0.0;        // x(lambda) = tv - lambda / (2 w);  x(alpha) = alpha / w
+      const double s0 = env_gsum<LW>(pm ? fmin(fmax(tv, lo), hi) : 0.0);
       double lam = 0.0;
       int free_at = 0;
-      if (rhs - s0 > f_hi) { free_at = 1; double a_ = lam_lo, b_ = 0.0;
-        for (int it = 0; it < ENV_BISECT; ++it) { const double mid = 0.5 * (a_ + b_); if (sum_mod(mid) + f_hi > rhs) a_ = mid; else b_ = mid; }
-        lam = 0.5 * (a_ + b_);
-      } else if (rhs - s0 < f_lo) { free_at = -1; double a_ = 0.0, b_ = lam_hi;
-        for (int it = 0; it < ENV_BISECT; ++it) { const double mid = 0.5 * (a_ + b_); if (sum_mod(mid) + f_lo > rhs) a_ = mid; else b_ = mid; }
-        lam = 0.5 * (a_ + b_);
-      }
-      if (pm) x = fmin(fmax(tv - lam / (2.0 * w), lo), hi);
+      if (rhs - s0 > f_hi) { free_at = 1; lam = env_root<LW>(pm, tv, g_mod, lo, hi, rhs - f_hi, lam_lo, 0.0, true); }
+      else if (rhs - s0 < f_lo) { free_at = -1; lam = env_root<LW>(pm, tv, g_mod, lo, hi, rhs - f_lo, 0.0, lam_hi, true); }
+      if (pm) x = fmin(fmax(fma(lam, g_mod, tv), lo), hi);
       const double got = env_gsum<LW>(pm ? x : 0.0);
       if (free_at != 0) {
         if (pf) x = free_at > 0 ? hi : lo;
@@ -1719,13 +1747,8 @@ __device__ inline bool env_dynamics_step(const EnvDyn& E, int k, int n_gen, int 
         const double r = rhs - got;
         double a_ = env_gmin<LW>(pf ? fmin(lo * w, hi * w) : 1e300), b_ = env_gmax<LW>(pf ? fmax(lo * w, hi * w) : -1e300);
         if (a_ <= b_) {
-          for (int it = 0; it < ENV_BISECT; ++it) {
-            const double mid = 0.5 * (a_ + b_);
-            const double sm = env_gsum<LW>(pf ? fmin(fmax(mid / w, lo), hi) : 0.0);
-            if (sm < r) a_ = mid; else b_ = mid;
-          }
-          const double alpha = 0.5 * (a_ + b_);
-          if (pf) x = fmin(fmax(alpha / w, lo), hi);
+          const double alpha = env_root<LW>(pf, 0.0, g_free, lo, hi, r, a_, b_, false);
+          if (pf) x = fmin(fmax(alpha * g_free, lo), hi);
         }
       }
       if (part) R.actual = (float)(a + x);
