@@ -752,3 +752,89 @@ def test_hazards_table_forces_lines_out_like_maintenance(load_model, load_npz):
     eng.step(0, n_steps=8, rebalance=1.02)
     assert eng.results().line_status.all()
     eng.close()
+
+
+def test_pandapower_recorded_do_nothing_episodes_in_multi_step_launches(load_model, load_npz):
+    """The reference's OWN recording of the headline workload (grid2op/data/rte_case5_example/_statistics: DoNothingAgent, default
+    parameters = protections ON, PandaPowerBackend, 20 scenarios, 7 930 observations; tests/golden/make_statistics_fixtures.py),
+    replayed with one lane per scenario in launches of 64 env steps (4 instances per wavefront on this grid): line status at every
+    step, flows / voltages / generator results at the fixture's sub-sampled rows, protection counters at every launch boundary,
+    and the step at which each episode ends (19 game overs after overloaded lines tripped) -- against pandapower's values."""
+    from grid2op_amd.engine import PowerFlowEngine
+    m = load_model("rte_case5_example")
+    fx = load_npz("stats_case5.npz")
+    start = fx["episode_start"]
+    n_ep = len(start) - 1
+    n_rows = np.diff(start).astype(int)
+    T = int(n_rows.max())
+    n_chron = 2 * m.n_load + 2 * m.n_gen
+    tables = np.zeros((n_ep, T, n_chron), np.float32)
+    for e in range(n_ep):
+        a, b = int(fx["chronics_start"][e]), int(fx["chronics_start"][e + 1])
+        rows = fx["chronics_rows"][a:b][:T]
+        tables[e, :rows.shape[0]] = rows
+        tables[e, rows.shape[0]:] = rows[-1]
+    pos = {int(r): i for i, r in enumerate(fx["row_idx"])}
+    lim = fx["thermal_limit"]
+    eng = PowerFlowEngine(m, n_lanes=n_ep, device=0)
+    eng.upload_chronics(tables)
+    eng.set_lane_chronics(lane_table=np.arange(n_ep, dtype=np.int32))
+    eng.set_thermal_limits(lim)
+    spl = 64
+    eng.set_trajectory(spl, eng.TRAJ_OBS)
+    n_cmp = 0
+    ended = np.full(n_ep, -1)
+
+    def compare(r, e, s):
+        nonlocal n_cmp
+        g = int(start[e]) + s
+        assert np.array_equal(r.line_status[e], fx["line_status_all"][g]), (e, s)
+        if g not in pos:
+            return
+        i = pos[g]
+        assert np.array_equal(r.topo_vect[e], fx["topo_vect"][i]), (e, s)
+        for f, tol in [("p_or", 1e-4), ("q_or", 3e-4), ("p_ex", 1e-4), ("q_ex", 3e-4), ("v_or", 1e-4), ("v_ex", 1e-4)]:
+            assert np.abs(getattr(r, f)[e] - fx[f][i]).max() < tol, (e, s, f, np.abs(getattr(r, f)[e] - fx[f][i]).max())
+        on = fx["a_or"][i] > 1e-6
+        assert np.abs(r.a_or[e][on] / fx["a_or"][i][on] - 1).max() < 1e-5, (e, s)
+        assert np.abs(r.gen_p[e] - fx["prod_p"][i]).max() < 1e-4 and np.abs(r.gen_q[e] - fx["prod_q"][i]).max() < 3e-4, (e, s)
+        assert np.abs(r.load_p[e] - fx["load_p"][i]).max() < 1e-5 and np.abs(r.load_v[e] - fx["load_v"][i]).max() < 1e-4, (e, s)
+        n_cmp += 1
+
+    # row 0 = the reset observation: a power flow without the protections, counters untouched
+    eng.step(0, n_steps=1, cascade=False)
+    r0 = eng.trajectory_obs(1)[0]
+    assert r0.converged.all()
+    for e in range(n_ep):
+        compare(r0, e, 0)
+    eng.set_overflow_count(np.zeros((n_ep, m.n_line), np.int32))
+    t = 1
+    while t < T:
+        n = min(spl, T - t)
+        eng.step(t, n_steps=n, cascade=True)
+        obs = eng.trajectory_obs(n)
+        rho, oc, _ = eng.step_outputs()
+        for j in range(n):
+            s = t + j
+            for e in range(n_ep):
+                if ended[e] >= 0 or s >= n_rows[e]:
+                    continue
+                if s == n_rows[e] - 1 and n_rows[e] < T:
+                    # the runner's final row repeats the last valid observation: this is the step the episode ends at
+                    assert not obs[j].converged[e], (e, s)
+                    ended[e] = s
+                    continue
+                assert obs[j].converged[e], (e, s, obs[j].status[e])
+                compare(obs[j], e, s)
+        s_last = t + n - 1
+        for e in range(n_ep):
+            if ended[e] < 0 and s_last < n_rows[e]:
+                g = int(start[e]) + s_last
+                assert np.array_equal(oc[e], fx["timestep_overflow_all"][g]), (e, s_last, oc[e], fx["timestep_overflow_all"][g])
+                on = fx["line_status_all"][g]
+                if g in pos:
+                    assert np.abs(rho[e][on] - fx["rho"][pos[g]][on]).max() < 1e-5, (e, s_last)
+        t += n
+    assert n_cmp >= 2000
+    assert (ended >= 0).sum() == 19 and all(ended[e] == n_rows[e] - 1 for e in range(n_ep) if n_rows[e] < T)
+    eng.close()

@@ -168,6 +168,68 @@ def test_runner_trajectories_recorded_with_pandapower_backend(load_model, load_n
     assert n_rows >= 380 and n_split >= 250
 
 
+def stats_episode_tables(fx, e, n_load, n_gen):
+    """chronics rows of episode e of tests/golden/stats_case5.npz: [rows, 2 n_load + 2 n_gen]"""
+    a, b = int(fx["chronics_start"][e]), int(fx["chronics_start"][e + 1])
+    return fx["chronics_rows"][a:b]
+
+
+def test_do_nothing_episodes_recorded_with_pandapower_backend(load_model, load_npz):
+    """grid2op/data/rte_case5_example/_statistics (shipped with the reference; EpisodeStatistics.compute,
+    utils/underlying_statistics.py:680-813): the DoNothingAgent through the 20 scenarios of rte_case5_example with the default
+    parameters -- overflow protections ON -- and PandaPowerBackend, every observation of every step (7 930 rows; 19 episodes end in a
+    game over after overloaded lines tripped).  The headline workload recorded with pandapower itself: replayed here step by step
+    with the oracle's environment step (chronics row -> injections -> `next_grid_state`), comparing the line status and the
+    protection counters at EVERY step, the flows / voltages / generator results at the sub-sampled rows of the fixture, and the
+    step at which the episode ends."""
+    from oracle.env_oracle import forecast_state, next_grid_state
+    m = load_model("rte_case5_example")
+    fx = load_npz("stats_case5.npz")
+    start = fx["episode_start"]
+    pos = {int(r): i for i, r in enumerate(fx["row_idx"])}
+    lim = fx["thermal_limit"]
+    n_cmp = n_trip = n_over = 0
+    for e in range(len(start) - 1):
+        n = int(start[e + 1] - start[e])
+        tab = stats_episode_tables(fx, e, m.n_load, m.n_gen)
+        st = LaneState.from_model(m)
+        ts = np.zeros(m.n_line, np.int64)
+        ended = None
+        for t in range(n):
+            s2 = forecast_state(m, st, tab[t])
+            # row 0 is the reset observation: a plain power flow, the protections do not run (Environment.reset)
+            res, s3, ts_new = next_grid_state(m, s2, lim, ts, cascade=t > 0)
+            if t > 0:
+                ts = ts_new
+            st.topo = s3.topo
+            r = int(start[e]) + t
+            if not res.converged:
+                ended = t
+                break
+            assert np.array_equal(res.line_status.astype(bool), fx["line_status_all"][r]), (e, t)
+            assert np.array_equal(ts, fx["timestep_overflow_all"][r]), (e, t, ts, fx["timestep_overflow_all"][r])
+            if r in pos:
+                i = pos[r]
+                assert np.array_equal(res.topo_vect, fx["topo_vect"][i]), (e, t)
+                for f, tol in [("p_or", 5e-5), ("q_or", 2e-4), ("p_ex", 5e-5), ("q_ex", 2e-4), ("v_or", 5e-5), ("v_ex", 5e-5)]:
+                    assert np.abs(getattr(res, f) - fx[f][i]).max() < tol, (e, t, f)
+                on = fx["a_or"][i] > 1e-6
+                assert np.abs(res.a_or[on] / fx["a_or"][i][on] - 1).max() < 5e-6, (e, t)
+                assert np.abs(res.a_or[on] / lim[on] - fx["rho"][i][on]).max() < 5e-6, (e, t)
+                assert np.abs(res.gen_p - fx["prod_p"][i]).max() < 5e-5 and np.abs(res.gen_q - fx["prod_q"][i]).max() < 2e-4, (e, t)
+                assert np.abs(res.load_p - fx["load_p"][i]).max() < 1e-5 and np.abs(res.load_v - fx["load_v"][i]).max() < 5e-5, (e, t)
+                n_cmp += 1
+        n_trip += int((~fx["line_status_all"][int(start[e + 1]) - 1]).any())
+        if n < 2017:
+            # game over: the runner stored the last valid observation once more in the episode's final row; the step that
+            # produces it is the one the oracle must fail at (divergence / islanding after the trips)
+            assert ended == n - 1, (e, ended, n)
+            n_over += 1
+        else:
+            assert ended is None, (e, ended)
+    assert n_cmp >= 2000 and n_over == 19 and n_trip == 19
+
+
 @pytest.mark.parametrize("name,sizes", [
     ("l2rpn_neurips_2020_track1", (36, 59, 37, 22, 0)), ("l2rpn_icaps_2021", (36, 59, 37, 22, 0)),
     ("l2rpn_neurips_2020_track2_x1", (118, 186, 99, 62, 0)), ("l2rpn_case14_sandbox", (14, 20, 11, 6, 0)),
