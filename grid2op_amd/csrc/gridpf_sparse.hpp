@@ -769,6 +769,7 @@ struct TopoState {
   int nb;             // number of active buses
   bool dc_base;       // the DC matrix of this topology is the reference one (StatOff::dc_inv applies)
   bool gen_base;      // every generator is connected (single-busbar layout): the static per-generator bus totals apply
+  int tc[2];          // topo_vect values of positions tid, tid + GW as the last solve with a NEW topology wrote them
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -1464,7 +1465,25 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     // one pass, every position written once by one lane: an element's bus, -1 for both ends of a line that is out of service
     // (StatOff::pos_line names the line of a position)
     const auto to = gptr(ctl.otraj ? b.traj_topo : b.topo_out) + (size_t)ctl.orow * g.dim_topo;
-    for (int i = tid; i < g.dim_topo; i += GW) {
+    // (observation trajectory: the row is written at every step although the topology stands -- the values of the first
+    //  positions of every lane then come from registers instead of a global round trip to the lane's topology row)
+    constexpr int TCN = IPW > 1 ? 2 : 0;          // (instance-group kernels: <= 2 positions per lane; -0.9 % on the 36-substation N-1 kernel otherwise)
+#pragma unroll
+    for (int k = 0; k < TCN; ++k) {
+      const int i = tid + k * GW;
+      if (i < g.dim_topo) {
+        int val;
+        if (reuse) val = ts.tc[k];
+        else {
+          const int v = topo_g[i], pl = sv.pos_line[i];
+          const bool line_out = pl >= 0 && c.lor_b[pl] < 0;
+          val = (v >= 1 && !line_out) ? v : -1;
+          ts.tc[k] = val;
+        }
+        to[i] = val;
+      }
+    }
+    for (int i = tid + TCN * GW; i < g.dim_topo; i += GW) {
       const int v = topo_g[i], pl = sv.pos_line[i];
       const bool line_out = pl >= 0 && c.lor_b[pl] < 0;
       to[i] = (v >= 1 && !line_out) ? v : -1;
@@ -1539,7 +1558,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   ctl.inj_staged = false; ctl.topo_staged = false; ctl.reuse = false; ctl.dcf = false; ctl.write_bus = true; ctl.warm = false; ctl.sums_done = false;
   ctl.otraj = false; ctl.orow = inst; ctl.write_topo = true;
   TopoState ts;
-  ts.status = 0; ts.nb = 0; ts.dc_base = false; ts.gen_base = false;
+  ts.status = 0; ts.nb = 0; ts.dc_base = false; ts.gen_base = false; ts.tc[0] = ts.tc[1] = -1;
   const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, is_dc, max_iter, tol_pu, tid, ctl, ts, n_iter, nb, a_first GPF_STAMPS_ARG);
   GPF_SYNC();
   if (st != 0) write_nan_results<GW>(P->g, P->b, inst, tid, inst, false);
@@ -1800,7 +1819,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   if (has_delta && tid < g.n_gen) gd0 = gptr(b.lane_gen_delta)[(size_t)inst * g.n_gen + tid];
   if (STAGE) { const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj; for (int i = oo.inj_sto_p + tid; i < g.n_inj; i += GW) c.inj[i] = inj_g[i]; }   // storage / shunt set-points
   TopoState ts;
-  ts.status = 0; ts.nb = 0; ts.dc_base = false; ts.gen_base = false;
+  ts.status = 0; ts.nb = 0; ts.dc_base = false; ts.gen_base = false; ts.tc[0] = ts.tc[1] = -1;
   bool reuse = false;                                         // block-uniform
   int n_iter = 0, nb = 0, st = 0, rounds = 0;
   // state of the lane's OWN line (line `tid`: the line loops all map line l to lane l % GW) kept in registers for the launch:
@@ -1834,6 +1853,16 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
     er.fresh = gptr(E.fresh)[inst] != 0;
   }
   bool env_fail = false;                                       // this group's dynamics ended the episode in the current step
+  // the chronics values this thread handles first (load tid, generator tid) of the NEXT step are fetched while the current step
+  // computes: K9 then starts from registers instead of an L2 / HBM round trip
+  // (single-wavefront instances only: the 2-wavefront kernels have no registers to spare -- measured -1.7 % on 118 substations)
+  constexpr bool PF9 = WPI == 1;
+  float pf_lp = 0.f, pf_lq = 0.f, pf_pp = 0.f, pf_pv = 1.f;
+  if (PF9) {
+    const auto ch0 = gptr(b.chron) + ((size_t)tab * sa.T + row) * g.n_chron;
+    if (tid < g.n_load) { pf_lp = ch0[tid]; pf_lq = ch0[g.n_load + tid]; }
+    if (tid < g.n_gen) { pf_pp = ch0[2 * g.n_load + tid]; pf_pv = ch0[2 * g.n_load + g.n_gen + tid]; }
+  }
   // Every step (and every cascade round) runs the same code on the same addresses, so the compiler would hoist each per-thread
   // pointer, offset and table entry it finds out of the loops (loop-invariant code motion) and keep them live for the whole
   // launch: > 250 VGPRs plus scratch spills.  GPF_REDERIVE makes the thread's coordinates opaque and re-derives the LDS carve
@@ -1879,8 +1908,17 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
         GPF_SYNC();
         for (int l = tid; l < g.n_line; l += GW) if (mrow[l]) { c.topo[sv.line_or_pos[l]] = -1; c.topo[sv.line_ex_pos[l]] = -1; }
       }
-      const float pp_pre = tid < g.n_gen ? ch[2 * g.n_load + tid] : 0.f;
-      const float pv_pre = tid < g.n_gen ? ch[2 * g.n_load + g.n_gen + tid] : 1.f;
+      float pp_pre = pf_pp, pv_pre = pf_pv, lp_pre = pf_lp, lq_pre = pf_lq;
+      if (!PF9) {
+        pp_pre = tid < g.n_gen ? ch[2 * g.n_load + tid] : 0.f;
+        pv_pre = tid < g.n_gen ? ch[2 * g.n_load + g.n_gen + tid] : 1.f;
+      }
+      if (PF9 && !last) {                           // next step's first values: in flight during this step's power flow
+        const int row_n = row + 1 >= sa.T ? 0 : row + 1;
+        const auto chn = gptr(b.chron) + ((size_t)tab * sa.T + row_n) * g.n_chron;
+        if (tid < g.n_load) { pf_lp = chn[tid]; pf_lq = chn[g.n_load + tid]; }
+        if (tid < g.n_gen) { pf_pp = chn[2 * g.n_load + tid]; pf_pv = chn[2 * g.n_load + g.n_gen + tid]; }
+      }
       double sum_load = 0.0, sum_prod = 0.0;
       // The element -> bus maps stand (reuse): every element adds its new set-point to the bus sums Psp / Qsp / Gs right here
       // (the same LDS atomics K1 would issue from four more loops over the injection row, SolveCtl::sums_done)
@@ -1898,7 +1936,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       const bool lane9 = tid < gw9;
       if (lane9)
       for (int i = tid; i < g.n_load; i += gw9) {
-        float lp = ch[i], lq = ch[g.n_load + i];
+        float lp = (PF9 && i == tid) ? lp_pre : ch[i], lq = (PF9 && i == tid) ? lq_pre : ch[g.n_load + i];
         if (has_sc) { lp *= (i == tid) ? sc_p0 : sc[i]; lq *= (i == tid) ? sc_q0 : sc[g.n_load + i]; }
         if (STAGE) { c.inj[oo.inj_load_p + i] = (double)lp; c.inj[oo.inj_load_q + i] = (double)lq; }   // HBM copy: end of kernel
         else { inj_g[oo.inj_load_p + i] = (double)lp; inj_g[oo.inj_load_q + i] = (double)lq; }
