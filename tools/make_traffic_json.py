@@ -30,7 +30,7 @@ out = {
     "lds_bank_conflict_frac_of_lds_cycles": conf / lds_act,
     "valu_busy_frac": 4.0 * valu / 1024.0 / (disp_us * 1e-6 * clk_ghz * 1e9),
     "waves_per_simd": waves / 1024.0,
-    "note": "PMC passes of `python bench.py --steps 32 --warmup 16 --windows 1 --no-cpu-baseline --no-secondary` under rocprofv3 --pmc (one counter "
+    "note": "PMC passes of `python bench.py --steps 48 --warmup 16 --windows 1 --no-cpu-baseline --no-secondary` under rocprofv3 --pmc (one counter "
             "group per pass, tools/profile_round.sh); busy fractions assume 2.4 GHz (profiled runs clock lower: upper bounds)",
 }
 print(json.dumps(out, indent=1))
