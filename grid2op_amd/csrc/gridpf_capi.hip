@@ -345,6 +345,8 @@ bool upload_flats(const gpf::Symbolic& S, DevArr<int>& buf, gpf::SymDev& D, int 
   return true;
 }
 
+gpf::Symbolic build_symbolic_resident(const gpf::GridDev& g, int n_rows, int n_line, const int* lo, const int* le, bool yb_in_lds);
+
 // Topology class of a lane whose substations are split (gridpf_sparse.hpp: TopoClassDev).  Key = busbar of every line end
 // (an open end counts as busbar 1) + which busbars >= 2 carry any element; classes are built on first sight and cached.
 // Returns the class id, or -1 (classes disabled / capacity) -> the lane falls back to the NB = n_busbar kernel.
@@ -381,7 +383,7 @@ int topo_class_of(gpf_engine* e, const int* topo, const int* shunt_bus) {
     lo[l] = node_of[(size_t)e->h_line_or_sub[l] * nbb + (key[2 * l] - 1)];
     le[l] = node_of[(size_t)e->h_line_ex_sub[l] * nbb + (key[2 * l + 1] - 1)];
   }
-  gpf::Symbolic S = gpf::build_symbolic(n_nodes, g.n_line, lo.data(), le.data());
+  gpf::Symbolic S = build_symbolic_resident(g, n_nodes, g.n_line, lo.data(), le.data(), true);
   if (S.nslot > 65535 || !gpf::flat_fits(S)) return -1;
   auto* c = new gpf_engine::TopoClassHost();
   std::vector<int> fi;
@@ -398,7 +400,7 @@ int topo_class_of(gpf_engine* e, const int* topo, const int* shunt_bus) {
   c->n_nodes = n_nodes; c->nslot = S.nslot; c->nslot_y = S.nslot_y;
   gpf::SymDev& D = c->dev.sym;
   D = e->sym_dev;                                            // the grid's static blob pointers / offsets
-  D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.back_first = S.back_first;
+  D.n = S.n; D.nslot = S.nslot; D.nslot_lu = S.nslot_lu; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.back_first = S.back_first;
   D.scale_off = S.scale_off; D.n_scale = S.n_scale; D.n_prog = (int)S.prog.size();
   {   // with every line in service the bus graph of a lane of this class is exactly this graph: connected <=> one component
       // over the nodes that carry an element (an element-only node without a line is an island)
@@ -428,6 +430,21 @@ int topo_class_of(gpf_engine* e, const int* topo, const int* shunt_bus) {
 
 constexpr size_t LDS_SMALL_LIMIT = 64 * 1024;   // above this Y and J move to an HBM/L2 workspace
 constexpr size_t LDS_HARD_LIMIT = 160 * 1024 - 256;   // dynamic LDS budget (a few static bytes: block-wide reductions)
+
+// Symbolic analysis whose Gauss-Jordan tail (Symbolic::gj_lv0) does not cost a resident workgroup per CU.  The 2-wavefront kernels
+// of the large grids live on 4 workgroups of ~39 KB per CU: the tail's fill blocks (40 bytes each with the kept DC factors) are
+// taken only as far as the count of workgroups that fit stays the same (measured on 118 substations: 52 extra blocks = 3 instead of
+// 4 workgroups per CU = -37 %; the allocation is granular and a 40 704-byte workgroup no longer fits four times).  Small grids
+// (instance groups / one wavefront, a few hundred bytes of fill) keep the default budget.
+size_t gj_workgroups_per_cu(size_t lds_bytes) { return (160 * 1024) / std::max<size_t>((lds_bytes + 512 + 1023) / 1024 * 1024, 1024); }
+gpf::Symbolic build_symbolic_resident(const gpf::GridDev& g, int n_rows, int n_line, const int* lo, const int* le, bool yb_in_lds) {
+  gpf::Symbolic S = gpf::build_symbolic(n_rows, n_line, lo, le);
+  if (n_rows < 64) return S;
+  auto lds = [&](int nslot) { return gpf::lds_bytes_sparse<1>(g, nslot, yb_in_lds ? S.nslot_y : 0, 0, false, 1, n_rows, true); };
+  while (S.nslot > S.nslot_lu && gj_workgroups_per_cu(lds(S.nslot)) < gj_workgroups_per_cu(lds(S.nslot_lu)))
+    S = gpf::build_symbolic(n_rows, n_line, lo, le, 1, S.nslot - S.nslot_lu - 1);
+  return S;
+}
 
 int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchPlan& pb);
 
@@ -466,8 +483,8 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
       const bool st = tier > 0;
       const bool dcf = e->dcf != 0;
       return nbk == 1 ? gpf::lds_bytes_sparse<1>(e->g, e->sym.nslot, e->sym.nslot_y, static_bytes, st, ipw, -1, dcf)
-           : nbk == 2 ? gpf::lds_bytes_sparse<2>(e->g, e->sym.nslot, e->sym.nslot_y, static_bytes, st, 1, -1, dcf)
-                      : gpf::lds_bytes_sparse<3>(e->g, e->sym.nslot, e->sym.nslot_y, static_bytes, st, 1, -1, dcf);
+           : nbk == 2 ? gpf::lds_bytes_sparse<2>(e->g, e->sym.nslot_lu, e->sym.nslot_y, static_bytes, st, 1, -1, dcf)
+                      : gpf::lds_bytes_sparse<3>(e->g, e->sym.nslot_lu, e->sym.nslot_y, static_bytes, st, 1, -1, dcf);
     };
     // stage the static tables + the injection row in LDS only when that does not cost residency: blocks per CU
     // (160 KiB / footprint) must still cover what the launch needs at once, or what the un-staged kernel would get
@@ -841,7 +858,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   e->h_lane_sb.assign((size_t)e->cap_lanes * std::max(g.n_shunt, 1), INT_MIN);
   {
     // symbolic analysis of the substation graph for the block-sparse kernels (once per grid)
-    e->sym = gpf::build_symbolic(g.n_sub, nl, e->h_line_or_sub.data(), e->h_line_ex_sub.data());
+    e->sym = build_symbolic_resident(g, g.n_sub, nl, e->h_line_or_sub.data(), e->h_line_ex_sub.data(), false);
     const gpf::Symbolic& S = e->sym;
     if (S.nslot > 65535 || g.n_sub > 32767) { gpf_destroy(e); return fail(GPF_E_CAPACITY, "grid too large for the 16-bit packed symbolic program"); }
     // the static blob of kernel S (layout: gpf::StatOff): doubles, then ints
@@ -935,7 +952,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     hipError_t eu = e->stat_dbl.upload(fd.data(), fd.size());
     if (eu == hipSuccess) eu = e->stat_int.upload(fi.data(), fi.size());
     if (eu != hipSuccess) { gpf_destroy(e); return fail(GPF_E_DEVICE, std::string("upload static tables: ") + hipGetErrorString(eu)); }
-    D.n = S.n; D.nslot = S.nslot; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.back_first = S.back_first;
+    D.n = S.n; D.nslot = S.nslot; D.nslot_lu = S.nslot_lu; D.nslot_y = S.nslot_y; D.n_levels = S.n_levels; D.back_off = S.back_off; D.back_first = S.back_first;
       {   // connectivity of the static substation graph (all lines in service): lets the kernel skip the label propagation
       std::vector<int> comp(g.n_sub);
       for (int i = 0; i < g.n_sub; ++i) comp[i] = i;

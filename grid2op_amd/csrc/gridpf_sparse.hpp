@@ -90,6 +90,7 @@ __host__ __device__ constexpr int gw_index(int gw) { return gw >= 128 ? 3 : gw >
 
 struct SymDev {
   int n, nslot, nslot_y, n_levels, back_off, n_prog, scale_off, n_scale;
+  int nslot_lu;             // blocks of the plain LU: what the level-header program of the NB > 1 kernels touches (Symbolic::nslot_lu)
   int n_up;                 // undirected off-diagonal pairs of the original pattern ((nslot_y - n) / 2)
   int rslot0;               // first right-hand-side pseudo-slot of the single-busbar block array (Symbolic::rslot0)
   const int* flat[4];       // flat programs of the single-busbar kernels, one per group width (gw_index), global memory
@@ -1010,7 +1011,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   if (!dc_skip || do_y) {
   // YR: the Ybus blocks are assembled in the (still unused) row-1 half of the block array and then moved to registers
   double* const ydst = YR ? c.A + HS : c.Yb;
-  if (!dc_skip) for (int i = tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
+  if (!dc_skip) for (int i = tid; i < (NB == 1 ? S.nslot : S.nslot_lu) * B2; i += GW) c.A[i] = 0.0;
   if (do_y) for (int i = tid; i < S.nslot_y * NB * NB * 2; i += GW) ydst[i] = 0.0;
   GPF_LSYNC();
   if (acc_lane)
@@ -1162,7 +1163,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       if (WPI > 1) { *rhsT(i) = 0.0; *rhsV(i) = 0.0; }      // wavefront 1's partial sums of S (see acc_lane above)
     }
     if (BS == 2) { for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; } }
-    else for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;     // fill blocks start at zero
+    else for (int i = S.nslot_y * B2 + tid; i < S.nslot_lu * B2; i += GW) c.A[i] = 0.0;     // fill blocks start at zero
     GPF_LSYNC();
     GPF_STAMPS(10);
     // Single-busbar layout: ONE lane per undirected pair (u, v) of connected substations computes both Jacobian blocks (u, v) and
@@ -1319,7 +1320,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         if (WPI > 1) { *rhsT(i) = 0.0; *rhsV(i) = 0.0; }
       }
       if (BS == 2) { for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; } }
-    else for (int i = S.nslot_y * B2 + tid; i < S.nslot * B2; i += GW) c.A[i] = 0.0;
+    else for (int i = S.nslot_y * B2 + tid; i < S.nslot_lu * B2; i += GW) c.A[i] = 0.0;
       GPF_LSYNC();
       if (!done && G::template any2<1>(!ok || !piv_ok, !fin) != 0u) { status = 4; done = true; }
       if (it == 1) GPF_STAMPS(14);
@@ -1521,7 +1522,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   pin_sgpr(S_loc.scale_off); pin_sgpr(S_loc.n_scale); pin_sgpr(S_loc.back_first); pin_sgpr(S_loc.static_connected);              \
   pin_sgpr(S_loc.rslot0); pin_sgpr(S_loc.n_up);                                                                                 \
   const SymDev& S = S_loc;                                                                                                       \
-  const int lds_rows = TC ? P->tc_rows : -1, lds_nslot = TC ? P->tc_nslot : P->sym.nslot,                                        \
+  const int lds_rows = TC ? P->tc_rows : -1, lds_nslot = TC ? P->tc_nslot : (NB == 1 ? P->sym.nslot : P->sym.nslot_lu),                                        \
             lds_nslot_y = YR ? 0 : TC ? P->tc_nslot_y : P->sym.nslot_y;      /* YR: the Ybus blocks live in registers */          \
   const bool lds_dcf = P->dcf != 0;                                                                                              \
   const size_t per_inst = lds_bytes_instance<NB>(G_, lds_nslot, lds_nslot_y, STAGE != 0, lds_rows, lds_dcf);                     \

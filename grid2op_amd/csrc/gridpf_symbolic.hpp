@@ -44,6 +44,19 @@ struct Symbolic {
   int back_off = 0;                // offset of the back-substitution level table
   int max_level_piv = 0;
   int rslot0 = 0;                  // first right-hand-side pseudo-slot of the flat program (FlatProg): max(nslot, ceil(1.5 n))
+  // ---- Gauss-Jordan tail of the FLAT programs (build_flat; the level-header program above stays plain LU) --------------------------
+  // The last levels of the elimination hold a handful of pivots each, yet every level costs the 2x2 sweeps one forward AND one back
+  // phase.  From level gj_lv0 on, a pivot's column is therefore also eliminated from the tail rows ABOVE it (same item:
+  // A_ij -= A_ik inv(D_k) A_kj, s_i -= A_ik inv(D_k) s_k for tail rows i of earlier levels with a block (i, k)): after the forward
+  // passes every tail row reads D_k x_k = s_k and the tail needs NO back substitution -- one phase less per tail level and solve.
+  // The rows above take fill the LU does not have (slots [nslot_lu, nslot)); gj_lv0 minimises the passes of the grid's usual group
+  // width under a fill budget of nslot_lu / 10 blocks.
+  int nslot_lu = 0;                // blocks of the plain LU (what the level-header program touches); nslot - nslot_lu = GJ fill
+  int gj_lv0 = 0;                  // first tail level (n_levels: no tail)
+  std::vector<int> gj_off;         // [n_levels + 1] offsets into gj_c / gj_r per level (pairs of ints)
+  std::vector<int> gj_c, gj_r;     // extra items of the tail levels, encoded like the c-items / r-items of the level headers
+  std::vector<int> gj_roff;
+  std::vector<int> level_of;       // [n] elimination level of every substation
 };
 
 // FLAT program of the 2x2 / scalar sweeps for one group width GW (threads per instance).  The block array of an instance holds
@@ -69,7 +82,9 @@ struct FlatProg {
   std::vector<int> words;
 };
 
-inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, const int* line_ex_sub, int degree_slack = 1) {
+// gj_budget: most fill blocks the Gauss-Jordan tail may add (< 0: nslot_lu / 10; the engine lowers it when the blocks would cost a
+// resident workgroup per CU, gridpf_capi.hip build_symbolic_resident)
+inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, const int* line_ex_sub, int degree_slack = 1, int gj_budget = -1) {
   Symbolic S;
   S.n = n_sub;
   std::vector<std::set<int>> adj(n_sub);
@@ -155,9 +170,78 @@ inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, co
     S.max_level_piv = std::max<int>(S.max_level_piv, (int)L.piv.size());
     levels.push_back(std::move(L));
   }
+  S.nslot_lu = (int)S.slot_row.size();
+  S.n_levels = (int)levels.size();
+  // ---- Gauss-Jordan tail (see Symbolic::gj_lv0) ------------------------------------------------------------------------------------
+  S.level_of.assign(n_sub, -1);
+  for (int lv = 0; lv < S.n_levels; ++lv) for (int p : levels[lv].piv) S.level_of[p] = lv;
+  {
+    const int gw_nat = n_sub <= 8 ? 16 : n_sub <= 24 ? 32 : n_sub < 64 ? 64 : 128;   // group width the launch planner gives this grid
+    std::vector<std::set<int>> pat(n_sub);                     // block pattern of L + U
+    for (size_t q = 0; q < S.slot_row.size(); ++q) pat[S.slot_row[q]].insert(S.slot_col[q]);
+    auto passes = [&](size_t items) { return (int)((items + gw_nat - 1) / gw_nat); };
+    // simulate the tail from level l0 on: fill of the rows above + items per level -> passes of the forward + back sweeps
+    auto simulate = [&](int l0, std::vector<std::set<int>>* out_pat, std::vector<size_t>* out_extra) -> std::pair<int, int> {
+      std::vector<std::set<int>> R = pat;
+      std::vector<size_t> extra(S.n_levels, 0);
+      int fill = 0;
+      for (int lv = l0; lv < S.n_levels; ++lv)
+        for (int pk : levels[lv].piv) {
+          std::vector<int> cols;
+          for (int c : R[pk]) if (S.level_of[c] > lv) cols.push_back(c);
+          for (int i = 0; i < n_sub; ++i)
+            if (S.level_of[i] >= l0 && S.level_of[i] < lv && R[i].count(pk)) {
+              for (int c : cols) if (R[i].insert(c).second) ++fill;
+              extra[lv] += cols.size() + 1;
+            }
+        }
+      int n_pass = 0;
+      for (int lv = 0; lv < S.n_levels; ++lv) {
+        const size_t fw = levels[lv].c_items.size() / 2 + levels[lv].r_items.size() / 2 + extra[lv];
+        size_t bk = 0;
+        if (lv < l0) for (const auto& ue : levels[lv].u_entries) bk += ue.size();
+        n_pass += passes(fw) + passes(bk);
+      }
+      if (out_pat) *out_pat = R;
+      if (out_extra) *out_extra = extra;
+      return {n_pass, fill};
+    };
+    int best_l0 = S.n_levels, best_pass = simulate(S.n_levels, nullptr, nullptr).first;
+    const int budget = gj_budget >= 0 ? gj_budget : std::max(4, S.nslot_lu / 10);
+    for (int l0 = S.n_levels - 2; l0 >= 0; --l0) {
+      const auto pf = simulate(l0, nullptr, nullptr);
+      if (pf.second > budget) break;
+      if (pf.first < best_pass) { best_pass = pf.first; best_l0 = l0; }
+    }
+    S.gj_lv0 = best_l0;
+    S.gj_off.assign(S.n_levels + 1, 0);
+    S.gj_roff.assign(S.n_levels + 1, 0);
+    for (int lv = 0; lv < S.n_levels; ++lv) {
+      if (lv >= best_l0)
+        for (int pk : levels[lv].piv) {
+          std::vector<int> cols;
+          for (const auto& pr : row_slots[pk]) if (S.level_of[pr.first] > lv) cols.push_back(pr.first);
+          std::sort(cols.begin(), cols.end());
+          for (int i = 0; i < n_sub; ++i) {
+            if (!(S.level_of[i] >= best_l0 && S.level_of[i] < lv)) continue;
+            int ls = -1;
+            for (const auto& pr : row_slots[i]) if (pr.first == pk) ls = pr.second;
+            if (ls < 0) continue;
+            for (int c : cols) {
+              const int dst = add_slot(i, c), us = add_slot(pk, c);
+              S.gj_c.push_back(dst | (ls << 16));
+              S.gj_c.push_back(us | (pk << 16));
+            }
+            S.gj_r.push_back(ls | (i << 16));
+            S.gj_r.push_back(pk);
+          }
+        }
+      S.gj_off[lv + 1] = (int)S.gj_c.size();
+      S.gj_roff[lv + 1] = (int)S.gj_r.size();
+    }
+  }
   S.nslot = (int)S.slot_row.size();
   S.rslot0 = std::max(S.nslot, (3 * n_sub + 1) / 2);
-  S.n_levels = (int)levels.size();
   // ---- flatten -------------------------------------------------------------------------------------------------------
   std::vector<int>& P = S.prog;
   P.assign((size_t)8 * S.n_levels, 0);
@@ -361,8 +445,19 @@ inline FlatProg build_flat(const Symbolic& S, int gw, int lane_opt = 0) {
   for (int lv = 0; lv < S.n_levels; ++lv) {
     const int* h = S.prog.data() + (size_t)8 * lv;
     const int c_off = h[4], n_c = h[5], r_off = h[6], n_r = h[7];
-    if (n_c + n_r == 0) continue;
+    const int g0 = S.gj_off.empty() ? 0 : S.gj_off[lv], g1 = S.gj_off.empty() ? 0 : S.gj_off[lv + 1];
+    const int q0 = S.gj_roff.empty() ? 0 : S.gj_roff[lv], q1 = S.gj_roff.empty() ? 0 : S.gj_roff[lv + 1];
+    if (n_c + n_r + (g1 - g0) + (q1 - q0) == 0) continue;
     std::vector<std::pair<unsigned, std::pair<unsigned, unsigned>>> items;
+    for (int o = g0; o < g1; o += 2) {                          // Gauss-Jordan tail: the pivots' columns in the tail rows above them
+      const unsigned w0 = (unsigned)S.gj_c[o], w1 = (unsigned)S.gj_c[o + 1];
+      items.push_back({fld(w0 & 0xffffu), {fld(w0 & 0xffffu) | (fld(w0 >> 16) << 16), fld(w1 & 0xffffu) | (fld(w1 >> 16) << 16)}});
+    }
+    for (int o = q0; o < q1; o += 2) {
+      const unsigned w0 = (unsigned)S.gj_r[o];
+      const int p = S.gj_r[o + 1];
+      items.push_back({rfld((int)(w0 >> 16)), {rfld((int)(w0 >> 16)) | (fld(w0 & 0xffffu) << 16), rfld(p) | (fld(p) << 16)}});
+    }
     for (int o = 0; o < n_c; ++o) {
       const unsigned w0 = (unsigned)S.prog[c_off + 2 * o], w1 = (unsigned)S.prog[c_off + 2 * o + 1];
       items.push_back({fld(w0 & 0xffffu), {fld(w0 & 0xffffu) | (fld(w0 >> 16) << 16), fld(w1 & 0xffffu) | (fld(w1 >> 16) << 16)}});
@@ -385,7 +480,7 @@ inline FlatProg build_flat(const Symbolic& S, int gw, int lane_opt = 0) {
   F.back_off = (int)W.size();
   for (int lv = S.back_first; lv >= 0; --lv) {
     const int ent_off = S.prog[S.back_off + 2 * lv], n_ent = S.prog[S.back_off + 2 * lv + 1];
-    if (n_ent == 0) continue;
+    if (n_ent == 0 || lv >= S.gj_lv0) continue;                // (tail rows: reduced to D_p x_p = s_p by the forward passes)
     std::vector<std::pair<unsigned, std::pair<unsigned, unsigned>>> items;
     for (int o = 0; o < n_ent; ++o) {
       const unsigned w = (unsigned)S.prog[ent_off + 2 * o];

@@ -149,7 +149,7 @@ extern "C" int sym_level_sizes(int n_sub, int n_line, const int* line_or, const 
 // updates are applied together (the device combines them with LDS atomics).  A_dense: [2n][2n] row-major.  Returns the number
 // of passes (forward + back), or a negative error (-2: a field out of range, -3: a padding word inside the valid prefix, ...).
 extern "C" int sym_emul_solve_flat(int n_sub, int n_line, const int* line_or, const int* line_ex, int gw, const double* A_dense,
-                                   const double* rhs_in, double* x_out, int* stats /* n_fwd, n_scale, n_back, n_words */) {
+                                   const double* rhs_in, double* x_out, int* stats /* n_fwd, levels of the Gauss-Jordan tail, n_back, n_words */) {
   gpf::Symbolic S = gpf::build_symbolic(n_sub, n_line, line_or, line_ex);
   if (!gpf::flat_fits(S)) return -10;
   const gpf::FlatProg F = gpf::build_flat(S, gw, 400);      // with the bank-conflict-aware lane assignment
@@ -226,7 +226,7 @@ extern "C" int sym_emul_solve_flat(int n_sub, int n_line, const int* line_or, co
     inv_apply((unsigned)p * 16u, A[((size_t)S.rslot0 + p) * 2], A[HS + ((size_t)S.rslot0 + p) * 2], x0, x1);
     x_out[p * 2] = x0; x_out[p * 2 + 1] = x1;
   }
-  if (stats) { stats[0] = F.n_fwd; stats[1] = F.n_scale; stats[2] = F.n_back; stats[3] = (int)F.words.size(); }
+  if (stats) { stats[0] = F.n_fwd; stats[1] = S.n_levels - S.gj_lv0; stats[2] = F.n_back; stats[3] = (int)F.words.size(); }
   return F.n_fwd + F.n_back;
 }
 
