@@ -438,6 +438,7 @@ constexpr size_t LDS_HARD_LIMIT = 160 * 1024 - 256;   // dynamic LDS budget (a f
 // (instance groups / one wavefront, a few hundred bytes of fill) keep the default budget.
 size_t gj_workgroups_per_cu(size_t lds_bytes) { return (160 * 1024) / std::max<size_t>((lds_bytes + 512 + 1023) / 1024 * 1024, 1024); }
 gpf::Symbolic build_symbolic_resident(const gpf::GridDev& g, int n_rows, int n_line, const int* lo, const int* le, bool yb_in_lds) {
+  if (const char* ev = std::getenv("GRIDPF_GJ_BUDGET")) return gpf::build_symbolic(n_rows, n_line, lo, le, 1, std::atoi(ev));   // developer override
   gpf::Symbolic S = gpf::build_symbolic(n_rows, n_line, lo, le);
   if (n_rows < 64) return S;
   auto lds = [&](int nslot) { return gpf::lds_bytes_sparse<1>(g, nslot, yb_in_lds ? S.nslot_y : 0, 0, false, 1, n_rows, true); };
