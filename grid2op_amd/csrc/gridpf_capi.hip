@@ -329,7 +329,7 @@ bool upload_flats(const gpf::Symbolic& S, DevArr<int>& buf, gpf::SymDev& D, int 
       key.assign(reinterpret_cast<const char*>(S.slot_row.data()), S.slot_row.size() * sizeof(int));
       key.append(reinterpret_cast<const char*>(S.slot_col.data()), S.slot_col.size() * sizeof(int));
       key.append(reinterpret_cast<const char*>(S.prog.data()), S.prog.size() * sizeof(int));
-      key += "/" + std::to_string(16 << k) + "/" + std::to_string(lane_opt);
+      key += "/" + std::to_string(16 << k) + "/" + std::to_string(lane_opt) + "/" + std::to_string(S.gj_lv0) + "/" + std::to_string(S.nslot_lu);
     }
     auto hit = lane_opt > 0 ? cache.find(key) : cache.end();
     const gpf::FlatProg F = hit != cache.end() ? hit->second : gpf::build_flat(S, 16 << k, lane_opt);
