@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <climits>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -859,7 +861,28 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   e->h_lane_sb.assign((size_t)e->cap_lanes * std::max(g.n_shunt, 1), INT_MIN);
   {
     // symbolic analysis of the substation graph for the block-sparse kernels (once per grid)
-    e->sym = build_symbolic_resident(g, g.n_sub, nl, e->h_line_or_sub.data(), e->h_line_ex_sub.data(), false);
+    {
+      // + slot layout search (gridpf_symbolic.hpp optimize_slot_layout; GRIDPF_SLOT_OPT=<iterations>, 0 = off); the result is a pure
+      // function of the substation graph: one search per process and graph
+      static std::mutex mu;
+      static std::map<std::string, gpf::Symbolic> cache;
+      const char* ev = std::getenv("GRIDPF_SLOT_OPT");
+      // (default: grids of more than 24 substations -- one instance per wavefront or two wavefronts per instance, LDS-pipe-bound:
+      //  N-1 fan-out on 36 substations +3.9 %, 118 substations +1.2 %; the instance-group kernels of the small grids lose 0.7 %)
+      const int slot_opt = ev ? std::atoi(ev) : (g.n_sub > 24 ? 3000 : 0);
+      std::string key(reinterpret_cast<const char*>(e->h_line_or_sub.data()), (size_t)nl * sizeof(int));
+      key.append(reinterpret_cast<const char*>(e->h_line_ex_sub.data()), (size_t)nl * sizeof(int));
+      const char* evb = std::getenv("GRIDPF_GJ_BUDGET");
+      key += "/" + std::to_string(g.n_sub) + "/" + std::to_string(slot_opt) + "/" + (evb ? evb : "") + "/" + std::to_string(g.n_gen) + "/" +
+             std::to_string(g.n_load) + "/" + std::to_string(g.n_sto) + "/" + std::to_string(g.n_shunt);
+      std::lock_guard<std::mutex> lk(mu);
+      auto it = cache.find(key);
+      if (it == cache.end()) {
+        gpf::Symbolic S0 = build_symbolic_resident(g, g.n_sub, nl, e->h_line_or_sub.data(), e->h_line_ex_sub.data(), false);
+        it = cache.emplace(key, gpf::optimize_slot_layout(S0, slot_opt)).first;
+      }
+      e->sym = it->second;
+    }
     const gpf::Symbolic& S = e->sym;
     if (S.nslot > 65535 || g.n_sub > 32767) { gpf_destroy(e); return fail(GPF_E_CAPACITY, "grid too large for the 16-bit packed symbolic program"); }
     // the static blob of kernel S (layout: gpf::StatOff): doubles, then ints

@@ -494,4 +494,90 @@ inline FlatProg build_flat(const Symbolic& S, int gw, int lane_opt = 0) {
   return F;
 }
 
+// ---- slot layout search ---------------------------------------------------------------------------------------------------------
+// Which LDS banks an item of a pass touches is decided by the SLOT numbers of its blocks (16 bytes per slot and row half: slot mod
+// 16 is the bank class of a ds_read_b128).  The numbering of build_symbolic is arbitrary inside three ranges -- off-diagonal blocks of
+// the original pattern [n, nslot_y), LU fill [nslot_y, nslot_lu), Gauss-Jordan fill [nslot_lu, nslot) (the diagonal slots are the
+// substation ids) -- so a local search renumbers the blocks inside each range to lower the bank-model cost of the passes of the
+// grid's usual group width (sequential lane assignment; the per-pass lane search of build_flat then starts from a better layout).
+// relabel_slots: new number of slot s is perm[s].
+inline Symbolic relabel_slots(const Symbolic& S0, const std::vector<int>& perm) {
+  Symbolic S = S0;
+  for (int q = 0; q < S0.nslot; ++q) { S.slot_row[perm[q]] = S0.slot_row[q]; S.slot_col[perm[q]] = S0.slot_col[q]; }
+  for (auto& v : S.br_slot) v = perm[v];
+  auto lo16 = [&](int w) { return (int)(((unsigned)w & 0xffff0000u) | (unsigned)perm[(unsigned)w & 0xffffu]); };
+  auto hi16 = [&](int w) { return (int)(((unsigned)w & 0xffffu) | ((unsigned)perm[(unsigned)w >> 16] << 16)); };
+  for (int lv = 0; lv < S.n_levels; ++lv) {
+    int* h = S.prog.data() + (size_t)8 * lv;
+    for (int k = 0; k < h[3]; ++k) S.prog[h[2] + k] = lo16(S.prog[h[2] + k]);                                    // (p << 16) | u
+    for (int k = 0; k < h[5]; ++k) { int& w0 = S.prog[h[4] + 2 * k]; int& w1 = S.prog[h[4] + 2 * k + 1]; w0 = hi16(lo16(w0)); w1 = lo16(w1); }
+    for (int k = 0; k < h[7]; ++k) { int& w0 = S.prog[h[6] + 2 * k]; w0 = lo16(w0); }                             // l | (row << 16), p
+  }
+  for (int k = 0; k < S.n_scale; ++k) S.prog[S.scale_off + k] = lo16(S.prog[S.scale_off + k]);
+  for (int lv = 0; lv < S.n_levels; ++lv) {
+    const int off = S.prog[S.back_off + 2 * lv], n_ent = S.prog[S.back_off + 2 * lv + 1];
+    for (int k = 0; k < n_ent; ++k) S.prog[off + 2 * k] = lo16(S.prog[off + 2 * k]);                              // u | (col << 16), p
+  }
+  for (size_t k = 0; k + 1 < S.gj_c.size(); k += 2) { S.gj_c[k] = hi16(lo16(S.gj_c[k])); S.gj_c[k + 1] = lo16(S.gj_c[k + 1]); }
+  for (size_t k = 0; k + 1 < S.gj_r.size(); k += 2) S.gj_r[k] = lo16(S.gj_r[k]);
+  return S;
+}
+// bank-model cost of every pass of the flat program of group width gw (sequential lanes) + the pair phase's block writes
+inline long flat_layout_cost(const Symbolic& S, int gw) {
+  const FlatProg F = build_flat(S, gw, 0);
+  const unsigned INV = 0xffffffffu, rhs0 = (unsigned)F.rhs_field0;
+  long tot = 0;
+  std::vector<FlatAcc> acc(gw);
+  auto pass = [&](int off, int k, bool back) {
+    for (int t = 0; t < gw; ++t) {
+      FlatAcc& a = acc[t];
+      a = FlatAcc{};
+      const unsigned w0 = (unsigned)F.words[off + 2 * (k * gw + t)], w1 = (unsigned)F.words[off + 2 * (k * gw + t) + 1];
+      a.valid = w0 != INV;
+      if (!a.valid) continue;
+      if (!back) { a.rd[0] = w1 >> 16; a.rd[1] = w0 >> 16; a.rd[2] = w1 & 0xffffu; a.n_rd = 3; a.at[0] = w0 & 0xffffu; a.at[1] = (w0 & 0xffffu) + 8; a.n_at = 2; }
+      else { a.rd[0] = w0 & 0xffffu; a.rd[1] = (w0 >> 16) - rhs0; a.n_rd = 2; a.r8 = w0 >> 16; a.has_r8 = true; a.at[0] = w1; a.n_at = 1; }
+    }
+    tot += flat_pass_cost(acc, gw);
+  };
+  for (int k = 0; k < F.n_fwd; ++k) pass(0, k, false);
+  for (int k = 0; k < F.n_back; ++k) pass(F.back_off, k, true);
+  const std::vector<int> up = build_upairs(S);                 // pair phase: lane k % gw writes both row halves of blocks (u, v) and (v, u)
+  const int n_up = (int)up.size() / 2;
+  for (int k0 = 0; k0 < n_up; k0 += gw) {
+    for (int t = 0; t < gw; ++t) {
+      FlatAcc& a = acc[t];
+      a = FlatAcc{};
+      a.valid = k0 + t < n_up;
+      if (!a.valid) continue;
+      const unsigned w1 = (unsigned)up[2 * (k0 + t) + 1];
+      a.rd[0] = (w1 & 0xffffu) * 16u; a.rd[1] = (w1 >> 16) * 16u; a.n_rd = 2;
+    }
+    tot += flat_pass_cost(acc, gw);
+  }
+  return tot;
+}
+inline Symbolic optimize_slot_layout(const Symbolic& S0, int iters) {
+  if (iters <= 0 || S0.nslot - S0.n < 2 || !flat_fits(S0)) return S0;
+  const int gw = S0.n <= 8 ? 16 : S0.n <= 24 ? 32 : S0.n < 64 ? 64 : 128;
+  Symbolic cur = S0;
+  long cost = flat_layout_cost(cur, gw);
+  unsigned long long rng = 0xD1B54A32D192ED03ull;               // fixed seed: the layout is a pure function of the grid
+  auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return (unsigned)(rng >> 32); };
+  std::vector<int> perm(S0.nslot);
+  for (int k = 0; k < iters; ++k) {
+    const int r = (int)(next() % 3u);
+    const int a0 = r == 0 ? S0.n : r == 1 ? S0.nslot_y : S0.nslot_lu, a1 = r == 0 ? S0.nslot_y : r == 1 ? S0.nslot_lu : S0.nslot;
+    if (a1 - a0 < 2) continue;
+    const int x = a0 + (int)(next() % (unsigned)(a1 - a0)), y = a0 + (int)(next() % (unsigned)(a1 - a0));
+    if (x == y || (x % 16) == (y % 16)) continue;               // same bank class: nothing changes
+    for (int q = 0; q < S0.nslot; ++q) perm[q] = q;
+    perm[x] = y; perm[y] = x;
+    Symbolic nx = relabel_slots(cur, perm);
+    const long c = flat_layout_cost(nx, gw);
+    if (c <= cost) { cost = c; cur = std::move(nx); }
+  }
+  return cur;
+}
+
 }  // namespace gpf

@@ -148,9 +148,35 @@ extern "C" int sym_level_sizes(int n_sub, int n_line, const int* line_or, const 
 // width: 2x2 blocks split by row, right-hand side in the pseudo-slots behind rslot0, every pass of exactly gw items whose
 // updates are applied together (the device combines them with LDS atomics).  A_dense: [2n][2n] row-major.  Returns the number
 // of passes (forward + back), or a negative error (-2: a field out of range, -3: a padding word inside the valid prefix, ...).
+static int solve_flat_impl(const gpf::Symbolic& S, int n_sub, int gw, const double* A_dense, const double* rhs_in, double* x_out, int* stats);
 extern "C" int sym_emul_solve_flat(int n_sub, int n_line, const int* line_or, const int* line_ex, int gw, const double* A_dense,
                                    const double* rhs_in, double* x_out, int* stats /* n_fwd, levels of the Gauss-Jordan tail, n_back, n_words */) {
   gpf::Symbolic S = gpf::build_symbolic(n_sub, n_line, line_or, line_ex);
+  return solve_flat_impl(S, n_sub, gw, A_dense, rhs_in, x_out, stats);
+}
+// the same with the slot layout search (optimize_slot_layout: blocks renumbered inside their ranges); cost[0..1]: bank-model cost
+// of the layout before / after
+extern "C" int sym_emul_solve_flat_opt(int n_sub, int n_line, const int* line_or, const int* line_ex, int gw, int opt_iters, const double* A_dense,
+                                       const double* rhs_in, double* x_out, int* stats, long long* cost) {
+  gpf::Symbolic S0 = gpf::build_symbolic(n_sub, n_line, line_or, line_ex);
+  gpf::Symbolic S = gpf::optimize_slot_layout(S0, opt_iters);
+  const int gwn = n_sub <= 8 ? 16 : n_sub <= 24 ? 32 : n_sub < 64 ? 64 : 128;
+  if (cost) { cost[0] = gpf::flat_layout_cost(S0, gwn); cost[1] = gpf::flat_layout_cost(S, gwn); }
+  if (S.nslot != S0.nslot || S.nslot_y != S0.nslot_y || S.nslot_lu != S0.nslot_lu) return -20;
+  for (int q = 0; q < n_sub; ++q) if (S.slot_row[q] != q || S.slot_col[q] != q) return -21;          // diagonal slots stay the substation ids
+  for (int q = n_sub; q < S.nslot_y; ++q) {                                                           // ranges keep their members
+    bool found = false;
+    for (int t = n_sub; t < S0.nslot_y && !found; ++t) found = S0.slot_row[t] == S.slot_row[q] && S0.slot_col[t] == S.slot_col[q];
+    if (!found) return -22;
+  }
+  for (int l = 0; l < n_line; ++l)
+    for (int k = 0; k < 4; ++k) {
+      const int q = S.br_slot[4 * l + k], r = k < 2 ? line_or[l] : line_ex[l], c2 = (k == 0 || k == 2) ? line_or[l] : line_ex[l];
+      if (S.slot_row[q] != r || S.slot_col[q] != c2) return -23;
+    }
+  return solve_flat_impl(S, n_sub, gw, A_dense, rhs_in, x_out, stats);
+}
+static int solve_flat_impl(const gpf::Symbolic& S, int n_sub, int gw, const double* A_dense, const double* rhs_in, double* x_out, int* stats) {
   if (!gpf::flat_fits(S)) return -10;
   const gpf::FlatProg F = gpf::build_flat(S, gw, 400);      // with the bank-conflict-aware lane assignment
   const int N = n_sub * 2;

@@ -108,3 +108,37 @@ def test_undirected_pair_table(emul, load_model, name):
     n_up = emul.sym_upairs_check(m.n_sub, m.n_line, lor.ctypes.data_as(ip), lex.ctypes.data_as(ip))
     distinct = {(min(a, b), max(a, b)) for a, b in zip(m.line_or_sub.tolist(), m.line_ex_sub.tolist()) if a != b}
     assert n_up == len(distinct)
+
+
+@pytest.mark.parametrize("name", ["rte_case5_example", "l2rpn_case14_sandbox", "l2rpn_neurips_2020_track1", "l2rpn_wcci_2022_dev"])
+def test_slot_layout_search_keeps_the_program_valid(emul, load_model, name):
+    """optimize_slot_layout renumbers the blocks inside their ranges (original off-diagonal / LU fill / Gauss-Jordan fill) to lower
+    the LDS bank-model cost of the passes: every slot-carrying table is relabelled consistently (the flat programs of all group
+    widths still reproduce dense solves, branch -> slot tables still name the right blocks) and the model cost does not go up."""
+    m = load_model(name)
+    n, BS = m.n_sub, 2
+    N = n * BS
+    lor = np.ascontiguousarray(m.line_or_sub, dtype=np.int32)
+    lex = np.ascontiguousarray(m.line_ex_sub, dtype=np.int32)
+    ip, dp = C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    emul.sym_emul_solve_flat_opt.restype = C.c_int
+    for gw in (16, 32, 64, 128):
+        rng = np.random.default_rng(n * 7 + gw)
+        A = np.zeros((N, N))
+        for a, b in zip(m.line_or_sub, m.line_ex_sub):
+            A[a * BS:(a + 1) * BS, b * BS:(b + 1) * BS] += rng.standard_normal((BS, BS))
+            A[b * BS:(b + 1) * BS, a * BS:(a + 1) * BS] += rng.standard_normal((BS, BS))
+        for s in range(n):
+            A[s * BS:(s + 1) * BS, s * BS:(s + 1) * BS] += rng.standard_normal((BS, BS)) + (4.0 + np.abs(A[s * BS:(s + 1) * BS]).sum() / BS) * np.eye(BS)
+        rhs = rng.standard_normal(N)
+        x = np.zeros(N)
+        stats = np.zeros(4, dtype=np.int32)
+        cost = np.zeros(2, dtype=np.int64)
+        rc = emul.sym_emul_solve_flat_opt(n, m.n_line, lor.ctypes.data_as(ip), lex.ctypes.data_as(ip), gw, 600, A.ctypes.data_as(dp),
+                                          rhs.ctypes.data_as(dp), x.ctypes.data_as(dp), stats.ctypes.data_as(ip),
+                                          cost.ctypes.data_as(C.POINTER(C.c_longlong)))
+        assert rc >= 1, (gw, rc)
+        ref = np.linalg.solve(A, rhs)
+        assert np.abs(x - ref).max() < 1e-9 * max(1.0, np.abs(ref).max()), gw
+        assert cost[1] <= cost[0], cost
+    assert cost[1] < cost[0] or n <= 5
