@@ -650,8 +650,10 @@ __device__ inline bool block_lu_flat(const FlatDev& F, PP prog, double* __restri
         double* d1_ = FL_D(a1, fd);
         atomicAdd(&d0_[0], fma(t00, uA.x, t01 * uB.x) * rd);
         atomicAdd(&d1_[0], fma(t10, uA.x, t11 * uB.x) * rd);
-        atomicAdd(&d0_[1], fma(t00, uA.y, t01 * uB.y) * rd);
-        atomicAdd(&d1_[1], fma(t10, uA.y, t11 * uB.y) * rd);
+        if (fd < (unsigned)F.rhs_field0) {     // (a right-hand-side pseudo-slot: its second column is padding, nothing to accumulate)
+          atomicAdd(&d0_[1], fma(t00, uA.y, t01 * uB.y) * rd);
+          atomicAdd(&d1_[1], fma(t10, uA.y, t11 * uB.y) * rd);
+        }
       }
       GPF_LSYNC();
       w0 = n0; w1 = n1;
