@@ -1353,6 +1353,100 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     }
     GPF_LSYNC();
   }
+  // Small grids, AC, every generator connected: every element kind fits one pass of the group, so the five loops below -- each a
+  // chain "element -> bus (LDS), bus state (LDS), arithmetic, stores" that waits for its own reads -- run as ONE straight-line block:
+  // all element -> bus reads first, then all state / table reads, then the arithmetic (removing the load + generator loops
+  // altogether bounds what they cost at 4.3 % of a 14-substation step).
+  const bool gen_static_k6 = NB == 1 && !TC && G::block_all_u(ts.gen_base);
+  constexpr bool K6F = IPW > 1;                   // (instance-group kernels only: the block costs ~40 VGPRs, which the one- and
+                                                  //  two-wavefront kernels -- 3 waves/SIMD at <= 168, Ybus in registers at 256 -- do not have)
+  const bool k6_fast = K6F && !is_dc && gen_static_k6 && g.n_line <= GW && g.n_load <= GW && g.n_gen <= GW && g.n_sto <= GW && g.n_shunt <= GW &&
+                       g.n_load > 0;
+  if (k6_fast) {
+    const int l = tid;
+    const bool hl = l < g.n_line, hd = l < g.n_load, hg = l < g.n_gen, hs = l < g.n_sto, hh = l < g.n_shunt;
+    const int il = hl ? l : 0, id = hd ? l : 0, ig = hg ? l : 0, is_ = hs ? l : 0, ih = hh ? l : 0;
+    // element -> bus
+    const int f = c.lor_b[il], t = c.lex_b[il], bd = c.load_b[id], bg = c.gen_b[ig];
+    const int bs = g.n_sto ? (int)c.sto_b[is_] : -1, bh = g.n_shunt ? (int)c.sh_b[ih] : -1;
+    const int fc = f >= 0 ? f : 0, tc = t >= 0 ? t : 0, bdc = bd >= 0 ? bd : 0, bgc = bg >= 0 ? bg : 0, bsc = bs >= 0 ? bs : 0, bhc = bh >= 0 ? bh : 0;
+    // bus state + tables
+    const double vmf = c.vm[fc], vmt = c.vm[tc], ef = c.e[fc], ff = c.f[fc], et = c.e[tc], ft = c.f[tc], vaf = c.va[fc], vat = c.va[tc];
+    const double4 ya = sv.br_y.ld4((size_t)8 * il), yb = sv.br_y.ld4((size_t)8 * il + 4);
+    const double vnf = sv.line_vn[2 * il], vnt = sv.line_vn[2 * il + 1];
+    const double vmd = c.vm[bdc], vad = c.va[bdc], lpd = GPF_INJ(oo.inj_load_p + id), lqd = GPF_INJ(oo.inj_load_q + id), vnd = sv.load_vn[id];
+    const double simg = *SimP(bgc), qspg = c.Qsp[bgc], sreg = *SreP(bgc), pspg = c.Psp[bgc], vmg = c.vm[bgc], vag = c.va[bgc];
+    const int gw_ = sv.gen_cnt[ig], gsl = sv.gen_slack[ig];
+    const double gqmn = sv.gen_qmin_tot[ig], gqmx = sv.gen_qmax_tot[ig], gmn = sv.gen_min_q[ig], gmx = sv.gen_max_q[ig], gvn = sv.gen_vn[ig];
+    const double gpi = GPF_INJ(oo.inj_gen_p + ig);
+    double vms = 0.0, vas = 0.0, sps = 0.0, sqs = 0.0, vns = 0.0, vmh = 0.0, hp = 0.0, hq = 0.0, hfac = 0.0, hvn = 0.0;
+    int shb_h = -1;
+    if (g.n_sto) { vms = c.vm[bsc]; vas = c.va[bsc]; sps = GPF_INJ(oo.inj_sto_p + is_); sqs = GPF_INJ(oo.inj_sto_q + is_); vns = sv.sto_vn[is_]; }
+    if (g.n_shunt) { vmh = c.vm[bhc]; hp = GPF_INJ(oo.inj_sh_p + ih); hq = GPF_INJ(oo.inj_sh_q + ih); hfac = sv.shunt_fact[ih]; hvn = sv.shunt_vn[ih]; if (wtopo) shb_h = shb[ih]; }
+    // lines
+    {
+      const bool on = f >= 0;
+      const double ifr = ya.x * ef - ya.y * ff + ya.z * et - ya.w * ft;
+      const double ifi = ya.x * ff + ya.y * ef + ya.z * ft + ya.w * et;
+      const double itr = yb.x * ef - yb.y * ff + yb.z * et - yb.w * ft;
+      const double iti = yb.x * ff + yb.y * ef + yb.z * ft + yb.w * et;
+      const double pf = (ef * ifr + ff * ifi) * sn, qf = (ff * ifr - ef * ifi) * sn;
+      const double pt = (et * itr + ft * iti) * sn, qt = (ft * itr - et * iti) * sn;
+      const float a_or = on ? (float)(sqrt(pf * pf + qf * qf) / (SQRT3 * vmf * vnf) * 1000.0) : 0.f;
+      const float a_ex = on ? (float)(sqrt(pt * pt + qt * qt) / (SQRT3 * vmt * vnt) * 1000.0) : 0.f;
+      if (hl) {
+        if (wtopo) lstat[l] = on ? 1 : 0;
+        out[oo.p_or + l] = on ? (float)pf : 0.f; out[oo.q_or + l] = on ? (float)qf : 0.f; out[oo.v_or + l] = on ? (float)(vmf * vnf) : 0.f;
+        out[oo.a_or + l] = a_or; out[oo.th_or + l] = on ? (float)(vaf * RAD2DEG) : 0.f;
+        out[oo.p_ex + l] = on ? (float)pt : 0.f; out[oo.q_ex + l] = on ? (float)qt : 0.f; out[oo.v_ex + l] = on ? (float)(vmt * vnt) : 0.f;
+        out[oo.a_ex + l] = a_ex; out[oo.th_ex + l] = on ? (float)(vat * RAD2DEG) : 0.f;
+      }
+      a_or_first = hl ? a_or : a_or_first;
+    }
+    GPF_STAMPS(22);
+    if (hd) {
+      const bool on = bd >= 0;
+      out[oo.load_p + l] = on ? (float)lpd : 0.f;
+      out[oo.load_q + l] = on ? (float)lqd : 0.f;
+      out[oo.load_v + l] = on ? (float)(vmd * vnd) : 0.f;
+      out[oo.load_th + l] = on ? (float)(vad * RAD2DEG) : 0.f;
+    }
+    if (hs) {
+      const bool on = bs >= 0;
+      out[oo.sto_p + l] = on ? (float)sps : 0.f;
+      out[oo.sto_q + l] = on ? (float)sqs : 0.f;
+      out[oo.sto_v + l] = on ? (float)(vms * vns) : 0.f;
+      out[oo.sto_th + l] = on ? (float)(vas * RAD2DEG) : 0.f;
+    }
+    if (hh) {
+      const bool on = bh >= 0;
+      const double v = on ? vmh : 0.0;
+      const auto sbo = gptr(ctl.otraj ? b.traj_shb : b.shunt_bus_out) + (size_t)ctl.orow * g.n_shunt;
+      out[oo.sh_p + l] = on ? (float)(hp * hfac * v * v) : 0.f;
+      out[oo.sh_q + l] = on ? (float)(hq * hfac * v * v) : 0.f;
+      out[oo.sh_v + l] = on ? (float)(v * hvn) : 0.f;
+      if (wtopo) sbo[l] = on ? shb_h : -1;
+    }
+    GPF_STAMPS(23);
+    GPF_STAMPS(24);
+    if (hg) {
+      float gp = 0.f, gq = 0.f, gv = 0.f, gth = 0.f;
+      if (bg >= 0) {
+        const double qtot = (simg - qspg) * sn;
+        const int cn = gw_ & 0xffff, ns = gw_ >> 16;
+        double q;
+        if (cn == 1) q = qtot;
+        else if (gqmn == gqmx) q = qtot / cn;
+        else q = gmn + (qtot - gqmn) / (gqmx - gqmn + 2.220446049250313e-16) * (gmx - gmn);
+        double p = gpi;
+        if (gsl) p = (sreg - pspg) * sn / ns;
+        gp = (float)p; gq = (float)q;
+        gv = (float)(vmg * gvn);
+        gth = (float)(vag * RAD2DEG);
+      }
+      out[oo.gen_p + l] = gp; out[oo.gen_q + l] = gq; out[oo.gen_v + l] = gv; out[oo.gen_th + l] = gth;
+    }
+  } else {
   for (int l = tid; l < g.n_line; l += GW) {
     const int f = c.lor_b[l], t = c.lex_b[l];
     if (wtopo) lstat[l] = f >= 0 ? 1 : 0;
@@ -1422,7 +1516,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     int* cnt = reinterpret_cast<int*>(c.A + 2 * (size_t)nbus);
     int* nsl = cnt + nbus;
     // every generator connected (single-busbar layout): the per-bus totals are the static per-generator tables of the grid
-    const bool gen_static = NB == 1 && !TC && G::block_all_u(ts.gen_base);
+    const bool gen_static = gen_static_k6;
     if (!gen_static) {
       GPF_LSYNC();
       for (int i = tid; i < nbus; i += GW) { qmin_t[i] = 0.0; qmax_t[i] = 0.0; cnt[i] = 0; nsl[i] = 0; }
@@ -1462,6 +1556,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       }
       out[oo.gen_p + i] = gp; out[oo.gen_q + i] = gq; out[oo.gen_v + i] = gv; out[oo.gen_th + i] = gth;
     }
+  }
   }
   GPF_STAMPS(25);
   if (wtopo) {                           // topo_vect only depends on the topology: it stands when the topology does
