@@ -84,7 +84,19 @@ struct FlatProg {
 
 // gj_budget: most fill blocks the Gauss-Jordan tail may add (< 0: nslot_lu / 10; the engine lowers it when the blocks would cost a
 // resident workgroup per CU, gridpf_capi.hip build_symbolic_resident)
-inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, const int* line_ex_sub, int degree_slack = 1, int gj_budget = -1) {
+struct FlatProg;
+inline FlatProg build_flat(const Symbolic& S, int gw, int lane_opt = 0);
+inline int flat_pass_count(const Symbolic& S, int gw);
+// resched: 1 = re-schedule the levels on the elimination DAG (below), 0 = keep the greedy levels, -1 = whichever gives fewer passes of
+// the grid's usual group width (ties: greedy)
+inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, const int* line_ex_sub, int degree_slack = 1, int gj_budget = -1,
+                               int resched = -1) {
+  if (resched < 0) {
+    const int gw_nat = n_sub <= 8 ? 16 : n_sub <= 24 ? 32 : n_sub < 64 ? 64 : 128;
+    Symbolic A = build_symbolic(n_sub, n_line, line_or_sub, line_ex_sub, degree_slack, gj_budget, 0);
+    Symbolic B = build_symbolic(n_sub, n_line, line_or_sub, line_ex_sub, degree_slack, gj_budget, 1);
+    return flat_pass_count(B, gw_nat) < flat_pass_count(A, gw_nat) ? B : A;
+  }
   Symbolic S;
   S.n = n_sub;
   std::vector<std::set<int>> adj(n_sub);
@@ -121,6 +133,7 @@ inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, co
   std::vector<Level> levels;
   std::vector<std::set<int>> g = adj;
   std::vector<char> done(n_sub, 0);
+  std::vector<int> asap(n_sub, 0);                               // earliest level of every substation (depth in the elimination DAG)
   int remaining = n_sub;
   while (remaining > 0) {
     size_t mind = (size_t)-1;
@@ -162,14 +175,83 @@ inline Symbolic build_symbolic(int n_sub, int n_line, const int* line_or_sub, co
       for (int i : nb) {
         g[i].erase(p);
         for (int j : nb) if (i != j) g[i].insert(j);
+        asap[i] = std::max(asap[i], asap[p] + 1);            // i is updated by p: it can be eliminated one level after p at the earliest
       }
       g[p].clear();
       done[p] = 1;
       --remaining;
     }
-    S.max_level_piv = std::max<int>(S.max_level_piv, (int)L.piv.size());
     levels.push_back(std::move(L));
   }
+  if (resched == 1)
+  // ---- levels re-scheduled on the elimination DAG ------------------------------------------------------------------------------------
+  // The greedy pass above fixes the elimination ORDER (hence the fill and every pivot's items) but holds pivots back until their
+  // degree is minimal.  Any schedule that keeps a pivot after the pivots that update it is valid with the same items (two pivots
+  // that are ready at the same time are never adjacent: one would update the other).  List scheduling on that DAG: a level takes
+  // every ready pivot that has no slack left (it sits on a longest chain: the number of levels stays the DAG's height), then fills
+  // the passes it has opened anyway -- capacity = its forward items rounded up to the grid's usual group width -- with further ready
+  // pivots, largest first; the rest wait.  Fewer, fuller passes: 118 substations 14 -> 13 levels, 36 substations one forward
+  // pass less.
+  {
+    const int gw_nat = n_sub <= 8 ? 16 : n_sub <= 24 ? 32 : n_sub < 64 ? 64 : 128;
+    struct Rec { int p; std::vector<int> b, c, r, ue, succ; };
+    std::vector<Rec> rec(n_sub);
+    std::vector<int> n_pred(n_sub, 0);
+    for (const Level& L : levels) {
+      size_t cq = 0, rq = 0, bq = 0;
+      for (size_t q = 0; q < L.piv.size(); ++q) {
+        const int p = L.piv[q];
+        Rec& R = rec[p];
+        const size_t deg = L.u_entries[q].size();             // items of this pivot: deg b-items, deg r-items, deg^2 c-items (in order)
+        R.p = p;
+        R.ue = L.u_entries[q];
+        R.b.assign(L.b_items.begin() + bq, L.b_items.begin() + bq + deg);
+        R.r.assign(L.r_items.begin() + rq, L.r_items.begin() + rq + 2 * deg);
+        R.c.assign(L.c_items.begin() + cq, L.c_items.begin() + cq + 2 * deg * deg);
+        bq += deg; rq += 2 * deg; cq += 2 * deg * deg;
+        for (int ue : R.ue) { R.succ.push_back(ue & 0xffff); ++n_pred[ue & 0xffff]; }      // p updates its neighbours at elimination time
+      }
+    }
+    std::vector<int> tail(n_sub, 0);                           // longest chain below a pivot
+    for (int lv = (int)levels.size() - 1; lv >= 0; --lv)
+      for (int p : levels[lv].piv) for (int sc : rec[p].succ) tail[p] = std::max(tail[p], tail[sc] + 1);
+    int height = 0;
+    for (int sidx = 0; sidx < n_sub; ++sidx) height = std::max(height, asap[sidx] + tail[sidx] + 1);
+    std::vector<Level> re;
+    std::vector<char> placed(n_sub, 0);
+    std::vector<int> ready;
+    for (int sidx = 0; sidx < n_sub; ++sidx) if (n_pred[sidx] == 0) ready.push_back(sidx);
+    int n_placed = 0;
+    auto load = [&](int p) { const size_t d = rec[p].ue.size(); return d * d + d; };
+    while (n_placed < n_sub) {
+      const int lv = (int)re.size();
+      std::vector<int> take, wait;
+      size_t items = 0;
+      for (int p : ready) if (lv + tail[p] + 1 >= height) { take.push_back(p); items += load(p); } else wait.push_back(p);
+      if (take.empty() && !wait.empty()) { take.push_back(wait.back()); items += load(wait.back()); wait.pop_back(); }   // (cannot happen)
+      const size_t cap = ((items + gw_nat - 1) / gw_nat) * gw_nat;
+      std::stable_sort(wait.begin(), wait.end(), [&](int x, int y) { return load(x) > load(y); });
+      std::vector<int> still;
+      for (int p : wait) { if (items + load(p) <= cap) { take.push_back(p); items += load(p); } else still.push_back(p); }
+      std::sort(take.begin(), take.end());
+      Level D;
+      for (int p : take) {
+        const Rec& R = rec[p];
+        D.piv.push_back(p);
+        D.u_entries.push_back(R.ue);
+        D.b_items.insert(D.b_items.end(), R.b.begin(), R.b.end());
+        D.r_items.insert(D.r_items.end(), R.r.begin(), R.r.end());
+        D.c_items.insert(D.c_items.end(), R.c.begin(), R.c.end());
+        placed[p] = 1;
+        ++n_placed;
+      }
+      ready = still;
+      for (int p : take) for (int sc : rec[p].succ) if (--n_pred[sc] == 0) ready.push_back(sc);
+      re.push_back(std::move(D));
+    }
+    levels = std::move(re);
+  }
+  for (const Level& L : levels) S.max_level_piv = std::max<int>(S.max_level_piv, (int)L.piv.size());
   S.nslot_lu = (int)S.slot_row.size();
   S.n_levels = (int)levels.size();
   // ---- Gauss-Jordan tail (see Symbolic::gj_lv0) ------------------------------------------------------------------------------------
@@ -375,7 +457,7 @@ inline void flat_assign_lanes(std::vector<FlatAcc>& it, std::vector<std::pair<un
 
 // lane_opt: iterations of the bank-conflict local search per pass (0: keep the sequential assignment -- topology classes are built
 // at run time, inside a step, and skip it)
-inline FlatProg build_flat(const Symbolic& S, int gw, int lane_opt = 0) {
+inline FlatProg build_flat(const Symbolic& S, int gw, int lane_opt) {
   FlatProg F;
   F.gw = gw;
   F.rhs_field0 = S.rslot0 * 16;
@@ -493,6 +575,8 @@ inline FlatProg build_flat(const Symbolic& S, int gw, int lane_opt = 0) {
   while (W.size() & 3) W.push_back((int)INV);
   return F;
 }
+
+inline int flat_pass_count(const Symbolic& S, int gw) { const FlatProg F = build_flat(S, gw, 0); return F.n_fwd + F.n_back; }
 
 // ---- slot layout search ---------------------------------------------------------------------------------------------------------
 // Which LDS banks an item of a pass touches is decided by the SLOT numbers of its blocks (16 bytes per slot and row half: slot mod
