@@ -272,3 +272,35 @@ extern "C" int sym_upairs_check(int n_sub, int n_line, const int* line_or, const
   }
   return n_up;
 }
+
+
+// structural check of the level schedule (build_symbolic: greedy levels or the re-scheduled ones): returns 0 when (1) the pivots of a
+// level are pairwise non-adjacent in the filled pattern, (2) every pivot that updates another one (a block (q, p) with p eliminated
+// after q) sits in an EARLIER level, (3) every substation is a pivot exactly once; a negative code otherwise.  out[0] = levels,
+// out[1] = height of the elimination DAG (the minimum any schedule with this fill can have), out[2] = passes of the flat program.
+extern "C" int sym_check_schedule(int n_sub, int n_line, const int* line_or, const int* line_ex, int resched, int gw, int* out) {
+  gpf::Symbolic S = gpf::build_symbolic(n_sub, n_line, line_or, line_ex, 1, -1, resched);
+  std::vector<int> seen(n_sub, 0);
+  for (int lv = 0; lv < S.n_levels; ++lv) {
+    const int* h = S.prog.data() + (size_t)8 * lv;
+    for (int k = 0; k < h[1]; ++k) { const int p = S.prog[h[0] + k]; if (p < 0 || p >= n_sub || seen[p]++) return -1; if (S.level_of[p] != lv) return -2; }
+  }
+  for (int p = 0; p < n_sub; ++p) if (seen[p] != 1) return -3;
+  std::vector<int> depth(n_sub, 0);
+  int height = 0;
+  for (int lv = 0; lv < S.n_levels; ++lv)
+    for (int p = 0; p < n_sub; ++p) {
+      if (S.level_of[p] != lv) continue;
+      for (int q = 0; q < S.nslot_lu; ++q) {
+        if (S.slot_row[q] != p || S.slot_col[q] == p) continue;
+        const int o = S.slot_col[q];
+        if (S.level_of[o] == lv) return -4;                        // adjacent pivots in one level
+        if (S.level_of[o] < lv) depth[p] = std::max(depth[p], depth[o] + 1);
+      }
+      height = std::max(height, depth[p] + 1);
+    }
+  if (S.n_levels < height) return -5;
+  const gpf::FlatProg F = gpf::build_flat(S, gw, 0);
+  if (out) { out[0] = S.n_levels; out[1] = height; out[2] = F.n_fwd + F.n_back; }
+  return 0;
+}

@@ -142,3 +142,28 @@ def test_slot_layout_search_keeps_the_program_valid(emul, load_model, name):
         assert np.abs(x - ref).max() < 1e-9 * max(1.0, np.abs(ref).max()), gw
         assert cost[1] <= cost[0], cost
     assert cost[1] < cost[0] or n <= 5
+
+
+@pytest.mark.parametrize("name", ["rte_case5_example", "l2rpn_case14_sandbox", "l2rpn_neurips_2020_track1", "l2rpn_wcci_2022_dev"])
+def test_level_schedules_are_valid_and_rescheduling_reaches_the_dag_height(emul, load_model, name):
+    """build_symbolic's level schedules (greedy minimum degree; re-scheduled on the elimination DAG by list scheduling): pivots of a
+    level pairwise non-adjacent in the filled pattern, every updating pivot in an earlier level, each substation eliminated once.
+    The re-scheduled variant has exactly as many levels as the elimination DAG is high; it is only TAKEN (resched = -1) when it has
+    fewer passes at the grid's usual group width."""
+    m = load_model(name)
+    lor = np.ascontiguousarray(m.line_or_sub, dtype=np.int32)
+    lex = np.ascontiguousarray(m.line_ex_sub, dtype=np.int32)
+    ip = C.POINTER(C.c_int32)
+    n = m.n_sub
+    gw = 16 if n <= 8 else 32 if n <= 24 else 64 if n < 64 else 128
+    res = {}
+    for mode in (0, 1, -1):
+        out = np.zeros(3, dtype=np.int32)
+        rc = emul.sym_check_schedule(n, m.n_line, lor.ctypes.data_as(ip), lex.ctypes.data_as(ip), mode, gw, out.ctypes.data_as(ip))
+        assert rc == 0, (name, mode, rc)
+        res[mode] = tuple(int(v) for v in out)
+    assert res[1][0] == res[1][1]                              # list scheduling: levels == height of the DAG
+    assert res[1][0] <= res[0][0]
+    assert res[-1][2] == min(res[0][2], res[1][2])             # auto: the variant with fewer passes
+    if name == "l2rpn_wcci_2022_dev":
+        assert res[1][2] < res[0][2] and res[1][0] == 13
