@@ -53,7 +53,10 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 F64_PEAK_TFLOPS = 78.6         # MI355X FP64 vector == FP64 matrix peak (spec)
-TRAFFIC_PROFILE = os.path.join("profiles", "r03_traffic.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r04_traffic.json")
+TRAFFIC_N1 = os.path.join("profiles", "r04_traffic_n1_neurips36.json")
+TRAFFIC_WCCI = os.path.join("profiles", "r04_traffic_wcci118.json")
+TRAFFIC_IDF = os.path.join("profiles", "r04_traffic_idf118.json")
 CASCADE_LIMIT_SCALE = 0.85     # `cascade_tripping` secondary: thermal limits x 0.85 -> ~20 % of the lane-steps overflow softly
 
 
@@ -125,11 +128,11 @@ def usable_cores():
     return n, how
 
 
-def traffic_profile():
+def traffic_profile(rel=None):
     """HBM bytes per launch of the dominant kernel from the COMMITTED rocprofv3 PMC run (FETCH_SIZE and WRITE_SIZE collected
     in separate --pmc passes of this same command, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950).  Not
     measured in this run: the JSON says so (``traffic_source``)."""
-    for rel in (TRAFFIC_PROFILE,):
+    for rel in (rel or TRAFFIC_PROFILE,):
         try:
             with open(os.path.join(ROOT, rel)) as f:
                 d = json.load(f)
@@ -289,7 +292,12 @@ def timed_windows(ctx, eng, steps, warmup, step_kw, n_windows, t0=0, preroll_ste
         el = time.perf_counter() - w0
         k_ms, n_l = eng.kernel_time()
         eng.set_profiling(0)
-        out.append((ctx.max(el), k_ms, n_l))
+        # the timed quantity: this rank's HIP-event window around its K steps (first launch begins ... last launch ends, on the
+        # engine's stream), MAX-reduced over the ranks AFTER the window -- the closing barrier (tens of microseconds of RCCL / gloo)
+        # is outside it.  The wall clock between the two barrier + synchronize brackets is kept beside it (`wall`).
+        wall = ctx.max(el)
+        dev = ctx.max(k_ms * 1e-3) if k_ms > 0 else wall
+        out.append((dev, k_ms, n_l, wall))
     return out, t
 
 
@@ -301,8 +309,58 @@ def median_window(wins):
 def summarize(wins, total_steps_per_window):
     el = [w[0] for w in wins]
     med = median_window(wins)[0]
-    return {"n": len(wins), "value_median": total_steps_per_window / med, "value_min": total_steps_per_window / max(el),
-            "value_max": total_steps_per_window / min(el), "elapsed_ms": [round(e * 1e3, 4) for e in el]}
+    out = {"n": len(wins), "value_median": total_steps_per_window / med, "value_min": total_steps_per_window / max(el),
+           "value_max": total_steps_per_window / min(el), "elapsed_ms": [round(e * 1e3, 4) for e in el]}
+    if len(wins[0]) > 3:
+        out["wall_clock_ms"] = [round(w[3] * 1e3, 4) for w in wins]
+        out["value_wall_clock_median"] = total_steps_per_window / sorted(w[3] for w in wins)[len(wins) // 2]
+    return out
+
+
+def measure_modes(ctx, eng, k, w, step_kw, n_win, preroll_steps, spl=None, last_obs_too=True):
+    """One workload in the two observation contracts: (1) EVERY env step of a launch writes its complete backend observation to its
+    own rows in HBM (gpf_set_trajectory GPF_TRAJ_OBS: the reference returns one observation per env.step) -- the figure every
+    config reports --, (2) the labelled sibling: each step overwrites the lane's row, only the last observation of a launch exists.
+    Returns (windows with observations, windows last-observation-only or None, next time index)."""
+    spl = ctx.args.steps_per_launch if spl is None else spl
+    traj = spl > 1 and not ctx.args.stub_engine and not ctx.args.last_obs_only
+    if traj:
+        eng.set_trajectory(spl, eng.TRAJ_OBS)
+    w_obs, t = timed_windows(ctx, eng, k, w, step_kw, n_win, preroll_steps=preroll_steps, spl=spl)
+    w_last = None
+    if traj and last_obs_too:
+        eng.set_trajectory(0)
+        w_last, _ = timed_windows(ctx, eng, k, 0, step_kw, max(2, n_win - 1), t0=t, preroll_steps=0, spl=spl)
+        eng.set_trajectory(spl, eng.TRAJ_OBS)        # the engine keeps the observation contract for whatever follows (spot checks read it)
+    return w_obs, w_last, t
+
+
+OBS_EVERY = ("every env step: each step of a launch writes its complete backend observation (results row, topo_vect, shunt buses, line "
+             "status, rho, status) to its own rows in HBM (gpf_set_trajectory GPF_TRAJ_OBS)")
+OBS_LAST = "LAST step of each launch only (each step overwrites the lane's result row) -- NOT the reference's env.step contract"
+
+
+def roofline_block(eng, wins, B, k, profile, note=None):
+    """`roofline` of one workload: ALGORITHMIC bytes per launch (SURVEY.md 8(d) bytes per env step x lanes x steps per launch) / the
+    average launch duration of the median HIP-event window; `traffic` = PMC bytes per launch of the committed profile of the same
+    command (profiles/<profile>, rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE)."""
+    med = median_window(wins)
+    n_l = max(int(med[2]), 1)
+    avg_s = (med[1] * 1e-3) / n_l if med[1] > 0 else med[0] / n_l
+    b_step = eng.algorithmic_bytes_per_step()
+    spl_eff = k / n_l
+    gbs = b_step * B * spl_eff / avg_s / 1e9 if avg_s > 0 else 0.0
+    tp = traffic_profile(profile)
+    blk = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "traffic": tp.get("hbm_bytes_per_launch"), "traffic_over_algorithmic": tp.get("traffic_over_algorithmic"),
+           "traffic_source": (f"committed profile {tp.get('_file')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
+                              f"{tp.get('env_steps_per_launch')} env steps per launch, observation trajectory on; NOT measured in this run)") if tp else None,
+           "kernel": tp.get("kernel"), "avg_launch_us": avg_s * 1e6, "launches": n_l, "env_steps_per_launch": spl_eff,
+           "algorithmic_bytes_per_step": b_step, "lds_pipe_busy_frac": tp.get("lds_pipe_busy_frac"),
+           "lds_bank_conflict_frac_of_lds_cycles": tp.get("lds_bank_conflict_frac_of_lds_cycles"), "valu_busy_frac": tp.get("valu_busy_frac")}
+    if note:
+        blk["note"] = note
+    return blk
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -334,6 +392,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo")
     ap.add_argument("--only-env-dynamics", action="store_true",
                     help="developer (profiling): run only the 118-substation workload with the injection dynamics on and print its record")
+    ap.add_argument("--only", default=None, choices=["n1_fanout", "secondary", "dc_ptdf", "secondary_env_dynamics"],
+                    help="developer (profiling): run only that BASELINE config's workload exactly as the default run does and print its record")
     ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)   # CPU launcher test: no arithmetic
     args = ap.parse_args()
     if args.gpus < 1:
@@ -355,6 +415,15 @@ def main():
         if rank == 0:
             print(json.dumps(dyn))
         return
+    if args.only:
+        k_o, w_o = max(16, args.steps), max(2, args.warmup)
+        rec = {"n1_fanout": lambda: workload_n1(ctx, "l2rpn_neurips_2020_track1", 1024, k_sec=k_o),
+               "secondary": lambda: workload_wcci(ctx, "l2rpn_wcci_2022_dev", 1024, k_o, w_o, args.cascade),
+               "secondary_env_dynamics": lambda: workload_wcci_dynamics(ctx, "l2rpn_wcci_2022_dev", 1024, k_o, w_o),
+               "dc_ptdf": lambda: workload_ptdf(ctx, "l2rpn_idf_2023", 2048, 50, k_sec=k_o, w_sec=w_o)}[args.only]()
+        if rank == 0:
+            print(json.dumps(rec))
+        return
     m, ch = load_env(args.env)
     n_envs = args.batch
     fan = 1 + m.n_line if args.n1 else 1
@@ -374,7 +443,7 @@ def main():
         eng.set_trajectory(args.steps_per_launch, eng.TRAJ_OBS)     # every step of a launch writes its observation to HBM
 
     wins, t_next = timed_windows(ctx, eng, args.steps, args.warmup, step_kw, args.windows)
-    elapsed, kern_ms, n_launch = median_window(wins)
+    elapsed, kern_ms, n_launch, wall_el = median_window(wins)
     r = eng.results()
     check = oracle_spot_check(ctx, eng, 32, t_last=None if (args.cascade or args.n1) else t_next - 1) if rank == 0 else None
     if args.dump_results:
@@ -413,15 +482,16 @@ def main():
                                    f"(row (t+7k) mod {T}, loads x (1+0.05 N(0,1)), prod_p rebalanced to 1.02 sum(load))",
                        "env": args.env, "lanes_per_gpu": B, "envs_per_gpu": n_envs, "total_lanes": world * B, "n1_fanout": fan,
                        "cascade": bool(args.cascade), "max_iter": 10, "tol_mva": 1e-8, "env_steps_per_launch": args.steps_per_launch,
-                       "observations": ("every env step: each of the steps of a launch writes its complete backend observation "
-                                        "(results row, topo_vect, shunt buses, line status, rho, status) to its own rows in HBM "
-                                        "(gpf_set_trajectory GPF_TRAJ_OBS)") if obs_every_step else
-                                       ("every env step (one launch per step)" if args.steps_per_launch == 1 else
-                                        "LAST step of each launch only (each step overwrites the lane's result row)"),
+                       "observations": OBS_EVERY if obs_every_step else
+                                       ("every env step (one launch per step)" if args.steps_per_launch == 1 else OBS_LAST),
                        "share_device": bool(args.share_device), "dist_backend": args.dist_backend if ctx.dist is not None else None,
                        "parallelism": f"independent lanes, static shard x{world} (one process per GPU), no collective"},
             "windows": dict(summarize(wins, total_steps), steps_each=args.steps,
-                            note="value / ms_per_step are those of the median window; each window is bracketed by barrier + sync"),
+                            note="value / ms_per_step are those of the median window.  Timed quantity: the HIP-event window on the engine's "
+                                 "stream around the K steps of each rank (first launch begins ... last launch ends), MAX-reduced over the ranks; "
+                                 "every window is bracketed by barrier + synchronize on both sides, whose wall clock is value_wall_clock_median "
+                                 "(the closing barrier of an N-rank run is outside the event window)"),
+            "value_wall_clock": total_steps / wall_el, "ms_per_step_wall_clock": wall_el / args.steps * 1e3,
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": tp.get("hbm_bytes_per_launch"),
                          "achieved_is": "ALGORITHMIC bytes per launch (SURVEY.md 8(d): inputs + outputs of one env step at API dtype, x "
@@ -453,10 +523,14 @@ def main():
     k_sec = max(20, args.steps // 4)
     w_sec = max(2, args.warmup // 4)
 
+    def sib(w_last, n_lanes_total, k):
+        return None if w_last is None else dict(summarize(w_last, n_lanes_total * k), unit="env steps/sec", observations=OBS_LAST)
+
     # ---- the same workload WITHOUT the observation trajectory: only the last observation of each launch exists in HBM --------
     if secondary and obs_every_step:
         eng.set_trajectory(0)
         w, _ = timed_windows(ctx, eng, k_sec, w_sec, step_kw, 3, preroll_steps=0)
+        eng.set_trajectory(args.steps_per_launch, eng.TRAJ_OBS)
         if rank == 0:
             res["rollout_last_observation_only"] = dict(
                 summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec, us_per_step=median_window(w)[0] / k_sec * 1e6,
@@ -469,16 +543,17 @@ def main():
         w, t_l = timed_windows(ctx, eng, k_sec, w_sec, step_kw, 3, preroll_steps=0, spl=1)
         if rank == 0:
             res["one_launch_per_step"] = dict(summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec,
+                                              observations="every env step (one launch per step: the lane's own rows)",
                                               us_per_step=median_window(w)[0] / k_sec * 1e6,
                                               oracle_check=oracle_spot_check(ctx, eng, 32, t_last=t_l - 1, seed=1))
 
     # ---- OPT-IN, NOT the reference's algorithm (never the headline): Newton warm-started from the previous step -----------------
     if secondary and args.steps_per_launch != 1:
         eng.reset()
-        w, _ = timed_windows(ctx, eng, k_sec, w_sec, dict(step_kw, warm_start=True), 3, preroll_steps=0)
+        w, w_l, _ = measure_modes(ctx, eng, k_sec, w_sec, dict(step_kw, warm_start=True), 3, 0, last_obs_too=False)
         rw = eng.results()
         if rank == 0:
-            res["warm_start_opt_in"] = dict(summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec,
+            res["warm_start_opt_in"] = dict(summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec, observations=OBS_EVERY,
                                             note="gpf_step_opts.warm_start=1: steps 2..n of a launch start Newton from the previous "
                                                  "step's voltages instead of pandapower's per-call DC initialisation; same solution "
                                                  "within tol_mva, n_iter differs from the reference's; NOT used for `value`",
@@ -489,11 +564,13 @@ def main():
     # ---- the same workload with the reference's DEFAULT parameters: overflow disconnections (cascade) on ---------------------
     if secondary and not args.cascade:
         eng.reset()
-        w, _ = timed_windows(ctx, eng, k_sec, w_sec, dict(rebalance=1.02, cascade=True, auto_reset=True), 3, preroll_steps=0)
+        kw_c = dict(rebalance=1.02, cascade=True, auto_reset=True)
+        w, w_l, _ = measure_modes(ctx, eng, k_sec, w_sec, kw_c, 3, 0)
         rc = eng.results()
         _, _, n_resets = eng.episode()
         if rank == 0:
-            res["cascade_on"] = dict(summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec,
+            res["cascade_on"] = dict(summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec, observations=OBS_EVERY,
+                                     last_observation_only=sib(w_l, world * B, k_sec),
                                      workload="same lanes, Parameters.NO_OVERFLOW_DISCONNECTION=False (hard_overflow 2.0, "
                                               "NB_TIMESTEP_OVERFLOW_ALLOWED 2): lines trip and the power flow is re-run inside the step; "
                                               "a lane whose step fails (game over) restarts at the next step like env.reset() "
@@ -506,21 +583,19 @@ def main():
         # ... and with thermal limits x CASCADE_LIMIT_SCALE, so that lines really trip and the power flow is re-run inside the step
         if "thermal_limits" in ch:
             eng.set_thermal_limits(ch["thermal_limits"] * np.float32(CASCADE_LIMIT_SCALE))
-            eng.set_trajectory(args.steps_per_launch, eng.TRAJ_RHO)
-            w, _ = timed_windows(ctx, eng, k_sec, w_sec, dict(rebalance=1.02, cascade=True, auto_reset=True), 3, preroll_steps=0)
+            w, w_l, _ = measure_modes(ctx, eng, k_sec, w_sec, kw_c, 3, 0, last_obs_too=False)
             rc = eng.results()
             _, _, n_resets = eng.episode()
             rounds = rc.status[:, 3]
             if rank == 0:
                 res["cascade_tripping"] = dict(
-                    summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec,
+                    summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec, observations=OBS_EVERY,
                     workload=f"as cascade_on with thermal limits x {CASCADE_LIMIT_SCALE}: soft overflows accumulate, lines trip, the "
                              "power flow is re-solved inside the step, lanes that end islanded / diverged restart (auto_reset)",
                     frac_converged=float(rc.converged.mean()),
                     frac_lanes_with_a_tripped_line=float((~rc.line_status).any(axis=1).mean()),
                     frac_lanes_resolved_in_last_step=float((rounds > 0).mean()), lane_resets=int(np.asarray(n_resets).sum()),
                     oracle_check=oracle_spot_check(ctx, eng, 32, seed=2, alive_only=True))
-            eng.set_trajectory(0)
             eng.set_thermal_limits(ch["thermal_limits"])
         eng.reset()
 
@@ -535,26 +610,29 @@ def main():
         for q in line_pos[::2][:max(1, len(line_pos) // 2 - 1)]:
             topo[pick, q] = 2
         eng.set_topology(topo)
-        w, _ = timed_windows(ctx, eng, k_sec, w_sec, step_kw, 3, preroll_steps=0)
+        w, w_l, _ = measure_modes(ctx, eng, k_sec, w_sec, step_kw, 3, 0)
         conv_s = float(eng.results().converged.mean())
         if rank == 0:
-            res["split_topologies"] = dict(summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec,
+            res["split_topologies"] = dict(summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec, observations=OBS_EVERY,
+                                           last_observation_only=sib(w_l, world * B, k_sec),
                                            oracle_check=oracle_spot_check(ctx, eng, 32, seed=3),
                                            workload=f"{args.env}, batch={B}: substation {sub} split (lines alternating between its two "
                                                     f"busbars) in {100.0 * pick.mean():.0f} % of the lanes", frac_converged=conv_s)
     eng.close()
 
-    # ---- batch sweep (throughput vs lanes per GPU) ------------------------------------------------------------------------
+    # ---- batch sweep (throughput vs lanes per GPU), observation per env step at every point -----------------------------------
     if secondary and world == 1:
         sweep = []
         for Bs in (1024, 2048, 8192, 16384, 65536):
             e_s, _, _ = setup_engine(ctx, m, ch, Bs)
             k_s = max(10, min(k_sec, 200 * 4096 // Bs))
-            w, _ = timed_windows(ctx, e_s, k_s, 2, step_kw, 3, preroll_steps=20)
-            sweep.append({"lanes": Bs, "value": Bs * k_s / median_window(w)[0], "us_per_step": median_window(w)[0] / k_s * 1e6})
+            w, w_l, _ = measure_modes(ctx, e_s, k_s, 2, step_kw, 3, 20)
+            sweep.append({"lanes": Bs, "value": Bs * k_s / median_window(w)[0], "us_per_step": median_window(w)[0] / k_s * 1e6,
+                          "value_last_observation_only": Bs * k_s / median_window(w_l)[0] if w_l else None})
             e_s.close()
-        sweep.append({"lanes": B, "value": res["value"], "us_per_step": res["ms_per_step"] * 1e3})
-        res["batch_sweep"] = {"unit": "env steps/sec", "workload": f"{args.env}, same synthetic inputs, 1 GPU",
+        sweep.append({"lanes": B, "value": res["value"], "us_per_step": res["ms_per_step"] * 1e3,
+                      "value_last_observation_only": (res.get("rollout_last_observation_only") or {}).get("value_median")})
+        res["batch_sweep"] = {"unit": "env steps/sec", "workload": f"{args.env}, same synthetic inputs, 1 GPU", "observations": OBS_EVERY,
                               "points": sorted(sweep, key=lambda d: d["lanes"])}
 
     # ---- BASELINE.json configs[2]: 36-substation grid, 1024 envs x (1 + 59 N-1 outages) fused into one batch ------------------
@@ -584,7 +662,7 @@ def main():
 
     # ---- DC sensitivity path of BASELINE.json configs[4]: l2rpn_idf_2023, 2048 lanes, PTDF GEMM next to the AC solve ------------
     if secondary and world == 1:
-        res["dc_ptdf"] = workload_ptdf(ctx, "l2rpn_idf_2023", 2048, max(20, args.steps // 2))
+        res["dc_ptdf"] = workload_ptdf(ctx, "l2rpn_idf_2023", 2048, max(20, args.steps // 2), k_sec=max(16, k_sec // 4), w_sec=w_sec)
 
     if rank == 0:
         # the CPU baseline is timed LAST (rank 0 of the 1-GPU run only): host-only work in the middle of the run would
@@ -615,14 +693,20 @@ def workload_n1(ctx, env, n_envs, k_sec):
         topo[c::fan, m.line_or_pos_topo_vect[c - 1]] = -1
         topo[c::fan, m.line_ex_pos_topo_vect[c - 1]] = -1
     eng.set_topology(topo)
-    w, _ = timed_windows(ctx, eng, k_sec, 2, dict(rebalance=1.02), 3, preroll_steps=10)
+    w, w_l, _ = measure_modes(ctx, eng, k_sec, 2, dict(rebalance=1.02), 3, 10)
     r = eng.results()
     med = median_window(w)[0]
     out = {"workload": f"{env} (36 substations): {n_envs} envs x (1 intact + {m.n_line} single-line outages) = {B} lanes per GPU, the "
                        f"obs.simulate / N1Reward fan-out fused into the stepped batch (BASELINE.json configs[2])",
+           "observations": OBS_EVERY if not ctx.args.last_obs_only else OBS_LAST,
            "value": ctx.world * n_envs * k_sec / med, "unit": "env steps/sec (each with its full N-1 screening)",
            "lane_power_flows_per_sec": ctx.world * B * k_sec / med, "ms_per_step": med / k_sec * 1e3, "steps_each": k_sec,
-           "windows": summarize(w, ctx.world * n_envs * k_sec), "frac_converged": float(r.converged.mean()),
+           "windows": summarize(w, ctx.world * n_envs * k_sec),
+           "last_observation_only": None if w_l is None else dict(summarize(w_l, ctx.world * n_envs * k_sec), observations=OBS_LAST,
+                                                                  lane_power_flows_per_sec=ctx.world * B * k_sec / median_window(w_l)[0]),
+           "roofline": roofline_block(eng, w, B, k_sec, TRAFFIC_N1),
+           "plan": eng.plan() if hasattr(eng, "plan") else None,
+           "frac_converged": float(r.converged.mean()),
            "frac_contingencies_diverged_or_islanding": float(1.0 - r.converged.reshape(n_envs, fan)[:, 1:].mean()),
            "oracle_check": oracle_spot_check(ctx, eng, 64, seed=4)}
     eng.close()
@@ -650,17 +734,18 @@ def workload_wcci(ctx, env, n_envs, k_sec, w_sec, cascade):
             delta[k, a], delta[k, b] = 1.0, -1.0
         eng.set_lane_redispatch(delta)
         note += " and a zero-sum +-1 MW redispatch on 2 random generators per lane"
-    w, _ = timed_windows(ctx, eng, k_sec, w_sec, dict(rebalance=1.02, cascade=cascade), 3, preroll_steps=20)
-    med, k_ms, n_l = median_window(w)
+    w, w_l, _ = measure_modes(ctx, eng, k_sec, w_sec, dict(rebalance=1.02, cascade=cascade), 3, 20)
+    med = median_window(w)[0]
     r = eng.results()
     out = None
     if ctx.rank == 0:
-        b2 = eng.algorithmic_bytes_per_step()
-        us = k_ms / max(n_l, 1) * 1e3
         out = {"workload": f"{env} (118 substations) AC NR env.step{note}, batch={B} lanes per GPU (BASELINE.json configs[3])",
+               "observations": OBS_EVERY if not ctx.args.last_obs_only else OBS_LAST,
                "value": ctx.world * B * k_sec / med, "unit": "env steps/sec", "ms_per_step": med / k_sec * 1e3, "steps_each": k_sec,
-               "windows": summarize(w, ctx.world * B * k_sec), "avg_launch_us": us, "algorithmic_bytes_per_step": b2,
-               "hbm_gbs": b2 * B * (k_sec / max(n_l, 1)) / (us * 1e-6) / 1e9 if us > 0 else 0.0,
+               "windows": summarize(w, ctx.world * B * k_sec),
+               "last_observation_only": None if w_l is None else dict(summarize(w_l, ctx.world * B * k_sec), observations=OBS_LAST),
+               "roofline": roofline_block(eng, w, B, k_sec, TRAFFIC_WCCI),
+               "plan": eng.plan() if hasattr(eng, "plan") else None,
                "frac_converged": float(r.converged.mean()), "mean_nr_iterations": float(r.n_iter[r.converged].mean()),
                "oracle_check": oracle_spot_check(ctx, eng, 32, seed=5)}
     eng.close()
@@ -671,7 +756,7 @@ def workload_wcci_dynamics(ctx, env, n_envs, k_sec, w_sec):
     """configs[3] with gpf_set_env_dynamics: every lane holds a storage action U(-2, 2) MW per unit over the launch and starts it with a
     zero-sum +-1 MW redispatch on two generators; the kernel evolves the state of charge and re-solves the ramp-limited dispatch
     (BaseEnv._compute_dispatch_vect) at every step.  Generator / storage characteristics: tests/golden/envdyn_<env>.npz (recorded from
-    the reference environment)."""
+    the reference environment).  Every step of a launch writes its observation to HBM (trajectory on)."""
     m, ch = load_env(env)
     fxp = os.path.join(GOLD, f"envdyn_{env}.npz")
     if not os.path.exists(fxp) or ctx.args.stub_engine:
@@ -694,6 +779,9 @@ def workload_wcci_dynamics(ctx, env, n_envs, k_sec, w_sec):
         sto[k] = rg.uniform(-2.0, 2.0, m.n_storage)
     spl = ctx.args.steps_per_launch
     kw = dict(rebalance=1.02, auto_reset=True)
+    traj = spl > 1 and not ctx.args.last_obs_only
+    if traj:
+        eng.set_trajectory(spl, eng.TRAJ_OBS)
 
     def run(t, n):
         done = 0
@@ -720,6 +808,7 @@ def workload_wcci_dynamics(ctx, env, n_envs, k_sec, w_sec):
                            f"held storage action U(-2,2) MW per unit and a zero-sum +-1 MW redispatch at every launch boundary ({spl} steps); the "
                            "state of charge and the ramp-limited dispatch (BaseEnv._compute_dispatch_vect, exact QP) evolve at every step "
                            "inside the launch (BASELINE.json configs[3]: storage + redispatch actions); actions uploaded from the host per launch",
+               "observations": OBS_EVERY if traj else OBS_LAST, "timing": "wall clock incl. the per-launch upload of the agents' actions",
                "value": ctx.world * B * k_sec / med, "unit": "env steps/sec", "ms_per_step": med / k_sec * 1e3, "steps_each": k_sec,
                "windows": summarize(wins, ctx.world * B * k_sec), "frac_converged": float(r.converged.mean()),
                "frac_infeasible_redispatch": float((r.status[:, 0] == 6).mean()),
@@ -801,19 +890,29 @@ def workload_single_env(ctx, env, reps):
             "frac_converged": ok / reps}
 
 
-def workload_ptdf(ctx, env, B, reps):
-    from grid2op_amd.grid_model import GridModel
-    m = GridModel.load_npz(os.path.join(GOLD, f"{env}.grid.npz"))
-    eng = ctx.make_engine(m, B)
-    inj = np.tile(eng.get_injections(0, 1), (B, 1))
+def workload_ptdf(ctx, env, B, reps, k_sec=64, w_sec=16):
+    """BASELINE.json configs[4] as SURVEY.md 8(d) specifies it: l2rpn_idf_2023 (118 substations), chronics 2035-01-15_0 (576 rows x
+    {99 load_p, 99 load_q, 62 prod_p}; tests/golden/l2rpn_idf_2023.chronics.npz), lane k on row (t + 7k) mod 576 with the jitter of
+    default_rng(k), batch = 2048 lanes: (1) AC Newton-Raphson env steps, one observation per step; (2) the DC sensitivity path next to
+    it ON THE SAME CHRONICS ROWS -- the injection rows the last AC step of every lane left on the device are evaluated as ONE FP64-MFMA
+    PTDF GEMM."""
+    m, ch = load_env(env)
+    eng, T, l0 = setup_engine(ctx, m, ch, B)
     lay = eng.layout
-    for k in range(B):                                   # +-5 % load jitter per lane, generators follow
-        f = 1.0 + 0.05 * np.random.default_rng(k).standard_normal(m.n_load)
-        lp = inj[k, lay.inj_load_p:lay.inj_load_p + m.n_load]
-        gp = inj[k, lay.inj_gen_p:lay.inj_gen_p + m.n_gen]
-        gp *= (lp * f).sum() / lp.sum()
-        lp *= f
-    eng.set_injections(inj)
+    kw = dict(rebalance=1.02)
+    w, w_l, t_next = measure_modes(ctx, eng, k_sec, w_sec, kw, 3, 20)
+    med = median_window(w)[0]
+    r_ac = eng.results()
+    ac = {"workload": f"{env} (118 substations) AC NR DoNothing env.step on chronics 2035-01-15_0 (row (t+7k) mod {T}, loads x (1+0.05 N(0,1)), "
+                      f"prod_p rebalanced), batch={B} lanes per GPU", "observations": OBS_EVERY if not ctx.args.last_obs_only else OBS_LAST,
+          "value": ctx.world * B * k_sec / med, "unit": "env steps/sec", "ms_per_step": med / k_sec * 1e3, "steps_each": k_sec,
+          "windows": summarize(w, ctx.world * B * k_sec),
+          "last_observation_only": None if w_l is None else dict(summarize(w_l, ctx.world * B * k_sec), observations=OBS_LAST),
+          "roofline": roofline_block(eng, w, B, k_sec, TRAFFIC_IDF), "plan": eng.plan() if hasattr(eng, "plan") else None,
+          "frac_converged": float(r_ac.converged.mean()), "mean_nr_iterations": float(r_ac.n_iter[r_ac.converged].mean()),
+          "oracle_check": oracle_spot_check(ctx, eng, 32, t_last=t_next - 1, seed=9)}
+    # ---- the DC sensitivity path on the rows the lanes hold now (= chronics rows of step t_next - 1, jittered and rebalanced) ------
+    inj = eng.get_injections()
     eng.ptdf_build(0)
     for _ in range(3):
         eng.ptdf_flows(fetch=False)
@@ -829,17 +928,18 @@ def workload_ptdf(ctx, env, B, reps):
     flows = eng.ptdf_flows()
     ptdf_check = None
     if not ctx.args.no_oracle_check and not ctx.args.stub_engine:
-        try:                                              # CHECKER leg: 32 lanes vs the C oracle's DC power flow (pp.rundcpp restated)
+        try:                                              # CHECKER leg: 64 lanes vs the C oracle's DC power flow (pp.rundcpp restated)
             from oracle.pf_oracle_c import COracle
-            ls_ = np.sort(np.random.default_rng(6).choice(B, 32, replace=False))
+            ls_ = np.sort(np.random.default_rng(6).choice(B, 64, replace=False))
             topo_, sb_ = eng.get_topology(0, 1)
-            ref = COracle(m).solve_rows(inj[ls_], np.tile(topo_, (32, 1)), np.tile(sb_, (32, 1)) if m.n_shunt else None, is_dc=True)
+            ref = COracle(m).solve_rows(inj[ls_], np.tile(topo_, (64, 1)), np.tile(sb_, (64, 1)) if m.n_shunt else None, is_dc=True)
             p_ref = ref["out"][:, lay.out_p_or:lay.out_p_or + m.n_line]
-            ptdf_check = {"n": 32, "max_abs_err_vs_oracle": float(np.abs(flows[ls_] - p_ref).max()),
+            ptdf_check = {"n": 64, "max_abs_err_vs_oracle": float(np.abs(flows[ls_] - p_ref).max()),
                           "ok": bool(np.all(np.abs(flows[ls_] - p_ref) <= 2e-4 + 5e-6 * np.abs(p_ref))),
-                          "against": "oracle/pf_oracle.c DC power flow of the same injection rows"}
+                          "against": "oracle/pf_oracle.c DC power flow of the same injection rows (64 lanes)"}
         except Exception as exc:
             ptdf_check = {"error": repr(exc)[:300]}
+    rows_rec = workload_ptdf_rows(ctx, eng, m, B, t_next) if hasattr(eng, "ptdf_flows_rows") else None
     eng.lodf_screen(0, 8)
     t0 = time.perf_counter()
     for _ in range(5):
@@ -855,7 +955,6 @@ def workload_ptdf(ctx, env, B, reps):
         eng.sync()
         return (time.perf_counter() - t1) / 5, eng.results()
     dc_s, r_dc = timed_runpf(True)
-    ac_s, r_ac = timed_runpf(False)
     nb_act = int(r_dc.status[0, 2])                     # active buses of the topology = K of the GEMM
     nb_pad, line_pad = (nb_act + 3) // 4 * 4, (m.n_line + 15) // 16 * 16
     us = k_ms / max(n_l, 1) * 1e3
@@ -884,22 +983,22 @@ def workload_ptdf(ctx, env, B, reps):
                "hbm_gbs": (8.0 * Bb * lay.n_inj + 4.0 * Bb * line_pad) / (usb * 1e-6) / 1e9}
     except Exception as exc:          # (memory on a shared box): the headline does not depend on it
         big = {"error": str(exc)[:200]}
-    out = {"workload": f"{env} (118 substations) batch={B} lanes per GPU: DC line flows of every lane as ONE FP64 MFMA GEMM "
-                       f"(flows = P_bus[{B}x{nb_pad}] . PTDF^T[{nb_pad}x{line_pad}], P_bus built in LDS from the injection rows in the "
-                       f"same launch) for a fixed topology",
+    out = {"workload": f"{env} (118 substations) batch={B} lanes per GPU, chronics 2035-01-15_0: AC env steps (`ac_env_steps`) and, alongside, "
+                       f"the DC line flows of every lane's current chronics row as ONE FP64 MFMA GEMM (flows = P_bus[{B}x{nb_pad}] . "
+                       f"PTDF^T[{nb_pad}x{line_pad}], P_bus built in LDS from the injection rows in the same launch) for the fixed topology "
+                       f"(BASELINE.json configs[4])",
+           "ac_env_steps": ac, "chronics_rows_per_launch": rows_rec,
            "large_batch": big, "oracle_check": ptdf_check,
            "value": B * reps / el, "unit": "DC power flows/sec", "us_per_batch": us, "launches_per_batch": n_l / max(reps, 1),
            "roofline": {"bound": "mfma", "achieved": tf, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_PEAK_TFLOPS,
-                        "hbm_gbs": hbm_bytes / (us * 1e-6) / 1e9 if us > 0 else 0.0,
-                        "note": f"{2.0 * B * nb_pad * line_pad / 1e6:.0f} MFLOP and {hbm_bytes / 1e6:.1f} MB per batch: launch / latency bound at "
-                                f"this size (see large_batch)"},
+                        "hbm_gbs": hbm_bytes / (us * 1e-6) / 1e9 if us > 0 else 0.0, "traffic": None,
+                        "note": f"{2.0 * B * nb_pad * line_pad / 1e6:.0f} MFLOP and {hbm_bytes / 1e6:.1f} MB per launch of ONE chronics row per lane: "
+                                f"launch / latency bound at this size (see chronics_rows_per_launch and large_batch)"},
            "per_lane_dc_solve_value": B / dc_s, "per_lane_dc_solve_unit": "DC power flows/sec (kernel S, B' refactorised per lane)",
            "max_abs_diff_vs_per_lane_dc_solve_mw": float(np.abs(flows - r_dc.p_or).max()),
            "lodf_n1_value": B * m.n_line / lodf_s, "lodf_n1_unit": "DC contingency cases/sec (every single-line outage of "
            "every lane: worst post-outage flow via LODF, result copied to the host)",
            "lodf_n1_frac_islanding": float(np.isinf(worst).mean()),
-           "ac_runpf_value": B / ac_s, "ac_runpf_unit": "AC power flows/sec (same lanes, gpf_runpf)",
-           "ac_frac_converged": float(r_ac.converged.mean()),
            "max_abs_dc_vs_ac_p_or_mw": float(np.abs(flows - r_ac.p_or)[r_ac.converged].max())}
     eng.close()
     return out

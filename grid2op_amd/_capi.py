@@ -16,6 +16,7 @@ __all__ = ["lib", "GridPFError", "GpfGridDesc", "GpfLayout", "GpfStepOpts", "lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libgridpf.so"
+ABI_VERSION = 300          # include/gridpf.h GPF_ABI_VERSION
 
 EXPORTED_SYMBOLS = [
     "gpf_last_error", "gpf_version", "gpf_set_deterministic", "gpf_device_count", "gpf_create", "gpf_destroy", "gpf_get_layout", "gpf_n_lanes",
@@ -24,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "gpf_upload_maintenance", "gpf_upload_hazards", "gpf_set_lane_chronics", "gpf_set_thermal_limits", "gpf_step", "gpf_step_n", "gpf_set_lane_redispatch", "gpf_set_gen_limits", "gpf_redispatch", "gpf_set_trajectory",
     "gpf_get_trajectory", "gpf_get_trajectory_obs", "gpf_upload_forecasts", "gpf_simulate_batch", "gpf_set_overflow_count",
     "gpf_set_storage_params", "gpf_set_env_dynamics", "gpf_set_lane_actions", "gpf_get_env_state", "gpf_set_env_state", "gpf_set_gen_renewable", "gpf_set_lane_curtailment", "gpf_get_episode", "gpf_lane_capacity", "gpf_get_step_outputs", "gpf_sync",
-    "gpf_set_profiling", "gpf_get_kernel_time", "gpf_get_plan", "gpf_device_pointers",
+    "gpf_set_profiling", "gpf_get_kernel_time", "gpf_get_plan", "gpf_device_pointers", "gpf_device_pointers_n",
     "gpf_ptdf_build", "gpf_ptdf_get", "gpf_ptdf_flows", "gpf_get_ptdf_flows", "gpf_lodf_screen",
 ]
 
@@ -159,6 +160,7 @@ def lib() -> C.CDLL:
     L.gpf_get_kernel_time.argtypes = [h, _dp, C.POINTER(C.c_int64)]
     L.gpf_get_plan.argtypes = [h, C.POINTER(C.c_int32)]
     L.gpf_device_pointers.argtypes = [h, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.gpf_device_pointers_n.argtypes = [h, C.POINTER(C.c_void_p), i32, C.POINTER(C.c_void_p)]
     L.gpf_ptdf_build.argtypes = [h, i32]
     L.gpf_ptdf_get.argtypes = [h, _dp]
     L.gpf_ptdf_flows.argtypes = [h, i32, i32]
@@ -168,6 +170,10 @@ def lib() -> C.CDLL:
         fn = getattr(L, name)
         if name not in ("gpf_last_error",):
             fn.restype = C.c_int
+    got = L.gpf_version()
+    if got != ABI_VERSION:               # a stale GRIDPF_LIB / an old build next to new Python: struct layouts and argument lists differ
+        raise GridPFError(f"{path} has ABI version {got}, this binding needs {ABI_VERSION} (include/gridpf.h GPF_ABI_VERSION): rebuild "
+                          f"with `python -c 'import __graft_entry__ as g; g.build(force=True)'`")
     _lib = L
     return L
 

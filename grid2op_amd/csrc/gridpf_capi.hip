@@ -161,6 +161,7 @@ struct gpf_engine {
   DevArr<float> lane_gen_delta, traj_rho;
   DevArr<unsigned char> maint;          // [chron_tables][chron_T][n_line] scheduled maintenance OR hazards (forced outages), or empty
   std::vector<unsigned char> h_maint, h_hazard;   // host copies of the two tables (the device holds their union)
+  std::vector<int> h_lane_table, h_lane_offset;   // host mirror of lane_table / lane_offset (gpf_simulate_batch: maintenance ahead of a source lane)
   // injection dynamics of the environment (gpf::EnvDyn)
   bool env_on = false, env_hold = false, env_act_r = false, env_act_s = false, sto_ready = false;
   int env_loss_on = 1;
@@ -325,17 +326,30 @@ bool upload_flats(const gpf::Symbolic& S, DevArr<int>& buf, gpf::SymDev& D, int 
   for (int k = 0; k < 4; ++k) {
     // (the lane assignment is a pure function of the graph: engines of the same grid -- every HipBackend copy pool, every test --
     //  share one build per process)
+    static std::mutex cache_mu;                                // engines are created from several host threads (one per device)
     static std::unordered_map<std::string, gpf::FlatProg> cache;
     std::string key;
     if (lane_opt > 0) {
-      key.assign(reinterpret_cast<const char*>(S.slot_row.data()), S.slot_row.size() * sizeof(int));
+      key = std::to_string(S.slot_row.size()) + ":" + std::to_string(S.slot_col.size()) + ":" + std::to_string(S.prog.size()) + ":";
+      key.append(reinterpret_cast<const char*>(S.slot_row.data()), S.slot_row.size() * sizeof(int));
       key.append(reinterpret_cast<const char*>(S.slot_col.data()), S.slot_col.size() * sizeof(int));
       key.append(reinterpret_cast<const char*>(S.prog.data()), S.prog.size() * sizeof(int));
       key += "/" + std::to_string(16 << k) + "/" + std::to_string(lane_opt) + "/" + std::to_string(S.gj_lv0) + "/" + std::to_string(S.nslot_lu);
     }
-    auto hit = lane_opt > 0 ? cache.find(key) : cache.end();
-    const gpf::FlatProg F = hit != cache.end() ? hit->second : gpf::build_flat(S, 16 << k, lane_opt);
-    if (lane_opt > 0 && hit == cache.end() && cache.size() < 64) cache.emplace(key, F);
+    gpf::FlatProg F;
+    bool have = false;
+    if (lane_opt > 0) {
+      std::lock_guard<std::mutex> lk(cache_mu);
+      auto hit = cache.find(key);
+      if (hit != cache.end()) { F = hit->second; have = true; }
+    }
+    if (!have) {
+      F = gpf::build_flat(S, 16 << k, lane_opt);               // (the search runs outside the lock: a second thread may repeat it)
+      if (lane_opt > 0) {
+        std::lock_guard<std::mutex> lk(cache_mu);
+        if (cache.size() < 64) cache.emplace(key, F);
+      }
+    }
     off[k] = all.size();
     all.insert(all.end(), F.words.begin(), F.words.end());
     gpf::FlatDev& f = D.fl[k];
@@ -730,7 +744,7 @@ bool check_range(gpf_engine* e, int lane0, int n) { return e && lane0 >= 0 && n 
 extern "C" {
 
 const char* gpf_last_error(void) { return g_err.c_str(); }
-int gpf_version(void) { return 200; }
+int gpf_version(void) { return GPF_ABI_VERSION; }
 
 int gpf_device_count(int32_t* n_devices) {
   if (!n_devices) return fail(GPF_E_INVALID, "gpf_device_count: null");
@@ -857,6 +871,8 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   e->lane_nj.assign(e->cap_lanes, e->init_nj);
   e->lane_mb.assign(e->cap_lanes, e->init_mb);
   e->lane_class.assign(e->cap_lanes, -1);
+  e->h_lane_table.assign(e->cap_lanes, 0);
+  e->h_lane_offset.assign(e->cap_lanes, 0);
   e->h_lane_topo.assign((size_t)e->cap_lanes * g.dim_topo, INT_MIN);
   e->h_lane_sb.assign((size_t)e->cap_lanes * std::max(g.n_shunt, 1), INT_MIN);
   {
@@ -1192,6 +1208,10 @@ int gpf_copy_lanes(gpf_handle e, int32_t src, int32_t dst, int32_t n) {
   CP(inj, g.n_inj); CP(topo, g.dim_topo); CP(shunt_bus, g.n_shunt); CP(out, g.n_out); CP(topo_out, g.dim_topo);
   CP(shunt_bus_out, g.n_shunt); CP(line_status, g.n_line); CP(status, 4); CP(bus_vm, g.nb_tot); CP(bus_va, g.nb_tot);
   CP(overflow_count, g.n_line); CP(disc_round, g.n_line); CP(rho, g.n_line); CP(topo0, g.dim_topo); CP(done, 1); CP(episode, 2);
+  if (e->env_on) {          // the environment's injection dynamics are part of the lane's state (Backend.copy / env.copy keep them)
+    CP(env_target, g.n_gen); CP(env_actual, g.n_gen); CP(env_prev, g.n_gen); CP(env_already, g.n_gen); CP(env_limit, g.n_gen);
+    CP(env_charge, g.n_sto); CP(env_amount_prev, 1); CP(env_curt_prev, 1); CP(env_fresh, 1);
+  }
 #undef CP
   for (int k = 0; k < n; ++k) { e->lane_nb[dst + k] = e->lane_nb[src + k]; e->lane_nj[dst + k] = e->lane_nj[src + k]; e->lane_mb[dst + k] = e->lane_mb[src + k]; e->lane_class[dst + k] = e->lane_class[src + k];
     std::copy_n(e->h_lane_topo.begin() + (size_t)(src + k) * g.dim_topo, g.dim_topo, e->h_lane_topo.begin() + (size_t)(dst + k) * g.dim_topo);
@@ -1209,6 +1229,15 @@ int gpf_fanout_n1(gpf_handle e, int32_t src, int32_t dst0, int32_t n_out, const 
   HIP_TRY(hipMemcpyAsync(e->tmp_lines.p, out_lines, (size_t)n_out * sizeof(int), hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(gpf::fanout_kernel, dim3(n_out), dim3(64), 0, e->stream, e->g, e->bufs(), src, dst0, n_out, e->tmp_lines.p);
   HIP_TRY(hipGetLastError());
+  if (e->env_on) {                          // the contingency lanes start from the source's injection dynamics
+    if (e->sim_src.n < 1) { e->sim_src.release(); HIP_TRY(e->sim_src.alloc(1)); }
+    HIP_TRY(hipMemcpyAsync(e->sim_src.p, &src, sizeof(int), hipMemcpyHostToDevice, e->stream));
+    gpf::EnvDyn E{};
+    E.target = e->env_target.p; E.actual = e->env_actual.p; E.prev_p = e->env_prev.p; E.already = e->env_already.p; E.charge = e->env_charge.p;
+    E.amount_prev = e->env_amount_prev.p; E.fresh = e->env_fresh.p; E.limit = e->env_limit.p; E.curt_prev = e->env_curt_prev.p;
+    hipLaunchKernelGGL(gpf::simulate_env_copy_kernel, dim3((unsigned)n_out), dim3(64), 0, e->stream, E, e->g.n_gen, e->g.n_sto, e->sim_src.p, n_out, n_out, dst0);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipStreamSynchronize(e->stream));   // out_lines may be reused by the caller
   for (int k = 0; k < n_out; ++k) { e->lane_nb[dst0 + k] = e->lane_nb[src]; e->lane_nj[dst0 + k] = e->lane_nj[src]; e->lane_mb[dst0 + k] = e->lane_mb[src]; e->lane_class[dst0 + k] = e->lane_class[src];
     e->h_lane_topo[(size_t)(dst0 + k) * e->g.dim_topo] = INT_MIN; }     // a line was forced off on the device: mirror unknown
@@ -1352,6 +1381,7 @@ int gpf_upload_chronics(gpf_handle e, int32_t n_tables, int32_t T, const float* 
     bool fix = false;
     for (int& v : lt) if (v < 0 || v >= n_tables) { v = 0; fix = true; }
     if (fix) HIP_TRY(hipMemcpy(e->lane_table.p, lt.data(), lt.size() * sizeof(int), hipMemcpyHostToDevice));
+    e->h_lane_table = lt;
   }
   e->chron_tables = n_tables;
   return GPF_OK;
@@ -1399,8 +1429,12 @@ int gpf_set_lane_chronics(gpf_handle e, const int32_t* lane_table, const int32_t
     for (size_t k = 0; k < B; ++k)
       if (lane_table[k] < 0 || (e->chron_tables && lane_table[k] >= e->chron_tables)) return fail(GPF_E_INVALID, "lane_table out of range");
     HIP_TRY(hipMemcpyAsync(e->lane_table.p, lane_table, B * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    std::copy(lane_table, lane_table + B, e->h_lane_table.begin());
   }
-  if (lane_offset) HIP_TRY(hipMemcpyAsync(e->lane_offset.p, lane_offset, B * sizeof(int), hipMemcpyHostToDevice, e->stream));
+  if (lane_offset) {
+    HIP_TRY(hipMemcpyAsync(e->lane_offset.p, lane_offset, B * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    std::copy(lane_offset, lane_offset + B, e->h_lane_offset.begin());
+  }
   if (lane_scale) {
     if (!e->lane_scale.p) {
       HIP_TRY(e->lane_scale.alloc((size_t)e->cap_lanes * 2 * e->g.n_load));
@@ -1674,12 +1708,37 @@ int gpf_simulate_batch(gpf_handle e, int32_t t_obs, int32_t time_step, int32_t n
   HIP_TRY(hipStreamSynchronize(e->stream));
   // 2. candidate topologies on the host (the launch planner needs them anyway: busbars per substation, topology classes)
   std::vector<int> topo((size_t)n_dst * g.dim_topo), sb((size_t)n_dst * std::max(g.n_shunt, 1));
+  // Scheduled maintenance ahead of the observation (_ObsEnv.init, Environment/_obsEnv.py:361-385 with
+  // BaseEnv._update_vector_with_timestep, baseEnv.py:4768-4825): a forecast `time_step` >= 1 steps ahead has the lines out whose
+  // NEXT maintenance (the one obs.time_next_maintenance / duration_next_maintenance describe: the first flagged row from the
+  // observation's row on) covers row idx + time_step -- it begins there (first_ts_maintenance) or is under way
+  // (still_in_maintenance).  Hazards are not forecast by the reference.  The line goes out BEFORE the candidate action is applied.
+  std::vector<std::vector<int>> maint_out(n_src);
+  if (time_step >= 1 && !e->h_maint.empty()) {
+    const int T = e->chron_T;
+    for (int b = 0; b < n_src; ++b) {
+      const int src = src_lanes[b];
+      int idx = (t_obs + e->h_lane_offset[src]) % T;
+      if (idx < 0) idx += T;
+      const unsigned char* M = e->h_maint.data() + (size_t)e->h_lane_table[src] * T * g.n_line;
+      for (int l = 0; l < g.n_line; ++l) {
+        int s_ = idx;
+        while (s_ < T && !M[(size_t)s_ * g.n_line + l]) ++s_;          // start of the next maintenance (idx itself: under way)
+        const int tgt = idx + time_step;
+        if (s_ >= T || tgt < s_ || tgt >= T) continue;
+        bool in = true;
+        for (int r = s_; r <= tgt && in; ++r) in = M[(size_t)r * g.n_line + l] != 0;
+        if (in) maint_out[b].push_back(l);
+      }
+    }
+  }
   for (int b = 0; b < n_src; ++b)
     for (int k = 0; k < n_act; ++k) {
       int* row = topo.data() + ((size_t)b * n_act + k) * g.dim_topo;
       int* srow = sb.data() + ((size_t)b * n_act + k) * std::max(g.n_shunt, 1);
       std::memcpy(row, rows.data() + (size_t)b * w, (size_t)g.dim_topo * sizeof(int));
       if (g.n_shunt) std::memcpy(srow, rows.data() + (size_t)b * w + g.dim_topo, (size_t)g.n_shunt * sizeof(int));
+      for (int l : maint_out[b]) { row[e->h_line_or_pos[l]] = -1; row[e->h_line_ex_pos[l]] = -1; }
       apply_topo_action(e, row, g.n_shunt ? srow : nullptr, last_bus ? last_bus + (size_t)b * g.dim_topo : nullptr,
                         act_items + 3 * (size_t)act_off[k], act_off[k + 1] - act_off[k]);
     }
@@ -1693,6 +1752,13 @@ int gpf_simulate_batch(gpf_handle e, int32_t t_obs, int32_t time_step, int32_t n
                      dst_lane0, t_obs, e->chron_T, fc ? e->fc_h : 1, time_step, e->lane_table.p, e->lane_offset.p,
                      e->has_scale ? e->lane_scale.p : nullptr, e->has_delta ? e->lane_gen_delta.p : nullptr);
   HIP_TRY(hipGetLastError());
+  for (long long q = 0; q < n_dst; ++q) {                     // host mirror of what the kernel writes
+    const int src = src_lanes[q / n_act];
+    int idx = (t_obs + e->h_lane_offset[src]) % e->chron_T;
+    if (idx < 0) idx += e->chron_T;
+    e->h_lane_table[dst_lane0 + q] = e->h_lane_table[src];
+    e->h_lane_offset[dst_lane0 + q] = time_step == 0 ? idx : (fc ? e->fc_h : 1) * idx + (time_step - 1);
+  }
   // with the injection dynamics on, the scratch lanes start from their source's dispatch / storage / curtailment state and take
   // ONE do-nothing step of the dynamics on the forecast (the candidates are topology actions: no redispatch / storage part)
   struct ActGuard {
@@ -2149,8 +2215,11 @@ int gpf_get_plan(gpf_handle e, int32_t out[8]) {
   return GPF_OK;
 }
 
-int gpf_device_pointers(gpf_handle e, void** ptrs, void** stream) {
-  if (!e || !ptrs) return fail(GPF_E_INVALID, "gpf_device_pointers: null");
+int gpf_device_pointers(gpf_handle e, void** ptrs, void** stream) { return gpf_device_pointers_n(e, ptrs, GPF_N_DEVICE_POINTERS, stream); }
+
+int gpf_device_pointers_n(gpf_handle e, void** out, int32_t n_ptrs, void** stream) {
+  if (!e || !out || n_ptrs < 0) return fail(GPF_E_INVALID, "gpf_device_pointers: null");
+  void* ptrs[GPF_N_DEVICE_POINTERS];
   ptrs[0] = e->inj.p; ptrs[1] = e->topo.p; ptrs[2] = e->shunt_bus.p; ptrs[3] = e->out.p; ptrs[4] = e->topo_out.p;
   ptrs[5] = e->line_status.p; ptrs[6] = e->status.p; ptrs[7] = e->chron.p;
   ptrs[8] = e->rho.p; ptrs[9] = e->overflow_count.p; ptrs[10] = e->done.p; ptrs[11] = e->episode.p; ptrs[12] = e->bus_vm.p;
@@ -2159,6 +2228,7 @@ int gpf_device_pointers(gpf_handle e, void** ptrs, void** stream) {
   const bool obs = e->traj_cap && (e->traj_what & GPF_TRAJ_OBS);
   ptrs[18] = obs ? e->traj_out.p : nullptr; ptrs[19] = obs ? e->traj_topo.p : nullptr; ptrs[20] = obs ? e->traj_shb.p : nullptr;
   ptrs[21] = obs ? e->traj_lstat.p : nullptr;
+  for (int i = 0; i < n_ptrs; ++i) out[i] = i < GPF_N_DEVICE_POINTERS ? ptrs[i] : nullptr;     // never writes beyond the caller's array
   if (stream) *stream = e->stream;
   return GPF_OK;
 }

@@ -1750,13 +1750,17 @@ __device__ inline bool env_dynamics_step(const EnvDyn& E, int k, int n_gen, int 
   sto_power = 0.f;
   if (n_sto > 0) {
     float pw = 0.f;
-    bool any_act = false;
-    if (is_sto && fabsf(act_s) >= 1e-7f) {
-      any_act = true;
+    const bool any_act = is_sto && fabsf(act_s) >= 1e-7f;
+    if (any_act) {
       double eff = 1.0;
       if (E.loss_on) eff = act_s > 0.f ? E.eff_c[k] : 1.0 / E.eff_d[k];
       R.charge += (float)((double)act_s * E.coeff * eff);
       pw = act_s;
+    }
+    // as soon as ANY unit of the environment acts (`modif`, :2861), EVERY unit is clamped to [Emin, Emax] and the power that the
+    // clamp takes back joins the storage amount -- also an idle unit whose charge the losses pulled below Emin > 0
+    const bool some = env_gmax<LW>(any_act ? 1.0 : 0.0) > 0.0;
+    if (some && is_sto) {
       const double emax = E.Emax[k], emin = E.Emin[k];
       if ((double)R.charge > emax) {
         double t_ = (1.0 / E.coeff) * ((double)R.charge - emax);
@@ -1772,7 +1776,6 @@ __device__ inline bool env_dynamics_step(const EnvDyn& E, int k, int n_gen, int 
       }
       R.charge = fmaxf(R.charge, (float)emin);
     }
-    const bool some = env_gmax<LW>(any_act ? 1.0 : 0.0) > 0.0;
     amount = some ? (double)(float)env_gsum<LW>((double)pw) : 0.0;       // (the reference sums a float32 array)
     const double tmp = amount;
     amount -= (double)R.amount_prev;

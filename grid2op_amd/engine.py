@@ -143,6 +143,7 @@ class PowerFlowEngine:
             off = getattr(lay, "inj_" + name)
             self.inj_slices[name] = slice(off, off + sizes[sz])
         self.init_inj = init_inj.copy()
+        self.env_dynamics_on = False
 
     # ------------------------------------------------------------------------------------------------
     def close(self):
@@ -492,6 +493,7 @@ class PowerFlowEngine:
         re-solves the ramp-limited redispatch (BaseEnv.step's path between the chronics and the backend); needs `set_gen_limits`
         (and `set_storage_params` on a grid with storage units).  Resets the dynamics of every lane."""
         check(self._lib.gpf_set_env_dynamics(self._h, int(bool(on)), float(tol_poly)), "gpf_set_env_dynamics")
+        self.env_dynamics_on = bool(on)
 
     def set_lane_actions(self, redispatch=None, storage_power=None, hold_storage: bool = False):
         """The agents' actions of the NEXT launch: redispatch ``[n_lanes, n_gen]`` MW (consumed by its first step), storage power
@@ -597,7 +599,7 @@ class PowerFlowEngine:
         import torch
         ptrs = (C.c_void_p * 22)()
         stream = C.c_void_p()
-        check(self._lib.gpf_device_pointers(self._h, ptrs, C.byref(stream)), "gpf_device_pointers")
+        check(self._lib.gpf_device_pointers_n(self._h, ptrs, 22, C.byref(stream)), "gpf_device_pointers_n")
         cap = self._lib.gpf_lane_capacity(self._h)
         m = self.model
         dev = torch.device("cuda", self.device)

@@ -157,13 +157,27 @@ class ShardedEngine:
             eng.set_thermal_limits(limit_a)
 
     # ---- solve (asynchronous: queued on every device's stream) ----------------------------------------------------------------
+    # One host thread per device: a launch call is planning + parameter upload + the launch itself (~10 us of host time on an
+    # MI355X box) and the ctypes call releases the GIL, so the launches of the devices are issued CONCURRENTLY -- issued from one
+    # thread, 8 devices x ~10 us serialised per step would be a third of a 26 us step.  The threads are created lazily and only with
+    # more than one device; HIP handles are thread-compatible (one engine is only ever driven by one thread at a time: `_fan` joins
+    # before it returns).
+    def _fan(self, calls):
+        if len(calls) <= 1:
+            for fn in calls:
+                fn()
+            return
+        if getattr(self, "_pool", None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=len(self.engines), thread_name_prefix="gridpf-dev")
+        for f in [self._pool.submit(fn) for fn in calls]:
+            f.result()                                   # re-raises a GridPFError of any device
+
     def runpf(self, lane0: int = 0, n=None, **kw):
-        for eng, l0, k, _ in self._parts(lane0, n):
-            eng.runpf(l0, k, **kw)
+        self._fan([(lambda e=eng, a=l0, b=k: e.runpf(a, b, **kw)) for eng, l0, k, _ in self._parts(lane0, n)])
 
     def step(self, t: int, **kw):
-        for eng in self.engines:
-            eng.step(t, **kw)
+        self._fan([(lambda e=eng: e.step(t, **kw)) for eng in self.engines])
 
     def set_lane_redispatch(self, delta_mw):
         for eng, (b0, bn) in zip(self.engines, self.blocks):
@@ -239,8 +253,9 @@ class ShardedEngine:
         return out
 
     def copy_lanes(self, src: int, dst: int, n: int = 1):
-        """Device-side copy inside one shard; a copy that crosses devices goes through the host (inputs only: the results of the
-        destination lanes are those of their next solve)."""
+        """Device-side copy inside one shard; a copy that crosses devices goes through the host (inputs, protection counters and --
+        when the injection dynamics are on -- the dispatch / storage / curtailment state: the results of the destination lanes are
+        those of their next solve)."""
         ps, pd = self._parts(src, n), self._parts(dst, n)
         if len(ps) == 1 and len(pd) == 1 and ps[0][0] is pd[0][0]:
             ps[0][0].copy_lanes(ps[0][1], pd[0][1], n)
@@ -248,6 +263,10 @@ class ShardedEngine:
         topo, sb = self.get_topology(src, n)
         self.set_injections(self.get_injections(src, n), lane0=dst)
         self.set_topology(topo, sb, lane0=dst)
+        _, ovc, _ = self.step_outputs(src, n)
+        self.set_overflow_count(ovc, lane0=dst)
+        if all(getattr(e, "env_dynamics_on", False) for e in self.engines):
+            self.set_env_state(dst, **self.env_state(src, n))
 
     def get_topology(self, lane0: int = 0, n=None):
         parts = [eng.get_topology(l0, k) for eng, l0, k, _ in self._parts(lane0, n)]
@@ -296,6 +315,15 @@ class ShardedEngine:
         parts = [eng.env_state(l0, k) for eng, l0, k, _ in self._parts(lane0, n)]
         return {key: np.concatenate([p[key] for p in parts]) for key in parts[0]}
 
+    def set_env_state(self, lane0: int = 0, **fields):
+        """`PowerFlowEngine.set_env_state` on the global lane range starting at ``lane0``: every array is cut by device block."""
+        arrs = {k: np.asarray(v) for k, v in fields.items() if v is not None}
+        if not arrs:
+            return
+        n = next(iter(arrs.values())).shape[0]
+        for eng, l0, k, off in self._parts(lane0, n):
+            eng.set_env_state(l0, **{key: a[off:off + k] for key, a in arrs.items()})
+
     def set_overflow_count(self, counts, lane0: int = 0):
         c = np.asarray(counts).reshape(-1, self.model.n_line)
         for eng, l0, n, off in self._parts(lane0, c.shape[0]):
@@ -324,6 +352,9 @@ class ShardedEngine:
         return [eng.plan() for eng in self.engines]
 
     def close(self):
+        if getattr(self, "_pool", None) is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
         for eng in self.engines:
             eng.close()
         self.engines = []

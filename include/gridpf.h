@@ -95,6 +95,10 @@ typedef struct gpf_layout {
 } gpf_layout;
 
 const char* gpf_last_error(void);
+/* ABI version of the library = GPF_ABI_VERSION of the header it was built from.  A binding MUST compare the two before any other
+ * call (grid2op_amd/_capi.py does): 300 = round 4 (gpf_set_trajectory(h, cap, what), 22 device pointers, GPF_ST_REDISPATCH,
+ * gpf_device_pointers_n). */
+#define GPF_ABI_VERSION 300
 int gpf_version(void);
 /* Bitwise run-to-run reproducibility is the DEFAULT on every grid: the same lane inputs give bit-identical results from run to
  * run and whatever the lane's position in the batch (grid2op's determinism contract: same seeds -> same episode,
@@ -132,10 +136,12 @@ int gpf_get_topology(gpf_handle h, int32_t lane0, int32_t n, int32_t* topo, int3
 int gpf_disconnect_line(gpf_handle h, int32_t lane, int32_t line_id);
 /* reset (:334-354): back to the pristine state. */
 int gpf_reset_lanes(gpf_handle h, int32_t lane0, int32_t n);
-/* copy (:1289-1409): device-side copy of the complete state (inputs and last results) of `n` lanes. */
+/* copy (:1289-1409): device-side copy of the complete state (inputs and last results; with gpf_set_env_dynamics on also the
+ * dispatch / storage / curtailment state of the environment's injection dynamics) of `n` lanes. */
 int gpf_copy_lanes(gpf_handle h, int32_t src_lane0, int32_t dst_lane0, int32_t n);
 /* N-1 fan-out (Reward/n1Reward.py:75-99, Observation/_obsEnv.py:321-503): lanes dst0+k (k < n_out)
- * become copies of `src_lane` with line out_lines[k] disconnected (out_lines[k] < 0: plain copy). */
+ * become copies of `src_lane` (injections, topology, shunts; with gpf_set_env_dynamics on also its dispatch / storage /
+ * curtailment state) with line out_lines[k] disconnected (out_lines[k] < 0: plain copy). */
 int gpf_fanout_n1(gpf_handle h, int32_t src_lane, int32_t dst_lane0, int32_t n_out, const int32_t* out_lines);
 
 /* runpf (pandaPowerBackend.py:1220-1255 -> pp.runpp / pp.rundcpp :1078-1120): one AC Newton-Raphson
@@ -371,7 +377,11 @@ int gpf_get_plan(gpf_handle h, int32_t out[8]);
  * episode, bus_vm, bus_va, shunt_bus_out, disc_round, then the trajectory buffers (NULL when not set): traj_rho, traj_status,
  * traj_out, traj_topo_vect, traj_shunt_bus, traj_line_status (rows are padded to gpf_lane_capacity lanes; trajectory buffers are
  * [cap][gpf_lane_capacity][row]); stream = hipStream_t */
-int gpf_device_pointers(gpf_handle h, void** ptrs, void** stream);
+#define GPF_N_DEVICE_POINTERS 22
+int gpf_device_pointers(gpf_handle h, void** ptrs /* [GPF_N_DEVICE_POINTERS] */, void** stream);
+/* The same with the length of the caller's array: entries beyond n_ptrs are not written, entries beyond the library's count are
+ * NULL -- a caller built against an older / newer header cannot be overrun. */
+int gpf_device_pointers_n(gpf_handle h, void** ptrs, int32_t n_ptrs, void** stream);
 
 #ifdef __cplusplus
 }

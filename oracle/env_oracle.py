@@ -122,8 +122,34 @@ def forecast_state(m, base: LaneState, row):
     return st
 
 
-def simulate(m, base: LaneState, row, act, thermal_limit, timestep_overflow, last_bus=None, **kw):
+def maintenance_ahead(maint, idx, horizon):
+    """Lines `_ObsEnv.init` forces out of a forecast `horizon` >= 1 steps ahead of the observation at chronics row `idx`
+    (Environment/_obsEnv.py:361-385 with BaseEnv._update_vector_with_timestep, baseEnv.py:4768-4825): the NEXT maintenance of the
+    line -- the one obs.time_next_maintenance / duration_next_maintenance describe, i.e. the first flagged run of rows of
+    maintenance.csv from `idx` on (Chronics/gridValue.py:264-340) -- begins at row idx + horizon (first_ts_maintenance) or covers
+    it (still_in_maintenance).  `maint`: [T, n_line] 0/1.  Returns a bool mask [n_line]."""
+    maint = np.asarray(maint) != 0
+    T, n_line = maint.shape
+    out = np.zeros(n_line, bool)
+    tgt = idx + horizon
+    if horizon < 1 or tgt >= T:
+        return out
+    for l in range(n_line):
+        on = np.nonzero(maint[idx:, l])[0]
+        if on.size == 0:
+            continue
+        s_ = idx + int(on[0])                      # tnm = s_ - idx (0: under way)
+        out[l] = s_ <= tgt and bool(maint[s_:tgt + 1, l].all())
+    return out
+
+
+def simulate(m, base: LaneState, row, act, thermal_limit, timestep_overflow, last_bus=None, maint_out=None, **kw):
     st = forecast_state(m, base, row)
+    if maint_out is not None and np.any(maint_out):             # scheduled maintenance ahead: out BEFORE the candidate action
+        lor, lex = np.asarray(m.line_or_pos_topo_vect), np.asarray(m.line_ex_pos_topo_vect)
+        st.topo = st.topo.copy()
+        st.topo[lor[np.asarray(maint_out, bool)]] = -1
+        st.topo[lex[np.asarray(maint_out, bool)]] = -1
     sb = st.shunt_bus.copy() if m.n_shunt else None
     st.topo = apply_topo_action(m, st.topo, act, last_bus, sb)
     if sb is not None:

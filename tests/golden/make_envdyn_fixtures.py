@@ -34,10 +34,28 @@ from grid2op.Parameters import Parameters  # noqa: E402
 from conformance_backend import OracleHipBackend  # noqa: E402
 
 
-def record(env_name, n_steps, every, seed, curtail=False):
+def record(env_name, n_steps, every, seed, curtail=False, storage_emin=None, out_name=None):
+    """storage_emin: the environment's DATA folder is copied to a scratch directory with the Emin column of storage_units_charac.csv
+    replaced (the reference code stays untouched), and every second action moves only the LAST storage unit: the idle units drift
+    below Emin > 0 through the losses and _compute_storage's clamp of ALL units pulls them back (baseEnv.py:2861-2888)."""
     p = Parameters()
     p.NO_OVERFLOW_DISCONNECTION = True
-    env = grid2op.make(env_name, test=True, backend=OracleHipBackend(), param=p, opponent_class=BaseOpponent,
+    make_arg = env_name
+    if storage_emin is not None:
+        import shutil
+        import tempfile
+        src = os.path.join(REFERENCE, "grid2op", "data", env_name)
+        make_arg = os.path.join(tempfile.mkdtemp(prefix="envdyn_"), env_name)
+        shutil.copytree(src, make_arg, ignore=shutil.ignore_patterns("__pycache__"))
+        csv = os.path.join(make_arg, "storage_units_charac.csv")
+        rows = open(csv).read().strip().splitlines()
+        hdr = rows[0].split(",")
+        for i, r in enumerate(rows[1:]):
+            c = r.split(",")
+            c[hdr.index("Emin")] = repr(float(storage_emin[i]))
+            rows[1 + i] = ",".join(c)
+        open(csv, "w").write("\n".join(rows) + "\n")
+    env = grid2op.make(make_arg, test=True, backend=OracleHipBackend(), param=p, opponent_class=BaseOpponent,
                        opponent_action_class=DontAct, opponent_init_budget=0.0, opponent_budget_per_ts=0.0)
     cls = type(env)
     env.seed(seed)
@@ -66,6 +84,8 @@ def record(env_name, n_steps, every, seed, curtail=False):
             red[k] = amp
             if cls.n_storage:
                 sto[:] = rng.uniform(-4.0, 4.0, cls.n_storage)
+                if storage_emin is not None and (t // every) % 2 == 1:
+                    sto[:-1] = 0.0                            # only the last unit acts: the others are clamped as idle units
         act = {}
         if (red != 0).any():
             act["redispatch"] = [(int(g), float(red[g])) for g in np.nonzero(red)[0]]
@@ -113,20 +133,27 @@ def record(env_name, n_steps, every, seed, curtail=False):
     from grid2op_amd.chronics import load_chronics_folder
     from grid2op_amd.grid_model import GridModel
     m = GridModel.load_npz(os.path.join(HERE, f"{env_name}.grid.npz"))
+    out_name = out_name or env_name
     ch = load_chronics_folder(env.chronics_handler.get_id(), m, max_rows=n_steps + 4)
     for k in ("load_p", "load_q", "prod_p", "prod_v"):
         out["ch_" + k] = ch[k]
     assert np.array_equal(out["new_p"], ch["prod_p"][out["row"]]), "chronics reader vs environment"
-    np.savez_compressed(os.path.join(HERE, f"envdyn_{env_name}.npz"), **out)
-    print(env_name, "steps", n_steps, "max |actual|", float(np.abs(out["actual"]).max()), "storage power range",
+    np.savez_compressed(os.path.join(HERE, f"envdyn_{out_name}.npz"), **out)
+    print(out_name, "steps", n_steps, "max |actual|", float(np.abs(out["actual"]).max()), "storage power range",
           (float(out["storage_power"].min()), float(out["storage_power"].max())) if cls.n_storage else None,
           "failed_redisp", int(out["failed_redisp"].sum()))
     env.close()
 
 
 def main():
-    record("educ_case14_storage", 24, 4, 5)
-    record("l2rpn_wcci_2022_dev", 16, 4, 6, curtail=True)
+    only = sys.argv[1:]
+    if not only or "educ_case14_storage" in only:
+        record("educ_case14_storage", 24, 4, 5)
+    if not only or "l2rpn_wcci_2022_dev" in only:
+        record("l2rpn_wcci_2022_dev", 16, 4, 6, curtail=True)
+    if not only or "educ_case14_storage_emin" in only:
+        # Emin just below the initial charge: two steps of losses put an idle unit under it (the clamp acts on ALL units)
+        record("educ_case14_storage", 24, 2, 7, storage_emin=(7.49, 3.49), out_name="educ_case14_storage_emin")
 
 
 if __name__ == "__main__":

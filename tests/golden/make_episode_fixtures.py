@@ -34,8 +34,12 @@ from grid2op.Reward import N1Reward, L2RPNReward  # noqa: E402
 from grid2op.Runner import Runner  # noqa: E402
 from grid2op.Agent import DoNothingAgent  # noqa: E402
 
-from conformance_backend import OracleHipBackend  # noqa: E402
 import replay as R  # noqa: E402
+
+
+def _default_base():
+    from conformance_backend import OracleHipBackend      # facade over the CPU oracle (build container: no GPU)
+    return OracleHipBackend
 
 
 class Trace:
@@ -80,74 +84,90 @@ class Trace:
         return out
 
 
-class RecordingBackend(OracleHipBackend):
-    trace = None
+def recording_backend(base):
+    """`base`: a grid2op Backend class -- the facade over the oracle engine in the build container, `HipBackend` over the HIP
+    engine on the GPU box (tests/reference_on_hip.py) -- wrapped so that every call of the framework is logged."""
 
-    def __init__(self, *a, **kw):
-        super().__init__(*a, **kw)
-        self._bid = type(self).trace.new_bid()
+    class RecordingBackend(base):
+        trace = None
 
-    def load_grid(self, path, filename=None):
-        super().load_grid(path, filename)
-        type(self).trace.add(R.EV_LOAD, self._bid)
+        def __init__(self, *a, **kw):
+            super().__init__(*a, **kw)
+            self._bid = type(self).trace.new_bid()
 
-    def copy(self):
-        res = super().copy()
-        type(self).trace.add(R.EV_COPY, self._bid, res._bid)
-        return res
+        def load_grid(self, path, filename=None):
+            super().load_grid(path, filename)
+            type(self).trace.add(R.EV_LOAD, self._bid)
 
-    def apply_action(self, backend_action):
-        if backend_action is not None:
+        def copy(self):
+            res = super().copy()
+            type(self).trace.add(R.EV_COPY, self._bid, res._bid)
+            return res
+
+        def apply_action(self, backend_action):
+            if backend_action is not None:
+                tr = type(self).trace
+                (_ab, (prod_p, prod_v, load_p, load_q, storage), topo__, shunts__) = backend_action()
+                cls = type(self)
+                rec = {}
+                for f, vs in (("prod_p", prod_p), ("prod_v", prod_v), ("load_p", load_p), ("load_q", load_q), ("storage", storage),
+                              ("topo", topo__)):
+                    rec[f] = (np.asarray(vs.values).copy(), np.asarray(vs.changed).copy())
+                sp, sq, sb = shunts__
+                rec["shunt_p"] = (np.asarray(sp.values).copy(), np.asarray(sp.changed).copy())
+                rec["shunt_q"] = (np.asarray(sq.values).copy(), np.asarray(sq.changed).copy())
+                rec["shunt_bus"] = (np.asarray(sb.values).copy(), np.asarray(sb.changed).copy())
+                if cls.n_storage > 0:
+                    stb = backend_action.get_storages_bus()
+                    rec["storage_bus"] = (np.asarray(stb.values).copy(), np.asarray(stb.changed).copy())
+                else:
+                    rec["storage_bus"] = (np.zeros(0, np.int32), np.zeros(0, bool))
+                tr.add(R.EV_APPLY, self._bid, 0, len(tr.acts))
+                tr.acts.append(rec)
+            return super().apply_action(backend_action)
+
+        def runpf(self, is_dc=False):
+            ok, exc = super().runpf(is_dc=is_dc)
             tr = type(self).trace
-            (_ab, (prod_p, prod_v, load_p, load_q, storage), topo__, shunts__) = backend_action()
-            cls = type(self)
-            rec = {}
-            for f, vs in (("prod_p", prod_p), ("prod_v", prod_v), ("load_p", load_p), ("load_q", load_q), ("storage", storage),
-                          ("topo", topo__)):
-                rec[f] = (np.asarray(vs.values).copy(), np.asarray(vs.changed).copy())
-            sp, sq, sb = shunts__
-            rec["shunt_p"] = (np.asarray(sp.values).copy(), np.asarray(sp.changed).copy())
-            rec["shunt_q"] = (np.asarray(sq.values).copy(), np.asarray(sq.changed).copy())
-            rec["shunt_bus"] = (np.asarray(sb.values).copy(), np.asarray(sb.changed).copy())
-            if cls.n_storage > 0:
-                stb = backend_action.get_storages_bus()
-                rec["storage_bus"] = (np.asarray(stb.values).copy(), np.asarray(stb.changed).copy())
-            else:
-                rec["storage_bus"] = (np.zeros(0, np.int32), np.zeros(0, bool))
-            tr.add(R.EV_APPLY, self._bid, 0, len(tr.acts))
-            tr.acts.append(rec)
-        return super().apply_action(backend_action)
+            d = R.read_backend(self)
+            d["ok"] = bool(ok)
+            tr.add(R.EV_RUNPF, self._bid, int(bool(is_dc)), len(tr.pfs))
+            tr.last_pf_row_of[self._bid] = len(tr.pfs)
+            tr.last_pf_row = len(tr.pfs)
+            tr.pfs.append(d)
+            return ok, exc
 
-    def runpf(self, is_dc=False):
-        ok, exc = super().runpf(is_dc=is_dc)
-        tr = type(self).trace
-        d = R.read_backend(self)
-        d["ok"] = bool(ok)
-        tr.add(R.EV_RUNPF, self._bid, int(bool(is_dc)), len(tr.pfs))
-        tr.last_pf_row_of[self._bid] = len(tr.pfs)
-        tr.last_pf_row = len(tr.pfs)
-        tr.pfs.append(d)
-        return ok, exc
+        def reset(self, path=None, grid_filename=None):
+            type(self).trace.add(R.EV_RESET, self._bid)
+            return super().reset(path, grid_filename)
 
-    def reset(self, path=None, grid_filename=None):
-        type(self).trace.add(R.EV_RESET, self._bid)
-        return super().reset(path, grid_filename)
+        def close(self):
+            if self._engine is not None:
+                type(self).trace.add(R.EV_CLOSE, self._bid)
+            return super().close()
 
-    def close(self):
-        if self._engine is not None:
-            type(self).trace.add(R.EV_CLOSE, self._bid)
-        return super().close()
+        def _disconnect_line(self, id_):
+            type(self).trace.add(R.EV_DISCO, self._bid, int(id_))
+            return super()._disconnect_line(id_)
 
-    def _disconnect_line(self, id_):
-        type(self).trace.add(R.EV_DISCO, self._bid, int(id_))
-        return super()._disconnect_line(id_)
+        def _reconnect_line(self, id_):
+            type(self).trace.add(R.EV_RECO, self._bid, int(id_))
+            return super()._reconnect_line(id_)
 
-    def _reconnect_line(self, id_):
-        type(self).trace.add(R.EV_RECO, self._bid, int(id_))
-        return super()._reconnect_line(id_)
+    return RecordingBackend
+
+
+RecordingBackend = None       # built on first use (set_backend_base selects the engine underneath)
+
+
+def set_backend_base(base):
+    global RecordingBackend
+    RecordingBackend = recording_backend(base)
 
 
 def _make(env_name, **kw):
+    if RecordingBackend is None:
+        set_backend_base(_default_base())
     RecordingBackend.trace = Trace()
     env = grid2op.make(env_name, test=True, backend=RecordingBackend(), **kw)
     return env, RecordingBackend.trace

@@ -48,7 +48,7 @@ GRIDS = {
                                   "data/l2rpn_neurips_2020_track1/config.py"),
     "l2rpn_wcci_2022_dev": ("data/l2rpn_wcci_2022_dev/grid.json", "data/l2rpn_wcci_2022_dev/chronics/2050-02-14_0",
                             "data/l2rpn_wcci_2022_dev/config.py"),
-    "l2rpn_idf_2023": ("data/l2rpn_idf_2023/grid.json", None, "data/l2rpn_idf_2023/config.py"),
+    "l2rpn_idf_2023": ("data/l2rpn_idf_2023/grid.json", "data/l2rpn_idf_2023/chronics/2035-01-15_0", "data/l2rpn_idf_2023/config.py"),
     "l2rpn_2019": ("data/l2rpn_2019/grid.json", None, None),
     "rte_case14_test": ("data/rte_case14_test/grid.json", "data/rte_case14_test/chronics/0", "data/rte_case14_test/config.py"),
     "test_case14": ("data_test/test_PandaPower/test_case14.json", None, None),

@@ -57,22 +57,25 @@ def candidates(env):
     return out
 
 
-def main():
+def record(env_name, out_name, played_of, cands_of, seed, scenario=None, fast_forward=0, params=None, horizons=(0, 1), maintenance=False):
     p = Parameters()
-    p.NB_TIMESTEP_COOLDOWN_LINE = 0
-    p.NB_TIMESTEP_COOLDOWN_SUB = 0
-    p.MAX_SUB_CHANGED = 3
-    p.MAX_LINE_STATUS_CHANGED = 3
-    env = grid2op.make(ENV, test=True, backend=OracleHipBackend(), param=p)
-    env.seed(3)
-    env.set_id(0)
+    for k, v in (params or {}).items():
+        setattr(p, k, v)
+    env = grid2op.make(env_name, test=True, backend=OracleHipBackend(), param=p)
+    env.seed(seed)
+    if scenario is None:
+        env.set_id(0)
+    else:
+        ids = [os.path.basename(os.path.normpath(q)) for q in env.chronics_handler.real_data.subpaths]
+        env.set_id(ids.index(scenario))
     obs = env.reset()
-    cands = candidates(env)
-    sp = env.action_space
-    played = [sp(), sp({"set_line_status": [(3, -1)]}), sp(), sp({"set_bus": {"substations_id": [(5, [1, 2, 1, 2, 1, 2, 1])]}}),
-              sp({"set_line_status": [(7, -1)]}), sp(), sp({"set_line_status": [(3, +1)]}), sp()]
-    rec = {k: [] for k in ["row", "topo_vect", "last_bus", "timestep_overflow", "line_status"]}
-    sims = {f"sim{ts}_{f}": [] for ts in (0, 1) for f in OBS_F + ["topo_vect", "line_status", "done"]}
+    if fast_forward:
+        env.fast_forward_chronics(fast_forward)
+        obs = env.get_obs()
+    cands = cands_of(env)
+    played = played_of(env)
+    rec = {k: [] for k in ["row", "topo_vect", "last_bus", "timestep_overflow", "line_status", "time_next_maintenance", "duration_next_maintenance"]}
+    sims = {f"sim{ts}_{f}": [] for ts in horizons for f in OBS_F + ["topo_vect", "line_status", "done"]}
     data = env.chronics_handler.real_data.data
     for act in played:
         obs, _, done, info = env.step(act)
@@ -82,7 +85,9 @@ def main():
         rec["last_bus"].append(np.asarray(env._backend_action.last_topo_registered.values).copy())
         rec["timestep_overflow"].append(obs.timestep_overflow.copy())
         rec["line_status"].append(obs.line_status.copy())
-        for ts in (0, 1):
+        rec["time_next_maintenance"].append(obs.time_next_maintenance.copy())
+        rec["duration_next_maintenance"].append(obs.duration_next_maintenance.copy())
+        for ts in horizons:
             per = {k: [] for k in OBS_F + ["topo_vect", "line_status", "done"]}
             for _, ga in cands:
                 so, _, sdone, sinfo = obs.simulate(ga, time_step=ts)
@@ -97,21 +102,52 @@ def main():
     out["scenario"] = np.array(os.path.basename(os.path.normpath(env.chronics_handler.get_id())))
     out["hard_overflow"] = np.float32(env.parameters.HARD_OVERFLOW_THRESHOLD)
     out["nb_ts_allowed"] = np.int32(env.parameters.NB_TIMESTEP_OVERFLOW_ALLOWED)
+    if env.parameters.NO_OVERFLOW_DISCONNECTION:
+        out["cascade"] = np.bool_(False)
     import json
     out["candidates_json"] = np.array(json.dumps([c for c, _ in cands]))
     # the chronics + forecast tables of that scenario, as grid2op_amd.chronics reads them (the GPU box has no /root/reference)
     from grid2op_amd.chronics import load_chronics_folder
     from grid2op_amd.grid_model import GridModel
-    m = GridModel.load_npz(os.path.join(HERE, f"{ENV}.grid.npz"))
-    ch = load_chronics_folder(env.chronics_handler.get_id(), m, forecasts=True, max_rows=64)
+    m = GridModel.load_npz(os.path.join(HERE, f"{env_name}.grid.npz"))
+    row0 = max(0, min(out["row"]) - 2) if fast_forward else 0
+    ch = load_chronics_folder(env.chronics_handler.get_id(), m, forecasts=True, max_rows=max(64, int(max(out["row"])) + 8))
+    if row0:
+        out["row0"] = np.int32(row0)                  # the tables are cut to rows [row0, ...): `row` counts from the scenario's start
     for k in ("load_p", "load_q", "prod_p", "prod_v"):
-        out["ch_" + k] = ch[k]
-        out["fc_" + k] = ch[k + "_forecasted"]
-    np.savez_compressed(os.path.join(HERE, "simulate_case14.npz"), **out)
-    print({k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.ndim > 1})
-    print("game overs among the simulations:", int(out["sim0_done"].sum()), int(out["sim1_done"].sum()),
+        out["ch_" + k] = ch[k][row0:]
+        # a scenario without prod_v_forecasted: _ObsEnv keeps the observation's own generator voltages (obs._get_gen_v_for_forecasts,
+        # Observation/baseObservation.py:4565), i.e. the set-points of the observation's row
+        out["fc_" + k] = ch[k + "_forecasted"][row0:] if k + "_forecasted" in ch else ch[k][row0:]
+    if maintenance:
+        out["maintenance"] = np.asarray(ch["maintenance"][row0:], dtype=np.uint8)
+        assert out["maintenance"].any()
+    np.savez_compressed(os.path.join(HERE, out_name), **out)
+    print(out_name, {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.ndim > 1 and k.startswith(("sim1_p_or", "ch_load_p"))})
+    print("   game overs among the simulations:", [int(out[f"sim{ts}_done"].sum()) for ts in horizons],
           "rows", out["row"].tolist(), "scenario", out["scenario"])
     env.close()
+
+
+def main():
+    only = sys.argv[1:]
+    if not only or "case14" in only:
+        def played(env):
+            sp = env.action_space
+            return [sp(), sp({"set_line_status": [(3, -1)]}), sp(), sp({"set_bus": {"substations_id": [(5, [1, 2, 1, 2, 1, 2, 1])]}}),
+                    sp({"set_line_status": [(7, -1)]}), sp(), sp({"set_line_status": [(3, +1)]}), sp()]
+        record(ENV, "simulate_case14.npz", played, candidates, 3,
+               params=dict(NB_TIMESTEP_COOLDOWN_LINE=0, NB_TIMESTEP_COOLDOWN_SUB=0, MAX_SUB_CHANGED=3, MAX_LINE_STATUS_CHANGED=3))
+    if not only or "maintenance" in only:
+        # Scheduled maintenance AHEAD of the observation: l2rpn_neurips_2020_track1 / Scenario_august_dummy takes lines out
+        # from row 108 on; the observations around that row are simulated 1 step ahead -- _ObsEnv.init forces out the lines whose
+        # maintenance begins at / covers the forecast step (Environment/_obsEnv.py:361-385)
+        def cands36(env):
+            sp = env.action_space
+            return [({}, sp()), ({"set_line_status": [(0, -1)]}, sp({"set_line_status": [(0, -1)]})),
+                    ({"set_line_status": [(20, -1)]}, sp({"set_line_status": [(20, -1)]}))]
+        record("l2rpn_neurips_2020_track1", "simulate_maintenance_neurips36.npz", lambda env: [env.action_space()] * 8, cands36, 4,
+               scenario="Scenario_august_dummy", fast_forward=103, params=dict(NO_OVERFLOW_DISCONNECTION=True), maintenance=True)
 
 
 if __name__ == "__main__":

@@ -77,8 +77,12 @@ def test_n1_fanout_1024_envs_x_60_lanes_vs_oracle(load_model, load_npz):
         topo[c::fan, m.line_or_pos_topo_vect[c - 1]] = -1
         topo[c::fan, m.line_ex_pos_topo_vect[c - 1]] = -1
     eng.set_topology(topo)
+    eng.set_trajectory(4, eng.TRAJ_OBS)               # as bench.py times it: every env step leaves its observation in HBM
     eng.step(3, n_steps=4, rebalance=1.02)
     r = eng.results(with_bus=False)
+    obs1 = eng.trajectory_obs(1, step0=1)[0]          # an earlier step of the launch: same verdicts, its own flows
+    assert np.array_equal(obs1.converged, r.converged) and np.array_equal(obs1.topo_vect, r.topo_vect)
+    assert not np.array_equal(obs1.out[:fan], r.out[:fan])
     conv = r.converged.reshape(n_envs, fan)
     assert conv[:, 0].all()                                       # the intact grid converges in every env
     lanes = np.unique(np.concatenate([np.arange(fan), 517 * fan + np.arange(fan), np.random.default_rng(2).choice(B, 80, replace=False)]))
@@ -108,7 +112,7 @@ def test_wcci_1024_lanes_storage_and_redispatch_16_step_launch_vs_oracle(load_mo
         delta[k, a], delta[k, b] = 1.0, -1.0
     eng.set_lane_redispatch(delta)
     p = eng.plan()
-    assert p["wavefronts_per_instance"] == 2
+    assert p["wavefronts_per_instance"] == 2 and p["ybus_in_registers"] == 1, p
     n, t0 = 16, 7
     eng.set_trajectory(n, eng.TRAJ_OBS)
     eng.step(t0, n_steps=n, rebalance=1.02)
@@ -139,6 +143,46 @@ def test_wcci_1024_lanes_storage_and_redispatch_16_step_launch_vs_oracle(load_mo
                      (m.shunt_sub, obs.shunt_p), (m.storage_sub, obs.storage_p)]:
         np.add.at(p_bus, (slice(None), sub), val.astype(np.float64))
     assert np.abs(p_bus).max() < 1e-2
+    eng.close()
+
+
+def test_idf_2023_ac_env_steps_and_ptdf_on_the_same_chronics_rows_vs_oracle(load_model, load_npz):
+    """configs[4] as bench.py runs it: l2rpn_idf_2023, chronics 2035-01-15_0, 2 048 lanes.  One 16-step launch with
+    the observation trajectory: 64 sampled lanes x 4 steps recomputed by the C oracle FROM THE CHRONICS TABLE; then the PTDF launch on
+    the injection rows the last step left (= the same chronics rows) against the oracle's DC power flow of those rows."""
+    from oracle.pf_oracle_c import COracle
+    name, B = "l2rpn_idf_2023", 2048
+    m, eng, tab, off, sc = _bench_engine(load_model, load_npz, name, B)
+    assert tab.shape == (576, 2 * 99 + 2 * 62)
+    assert eng.plan()["wavefronts_per_instance"] == 2
+    n, t0 = 16, 9
+    eng.set_trajectory(n, eng.TRAJ_OBS)
+    eng.step(t0, n_steps=n, rebalance=1.02)
+    obs = eng.trajectory_obs(n)
+    _, st = eng.trajectory(n)
+    lanes = np.sort(np.random.default_rng(23).choice(B, 64, replace=False))
+    for k in (0, 6, 11, 15):
+        assert (st[k] == 0).all(), k
+        res = check_step(m, tab, off, sc, 1.02, t0 + k, lanes, obs[k].out[lanes], st[k][lanes])
+        assert res["ok"] and res["n_converged"] == 64, (k, res)
+    last = eng.results(with_bus=False)
+    res = check_step(m, tab, off, sc, 1.02, t0 + n - 1, lanes, last.out[lanes], last.status[lanes])
+    assert res["ok"] and res.get("n_iter_mismatch", 1) == 0, res
+    # DC sensitivity path on the rows the lanes hold now
+    inj = eng.get_injections()
+    lay = eng.layout
+    nl = m.n_load
+    for k in lanes[:8]:                                # ... which ARE the chronics rows of the last step (float32 values, jittered)
+        row = tab[(t0 + n - 1 + off[k]) % tab.shape[0]]
+        assert np.array_equal(inj[k, lay.inj_load_p:lay.inj_load_p + nl], (row[:nl] * sc[k, :nl]).astype(np.float64))
+    eng.ptdf_build(0)
+    flows = eng.ptdf_flows()
+    topo, sb = eng.get_topology(0, 1)
+    ref = COracle(m).solve_rows(inj[lanes], np.tile(topo, (64, 1)), np.tile(sb, (64, 1)) if m.n_shunt else None, is_dc=True)
+    assert (ref["status"][:, 0] == 0).all()
+    p_ref = ref["out"][:, lay.out_p_or:lay.out_p_or + m.n_line]
+    err = np.abs(flows[lanes] - p_ref)
+    assert np.all(err <= 2e-4 + 5e-6 * np.abs(p_ref)), float(err.max())
     eng.close()
 
 

@@ -30,13 +30,15 @@ def _engine(m, fx, B):
     return eng
 
 
-@pytest.mark.parametrize("name", ["educ_case14_storage", "l2rpn_wcci_2022_dev"])
+@pytest.mark.parametrize("name", ["educ_case14_storage", "l2rpn_wcci_2022_dev", "educ_case14_storage_emin"])
 def test_recorded_reference_episode_in_multi_step_launches(name, load_model, load_npz):
     """The recorded episode (actions every 4 steps, nothing in between) replayed with ONE multi-step launch per stretch.  The device
     solves the redispatch projection EXACTLY where the reference's SLSQP stops at ftol (tests/test_oracle_envdyn.py: up to 0.8 MW
     apart on single steps, objective never worse), so the comparison is two-fold: tight against the oracle run with the exact
-    minimiser from the same start, and within SLSQP's inexactness against the recorded reference states / observations."""
-    m = load_model(name)
+    minimiser from the same start, and within SLSQP's inexactness against the recorded reference states / observations.
+    ``_emin``: the same environment recorded with storage_Emin just below the initial charge and actions that move only ONE of the two
+    units: the idle unit drifts below Emin through the losses and is pulled back by the clamp of ALL units (baseEnv.py:2861-2888)."""
+    m = load_model(name.replace("_emin", ""))
     fx = load_npz(f"envdyn_{name}.npz")
     B = 3                                                  # three lanes play the same episode (a wavefront shared by 2 instances on 14 substations)
     eng = _engine(m, fx, B)
@@ -159,6 +161,15 @@ def test_batch_of_lanes_with_different_actions_vs_oracle(load_model, load_npz):
             assert np.abs(r.gen_p[k][ns] - gen[ns]).max() < 3e-3, (launch, k)
         t += spl
     assert (~dead).sum() >= B // 2
+    # a lane copy / an N-1 fan-out carries the dynamics of its source
+    before = eng.env_state()
+    eng.copy_lanes(0, B - 1, 1)
+    eng.fanout_n1(1, B - 3, [-1, 2])
+    st2 = eng.env_state()
+    for key in st2:
+        assert np.array_equal(st2[key][B - 1], before[key][0]), key
+        assert np.array_equal(st2[key][B - 3], before[key][1]) and np.array_equal(st2[key][B - 2], before[key][1]), key
+        assert np.array_equal(st2[key][:B - 3], before[key][:B - 3]), key
     # a reset clears the dynamics; switching them off gives the plain chronics back
     eng.reset()
     st = eng.env_state()

@@ -25,7 +25,8 @@ def _run(argv, timeout=900):
     return subprocess.run([sys.executable, BENCH] + argv, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
 
 
-@pytest.mark.parametrize("env_name,batch", [("l2rpn_case14_sandbox", 256), ("l2rpn_neurips_2020_track1", 96)])
+@pytest.mark.parametrize("env_name,batch", [("l2rpn_case14_sandbox", 256), ("l2rpn_neurips_2020_track1", 96),
+                                            ("l2rpn_wcci_2022_dev", 64)])       # 118 substations: the 2-wavefront kernel (BASELINE configs[3])
 def test_two_ranks_with_real_engines_equal_the_halves_of_one_rank(env_name, batch, tmp_path):
     common = ["--env", env_name, "--steps", "12", "--warmup", "4", "--windows", "2", "--no-secondary", "--no-cpu-baseline"]
     two = str(tmp_path / "two")
@@ -38,6 +39,9 @@ def test_two_ranks_with_real_engines_equal_the_halves_of_one_rank(env_name, batc
     assert res["config"]["dist_backend"] == "gloo" and res["data"] == "synthetic" and res["frac_converged"] == 1.0
     assert res["oracle_check"]["ok"], res["oracle_check"]
     assert res["value"] == pytest.approx(2 * batch * 12 / (res["ms_per_step"] * 12 * 1e-3), rel=1e-9)
+    # both timings are reported: the per-rank HIP-event window (MAX over ranks; `value`) and the wall clock between the barriers
+    assert res["value_wall_clock"] > 0 and res["value_wall_clock"] <= res["value"] * 1.02
+    assert len(res["windows"]["wall_clock_ms"]) == len(res["windows"]["elapsed_ms"]) == 2
     one = str(tmp_path / "one")
     p1 = _run(["--gpus", "1", "--batch", str(2 * batch), "--dump-results", one] + common)
     assert p1.returncode == 0, p1.stderr[-3000:]

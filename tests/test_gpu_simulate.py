@@ -13,23 +13,30 @@ from test_oracle_simulate import sim_cases
 pytestmark = pytest.mark.gpu
 
 
-def test_recorded_reference_simulations_in_one_call_per_horizon(load_model, load_npz):
+@pytest.mark.parametrize("grid,fixture,min_done", [("l2rpn_case14_sandbox", "simulate_case14.npz", 20),
+                                                  ("l2rpn_neurips_2020_track1", "simulate_maintenance_neurips36.npz", 0)])
+def test_recorded_reference_simulations_in_one_call_per_horizon(grid, fixture, min_done, load_model, load_npz):
+    """second fixture: scheduled maintenance ahead of the observation -- the forecast one step ahead has the line out that the
+    maintenance table takes out at the next row (_ObsEnv.init, Environment/_obsEnv.py:361-385), the forecast of horizon 0 has not"""
     from grid2op_amd.engine import PowerFlowEngine
-    m = load_model("l2rpn_case14_sandbox")
-    fx = load_npz("simulate_case14.npz")
+    m = load_model(grid)
+    fx = load_npz(fixture)
     cands = sim_cases(fx)
+    row0 = int(fx["row0"]) if "row0" in fx else 0
     S, K = fx["row"].shape[0], len(cands)
     eng = PowerFlowEngine(m, n_lanes=S + S * K, device=0)
     eng.upload_chronics(eng.pack_chronics(fx["ch_load_p"], fx["ch_load_q"], fx["ch_prod_p"], fx["ch_prod_v"]))
     eng.upload_forecasts(eng.pack_chronics(fx["fc_load_p"], fx["fc_load_q"], fx["fc_prod_p"], fx["fc_prod_v"]))
+    if "maintenance" in fx:
+        eng.upload_maintenance(fx["maintenance"])
     eng.set_thermal_limits(fx["thermal_limit"])
     # source lane s = the environment after recorded step s: topology, chronics cursor (row = t_obs + offset), protection counters
     off = np.zeros(S + S * K, np.int32)
-    off[:S] = fx["row"]
+    off[:S] = fx["row"] - row0
     eng.set_lane_chronics(lane_offset=off)
     eng.set_topology(fx["topo_vect"].astype(np.int32), lane0=0)
     eng.set_overflow_count(fx["timestep_overflow"], lane0=0)
-    kw = dict(cascade=True, hard_overflow=float(fx["hard_overflow"]), nb_ts_allowed=int(fx["nb_ts_allowed"]))
+    kw = dict(cascade=bool(fx["cascade"]) if "cascade" in fx else True, hard_overflow=float(fx["hard_overflow"]), nb_ts_allowed=int(fx["nb_ts_allowed"]))
     n_done = 0
     for ts in (0, 1):
         n = eng.simulate_batch(0, np.arange(S), cands, dst_lane0=S, time_step=ts, last_bus=fx["last_bus"], **kw)
@@ -50,7 +57,9 @@ def test_recorded_reference_simulations_in_one_call_per_horizon(load_model, load
                                ("load_p", 1e-5), ("load_v", 3e-4)]:
                     assert np.abs(getattr(r, f)[q].astype(np.float64) - fx[f"sim{ts}_{f}"][s, k]).max() < tol, (ts, s, k, f)
                 assert np.abs(rho[q] - fx[f"sim{ts}_rho"][s, k]).max() < 3e-5, (ts, s, k)
-    assert n_done >= 20
+    assert n_done >= min_done
+    if "maintenance" in fx:                     # (the recording has an observation with the line still on whose 1-step forecast has it off)
+        assert (fx["line_status"] & ~fx["sim1_line_status"][:, 0]).any()
     # the source lanes were not touched
     t_src, _ = eng.get_topology(0, S)
     assert np.array_equal(t_src, fx["topo_vect"])

@@ -20,7 +20,7 @@ def dyn_from_fixture(fx, exact=False):
                              bool(fx["activate_storage_loss"]), exact=exact)
 
 
-@pytest.mark.parametrize("name", ["educ_case14_storage", "l2rpn_wcci_2022_dev"])
+@pytest.mark.parametrize("name", ["educ_case14_storage", "l2rpn_wcci_2022_dev", "educ_case14_storage_emin"])
 def test_injection_dynamics_reproduce_the_reference_environment(name, load_npz):
     fx = load_npz(f"envdyn_{name}.npz")
     dyn = dyn_from_fixture(fx)

@@ -5,8 +5,9 @@ parameters = overflow disconnections on)."""
 import json
 
 import numpy as np
+import pytest
 
-from oracle.env_oracle import simulate
+from oracle.env_oracle import maintenance_ahead, simulate
 from oracle.pf_oracle import LaneState
 
 
@@ -18,20 +19,33 @@ def sim_cases(fx):
     return cands
 
 
-def test_oracle_reproduces_recorded_obs_simulate(load_model, load_npz):
-    m = load_model("l2rpn_case14_sandbox")
-    fx = load_npz("simulate_case14.npz")
+@pytest.mark.parametrize("grid,fixture,min_done", [("l2rpn_case14_sandbox", "simulate_case14.npz", 20),
+                                                  ("l2rpn_neurips_2020_track1", "simulate_maintenance_neurips36.npz", 0)])
+def test_oracle_reproduces_recorded_obs_simulate(grid, fixture, min_done, load_model, load_npz):
+    """second fixture: a scenario with scheduled maintenance -- the forecast one step ahead of the observations around the first
+    maintenance row has the line out already (maintenance_ahead: _ObsEnv.init, Environment/_obsEnv.py:361-385)"""
+    m = load_model(grid)
+    fx = load_npz(fixture)
     cands = sim_cases(fx)
+    row0 = int(fx["row0"]) if "row0" in fx else 0
+    n_forced = 0
     tab = {p: np.concatenate([fx[p + "_load_p"], fx[p + "_load_q"], fx[p + "_prod_p"], fx[p + "_prod_v"]], axis=1) for p in ("ch", "fc")}
     n_done = n_trip = 0
     for s in range(fx["row"].shape[0]):
         base = LaneState.from_model(m)
         base.topo = fx["topo_vect"][s].astype(np.int32)
         for ts in (0, 1):
-            row = tab["ch" if ts == 0 else "fc"][int(fx["row"][s])]
+            idx = int(fx["row"][s]) - row0
+            row = tab["ch" if ts == 0 else "fc"][idx]
+            mo = maintenance_ahead(fx["maintenance"], idx, ts) if "maintenance" in fx else None
+            if mo is not None and ts >= 1:                   # the rule itself against what the reference's observation announces
+                tnm, dnm = fx["time_next_maintenance"][s], fx["duration_next_maintenance"][s]
+                assert np.array_equal(mo, (tnm != -1) & (tnm <= ts) & (tnm + dnm > ts)), (s, ts)
+                n_forced += int((mo & fx["line_status"][s]).sum())
             for k, act in enumerate(cands):
                 res, st, _ = simulate(m, base, row, act, fx["thermal_limit"], fx["timestep_overflow"][s], last_bus=fx["last_bus"][s],
-                                      hard_overflow=float(fx["hard_overflow"]), nb_ts_allowed=int(fx["nb_ts_allowed"]))
+                                      hard_overflow=float(fx["hard_overflow"]), nb_ts_allowed=int(fx["nb_ts_allowed"]), maint_out=mo,
+                                      cascade=bool(fx["cascade"]) if "cascade" in fx else True)
                 done = bool(fx[f"sim{ts}_done"][s, k])
                 assert (not res.converged) == done, (s, ts, k, res.reason)
                 n_done += done
@@ -44,4 +58,6 @@ def test_oracle_reproduces_recorded_obs_simulate(load_model, load_npz):
                     assert np.abs(getattr(res, f) - fx[f"sim{ts}_{f}"][s, k]).max() < tol, (s, ts, k, f)
                 rho = res.a_or / fx["thermal_limit"]
                 assert np.abs(rho - fx[f"sim{ts}_rho"][s, k]).max() < 2e-5, (s, ts, k)
-    assert n_done >= 20
+    assert n_done >= min_done
+    if "maintenance" in fx:
+        assert n_forced >= 1, "the fixture is meant to contain a forecast that takes a still-connected line out"
