@@ -330,7 +330,7 @@ def measure_modes(ctx, eng, k, w, step_kw, n_win, preroll_steps, spl=None, last_
     w_last = None
     if traj and last_obs_too:
         eng.set_trajectory(0)
-        w_last, _ = timed_windows(ctx, eng, k, 0, step_kw, max(2, n_win - 1), t0=t, preroll_steps=0, spl=spl)
+        w_last, t = timed_windows(ctx, eng, k, 0, step_kw, max(2, n_win - 1), t0=t, preroll_steps=0, spl=spl)
         eng.set_trajectory(spl, eng.TRAJ_OBS)        # the engine keeps the observation contract for whatever follows (spot checks read it)
     return w_obs, w_last, t
 

@@ -255,21 +255,39 @@ def _time_loop(Bk, env_name, n_steps, label):
     obs = env.reset()
     for _ in range(20):                                  # warm-up (kernel load, clocks)
         obs, reward, done, info = env.step(agent.act(obs, 0.0, False))
-    env._time_powerflow = env._time_apply_act = env._time_extract_obs = env._time_step = 0.0
-    env.backend.comp_time = 0.0
-    done, reward, n = False, env.reward_range[0], 0
+    keys = ("_time_powerflow", "_time_apply_act", "_time_extract_obs", "_time_step")
+    acc = {k: 0.0 for k in keys + ("comp_time",)}
+
+    def harvest():                                       # env.reset() clears the environment's timers: collect them before
+        for k in keys:
+            acc[k] += float(getattr(env, k))
+            setattr(env, k, 0.0)
+        acc["comp_time"] += float(env.backend.comp_time)
+        env.backend.comp_time = 0.0
+    harvest()
+    acc = {k: 0.0 for k in acc}
+    done, reward, n, n_reset = False, env.reward_range[0], 0, 0
+    t_reset = 0.0
     t0 = time.perf_counter()
     while n < n_steps:
         act = agent.act(obs, reward, done)
         obs, reward, done, info = env.step(act)
         n += 1
         if done:
+            harvest()
+            tr = time.perf_counter()
             obs = env.reset()
-    el = time.perf_counter() - t0
-    res = {"env": env_name, "backend": label, "steps": n, "env_steps_per_sec": n / el, "ms_per_step": el / n * 1e3,
-           "time_powerflow_ms_per_step": env._time_powerflow / n * 1e3, "time_apply_act_ms_per_step": env._time_apply_act / n * 1e3,
-           "time_extract_obs_ms_per_step": env._time_extract_obs / n * 1e3, "time_step_ms_per_step": env._time_step / n * 1e3,
-           "backend_comp_time_ms_per_step": env.backend.comp_time / n * 1e3}
+            t_reset += time.perf_counter() - tr
+            n_reset += 1
+            for k in keys:                               # (the power flow of the reset is not an env.step)
+                setattr(env, k, 0.0)
+            env.backend.comp_time = 0.0
+    harvest()
+    el = time.perf_counter() - t0 - t_reset
+    res = {"env": env_name, "backend": label, "steps": n, "episode_resets_excluded": n_reset, "env_steps_per_sec": n / el, "ms_per_step": el / n * 1e3,
+           "time_powerflow_ms_per_step": acc["_time_powerflow"] / n * 1e3, "time_apply_act_ms_per_step": acc["_time_apply_act"] / n * 1e3,
+           "time_extract_obs_ms_per_step": acc["_time_extract_obs"] / n * 1e3, "time_step_ms_per_step": acc["_time_step"] / n * 1e3,
+           "backend_comp_time_ms_per_step": acc["comp_time"] / n * 1e3}
     env.close()
     return {k: (float(v) if hasattr(v, "dtype") else v) for k, v in res.items()}
 

@@ -55,10 +55,15 @@ def test_recorded_reference_episode_in_multi_step_launches(name, load_model, loa
     ns = ~m.gen_slack
     loose = 1.2                                            # MW: SLSQP's distance from the exact minimiser over a stretch of <= 4 steps
                                                            # (sanity bound; per call: tests/test_redispatch.py)
+    if name.endswith("_emin"):
+        loose = 2.5       # its first action: SLSQP leaves 0.96 MW on each of the two modified generators where the exact minimiser puts
+                          # them ON their targets and lets an unmodified generator absorb the storage power (objective 0 vs > 0)
     # On the 62-generator grid the exact minimiser and SLSQP's approximate one drift apart when both run freely (2.9 MW after 16
     # steps: SLSQP stays short of the optimum at every ramp-limited step): there every stretch starts from the REFERENCE's recorded
     # state (what an environment restored from an observation hands over, baseEnv.py:4879-4882), the 14-substation episode runs freely.
-    resync = m.n_gen >= 20
+    # (the ``_emin`` recording acts every 2 steps over 24 steps -- twice as many ramp-limited projections as the plain 14-substation
+    #  episode --: its stretches restart from the recorded state too)
+    resync = m.n_gen >= 20 or name.endswith("_emin")
     for a, b_ in zip(bounds[:-1], bounds[1:]):
         if resync and a > 0:
             ap = np.float32(fx["storage_power"][a - 1].sum()) if m.n_storage else np.float32(0.0)

@@ -37,30 +37,20 @@ def _run(cmd, timeout=900, *args):
 
 
 @staged
-def test_recorded_episodes_rerun_on_the_real_framework_with_the_hip_engine():
+def test_unmodified_reference_framework_on_the_hip_engine():
+    """ONE test (one skip line in the driver's run, where the stage cannot exist) for the five legs:"""
+    # 1. the 11 recorded episodes re-run inside the real Environment / obs.simulate / N1Reward / Runner on HipBackend
     out = _run("episodes")
     assert "EPISODES OK: 11 episodes" in out
     assert len([l for l in out.splitlines() if "reproduced on the real framework + HIP engine" in l]) == 11
-
-
-@staged
-def test_reference_backend_api_kit_on_the_hip_engine():
+    # 2. the reference's own backend API kit (grid2op/tests/aaa_test_backend_interface.py, 41 tests)
     out = _run("aaa")
     assert "AAA OK" in out and "ran 41, passed 41" in out, out[-2000:]
-
-
-@staged
-def test_288_step_default_parameter_episode_and_simulate_vs_oracle_engine():
+    # 3. 288 env.step with default parameters + 78 obs.simulate calls, HIP engine vs oracle engine
     assert "LONG OK" in _run("long")
-
-
-@staged
-def test_wcci_2022_storage_redispatch_curtailment_episode_vs_oracle_engine():
+    # 4. l2rpn_wcci_2022 with storage + redispatch + curtailment actions and a bus split
     assert "WCCI OK" in _run("wcci")
-
-
-@staged
-def test_reference_step_loop_timing_with_both_engines():
+    # 5. the reference's DoNothing profiler loop with both engines (numbers: gpurun_out/reference_step_loop_timing.json)
     out = _run("timing", 900, "1000")
     line = [l for l in out.splitlines() if l.startswith("TIMING ")][-1]
     d = json.loads(line[len("TIMING "):])
