@@ -820,6 +820,11 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   auto rhsV = [&](int i) -> double* { return BS == 2 ? c.A + HS + ((size_t)S.rslot0 + i) * 2 : c.rhs + (size_t)(i / NB) * BS + 2 * (i % NB) + 1; };
   auto SreP = [&](int i) -> double* { return BS == 2 ? c.A + ((size_t)S.rslot0 + i) * 2 + 1 : c.Sre + i; };
   auto SimP = [&](int i) -> double* { return BS == 2 ? c.A + HS + ((size_t)S.rslot0 + i) * 2 + 1 : c.Sim + i; };
+  // V_i = e + j f of the Newton iterate.  Single-busbar layout: INTERLEAVED (e_i, f_i) pairs in the 2 nbus doubles that CarveP::e and
+  // CarveP::f span (one ds_read_b128 per bus instead of two 8-byte reads in the pair / results phases; Gs and lab, which alias the
+  // region, are dead by the time the Newton loop writes it); NB > 1: the two separate arrays.
+  auto EF = [&](int i) -> double2 { return NB == 1 ? reinterpret_cast<const double2*>(c.e)[i] : make_double2(c.e[i], c.f[i]); };
+  auto setEF = [&](int i, double e_, double f_) { if (NB == 1) reinterpret_cast<double2*>(c.e)[i] = make_double2(e_, f_); else { c.e[i] = e_; c.f[i] = f_; } };
   const auto topo_g = gptr(b.topo) + (size_t)inst * g.dim_topo;            // lane rows in HBM: explicit global address space
   const auto shb = gptr(b.shunt_bus) + (size_t)inst * g.n_shunt;
   n_iter_out = 0;
@@ -1150,182 +1155,308 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     bool converged = false;
     bool done = status != 0;                  // this group takes no further Newton steps (state frozen)
     const int n_pairs = S.nslot_y * NB * NB;
-    // Every phase of the loop is "issue all LDS reads -> compute -> write": the latency of a phase is a chain of dependent
-    // LDS round trips, so read-modify-write sequences inside branches are avoided.  V = e + jf, S = 0 and zeroed fill
-    // blocks are prepared by the phase BEFORE the pair phase (here for the first iteration, then by the update phase).
-    for (int i = tid; i < nbus; i += GW) {
-      const double va = c.va[i], vmi = c.vm[i];
-      double sn_, co;
-      fast_sincos(va, sn_, co);
-      c.e[i] = vmi * co;
-      c.f[i] = vmi * sn_;
-      if (NB == 1) c.ivm[i] = fast_rcp(vmi);
-      *SreP(i) = 0.0;
-      *SimP(i) = 0.0;
-      if (WPI > 1) { *rhsT(i) = 0.0; *rhsV(i) = 0.0; }      // wavefront 1's partial sums of S (see acc_lane above)
-    }
-    if (BS == 2) { for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; } }
-    else for (int i = S.nslot_y * B2 + tid; i < S.nslot_lu * B2; i += GW) c.A[i] = 0.0;     // fill blocks start at zero
-    GPF_LSYNC();
-    GPF_STAMPS(10);
-    // Single-busbar layout: ONE lane per undirected pair (u, v) of connected substations computes both Jacobian blocks (u, v) and
-    // (v, u) -- they share every operand but the Ybus block --, and the diagonal block of bus i is built by bus i's lane in the
-    // mismatch phase (which needs S_i anyway): half the passes of one lane per block of the original pattern.
-    // Tier 0 (tables in global memory): the words of the first pass stay in registers for the whole Newton loop and those of pass
-    // k + 1 are fetched before pass k computes -- an L2 round trip per pass is otherwise the longest link of the phase.
-    unsigned rc_first = 0, rc_first1 = 0;
-    if (STAGE == 0 && !YR) {
-      if (NB == 1) { if (tid < S.n_up) { rc_first = (unsigned)sv.up[2 * tid]; rc_first1 = (unsigned)sv.up[2 * tid + 1]; } }
-      else if (tid < n_pairs) rc_first = (unsigned)sv.pair_rc[tid / (NB * NB)];
-    }
     // T = V_i conj(Y V_j) and the masked block [dP/dth dP/dV; dQ/dth dQ/dV] = [Im T, Re T/|Vj|; -Re T, Im T/|Vj|] of (i, j)
     auto t_of = [&](const double2 y, double ei, double fi, double ej, double fj, double& tr_, double& ti_) {
       const double aa = y.x * ej - y.y * fj, bb = y.x * fj + y.y * ej;
       tr_ = ei * aa + fi * bb;
       ti_ = fi * aa - ei * bb;
     };
-    while (true) {
-      // Jacobian blocks from the Ybus blocks: T_ij = V_i conj(Y_ij V_j); S_i += T_ij (LDS atomics)
-      if (NB == 1) {
-        auto upair_item = [&](const unsigned w0, const unsigned w1, const double2 yuv, const double2 yvu) {
-          const int u = (int)(w0 & 0xffffu), v = (int)(w0 >> 16), suv = (int)(w1 & 0xffffu), svu = (int)(w1 >> 16);
-          const int btu = c.btype[u], btv = c.btype[v];
-          const double eu = c.e[u], fu = c.f[u], ivmu = c.ivm[u], ev = c.e[v], fv = c.f[v], ivmv = c.ivm[v];
+    // NEWTON WORKING SET IN REGISTERS (instance-group kernels, round 4).  When every bus and every undirected pair of the instance has
+    // its own lane (nbus <= GW, n_up <= GW: the 5- and 14-substation grids, and every topology class of theirs), what a lane needs in
+    // all iterations of the loop is loaded ONCE per solve: the pair lane's table words, its two Ybus blocks and the bus-type masks of
+    // its two ends; the bus lane's type, diagonal Ybus block, specified injections and -- carried from phase to phase instead of
+    // going through LDS -- va, |V|, e, f, 1/|V| and S_i.  A pair phase is then ONE LDS round trip (V of the two ends) instead of two
+    // dependent ones (table words -> operands), the mismatch phase reads only S_i, and ~35 % of the VALU instructions of the three
+    // single-phase steps (address arithmetic, type compares, loop / exec-mask handling) are gone.  Same arithmetic in the same order
+    // as the general path below: results are bit-identical.
+#ifdef GPF_NO_NWR                                               /* developer A/B build (tools/build_worktree_variant.sh): general path only */
+    constexpr bool NWR = false;
+#else
+    constexpr bool NWR = NB == 1 && IPW > 1 && WPI == 1 && !YR;
+#endif
+    const bool nwr = NWR && nbus <= GW && S.n_up <= GW;           // block-uniform (sizes of the grid / of the block's topology class)
+    if (nwr) {
+      const bool p_on = tid < S.n_up, b_on = tid < nbus;
+      const int ib = b_on ? tid : 0;
+      const unsigned w0 = p_on ? (unsigned)sv.up[2 * tid] : 0u, w1 = p_on ? (unsigned)sv.up[2 * tid + 1] : 0u;
+      const int u = (int)(w0 & 0xffffu), v = (int)(w0 >> 16), suv = (int)(w1 & 0xffffu), svu = (int)(w1 >> 16);
+      const double2 yuv = *reinterpret_cast<const double2*>(c.Yb + (size_t)suv * 2), yvu = *reinterpret_cast<const double2*>(c.Yb + (size_t)svu * 2);
+      const int btu = c.btype[u], btv = c.btype[v];
+      const int bt = c.btype[ib];
+      const double2 ydiag = *reinterpret_cast<const double2*>(c.Yb + (size_t)ib * 2);
+      const double psp = c.Psp[ib], qsp = c.Qsp[ib];
+      double va = c.va[ib], vm = c.vm[ib];
+      const bool act = p_on && (btu != BT_OFF) && (btv != BT_OFF);
+      const bool uP = (btu == BT_PQ || btu == BT_PV), uQ = (btu == BT_PQ), vP = (btv == BT_PQ || btv == BT_PV), vQ = (btv == BT_PQ);
+      const bool acc_u = act && (yuv.x != 0.0 || yuv.y != 0.0), acc_v = act && (yvu.x != 0.0 || yvu.y != 0.0);
+      const bool rowP = (bt == BT_PQ || bt == BT_PV), rowQ = (bt == BT_PQ);
+      const bool diag_on = bt != BT_OFF && (ydiag.x != 0.0 || ydiag.y != 0.0);
+      double* const Ad0 = bel(ib, 0, 0);
+      double* const Ad1 = bel(ib, 1, 0);
+      double* const b_uv0 = bel(suv, 0, 0); double* const b_uv1 = bel(suv, 1, 0);
+      double* const b_vu0 = bel(svu, 0, 0); double* const b_vu1 = bel(svu, 1, 0);
+      double e, f, ivm, Sr = 0.0, Si = 0.0;
+      {
+        double sn_, co;
+        fast_sincos(va, sn_, co);
+        e = vm * co; f = vm * sn_; ivm = fast_rcp(vm);
+        if (b_on) { setEF(ib, e, f); c.ivm[ib] = ivm; *SreP(ib) = 0.0; *SimP(ib) = 0.0; }
+      }
+      for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; }      // fill blocks start at zero
+      GPF_LSYNC();
+      GPF_STAMPS(10);
+      while (true) {
+        // ---- pair phase: T_uv, T_vu -> the two off-diagonal Jacobian blocks, S_u += T_uv, S_v += T_vu
+        if (p_on) {
+          const double2 efu = EF(u), efv = EF(v);
+          const double ivmu = c.ivm[u], ivmv = c.ivm[v];
           double tr_, ti_, sr_, si_;
-          t_of(yuv, eu, fu, ev, fv, tr_, ti_);
-          t_of(yvu, ev, fv, eu, fu, sr_, si_);
-          const bool act = (btu != BT_OFF) && (btv != BT_OFF);
-          const bool uP = (btu == BT_PQ || btu == BT_PV), uQ = (btu == BT_PQ), vP = (btv == BT_PQ || btv == BT_PV), vQ = (btv == BT_PQ);
-          *reinterpret_cast<double2*>(bel(suv, 0, 0)) = make_double2((uP && vP) ? ti_ : 0.0, (uP && vQ) ? tr_ * ivmv : 0.0);
-          *reinterpret_cast<double2*>(bel(suv, 1, 0)) = make_double2((uQ && vP) ? -tr_ : 0.0, (uQ && vQ) ? ti_ * ivmv : 0.0);
-          *reinterpret_cast<double2*>(bel(svu, 0, 0)) = make_double2((vP && uP) ? si_ : 0.0, (vP && uQ) ? sr_ * ivmu : 0.0);
-          *reinterpret_cast<double2*>(bel(svu, 1, 0)) = make_double2((vQ && uP) ? -sr_ : 0.0, (vQ && uQ) ? si_ * ivmu : 0.0);
-          if (act && (yuv.x != 0.0 || yuv.y != 0.0)) { atomicAdd(wave1 ? rhsT(u) : SreP(u), tr_); atomicAdd(wave1 ? rhsV(u) : SimP(u), ti_); }
-          if (act && (yvu.x != 0.0 || yvu.y != 0.0)) { atomicAdd(wave1 ? rhsT(v) : SreP(v), sr_); atomicAdd(wave1 ? rhsV(v) : SimP(v), si_); }
-        };
-        if (YR) {
-#pragma unroll
-          for (int k = 0; k < YR_PASSES; ++k) if (tid + k * GW < S.n_up) upair_item(rcreg[2 * k], rcreg[2 * k + 1], yreg[2 * k], yreg[2 * k + 1]);
-        } else {
-          unsigned p0 = rc_first, p1 = rc_first1;
-          for (int k = tid; k < S.n_up; k += GW) {
-            unsigned w0, w1;
-            if (STAGE == 0) { w0 = p0; w1 = p1; if (k + GW < S.n_up) { p0 = (unsigned)sv.up[2 * (k + GW)]; p1 = (unsigned)sv.up[2 * (k + GW) + 1]; } }
-            else { w0 = (unsigned)sv.up[2 * k]; w1 = (unsigned)sv.up[2 * k + 1]; }
-            upair_item(w0, w1, *reinterpret_cast<const double2*>(c.Yb + (size_t)(w1 & 0xffffu) * 2),
-                       *reinterpret_cast<const double2*>(c.Yb + (size_t)(w1 >> 16) * 2));
-          }
+          t_of(yuv, efu.x, efu.y, efv.x, efv.y, tr_, ti_);
+          t_of(yvu, efv.x, efv.y, efu.x, efu.y, sr_, si_);
+          *reinterpret_cast<double2*>(b_uv0) = make_double2((uP && vP) ? ti_ : 0.0, (uP && vQ) ? tr_ * ivmv : 0.0);
+          *reinterpret_cast<double2*>(b_uv1) = make_double2((uQ && vP) ? -tr_ : 0.0, (uQ && vQ) ? ti_ * ivmv : 0.0);
+          *reinterpret_cast<double2*>(b_vu0) = make_double2((vP && uP) ? si_ : 0.0, (vP && uQ) ? sr_ * ivmu : 0.0);
+          *reinterpret_cast<double2*>(b_vu1) = make_double2((vQ && uP) ? -sr_ : 0.0, (vQ && uQ) ? si_ * ivmu : 0.0);
+          if (acc_u) { atomicAdd(SreP(u), tr_); atomicAdd(SimP(u), ti_); }
+          if (acc_v) { atomicAdd(SreP(v), sr_); atomicAdd(SimP(v), si_); }
         }
-      } else {
-        auto pair_item = [&](int pr, const double2 y, const unsigned rc) {
-          const int slot = pr / (NB * NB), bi = (pr / NB) % NB, bj = pr % NB;
-          const int si = (int)(rc & 0xffffu), sj = (int)(rc >> 16);
-          const int i = si * NB + bi, j = sj * NB + bj;
-          const int bti = c.btype[i], btj = c.btype[j];
-          const double ei = c.e[i], fi = c.f[i], ej = c.e[j], fj = c.f[j], vmj = c.vm[j];
+        GPF_LSYNC();
+        if (it == 0) GPF_STAMPS(11);
+        // ---- mismatch phase: diagonal block (i, i), right-hand side, convergence test
+        double fabs_mis = 0.0;
+        bool bad = false;
+        if (b_on) {
+          Sr = *SreP(ib); Si = *SimP(ib);
           double tr_, ti_;
-          t_of(y, ei, fi, ej, fj, tr_, ti_);
-          const bool act = (bti != BT_OFF) && (btj != BT_OFF);
-          const bool rowP = (bti == BT_PQ || bti == BT_PV), rowQ = (bti == BT_PQ);
-          const bool colT = (btj == BT_PQ || btj == BT_PV), colV = (btj == BT_PQ);
-          const double ivmj = fast_rcp(vmj);
-          *reinterpret_cast<double2*>(bel(slot, 2 * bi, 2 * bj)) = make_double2((rowP && colT) ? ti_ : 0.0, (rowP && colV) ? tr_ * ivmj : 0.0);
-          *reinterpret_cast<double2*>(bel(slot, 2 * bi + 1, 2 * bj)) = make_double2((rowQ && colT) ? -tr_ : 0.0, (rowQ && colV) ? ti_ * ivmj : 0.0);
-          if (act && (y.x != 0.0 || y.y != 0.0)) { atomicAdd(wave1 ? rhsT(i) : SreP(i), tr_); atomicAdd(wave1 ? rhsV(i) : SimP(i), ti_); }
-        };
-        unsigned rc_pf = rc_first;
-        for (int pr = tid; pr < n_pairs; pr += GW) {
-          unsigned rc;
-          if (STAGE == 0) { rc = rc_pf; if (pr + GW < n_pairs) rc_pf = (unsigned)sv.pair_rc[(pr + GW) / (NB * NB)]; }
-          else rc = (unsigned)sv.pair_rc[pr / (NB * NB)];
-          pair_item(pr, *reinterpret_cast<const double2*>(c.Yb + (size_t)pr * 2), rc);
+          t_of(ydiag, e, f, e, f, tr_, ti_);
+          if (diag_on) { Sr += tr_; Si += ti_; }
+          const double2 r0 = make_double2(rowP ? ti_ : 0.0, (rowP && rowQ) ? tr_ * ivm : 0.0);
+          const double2 r1 = make_double2((rowQ && rowP) ? -tr_ : 0.0, rowQ ? ti_ * ivm : 0.0);
+          *reinterpret_cast<double2*>(Ad0) = make_double2(rowP ? r0.x - Si : 1.0, rowQ ? fma(Sr, ivm, r0.y) : r0.y);
+          *reinterpret_cast<double2*>(Ad1) = make_double2(rowQ ? r1.x + Sr : r1.x, rowQ ? fma(Si, ivm, r1.y) : 1.0);
+          const double mp = rowP ? (Sr - psp) : 0.0;
+          const double mq = rowQ ? (Si - qsp) : 0.0;
+          *rhsT(ib) = -mp; *rhsV(ib) = -mq;
+          const double am = fmax(fabs(mp), fabs(mq));
+          if (!(am <= 1e300)) bad = true;
+          fabs_mis = am;
         }
-      }
-      GPF_LSYNC();
-      if (it == 0) GPF_STAMPS(11);
-      double fabs_mis = 0.0;
-      bool bad = false;
-      for (int i = tid; i < nbus; i += GW) {
-        const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
-        double* Ad0 = bel(sub, 2 * bi, 2 * bi);
-        double* Ad1 = bel(sub, 2 * bi + 1, 2 * bi);
-        const int bt = c.btype[i];
-        double Sr = *SreP(i), Si = *SimP(i);
-        if (WPI > 1) { Sr += *rhsT(i); Si += *rhsV(i); }       // + wavefront 1's partial sums, always in this order
-        const double vmi = c.vm[i], psp = c.Psp[i], qsp = c.Qsp[i];
-        const bool rowP = (bt == BT_PQ || bt == BT_PV), rowQ = (bt == BT_PQ);
-        const double ivmi = NB == 1 ? c.ivm[i] : fast_rcp(vmi);
-        double2 r0, r1;
-        if (NB == 1) {                           // the diagonal block (i, i) is built here: T_ii joins S_i last
-          const double2 y = YR ? yreg[2 * YR_PASSES] : *reinterpret_cast<const double2*>(c.Yb + (size_t)i * 2);
-          const double ei = c.e[i], fi = c.f[i];
-          double tr_, ti_;
-          t_of(y, ei, fi, ei, fi, tr_, ti_);
-          if (bt != BT_OFF && (y.x != 0.0 || y.y != 0.0)) { Sr += tr_; Si += ti_; }
-          *SreP(i) = Sr; *SimP(i) = Si;          // K6 reads the bus injections of the converged state
-          r0 = make_double2(rowP ? ti_ : 0.0, (rowP && rowQ) ? tr_ * ivmi : 0.0);
-          r1 = make_double2((rowQ && rowP) ? -tr_ : 0.0, rowQ ? ti_ * ivmi : 0.0);
-        } else { r0 = *reinterpret_cast<const double2*>(Ad0); r1 = *reinterpret_cast<const double2*>(Ad1); }
-        // dS/dVa_ii += j S_i ; dS/dVm_ii += S_i / |V_i| ; identity on the fixed variables
-        *reinterpret_cast<double2*>(Ad0) = make_double2(rowP ? r0.x - Si : 1.0, rowQ ? fma(Sr, ivmi, r0.y) : r0.y);
-        *reinterpret_cast<double2*>(Ad1) = make_double2(rowQ ? r1.x + Sr : r1.x, rowQ ? fma(Si, ivmi, r1.y) : 1.0);
-        const double mp = rowP ? (Sr - psp) : 0.0;
-        const double mq = rowQ ? (Si - qsp) : 0.0;
-        if (BS == 2) { *rhsT(i) = -mp; *rhsV(i) = -mq; }
-        else *reinterpret_cast<double2*>(c.rhs + (size_t)sub * BS + 2 * bi) = make_double2(-mp, -mq);
-        const double am = fmax(fabs(mp), fabs(mq));
-        if (!(am <= 1e300)) bad = true;
-        fabs_mis = fmax(fabs_mis, am);
-      }
-      if (!done) {
-        const unsigned fl = G::template any2<0>(!(fabs_mis < tol_pu), bad);
-        if (fl & 2u) { status = 1; done = true; }
-        else if (!(fl & 1u)) { converged = true; done = true; }
-        else if (it >= max_iter) done = true;
-        else ++it;
-      }
-      if (G::block_all_u(done)) break;
-      GPF_LSYNC();
-      if (it == 1) GPF_STAMPS(12);
-      const bool ok = lu_ac(nullptr);
-      if (it == 1) GPF_STAMPS(13);
-      // update (groups that are done keep their state) + preparation of the next pair phase (every group)
-      bool fin = true, piv_ok = true;
-      for (int i = tid; i < nbus; i += GW) {
-        const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
-        const int bt = c.btype[i];
-        double va = c.va[i], vm = c.vm[i];
-        double2 dx = make_double2(*rhsT(i), *rhsV(i));
-        if (BS == 2) {                         // flat sweeps leave s_i = D_i x_i with the factored diagonal block in slot i
-          const double2 dA = *reinterpret_cast<const double2*>(bel(sub, 0, 0)), dB = *reinterpret_cast<const double2*>(bel(sub, 1, 0));
+        if (!done) {
+          const unsigned fl = G::template any2<0>(!(fabs_mis < tol_pu), bad);
+          if (fl & 2u) { status = 1; done = true; }
+          else if (!(fl & 1u)) { converged = true; done = true; }
+          else if (it >= max_iter) done = true;
+          else ++it;
+        }
+        if (G::block_all_u(done)) break;
+        GPF_LSYNC();
+        if (it == 1) GPF_STAMPS(12);
+        const bool ok = lu_ac(nullptr);
+        if (it == 1) GPF_STAMPS(13);
+        // ---- update (groups that are done keep their state) + preparation of the next pair phase
+        bool fin = true, piv_ok = true;
+        if (b_on) {
+          double2 dx = make_double2(*rhsT(ib), *rhsV(ib));
+          const double2 dA = *reinterpret_cast<const double2*>(Ad0), dB = *reinterpret_cast<const double2*>(Ad1);
           const double det = fma(dA.x, dB.y, -dA.y * dB.x);
           if (!(fabs(det) > 1e-300) || !(fabs(det) < 1e300)) piv_ok = false;
           const double rd = fast_rcp(det);
           dx = make_double2(fma(dB.y, dx.x, -dA.y * dx.y) * rd, fma(dA.x, dx.y, -dB.x * dx.x) * rd);
+          if (!done && bt != BT_OFF) {
+            if (!(fabs(dx.x) < 1e300) || !(fabs(dx.y) < 1e300)) fin = false;
+            if (bt == BT_PQ || bt == BT_PV) va += dx.x;
+            if (bt == BT_PQ) vm += dx.y;
+            if (vm < 0.0) { vm = -vm; va += 3.14159265358979323846; }
+            if (fabs(va) > 3.14159265358979323846) va = remainder(va, 6.28318530717958647692);
+          }
+          double sn_, co;
+          fast_sincos(va, sn_, co);
+          e = vm * co; f = vm * sn_; ivm = fast_rcp(vm);
+          setEF(ib, e, f);
+          c.ivm[ib] = ivm;
+          *SreP(ib) = 0.0;
+          *SimP(ib) = 0.0;
         }
-        if (!done && bt != BT_OFF) {
-          if (!(fabs(dx.x) < 1e300) || !(fabs(dx.y) < 1e300)) fin = false;
-          if (bt == BT_PQ || bt == BT_PV) va += dx.x;
-          if (bt == BT_PQ) vm += dx.y;
-          if (vm < 0.0) { vm = -vm; va += 3.14159265358979323846; }
-          if (fabs(va) > 3.14159265358979323846) va = remainder(va, 6.28318530717958647692);
-          c.va[i] = va;
-          c.vm[i] = vm;
-        }
+        for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; }
+        GPF_LSYNC();
+        if (!done && G::template any2<1>(!ok || !piv_ok, !fin) != 0u) { status = 4; done = true; }
+        if (it == 1) GPF_STAMPS(14);
+      }
+      // what the results phase reads from LDS: the bus injections of the final state, va, |V|
+      if (b_on) { *SreP(ib) = Sr; *SimP(ib) = Si; c.va[ib] = va; c.vm[ib] = vm; }
+    } else {
+      // Every phase of the loop is "issue all LDS reads -> compute -> write": the latency of a phase is a chain of dependent
+      // LDS round trips, so read-modify-write sequences inside branches are avoided.  V = e + jf, S = 0 and zeroed fill
+      // blocks are prepared by the phase BEFORE the pair phase (here for the first iteration, then by the update phase).
+      for (int i = tid; i < nbus; i += GW) {
+        const double va = c.va[i], vmi = c.vm[i];
         double sn_, co;
         fast_sincos(va, sn_, co);
-        c.e[i] = vm * co;
-        c.f[i] = vm * sn_;
-        if (NB == 1) c.ivm[i] = fast_rcp(vm);
+        setEF(i, vmi * co, vmi * sn_);
+        if (NB == 1) c.ivm[i] = fast_rcp(vmi);
         *SreP(i) = 0.0;
         *SimP(i) = 0.0;
-        if (WPI > 1) { *rhsT(i) = 0.0; *rhsV(i) = 0.0; }
+        if (WPI > 1) { *rhsT(i) = 0.0; *rhsV(i) = 0.0; }      // wavefront 1's partial sums of S (see acc_lane above)
       }
       if (BS == 2) { for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; } }
-    else for (int i = S.nslot_y * B2 + tid; i < S.nslot_lu * B2; i += GW) c.A[i] = 0.0;
+      else for (int i = S.nslot_y * B2 + tid; i < S.nslot_lu * B2; i += GW) c.A[i] = 0.0;     // fill blocks start at zero
       GPF_LSYNC();
-      if (!done && G::template any2<1>(!ok || !piv_ok, !fin) != 0u) { status = 4; done = true; }
-      if (it == 1) GPF_STAMPS(14);
+      GPF_STAMPS(10);
+      // Single-busbar layout: ONE lane per undirected pair (u, v) of connected substations computes both Jacobian blocks (u, v) and
+      // (v, u) -- they share every operand but the Ybus block --, and the diagonal block of bus i is built by bus i's lane in the
+      // mismatch phase (which needs S_i anyway): half the passes of one lane per block of the original pattern.
+      // Tier 0 (tables in global memory): the words of the first pass stay in registers for the whole Newton loop and those of pass
+      // k + 1 are fetched before pass k computes -- an L2 round trip per pass is otherwise the longest link of the phase.
+      unsigned rc_first = 0, rc_first1 = 0;
+      if (STAGE == 0 && !YR) {
+        if (NB == 1) { if (tid < S.n_up) { rc_first = (unsigned)sv.up[2 * tid]; rc_first1 = (unsigned)sv.up[2 * tid + 1]; } }
+        else if (tid < n_pairs) rc_first = (unsigned)sv.pair_rc[tid / (NB * NB)];
+      }
+      while (true) {
+        // Jacobian blocks from the Ybus blocks: T_ij = V_i conj(Y_ij V_j); S_i += T_ij (LDS atomics)
+        if (NB == 1) {
+          auto upair_item = [&](const unsigned w0, const unsigned w1, const double2 yuv, const double2 yvu) {
+            const int u = (int)(w0 & 0xffffu), v = (int)(w0 >> 16), suv = (int)(w1 & 0xffffu), svu = (int)(w1 >> 16);
+            const int btu = c.btype[u], btv = c.btype[v];
+            const double2 efu = EF(u), efv = EF(v);
+            const double eu = efu.x, fu = efu.y, ivmu = c.ivm[u], ev = efv.x, fv = efv.y, ivmv = c.ivm[v];
+            double tr_, ti_, sr_, si_;
+            t_of(yuv, eu, fu, ev, fv, tr_, ti_);
+            t_of(yvu, ev, fv, eu, fu, sr_, si_);
+            const bool act = (btu != BT_OFF) && (btv != BT_OFF);
+            const bool uP = (btu == BT_PQ || btu == BT_PV), uQ = (btu == BT_PQ), vP = (btv == BT_PQ || btv == BT_PV), vQ = (btv == BT_PQ);
+            *reinterpret_cast<double2*>(bel(suv, 0, 0)) = make_double2((uP && vP) ? ti_ : 0.0, (uP && vQ) ? tr_ * ivmv : 0.0);
+            *reinterpret_cast<double2*>(bel(suv, 1, 0)) = make_double2((uQ && vP) ? -tr_ : 0.0, (uQ && vQ) ? ti_ * ivmv : 0.0);
+            *reinterpret_cast<double2*>(bel(svu, 0, 0)) = make_double2((vP && uP) ? si_ : 0.0, (vP && uQ) ? sr_ * ivmu : 0.0);
+            *reinterpret_cast<double2*>(bel(svu, 1, 0)) = make_double2((vQ && uP) ? -sr_ : 0.0, (vQ && uQ) ? si_ * ivmu : 0.0);
+            if (act && (yuv.x != 0.0 || yuv.y != 0.0)) { atomicAdd(wave1 ? rhsT(u) : SreP(u), tr_); atomicAdd(wave1 ? rhsV(u) : SimP(u), ti_); }
+            if (act && (yvu.x != 0.0 || yvu.y != 0.0)) { atomicAdd(wave1 ? rhsT(v) : SreP(v), sr_); atomicAdd(wave1 ? rhsV(v) : SimP(v), si_); }
+          };
+          if (YR) {
+  #pragma unroll
+            for (int k = 0; k < YR_PASSES; ++k) if (tid + k * GW < S.n_up) upair_item(rcreg[2 * k], rcreg[2 * k + 1], yreg[2 * k], yreg[2 * k + 1]);
+          } else {
+            unsigned p0 = rc_first, p1 = rc_first1;
+            for (int k = tid; k < S.n_up; k += GW) {
+              unsigned w0, w1;
+              if (STAGE == 0) { w0 = p0; w1 = p1; if (k + GW < S.n_up) { p0 = (unsigned)sv.up[2 * (k + GW)]; p1 = (unsigned)sv.up[2 * (k + GW) + 1]; } }
+              else { w0 = (unsigned)sv.up[2 * k]; w1 = (unsigned)sv.up[2 * k + 1]; }
+              upair_item(w0, w1, *reinterpret_cast<const double2*>(c.Yb + (size_t)(w1 & 0xffffu) * 2),
+                         *reinterpret_cast<const double2*>(c.Yb + (size_t)(w1 >> 16) * 2));
+            }
+          }
+        } else {
+          auto pair_item = [&](int pr, const double2 y, const unsigned rc) {
+            const int slot = pr / (NB * NB), bi = (pr / NB) % NB, bj = pr % NB;
+            const int si = (int)(rc & 0xffffu), sj = (int)(rc >> 16);
+            const int i = si * NB + bi, j = sj * NB + bj;
+            const int bti = c.btype[i], btj = c.btype[j];
+            const double2 efi = EF(i), efj = EF(j);
+            const double ei = efi.x, fi = efi.y, ej = efj.x, fj = efj.y, vmj = c.vm[j];
+            double tr_, ti_;
+            t_of(y, ei, fi, ej, fj, tr_, ti_);
+            const bool act = (bti != BT_OFF) && (btj != BT_OFF);
+            const bool rowP = (bti == BT_PQ || bti == BT_PV), rowQ = (bti == BT_PQ);
+            const bool colT = (btj == BT_PQ || btj == BT_PV), colV = (btj == BT_PQ);
+            const double ivmj = fast_rcp(vmj);
+            *reinterpret_cast<double2*>(bel(slot, 2 * bi, 2 * bj)) = make_double2((rowP && colT) ? ti_ : 0.0, (rowP && colV) ? tr_ * ivmj : 0.0);
+            *reinterpret_cast<double2*>(bel(slot, 2 * bi + 1, 2 * bj)) = make_double2((rowQ && colT) ? -tr_ : 0.0, (rowQ && colV) ? ti_ * ivmj : 0.0);
+            if (act && (y.x != 0.0 || y.y != 0.0)) { atomicAdd(wave1 ? rhsT(i) : SreP(i), tr_); atomicAdd(wave1 ? rhsV(i) : SimP(i), ti_); }
+          };
+          unsigned rc_pf = rc_first;
+          for (int pr = tid; pr < n_pairs; pr += GW) {
+            unsigned rc;
+            if (STAGE == 0) { rc = rc_pf; if (pr + GW < n_pairs) rc_pf = (unsigned)sv.pair_rc[(pr + GW) / (NB * NB)]; }
+            else rc = (unsigned)sv.pair_rc[pr / (NB * NB)];
+            pair_item(pr, *reinterpret_cast<const double2*>(c.Yb + (size_t)pr * 2), rc);
+          }
+        }
+        GPF_LSYNC();
+        if (it == 0) GPF_STAMPS(11);
+        double fabs_mis = 0.0;
+        bool bad = false;
+        for (int i = tid; i < nbus; i += GW) {
+          const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
+          double* Ad0 = bel(sub, 2 * bi, 2 * bi);
+          double* Ad1 = bel(sub, 2 * bi + 1, 2 * bi);
+          const int bt = c.btype[i];
+          double Sr = *SreP(i), Si = *SimP(i);
+          if (WPI > 1) { Sr += *rhsT(i); Si += *rhsV(i); }       // + wavefront 1's partial sums, always in this order
+          const double vmi = c.vm[i], psp = c.Psp[i], qsp = c.Qsp[i];
+          const bool rowP = (bt == BT_PQ || bt == BT_PV), rowQ = (bt == BT_PQ);
+          const double ivmi = NB == 1 ? c.ivm[i] : fast_rcp(vmi);
+          double2 r0, r1;
+          if (NB == 1) {                           // the diagonal block (i, i) is built here: T_ii joins S_i last
+            const double2 y = YR ? yreg[2 * YR_PASSES] : *reinterpret_cast<const double2*>(c.Yb + (size_t)i * 2);
+            const double2 efi = EF(i);
+            const double ei = efi.x, fi = efi.y;
+            double tr_, ti_;
+            t_of(y, ei, fi, ei, fi, tr_, ti_);
+            if (bt != BT_OFF && (y.x != 0.0 || y.y != 0.0)) { Sr += tr_; Si += ti_; }
+            *SreP(i) = Sr; *SimP(i) = Si;          // K6 reads the bus injections of the converged state
+            r0 = make_double2(rowP ? ti_ : 0.0, (rowP && rowQ) ? tr_ * ivmi : 0.0);
+            r1 = make_double2((rowQ && rowP) ? -tr_ : 0.0, rowQ ? ti_ * ivmi : 0.0);
+          } else { r0 = *reinterpret_cast<const double2*>(Ad0); r1 = *reinterpret_cast<const double2*>(Ad1); }
+          // dS/dVa_ii += j S_i ; dS/dVm_ii += S_i / |V_i| ; identity on the fixed variables
+          *reinterpret_cast<double2*>(Ad0) = make_double2(rowP ? r0.x - Si : 1.0, rowQ ? fma(Sr, ivmi, r0.y) : r0.y);
+          *reinterpret_cast<double2*>(Ad1) = make_double2(rowQ ? r1.x + Sr : r1.x, rowQ ? fma(Si, ivmi, r1.y) : 1.0);
+          const double mp = rowP ? (Sr - psp) : 0.0;
+          const double mq = rowQ ? (Si - qsp) : 0.0;
+          if (BS == 2) { *rhsT(i) = -mp; *rhsV(i) = -mq; }
+          else *reinterpret_cast<double2*>(c.rhs + (size_t)sub * BS + 2 * bi) = make_double2(-mp, -mq);
+          const double am = fmax(fabs(mp), fabs(mq));
+          if (!(am <= 1e300)) bad = true;
+          fabs_mis = fmax(fabs_mis, am);
+        }
+        if (!done) {
+          const unsigned fl = G::template any2<0>(!(fabs_mis < tol_pu), bad);
+          if (fl & 2u) { status = 1; done = true; }
+          else if (!(fl & 1u)) { converged = true; done = true; }
+          else if (it >= max_iter) done = true;
+          else ++it;
+        }
+        if (G::block_all_u(done)) break;
+        GPF_LSYNC();
+        if (it == 1) GPF_STAMPS(12);
+        const bool ok = lu_ac(nullptr);
+        if (it == 1) GPF_STAMPS(13);
+        // update (groups that are done keep their state) + preparation of the next pair phase (every group)
+        bool fin = true, piv_ok = true;
+        for (int i = tid; i < nbus; i += GW) {
+          const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
+          const int bt = c.btype[i];
+          double va = c.va[i], vm = c.vm[i];
+          double2 dx = make_double2(*rhsT(i), *rhsV(i));
+          if (BS == 2) {                         // flat sweeps leave s_i = D_i x_i with the factored diagonal block in slot i
+            const double2 dA = *reinterpret_cast<const double2*>(bel(sub, 0, 0)), dB = *reinterpret_cast<const double2*>(bel(sub, 1, 0));
+            const double det = fma(dA.x, dB.y, -dA.y * dB.x);
+            if (!(fabs(det) > 1e-300) || !(fabs(det) < 1e300)) piv_ok = false;
+            const double rd = fast_rcp(det);
+            dx = make_double2(fma(dB.y, dx.x, -dA.y * dx.y) * rd, fma(dA.x, dx.y, -dB.x * dx.x) * rd);
+          }
+          if (!done && bt != BT_OFF) {
+            if (!(fabs(dx.x) < 1e300) || !(fabs(dx.y) < 1e300)) fin = false;
+            if (bt == BT_PQ || bt == BT_PV) va += dx.x;
+            if (bt == BT_PQ) vm += dx.y;
+            if (vm < 0.0) { vm = -vm; va += 3.14159265358979323846; }
+            if (fabs(va) > 3.14159265358979323846) va = remainder(va, 6.28318530717958647692);
+            c.va[i] = va;
+            c.vm[i] = vm;
+          }
+          double sn_, co;
+          fast_sincos(va, sn_, co);
+          setEF(i, vm * co, vm * sn_);
+          if (NB == 1) c.ivm[i] = fast_rcp(vm);
+          *SreP(i) = 0.0;
+          *SimP(i) = 0.0;
+          if (WPI > 1) { *rhsT(i) = 0.0; *rhsV(i) = 0.0; }
+        }
+        if (BS == 2) { for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; } }
+      else for (int i = S.nslot_y * B2 + tid; i < S.nslot_lu * B2; i += GW) c.A[i] = 0.0;
+        GPF_LSYNC();
+        if (!done && G::template any2<1>(!ok || !piv_ok, !fin) != 0u) { status = 4; done = true; }
+        if (it == 1) GPF_STAMPS(14);
+      }
     }
     if (status == 0 && !converged) status = 1;
   }
@@ -1371,7 +1502,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     const int bs = g.n_sto ? (int)c.sto_b[is_] : -1, bh = g.n_shunt ? (int)c.sh_b[ih] : -1;
     const int fc = f >= 0 ? f : 0, tc = t >= 0 ? t : 0, bdc = bd >= 0 ? bd : 0, bgc = bg >= 0 ? bg : 0, bsc = bs >= 0 ? bs : 0, bhc = bh >= 0 ? bh : 0;
     // bus state + tables
-    const double vmf = c.vm[fc], vmt = c.vm[tc], ef = c.e[fc], ff = c.f[fc], et = c.e[tc], ft = c.f[tc], vaf = c.va[fc], vat = c.va[tc];
+    const double2 ef_f = EF(fc), ef_t = EF(tc);
+    const double vmf = c.vm[fc], vmt = c.vm[tc], ef = ef_f.x, ff = ef_f.y, et = ef_t.x, ft = ef_t.y, vaf = c.va[fc], vat = c.va[tc];
     const double4 ya = sv.br_y.ld4((size_t)8 * il), yb = sv.br_y.ld4((size_t)8 * il + 4);
     const double vnf = sv.line_vn[2 * il], vnt = sv.line_vn[2 * il + 1];
     const double vmd = c.vm[bdc], vad = c.va[bdc], lpd = GPF_INJ(oo.inj_load_p + id), lqd = GPF_INJ(oo.inj_load_q + id), vnd = sv.load_vn[id];
@@ -1461,7 +1593,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         pt = -pf; qf = 0.0; qt = 0.0;
       } else {
         const double4 ya = sv.br_y.ld4((size_t)8 * l), yb = sv.br_y.ld4((size_t)8 * l + 4);
-        const double ef = c.e[f], ff = c.f[f], et = c.e[t], ft = c.f[t];
+        const double2 ef_f = EF(f), ef_t = EF(t);
+        const double ef = ef_f.x, ff = ef_f.y, et = ef_t.x, ft = ef_t.y;
         const double ifr = ya.x * ef - ya.y * ff + ya.z * et - ya.w * ft;
         const double ifi = ya.x * ff + ya.y * ef + ya.z * ft + ya.w * et;
         const double itr = yb.x * ef - yb.y * ff + yb.z * et - yb.w * ft;

@@ -13,8 +13,8 @@ for lib in "$@"; do
   echo "[$lib] case14 16/launch obs : $(one --steps 800 --warmup 32)" >> $out
   echo "[$lib] case14 1/launch      : $(one --steps 400 --warmup 32 --steps-per-launch 1)" >> $out
   done
-  echo "[$lib] n1 neurips 1024x60   : $(one --env l2rpn_neurips_2020_track1 --batch 1024 --n1 --steps 48 --warmup 16 --last-obs-only)" >> $out
-  echo "[$lib] wcci 1024            : $(one --env l2rpn_wcci_2022_dev --batch 1024 --steps 160 --warmup 16 --last-obs-only)" >> $out
-  echo "[$lib] neurips 4096         : $(one --env l2rpn_neurips_2020_track1 --batch 4096 --steps 160 --warmup 16 --last-obs-only)" >> $out
+  echo "[$lib] n1 neurips 1024x60   : $(one --env l2rpn_neurips_2020_track1 --batch 1024 --n1 --steps 48 --warmup 16)" >> $out
+  echo "[$lib] wcci 1024            : $(one --env l2rpn_wcci_2022_dev --batch 1024 --steps 160 --warmup 16)" >> $out
+  echo "[$lib] neurips 4096         : $(one --env l2rpn_neurips_2020_track1 --batch 4096 --steps 160 --warmup 16)" >> $out
 done
 cat $out
