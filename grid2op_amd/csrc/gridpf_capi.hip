@@ -786,7 +786,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   gpf::GridDev& g = e->g;
   g.n_sub = d->n_sub; g.n_busbar = d->n_busbar; g.nb_tot = d->n_sub * d->n_busbar;
   g.n_line = d->n_line; g.n_gen = d->n_gen; g.n_load = d->n_load; g.n_sto = d->n_storage; g.n_shunt = d->n_shunt;
-  g.dim_topo = d->dim_topo; g.sn_mva = d->sn_mva;
+  g.dim_topo = d->dim_topo; g.sn_mva = d->sn_mva; g.inv_sn_mva = 1.0 / d->sn_mva;
   const int nl = g.n_line, ng = g.n_gen, nd = g.n_load, ns = g.n_sto, nsh = g.n_shunt;
   e->oo = gpf::make_offsets(nl, ng, nd, ns, nsh);
   g.n_inj = 2 * ng + 2 * nd + 2 * ns + 2 * nsh;
@@ -915,6 +915,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
       std::vector<double> lv((size_t)2 * nl);
       for (int l = 0; l < nl; ++l) { lv[2 * (size_t)l] = d->sub_vn_kv[d->line_or_sub[l]]; lv[2 * (size_t)l + 1] = d->sub_vn_kv[d->line_ex_sub[l]]; }
       so.line_vn = putd(lv.data(), lv.size());
+      { std::vector<double> ka(lv.size()); for (size_t i = 0; i < lv.size(); ++i) ka[i] = 1000.0 / (1.7320508075688772935 * lv[i]); so.line_ka = putd(ka.data(), ka.size()); }
       { auto v = vn_of(d->load_sub, nd); so.load_vn = putd(v.data(), v.size()); }
       { auto v = vn_of(d->gen_sub, ng); so.gen_vn = putd(v.data(), v.size()); }
       { auto v = vn_of(d->storage_sub, ns); so.sto_vn = putd(v.data(), v.size()); }

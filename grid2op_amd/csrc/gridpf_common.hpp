@@ -26,6 +26,7 @@ struct GridDev {
   int n_sub, n_busbar, nb_tot, n_line, n_gen, n_load, n_sto, n_shunt, dim_topo;
   int n_inj, n_out, n_chron;
   double sn_mva;
+  double inv_sn_mva;       // 1 / sn_mva (host, correctly rounded: what the device's own division gave)
   const double* sub_vn_kv;
   const int* line_or_sub;
   const int* line_ex_sub;

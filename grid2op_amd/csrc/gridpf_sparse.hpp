@@ -23,6 +23,7 @@ struct StatOff {
   int n_int_hot;   // the int section starts with the tables of the Newton loop (prog, pair_rc): staging tier 1 copies only these
   int br_y, br_bdc, sub_vn_kv, shunt_fact, gen_min_q, gen_max_q;
   int line_vn, load_vn, gen_vn, sto_vn, shunt_vn;   // nominal kV of the substation of every element (line: [n_line][2] = or, ex)
+  int line_ka;     // [n_line][2] 1000 / (sqrt(3) vn) of the two ends: i [A] = |S| [MVA] / |V| [pu] * line_ka
   int gen_qmin_tot, gen_qmax_tot;   // [n_gen] sum of min_q / max_q over the generators of the generator's substation (every generator
                                     // connected, single busbar): what pfsoln's reactive split needs, per generator
   int gen_cnt;     // (int section) [n_gen] generators | slack generators << 16 of the generator's substation, same assumption
@@ -48,7 +49,7 @@ struct SP {
 template <int STAGE>
 struct StatView {
   static constexpr bool ALL = STAGE == 2, HOT = STAGE >= 1;
-  SP<double, ALL> br_y, br_bdc, sub_vn_kv, shunt_fact, gen_min_q, gen_max_q, line_vn, load_vn, gen_vn, sto_vn, shunt_vn, dc_inv, gen_qmin_tot, gen_qmax_tot;
+  SP<double, ALL> br_y, br_bdc, sub_vn_kv, shunt_fact, gen_min_q, gen_max_q, line_vn, line_ka, load_vn, gen_vn, sto_vn, shunt_vn, dc_inv, gen_qmin_tot, gen_qmax_tot;
   SP<int, ALL> line_or_pos, line_ex_pos, line_or_sub, line_ex_sub, br_slot, gen_pos, gen_sub, gen_slack, load_pos, load_sub,
       sto_pos, sto_sub, shunt_sub, gen_cnt, pos_line;
   SP<int, HOT> pair_rc;   // [nslot_y] slot_row | slot_col << 16 of the original-pattern blocks
@@ -62,7 +63,7 @@ __device__ inline void stat_view(StatView<STAGE>& v, const StatOff& o, const dou
   v.gen_min_q.p = d + o.gen_min_q; v.gen_max_q.p = d + o.gen_max_q;
   v.dc_inv.p = d + (o.dc_inv >= 0 ? o.dc_inv : 0);
   v.gen_qmin_tot.p = d + o.gen_qmin_tot; v.gen_qmax_tot.p = d + o.gen_qmax_tot; v.gen_cnt.p = i + o.gen_cnt;
-  v.line_vn.p = d + o.line_vn; v.load_vn.p = d + o.load_vn; v.gen_vn.p = d + o.gen_vn; v.sto_vn.p = d + o.sto_vn; v.shunt_vn.p = d + o.shunt_vn;
+  v.line_vn.p = d + o.line_vn; v.line_ka.p = d + o.line_ka; v.load_vn.p = d + o.load_vn; v.gen_vn.p = d + o.gen_vn; v.sto_vn.p = d + o.sto_vn; v.shunt_vn.p = d + o.shunt_vn;
   v.line_or_pos.p = i + o.line_or_pos; v.line_ex_pos.p = i + o.line_ex_pos; v.line_or_sub.p = i + o.line_or_sub;
   v.line_ex_sub.p = i + o.line_ex_sub; v.br_slot.p = i + o.br_slot; v.gen_pos.p = i + o.gen_pos; v.gen_sub.p = i + o.gen_sub;
   v.gen_slack.p = i + o.gen_slack; v.load_pos.p = i + o.load_pos; v.load_sub.p = i + o.load_sub; v.sto_pos.p = i + o.sto_pos;
@@ -837,8 +838,22 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   const bool reuse = ctl.reuse;
   const bool dc_kept = reuse && ctl.dcf && NB == 1;        // the factored DC matrix of the previous solve is still valid
   const bool warm = reuse && ctl.warm && !is_dc;            // block-uniform: skip the DC initialisation, keep va / |V| of PQ buses
+  // Newton working set in registers (instance-group kernels, see the Newton loop below); block-uniform
+#ifdef GPF_NO_NWR                                               /* developer A/B build (tools/build_worktree_variant.sh): general path only */
+  constexpr bool NWR = false;
+#else
+  constexpr bool NWR = NB == 1 && IPW > 1 && WPI == 1 && !YR;
+#endif
+  const bool nwr = NWR && !is_dc && nbus <= GW && S.n_up <= GW;
+  // FUSED START of a step whose topology stands (reuse, K9 already accumulated the bus sums) on the reference topology of a small
+  // grid (static DC inverse): the phases "initial |V|", "DC right-hand side", "theta = inv(B') P" and "Newton initialisation" only
+  // exchange per-bus values that the bus lane itself produces and consumes -- they run as ONE phase inside the Newton
+  // initialisation (the matrix-vector product reads Psp - Gs directly: the rows / columns of the reference buses of the static
+  // inverse are exact unit vectors, so their right-hand-side entries do not matter).  Three phase boundaries and their LDS round
+  // trips less per step.
+  const bool fast_pre = nwr && reuse && ctl.sums_done && !warm && !TC && S.so.dc_inv >= 0 && G::block_all_u(ts.dc_base);
 #define GPF_INJ(i_) (STAGE ? c.inj[(i_)] : (double)inj_g[(i_)])      /* staged row in LDS, else the lane's row in HBM / L2 */
-  const double sn = g.sn_mva, inv_sn = 1.0 / sn;
+  const double sn = g.sn_mva, inv_sn = g.inv_sn_mva;
 
   // ---- K1: element -> bus, bus activity / types / injections with LDS atomics from the element lanes ---------------------
   // (reuse: the maps and types of the previous solve stand, only the injection sums are rebuilt)
@@ -949,6 +964,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   GPF_LSYNC();
   GPF_STAMPS(28);
   int nb = 0, nref = 0;
+  if (!fast_pre)
   for (int i0 = 0; i0 < nbus; i0 += GW) {
     const int i = i0 + tid;
     const int bt = i < nbus ? c.btype[i] : BT_OFF;
@@ -966,7 +982,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   }
   if (reuse) nb = ts.nb;
   nb_out = nb;
-  GPF_LSYNC();
+  if (!fast_pre) GPF_LSYNC();
   int status = reuse ? ts.status : ((nref == 0) ? 3 : 0);           // first failure of this group (0 = alive)
   if (!reuse) { ts.status = status; ts.nb = nb; }
   if (G::block_all_u(status != 0)) return status;
@@ -1014,7 +1030,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   const bool dc_inv = NB == 1 && !TC && G::block_all_u(ts.dc_base);
   const bool dc_skip = dc_kept || dc_inv;              // no DC matrix to assemble
   auto lidx = [&](int bus) -> int { return (NB == 1) ? 0 : bus % NB; };
-  if (!warm) {
+  if (!warm && !fast_pre) {
   if (!dc_skip || do_y) {
   // YR: the Ybus blocks are assembled in the (still unused) row-1 half of the block array and then moved to registers
   double* const ydst = YR ? c.A + HS : c.Yb;
@@ -1115,7 +1131,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     if (PROG_LDS) return scalar_lu_flat<GW, true, false>(FL, sv.prog.p, c.A, c.A, tid, dbg);
     return scalar_lu_flat<GW, true, false>(FL, gptr(flat_g), c.A, c.A, tid, dbg);
   };
-  if (!warm) {
+  if (!warm && !fast_pre) {
 #ifdef GPF_TIMING
     bool ok = dc_inv ? true : (NB == 1) ? lu_dc(&stamps.v[20])
                                         : lu_ac(&stamps.v[20]);
@@ -1169,12 +1185,6 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     // dependent ones (table words -> operands), the mismatch phase reads only S_i, and ~35 % of the VALU instructions of the three
     // single-phase steps (address arithmetic, type compares, loop / exec-mask handling) are gone.  Same arithmetic in the same order
     // as the general path below: results are bit-identical.
-#ifdef GPF_NO_NWR                                               /* developer A/B build (tools/build_worktree_variant.sh): general path only */
-    constexpr bool NWR = false;
-#else
-    constexpr bool NWR = NB == 1 && IPW > 1 && WPI == 1 && !YR;
-#endif
-    const bool nwr = NWR && nbus <= GW && S.n_up <= GW;           // block-uniform (sizes of the grid / of the block's topology class)
     if (nwr) {
       const bool p_on = tid < S.n_up, b_on = tid < nbus;
       const int ib = b_on ? tid : 0;
@@ -1185,7 +1195,33 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       const int bt = c.btype[ib];
       const double2 ydiag = *reinterpret_cast<const double2*>(c.Yb + (size_t)ib * 2);
       const double psp = c.Psp[ib], qsp = c.Qsp[ib];
-      double va = c.va[ib], vm = c.vm[ib];
+      double va, vm;
+      if (fast_pre) {
+        // initial |V| (K1), DC right-hand side (K3) and theta = inv(B') (P - G) in the bus lane itself; row ib of the column-major
+        // static inverse, all operands in flight before the two FMA chains (even / odd k, the order of the general path)
+        const int vi = c.vidx[ib];
+        double t0 = 0.0, t1 = 0.0;
+        for (int k0 = 0; k0 < nbus; k0 += 8) {
+          double a_[8], r_[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int k = k0 + q < nbus ? k0 + q : nbus - 1;
+            a_[q] = sv.dc_inv[k * nbus + ib];
+            r_[q] = c.Psp[k] - c.Gs[k];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; q += 2) {
+            if (k0 + q < nbus) t0 = fma(a_[q], r_[q], t0);
+            if (k0 + q + 1 < nbus) t1 = fma(a_[q + 1], r_[q + 1], t1);
+          }
+        }
+        const double th = t0 + t1;
+        const bool live = (bt == BT_PQ || bt == BT_PV);
+        va = live ? th : 0.0;
+        vm = (vi >= 0 && (bt == BT_PV || bt == BT_REF)) ? GPF_INJ(oo.inj_gen_vm + vi) : 1.0;
+        const bool th_bad = b_on && bt != BT_OFF && !(fabs(th) < 1e300);
+        if (status == 0 && G::any(th_bad)) { status = 4; done = true; }
+      } else { va = c.va[ib]; vm = c.vm[ib]; }
       const bool act = p_on && (btu != BT_OFF) && (btv != BT_OFF);
       const bool uP = (btu == BT_PQ || btu == BT_PV), uQ = (btu == BT_PQ), vP = (btv == BT_PQ || btv == BT_PV), vQ = (btv == BT_PQ);
       const bool acc_u = act && (yuv.x != 0.0 || yuv.y != 0.0), acc_v = act && (yvu.x != 0.0 || yvu.y != 0.0);
@@ -1505,7 +1541,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     const double2 ef_f = EF(fc), ef_t = EF(tc);
     const double vmf = c.vm[fc], vmt = c.vm[tc], ef = ef_f.x, ff = ef_f.y, et = ef_t.x, ft = ef_t.y, vaf = c.va[fc], vat = c.va[tc];
     const double4 ya = sv.br_y.ld4((size_t)8 * il), yb = sv.br_y.ld4((size_t)8 * il + 4);
-    const double vnf = sv.line_vn[2 * il], vnt = sv.line_vn[2 * il + 1];
+    const double vnf = sv.line_vn[2 * il], vnt = sv.line_vn[2 * il + 1], kaf = sv.line_ka[2 * il], kat = sv.line_ka[2 * il + 1];
+    const double ivmf = c.ivm[fc], ivmt = c.ivm[tc];       // 1 / |V| of the final iterate (Newton update phase)
     const double vmd = c.vm[bdc], vad = c.va[bdc], lpd = GPF_INJ(oo.inj_load_p + id), lqd = GPF_INJ(oo.inj_load_q + id), vnd = sv.load_vn[id];
     const double simg = *SimP(bgc), qspg = c.Qsp[bgc], sreg = *SreP(bgc), pspg = c.Psp[bgc], vmg = c.vm[bgc], vag = c.va[bgc];
     const int gw_ = sv.gen_cnt[ig], gsl = sv.gen_slack[ig];
@@ -1524,8 +1561,9 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       const double iti = yb.x * ff + yb.y * ef + yb.z * ft + yb.w * et;
       const double pf = (ef * ifr + ff * ifi) * sn, qf = (ff * ifr - ef * ifi) * sn;
       const double pt = (et * itr + ft * iti) * sn, qt = (ft * itr - et * iti) * sn;
-      const float a_or = on ? (float)(sqrt(pf * pf + qf * qf) / (SQRT3 * vmf * vnf) * 1000.0) : 0.f;
-      const float a_ex = on ? (float)(sqrt(pt * pt + qt * qt) / (SQRT3 * vmt * vnt) * 1000.0) : 0.f;
+      // i = |S| / (sqrt(3) |V| vn): reciprocals instead of two float64 divisions (~25 VALU instructions each)
+      const float a_or = on ? (float)(sqrt(pf * pf + qf * qf) * ivmf * kaf) : 0.f;
+      const float a_ex = on ? (float)(sqrt(pt * pt + qt * qt) * ivmt * kat) : 0.f;
       if (hl) {
         if (wtopo) lstat[l] = on ? 1 : 0;
         out[oo.p_or + l] = on ? (float)pf : 0.f; out[oo.q_or + l] = on ? (float)qf : 0.f; out[oo.v_or + l] = on ? (float)(vmf * vnf) : 0.f;
@@ -1568,10 +1606,10 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         const int cn = gw_ & 0xffff, ns = gw_ >> 16;
         double q;
         if (cn == 1) q = qtot;
-        else if (gqmn == gqmx) q = qtot / cn;
-        else q = gmn + (qtot - gqmn) / (gqmx - gqmn + 2.220446049250313e-16) * (gmx - gmn);
+        else if (gqmn == gqmx) q = qtot * fast_rcp((double)cn);
+        else q = gmn + (qtot - gqmn) * fast_rcp(gqmx - gqmn + 2.220446049250313e-16) * (gmx - gmn);
         double p = gpi;
-        if (gsl) p = (sreg - pspg) * sn / ns;
+        if (gsl) p = (sreg - pspg) * sn * fast_rcp((double)ns);
         gp = (float)p; gq = (float)q;
         gv = (float)(vmg * gvn);
         gth = (float)(vag * RAD2DEG);
@@ -1603,8 +1641,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         pt = (et * itr + ft * iti) * sn;  qt = (ft * itr - et * iti) * sn;
       }
       p_or = (float)pf; q_or = (float)qf; p_ex = (float)pt; q_ex = (float)qt;
-      a_or = (float)(sqrt(pf * pf + qf * qf) / (SQRT3 * vmf * vnf) * 1000.0);
-      a_ex = (float)(sqrt(pt * pt + qt * qt) / (SQRT3 * vmt * vnt) * 1000.0);
+      a_or = (float)(sqrt(pf * pf + qf * qf) * fast_rcp(vmf) * sv.line_ka[2 * l]);
+      a_ex = (float)(sqrt(pt * pt + qt * qt) * fast_rcp(vmt) * sv.line_ka[2 * l + 1]);
       v_or = (float)(vmf * vnf); v_ex = (float)(vmt * vnt);
       th_or = (float)(c.va[f] * RAD2DEG); th_ex = (float)(c.va[t] * RAD2DEG);
     }
@@ -1679,10 +1717,10 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         double q;
         if (is_dc) q = 0.0;
         else if (cn == 1) q = qtot;
-        else if (qmn == qmx) q = qtot / cn;
-        else q = mn + (qtot - qmn) / (qmx - qmn + 2.220446049250313e-16) * (mx - mn);
+        else if (qmn == qmx) q = qtot * fast_rcp((double)cn);
+        else q = mn + (qtot - qmn) * fast_rcp(qmx - qmn + 2.220446049250313e-16) * (mx - mn);
         double p = GPF_INJ(oo.inj_gen_p + i);
-        if (sv.gen_slack[i]) p = (*SreP(bu) - c.Psp[bu]) * sn / ns;
+        if (sv.gen_slack[i]) p = (*SreP(bu) - c.Psp[bu]) * sn * fast_rcp((double)ns);
         gp = (float)p; gq = (float)q;
         gv = (float)(c.vm[bu] * sv.gen_vn[i]);
         gth = (float)(c.va[bu] * RAD2DEG);
@@ -2157,7 +2195,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       // The element -> bus maps stand (reuse): every element adds its new set-point to the bus sums Psp / Qsp / Gs right here
       // (the same LDS atomics K1 would issue from four more loops over the injection row, SolveCtl::sums_done)
       sums_in_k9 = reuse;
-      const double inv_sn9 = 1.0 / g.sn_mva;
+      const double inv_sn9 = g.inv_sn_mva;
       if (sums_in_k9) {
         const int nbus9 = TC ? S.n : g.n_sub * NB;
         for (int i = tid; i < nbus9; i += GW) { c.Psp[i] = 0.0; c.Qsp[i] = 0.0; c.Gs[i] = 0.0; }
