@@ -842,7 +842,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
 #ifdef GPF_NO_NWR                                               /* developer A/B build (tools/build_worktree_variant.sh): general path only */
   constexpr bool NWR = false;
 #else
-  constexpr bool NWR = NB == 1 && IPW > 1 && WPI == 1 && !YR;
+  constexpr bool NWR = NB == 1 && WPI == 1 && !YR;             // every single-wavefront single-busbar kernel
 #endif
   const bool nwr = NWR && !is_dc && nbus <= GW && S.n_up <= GW;
   // FUSED START of a step whose topology stands (reuse, K9 already accumulated the bus sums) on the reference topology of a small
@@ -1177,8 +1177,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       tr_ = ei * aa + fi * bb;
       ti_ = fi * aa - ei * bb;
     };
-    // NEWTON WORKING SET IN REGISTERS (instance-group kernels, round 4).  When every bus and every undirected pair of the instance has
-    // its own lane (nbus <= GW, n_up <= GW: the 5- and 14-substation grids, and every topology class of theirs), what a lane needs in
+    // NEWTON WORKING SET IN REGISTERS (single-wavefront kernels, round 4).  When every bus and every undirected pair of the instance has
+    // its own lane (nbus <= GW, n_up <= GW: the 5-, 14- and 36-substation grids, and the topology classes of theirs that fit), what a lane needs in
     // all iterations of the loop is loaded ONCE per solve: the pair lane's table words, its two Ybus blocks and the bus-type masks of
     // its two ends; the bus lane's type, diagonal Ybus block, specified injections and -- carried from phase to phase instead of
     // going through LDS -- va, |V|, e, f, 1/|V| and S_i.  A pair phase is then ONE LDS round trip (V of the two ends) instead of two
@@ -1190,11 +1190,21 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       const int ib = b_on ? tid : 0;
       const unsigned w0 = p_on ? (unsigned)sv.up[2 * tid] : 0u, w1 = p_on ? (unsigned)sv.up[2 * tid + 1] : 0u;
       const int u = (int)(w0 & 0xffffu), v = (int)(w0 >> 16), suv = (int)(w1 & 0xffffu), svu = (int)(w1 >> 16);
-      const double2 yuv = *reinterpret_cast<const double2*>(c.Yb + (size_t)suv * 2), yvu = *reinterpret_cast<const double2*>(c.Yb + (size_t)svu * 2);
+      // (one instance per wavefront -- the 36-substation kernels, 3 waves per SIMD at <= 168 VGPRs -- has no registers for the Ybus
+      //  blocks and the specified injections: they are re-read from LDS where they are used)
+      constexpr bool KEEP_Y = IPW > 1;
+      const double2* const p_yuv = reinterpret_cast<const double2*>(c.Yb + (size_t)suv * 2);
+      const double2* const p_yvu = reinterpret_cast<const double2*>(c.Yb + (size_t)svu * 2);
+      const double2* const p_yd = reinterpret_cast<const double2*>(c.Yb + (size_t)ib * 2);
+      const double2 yuv0 = *p_yuv, yvu0 = *p_yvu, ydiag0 = *p_yd;
       const int btu = c.btype[u], btv = c.btype[v];
       const int bt = c.btype[ib];
-      const double2 ydiag = *reinterpret_cast<const double2*>(c.Yb + (size_t)ib * 2);
-      const double psp = c.Psp[ib], qsp = c.Qsp[ib];
+      const double psp0 = c.Psp[ib], qsp0 = c.Qsp[ib];
+#define NWR_YUV (KEEP_Y ? yuv0 : *p_yuv)
+#define NWR_YVU (KEEP_Y ? yvu0 : *p_yvu)
+#define NWR_YD (KEEP_Y ? ydiag0 : *p_yd)
+#define NWR_PSP (KEEP_Y ? psp0 : c.Psp[ib])
+#define NWR_QSP (KEEP_Y ? qsp0 : c.Qsp[ib])
       double va, vm;
       if (fast_pre) {
         // initial |V| (K1), DC right-hand side (K3) and theta = inv(B') (P - G) in the bus lane itself; row ib of the column-major
@@ -1224,9 +1234,9 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       } else { va = c.va[ib]; vm = c.vm[ib]; }
       const bool act = p_on && (btu != BT_OFF) && (btv != BT_OFF);
       const bool uP = (btu == BT_PQ || btu == BT_PV), uQ = (btu == BT_PQ), vP = (btv == BT_PQ || btv == BT_PV), vQ = (btv == BT_PQ);
-      const bool acc_u = act && (yuv.x != 0.0 || yuv.y != 0.0), acc_v = act && (yvu.x != 0.0 || yvu.y != 0.0);
+      const bool acc_u = act && (yuv0.x != 0.0 || yuv0.y != 0.0), acc_v = act && (yvu0.x != 0.0 || yvu0.y != 0.0);
       const bool rowP = (bt == BT_PQ || bt == BT_PV), rowQ = (bt == BT_PQ);
-      const bool diag_on = bt != BT_OFF && (ydiag.x != 0.0 || ydiag.y != 0.0);
+      const bool diag_on = bt != BT_OFF && (ydiag0.x != 0.0 || ydiag0.y != 0.0);
       double* const Ad0 = bel(ib, 0, 0);
       double* const Ad1 = bel(ib, 1, 0);
       double* const b_uv0 = bel(suv, 0, 0); double* const b_uv1 = bel(suv, 1, 0);
@@ -1247,6 +1257,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
           const double2 efu = EF(u), efv = EF(v);
           const double ivmu = c.ivm[u], ivmv = c.ivm[v];
           double tr_, ti_, sr_, si_;
+          const double2 yuv = NWR_YUV, yvu = NWR_YVU;
           t_of(yuv, efu.x, efu.y, efv.x, efv.y, tr_, ti_);
           t_of(yvu, efv.x, efv.y, efu.x, efu.y, sr_, si_);
           *reinterpret_cast<double2*>(b_uv0) = make_double2((uP && vP) ? ti_ : 0.0, (uP && vQ) ? tr_ * ivmv : 0.0);
@@ -1263,6 +1274,8 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         bool bad = false;
         if (b_on) {
           Sr = *SreP(ib); Si = *SimP(ib);
+          const double2 ydiag = NWR_YD;
+          const double psp = NWR_PSP, qsp = NWR_QSP;
           double tr_, ti_;
           t_of(ydiag, e, f, e, f, tr_, ti_);
           if (diag_on) { Sr += tr_; Si += ti_; }
@@ -1320,6 +1333,11 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       }
       // what the results phase reads from LDS: the bus injections of the final state, va, |V|
       if (b_on) { *SreP(ib) = Sr; *SimP(ib) = Si; c.va[ib] = va; c.vm[ib] = vm; }
+#undef NWR_YUV
+#undef NWR_YVU
+#undef NWR_YD
+#undef NWR_PSP
+#undef NWR_QSP
     } else {
       // Every phase of the loop is "issue all LDS reads -> compute -> write": the latency of a phase is a chain of dependent
       // LDS round trips, so read-modify-write sequences inside branches are avoided.  V = e + jf, S = 0 and zeroed fill
