@@ -818,6 +818,67 @@ def workload_wcci_dynamics(ctx, env, n_envs, k_sec, w_sec):
     return out
 
 
+def workload_ptdf_rows(ctx, eng, m, B, t0, n_rows=16, reps=20):
+    """configs[4], the DC path at the CONFIGURED batch: the flows of `n_rows` consecutive chronics rows of all B lanes as ONE FP64-MFMA
+    GEMM with M = B x n_rows (gpf_ptdf_flows_rows: the injections are gathered from the device-resident chronics table in the
+    launch's prologue, as the step kernel's K9 does) -- the next `n_rows` DoNothing env steps of the batch in the DC approximation."""
+    lay = eng.layout
+    for _ in range(3):
+        eng.ptdf_flows_rows(t0, n_rows, rebalance=1.02, fetch=False)
+    eng.sync()
+    eng.set_profiling(1)
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        eng.ptdf_flows_rows(t0, n_rows, rebalance=1.02, fetch=False)
+    eng.sync()
+    el = time.perf_counter() - t1
+    k_ms, n_l = eng.kernel_time()
+    eng.set_profiling(0)
+    flows = eng.ptdf_flows_rows(t0, n_rows, rebalance=1.02)
+    r_dc = eng.results(0, 1)
+    chk = None
+    if not ctx.args.no_oracle_check and not ctx.args.stub_engine:
+        try:                       # CHECKER leg: 64 (lane, row) pairs vs the C oracle's DC power flow of the K9 injections of that row
+            from oracle.pf_oracle_c import COracle
+            tab, off, sc = eng.bench_inputs
+            rg = np.random.default_rng(16)
+            ls_, rs_ = rg.choice(B, 64, replace=False), rg.integers(0, n_rows, 64)
+            nl, ng = m.n_load, m.n_gen
+            inj0 = eng.get_injections()
+            rows = []
+            for k, j in zip(ls_, rs_):
+                row = tab[(t0 + j + off[k]) % tab.shape[0]]
+                lp = row[:nl] * sc[k, :nl]
+                pp = row[2 * nl:2 * nl + ng].copy()
+                ns = ~m.gen_slack
+                pp[ns] = pp[ns] * np.float32(1.02 * lp.astype(np.float64).sum() / row[2 * nl:2 * nl + ng][ns].astype(np.float64).sum())
+                x = inj0[k].copy()
+                x[lay.inj_load_p:lay.inj_load_p + nl] = lp
+                x[lay.inj_gen_p:lay.inj_gen_p + ng] = pp
+                rows.append(x)
+            topo_, sb_ = eng.get_topology(0, 1)
+            ref = COracle(m).solve_rows(np.asarray(rows), np.tile(topo_, (64, 1)), np.tile(sb_, (64, 1)) if m.n_shunt else None, is_dc=True)
+            p_ref = ref["out"][:, lay.out_p_or:lay.out_p_or + m.n_line]
+            got = flows[rs_, ls_]
+            chk = {"n": 64, "max_abs_err_vs_oracle": float(np.abs(got - p_ref).max()), "ok": bool(np.all(np.abs(got - p_ref) <= 2e-4 + 5e-6 * np.abs(p_ref))),
+                   "against": "oracle/pf_oracle.c DC power flow of the chronics row's injections, 64 (lane, row) pairs"}
+        except Exception as exc:
+            chk = {"error": repr(exc)[:300]}
+    nb_act = int(np.count_nonzero(~np.isnan(eng.results(0, 1).bus_vm[0])))
+    nb_pad, line_pad = (nb_act + 3) // 4 * 4, (m.n_line + 15) // 16 * 16
+    us = k_ms / max(n_l, 1) * 1e3
+    M = B * n_rows
+    tf = 2.0 * M * nb_pad * line_pad / (us * 1e-6) / 1e12 if us > 0 else 0.0
+    hbm = 4.0 * M * line_pad + 4.0 * M * (m.n_load + m.n_gen)            # flows out + chronics values in (the table itself is L2 resident)
+    return {"workload": f"{n_rows} consecutive chronics rows of all {B} lanes per launch: flows = P_bus[{M}x{nb_pad}] . PTDF^T[{nb_pad}x{line_pad}], "
+                        "injections gathered from the device-resident chronics table in the launch (gpf_ptdf_flows_rows)",
+            "value": M * reps / el, "unit": "DC power flows/sec (one per lane and chronics row)", "us_per_launch": us, "rows_per_launch": n_rows,
+            "roofline": {"bound": "mfma", "achieved": tf, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_PEAK_TFLOPS,
+                         "hbm_gbs": hbm / (us * 1e-6) / 1e9 if us > 0 else 0.0, "traffic": None,
+                         "flops_per_launch": 2.0 * M * nb_pad * line_pad},
+            "oracle_check": chk}
+
+
 def workload_simulate(ctx, env, n_envs, n_act):
     """Batched obs.simulate (gpf_simulate_batch): `n_envs` environments x `n_act` candidate actions (do nothing + single-line
     disconnections) on the 1-step-ahead forecast, ONE call = host topology bookkeeping + device copy + one launch.  Synthetic forecast
@@ -939,7 +1000,11 @@ def workload_ptdf(ctx, env, B, reps, k_sec=64, w_sec=16):
                           "against": "oracle/pf_oracle.c DC power flow of the same injection rows (64 lanes)"}
         except Exception as exc:
             ptdf_check = {"error": repr(exc)[:300]}
-    rows_rec = workload_ptdf_rows(ctx, eng, m, B, t_next) if hasattr(eng, "ptdf_flows_rows") else None
+    rows_rec = None
+    if hasattr(eng, "ptdf_flows_rows"):
+        rows_rec = workload_ptdf_rows(ctx, eng, m, B, t_next, n_rows=ctx.args.steps_per_launch if ctx.args.steps_per_launch > 1 else 16)
+        r64 = workload_ptdf_rows(ctx, eng, m, B, t_next, n_rows=64, reps=10)
+        rows_rec["with_64_rows_per_launch"] = {k: r64[k] for k in ("value", "us_per_launch", "roofline", "oracle_check")}
     eng.lodf_screen(0, 8)
     t0 = time.perf_counter()
     for _ in range(5):

@@ -35,7 +35,7 @@ __all__ = ["HipBackend"]
 
 
 _MODEL_CACHE = {}      # (real path, mtime) -> GridModel: the parsed grid file is immutable, re-loads reuse it (and its engine)
-MAX_BUSBAR_PER_SUB = 3   # include/gridpf.h GPF_MAX_BUSBAR: busbars per substation the compiled HIP kernels cover
+MAX_BUSBAR_PER_SUB = 64  # include/gridpf.h GPF_MAX_BUSBAR (split substations run on the bus-level graph of their topology class)
 
 
 class _LanePool:
@@ -163,9 +163,9 @@ class HipBackend(Backend):
             _MODEL_CACHE[src] = m
         self._m = m
         if self.n_busbar_per_sub > MAX_BUSBAR_PER_SUB:
-            # PandaPowerBackend takes any n_busbar_per_sub (pandaPowerBackend.py:356-372 duplicates the buses n times); the HIP
-            # kernels are compiled for 1..3 busbars per substation (include/gridpf.h GPF_MAX_BUSBAR): refuse at load time,
-            # with the reason, instead of failing at the first power flow
+            # PandaPowerBackend takes any n_busbar_per_sub (pandaPowerBackend.py:562-577 duplicates the buses n times); the engine
+            # takes up to include/gridpf.h GPF_MAX_BUSBAR (a split substation is solved on the bus-level graph of its topology
+            # class, whatever the busbar count): refuse beyond that at load time, with the reason
             raise BackendError(f"HipBackend supports at most {MAX_BUSBAR_PER_SUB} busbars per substation "
                                f"(n_busbar_per_sub={self.n_busbar_per_sub} requested)")
         self._init_from_model(m)

@@ -204,6 +204,8 @@ struct gpf_engine {
   DevArr<int> ptdf_inj_bus;
   DevArr<double> ptdf_inj_w, ptdf_t;
   DevArr<float> ptdf_flow, lodf_worst, lodf_inv_cap;
+  DevArr<float> ptdf_flow_rows;    // [rows][cap_lanes][line_pad] flows of the last gpf_ptdf_flows_rows
+  int ptdf_rows_valid = 0;
   DevArr<double> lodf;             // [n_line][line_pad] line outage distribution factors of the PTDF topology (NaN column: islanding outage)
   std::vector<double> h_ptdf;      // [n_line][nb_tot]
   std::vector<double> h_br_bdc, h_shunt_fact;
@@ -540,7 +542,9 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
     }
     return true;
   };
-  if (e->g.n_sub * mb <= 32000 && e->g.n_busbar <= 3) {
+  // more than 3 busbars per substation: only through topology classes (the NB = n_busbar block kernels exist for 1..3)
+  const bool blocks_ok = e->g.n_busbar <= GPF_MAX_BUSBAR_BLOCKS;
+  if (e->g.n_sub * mb <= 32000) {
 #ifdef GPF_TIMING
     if (e->work.n < (size_t)e->cap_lanes * 32) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->cap_lanes * 32)); }
 #endif
@@ -598,7 +602,7 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
           e->d_classes_count = hc.size();
         }
       } else {
-        ok_b = plan_sparse(e->g.n_busbar, (int)lb.size(), 0, true, qb);
+        ok_b = blocks_ok && plan_sparse(e->g.n_busbar, (int)lb.size(), 0, true, qb);
       }
       const bool ok_a = la.empty() || plan_sparse(1, (int)la.size(), 0, true, qa);
       if (ok_a && ok_b) {
@@ -621,7 +625,10 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
         return GPF_OK;
       }
     }
-    if (plan_sparse(mb == 1 ? 1 : e->g.n_busbar, n, lane0, false, p)) return GPF_OK;
+    if ((mb == 1 || blocks_ok) && plan_sparse(mb == 1 ? 1 : e->g.n_busbar, n, lane0, false, p)) return GPF_OK;
+    if (mb > 1 && !blocks_ok)
+      return fail(GPF_E_CAPACITY, "a lane with a split substation has no topology class (GRIDPF_NO_CLASSES / GRIDPF_NO_PARTITION set, or the class "
+                                  "could not be built) and the grid has more than 3 busbars per substation: the block kernels cover 1..3");
   }
   return fail(GPF_E_CAPACITY, "grid too large: per-instance LDS footprint of the block-sparse kernel exceeds 160 KiB");
 }
@@ -759,7 +766,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   if (d->n_sub <= 0 || d->n_busbar <= 0 || d->n_line < 0 || d->n_gen <= 0) return fail(GPF_E_INVALID, "gpf_create: bad sizes");
   if (d->n_line > 256) return fail(GPF_E_CAPACITY, "gpf_create: n_line > 256 not supported by the step kernel");
   if (d->n_busbar > GPF_MAX_BUSBAR)
-    return fail(GPF_E_CAPACITY, "gpf_create: n_busbar > 3 is not supported (the compiled kernels cover 1..3 busbars per substation)");
+    return fail(GPF_E_CAPACITY, "gpf_create: more than 64 busbars per substation (GPF_MAX_BUSBAR)");
   int ndev = 0;
   hipError_t e0 = hipGetDeviceCount(&ndev);
   if (e0 != hipSuccess || ndev == 0)
@@ -1078,7 +1085,7 @@ int gpf_destroy(gpf_handle e) {
   for (auto* c : e->classes) { c->tables.release(); c->flat.release(); delete c; }
   e->classes.clear();
   e->ptdf_inj_bus.release(); e->ptdf_inj_w.release(); e->ptdf_t.release(); e->ptdf_flow.release();
-  e->lodf.release(); e->lodf_worst.release(); e->lodf_inv_cap.release();
+  e->lodf.release(); e->lodf_worst.release(); e->lodf_inv_cap.release(); e->ptdf_flow_rows.release();
   e->stat_int.release();
   e->flat_prog.release();
   delete e;
@@ -2096,7 +2103,8 @@ int gpf_ptdf_build(gpf_handle e, int32_t lane) {
   int n_act = 0;
   for (int b = 0; b < nbt; ++b) if (act[b]) compact[b] = n_act++;
   const int nb_pad = std::max(4, (n_act + 3) & ~3), line_pad = (g.n_line + 15) & ~15;
-  std::vector<double> pt((size_t)nb_pad * line_pad, 0.0);
+  const int kpad = (nb_pad + 31) & ~31;                      // (rows behind nb_pad stay zero: gpf_ptdf_flows_rows runs whole trips of 8 k-steps)
+  std::vector<double> pt((size_t)kpad * line_pad, 0.0);
   for (int l = 0; l < g.n_line; ++l) {
     if (lf[l] < 0 || lf[l] == lt[l]) continue;
     for (int b = 0; b < nbt; ++b) {
@@ -2157,6 +2165,63 @@ int gpf_ptdf_flows(gpf_handle e, int32_t lane0, int32_t n) {
                      e->ptdf_flow.p);
   HIP_TRY(hipGetLastError());
   if (e->window) ++e->win_launches;
+  return GPF_OK;
+}
+
+int gpf_ptdf_flows_rows(gpf_handle e, int32_t t0, int32_t n_rows, double rebalance) {
+  if (!e || n_rows <= 0) return fail(GPF_E_INVALID, "gpf_ptdf_flows_rows: bad arguments");
+  if (!e->ptdf_ready) return fail(GPF_E_INVALID, "gpf_ptdf_flows_rows: call gpf_ptdf_build first");
+  if (!e->chron.p || e->chron_T <= 0) return fail(GPF_E_INVALID, "gpf_ptdf_flows_rows: no chronics uploaded");
+  HIP_TRY(hipSetDevice(e->device));
+  const size_t need = (size_t)n_rows * e->cap_lanes * e->ptdf_line_pad;
+  if (e->ptdf_flow_rows.n < need) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->ptdf_flow_rows.release();
+    HIP_TRY(e->ptdf_flow_rows.alloc(need));
+  }
+  gpf::PtdfDev P{};
+  P.n_inj = e->g.n_inj; P.nb_pad = e->ptdf_nb_pad; P.line_pad = e->ptdf_line_pad; P.n_line = e->g.n_line;
+  P.inj_bus = e->ptdf_inj_bus.p; P.inj_w = e->ptdf_inj_w.p; P.ptdf_t = e->ptdf_t.p;
+  gpf::PtdfRowsDev R{};
+  R.chron = e->chron.p; R.lane_table = e->lane_table.p; R.lane_offset = e->lane_offset.p;
+  R.lane_scale = e->has_scale ? e->lane_scale.p : nullptr; R.lane_gen_delta = e->has_delta ? e->lane_gen_delta.p : nullptr;
+  R.gen_slack = e->gen_slack.p; R.T = e->chron_T; R.n_chron = e->g.n_chron; R.n_load = e->g.n_load; R.n_gen = e->g.n_gen;
+  R.inj_gen_p = e->oo.inj_gen_p; R.inj_load_p = e->oo.inj_load_p; R.inj_sto_p = e->oo.inj_sto_p; R.n_inj_tail = e->g.n_inj - e->oo.inj_sto_p;
+  R.rebalance = rebalance;
+  R.kpad = (P.nb_pad + 31) & ~31;
+  static const int mt_env = std::getenv("GRIDPF_PTDF_MT") ? std::atoi(std::getenv("GRIDPF_PTDF_MT")) : 0;      // developer override (1 | 2 | 4)
+  const int mt = (mt_env == 1 || mt_env == 2 || mt_env == 4) ? mt_env : 2;
+  const int NP = 16 * mt;
+  const size_t lds_a = (size_t)NP * gpf::ptdf_rows_stride(R.kpad) * sizeof(double);
+  const long long n_pairs = (long long)e->n_lanes * n_rows;
+  const dim3 grid((unsigned)((n_pairs + NP - 1) / NP));
+  static size_t lds_set[64][3] = {{0}};
+#define GPF_PTDF_ROWS(MT_, SLOT_)                                                                                                      \
+  do {                                                                                                                                 \
+    if (lds_a > lds_set[e->device & 63][SLOT_]) {                                                                                      \
+      HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::ptdf_rows_kernel<MT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a)); \
+      lds_set[e->device & 63][SLOT_] = lds_a;                                                                                          \
+    }                                                                                                                                  \
+    hipLaunchKernelGGL(gpf::ptdf_rows_kernel<MT_>, grid, dim3(256), lds_a, e->stream, P, R, e->inj.p, e->n_lanes, (long long)e->cap_lanes, t0, \
+                       n_rows, e->ptdf_flow_rows.p);                                                                                   \
+  } while (0)
+  if (mt == 4) GPF_PTDF_ROWS(4, 2); else if (mt == 2) GPF_PTDF_ROWS(2, 1); else GPF_PTDF_ROWS(1, 0);
+#undef GPF_PTDF_ROWS
+  HIP_TRY(hipGetLastError());
+  e->ptdf_rows_valid = n_rows;
+  if (e->window) ++e->win_launches;
+  return GPF_OK;
+}
+
+int gpf_get_ptdf_flows_rows(gpf_handle e, int32_t row0, int32_t n_rows, int32_t lane0, int32_t n, float* p_or) {
+  if (!check_range(e, lane0, n) || !p_or || row0 < 0 || n_rows < 0 || row0 + n_rows > e->ptdf_rows_valid)
+    return fail(GPF_E_INVALID, "gpf_get_ptdf_flows_rows: bad range (only the rows of the last gpf_ptdf_flows_rows are retrievable)");
+  HIP_TRY(hipSetDevice(e->device));
+  for (int r = 0; r < n_rows; ++r)
+    HIP_TRY(hipMemcpy2DAsync(p_or + (size_t)r * n * e->g.n_line, (size_t)e->g.n_line * sizeof(float),
+                             e->ptdf_flow_rows.p + ((size_t)(row0 + r) * e->cap_lanes + lane0) * e->ptdf_line_pad,
+                             (size_t)e->ptdf_line_pad * sizeof(float), (size_t)e->g.n_line * sizeof(float), (size_t)n, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
   return GPF_OK;
 }
 

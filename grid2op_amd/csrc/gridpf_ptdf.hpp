@@ -74,6 +74,166 @@ __global__ __launch_bounds__(256) void ptdf_flows_kernel(PtdfDev P, const double
   }
 }
 
+// K_PR: the same GEMM over M = lanes x chronics rows.  A batch of 2 048 lanes x ONE row is 94 MFLOP -- a few microseconds, launch /
+// latency bound (13.6 % of the FP64-MFMA peak in round 3); the flows of T consecutive chronics rows for the same topology are ONE GEMM
+// with M = lanes x T.  Pair p = row * n_lanes + lane; a block owns PTDF_MT * 16 pairs and ALL line tiles (wavefront w: tiles w, w + 4,
+// ...): its prologue gathers the injections of its pairs straight from the device-resident chronics table as K9 of the step kernel
+// does -- lane k reads row (t0 + row + lane_offset[k]) mod T of table lane_table[k], loads x lane_scale, non-slack prod_p rescaled to
+// rebalance x sum(load) (float32, Environment/baseEnv.py:2516-2563 feeds these vectors), + the lane's redispatch delta; storage and
+// shunt set-points from the lane's injection row -- and builds P_bus[pairs][bus] in LDS (f64 atomics); every B operand fetched from
+// L2 then feeds PTDF_MT MFMAs (4 x the arithmetic per PTDF^T byte of K_PG) and the chronics gather is done once per pair.
+struct PtdfRowsDev {
+  const float* chron;          // [n_tab][T][n_chron]: load_p | load_q | prod_p | prod_v
+  const int* lane_table;       // [lanes]
+  const int* lane_offset;      // [lanes]
+  const float* lane_scale;     // [lanes][2 n_load] or nullptr
+  const float* lane_gen_delta; // [lanes][n_gen] or nullptr
+  const unsigned char* gen_slack;
+  int T, n_chron, n_load, n_gen, inj_gen_p, inj_load_p, inj_sto_p, n_inj_tail;   // n_inj_tail: injection columns from inj_sto_p on (storage / shunt set-points)
+  int kpad;                    // rows of ptdf_t rounded up to a multiple of 32 (zero rows behind nb_pad): whole trips of 8 k-steps
+  double rebalance;            // <= 0: prod_p as in the table
+};
+__host__ __device__ inline int ptdf_rows_stride(int kpad) { return kpad | 1; }
+constexpr int PTDF_EPT = 8;    // chronics values a gather thread keeps in registers per kind (loads, generators)
+template <int MT>
+__global__ __launch_bounds__(256) void ptdf_rows_kernel(PtdfDev P, PtdfRowsDev R, const double* __restrict__ inj, int n_lanes, long long lane_stride,
+                                                        int t0, int n_rows, float* __restrict__ flow) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NP = 16 * MT;                               // pairs per block
+  constexpr int TPP = 256 / NP;                             // threads per pair in the gather (4 / 8 / 16)
+  double* A = reinterpret_cast<double*>(smem);              // [NP][stride]
+  const int stride = ptdf_rows_stride(R.kpad);
+  const long long n_pairs = (long long)n_lanes * n_rows;
+  const long long p0 = (long long)blockIdx.x * NP;
+  for (int i = threadIdx.x; i < NP * stride; i += 256) A[i] = 0.0;
+  // ---- gather: TPP threads per pair, 4 elements in flight per thread -------------------------------------------------------------
+  // (chronics row, lane) of the block's pairs: ONE 64-bit division per block (uniform), 32-bit arithmetic per pair, kept in LDS for
+  // the epilogue (a 64-bit division per stored element cost more than the whole GEMM)
+  __shared__ int p_row[NP], p_lane[NP];
+  {
+    const long long row0 = p0 / n_lanes;
+    const unsigned ln0 = (unsigned)(p0 - row0 * n_lanes);
+    if (threadIdx.x < NP) {
+      const unsigned x = ln0 + threadIdx.x, dr = x / (unsigned)n_lanes;
+      const bool ok = p0 + threadIdx.x < n_pairs;
+      p_row[threadIdx.x] = ok ? (int)(row0 + dr) : -1;
+      p_lane[threadIdx.x] = (int)(x - dr * (unsigned)n_lanes);
+    }
+  }
+  __syncthreads();
+  const int r = threadIdx.x / TPP, q = threadIdx.x % TPP;
+  const bool on = p_row[r] >= 0;
+  const int row = on ? p_row[r] : 0, lane = on ? p_lane[r] : 0;
+  int crow = (t0 + row + (R.lane_offset ? R.lane_offset[lane] : 0)) % R.T;
+  if (crow < 0) crow += R.T;
+  const float* ch = R.chron + ((size_t)(R.lane_table ? R.lane_table[lane] : 0) * R.T + crow) * R.n_chron;
+  const float* sc = R.lane_scale ? R.lane_scale + (size_t)lane * 2 * R.n_load : nullptr;
+  // ONE pass over the chronics row: every thread keeps its (at most PTDF_EPT) load and generator values in registers -- all the
+  // global loads of the gather are in flight together --, the TPP threads of a pair reduce the two sums of the rebalancing rule,
+  // then the values go to P_bus with LDS atomics.  (Rows with more than PTDF_EPT * TPP loads or generators: the tail is re-read.)
+  constexpr int EPT = PTDF_EPT;
+  float lv[EPT], gv[EPT];
+  int lb[EPT], gb[EPT];
+#pragma unroll
+  for (int u = 0; u < EPT; ++u) {
+    const int i = q + u * TPP;
+    const bool okl = on && i < R.n_load, okg = on && i < R.n_gen;
+    lv[u] = okl ? ch[i] * (sc ? sc[i] : 1.f) : 0.f;
+    lb[u] = okl ? P.inj_bus[R.inj_load_p + i] : -1;
+    gv[u] = okg ? ch[2 * R.n_load + i] : 0.f;
+    gb[u] = okg ? P.inj_bus[R.inj_gen_p + i] : -2;          // -1: slack generator or not connected, -2: no such generator
+  }
+  double s_load = 0.0, s_prod = 0.0;
+  if (R.rebalance > 0.0) {
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) { s_load += (double)lv[u]; if (q + u * TPP < R.n_gen && !R.gen_slack[q + u * TPP]) s_prod += (double)gv[u]; }
+    for (int i = q + EPT * TPP; i < R.n_load; i += TPP) s_load += (double)(ch[i] * (sc ? sc[i] : 1.f));
+    for (int i = q + EPT * TPP; i < R.n_gen; i += TPP) if (!R.gen_slack[i]) s_prod += (double)ch[2 * R.n_load + i];
+#pragma unroll
+    for (int o = 1; o < TPP; o <<= 1) { s_load += __shfl_xor(s_load, o); s_prod += __shfl_xor(s_prod, o); }
+  }
+  const float sp = (R.rebalance > 0.0 && s_prod > 0.0) ? (float)(R.rebalance * s_load / s_prod) : 1.0f;
+  __syncthreads();                                          // A is zero
+  if (on) {
+    double* Ar = A + (size_t)r * stride;
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+      const int i = q + u * TPP;
+      if (lb[u] >= 0) atomicAdd(&Ar[lb[u]], (double)lv[u] * P.inj_w[R.inj_load_p + i]);
+      if (gb[u] >= 0) {
+        float pp = gv[u] * sp;
+        if (R.lane_gen_delta) pp += R.lane_gen_delta[(size_t)lane * R.n_gen + i];
+        atomicAdd(&Ar[gb[u]], (double)pp * P.inj_w[R.inj_gen_p + i]);
+      }
+    }
+    for (int i = q + EPT * TPP; i < R.n_load; i += TPP) {
+      const int b = P.inj_bus[R.inj_load_p + i];
+      if (b >= 0) atomicAdd(&Ar[b], (double)(ch[i] * (sc ? sc[i] : 1.f)) * P.inj_w[R.inj_load_p + i]);
+    }
+    for (int i = q + EPT * TPP; i < R.n_gen; i += TPP) {
+      const int b = P.inj_bus[R.inj_gen_p + i];
+      if (b < 0) continue;
+      float pp = ch[2 * R.n_load + i] * sp;
+      if (R.lane_gen_delta) pp += R.lane_gen_delta[(size_t)lane * R.n_gen + i];
+      atomicAdd(&Ar[b], (double)pp * P.inj_w[R.inj_gen_p + i]);
+    }
+    const double* irow = inj + (size_t)lane * P.n_inj;
+    for (int i = R.inj_sto_p + q; i < R.inj_sto_p + R.n_inj_tail; i += TPP) {
+      const int b = P.inj_bus[i];
+      if (b >= 0) atomicAdd(&Ar[b], irow[i] * P.inj_w[i]);
+    }
+  }
+  __syncthreads();
+  // ---- GEMM: wavefront w owns the line tiles w, w + 4, ...; MT row tiles share every B operand; the operands of trip s + 1 are
+  //      fetched (L2 / LDS) before the 4 MT MFMAs of trip s issue --------------------------------------------------------------------
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int KT = 8;                                     // k-steps per trip
+  const int trips = R.kpad / (4 * KT);
+  const int n_tiles = P.line_pad / 16;
+  const double* arow = A + (size_t)(l & 15) * stride + (l >> 4);
+  for (int t = w; t < n_tiles; t += 4) {
+    v4d c[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) c[m] = v4d{0.0, 0.0, 0.0, 0.0};
+    const double* bcol = P.ptdf_t + (size_t)(l >> 4) * P.line_pad + t * 16 + (l & 15);
+    double a[MT][KT], b[KT];
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+      b[u] = bcol[(size_t)4 * u * P.line_pad];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m][u] = arow[(size_t)16 * m * stride + 4 * u];
+    }
+    for (int s = 0; s < trips; ++s) {
+      double an[MT][KT], bn[KT];
+      const int sn = s + 1 < trips ? s + 1 : s;             // (the last trip re-fetches its own operands: no branch in the loop)
+#pragma unroll
+      for (int u = 0; u < KT; ++u) {
+        bn[u] = bcol[(size_t)4 * (KT * sn + u) * P.line_pad];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) an[m][u] = arow[(size_t)16 * m * stride + 4 * (KT * sn + u)];
+      }
+#pragma unroll
+      for (int u = 0; u < KT; ++u)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) c[m] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m][u], b[u], c[m], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < KT; ++u) {
+        b[u] = bn[u];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a[m][u] = an[m][u];
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int pi = 16 * m + 4 * v + (l >> 4);
+        const int rw = p_row[pi], ln = p_lane[pi];
+        if (rw >= 0) flow[((size_t)rw * lane_stride + ln) * P.line_pad + t * 16 + (l & 15)] = (float)c[m][v];
+      }
+  }
+}
+
 // K_L: DC N-1 screening.  Post-outage flows are f_l + LODF[l][k] * f_k (rank-1 update of the pre-outage flows), so for
 // every lane and every single-line outage k the worst loading max_l |f_l + LODF[l][k] f_k| * inv_cap[l] needs no solve.
 // A block of 4 wavefronts serves LODF_LPW lanes; a thread owns the outages k = tid, tid + 64, ... and each wavefront walks a

@@ -670,6 +670,19 @@ class PowerFlowEngine:
         check(self._lib.gpf_get_ptdf_flows(self._h, lane0, n, ptr(out, C.c_float)), "gpf_get_ptdf_flows")
         return out
 
+    def ptdf_flows_rows(self, t0: int, n_rows: int, rebalance: float = 0.0, fetch: bool = True, lane0: int = 0, n: Optional[int] = None):
+        """DC active-power flows of ``n_rows`` consecutive chronics rows of EVERY lane in ONE launch (the GEMM has
+        ``n_lanes * n_rows`` rows): row ``j`` of lane ``k`` is chronics row ``(t0 + j + lane_offset[k]) mod T`` turned into injections
+        as `step` does.  Returns float32 ``[n_rows, n, n_line]`` (MW at the origin side) of lanes ``[lane0, lane0 + n)``, or None with
+        ``fetch=False`` (asynchronous)."""
+        check(self._lib.gpf_ptdf_flows_rows(self._h, int(t0), int(n_rows), float(rebalance)), "gpf_ptdf_flows_rows")
+        if not fetch:
+            return None
+        lane0, n = self._range(lane0, n)
+        out = np.empty((n_rows, n, self.model.n_line), dtype=np.float32)
+        check(self._lib.gpf_get_ptdf_flows_rows(self._h, 0, int(n_rows), lane0, n, ptr(out, C.c_float)), "gpf_get_ptdf_flows_rows")
+        return out
+
     def lodf_screen(self, lane0: int = 0, n: Optional[int] = None, cap_mw: Optional[np.ndarray] = None) -> np.ndarray:
         """DC N-1 screening from the flows of the last ``ptdf_flows``: [n, n_line] largest post-outage loading
         max_l |f_l + LODF[l, k] f_k| / cap_mw[l] for every single-line outage k (MW if ``cap_mw`` is None; inf: the

@@ -40,7 +40,12 @@ extern "C" {
 #define GPF_ST_CAPACITY 5    /* more active buses than the handle was sized for           */
 #define GPF_ST_NOTRUN (-1)
 
-#define GPF_MAX_BUSBAR 3     /* busbars per substation the compiled kernels cover (gpf_create refuses more: GPF_E_CAPACITY) */
+#define GPF_MAX_BUSBAR 64          /* busbars per substation a grid may have (the reference takes any n_busbar_per_sub,
+                                      pandaPowerBackend.py:562-577; grid2op/tests/test_issue_l2g_128.py:218 uses 6)                  */
+#define GPF_MAX_BUSBAR_BLOCKS 3    /* ... of which the NB = n_busbar block kernels cover 1..3.  Lanes with split substations normally
+                                      run the single-busbar kernel on the bus-level graph of their topology class (any busbar count);
+                                      only the developer fallback GRIDPF_NO_CLASSES=1 / a class that cannot be built needs the block
+                                      kernels and is refused beyond 3 busbars (GPF_E_CAPACITY, at launch planning)                   */
 
 typedef struct gpf_engine* gpf_handle;
 
@@ -348,6 +353,14 @@ int gpf_ptdf_build(gpf_handle h, int32_t lane);
 int gpf_ptdf_get(gpf_handle h, double* ptdf /* [n_line][n_sub*n_busbar] row-major, MW per MW */);
 int gpf_ptdf_flows(gpf_handle h, int32_t lane0, int32_t n);
 int gpf_get_ptdf_flows(gpf_handle h, int32_t lane0, int32_t n, float* p_or);
+/* The same over n_rows CONSECUTIVE CHRONICS ROWS of every lane in ONE launch (M = n_lanes x n_rows rows of the GEMM): row j of lane k
+ * is chronics row (t0 + j + lane_offset[k]) mod T of table lane_table[k] turned into injections exactly as gpf_step does (loads x
+ * lane_scale, non-slack prod_p rescaled to rebalance x sum(load) when rebalance > 0, + the lane's redispatch delta; storage and shunt
+ * set-points from the lane's injection row), i.e. the DC flows of the next n_rows DoNothing env steps of the whole batch for the
+ * fixed topology of gpf_ptdf_build -- what rundcpp would return at each of them (pandaPowerBackend.py:1090).  Asynchronous;
+ * gpf_get_ptdf_flows_rows copies rows [row0, row0 + n_rows) of lanes [lane0, lane0 + n): float32 [n_rows][n][n_line] MW at the origin. */
+int gpf_ptdf_flows_rows(gpf_handle h, int32_t t0, int32_t n_rows, double rebalance);
+int gpf_get_ptdf_flows_rows(gpf_handle h, int32_t row0, int32_t n_rows, int32_t lane0, int32_t n, float* p_or);
 /* DC N-1 screening on top of the PTDF path (what N1Reward / obs.simulate loops do one contingency at a time,
  * grid2op/Reward/n1Reward.py:70-99): post-outage flows are f_l + LODF[l][k] * f_k, so for every lane of the range and
  * every single-line outage k this returns the largest post-outage loading max_l |f_l + LODF[l][k] f_k| / cap_mw[l]

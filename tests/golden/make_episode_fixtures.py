@@ -238,9 +238,10 @@ def ep_topology(env_name, n_steps):
     return tr
 
 
-def ep_three_busbars(env_name, n_steps):
-    """``grid2op.make(..., n_busbar=3)`` (Backend.can_handle_more_than_2_busbar, backend.py:212-260): substations split three ways"""
-    env, tr = _make(env_name, n_busbar=3, param=_params(NB_TIMESTEP_COOLDOWN_LINE=0, NB_TIMESTEP_COOLDOWN_SUB=0, MAX_SUB_CHANGED=2,
+def ep_three_busbars(env_name, n_steps, n_busbar=3):
+    """``grid2op.make(..., n_busbar=3)`` (Backend.can_handle_more_than_2_busbar, backend.py:212-260): substations split three ways;
+    ``n_busbar=6``: what grid2op/tests/test_issue_l2g_128.py:218 asks of a backend"""
+    env, tr = _make(env_name, n_busbar=n_busbar, param=_params(NB_TIMESTEP_COOLDOWN_LINE=0, NB_TIMESTEP_COOLDOWN_SUB=0, MAX_SUB_CHANGED=2,
                                                         NO_OVERFLOW_DISCONNECTION=True))
     env.seed(6)
     env.reset()
@@ -253,7 +254,7 @@ def ep_three_busbars(env_name, n_steps):
         if t % 3 == 2:
             tgt = np.ones(n_el, dtype=int)
         else:
-            tgt = 1 + (np.arange(n_el) + int(rng.integers(0, 3))) % 3
+            tgt = 1 + (np.arange(n_el) + int(rng.integers(0, n_busbar))) % n_busbar
         act = sp({"set_bus": {"substations_id": [(s, tgt.astype(int))]}})
         _, done, _ = _step(env, tr, act, simulate=act)
         if done:
@@ -347,6 +348,7 @@ EPISODES = {
     "case14_dc": ("l2rpn_case14_sandbox", lambda: ep_dc("l2rpn_case14_sandbox", 6)),
     "case14_runner": ("l2rpn_case14_sandbox", lambda: ep_runner("l2rpn_case14_sandbox", 5)),
     "case14_three_busbars": ("l2rpn_case14_sandbox", lambda: ep_three_busbars("l2rpn_case14_sandbox", 12)),
+    "case14_six_busbars": ("l2rpn_case14_sandbox", lambda: ep_three_busbars("l2rpn_case14_sandbox", 12, n_busbar=6)),
     "storage14_actions": ("educ_case14_storage", lambda: ep_storage("educ_case14_storage", 12)),
     "neurips36_topology": ("l2rpn_neurips_2020_track1", lambda: ep_topology("l2rpn_neurips_2020_track1", 16)),
     "neurips36_cascade": ("l2rpn_neurips_2020_track1", lambda: ep_cascade("l2rpn_neurips_2020_track1", 8)),
@@ -362,7 +364,7 @@ def main():
         if only and name not in only:
             continue
         tr = fn()
-        d = tr.save(os.path.join(out_dir, f"{name}.npz"), {"grid": grid, "n_busbar": 3 if "three_busbars" in name else 2})
+        d = tr.save(os.path.join(out_dir, f"{name}.npz"), {"grid": grid, "n_busbar": 3 if "three_busbars" in name else 6 if "six_busbars" in name else 2})
         n_div = int((~d["pf_ok"]).sum())
         print(f"{name}: {len(tr.ev)} events, {tr.n_bid} backend instances, {len(tr.pfs)} power flows ({n_div} diverged), "
               f"{len(tr.obs)} observations, {os.path.getsize(os.path.join(out_dir, name + '.npz')) / 1024:.0f} KiB")

@@ -10,7 +10,7 @@ import stub (tests/_refshim) and drives the REAL ``grid2op.make(..., backend=Hip
 ``obs.simulate`` (Observation/baseObservation.py:3365-3670) / ``N1Reward`` (Reward/n1Reward.py:70-99) / ``Runner``
 (Runner/runner.py:739-756) with the HIP engine underneath:
 
-  episodes  the 11 episodes of tests/golden/make_episode_fixtures.py re-run on HipBackend; every call the framework makes on
+  episodes  the 12 episodes of tests/golden/make_episode_fixtures.py re-run on HipBackend; every call the framework makes on
             every backend instance, every power-flow result and every observation must equal the committed recordings
             (tests/golden/episodes/*.npz; integers bit-exact, floats 2e-4 + 5e-6 |x|)
   aaa       the reference's own backend API kit, AAATestBackendAPI (grid2op/tests/aaa_test_backend_interface.py, 41 tests)

@@ -65,13 +65,25 @@ def test_layout_struct_matches_header():
     assert dnames == [f[0] for f in GpfGridDesc._fields_]
 
 
-def test_more_than_three_busbars_is_refused_with_the_reason(load_model):
-    """gpf_create validates n_busbar before it touches the device: the compiled kernels cover 1..3 busbars per substation
-    (the reference takes any n_busbar_per_sub); the refusal names the limit instead of a misleading LDS-capacity error later."""
+def test_busbar_limit_is_declared_and_validated_before_the_device_is_touched(load_model):
+    """The reference takes any n_busbar_per_sub (pandaPowerBackend.py:562-577; grid2op/tests/test_issue_l2g_128.py:218 uses 6).  The
+    engine takes up to GPF_MAX_BUSBAR busbars -- split substations run on the bus-level graph of their topology class, only the
+    block-kernel fallback is limited to 3 -- and validates the count before it touches the device (no GPU here: a larger count must
+    be refused with THAT reason, a legal one must get as far as the missing device)."""
     from grid2op_amd.engine import PowerFlowEngine, GridPFError
     m = load_model("rte_case5_example")
-    with pytest.raises(GridPFError, match="n_busbar > 3"):
-        PowerFlowEngine(m, n_lanes=2, n_busbar=4)
+    hdr = open(os.path.join(ROOT, "include", "gridpf.h")).read()
+    assert "#define GPF_MAX_BUSBAR 64" in hdr and "#define GPF_MAX_BUSBAR_BLOCKS 3" in hdr
+    with pytest.raises(GridPFError, match="more than 64 busbars"):
+        PowerFlowEngine(m, n_lanes=2, n_busbar=65)
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except ImportError:
+        has_gpu = False
+    if not has_gpu:
+        with pytest.raises(GridPFError, match="no HIP device"):
+            PowerFlowEngine(m, n_lanes=2, n_busbar=6)
 
 
 def test_bench_uses_the_oracle_only_as_checker_or_cpu_baseline():
@@ -79,7 +91,7 @@ def test_bench_uses_the_oracle_only_as_checker_or_cpu_baseline():
     else (the measured path must be the HIP engine)."""
     import ast
     tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
-    allowed = {"cpu_baseline", "oracle_spot_check", "workload_ptdf"}
+    allowed = {"cpu_baseline", "oracle_spot_check", "workload_ptdf", "workload_ptdf_rows"}       # (the two PTDF records: checker legs after the timed loops)
     found = set()
     for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
         for n in ast.walk(fn):

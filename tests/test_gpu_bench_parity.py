@@ -183,6 +183,33 @@ def test_idf_2023_ac_env_steps_and_ptdf_on_the_same_chronics_rows_vs_oracle(load
     p_ref = ref["out"][:, lay.out_p_or:lay.out_p_or + m.n_line]
     err = np.abs(flows[lanes] - p_ref)
     assert np.all(err <= 2e-4 + 5e-6 * np.abs(p_ref)), float(err.max())
+    # ... and 16 consecutive chronics rows of every lane as ONE GEMM (gpf_ptdf_flows_rows gathers the injections from the chronics table
+    # itself): row n - 1 of the launch that starts at t0 is the row the lanes hold -> the two device paths agree; 64 (lane, row) pairs
+    # against the oracle's DC power flow of the K9 injections of that row
+    rows = eng.ptdf_flows_rows(t0, n, rebalance=1.02)
+    assert rows.shape == (n, B, m.n_line)
+    assert np.abs(rows[n - 1] - flows).max() < 2e-4
+    rg = np.random.default_rng(29)
+    ls_, rs_ = rg.choice(B, 64, replace=False), rg.integers(0, n, 64)
+    ng = m.n_gen
+    xs = []
+    for k, j in zip(ls_, rs_):
+        row = tab[(t0 + j + off[k]) % tab.shape[0]]
+        lp = row[:nl] * sc[k, :nl]
+        pp = row[2 * nl:2 * nl + ng].copy()
+        ns = ~m.gen_slack
+        pp[ns] = pp[ns] * np.float32(1.02 * lp.astype(np.float64).sum() / row[2 * nl:2 * nl + ng][ns].astype(np.float64).sum())
+        x = inj[k].copy()
+        x[lay.inj_load_p:lay.inj_load_p + nl] = lp
+        x[lay.inj_gen_p:lay.inj_gen_p + ng] = pp
+        xs.append(x)
+    ref = COracle(m).solve_rows(np.asarray(xs), np.tile(topo, (64, 1)), np.tile(sb, (64, 1)) if m.n_shunt else None, is_dc=True)
+    p_ref = ref["out"][:, lay.out_p_or:lay.out_p_or + m.n_line]
+    err = np.abs(rows[rs_, ls_] - p_ref)
+    assert np.all(err <= 2e-4 + 5e-6 * np.abs(p_ref)), float(err.max())
+    # a ragged tail (a lane count that is not a multiple of the 64-pair blocks) and a single row
+    one = eng.ptdf_flows_rows(t0 + n - 1, 1, rebalance=1.02, lane0=3, n=101)
+    assert np.abs(one[0] - flows[3:104]).max() < 2e-4
     eng.close()
 
 

@@ -236,6 +236,69 @@ def test_three_busbars(load_model):
     eng.close()
 
 
+@pytest.mark.parametrize("name,nbb,B", [("l2rpn_case14_sandbox", 6, 24), ("l2rpn_neurips_2020_track1", 4, 6), ("l2rpn_wcci_2022_dev", 5, 4)])
+def test_more_than_three_busbars_through_topology_classes(name, nbb, B, load_model):
+    """n_busbar_per_sub = 4 .. 6 (grid2op/tests/test_issue_l2g_128.py:218 runs l2rpn_case14_sandbox with 6; PandaPowerBackend duplicates
+    the buses n times, pandaPowerBackend.py:562-577).  The compiled block kernels cover 1..3 busbars; beyond that every lane with a
+    split substation runs the single-busbar kernel on the bus-level graph of its topology class.  Random multi-way splits (elements
+    of up to three substations spread over up to `nbb` busbars, a line outage) vs the oracle with the same busbar count: bus
+    voltages on the global bus ids sub + (busbar - 1) n_sub (GridObjects.py:4683-4745), topo_vect bit-exact."""
+    m = load_model(name)
+    eng = _engine(m, B, n_busbar=nbb)
+    rng = np.random.default_rng(nbb * 100 + B)
+    cum = np.concatenate(([0], np.cumsum(m.sub_info)))
+    big = [s_ for s_ in range(m.n_sub) if m.sub_info[s_] >= 4]
+    states = []
+    for k in range(B):
+        s = LaneState.from_model(m)
+        if k > 0:
+            for sub in rng.choice(big, size=min(len(big), 1 + k % 2), replace=False):
+                pos = np.arange(cum[sub], cum[sub + 1])
+                if k % 5 == 4:                                  # a fully random assignment over all busbars (mostly islanding)
+                    s.topo[pos] = 1 + rng.integers(0, nbb, pos.size)
+                else:                                           # elements alternating between 2 (or 3) busbars picked among 1 .. nbb
+                    used = rng.choice(np.arange(1, nbb + 1), size=2 + (k % 3 == 2), replace=False)
+                    s.topo[pos] = used[(np.arange(pos.size) + int(rng.integers(0, 3))) % used.size]
+            if k % 4 == 1:
+                l = int(rng.integers(0, m.n_line))
+                s.topo[m.line_or_pos_topo_vect[l]] = s.topo[m.line_ex_pos_topo_vect[l]] = -1
+        states.append(s)
+    states[min(2, B - 1)].topo[m.gen_pos_topo_vect[0]] = nbb               # a generator alone on the LAST busbar
+    inj, topo, sb = _pack(eng, states)
+    eng.set_injections(inj)
+    eng.set_topology(topo, sb)
+    assert eng.plan()["topology_classes"] == 1 and eng.plan()["busbars_per_block"] == 1
+    eng.runpf()
+    r = eng.results()
+    n_conv = 0
+    for k, s in enumerate(states):
+        o = solve(m, s, n_busbar=nbb)
+        _compare(m, r, k, o)
+        n_conv += int(o.converged)
+    assert n_conv >= max(2, B // 4), n_conv                               # (splits island part of the lanes: same verdict on both sides)
+    assert (r.topo_vect.max(axis=1) > 3).any()
+    # DC mode on the same topologies
+    eng.runpf(is_dc=True)
+    r = eng.results()
+    for k in (0, 1, B - 1):
+        _compare(m, r, k, solve(m, states[k], n_busbar=nbb, is_dc=True))
+    eng.close()
+    # the block-kernel fallback cannot serve a split lane beyond 3 busbars: refused with the reason
+    import os
+    from grid2op_amd.engine import PowerFlowEngine, GridPFError
+    os.environ["GRIDPF_NO_CLASSES"] = "1"
+    try:
+        e2 = PowerFlowEngine(m, n_lanes=2, device=0, n_busbar=nbb)
+    finally:
+        os.environ.pop("GRIDPF_NO_CLASSES", None)
+    inj, topo, sb = _pack(e2, states[:2])
+    e2.set_injections(inj)
+    e2.set_topology(topo, sb)
+    with pytest.raises(GridPFError, match="more than 3 busbars"):
+        e2.runpf()
+    e2.close()
+
+
 def test_batched_step_matches_oracle(load_model, load_npz):
     """Device-resident chronics -> injections (float32, incl. the float32 prod_v/kV division) -> AC PF."""
     m = load_model("l2rpn_case14_sandbox")

@@ -39,10 +39,10 @@ def _run(cmd, timeout=900, *args):
 @staged
 def test_unmodified_reference_framework_on_the_hip_engine():
     """ONE test (one skip line in the driver's run, where the stage cannot exist) for the five legs:"""
-    # 1. the 11 recorded episodes re-run inside the real Environment / obs.simulate / N1Reward / Runner on HipBackend
+    # 1. the 12 recorded episodes re-run inside the real Environment / obs.simulate / N1Reward / Runner on HipBackend
     out = _run("episodes")
-    assert "EPISODES OK: 11 episodes" in out
-    assert len([l for l in out.splitlines() if "reproduced on the real framework + HIP engine" in l]) == 11
+    assert "EPISODES OK: 12 episodes" in out
+    assert len([l for l in out.splitlines() if "reproduced on the real framework + HIP engine" in l]) == 12
     # 2. the reference's own backend API kit (grid2op/tests/aaa_test_backend_interface.py, 41 tests)
     out = _run("aaa")
     assert "AAA OK" in out and "ran 41, passed 41" in out, out[-2000:]
