@@ -324,6 +324,8 @@ def measure_modes(ctx, eng, k, w, step_kw, n_win, preroll_steps, spl=None, last_
     Returns (windows with observations, windows last-observation-only or None, next time index)."""
     spl = ctx.args.steps_per_launch if spl is None else spl
     traj = spl > 1 and not ctx.args.stub_engine and not ctx.args.last_obs_only
+    if getattr(ctx.args, "profile", False):
+        preroll_steps, last_obs_too = 0, False
     if traj:
         eng.set_trajectory(spl, eng.TRAJ_OBS)
     w_obs, t = timed_windows(ctx, eng, k, w, step_kw, n_win, preroll_steps=preroll_steps, spl=spl)
@@ -394,6 +396,9 @@ def main():
                     help="developer (profiling): run only the 118-substation workload with the injection dynamics on and print its record")
     ap.add_argument("--only", default=None, choices=["n1_fanout", "secondary", "dc_ptdf", "secondary_env_dynamics"],
                     help="developer (profiling): run only that BASELINE config's workload exactly as the default run does and print its record")
+    ap.add_argument("--profile", action="store_true",
+                    help="developer (rocprofv3 runs): no pre-roll launches of odd sizes and no last-observation-only sibling windows, so that "
+                         "every dispatch of the step kernel is a full --steps-per-launch launch with the observation trajectory on")
     ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)   # CPU launcher test: no arithmetic
     args = ap.parse_args()
     if args.gpus < 1:
@@ -442,7 +447,7 @@ def main():
     if obs_every_step:
         eng.set_trajectory(args.steps_per_launch, eng.TRAJ_OBS)     # every step of a launch writes its observation to HBM
 
-    wins, t_next = timed_windows(ctx, eng, args.steps, args.warmup, step_kw, args.windows)
+    wins, t_next = timed_windows(ctx, eng, args.steps, args.warmup, step_kw, args.windows, preroll_steps=0 if args.profile else 400)
     elapsed, kern_ms, n_launch, wall_el = median_window(wins)
     r = eng.results()
     check = oracle_spot_check(ctx, eng, 32, t_last=None if (args.cascade or args.n1) else t_next - 1) if rank == 0 else None

@@ -212,6 +212,7 @@ struct gpf_engine {
   std::vector<int> h_gen_cnt;
   int ptdf_nb_pad = 0, ptdf_line_pad = 0;
   bool ptdf_ready = false;
+  DevArr<double> dc_inv_g;     // static DC inverse of the larger grids (gpf::SymDev::dc_inv_g)
   DevArr<double> stat_dbl;     // static blob of kernel S (gpf::StatOff)
   DevArr<int> stat_int;
   DevArr<int> flat_prog;       // flat programs of the substation graph (4 group widths)
@@ -941,7 +942,8 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
       e->h_gen_cnt = w;
     }
     so.dc_inv = -1;
-    if (g.n_sub <= 24 && !std::getenv("GRIDPF_NO_DCINV")) {
+    D.dc_inv_g = nullptr;
+    if (g.n_sub <= 512 && !std::getenv("GRIDPF_NO_DCINV")) {
       // inverse of the DC matrix of the reference topology (every line in service, reference buses = substations of the slack
       // generators), exactly as K3 assembles it: rows / columns of the reference buses are identity.  Column-major.
       const int n = g.n_sub;
@@ -975,7 +977,17 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
       if (ok) {
         std::vector<double> cm((size_t)n * n);
         for (int i = 0; i < n; ++i) for (int k = 0; k < n; ++k) cm[(size_t)k * n + i] = M[(size_t)i * 2 * n + n + k];
-        so.dc_inv = putd(cm.data(), cm.size());
+        // small grids: inside the static blob (staged in LDS with it); up to 63 substations (the single-wavefront kernels): a table of
+        // its own in global memory, read through L2 (36 substations: 10 KB shared by every lane; +5.7 % at 4 096 lanes, +1.8 % on the
+        // N-1 fan-out).  The two-wavefront kernels of the 118-substation grids keep their factored DC matrix in LDS instead: 118
+        // dependent L2 reads per bus lane measured -6.8 % against 19 light passes over kept factors.  GRIDPF_DCINV_MAX moves the limit.
+        const char* mx = std::getenv("GRIDPF_DCINV_MAX");
+        if (n <= 24) so.dc_inv = putd(cm.data(), cm.size());
+        else if (n <= (mx ? std::atoi(mx) : 63)) {
+          if (e->dc_inv_g.upload(cm.data(), cm.size()) != hipSuccess) { gpf_destroy(e); return fail(GPF_E_DEVICE, "upload dc_inv"); }
+          so.dc_inv = -2;
+          D.dc_inv_g = e->dc_inv_g.p;
+        }
       }
     }
     so.prog = puti(S.prog.data(), S.prog.size());                // 16-byte aligned: level headers are read as int4
@@ -1080,7 +1092,7 @@ int gpf_destroy(gpf_handle e) {
   e->topo0.release(); e->done.release(); e->episode.release(); e->lane_gen_delta.release(); e->traj_rho.release(); e->traj_status.release();
   e->traj_out.release(); e->traj_topo.release(); e->traj_shb.release(); e->traj_lstat.release();
   if (e->d_params_s) (void)hipFree(e->d_params_s);
-  e->stat_dbl.release();
+  e->stat_dbl.release(); e->dc_inv_g.release();
   e->list_a.release(); e->list_b.release(); e->list_c.release(); e->d_classes.release();
   for (auto* c : e->classes) { c->tables.release(); c->flat.release(); delete c; }
   e->classes.clear();

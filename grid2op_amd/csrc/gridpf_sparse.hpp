@@ -28,7 +28,8 @@ struct StatOff {
                                     // connected, single busbar): what pfsoln's reactive split needs, per generator
   int gen_cnt;     // (int section) [n_gen] generators | slack generators << 16 of the generator's substation, same assumption
   int dc_inv;      // >= 0: [n_sub][n_sub] COLUMN-major inverse of the DC matrix B' of the reference topology (every line in service,
-                   // every slack generator connected; reference / fixed rows are identity), small grids only; -1: none
+                   // every slack generator connected; reference / fixed rows are identity) inside the blob (small grids: staged in LDS
+                   // with it); -2: the same table in global memory, SymDev::dc_inv_g (larger grids: read through L2); -1: none
   int line_or_pos, line_ex_pos, line_or_sub, line_ex_sub, br_slot, gen_pos, gen_sub, gen_slack, load_pos, load_sub, sto_pos,
       sto_sub, shunt_sub, pair_rc, up, prog;
   int pos_line;    // (int section) [dim_topo] line whose end sits at that topo_vect position, -1: the position of a generator / load / storage unit
@@ -56,6 +57,7 @@ struct StatView {
   SP<int, HOT> up;        // [n_up][2] undirected off-diagonal pairs (gridpf_symbolic.hpp: build_upairs), single-busbar Newton loop
   SP<int, HOT> prog;      // level-scheduled program (layout: gridpf_symbolic.hpp)
   SP<int, false> node_of; // topology-class launches only (TopoClassDev::node_of)
+  SP<double, false> dc_inv_g;   // StatOff::dc_inv == -2
 };
 template <int STAGE>
 __device__ inline void stat_view(StatView<STAGE>& v, const StatOff& o, const double* d, const int* i) {
@@ -99,6 +101,7 @@ struct SymDev {
   int back_first;           // highest level that has U entries (back substitution starts there)
   int static_connected;     // the substation graph with every line in service is connected (host check at gpf_create)
   const int* prog;          // level-scheduled program in global memory (tools/lu_bench; the kernels use StatView::prog)
+  const double* dc_inv_g;   // StatOff::dc_inv == -2: the static DC inverse in global memory
   const double* stat_dbl;   // the static blob: [so.n_dbl] doubles ...
   const int* stat_int;      // ... and [so.n_int] ints
   StatOff so;
@@ -252,6 +255,7 @@ __device__ inline void make_stat_view(StatView<STAGE>& sv, const SymDev& S, unsi
   const auto gd = gptr(S.stat_dbl);
   const auto gi = gptr(S.stat_int);
   stat_view(sv, S.so, S.stat_dbl, S.stat_int);
+  sv.dc_inv_g.p = S.dc_inv_g;
   if (NB1) sv.prog.p = flat;
   if (STAGE == 0) return;
   if (!NB1) {                                                     // tier 1 of the NB > 1 kernels: [level-header program][pair_rc]
@@ -353,6 +357,11 @@ struct Grp {
   static __device__ __forceinline__ int count(bool x) {
     if (WPI > 1) return __syncthreads_count(x);
     return __popcll(__ballot(x) & mask());
+  }
+  // index inside the caller's instance of the first lane with x (single-wavefront instances only), -1: none
+  static __device__ __forceinline__ int first(bool x) {
+    const unsigned long long b = __ballot(x) & mask();
+    return b ? (int)__ffsll((long long)b) - 1 - (IPW == 1 ? 0 : (int)(threadIdx.x / GW) * GW) : -1;
   }
   static __device__ __forceinline__ double sum(double v) {
     if (WPI > 1) {
@@ -771,7 +780,9 @@ struct SolveCtl {
 struct TopoState {
   int status;         // 0, GPF_ST_NOSLACK or GPF_ST_ISLANDED
   int nb;             // number of active buses
-  bool dc_base;       // the DC matrix of this topology is the reference one (StatOff::dc_inv applies)
+  bool dc_base;       // the DC start of this topology comes from the static inverse of the reference DC matrix (StatOff::dc_inv): every
+                      // line in service, or (dc_out >= 0) exactly ONE line out, whose effect is a rank-1 correction
+  int dc_out;         // the line that is out (Sherman-Morrison correction of the static inverse), -1: none
   bool gen_base;      // every generator is connected (single-busbar layout): the static per-generator bus totals apply
   int tc[2];          // topo_vect values of positions tid, tid + GW as the last solve with a NEW topology wrote them
 };
@@ -851,7 +862,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   // initialisation (the matrix-vector product reads Psp - Gs directly: the rows / columns of the reference buses of the static
   // inverse are exact unit vectors, so their right-hand-side entries do not matter).  Three phase boundaries and their LDS round
   // trips less per step.
-  const bool fast_pre = nwr && reuse && ctl.sums_done && !warm && !TC && S.so.dc_inv >= 0 && G::block_all_u(ts.dc_base);
+  const bool fast_pre = nwr && reuse && ctl.sums_done && !warm && !TC && S.so.dc_inv != -1 && G::block_all_u(ts.dc_base && ts.dc_out < 0);
 #define GPF_INJ(i_) (STAGE ? c.inj[(i_)] : (double)inj_g[(i_)])      /* staged row in LDS, else the lane's row in HBM / L2 */
   const double sn = g.sn_mva, inv_sn = g.inv_sn_mva;
 
@@ -874,9 +885,18 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     return (NB == 1) ? sub : sub * NB + (local - 1);
   };
   bool line_off = false, slack_off = false, gen_off = false;
+  int n_line_off = 0, l_first_off = -1;                  // (single-wavefront instances: open lines of this group, the first of them)
   if (!sums_done) {
   if (!reuse)
-  for (int l = tid; l < g.n_line; l += GW) {
+  for (int l0 = 0; l0 < g.n_line; l0 += GW) {
+    const int l = l0 + tid;
+    const bool have = l < g.n_line;
+    const bool off_l = have && !((topo[sv.line_or_pos[l]] >= 1) && (topo[sv.line_ex_pos[l]] >= 1));
+    if (WPI == 1 && NB == 1 && !TC) {
+      const int cnt = G::count(off_l);
+      if (cnt) { if (l_first_off < 0) l_first_off = l0 + G::first(off_l); n_line_off += cnt; }
+    }
+    if (!have) continue;
     const int bo = topo[sv.line_or_pos[l]], be = topo[sv.line_ex_pos[l]];
     const bool on = (bo >= 1) && (be >= 1);
     line_off |= !on;
@@ -996,7 +1016,14 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   const unsigned off_bits = G::template any_bits<2, 3>((line_off ? 1u : 0u) | (slack_off ? 2u : 0u) | (gen_off ? 4u : 0u));
   ts.gen_base = NB == 1 && !TC && !(off_bits & 4u);
   // the DC matrix only depends on which lines are in service and where the reference buses are
-  ts.dc_base = NB == 1 && !TC && S.so.dc_inv >= 0 && (off_bits & 3u) == 0u;
+  {
+    const bool inv_ok = NB == 1 && !TC && S.so.dc_inv != -1 && !(off_bits & 2u);
+    // exactly one line out, every substation still active, a real branch (two different substations): rank-1 correction
+    bool one_out = false;
+    if (WPI == 1 && inv_ok && n_line_off == 1 && nb == nsub) one_out = sv.line_or_sub[l_first_off] != sv.line_ex_sub[l_first_off];
+    ts.dc_base = inv_ok && (WPI == 1 ? (n_line_off == 0 || one_out) : !(off_bits & 1u));
+    ts.dc_out = (ts.dc_base && one_out) ? l_first_off : -1;
+  }
   const bool conn_known = (NB == 1) && S.static_connected && !(off_bits & 1u);
   if (!G::block_all(conn_known))
   for (int sweep = 0; sweep < nbus; ++sweep) {
@@ -1029,6 +1056,13 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   // groups differ takes the LU path for all of them.
   const bool dc_inv = NB == 1 && !TC && G::block_all_u(ts.dc_base);
   const bool dc_skip = dc_kept || dc_inv;              // no DC matrix to assemble
+  // the static-inverse DC start runs inside the Newton initialisation of the register-resident path (see fast_pre): no right-hand
+  // side phase, no separate matrix-vector phase -- also on a step that rebuilt its topology tables (one launch per step)
+  const bool fuse_dc = nwr && !warm && dc_inv && G::block_all_u(ts.dc_out < 0);
+  auto dcinv = [&](int idx) -> double { return S.so.dc_inv >= 0 ? sv.dc_inv[idx] : sv.dc_inv_g[idx]; };
+  // operand pairs of the static-inverse matrix-vector product in flight per trip (the one-instance kernels live on 3 waves per SIMD
+  // at <= 168 VGPRs: 4 pairs there)
+  constexpr int MVC = IPW > 1 ? 8 : 4;
   auto lidx = [&](int bus) -> int { return (NB == 1) ? 0 : bus % NB; };
   if (!warm && !fast_pre) {
   if (!dc_skip || do_y) {
@@ -1091,6 +1125,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   }
   }
   // identity rows (fixed variables) + DC right-hand side
+  if (!fuse_dc)
   for (int i = tid; i < nbus; i += GW) {
     const int sub = (NB == 1) ? i : i / NB, bi = lidx(i);
     const int bt = c.btype[i];
@@ -1102,7 +1137,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     *rhsT(i) = th_live ? (c.Psp[i] - c.Gs[i]) : 0.0;
     *rhsV(i) = 0.0;
   }
-  GPF_LSYNC();
+  if (!fuse_dc) GPF_LSYNC();
   }
   GPF_STAMPS(3);
   // the program is in LDS (tier >= 1) or read in place through a global-address-space pointer (tier 0)
@@ -1131,7 +1166,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     if (PROG_LDS) return scalar_lu_flat<GW, true, false>(FL, sv.prog.p, c.A, c.A, tid, dbg);
     return scalar_lu_flat<GW, true, false>(FL, gptr(flat_g), c.A, c.A, tid, dbg);
   };
-  if (!warm && !fast_pre) {
+  if (!warm && !fuse_dc) {
 #ifdef GPF_TIMING
     bool ok = dc_inv ? true : (NB == 1) ? lu_dc(&stamps.v[20])
                                         : lu_ac(&stamps.v[20]);
@@ -1141,13 +1176,21 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     for (int i = tid; i < nbus; i += GW) {
       double th;
       if (dc_inv) {                                                 // row i of inv(B') (column-major table) times the right-hand side
-        double t0 = 0.0, t1 = 0.0;                                  // two chains: half the dependent-FMA depth
-        int k = 0;
-        for (; k + 1 < nbus; k += 2) {
-          t0 = fma(sv.dc_inv[k * nbus + i], *rhsT(k), t0);
-          t1 = fma(sv.dc_inv[(k + 1) * nbus + i], *rhsT(k + 1), t1);
+        double t0 = 0.0, t1 = 0.0;                                  // two chains (even / odd k), 8 operand pairs in flight per trip
+        for (int k0 = 0; k0 < nbus; k0 += MVC) {
+          double a_[MVC], r_[MVC];
+#pragma unroll
+          for (int q = 0; q < MVC; ++q) {
+            const int k = k0 + q < nbus ? k0 + q : nbus - 1;
+            a_[q] = dcinv(k * nbus + i);
+            r_[q] = *rhsT(k);
+          }
+#pragma unroll
+          for (int q = 0; q < MVC; q += 2) {
+            if (k0 + q < nbus) t0 = fma(a_[q], r_[q], t0);
+            if (k0 + q + 1 < nbus) t1 = fma(a_[q + 1], r_[q + 1], t1);
+          }
         }
-        if (k < nbus) t0 = fma(sv.dc_inv[k * nbus + i], *rhsT(k), t0);
         th = t0 + t1;
       } else if (NB == 1) {                                         // flat sweeps leave s_i = d_i theta_i (scalar_lu_flat)
         const double d = dc_kept ? c.Adc[i] : c.A[(size_t)i * 2];
@@ -1161,6 +1204,28 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     if (NB == 1 && ctl.dcf && !dc_skip)                            // keep the factors for the next solves of this launch
       for (int q = tid; q < S.nslot; q += GW) c.Adc[q] = c.A[(size_t)q * 2];
     GPF_LSYNC();
+    if (WPI == 1 && dc_inv && G::block_any_u(ts.dc_out >= 0)) {
+      // ONE line l = (f, t) out: B'_c = B' - b_l a a^T (a = e_f - e_t over the non-reference buses), so by Sherman-Morrison
+      //   theta_c = theta_0 + X a * b_l (a^T theta_0) / (1 - b_l a^T X a),   X = inv(B') = the static table
+      // -- two more reads of the table per bus instead of assembling, factoring and sweeping the DC system of the contingency
+      // (the N-1 fan-out: every lane but the intact one of each environment).  c.va holds theta_0 (0 at reference buses).
+      const int lo_ = ts.dc_out >= 0 ? ts.dc_out : 0;
+      const int f_ = sv.line_or_sub[lo_], t_ = sv.line_ex_sub[lo_];
+      const double bl = ts.dc_out >= 0 ? sv.br_bdc[lo_] : 0.0;
+      const bool f_ref = c.btype[f_] == BT_REF, t_ref = c.btype[t_] == BT_REF;
+      const double dth = c.va[f_] - c.va[t_];
+      const double xff = f_ref ? 0.0 : dcinv(f_ * nbus + f_), xtt = t_ref ? 0.0 : dcinv(t_ * nbus + t_);
+      const double xft = (f_ref || t_ref) ? 0.0 : dcinv(t_ * nbus + f_);
+      const double den = 1.0 - bl * (xff - 2.0 * xft + xtt);
+      if (!(fabs(den) > 1e-12)) ok = false;
+      const double kk = bl * dth / den;
+      for (int i = tid; i < nbus; i += GW) {
+        const int bt = c.btype[i];
+        const double u_ = (f_ref ? 0.0 : dcinv(f_ * nbus + i)) - (t_ref ? 0.0 : dcinv(t_ * nbus + i));
+        if (bt == BT_PQ || bt == BT_PV) c.va[i] += u_ * kk;        // (every lane read c.va[f], c.va[t] above: one wavefront, in order)
+      }
+      GPF_LSYNC();
+    }
     if (status == 0 && G::any(!ok)) status = 4;
     if (G::block_all_u(status != 0)) return status;
   }
@@ -1206,21 +1271,23 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
 #define NWR_PSP (KEEP_Y ? psp0 : c.Psp[ib])
 #define NWR_QSP (KEEP_Y ? qsp0 : c.Qsp[ib])
       double va, vm;
-      if (fast_pre) {
-        // initial |V| (K1), DC right-hand side (K3) and theta = inv(B') (P - G) in the bus lane itself; row ib of the column-major
-        // static inverse, all operands in flight before the two FMA chains (even / odd k, the order of the general path)
-        const int vi = c.vidx[ib];
+      if (fuse_dc) {
+        // initial |V| (K1; a step that rebuilt its tables already has it in LDS), DC right-hand side (K3) and theta = inv(B') (P - G)
+        // in the bus lane itself; row ib of the column-major static inverse, all operands in flight before the two FMA chains
+        // (even / odd k, the order of the general path)
+        const int vi = fast_pre ? c.vidx[ib] : -1;
+        const double vm_lds = fast_pre ? 1.0 : c.vm[ib];
         double t0 = 0.0, t1 = 0.0;
-        for (int k0 = 0; k0 < nbus; k0 += 8) {
-          double a_[8], r_[8];
+        for (int k0 = 0; k0 < nbus; k0 += MVC) {
+          double a_[MVC], r_[MVC];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
+          for (int q = 0; q < MVC; ++q) {
             const int k = k0 + q < nbus ? k0 + q : nbus - 1;
-            a_[q] = sv.dc_inv[k * nbus + ib];
+            a_[q] = dcinv(k * nbus + ib);
             r_[q] = c.Psp[k] - c.Gs[k];
           }
 #pragma unroll
-          for (int q = 0; q < 8; q += 2) {
+          for (int q = 0; q < MVC; q += 2) {
             if (k0 + q < nbus) t0 = fma(a_[q], r_[q], t0);
             if (k0 + q + 1 < nbus) t1 = fma(a_[q + 1], r_[q + 1], t1);
           }
@@ -1228,7 +1295,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         const double th = t0 + t1;
         const bool live = (bt == BT_PQ || bt == BT_PV);
         va = live ? th : 0.0;
-        vm = (vi >= 0 && (bt == BT_PV || bt == BT_REF)) ? GPF_INJ(oo.inj_gen_vm + vi) : 1.0;
+        vm = (vi >= 0 && (bt == BT_PV || bt == BT_REF)) ? GPF_INJ(oo.inj_gen_vm + vi) : vm_lds;
         const bool th_bad = b_on && bt != BT_OFF && !(fabs(th) < 1e300);
         if (status == 0 && G::any(th_bad)) { status = 4; done = true; }
       } else { va = c.va[ib]; vm = c.vm[ib]; }
@@ -1845,7 +1912,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   ctl.inj_staged = false; ctl.topo_staged = false; ctl.reuse = false; ctl.dcf = false; ctl.write_bus = true; ctl.warm = false; ctl.sums_done = false;
   ctl.otraj = false; ctl.orow = inst; ctl.write_topo = true;
   TopoState ts;
-  ts.status = 0; ts.nb = 0; ts.dc_base = false; ts.gen_base = false; ts.tc[0] = ts.tc[1] = -1;
+  ts.status = 0; ts.nb = 0; ts.dc_base = false; ts.dc_out = -1; ts.gen_base = false; ts.tc[0] = ts.tc[1] = -1;
   const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, is_dc, max_iter, tol_pu, tid, ctl, ts, n_iter, nb, a_first GPF_STAMPS_ARG);
   GPF_SYNC();
   if (st != 0) write_nan_results<GW>(P->g, P->b, inst, tid, inst, false);
@@ -2109,7 +2176,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   if (has_delta && tid < g.n_gen) gd0 = gptr(b.lane_gen_delta)[(size_t)inst * g.n_gen + tid];
   if (STAGE) { const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj; for (int i = oo.inj_sto_p + tid; i < g.n_inj; i += GW) c.inj[i] = inj_g[i]; }   // storage / shunt set-points
   TopoState ts;
-  ts.status = 0; ts.nb = 0; ts.dc_base = false; ts.gen_base = false; ts.tc[0] = ts.tc[1] = -1;
+  ts.status = 0; ts.nb = 0; ts.dc_base = false; ts.dc_out = -1; ts.gen_base = false; ts.tc[0] = ts.tc[1] = -1;
   bool reuse = false;                                         // block-uniform
   int n_iter = 0, nb = 0, st = 0, rounds = 0;
   // state of the lane's OWN line (line `tid`: the line loops all map line l to lane l % GW) kept in registers for the launch:

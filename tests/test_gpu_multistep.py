@@ -368,11 +368,14 @@ def test_split_batches_in_every_kernel_mode(mode, load_model, load_npz):
     e2.close()
 
 
-@pytest.mark.parametrize("name,B", [("l2rpn_case14_sandbox", 26), ("rte_case5_example", 12), ("educ_case14_storage", 8)])
+@pytest.mark.parametrize("name,B", [("l2rpn_case14_sandbox", 26), ("rte_case5_example", 12), ("educ_case14_storage", 8),
+                                    ("l2rpn_neurips_2020_track1", 13), ("l2rpn_wcci_2022_dev", 7)])
 def test_static_dc_inverse_equals_the_dc_solve(name, B, load_model, load_npz):
-    """Small grids: lanes in the reference topology get their DC initialisation from the static inverse of B' (one
-    matrix-vector phase), the others -- here every third lane has a line out, so that wavefronts mix both kinds -- from the DC
-    factorisation.  GRIDPF_NO_DCINV=1 (always factorise) must give the same power flows."""
+    """Lanes in the reference topology get their DC initialisation from the static inverse of B' (one matrix-vector phase; round 4:
+    on every grid size -- the table of the larger grids is read from global memory); lanes with exactly ONE line out -- here every
+    third lane, so that wavefronts mix both kinds -- from the same table + a Sherman-Morrison rank-1 correction (single-wavefront
+    kernels; the two-wavefront kernels of the 118-substation grids factorise those lanes).  GRIDPF_NO_DCINV=1 (always assemble and
+    factorise the DC system) must give the same power flows, iteration counts included."""
     m, ch, e1, tab, off, scale = _setup(load_model, load_npz, name, B)
     _, _, e2, _, _, _ = _setup(load_model, load_npz, name, B, env={"GRIDPF_NO_DCINV": "1"})
     topo = np.tile(m.initial_topo_vect(), (B, 1))
