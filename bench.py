@@ -109,6 +109,40 @@ def cpu_baseline(env_name, m, ch, T, budget_s=10.0):
     return res
 
 
+def reference_step_loop():
+    """The reference's own DoNothing profiler loop (_profiling/profiler_do_nothing.py:42-61: Environment.step, DoNothingAgent,
+    NO_OVERFLOW_DISCONNECTION, AlwaysLegal) with BOTH engines under the unmodified framework: HipBackend + libgridpf.so and the facade
+    over the CPU oracle.  grid2op cannot be part of this repository or of the GPU box's image: when tools/gpurun_staged.sh has staged
+    the unmodified reference package for this call (`_stage/`), the loop is MEASURED HERE (tests/reference_on_hip.py timing, a
+    subprocess); otherwise the committed figures of the staged MI355X run of this round are quoted and labelled as such."""
+    stage = os.path.join(ROOT, "_stage")
+    if os.path.isdir(os.path.join(stage, "grid2op")):
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in ("PYTHONPATH", "REFERENCE_ON_HIP_DRYRUN")}
+            env["GRID2OP_REFERENCE"] = stage
+            p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "reference_on_hip.py"), "timing", "500"], capture_output=True,
+                               text=True, timeout=600, env=env, cwd=ROOT)
+            line = [l for l in p.stdout.splitlines() if l.startswith("TIMING ")][-1]
+            return dict(json.loads(line[len("TIMING "):]), source="measured in this run (unmodified reference package staged for this call)")
+        except Exception as exc:
+            err = repr(exc)[:200]
+    else:
+        err = None
+    for rel, src in ((os.path.join("profiles", "r04_reference_step_loop_mi355x.json"),
+                      "committed profiles/r04_reference_step_loop_mi355x.json: tests/reference_on_hip.py timing on an MI355X box with the unmodified "
+                      "reference package staged for that call (tools/gpurun_staged.sh); NOT measured in this run (the reference cannot be staged here)"),
+                     (os.path.join("profiles", "r02_framework_loop_cpu.json"), "committed profiles/r02_framework_loop_cpu.json (build container CPU, round 2)")):
+        try:
+            with open(os.path.join(ROOT, rel)) as f:
+                d = dict(json.load(f), source=src)
+            if err:
+                d["staged_run_error"] = err
+            return d
+        except Exception:
+            continue
+    return None
+
+
 def usable_cores():
     """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU boxes expose 256 logical CPUs
     behind a quota of 16: 256 busy processes there are SLOWER than 16)."""
@@ -674,14 +708,7 @@ def main():
         # let the GPU clocks drop before the secondary workloads
         if not args.no_cpu_baseline and world == 1 and not args.stub_engine:
             res["cpu_baseline"] = cpu_baseline(args.env, m, ch, T)
-            try:    # the reference Environment.step loop itself (profiler_do_nothing.py:42-65) cannot run on the GPU box (grid2op is
-                    # not installable there): figure measured in the build container, committed, quoted -- not measured in this run
-                with open(os.path.join(ROOT, "profiles", "r02_framework_loop_cpu.json")) as f:
-                    res["cpu_baseline"]["reference_environment_step_loop"] = dict(
-                        json.load(f), source="committed profiles/r02_framework_loop_cpu.json (tools/framework_loop.py, build container "
-                                             "CPU, NOT measured in this run)")
-            except Exception:
-                pass
+            res["cpu_baseline"]["reference_environment_step_loop"] = reference_step_loop()
         print(json.dumps(res), flush=True)
     if ctx.dist is not None:
         ctx.dist.barrier()

@@ -2004,6 +2004,7 @@ __device__ inline bool env_dynamics_step(const EnvDyn& E, int k, int n_gen, int 
   // ---- _compute_storage (:2829-2905) + _withdraw_storage_losses (:2777-2790)
   double amount = 0.0;
   sto_power = 0.f;
+  const float charge_before = R.charge;                     // _storage_previous_charge (:2830)
   if (n_sto > 0) {
     float pw = 0.f;
     const bool any_act = is_sto && fabsf(act_s) >= 1e-7f;
@@ -2064,6 +2065,23 @@ __device__ inline bool env_dynamics_step(const EnvDyn& E, int k, int n_gen, int 
   if (is_gen && fabsf(act_r) > 1e-7f) {
     R.target = R.already ? R.target + act_r : R.actual + act_r;
     R.already = true;
+  }
+  // ---- _prepare_redisp (:2117-2186): a target dispatch beyond pmax - pmin (below pmin - pmax) can never be met -> the action is
+  //      ILLEGAL: it is taken back out of the target and BaseEnv.step replaces the whole action by do-nothing (:3189-3212): the
+  //      state of charge goes back to the previous step's, the storage amount is withdrawn, the losses are applied again; the
+  //      storage power already handed to the backend stays (:3829-3831).  float32 comparisons like the reference's dt_float arrays.
+  {
+    const bool busy = env_gmax<LW>((is_gen && (fabsf(act_r) > 1e-7f || fabsf(R.target) > 1e-7f || fabsf(R.actual) > 1e-7f)) ? 1.0 : 0.0) > 0.0;
+    const float span = is_gen ? (float)E.pmax[k] - (float)E.pmin[k] : 0.f;
+    const bool illegal = busy && env_gmax<LW>((is_gen && (R.target > span || R.target < -span)) ? 1.0 : 0.0) > 0.0;
+    if (illegal) {
+      if (is_gen) R.target -= act_r;
+      if (n_sto > 0) {
+        if (is_sto) R.charge = charge_before;
+        amount -= (double)R.amount_prev;
+        if (E.loss_on && is_sto) R.charge = fmaxf(R.charge - (float)(E.loss[k] * E.coeff), 0.f);
+      }
+    }
   }
   // ---- _make_redisp gate (:2198-2209)
   const double tol = E.tol_poly;

@@ -252,8 +252,10 @@ int gpf_redispatch(gpf_handle h, int32_t lane0, int32_t n, const double* new_p, 
  * prod_p = chronics + actual dispatch (:3830 set_redispatch) and the storage power (:3831 set_storage).  A lane whose projection is
  * infeasible ends its episode (status GPF_ST_REDISPATCH; ImpossibleRedispatching :3227-3247).  Curtailment
  * (_aux_handle_curtailment_without_limit, :2956-2982): renewable generators are capped at limit * pmax, the change of the curtailed
- * total joins the right-hand side of the projection.  Not modelled: detachment, generator up / down times, the cancellation of
- * illegal redispatch actions (:2140-2173), LIMIT_INFEASIBLE_CURTAILMENT_STORAGE_ACTION.
+ * total joins the right-hand side of the projection.  An ILLEGAL redispatch -- the accumulated target beyond pmax - pmin or below
+ * pmin - pmax (_prepare_redisp :2140-2173) -- is cancelled as the reference cancels it: taken back out of the target, the storage
+ * part of the step undone (:3189-3212).  Not modelled: detachment, generator up / down times, the dispatch of switched-off generators
+ * (Parameters.ALLOW_DISPATCH_GEN_SWITCH_OFF = False), LIMIT_INFEASIBLE_CURTAILMENT_STORAGE_ACTION.
  *   gpf_set_storage_params : storage_Emax / Emin / loss / charging & discharging efficiency / initial charge [n_storage], the
  *                            step length and Parameters.ACTIVATE_STORAGE_LOSS.
  *   gpf_set_env_dynamics   : on != 0 switches the dynamics on (needs gpf_set_gen_limits, and gpf_set_storage_params on a grid

@@ -163,8 +163,9 @@ class InjectionDynamics:
     `_withdraw_storage_losses` (:2777-2790), `_get_already_modified_gen` (:2101-2115), the `_make_redisp` gate (:2188-2209) and
     `_compute_dispatch_vect` (:2211-2470, restated in oracle/redispatch_oracle.py with the reference's own solver), the set-points
     of `set_redispatch` / `set_storage` (:3829-3831) and `_gen_activeprod_t_redisp` (:3439).  State arrays are float32 like the
-    reference's (dt_float).  Not restated: curtailment, detachment, generator up / down times, the cancellation of illegal
-    redispatch actions (`_prepare_redisp` :2140-2173: the tests only hand over legal ones)."""
+    reference's (dt_float).  Restated since round 4: the cancellation of an illegal redispatch action (`_prepare_redisp` :2140-2173,
+    `self.illegal` after a step).  Not restated: detachment, generator up / down times, the dispatch of switched-off generators
+    (Parameters.ALLOW_DISPATCH_GEN_SWITCH_OFF = False), LIMIT_INFEASIBLE_CURTAILMENT_STORAGE_ACTION."""
 
     def __init__(self, lim, n_gen, sto=None, delta_time_seconds=300.0, storage_charge0=None, activate_storage_loss=True, exact=False):
         self.lim = lim
@@ -190,6 +191,7 @@ class InjectionDynamics:
 
     def _compute_storage(self, act):
         s = self.sto
+        self.charge_prev = self.charge.copy()                # _storage_previous_charge (baseEnv.py:2830)
         act = np.asarray(act, np.float32)
         sel = np.isfinite(act) & (np.abs(act) >= 1e-7)
         self.power[:] = 0.0
@@ -266,6 +268,23 @@ class InjectionDynamics:
             first_mod = (~self.already) & is_red
             self.target[first_mod] = self.actual[first_mod] + act[first_mod]
             self.already[is_red] = True
+        # _prepare_redisp (baseEnv.py:2117-2186): a target dispatch beyond pmax - pmin (or below pmin - pmax) can never be met -> the
+        # action is ILLEGAL: it is taken back out of the target, and BaseEnv.step replaces the whole action by do-nothing
+        # (:3189-3212): the storage charge goes back to the previous step's, the storage amount is withdrawn and the losses are
+        # applied again -- the storage POWER already handed to the backend stays (:3829-3831), as in the reference
+        self.illegal = False
+        act_v = np.zeros(len(self.target), np.float32) if act_redisp is None else np.asarray(act_redisp, np.float32)
+        skip = (np.abs(act_v) <= 1e-7).all() and (np.abs(self.target) <= 1e-7).all() and (np.abs(self.actual) <= 1e-7).all()
+        span = (self.lim["pmax"] - self.lim["pmin"]).astype(np.float32)
+        if not skip and ((self.target > span).any() or (self.target < -span).any()):
+            self.target -= act_v
+            self.illegal = True
+            if self.sto is not None:
+                self.charge[:] = self.charge_prev
+                self.amount -= self.amount_prev
+                if self.loss_on:
+                    self.charge -= (self.sto["loss"] * self.coeff).astype(np.float32)
+                    self.charge[:] = np.maximum(self.charge, 0.0)
         tol = self.lim["tol_poly"]
         ok = True
         if self.fresh and not self.prev_p.any():

@@ -34,8 +34,12 @@ from grid2op.Parameters import Parameters  # noqa: E402
 from conformance_backend import OracleHipBackend  # noqa: E402
 
 
-def record(env_name, n_steps, every, seed, curtail=False, storage_emin=None, out_name=None):
-    """storage_emin: the environment's DATA folder is copied to a scratch directory with the Emin column of storage_units_charac.csv
+def record(env_name, n_steps, every, seed, curtail=False, storage_emin=None, out_name=None, push=None):
+    """push = (gen up, gen down, gen down 2): EVERY step asks for +ramp on the first generator (and the matching amounts down on the
+    other two) -- legal actions one by one, until the accumulated target dispatch exceeds pmax - pmin: _prepare_redisp then declares
+    the action illegal, takes it back out of the target and the environment replaces the whole action by do-nothing, storage part
+    included (baseEnv.py:2140-2173, 3189-3212).
+    storage_emin: the environment's DATA folder is copied to a scratch directory with the Emin column of storage_units_charac.csv
     replaced (the reference code stays untouched), and every second action moves only the LAST storage unit: the idle units drift
     below Emin > 0 through the losses and _compute_storage's clamp of ALL units pulls them back (baseEnv.py:2861-2888)."""
     p = Parameters()
@@ -78,7 +82,14 @@ def record(env_name, n_steps, every, seed, curtail=False, storage_emin=None, out
             ratio = np.asarray(data.prod_p[data.current_index + 1])[ren] / cls.gen_pmax[ren]      # the two renewables producing most
             k = ren[np.argsort(-ratio)[(t // every) % 2 * 2:(t // every) % 2 * 2 + 2]]
             cur[k] = 1.0 if t >= 10 else (ratio[np.isin(ren, k)] * rng.uniform(0.85, 0.95, 2)).astype(np.float32)
-        if t % every == 0:
+        if push is not None:
+            up, d1, d2 = push
+            red[up] = cls.gen_max_ramp_up[up]
+            red[d1] = -min(cls.gen_max_ramp_down[d1], cls.gen_max_ramp_up[up])
+            red[d2] = -(cls.gen_max_ramp_up[up] + red[d1])
+            if cls.n_storage and t % 3 == 1:
+                sto[:] = rng.uniform(-3.0, 3.0, cls.n_storage)
+        elif t % every == 0:
             k = rng.choice(disp, size=min(len(disp), 2), replace=False)
             amp = cls.gen_max_ramp_up[k] * rng.uniform(0.2, 0.7, len(k)) * np.array([1.0, -1.0])[:len(k)]
             red[k] = amp
@@ -151,6 +162,9 @@ def main():
         record("educ_case14_storage", 24, 4, 5)
     if not only or "l2rpn_wcci_2022_dev" in only:
         record("l2rpn_wcci_2022_dev", 16, 4, 6, curtail=True)
+    if not only or "educ_case14_storage_illegal" in only:
+        # the accumulated target of generator 5 crosses pmax - pmin: illegal redispatch, whole action cancelled (N4: _prepare_redisp)
+        record("educ_case14_storage", 12, 1, 9, out_name="educ_case14_storage_illegal", push=(5, 1, 0))
     if not only or "educ_case14_storage_emin" in only:
         # Emin just below the initial charge: two steps of losses put an idle unit under it (the clamp acts on ALL units)
         record("educ_case14_storage", 24, 2, 7, storage_emin=(7.49, 3.49), out_name="educ_case14_storage_emin")

@@ -30,15 +30,17 @@ def _engine(m, fx, B):
     return eng
 
 
-@pytest.mark.parametrize("name", ["educ_case14_storage", "l2rpn_wcci_2022_dev", "educ_case14_storage_emin"])
+@pytest.mark.parametrize("name", ["educ_case14_storage", "l2rpn_wcci_2022_dev", "educ_case14_storage_emin", "educ_case14_storage_illegal"])
 def test_recorded_reference_episode_in_multi_step_launches(name, load_model, load_npz):
     """The recorded episode (actions every 4 steps, nothing in between) replayed with ONE multi-step launch per stretch.  The device
     solves the redispatch projection EXACTLY where the reference's SLSQP stops at ftol (tests/test_oracle_envdyn.py: up to 0.8 MW
     apart on single steps, objective never worse), so the comparison is two-fold: tight against the oracle run with the exact
     minimiser from the same start, and within SLSQP's inexactness against the recorded reference states / observations.
     ``_emin``: the same environment recorded with storage_Emin just below the initial charge and actions that move only ONE of the two
-    units: the idle unit drifts below Emin through the losses and is pulled back by the clamp of ALL units (baseEnv.py:2861-2888)."""
-    m = load_model(name.replace("_emin", ""))
+    units: the idle unit drifts below Emin through the losses and is pulled back by the clamp of ALL units (baseEnv.py:2861-2888).
+    ``_illegal``: every step pushes generator 5 up by its ramp until the accumulated target crosses pmax - pmin: from then on
+    _prepare_redisp cancels the whole action, storage part included (:2140-2173, 3189-3212) -- 6 of the 12 recorded steps."""
+    m = load_model(name.replace("_emin", "").replace("_illegal", ""))
     fx = load_npz(f"envdyn_{name}.npz")
     B = 3                                                  # three lanes play the same episode (a wavefront shared by 2 instances on 14 substations)
     eng = _engine(m, fx, B)
@@ -55,7 +57,7 @@ def test_recorded_reference_episode_in_multi_step_launches(name, load_model, loa
     ns = ~m.gen_slack
     loose = 1.2                                            # MW: SLSQP's distance from the exact minimiser over a stretch of <= 4 steps
                                                            # (sanity bound; per call: tests/test_redispatch.py)
-    if name.endswith("_emin"):
+    if name.endswith("_emin") or name.endswith("_illegal"):
         loose = 2.5       # its first action: SLSQP leaves 0.96 MW on each of the two modified generators where the exact minimiser puts
                           # them ON their targets and lets an unmodified generator absorb the storage power (objective 0 vs > 0)
     # On the 62-generator grid the exact minimiser and SLSQP's approximate one drift apart when both run freely (2.9 MW after 16
@@ -63,7 +65,7 @@ def test_recorded_reference_episode_in_multi_step_launches(name, load_model, loa
     # state (what an environment restored from an observation hands over, baseEnv.py:4879-4882), the 14-substation episode runs freely.
     # (the ``_emin`` recording acts every 2 steps over 24 steps -- twice as many ramp-limited projections as the plain 14-substation
     #  episode --: its stretches restart from the recorded state too)
-    resync = m.n_gen >= 20 or name.endswith("_emin")
+    resync = m.n_gen >= 20 or name.endswith("_emin") or name.endswith("_illegal")
     for a, b_ in zip(bounds[:-1], bounds[1:]):
         if resync and a > 0:
             ap = np.float32(fx["storage_power"][a - 1].sum()) if m.n_storage else np.float32(0.0)

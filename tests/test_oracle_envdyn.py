@@ -20,7 +20,7 @@ def dyn_from_fixture(fx, exact=False):
                              bool(fx["activate_storage_loss"]), exact=exact)
 
 
-@pytest.mark.parametrize("name", ["educ_case14_storage", "l2rpn_wcci_2022_dev", "educ_case14_storage_emin"])
+@pytest.mark.parametrize("name", ["educ_case14_storage", "l2rpn_wcci_2022_dev", "educ_case14_storage_emin", "educ_case14_storage_illegal"])
 def test_injection_dynamics_reproduce_the_reference_environment(name, load_npz):
     fx = load_npz(f"envdyn_{name}.npz")
     dyn = dyn_from_fixture(fx)
@@ -31,6 +31,7 @@ def test_injection_dynamics_reproduce_the_reference_environment(name, load_npz):
             dyn.prev_p[:] = fx["ch_prod_p"][fx["row"][0] - 1]
         ok, gen, sto = dyn.step(fx["new_p"][t], fx["act_redisp"][t], fx["act_storage"][t], fx["act_curtail"][t])
         assert ok
+        assert bool(dyn.illegal) == bool(fx["failed_redisp"][t]), t          # (_prepare_redisp: the action was cancelled)
         assert np.abs(dyn.limit - fx["limit_curtailment"][t]).max() < 1e-6 and abs(dyn.sum_curt - fx["sum_curtailment"][t]) < 1e-4, t
         assert np.abs(dyn.target - fx["target"][t]).max() < 1e-5, t
         assert np.abs(dyn.actual - fx["actual"][t]).max() < 2e-4, (t, np.abs(dyn.actual - fx["actual"][t]).max())
