@@ -25,8 +25,8 @@ for w in "$@"; do
   case $w in
     case14) prof r04_step_kernel_case14 96468992 "step_sparse_kernel<1, 2, 2" "$FULL" --steps 48 --warmup 16 --windows 2 --no-secondary ;;
     case14_1) prof r04_step_kernel_case14_1perlaunch 6029312 "step_sparse_kernel<1, 2, 2" "pmc_fetch:FETCH_SIZE pmc_write:WRITE_SIZE" --steps 48 --warmup 16 --windows 2 --no-secondary --steps-per-launch 1 ;;
-    n1) prof r04_step_kernel_n1_neurips36 4560322560 "step_sparse_kernel<1, 0, 1, 2, 1" "$LITE" --only n1_fanout --steps 32 --warmup 16 ;;
+    n1) prof r04_step_kernel_n1_neurips36 4560322560 "step_sparse_kernel<1, 0, 1, 2, 1" "$LITE" --only n1_fanout --steps 48 --warmup 16 ;;
     wcci) prof r04_step_kernel_wcci118 225935360 "step_sparse_kernel<1, 0, 1, 2, 2" "$LITE" --only secondary --steps 64 --warmup 16 ;;
-    idf) prof r04_kernels_idf118 459210752 "step_sparse_kernel<1, 0, 1, 2, 2" "$LITE" --only dc_ptdf --steps 32 --warmup 16 ;;
+    idf) prof r04_kernels_idf118 459210752 "step_sparse_kernel<1, 0, 1, 2, 2" "$LITE" --only dc_ptdf --steps 48 --warmup 16 ;;
   esac
 done
