@@ -16,7 +16,7 @@ __all__ = ["lib", "GridPFError", "GpfGridDesc", "GpfLayout", "GpfStepOpts", "lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libgridpf.so"
-ABI_VERSION = 300          # include/gridpf.h GPF_ABI_VERSION
+ABI_VERSION = 310          # include/gridpf.h GPF_ABI_VERSION
 
 EXPORTED_SYMBOLS = [
     "gpf_last_error", "gpf_version", "gpf_set_deterministic", "gpf_device_count", "gpf_create", "gpf_destroy", "gpf_get_layout", "gpf_n_lanes",
@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = [
     "gpf_set_storage_params", "gpf_set_env_dynamics", "gpf_set_lane_actions", "gpf_get_env_state", "gpf_set_env_state", "gpf_set_gen_renewable", "gpf_set_lane_curtailment", "gpf_get_episode", "gpf_lane_capacity", "gpf_get_step_outputs", "gpf_sync",
     "gpf_set_profiling", "gpf_get_kernel_time", "gpf_get_plan", "gpf_device_pointers", "gpf_device_pointers_n",
     "gpf_ptdf_build", "gpf_ptdf_get", "gpf_ptdf_flows", "gpf_get_ptdf_flows", "gpf_ptdf_flows_rows", "gpf_get_ptdf_flows_rows", "gpf_lodf_screen",
+    "gpf_jit_enable", "gpf_jit_disable", "gpf_jit_info", "gpf_jit_source",
 ]
 
 
@@ -168,6 +169,10 @@ def lib() -> C.CDLL:
     L.gpf_ptdf_flows_rows.argtypes = [h, i32, i32, C.c_double]
     L.gpf_get_ptdf_flows_rows.argtypes = [h, i32, i32, i32, i32, _fp]
     L.gpf_lodf_screen.argtypes = [h, i32, i32, _fp, _fp]
+    L.gpf_jit_enable.argtypes = [h, C.c_char_p, C.c_char_p]
+    L.gpf_jit_disable.argtypes = [h]
+    L.gpf_jit_info.argtypes = [h, C.POINTER(C.c_int64), _dp, C.c_char_p, C.c_size_t]
+    L.gpf_jit_source.argtypes = [h, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(L, name)
         if name not in ("gpf_last_error",):

@@ -190,6 +190,10 @@ struct gpf_engine {
   bool rd_ready = false;
   unsigned char* pin = nullptr;         // pinned host staging of gpf_solve_lane (one lane in, one lane out)
   size_t pin_bytes = 0;
+  GpfJit jit;                           // grid-specialised step kernels (gpf_jit_enable; gridpf_jit.hip)
+  gpf::GridDev jit_g;                   // the grid-level part of the parameter block the specialisation was generated from
+  gpf::OutOff jit_oo;
+  gpf::SymDev jit_sym;
   int dcf = 0;                          // the NB == 1 LDS layout has room for the factored DC matrix (decided once at gpf_create)
   DevArr<double> d_init_inj;
   DevArr<int> d_init_topo, d_init_shunt_bus;
@@ -754,6 +758,53 @@ extern "C" {
 const char* gpf_last_error(void) { return g_err.c_str(); }
 int gpf_version(void) { return GPF_ABI_VERSION; }
 
+// ---- grid-specialised step kernels (gridpf_jit.hip) ----------------------------------------------------------------------------
+namespace {
+gpf::DevParamsS jit_block(gpf_engine* e) {
+  gpf::DevParamsS hp{};
+  hp.g = e->g; hp.oo = e->oo; hp.sym = e->sym_dev;
+  return hp;
+}
+}  // namespace
+
+int gpf_jit_enable(gpf_handle e, const char* src_dir, const char* cache_dir) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_jit_enable: null handle");
+  (void)hipSetDevice(e->device);
+  std::string err;
+  if (gpf_jit_configure(e->jit, src_dir, cache_dir, err) != 0) { e->jit.on = false; e->jit.message = err; return fail(GPF_E_UNSUPPORTED, err); }
+  const gpf::DevParamsS hp = jit_block(e);
+  const std::string header = gpf_jit_header(hp);
+  if (header != e->jit.header) { gpf_jit_release(e->jit); e->jit.header = header; }
+  e->jit_g = hp.g; e->jit_oo = hp.oo; e->jit_sym = hp.sym;
+  e->jit.on = true;
+  return GPF_OK;
+}
+
+int gpf_jit_disable(gpf_handle e) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_jit_disable: null handle");
+  e->jit.on = false;
+  return GPF_OK;
+}
+
+int gpf_jit_info(gpf_handle e, int64_t* counts, double* seconds, char* text, size_t cap) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_jit_info: null handle");
+  if (counts) { counts[0] = e->jit.on ? 1 : 0; counts[1] = e->jit.n_compiled; counts[2] = e->jit.n_cached; counts[3] = e->jit.n_failed; counts[4] = e->jit.n_launches; }
+  if (seconds) *seconds = e->jit.seconds;
+  if (text && cap) {
+    const std::string t = e->jit.variants + (e->jit.message.empty() ? "" : " | " + e->jit.message);
+    snprintf(text, cap, "%s", t.c_str());
+  }
+  return GPF_OK;
+}
+
+int gpf_jit_source(gpf_handle e, char* text, size_t cap, size_t* need) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_jit_source: null handle");
+  const std::string header = gpf_jit_header(jit_block(e));
+  if (need) *need = header.size() + 1;
+  if (text && cap) snprintf(text, cap, "%s", header.c_str());
+  return GPF_OK;
+}
+
 int gpf_device_count(int32_t* n_devices) {
   if (!n_devices) return fail(GPF_E_INVALID, "gpf_device_count: null");
   int n = 0;
@@ -1059,6 +1110,9 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     HIP_TRY(hipMemcpyAsync(e->thermal_limit.p, lim.data(), nl * sizeof(float), hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
   }
+  if (const char* j = getenv("GRIDPF_JIT")) {
+    if (atoi(j) > 0 && gpf_jit_enable(e, nullptr, nullptr) != GPF_OK) fprintf(stderr, "[gridpf] GRIDPF_JIT: %s\n", g_err.c_str());
+  }
   *out_h = e;
   int rc = reset_lanes_unchecked(e, 0, e->cap_lanes);
   if (rc != GPF_OK) { gpf_destroy(e); *out_h = nullptr; return rc; }
@@ -1091,6 +1145,7 @@ int gpf_destroy(gpf_handle e) {
   e->rd_u8.release(); e->rd_after.release();
   e->topo0.release(); e->done.release(); e->episode.release(); e->lane_gen_delta.release(); e->traj_rho.release(); e->traj_status.release();
   e->traj_out.release(); e->traj_topo.release(); e->traj_shb.release(); e->traj_lstat.release();
+  gpf_jit_release(e->jit);
   if (e->d_params_s) (void)hipFree(e->d_params_s);
   e->stat_dbl.release(); e->dc_inv_g.release();
   e->list_a.release(); e->list_b.release(); e->list_c.release(); e->d_classes.release();
@@ -1506,6 +1561,16 @@ int step_range(gpf_engine* e, const gpf::Bufs& b_in, int lane0, int n, int t0, i
   if (rc != GPF_OK) return rc;
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
   p.env = pb.env = e->env_on;
+  if (e->jit.on) {
+    // the literals of the specialised kernels ARE this engine's grid: any change of the grid-level part of the block switches them off
+    const gpf::DevParamsS& hp = e->h_params_s;
+    if (std::memcmp(&hp.g, &e->jit_g, sizeof(hp.g)) || std::memcmp(&hp.oo, &e->jit_oo, sizeof(hp.oo)) || std::memcmp(&hp.sym, &e->jit_sym, sizeof(hp.sym))) {
+      e->jit.on = false;
+      e->jit.message = "the grid-level parameter block changed after gpf_jit_enable: specialised kernels switched off";
+      fprintf(stderr, "[gridpf] jit: %s\n", e->jit.message.c_str());
+    }
+  }
+  p.jit = pb.jit = e->jit.on ? &e->jit : nullptr;
   HIP_TRY(gpf_launch_step_sparse(p, e->device, e->d_params_s, e->stream, n, o->max_iter, tol_pu, sa));
   if (pb.sparse_nb) HIP_TRY(gpf_launch_step_sparse(pb, e->device, e->d_params_s, e->stream, n, o->max_iter, tol_pu, sa));
   HIP_TRY(hipGetLastError());

@@ -47,6 +47,11 @@ struct GridDev {
   const double* shunt_fact;
 };
 
+// Field lists for the grid-specialised (run-time compiled) kernels, gridpf_capi.hip: jit_header().  Every scalar of the launch
+// parameter block that depends on the GRID alone is listed here; pointers and per-launch values stay run-time values.
+#define GPF_GRIDDEV_INTS(X) X(n_sub) X(n_busbar) X(nb_tot) X(n_line) X(n_gen) X(n_load) X(n_sto) X(n_shunt) X(dim_topo) X(n_inj) X(n_out) X(n_chron)
+#define GPF_GRIDDEV_DBLS(X) X(sn_mva) X(inv_sn_mva)
+
 struct Bufs {
   double* inj;                 // [B][n_inj]
   int* topo;                   // [B][dim_topo]
@@ -134,6 +139,12 @@ struct OutOff {
   int gen_p, gen_q, gen_v, gen_th, load_p, load_q, load_v, load_th, sto_p, sto_q, sto_v, sto_th, sh_p, sh_q, sh_v;
   int inj_gen_p, inj_gen_vm, inj_load_p, inj_load_q, inj_sto_p, inj_sto_q, inj_sh_p, inj_sh_q;
 };
+
+#define GPF_OUTOFF_INTS(X) X(p_or) X(q_or) X(v_or) X(a_or) X(th_or) X(p_ex) X(q_ex) X(v_ex) X(a_ex) X(th_ex) X(gen_p) X(gen_q) X(gen_v) X(gen_th) \
+  X(load_p) X(load_q) X(load_v) X(load_th) X(sto_p) X(sto_q) X(sto_v) X(sto_th) X(sh_p) X(sh_q) X(sh_v) X(inj_gen_p) X(inj_gen_vm) X(inj_load_p) \
+  X(inj_load_q) X(inj_sto_p) X(inj_sto_q) X(inj_sh_p) X(inj_sh_q)
+#define GPF_COUNT_FIELD(f) +1
+static_assert(sizeof(OutOff) == sizeof(int) * (0 GPF_OUTOFF_INTS(GPF_COUNT_FIELD)), "GPF_OUTOFF_INTS must list every field of OutOff");
 
 __host__ __device__ inline OutOff make_offsets(int nl, int ng, int nd, int ns, int nsh) {
   OutOff o;

@@ -4,7 +4,29 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <string>
+#include <vector>
+
 #include "gridpf_sparse.hpp"
+
+// Run-time specialisation of the step kernel for the engine's grid (gridpf_jit.hip); one per engine, off by default.
+struct GpfJit {
+  bool on = false;
+  std::string header;                       // gpf_jit_header() of the engine's parameter block at gpf_jit_enable
+  std::string src_dir, cache_dir, hipcc, flags;
+  uint64_t src_hash = 0;
+  std::map<unsigned, hipFunction_t> fns;    // kernel variant -> specialised kernel (nullptr: failed, ahead-of-time kernel used)
+  std::vector<hipModule_t> mods;
+  std::string variants, message;            // "<1,2,2,2,1,false,false,false> ..." loaded so far; last error
+  int n_compiled = 0, n_cached = 0, n_failed = 0;
+  long long n_launches = 0;                 // launches that went through a specialised kernel
+  double seconds = 0.0;                     // time spent compiling / loading
+};
+std::string gpf_jit_header(const gpf::DevParamsS& hp);
+int gpf_jit_configure(GpfJit& j, const char* src_dir, const char* cache_dir, std::string& err);
+void gpf_jit_release(GpfJit& j);
+hipFunction_t gpf_jit_get(GpfJit& j, int NB, int ST, int IPW, int WP, bool TC, bool YR, bool ENV);
 
 struct LaunchPlan {
   size_t lds;
@@ -20,6 +42,7 @@ struct LaunchPlan {
   bool env;          // step launches: the ENV instantiation (environment injection dynamics on): tables in global memory unless instance groups
   bool yreg;         // Ybus blocks in registers (gridpf_sparse.hpp: YR): NB == 1, 2 wavefronts per instance, tables in global memory
   int dcf;           // the LDS layout of this launch has room for the factored DC matrix (DevParamsS::dcf)
+  GpfJit* jit;       // step launches: grid-specialised kernels of the engine (nullptr / !on: ahead-of-time kernels)
   int sparse_stage;  // 0: static tables read in place (L2), 1: program + pair table + injection row in LDS, 2: everything in LDS // program staged in LDS (small grids) or streamed from L2 (keeps 3 instances per CU on 118-bus grids)
 };
 

@@ -11,6 +11,14 @@ hipError_t launch(const LaunchPlan& p, int device, const gpf::DevParamsS* d_para
   static const size_t pad = getenv("GRIDPF_LDS_PAD") ? (size_t)atoi(getenv("GRIDPF_LDS_PAD")) : 0;   // occupancy experiments only
   auto kern = &gpf::step_sparse_kernel<NB, ST, IPW, 2, WP, TC, YR, ENV>;
   const size_t lds = p.lds + pad;
+  if (p.jit && p.jit->on) {                  // grid-specialised kernel of this variant (gridpf_jit.hip), compiled on first use
+    if (hipFunction_t f = gpf_jit_get(*p.jit, NB, ST, IPW, WP, TC, YR, ENV)) {
+      const int* cls = p.cls_list;
+      void* args[] = {(void*)&d_params, (void*)&list, (void*)&cls, (void*)&max_iter, (void*)&tol_pu, (void*)&sa};
+      ++p.jit->n_launches;
+      return hipModuleLaunchKernel(f, (unsigned)((n_l + IPW - 1) / IPW), 1, 1, (unsigned)(gpf::WAVE * WP), 1, 1, (unsigned)lds, stream, args, nullptr);
+    }
+  }
   if (lds > lds_set[device & 63]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

@@ -34,6 +34,10 @@ struct StatOff {
       sto_sub, shunt_sub, pair_rc, up, prog;
   int pos_line;    // (int section) [dim_topo] line whose end sits at that topo_vect position, -1: the position of a generator / load / storage unit
 };
+#define GPF_STATOFF_INTS(X) X(n_dbl) X(n_int) X(n_int_hot) X(br_y) X(br_bdc) X(sub_vn_kv) X(shunt_fact) X(gen_min_q) X(gen_max_q) X(line_vn) X(load_vn) \
+  X(gen_vn) X(sto_vn) X(shunt_vn) X(line_ka) X(gen_qmin_tot) X(gen_qmax_tot) X(gen_cnt) X(dc_inv) X(line_or_pos) X(line_ex_pos) X(line_or_sub) \
+  X(line_ex_sub) X(br_slot) X(gen_pos) X(gen_sub) X(gen_slack) X(load_pos) X(load_sub) X(sto_pos) X(sto_sub) X(shunt_sub) X(pair_rc) X(up) X(prog) X(pos_line)
+static_assert(sizeof(StatOff) == sizeof(int) * (0 GPF_STATOFF_INTS(GPF_COUNT_FIELD)), "GPF_STATOFF_INTS must list every field of StatOff");
 // Pointer to a static table that is either staged in LDS or read in place: in place it is re-typed as a GLOBAL pointer
 // (gptr, gridpf_common.hpp) so that global_load is emitted instead of flat_load.
 template <class T, bool IN_LDS>
@@ -88,6 +92,8 @@ struct FlatDev {
   int n_fwd, n_scale, n_scale_rhs, n_back, scale_off, back_off, rhs_field0, n_words;
   int wave_closed;   // (group width 128) every destination of a pass is accumulated by ONE wavefront (FlatProg::wave_closed)
 };
+#define GPF_FLATDEV_INTS(X) X(n_fwd) X(n_scale) X(n_scale_rhs) X(n_back) X(scale_off) X(back_off) X(rhs_field0) X(n_words) X(wave_closed)
+static_assert(sizeof(FlatDev) == sizeof(int) * (0 GPF_FLATDEV_INTS(GPF_COUNT_FIELD)), "GPF_FLATDEV_INTS must list every field of FlatDev");
 // group width (threads per instance) -> index of its flat-program variant: 16, 32, 64, 128 -> 0 .. 3
 __host__ __device__ constexpr int gw_index(int gw) { return gw >= 128 ? 3 : gw >= 64 ? 2 : gw >= 32 ? 1 : 0; }
 
@@ -106,6 +112,9 @@ struct SymDev {
   const int* stat_int;      // ... and [so.n_int] ints
   StatOff so;
 };
+
+#define GPF_SYMDEV_INTS(X) X(n) X(nslot) X(nslot_y) X(n_levels) X(back_off) X(n_prog) X(scale_off) X(n_scale) X(nslot_lu) X(n_up) X(rslot0) X(back_first) \
+  X(static_connected)
 
 // Topology class (gridpf_capi.hip: build_topo_class): lanes whose substations are SPLIT do not fall back to NB = n_busbar
 // blocks -- their bus-level graph (one node per live busbar: node = substation for busbar 1, extra nodes behind) gets its
@@ -185,7 +194,24 @@ typedef short i16;
 // where they are used -- inside the phases of the LU, where that wait also drains every LDS operation in flight.  Passing a
 // value through pin_sgpr makes it opaque (no longer "a load the compiler may repeat"): it then lives in an SGPR or is spilled to
 // a VGPR lane (v_readlane, no memory wait).
+#ifndef GPF_JIT
 __device__ __forceinline__ void pin_sgpr(int& x) { x = __builtin_amdgcn_readfirstlane(x); asm volatile("" : "+s"(x)); }
+#define GPF_SPEC_G(v) do {} while (0)
+#define GPF_SPEC_OO(v) do {} while (0)
+#define GPF_SPEC_SYM(v) do {} while (0)
+#define GPF_SPEC_SO(v) do {} while (0)
+#else
+// GRID-SPECIALISED BUILD (compiled at run time for ONE grid, gridpf_capi.hip: jit_*; -include of the generated header that defines the
+// GPF_JIT_SET_* macros).  Every size of the grid, every offset into its static blob / result row / symbolic program header is a
+// literal: the loads of the parameter block, the SGPRs (and SGPR spills to VGPR lanes: v_readlane / v_writelane are VALU instructions)
+// that carried them, the address arithmetic on them and the branches on them fold away.  Same source, same arithmetic in the same
+// order: results are bit-identical to the ahead-of-time kernels (tests/test_gpu_jit.py).
+__device__ __forceinline__ void pin_sgpr(int&) {}
+#define GPF_SPEC_G(v) GPF_JIT_SET_G(v)
+#define GPF_SPEC_OO(v) GPF_JIT_SET_OO(v)
+#define GPF_SPEC_SYM(v) GPF_JIT_SET_SYM(v)
+#define GPF_SPEC_SO(v) GPF_JIT_SET_SO(v)
+#endif
 
 template <int NB>
 struct CarveP {
@@ -804,11 +830,18 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   constexpr int BS = 2 * NB;
   constexpr int B2 = BS * BS;
   GridDev g_loc = P->g;                                  // sizes pinned in registers (see pin_sgpr)
+  GPF_SPEC_G(g_loc);
   pin_sgpr(g_loc.n_sub); pin_sgpr(g_loc.n_line); pin_sgpr(g_loc.n_gen); pin_sgpr(g_loc.n_load); pin_sgpr(g_loc.n_sto);
   pin_sgpr(g_loc.n_shunt); pin_sgpr(g_loc.dim_topo); pin_sgpr(g_loc.nb_tot);
   const GridDev& g = g_loc;
   const Bufs& b = P->b;
+#ifdef GPF_JIT
+  OutOff oo_loc = P->oo;
+  GPF_SPEC_OO(oo_loc);
+  const OutOff& oo = oo_loc;
+#else
   const OutOff& oo = P->oo;
+#endif
   const int nsub = g.n_sub;
   const int nbus = TC ? S.n : nsub * NB;               // block rows x NB: substations, or the nodes of the topology class
   // BITWISE REPRODUCIBILITY with several wavefronts per instance.  The LDS applies the f64 atomics of ONE wavefront in issue order,
@@ -1868,15 +1901,23 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
 // LDS carve + static view + symbolic header of a block.  Topology-class launches (TC): the header and the graph-dependent
 // tables come from the class of the block's lanes (the host packs lanes of ONE class into a block), LDS is sized for the
 // largest class of the launch.
+#ifdef GPF_JIT
+#define GPF_GRID_SYM Sg_loc
+#define GPF_GRID_SYM_DECL SymDev Sg_loc = P->sym; GPF_SPEC_SYM(Sg_loc); GPF_SPEC_SO(Sg_loc.so);
+#else
+#define GPF_GRID_SYM P->sym
+#define GPF_GRID_SYM_DECL
+#endif
 #define GPF_CARVE_AND_VIEW(G_)                                                                                                   \
-  SymDev S_loc = P->sym;                                                                                                         \
-  if (TC) S_loc = P->classes[gptr(lane_class)[blockIdx.x * IPW]].sym;                                                            \
+  GPF_GRID_SYM_DECL                                                                                                              \
+  SymDev S_loc = GPF_GRID_SYM;                                                                                                   \
+  if (TC) { S_loc = P->classes[gptr(lane_class)[blockIdx.x * IPW]].sym; GPF_SPEC_SO(S_loc.so); }                                 \
   pin_sgpr(S_loc.n); pin_sgpr(S_loc.nslot); pin_sgpr(S_loc.nslot_y); pin_sgpr(S_loc.back_off);                                  \
   pin_sgpr(S_loc.scale_off); pin_sgpr(S_loc.n_scale); pin_sgpr(S_loc.back_first); pin_sgpr(S_loc.static_connected);              \
   pin_sgpr(S_loc.rslot0); pin_sgpr(S_loc.n_up);                                                                                 \
   const SymDev& S = S_loc;                                                                                                       \
-  const int lds_rows = TC ? P->tc_rows : -1, lds_nslot = TC ? P->tc_nslot : (NB == 1 ? P->sym.nslot : P->sym.nslot_lu),                                        \
-            lds_nslot_y = YR ? 0 : TC ? P->tc_nslot_y : P->sym.nslot_y;      /* YR: the Ybus blocks live in registers */          \
+  const int lds_rows = TC ? P->tc_rows : -1, lds_nslot = TC ? P->tc_nslot : (NB == 1 ? GPF_GRID_SYM.nslot : GPF_GRID_SYM.nslot_lu),                                        \
+            lds_nslot_y = YR ? 0 : TC ? P->tc_nslot_y : GPF_GRID_SYM.nslot_y;      /* YR: the Ybus blocks live in registers */          \
   const bool lds_dcf = P->dcf != 0;                                                                                              \
   const size_t per_inst = lds_bytes_instance<NB>(G_, lds_nslot, lds_nslot_y, STAGE != 0, lds_rows, lds_dcf);                     \
   carve_sparse<NB>(c, smem + (size_t)grp * per_inst, G_, lds_nslot, lds_nslot_y, STAGE != 0, lds_rows, lds_dcf);                 \
@@ -1886,7 +1927,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   pin_sgpr(F_loc.back_off); pin_sgpr(F_loc.rhs_field0);                                                                          \
   const FlatDev& FL = F_loc;                                                                                                     \
   StatView<STAGE> sv;                                                                                                            \
-  make_stat_view<STAGE, NB == 1>(sv, P->sym, smem + (size_t)IPW * per_inst, S_loc.flat[GWI], IPW > 1 ? 0 : F_loc.n_words);        \
+  make_stat_view<STAGE, NB == 1>(sv, GPF_GRID_SYM, smem + (size_t)IPW * per_inst, S_loc.flat[GWI], IPW > 1 ? 0 : F_loc.n_words);        \
   if (TC) {                                                                                                                      \
     const TopoClassDev& tc_ = P->classes[gptr(lane_class)[blockIdx.x * IPW]];                                              \
     sv.pair_rc.p = tc_.pair_rc; sv.up.p = tc_.up; sv.br_slot.p = tc_.br_slot; sv.node_of.p = tc_.node_of;                        \
@@ -1902,7 +1943,14 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   // contiguous range, or (mixed batches) a device list of lanes; both padded by the host with ghost lanes to a multiple of IPW
   const int inst = lane_list ? gptr(lane_list)[blockIdx.x * IPW + grp] : lane0 + blockIdx.x * IPW + grp;
   CarveP<NB> c;
-  GPF_CARVE_AND_VIEW(P->g);
+#ifdef GPF_JIT
+  GridDev g_k = P->g;
+  GPF_SPEC_G(g_k);
+  const GridDev& g = g_k;
+#else
+  const GridDev& g = P->g;
+#endif
+  GPF_CARVE_AND_VIEW(g);
   double2 yreg[2 * YR_PASSES + 1];
   unsigned rcreg[2 * YR_PASSES];
   int n_iter, nb;
@@ -1915,7 +1963,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const De
   ts.status = 0; ts.nb = 0; ts.dc_base = false; ts.dc_out = -1; ts.gen_base = false; ts.tc[0] = ts.tc[1] = -1;
   const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, is_dc, max_iter, tol_pu, tid, ctl, ts, n_iter, nb, a_first GPF_STAMPS_ARG);
   GPF_SYNC();
-  if (st != 0) write_nan_results<GW>(P->g, P->b, inst, tid, inst, false);
+  if (st != 0) write_nan_results<GW>(g, P->b, inst, tid, inst, false);
   if (tid == 0) {
     const auto s = gptr(P->b.status) + (size_t)inst * 4;
     s[0] = st; s[1] = n_iter; s[2] = nb; s[3] = 0;
@@ -2167,9 +2215,18 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   typedef Grp<IPW, WPI> G;
   constexpr int GW = G::GW;
+#ifdef GPF_JIT
+  GridDev g_k = P->g;
+  GPF_SPEC_G(g_k);
+  const GridDev& g = g_k;
+  OutOff oo_k = P->oo;
+  GPF_SPEC_OO(oo_k);
+  const OutOff& oo = oo_k;
+#else
   const GridDev& g = P->g;
-  const Bufs& b = P->b;
   const OutOff& oo = P->oo;
+#endif
+  const Bufs& b = P->b;
   const int grp0 = threadIdx.x / GW, tid0 = threadIdx.x % GW;
   const int inst0 = lane_list ? gptr(lane_list)[blockIdx.x * IPW + grp0] : sa.lane0 + blockIdx.x * IPW + grp0;   // ghost-padded by the host
   int grp = grp0, tid = tid0, inst = inst0;

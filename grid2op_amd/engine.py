@@ -707,6 +707,82 @@ class PowerFlowEngine:
         check(self._lib.gpf_get_kernel_time(self._h, C.byref(ms), C.byref(n)), "gpf_get_kernel_time")
         return ms.value, n.value
 
+    def specialize(self, enable: bool = True, cache_dir: str = None, verify: bool = True) -> dict:
+        """Switch the engine's step launches (`step`, `simulate_batch`) to kernels compiled AT RUN TIME FOR THIS GRID
+        (gpf_jit_enable): every size and table offset of the grid is a literal in them instead of a value read from the
+        launch parameter block.  The first launch of each kernel variant compiles it (hipcc, about a second; cached on disk per
+        grid in ``cache_dir`` / $GRIDPF_JIT_CACHE / ``grid2op_amd/_jit_cache``); results are bit-identical to the shipped kernels.
+        ``verify`` (default): before this engine is switched, a 64-lane twin engine of the same grid runs two 8-step launches
+        (synthetic chronics around the grid's own injections, load jitter, generation rebalancing) with the shipped and with
+        the specialised kernels, and every result must agree bit for bit -- a specialised kernel is a new binary, and a binary
+        is only trusted after it reproduced the validated one; on a mismatch the engine keeps the shipped kernels and
+        `GridPFError` is raised.  Raises `GridPFError` too when no hipcc is available (shipped kernels stay)."""
+        if not enable:
+            check(self._lib.gpf_jit_disable(self._h), "gpf_jit_disable")
+            return self.specialization()
+        if verify:
+            self._verify_specialization(cache_dir)
+        src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc").encode()
+        check(self._lib.gpf_jit_enable(self._h, src, cache_dir.encode() if cache_dir else None), "gpf_jit_enable")
+        return self.specialization()
+
+    def _verify_specialization(self, cache_dir=None, n_lanes: int = 64, n_steps: int = 8, T: int = 24):
+        twin = PowerFlowEngine(self.model, n_lanes=n_lanes, device=self.device, n_busbar=self.n_busbar)
+        try:
+            sl, inj = twin.inj_slices, twin.init_inj
+            m = self.model
+            w = 1.0 + 0.04 * np.sin(0.7 * np.arange(T))[:, None]
+            load_p = inj[sl["load_p"]][None, :] * w
+            load_q = inj[sl["load_q"]][None, :] * w
+            prod_p = inj[sl["gen_p"]][None, :] * w
+            prod_v = np.tile((inj[sl["gen_vm"]] * m.sub_vn_kv[m.gen_sub])[None, :], (T, 1))
+            twin.upload_chronics(twin.pack_chronics(load_p, load_q, prod_p, prod_v))
+            rng = np.random.default_rng(0)
+            twin.set_lane_chronics(lane_offset=(5 * np.arange(n_lanes) % T).astype(np.int32),
+                                   lane_scale=(1.0 + 0.03 * rng.standard_normal((n_lanes, 2 * m.n_load))).astype(np.float32))
+
+            def run():
+                twin.reset()
+                twin.set_trajectory(n_steps, twin.TRAJ_OBS)
+                got = []
+                for k in range(2):
+                    twin.step(k * n_steps, n_steps=n_steps, rebalance=1.02, auto_reset=True)
+                    r = twin.results()
+                    got += [r.out, r.topo_vect, r.status, r.bus_vm, r.bus_va] + [x.out for x in twin.trajectory_obs(n_steps)]
+                return got
+
+            ref = run()
+            src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc").encode()
+            check(twin._lib.gpf_jit_enable(twin._h, src, cache_dir.encode() if cache_dir else None), "gpf_jit_enable")
+            got = run()
+            info = twin.specialization()
+            if info["launches"] == 0:
+                raise GridPFError(f"specialised kernels could not be built for this grid ({info['variants']}): the shipped kernels stay")
+            bad = [i for i, (a, b) in enumerate(zip(ref, got)) if not np.array_equal(a, b, equal_nan=True)]
+            if bad:
+                raise GridPFError(f"specialised kernels {info['variants']} do NOT reproduce the shipped kernels on the {n_lanes}-lane self-test "
+                                  f"({len(bad)} of {len(ref)} result arrays differ): the shipped kernels stay")
+        finally:
+            twin.close()
+
+    def specialization(self) -> dict:
+        """State of the run-time specialised kernels (gpf_jit_info): enabled, variants compiled / taken from the cache / failed,
+        launches that went through them, seconds spent compiling + loading, the variants' template arguments."""
+        counts = (C.c_int64 * 5)()
+        sec = C.c_double()
+        text = C.create_string_buffer(2048)
+        check(self._lib.gpf_jit_info(self._h, counts, C.byref(sec), text, len(text)), "gpf_jit_info")
+        return {"enabled": bool(counts[0]), "compiled": int(counts[1]), "cached": int(counts[2]), "failed": int(counts[3]),
+                "launches": int(counts[4]), "seconds": float(sec.value), "variants": text.value.decode()}
+
+    def specialization_header(self) -> str:
+        """The generated header the specialised kernels are compiled with (gpf_jit_source): this grid's numbers as C literals."""
+        need = C.c_size_t()
+        check(self._lib.gpf_jit_source(self._h, None, 0, C.byref(need)), "gpf_jit_source")
+        buf = C.create_string_buffer(need.value + 1)
+        check(self._lib.gpf_jit_source(self._h, buf, len(buf), None), "gpf_jit_source")
+        return buf.value.decode()
+
     def plan(self) -> dict:
         """Diagnostics: the kernel configuration a launch over all lanes would use right now (gpf_get_plan)."""
         out = (C.c_int32 * 8)()

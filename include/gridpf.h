@@ -30,6 +30,7 @@ extern "C" {
 #define GPF_E_INVALID (-1)   /* bad argument                                  */
 #define GPF_E_DEVICE (-2)    /* HIP runtime error (no device, OOM, launch)    */
 #define GPF_E_CAPACITY (-3)  /* grid too large for the compiled kernels       */
+#define GPF_E_UNSUPPORTED (-4) /* optional facility not available on this host (gpf_jit_enable without hipcc) */
 
 /* per-lane solver status written by gpf_runpf / gpf_step (status[lane*4 + 0]) */
 #define GPF_ST_CONVERGED 0
@@ -103,7 +104,7 @@ const char* gpf_last_error(void);
 /* ABI version of the library = GPF_ABI_VERSION of the header it was built from.  A binding MUST compare the two before any other
  * call (grid2op_amd/_capi.py does): 300 = round 4 (gpf_set_trajectory(h, cap, what), 22 device pointers, GPF_ST_REDISPATCH,
  * gpf_device_pointers_n). */
-#define GPF_ABI_VERSION 300
+#define GPF_ABI_VERSION 310
 int gpf_version(void);
 /* Bitwise run-to-run reproducibility is the DEFAULT on every grid: the same lane inputs give bit-identical results from run to
  * run and whatever the lane's position in the batch (grid2op's determinism contract: same seeds -> same episode,
@@ -397,6 +398,28 @@ int gpf_device_pointers(gpf_handle h, void** ptrs /* [GPF_N_DEVICE_POINTERS] */,
 /* The same with the length of the caller's array: entries beyond n_ptrs are not written, entries beyond the library's count are
  * NULL -- a caller built against an older / newer header cannot be overrun. */
 int gpf_device_pointers_n(gpf_handle h, void** ptrs, int32_t n_ptrs, void** stream);
+
+/* ---- grid-specialised step kernels (run-time compilation; grid2op_amd/csrc/gridpf_jit.hip) -------------------------------------
+ * The shipped (ahead-of-time) kernels serve every grid: sizes, offsets of the static tables / result rows and the header of the
+ * symbolic program reach them through a parameter block.  gpf_jit_enable() switches the engine's STEP launches (gpf_step,
+ * gpf_step_n, gpf_simulate_batch) to kernels compiled for THIS grid, in which those numbers are literals: at the first launch of
+ * each kernel variant the library writes a header with the grid's numbers, compiles the unchanged kernel source of
+ * <src_dir>/gridpf_sparse.hpp for that variant (hipcc --genco, ~20-40 s), loads the code object and launches it from then on;
+ * code objects are cached in <cache_dir> by a hash of header + variant + sources, so a grid is compiled once per machine.
+ * Results are BIT-IDENTICAL to the ahead-of-time kernels (same source, same arithmetic in the same order).  Nothing else changes: same
+ * buffers, same calls; gpf_runpf / gpf_solve_lane keep the ahead-of-time kernels.
+ *   src_dir   directory with the kernel sources (NULL: "csrc" next to the library)
+ *   cache_dir NULL: $GRIDPF_JIT_CACHE, else "_jit_cache" next to the library
+ * The compiler is $GRIDPF_HIPCC, else /opt/rocm/bin/hipcc, else hipcc on PATH; GPF_E_UNSUPPORTED when it does not run or the sources are
+ * absent -- the engine then simply keeps the ahead-of-time kernels.  A variant that fails to compile / load is reported on stderr and
+ * in gpf_jit_info and runs ahead-of-time.  GRIDPF_JIT=1 in the environment enables it at gpf_create. */
+int gpf_jit_enable(gpf_handle h, const char* src_dir, const char* cache_dir);
+int gpf_jit_disable(gpf_handle h);
+/* counts[5] = {enabled, variants compiled, variants loaded from the cache, variants failed, launches through specialised kernels};
+ * seconds = time spent compiling / loading; text = the variants loaded so far (+ the last error).  Any pointer may be NULL. */
+int gpf_jit_info(gpf_handle h, int64_t* counts, double* seconds, char* text, size_t cap);
+/* the header the specialised kernels are compiled with (one grid's numbers as C literals); *need = bytes incl. the terminator */
+int gpf_jit_source(gpf_handle h, char* text, size_t cap, size_t* need);
 
 #ifdef __cplusplus
 }
