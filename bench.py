@@ -190,6 +190,7 @@ class Ctx:
         self.dist = None
         self.torch = None
         self.red_dev = None
+        self.engines, self.jit_verified, self.jit_errors, self.jit_closed = [], set(), [], []
         try:
             import torch
             self.torch = torch
@@ -229,7 +230,51 @@ class Ctx:
             from stub_engine import StubEngine           # launcher test hook (CPU): no arithmetic, see tests/stub_engine.py
             return StubEngine(m, n_lanes=n_lanes, device=self.device)
         from grid2op_amd.engine import PowerFlowEngine
-        return PowerFlowEngine(m, n_lanes=n_lanes, device=self.device)
+        eng = PowerFlowEngine(m, n_lanes=n_lanes, device=self.device)
+        if not self.args.no_jit:
+            # step kernels compiled for THIS grid (gpf_jit_enable): the first engine of each grid runs the library's self-test of the
+            # specialised kernels against the shipped ones (64-lane twin, bit-for-bit); compilation happens at the first launch of each
+            # kernel variant, i.e. in the untimed warm-up, and is cached on disk
+            key = (m.n_sub, m.n_line, m.n_gen, m.n_load, getattr(m, "name", None))
+            try:
+                eng.specialize(True, verify=key not in self.jit_verified)
+                self.jit_verified.add(key)
+            except Exception as exc:                 # no hipcc on this host / self-test failed: shipped kernels, said so in the JSON
+                self.jit_errors.append(str(exc)[:300])
+        self.engines.append(eng)
+        orig_close = eng.close
+
+        def close_and_remember():               # the workloads close their engines: keep what they launched for the record
+            try:
+                self.jit_closed.append(eng.specialization())
+            except Exception:
+                pass
+            if eng in self.engines:
+                self.engines.remove(eng)
+            orig_close()
+        eng.close = close_and_remember
+        return eng
+
+    def specialization(self):
+        """what the engines of this run launched: shipped kernels or kernels specialised at run time (summed over the engines)"""
+        tot = {"enabled": False, "compiled": 0, "cached": 0, "failed": 0, "launches": 0, "seconds": 0.0, "variants": []}
+        infos = list(self.jit_closed)
+        for e in self.engines:
+            if hasattr(e, "specialization"):
+                try:
+                    infos.append(e.specialization())
+                except Exception:
+                    pass
+        for i in infos:
+            tot["enabled"] = tot["enabled"] or i["enabled"]
+            for k in ("compiled", "cached", "failed", "launches"):
+                tot[k] += i[k]
+            tot["seconds"] += i["seconds"]
+            for v in i["variants"].split(" | ")[0].split():
+                if v not in tot["variants"]:
+                    tot["variants"].append(v)
+        tot["errors"] = self.jit_errors or None
+        return tot
 
 
 def load_env(name):
@@ -322,6 +367,7 @@ def timed_windows(ctx, eng, steps, warmup, step_kw, n_windows, t0=0, preroll_ste
         eng.set_profiling(1)     # ONE HIP event pair on the engine's stream around the K timed launches (no per-launch events)
         w0 = time.perf_counter()
         t = run_steps(eng, t, steps, step_kw, spl)
+        eng.set_profiling(3)     # the event window ends right behind the last launch (not when it is read, after the barrier)
         ctx.sync_all(eng)
         el = time.perf_counter() - w0
         k_ms, n_l = eng.kernel_time()
@@ -433,6 +479,10 @@ def main():
     ap.add_argument("--profile", action="store_true",
                     help="developer (rocprofv3 runs): no pre-roll launches of odd sizes and no last-observation-only sibling windows, so that "
                          "every dispatch of the step kernel is a full --steps-per-launch launch with the observation trajectory on")
+    ap.add_argument("--no-jit", action="store_true",
+                    help="run on the shipped (ahead-of-time) kernels only.  Default: the engines switch their step launches to kernels compiled at run "
+                         "time for the workload's grid (gpf_jit_enable: sizes / offsets as literals, bit-identical results, self-tested against the "
+                         "shipped kernels); the shipped-kernel headline is then reported beside it as `shipped_kernels`")
     ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)   # CPU launcher test: no arithmetic
     args = ap.parse_args()
     if args.gpus < 1:
@@ -461,6 +511,7 @@ def main():
                "secondary_env_dynamics": lambda: workload_wcci_dynamics(ctx, "l2rpn_wcci_2022_dev", 1024, k_o, w_o),
                "dc_ptdf": lambda: workload_ptdf(ctx, "l2rpn_idf_2023", 2048, 50, k_sec=k_o, w_sec=w_o)}[args.only]()
         if rank == 0:
+            rec["specialization"] = ctx.specialization()
             print(json.dumps(rec))
         return
     m, ch = load_env(args.env)
@@ -564,6 +615,18 @@ def main():
 
     def sib(w_last, n_lanes_total, k):
         return None if w_last is None else dict(summarize(w_last, n_lanes_total * k), unit="env steps/sec", observations=OBS_LAST)
+
+    # ---- the same workload, same engine, same state on the SHIPPED (ahead-of-time) kernels ------------------------------------------
+    jit_on = (not args.stub_engine) and hasattr(eng, "specialization") and eng.specialization()["enabled"]
+    if jit_on and not args.profile:
+        eng.specialize(False)
+        w, _ = timed_windows(ctx, eng, k_sec, w_sec, step_kw, 3, preroll_steps=0)
+        eng.specialize(True, verify=False)
+        if rank == 0:
+            res["shipped_kernels"] = dict(summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec, observations=res["config"]["observations"],
+                                          us_per_step=median_window(w)[0] / k_sec * 1e6,
+                                          note="the headline workload on the kernels libgridpf.so ships (grid sizes / offsets read from the launch "
+                                               "parameter block); `value` runs the same source compiled at run time with this grid's numbers as literals")
 
     # ---- the same workload WITHOUT the observation trajectory: only the last observation of each launch exists in HBM --------
     if secondary and obs_every_step:
@@ -709,6 +772,12 @@ def main():
         if not args.no_cpu_baseline and world == 1 and not args.stub_engine:
             res["cpu_baseline"] = cpu_baseline(args.env, m, ch, T)
             res["cpu_baseline"]["reference_environment_step_loop"] = reference_step_loop()
+        res["specialization"] = dict(ctx.specialization(),
+                                     what="step kernels compiled at run time for each workload's grid (gpf_jit_enable: hipcc --genco of the unchanged "
+                                          "kernel source with the grid's sizes / table offsets as literals; results bit-identical to the shipped "
+                                          "kernels, self-tested at enable time; compile + load seconds are outside every timed region)"
+                                     if not args.no_jit else "off (--no-jit): shipped kernels")
+        res["config"]["kernels"] = ("grid-specialised at run time (gpf_jit_enable)" if res["specialization"].get("launches") else "shipped (ahead-of-time)")
         print(json.dumps(res), flush=True)
     if ctx.dist is not None:
         ctx.dist.barrier()

@@ -254,6 +254,7 @@ struct gpf_engine {
   bool profiling = false;      // per-launch event pairs (gpf_set_profiling(h, 2))
   bool window = false;         // one event pair around a window of launches (gpf_set_profiling(h, 1))
   hipEvent_t win_a = nullptr, win_b = nullptr;
+  bool win_marked = false;              // win_b was recorded by gpf_set_profiling(3) behind the last launch of the window
   long long win_launches = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
@@ -1338,7 +1339,7 @@ int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
   if (pb.sparse_nb) HIP_TRY(gpf_launch_runpf_sparse(pb, e->device, e->d_params_s, e->stream, lane0, n, is_dc, max_iter, tol_pu));
   HIP_TRY(hipGetLastError());
   if (e->profiling) HIP_TRY(hipEventRecord(eb, e->stream));
-  if (e->window) ++e->win_launches;
+  if (e->window) { ++e->win_launches; e->win_marked = false; }
   return GPF_OK;
 }
 
@@ -1405,7 +1406,7 @@ int gpf_solve_lane(gpf_handle e, int32_t lane, const double* inj, const int32_t*
   const double tol_pu = tol_mva / g.sn_mva;
   HIP_TRY(gpf_launch_runpf_sparse(p, e->device, e->d_params_s, st, lane, 1, is_dc, max_iter, tol_pu));
   if (pb.sparse_nb) HIP_TRY(gpf_launch_runpf_sparse(pb, e->device, e->d_params_s, st, lane, 1, is_dc, max_iter, tol_pu));
-  if (e->window) ++e->win_launches;
+  if (e->window) { ++e->win_launches; e->win_marked = false; }
 #define DL1(off, arr, stride, bytes_per) \
   if ((stride) > 0) HIP_TRY(hipMemcpyAsync(P + (off), e->arr.p + (size_t)lane * (stride), (size_t)(stride) * (bytes_per), hipMemcpyDeviceToHost, st))
   DL1(o_out, out, g.n_out, 4); DL1(o_tv, topo_out, g.dim_topo, 4); DL1(o_sbo, shunt_bus_out, g.n_shunt, 4); DL1(o_ls, line_status, g.n_line, 1);
@@ -1575,7 +1576,7 @@ int step_range(gpf_engine* e, const gpf::Bufs& b_in, int lane0, int n, int t0, i
   if (pb.sparse_nb) HIP_TRY(gpf_launch_step_sparse(pb, e->device, e->d_params_s, e->stream, n, o->max_iter, tol_pu, sa));
   HIP_TRY(hipGetLastError());
   if (e->profiling) HIP_TRY(hipEventRecord(eb, e->stream));
-  if (e->window) ++e->win_launches;
+  if (e->window) { ++e->win_launches; e->win_marked = false; }
   return GPF_OK;
 }
 
@@ -2049,7 +2050,7 @@ int gpf_sync(gpf_handle e) {
 static int close_window(gpf_engine* e) {
   if (!e->window) return GPF_OK;
   if (e->win_launches > 0) {
-    HIP_TRY(hipEventRecord(e->win_b, e->stream));
+    if (!e->win_marked) HIP_TRY(hipEventRecord(e->win_b, e->stream));     // (mode 3 already recorded it behind the last launch)
     HIP_TRY(hipEventSynchronize(e->win_b));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e->win_a, e->win_b));
@@ -2058,6 +2059,7 @@ static int close_window(gpf_engine* e) {
   }
   e->win_launches = 0;
   e->window = false;
+  e->win_marked = false;
   return GPF_OK;
 }
 
@@ -2066,12 +2068,17 @@ static int open_window(gpf_engine* e) {
   HIP_TRY(hipEventRecord(e->win_a, e->stream));
   e->win_launches = 0;
   e->window = true;
+  e->win_marked = false;
   return GPF_OK;
 }
 
 int gpf_set_profiling(gpf_handle e, int32_t mode) {
   if (!e) return fail(GPF_E_INVALID, "gpf_set_profiling: null");
   HIP_TRY(hipSetDevice(e->device));
+  if (mode == 3) {                      // end of the running window = this point of the stream (asynchronous; read by the next call)
+    if (e->window && e->win_launches > 0) { HIP_TRY(hipEventRecord(e->win_b, e->stream)); e->win_marked = true; }
+    return GPF_OK;
+  }
   int rc = close_window(e);
   if (rc != GPF_OK) return rc;
   e->profiling = mode == 2;
@@ -2241,7 +2248,7 @@ int gpf_ptdf_flows(gpf_handle e, int32_t lane0, int32_t n) {
   hipLaunchKernelGGL(gpf::ptdf_flows_kernel, dim3((n + 15) / 16, (P.line_pad / 16 + 3) / 4), dim3(256), lds_a, e->stream, P, e->inj.p, lane0, n,
                      e->ptdf_flow.p);
   HIP_TRY(hipGetLastError());
-  if (e->window) ++e->win_launches;
+  if (e->window) { ++e->win_launches; e->win_marked = false; }
   return GPF_OK;
 }
 
@@ -2286,7 +2293,7 @@ int gpf_ptdf_flows_rows(gpf_handle e, int32_t t0, int32_t n_rows, double rebalan
 #undef GPF_PTDF_ROWS
   HIP_TRY(hipGetLastError());
   e->ptdf_rows_valid = n_rows;
-  if (e->window) ++e->win_launches;
+  if (e->window) { ++e->win_launches; e->win_marked = false; }
   return GPF_OK;
 }
 
@@ -2332,7 +2339,7 @@ int gpf_lodf_screen(gpf_handle e, int32_t lane0, int32_t n, const float* cap_mw,
   hipLaunchKernelGGL(gpf::lodf_screen_kernel, dim3((n + gpf::LODF_LPW - 1) / gpf::LODF_LPW), dim3(256), lds, e->stream, nl, lp, e->lodf.p, ic,
                      e->ptdf_flow.p, lane0, n, e->lodf_worst.p + (size_t)lane0 * lp);
   HIP_TRY(hipGetLastError());
-  if (e->window) ++e->win_launches;
+  if (e->window) { ++e->win_launches; e->win_marked = false; }
   HIP_TRY(hipMemcpy2DAsync(worst, (size_t)nl * sizeof(float), e->lodf_worst.p + (size_t)lane0 * lp, (size_t)lp * sizeof(float),
                            (size_t)nl * sizeof(float), (size_t)n, hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));

@@ -698,7 +698,8 @@ class PowerFlowEngine:
 
     def set_profiling(self, mode):
         """0/False: off; 1/True: one HIP event pair around the window of launches up to the next ``kernel_time()``;
-        2: an event pair per launch (exact per-kernel durations, costs ~7 us of stream time per launch)."""
+        2: an event pair per launch (exact per-kernel durations, costs ~7 us of stream time per launch); 3 (inside a window): the
+        window ends at this point of the stream (recorded asynchronously behind the launches issued so far)."""
         check(self._lib.gpf_set_profiling(self._h, int(mode)), "gpf_set_profiling")
 
     def kernel_time(self) -> Tuple[float, int]:

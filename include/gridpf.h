@@ -103,7 +103,7 @@ typedef struct gpf_layout {
 const char* gpf_last_error(void);
 /* ABI version of the library = GPF_ABI_VERSION of the header it was built from.  A binding MUST compare the two before any other
  * call (grid2op_amd/_capi.py does): 300 = round 4 (gpf_set_trajectory(h, cap, what), 22 device pointers, GPF_ST_REDISPATCH,
- * gpf_device_pointers_n). */
+ * gpf_device_pointers_n); 310 = + gpf_jit_*, GPF_E_UNSUPPORTED, gpf_set_profiling mode 3. */
 #define GPF_ABI_VERSION 310
 int gpf_version(void);
 /* Bitwise run-to-run reproducibility is the DEFAULT on every grid: the same lane inputs give bit-identical results from run to
@@ -377,7 +377,10 @@ int gpf_sync(gpf_handle h);
  * launches issued until the next gpf_get_kernel_time / gpf_set_profiling call -- no per-launch events, so back-to-back
  * launches stay back-to-back (a per-launch pair costs ~7 us of stream time per launch on MI355X); the window time divided
  * by the launch count is the average launch duration when the stream never runs dry.  mode 2: every launch is bracketed
- * by its own event pair (exact per-kernel durations, perturbs throughput). */
+ * by its own event pair (exact per-kernel durations, perturbs throughput).  mode 3 (inside a window): the window ENDS at this
+ * point of the stream -- the closing event is recorded right behind the launches issued so far (asynchronous, no wait), so that
+ * host work between the last launch and the next gpf_get_kernel_time (a barrier with other ranks, say) is not part of the window;
+ * without it the window ends when gpf_get_kernel_time / gpf_set_profiling is called. */
 int gpf_set_profiling(gpf_handle h, int32_t mode);
 /* Sum of the event-measured durations (ms) and number of solver launches since the last call (closes the running
  * window of mode 1 and opens the next one). */

@@ -22,6 +22,7 @@ class A:
     share_device = False
     dist_backend = "gloo"
     stub_engine = False
+    no_jit = True
 
 
 def run(name, B, jit):
@@ -30,7 +31,7 @@ def run(name, B, jit):
     eng, T, _ = bench.setup_engine(ctx, m, ch, B)
     info = None
     if jit:
-        eng.specialize(True, cache_dir=os.path.join(OUT, "cache"))
+        eng.specialize(True, cache_dir=os.path.join(OUT, "cache"), verify=False)
     eng.set_trajectory(16, eng.TRAJ_OBS)
     kw = dict(rebalance=1.02, cascade=False, auto_reset=True)
     t0 = time.time()
@@ -59,7 +60,7 @@ def run(name, B, jit):
 
 
 grids = sys.argv[1:] or ["l2rpn_case14_sandbox", "l2rpn_neurips_2020_track1", "l2rpn_wcci_2022_dev"]
-for name, B in [(g, 4096 if "case14" in g else 1024) for g in grids]:
+for name, B in [(g, int(os.environ.get("JIT_PROBE_LANES", 4096 if "case14" in g else 1024))) for g in grids]:
     a, dta, fa, _, plan = run(name, B, False)
     for flags in os.environ.get("JIT_PROBE_FLAGS", "|-fno-unroll-loops").split("|"):
         os.environ["GRIDPF_JIT_FLAGS"] = flags
