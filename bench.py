@@ -237,7 +237,7 @@ class Ctx:
             # kernel variant, i.e. in the untimed warm-up, and is cached on disk
             key = (m.n_sub, m.n_line, m.n_gen, m.n_load, getattr(m, "name", None))
             try:
-                eng.specialize(True, verify=key not in self.jit_verified)
+                eng.specialize(True, verify=key not in self.jit_verified and not self.args.profile)   # (--profile: no twin-engine dispatches in the trace)
                 self.jit_verified.add(key)
             except Exception as exc:                 # no hipcc on this host / self-test failed: shipped kernels, said so in the JSON
                 self.jit_errors.append(str(exc)[:300])

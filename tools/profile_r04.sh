@@ -4,10 +4,12 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 cd $R
+STATS_EXTRA="--steps 480 --warmup 480"     # (argparse: the last occurrence wins)
 prof() {   # label, algorithmic bytes per launch, kernel filter, pmc-set list, bench args...
   label=$1; alg=$2; kf=$3; sets=$4; shift 4
   O=$R/gpurun_out/prof/$label; mkdir -p $O
-  rocprofv3 --kernel-trace --stats -d $O/stats -- python bench.py --profile --no-cpu-baseline --no-oracle-check "$@" > $O/stats.log 2>&1
+  # the duration pass runs 10x the launches of the counter passes: an idle MI355X needs tens of milliseconds of work to reach its clocks
+  rocprofv3 --kernel-trace --stats -d $O/stats -- python bench.py --profile --no-cpu-baseline --no-oracle-check "$@" $STATS_EXTRA > $O/stats.log 2>&1
   dbs=""
   for set in $sets; do
     name=${set%%:*}; ctrs=$(echo ${set#*:} | tr ',' ' ')
