@@ -1095,7 +1095,10 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   auto dcinv = [&](int idx) -> double { return S.so.dc_inv >= 0 ? sv.dc_inv[idx] : sv.dc_inv_g[idx]; };
   // operand pairs of the static-inverse matrix-vector product in flight per trip (the one-instance kernels live on 3 waves per SIMD
   // at <= 168 VGPRs: 4 pairs there)
-  constexpr int MVC = IPW > 1 ? 8 : 4;
+#ifndef GPF_TUNE_MVC
+#define GPF_TUNE_MVC 4        /* operand pairs in flight in the static-DC-inverse product of the one-instance kernels (-D: experiments) */
+#endif
+  constexpr int MVC = IPW > 1 ? 8 : GPF_TUNE_MVC;
   auto lidx = [&](int bus) -> int { return (NB == 1) ? 0 : bus % NB; };
   if (!warm && !fast_pre) {
   if (!dc_skip || do_y) {
