@@ -90,7 +90,7 @@ __global__ void simulate_env_copy_kernel(EnvDyn E, int n_gen, int n_sto, const i
     E.target[d_] = E.target[s_]; E.actual[d_] = E.actual[s_]; E.prev_p[d_] = E.prev_p[s_]; E.already[d_] = E.already[s_]; E.limit[d_] = E.limit[s_];
   }
   for (int i = tid; i < n_sto; i += blockDim.x) E.charge[(size_t)dst * n_sto + i] = E.charge[(size_t)src * n_sto + i];
-  if (tid == 0) { E.amount_prev[dst] = E.amount_prev[src]; E.curt_prev[dst] = E.curt_prev[src]; E.fresh[dst] = E.fresh[src]; }
+  if (tid == 0) { E.amount_prev[dst] = E.amount_prev[src]; E.curt_prev[dst] = E.curt_prev[src]; E.fresh[dst] = E.fresh[src]; E.illegal[dst] = E.illegal[src]; }
 }
 
 }  // namespace gpf
@@ -168,6 +168,7 @@ struct gpf_engine {
   double env_coeff = 300.0 / 3600.0, env_tol = 1e-2;
   DevArr<float> env_target, env_actual, env_prev, env_charge, env_amount_prev, env_act_redisp, env_act_storage, sto_charge0;
   DevArr<float> env_limit, env_curt_prev, env_act_curtail;
+  DevArr<int> env_illegal;              // [B] cancelled (illegal) actions since the reset
   DevArr<unsigned char> env_already, env_fresh, env_renewable;
   bool env_act_c = false, env_has_ren = false;
   DevArr<double> sto_emax, sto_emin, sto_loss, sto_effc, sto_effd;
@@ -655,6 +656,7 @@ int upload_params_s(gpf_engine* e, const gpf::Bufs& b, const LaunchPlan* tc, int
     E.amount_prev = e->env_amount_prev.p; E.fresh = e->env_fresh.p;
     E.act_redisp = e->env_act_r ? e->env_act_redisp.p : nullptr; E.act_storage = e->env_act_s ? e->env_act_storage.p : nullptr;
     E.limit = e->env_limit.p; E.curt_prev = e->env_curt_prev.p; E.act_curtail = e->env_act_c ? e->env_act_curtail.p : nullptr;
+    E.illegal = e->env_illegal.p;
     E.renewable = e->env_has_ren ? e->env_renewable.p : nullptr;
     E.pmin = e->rd_pmin.p; E.pmax = e->rd_pmax.p; E.ramp_up = e->rd_ru.p; E.ramp_down = e->rd_rd.p; E.redispatchable = e->rd_redisp.p;
     E.Emax = e->sto_emax.p; E.Emin = e->sto_emin.p; E.loss = e->sto_loss.p; E.eff_c = e->sto_effc.p; E.eff_d = e->sto_effd.p; E.charge0 = e->sto_charge0.p;
@@ -703,6 +705,7 @@ int reset_env_state(gpf_engine* e, int lane0, int n) {
   HIP_TRY(hipMemsetAsync(e->env_already.p + lane0 * ng, 0, n * ng, e->stream));
   HIP_TRY(hipMemsetAsync(e->env_amount_prev.p + lane0, 0, (size_t)n * sizeof(float), e->stream));
   HIP_TRY(hipMemsetAsync(e->env_curt_prev.p + lane0, 0, (size_t)n * sizeof(float), e->stream));
+  HIP_TRY(hipMemsetAsync(e->env_illegal.p + lane0, 0, (size_t)n * sizeof(int), e->stream));
   {
     std::vector<float> ones((size_t)n * ng, 1.0f);
     HIP_TRY(hipMemcpyAsync(e->env_limit.p + lane0 * ng, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice, e->stream));
@@ -1141,7 +1144,7 @@ int gpf_destroy(gpf_handle e) {
   e->env_target.release(); e->env_actual.release(); e->env_prev.release(); e->env_charge.release(); e->env_amount_prev.release();
   e->env_act_redisp.release(); e->env_act_storage.release(); e->sto_charge0.release(); e->env_already.release(); e->env_fresh.release();
   e->sto_emax.release(); e->sto_emin.release(); e->sto_loss.release(); e->sto_effc.release(); e->sto_effd.release();
-  e->env_limit.release(); e->env_curt_prev.release(); e->env_act_curtail.release(); e->env_renewable.release();
+  e->env_limit.release(); e->env_curt_prev.release(); e->env_act_curtail.release(); e->env_renewable.release(); e->env_illegal.release();
   e->rd_pmin.release(); e->rd_pmax.release(); e->rd_ru.release(); e->rd_rd.release(); e->rd_in.release(); e->rd_redisp.release();
   e->rd_u8.release(); e->rd_after.release();
   e->topo0.release(); e->done.release(); e->episode.release(); e->lane_gen_delta.release(); e->traj_rho.release(); e->traj_status.release();
@@ -1286,7 +1289,7 @@ int gpf_copy_lanes(gpf_handle e, int32_t src, int32_t dst, int32_t n) {
   CP(overflow_count, g.n_line); CP(disc_round, g.n_line); CP(rho, g.n_line); CP(topo0, g.dim_topo); CP(done, 1); CP(episode, 2);
   if (e->env_on) {          // the environment's injection dynamics are part of the lane's state (Backend.copy / env.copy keep them)
     CP(env_target, g.n_gen); CP(env_actual, g.n_gen); CP(env_prev, g.n_gen); CP(env_already, g.n_gen); CP(env_limit, g.n_gen);
-    CP(env_charge, g.n_sto); CP(env_amount_prev, 1); CP(env_curt_prev, 1); CP(env_fresh, 1);
+    CP(env_charge, g.n_sto); CP(env_amount_prev, 1); CP(env_curt_prev, 1); CP(env_fresh, 1); CP(env_illegal, 1);
   }
 #undef CP
   for (int k = 0; k < n; ++k) { e->lane_nb[dst + k] = e->lane_nb[src + k]; e->lane_nj[dst + k] = e->lane_nj[src + k]; e->lane_mb[dst + k] = e->lane_mb[src + k]; e->lane_class[dst + k] = e->lane_class[src + k];
@@ -1310,7 +1313,7 @@ int gpf_fanout_n1(gpf_handle e, int32_t src, int32_t dst0, int32_t n_out, const 
     HIP_TRY(hipMemcpyAsync(e->sim_src.p, &src, sizeof(int), hipMemcpyHostToDevice, e->stream));
     gpf::EnvDyn E{};
     E.target = e->env_target.p; E.actual = e->env_actual.p; E.prev_p = e->env_prev.p; E.already = e->env_already.p; E.charge = e->env_charge.p;
-    E.amount_prev = e->env_amount_prev.p; E.fresh = e->env_fresh.p; E.limit = e->env_limit.p; E.curt_prev = e->env_curt_prev.p;
+    E.amount_prev = e->env_amount_prev.p; E.fresh = e->env_fresh.p; E.limit = e->env_limit.p; E.curt_prev = e->env_curt_prev.p; E.illegal = e->env_illegal.p;
     hipLaunchKernelGGL(gpf::simulate_env_copy_kernel, dim3((unsigned)n_out), dim3(64), 0, e->stream, E, e->g.n_gen, e->g.n_sto, e->sim_src.p, n_out, n_out, dst0);
     HIP_TRY(hipGetLastError());
   }
@@ -1665,7 +1668,7 @@ int gpf_set_env_dynamics(gpf_handle e, int32_t on, double tol_poly) {
     HIP_TRY(e->env_target.alloc(B * ng)); HIP_TRY(e->env_actual.alloc(B * ng)); HIP_TRY(e->env_prev.alloc(B * ng)); HIP_TRY(e->env_already.alloc(B * ng));
     HIP_TRY(e->env_charge.alloc(B * ns)); HIP_TRY(e->env_amount_prev.alloc(B)); HIP_TRY(e->env_fresh.alloc(B));
     HIP_TRY(e->env_act_redisp.alloc(B * ng)); HIP_TRY(e->env_act_storage.alloc(B * ns));
-    HIP_TRY(e->env_limit.alloc(B * ng)); HIP_TRY(e->env_curt_prev.alloc(B)); HIP_TRY(e->env_act_curtail.alloc(B * ng));
+    HIP_TRY(e->env_limit.alloc(B * ng)); HIP_TRY(e->env_curt_prev.alloc(B)); HIP_TRY(e->env_act_curtail.alloc(B * ng)); HIP_TRY(e->env_illegal.alloc(B));
     HIP_TRY(hipMemset(e->env_act_redisp.p, 0, B * ng * sizeof(float))); HIP_TRY(hipMemset(e->env_act_storage.p, 0, B * ns * sizeof(float)));
     HIP_TRY(hipMemset(e->env_charge.p, 0, B * ns * sizeof(float)));
   }
@@ -1724,6 +1727,15 @@ int gpf_get_env_state(gpf_handle e, int32_t lane0, int32_t n, float* target, flo
   DLE(target, env_target, ng); DLE(actual, env_actual, ng); DLE(prev_p, env_prev, ng); DLE(already_modified, env_already, ng);
   DLE(charge, env_charge, ns); DLE(amount_prev, env_amount_prev, 1); DLE(curtail_limit, env_limit, ng); DLE(curtail_prev, env_curt_prev, 1);
 #undef DLE
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_get_env_illegal(gpf_handle e, int32_t lane0, int32_t n, int32_t* count) {
+  if (!check_range(e, lane0, n) || !count) return fail(GPF_E_INVALID, "gpf_get_env_illegal: bad range / null");
+  if (!e->env_on) return fail(GPF_E_INVALID, "gpf_get_env_illegal: the environment dynamics are off");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(count, e->env_illegal.p + lane0, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return GPF_OK;
 }
@@ -1855,7 +1867,7 @@ int gpf_simulate_batch(gpf_handle e, int32_t t_obs, int32_t time_step, int32_t n
   if (e->env_on) {
     gpf::EnvDyn E{};
     E.target = e->env_target.p; E.actual = e->env_actual.p; E.prev_p = e->env_prev.p; E.already = e->env_already.p; E.charge = e->env_charge.p;
-    E.amount_prev = e->env_amount_prev.p; E.fresh = e->env_fresh.p; E.limit = e->env_limit.p; E.curt_prev = e->env_curt_prev.p;
+    E.amount_prev = e->env_amount_prev.p; E.fresh = e->env_fresh.p; E.limit = e->env_limit.p; E.curt_prev = e->env_curt_prev.p; E.illegal = e->env_illegal.p;
     hipLaunchKernelGGL(gpf::simulate_env_copy_kernel, dim3((unsigned)n_dst), dim3(64), 0, e->stream, E, g.n_gen, g.n_sto, e->sim_src.p, n_act,
                        (int)n_dst, dst_lane0);
     HIP_TRY(hipGetLastError());

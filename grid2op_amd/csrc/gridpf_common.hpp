@@ -112,6 +112,7 @@ struct EnvDyn {
   float* limit;                         // [B][n_gen] _limit_curtailment (ratio of pmax, 1 = not curtailed)
   float* curt_prev;                     // [B] _sum_curtailment_mw_prev
   unsigned char* fresh;                 // [B] 1: no step since the reset (nb_time_step == 0: prev_p := the step's own set-points)
+  int* illegal;                         // [B] steps since the reset whose action was cancelled as an illegal redispatch (info["is_illegal_redisp"])
   // per-lane actions of the NEXT launch [B][n_gen] / [B][n_storage]: redispatch is consumed by the first step
   const float *act_redisp, *act_storage;
   const float* act_curtail;             // [B][n_gen] curtailment action (ratio of pmax; -1 = no change), consumed by the first step

@@ -2043,6 +2043,7 @@ __device__ inline double env_root(bool act, double c, double gi, double lo, doub
 struct EnvRegs {
   float target, actual, prev_p, charge, amount_prev, limit, curt_prev;
   bool already, fresh;
+  int illegal;        // cancelled (illegal) actions since the reset: instance-uniform
 };
 // One env step of the dynamics for the caller's instance.  new_p: chronics set-point of generator `k` (after the environment's own
 // modifications); act_r / act_s: the agent's redispatch / storage action of this step for generator / unit k (0 = none).
@@ -2126,6 +2127,7 @@ __device__ inline bool env_dynamics_step(const EnvDyn& E, int k, int n_gen, int 
     const float span = is_gen ? (float)E.pmax[k] - (float)E.pmin[k] : 0.f;
     const bool illegal = busy && env_gmax<LW>((is_gen && (R.target > span || R.target < -span)) ? 1.0 : 0.0) > 0.0;
     if (illegal) {
+      ++R.illegal;
       if (is_gen) R.target -= act_r;
       if (n_sto > 0) {
         if (is_sto) R.charge = charge_before;
@@ -2269,6 +2271,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
   constexpr bool env_on = ENV && NB == 1;                       // single-busbar kernels (incl. topology classes) only
   EnvRegs er;
   er.target = er.actual = er.prev_p = er.charge = er.amount_prev = er.curt_prev = 0.f; er.limit = 1.f; er.already = false; er.fresh = true;
+  er.illegal = 0;
   float env_ar0 = 0.f, env_as0 = 0.f, env_ac0 = -1.f;
   if (env_on && tid < LWE) {
     const EnvDyn& E = P->env;
@@ -2286,6 +2289,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
     er.amount_prev = gptr(E.amount_prev)[inst];
     er.curt_prev = gptr(E.curt_prev)[inst];
     er.fresh = gptr(E.fresh)[inst] != 0;
+    er.illegal = gptr(E.illegal)[inst];
   }
   bool env_fail = false;                                       // this group's dynamics ended the episode in the current step
   // the chronics values this thread handles first (load tid, generator tid) of the NEXT step are fetched while the current step
@@ -2556,6 +2560,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       ovc_first = 0;
       if (env_on) {                                              // env.reset(): dispatch cleared, storage back to its initial charge
         er.target = er.actual = er.prev_p = er.amount_prev = er.curt_prev = 0.f; er.limit = 1.f; er.already = false; er.fresh = true;
+        er.illegal = 0;
         er.charge = (tid < g.n_sto && P->env.charge0) ? gptr(P->env.charge0)[tid] : 0.f;
       }
     }
@@ -2591,7 +2596,10 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       gptr(E.limit)[q] = er.limit;
     }
     if (tid < g.n_sto) gptr(E.charge)[(size_t)inst * g.n_sto + tid] = er.charge;
-    if (tid == 0) { gptr(E.amount_prev)[inst] = er.amount_prev; gptr(E.curt_prev)[inst] = er.curt_prev; gptr(E.fresh)[inst] = er.fresh ? 1 : 0; }
+    if (tid == 0) {
+      gptr(E.amount_prev)[inst] = er.amount_prev; gptr(E.curt_prev)[inst] = er.curt_prev; gptr(E.fresh)[inst] = er.fresh ? 1 : 0;
+      gptr(E.illegal)[inst] = er.illegal;
+    }
   }
   GPF_STAMPS(15);
   GPF_STAMPS_FLUSH(inst);

@@ -516,7 +516,7 @@ class PowerFlowEngine:
 
     def env_state(self, lane0: int = 0, n: Optional[int] = None) -> dict:
         """``target`` / ``actual`` dispatch, ``prev_p``, ``already_modified`` ``[n, n_gen]``, ``charge`` ``[n, n_storage]``,
-        ``amount_prev`` ``[n]`` of the lanes' environment dynamics."""
+        ``amount_prev`` ``[n]`` of the lanes' environment dynamics; ``illegal`` ``[n]``: actions cancelled as illegal redispatch since the reset."""
         lane0, n = self._range(lane0, n)
         ng, ns = self.model.n_gen, self.model.n_storage
         d = dict(target=np.empty((n, ng), np.float32), actual=np.empty((n, ng), np.float32), prev_p=np.empty((n, ng), np.float32),
@@ -527,6 +527,8 @@ class PowerFlowEngine:
                                           ptr(d["charge"] if ns else None, C.c_float), ptr(d["amount_prev"], C.c_float),
                                           ptr(d["curtail_limit"], C.c_float), ptr(d["curtail_prev"], C.c_float)), "gpf_get_env_state")
         d["already_modified"] = d["already_modified"].astype(bool)
+        d["illegal"] = np.empty(n, np.int32)             # steps whose action BaseEnv.step would have cancelled as an illegal redispatch
+        check(self._lib.gpf_get_env_illegal(self._h, lane0, n, ptr(d["illegal"], C.c_int32)), "gpf_get_env_illegal")
         return d
 
     def set_env_state(self, lane0: int = 0, target=None, actual=None, prev_p=None, already_modified=None, charge=None, amount_prev=None,

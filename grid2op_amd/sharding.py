@@ -351,6 +351,17 @@ class ShardedEngine:
     def plan(self):
         return [eng.plan() for eng in self.engines]
 
+    def specialize(self, enable: bool = True, cache_dir=None, verify: bool = True):
+        """`PowerFlowEngine.specialize` on every device's engine (same grid: the self-test runs once, the code objects are shared
+        through the on-disk cache); returns one `specialization()` dict per device."""
+        out = []
+        for k, eng in enumerate(self.engines):
+            out.append(eng.specialize(enable, cache_dir=cache_dir, verify=verify and k == 0) if hasattr(eng, "specialize") else None)
+        return out
+
+    def specialization(self):
+        return [eng.specialization() if hasattr(eng, "specialization") else None for eng in self.engines]
+
     def close(self):
         if getattr(self, "_pool", None) is not None:
             self._pool.shutdown(wait=True)

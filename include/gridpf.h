@@ -283,6 +283,10 @@ int gpf_set_gen_renewable(gpf_handle h, const uint8_t* renewable);
 int gpf_set_lane_curtailment(gpf_handle h, const float* limit);
 int gpf_get_env_state(gpf_handle h, int32_t lane0, int32_t n, float* target, float* actual, float* prev_p, uint8_t* already_modified,
                       float* charge, float* amount_prev, float* curtail_limit, float* curtail_prev);
+/* count[n]: steps since the lane's last reset whose action was CANCELLED as an illegal redispatch (what BaseEnv.step reports as
+ * info["is_illegal_redisp"] / the IllegalRedispatching exception of that step, baseEnv.py:2140-2173, 3400-3425); copied with the lane
+ * by gpf_copy_lanes / gpf_fanout_n1 / gpf_simulate_batch, cleared by gpf_reset_lanes and auto-reset. */
+int gpf_get_env_illegal(gpf_handle h, int32_t lane0, int32_t n, int32_t* count);
 int gpf_set_env_state(gpf_handle h, int32_t lane0, int32_t n, const float* target, const float* actual, const float* prev_p,
                       const uint8_t* already_modified, const float* charge, const float* amount_prev, const float* curtail_limit,
                       const float* curtail_prev);

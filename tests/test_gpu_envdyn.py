@@ -81,6 +81,9 @@ def test_recorded_reference_episode_in_multi_step_launches(name, load_model, loa
         eng.step(row0 + a, n_steps=b_ - a)                 # ONE launch from this action up to the next one
         obs = eng.trajectory_obs(b_ - a)
         st = eng.env_state()
+        # the steps whose action the reference environment cancelled as illegal (info["is_illegal_redisp"]), counted per lane
+        n_illegal = int(np.asarray(fx["failed_redisp"][:b_]).sum()) if "failed_redisp" in fx else 0
+        assert (st["illegal"] == n_illegal).all(), (a, st["illegal"], n_illegal)
         gens = []
         for t in range(a, b_):
             ok, gen, spw = ex.step(fx["new_p"][t], fx["act_redisp"][t], fx["act_storage"][t], fx["act_curtail"][t])

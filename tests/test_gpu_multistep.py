@@ -505,6 +505,15 @@ def test_sharded_engine_on_real_engines(load_model, load_npz):
     with pytest.raises(ValueError):
         se.fanout_n1(2, 50, [1])                                                      # source and destinations on different devices
     assert len(se.device_views()) == 2 and len(se.plan()) == 2
+    # run-time specialised kernels on every shard (self-test on the first, code objects shared through the cache): same results again
+    one_before = one.specialization()                 # (already on when the suite itself runs with GRIDPF_JIT=1)
+    infos = se.specialize(True)
+    assert len(infos) == 2 and all(i["enabled"] for i in infos)
+    for e in (one, se):
+        e.step(13, n_steps=4, rebalance=1.02)
+    assert np.array_equal(one.results().out, se.results().out, equal_nan=True)
+    assert all(b["launches"] == a["launches"] + 1 and b["failed"] == 0 for a, b in zip(infos, se.specialization()))
+    assert one.specialization()["launches"] == one_before["launches"] + (1 if one_before["enabled"] else 0)
     one.close()
     se.close()
 
