@@ -26,6 +26,11 @@ LITE="pmc_fetch:FETCH_SIZE pmc_write:WRITE_SIZE pmc_sq1:SQ_WAVES,SQ_INSTS_VALU,S
 for w in "$@"; do
   case $w in
     case14) prof r04_step_kernel_case14 96468992 "step_sparse_kernel<1, 2, 2" "$FULL" --steps 48 --warmup 16 --windows 2 --no-secondary ;;
+    case14_shipped) prof r04_step_kernel_case14_shipped 96468992 "step_sparse_kernel<1, 2, 2" "pmc_fetch:FETCH_SIZE pmc_write:WRITE_SIZE pmc_sq1:SQ_WAVES,SQ_INSTS_VALU,SQ_INSTS_SALU,SQ_INSTS_LDS" --steps 48 --warmup 16 --windows 2 --no-secondary --no-jit ;;
+    all) O=$R/gpurun_out/prof/r04_all; mkdir -p $O
+         rocprofv3 --kernel-trace --stats -d $O/stats -- python bench.py --no-cpu-baseline > $O/stats.log 2>&1
+         python profiles/summarize_rocprof.py "r04_all_kernels_bench: python bench.py --no-cpu-baseline (1x MI355X; every kernel of the default run, step kernels specialised at run time)" $(find $O/stats -name "*_results.db" | head -1) > $R/gpurun_out/prof/r04_all_kernels_bench.txt
+         tail -1 $O/stats.log | cut -c1-200 ;;
     case14_1) prof r04_step_kernel_case14_1perlaunch 6029312 "step_sparse_kernel<1, 2, 2" "pmc_fetch:FETCH_SIZE pmc_write:WRITE_SIZE" --steps 48 --warmup 16 --windows 2 --no-secondary --steps-per-launch 1 ;;
     n1) prof r04_step_kernel_n1_neurips36 4560322560 "step_sparse_kernel<1, 0, 1, 2, 1" "$LITE" --only n1_fanout --steps 48 --warmup 16 ;;
     wcci) prof r04_step_kernel_wcci118 225935360 "step_sparse_kernel<1, 0, 1, 2, 2" "$LITE" --only secondary --steps 64 --warmup 16 ;;
