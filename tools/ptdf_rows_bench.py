@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np
 import bench
 
-class A: stub_engine=False; share_device=False; dist_backend="nccl"; no_oracle_check=False; steps_per_launch=16; last_obs_only=False
+class A: no_jit=True; profile=False; stub_engine=False; share_device=False; dist_backend="nccl"; no_oracle_check=False; steps_per_launch=16; last_obs_only=False
 ctx = bench.Ctx(A())
 m, ch = bench.load_env("l2rpn_idf_2023")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
