@@ -2426,6 +2426,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
           if (bu >= 0 && !sv.gen_slack[i]) atomicAdd(&c.Psp[bu], (double)pp * inv_sn9);
         }
       }
+      GPF_STAMPS(29);
       if (sums_in_k9 && lane9) {                     // storage and shunt set-points do not change during a launch
         for (int i = tid; i < g.n_sto; i += gw9) {
           const int bu = c.sto_b[i];
@@ -2445,6 +2446,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
         }
       }
       GPF_SYNC_IF(!STAGE);                         // tier 0: the injection row went to global memory and is read back from there
+      GPF_STAMPS(30);
     }
     // ---- power flow + K7 (Backend.next_grid_state) --------------------------------------------------------------------------
     n_iter = 0; nb = 0; st = 0; rounds = 0;
@@ -2470,6 +2472,7 @@ __global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const Dev
       ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && sa.n_steps > 1; ctl.write_bus = last; ctl.warm = sa.warm_start != 0; ctl.sums_done = first && sums_in_k9;
       orow = otraj ? step * (int)b.lane_stride + inst : inst;          // (re-derived: see GPF_REDERIVE)
       ctl.otraj = otraj; ctl.orow = orow; ctl.write_topo = otraj;
+      GPF_STAMPS(31);
       const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, sa.is_dc, max_iter, tol_pu, tid, ctl, ts, it_k, nb_k, a_first GPF_STAMPS_ARG);
       first = false;
       GPF_SYNC_IF(sa.cascade != 0 && g.n_line > GW);   // (every line loop maps line l to lane l % GW: lanes read their own rows)
