@@ -1030,8 +1030,10 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
         }
       }
       if (ok) {
+        // (the matrix is symmetric, its computed inverse only up to rounding: the table is made EXACTLY symmetric, so that the kernels may
+        //  read it by rows or by columns, whichever their memory prefers, with identical results)
         std::vector<double> cm((size_t)n * n);
-        for (int i = 0; i < n; ++i) for (int k = 0; k < n; ++k) cm[(size_t)k * n + i] = M[(size_t)i * 2 * n + n + k];
+        for (int i = 0; i < n; ++i) for (int k = 0; k < n; ++k) cm[(size_t)k * n + i] = 0.5 * (M[(size_t)i * 2 * n + n + k] + M[(size_t)k * 2 * n + n + i]);
         // small grids: inside the static blob (staged in LDS with it); up to 63 substations (the single-wavefront kernels): a table of
         // its own in global memory, read through L2 (36 substations: 10 KB shared by every lane; +5.7 % at 4 096 lanes, +1.8 % on the
         // N-1 fan-out).  The two-wavefront kernels of the 118-substation grids keep their factored DC matrix in LDS instead: 118

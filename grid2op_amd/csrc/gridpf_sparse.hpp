@@ -1212,22 +1212,27 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     for (int i = tid; i < nbus; i += GW) {
       double th;
       if (dc_inv) {                                                 // row i of inv(B') (column-major table) times the right-hand side
-        double t0 = 0.0, t1 = 0.0;                                  // two chains (even / odd k), 8 operand pairs in flight per trip
-        for (int k0 = 0; k0 < nbus; k0 += MVC) {
-          double a_[MVC], r_[MVC];
+        // (the table is in the LDS-staged blob or in global memory: ONE branch around the whole product, not one per element -- a
+        //  select between two address spaces per operand made every load wait for itself: 3 000 instead of 500 cycles on 14 substations)
+        auto row_times_rhs = [&](const auto tab) -> double {
+          double t0 = 0.0, t1 = 0.0;                                // two chains (even / odd k), MVC operand pairs in flight per trip
+          for (int k0 = 0; k0 < nbus; k0 += MVC) {
+            double a_[MVC], r_[MVC];
 #pragma unroll
-          for (int q = 0; q < MVC; ++q) {
-            const int k = k0 + q < nbus ? k0 + q : nbus - 1;
-            a_[q] = dcinv(k * nbus + i);
-            r_[q] = *rhsT(k);
-          }
+            for (int q = 0; q < MVC; ++q) {
+              const int k = k0 + q < nbus ? k0 + q : nbus - 1;
+              a_[q] = tab[k * nbus + i];
+              r_[q] = *rhsT(k);
+            }
 #pragma unroll
-          for (int q = 0; q < MVC; q += 2) {
-            if (k0 + q < nbus) t0 = fma(a_[q], r_[q], t0);
-            if (k0 + q + 1 < nbus) t1 = fma(a_[q + 1], r_[q + 1], t1);
+            for (int q = 0; q < MVC; q += 2) {
+              if (k0 + q < nbus) t0 = fma(a_[q], r_[q], t0);
+              if (k0 + q + 1 < nbus) t1 = fma(a_[q + 1], r_[q + 1], t1);
+            }
           }
-        }
-        th = t0 + t1;
+          return t0 + t1;
+        };
+        th = S.so.dc_inv >= 0 ? row_times_rhs(sv.dc_inv) : row_times_rhs(sv.dc_inv_g);
       } else if (NB == 1) {                                         // flat sweeps leave s_i = d_i theta_i (scalar_lu_flat)
         const double d = dc_kept ? c.Adc[i] : c.A[(size_t)i * 2];
         if (!(fabs(d) > 1e-300) || !(fabs(d) < 1e300)) ok = false;
@@ -1307,34 +1312,49 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
 #define NWR_PSP (KEEP_Y ? psp0 : c.Psp[ib])
 #define NWR_QSP (KEEP_Y ? qsp0 : c.Qsp[ib])
       double va, vm;
+#ifdef GPF_TIMING
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      GPF_STAMPS(20);                 // (developer timing build: the solve's constants are in registers)
+#endif
       if (fuse_dc) {
         // initial |V| (K1; a step that rebuilt its tables already has it in LDS), DC right-hand side (K3) and theta = inv(B') (P - G)
         // in the bus lane itself; row ib of the column-major static inverse, all operands in flight before the two FMA chains
         // (even / odd k, the order of the general path)
         const int vi = fast_pre ? c.vidx[ib] : -1;
         const double vm_lds = fast_pre ? 1.0 : c.vm[ib];
-        double t0 = 0.0, t1 = 0.0;
-        for (int k0 = 0; k0 < nbus; k0 += MVC) {
-          double a_[MVC], r_[MVC];
+        // r_k = Psp_k - Gs_k of every bus goes through ONE contiguous array (c.ivm: dead until the sincos step below rewrites it), so that the
+        // product reads one operand per term instead of two; the table is SYMMETRIC (gpf_create symmetrises it), so a lane may walk its
+        // row k-contiguously when the table is staged in LDS, and column by column (coalesced across the lanes) when it is read through L2
+        if (b_on) c.ivm[ib] = psp0 - c.Gs[ib];
+        GPF_LSYNC();
+        auto row_times_rhs = [&](const auto tab, const bool by_row) -> double {
+          double t0 = 0.0, t1 = 0.0;                                // two chains (even / odd k), MVC operand pairs in flight per trip
+          for (int k0 = 0; k0 < nbus; k0 += MVC) {
+            double a_[MVC], r_[MVC];
 #pragma unroll
-          for (int q = 0; q < MVC; ++q) {
-            const int k = k0 + q < nbus ? k0 + q : nbus - 1;
-            a_[q] = dcinv(k * nbus + ib);
-            r_[q] = c.Psp[k] - c.Gs[k];
-          }
+            for (int q = 0; q < MVC; ++q) {
+              const int k = k0 + q < nbus ? k0 + q : nbus - 1;
+              a_[q] = by_row ? tab[ib * nbus + k] : tab[k * nbus + ib];
+              r_[q] = c.ivm[k];
+            }
 #pragma unroll
-          for (int q = 0; q < MVC; q += 2) {
-            if (k0 + q < nbus) t0 = fma(a_[q], r_[q], t0);
-            if (k0 + q + 1 < nbus) t1 = fma(a_[q + 1], r_[q + 1], t1);
+            for (int q = 0; q < MVC; q += 2) {
+              if (k0 + q < nbus) t0 = fma(a_[q], r_[q], t0);
+              if (k0 + q + 1 < nbus) t1 = fma(a_[q + 1], r_[q + 1], t1);
+            }
           }
-        }
-        const double th = t0 + t1;
+          return t0 + t1;
+        };
+        const double th = S.so.dc_inv >= 0 ? row_times_rhs(sv.dc_inv, STAGE == 2) : row_times_rhs(sv.dc_inv_g, false);
         const bool live = (bt == BT_PQ || bt == BT_PV);
         va = live ? th : 0.0;
         vm = (vi >= 0 && (bt == BT_PV || bt == BT_REF)) ? GPF_INJ(oo.inj_gen_vm + vi) : vm_lds;
         const bool th_bad = b_on && bt != BT_OFF && !(fabs(th) < 1e300);
         if (status == 0 && G::any(th_bad)) { status = 4; done = true; }
       } else { va = c.va[ib]; vm = c.vm[ib]; }
+#ifdef GPF_TIMING
+      GPF_STAMPS(21);                 // (developer timing build: DC start done)
+#endif
       const bool act = p_on && (btu != BT_OFF) && (btv != BT_OFF);
       const bool uP = (btu == BT_PQ || btu == BT_PV), uQ = (btu == BT_PQ), vP = (btv == BT_PQ || btv == BT_PV), vQ = (btv == BT_PQ);
       const bool acc_u = act && (yuv0.x != 0.0 || yuv0.y != 0.0), acc_v = act && (yvu0.x != 0.0 || yvu0.y != 0.0);

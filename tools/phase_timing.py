@@ -55,6 +55,8 @@ if SPARSE:
           f"diag + mismatch + test {med[12] - med[11]:.0f}, block LU {med[13] - med[12]:.0f}, update + sincos {med[14] - med[13]:.0f}")
     print(f"  K9 detail: topo row + first loads {med[16] - med[8]:.0f}, load rows + sums {med[17] - med[16]:.0f}, reductions {med[18] - med[17]:.0f}, "
           f"gens + stores {med[0] - med[18]:.0f}")
+    print(f"  start of the Newton loop (register-resident path): constants of the solve {med[20] - med[4]:.0f}, fused DC start {med[21] - med[20]:.0f}, "
+          f"sincos + first stores {med[10] - med[21]:.0f}")
     print(f"  K9 tail: generators {med[29] - med[18]:.0f}, storage / shunt sums + boundary {med[30] - med[29]:.0f}, cascade-loop set-up {med[31] - med[30]:.0f}, "
           f"entry of the solve {med[0] - med[31]:.0f}")
     print(f"  K1 detail: topo row -> LDS {med[27] - med[0]:.0f}, element loops (atomics) {med[28] - med[27]:.0f}, types / counts {med[1] - med[28]:.0f}")
