@@ -670,6 +670,20 @@ int upload_params_s(gpf_engine* e, const gpf::Bufs& b, const LaunchPlan* tc, int
   return GPF_OK;
 }
 
+// the engine's specialised kernels for the launch that follows upload_params_s (nullptr: ahead-of-time kernels).  The literals of the
+// specialised kernels ARE this engine's grid: any change of the grid-level part of the parameter block switches them off.
+GpfJit* jit_for_launch(gpf_engine* e) {
+  if (!e->jit.on) return nullptr;
+  const gpf::DevParamsS& hp = e->h_params_s;
+  if (std::memcmp(&hp.g, &e->jit_g, sizeof(hp.g)) || std::memcmp(&hp.oo, &e->jit_oo, sizeof(hp.oo)) || std::memcmp(&hp.sym, &e->jit_sym, sizeof(hp.sym))) {
+    e->jit.on = false;
+    e->jit.message = "the grid-level parameter block changed after gpf_jit_enable: specialised kernels switched off";
+    fprintf(stderr, "[gridpf] jit: %s\n", e->jit.message.c_str());
+    return nullptr;
+  }
+  return &e->jit;
+}
+
 int prof_begin(gpf_engine* e, hipEvent_t& a, hipEvent_t& b) {
   if (e->ev_used == e->ev_pool.size()) {
     hipEvent_t x, y;
@@ -1340,6 +1354,7 @@ int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
   if (rc != GPF_OK) return rc;
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
   // (measured: forking the second launch onto its own stream costs more in cross-stream events than the overlap gains)
+  p.jit = pb.jit = jit_for_launch(e);
   HIP_TRY(gpf_launch_runpf_sparse(p, e->device, e->d_params_s, e->stream, lane0, n, is_dc, max_iter, tol_pu));
   if (pb.sparse_nb) HIP_TRY(gpf_launch_runpf_sparse(pb, e->device, e->d_params_s, e->stream, lane0, n, is_dc, max_iter, tol_pu));
   HIP_TRY(hipGetLastError());
@@ -1409,6 +1424,7 @@ int gpf_solve_lane(gpf_handle e, int32_t lane, const double* inj, const int32_t*
   HIP_TRY(hipMemcpyAsync(e->topo0.p + (size_t)lane * g.dim_topo, P + o_topo, (size_t)g.dim_topo * 4, hipMemcpyHostToDevice, st));
   if (g.n_shunt) HIP_TRY(hipMemcpyAsync(e->shunt_bus.p + (size_t)lane * g.n_shunt, P + o_sb, (size_t)g.n_shunt * 4, hipMemcpyHostToDevice, st));
   const double tol_pu = tol_mva / g.sn_mva;
+  p.jit = pb.jit = jit_for_launch(e);
   HIP_TRY(gpf_launch_runpf_sparse(p, e->device, e->d_params_s, st, lane, 1, is_dc, max_iter, tol_pu));
   if (pb.sparse_nb) HIP_TRY(gpf_launch_runpf_sparse(pb, e->device, e->d_params_s, st, lane, 1, is_dc, max_iter, tol_pu));
   if (e->window) { ++e->win_launches; e->win_marked = false; }
@@ -1567,16 +1583,7 @@ int step_range(gpf_engine* e, const gpf::Bufs& b_in, int lane0, int n, int t0, i
   if (rc != GPF_OK) return rc;
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
   p.env = pb.env = e->env_on;
-  if (e->jit.on) {
-    // the literals of the specialised kernels ARE this engine's grid: any change of the grid-level part of the block switches them off
-    const gpf::DevParamsS& hp = e->h_params_s;
-    if (std::memcmp(&hp.g, &e->jit_g, sizeof(hp.g)) || std::memcmp(&hp.oo, &e->jit_oo, sizeof(hp.oo)) || std::memcmp(&hp.sym, &e->jit_sym, sizeof(hp.sym))) {
-      e->jit.on = false;
-      e->jit.message = "the grid-level parameter block changed after gpf_jit_enable: specialised kernels switched off";
-      fprintf(stderr, "[gridpf] jit: %s\n", e->jit.message.c_str());
-    }
-  }
-  p.jit = pb.jit = e->jit.on ? &e->jit : nullptr;
+  p.jit = pb.jit = jit_for_launch(e);
   HIP_TRY(gpf_launch_step_sparse(p, e->device, e->d_params_s, e->stream, n, o->max_iter, tol_pu, sa));
   if (pb.sparse_nb) HIP_TRY(gpf_launch_step_sparse(pb, e->device, e->d_params_s, e->stream, n, o->max_iter, tol_pu, sa));
   HIP_TRY(hipGetLastError());

@@ -26,7 +26,7 @@ struct GpfJit {
 std::string gpf_jit_header(const gpf::DevParamsS& hp);
 int gpf_jit_configure(GpfJit& j, const char* src_dir, const char* cache_dir, std::string& err);
 void gpf_jit_release(GpfJit& j);
-hipFunction_t gpf_jit_get(GpfJit& j, int NB, int ST, int IPW, int WP, bool TC, bool YR, bool ENV);
+hipFunction_t gpf_jit_get(GpfJit& j, int NB, int ST, int IPW, int WP, bool TC, bool YR, bool ENV, bool runpf = false);
 
 struct LaunchPlan {
   size_t lds;
@@ -42,7 +42,7 @@ struct LaunchPlan {
   bool env;          // step launches: the ENV instantiation (environment injection dynamics on): tables in global memory unless instance groups
   bool yreg;         // Ybus blocks in registers (gridpf_sparse.hpp: YR): NB == 1, 2 wavefronts per instance, tables in global memory
   int dcf;           // the LDS layout of this launch has room for the factored DC matrix (DevParamsS::dcf)
-  GpfJit* jit;       // step launches: grid-specialised kernels of the engine (nullptr / !on: ahead-of-time kernels)
+  GpfJit* jit;       // grid-specialised kernels of the engine (nullptr / !on: ahead-of-time kernels)
   int sparse_stage;  // 0: static tables read in place (L2), 1: program + pair table + injection row in LDS, 2: everything in LDS // program staged in LDS (small grids) or streamed from L2 (keeps 3 instances per CU on 118-bus grids)
 };
 

@@ -7,6 +7,14 @@ template <int NB, int ST, int IPW, int WP, bool TC, bool YR = false>
 hipError_t launch(const LaunchPlan& p, int device, const gpf::DevParamsS* d_params, hipStream_t stream, int lane0, int n_l,
                   const int* list, int is_dc, int max_iter, double tol_pu) {
   static size_t lds_set[64] = {0};
+  if (p.jit && p.jit->on) {                  // grid-specialised kernel of this variant (gridpf_jit.hip), compiled on first use
+    if (hipFunction_t f = gpf_jit_get(*p.jit, NB, ST, IPW, WP, TC, YR, false, true)) {
+      const int* cls = p.cls_list;
+      void* args[] = {(void*)&d_params, (void*)&lane0, (void*)&list, (void*)&cls, (void*)&is_dc, (void*)&max_iter, (void*)&tol_pu};
+      ++p.jit->n_launches;
+      return hipModuleLaunchKernel(f, (unsigned)((n_l + IPW - 1) / IPW), 1, 1, (unsigned)(gpf::WAVE * WP), 1, 1, (unsigned)p.lds, stream, args, nullptr);
+    }
+  }
   auto kern = &gpf::runpf_sparse_kernel<NB, ST, IPW, 2, WP, TC, YR>;
   if (p.lds > lds_set[device & 63]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds);

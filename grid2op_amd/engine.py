@@ -711,7 +711,7 @@ class PowerFlowEngine:
         return ms.value, n.value
 
     def specialize(self, enable: bool = True, cache_dir: str = None, verify: bool = True) -> dict:
-        """Switch the engine's step launches (`step`, `simulate_batch`) to kernels compiled AT RUN TIME FOR THIS GRID
+        """Switch the engine's solver launches (`step`, `simulate_batch`, `runpf`, `solve_lane`) to kernels compiled AT RUN TIME FOR THIS GRID
         (gpf_jit_enable): every size and table offset of the grid is a literal in them instead of a value read from the
         launch parameter block.  The first launch of each kernel variant compiles it (hipcc, about a second; cached on disk per
         grid in ``cache_dir`` / $GRIDPF_JIT_CACHE / ``grid2op_amd/_jit_cache``); results are bit-identical to the shipped kernels.

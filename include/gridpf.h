@@ -408,13 +408,13 @@ int gpf_device_pointers_n(gpf_handle h, void** ptrs, int32_t n_ptrs, void** stre
 
 /* ---- grid-specialised step kernels (run-time compilation; grid2op_amd/csrc/gridpf_jit.hip) -------------------------------------
  * The shipped (ahead-of-time) kernels serve every grid: sizes, offsets of the static tables / result rows and the header of the
- * symbolic program reach them through a parameter block.  gpf_jit_enable() switches the engine's STEP launches (gpf_step,
- * gpf_step_n, gpf_simulate_batch) to kernels compiled for THIS grid, in which those numbers are literals: at the first launch of
+ * symbolic program reach them through a parameter block.  gpf_jit_enable() switches the engine's solver launches (gpf_step,
+ * gpf_step_n, gpf_simulate_batch, gpf_runpf, gpf_solve_lane) to kernels compiled for THIS grid, in which those numbers are literals: at the first launch of
  * each kernel variant the library writes a header with the grid's numbers, compiles the unchanged kernel source of
  * <src_dir>/gridpf_sparse.hpp for that variant (hipcc --genco, ~20-40 s), loads the code object and launches it from then on;
  * code objects are cached in <cache_dir> by a hash of header + variant + sources, so a grid is compiled once per machine.
  * Results are BIT-IDENTICAL to the ahead-of-time kernels (same source, same arithmetic in the same order).  Nothing else changes: same
- * buffers, same calls; gpf_runpf / gpf_solve_lane keep the ahead-of-time kernels.
+ * buffers, same calls.  The one-power-flow-per-lane kernels of gpf_runpf / gpf_solve_lane are specialised the same way.
  *   src_dir   directory with the kernel sources (NULL: "csrc" next to the library)
  *   cache_dir NULL: $GRIDPF_JIT_CACHE, else "_jit_cache" next to the library
  * The compiler is $GRIDPF_HIPCC, else /opt/rocm/bin/hipcc, else hipcc on PATH; GPF_E_UNSUPPORTED when it does not run or the sources are

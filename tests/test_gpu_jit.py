@@ -136,6 +136,32 @@ def test_specialised_environment_dynamics_kernel(load_model, load_npz, jit_cache
     _assert_same(outs[0], outs[1], info["variants"])
 
 
+@pytest.mark.parametrize("name,B", [("l2rpn_case14_sandbox", 33), ("l2rpn_neurips_2020_track1", 61), ("l2rpn_wcci_2022_dev", 5)])
+def test_specialised_runpf_kernels_and_n1_scan(name, B, load_model, load_npz, jit_cache):
+    """gpf_runpf / gpf_solve_lane (one power flow per lane: what HipBackend.runpf and an N-1 scan use) on specialised kernels"""
+    m, ch, e_ref, tab, off, scale = _setup(load_model, load_npz, name, B)
+    _, _, e_jit, _, _, _ = _setup(load_model, load_npz, name, B)
+    e_jit.specialize(True, cache_dir=jit_cache, verify=False)
+    rng = np.random.default_rng(2)
+    inj = e_ref.pack_injections(B)
+    inj[:, e_ref.inj_slices["load_p"]] *= 1 + 0.05 * rng.standard_normal((B, m.n_load))
+    outs = []
+    for e in (e_ref, e_jit):
+        e.set_injections(inj)
+        e.fanout_n1(0, 1, np.arange(min(B - 1, m.n_line)))          # lanes 1.. = lane 0 with one line out each
+        e.runpf()
+        r = e.results()
+        got = [r.out, r.status, r.topo_vect, r.bus_vm, r.bus_va]
+        e.runpf(is_dc=True)
+        got += [e.results().out]
+        one = e.solve_lane(0, inj[1], np.asarray(m.initial_topo_vect(), np.int32), shunt_bus=np.asarray(m.initial_shunt_bus(), np.int32) if m.n_shunt else None)
+        got += [one.out, one.status]
+        outs.append(got)
+    info = e_jit.specialization()
+    assert info["failed"] == 0 and info["launches"] >= 3 and "runpf<" in info["variants"], info
+    _assert_same(outs[0], outs[1], (name, info["variants"]))
+
+
 def test_specialize_self_test_header_and_refusal(load_model, load_npz, jit_cache, monkeypatch):
     from grid2op_amd.engine import GridPFError
     m, ch, eng, tab, off, scale = _setup(load_model, load_npz, "l2rpn_case14_sandbox", 32)
