@@ -14,7 +14,7 @@
 struct GpfJit {
   bool on = false;
   std::string header;                       // gpf_jit_header() of the engine's parameter block at gpf_jit_enable
-  std::string src_dir, cache_dir, hipcc, flags;
+  std::string src_dir, cache_dir, hipcc, flags_user;   // flags_user: GRIDPF_JIT_FLAGS (experiments), empty: default policy
   uint64_t src_hash = 0;
   std::map<unsigned, hipFunction_t> fns;    // kernel variant -> specialised kernel (nullptr: failed, ahead-of-time kernel used)
   std::vector<hipModule_t> mods;
@@ -26,7 +26,7 @@ struct GpfJit {
 std::string gpf_jit_header(const gpf::DevParamsS& hp);
 int gpf_jit_configure(GpfJit& j, const char* src_dir, const char* cache_dir, std::string& err);
 void gpf_jit_release(GpfJit& j);
-hipFunction_t gpf_jit_get(GpfJit& j, int NB, int ST, int IPW, int WP, bool TC, bool YR, bool ENV, bool runpf = false);
+hipFunction_t gpf_jit_get(GpfJit& j, int NB, int ST, int IPW, int WP, bool TC, bool YR, bool ENV, bool runpf, size_t lds_bytes);
 
 struct LaunchPlan {
   size_t lds;

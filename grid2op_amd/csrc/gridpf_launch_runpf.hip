@@ -8,7 +8,7 @@ hipError_t launch(const LaunchPlan& p, int device, const gpf::DevParamsS* d_para
                   const int* list, int is_dc, int max_iter, double tol_pu) {
   static size_t lds_set[64] = {0};
   if (p.jit && p.jit->on) {                  // grid-specialised kernel of this variant (gridpf_jit.hip), compiled on first use
-    if (hipFunction_t f = gpf_jit_get(*p.jit, NB, ST, IPW, WP, TC, YR, false, true)) {
+    if (hipFunction_t f = gpf_jit_get(*p.jit, NB, ST, IPW, WP, TC, YR, false, true, p.lds)) {
       const int* cls = p.cls_list;
       void* args[] = {(void*)&d_params, (void*)&lane0, (void*)&list, (void*)&cls, (void*)&is_dc, (void*)&max_iter, (void*)&tol_pu};
       ++p.jit->n_launches;

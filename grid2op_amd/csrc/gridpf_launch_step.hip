@@ -12,7 +12,7 @@ hipError_t launch(const LaunchPlan& p, int device, const gpf::DevParamsS* d_para
   auto kern = &gpf::step_sparse_kernel<NB, ST, IPW, 2, WP, TC, YR, ENV>;
   const size_t lds = p.lds + pad;
   if (p.jit && p.jit->on) {                  // grid-specialised kernel of this variant (gridpf_jit.hip), compiled on first use
-    if (hipFunction_t f = gpf_jit_get(*p.jit, NB, ST, IPW, WP, TC, YR, ENV)) {
+    if (hipFunction_t f = gpf_jit_get(*p.jit, NB, ST, IPW, WP, TC, YR, ENV, false, lds)) {
       const int* cls = p.cls_list;
       void* args[] = {(void*)&d_params, (void*)&list, (void*)&cls, (void*)&max_iter, (void*)&tol_pu, (void*)&sa};
       ++p.jit->n_launches;
