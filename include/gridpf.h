@@ -411,7 +411,7 @@ int gpf_device_pointers_n(gpf_handle h, void** ptrs, int32_t n_ptrs, void** stre
  * symbolic program reach them through a parameter block.  gpf_jit_enable() switches the engine's solver launches (gpf_step,
  * gpf_step_n, gpf_simulate_batch, gpf_runpf, gpf_solve_lane) to kernels compiled for THIS grid, in which those numbers are literals: at the first launch of
  * each kernel variant the library writes a header with the grid's numbers, compiles the unchanged kernel source of
- * <src_dir>/gridpf_sparse.hpp for that variant (hipcc --genco, ~20-40 s), loads the code object and launches it from then on;
+ * <src_dir>/gridpf_sparse.hpp for that variant (hipcc --genco, about a second), loads the code object and launches it from then on;
  * code objects are cached in <cache_dir> by a hash of header + variant + sources, so a grid is compiled once per machine.
  * Results are BIT-IDENTICAL to the ahead-of-time kernels (same source, same arithmetic in the same order).  Nothing else changes: same
  * buffers, same calls.  The one-power-flow-per-lane kernels of gpf_runpf / gpf_solve_lane are specialised the same way.
