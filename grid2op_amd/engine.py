@@ -716,8 +716,8 @@ class PowerFlowEngine:
         launch parameter block.  The first launch of each kernel variant compiles it (hipcc, about a second; cached on disk per
         grid in ``cache_dir`` / $GRIDPF_JIT_CACHE / ``grid2op_amd/_jit_cache``); results are bit-identical to the shipped kernels.
         ``verify`` (default): before this engine is switched, a 64-lane twin engine of the same grid runs two 8-step launches
-        (synthetic chronics around the grid's own injections, load jitter, generation rebalancing) with the shipped and with
-        the specialised kernels, and every result must agree bit for bit -- a specialised kernel is a new binary, and a binary
+        (synthetic chronics around the grid's own injections, load jitter, generation rebalancing) and an AC + a DC `runpf` with the
+        shipped and with the specialised kernels, and every result must agree bit for bit -- a specialised kernel is a new binary, and a binary
         is only trusted after it reproduced the validated one; on a mismatch the engine keeps the shipped kernels and
         `GridPFError` is raised.  Raises `GridPFError` too when no hipcc is available (shipped kernels stay)."""
         if not enable:
@@ -752,6 +752,11 @@ class PowerFlowEngine:
                     twin.step(k * n_steps, n_steps=n_steps, rebalance=1.02, auto_reset=True)
                     r = twin.results()
                     got += [r.out, r.topo_vect, r.status, r.bus_vm, r.bus_va] + [x.out for x in twin.trajectory_obs(n_steps)]
+                twin.runpf()                                        # the one-power-flow-per-lane kernels (runpf / solve_lane), AC and DC
+                r = twin.results()
+                got += [r.out, r.status, r.bus_vm, r.bus_va]
+                twin.runpf(is_dc=True)
+                got += [twin.results().out]
                 return got
 
             ref = run()
