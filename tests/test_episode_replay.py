@@ -92,3 +92,36 @@ def test_replay_through_hipbackend_on_the_hip_engine(name):
     # lane sharing: copies AND re-loads of the same grid file (Runner) take lanes of the same engine
     assert len(seen) <= 1 + n_bk // _LanePool.LANES
     assert not _LanePool._pools
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["case14_topology", "storage14_actions"])
+def test_replay_through_hipbackend_with_run_time_specialised_kernels(name):
+    """`HipBackend(specialize=True)`: the recorded calls of the reference framework replayed on the engine's kernels compiled at run time
+    for the grid (PowerFlowEngine.specialize: self-test against the shipped kernels, then every runpf on the specialised one-lane kernel)"""
+    try:
+        import grid2op  # noqa: F401
+    except ImportError:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "grid2op_stub"))
+    from grid2op_amd.backend import HipBackend, _LanePool
+    import functools
+    import replay as R
+    tr, grid = _load(name)
+    seen = []
+
+    class Bk(HipBackend):
+        def _make_engine(self, model, n_busbar, n_lanes=1):
+            eng = super()._make_engine(model, n_busbar, n_lanes)
+            close = eng.close
+
+            def close_and_report():                       # (the lane pool closes an engine when its last backend is gone)
+                seen.append(eng.specialization())
+                close()
+            eng.close = close_and_report
+            return eng
+    n_pf, n_obs, worst = R.replay(tr, functools.partial(Bk, specialize=True), grid)
+    assert n_pf == len(tr["pf_ok"])
+    infos = seen
+    assert infos and all(i["enabled"] and i["failed"] == 0 for i in infos), infos
+    assert sum(i["launches"] for i in infos) >= n_pf and all("runpf<" in i["variants"] for i in infos if i["launches"]), infos
+    assert not _LanePool._pools
