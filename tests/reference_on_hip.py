@@ -298,6 +298,10 @@ def cmd_timing():
                    "measured on the GPU box with the staged unmodified reference package", "host_cpus": os.cpu_count(), "rows": []}
     for env_name in ("l2rpn_case14_sandbox", "l2rpn_wcci_2022"):
         out["rows"].append(_time_loop(hip_backend_class(), env_name, n, "HipBackend + libgridpf.so (MI355X), one gpf_solve_lane per runpf"))
+        if os.environ.get("REFERENCE_ON_HIP_DRYRUN") != "1":
+            import functools
+            out["rows"].append(_time_loop(functools.partial(hip_backend_class(), specialize=True), env_name, n,
+                                          "HipBackend(specialize=True) + libgridpf.so (MI355X): kernels compiled at run time for the grid"))
         out["rows"].append(_time_loop(oracle_backend_class(), env_name, n, "HipBackend facade over the CPU oracle engine (oracle/pf_oracle.c, 1 core)"))
     print("TIMING " + json.dumps(out))
 

@@ -54,6 +54,6 @@ def test_unmodified_reference_framework_on_the_hip_engine():
     out = _run("timing", 900, "1000")
     line = [l for l in out.splitlines() if l.startswith("TIMING ")][-1]
     d = json.loads(line[len("TIMING "):])
-    assert len(d["rows"]) == 4 and all(r["steps"] == 1000 for r in d["rows"])
+    assert len(d["rows"]) == 6 and all(r["steps"] == 1000 for r in d["rows"])
     with open(os.path.join(ROOT, "gpurun_out", "reference_step_loop_timing.json"), "w") as f:
         json.dump(d, f, indent=1)
