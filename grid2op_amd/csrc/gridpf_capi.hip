@@ -553,7 +553,7 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
   const bool blocks_ok = e->g.n_busbar <= GPF_MAX_BUSBAR_BLOCKS;
   if (e->g.n_sub * mb <= 32000) {
 #ifdef GPF_TIMING
-    if (e->work.n < (size_t)e->cap_lanes * 32) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->cap_lanes * 32)); }
+    if (e->work.n < (size_t)e->cap_lanes * 40) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->cap_lanes * 40)); }
 #endif
     // lanes with split substations: (1) topology classes -- the single-busbar kernel on the lane's bus-level graph --, else
     // (2) the NB = n_busbar kernel; the lanes without a split keep the plain single-busbar kernel (mixed batch: two launches)

@@ -144,12 +144,13 @@ struct DevParamsS {
 // -DGPF_TIMING developer build: cycle-counter stamps are kept in REGISTERS (a global store per stamp would be waited for
 // at the next barrier and distort the phases) and written to b.work[inst][32] once at the end of the kernel.
 #ifdef GPF_TIMING
-struct Stamps { long long v[32]; };
+constexpr int GPF_NSTAMP = 40;
+struct Stamps { long long v[GPF_NSTAMP]; };
 #define GPF_STAMPS(k) do { stamps.v[(k)] = (long long)__builtin_readcyclecounter(); } while (0)
 #define GPF_STAMPS_PARAM , Stamps& stamps
 #define GPF_STAMPS_ARG , stamps
-#define GPF_STAMPS_DECL Stamps stamps; for (int k_ = 0; k_ < 32; ++k_) stamps.v[k_] = 0
-#define GPF_STAMPS_FLUSH(inst_) do { if (tid == 0) for (int k_ = 0; k_ < 32; ++k_) P->b.work[(size_t)(inst_) * 32 + k_] = (double)stamps.v[k_]; } while (0)
+#define GPF_STAMPS_DECL Stamps stamps; for (int k_ = 0; k_ < GPF_NSTAMP; ++k_) stamps.v[k_] = 0
+#define GPF_STAMPS_FLUSH(inst_) do { if (tid == 0) for (int k_ = 0; k_ < GPF_NSTAMP; ++k_) P->b.work[(size_t)(inst_) * GPF_NSTAMP + k_] = (double)stamps.v[k_]; } while (0)
 #else
 #define GPF_STAMPS(k) do {} while (0)
 #define GPF_STAMPS_PARAM

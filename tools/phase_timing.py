@@ -29,7 +29,7 @@ for t in range(5):
     eng.step(t * NS, rebalance=1.02, n_steps=NS)
 eng.sync()
 L = _capi.lib()
-buf = np.zeros((B, 32))
+buf = np.zeros((B, 40))
 L.gpf_debug_read_work.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int64]
 assert L.gpf_debug_read_work(eng._h, buf.ctypes.data_as(C.POINTER(C.c_double)), buf.size) == 0
 SPARSE = True
