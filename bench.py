@@ -30,8 +30,15 @@ status, rho, status) to its own rows in HBM.  The cheaper contracts are labelled
 every timed region): ``max_abs_err_vs_oracle``.
 
 Timing: W warm-up steps, then ``--windows`` (default 5) timed windows of EXACTLY K steps each, every window
-bracketed by barrier + synchronize on both sides and MAX-reduced over the ranks; ``value`` / ``ms_per_step``
-are those of the MEDIAN window, min / max are reported in ``windows``.
+bracketed by barrier + synchronize on both sides; the timed quantity is the HIP-event window on the engine's stream around
+the K steps (closed right behind the last launch), MAX-reduced over the ranks; the wall clock between the brackets is reported
+beside it (``value_wall_clock``).  ``value`` / ``ms_per_step`` are those of the MEDIAN window, min / max are in ``windows``.
+
+Kernels: by default every engine switches its solver launches to kernels compiled at run time for the workload's grid
+(``PowerFlowEngine.specialize`` = gpf_jit_enable: the grid's sizes / table offsets as literals, results bit-identical to the
+shipped kernels, self-tested against them on a twin engine first; compilation happens in the untimed warm-up and is cached on
+disk; ``specialization`` in the JSON says what was loaded).  The same headline on the shipped kernels is reported as
+``shipped_kernels``; ``--no-jit`` runs everything on the shipped kernels (also what happens when no hipcc is available).
 
 Prints ONE JSON line (rank 0).
 """
