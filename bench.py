@@ -64,6 +64,7 @@ TRAFFIC_PROFILE = os.path.join("profiles", "r04_traffic.json")
 TRAFFIC_N1 = os.path.join("profiles", "r04_traffic_n1_neurips36.json")
 TRAFFIC_WCCI = os.path.join("profiles", "r04_traffic_wcci118.json")
 TRAFFIC_IDF = os.path.join("profiles", "r04_traffic_idf118.json")
+TRAFFIC_1PL = os.path.join("profiles", "r04_traffic_case14_1perlaunch.json")
 CASCADE_LIMIT_SCALE = 0.85     # `cascade_tripping` secondary: thermal limits x 0.85 -> ~20 % of the lane-steps overflow softly
 
 
@@ -654,6 +655,9 @@ def main():
             res["one_launch_per_step"] = dict(summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec,
                                               observations="every env step (one launch per step: the lane's own rows)",
                                               us_per_step=median_window(w)[0] / k_sec * 1e6,
+                                              roofline=roofline_block(eng, w, B, k_sec, TRAFFIC_1PL,
+                                                                      note="one env step per launch: the float64 bus voltages and the injection row go "
+                                                                           "back to HBM every step (2.3 x the algorithmic bytes)"),
                                               oracle_check=oracle_spot_check(ctx, eng, 32, t_last=t_l - 1, seed=1))
 
     # ---- OPT-IN, NOT the reference's algorithm (never the headline): Newton warm-started from the previous step -----------------

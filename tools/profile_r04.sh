@@ -18,7 +18,7 @@ prof() {   # label, algorithmic bytes per launch, kernel filter, pmc-set list, b
   done
   python profiles/summarize_rocprof.py "$label: python bench.py --profile --no-cpu-baseline --no-oracle-check $* (1x MI355X; every step-kernel dispatch = 16 env steps, observation trajectory on)" \
       $(find $O/stats -name "*_results.db" | head -1) $dbs > $R/gpurun_out/prof/$label.txt
-  python tools/make_traffic_json.py $R/gpurun_out/prof/$label.txt 16 $alg "$kf" > $R/gpurun_out/prof/${label}_traffic.json 2> $O/traffic.err || cat $O/traffic.err
+  python tools/make_traffic_json.py $R/gpurun_out/prof/$label.txt ${SPL:-16} $alg "$kf" > $R/gpurun_out/prof/${label}_traffic.json 2> $O/traffic.err || cat $O/traffic.err
   tail -1 $O/stats.log | cut -c1-200
 }
 FULL="pmc_fetch:FETCH_SIZE pmc_write:WRITE_SIZE pmc_sq1:SQ_WAVES,SQ_INSTS_VALU,SQ_INSTS_SALU,SQ_INSTS_LDS pmc_sq2:SQ_INSTS_SMEM,SQ_INSTS_VMEM_RD,SQ_INSTS_VMEM_WR,SQ_WAVE_CYCLES pmc_sq3:SQ_BUSY_CYCLES,SQ_ACTIVE_INST_VALU,SQ_ACTIVE_INST_LDS,SQ_ACTIVE_INST_ANY pmc_sq4:SQ_WAIT_INST_ANY,SQ_WAIT_INST_LDS,SQ_LDS_BANK_CONFLICT,SQ_LDS_IDX_ACTIVE pmc_sq5:SQ_INSTS_VALU_FMA_F64,SQ_INSTS_VALU_MUL_F64,SQ_INSTS_VALU_ADD_F64,SQ_INSTS_VALU_TRANS_F64"
@@ -31,7 +31,7 @@ for w in "$@"; do
          rocprofv3 --kernel-trace --stats -d $O/stats -- python bench.py --no-cpu-baseline > $O/stats.log 2>&1
          python profiles/summarize_rocprof.py "r04_all_kernels_bench: python bench.py --no-cpu-baseline (1x MI355X; every kernel of the default run, step kernels specialised at run time)" $(find $O/stats -name "*_results.db" | head -1) > $R/gpurun_out/prof/r04_all_kernels_bench.txt
          tail -1 $O/stats.log | cut -c1-200 ;;
-    case14_1) prof r04_step_kernel_case14_1perlaunch 6029312 "step_sparse_kernel<1, 2, 2" "pmc_fetch:FETCH_SIZE pmc_write:WRITE_SIZE" --steps 48 --warmup 16 --windows 2 --no-secondary --steps-per-launch 1 ;;
+    case14_1) SPL=1 prof r04_step_kernel_case14_1perlaunch 6029312 "step_sparse_kernel<1, 2, 2" "pmc_fetch:FETCH_SIZE pmc_write:WRITE_SIZE" --steps 48 --warmup 16 --windows 2 --no-secondary --steps-per-launch 1 ;;
     n1) prof r04_step_kernel_n1_neurips36 4560322560 "step_sparse_kernel<1, 0, 1, 2, 1" "$LITE" --only n1_fanout --steps 48 --warmup 16 ;;
     wcci) prof r04_step_kernel_wcci118 225935360 "step_sparse_kernel<1, 0, 1, 2, 2" "$LITE" --only secondary --steps 64 --warmup 16 ;;
     idf) prof r04_kernels_idf118 459210752 "step_sparse_kernel<1, 0, 1, 2, 2" "$LITE" --only dc_ptdf --steps 48 --warmup 16 ;;
