@@ -806,7 +806,7 @@ int gpf_jit_disable(gpf_handle e) {
 
 int gpf_jit_info(gpf_handle e, int64_t* counts, double* seconds, char* text, size_t cap) {
   if (!e) return fail(GPF_E_INVALID, "gpf_jit_info: null handle");
-  if (counts) { counts[0] = e->jit.on ? 1 : 0; counts[1] = e->jit.n_compiled; counts[2] = e->jit.n_cached; counts[3] = e->jit.n_failed; counts[4] = e->jit.n_launches; }
+  if (counts) { counts[0] = e->jit.on ? 1 : 0; counts[1] = e->jit.n_compiled; counts[2] = e->jit.n_cached; counts[3] = e->jit.n_failed; counts[4] = e->jit.n_launches; counts[5] = e->jit.n_aot; }
   if (seconds) *seconds = e->jit.seconds;
   if (text && cap) {
     const std::string t = e->jit.variants + (e->jit.message.empty() ? "" : " | " + e->jit.message);
@@ -1745,6 +1745,15 @@ int gpf_get_env_illegal(gpf_handle e, int32_t lane0, int32_t n, int32_t* count) 
   if (!e->env_on) return fail(GPF_E_INVALID, "gpf_get_env_illegal: the environment dynamics are off");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipMemcpyAsync(count, e->env_illegal.p + lane0, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_set_env_illegal(gpf_handle e, int32_t lane0, int32_t n, const int32_t* count) {
+  if (!check_range(e, lane0, n) || !count) return fail(GPF_E_INVALID, "gpf_set_env_illegal: bad range / null");
+  if (!e->env_on) return fail(GPF_E_INVALID, "gpf_set_env_illegal: the environment dynamics are off");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(e->env_illegal.p + lane0, count, (size_t)n * sizeof(int), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return GPF_OK;
 }

@@ -15,7 +15,10 @@ struct GpfJit {
   bool on = false;
   std::string header;                       // gpf_jit_header() of the engine's parameter block at gpf_jit_enable
   std::string src_dir, cache_dir, hipcc, flags_user;   // flags_user: GRIDPF_JIT_FLAGS (experiments), empty: default policy
-  uint64_t src_hash = 0;
+  std::string aot_dir, arch, defines, compile_why;     // ahead-of-time code objects ("_aot" next to the library; empty: none), device arch, -D flags of the library build
+  uint64_t src_hash = 0, aot_hash = 0;      // cache key seeds: sources + compiler version / sources only (ahead-of-time objects)
+  bool can_compile = false;                 // a private cache directory and a compiler that runs
+  int n_aot = 0;                            // variants loaded from the ahead-of-time directory
   std::map<unsigned, hipFunction_t> fns;    // kernel variant -> specialised kernel (nullptr: failed, ahead-of-time kernel used)
   std::vector<hipModule_t> mods;
   std::string variants, message;            // "<1,2,2,2,1,false,false,false> ..." loaded so far; last error

@@ -532,8 +532,9 @@ class PowerFlowEngine:
         return d
 
     def set_env_state(self, lane0: int = 0, target=None, actual=None, prev_p=None, already_modified=None, charge=None, amount_prev=None,
-                      curtail_limit=None, curtail_prev=None):
-        """Overwrite (parts of) the lanes' environment dynamics, e.g. to restore them from an observation."""
+                      curtail_limit=None, curtail_prev=None, illegal=None):
+        """Overwrite (parts of) the lanes' environment dynamics, e.g. to restore them from an observation.  Accepts every key
+        `env_state` returns (``eng.set_env_state(l0, **eng.env_state(l1, n))`` moves the complete state of n lanes)."""
         f = lambda a, w: None if a is None else np.ascontiguousarray(a, dtype=np.float32).reshape(-1, w)  # noqa: E731
         ng, ns = self.model.n_gen, max(self.model.n_storage, 1)
         arrs = [f(target, ng), f(actual, ng), f(prev_p, ng)]
@@ -542,7 +543,12 @@ class PowerFlowEngine:
         ap = None if amount_prev is None else np.ascontiguousarray(amount_prev, dtype=np.float32).reshape(-1)
         cl = f(curtail_limit, ng)
         cp = None if curtail_prev is None else np.ascontiguousarray(curtail_prev, dtype=np.float32).reshape(-1)
-        n = next(x.shape[0] for x in arrs + [am, ch, ap, cl, cp] if x is not None)
+        il = None if illegal is None else np.ascontiguousarray(illegal, dtype=np.int32).reshape(-1)
+        n = next((x.shape[0] for x in arrs + [am, ch, ap, cl, cp] if x is not None), None)
+        if il is not None:
+            check(self._lib.gpf_set_env_illegal(self._h, int(lane0), il.shape[0], ptr(il, C.c_int32)), "gpf_set_env_illegal")
+        if n is None:
+            return
         check(self._lib.gpf_set_env_state(self._h, int(lane0), n, ptr(arrs[0], C.c_float), ptr(arrs[1], C.c_float), ptr(arrs[2], C.c_float),
                                           ptr(am, C.c_uint8), ptr(ch, C.c_float), ptr(ap, C.c_float), ptr(cl, C.c_float), ptr(cp, C.c_float)),
               "gpf_set_env_state")
@@ -776,12 +782,12 @@ class PowerFlowEngine:
     def specialization(self) -> dict:
         """State of the run-time specialised kernels (gpf_jit_info): enabled, variants compiled / taken from the cache / failed,
         launches that went through them, seconds spent compiling + loading, the variants' template arguments."""
-        counts = (C.c_int64 * 5)()
+        counts = (C.c_int64 * 6)()
         sec = C.c_double()
         text = C.create_string_buffer(2048)
         check(self._lib.gpf_jit_info(self._h, counts, C.byref(sec), text, len(text)), "gpf_jit_info")
         return {"enabled": bool(counts[0]), "compiled": int(counts[1]), "cached": int(counts[2]), "failed": int(counts[3]),
-                "launches": int(counts[4]), "seconds": float(sec.value), "variants": text.value.decode()}
+                "launches": int(counts[4]), "aot": int(counts[5]), "seconds": float(sec.value), "variants": text.value.decode()}
 
     def specialization_header(self) -> str:
         """The generated header the specialised kernels are compiled with (gpf_jit_source): this grid's numbers as C literals."""

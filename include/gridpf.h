@@ -104,7 +104,7 @@ const char* gpf_last_error(void);
 /* ABI version of the library = GPF_ABI_VERSION of the header it was built from.  A binding MUST compare the two before any other
  * call (grid2op_amd/_capi.py does): 300 = round 4 (gpf_set_trajectory(h, cap, what), 22 device pointers, GPF_ST_REDISPATCH,
  * gpf_device_pointers_n); 310 = + gpf_jit_*, GPF_E_UNSUPPORTED, gpf_set_profiling mode 3. */
-#define GPF_ABI_VERSION 310
+#define GPF_ABI_VERSION 320
 int gpf_version(void);
 /* Bitwise run-to-run reproducibility is the DEFAULT on every grid: the same lane inputs give bit-identical results from run to
  * run and whatever the lane's position in the batch (grid2op's determinism contract: same seeds -> same episode,
@@ -287,6 +287,8 @@ int gpf_get_env_state(gpf_handle h, int32_t lane0, int32_t n, float* target, flo
  * info["is_illegal_redisp"] / the IllegalRedispatching exception of that step, baseEnv.py:2140-2173, 3400-3425); copied with the lane
  * by gpf_copy_lanes / gpf_fanout_n1 / gpf_simulate_batch, cleared by gpf_reset_lanes and auto-reset. */
 int gpf_get_env_illegal(gpf_handle h, int32_t lane0, int32_t n, int32_t* count);
+/* overwrite the counters (a lane moved between engines / devices through the host carries its count: ShardedEngine.copy_lanes) */
+int gpf_set_env_illegal(gpf_handle h, int32_t lane0, int32_t n, const int32_t* count);
 int gpf_set_env_state(gpf_handle h, int32_t lane0, int32_t n, const float* target, const float* actual, const float* prev_p,
                       const uint8_t* already_modified, const float* charge, const float* amount_prev, const float* curtail_limit,
                       const float* curtail_prev);
@@ -416,13 +418,18 @@ int gpf_device_pointers_n(gpf_handle h, void** ptrs, int32_t n_ptrs, void** stre
  * Results are BIT-IDENTICAL to the ahead-of-time kernels (same source, same arithmetic in the same order).  Nothing else changes: same
  * buffers, same calls.  The one-power-flow-per-lane kernels of gpf_runpf / gpf_solve_lane are specialised the same way.
  *   src_dir   directory with the kernel sources (NULL: "csrc" next to the library)
- *   cache_dir NULL: $GRIDPF_JIT_CACHE, else "_jit_cache" next to the library
- * The compiler is $GRIDPF_HIPCC, else /opt/rocm/bin/hipcc, else hipcc on PATH; GPF_E_UNSUPPORTED when it does not run or the sources are
- * absent -- the engine then simply keeps the ahead-of-time kernels.  A variant that fails to compile / load is reported on stderr and
+ *   cache_dir NULL: $GRIDPF_JIT_CACHE, else "_jit_cache" next to the library; when that is not writable or not private (owned by
+ *             another user / group- or world-writable / a symbolic link): $XDG_CACHE_HOME/gridpf_jit, $HOME/.cache/gridpf_jit -- created 0700
+ *             and held to the same rule.  Code objects are loaded without an integrity check: only private directories are trusted.
+ * Code objects built ahead of time (grid2op_amd/_aot, made by __graft_entry__.build() for the grids of grid2op_amd/aot/) are used first
+ * and need no compiler at run time.  The compiler is $GRIDPF_HIPCC, else /opt/rocm/bin/hipcc, else hipcc on PATH, started without a
+ * shell; GPF_E_UNSUPPORTED when neither a compiler + cache nor ahead-of-time objects exist, when the sources are absent or the device
+ * is not gfx950 -- the engine then simply keeps the ahead-of-time kernels.  A variant that fails to compile / load is reported on stderr and
  * in gpf_jit_info and runs ahead-of-time.  GRIDPF_JIT=1 in the environment enables it at gpf_create. */
 int gpf_jit_enable(gpf_handle h, const char* src_dir, const char* cache_dir);
 int gpf_jit_disable(gpf_handle h);
-/* counts[5] = {enabled, variants compiled, variants loaded from the cache, variants failed, launches through specialised kernels};
+/* counts[6] = {enabled, variants compiled, variants loaded from the cache, variants failed, launches through specialised kernels,
+ * variants loaded from the ahead-of-time directory ("_aot" next to the library)};
  * seconds = time spent compiling / loading; text = the variants loaded so far (+ the last error).  Any pointer may be NULL. */
 int gpf_jit_info(gpf_handle h, int64_t* counts, double* seconds, char* text, size_t cap);
 /* the header the specialised kernels are compiled with (one grid's numbers as C literals); *need = bytes incl. the terminator */
