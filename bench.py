@@ -67,6 +67,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 F64_PEAK_TFLOPS = 78.6         # MI355X FP64 vector == FP64 matrix peak (spec)
 TRAFFIC_PROFILE = os.path.join("profiles", "r04_traffic.json")
 TRAFFIC_N1 = os.path.join("profiles", "r04_traffic_n1_neurips36.json")
+TRAFFIC_N1_118 = os.path.join("profiles", "r05_traffic_n1_case118.json")
 TRAFFIC_WCCI = os.path.join("profiles", "r04_traffic_wcci118.json")
 TRAFFIC_IDF = os.path.join("profiles", "r04_traffic_idf118.json")
 TRAFFIC_1PL = os.path.join("profiles", "r04_traffic_case14_1perlaunch.json")
@@ -260,6 +261,8 @@ class Ctx:
         def close_and_remember():               # the workloads close their engines: keep what they launched for the record
             try:
                 self.jit_closed.append(eng.specialization())
+                if getattr(self.args, "dump_aot", None):
+                    self.dump_aot(eng, getattr(m, "name", None) or f"grid{m.n_sub}")
             except Exception:
                 pass
             if eng in self.engines:
@@ -267,6 +270,29 @@ class Ctx:
             orig_close()
         eng.close = close_and_remember
         return eng
+
+    def dump_aot(self, eng, label):
+        """developer (--dump-aot DIR): the generated header of every engine's grid + the kernel variants it launched, merged into
+        DIR/manifest.json -- the input of __graft_entry__.build()'s ahead-of-time specialisation (grid2op_amd/aot/)"""
+        import hashlib
+        d = self.args.dump_aot
+        os.makedirs(d, exist_ok=True)
+        hdr = eng.specialization_header()
+        hid = hashlib.sha1(hdr.encode()).hexdigest()[:12]
+        mp = os.path.join(d, "manifest.json")
+        man = json.load(open(mp)) if os.path.exists(mp) else {}
+        ent = man.setdefault(hid, {"header": f"{hid}.h", "grids": [], "variants": []})
+        with open(os.path.join(d, ent["header"]), "w") as f:
+            f.write(hdr)
+        if label not in ent["grids"]:
+            ent["grids"].append(label)
+        for v in eng.specialization()["variants"].split(" | ")[0].split():
+            kname = "runpf" if v.startswith("runpf<") else "step"
+            var = v[v.index("<") + 1:v.index(">")]
+            if [kname, var] not in ent["variants"]:
+                ent["variants"].append([kname, var])
+        with open(mp, "w") as f:
+            json.dump(man, f, indent=1, sort_keys=True)
 
     def specialization(self):
         """what the engines of this run launched: shipped kernels or kernels specialised at run time (summed over the engines)"""
@@ -293,6 +319,10 @@ class Ctx:
 def load_env(name):
     from grid2op_amd.grid_model import GridModel
     m = GridModel.load_npz(os.path.join(GOLD, f"{name}.grid.npz"))
+    try:
+        m.name = name
+    except Exception:
+        pass
     ch = dict(np.load(os.path.join(GOLD, f"{name}.chronics.npz")))
     if "prod_v" not in ch:
         ch["prod_v"] = np.tile((m.gen_vm0 * m.sub_vn_kv[m.gen_sub]).astype(np.float32), (ch["prod_p"].shape[0], 1))
@@ -462,6 +492,15 @@ def roofline_block(eng, wins, B, k, profile, note=None):
            "kernel": tp.get("kernel"), "avg_launch_us": avg_s * 1e6, "launches": n_l, "env_steps_per_launch": spl_eff,
            "algorithmic_bytes_per_step": b_step, "lds_pipe_busy_frac": tp.get("lds_pipe_busy_frac"),
            "lds_bank_conflict_frac_of_lds_cycles": tp.get("lds_bank_conflict_frac_of_lds_cycles"), "valu_busy_frac": tp.get("valu_busy_frac")}
+    if hasattr(eng, "counters"):
+        try:
+            cn = eng.counters()
+            ratio = cn["kernel_dispatches"] / max(cn["step_launches"], 1)
+            if ratio > 1.01:         # a batch of a few residency rounds goes out as one kernel dispatch per round (gridpf_launch_step.hip)
+                blk["kernel_dispatches_per_launch"] = round(ratio, 2)
+                blk["avg_dispatch_us"] = blk["avg_launch_us"] / ratio
+        except Exception:
+            pass
     if note:
         blk["note"] = note
     return blk
@@ -662,7 +701,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo")
     ap.add_argument("--only-env-dynamics", action="store_true",
                     help="developer (profiling): run only the 118-substation workload with the injection dynamics on and print its record")
-    ap.add_argument("--only", default=None, choices=["n1_fanout", "secondary", "dc_ptdf", "secondary_env_dynamics"],
+    ap.add_argument("--only", default=None, choices=["n1_fanout", "n1_fanout_118", "secondary", "dc_ptdf", "secondary_env_dynamics", "ptdf_build_batch"],
                     help="developer (profiling): run only that BASELINE config's workload exactly as the default run does and print its record")
     ap.add_argument("--profile", action="store_true",
                     help="developer (rocprofv3 runs): no pre-roll launches of odd sizes and no last-observation-only sibling windows, so that "
@@ -671,6 +710,7 @@ def main():
                     help="run on the shipped (ahead-of-time) kernels only.  Default: the engines switch their step launches to kernels compiled at run "
                          "time for the workload's grid (gpf_jit_enable: sizes / offsets as literals, bit-identical results, self-tested against the "
                          "shipped kernels); the shipped-kernel headline is then reported beside it as `shipped_kernels`")
+    ap.add_argument("--dump-aot", default=None, help="developer: write the generated headers + launched kernel variants of every engine to this directory")
     ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)   # CPU launcher test: no arithmetic
     args = ap.parse_args()
     if args.gpus < 1:
@@ -697,7 +737,9 @@ def main():
         rec = {"n1_fanout": lambda: workload_n1(ctx, "l2rpn_neurips_2020_track1", 1024, k_sec=k_o),
                "secondary": lambda: workload_wcci(ctx, "l2rpn_wcci_2022_dev", 1024, k_o, w_o, args.cascade),
                "secondary_env_dynamics": lambda: workload_wcci_dynamics(ctx, "l2rpn_wcci_2022_dev", 1024, k_o, w_o),
-               "dc_ptdf": lambda: workload_ptdf(ctx, "l2rpn_idf_2023", 2048, 50, k_sec=k_o, w_sec=w_o)}[args.only]()
+               "dc_ptdf": lambda: workload_ptdf(ctx, "l2rpn_idf_2023", 2048, 50, k_sec=k_o, w_sec=w_o),
+               "n1_fanout_118": lambda: workload_n1(ctx, "l2rpn_wcci_2022_dev", 1024, k_sec=8, profile=TRAFFIC_N1_118, spl=4),
+               "ptdf_build_batch": lambda: workload_ptdf_build_batch(ctx, "l2rpn_idf_2023", 2048, 256)}[args.only]()
         if rank == 0:
             rec["specialization"] = ctx.specialization()
             print(json.dumps(rec))
@@ -939,6 +981,11 @@ def main():
     if secondary and world == 1:
         res["n1_fanout"] = workload_n1(ctx, "l2rpn_neurips_2020_track1", 1024, k_sec=max(10, args.steps // 40))
 
+    # ---- configs[2] on a REAL 118-substation grid (BASELINE says "IEEE 118-bus"; the bundled l2rpn_neurips_2020_track1 is a 36-substation
+    #      sub-area): 1024 envs x (1 intact + 186 single-line outages) = 191 488 lanes, observation per step ------------------
+    if secondary and world == 1:
+        res["n1_fanout_118"] = workload_n1(ctx, "l2rpn_wcci_2022_dev", 1024, k_sec=8, profile=TRAFFIC_N1_118, spl=4)
+
     # ---- BASELINE.json configs[3]: 118-substation grid, storage set-points + zero-sum redispatch, 1024 lanes per GPU -----------
     if secondary:
         sec = workload_wcci(ctx, "l2rpn_wcci_2022_dev", 1024, k_sec, w_sec, args.cascade)
@@ -964,6 +1011,10 @@ def main():
     if secondary and world == 1:
         res["dc_ptdf"] = workload_ptdf(ctx, "l2rpn_idf_2023", 2048, max(20, args.steps // 2), k_sec=max(16, k_sec // 4), w_sec=w_sec)
 
+    # ---- configs[4], per-lane topologies: the DC matrices of 256 distinct topologies factorised on the matrix cores in one launch ----
+    if secondary and world == 1:
+        res["ptdf_build_batch"] = workload_ptdf_build_batch(ctx, "l2rpn_idf_2023", 2048, 256)
+
     if rank == 0:
         # the CPU baseline is timed LAST (rank 0 of the 1-GPU run only): host-only work in the middle of the run would
         # let the GPU clocks drop before the secondary workloads
@@ -982,7 +1033,9 @@ def main():
         ctx.dist.destroy_process_group()
 
 
-def workload_n1(ctx, env, n_envs, k_sec):
+def workload_n1(ctx, env, n_envs, k_sec, profile=None, spl=None):
+    """`spl`: env steps per launch of this workload (default: --steps-per-launch); the 118-substation fan-out (191 488 lanes) runs 4 steps
+    per launch -- its observation trajectory is 2.7 GB per step"""
     m, ch = load_env(env)
     fan = 1 + m.n_line
     eng, T, _ = setup_engine(ctx, m, ch, n_envs, fan)
@@ -992,8 +1045,8 @@ def workload_n1(ctx, env, n_envs, k_sec):
         topo[c::fan, m.line_or_pos_topo_vect[c - 1]] = -1
         topo[c::fan, m.line_ex_pos_topo_vect[c - 1]] = -1
     eng.set_topology(topo)
-    k_sec = cfg_steps(ctx, k_sec)
-    w, w_l, _ = measure_modes(ctx, eng, k_sec, 2, dict(rebalance=1.02), N_WIN_CFG, 10)
+    k_sec = cfg_steps(ctx, k_sec) if spl is None else max(k_sec, 2 * spl)
+    w, w_l, _ = measure_modes(ctx, eng, k_sec, 2, dict(rebalance=1.02), N_WIN_CFG, 10 if spl is None else 2 * spl, spl=spl)
     r = eng.results()
     med = median_window(w)[0]
     out = {"workload": f"{env} ({m.n_sub} substations): {n_envs} envs x (1 intact + {m.n_line} single-line outages) = {B} lanes per GPU, the "
@@ -1004,7 +1057,7 @@ def workload_n1(ctx, env, n_envs, k_sec):
            "windows": summarize(w, ctx.world * n_envs * k_sec),
            "last_observation_only": None if w_l is None else dict(summarize(w_l, ctx.world * n_envs * k_sec), observations=OBS_LAST,
                                                                   lane_power_flows_per_sec=ctx.world * B * k_sec / median_window(w_l)[0]),
-           "roofline": roofline_block(eng, w, B, k_sec, TRAFFIC_N1),
+           "roofline": roofline_block(eng, w, B, k_sec, profile or TRAFFIC_N1),
            "plan": eng.plan() if hasattr(eng, "plan") else None,
            "frac_converged": float(r.converged.mean()),
            "frac_contingencies_diverged_or_islanding": float(1.0 - r.converged.reshape(n_envs, fan)[:, 1:].mean()),
@@ -1179,6 +1232,123 @@ def workload_ptdf_rows(ctx, eng, m, B, t0, n_rows=16, reps=20):
                          "hbm_gbs": hbm / (us * 1e-6) / 1e9 if us > 0 else 0.0, "traffic": None,
                          "flops_per_launch": 2.0 * M * nb_pad * line_pad},
             "oracle_check": chk}
+
+
+def oracle_dc_check(ctx, eng, flows, lanes):
+    """CHECKER leg (never timed): the lanes' DC flows vs the C oracle's DC power flow of the same injection rows on each lane's OWN topology;
+    topologies the oracle reports as islanded must come back as NaN rows."""
+    if ctx.args.no_oracle_check or ctx.args.stub_engine:
+        return None
+    try:
+        from oracle.pf_oracle_c import COracle
+        m = eng.model
+        inj = eng.get_injections()
+        tp, sbv = eng.get_topology()
+        ref = COracle(m).solve_rows(inj[lanes], tp[lanes], sbv[lanes] if m.n_shunt else None, is_dc=True)
+        lay = eng.layout
+        p_ref = ref["out"][:, lay.out_p_or:lay.out_p_or + m.n_line]
+        bad_ref = ref["status"][:, 0] != 0
+        got = flows[lanes]
+        isl_ok = bool(np.array_equal(np.isnan(got).any(axis=1), bad_ref))
+        g_, r_ = got[~bad_ref], p_ref[~bad_ref]
+        return {"n": int(len(lanes)), "n_islanded_in_sample": int(bad_ref.sum()), "islanding_verdicts_equal": isl_ok,
+                "max_abs_err_vs_oracle": float(np.abs(g_ - r_).max()), "ok": bool(isl_ok and np.all(np.abs(g_ - r_) <= 2e-4 + 5e-6 * np.abs(r_))),
+                "against": "oracle/pf_oracle.c DC power flow of the same injection rows on each lane's own topology"}
+    except Exception as exc:
+        return {"error": repr(exc)[:300]}
+
+
+def synthetic_topologies(m, n_topo, rng, max_out=2, max_split=2):
+    """`n_topo` distinct topology rows of an agent population: up to `max_out` lines out, up to `max_split` substations split over two busbars
+    (every other element to busbar 2).  Combinations that island the grid are kept: the engine must report them, not solve them."""
+    pos_sub = np.empty(m.dim_topo, dtype=np.int64)
+    for pos, sub in ((m.line_or_pos_topo_vect, m.line_or_sub), (m.line_ex_pos_topo_vect, m.line_ex_sub), (m.gen_pos_topo_vect, m.gen_sub),
+                     (m.load_pos_topo_vect, m.load_sub)) + (((m.storage_pos_topo_vect, m.storage_sub),) if m.n_storage else ()):
+        pos_sub[pos] = sub
+    big = [s_ for s_ in range(m.n_sub) if (pos_sub == s_).sum() >= 4]
+    base = m.initial_topo_vect()
+    seen, out = set(), []
+    while len(out) < n_topo:
+        t = base.copy()
+        for l in rng.choice(m.n_line, int(rng.integers(0, max_out + 1)), replace=False):
+            t[m.line_or_pos_topo_vect[l]] = -1
+            t[m.line_ex_pos_topo_vect[l]] = -1
+        for s_ in rng.choice(big, int(rng.integers(0, max_split + 1)), replace=False):
+            sel = np.nonzero(pos_sub == s_)[0][int(rng.integers(0, 2))::2]
+            t[sel] = np.where(t[sel] >= 1, 2, t[sel])
+        if t.tobytes() not in seen:
+            seen.add(t.tobytes())
+            out.append(t)
+    return out
+
+
+def workload_ptdf_build_batch(ctx, env, B, n_topo, reps=5):
+    """BASELINE.json configs[4] ("MFMA batched dense solve") with PER-LANE topologies: `B` lanes of the 118-substation grid hold `n_topo`
+    distinct topologies (line outages + bus splits); gpf_ptdf_build_batch factorises the DC matrix of every distinct topology ON THE
+    DEVICE (one workgroup per class, blocked Gauss-Jordan on the FP64 matrix cores, PTDF / LODF formed there), then every lane's DC flows
+    are PTDF_class(lane) x P_bus.  Timed: the build kernel (HIP events) and the whole call (host grouping + upload + kernel); beside it the
+    round-3 host path (gpf_ptdf_build: one topology per call, Gauss-Jordan on a host core)."""
+    if ctx.args.stub_engine:
+        return None
+    m, ch = load_env(env)
+    eng, T, l0 = setup_engine(ctx, m, ch, B)
+    rng = np.random.default_rng(77)
+    topos = synthetic_topologies(m, n_topo, rng)
+    lane_topo = np.concatenate([np.arange(n_topo), rng.integers(0, n_topo, B - n_topo)])
+    rng.shuffle(lane_topo)
+    eng.set_topology(np.stack([topos[i] for i in lane_topo]).astype(np.int32))
+    eng.step(3, n_steps=1, rebalance=1.02)                       # the lanes hold the injections of their chronics row
+    info = eng.ptdf_build_batch(with_lodf=True)                   # warm-up (allocations, LDS attribute)
+    k_ms, w_ms = [], []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        info = eng.ptdf_build_batch(with_lodf=True)
+        w_ms.append((time.perf_counter() - t0) * 1e3)
+        k_ms.append(info["kernel_ms"])
+    k_med, w_med = float(np.median(k_ms)), float(np.median(w_ms))
+    ok_cls = info["class_status"] == 0
+    npad = (np.maximum(info["class_n"], 1) + 15) // 16 * 16
+    flops = float((2.0 * npad[ok_cls].astype(np.float64) ** 3).sum())
+    tf = flops / (k_med * 1e-3) / 1e12
+    # the host path beside it: gpf_ptdf_build of 8 of the same topologies (one lane each)
+    reps_h = [int(np.nonzero(info["lane_class"] == c)[0][0]) for c in np.nonzero(ok_cls)[0][:8]]
+    t0 = time.perf_counter()
+    for k in reps_h:
+        eng.ptdf_build(k)
+    host_s = (time.perf_counter() - t0) / max(len(reps_h), 1)
+    info = eng.ptdf_build_batch(with_lodf=True)                   # back to the per-lane tables
+    for _ in range(3):
+        eng.ptdf_flows(fetch=False)
+    eng.sync()
+    eng.set_profiling(1)
+    for _ in range(20):
+        eng.ptdf_flows(fetch=False)
+    eng.sync()
+    f_ms, f_n = eng.kernel_time()
+    eng.set_profiling(0)
+    flows = eng.ptdf_flows()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        worst = eng.lodf_screen()
+    lodf_s = (time.perf_counter() - t0) / 3
+    chk = oracle_dc_check(ctx, eng, flows, np.sort(np.random.default_rng(78).choice(B, 64, replace=False)))
+    out = {"workload": f"{env} (118 substations), {B} lanes holding {n_topo} distinct topologies (0-2 line outages + 0-2 split substations each): "
+                       "gpf_ptdf_build_batch = B' of every distinct topology assembled, inverted (blocked Gauss-Jordan, FP64 MFMA 16x16x4 tiles) and turned "
+                       "into PTDF^T + LODF on the device, one workgroup per topology (BASELINE.json configs[4]: MFMA batched dense solve)",
+           "classes": int(info["n_classes"]), "classes_ok": int(ok_cls.sum()), "classes_islanded": int((info["class_status"] == 2).sum()),
+           "reduced_dimension": {"min": int(info["class_n"].min()), "max": int(info["class_n"].max())},
+           "value": float(ok_cls.sum()) / (k_med * 1e-3), "unit": "topologies factorised/sec (build kernel)", "kernel_ms": k_med, "kernel_ms_all": [round(x, 4) for x in k_ms],
+           "call_ms": w_med, "call_value": float(ok_cls.sum()) / (w_med * 1e-3), "call_is": "host grouping of the lanes' topology rows + descriptor upload + kernel + status readback",
+           "host_builds_per_sec": 1.0 / host_s, "host_is": "gpf_ptdf_build: the same matrices by Gauss-Jordan on ONE host core (round-3 path), per topology",
+           "speedup_vs_host_path": (float(ok_cls.sum()) / (w_med * 1e-3)) * host_s,
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_PEAK_TFLOPS, "traffic": None,
+                        "flops_per_launch": flops, "flops_are": "2 n^3 per class, n = reduced dimension padded to 16 (the tiles the matrix cores run)",
+                        "avg_launch_us": k_med * 1e3, "kernel": "ptdf_build_kernel"},
+           "flows_per_lane_topology": {"value": B / (f_ms / max(f_n, 1) * 1e-3), "unit": "DC power flows/sec (each lane x its own PTDF)", "us_per_batch": f_ms / max(f_n, 1) * 1e3},
+           "lodf_n1_value": B * m.n_line / lodf_s, "lodf_n1_unit": "DC contingency cases/sec, every lane screened against the LODF of ITS topology (result copied to the host)",
+           "oracle_check": chk}
+    eng.close()
+    return out
 
 
 def workload_simulate(ctx, env, n_envs, n_act):

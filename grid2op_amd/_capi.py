@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "gpf_get_trajectory", "gpf_get_trajectory_obs", "gpf_upload_forecasts", "gpf_simulate_batch", "gpf_set_overflow_count",
     "gpf_set_storage_params", "gpf_set_env_dynamics", "gpf_set_lane_actions", "gpf_get_env_state", "gpf_get_env_illegal", "gpf_set_env_illegal", "gpf_set_env_state", "gpf_set_gen_renewable", "gpf_set_lane_curtailment", "gpf_get_episode", "gpf_lane_capacity", "gpf_get_step_outputs", "gpf_sync",
     "gpf_set_profiling", "gpf_get_kernel_time", "gpf_get_plan", "gpf_device_pointers", "gpf_device_pointers_n",
-    "gpf_ptdf_build", "gpf_ptdf_get", "gpf_ptdf_flows", "gpf_get_ptdf_flows", "gpf_ptdf_flows_rows", "gpf_get_ptdf_flows_rows", "gpf_lodf_screen",
+    "gpf_get_counters", "gpf_ptdf_build", "gpf_ptdf_build_batch", "gpf_ptdf_batch_info", "gpf_ptdf_batch_get", "gpf_ptdf_get", "gpf_ptdf_flows", "gpf_get_ptdf_flows", "gpf_ptdf_flows_rows", "gpf_get_ptdf_flows_rows", "gpf_lodf_screen",
     "gpf_jit_enable", "gpf_jit_disable", "gpf_jit_info", "gpf_jit_source",
 ]
 
@@ -166,6 +166,10 @@ def lib() -> C.CDLL:
     L.gpf_device_pointers_n.argtypes = [h, C.POINTER(C.c_void_p), i32, C.POINTER(C.c_void_p)]
     L.gpf_ptdf_build.argtypes = [h, i32]
     L.gpf_ptdf_get.argtypes = [h, _dp]
+    L.gpf_get_counters.argtypes = [h, C.POINTER(C.c_int64)]
+    L.gpf_ptdf_build_batch.argtypes = [h, i32, i32, i32, _ip]
+    L.gpf_ptdf_batch_info.argtypes = [h, _ip, _ip, _ip, _dp]
+    L.gpf_ptdf_batch_get.argtypes = [h, i32, _dp, _dp]
     L.gpf_ptdf_flows.argtypes = [h, i32, i32]
     L.gpf_get_ptdf_flows.argtypes = [h, i32, i32, _fp]
     L.gpf_ptdf_flows_rows.argtypes = [h, i32, i32, C.c_double]

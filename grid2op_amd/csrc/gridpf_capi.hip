@@ -20,6 +20,7 @@
 #include "gridpf_sparse.hpp"
 #include "gridpf_host.hpp"
 #include "gridpf_ptdf.hpp"
+#include "gridpf_ptdf_batch.hpp"
 #include "gridpf_redispatch.hpp"
 #include <string>
 #include <unordered_map>
@@ -217,6 +218,15 @@ struct gpf_engine {
   std::vector<int> h_gen_cnt;
   int ptdf_nb_pad = 0, ptdf_line_pad = 0;
   bool ptdf_ready = false;
+  // per-lane topologies (gpf_ptdf_build_batch, gridpf_ptdf_batch.hpp): one PTDF^T / LODF block per distinct topology class of a lane range
+  long long n_step_calls = 0, n_step_dispatches = 0;   // gpf_step_n calls / kernel dispatches they issued (gpf_get_counters)
+  bool ptdf_batch = false;                 // the flows / screening calls run on the class tables of the last gpf_ptdf_build_batch
+  int ptdfb_lane0 = 0, ptdfb_n = 0, ptdfb_classes = 0, ptdfb_slots = 0, ptdfb_kpad = 0, ptdfb_npad_max = 0, ptdfb_desc_stride = 0;
+  DevArr<int> ptdfb_desc, ptdfb_order, ptdfb_blk_class, ptdfb_status;
+  DevArr<double> ptdfb_work, ptdfb_t, ptdfb_lodf, ptdfb_inj_w;
+  std::vector<int> h_ptdfb_lane_class, h_ptdfb_status, h_ptdfb_desc;
+  std::vector<std::vector<int>> h_ptdfb_bus;   // per class: compact bus index -> bus id (sub + (local - 1) * n_sub)
+  double ptdfb_kernel_ms = 0.0;            // duration of the last build kernel (HIP events)
   DevArr<double> dc_inv_g;     // static DC inverse of the larger grids (gpf::SymDev::dc_inv_g)
   DevArr<double> stat_dbl;     // static blob of kernel S (gpf::StatOff)
   DevArr<int> stat_int;
@@ -1173,6 +1183,8 @@ int gpf_destroy(gpf_handle e) {
   e->classes.clear();
   e->ptdf_inj_bus.release(); e->ptdf_inj_w.release(); e->ptdf_t.release(); e->ptdf_flow.release();
   e->lodf.release(); e->lodf_worst.release(); e->lodf_inv_cap.release(); e->ptdf_flow_rows.release();
+  e->ptdfb_desc.release(); e->ptdfb_order.release(); e->ptdfb_blk_class.release(); e->ptdfb_status.release();
+  e->ptdfb_work.release(); e->ptdfb_t.release(); e->ptdfb_lodf.release(); e->ptdfb_inj_w.release();
   e->stat_int.release();
   e->flat_prog.release();
   delete e;
@@ -1584,8 +1596,10 @@ int step_range(gpf_engine* e, const gpf::Bufs& b_in, int lane0, int n, int t0, i
   if (e->profiling) { rc = prof_begin(e, ea, eb); if (rc != GPF_OK) return rc; }
   p.env = pb.env = e->env_on;
   p.jit = pb.jit = jit_for_launch(e);
-  HIP_TRY(gpf_launch_step_sparse(p, e->device, e->d_params_s, e->stream, n, o->max_iter, tol_pu, sa));
-  if (pb.sparse_nb) HIP_TRY(gpf_launch_step_sparse(pb, e->device, e->d_params_s, e->stream, n, o->max_iter, tol_pu, sa));
+  int n_disp = 0;
+  HIP_TRY(gpf_launch_step_sparse(p, e->device, e->d_params_s, e->stream, n, o->max_iter, tol_pu, sa, &n_disp));
+  if (pb.sparse_nb) HIP_TRY(gpf_launch_step_sparse(pb, e->device, e->d_params_s, e->stream, n, o->max_iter, tol_pu, sa, &n_disp));
+  e->n_step_calls += 1; e->n_step_dispatches += n_disp;
   HIP_TRY(hipGetLastError());
   if (e->profiling) HIP_TRY(hipEventRecord(eb, e->stream));
   if (e->window) { ++e->win_launches; e->win_marked = false; }
@@ -2240,13 +2254,22 @@ int gpf_ptdf_build(gpf_handle e, int32_t lane) {
   }
   {   // LODF[l][k] = H[l][k] / (1 - H[k][k]), H[l][k] = PTDF[l][from_k] - PTDF[l][to_k]; LODF[k][k] = -1
     std::vector<double> lo_((size_t)g.n_line * line_pad, 0.0);
+    // elements on every bus: a line whose outage only removes a bus that carries nothing else (one line end, no injection) does not
+    // island anything -- the reference's DC power flow of that contingency converges with every other flow unchanged: column of zeros
+    std::vector<int> n_lines_at(nbt, 0), n_other_at(nbt, 0);
+    for (int l = 0; l < g.n_line; ++l) if (lf[l] >= 0) { ++n_lines_at[lf[l]]; ++n_lines_at[lt[l]]; }
+    for (int i = 0; i < g.n_gen; ++i) { const int b = bus_of(e->h_gen_sub[i], topo[e->h_gen_pos[i]]); if (b >= 0) ++n_other_at[b]; }
+    for (int i = 0; i < g.n_load; ++i) { const int b = bus_of(e->h_load_sub[i], topo[e->h_load_pos[i]]); if (b >= 0) ++n_other_at[b]; }
+    for (int i = 0; i < g.n_sto; ++i) { const int b = bus_of(e->h_sto_sub[i], topo[e->h_sto_pos[i]]); if (b >= 0) ++n_other_at[b]; }
+    for (int i = 0; i < g.n_shunt; ++i) { const int b = bus_of(e->h_shunt_sub[i], sb[i]); if (b >= 0) ++n_other_at[b]; }
     for (int k = 0; k < g.n_line; ++k) {
       if (lf[k] < 0 || lf[k] == lt[k]) continue;                 // an open line: its outage changes nothing
       const double hkk = e->h_ptdf[(size_t)k * nbt + lf[k]] - e->h_ptdf[(size_t)k * nbt + lt[k]];
       const double den = 1.0 - hkk;
+      const bool dangling = (n_lines_at[lf[k]] == 1 && n_other_at[lf[k]] == 0) || (n_lines_at[lt[k]] == 1 && n_other_at[lt[k]] == 0);
       for (int l = 0; l < g.n_line; ++l) {
         const double hlk = e->h_ptdf[(size_t)l * nbt + lf[k]] - e->h_ptdf[(size_t)l * nbt + lt[k]];
-        lo_[(size_t)l * line_pad + k] = std::fabs(den) < 1e-8 ? std::nan("") : (l == k ? -1.0 : hlk / den);
+        lo_[(size_t)l * line_pad + k] = std::fabs(den) < 1e-8 ? (dangling ? 0.0 : std::nan("")) : (l == k ? -1.0 : hlk / den);
       }
     }
     e->lodf.release();
@@ -2256,12 +2279,240 @@ int gpf_ptdf_build(gpf_handle e, int32_t lane) {
   }
   e->ptdf_nb_pad = nb_pad; e->ptdf_line_pad = line_pad;
   e->ptdf_ready = true;
+  e->ptdf_batch = false;
+  return GPF_OK;
+}
+
+// PtdfDev of the tables the flows / screening kernels run on: the single topology of gpf_ptdf_build or the class tables of gpf_ptdf_build_batch
+static gpf::PtdfDev ptdf_dev(gpf_engine* e) {
+  gpf::PtdfDev P{};
+  P.n_inj = e->g.n_inj; P.nb_pad = e->ptdf_nb_pad; P.line_pad = e->ptdf_line_pad; P.n_line = e->g.n_line;
+  if (e->ptdf_batch) {
+    P.inj_bus = nullptr; P.inj_w = e->ptdfb_inj_w.p; P.ptdf_t = e->ptdfb_t.p;
+    P.order = e->ptdfb_order.p; P.blk_class = e->ptdfb_blk_class.p; P.cls_desc = e->ptdfb_desc.p; P.cls_status = e->ptdfb_status.p;
+    P.desc_stride = e->ptdfb_desc_stride; P.inj_bus_off = gpf::PTDFB_HDR + 2 * e->g.n_line;
+    P.ptdf_stride = (long long)e->ptdfb_kpad * e->ptdf_line_pad;
+  } else {
+    P.inj_bus = e->ptdf_inj_bus.p; P.inj_w = e->ptdf_inj_w.p; P.ptdf_t = e->ptdf_t.p;
+  }
+  return P;
+}
+
+/* ---- PTDF / LODF of every distinct topology of a lane range, built on the device (gridpf_ptdf_batch.hpp) --------------------------- */
+int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lodf, int32_t* n_classes_out) {
+  if (!check_range(e, lane0, n) || n <= 0) return fail(GPF_E_INVALID, "gpf_ptdf_build_batch: bad lane range");
+  HIP_TRY(hipSetDevice(e->device));
+  const gpf::GridDev& g = e->g;
+  const gpf::OutOff& oo = e->oo;
+  const int nl = g.n_line, nbt = g.nb_tot, nsh = g.n_shunt;
+  // the lanes' topology rows as they are on the device (a cascade inside gpf_step_n may have tripped lines the host never saw)
+  std::vector<int> topo((size_t)n * g.dim_topo), sb((size_t)n * std::max(nsh, 1));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpy(topo.data(), e->topo.p + (size_t)lane0 * g.dim_topo, topo.size() * sizeof(int), hipMemcpyDeviceToHost));
+  if (nsh) HIP_TRY(hipMemcpy(sb.data(), e->shunt_bus.p + (size_t)lane0 * nsh, (size_t)n * nsh * sizeof(int), hipMemcpyDeviceToHost));
+  // ---- classes: lanes with identical (topology row, shunt buses) ----------------------------------------------------------------------
+  std::unordered_map<std::string, int> cls_of;
+  std::vector<int> first_lane;                       // representative lane (index in the range) of each class
+  e->h_ptdfb_lane_class.assign(n, -1);
+  for (int k = 0; k < n; ++k) {
+    std::string key(reinterpret_cast<const char*>(topo.data() + (size_t)k * g.dim_topo), (size_t)g.dim_topo * sizeof(int));
+    if (nsh) key.append(reinterpret_cast<const char*>(sb.data() + (size_t)k * nsh), (size_t)nsh * sizeof(int));
+    auto it = cls_of.find(key);
+    if (it == cls_of.end()) { it = cls_of.emplace(std::move(key), (int)first_lane.size()).first; first_lane.push_back(k); }
+    e->h_ptdfb_lane_class[k] = it->second;
+  }
+  const int nc = (int)first_lane.size();
+  const int stride = (gpf::PTDFB_HDR + 3 * nl + g.n_inj + 3) & ~3;
+  std::vector<int> desc((size_t)nc * stride, -1);
+  e->h_ptdfb_bus.assign(nc, std::vector<int>());
+  int npad_max = 16, nact_max = 1;
+  auto bus_of = [&](int sub, int local) -> int { return (local >= 1 && local <= g.n_busbar) ? sub + (local - 1) * g.n_sub : -1; };
+  for (int c = 0; c < nc; ++c) {
+    const int* tp = topo.data() + (size_t)first_lane[c] * g.dim_topo;
+    const int* sbp = sb.data() + (size_t)first_lane[c] * std::max(nsh, 1);
+    int* d = desc.data() + (size_t)c * stride;
+    int* lf = d + gpf::PTDFB_HDR;
+    int* lt = lf + nl;
+    int* ib = lt + nl;
+    int* lflag = ib + g.n_inj;
+    std::vector<char> act(nbt, 0), ref(nbt, 0);
+    std::vector<int> bf(nl, -1), bt(nl, -1);
+    std::vector<int> n_lines_at(nbt, 0), n_other_at(nbt, 0);   // in-service line ends / other elements on each bus
+    for (int l = 0; l < nl; ++l) {
+      const int bo = tp[e->h_line_or_pos[l]], be = tp[e->h_line_ex_pos[l]];
+      if (bo >= 1 && be >= 1) {
+        bf[l] = bus_of(e->h_line_or_sub[l], bo); bt[l] = bus_of(e->h_line_ex_sub[l], be);
+        if (bf[l] < 0 || bt[l] < 0) return fail(GPF_E_INVALID, "gpf_ptdf_build_batch: bus id out of range");
+        act[bf[l]] = act[bt[l]] = 1;
+      }
+    }
+    std::vector<int> ibus(g.n_inj, -1);
+    for (int i = 0; i < g.n_gen; ++i) {
+      const int b = bus_of(e->h_gen_sub[i], tp[e->h_gen_pos[i]]);
+      if (b < 0) continue;
+      act[b] = 1;
+      ++n_other_at[b];
+      if (e->h_gen_slack[i]) ref[b] = 1; else ibus[oo.inj_gen_p + i] = b;
+    }
+    for (int i = 0; i < g.n_load; ++i) { const int b = bus_of(e->h_load_sub[i], tp[e->h_load_pos[i]]); if (b >= 0) { act[b] = 1; ++n_other_at[b]; ibus[oo.inj_load_p + i] = b; } }
+    for (int i = 0; i < g.n_sto; ++i) { const int b = bus_of(e->h_sto_sub[i], tp[e->h_sto_pos[i]]); if (b >= 0) { act[b] = 1; ++n_other_at[b]; ibus[oo.inj_sto_p + i] = b; } }
+    for (int i = 0; i < nsh; ++i) { const int b = bus_of(e->h_shunt_sub[i], sbp[i]); if (b >= 0) { act[b] = 1; ++n_other_at[b]; ibus[oo.inj_sh_p + i] = b; } }
+    for (int l = 0; l < nl; ++l) if (bf[l] >= 0) { ++n_lines_at[bf[l]]; ++n_lines_at[bt[l]]; }
+    // compact numbering: active non-reference buses first, then the active reference buses
+    std::vector<int> compact(nbt, -1);
+    std::vector<int>& c2b = e->h_ptdfb_bus[c];
+    int nr = 0, n_act = 0;
+    for (int b = 0; b < nbt; ++b) if (act[b] && !ref[b]) { compact[b] = nr++; c2b.push_back(b); }
+    n_act = nr;
+    bool any_ref = false;
+    for (int b = 0; b < nbt; ++b) if (act[b] && ref[b]) { compact[b] = n_act++; c2b.push_back(b); any_ref = true; }
+    // connectivity (rundcpp(check_connectivity=True), pandaPowerBackend.py:1090): every active bus must reach a reference bus
+    int status = any_ref ? 0 : 3;
+    if (any_ref) {
+      std::vector<int> comp(nbt);
+      for (int b = 0; b < nbt; ++b) comp[b] = b;
+      auto find = [&](int x) { while (comp[x] != x) { comp[x] = comp[comp[x]]; x = comp[x]; } return x; };
+      for (int l = 0; l < nl; ++l) if (bf[l] >= 0 && bf[l] != bt[l]) comp[find(bf[l])] = find(bt[l]);
+      std::vector<char> has_ref(nbt, 0);
+      for (int b = 0; b < nbt; ++b) if (act[b] && ref[b]) has_ref[find(b)] = 1;
+      for (int b = 0; b < nbt; ++b) if (act[b] && !has_ref[find(b)]) { status = 2; break; }
+    }
+    const int n_pad = std::max(16, (nr + 15) & ~15);
+    if (n_pad > gpf::PTDFB_MAX_N) return fail(GPF_E_CAPACITY, "gpf_ptdf_build_batch: more than 256 active non-reference buses in one topology");
+    d[0] = nr; d[1] = n_act; d[2] = n_pad; d[3] = status;
+    for (int l = 0; l < nl; ++l) {
+      const bool on = bf[l] >= 0 && bf[l] != bt[l];
+      lf[l] = on ? compact[bf[l]] : -1; lt[l] = on ? compact[bt[l]] : -1;
+      // a line end on a bus that carries nothing else: the outage of the line removes the bus (no islanding, the other flows stand)
+      lflag[l] = (on && ((n_lines_at[bf[l]] == 1 && n_other_at[bf[l]] == 0) || (n_lines_at[bt[l]] == 1 && n_other_at[bt[l]] == 0))) ? 1 : 0;
+    }
+    for (int i = 0; i < g.n_inj; ++i) ib[i] = ibus[i] >= 0 ? compact[ibus[i]] : -1;
+    npad_max = std::max(npad_max, n_pad);
+    nact_max = std::max(nact_max, n_act);
+  }
+  // ---- slots: lanes grouped by class, every group padded to a multiple of 16 ------------------------------------------------------------
+  std::vector<std::vector<int>> members(nc);
+  for (int k = 0; k < n; ++k) members[e->h_ptdfb_lane_class[k]].push_back(lane0 + k);
+  std::vector<int> order, blk_class;
+  for (int c = 0; c < nc; ++c) {
+    for (int ln : members[c]) order.push_back(ln);
+    while (order.size() & 15) order.push_back(-1);
+    while (blk_class.size() * 16 < order.size()) blk_class.push_back(c);
+  }
+  const int line_pad = (nl + 15) & ~15;
+  const int nb_pad = std::max(4, (nact_max + 3) & ~3), kpad = (nb_pad + 31) & ~31;
+  e->ptdf_ready = false;
+  e->ptdfb_desc.release(); e->ptdfb_order.release(); e->ptdfb_blk_class.release(); e->ptdfb_status.release();
+  e->ptdfb_work.release(); e->ptdfb_t.release(); e->ptdfb_lodf.release();
+  HIP_TRY(e->ptdfb_desc.upload(desc.data(), desc.size()));
+  HIP_TRY(e->ptdfb_order.upload(order.data(), order.size()));
+  HIP_TRY(e->ptdfb_blk_class.upload(blk_class.data(), blk_class.size()));
+  HIP_TRY(e->ptdfb_status.alloc(nc));
+  HIP_TRY(e->ptdfb_work.alloc((size_t)nc * npad_max * npad_max));
+  HIP_TRY(e->ptdfb_t.alloc((size_t)nc * kpad * line_pad));
+  if (with_lodf) HIP_TRY(e->ptdfb_lodf.alloc((size_t)nc * nl * line_pad));
+  if (!e->ptdfb_inj_w.p) {
+    std::vector<double> w(g.n_inj, 0.0);
+    for (int i = 0; i < g.n_gen; ++i) w[oo.inj_gen_p + i] = 1.0;
+    for (int i = 0; i < g.n_load; ++i) w[oo.inj_load_p + i] = -1.0;
+    for (int i = 0; i < g.n_sto; ++i) w[oo.inj_sto_p + i] = -1.0;
+    for (int i = 0; i < nsh; ++i) w[oo.inj_sh_p + i] = -e->h_shunt_fact[i];
+    HIP_TRY(e->ptdfb_inj_w.upload(w.data(), w.size()));
+  }
+  if (e->ptdf_line_pad != line_pad || !e->ptdf_flow.p) { e->ptdf_flow.release(); HIP_TRY(e->ptdf_flow.alloc((size_t)e->cap_lanes * line_pad)); }
+  if (with_lodf && (e->ptdf_line_pad != line_pad || !e->lodf_worst.p)) { e->lodf_worst.release(); HIP_TRY(e->lodf_worst.alloc((size_t)e->cap_lanes * line_pad)); }
+  gpf::PtdfBuildDev D{};
+  D.n_line = nl; D.line_pad = line_pad; D.n_inj = g.n_inj; D.kpad = kpad; D.desc_stride = stride;
+  D.work_stride = (long long)npad_max * npad_max; D.ptdf_stride = (long long)kpad * line_pad; D.lodf_stride = (long long)nl * line_pad;
+  D.desc = e->ptdfb_desc.p; D.br_bdc = e->br_bdc.p; D.work = e->ptdfb_work.p; D.ptdf_t = e->ptdfb_t.p; D.lodf = with_lodf ? e->ptdfb_lodf.p : nullptr;
+  D.status = e->ptdfb_status.p;
+  DevArr<long long> dbg;
+  static const bool want_dbg = getenv("GRIDPF_PTDFB_DEBUG") != nullptr;     // developer: per-phase shader-clock stamps of class 0 on stderr
+  if (want_dbg) { HIP_TRY(dbg.alloc((size_t)nc * 8)); HIP_TRY(hipMemset(dbg.p, 0, (size_t)nc * 8 * sizeof(long long))); D.dbg = dbg.p; }
+  // reduced dimension <= 128 (118-substation grids): the matrix of a class lives in LDS (ptdf_build_lds_kernel), else in global memory
+  static const bool no_resident = getenv("GRIDPF_PTDFB_GLOBAL") != nullptr;   // developer: force the global-memory kernel
+  const bool resident = npad_max <= 128 && !no_resident;
+  const size_t lds = resident ? gpf::ptdfb_lds_bytes_resident(npad_max, line_pad) : gpf::ptdfb_lds_bytes(npad_max, line_pad);
+  static size_t lds_set[64][2] = {{0}};
+  if (lds > lds_set[e->device & 63][resident]) {
+    HIP_TRY(hipFuncSetAttribute(resident ? reinterpret_cast<const void*>(&gpf::ptdf_build_lds_kernel) : reinterpret_cast<const void*>(&gpf::ptdf_build_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set[e->device & 63][resident] = lds;
+  }
+  hipEvent_t ea = nullptr, eb = nullptr;
+  HIP_TRY(hipEventCreate(&ea)); HIP_TRY(hipEventCreate(&eb));
+  HIP_TRY(hipEventRecord(ea, e->stream));
+  if (resident) hipLaunchKernelGGL(gpf::ptdf_build_lds_kernel, dim3(nc), dim3(gpf::PTDFB_THREADS), lds, e->stream, D);
+  else hipLaunchKernelGGL(gpf::ptdf_build_kernel, dim3(nc), dim3(gpf::PTDFB_THREADS), lds, e->stream, D);
+  hipError_t le = hipGetLastError();
+  HIP_TRY(hipEventRecord(eb, e->stream));
+  if (le != hipSuccess) { (void)hipEventDestroy(ea); (void)hipEventDestroy(eb); return fail(GPF_E_DEVICE, std::string("ptdf_build_kernel: ") + hipGetErrorString(le)); }
+  e->h_ptdfb_status.assign(nc, 0);
+  HIP_TRY(hipMemcpyAsync(e->h_ptdfb_status.data(), e->ptdfb_status.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, ea, eb);
+  (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+  e->ptdfb_kernel_ms = ms;
+  if (want_dbg) {
+    std::vector<long long> h((size_t)nc * 8);
+    (void)hipMemcpy(h.data(), dbg.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+    int c_ok = 0;
+    while (c_ok < nc - 1 && e->h_ptdfb_status[c_ok] != 0) ++c_ok;
+    const long long* s_ = h.data() + (size_t)c_ok * 8;
+    fprintf(stderr, "[gridpf] ptdf_build_kernel class %d (n_pad %d), shader clocks: assemble %lld, gauss-jordan %lld (panel loads %lld, tile inversions %lld, trailing "
+                    "updates %lld), PTDF^T %lld, LODF %lld; kernel %.1f us\n", c_ok, desc[(size_t)c_ok * stride + 2], s_[1] - s_[0], s_[3] - s_[1], s_[7], s_[2], s_[6],
+            s_[4] - s_[3], s_[5] ? s_[5] - s_[4] : 0LL, ms * 1e3);
+    dbg.release();
+  }
+  if (e->window) { ++e->win_launches; e->win_marked = false; }
+  e->h_ptdfb_desc = desc;
+  e->ptdfb_lane0 = lane0; e->ptdfb_n = n; e->ptdfb_classes = nc; e->ptdfb_slots = (int)order.size(); e->ptdfb_kpad = kpad;
+  e->ptdfb_npad_max = npad_max; e->ptdfb_desc_stride = stride;
+  e->ptdf_nb_pad = nb_pad; e->ptdf_line_pad = line_pad;
+  e->ptdf_rows_valid = 0;
+  e->ptdf_batch = true;
+  e->ptdf_ready = true;
+  if (n_classes_out) *n_classes_out = nc;
+  return GPF_OK;
+}
+
+int gpf_ptdf_batch_info(gpf_handle e, int32_t* lane_class, int32_t* class_status, int32_t* class_n, double* kernel_ms) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_ptdf_batch_info: null");
+  if (!e->ptdf_ready || !e->ptdf_batch) return fail(GPF_E_INVALID, "gpf_ptdf_batch_info: call gpf_ptdf_build_batch first");
+  if (lane_class) std::copy(e->h_ptdfb_lane_class.begin(), e->h_ptdfb_lane_class.end(), lane_class);
+  if (class_status) std::copy(e->h_ptdfb_status.begin(), e->h_ptdfb_status.end(), class_status);
+  if (class_n) for (int c = 0; c < e->ptdfb_classes; ++c) class_n[c] = e->h_ptdfb_desc[(size_t)c * e->ptdfb_desc_stride];
+  if (kernel_ms) *kernel_ms = e->ptdfb_kernel_ms;
+  return GPF_OK;
+}
+
+int gpf_ptdf_batch_get(gpf_handle e, int32_t cls, double* ptdf, double* lodf) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_ptdf_batch_get: null");
+  if (!e->ptdf_ready || !e->ptdf_batch) return fail(GPF_E_INVALID, "gpf_ptdf_batch_get: call gpf_ptdf_build_batch first");
+  if (cls < 0 || cls >= e->ptdfb_classes) return fail(GPF_E_INVALID, "gpf_ptdf_batch_get: bad class");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const int nl = e->g.n_line, lp = e->ptdf_line_pad, nbt = e->g.nb_tot, kpad = e->ptdfb_kpad;
+  if (ptdf) {
+    std::vector<double> pt((size_t)kpad * lp);
+    HIP_TRY(hipMemcpy(pt.data(), e->ptdfb_t.p + (size_t)cls * kpad * lp, pt.size() * sizeof(double), hipMemcpyDeviceToHost));
+    std::fill(ptdf, ptdf + (size_t)nl * nbt, 0.0);
+    const std::vector<int>& c2b = e->h_ptdfb_bus[cls];
+    for (size_t c = 0; c < c2b.size(); ++c)
+      for (int l = 0; l < nl; ++l) ptdf[(size_t)l * nbt + c2b[c]] = pt[c * lp + l];
+  }
+  if (lodf) {
+    if (!e->ptdfb_lodf.p) return fail(GPF_E_INVALID, "gpf_ptdf_batch_get: the batch was built without LODF tables");
+    HIP_TRY(hipMemcpy2D(lodf, (size_t)nl * sizeof(double), e->ptdfb_lodf.p + (size_t)cls * nl * lp, (size_t)lp * sizeof(double), (size_t)nl * sizeof(double),
+                        (size_t)nl, hipMemcpyDeviceToHost));
+  }
   return GPF_OK;
 }
 
 int gpf_ptdf_get(gpf_handle e, double* ptdf) {
   if (!e || !ptdf) return fail(GPF_E_INVALID, "gpf_ptdf_get: null");
-  if (!e->ptdf_ready) return fail(GPF_E_INVALID, "gpf_ptdf_get: call gpf_ptdf_build first");
+  if (!e->ptdf_ready || e->ptdf_batch) return fail(GPF_E_INVALID, "gpf_ptdf_get: call gpf_ptdf_build first (per-lane topologies: gpf_ptdf_batch_get)");
   std::copy(e->h_ptdf.begin(), e->h_ptdf.end(), ptdf);
   return GPF_OK;
 }
@@ -2270,12 +2521,13 @@ int gpf_ptdf_flows(gpf_handle e, int32_t lane0, int32_t n) {
   if (!check_range(e, lane0, n)) return fail(GPF_E_INVALID, "gpf_ptdf_flows: bad range");
   if (!e->ptdf_ready) return fail(GPF_E_INVALID, "gpf_ptdf_flows: call gpf_ptdf_build first");
   if (n == 0) return GPF_OK;
+  if (e->ptdf_batch && (lane0 != e->ptdfb_lane0 || n != e->ptdfb_n))
+    return fail(GPF_E_INVALID, "gpf_ptdf_flows: per-lane topologies (gpf_ptdf_build_batch): the call must cover exactly the lane range that was built");
   HIP_TRY(hipSetDevice(e->device));
-  gpf::PtdfDev P{};
-  P.n_inj = e->g.n_inj; P.nb_pad = e->ptdf_nb_pad; P.line_pad = e->ptdf_line_pad; P.n_line = e->g.n_line;
-  P.inj_bus = e->ptdf_inj_bus.p; P.inj_w = e->ptdf_inj_w.p; P.ptdf_t = e->ptdf_t.p;
+  const gpf::PtdfDev P = ptdf_dev(e);
   const size_t lds_a = (size_t)16 * gpf::ptdf_a_stride(P.nb_pad) * sizeof(double);
-  hipLaunchKernelGGL(gpf::ptdf_flows_kernel, dim3((n + 15) / 16, (P.line_pad / 16 + 3) / 4), dim3(256), lds_a, e->stream, P, e->inj.p, lane0, n,
+  const int n_blk = e->ptdf_batch ? e->ptdfb_slots / 16 : (n + 15) / 16;
+  hipLaunchKernelGGL(gpf::ptdf_flows_kernel, dim3(n_blk, (P.line_pad / 16 + 3) / 4), dim3(256), lds_a, e->stream, P, e->inj.p, lane0, n,
                      e->ptdf_flow.p);
   HIP_TRY(hipGetLastError());
   if (e->window) { ++e->win_launches; e->win_marked = false; }
@@ -2293,9 +2545,9 @@ int gpf_ptdf_flows_rows(gpf_handle e, int32_t t0, int32_t n_rows, double rebalan
     e->ptdf_flow_rows.release();
     HIP_TRY(e->ptdf_flow_rows.alloc(need));
   }
-  gpf::PtdfDev P{};
-  P.n_inj = e->g.n_inj; P.nb_pad = e->ptdf_nb_pad; P.line_pad = e->ptdf_line_pad; P.n_line = e->g.n_line;
-  P.inj_bus = e->ptdf_inj_bus.p; P.inj_w = e->ptdf_inj_w.p; P.ptdf_t = e->ptdf_t.p;
+  if (e->ptdf_batch && (e->ptdfb_lane0 != 0 || e->ptdfb_n != e->n_lanes))
+    return fail(GPF_E_INVALID, "gpf_ptdf_flows_rows: per-lane topologies (gpf_ptdf_build_batch) must have been built for ALL lanes");
+  const gpf::PtdfDev P = ptdf_dev(e);
   gpf::PtdfRowsDev R{};
   R.chron = e->chron.p; R.lane_table = e->lane_table.p; R.lane_offset = e->lane_offset.p;
   R.lane_scale = e->has_scale ? e->lane_scale.p : nullptr; R.lane_gen_delta = e->has_delta ? e->lane_gen_delta.p : nullptr;
@@ -2308,7 +2560,9 @@ int gpf_ptdf_flows_rows(gpf_handle e, int32_t t0, int32_t n_rows, double rebalan
   const int NP = 16 * mt;
   const size_t lds_a = (size_t)NP * gpf::ptdf_rows_stride(R.kpad) * sizeof(double);
   const long long n_pairs = (long long)e->n_lanes * n_rows;
-  const dim3 grid((unsigned)((n_pairs + NP - 1) / NP));
+  // per-lane topologies: one block per (group of 16 slots, mt consecutive rows), see ptdf_rows_kernel
+  const int n_units = e->ptdf_batch ? e->ptdfb_slots : e->n_lanes;
+  const dim3 grid(e->ptdf_batch ? (unsigned)((size_t)(e->ptdfb_slots / 16) * ((n_rows + mt - 1) / mt)) : (unsigned)((n_pairs + NP - 1) / NP));
   static size_t lds_set[64][3] = {{0}};
 #define GPF_PTDF_ROWS(MT_, SLOT_)                                                                                                      \
   do {                                                                                                                                 \
@@ -2316,7 +2570,7 @@ int gpf_ptdf_flows_rows(gpf_handle e, int32_t t0, int32_t n_rows, double rebalan
       HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::ptdf_rows_kernel<MT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_a)); \
       lds_set[e->device & 63][SLOT_] = lds_a;                                                                                          \
     }                                                                                                                                  \
-    hipLaunchKernelGGL(gpf::ptdf_rows_kernel<MT_>, grid, dim3(256), lds_a, e->stream, P, R, e->inj.p, e->n_lanes, (long long)e->cap_lanes, t0, \
+    hipLaunchKernelGGL(gpf::ptdf_rows_kernel<MT_>, grid, dim3(256), lds_a, e->stream, P, R, e->inj.p, n_units, (long long)e->cap_lanes, t0, \
                        n_rows, e->ptdf_flow_rows.p);                                                                                   \
   } while (0)
   if (mt == 4) GPF_PTDF_ROWS(4, 2); else if (mt == 2) GPF_PTDF_ROWS(2, 1); else GPF_PTDF_ROWS(1, 0);
@@ -2354,6 +2608,8 @@ int gpf_lodf_screen(gpf_handle e, int32_t lane0, int32_t n, const float* cap_mw,
   if (!check_range(e, lane0, n) || !worst) return fail(GPF_E_INVALID, "gpf_lodf_screen: bad arguments");
   if (!e->ptdf_ready) return fail(GPF_E_INVALID, "gpf_lodf_screen: call gpf_ptdf_build and gpf_ptdf_flows first");
   if (n == 0) return GPF_OK;
+  if (e->ptdf_batch && (lane0 != e->ptdfb_lane0 || n != e->ptdfb_n || !e->ptdfb_lodf.p))
+    return fail(GPF_E_INVALID, "gpf_lodf_screen: per-lane topologies: build them with LODF tables and screen exactly the lane range that was built");
   HIP_TRY(hipSetDevice(e->device));
   const int nl = e->g.n_line, lp = e->ptdf_line_pad;
   const float* ic = nullptr;
@@ -2366,8 +2622,12 @@ int gpf_lodf_screen(gpf_handle e, int32_t lane0, int32_t n, const float* cap_mw,
     ic = e->lodf_inv_cap.p;
   }
   const size_t lds = ((size_t)5 * gpf::LODF_LPW + 1) * lp * sizeof(float);
-  hipLaunchKernelGGL(gpf::lodf_screen_kernel, dim3((n + gpf::LODF_LPW - 1) / gpf::LODF_LPW), dim3(256), lds, e->stream, nl, lp, e->lodf.p, ic,
-                     e->ptdf_flow.p, lane0, n, e->lodf_worst.p + (size_t)lane0 * lp);
+  if (e->ptdf_batch)
+    hipLaunchKernelGGL(gpf::lodf_screen_kernel, dim3(e->ptdfb_slots / gpf::LODF_LPW), dim3(256), lds, e->stream, nl, lp, e->ptdfb_lodf.p, ic, e->ptdf_flow.p,
+                       lane0, n, e->lodf_worst.p, e->ptdfb_order.p, e->ptdfb_blk_class.p, (long long)nl * lp, e->ptdfb_status.p);
+  else
+    hipLaunchKernelGGL(gpf::lodf_screen_kernel, dim3((n + gpf::LODF_LPW - 1) / gpf::LODF_LPW), dim3(256), lds, e->stream, nl, lp, e->lodf.p, ic,
+                       e->ptdf_flow.p, lane0, n, e->lodf_worst.p, nullptr, nullptr, 0LL, nullptr);
   HIP_TRY(hipGetLastError());
   if (e->window) { ++e->win_launches; e->win_marked = false; }
   HIP_TRY(hipMemcpy2DAsync(worst, (size_t)nl * sizeof(float), e->lodf_worst.p + (size_t)lane0 * lp, (size_t)lp * sizeof(float),
@@ -2384,6 +2644,12 @@ int gpf_debug_read_work(gpf_handle e, double* out, int64_t n) {
   return GPF_OK;
 }
 #endif
+
+int gpf_get_counters(gpf_handle e, int64_t out[2]) {
+  if (!e || !out) return fail(GPF_E_INVALID, "gpf_get_counters: null");
+  out[0] = e->n_step_calls; out[1] = e->n_step_dispatches;
+  return GPF_OK;
+}
 
 int gpf_get_plan(gpf_handle e, int32_t out[8]) {
   if (!e || !out) return fail(GPF_E_INVALID, "gpf_get_plan: null");

@@ -53,5 +53,6 @@ struct LaunchPlan {
 // dispatch of the kernel-S variants (gridpf_launch_runpf.hip / gridpf_launch_step.hip); they return the HIP status of the launch
 hipError_t gpf_launch_runpf_sparse(const LaunchPlan& p, int device, const gpf::DevParamsS* d_params, hipStream_t stream, int lane0, int n,
                                    int is_dc, int max_iter, double tol_pu);
+// (*n_dispatched += the kernel dispatches issued: a batch of a few residency rounds goes out as one dispatch per round)
 hipError_t gpf_launch_step_sparse(const LaunchPlan& p, int device, const gpf::DevParamsS* d_params, hipStream_t stream, int n_lanes,
-                                  int max_iter, double tol_pu, const gpf::StepArgs& sa);
+                                  int max_iter, double tol_pu, const gpf::StepArgs& sa, int* n_dispatched = nullptr);

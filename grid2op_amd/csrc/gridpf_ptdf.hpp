@@ -20,6 +20,13 @@ struct PtdfDev {
   const double* inj_w;       // [n_inj] weight (+1 generators except the slack, -1 loads / storages, -factor shunts)
   const double* ptdf_t;      // [nb_pad][line_pad] row-major: transposed PTDF over the compact active buses (zero rows /
                              // columns for padding, reference buses, open lines)
+  // ---- per-lane topologies (gpf_ptdf_build_batch, gridpf_ptdf_batch.hpp); order == nullptr: ONE topology for all lanes --------------
+  const int* order;          // [n_slots] slot -> lane, lanes grouped by topology class, every group padded to a multiple of 16 with -1
+  const int* blk_class;      // [n_slots / 16] class of each group of 16 slots
+  const int* cls_desc;       // class descriptors; the class's inj_bus table starts at cls_desc + cls * desc_stride + inj_bus_off
+  const int* cls_status;     // [n_classes] != 0: no sensitivities for this class (islanded / singular): its lanes get NaN flows
+  int desc_stride, inj_bus_off;
+  long long ptdf_stride;     // doubles between the PTDF^T blocks of two classes
 };
 
 // K_PG: bus injections + GEMM in ONE launch.  Block (x, y) of 4 wavefronts: 16 lanes x the line tiles 4y .. 4y+3 (one 16 x 16
@@ -35,17 +42,27 @@ __global__ __launch_bounds__(256) void ptdf_flows_kernel(PtdfDev P, const double
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* A = reinterpret_cast<double*>(smem);             // [16][stride]
   const int stride = ptdf_a_stride(P.nb_pad);
-  const int row0 = blockIdx.x * 16;                        // first lane (of the range) of this block
+  const int row0 = blockIdx.x * 16;                        // first lane (of the range) / first slot of this block
+  __shared__ int s_lane[16];
+  const int* inj_bus = P.inj_bus;
+  const double* ptdf_t = P.ptdf_t;
+  bool nan_out = false;
+  if (P.order) {                                           // per-lane topologies: the 16 slots of a block share one class
+    const int cls = P.blk_class[blockIdx.x];
+    inj_bus = P.cls_desc + (size_t)cls * P.desc_stride + P.inj_bus_off;
+    ptdf_t += (size_t)cls * P.ptdf_stride;
+    nan_out = P.cls_status[cls] != 0;
+    if (threadIdx.x < 16) s_lane[threadIdx.x] = P.order[row0 + threadIdx.x];
+  } else if (threadIdx.x < 16) s_lane[threadIdx.x] = (row0 + (int)threadIdx.x < n_lanes) ? lane0 + row0 + (int)threadIdx.x : -1;
   for (int i = threadIdx.x; i < 16 * stride; i += 256) A[i] = 0.0;
   __syncthreads();
   for (int i = threadIdx.x; i < P.n_inj; i += 256) {
-    const int b = P.inj_bus[i];
+    const int b = inj_bus[i];
     if (b < 0) continue;
     const double w = P.inj_w[i];
-    const double* col = inj + (size_t)(lane0 + row0) * P.n_inj + i;
     double v[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = (row0 + r < n_lanes) ? col[(size_t)r * P.n_inj] : 0.0;      // 16 loads in flight
+    for (int r = 0; r < 16; ++r) v[r] = (s_lane[r] >= 0) ? inj[(size_t)s_lane[r] * P.n_inj + i] : 0.0;      // 16 loads in flight
 #pragma unroll
     for (int r = 0; r < 16; ++r) atomicAdd(&A[r * stride + b], v[r] * w);
   }
@@ -56,7 +73,7 @@ __global__ __launch_bounds__(256) void ptdf_flows_kernel(PtdfDev P, const double
   const int n_tiles = P.line_pad / 16;
   for (int t = blockIdx.y * 4 + w; t < n_tiles; t += 4 * gridDim.y) {      // one 16 x 16 tile per wavefront when gridDim.y covers the tiles
     v4d c = {0.0, 0.0, 0.0, 0.0};
-    const double* bcol = P.ptdf_t + (size_t)(l >> 4) * P.line_pad + t * 16 + (l & 15);
+    const double* bcol = ptdf_t + (size_t)(l >> 4) * P.line_pad + t * 16 + (l & 15);
     int s = 0;
     for (; s + 8 <= ksteps; s += 8) {                       // 8 k-steps per trip: 8 L2 loads + 8 LDS reads in flight, then 8 MFMAs
       double a[8], b[8];
@@ -68,8 +85,8 @@ __global__ __launch_bounds__(256) void ptdf_flows_kernel(PtdfDev P, const double
     for (; s < ksteps; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[4 * s], bcol[(size_t)4 * s * P.line_pad], c, 0, 0, 0);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-      const int r = row0 + 4 * v + (l >> 4);
-      if (r < n_lanes) flow[(size_t)(lane0 + r) * P.line_pad + t * 16 + (l & 15)] = (float)c[v];
+      const int ln = s_lane[4 * v + (l >> 4)];
+      if (ln >= 0) flow[(size_t)ln * P.line_pad + t * 16 + (l & 15)] = nan_out ? __builtin_nanf("") : (float)c[v];
     }
   }
 }
@@ -110,7 +127,23 @@ __global__ __launch_bounds__(256) void ptdf_rows_kernel(PtdfDev P, PtdfRowsDev R
   // (chronics row, lane) of the block's pairs: ONE 64-bit division per block (uniform), 32-bit arithmetic per pair, kept in LDS for
   // the epilogue (a 64-bit division per stored element cost more than the whole GEMM)
   __shared__ int p_row[NP], p_lane[NP];
-  {
+  const int* inj_bus = P.inj_bus;
+  const double* ptdf_t = P.ptdf_t;
+  bool nan_out = false;
+  if (P.order) {
+    // per-lane topologies: n_lanes = number of SLOTS (a multiple of 16); block -> (group of 16 slots sg, MT consecutive rows): the
+    // MT row tiles of the block are the same 16 lanes at MT chronics rows, so that they share the class's PTDF^T operands
+    const int n_sg = n_lanes / 16, sg = blockIdx.x % n_sg, rg = blockIdx.x / n_sg;
+    const int cls = P.blk_class[sg];
+    inj_bus = P.cls_desc + (size_t)cls * P.desc_stride + P.inj_bus_off;
+    ptdf_t += (size_t)cls * P.ptdf_stride;
+    nan_out = P.cls_status[cls] != 0;
+    if (threadIdx.x < NP) {
+      const int m_ = threadIdx.x / 16, rw_ = rg * MT + m_, ln_ = P.order[sg * 16 + (threadIdx.x & 15)];
+      p_row[threadIdx.x] = (rw_ < n_rows && ln_ >= 0) ? rw_ : -1;
+      p_lane[threadIdx.x] = ln_ >= 0 ? ln_ : 0;
+    }
+  } else {
     const long long row0 = p0 / n_lanes;
     const unsigned ln0 = (unsigned)(p0 - row0 * n_lanes);
     if (threadIdx.x < NP) {
@@ -139,9 +172,9 @@ __global__ __launch_bounds__(256) void ptdf_rows_kernel(PtdfDev P, PtdfRowsDev R
     const int i = q + u * TPP;
     const bool okl = on && i < R.n_load, okg = on && i < R.n_gen;
     lv[u] = okl ? ch[i] * (sc ? sc[i] : 1.f) : 0.f;
-    lb[u] = okl ? P.inj_bus[R.inj_load_p + i] : -1;
+    lb[u] = okl ? inj_bus[R.inj_load_p + i] : -1;
     gv[u] = okg ? ch[2 * R.n_load + i] : 0.f;
-    gb[u] = okg ? P.inj_bus[R.inj_gen_p + i] : -2;          // -1: slack generator or not connected, -2: no such generator
+    gb[u] = okg ? inj_bus[R.inj_gen_p + i] : -2;          // -1: slack generator or not connected, -2: no such generator
   }
   double s_load = 0.0, s_prod = 0.0;
   if (R.rebalance > 0.0) {
@@ -167,11 +200,11 @@ __global__ __launch_bounds__(256) void ptdf_rows_kernel(PtdfDev P, PtdfRowsDev R
       }
     }
     for (int i = q + EPT * TPP; i < R.n_load; i += TPP) {
-      const int b = P.inj_bus[R.inj_load_p + i];
+      const int b = inj_bus[R.inj_load_p + i];
       if (b >= 0) atomicAdd(&Ar[b], (double)(ch[i] * (sc ? sc[i] : 1.f)) * P.inj_w[R.inj_load_p + i]);
     }
     for (int i = q + EPT * TPP; i < R.n_gen; i += TPP) {
-      const int b = P.inj_bus[R.inj_gen_p + i];
+      const int b = inj_bus[R.inj_gen_p + i];
       if (b < 0) continue;
       float pp = ch[2 * R.n_load + i] * sp;
       if (R.lane_gen_delta) pp += R.lane_gen_delta[(size_t)lane * R.n_gen + i];
@@ -179,7 +212,7 @@ __global__ __launch_bounds__(256) void ptdf_rows_kernel(PtdfDev P, PtdfRowsDev R
     }
     const double* irow = inj + (size_t)lane * P.n_inj;
     for (int i = R.inj_sto_p + q; i < R.inj_sto_p + R.n_inj_tail; i += TPP) {
-      const int b = P.inj_bus[i];
+      const int b = inj_bus[i];
       if (b >= 0) atomicAdd(&Ar[b], irow[i] * P.inj_w[i]);
     }
   }
@@ -195,7 +228,7 @@ __global__ __launch_bounds__(256) void ptdf_rows_kernel(PtdfDev P, PtdfRowsDev R
     v4d c[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) c[m] = v4d{0.0, 0.0, 0.0, 0.0};
-    const double* bcol = P.ptdf_t + (size_t)(l >> 4) * P.line_pad + t * 16 + (l & 15);
+    const double* bcol = ptdf_t + (size_t)(l >> 4) * P.line_pad + t * 16 + (l & 15);
     double a[MT][KT], b[KT];
 #pragma unroll
     for (int u = 0; u < KT; ++u) {
@@ -229,7 +262,7 @@ __global__ __launch_bounds__(256) void ptdf_rows_kernel(PtdfDev P, PtdfRowsDev R
       for (int v = 0; v < 4; ++v) {
         const int pi = 16 * m + 4 * v + (l >> 4);
         const int rw = p_row[pi], ln = p_lane[pi];
-        if (rw >= 0) flow[((size_t)rw * lane_stride + ln) * P.line_pad + t * 16 + (l & 15)] = (float)c[m][v];
+        if (rw >= 0) flow[((size_t)rw * lane_stride + ln) * P.line_pad + t * 16 + (l & 15)] = nan_out ? __builtin_nanf("") : (float)c[m][v];
       }
   }
 }
@@ -243,15 +276,27 @@ constexpr int LODF_LPW = 4;
 __global__ __launch_bounds__(256) void lodf_screen_kernel(int n_line, int line_pad, const double* __restrict__ lodf /* [n_line][line_pad] */,
                                                            const float* __restrict__ inv_cap /* [n_line] or nullptr */,
                                                            const float* __restrict__ flow, int lane0, int n_lanes,
-                                                           float* __restrict__ worst /* [n_lanes][line_pad] */) {
+                                                           float* __restrict__ worst /* [lanes][line_pad], indexed by lane */,
+                                                           const int* __restrict__ order = nullptr /* per-lane topologies: slot -> lane (PtdfDev::order) */,
+                                                           const int* __restrict__ blk_class = nullptr, long long lodf_stride = 0,
+                                                           const int* __restrict__ cls_status = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* f = reinterpret_cast<float*>(smem);                     // [LODF_LPW][line_pad]
   float* ic = f + (size_t)LODF_LPW * line_pad;                   // [line_pad]
   float* part = ic + line_pad;                                   // [4 wavefronts][LODF_LPW][line_pad] partial maxima (+inf: islanding)
   const int tid = threadIdx.x & 63, wv = threadIdx.x >> 6, r0 = blockIdx.x * LODF_LPW;
+  __shared__ int s_ln[LODF_LPW];
+  bool nan_out = false;
+  if (order) {                                                   // the LODF_LPW slots of a block lie in one group of 16: one class
+    const int cls = blk_class[r0 / 16];
+    lodf += (size_t)cls * lodf_stride;
+    nan_out = cls_status[cls] != 0;
+    if (threadIdx.x < LODF_LPW) s_ln[threadIdx.x] = order[r0 + threadIdx.x];
+  } else if (threadIdx.x < LODF_LPW) s_ln[threadIdx.x] = (r0 + (int)threadIdx.x < n_lanes) ? lane0 + r0 + (int)threadIdx.x : -1;
+  __syncthreads();
   for (int i = threadIdx.x; i < LODF_LPW * line_pad; i += 256) {
-    const int r = r0 + i / line_pad, l = i % line_pad;
-    f[i] = (r < n_lanes && l < n_line) ? flow[(size_t)(lane0 + r) * line_pad + l] : 0.f;
+    const int ln = s_ln[i / line_pad], l = i % line_pad;
+    f[i] = (ln >= 0 && l < n_line) ? flow[(size_t)ln * line_pad + l] : 0.f;
   }
   for (int l = threadIdx.x; l < line_pad; l += 256) ic[l] = l < n_line ? (inv_cap ? inv_cap[l] : 1.f) : 0.f;
   __syncthreads();
@@ -287,11 +332,11 @@ __global__ __launch_bounds__(256) void lodf_screen_kernel(int n_line, int line_p
   __syncthreads();
   for (int i = threadIdx.x; i < LODF_LPW * n_line; i += 256) {
     const int r = i / n_line, k = i % n_line;
-    if (r0 + r >= n_lanes) continue;
+    if (s_ln[r] < 0) continue;
     float m = part[(size_t)r * line_pad + k];
 #pragma unroll
     for (int w2 = 1; w2 < 4; ++w2) m = fmaxf(m, part[((size_t)w2 * LODF_LPW + r) * line_pad + k]);
-    worst[(size_t)(r0 + r) * line_pad + k] = m;
+    worst[(size_t)s_ln[r] * line_pad + k] = nan_out ? __builtin_nanf("") : m;
   }
 }
 

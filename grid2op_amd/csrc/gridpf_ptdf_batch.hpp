@@ -1,0 +1,471 @@
+// gridpf_ptdf_batch.hpp -- DC sensitivities of MANY topologies at once: one workgroup per distinct topology ("class") builds the reduced
+// DC matrix B' of its topology, inverts it with a blocked Gauss-Jordan whose panel / trailing updates run on the FP64 matrix cores
+// (v_mfma_f64_16x16x4_f64), and forms PTDF^T and the LODF table on the device (gpf_ptdf_build_batch).
+//
+// Reference: every DC power flow of the reference factorises B' of whatever topology the environment has at that moment
+// (pp.rundcpp, grid2op/Backend/pandaPowerBackend.py:1090; N1Reward does it once per contingency, grid2op/Reward/n1Reward.py:70-99).
+// gpf_ptdf_build (round 3) inverted ONE lane's topology on the host; a batch of 2 048 lanes with a few hundred distinct topologies
+// (bus splits, outages) had no fast DC path.  Here the host only does the integer work per class (which buses are live, the compact
+// bus numbering, the connectivity check of rundcpp(check_connectivity=True)); all floating point is on the device.
+//
+// Numbering of a class: COMPACT bus index = [active non-reference buses 0 .. nr-1 | active reference buses nr .. n_act-1].  The
+// reduced matrix is over the first nr; rows / columns nr .. n_pad-1 (n_pad = nr rounded up to 16) are identity.  B' of a connected grid
+// with positive branch susceptances is symmetric positive definite: every Schur complement is too, so the elimination needs no
+// pivoting across tiles; a pivot that is not > 1e-12 (the host routine's test) marks the class GPF_PTDF_SINGULAR.
+#pragma once
+#include "gridpf_ptdf.hpp"
+
+namespace gpf {
+
+constexpr int PTDFB_TILE = 16;
+constexpr int PTDFB_MAX_N = 256;          // reduced dimension (padded) a workgroup handles: panels of 2 x 34 KB in LDS
+constexpr int PTDFB_THREADS = 256;
+constexpr int PTDFB_ROWS = 4;             // rows of X a wavefront has in flight while it forms PTDF^T / LODF rows
+
+// class descriptor (ints): [0] nr, [1] n_act, [2] n_pad, [3] host status (0 ok, 2 islanded, 3 no slack), then lf[n_line], lt[n_line]
+// (compact bus of each line end; -1: line out of service or both ends on the same bus), then inj_bus[n_inj] (compact bus of each
+// injection column, -1: not an active-power injection of this topology), then lflag[n_line] (1: one end of the line is a bus that
+// carries NOTHING but this line end -- its outage removes that bus instead of islanding it: the reference's DC power flow of the
+// contingency converges with every other flow unchanged, so the LODF column is 0 instead of NaN)
+constexpr int PTDFB_HDR = 4;
+
+struct PtdfBuildDev {
+  int n_line, line_pad, n_inj, kpad;        // kpad: rows of every class's PTDF^T block (max n_act rounded up to 32)
+  int desc_stride;                          // ints per class descriptor
+  long long work_stride, ptdf_stride, lodf_stride;   // doubles per class
+  const int* desc;                          // [n_classes][desc_stride]
+  const double* br_bdc;                     // [n_line]
+  long long* dbg;                           // developer: [n_classes][8] shader-clock stamps of the phases (nullptr: off)
+  double* work;                             // [n_classes][n_pad_max^2] B' -> its inverse (row-major, leading dimension = the class's n_pad)
+  double* ptdf_t;                           // [n_classes][kpad][line_pad]
+  double* lodf;                             // [n_classes][n_line][line_pad] or nullptr
+  int* status;                              // [n_classes] 0 ok, 1 singular pivot, 2 islanded, 3 no slack
+};
+
+__host__ __device__ inline int ptdfb_lcol_stride() { return PTDFB_TILE + 1; }
+__host__ __device__ inline int ptdfb_r_stride(int n_pad) { return n_pad + 4; }
+__host__ __device__ inline size_t ptdfb_lds_bytes(int n_pad_max, int line_pad) {
+  // Gauss-Jordan: column panel [n_pad][17] + row panel [16][n_pad + 4] + diagonal tile [16][17];
+  // tables: 1 / (1 - H[k][k]) [line_pad] + 4 wavefronts x PTDFB_ROWS rows [n_pad] + the line-end tables (3 x line_pad ints)
+  const size_t gj = (size_t)n_pad_max * ptdfb_lcol_stride() + (size_t)PTDFB_TILE * ptdfb_r_stride(n_pad_max) + PTDFB_TILE * (PTDFB_TILE + 1);
+  const size_t fin = (size_t)line_pad + 4 * (size_t)PTDFB_ROWS * n_pad_max + (3 * (size_t)line_pad + 1) / 2;
+  return (gj > fin ? gj : fin) * sizeof(double);
+}
+
+// inverse of the 16 x 16 tile Pt (LDS, row stride 17), in place, by ONE wavefront: Gauss-Jordan without pivoting, lane l owns row
+// l % 16, columns 4 (l / 16) .. + 3.  The LDS executes the DS operations of one wavefront in issue order: the reads of step p + 1
+// see the writes of step p without a barrier; the compiler is held by the wave barriers.
+__device__ inline bool ptdfb_invert_tile(double* Pt, int l) {
+  const int i = l & 15, c0 = 4 * (l >> 4);
+  double t[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) t[q] = Pt[i * 17 + c0 + q];
+  bool ok = true;
+#pragma unroll
+  for (int p = 0; p < PTDFB_TILE; ++p) {
+    const double piv = Pt[p * 17 + p];
+    const double colp = Pt[i * 17 + p];
+    double rowp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rowp[q] = Pt[p * 17 + c0 + q];
+    ok = ok && (fabs(piv) > 1e-12);
+    const double rp = 1.0 / piv;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = c0 + q;
+      if (i == p) t[q] = (j == p) ? rp : rowp[q] * rp;
+      else t[q] = (j == p) ? -colp * rp : t[q] - colp * (rowp[q] * rp);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Pt[i * 17 + c0 + q] = t[q];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  return __all(ok);
+}
+
+// B' of one class into M (row-major, leading dimension ld): zero fill by all threads, then thread r < nr owns row r and walks the lines
+// in ascending order (no atomics: the same bits on every run)
+__device__ inline void ptdfb_assemble(double* M, int ld, int n_pad, int nr, const int* lf, const int* lt, const double* __restrict__ br_bdc, int n_line, int tid) {
+  for (int i = tid; i < n_pad * n_pad; i += PTDFB_THREADS) { const int r = i / n_pad, c = i - r * n_pad; M[(size_t)r * ld + c] = (r == c && r >= nr) ? 1.0 : 0.0; }
+  __syncthreads();
+  for (int r = tid; r < nr; r += PTDFB_THREADS) {
+    double* row = M + (size_t)r * ld;
+    double diag = 0.0;
+    for (int k = 0; k < n_line; ++k) {
+      const int a = lf[k], b = lt[k];
+      if (a < 0 || b < 0 || a == b || (a != r && b != r)) continue;
+      const double bb = br_bdc[k];
+      diag += bb;
+      const int o = a == r ? b : a;
+      if (o < nr) row[o] -= bb;
+    }
+    row[r] = diag;
+  }
+}
+
+#define PTDFB_STAMP(i_) do { if (D.dbg && threadIdx.x == 0) D.dbg[(size_t)blockIdx.x * 8 + (i_)] = (long long)__builtin_readcyclecounter(); } while (0)
+
+// K_PB: one workgroup (4 wavefronts) per topology class.
+__global__ __launch_bounds__(PTDFB_THREADS) void ptdf_build_kernel(PtdfBuildDev D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_bad;
+  const int cls = blockIdx.x, tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int* desc = D.desc + (size_t)cls * D.desc_stride;
+  const int nr = desc[0], n_pad = desc[2], host_st = desc[3];
+  const int* lf = desc + PTDFB_HDR;
+  const int* lt = lf + D.n_line;
+  double* M = D.work + (size_t)cls * D.work_stride;
+  double* PT = D.ptdf_t + (size_t)cls * D.ptdf_stride;
+  double* LO = D.lodf ? D.lodf + (size_t)cls * D.lodf_stride : nullptr;
+  if (tid == 0) s_bad = 0;
+  PTDFB_STAMP(0);
+  if (host_st != 0) {                                   // islanded topology / no slack: no sensitivities (the flows kernels write NaN)
+    for (int i = tid; i < D.kpad * D.line_pad; i += PTDFB_THREADS) PT[i] = 0.0;
+    if (LO) for (int i = tid; i < D.n_line * D.line_pad; i += PTDFB_THREADS) LO[i] = 0.0;
+    if (tid == 0) D.status[cls] = host_st;
+    return;
+  }
+  // ---- 1. assemble B' (reduced: rows / columns of the reference buses dropped; padding = identity) ------------------------------
+  //         one thread per row, lines in ascending order: no atomics, the same bits on every run
+  ptdfb_assemble(M, n_pad, n_pad, nr, lf, lt, D.br_bdc, D.n_line, tid);
+  __syncthreads();
+  PTDFB_STAMP(1);
+  // ---- 2. in-place inverse: blocked Gauss-Jordan, 16 x 16 tiles, updates on the FP64 matrix cores ---------------------------------
+  //   step k:  P = inv(A_kk);  A_kj <- P A_kj (j != k);  A_ij <- A_ij - A_ik A_kj (i, j != k);  A_ik <- -A_ik P;  A_kk <- P
+  // MFMA operand layout (gridpf_ptdf.hpp): A[i = l % 16][k = l / 16], B[k = l / 16][j = l % 16], D[i = 4 v + l / 16][j = l % 16].
+  double* Lc = reinterpret_cast<double*>(smem);                       // column panel A_:,k   [n_pad][17]
+  double* R = Lc + (size_t)n_pad * ptdfb_lcol_stride();               // row panel    A_k,:   [16][n_pad + 4]
+  const int ldr = ptdfb_r_stride(n_pad);
+  double* Pt = R + (size_t)PTDFB_TILE * ldr;                          // diagonal tile [16][17]
+  const int N = n_pad / PTDFB_TILE;
+  long long acc_ld = 0, acc_inv = 0, acc_tr = 0, c0_ = 0, c1_ = 0;          // developer stamps (D.dbg): panel loads / tile inversions / trailing updates
+  for (int k = 0; k < N; ++k) {
+    if (D.dbg) c0_ = (long long)__builtin_readcyclecounter();
+    for (int i = tid; i < n_pad * PTDFB_TILE; i += PTDFB_THREADS) { const int r = i >> 4, c = i & 15; Lc[r * 17 + c] = M[(size_t)r * n_pad + k * 16 + c]; }
+    for (int i = tid; i < PTDFB_TILE * n_pad; i += PTDFB_THREADS) { const int r = i / n_pad, c = i - r * n_pad; R[r * ldr + c] = M[(size_t)(k * 16 + r) * n_pad + c]; }
+    __syncthreads();
+    if (D.dbg) { c1_ = (long long)__builtin_readcyclecounter(); acc_ld += c1_ - c0_; }
+    if (w == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int e = l + 64 * q; Pt[(e >> 4) * 17 + (e & 15)] = Lc[(k * 16 + (e >> 4)) * 17 + (e & 15)]; }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (!ptdfb_invert_tile(Pt, l) && l == 0) s_bad = 1;
+    }
+    __syncthreads();
+    if (D.dbg) { c0_ = (long long)__builtin_readcyclecounter(); acc_inv += c0_ - c1_; }
+    // row panel: R_j <- P R_j (tile k itself becomes P); written back to the matrix as well
+    for (int j = w; j < N; j += 4) {
+      v4d c = {0.0, 0.0, 0.0, 0.0};
+      if (j != k) {
+        double a[4], b[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { a[s] = Pt[(l & 15) * 17 + 4 * s + (l >> 4)]; b[s] = R[(4 * s + (l >> 4)) * ldr + j * 16 + (l & 15)]; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], c, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) c[v] = Pt[(4 * v + (l >> 4)) * 17 + (l & 15)];
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = 4 * v + (l >> 4), cc = j * 16 + (l & 15);
+        R[r * ldr + cc] = c[v];
+        M[(size_t)(k * 16 + r) * n_pad + cc] = c[v];
+      }
+    }
+    __syncthreads();
+    if (D.dbg) c1_ = (long long)__builtin_readcyclecounter();
+    // trailing update + column panel: tile (i, j), i != k:  C <- (j == k ? 0 : C) - L_i R_j   (R_k holds P)
+    const int n_t = (N - 1) * N;
+    for (int q = w; q < n_t; q += 4) {
+      int i = q / N;
+      const int j = q - i * N;
+      if (i >= k) ++i;
+      double a[4], b[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { a[s] = -Lc[(i * 16 + (l & 15)) * 17 + 4 * s + (l >> 4)]; b[s] = R[(4 * s + (l >> 4)) * ldr + j * 16 + (l & 15)]; }
+      double* Ct = M + (size_t)(i * 16 + (l >> 4)) * n_pad + j * 16 + (l & 15);
+      v4d c = {0.0, 0.0, 0.0, 0.0};
+      if (j != k) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) c[v] = Ct[(size_t)4 * v * n_pad];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], c, 0, 0, 0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) Ct[(size_t)4 * v * n_pad] = c[v];
+    }
+    __syncthreads();
+    if (D.dbg) acc_tr += (long long)__builtin_readcyclecounter() - c1_;
+  }
+  if (D.dbg && tid == 0) { D.dbg[(size_t)cls * 8 + 2] = acc_inv; D.dbg[(size_t)cls * 8 + 6] = acc_tr; D.dbg[(size_t)cls * 8 + 7] = acc_ld; }
+  const bool bad = s_bad != 0;
+  PTDFB_STAMP(3);
+  // ---- 3. PTDF^T[b][k] = bdc_k (X[b][from_k] - X[b][to_k])  (X symmetric; reference buses: zero rows and zero terms) ---------------
+  // A wavefront takes PTDFB_ROWS rows b of X at a time into LDS (coalesced, all loads in flight together), then its lanes walk the lines.
+  double* hden = reinterpret_cast<double*>(smem);                     // [line_pad] 1 / (1 - H[k][k]); 0: column of zeros; NaN: islanding outage
+  double* rows = hden + D.line_pad;                                   // [4 wavefronts][PTDFB_ROWS][n_pad]
+  int* s_lf = reinterpret_cast<int*>(rows + (size_t)4 * PTDFB_ROWS * n_pad);   // line-end tables of the class
+  int* s_lt = s_lf + D.line_pad;
+  int* s_fl = s_lt + D.line_pad;
+  const int* lflag = desc + PTDFB_HDR + 2 * D.n_line + D.n_inj;
+  for (int k = tid; k < D.line_pad; k += PTDFB_THREADS) {
+    const bool in = k < D.n_line;
+    const int f = in ? lf[k] : -1, t = in ? lt[k] : -1;
+    const bool on = f >= 0 && t >= 0 && f != t;
+    s_lf[k] = on ? f : -1; s_lt[k] = on ? t : -1; s_fl[k] = in ? lflag[k] : 0;
+  }
+  __syncthreads();
+  double* wrow = rows + (size_t)w * PTDFB_ROWS * n_pad;
+  for (int b0 = w * PTDFB_ROWS; b0 < D.kpad; b0 += 4 * PTDFB_ROWS) {
+#pragma unroll
+    for (int u = 0; u < PTDFB_ROWS; ++u) {
+      const int b = b0 + u;
+      for (int c = l; c < n_pad; c += 64) wrow[u * n_pad + c] = (!bad && b < nr) ? M[(size_t)b * n_pad + c] : 0.0;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < PTDFB_ROWS; ++u) {
+      const int b = b0 + u;
+      if (b >= D.kpad) break;
+      for (int k = l; k < D.line_pad; k += 64) {
+        const int f = s_lf[k], t = s_lt[k];
+        double v = 0.0;
+        if (f >= 0) v = D.br_bdc[k] * ((f < nr ? wrow[u * n_pad + f] : 0.0) - (t < nr ? wrow[u * n_pad + t] : 0.0));
+        PT[(size_t)b * D.line_pad + k] = v;
+      }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (tid == 0) D.status[cls] = bad ? 1 : 0;
+  PTDFB_STAMP(4);
+  if (!LO) return;
+  __syncthreads();
+  // ---- 4. LODF[m][k] = H[m][k] / (1 - H[k][k]),  H[m][k] = PTDF[m][from_k] - PTDF[m][to_k];  LODF[k][k] = -1;  NaN column: the outage
+  //         of k islands the grid (as gpf_ptdf_build); column of zeros: line k is out of service, or its outage only removes a bus that
+  //         carries nothing else (lflag) ---------------------------------------------------------------------------------------------
+  for (int k = tid; k < D.line_pad; k += PTDFB_THREADS) {
+    double d = 0.0;
+    const int f = s_lf[k], t = s_lt[k];
+    if (f >= 0) {
+      const double den = 1.0 - (PT[(size_t)f * D.line_pad + k] - PT[(size_t)t * D.line_pad + k]);   // (rows >= nr of PT are zero)
+      d = fabs(den) < 1e-8 ? (s_fl[k] ? 0.0 : __builtin_nan("")) : 1.0 / den;
+    }
+    hden[k] = d;
+  }
+  __syncthreads();
+  for (int m0 = w * PTDFB_ROWS; m0 < D.n_line; m0 += 4 * PTDFB_ROWS) {
+#pragma unroll
+    for (int u = 0; u < PTDFB_ROWS; ++u) {                              // PTDF rows of the lines m0 .. m0 + 3 over the reduced buses (coalesced rows of X)
+      const int m = m0 + u;
+      const int fm = m < D.n_line ? s_lf[m] : -1, tm = m < D.n_line ? s_lt[m] : -1;
+      const bool on_m = !bad && fm >= 0;
+      const double bm = on_m ? D.br_bdc[m] : 0.0;
+      for (int b = l; b < n_pad; b += 64)
+        wrow[u * n_pad + b] = (on_m && b < nr) ? bm * ((fm < nr ? M[(size_t)fm * n_pad + b] : 0.0) - (tm < nr ? M[(size_t)tm * n_pad + b] : 0.0)) : 0.0;
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < PTDFB_ROWS; ++u) {
+      const int m = m0 + u;
+      if (m >= D.n_line) break;
+      for (int k = l; k < D.line_pad; k += 64) {
+        const int f = s_lf[k], t = s_lt[k];
+        double v = 0.0;
+        if (f >= 0) {                                                  // (an open line: its outage changes nothing -> column of zeros)
+          const double hd = hden[k];
+          const double h = (f < nr ? wrow[u * n_pad + f] : 0.0) - (t < nr ? wrow[u * n_pad + t] : 0.0);
+          v = (hd != hd) ? hd : (m == k ? -1.0 : h * hd);
+        }
+        LO[(size_t)m * D.line_pad + k] = v;
+      }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  PTDFB_STAMP(5);
+}
+
+
+
+// K_PB, reduced dimension <= 128 (the 118-substation grids: 117 .. 128 non-reference buses): the WHOLE matrix lives in LDS (128 x 130
+// doubles = 133 KB of the CU's 160 KB), one workgroup per CU.  Same algorithm; what changes is where the operands come from (every
+// MFMA operand and every result tile is an LDS access instead of an L2 round trip) and the schedule of a step: the diagonal tile of step
+// k + 1 is final as soon as ITS trailing update of step k is done, so wavefront 0 updates that tile first and inverts it (a chain of 16
+// dependent pivots, ~6 k cycles) while the other wavefronts run the rest of the trailing update -- the inversions leave the critical path.
+__host__ __device__ inline int ptdfb_ldm(int n_pad) { return n_pad + 2; }
+__host__ __device__ inline size_t ptdfb_lds_bytes_resident(int n_pad_max, int line_pad) {
+  // matrix [n_pad][n_pad + 2] + column panel copy [n_pad][17] (later: the line tables) + two diagonal tiles [16][17]
+  const size_t panel = (size_t)n_pad_max * ptdfb_lcol_stride();
+  const size_t tabs = (size_t)line_pad + (3 * (size_t)line_pad + 1) / 2;
+  return ((size_t)n_pad_max * ptdfb_ldm(n_pad_max) + (panel > tabs ? panel : tabs) + 2 * PTDFB_TILE * (PTDFB_TILE + 1)) * sizeof(double);
+}
+
+__global__ __launch_bounds__(PTDFB_THREADS) void ptdf_build_lds_kernel(PtdfBuildDev D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_bad, s_next;
+  const int cls = blockIdx.x, tid = threadIdx.x, l = tid & 63, w = tid >> 6;
+  const int* desc = D.desc + (size_t)cls * D.desc_stride;
+  const int nr = desc[0], n_pad = desc[2], host_st = desc[3];
+  const int* lf = desc + PTDFB_HDR;
+  const int* lt = lf + D.n_line;
+  double* PT = D.ptdf_t + (size_t)cls * D.ptdf_stride;
+  double* LO = D.lodf ? D.lodf + (size_t)cls * D.lodf_stride : nullptr;
+  if (tid == 0) { s_bad = 0; s_next = 0; }
+  PTDFB_STAMP(0);
+  if (host_st != 0) {
+    for (int i = tid; i < D.kpad * D.line_pad; i += PTDFB_THREADS) PT[i] = 0.0;
+    if (LO) for (int i = tid; i < D.n_line * D.line_pad; i += PTDFB_THREADS) LO[i] = 0.0;
+    if (tid == 0) D.status[cls] = host_st;
+    return;
+  }
+  const int ldm = ptdfb_ldm(n_pad);
+  double* M = reinterpret_cast<double*>(smem);                        // [n_pad][ldm]
+  double* Lc = M + (size_t)n_pad * ldm;                               // column panel copy [n_pad][17]
+  double* Pa = Lc + (size_t)n_pad * ptdfb_lcol_stride();             // inverse of the current diagonal tile [16][17]
+  double* Pb = Pa + PTDFB_TILE * (PTDFB_TILE + 1);                    // ... of the next one (lookahead)
+  // the line-end tables of the class: in LDS for the assembly and the table phases (they alias the column panel, unused then)
+  ptdfb_assemble(M, ldm, n_pad, nr, lf, lt, D.br_bdc, D.n_line, tid);
+  __syncthreads();
+  PTDFB_STAMP(1);
+  const int N = n_pad / PTDFB_TILE;
+  long long acc_inv = 0, acc_tr = 0, c0_ = 0;
+  if (w == 0) {                                                       // inverse of the first diagonal tile
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int e = l + 64 * q; Pa[(e >> 4) * 17 + (e & 15)] = M[(size_t)(e >> 4) * ldm + (e & 15)]; }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (!ptdfb_invert_tile(Pa, l) && l == 0) s_bad = 1;
+  }
+  for (int k = 0; k < N; ++k) {
+    double* Pt = (k & 1) ? Pb : Pa;
+    double* Pn = (k & 1) ? Pa : Pb;
+    for (int i = tid; i < n_pad * PTDFB_TILE; i += PTDFB_THREADS) { const int r = i >> 4, c = i & 15; Lc[r * 17 + c] = M[(size_t)r * ldm + k * 16 + c]; }
+    if (tid == 0) s_next = 0;
+    __syncthreads();
+    // row panel: A_kj <- P A_kj (tile k itself becomes P)
+    for (int j = w; j < N; j += 4) {
+      v4d c = {0.0, 0.0, 0.0, 0.0};
+      if (j != k) {
+        double a[4], b[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { a[s] = Pt[(l & 15) * 17 + 4 * s + (l >> 4)]; b[s] = M[(size_t)(k * 16 + 4 * s + (l >> 4)) * ldm + j * 16 + (l & 15)]; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], c, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) c[v] = Pt[(4 * v + (l >> 4)) * 17 + (l & 15)];
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) M[(size_t)(k * 16 + 4 * v + (l >> 4)) * ldm + j * 16 + (l & 15)] = c[v];
+    }
+    __syncthreads();
+    if (D.dbg) c0_ = (long long)__builtin_readcyclecounter();
+    // trailing update + column panel: tile (i, j), i != k:  C <- (j == k ? 0 : C) - L_i R_j   (row k of the matrix holds R, R_k = P)
+    auto tile = [&](int i, int j) {
+      double a[4], b[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { a[s] = -Lc[(i * 16 + (l & 15)) * 17 + 4 * s + (l >> 4)]; b[s] = M[(size_t)(k * 16 + 4 * s + (l >> 4)) * ldm + j * 16 + (l & 15)]; }
+      double* Ct = M + (size_t)(i * 16 + (l >> 4)) * ldm + j * 16 + (l & 15);
+      v4d c = {0.0, 0.0, 0.0, 0.0};
+      if (j != k) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) c[v] = Ct[(size_t)4 * v * ldm];
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], c, 0, 0, 0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) Ct[(size_t)4 * v * ldm] = c[v];
+    };
+    const int n_t = (N - 1) * N;                                       // tiles of the step; the lookahead tile (k + 1, k + 1) is q_la
+    const int q_la = k + 1 < N ? k * N + (k + 1) : -1;                 // (row index k in the i != k numbering is block row k + 1)
+    if (w == 0 && q_la >= 0) {
+      tile(k + 1, k + 1);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      long long t0_ = D.dbg ? (long long)__builtin_readcyclecounter() : 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int e = l + 64 * q; Pn[(e >> 4) * 17 + (e & 15)] = M[(size_t)((k + 1) * 16 + (e >> 4)) * ldm + (k + 1) * 16 + (e & 15)]; }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      if (!ptdfb_invert_tile(Pn, l) && l == 0) s_bad = 1;
+      if (D.dbg) acc_inv += (long long)__builtin_readcyclecounter() - t0_;
+    }
+    for (;;) {                                                         // the other tiles: taken one by one from a counter in LDS
+      int q = 0;
+      if (l == 0) q = atomicAdd(&s_next, 1);
+      q = __builtin_amdgcn_readfirstlane(q);
+      if (q >= n_t) break;
+      if (q == q_la) continue;
+      int i = q / N;
+      const int j = q - i * N;
+      if (i >= k) ++i;
+      tile(i, j);
+    }
+    __syncthreads();
+    if (D.dbg) acc_tr += (long long)__builtin_readcyclecounter() - c0_;
+  }
+  if (D.dbg && tid == 0) { D.dbg[(size_t)cls * 8 + 2] = acc_inv; D.dbg[(size_t)cls * 8 + 6] = acc_tr; D.dbg[(size_t)cls * 8 + 7] = 0; }
+  const bool bad = s_bad != 0;
+  PTDFB_STAMP(3);
+  // ---- PTDF^T and LODF straight from the inverse in LDS -------------------------------------------------------------------------------
+  double* hden = Lc;                                                   // [line_pad]
+  int* s_lf = reinterpret_cast<int*>(hden + D.line_pad);
+  int* s_lt = s_lf + D.line_pad;
+  int* s_fl = s_lt + D.line_pad;
+  const int* lflag = desc + PTDFB_HDR + 2 * D.n_line + D.n_inj;
+  for (int k = tid; k < D.line_pad; k += PTDFB_THREADS) {
+    const bool in = k < D.n_line;
+    const int f = in ? lf[k] : -1, t = in ? lt[k] : -1;
+    const bool on = f >= 0 && t >= 0 && f != t;
+    s_lf[k] = on ? f : -1; s_lt[k] = on ? t : -1; s_fl[k] = in ? lflag[k] : 0;
+  }
+  __syncthreads();
+  auto X = [&](int r, int c) -> double { return (r < nr && c < nr) ? M[(size_t)r * ldm + c] : 0.0; };
+  for (int i = tid; i < D.kpad * D.line_pad; i += PTDFB_THREADS) {
+    const int b = i / D.line_pad, k = i - b * D.line_pad;
+    double v = 0.0;
+    const int f = s_lf[k];
+    if (!bad && b < nr && f >= 0) v = D.br_bdc[k] * (X(b, f) - X(b, s_lt[k]));
+    PT[i] = v;
+  }
+  if (tid == 0) D.status[cls] = bad ? 1 : 0;
+  PTDFB_STAMP(4);
+  if (!LO) return;
+  for (int k = tid; k < D.line_pad; k += PTDFB_THREADS) {
+    double d = 0.0;
+    const int f = s_lf[k], t = s_lt[k];
+    if (f >= 0 && !bad) {
+      const double bk = D.br_bdc[k];
+      const double den = 1.0 - (bk * (X(f, f) - X(f, t)) - bk * (X(t, f) - X(t, t)));      // 1 - (PTDF[k][f] - PTDF[k][t])
+      d = fabs(den) < 1e-8 ? (s_fl[k] ? 0.0 : __builtin_nan("")) : 1.0 / den;
+    }
+    hden[k] = d;
+  }
+  __syncthreads();
+  for (int i = tid; i < D.n_line * D.line_pad; i += PTDFB_THREADS) {
+    const int m = i / D.line_pad, k = i - m * D.line_pad;
+    const int f = s_lf[k], fm = s_lf[m];
+    double v = 0.0;
+    if (f >= 0) {
+      const int t = s_lt[k], tm = s_lt[m];
+      const double hd = hden[k];
+      double h = 0.0;
+      if (fm >= 0 && !bad) { const double bm = D.br_bdc[m]; h = bm * (X(f, fm) - X(f, tm)) - bm * (X(t, fm) - X(t, tm)); }   // PTDF[m][f] - PTDF[m][t] as stored in PT
+      v = (hd != hd) ? hd : (m == k ? -1.0 : h * hd);
+    }
+    LO[i] = v;
+  }
+  PTDFB_STAMP(5);
+}
+
+#undef PTDFB_STAMP
+
+}  // namespace gpf

@@ -661,6 +661,27 @@ class PowerFlowEngine:
         """Factorise the DC system of the topology currently held by ``lane`` (once per topology)."""
         check(self._lib.gpf_ptdf_build(self._h, int(lane)), "gpf_ptdf_build")
 
+    def ptdf_build_batch(self, lane0: int = 0, n: Optional[int] = None, with_lodf: bool = True) -> dict:
+        """PTDF (and LODF) tables of EVERY distinct topology the lanes ``[lane0, lane0 + n)`` hold right now, built on the device in
+        one launch (gpf_ptdf_build_batch: one workgroup per topology class, blocked Gauss-Jordan on the FP64 matrix cores).  Afterwards
+        `ptdf_flows` / `ptdf_flows_rows` / `lodf_screen` evaluate every lane against the tables of its own class.  Returns
+        ``lane_class`` [n], ``class_status`` [n_classes] (0 ok, 1 singular, 2 islanded, 3 no slack: the lanes of such a class get NaN
+        flows), ``class_n`` (dimension of each reduced B'), ``kernel_ms``."""
+        lane0, n = self._range(lane0, n)
+        nc = C.c_int32(0)
+        check(self._lib.gpf_ptdf_build_batch(self._h, lane0, n, 1 if with_lodf else 0, C.byref(nc)), "gpf_ptdf_build_batch")
+        lc, st, cn = np.empty(n, np.int32), np.empty(nc.value, np.int32), np.empty(nc.value, np.int32)
+        ms = C.c_double(0.0)
+        check(self._lib.gpf_ptdf_batch_info(self._h, ptr(lc, C.c_int32), ptr(st, C.c_int32), ptr(cn, C.c_int32), C.byref(ms)), "gpf_ptdf_batch_info")
+        return {"n_classes": int(nc.value), "lane_class": lc, "class_status": st, "class_n": cn, "kernel_ms": float(ms.value)}
+
+    def ptdf_class(self, cls: int, lodf: bool = False):
+        """PTDF [n_line, n_sub * n_busbar] of topology class ``cls`` of the last `ptdf_build_batch` (and its LODF [n_line, n_line])."""
+        out = np.empty((self.model.n_line, self.nb_total), dtype=np.float64)
+        lo = np.empty((self.model.n_line, self.model.n_line), dtype=np.float64) if lodf else None
+        check(self._lib.gpf_ptdf_batch_get(self._h, int(cls), ptr(out, C.c_double), ptr(lo, C.c_double)), "gpf_ptdf_batch_get")
+        return (out, lo) if lodf else out
+
     def ptdf(self) -> np.ndarray:
         """PTDF [n_line, n_sub * n_busbar] (MW of origin-side flow per MW injected at the bus, slack-referenced)."""
         out = np.empty((self.model.n_line, self.nb_total), dtype=np.float64)
@@ -796,6 +817,13 @@ class PowerFlowEngine:
         buf = C.create_string_buffer(need.value + 1)
         check(self._lib.gpf_jit_source(self._h, buf, len(buf), None), "gpf_jit_source")
         return buf.value.decode()
+
+    def counters(self) -> dict:
+        """Step launches issued since the engine was created and the kernel dispatches they took (a batch of a few residency rounds goes
+        out as one dispatch per round)."""
+        out = (C.c_int64 * 2)()
+        check(self._lib.gpf_get_counters(self._h, out), "gpf_get_counters")
+        return {"step_launches": int(out[0]), "kernel_dispatches": int(out[1])}
 
     def plan(self) -> dict:
         """Diagnostics: the kernel configuration a launch over all lanes would use right now (gpf_get_plan)."""

@@ -362,6 +362,25 @@ int gpf_ptdf_build(gpf_handle h, int32_t lane);
 int gpf_ptdf_get(gpf_handle h, double* ptdf /* [n_line][n_sub*n_busbar] row-major, MW per MW */);
 int gpf_ptdf_flows(gpf_handle h, int32_t lane0, int32_t n);
 int gpf_get_ptdf_flows(gpf_handle h, int32_t lane0, int32_t n, float* p_or);
+/* ---- the same for PER-LANE topologies: the DC matrices of every DISTINCT topology of a lane range factorised ON THE DEVICE ------------
+ * The reference factorises B' of whatever topology each environment has on every DC call (pp.rundcpp, pandaPowerBackend.py:1090;
+ * N1Reward once per contingency, grid2op/Reward/n1Reward.py:70-99).  gpf_ptdf_build_batch groups lanes [lane0, lane0 + n) by their
+ * CURRENT topology rows (as on the device: lines tripped by a cascade included) into classes and, in ONE launch with one workgroup per
+ * class, assembles the reduced B', inverts it with a blocked Gauss-Jordan whose panel / trailing updates run on the FP64 matrix cores
+ * (v_mfma_f64_16x16x4_f64; 2 n^3 flops per class) and forms PTDF^T and (with_lodf != 0) the LODF table of the class
+ * (grid2op_amd/csrc/gridpf_ptdf_batch.hpp).  The host only does the integer work per class (live buses, compact numbering, the
+ * connectivity check of rundcpp(check_connectivity=True)).  Afterwards gpf_ptdf_flows / gpf_ptdf_flows_rows / gpf_lodf_screen evaluate
+ * every lane against the tables of ITS class (gpf_ptdf_flows and gpf_lodf_screen must be called on exactly [lane0, lane0 + n),
+ * gpf_ptdf_flows_rows needs the batch built for all lanes); lanes of a class without sensitivities (islanded topology, no in-service
+ * slack, singular pivot) get NaN flows instead of an error.  gpf_ptdf_build switches back to the single-topology tables.
+ * Capacity: at most 256 active non-reference buses per topology (GPF_E_CAPACITY).  *n_classes (may be NULL) = distinct topologies. */
+int gpf_ptdf_build_batch(gpf_handle h, int32_t lane0, int32_t n, int32_t with_lodf, int32_t* n_classes);
+/* lane_class[n]: class of every lane of the built range; class_status[n_classes]: 0 ok, 1 singular pivot, 2 islanded, 3 no in-service
+ * slack; class_n[n_classes]: dimension of the reduced B' of the class; *kernel_ms: duration of the build kernel (HIP events).  Any
+ * pointer may be NULL. */
+int gpf_ptdf_batch_info(gpf_handle h, int32_t* lane_class, int32_t* class_status, int32_t* class_n, double* kernel_ms);
+/* tables of one class in the layout of gpf_ptdf_get: ptdf [n_line][n_sub*n_busbar], lodf [n_line][n_line] (either may be NULL) */
+int gpf_ptdf_batch_get(gpf_handle h, int32_t cls, double* ptdf, double* lodf);
 /* The same over n_rows CONSECUTIVE CHRONICS ROWS of every lane in ONE launch (M = n_lanes x n_rows rows of the GEMM): row j of lane k
  * is chronics row (t0 + j + lane_offset[k]) mod T of table lane_table[k] turned into injections exactly as gpf_step does (loads x
  * lane_scale, non-slack prod_p rescaled to rebalance x sum(load) when rebalance > 0, + the lane's redispatch delta; storage and shunt
@@ -391,6 +410,10 @@ int gpf_set_profiling(gpf_handle h, int32_t mode);
 /* Sum of the event-measured durations (ms) and number of solver launches since the last call (closes the running
  * window of mode 1 and opens the next one). */
 int gpf_get_kernel_time(gpf_handle h, double* total_ms, int64_t* n_launches);
+/* out[2] = {gpf_step / gpf_step_n / gpf_simulate_batch step launches since gpf_create, kernel dispatches they issued}.  A batch of a few
+ * residency rounds of equal lanes (e.g. 2 048 lanes of a 118-substation grid: 2 x the 1 024 resident blocks) goes out as one dispatch per
+ * round, back to back on the engine's stream (gridpf_launch_step.hip); everything else is one dispatch per launch. */
+int gpf_get_counters(gpf_handle h, int64_t out[2]);
 /* Diagnostics (no reference counterpart): the kernel configuration a launch over ALL lanes would use right now.
  * out[0] busbars per block (1: single-busbar kernel; 2, 3: NB = n_busbar kernel), out[1] instances per wavefront,
  * out[2] wavefronts per instance, out[3] static-table staging tier (0 global memory, 1 program + pair table in LDS, 2 all),

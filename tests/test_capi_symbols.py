@@ -91,7 +91,7 @@ def test_bench_uses_the_oracle_only_as_checker_or_cpu_baseline():
     else (the measured path must be the HIP engine)."""
     import ast
     tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
-    allowed = {"cpu_baseline", "oracle_spot_check", "workload_ptdf", "workload_ptdf_rows"}       # (the two PTDF records: checker legs after the timed loops)
+    allowed = {"cpu_baseline", "oracle_spot_check", "oracle_dc_check", "workload_ptdf", "workload_ptdf_rows"}       # (the two PTDF records: checker legs after the timed loops)
     found = set()
     for fn in [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef)]:
         for n in ast.walk(fn):

@@ -95,6 +95,38 @@ def test_n1_fanout_1024_envs_x_60_lanes_vs_oracle(load_model, load_npz):
     eng.close()
 
 
+def test_n1_fanout_118_substations_1024_envs_x_187_lanes_vs_oracle(load_model, load_npz):
+    """configs[2] on a REAL 118-substation grid (BASELINE.json says "IEEE 118-bus"; the bundled l2rpn_neurips_2020_track1 is a
+    36-substation sub-area, grid2op/tests/test_attached_envs.py:31-35): l2rpn_wcci_2022_dev, 1 024 envs x (1 intact + 186 single-line
+    outages) = 191 488 lanes stepped together as bench.py's `n1_fanout_118` does (4 steps per launch, observation per step).  All 187
+    lanes of two envs and 80 random lanes are re-solved by the C oracle from the inputs the lanes hold on the device, incl. the
+    contingencies that island the grid (grid2op/Reward/n1Reward.py:70-99, Environment/_obsEnv.py:321-428 is what the fan-out replaces)."""
+    name, n_envs = "l2rpn_wcci_2022_dev", 1024
+    m0 = load_model(name)
+    fan = 1 + m0.n_line
+    m, eng, tab, off, sc = _bench_engine(load_model, load_npz, name, n_envs, fan)
+    B = n_envs * fan
+    topo = np.tile(m.initial_topo_vect().astype(np.int32), (B, 1))
+    for c in range(1, fan):
+        topo[c::fan, m.line_or_pos_topo_vect[c - 1]] = -1
+        topo[c::fan, m.line_ex_pos_topo_vect[c - 1]] = -1
+    eng.set_topology(topo)
+    eng.set_trajectory(4, eng.TRAJ_OBS)
+    eng.step(3, n_steps=4, rebalance=1.02)
+    r = eng.results(with_bus=False)
+    conv = r.converged.reshape(n_envs, fan)
+    assert conv[:, 0].all()                                       # the intact grid converges in every env
+    obs1 = eng.trajectory_obs(1, step0=1, lane0=0, n=fan)[0]      # an earlier step of the launch (first env): same verdicts, its own flows
+    assert np.array_equal(obs1.converged, r.converged[:fan]) and not np.array_equal(obs1.out, r.out[:fan])
+    lanes = np.unique(np.concatenate([np.arange(fan), 517 * fan + np.arange(fan), np.random.default_rng(2).choice(B, 80, replace=False)]))
+    res = check_lanes(eng, lanes, results=r)
+    assert res["ok"], res
+    assert res["n_converged"] < res["n"], "the sample is meant to contain islanding contingencies"
+    isl = r.status.reshape(n_envs, fan, 4)[:, :, 0] == 2
+    assert (isl == isl[:1]).all() and isl[0].any()
+    eng.close()
+
+
 def test_wcci_1024_lanes_storage_and_redispatch_16_step_launch_vs_oracle(load_model, load_npz):
     """configs[3] as bench.py runs it: l2rpn_wcci_2022_dev (118 substations), 1 024 lanes, storage set-points U(-2, 2) MW and a
     zero-sum +-1 MW redispatch per lane, one 16-step launch (2 wavefronts per instance, Ybus blocks in registers)."""

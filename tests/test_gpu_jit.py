@@ -200,3 +200,51 @@ def test_parity_suites_on_specialised_kernels(jit_cache):
     assert " passed" in p.stdout and "failed" not in p.stdout.splitlines()[-1], tail
     n_after = len([f for f in os.listdir(jit_cache) if f.endswith(".hsaco")])
     assert n_after >= n_before + 5, (n_before, n_after)      # the suites' own grids / kernel variants were compiled: the switch was on
+
+
+def test_bench_grids_run_on_ahead_of_time_objects_without_a_compiler(load_model, load_npz, tmp_path):
+    """The grids of grid2op_amd/aot/manifest.json (BASELINE configs) get their specialised kernels from grid2op_amd/_aot -- built by
+    __graft_entry__.build() on the CPU box, found by a hash of (generated header, variant, flags, kernel sources) -- even when NO compiler
+    is available at run time (GRIDPF_HIPCC pointing nowhere, an empty cache): nothing is compiled, results equal the shipped kernels'.
+    (A header that changed since the manifest was recorded simply misses the ahead-of-time objects: then this test reports it.)"""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import json, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from conftest import ROOT
+from grid2op_amd.grid_model import GridModel
+from grid2op_amd.engine import PowerFlowEngine
+import os
+gold = os.path.join(ROOT, "tests", "golden")
+out = {}
+for name, B in (("l2rpn_case14_sandbox", 4096), ("l2rpn_wcci_2022_dev", 1024)):
+    m = GridModel.load_npz(os.path.join(gold, name + ".grid.npz"))
+    ch = dict(np.load(os.path.join(gold, name + ".chronics.npz")))
+    if "prod_v" not in ch:
+        ch["prod_v"] = np.tile((m.gen_vm0 * m.sub_vn_kv[m.gen_sub]).astype(np.float32), (ch["prod_p"].shape[0], 1))
+    res = []
+    for jit in (False, True):
+        eng = PowerFlowEngine(m, n_lanes=B, device=0)
+        eng.upload_chronics(eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"]))
+        eng.set_lane_chronics(lane_offset=(7 * np.arange(B)).astype(np.int32))
+        if jit:
+            eng.specialize(True, verify=False)
+        eng.set_trajectory(16, eng.TRAJ_OBS)
+        eng.step(2, n_steps=16, rebalance=1.02)
+        r = eng.results()
+        res.append((r.out.copy(), r.status.copy()))
+        info = eng.specialization()
+        eng.close()
+    out[name] = dict(info, same=bool(np.array_equal(res[0][0], res[1][0], equal_nan=True) and np.array_equal(res[0][1], res[1][1])))
+print("RESULT " + json.dumps(out))
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, GRIDPF_HIPCC=str(tmp_path / "no_such_hipcc"), GRIDPF_JIT_CACHE=str(tmp_path / "cache"))
+    env.pop("GRIDPF_JIT", None)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    for name, info in res.items():
+        assert info["enabled"] and info["aot"] >= 1 and info["compiled"] == 0 and info["failed"] == 0 and info["launches"] == 1, (name, info)
+        assert info["same"], name
