@@ -130,6 +130,23 @@ struct DevArr {
     if (p) (void)hipFree(p);
     p = nullptr;
     n = 0;
+    cap = 0;
+  }
+  size_t cap = 0;                          // elements allocated (ensure / put: grow-only buffers reused across calls)
+  hipError_t ensure(size_t count) {        // room for `count` elements; contents undefined afterwards when it had to grow
+    if (count <= cap && p) { n = count; return hipSuccess; }
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    const size_t want = count + count / 4;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(want, 1) * sizeof(T));
+    cap = e == hipSuccess ? std::max<size_t>(want, 1) : 0;
+    n = e == hipSuccess ? count : 0;
+    return e;
+  }
+  hipError_t put(const T* src, size_t count, hipStream_t stream) {   // ensure + asynchronous upload on `stream` (src must stay alive until it ran)
+    hipError_t e = ensure(count);
+    if (e != hipSuccess || count == 0) return e;
+    return hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, stream);
   }
 };
 
@@ -163,6 +180,7 @@ struct gpf_engine {
   DevArr<unsigned char> maint;          // [chron_tables][chron_T][n_line] scheduled maintenance OR hazards (forced outages), or empty
   std::vector<unsigned char> h_maint, h_hazard;   // host copies of the two tables (the device holds their union)
   std::vector<int> h_lane_table, h_lane_offset;   // host mirror of lane_table / lane_offset (gpf_simulate_batch: maintenance ahead of a source lane)
+  std::vector<char> h_lane_forecast;              // 1: the lane is a scratch lane of gpf_simulate_batch (its offset is an absolute row, of the forecast tables for time_step > 0)
   // injection dynamics of the environment (gpf::EnvDyn)
   bool env_on = false, env_hold = false, env_act_r = false, env_act_s = false, sto_ready = false;
   int env_loss_on = 1;
@@ -960,6 +978,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   e->lane_class.assign(e->cap_lanes, -1);
   e->h_lane_table.assign(e->cap_lanes, 0);
   e->h_lane_offset.assign(e->cap_lanes, 0);
+  e->h_lane_forecast.assign(e->cap_lanes, 0);
   e->h_lane_topo.assign((size_t)e->cap_lanes * g.dim_topo, INT_MIN);
   e->h_lane_sb.assign((size_t)e->cap_lanes * std::max(g.n_shunt, 1), INT_MIN);
   {
@@ -1543,6 +1562,7 @@ int gpf_set_lane_chronics(gpf_handle e, const int32_t* lane_table, const int32_t
   if (lane_offset) {
     HIP_TRY(hipMemcpyAsync(e->lane_offset.p, lane_offset, B * sizeof(int), hipMemcpyHostToDevice, e->stream));
     std::copy(lane_offset, lane_offset + B, e->h_lane_offset.begin());
+    std::fill(e->h_lane_forecast.begin(), e->h_lane_forecast.end(), 0);       // every lane is back on the chronics tables
   }
   if (lane_scale) {
     if (!e->lane_scale.p) {
@@ -1814,6 +1834,11 @@ int gpf_simulate_batch(gpf_handle e, int32_t t_obs, int32_t time_step, int32_t n
   for (int b = 0; b < n_src; ++b)
     if (src_lanes[b] < 0 || src_lanes[b] >= e->n_lanes || (src_lanes[b] >= dst_lane0 && src_lanes[b] < dst_lane0 + n_dst))
       return fail(GPF_E_INVALID, "gpf_simulate_batch: source lane out of range or inside the destination range");
+  for (int b = 0; b < n_src; ++b)
+    if (e->h_lane_forecast[src_lanes[b]])
+      return fail(GPF_E_INVALID, "gpf_simulate_batch: a source lane is itself a scratch lane of an earlier gpf_simulate_batch (its chronics cursor is an "
+                                 "absolute row, of the forecast tables when it simulated a forecast): chained simulate is not supported -- simulate from "
+                                 "the environment's lane, or send gpf_set_lane_chronics again");
   const int n_items_total = act_off[n_act];
   if (act_off[0] != 0 || (n_items_total > 0 && !act_items)) return fail(GPF_E_INVALID, "gpf_simulate_batch: bad action offsets");
   for (int k = 0; k < n_act; ++k) if (act_off[k + 1] < act_off[k]) return fail(GPF_E_INVALID, "gpf_simulate_batch: bad action offsets");
@@ -1888,6 +1913,7 @@ int gpf_simulate_batch(gpf_handle e, int32_t t_obs, int32_t time_step, int32_t n
     if (idx < 0) idx += e->chron_T;
     e->h_lane_table[dst_lane0 + q] = e->h_lane_table[src];
     e->h_lane_offset[dst_lane0 + q] = time_step == 0 ? idx : (fc ? e->fc_h : 1) * idx + (time_step - 1);
+    e->h_lane_forecast[dst_lane0 + q] = 1;          // its cursor is an ABSOLUTE row (of the forecast tables when time_step > 0), not an offset to t
   }
   // with the injection dynamics on, the scratch lanes start from their source's dispatch / storage / curtailment state and take
   // ONE do-nothing step of the dynamics on the forecast (the candidates are topology actions: no redispatch / storage part)
@@ -2311,18 +2337,28 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
   HIP_TRY(hipMemcpy(topo.data(), e->topo.p + (size_t)lane0 * g.dim_topo, topo.size() * sizeof(int), hipMemcpyDeviceToHost));
   if (nsh) HIP_TRY(hipMemcpy(sb.data(), e->shunt_bus.p + (size_t)lane0 * nsh, (size_t)n * nsh * sizeof(int), hipMemcpyDeviceToHost));
   // ---- classes: lanes with identical (topology row, shunt buses) ----------------------------------------------------------------------
-  std::unordered_map<std::string, int> cls_of;
+  std::unordered_map<uint64_t, std::vector<int>> cls_of;     // row hash -> classes with that hash (rows compared on a hit)
   std::vector<int> first_lane;                       // representative lane (index in the range) of each class
   e->h_ptdfb_lane_class.assign(n, -1);
+  auto same_rows = [&](int a, int b) {
+    return std::memcmp(topo.data() + (size_t)a * g.dim_topo, topo.data() + (size_t)b * g.dim_topo, (size_t)g.dim_topo * sizeof(int)) == 0 &&
+           (!nsh || std::memcmp(sb.data() + (size_t)a * nsh, sb.data() + (size_t)b * nsh, (size_t)nsh * sizeof(int)) == 0);
+  };
   for (int k = 0; k < n; ++k) {
-    std::string key(reinterpret_cast<const char*>(topo.data() + (size_t)k * g.dim_topo), (size_t)g.dim_topo * sizeof(int));
-    if (nsh) key.append(reinterpret_cast<const char*>(sb.data() + (size_t)k * nsh), (size_t)nsh * sizeof(int));
-    auto it = cls_of.find(key);
-    if (it == cls_of.end()) { it = cls_of.emplace(std::move(key), (int)first_lane.size()).first; first_lane.push_back(k); }
-    e->h_ptdfb_lane_class[k] = it->second;
+    uint64_t h = 1469598103934665603ull;
+    const int* tp = topo.data() + (size_t)k * g.dim_topo;
+    for (int i = 0; i < g.dim_topo; ++i) { h ^= (uint32_t)tp[i]; h *= 1099511628211ull; }
+    for (int i = 0; i < nsh; ++i) { h ^= (uint32_t)sb[(size_t)k * nsh + i] + 0x9E3779B9u; h *= 1099511628211ull; }
+    std::vector<int>& cand = cls_of[h];
+    int c = -1;
+    for (int cc : cand) if (same_rows(first_lane[cc], k)) { c = cc; break; }
+    if (c < 0) { c = (int)first_lane.size(); first_lane.push_back(k); cand.push_back(c); }
+    e->h_ptdfb_lane_class[k] = c;
   }
   const int nc = (int)first_lane.size();
-  const int stride = (gpf::PTDFB_HDR + 3 * nl + g.n_inj + 3) & ~3;
+  // descriptor: header | lf | lt | inj_bus | lflag | row pointers of B' [PTDFB_MAX_N + 1] | row entries [2 n_line] (gridpf_ptdf_batch.hpp)
+  if (nl > 65535) return fail(GPF_E_CAPACITY, "gpf_ptdf_build_batch: more than 65535 lines");
+  const int stride = (gpf::PTDFB_HDR + 3 * nl + g.n_inj + gpf::PTDFB_MAX_N + 1 + 2 * nl + 3) & ~3;
   std::vector<int> desc((size_t)nc * stride, -1);
   e->h_ptdfb_bus.assign(nc, std::vector<int>());
   int npad_max = 16, nact_max = 1;
@@ -2386,6 +2422,21 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
       // a line end on a bus that carries nothing else: the outage of the line removes the bus (no islanding, the other flows stand)
       lflag[l] = (on && ((n_lines_at[bf[l]] == 1 && n_other_at[bf[l]] == 0) || (n_lines_at[bt[l]] == 1 && n_other_at[bt[l]] == 0))) ? 1 : 0;
     }
+    {   // rows of the reduced B': for every non-reference bus r the lines at it, ascending, as line | other end << 16
+      int* cptr = lflag + nl;
+      int* cent = cptr + gpf::PTDFB_MAX_N + 1;
+      std::vector<int> cnt(nr + 1, 0);
+      for (int l = 0; l < nl; ++l) { if (lf[l] < 0) continue; if (lf[l] < nr) ++cnt[lf[l]]; if (lt[l] < nr) ++cnt[lt[l]]; }
+      int acc = 0;
+      for (int r = 0; r < nr; ++r) { cptr[r] = acc; acc += cnt[r]; cnt[r] = cptr[r]; }
+      for (int r = nr; r <= gpf::PTDFB_MAX_N; ++r) cptr[r] = acc;
+      for (int i = 0; i < 2 * nl; ++i) cent[i] = 0;
+      for (int l = 0; l < nl; ++l) {
+        if (lf[l] < 0) continue;
+        if (lf[l] < nr) cent[cnt[lf[l]]++] = l | (lt[l] << 16);
+        if (lt[l] < nr) cent[cnt[lt[l]]++] = l | (lf[l] << 16);
+      }
+    }
     for (int i = 0; i < g.n_inj; ++i) ib[i] = ibus[i] >= 0 ? compact[ibus[i]] : -1;
     npad_max = std::max(npad_max, n_pad);
     nact_max = std::max(nact_max, n_act);
@@ -2402,15 +2453,14 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
   const int line_pad = (nl + 15) & ~15;
   const int nb_pad = std::max(4, (nact_max + 3) & ~3), kpad = (nb_pad + 31) & ~31;
   e->ptdf_ready = false;
-  e->ptdfb_desc.release(); e->ptdfb_order.release(); e->ptdfb_blk_class.release(); e->ptdfb_status.release();
-  e->ptdfb_work.release(); e->ptdfb_t.release(); e->ptdfb_lodf.release();
-  HIP_TRY(e->ptdfb_desc.upload(desc.data(), desc.size()));
-  HIP_TRY(e->ptdfb_order.upload(order.data(), order.size()));
-  HIP_TRY(e->ptdfb_blk_class.upload(blk_class.data(), blk_class.size()));
-  HIP_TRY(e->ptdfb_status.alloc(nc));
-  HIP_TRY(e->ptdfb_work.alloc((size_t)nc * npad_max * npad_max));
-  HIP_TRY(e->ptdfb_t.alloc((size_t)nc * kpad * line_pad));
-  if (with_lodf) HIP_TRY(e->ptdfb_lodf.alloc((size_t)nc * nl * line_pad));
+  // (grow-only buffers: a rebuild after a few topology changes allocates nothing; uploads ride the engine's stream in front of the kernel)
+  HIP_TRY(e->ptdfb_desc.put(desc.data(), desc.size(), e->stream));
+  HIP_TRY(e->ptdfb_order.put(order.data(), order.size(), e->stream));
+  HIP_TRY(e->ptdfb_blk_class.put(blk_class.data(), blk_class.size(), e->stream));
+  HIP_TRY(e->ptdfb_status.ensure(nc));
+  HIP_TRY(e->ptdfb_work.ensure((size_t)nc * npad_max * npad_max));
+  HIP_TRY(e->ptdfb_t.ensure((size_t)nc * kpad * line_pad));
+  if (with_lodf) HIP_TRY(e->ptdfb_lodf.ensure((size_t)nc * nl * line_pad)); else e->ptdfb_lodf.release();
   if (!e->ptdfb_inj_w.p) {
     std::vector<double> w(g.n_inj, 0.0);
     for (int i = 0; i < g.n_gen; ++i) w[oo.inj_gen_p + i] = 1.0;
@@ -2431,8 +2481,8 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
   if (want_dbg) { HIP_TRY(dbg.alloc((size_t)nc * 8)); HIP_TRY(hipMemset(dbg.p, 0, (size_t)nc * 8 * sizeof(long long))); D.dbg = dbg.p; }
   // reduced dimension <= 128 (118-substation grids): the matrix of a class lives in LDS (ptdf_build_lds_kernel), else in global memory
   static const bool no_resident = getenv("GRIDPF_PTDFB_GLOBAL") != nullptr;   // developer: force the global-memory kernel
-  const bool resident = npad_max <= 128 && !no_resident;
-  const size_t lds = resident ? gpf::ptdfb_lds_bytes_resident(npad_max, line_pad) : gpf::ptdfb_lds_bytes(npad_max, line_pad);
+  const bool resident = npad_max <= 128 && line_pad <= gpf::PTDFB_LDS_THREADS && !no_resident && gpf::ptdfb_lds_bytes_resident(npad_max, line_pad, nl) <= LDS_HARD_LIMIT;
+  const size_t lds = resident ? gpf::ptdfb_lds_bytes_resident(npad_max, line_pad, nl) : gpf::ptdfb_lds_bytes(npad_max, line_pad);
   static size_t lds_set[64][2] = {{0}};
   if (lds > lds_set[e->device & 63][resident]) {
     HIP_TRY(hipFuncSetAttribute(resident ? reinterpret_cast<const void*>(&gpf::ptdf_build_lds_kernel) : reinterpret_cast<const void*>(&gpf::ptdf_build_kernel),
@@ -2442,7 +2492,7 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
   hipEvent_t ea = nullptr, eb = nullptr;
   HIP_TRY(hipEventCreate(&ea)); HIP_TRY(hipEventCreate(&eb));
   HIP_TRY(hipEventRecord(ea, e->stream));
-  if (resident) hipLaunchKernelGGL(gpf::ptdf_build_lds_kernel, dim3(nc), dim3(gpf::PTDFB_THREADS), lds, e->stream, D);
+  if (resident) hipLaunchKernelGGL(gpf::ptdf_build_lds_kernel, dim3(nc), dim3(gpf::PTDFB_LDS_THREADS), lds, e->stream, D);
   else hipLaunchKernelGGL(gpf::ptdf_build_kernel, dim3(nc), dim3(gpf::PTDFB_THREADS), lds, e->stream, D);
   hipError_t le = hipGetLastError();
   HIP_TRY(hipEventRecord(eb, e->stream));

@@ -299,115 +299,210 @@ __global__ __launch_bounds__(PTDFB_THREADS) void ptdf_build_kernel(PtdfBuildDev 
 // doubles = 133 KB of the CU's 160 KB), one workgroup per CU.  Same algorithm; what changes is where the operands come from (every
 // MFMA operand and every result tile is an LDS access instead of an L2 round trip) and the schedule of a step: the diagonal tile of step
 // k + 1 is final as soon as ITS trailing update of step k is done, so wavefront 0 updates that tile first and inverts it (a chain of 16
-// dependent pivots, ~6 k cycles) while the other wavefronts run the rest of the trailing update -- the inversions leave the critical path.
+// dependent pivots) while the other wavefronts run the rest of the trailing update, two tiles at a time (independent accumulators: the
+// operands of the second tile load while the first one's MFMAs run) -- the inversions leave the critical path.  The class tables
+// (line ends, susceptances, the row lists of B') are staged in LDS once; PTDF^T and LODF are written one COLUMN per thread (coalesced
+// stores, every operand from LDS).
+constexpr int PTDFB_LDS_THREADS = 512;       // the LDS-resident kernel: 8 wavefronts (2 per SIMD: one's LDS / MFMA latency hides behind the other's)
+constexpr int PTDFB_LROWS = 8;               // PTDF rows per round of the LODF phase
+constexpr int PTDFB_PT = 18;                 // row stride (doubles) of a diagonal-tile buffer: 16-byte aligned quads, conflict-free columns
 __host__ __device__ inline int ptdfb_ldm(int n_pad) { return n_pad + 2; }
-__host__ __device__ inline size_t ptdfb_lds_bytes_resident(int n_pad_max, int line_pad) {
-  // matrix [n_pad][n_pad + 2] + column panel copy [n_pad][17] (later: the line tables) + two diagonal tiles [16][17]
+__host__ __device__ inline size_t ptdfb_lds_bytes_resident(int n_pad_max, int line_pad, int n_line) {
+  // matrix [n_pad][n_pad + 2] | column panel copy [n_pad][17] (later: 1 / (1 - H[k][k])) | two diagonal tiles [16][18] | br_bdc [line_pad]
+  // | lf, lt, lflag [line_pad] ints | row pointers [n_pad + 1] + row entries [2 n_line] ints
   const size_t panel = (size_t)n_pad_max * ptdfb_lcol_stride();
-  const size_t tabs = (size_t)line_pad + (3 * (size_t)line_pad + 1) / 2;
-  return ((size_t)n_pad_max * ptdfb_ldm(n_pad_max) + (panel > tabs ? panel : tabs) + 2 * PTDFB_TILE * (PTDFB_TILE + 1)) * sizeof(double);
+  const size_t tabs = (size_t)line_pad + (size_t)PTDFB_LROWS * n_pad_max;     // 1 / (1 - H[k][k]) + the PTDF rows of a LODF round
+  const size_t dbl = (size_t)n_pad_max * ptdfb_ldm(n_pad_max) + (panel > tabs ? panel : tabs) + 2 * PTDFB_TILE * PTDFB_PT + line_pad;
+  const size_t ints = 3 * (size_t)line_pad + (size_t)n_pad_max + 1 + 2 * (size_t)n_line;
+  return dbl * sizeof(double) + ((ints + 3) & ~(size_t)3) * sizeof(int);
 }
 
-__global__ __launch_bounds__(PTDFB_THREADS) void ptdf_build_lds_kernel(PtdfBuildDev D) {
+// inverse of the 16 x 16 tile Pt (LDS, row stride PTDFB_PT), in place, by ONE wavefront -- as ptdfb_invert_tile, with v_rcp_f64 + two
+// Newton steps instead of the IEEE division (pivots are checked against 1e-12 separately) and 16-byte LDS accesses
+__device__ inline bool ptdfb_invert_tile_fast(double* Pt, int l) {
+  const int i = l & 15, c0 = 4 * (l >> 4);
+  double t[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) t[q] = Pt[i * PTDFB_PT + c0 + q];
+  bool ok = true;
+#pragma unroll
+  for (int p = 0; p < PTDFB_TILE; ++p) {
+    const double piv = Pt[p * PTDFB_PT + p];
+    const double colp = Pt[i * PTDFB_PT + p];
+    double rowp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rowp[q] = Pt[p * PTDFB_PT + c0 + q];
+    ok = ok && (fabs(piv) > 1e-12);
+    const double rp = fast_rcp(piv);
+    const double f = colp * rp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = c0 + q;
+      if (i == p) t[q] = (j == p) ? rp : rowp[q] * rp;
+      else t[q] = (j == p) ? -f : fma(-f, rowp[q], t[q]);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Pt[i * PTDFB_PT + c0 + q] = t[q];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  return __all(ok);
+}
+
+__global__ __launch_bounds__(PTDFB_LDS_THREADS) void ptdf_build_lds_kernel(PtdfBuildDev D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ int s_bad, s_next;
   const int cls = blockIdx.x, tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   const int* desc = D.desc + (size_t)cls * D.desc_stride;
   const int nr = desc[0], n_pad = desc[2], host_st = desc[3];
-  const int* lf = desc + PTDFB_HDR;
-  const int* lt = lf + D.n_line;
   double* PT = D.ptdf_t + (size_t)cls * D.ptdf_stride;
   double* LO = D.lodf ? D.lodf + (size_t)cls * D.lodf_stride : nullptr;
   if (tid == 0) { s_bad = 0; s_next = 0; }
   PTDFB_STAMP(0);
   if (host_st != 0) {
-    for (int i = tid; i < D.kpad * D.line_pad; i += PTDFB_THREADS) PT[i] = 0.0;
-    if (LO) for (int i = tid; i < D.n_line * D.line_pad; i += PTDFB_THREADS) LO[i] = 0.0;
+    for (int i = tid; i < D.kpad * D.line_pad; i += PTDFB_LDS_THREADS) PT[i] = 0.0;
+    if (LO) for (int i = tid; i < D.n_line * D.line_pad; i += PTDFB_LDS_THREADS) LO[i] = 0.0;
     if (tid == 0) D.status[cls] = host_st;
     return;
   }
   const int ldm = ptdfb_ldm(n_pad);
+  const size_t panel = (size_t)n_pad * ptdfb_lcol_stride();
   double* M = reinterpret_cast<double*>(smem);                        // [n_pad][ldm]
-  double* Lc = M + (size_t)n_pad * ldm;                               // column panel copy [n_pad][17]
-  double* Pa = Lc + (size_t)n_pad * ptdfb_lcol_stride();             // inverse of the current diagonal tile [16][17]
-  double* Pb = Pa + PTDFB_TILE * (PTDFB_TILE + 1);                    // ... of the next one (lookahead)
-  // the line-end tables of the class: in LDS for the assembly and the table phases (they alias the column panel, unused then)
-  ptdfb_assemble(M, ldm, n_pad, nr, lf, lt, D.br_bdc, D.n_line, tid);
+  double* Lc = M + (size_t)n_pad * ldm;                               // column panel copy [n_pad][17]; later hden [line_pad]
+  const size_t tabs_ = (size_t)D.line_pad + (size_t)PTDFB_LROWS * n_pad;
+  double* Pa = Lc + (panel > tabs_ ? panel : tabs_);                  // inverse of the current diagonal tile [16][18]
+  double* Pb = Pa + PTDFB_TILE * PTDFB_PT;                            // ... of the next one (lookahead)
+  double* s_bdc = Pb + PTDFB_TILE * PTDFB_PT;                         // [line_pad]
+  int* s_lf = reinterpret_cast<int*>(s_bdc + D.line_pad);             // [line_pad] compact bus of the line's origin (-1: line not in the DC graph)
+  int* s_lt = s_lf + D.line_pad;
+  int* s_fl = s_lt + D.line_pad;
+  int* s_ptr = s_fl + D.line_pad;                                     // [n_pad + 1] row r of B': entries s_ent[s_ptr[r] .. s_ptr[r + 1])
+  int* s_ent = s_ptr + n_pad + 1;                                     // line | other bus << 16, lines ascending
+  {
+    const int* lf = desc + PTDFB_HDR;
+    const int* lt = lf + D.n_line;
+    const int* lflag = lt + D.n_line + D.n_inj;
+    const int* cptr = lflag + D.n_line;
+    const int* cent = cptr + PTDFB_MAX_N + 1;
+    for (int k = tid; k < D.line_pad; k += PTDFB_LDS_THREADS) {
+      const bool in = k < D.n_line;
+      const int f = in ? lf[k] : -1, t = in ? lt[k] : -1;
+      const bool on = f >= 0 && t >= 0 && f != t;
+      s_lf[k] = on ? f : -1; s_lt[k] = on ? t : -1; s_fl[k] = in ? lflag[k] : 0;
+      s_bdc[k] = in ? D.br_bdc[k] : 0.0;
+    }
+    for (int r = tid; r <= n_pad; r += PTDFB_LDS_THREADS) s_ptr[r] = cptr[r < nr ? r : nr];
+    for (int i = tid; i < 2 * D.n_line; i += PTDFB_LDS_THREADS) s_ent[i] = cent[i];
+    for (int i = tid; i < n_pad * n_pad; i += PTDFB_LDS_THREADS) { const int r = i / n_pad, c = i - r * n_pad; M[(size_t)r * ldm + c] = (r == c && r >= nr) ? 1.0 : 0.0; }
+  }
+  __syncthreads();
+  // ---- 1. B': thread r owns row r and walks its lines in ascending order (no atomics: the same bits on every run) --------------------
+  for (int r = tid; r < nr; r += PTDFB_LDS_THREADS) {
+    double* row = M + (size_t)r * ldm;
+    double diag = 0.0;
+    for (int e = s_ptr[r]; e < s_ptr[r + 1]; ++e) {
+      const int w_ = s_ent[e], o = w_ >> 16;
+      const double bb = s_bdc[w_ & 0xFFFF];
+      diag += bb;
+      if (o < nr) row[o] -= bb;
+    }
+    row[r] = diag;
+  }
   __syncthreads();
   PTDFB_STAMP(1);
+  // ---- 2. blocked Gauss-Jordan with lookahead --------------------------------------------------------------------------------------------
   const int N = n_pad / PTDFB_TILE;
   long long acc_inv = 0, acc_tr = 0, c0_ = 0;
   if (w == 0) {                                                       // inverse of the first diagonal tile
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const int e = l + 64 * q; Pa[(e >> 4) * 17 + (e & 15)] = M[(size_t)(e >> 4) * ldm + (e & 15)]; }
+    for (int q = 0; q < 4; ++q) { const int e = l + 64 * q; Pa[(e >> 4) * PTDFB_PT + (e & 15)] = M[(size_t)(e >> 4) * ldm + (e & 15)]; }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    if (!ptdfb_invert_tile(Pa, l) && l == 0) s_bad = 1;
+    if (!ptdfb_invert_tile_fast(Pa, l) && l == 0) s_bad = 1;
   }
   for (int k = 0; k < N; ++k) {
     double* Pt = (k & 1) ? Pb : Pa;
     double* Pn = (k & 1) ? Pa : Pb;
-    for (int i = tid; i < n_pad * PTDFB_TILE; i += PTDFB_THREADS) { const int r = i >> 4, c = i & 15; Lc[r * 17 + c] = M[(size_t)r * ldm + k * 16 + c]; }
+    for (int i = tid; i < n_pad * PTDFB_TILE; i += PTDFB_LDS_THREADS) { const int r = i >> 4, c = i & 15; Lc[r * 17 + c] = M[(size_t)r * ldm + k * 16 + c]; }
     if (tid == 0) s_next = 0;
     __syncthreads();
     // row panel: A_kj <- P A_kj (tile k itself becomes P)
-    for (int j = w; j < N; j += 4) {
+    for (int j = w; j < N; j += PTDFB_LDS_THREADS / 64) {
       v4d c = {0.0, 0.0, 0.0, 0.0};
       if (j != k) {
         double a[4], b[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { a[s] = Pt[(l & 15) * 17 + 4 * s + (l >> 4)]; b[s] = M[(size_t)(k * 16 + 4 * s + (l >> 4)) * ldm + j * 16 + (l & 15)]; }
+        for (int s = 0; s < 4; ++s) { a[s] = Pt[(l & 15) * PTDFB_PT + 4 * s + (l >> 4)]; b[s] = M[(size_t)(k * 16 + 4 * s + (l >> 4)) * ldm + j * 16 + (l & 15)]; }
 #pragma unroll
         for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], c, 0, 0, 0);
       } else {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) c[v] = Pt[(4 * v + (l >> 4)) * 17 + (l & 15)];
+        for (int v = 0; v < 4; ++v) c[v] = Pt[(4 * v + (l >> 4)) * PTDFB_PT + (l & 15)];
       }
 #pragma unroll
       for (int v = 0; v < 4; ++v) M[(size_t)(k * 16 + 4 * v + (l >> 4)) * ldm + j * 16 + (l & 15)] = c[v];
     }
     __syncthreads();
     if (D.dbg) c0_ = (long long)__builtin_readcyclecounter();
-    // trailing update + column panel: tile (i, j), i != k:  C <- (j == k ? 0 : C) - L_i R_j   (row k of the matrix holds R, R_k = P)
-    auto tile = [&](int i, int j) {
-      double a[4], b[4];
+    // trailing update + column panel: tile (i, j), i != k:  C <- (j == k ? 0 : C) - L_i R_j   (row k of the matrix holds R, R_k = P).
+    // Work unit = FOUR tiles of one block row (columns 4 h .. 4 h + 3): one A operand, four independent accumulator chains -- the LDS
+    // and MFMA latencies of one tile hide behind the other three; units are taken one by one from a counter in LDS.
+    const int H = (N + 3) / 4, n_u = (N - 1) * H;
+    const int u_la = k + 1 < N ? k * H + (k + 1) / 4 : -1;             // the unit of the lookahead tile (k + 1, k + 1): wavefront 0's first
+    auto unit = [&](int u, v4d (&c)[4]) {
+      int i = u / H;
+      const int j0 = 4 * (u - i * H);
+      if (i >= k) ++i;
+      double a[4], b[4][4];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) { a[s] = -Lc[(i * 16 + (l & 15)) * 17 + 4 * s + (l >> 4)]; b[s] = M[(size_t)(k * 16 + 4 * s + (l >> 4)) * ldm + j * 16 + (l & 15)]; }
-      double* Ct = M + (size_t)(i * 16 + (l >> 4)) * ldm + j * 16 + (l & 15);
-      v4d c = {0.0, 0.0, 0.0, 0.0};
-      if (j != k) {
+      for (int s_ = 0; s_ < 4; ++s_) a[s_] = -Lc[(i * 16 + (l & 15)) * 17 + 4 * s_ + (l >> 4)];
 #pragma unroll
-        for (int v = 0; v < 4; ++v) c[v] = Ct[(size_t)4 * v * ldm];
+      for (int t = 0; t < 4; ++t) {
+        const int j = j0 + t < N ? j0 + t : N - 1;                     // (a ragged last group recomputes its last tile: same values)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) b[t][s_] = M[(size_t)(k * 16 + 4 * s_ + (l >> 4)) * ldm + j * 16 + (l & 15)];
+        const double* Ct = M + (size_t)(i * 16 + (l >> 4)) * ldm + j * 16 + (l & 15);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) c[t][v] = (j != k) ? Ct[(size_t)4 * v * ldm] : 0.0;
       }
 #pragma unroll
-      for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], c, 0, 0, 0);
+      for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) Ct[(size_t)4 * v * ldm] = c[v];
+        for (int t = 0; t < 4; ++t) c[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s_], b[t][s_], c[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int j = j0 + t < N ? j0 + t : N - 1;
+        double* Ct = M + (size_t)(i * 16 + (l >> 4)) * ldm + j * 16 + (l & 15);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Ct[(size_t)4 * v * ldm] = c[t][v];
+      }
     };
-    const int n_t = (N - 1) * N;                                       // tiles of the step; the lookahead tile (k + 1, k + 1) is q_la
-    const int q_la = k + 1 < N ? k * N + (k + 1) : -1;                 // (row index k in the i != k numbering is block row k + 1)
-    if (w == 0 && q_la >= 0) {
-      tile(k + 1, k + 1);
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
+    if (w == 0 && u_la >= 0) {
+      v4d c[4];
+      unit(u_la, c);
       long long t0_ = D.dbg ? (long long)__builtin_readcyclecounter() : 0;
+      const int tl = (k + 1) & 3;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const int e = l + 64 * q; Pn[(e >> 4) * 17 + (e & 15)] = M[(size_t)((k + 1) * 16 + (e >> 4)) * ldm + (k + 1) * 16 + (e & 15)]; }
+      for (int t = 0; t < 4; ++t)
+        if (t == tl) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) Pn[(4 * v + (l >> 4)) * PTDFB_PT + (l & 15)] = c[t][v];   // (the updated tile is in this wavefront's registers)
+        }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-      if (!ptdfb_invert_tile(Pn, l) && l == 0) s_bad = 1;
+      if (!ptdfb_invert_tile_fast(Pn, l) && l == 0) s_bad = 1;
       if (D.dbg) acc_inv += (long long)__builtin_readcyclecounter() - t0_;
     }
-    for (;;) {                                                         // the other tiles: taken one by one from a counter in LDS
-      int q = 0;
-      if (l == 0) q = atomicAdd(&s_next, 1);
-      q = __builtin_amdgcn_readfirstlane(q);
-      if (q >= n_t) break;
-      if (q == q_la) continue;
-      int i = q / N;
-      const int j = q - i * N;
-      if (i >= k) ++i;
-      tile(i, j);
+    for (;;) {
+      int u = 0;
+      if (l == 0) u = atomicAdd(&s_next, 1);
+      u = __builtin_amdgcn_readfirstlane(u);
+      if (u >= n_u) break;
+      if (u == u_la) continue;
+      v4d c[4];
+      unit(u, c);
     }
     __syncthreads();
     if (D.dbg) acc_tr += (long long)__builtin_readcyclecounter() - c0_;
@@ -415,53 +510,63 @@ __global__ __launch_bounds__(PTDFB_THREADS) void ptdf_build_lds_kernel(PtdfBuild
   if (D.dbg && tid == 0) { D.dbg[(size_t)cls * 8 + 2] = acc_inv; D.dbg[(size_t)cls * 8 + 6] = acc_tr; D.dbg[(size_t)cls * 8 + 7] = 0; }
   const bool bad = s_bad != 0;
   PTDFB_STAMP(3);
-  // ---- PTDF^T and LODF straight from the inverse in LDS -------------------------------------------------------------------------------
-  double* hden = Lc;                                                   // [line_pad]
-  int* s_lf = reinterpret_cast<int*>(hden + D.line_pad);
-  int* s_lt = s_lf + D.line_pad;
-  int* s_fl = s_lt + D.line_pad;
-  const int* lflag = desc + PTDFB_HDR + 2 * D.n_line + D.n_inj;
-  for (int k = tid; k < D.line_pad; k += PTDFB_THREADS) {
-    const bool in = k < D.n_line;
-    const int f = in ? lf[k] : -1, t = in ? lt[k] : -1;
-    const bool on = f >= 0 && t >= 0 && f != t;
-    s_lf[k] = on ? f : -1; s_lt[k] = on ? t : -1; s_fl[k] = in ? lflag[k] : 0;
-  }
-  __syncthreads();
+  // ---- 3. PTDF^T[b][k] = bdc_k (X[b][from_k] - X[b][to_k]): thread k owns column k (coalesced stores, operands from LDS) ----------------
   auto X = [&](int r, int c) -> double { return (r < nr && c < nr) ? M[(size_t)r * ldm + c] : 0.0; };
-  for (int i = tid; i < D.kpad * D.line_pad; i += PTDFB_THREADS) {
-    const int b = i / D.line_pad, k = i - b * D.line_pad;
-    double v = 0.0;
-    const int f = s_lf[k];
-    if (!bad && b < nr && f >= 0) v = D.br_bdc[k] * (X(b, f) - X(b, s_lt[k]));
-    PT[i] = v;
+  double* hden = Lc;                                                   // [line_pad] 1 / (1 - H[k][k]); 0: column of zeros; NaN: islanding outage
+  for (int k = tid; k < D.line_pad; k += PTDFB_LDS_THREADS) {
+    const int f = s_lf[k], t = s_lt[k];
+    const bool on = f >= 0 && !bad;
+    const double bk = s_bdc[k];
+    const int fc = (on && f < nr) ? f : -1, tc = (on && t < nr) ? t : -1;
+#pragma unroll 4
+    for (int b = 0; b < D.kpad; ++b) {
+      double v = 0.0;
+      if (b < nr) v = bk * ((fc >= 0 ? M[(size_t)b * ldm + fc] : 0.0) - (tc >= 0 ? M[(size_t)b * ldm + tc] : 0.0));
+      PT[(size_t)b * D.line_pad + k] = v;
+    }
+    double d = 0.0;
+    if (on) {
+      const double den = 1.0 - (bk * (X(f, f) - X(f, t)) - bk * (X(t, f) - X(t, t)));      // 1 - (PTDF[k][f] - PTDF[k][t]) as stored in PT
+      d = fabs(den) < 1e-8 ? (s_fl[k] ? 0.0 : __builtin_nan("")) : 1.0 / den;
+    }
+    hden[k] = d;                                                       // (Lc is free: the elimination is over)
   }
   if (tid == 0) D.status[cls] = bad ? 1 : 0;
   PTDFB_STAMP(4);
   if (!LO) return;
-  for (int k = tid; k < D.line_pad; k += PTDFB_THREADS) {
-    double d = 0.0;
-    const int f = s_lf[k], t = s_lt[k];
-    if (f >= 0 && !bad) {
-      const double bk = D.br_bdc[k];
-      const double den = 1.0 - (bk * (X(f, f) - X(f, t)) - bk * (X(t, f) - X(t, t)));      // 1 - (PTDF[k][f] - PTDF[k][t])
-      d = fabs(den) < 1e-8 ? (s_fl[k] ? 0.0 : __builtin_nan("")) : 1.0 / den;
+  // ---- 4. LODF[m][k] = (PTDF[m][from_k] - PTDF[m][to_k]) / (1 - H[k][k]); LODF[k][k] = -1.  Rounds of PTDFB_LROWS lines m: all threads
+  //         build the PTDF rows of those lines over the reduced buses in LDS (rows of X read contiguously: no bank conflicts), then thread
+  //         k takes its two entries of every row (2 gathers per output instead of 4) and stores column k (coalesced) ----------------------
+  __syncthreads();                                                     // hden complete; Lc beyond it is free
+  double* rows = Lc + D.line_pad;                                      // [PTDFB_LROWS][n_pad]
+  const int kk = tid < D.line_pad ? tid : -1;                          // (line_pad <= 256 threads is checked by the host)
+  const int kf = kk >= 0 ? s_lf[kk] : -1, kt = kk >= 0 ? s_lt[kk] : -1;
+  const double khd = kk >= 0 ? hden[kk] : 0.0;
+  for (int m0 = 0; m0 < D.n_line; m0 += PTDFB_LROWS) {
+    for (int e = tid; e < PTDFB_LROWS * n_pad; e += PTDFB_LDS_THREADS) {
+      const int u = e / n_pad, b = e - u * n_pad, m = m0 + u;
+      double v = 0.0;
+      if (m < D.n_line && b < nr && !bad) {
+        const int fm = s_lf[m], tm = s_lt[m];
+        if (fm >= 0) v = s_bdc[m] * ((fm < nr ? M[(size_t)fm * ldm + b] : 0.0) - (tm < nr ? M[(size_t)tm * ldm + b] : 0.0));   // = PT[b][m] (X symmetric to rounding)
+      }
+      rows[e] = v;
     }
-    hden[k] = d;
-  }
-  __syncthreads();
-  for (int i = tid; i < D.n_line * D.line_pad; i += PTDFB_THREADS) {
-    const int m = i / D.line_pad, k = i - m * D.line_pad;
-    const int f = s_lf[k], fm = s_lf[m];
-    double v = 0.0;
-    if (f >= 0) {
-      const int t = s_lt[k], tm = s_lt[m];
-      const double hd = hden[k];
-      double h = 0.0;
-      if (fm >= 0 && !bad) { const double bm = D.br_bdc[m]; h = bm * (X(f, fm) - X(f, tm)) - bm * (X(t, fm) - X(t, tm)); }   // PTDF[m][f] - PTDF[m][t] as stored in PT
-      v = (hd != hd) ? hd : (m == k ? -1.0 : h * hd);
+    __syncthreads();
+    if (kk >= 0) {
+#pragma unroll
+      for (int u = 0; u < PTDFB_LROWS; ++u) {
+        const int m = m0 + u;
+        if (m >= D.n_line) break;
+        double v = 0.0;
+        if (kf >= 0) {
+          const double h = (kf < nr ? rows[u * n_pad + kf] : 0.0) - (kt < nr ? rows[u * n_pad + kt] : 0.0);
+          v = (khd != khd) ? khd : (m == kk ? -1.0 : h * khd);
+        }
+        LO[(size_t)m * D.line_pad + kk] = v;
+      }
     }
-    LO[i] = v;
+    __syncthreads();
   }
   PTDFB_STAMP(5);
 }

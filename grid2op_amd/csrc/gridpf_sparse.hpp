@@ -1957,8 +1957,16 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     sv.pair_rc.p = tc_.pair_rc; sv.up.p = tc_.up; sv.br_slot.p = tc_.br_slot; sv.node_of.p = tc_.node_of;                        \
   }
 
+// developer (tools/unroll_bisect.py): -DGPF_FORCE_MINW=<waves per SIMD> makes the compiler fit the kernels below into 512 / waves
+// registers whatever their MINW argument says, i.e. forces spills to scratch memory
+#ifdef GPF_FORCE_MINW
+#define GPF_MINW(m_) GPF_FORCE_MINW
+#else
+#define GPF_MINW(m_) m_
+#endif
+
 template <int NB, int STAGE, int IPW, int MINW, int WPI, bool TC = false, bool YR = false>
-__global__ __launch_bounds__(WAVE * WPI, MINW) void runpf_sparse_kernel(const DevParamsS* __restrict__ P, int lane0, const int* __restrict__ lane_list,
+__global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void runpf_sparse_kernel(const DevParamsS* __restrict__ P, int lane0, const int* __restrict__ lane_list,
                                                             const int* __restrict__ lane_class, int is_dc, int max_iter,
                                                             double tol_pu) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2235,7 +2243,7 @@ __device__ inline bool env_dynamics_step(const EnvDyn& E, int k, int n_gen, int 
 // ENV: the kernel also evaluates the environment's injection dynamics (EnvDyn) at every step -- a separate instantiation, so that
 // the plain DoNothing kernels do not carry its registers and code (measured: -2.5 % on the 14-substation headline otherwise).
 template <int NB, int STAGE, int IPW, int MINW, int WPI, bool TC = false, bool YR = false, bool ENV = false>
-__global__ __launch_bounds__(WAVE * WPI, MINW) void step_sparse_kernel(const DevParamsS* __restrict__ P, const int* __restrict__ lane_list,
+__global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel(const DevParamsS* __restrict__ P, const int* __restrict__ lane_list,
                                                            const int* __restrict__ lane_class, int max_iter, double tol_pu,
                                                            StepArgs sa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

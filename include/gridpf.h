@@ -314,6 +314,8 @@ int gpf_set_env_state(gpf_handle h, int32_t lane0, int32_t n, const float* targe
  * With the injection dynamics on (gpf_set_env_dynamics) every scratch lane also inherits its source's dispatch / storage /
  * curtailment state (what _ObsEnv is initialised with) and takes ONE do-nothing step of the dynamics on the simulated injections
  * (the candidates are topology actions); the sources' state and the per-lane actions waiting for the next gpf_step_n are untouched.
+ * A scratch lane cannot be the SOURCE of a later call -- its chronics cursor is an absolute row (of the forecast tables when it simulated
+ * a forecast), not an offset to the time index (GPF_E_INVALID; gpf_set_lane_chronics puts every lane back on the chronics).
  * Asynchronous launch (the topology bookkeeping before it synchronises once). */
 #define GPF_ACT_SET_BUS 0
 #define GPF_ACT_SET_LINE_STATUS 1

@@ -1,8 +1,12 @@
 """GPU parity at the sizes and in the variants bench.py times (BASELINE.json configs[1..4]): the bench-size launches pick other
 kernel variants (instances per wavefront, staging tier, wavefronts per instance, Ybus in registers) than the small batches of
 the other test files, so every configuration of the bench line is solved here as bench.py sets it up and a sample of >= 64
-lanes is re-solved by the C oracle (oracle/pf_oracle.c): convergence status and Newton iteration count bit-exact, float32
-outputs within 2e-4 + 5e-6 |x| (the north star's bar is 1e-4 pu = 1e-2 MW), integer vectors bit-exact."""
+lanes is re-solved by the C oracle (oracle/pf_oracle.c): convergence status and Newton iteration count bit-exact, integer vectors
+bit-exact, float32 API outputs within 2e-4 + 5e-6 |x| (MW, MVAr, kV, A, deg).  The north star's bar -- max line-flow error < 1e-4 pu --
+is stated on each grid's OWN base: 1e-2 MW on the 100 MVA grids (case14), 1e-4 MW on l2rpn_neurips_2020_track1 / l2rpn_wcci_2022_dev /
+l2rpn_idf_2023 whose sn_mva is 1 -- there a float32 output cannot resolve it (1 ulp of a 500 MW flow is 3e-5 MW), so `check_lanes`
+also recomputes the line flows in float64 from the engine's pre-cast bus voltages (bus_vm / bus_va) and holds THEM to 1e-4 pu
+(`max_flow_err_pu_f64`, oracle/spot_check.py)."""
 import numpy as np
 import pytest
 

@@ -1,9 +1,12 @@
 """GPU parity tests: the HIP engine (through the C ABI) vs the CPU oracle, on the committed fixtures.
 
-Tolerances (stated per the north star: max line-flow error < 1e-4 pu on a 100 MVA base = 1e-2 MW):
-* float64 bus voltages (pre-cast):  |dVm| < 1e-9 pu, |dVa| < 1e-7 deg
-* float32 outputs: |x - oracle| <= 2e-6*|oracle| + abs_tol with abs_tol = 2e-4 (MW, MVAr, kV, deg), i.e. a few
-  float32 ulps of the largest flows -- two orders of magnitude inside the 1e-2 MW bar
+Tolerances.  The north star's bar is "max line-flow error < 1e-4 pu": on each grid's OWN base that is 1e-2 MW on the 100 MVA grids
+(5 / 14 substations) and 1e-4 MW on l2rpn_neurips_2020_track1 / l2rpn_wcci_2022_dev / l2rpn_idf_2023, whose sn_mva is 1.
+* float64 bus voltages (pre-cast):  |dVm| < 1e-9 pu, |dVa| < 1e-7 deg -- five orders inside the bar on EVERY grid; line flows recomputed in
+  float64 from these voltages are held to 1e-4 pu of the grid's base at the bench sizes (tests/test_gpu_bench_parity.py, oracle/spot_check.py)
+* float32 outputs (the API dtype, grid2op's dt_float): |x - oracle| <= 2e-6*|oracle| + abs_tol with abs_tol = 2e-4 (MW, MVAr, kV, deg), i.e. a few
+  float32 ulps of the largest flows: two orders of magnitude inside the bar on the 100 MVA grids; on the sn_mva = 1 grids a float32 cannot
+  resolve 1e-4 MW on a 500 MW flow (1 ulp = 3e-5 MW) -- the float64 check above is the one that carries the bar there
 * topo_vect / line_status / shunt_bus / convergence flags: bit-exact
 """
 import numpy as np

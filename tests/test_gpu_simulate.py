@@ -134,3 +134,34 @@ def test_simulate_batch_vs_oracle_restatement(name, B, load_model, load_npz):
     with pytest.raises(GridPFError):
         eng.simulate_batch(t_obs, np.arange(B), [{"set_bus": {0: 7}}], dst_lane0=B)       # bus id beyond n_busbar
     eng.close()
+
+
+def test_a_scratch_lane_cannot_be_the_source_of_another_simulation(load_model, load_npz):
+    """Round-4 advisor finding: the chronics cursor of a scratch lane of gpf_simulate_batch is an ABSOLUTE row -- of the forecast tables
+    when it simulated a forecast --, not an offset to the time index; using it as the source of another gpf_simulate_batch would read the
+    maintenance table (and the chronics) at the wrong row.  The call is refused; after gpf_set_lane_chronics every lane is a source again."""
+    from grid2op_amd.engine import GridPFError, PowerFlowEngine
+    name = "l2rpn_case14_sandbox"
+    m = load_model(name)
+    ch = dict(load_npz(f"{name}.chronics.npz"))
+    eng = PowerFlowEngine(m, n_lanes=16, device=0)
+    prod_v = np.tile((m.gen_vm0 * m.sub_vn_kv[m.gen_sub]).astype(np.float32), (ch["prod_p"].shape[0], 1))
+    tab = eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch.get("prod_v", prod_v))[:48]
+    eng.upload_chronics(tab)
+    eng.upload_forecasts(np.stack([tab * np.float32(1.01)], axis=1)[None])
+    off = np.zeros(16, np.int32)
+    off[:2] = (3, 9)
+    eng.set_lane_chronics(lane_offset=off)
+    cands = [{}, {"set_line_status": [(1, -1)]}]
+    eng.simulate_batch(2, [0, 1], cands, dst_lane0=2, time_step=1)          # lanes 2..5: forecast rows
+    eng.simulate_batch(2, [0, 1], cands, dst_lane0=6, time_step=0)          # lanes 6..9: the current chronics row, absolute
+    eng.sync()
+    assert eng.results(2, 8).converged.all()
+    for bad_src, ts in (([2], 1), ([0, 3], 0), ([6], 1)):
+        with pytest.raises(GridPFError, match="chained simulate"):
+            eng.simulate_batch(2, bad_src, cands, dst_lane0=12, time_step=ts)
+    eng.set_lane_chronics(lane_offset=off)                                   # every lane back on the chronics tables
+    eng.simulate_batch(2, [2], cands, dst_lane0=8, time_step=1)
+    eng.sync()
+    assert eng.results(8, 2).converged.all()
+    eng.close()

@@ -49,9 +49,11 @@ def patched(src, lo, hi):
 
 def main():
     argv = sys.argv[1:]
-    flags, env_name = "", "l2rpn_neurips_2020_track1"
+    flags, env_name, n1 = "", "l2rpn_neurips_2020_track1", 0
     while "--flags" in argv:
         i = argv.index("--flags"); flags = argv[i + 1]; del argv[i:i + 2]
+    while "--n1" in argv:                 # N-1 fan-out shape of bench.py: that many envs x (1 + n_line) lanes, no cascade (islanding / diverging contingencies)
+        i = argv.index("--n1"); n1 = int(argv[i + 1]); del argv[i:i + 2]
     while "--env" in argv:
         i = argv.index("--env"); env_name = argv[i + 1]; del argv[i:i + 2]
     os.environ["GRIDPF_JIT_FLAGS"] = flags
@@ -67,11 +69,24 @@ def main():
     src0 = open(os.path.join(CSRC, "gridpf_sparse.hpp")).read()
     n_loops = len(loops(src0))
     print(f"{n_loops} loops without a pragma of their own; flags={flags!r}", flush=True)
-    kw = dict(rebalance=1.02, cascade=True, auto_reset=True)
-    m, ch, e_ref, tab, off, scale = _setup(load_model_impl, load_npz_impl, env_name, 65)
-    if "thermal_limits" in ch:
-        e_ref.set_thermal_limits(np.asarray(ch["thermal_limits"]) * 0.9)
+    kw = dict(rebalance=1.02, cascade=True, auto_reset=True) if not n1 else dict(rebalance=1.02)
+    m0 = load_model_impl(env_name)
+    B = 65 if not n1 else n1 * (1 + m0.n_line)
+
+    def prepare(eng, m):
+        if n1:
+            fan = 1 + m.n_line
+            topo = np.tile(m.initial_topo_vect().astype(np.int32), (B, 1))
+            for c in range(1, fan):
+                topo[c::fan, m.line_or_pos_topo_vect[c - 1]] = -1
+                topo[c::fan, m.line_ex_pos_topo_vect[c - 1]] = -1
+            eng.set_topology(topo)
+        elif "thermal_limits" in ch:
+            eng.set_thermal_limits(np.asarray(ch["thermal_limits"]) * 0.9)
+    m, ch, e_ref, tab, off, scale = _setup(load_model_impl, load_npz_impl, env_name, B)
+    prepare(e_ref, m)
     ref = _run(e_ref, kw, 6, 3)
+    print(f"workload: {env_name}, {B} lanes, {'N-1 fan-out of ' + str(n1) + ' envs' if n1 else 'cascade on, limits x 0.9'}; converged {float(e_ref.results().converged.mean()):.3f}", flush=True)
     for spec in argv:
         lo, hi = (0, 0) if spec == "none" else (0, 10 ** 6) if spec == "all" else tuple(int(x) for x in spec.split("-"))
         d = tempfile.mkdtemp(prefix="gpf_bisect_")
@@ -82,9 +97,8 @@ def main():
             shutil.copy(os.path.join(CSRC, f), srcd)
         txt, _ = patched(src0, lo, hi)
         open(os.path.join(srcd, "gridpf_sparse.hpp"), "w").write(txt)
-        _, _, e_jit, _, _, _ = _setup(load_model_impl, load_npz_impl, env_name, 65)
-        if "thermal_limits" in ch:
-            e_jit.set_thermal_limits(np.asarray(ch["thermal_limits"]) * 0.9)
+        _, _, e_jit, _, _, _ = _setup(load_model_impl, load_npz_impl, env_name, B)
+        prepare(e_jit, m)
         check(e_jit._lib.gpf_jit_enable(e_jit._h, srcd.encode(), cache.encode()), "gpf_jit_enable")
         got = _run(e_jit, kw, 6, 3)
         info = e_jit.specialization()
