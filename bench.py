@@ -71,6 +71,7 @@ TRAFFIC_N1_118 = os.path.join("profiles", "r05_traffic_n1_wcci118.json")
 TRAFFIC_WCCI = os.path.join("profiles", "r05_traffic_wcci118.json")
 TRAFFIC_IDF = os.path.join("profiles", "r05_traffic_idf118.json")
 TRAFFIC_1PL = os.path.join("profiles", "r05_traffic_case14_1perlaunch.json")
+TRAFFIC_PTDF = os.path.join("profiles", "r05_traffic_ptdf.json")
 CASCADE_LIMIT_SCALE = 0.85     # `cascade_tripping` secondary: thermal limits x 0.85 -> ~20 % of the lane-steps overflow softly
 
 
@@ -472,6 +473,16 @@ def cfg_steps(ctx, k_sec):
 OBS_EVERY = ("every env step: each step of a launch writes its complete backend observation (results row, topo_vect, shunt buses, line "
              "status, rho, status) to its own rows in HBM (gpf_set_trajectory GPF_TRAJ_OBS)")
 OBS_LAST = "LAST step of each launch only (each step overwrites the lane's result row) -- NOT the reference's env.step contract"
+
+
+def ptdf_traffic(prefix):
+    """HBM bytes per launch of a PTDF-path kernel at a bench shape, from the committed PMC passes (profiles/r05_traffic_ptdf.json; entry whose
+    name starts with `prefix`); (bytes, source text) or (None, None)"""
+    tp = traffic_profile(TRAFFIC_PTDF)
+    for key, v in tp.items():
+        if isinstance(v, dict) and key.startswith(prefix):
+            return v.get("hbm_bytes_per_launch"), f"committed profile {TRAFFIC_PTDF}: {key} (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE; NOT measured in this run)"
+    return None, None
 
 
 def roofline_block(eng, wins, B, k, profile, note=None):
@@ -1090,7 +1101,7 @@ def workload_wcci(ctx, env, n_envs, k_sec, w_sec, cascade):
         eng.set_lane_redispatch(delta)
         note += " and a zero-sum +-1 MW redispatch on 2 random generators per lane"
     k_sec = cfg_steps(ctx, k_sec)
-    w, w_l, _ = measure_modes(ctx, eng, k_sec, w_sec, dict(rebalance=1.02, cascade=cascade), N_WIN_CFG, 20)
+    w, w_l, _ = measure_modes(ctx, eng, k_sec, w_sec, dict(rebalance=1.02, cascade=cascade), N_WIN_CFG, 200)
     med = median_window(w)[0]
     r = eng.results()
     out = None
@@ -1148,7 +1159,7 @@ def workload_wcci_dynamics(ctx, env, n_envs, k_sec, w_sec):
             done += k
         return t + n
     k_sec = cfg_steps(ctx, k_sec)
-    t = run(0, max(w_sec, spl))
+    t = run(0, max(w_sec, 10 * spl))          # (pre-roll: the clocks of an idle MI355X settle within ~10 ms of work)
     wins = []
     for _ in range(N_WIN_CFG):
         ctx.sync_all(eng)
@@ -1225,14 +1236,15 @@ def workload_ptdf_rows(ctx, eng, m, B, t0, n_rows=16, reps=20):
     nb_pad, line_pad = (nb_act + 3) // 4 * 4, (m.n_line + 15) // 16 * 16
     us = k_ms / max(n_l, 1) * 1e3
     M = B * n_rows
+    tr_b, tr_src = ptdf_traffic(f"ptdf_rows_kernel<2>, {n_rows} chronics rows x {B:,}".replace(",", " "))
     tf = 2.0 * M * nb_pad * line_pad / (us * 1e-6) / 1e12 if us > 0 else 0.0
     hbm = 4.0 * M * line_pad + 4.0 * M * (m.n_load + m.n_gen)            # flows out + chronics values in (the table itself is L2 resident)
     return {"workload": f"{n_rows} consecutive chronics rows of all {B} lanes per launch: flows = P_bus[{M}x{nb_pad}] . PTDF^T[{nb_pad}x{line_pad}], "
                         "injections gathered from the device-resident chronics table in the launch (gpf_ptdf_flows_rows)",
             "value": M * reps / el, "unit": "DC power flows/sec (one per lane and chronics row)", "us_per_launch": us, "rows_per_launch": n_rows,
             "roofline": {"bound": "mfma", "achieved": tf, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_PEAK_TFLOPS,
-                         "hbm_gbs": hbm / (us * 1e-6) / 1e9 if us > 0 else 0.0, "traffic": None,
-                         "flops_per_launch": 2.0 * M * nb_pad * line_pad},
+                         "hbm_gbs": hbm / (us * 1e-6) / 1e9 if us > 0 else 0.0, "traffic": tr_b, "traffic_source": tr_src,
+                         "flops_per_launch": 2.0 * M * nb_pad * line_pad, "avg_launch_us": us, "kernel": "ptdf_rows_kernel<2>"},
             "oracle_check": chk}
 
 
@@ -1343,9 +1355,11 @@ def workload_ptdf_build_batch(ctx, env, B, n_topo, reps=5):
            "call_ms": w_med, "call_value": float(ok_cls.sum()) / (w_med * 1e-3), "call_is": "host grouping of the lanes' topology rows + descriptor upload + kernel + status readback",
            "host_builds_per_sec": 1.0 / host_s, "host_is": "gpf_ptdf_build: the same matrices by Gauss-Jordan on ONE host core (round-3 path), per topology",
            "speedup_vs_host_path": (float(ok_cls.sum()) / (w_med * 1e-3)) * host_s,
-           "roofline": {"bound": "mfma", "achieved": tf, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_PEAK_TFLOPS, "traffic": None,
+           "roofline": {"bound": "mfma", "achieved": tf, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_PEAK_TFLOPS,
+                        "traffic": ptdf_traffic("ptdf_build_lds_kernel")[0], "traffic_source": ptdf_traffic("ptdf_build_lds_kernel")[1],
+                        "hbm_gbs": (ptdf_traffic("ptdf_build_lds_kernel")[0] or 0.0) / (k_med * 1e-3) / 1e9,
                         "flops_per_launch": flops, "flops_are": "2 n^3 per class, n = reduced dimension padded to 16 (the tiles the matrix cores run)",
-                        "avg_launch_us": k_med * 1e3, "kernel": "ptdf_build_kernel"},
+                        "avg_launch_us": k_med * 1e3, "kernel": "ptdf_build_lds_kernel (reduced dimension <= 128: matrix in LDS)"},
            "flows_per_lane_topology": {"value": B / (f_ms / max(f_n, 1) * 1e-3), "unit": "DC power flows/sec (each lane x its own PTDF)", "us_per_batch": f_ms / max(f_n, 1) * 1e3},
            "lodf_n1_value": B * m.n_line / lodf_s, "lodf_n1_unit": "DC contingency cases/sec, every lane screened against the LODF of ITS topology (result copied to the host)",
            "oracle_check": chk}
@@ -1436,7 +1450,7 @@ def workload_ptdf(ctx, env, B, reps, k_sec=64, w_sec=16):
     lay = eng.layout
     kw = dict(rebalance=1.02)
     k_sec = cfg_steps(ctx, k_sec)
-    w, w_l, t_next = measure_modes(ctx, eng, k_sec, w_sec, kw, N_WIN_CFG, 20)
+    w, w_l, t_next = measure_modes(ctx, eng, k_sec, w_sec, kw, N_WIN_CFG, 200)
     med = median_window(w)[0]
     r_ac = eng.results()
     ac = {"workload": f"{env} (118 substations) AC NR DoNothing env.step on chronics 2035-01-15_0 (row (t+7k) mod {T}, loads x (1+0.05 N(0,1)), "
@@ -1531,7 +1545,8 @@ def workload_ptdf(ctx, env, B, reps, k_sec=64, w_sec=16):
            "large_batch": big, "oracle_check": ptdf_check,
            "value": B * reps / el, "unit": "DC power flows/sec", "us_per_batch": us, "launches_per_batch": n_l / max(reps, 1),
            "roofline": {"bound": "mfma", "achieved": tf, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_PEAK_TFLOPS,
-                        "hbm_gbs": hbm_bytes / (us * 1e-6) / 1e9 if us > 0 else 0.0, "traffic": None,
+                        "hbm_gbs": hbm_bytes / (us * 1e-6) / 1e9 if us > 0 else 0.0, "traffic": ptdf_traffic(f"ptdf_flows_kernel, 1 row x {B:,}".replace(",", " "))[0],
+                        "traffic_source": ptdf_traffic(f"ptdf_flows_kernel, 1 row x {B:,}".replace(",", " "))[1], "avg_launch_us": us, "kernel": "ptdf_flows_kernel",
                         "note": f"{2.0 * B * nb_pad * line_pad / 1e6:.0f} MFLOP and {hbm_bytes / 1e6:.1f} MB per launch of ONE chronics row per lane: "
                                 f"launch / latency bound at this size (see chronics_rows_per_launch and large_batch)"},
            "per_lane_dc_solve_value": B / dc_s, "per_lane_dc_solve_unit": "DC power flows/sec (kernel S, B' refactorised per lane)",

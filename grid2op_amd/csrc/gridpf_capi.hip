@@ -820,6 +820,11 @@ int gpf_jit_enable(gpf_handle e, const char* src_dir, const char* cache_dir) {
   if (gpf_jit_configure(e->jit, src_dir, cache_dir, err) != 0) { e->jit.on = false; e->jit.message = err; return fail(GPF_E_UNSUPPORTED, err); }
   const gpf::DevParamsS hp = jit_block(e);
   const std::string header = gpf_jit_header(hp);
+  if (!e->jit.can_compile && !gpf_jit_has_aot(e->jit, header)) {       // nothing to load and nothing to compile with: say so now, not launch by launch
+    e->jit.on = false;
+    e->jit.message = "gpf_jit_enable: no ahead-of-time code objects for this grid (grid2op_amd/_aot) and no compiler at run time: " + e->jit.compile_why;
+    return fail(GPF_E_UNSUPPORTED, e->jit.message);
+  }
   if (header != e->jit.header) { gpf_jit_release(e->jit); e->jit.header = header; }
   e->jit_g = hp.g; e->jit_oo = hp.oo; e->jit_sym = hp.sym;
   e->jit.on = true;

@@ -28,6 +28,7 @@ struct GpfJit {
 };
 std::string gpf_jit_header(const gpf::DevParamsS& hp);
 int gpf_jit_configure(GpfJit& j, const char* src_dir, const char* cache_dir, std::string& err);
+bool gpf_jit_has_aot(const GpfJit& j, const std::string& header);
 void gpf_jit_release(GpfJit& j);
 hipFunction_t gpf_jit_get(GpfJit& j, int NB, int ST, int IPW, int WP, bool TC, bool YR, bool ENV, bool runpf, size_t lds_bytes);
 

@@ -173,15 +173,18 @@ def test_specialize_self_test_header_and_refusal(load_model, load_npz, jit_cache
     assert f"(v).n_sub = {m.n_sub};" in hdr and f"(v).n_line = {m.n_line};" in hdr and f"(v).dim_topo = {m.dim_topo};" in hdr
     eng.step(0, n_steps=4, rebalance=1.02)
     assert eng.specialization()["launches"] == 1
-    # no compiler: refused loudly, the engine keeps its shipped kernels and keeps working
-    _, _, e2, _, _, _ = _setup(load_model, load_npz, "l2rpn_case14_sandbox", 32)
+    # no compiler and no ahead-of-time objects for the grid (rte_case5_example is not in grid2op_amd/aot/manifest.json): refused loudly,
+    # the engine keeps its shipped kernels and keeps working
+    _, _, e2, _, _, _ = _setup(load_model, load_npz, "rte_case5_example", 32)
+    _, _, e3, _, _, _ = _setup(load_model, load_npz, "rte_case5_example", 32)
     monkeypatch.setenv("GRIDPF_HIPCC", "/nonexistent/hipcc")
-    with pytest.raises(GridPFError, match="does not run"):
+    with pytest.raises(GridPFError, match="no compiler at run time"):
         e2.specialize(True, cache_dir=jit_cache, verify=False)
     monkeypatch.delenv("GRIDPF_HIPCC")
-    e2.step(0, n_steps=4, rebalance=1.02)
+    for e in (e2, e3):
+        e.step(0, n_steps=4, rebalance=1.02)
     assert not e2.specialization()["enabled"] and e2.specialization()["launches"] == 0
-    assert np.array_equal(e2.results().out, eng.results().out, equal_nan=True)
+    assert np.array_equal(e2.results().out, e3.results().out, equal_nan=True) and e2.results().converged.all()
 
 
 def test_parity_suites_on_specialised_kernels(jit_cache):
