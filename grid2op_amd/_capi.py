@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "gpf_get_trajectory", "gpf_get_trajectory_obs", "gpf_upload_forecasts", "gpf_simulate_batch", "gpf_set_overflow_count",
     "gpf_set_storage_params", "gpf_set_env_dynamics", "gpf_set_lane_actions", "gpf_get_env_state", "gpf_get_env_illegal", "gpf_set_env_illegal", "gpf_set_env_state", "gpf_set_gen_renewable", "gpf_set_lane_curtailment", "gpf_get_episode", "gpf_lane_capacity", "gpf_get_step_outputs", "gpf_sync",
     "gpf_set_profiling", "gpf_get_kernel_time", "gpf_get_plan", "gpf_device_pointers", "gpf_device_pointers_n",
-    "gpf_get_counters", "gpf_ptdf_build", "gpf_ptdf_build_batch", "gpf_ptdf_batch_info", "gpf_ptdf_batch_get", "gpf_ptdf_get", "gpf_ptdf_flows", "gpf_get_ptdf_flows", "gpf_ptdf_flows_rows", "gpf_get_ptdf_flows_rows", "gpf_lodf_screen",
+    "gpf_get_counters", "gpf_upload_outage_durations", "gpf_get_cooldown", "gpf_set_cooldown", "gpf_get_trajectory_cooldown", "gpf_ptdf_build", "gpf_ptdf_build_batch", "gpf_ptdf_batch_info", "gpf_ptdf_batch_get", "gpf_ptdf_get", "gpf_ptdf_flows", "gpf_get_ptdf_flows", "gpf_ptdf_flows_rows", "gpf_get_ptdf_flows_rows", "gpf_lodf_screen",
     "gpf_jit_enable", "gpf_jit_disable", "gpf_jit_info", "gpf_jit_source",
 ]
 
@@ -78,7 +78,7 @@ class GpfLayout(C.Structure):
 class GpfStepOpts(C.Structure):
     _fields_ = [("max_iter", C.c_int32), ("tol_mva", C.c_double), ("rebalance", C.c_double), ("cascade", C.c_int32),
                 ("hard_overflow", C.c_float), ("soft_overflow", C.c_float), ("nb_ts_allowed", C.c_int32), ("max_rounds", C.c_int32),
-                ("is_dc", C.c_int32), ("auto_reset", C.c_int32), ("warm_start", C.c_int32)]
+                ("is_dc", C.c_int32), ("auto_reset", C.c_int32), ("warm_start", C.c_int32), ("nb_ts_reco", C.c_int32)]
 
 
 _lib: Optional[C.CDLL] = None
@@ -167,6 +167,10 @@ def lib() -> C.CDLL:
     L.gpf_ptdf_build.argtypes = [h, i32]
     L.gpf_ptdf_get.argtypes = [h, _dp]
     L.gpf_get_counters.argtypes = [h, C.POINTER(C.c_int64)]
+    L.gpf_get_cooldown.argtypes = [h, i32, i32, _ip]
+    L.gpf_upload_outage_durations.argtypes = [h, i32, i32, C.POINTER(C.c_uint16)]
+    L.gpf_set_cooldown.argtypes = [h, i32, i32, _ip]
+    L.gpf_get_trajectory_cooldown.argtypes = [h, i32, i32, i32, i32, C.POINTER(C.c_int16)]
     L.gpf_ptdf_build_batch.argtypes = [h, i32, i32, i32, _ip]
     L.gpf_ptdf_batch_info.argtypes = [h, _ip, _ip, _ip, _dp]
     L.gpf_ptdf_batch_get.argtypes = [h, i32, _dp, _dp]

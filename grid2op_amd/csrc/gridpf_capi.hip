@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -69,6 +70,7 @@ __global__ void simulate_prepare_kernel(GridDev g, Bufs b, const int* __restrict
   const int src = src_lanes[q / n_act], dst = dst0 + q, tid = threadIdx.x;
   for (int i = tid; i < g.n_inj; i += blockDim.x) b.inj[(size_t)dst * g.n_inj + i] = b.inj[(size_t)src * g.n_inj + i];
   for (int i = tid; i < g.n_line; i += blockDim.x) b.overflow_count[(size_t)dst * g.n_line + i] = b.overflow_count[(size_t)src * g.n_line + i];
+  for (int i = tid; i < g.n_line; i += blockDim.x) b.cooldown[(size_t)dst * g.n_line + i] = b.cooldown[(size_t)src * g.n_line + i];
   if (lane_scale) for (int i = tid; i < 2 * g.n_load; i += blockDim.x) lane_scale[(size_t)dst * 2 * g.n_load + i] = lane_scale[(size_t)src * 2 * g.n_load + i];
   if (lane_gen_delta) for (int i = tid; i < g.n_gen; i += blockDim.x) lane_gen_delta[(size_t)dst * g.n_gen + i] = lane_gen_delta[(size_t)src * g.n_gen + i];
   if (tid == 0) {
@@ -173,12 +175,16 @@ struct gpf_engine {
   // per-lane state (device)
   DevArr<double> inj, bus_vm, bus_va, work;
   DevArr<int> topo, shunt_bus, topo_out, shunt_bus_out, status, overflow_count, disc_round, lane_table, lane_offset, tmp_lines;
+  DevArr<int> cooldown;                 // [B][n_line] line cooldowns of the environment (gpf::Bufs::cooldown)
+  DevArr<unsigned short> maint_dur;     // [chron_tables][chron_T][n_line] remaining duration of the maintenance / hazard under way, or empty
+  DevArr<short> traj_cool;              // [traj_cap][cap_lanes][n_line]
   DevArr<float> out, chron, lane_scale, thermal_limit, rho;
   DevArr<unsigned char> line_status, done;
   DevArr<int> topo0, episode;           // topology last sent by the host (auto-reset target); {steps survived, resets} per lane
   DevArr<float> lane_gen_delta, traj_rho;
   DevArr<unsigned char> maint;          // [chron_tables][chron_T][n_line] scheduled maintenance OR hazards (forced outages), or empty
   std::vector<unsigned char> h_maint, h_hazard;   // host copies of the two tables (the device holds their union)
+  std::vector<unsigned short> h_outage_dur;       // gpf_upload_outage_durations: remaining durations given by the caller (else derived from the tables)
   std::vector<int> h_lane_table, h_lane_offset;   // host mirror of lane_table / lane_offset (gpf_simulate_batch: maintenance ahead of a source lane)
   std::vector<char> h_lane_forecast;              // 1: the lane is a scratch lane of gpf_simulate_batch (its offset is an absolute row, of the forecast tables for time_step > 0)
   // injection dynamics of the environment (gpf::EnvDyn)
@@ -230,7 +236,7 @@ struct gpf_engine {
   DevArr<float> ptdf_flow, lodf_worst, lodf_inv_cap;
   DevArr<float> ptdf_flow_rows;    // [rows][cap_lanes][line_pad] flows of the last gpf_ptdf_flows_rows
   int ptdf_rows_valid = 0;
-  DevArr<double> lodf;             // [n_line][line_pad] line outage distribution factors of the PTDF topology (NaN column: islanding outage)
+  DevArr<float> lodf;              // [n_line][line_pad] line outage distribution factors of the PTDF topology, float32 (NaN column: islanding outage)
   std::vector<double> h_ptdf;      // [n_line][nb_tot]
   std::vector<double> h_br_bdc, h_shunt_fact;
   std::vector<int> h_gen_cnt;
@@ -241,7 +247,8 @@ struct gpf_engine {
   bool ptdf_batch = false;                 // the flows / screening calls run on the class tables of the last gpf_ptdf_build_batch
   int ptdfb_lane0 = 0, ptdfb_n = 0, ptdfb_classes = 0, ptdfb_slots = 0, ptdfb_kpad = 0, ptdfb_npad_max = 0, ptdfb_desc_stride = 0;
   DevArr<int> ptdfb_desc, ptdfb_order, ptdfb_blk_class, ptdfb_status;
-  DevArr<double> ptdfb_work, ptdfb_t, ptdfb_lodf, ptdfb_inj_w;
+  DevArr<double> ptdfb_work, ptdfb_t, ptdfb_inj_w;
+  DevArr<float> ptdfb_lodf;
   std::vector<int> h_ptdfb_lane_class, h_ptdfb_status, h_ptdfb_desc;
   std::vector<std::vector<int>> h_ptdfb_bus;   // per class: compact bus index -> bus id (sub + (local - 1) * n_sub)
   double ptdfb_kernel_ms = 0.0;            // duration of the last build kernel (HIP events)
@@ -300,6 +307,7 @@ struct gpf_engine {
     b.thermal_limit = thermal_limit.p; b.rho = rho.p; b.overflow_count = overflow_count.p; b.disc_round = disc_round.p;
     b.lane_gen_delta = has_delta ? lane_gen_delta.p : nullptr;
     b.maint = maint.n ? maint.p : nullptr;
+    b.cooldown = cooldown.p; b.maint_dur = maint_dur.n ? maint_dur.p : nullptr; b.traj_cool = (traj_cap && traj_cool.n) ? traj_cool.p : nullptr;
     b.topo0 = topo0.p; b.done = done.p; b.episode = episode.p;
     b.traj_rho = traj_cap ? traj_rho.p : nullptr; b.traj_status = traj_cap ? traj_status.p : nullptr; b.traj_cap = traj_cap;
     const bool obs = traj_cap && (traj_what & GPF_TRAJ_OBS);
@@ -780,6 +788,7 @@ int reset_lanes_unchecked(gpf_engine* e, int lane0, int n) {
   if (g.n_shunt)
     HIP_TRY(hipMemcpyAsync(e->shunt_bus.p + (size_t)lane0 * g.n_shunt, sb.data(), sb.size() * sizeof(int), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipMemsetAsync(e->overflow_count.p + (size_t)lane0 * g.n_line, 0, (size_t)n * g.n_line * sizeof(int), e->stream));
+  HIP_TRY(hipMemsetAsync(e->cooldown.p + (size_t)lane0 * g.n_line, 0, (size_t)n * g.n_line * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->done.p + lane0, 0, (size_t)n, e->stream));
   HIP_TRY(hipMemsetAsync(e->episode.p + (size_t)lane0 * 2, 0, (size_t)n * 2 * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->status.p + (size_t)lane0 * 4, 0xFF, (size_t)n * 4 * sizeof(int), e->stream));
@@ -969,7 +978,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   AL(inj, B * g.n_inj); AL(topo, B * g.dim_topo); AL(shunt_bus, B * nsh);
   AL(out, B * g.n_out); AL(topo_out, B * g.dim_topo); AL(shunt_bus_out, B * nsh); AL(line_status, B * nl);
   AL(status, B * 4); AL(bus_vm, B * g.nb_tot); AL(bus_va, B * g.nb_tot);
-  AL(overflow_count, B * nl); AL(disc_round, B * nl); AL(rho, B * nl);
+  AL(overflow_count, B * nl); AL(disc_round, B * nl); AL(rho, B * nl); AL(cooldown, B * nl);
   AL(topo0, B * g.dim_topo); AL(done, B); AL(episode, B * 2);
   AL(lane_table, B); AL(lane_offset, B); AL(thermal_limit, nl); AL(tmp_lines, std::max<size_t>(B, 1));
 #undef UP
@@ -1155,6 +1164,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   }
   HIP_TRY(hipMemsetAsync(e->status.p, 0xFF, B * 4 * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->overflow_count.p, 0, B * nl * sizeof(int), e->stream));
+  HIP_TRY(hipMemsetAsync(e->cooldown.p, 0, B * nl * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->done.p, 0, B, e->stream));
   HIP_TRY(hipMemsetAsync(e->episode.p, 0, B * 2 * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->lane_table.p, 0, B * sizeof(int), e->stream));
@@ -1185,7 +1195,7 @@ int gpf_destroy(gpf_handle e) {
   e->line_ex_pos.release(); e->gen_sub.release(); e->gen_pos.release(); e->load_sub.release(); e->load_pos.release();
   e->sto_sub.release(); e->sto_pos.release(); e->shunt_sub.release(); e->gen_slack.release();
   e->inj.release(); e->bus_vm.release(); e->bus_va.release(); e->work.release(); e->topo.release(); e->shunt_bus.release();
-  e->topo_out.release(); e->shunt_bus_out.release(); e->status.release(); e->overflow_count.release(); e->disc_round.release();
+  e->topo_out.release(); e->shunt_bus_out.release(); e->status.release(); e->overflow_count.release(); e->disc_round.release(); e->cooldown.release(); e->maint_dur.release(); e->traj_cool.release();
   e->lane_table.release(); e->lane_offset.release(); e->tmp_lines.release(); e->out.release(); e->chron.release();
   e->lane_scale.release(); e->thermal_limit.release(); e->rho.release(); e->line_status.release();
   e->d_init_inj.release(); e->d_init_topo.release(); e->d_init_shunt_bus.release();
@@ -1338,7 +1348,7 @@ int gpf_copy_lanes(gpf_handle e, int32_t src, int32_t dst, int32_t n) {
                          (size_t)n * (stride) * sizeof(*e->arr.p), hipMemcpyDeviceToDevice, e->stream))
   CP(inj, g.n_inj); CP(topo, g.dim_topo); CP(shunt_bus, g.n_shunt); CP(out, g.n_out); CP(topo_out, g.dim_topo);
   CP(shunt_bus_out, g.n_shunt); CP(line_status, g.n_line); CP(status, 4); CP(bus_vm, g.nb_tot); CP(bus_va, g.nb_tot);
-  CP(overflow_count, g.n_line); CP(disc_round, g.n_line); CP(rho, g.n_line); CP(topo0, g.dim_topo); CP(done, 1); CP(episode, 2);
+  CP(overflow_count, g.n_line); CP(cooldown, g.n_line); CP(disc_round, g.n_line); CP(rho, g.n_line); CP(topo0, g.dim_topo); CP(done, 1); CP(episode, 2);
   if (e->env_on) {          // the environment's injection dynamics are part of the lane's state (Backend.copy / env.copy keep them)
     CP(env_target, g.n_gen); CP(env_actual, g.n_gen); CP(env_prev, g.n_gen); CP(env_already, g.n_gen); CP(env_limit, g.n_gen);
     CP(env_charge, g.n_sto); CP(env_amount_prev, 1); CP(env_curt_prev, 1); CP(env_fresh, 1); CP(env_illegal, 1);
@@ -1528,10 +1538,32 @@ int upload_outage_tables(gpf_engine* e) {
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   e->maint.release();
+  e->maint_dur.release();
   if (e->h_maint.empty() && e->h_hazard.empty()) return GPF_OK;
   std::vector<unsigned char> u = e->h_maint.empty() ? e->h_hazard : e->h_maint;
   if (!e->h_maint.empty() && !e->h_hazard.empty()) for (size_t i = 0; i < u.size(); ++i) u[i] = (u[i] || e->h_hazard[i]) ? 1 : 0;
   HIP_TRY(e->maint.upload(u.data(), u.size()));
+  // remaining duration of the maintenance / hazard under way at every row (GridValue.get_maintenance_duration_1d / get_hazard_duration_1d
+  // while the outage lasts: 3, 2, 1 over a 3-step outage): what BaseEnv._update_time_reconnection_hazards_maintenance raises the line
+  // cooldown to (baseEnv.py:2590-2597: the maximum of the two)
+  const size_t nl = e->g.n_line, T = (size_t)e->chron_T, nt = (size_t)e->chron_tables;
+  std::vector<unsigned short> dur(nt * T * nl, 0);
+  auto scan = [&](const std::vector<unsigned char>& tab) {
+    if (tab.empty()) return;
+    for (size_t k = 0; k < nt; ++k)
+      for (size_t l = 0; l < nl; ++l) {
+        unsigned run = 0;
+        for (size_t t = T; t-- > 0;) {
+          run = tab[(k * T + t) * nl + l] ? std::min(run + 1u, 65535u) : 0u;
+          unsigned short& d = dur[(k * T + t) * nl + l];
+          if (run > d) d = (unsigned short)run;
+        }
+      }
+  };
+  scan(e->h_maint); scan(e->h_hazard);
+  // (durations given by the caller win: tables that are a WINDOW of longer chronics cannot know how long an outage at their end lasts)
+  if (e->h_outage_dur.size() == dur.size()) for (size_t i = 0; i < dur.size(); ++i) if (u[i]) dur[i] = e->h_outage_dur[i];
+  HIP_TRY(e->maint_dur.upload(dur.data(), dur.size()));
   return GPF_OK;
 }
 int set_outage_table(gpf_engine* e, std::vector<unsigned char>& dst, int n_tables, int T, const uint8_t* data, const char* who) {
@@ -1547,6 +1579,15 @@ extern "C" {
 int gpf_upload_maintenance(gpf_handle e, int32_t n_tables, int32_t T, const uint8_t* data) {
   if (!e) return fail(GPF_E_INVALID, "gpf_upload_maintenance: null");
   return set_outage_table(e, e->h_maint, n_tables, T, data, "gpf_upload_maintenance");
+}
+
+int gpf_upload_outage_durations(gpf_handle e, int32_t n_tables, int32_t T, const uint16_t* data) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_upload_outage_durations: null");
+  if (!data) { e->h_outage_dur.clear(); return upload_outage_tables(e); }
+  if (n_tables != e->chron_tables || T != e->chron_T)
+    return fail(GPF_E_INVALID, "gpf_upload_outage_durations: shape must match the uploaded chronics tables (n_tables, T)");
+  e->h_outage_dur.assign(data, data + (size_t)n_tables * T * e->g.n_line);
+  return upload_outage_tables(e);
 }
 
 int gpf_upload_hazards(gpf_handle e, int32_t n_tables, int32_t T, const uint8_t* data) {
@@ -1613,6 +1654,7 @@ int step_range(gpf_engine* e, const gpf::Bufs& b_in, int lane0, int n, int t0, i
   sa.t = t0; sa.T = T; sa.rebalance_on = o->rebalance > 0.0 ? 1 : 0; sa.rebalance = o->rebalance; sa.cascade = o->cascade;
   sa.is_dc = o->is_dc ? 1 : 0; sa.n_steps = n_steps; sa.auto_reset = o->auto_reset ? 1 : 0; sa.warm_start = o->warm_start ? 1 : 0;
   sa.nb_ts_allowed = o->nb_ts_allowed; sa.max_rounds = o->max_rounds; sa.hard_overflow = o->hard_overflow; sa.soft_overflow = o->soft_overflow;
+  sa.nb_ts_reco = o->nb_ts_reco;
   sa.lane0 = lane0;
   const double tol_pu = o->tol_mva / e->g.sn_mva;
   hipEvent_t ea = nullptr, eb = nullptr;
@@ -1949,7 +1991,7 @@ int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double r
              float soft_overflow, int32_t nb_ts_allowed, int32_t max_rounds, int32_t is_dc) {
   gpf_step_opts o{};
   o.max_iter = max_iter; o.tol_mva = tol_mva; o.rebalance = rebalance; o.cascade = cascade; o.hard_overflow = hard_overflow;
-  o.soft_overflow = soft_overflow; o.nb_ts_allowed = nb_ts_allowed; o.max_rounds = max_rounds; o.is_dc = is_dc; o.auto_reset = 0; o.warm_start = 0;
+  o.soft_overflow = soft_overflow; o.nb_ts_allowed = nb_ts_allowed; o.max_rounds = max_rounds; o.is_dc = is_dc; o.auto_reset = 0; o.warm_start = 0; o.nb_ts_reco = -1;
   return gpf_step_n(e, t, 1, &o);
 }
 
@@ -2021,7 +2063,7 @@ int gpf_set_trajectory(gpf_handle e, int32_t n_steps_cap, int32_t what) {
   if (!e || n_steps_cap < 0 || (what & ~(GPF_TRAJ_RHO | GPF_TRAJ_OBS))) return fail(GPF_E_INVALID, "gpf_set_trajectory: bad arguments");
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  e->traj_rho.release(); e->traj_status.release();
+  e->traj_rho.release(); e->traj_status.release(); e->traj_cool.release();
   e->traj_out.release(); e->traj_topo.release(); e->traj_shb.release(); e->traj_lstat.release();
   e->traj_cap = 0; e->traj_what = 0; e->traj_valid = 0;
   if (n_steps_cap > 0 && what) {
@@ -2030,6 +2072,8 @@ int gpf_set_trajectory(gpf_handle e, int32_t n_steps_cap, int32_t what) {
     HIP_TRY(e->traj_rho.alloc(rows * g.n_line));
     HIP_TRY(e->traj_status.alloc(rows));
     HIP_TRY(hipMemset(e->traj_status.p, 0xFF, rows));
+    HIP_TRY(e->traj_cool.alloc(rows * g.n_line));                 // line cooldowns of every step (written when the step tracks them)
+    HIP_TRY(hipMemset(e->traj_cool.p, 0, rows * g.n_line * sizeof(short)));
     if (what & GPF_TRAJ_OBS) {
       HIP_TRY(e->traj_out.alloc(rows * g.n_out)); HIP_TRY(e->traj_topo.alloc(rows * g.dim_topo));
       HIP_TRY(e->traj_shb.alloc(rows * std::max(g.n_shunt, 1))); HIP_TRY(e->traj_lstat.alloc(rows * g.n_line));
@@ -2061,6 +2105,33 @@ int gpf_get_trajectory(gpf_handle e, int32_t step0, int32_t n_steps, int32_t lan
   int rc = traj_copy(e, rho, e->traj_rho.p, (size_t)e->g.n_line, step0, n_steps, lane0, n);
   if (rc == GPF_OK) rc = traj_copy(e, reinterpret_cast<signed char*>(status), e->traj_status.p, 1, step0, n_steps, lane0, n);
   if (rc != GPF_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_get_trajectory_cooldown(gpf_handle e, int32_t step0, int32_t n_steps, int32_t lane0, int32_t n, int16_t* line_cooldown) {
+  if (!check_range(e, lane0, n) || !line_cooldown || step0 < 0 || n_steps < 0 || step0 + n_steps > e->traj_valid || !e->traj_cool.p)
+    return fail(GPF_E_INVALID, "gpf_get_trajectory_cooldown: bad range (only the steps of the last gpf_step_n are retrievable)");
+  HIP_TRY(hipSetDevice(e->device));
+  int rc = traj_copy(e, line_cooldown, e->traj_cool.p, (size_t)e->g.n_line, step0, n_steps, lane0, n);
+  if (rc != GPF_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_get_cooldown(gpf_handle e, int32_t lane0, int32_t n, int32_t* line_cooldown) {
+  if (!check_range(e, lane0, n) || !line_cooldown) return fail(GPF_E_INVALID, "gpf_get_cooldown: bad arguments");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(line_cooldown, e->cooldown.p + (size_t)lane0 * e->g.n_line, (size_t)n * e->g.n_line * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+int gpf_set_cooldown(gpf_handle e, int32_t lane0, int32_t n, const int32_t* line_cooldown) {
+  if (!check_range(e, lane0, n) || !line_cooldown) return fail(GPF_E_INVALID, "gpf_set_cooldown: bad arguments");
+  for (size_t i = 0; i < (size_t)n * e->g.n_line; ++i) if (line_cooldown[i] < 0) return fail(GPF_E_INVALID, "gpf_set_cooldown: negative counter");
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipMemcpyAsync(e->cooldown.p + (size_t)lane0 * e->g.n_line, line_cooldown, (size_t)n * e->g.n_line * sizeof(int), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return GPF_OK;
 }
@@ -2118,6 +2189,20 @@ int gpf_get_step_outputs(gpf_handle e, int32_t lane0, int32_t n, float* rho, int
 int gpf_sync(gpf_handle e) {
   if (!e) return fail(GPF_E_INVALID, "gpf_sync: null");
   HIP_TRY(hipSetDevice(e->device));
+  // A blocking hipStreamSynchronize wakes up 10-15 us after the stream drained (interrupt + scheduler): a consumer that steps in short
+  // launches (one 20-step launch of 14 substations is 0.4 ms) pays that on every synchronisation.  Poll the stream for up to ~0.5 ms
+  // first (GRIDPF_SYNC_SPIN_US, 0: never), then block: long waits do not burn a host core.
+  static const long spin_us = getenv("GRIDPF_SYNC_SPIN_US") ? atol(getenv("GRIDPF_SYNC_SPIN_US")) : 500;
+  if (spin_us > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t q = hipStreamQuery(e->stream);
+      if (q == hipSuccess) return GPF_OK;
+      if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+    }
+    (void)hipGetLastError();
+  }
   HIP_TRY(hipStreamSynchronize(e->stream));
   return GPF_OK;
 }
@@ -2304,7 +2389,7 @@ int gpf_ptdf_build(gpf_handle e, int32_t lane) {
       }
     }
     e->lodf.release();
-    HIP_TRY(e->lodf.upload(lo_.data(), lo_.size()));
+    { std::vector<float> lof(lo_.begin(), lo_.end()); HIP_TRY(e->lodf.upload(lof.data(), lof.size())); }
     e->lodf_worst.release();
     HIP_TRY(e->lodf_worst.alloc((size_t)e->cap_lanes * line_pad));
   }
@@ -2485,7 +2570,7 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
   static const bool want_dbg = getenv("GRIDPF_PTDFB_DEBUG") != nullptr;     // developer: per-phase shader-clock stamps of class 0 on stderr
   if (want_dbg) { HIP_TRY(dbg.alloc((size_t)nc * 8)); HIP_TRY(hipMemset(dbg.p, 0, (size_t)nc * 8 * sizeof(long long))); D.dbg = dbg.p; }
   // reduced dimension <= 128 (118-substation grids): the matrix of a class lives in LDS (ptdf_build_lds_kernel), else in global memory
-  static const bool no_resident = getenv("GRIDPF_PTDFB_GLOBAL") != nullptr;   // developer: force the global-memory kernel
+  const bool no_resident = getenv("GRIDPF_PTDFB_GLOBAL") != nullptr;   // developer / tests: force the global-memory kernel (read at every call)
   const bool resident = npad_max <= 128 && line_pad <= gpf::PTDFB_LDS_THREADS && !no_resident && gpf::ptdfb_lds_bytes_resident(npad_max, line_pad, nl) <= LDS_HARD_LIMIT;
   const size_t lds = resident ? gpf::ptdfb_lds_bytes_resident(npad_max, line_pad, nl) : gpf::ptdfb_lds_bytes(npad_max, line_pad);
   static size_t lds_set[64][2] = {{0}};
@@ -2516,8 +2601,8 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
     while (c_ok < nc - 1 && e->h_ptdfb_status[c_ok] != 0) ++c_ok;
     const long long* s_ = h.data() + (size_t)c_ok * 8;
     fprintf(stderr, "[gridpf] ptdf_build_kernel class %d (n_pad %d), shader clocks: assemble %lld, gauss-jordan %lld (panel loads %lld, tile inversions %lld, trailing "
-                    "updates %lld), PTDF^T %lld, LODF %lld; kernel %.1f us\n", c_ok, desc[(size_t)c_ok * stride + 2], s_[1] - s_[0], s_[3] - s_[1], s_[7], s_[2], s_[6],
-            s_[4] - s_[3], s_[5] ? s_[5] - s_[4] : 0LL, ms * 1e3);
+                    "updates %lld), PTDF^T %lld, LODF %lld (row builds %lld); kernel %.1f us\n", c_ok, desc[(size_t)c_ok * stride + 2], s_[1] - s_[0], s_[3] - s_[1], s_[7], s_[2], s_[6],
+            s_[4] - s_[3], s_[5] ? s_[5] - s_[4] : 0LL, s_[7], ms * 1e3);
     dbg.release();
   }
   if (e->window) { ++e->win_launches; e->win_marked = false; }
@@ -2559,8 +2644,9 @@ int gpf_ptdf_batch_get(gpf_handle e, int32_t cls, double* ptdf, double* lodf) {
   }
   if (lodf) {
     if (!e->ptdfb_lodf.p) return fail(GPF_E_INVALID, "gpf_ptdf_batch_get: the batch was built without LODF tables");
-    HIP_TRY(hipMemcpy2D(lodf, (size_t)nl * sizeof(double), e->ptdfb_lodf.p + (size_t)cls * nl * lp, (size_t)lp * sizeof(double), (size_t)nl * sizeof(double),
-                        (size_t)nl, hipMemcpyDeviceToHost));
+    std::vector<float> lof((size_t)nl * lp);
+    HIP_TRY(hipMemcpy(lof.data(), e->ptdfb_lodf.p + (size_t)cls * nl * lp, lof.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int m = 0; m < nl; ++m) for (int k = 0; k < nl; ++k) lodf[(size_t)m * nl + k] = (double)lof[(size_t)m * lp + k];
   }
   return GPF_OK;
 }

@@ -74,6 +74,12 @@ struct Bufs {
   float* rho;                  // [B][n_line]
   int* overflow_count;         // [B][n_line]
   int* disc_round;             // [B][n_line]
+  // BaseEnv._times_before_line_status_actionable (obs.time_before_cooldown_line) of a DoNothing step (baseEnv.py:3352-3358, 2590-2597):
+  // decremented every step, set to NB_TIMESTEP_RECONNECTION when the protections trip the line, raised to the remaining duration of a
+  // maintenance / hazard under way.  Maintained by the step kernel when StepArgs::nb_ts_reco >= 0.
+  int* cooldown;               // [B][n_line]
+  const unsigned short* maint_dur;   // [n_tab][T][n_line] steps the maintenance / hazard under way at that row still lasts (0: none), or nullptr
+  short* traj_cool;            // [traj_cap][B][n_line] cooldown of every step of the last multi-step launch (with traj_rho), or nullptr
   const float* lane_gen_delta; // [B][n_gen] MW added to prod_p after the chronics (redispatch, baseEnv.py:2211-2470), or nullptr
   const unsigned char* maint;  // [n_tab][T][n_line] 1: the line is in maintenance at that chronics row (forced out of service), or nullptr
   const int* topo0;            // [B][dim_topo] topology last SENT by the host (what an auto-reset restores)
@@ -130,6 +136,7 @@ struct StepArgs {
   int n_steps;       // env steps per launch (t, t+1, ...): lane state and topology-derived tables stay in LDS in between
   int warm_start;    // opt-in: Newton starts from the previous step's voltages while the topology stands (see SolveCtl::warm)
   int auto_reset;    // a lane whose step failed restarts from the topology last sent by the host, counters cleared
+  int nb_ts_reco;    // Parameters.NB_TIMESTEP_RECONNECTION: cooldown a line gets when the protections trip it; < 0: the cooldown counters are not maintained
   double rebalance;
   float hard_overflow, soft_overflow;
 };

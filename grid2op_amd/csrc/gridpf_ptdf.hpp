@@ -267,13 +267,14 @@ __global__ __launch_bounds__(256) void ptdf_rows_kernel(PtdfDev P, PtdfRowsDev R
   }
 }
 
-// K_L: DC N-1 screening.  Post-outage flows are f_l + LODF[l][k] * f_k (rank-1 update of the pre-outage flows), so for
+// K_L: DC N-1 screening.  (The LODF table is float32 -- the screening result is float32 and the flows it multiplies are; the builder of
+// per-lane tables streams one table per topology class to HBM, half the bytes.)  Post-outage flows are f_l + LODF[l][k] * f_k (rank-1 update of the pre-outage flows), so for
 // every lane and every single-line outage k the worst loading max_l |f_l + LODF[l][k] f_k| * inv_cap[l] needs no solve.
 // A block of 4 wavefronts serves LODF_LPW lanes; a thread owns the outages k = tid, tid + 64, ... and each wavefront walks a
 // QUARTER of the monitored lines l (8 LODF loads in flight per thread; every element fetched from L2 is used for all the lanes of
 // the block); the four partial maxima are combined through LDS.
 constexpr int LODF_LPW = 4;
-__global__ __launch_bounds__(256) void lodf_screen_kernel(int n_line, int line_pad, const double* __restrict__ lodf /* [n_line][line_pad] */,
+__global__ __launch_bounds__(256) void lodf_screen_kernel(int n_line, int line_pad, const float* __restrict__ lodf /* [n_line][line_pad], float32 */,
                                                            const float* __restrict__ inv_cap /* [n_line] or nullptr */,
                                                            const float* __restrict__ flow, int lane0, int n_lanes,
                                                            float* __restrict__ worst /* [lanes][line_pad], indexed by lane */,
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256) void lodf_screen_kernel(int n_line, int line_p
     for (; l + 8 <= l_end; l += 8) {
       double d[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) d[u] = lodf[(size_t)(l + u) * line_pad + k];
+      for (int u = 0; u < 8; ++u) d[u] = (double)lodf[(size_t)(l + u) * line_pad + k];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         island |= (d[u] != d[u]);
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256) void lodf_screen_kernel(int n_line, int line_p
       }
     }
     for (; l < l_end; ++l) {
-      const double d = lodf[(size_t)l * line_pad + k];
+      const double d = (double)lodf[(size_t)l * line_pad + k];
       island |= (d != d);
       const double w = (double)ic[l];
 #pragma unroll

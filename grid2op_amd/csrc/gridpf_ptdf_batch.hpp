@@ -38,7 +38,7 @@ struct PtdfBuildDev {
   long long* dbg;                           // developer: [n_classes][8] shader-clock stamps of the phases (nullptr: off)
   double* work;                             // [n_classes][n_pad_max^2] B' -> its inverse (row-major, leading dimension = the class's n_pad)
   double* ptdf_t;                           // [n_classes][kpad][line_pad]
-  double* lodf;                             // [n_classes][n_line][line_pad] or nullptr
+  float* lodf;                              // [n_classes][n_line][line_pad] (float32: what the screening kernel reads) or nullptr
   int* status;                              // [n_classes] 0 ok, 1 singular pivot, 2 islanded, 3 no slack
 };
 
@@ -55,7 +55,7 @@ __host__ __device__ inline size_t ptdfb_lds_bytes(int n_pad_max, int line_pad) {
 // inverse of the 16 x 16 tile Pt (LDS, row stride 17), in place, by ONE wavefront: Gauss-Jordan without pivoting, lane l owns row
 // l % 16, columns 4 (l / 16) .. + 3.  The LDS executes the DS operations of one wavefront in issue order: the reads of step p + 1
 // see the writes of step p without a barrier; the compiler is held by the wave barriers.
-__device__ inline bool ptdfb_invert_tile(double* Pt, int l) {
+__device__ __forceinline__ bool ptdfb_invert_tile(double* Pt, int l) {
   const int i = l & 15, c0 = 4 * (l >> 4);
   double t[4];
 #pragma unroll
@@ -119,12 +119,12 @@ __global__ __launch_bounds__(PTDFB_THREADS) void ptdf_build_kernel(PtdfBuildDev 
   const int* lt = lf + D.n_line;
   double* M = D.work + (size_t)cls * D.work_stride;
   double* PT = D.ptdf_t + (size_t)cls * D.ptdf_stride;
-  double* LO = D.lodf ? D.lodf + (size_t)cls * D.lodf_stride : nullptr;
+  float* LO = D.lodf ? D.lodf + (size_t)cls * D.lodf_stride : nullptr;
   if (tid == 0) s_bad = 0;
   PTDFB_STAMP(0);
   if (host_st != 0) {                                   // islanded topology / no slack: no sensitivities (the flows kernels write NaN)
     for (int i = tid; i < D.kpad * D.line_pad; i += PTDFB_THREADS) PT[i] = 0.0;
-    if (LO) for (int i = tid; i < D.n_line * D.line_pad; i += PTDFB_THREADS) LO[i] = 0.0;
+    if (LO) for (int i = tid; i < D.n_line * D.line_pad; i += PTDFB_THREADS) LO[i] = 0.f;
     if (tid == 0) D.status[cls] = host_st;
     return;
   }
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(PTDFB_THREADS) void ptdf_build_kernel(PtdfBuildDev 
           const double h = (f < nr ? wrow[u * n_pad + f] : 0.0) - (t < nr ? wrow[u * n_pad + t] : 0.0);
           v = (hd != hd) ? hd : (m == k ? -1.0 : h * hd);
         }
-        LO[(size_t)m * D.line_pad + k] = v;
+        LO[(size_t)m * D.line_pad + k] = (float)v;
       }
     }
     asm volatile("" ::: "memory");
@@ -295,51 +295,72 @@ __global__ __launch_bounds__(PTDFB_THREADS) void ptdf_build_kernel(PtdfBuildDev 
 
 
 
-// K_PB, reduced dimension <= 128 (the 118-substation grids: 117 .. 128 non-reference buses): the WHOLE matrix lives in LDS (128 x 130
-// doubles = 133 KB of the CU's 160 KB), one workgroup per CU.  Same algorithm; what changes is where the operands come from (every
-// MFMA operand and every result tile is an LDS access instead of an L2 round trip) and the schedule of a step: the diagonal tile of step
-// k + 1 is final as soon as ITS trailing update of step k is done, so wavefront 0 updates that tile first and inverts it (a chain of 16
-// dependent pivots) while the other wavefronts run the rest of the trailing update, two tiles at a time (independent accumulators: the
-// operands of the second tile load while the first one's MFMAs run) -- the inversions leave the critical path.  The class tables
-// (line ends, susceptances, the row lists of B') are staged in LDS once; PTDF^T and LODF are written one COLUMN per thread (coalesced
-// stores, every operand from LDS).
-constexpr int PTDFB_LDS_THREADS = 512;       // the LDS-resident kernel: 8 wavefronts (2 per SIMD: one's LDS / MFMA latency hides behind the other's)
-constexpr int PTDFB_LROWS = 8;               // PTDF rows per round of the LODF phase
+// K_PB, reduced dimension <= 128 (the 118-substation grids: 117 .. 128 non-reference buses): REGISTER-RESIDENT blocked Gauss-Jordan.
+// Wavefront w owns block row w: its (up to) 8 tiles stay in its registers (32 accumulator doubles per lane) for the whole elimination, so
+// a trailing update is 4 operand reads + 4 MFMAs per tile -- no result tile goes through LDS.  What makes that possible:
+//   * the MFMA result layout D[i = 4 v + l / 16][j = l % 16] IS the B-operand layout B[k = 4 s + l / 16][j = l % 16]: a tile in registers
+//     is a B operand as it stands;
+//   * the matrix is symmetric and the partially inverted matrix of an in-place Gauss-Jordan keeps A_ik = +-(A_ki)^T (minus for an already
+//     eliminated block row i < k): the A operand of L_i = A_ik, element (l % 16, 4 s + l / 16), is element (4 s + l / 16, l % 16) of tile
+//     A_ki of block row k -- the natural layout of the row the pivot wavefront publishes.  No transposition anywhere.
+// Step k: wavefront k publishes its row (old values) to LDS; every wavefront j forms R_j = P A_kj (tile k: P) from it and publishes the new
+// row; wavefront k reloads its row, the others update their 8 tiles; then wavefront k + 1 inverts its tile (k + 1, k + 1) -- a chain of 8
+// dependent 2 x 2 pivot blocks -- ALONE: the FP64 vector unit its pivots run on is the one the other wavefronts' FP64 MFMAs occupy (64 cycles
+// each), so an inversion that overlaps with a trailing update (a ninth "inverter" wavefront, or lookahead inside the update: both built
+// and measured) takes 7.3 k cycles per tile instead of the ~3 k it takes with the SIMDs to itself.
+// The matrix goes through LDS twice: assembled there (one thread per row, sorted line lists: deterministic), and stored back as the inverse
+// for the table phases, which write PTDF^T and LODF one COLUMN per thread (coalesced stores, every operand from LDS).
 constexpr int PTDFB_PT = 18;                 // row stride (doubles) of a diagonal-tile buffer: 16-byte aligned quads, conflict-free columns
+constexpr int PTDFB_NT = 8;                  // block rows = worker wavefronts (reduced dimension <= 128)
+constexpr int PTDFB_LDS_THREADS = 64 * PTDFB_NT;         // one wavefront per block row
+constexpr int PTDFB_LROWS = 8;               // PTDF rows per round of the LODF phase
 __host__ __device__ inline int ptdfb_ldm(int n_pad) { return n_pad + 2; }
 __host__ __device__ inline size_t ptdfb_lds_bytes_resident(int n_pad_max, int line_pad, int n_line) {
-  // matrix [n_pad][n_pad + 2] | column panel copy [n_pad][17] (later: 1 / (1 - H[k][k])) | two diagonal tiles [16][18] | br_bdc [line_pad]
-  // | lf, lt, lflag [line_pad] ints | row pointers [n_pad + 1] + row entries [2 n_line] ints
-  const size_t panel = (size_t)n_pad_max * ptdfb_lcol_stride();
-  const size_t tabs = (size_t)line_pad + (size_t)PTDFB_LROWS * n_pad_max;     // 1 / (1 - H[k][k]) + the PTDF rows of a LODF round
-  const size_t dbl = (size_t)n_pad_max * ptdfb_ldm(n_pad_max) + (panel > tabs ? panel : tabs) + 2 * PTDFB_TILE * PTDFB_PT + line_pad;
+  // matrix [n_pad][n_pad + 2] (during the elimination: the two row panels) | 1 / (1 - H[k][k]) [line_pad] + LODF round rows
+  // [PTDFB_LROWS][n_pad] | two diagonal tiles [16][18] | br_bdc [line_pad] | lf, lt, lflag [line_pad] ints | row pointers + entries of B'
+  const size_t dbl = (size_t)n_pad_max * ptdfb_ldm(n_pad_max) + (size_t)line_pad + (size_t)PTDFB_LROWS * n_pad_max + 2 * PTDFB_TILE * PTDFB_PT + line_pad;
   const size_t ints = 3 * (size_t)line_pad + (size_t)n_pad_max + 1 + 2 * (size_t)n_line;
   return dbl * sizeof(double) + ((ints + 3) & ~(size_t)3) * sizeof(int);
 }
 
-// inverse of the 16 x 16 tile Pt (LDS, row stride PTDFB_PT), in place, by ONE wavefront -- as ptdfb_invert_tile, with v_rcp_f64 + two
-// Newton steps instead of the IEEE division (pivots are checked against 1e-12 separately) and 16-byte LDS accesses
-__device__ inline bool ptdfb_invert_tile_fast(double* Pt, int l) {
-  const int i = l & 15, c0 = 4 * (l >> 4);
+// inverse of the 16 x 16 tile Pt (LDS, row stride PTDFB_PT), in place, by ONE wavefront: Gauss-Jordan with 2 x 2 PIVOT BLOCKS.  The chain of
+// dependent pivots is what bounds the whole elimination (the tile of step k + 1 cannot be inverted before step k updated it): a scalar pivot
+// step costs an LDS round trip (the tile is exchanged through LDS, ~130 cycles under load) + a reciprocal chain + the update ~ 450 cycles; a
+// 2 x 2 block step does two pivots per round trip with ONE reciprocal (of the block's determinant): 8 steps instead of 16.
+// Lane l owns row l % 16, columns 4 (l / 16) .. + 3; every 16-byte LDS access below is aligned (row stride 18, even pivot index).
+// Pivot test as the scalar routine's (each of the two scalar pivots > 1e-12 in magnitude): |a| and |det / a|.
+__device__ __forceinline__ bool ptdfb_invert_tile_fast(double* Pt, int l) {   // (forceinline: Pt must be KNOWN to be LDS at the call site -- as a real function it compiled to flat loads / stores, 4 x slower)
+  const int i = l & 15, g = l >> 4, c0 = 4 * g;
   double t[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) t[q] = Pt[i * PTDFB_PT + c0 + q];
   bool ok = true;
 #pragma unroll
-  for (int p = 0; p < PTDFB_TILE; ++p) {
-    const double piv = Pt[p * PTDFB_PT + p];
-    const double colp = Pt[i * PTDFB_PT + p];
-    double rowp[4];
+  for (int p = 0; p < PTDFB_TILE; p += 2) {
+    const double a = Pt[p * PTDFB_PT + p], b = Pt[p * PTDFB_PT + p + 1], c = Pt[(p + 1) * PTDFB_PT + p], d = Pt[(p + 1) * PTDFB_PT + p + 1];
+    double C0 = Pt[i * PTDFB_PT + p], C1 = Pt[i * PTDFB_PT + p + 1];
+    double R0[4], R1[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) rowp[q] = Pt[p * PTDFB_PT + c0 + q];
-    ok = ok && (fabs(piv) > 1e-12);
-    const double rp = fast_rcp(piv);
-    const double f = colp * rp;
+    for (int q = 0; q < 4; ++q) { R0[q] = Pt[p * PTDFB_PT + c0 + q]; R1[q] = Pt[(p + 1) * PTDFB_PT + c0 + q]; }
+    const double det = fma(a, d, -b * c);
+    ok = ok && (fabs(a) > 1e-12) && (fabs(det) > 1e-12 * fabs(a));
+    const double rdet = fast_rcp(det);
+    const double ia = d * rdet, ib = -b * rdet, ic = -c * rdet, id = a * rdet;      // inverse of the pivot block
+    // ONE formula for every element, v = keep t - (C0' U0 + C1' U1), instead of a select tree per element (the VALU work of the selects,
+    // not the LDS round trip, was what a pivot step cost):
+    //   rows:    general (C0, C1, keep t)      pivot row p (-1, 0, drop t)       pivot row p + 1 (0, -1, drop t)
+    //   columns: general U = the new pivot rows (Binv R)[., j]      column p: U = (ia, ic), drop t      column p + 1: U = (ib, id), drop t
+    const bool rp0 = i == p, rp1 = i == p + 1, pg = g == p / 4;                      // (pg: this lane's column group holds the pivot columns)
+    C0 = rp0 ? -1.0 : rp1 ? 0.0 : C0;
+    C1 = rp0 ? 0.0 : rp1 ? -1.0 : C1;
+    const bool keep_row = !(rp0 || rp1);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int j = c0 + q;
-      if (i == p) t[q] = (j == p) ? rp : rowp[q] * rp;
-      else t[q] = (j == p) ? -f : fma(-f, rowp[q], t[q]);
+      double U0 = fma(ia, R0[q], ib * R1[q]), U1 = fma(ic, R0[q], id * R1[q]);
+      bool keep = keep_row;
+      if (q == p % 4) { U0 = pg ? ia : U0; U1 = pg ? ic : U1; keep = keep && !pg; }          // (q == p % 4 is a compile-time fact)
+      if (q == p % 4 + 1) { U0 = pg ? ib : U0; U1 = pg ? id : U1; keep = keep && !pg; }
+      t[q] = (keep ? t[q] : 0.0) - fma(C0, U0, C1 * U1);
     }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
@@ -351,28 +372,33 @@ __device__ inline bool ptdfb_invert_tile_fast(double* Pt, int l) {
   return __all(ok);
 }
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the global stores in flight (s_waitcnt vmcnt(0)) -- in the table
+// phases that is a full HBM write round trip per round
+#define PTDFB_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 __global__ __launch_bounds__(PTDFB_LDS_THREADS) void ptdf_build_lds_kernel(PtdfBuildDev D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int s_bad, s_next;
+  __shared__ int s_bad;
   const int cls = blockIdx.x, tid = threadIdx.x, l = tid & 63, w = tid >> 6;
   const int* desc = D.desc + (size_t)cls * D.desc_stride;
   const int nr = desc[0], n_pad = desc[2], host_st = desc[3];
   double* PT = D.ptdf_t + (size_t)cls * D.ptdf_stride;
-  double* LO = D.lodf ? D.lodf + (size_t)cls * D.lodf_stride : nullptr;
-  if (tid == 0) { s_bad = 0; s_next = 0; }
+  float* LO = D.lodf ? D.lodf + (size_t)cls * D.lodf_stride : nullptr;
+  if (tid == 0) s_bad = 0;
   PTDFB_STAMP(0);
   if (host_st != 0) {
     for (int i = tid; i < D.kpad * D.line_pad; i += PTDFB_LDS_THREADS) PT[i] = 0.0;
-    if (LO) for (int i = tid; i < D.n_line * D.line_pad; i += PTDFB_LDS_THREADS) LO[i] = 0.0;
+    if (LO) for (int i = tid; i < D.n_line * D.line_pad; i += PTDFB_LDS_THREADS) LO[i] = 0.f;
     if (tid == 0) D.status[cls] = host_st;
     return;
   }
   const int ldm = ptdfb_ldm(n_pad);
-  const size_t panel = (size_t)n_pad * ptdfb_lcol_stride();
-  double* M = reinterpret_cast<double*>(smem);                        // [n_pad][ldm]
-  double* Lc = M + (size_t)n_pad * ldm;                               // column panel copy [n_pad][17]; later hden [line_pad]
-  const size_t tabs_ = (size_t)D.line_pad + (size_t)PTDFB_LROWS * n_pad;
-  double* Pa = Lc + (panel > tabs_ ? panel : tabs_);                  // inverse of the current diagonal tile [16][18]
+  double* M = reinterpret_cast<double*>(smem);                        // [n_pad][ldm]: B', later its inverse
+  double* Rold = M;                                                   // during the elimination: block row k as it was [16][ldm]
+  double* Rnew = M + (size_t)PTDFB_TILE * ldm;                        // ... and after the row-panel update (tile k = P)
+  double* hden = M + (size_t)n_pad * ldm;                             // [line_pad] 1 / (1 - H[k][k]); 0: column of zeros; NaN: islanding outage
+  double* rows = hden + D.line_pad;                                   // [PTDFB_LROWS][n_pad] PTDF rows of a LODF round
+  double* Pa = rows + (size_t)PTDFB_LROWS * n_pad;                    // inverse of the current diagonal tile [16][18]
   double* Pb = Pa + PTDFB_TILE * PTDFB_PT;                            // ... of the next one (lookahead)
   double* s_bdc = Pb + PTDFB_TILE * PTDFB_PT;                         // [line_pad]
   int* s_lf = reinterpret_cast<int*>(s_bdc + D.line_pad);             // [line_pad] compact bus of the line's origin (-1: line not in the DC graph)
@@ -412,113 +438,123 @@ __global__ __launch_bounds__(PTDFB_LDS_THREADS) void ptdf_build_lds_kernel(PtdfB
   }
   __syncthreads();
   PTDFB_STAMP(1);
-  // ---- 2. blocked Gauss-Jordan with lookahead --------------------------------------------------------------------------------------------
+  // ---- 2. register-resident blocked Gauss-Jordan -------------------------------------------------------------------------------------------
   const int N = n_pad / PTDFB_TILE;
-  long long acc_inv = 0, acc_tr = 0, c0_ = 0;
-  if (w == 0) {                                                       // inverse of the first diagonal tile
+  const bool worker = w < N;                                          // owns block row w
+  const int g = l >> 4, cc = l & 15;
+  v4d c[PTDFB_NT];                                                    // tile (w, j) in the MFMA result layout: c[j][v] = A[16 w + 4 v + g][16 j + cc]
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { const int e = l + 64 * q; Pa[(e >> 4) * PTDFB_PT + (e & 15)] = M[(size_t)(e >> 4) * ldm + (e & 15)]; }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    if (!ptdfb_invert_tile_fast(Pa, l) && l == 0) s_bad = 1;
+  for (int j = 0; j < PTDFB_NT; ++j)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) c[j][v] = (worker && j < N) ? M[(size_t)(w * 16 + 4 * v + g) * ldm + j * 16 + cc] : 0.0;
+  long long acc_inv = 0, acc_tr = 0, c0_ = 0;
+  __syncthreads();                                                    // the matrix left LDS: its region now carries the row panels
+  if (w == 0) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) Pa[(4 * v + g) * PTDFB_PT + cc] = c[0][v];
   }
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+  if (w == 0 && !ptdfb_invert_tile_fast(Pa, l) && l == 0) s_bad = 1;
   for (int k = 0; k < N; ++k) {
     double* Pt = (k & 1) ? Pb : Pa;
     double* Pn = (k & 1) ? Pa : Pb;
-    for (int i = tid; i < n_pad * PTDFB_TILE; i += PTDFB_LDS_THREADS) { const int r = i >> 4, c = i & 15; Lc[r * 17 + c] = M[(size_t)r * ldm + k * 16 + c]; }
-    if (tid == 0) s_next = 0;
-    __syncthreads();
-    // row panel: A_kj <- P A_kj (tile k itself becomes P)
-    for (int j = w; j < N; j += PTDFB_LDS_THREADS / 64) {
-      v4d c = {0.0, 0.0, 0.0, 0.0};
-      if (j != k) {
+    if (D.dbg) c0_ = (long long)__builtin_readcyclecounter();
+    if (w == k) {                                                     // publish block row k as it is
+#pragma unroll
+      for (int j = 0; j < PTDFB_NT; ++j)
+        if (j < N) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) Rold[(size_t)(4 * v + g) * ldm + j * 16 + cc] = c[j][v];
+        }
+    }
+    __syncthreads();                                                  // (also: the inverse of tile k is complete)
+    if (worker) {                                                     // row panel, one tile per wavefront: R_w = P A_kw (tile k: P itself)
+      v4d r = {0.0, 0.0, 0.0, 0.0};
+      if (w != k) {
         double a[4], b[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) { a[s] = Pt[(l & 15) * PTDFB_PT + 4 * s + (l >> 4)]; b[s] = M[(size_t)(k * 16 + 4 * s + (l >> 4)) * ldm + j * 16 + (l & 15)]; }
+        for (int s_ = 0; s_ < 4; ++s_) { a[s_] = Pt[cc * PTDFB_PT + 4 * s_ + g]; b[s_] = Rold[(size_t)(4 * s_ + g) * ldm + w * 16 + cc]; }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], c, 0, 0, 0);
+        for (int s_ = 0; s_ < 4; ++s_) r = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s_], b[s_], r, 0, 0, 0);
       } else {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) c[v] = Pt[(4 * v + (l >> 4)) * PTDFB_PT + (l & 15)];
+        for (int v = 0; v < 4; ++v) r[v] = Pt[(4 * v + g) * PTDFB_PT + cc];
       }
 #pragma unroll
-      for (int v = 0; v < 4; ++v) M[(size_t)(k * 16 + 4 * v + (l >> 4)) * ldm + j * 16 + (l & 15)] = c[v];
+      for (int v = 0; v < 4; ++v) Rnew[(size_t)(4 * v + g) * ldm + w * 16 + cc] = r[v];
     }
     __syncthreads();
-    if (D.dbg) c0_ = (long long)__builtin_readcyclecounter();
-    // trailing update + column panel: tile (i, j), i != k:  C <- (j == k ? 0 : C) - L_i R_j   (row k of the matrix holds R, R_k = P).
-    // Work unit = FOUR tiles of one block row (columns 4 h .. 4 h + 3): one A operand, four independent accumulator chains -- the LDS
-    // and MFMA latencies of one tile hide behind the other three; units are taken one by one from a counter in LDS.
-    const int H = (N + 3) / 4, n_u = (N - 1) * H;
-    const int u_la = k + 1 < N ? k * H + (k + 1) / 4 : -1;             // the unit of the lookahead tile (k + 1, k + 1): wavefront 0's first
-    auto unit = [&](int u, v4d (&c)[4]) {
-      int i = u / H;
-      const int j0 = 4 * (u - i * H);
-      if (i >= k) ++i;
-      double a[4], b[4][4];
+    // trailing update: block row i = w != k:  C_ij <- (j == k ? 0 : C_ij) - L_i R_j with L_i = A_ik = sigma (A_ki)^T read from the OLD row k
+    double a[4];
+    if (worker && w != k) {
+      const double sg = w < k ? 1.0 : -1.0;                           // a = -L_i = -sigma A_ki^T, sigma = -1 for an eliminated block row
 #pragma unroll
-      for (int s_ = 0; s_ < 4; ++s_) a[s_] = -Lc[(i * 16 + (l & 15)) * 17 + 4 * s_ + (l >> 4)];
+      for (int s_ = 0; s_ < 4; ++s_) a[s_] = sg * Rold[(size_t)(4 * s_ + g) * ldm + w * 16 + cc];
+    }
+    auto upd = [&](int j) {                                           // (j is a compile-time constant at every call site: c[] stays in registers)
+      double b[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int j = j0 + t < N ? j0 + t : N - 1;                     // (a ragged last group recomputes its last tile: same values)
+      for (int s_ = 0; s_ < 4; ++s_) b[s_] = Rnew[(size_t)(4 * s_ + g) * ldm + j * 16 + cc];
+      v4d t = c[j];
+      if (j == k) t = v4d{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s_ = 0; s_ < 4; ++s_) b[t][s_] = M[(size_t)(k * 16 + 4 * s_ + (l >> 4)) * ldm + j * 16 + (l & 15)];
-        const double* Ct = M + (size_t)(i * 16 + (l >> 4)) * ldm + j * 16 + (l & 15);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) c[t][v] = (j != k) ? Ct[(size_t)4 * v * ldm] : 0.0;
-      }
-#pragma unroll
-      for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) c[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s_], b[t][s_], c[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int j = j0 + t < N ? j0 + t : N - 1;
-        double* Ct = M + (size_t)(i * 16 + (l >> 4)) * ldm + j * 16 + (l & 15);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) Ct[(size_t)4 * v * ldm] = c[t][v];
-      }
+      for (int s_ = 0; s_ < 4; ++s_) t = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s_], b[s_], t, 0, 0, 0);
+      c[j] = t;
     };
-    if (w == 0 && u_la >= 0) {
-      v4d c[4];
-      unit(u_la, c);
+    const int jla = k + 1 < N ? k + 1 : -1;                           // block row whose diagonal tile is the next pivot
+    if (worker && w == k) {                                           // the pivot wavefront takes its new row back
+#pragma unroll
+      for (int j = 0; j < PTDFB_NT; ++j)
+        if (j < N) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) c[j][v] = Rnew[(size_t)(4 * v + g) * ldm + j * 16 + cc];
+        }
+    }
+    if (worker && w != k) {
+#pragma unroll
+      for (int j = 0; j < PTDFB_NT; ++j)
+        if (j < N) upd(j);
+    }
+    __syncthreads();                                                  // every MFMA of the step has retired: the FP64 unit is free
+    if (worker && w == jla) {                                         // the next diagonal tile, inverted by its owner while the others wait
       long long t0_ = D.dbg ? (long long)__builtin_readcyclecounter() : 0;
-      const int tl = (k + 1) & 3;
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (t == tl) {
+      for (int j = 0; j < PTDFB_NT; ++j)
+        if (j == jla) {
 #pragma unroll
-          for (int v = 0; v < 4; ++v) Pn[(4 * v + (l >> 4)) * PTDFB_PT + (l & 15)] = c[t][v];   // (the updated tile is in this wavefront's registers)
+          for (int v = 0; v < 4; ++v) Pn[(4 * v + g) * PTDFB_PT + cc] = c[j][v];
         }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       if (!ptdfb_invert_tile_fast(Pn, l) && l == 0) s_bad = 1;
       if (D.dbg) acc_inv += (long long)__builtin_readcyclecounter() - t0_;
     }
-    for (;;) {
-      int u = 0;
-      if (l == 0) u = atomicAdd(&s_next, 1);
-      u = __builtin_amdgcn_readfirstlane(u);
-      if (u >= n_u) break;
-      if (u == u_la) continue;
-      v4d c[4];
-      unit(u, c);
-    }
     __syncthreads();
     if (D.dbg) acc_tr += (long long)__builtin_readcyclecounter() - c0_;
   }
-  if (D.dbg && tid == 0) { D.dbg[(size_t)cls * 8 + 2] = acc_inv; D.dbg[(size_t)cls * 8 + 6] = acc_tr; D.dbg[(size_t)cls * 8 + 7] = 0; }
+  if (D.dbg && tid == 0) { D.dbg[(size_t)cls * 8 + 6] = acc_tr; D.dbg[(size_t)cls * 8 + 7] = 0; }
+  if (D.dbg && l == 0 && acc_inv) atomicAdd(reinterpret_cast<unsigned long long*>(&D.dbg[(size_t)cls * 8 + 2]), (unsigned long long)acc_inv);
+  // the inverse back to LDS for the table phases
+  if (worker) {
+#pragma unroll
+    for (int j = 0; j < PTDFB_NT; ++j)
+      if (j < N) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) M[(size_t)(w * 16 + 4 * v + g) * ldm + j * 16 + cc] = c[j][v];
+      }
+  }
+  __syncthreads();
   const bool bad = s_bad != 0;
   PTDFB_STAMP(3);
   // ---- 3. PTDF^T[b][k] = bdc_k (X[b][from_k] - X[b][to_k]): thread k owns column k (coalesced stores, operands from LDS) ----------------
-  auto X = [&](int r, int c) -> double { return (r < nr && c < nr) ? M[(size_t)r * ldm + c] : 0.0; };
-  double* hden = Lc;                                                   // [line_pad] 1 / (1 - H[k][k]); 0: column of zeros; NaN: islanding outage
+  auto X = [&](int r, int c_) -> double { return (r < nr && c_ < nr) ? M[(size_t)r * ldm + c_] : 0.0; };
   for (int k = tid; k < D.line_pad; k += PTDFB_LDS_THREADS) {
     const int f = s_lf[k], t = s_lt[k];
     const bool on = f >= 0 && !bad;
     const double bk = s_bdc[k];
     const int fc = (on && f < nr) ? f : -1, tc = (on && t < nr) ? t : -1;
-#pragma unroll 4
+#pragma unroll 8
     for (int b = 0; b < D.kpad; ++b) {
       double v = 0.0;
       if (b < nr) v = bk * ((fc >= 0 ? M[(size_t)b * ldm + fc] : 0.0) - (tc >= 0 ? M[(size_t)b * ldm + tc] : 0.0));
@@ -529,7 +565,7 @@ __global__ __launch_bounds__(PTDFB_LDS_THREADS) void ptdf_build_lds_kernel(PtdfB
       const double den = 1.0 - (bk * (X(f, f) - X(f, t)) - bk * (X(t, f) - X(t, t)));      // 1 - (PTDF[k][f] - PTDF[k][t]) as stored in PT
       d = fabs(den) < 1e-8 ? (s_fl[k] ? 0.0 : __builtin_nan("")) : 1.0 / den;
     }
-    hden[k] = d;                                                       // (Lc is free: the elimination is over)
+    hden[k] = d;
   }
   if (tid == 0) D.status[cls] = bad ? 1 : 0;
   PTDFB_STAMP(4);
@@ -537,40 +573,46 @@ __global__ __launch_bounds__(PTDFB_LDS_THREADS) void ptdf_build_lds_kernel(PtdfB
   // ---- 4. LODF[m][k] = (PTDF[m][from_k] - PTDF[m][to_k]) / (1 - H[k][k]); LODF[k][k] = -1.  Rounds of PTDFB_LROWS lines m: all threads
   //         build the PTDF rows of those lines over the reduced buses in LDS (rows of X read contiguously: no bank conflicts), then thread
   //         k takes its two entries of every row (2 gathers per output instead of 4) and stores column k (coalesced) ----------------------
-  __syncthreads();                                                     // hden complete; Lc beyond it is free
-  double* rows = Lc + D.line_pad;                                      // [PTDFB_LROWS][n_pad]
-  const int kk = tid < D.line_pad ? tid : -1;                          // (line_pad <= 256 threads is checked by the host)
+  PTDFB_LDS_BARRIER();                                                 // (NOT __syncthreads(): the PTDF^T stores keep draining behind the LODF rounds)
+  const int kk = tid < D.line_pad ? tid : -1;                          // (line_pad <= the block's threads is checked by the host)
   const int kf = kk >= 0 ? s_lf[kk] : -1, kt = kk >= 0 ? s_lt[kk] : -1;
   const double khd = kk >= 0 ? hden[kk] : 0.0;
+  long long acc_b = 0;
   for (int m0 = 0; m0 < D.n_line; m0 += PTDFB_LROWS) {
+    const long long tb_ = D.dbg ? (long long)__builtin_readcyclecounter() : 0;
     for (int e = tid; e < PTDFB_LROWS * n_pad; e += PTDFB_LDS_THREADS) {
       const int u = e / n_pad, b = e - u * n_pad, m = m0 + u;
       double v = 0.0;
       if (m < D.n_line && b < nr && !bad) {
         const int fm = s_lf[m], tm = s_lt[m];
-        if (fm >= 0) v = s_bdc[m] * ((fm < nr ? M[(size_t)fm * ldm + b] : 0.0) - (tm < nr ? M[(size_t)tm * ldm + b] : 0.0));   // = PT[b][m] (X symmetric to rounding)
+        if (fm >= 0) v = s_bdc[m] * ((fm < nr ? M[(size_t)fm * ldm + b] : 0.0) - (tm < nr ? M[(size_t)tm * ldm + b] : 0.0));
       }
       rows[e] = v;
     }
-    __syncthreads();
+    PTDFB_LDS_BARRIER();
+    if (D.dbg) acc_b += (long long)__builtin_readcyclecounter() - tb_;
     if (kk >= 0) {
+      double hf[PTDFB_LROWS], ht[PTDFB_LROWS];
+#pragma unroll
+      for (int u = 0; u < PTDFB_LROWS; ++u) {
+        hf[u] = (kf >= 0 && kf < nr) ? rows[u * n_pad + kf] : 0.0;
+        ht[u] = (kf >= 0 && kt < nr) ? rows[u * n_pad + kt] : 0.0;
+      }
 #pragma unroll
       for (int u = 0; u < PTDFB_LROWS; ++u) {
         const int m = m0 + u;
-        if (m >= D.n_line) break;
         double v = 0.0;
-        if (kf >= 0) {
-          const double h = (kf < nr ? rows[u * n_pad + kf] : 0.0) - (kt < nr ? rows[u * n_pad + kt] : 0.0);
-          v = (khd != khd) ? khd : (m == kk ? -1.0 : h * khd);
-        }
-        LO[(size_t)m * D.line_pad + kk] = v;
+        if (kf >= 0) v = (khd != khd) ? khd : (m == kk ? -1.0 : (hf[u] - ht[u]) * khd);
+        if (m < D.n_line) LO[(size_t)m * D.line_pad + kk] = (float)v;
       }
     }
-    __syncthreads();
+    PTDFB_LDS_BARRIER();
   }
+  if (D.dbg && tid == 0) D.dbg[(size_t)cls * 8 + 7] = acc_b;
   PTDFB_STAMP(5);
 }
 
 #undef PTDFB_STAMP
+#undef PTDFB_LDS_BARRIER
 
 }  // namespace gpf

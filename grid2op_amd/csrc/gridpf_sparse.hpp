@@ -2570,6 +2570,24 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
           ovc[l] = now;
         }
       }
+      // line cooldowns (obs.time_before_cooldown_line): one step passed; a line the protections tripped in this step starts its
+      // reconnection cooldown; a maintenance / hazard under way holds the counter at its remaining duration (baseEnv.py:3352-3358,
+      // 2590-2597: only on a converged step -- a failed one ends the episode)
+      if (sa.nb_ts_reco >= 0 && st == 0 && !ghost) {
+        const auto cool = gptr(b.cooldown) + (size_t)inst * g.n_line;
+        const auto dround = gptr(b.disc_round) + (size_t)inst * g.n_line;
+        const auto mdur = gptr(b.maint_dur) + ((size_t)tab * sa.T + row) * g.n_line;
+        GPF_GLOBAL short* tcool = nullptr;
+        if (b.traj_cool && step < b.traj_cap) tcool = gptr(b.traj_cool) + ((size_t)step * b.lane_stride + inst) * g.n_line;
+        for (int l = tid; l < g.n_line; l += GW) {
+          int cd = cool[l];
+          cd = cd > 0 ? cd - 1 : 0;
+          if (dround[l] >= 0) cd = sa.nb_ts_reco;
+          if (b.maint_dur) { const int md = (int)mdur[l]; cd = md > cd ? md : cd; }
+          cool[l] = cd;
+          if (tcool) tcool[l] = (short)(cd > 32767 ? 32767 : cd);
+        }
+      }
     }
     const bool failed = st != 0;
     if (tid == 0) {
@@ -2589,6 +2607,7 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
       const auto ovc = gptr(b.overflow_count) + (size_t)inst * g.n_line;
       for (int i = tid; i < g.dim_topo; i += GW) topo[i] = t0[i];
       for (int l = tid; l < g.n_line; l += GW) ovc[l] = 0;
+      if (sa.nb_ts_reco >= 0) { const auto cool = gptr(b.cooldown) + (size_t)inst * g.n_line; for (int l = tid; l < g.n_line; l += GW) cool[l] = 0; }   // env.reset(): baseEnv.py:3979
       ovc_first = 0;
       if (env_on) {                                              // env.reset(): dispatch cleared, storage back to its initial charge
         er.target = er.actual = er.prev_p = er.amount_prev = er.curt_prev = 0.f; er.limit = 1.f; er.already = false; er.fresh = true;

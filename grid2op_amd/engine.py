@@ -324,7 +324,7 @@ class PowerFlowEngine:
         off, items = self.pack_actions(actions)
         lb = None if last_bus is None else np.ascontiguousarray(last_bus, dtype=np.int32).reshape(src.size, self.model.dim_topo)
         o = GpfStepOpts(int(max_iter), float(tol_mva), float(rebalance), int(bool(cascade)), float(hard_overflow), float(soft_overflow),
-                        int(nb_ts_allowed), int(max_rounds), int(bool(is_dc)), 0, 0)
+                        int(nb_ts_allowed), int(max_rounds), int(bool(is_dc)), 0, 0, -1)
         check(self._lib.gpf_simulate_batch(self._h, int(t_obs), int(time_step), src.size, ptr(src, C.c_int32), len(actions),
                                            ptr(off, C.c_int32), ptr(items if items.size else None, C.c_int32), ptr(lb, C.c_int32),
                                            int(dst_lane0), C.byref(o)), "gpf_simulate_batch")
@@ -390,6 +390,8 @@ class PowerFlowEngine:
 
     def upload_maintenance(self, maintenance):
         """Scheduled maintenance of the uploaded tables: ``[n_tables, T, n_line]`` (or ``[T, n_line]``) 0/1; None removes it."""
+        self._has_maint = maintenance is not None
+        self._has_outages = self._has_maint or getattr(self, "_has_hazard", False)
         if maintenance is None:
             check(self._lib.gpf_upload_maintenance(self._h, 0, 0, None), "gpf_upload_maintenance")
             return
@@ -399,9 +401,24 @@ class PowerFlowEngine:
         assert mt.shape[2] == self.model.n_line
         check(self._lib.gpf_upload_maintenance(self._h, mt.shape[0], mt.shape[1], ptr(mt, C.c_uint8)), "gpf_upload_maintenance")
 
+    def upload_outage_durations(self, durations):
+        """Remaining duration of the maintenance / hazard under way at every row, ``[n_tables, T, n_line]`` (or ``[T, n_line]``): what the line
+        cooldowns are held at during an outage.  Only needed when the uploaded tables are a window of longer chronics (the library derives
+        the durations from the outage tables otherwise); None: derived again."""
+        if durations is None:
+            check(self._lib.gpf_upload_outage_durations(self._h, 0, 0, None), "gpf_upload_outage_durations")
+            return
+        d = np.ascontiguousarray(np.minimum(np.asarray(durations), 65535), dtype=np.uint16)
+        if d.ndim == 2:
+            d = d[None]
+        assert d.shape[2] == self.model.n_line
+        check(self._lib.gpf_upload_outage_durations(self._h, d.shape[0], d.shape[1], d.ctypes.data_as(C.POINTER(C.c_uint16))), "gpf_upload_outage_durations")
+
     def upload_hazards(self, hazards):
         """Hazards of the uploaded tables (``hazards.csv``: unplanned outages): ``[n_tables, T, n_line]`` (or ``[T, n_line]``) 0/1; None
         removes them.  Independent of the maintenance table; a line is out of service where either flags it."""
+        self._has_hazard = hazards is not None
+        self._has_outages = self._has_hazard or getattr(self, "_has_maint", False)
         if hazards is None:
             check(self._lib.gpf_upload_hazards(self._h, 0, 0, None), "gpf_upload_hazards")
             return
@@ -431,13 +448,18 @@ class PowerFlowEngine:
 
     def step(self, t: int, max_iter: int = 10, tol_mva: float = 1e-8, rebalance: float = 0.0, cascade: bool = False,
              hard_overflow: float = 2.0, soft_overflow: float = 1.0, nb_ts_allowed: int = 2, max_rounds: int = 16,
-             is_dc: bool = False, n_steps: int = 1, auto_reset: bool = False, warm_start: bool = False):
+             is_dc: bool = False, n_steps: int = 1, auto_reset: bool = False, warm_start: bool = False, nb_ts_reco: Optional[int] = None):
         """``n_steps`` consecutive DoNothing ``env.step`` (t, t+1, ...) for every lane in ONE launch (asynchronous).  Every step
         writes its results; the getters return the last one, `trajectory` the rho / status of each when requested.
         ``warm_start`` (opt-in, NOT the reference's algorithm) starts Newton of steps 2..n from the previous step's voltages
-        while a lane's topology stands: same solution within ``tol_mva``, fewer iterations, ``n_iter`` differs."""
+        while a lane's topology stands: same solution within ``tol_mva``, fewer iterations, ``n_iter`` differs.
+        ``nb_ts_reco`` (Parameters.NB_TIMESTEP_RECONNECTION): the environment's line cooldowns (`cooldown`, obs.time_before_cooldown_line) are
+        maintained at every step -- default: 10 (the reference's default) when lines can go out by themselves (``cascade`` or uploaded
+        maintenance / hazard tables), else not tracked; -1 switches the tracking off."""
+        if nb_ts_reco is None:
+            nb_ts_reco = 10 if (cascade or getattr(self, "_has_outages", False)) else -1
         o = GpfStepOpts(int(max_iter), float(tol_mva), float(rebalance), int(bool(cascade)), float(hard_overflow), float(soft_overflow),
-                        int(nb_ts_allowed), int(max_rounds), int(bool(is_dc)), int(bool(auto_reset)), int(bool(warm_start)))
+                        int(nb_ts_allowed), int(max_rounds), int(bool(is_dc)), int(bool(auto_reset)), int(bool(warm_start)), int(nb_ts_reco))
         check(self._lib.gpf_step_n(self._h, int(t), int(n_steps), C.byref(o)), "gpf_step_n")
 
     def set_lane_redispatch(self, delta_mw):
@@ -644,6 +666,25 @@ class PowerFlowEngine:
         ``lane0 ...``: ``[n, n_line]`` ints."""
         c = np.ascontiguousarray(counts, dtype=np.int32).reshape(-1, self.model.n_line)
         check(self._lib.gpf_set_overflow_count(self._h, int(lane0), c.shape[0], ptr(c, C.c_int32)), "gpf_set_overflow_count")
+
+    def cooldown(self, lane0: int = 0, n: Optional[int] = None) -> np.ndarray:
+        """The environment's line cooldowns of the lanes (obs.time_before_cooldown_line; `step(nb_ts_reco=...)`), int32 ``[n, n_line]``."""
+        lane0, n = self._range(lane0, n)
+        out = np.empty((n, self.model.n_line), dtype=np.int32)
+        check(self._lib.gpf_get_cooldown(self._h, lane0, n, ptr(out, C.c_int32)), "gpf_get_cooldown")
+        return out
+
+    def set_cooldown(self, line_cooldown, lane0: int = 0):
+        """Restore the line cooldowns (an environment restored from an observation hands over obs.time_before_cooldown_line)."""
+        c = np.ascontiguousarray(line_cooldown, dtype=np.int32).reshape(-1, self.model.n_line)
+        check(self._lib.gpf_set_cooldown(self._h, int(lane0), c.shape[0], ptr(c, C.c_int32)), "gpf_set_cooldown")
+
+    def trajectory_cooldown(self, n_steps: int, step0: int = 0, lane0: int = 0, n: Optional[int] = None) -> np.ndarray:
+        """Line cooldowns after every step of the last multi-step launch, int16 ``[n_steps, n, n_line]`` (needs `set_trajectory`)."""
+        lane0, n = self._range(lane0, n)
+        out = np.empty((n_steps, n, self.model.n_line), dtype=np.int16)
+        check(self._lib.gpf_get_trajectory_cooldown(self._h, int(step0), int(n_steps), lane0, n, out.ctypes.data_as(C.POINTER(C.c_int16))), "gpf_get_trajectory_cooldown")
+        return out
 
     def step_outputs(self, lane0: int = 0, n: Optional[int] = None):
         lane0, n = self._range(lane0, n)

@@ -198,6 +198,14 @@ class ShardedEngine:
         return LaneResults(out=cat("out"), topo_vect=cat("topo_vect"), shunt_bus=cat("shunt_bus"), line_status=cat("line_status"),
                            status=cat("status"), bus_vm=cat("bus_vm"), bus_va=cat("bus_va"), _slices=rs[0]._slices)
 
+    def cooldown(self, lane0: int = 0, n=None):
+        return np.concatenate([eng.cooldown(l0, k) for eng, l0, k, _ in self._parts(lane0, n)])
+
+    def set_cooldown(self, line_cooldown, lane0: int = 0):
+        c = np.asarray(line_cooldown).reshape(-1, self.model.n_line)
+        for eng, l0, k, off in self._parts(lane0, c.shape[0]):
+            eng.set_cooldown(c[off:off + k], lane0=l0)
+
     def step_outputs(self, lane0: int = 0, n=None):
         parts = [eng.step_outputs(l0, k) for eng, l0, k, _ in self._parts(lane0, n)]
         return tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
@@ -208,6 +216,10 @@ class ShardedEngine:
     def upload_maintenance(self, maintenance):
         for eng in self.engines:
             eng.upload_maintenance(maintenance)
+
+    def upload_outage_durations(self, durations):
+        for e in self.engines:
+            e.upload_outage_durations(durations)
 
     def upload_hazards(self, hazards):
         for eng in self.engines:
@@ -265,6 +277,7 @@ class ShardedEngine:
         self.set_topology(topo, sb, lane0=dst)
         _, ovc, _ = self.step_outputs(src, n)
         self.set_overflow_count(ovc, lane0=dst)
+        self.set_cooldown(self.cooldown(src, n), lane0=dst)
         if all(getattr(e, "env_dynamics_on", False) for e in self.engines):
             self.set_env_state(dst, **self.env_state(src, n))
 

@@ -190,6 +190,12 @@ int gpf_upload_maintenance(gpf_handle h, int32_t n_tables, int32_t T, const uint
  * same effect on the backend as the maintenance table -- the line is forced out of service at the rows where it is flagged (the
  * "hazards" modification the environment applies every step); the two tables are independent, the device applies their union. */
 int gpf_upload_hazards(gpf_handle h, int32_t n_tables, int32_t T, const uint8_t* data);
+/* Remaining duration (steps, incl. the current one) of the maintenance / hazard under way at every row, [n_tables][T][n_line] uint16: what the
+ * line cooldowns are raised to during an outage (gpf_step_opts::nb_ts_reco; GridValue.get_maintenance_duration_1d / get_hazard_duration_1d,
+ * grid2op/Chronics/gridValue.py:339).  By default the library derives it from the uploaded outage tables (one backward scan); a caller whose
+ * tables are a WINDOW of longer chronics passes the true values here, because an outage that runs past the end of the window looks shorter than it
+ * is.  Used where an outage table flags the line; NULL: back to the derived values. */
+int gpf_upload_outage_durations(gpf_handle h, int32_t n_tables, int32_t T, const uint16_t* data);
 int gpf_set_lane_chronics(gpf_handle h, const int32_t* lane_table, const int32_t* lane_offset, const float* lane_scale);
 int gpf_set_thermal_limits(gpf_handle h, const float* limit_a /* [n_line] */);
 /* One DoNothing env.step for every lane (Environment/baseEnv.py:3562 -> Backend.next_grid_state
@@ -217,6 +223,14 @@ typedef struct gpf_step_opts {
                             performs on every runpf (pandaPowerBackend.py:1086 _pf_init = "dc"; LightSimBackend-style warm start).
                             Same solution within the solver tolerance, fewer iterations: n_iter and the last digits differ
                             from the reference's.  Default 0 = the reference's algorithm. */
+  int32_t nb_ts_reco;    /* >= 0: maintain the environment's LINE COOLDOWNS (BaseEnv._times_before_line_status_actionable =
+                            obs.time_before_cooldown_line, Environment/baseEnv.py:3352-3358, 2590-2597) at every converged step: decremented,
+                            set to this value (Parameters.NB_TIMESTEP_RECONNECTION, default 10) for a line the protections trip in
+                            the step, raised to the remaining duration of a maintenance / hazard under way (the uploaded outage
+                            tables).  < 0: the counters are left alone (gpf_step: always).  Read with gpf_get_cooldown /
+                            gpf_get_trajectory_cooldown; cleared by gpf_reset_lanes and by an auto-reset, copied by gpf_copy_lanes and
+                            gpf_simulate_batch.  (Cooldowns caused by the agents' own line / substation actions belong to the
+                            caller: a DoNothing step has none.) */
 } gpf_step_opts;
 /* n_steps consecutive DoNothing env.step (t0, t0+1, ...) of every lane in ONE launch.  Every step does the whole of gpf_step;
  * between the steps of a launch the lane state stays on chip and whatever only depends on the topology (element->bus maps, bus
@@ -348,6 +362,12 @@ int gpf_get_episode(gpf_handle h, int32_t lane0, int32_t n, uint8_t* done, int32
  * consecutive steps each line has spent above its thermal limit), [n][n_line]: what an environment restored from an observation
  * hands over (Environment/_obsEnv.py init copies obs.timestep_overflow).  gpf_step / gpf_step_n maintain them on the device. */
 int gpf_set_overflow_count(gpf_handle h, int32_t lane0, int32_t n, const int32_t* overflow_count);
+/* The lanes' line cooldowns (gpf_step_opts::nb_ts_reco), [n][n_line]; gpf_set_cooldown: what an environment restored from an observation
+ * hands over (obs.time_before_cooldown_line).  gpf_get_trajectory_cooldown: the counters after every step of the last multi-step launch,
+ * int16 [n_steps][n][n_line] (saturating at 32767), kept with any trajectory (gpf_set_trajectory). */
+int gpf_get_cooldown(gpf_handle h, int32_t lane0, int32_t n, int32_t* line_cooldown);
+int gpf_set_cooldown(gpf_handle h, int32_t lane0, int32_t n, const int32_t* line_cooldown);
+int gpf_get_trajectory_cooldown(gpf_handle h, int32_t step0, int32_t n_steps, int32_t lane0, int32_t n, int16_t* line_cooldown);
 /* rho = a_or / thermal_limit (backend.py:1145-1168) and overflow counters of the last gpf_step. */
 int gpf_get_step_outputs(gpf_handle h, int32_t lane0, int32_t n, float* rho, int32_t* overflow_count,
                          int32_t* disc_round);

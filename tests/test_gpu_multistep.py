@@ -400,14 +400,17 @@ def test_static_dc_inverse_equals_the_dc_solve(name, B, load_model, load_npz):
     e2.close()
 
 
-@pytest.mark.parametrize("name", ["l2rpn_case14_sandbox", "l2rpn_neurips_2020_track1"])
+@pytest.mark.parametrize("name", ["l2rpn_case14_sandbox", "l2rpn_neurips_2020_track1", "l2rpn_case14_sandbox_trips"])
 def test_device_rollout_reproduces_the_reference_environment(name, load_model, load_npz):
     """A DoNothing rollout of the UNMODIFIED reference Environment (default parameters: overflow disconnections on; all the
     scenarios of its chronics folder, scheduled maintenance included) recorded by tests/golden/make_rollout_fixtures.py, against ONE
-    multi-step launch of the engine with one lane per scenario: rho of every step, final line status and overflow counters."""
+    multi-step launch of the engine with one lane per scenario: rho of every step, final line status and overflow counters, and -- round 5 --
+    the LINE COOLDOWNS of every step (obs.time_before_cooldown_line: `_trips` has two thermal limits below the initial flows, so that the
+    protections trip lines 3, 12 and then 4 and their reconnection cooldowns run 10, 9, ...; the 36-substation rollout has a 96-step
+    scheduled maintenance that holds the counter at its remaining duration)."""
     from grid2op_amd.engine import PowerFlowEngine
     from grid2op_amd.chronics import chronics_table
-    m = load_model(name)
+    m = load_model(name.replace("_trips", ""))
     fx = load_npz(f"rollout_{name}.npz")
     n_scen, n_steps = fx["rho"].shape[:2]
     reps = 5                                              # every scenario on several lanes (different wavefront positions)
@@ -417,19 +420,37 @@ def test_device_rollout_reproduces_the_reference_environment(name, load_model, l
     eng.upload_chronics(chronics_table(ch))
     if "maintenance" in ch:
         eng.upload_maintenance(ch["maintenance"])
+        # the fixture is a 132-row WINDOW of the chronics: the maintenance that starts at row 108 lasts 96 steps, of which the window shows 24
+        eng.upload_outage_durations(ch["maintenance_duration"])
     eng.set_lane_chronics(lane_table=np.tile(np.arange(n_scen), reps), lane_offset=np.ones(B, np.int32))   # env step k reads row k
     eng.set_thermal_limits(fx["thermal_limit"])
     eng.set_trajectory(n_steps)
-    eng.step(0, n_steps=n_steps, cascade=True, hard_overflow=float(fx["hard_overflow"]), nb_ts_allowed=int(fx["nb_ts_allowed"]))
+    kw = dict(cascade=True, hard_overflow=float(fx["hard_overflow"]), nb_ts_allowed=int(fx["nb_ts_allowed"]), nb_ts_reco=int(fx["nb_ts_reco"]))
+    eng.step(0, n_steps=n_steps, **kw)
     rho, st = eng.trajectory(n_steps)
+    cool = eng.trajectory_cooldown(n_steps)
     r = eng.results()
     _, ovc, _ = eng.step_outputs()
     assert (fx["done_at"] < 0).all() and (st == 0).all()
     for lane in range(B):
         k = lane % n_scen
-        assert np.allclose(rho[:, lane], fx["rho"][k], rtol=2e-5, atol=2e-6), (lane, np.abs(rho[:, lane] - fx["rho"][k]).max())
+        ok = ~np.isnan(fx["rho"][k])                      # (a tripped line has rho 0 in the recording and on the device)
+        assert np.allclose(rho[:, lane][ok], fx["rho"][k][ok], rtol=2e-5, atol=2e-6), (lane, np.abs(rho[:, lane] - fx["rho"][k]).max())
         assert np.array_equal(r.line_status[lane], fx["line_status"][k, -1]), lane
         assert np.array_equal(ovc[lane], fx["timestep_overflow"][k, -1]), lane
+        assert np.array_equal(cool[:, lane], fx["time_before_cooldown_line"][k]), (lane, np.argwhere(cool[:, lane] != fx["time_before_cooldown_line"][k])[:4])
+    assert np.array_equal(eng.cooldown(), cool[-1])
+    if name.endswith("_trips"):
+        assert cool.max() == int(fx["nb_ts_reco"]) and (~r.line_status).sum() >= 2 * reps
+    if name == "l2rpn_neurips_2020_track1":
+        assert cool.max() == 96                           # the scheduled maintenance of the first scenario
+        eng.upload_outage_durations(None)                 # derived from the window alone: the outage looks 24 steps long
+        eng.reset()
+        eng.set_lane_chronics(lane_table=np.tile(np.arange(n_scen), reps), lane_offset=np.ones(B, np.int32))
+        eng.step(0, n_steps=n_steps, **kw)
+        c2 = eng.trajectory_cooldown(n_steps)
+        assert c2.max() == 24 and np.array_equal(c2 > 0, cool > 0)
+        eng.upload_outage_durations(ch["maintenance_duration"])
     if "maintenance" in ch:
         assert (~r.line_status).any()                     # the scheduled outage really happened
     # the same rollout one launch per step, and in launches of 7
@@ -439,10 +460,11 @@ def test_device_rollout_reproduces_the_reference_environment(name, load_model, l
         t = 0
         while t < n_steps:
             k = min(spl, n_steps - t)
-            eng.step(t, n_steps=k, cascade=True, hard_overflow=float(fx["hard_overflow"]), nb_ts_allowed=int(fx["nb_ts_allowed"]))
+            eng.step(t, n_steps=k, **kw)
             t += k
         r2 = eng.results()
-        assert np.array_equal(r2.line_status, r.line_status) and np.allclose(r2.out, r.out, rtol=2e-6, atol=2e-5)
+        assert np.array_equal(r2.line_status, r.line_status) and np.allclose(r2.out, r.out, rtol=2e-6, atol=2e-5, equal_nan=True)
+        assert np.array_equal(eng.cooldown(), cool[-1])
     eng.close()
 
 
@@ -851,4 +873,32 @@ def test_pandapower_recorded_do_nothing_episodes_in_multi_step_launches(load_mod
         t += n
     assert n_cmp >= 2000
     assert (ended >= 0).sum() == 19 and all(ended[e] == n_rows[e] - 1 for e in range(n_ep) if n_rows[e] < T)
+    eng.close()
+
+
+def test_line_cooldowns_decrement_copy_reset_and_opt_out(load_model, load_npz):
+    """The line cooldowns outside the recorded rollouts: an environment restored from an observation hands its counters over
+    (`set_cooldown`), every tracked step takes one off (never below 0), `copy_lanes` / `reset` treat them like the other per-lane counters,
+    an untracked step (nb_ts_reco < 0: the default when nothing can take a line out) leaves them alone."""
+    m, ch, eng, tab, off, scale = _setup(load_model, load_npz, "l2rpn_case14_sandbox", 9)
+    c0 = np.zeros((9, m.n_line), np.int32)
+    c0[0, :5] = (5, 1, 0, 3, 12)
+    c0[1, 7] = 2
+    eng.set_cooldown(c0)
+    assert np.array_equal(eng.cooldown(), c0)
+    eng.set_trajectory(4)
+    eng.step(0, n_steps=3, rebalance=1.02, nb_ts_reco=10)
+    want = np.maximum(c0 - 3, 0)
+    assert np.array_equal(eng.cooldown(), want)
+    tr = eng.trajectory_cooldown(3)
+    for k in range(3):
+        assert np.array_equal(tr[k], np.maximum(c0 - (k + 1), 0)), k
+    eng.step(3, n_steps=2, rebalance=1.02)                       # default: not tracked (no cascade, no outage tables)
+    assert np.array_equal(eng.cooldown(), want)
+    eng.copy_lanes(0, 5, 2)
+    assert np.array_equal(eng.cooldown(5, 2), want[:2])
+    eng.reset(0, 1)
+    assert (eng.cooldown(0, 1) == 0).all() and np.array_equal(eng.cooldown(5, 1), want[:1])
+    with pytest.raises(Exception):
+        eng.set_cooldown(-np.ones((1, m.n_line), np.int32))
     eng.close()

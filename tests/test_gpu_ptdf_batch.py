@@ -70,9 +70,14 @@ def _states(m, topos, lane_topo, rng):
     return states
 
 
-@pytest.mark.parametrize("name,n_lanes,n_topo", [("l2rpn_case14_sandbox", 70, 24), ("l2rpn_neurips_2020_track1", 90, 40), ("l2rpn_idf_2023", 96, 48),
-                                                 ("educ_case14_storage", 37, 12)])
-def test_tables_and_flows_of_every_class_match_the_oracle(name, n_lanes, n_topo, load_model):
+@pytest.mark.parametrize("name,n_lanes,n_topo,global_kernel", [("l2rpn_case14_sandbox", 70, 24, False), ("l2rpn_neurips_2020_track1", 90, 40, False),
+                                                               ("l2rpn_idf_2023", 96, 48, False), ("educ_case14_storage", 37, 12, False),
+                                                               ("l2rpn_idf_2023", 40, 20, True), ("l2rpn_neurips_2020_track1", 33, 16, True)])
+def test_tables_and_flows_of_every_class_match_the_oracle(name, n_lanes, n_topo, global_kernel, load_model, monkeypatch):
+    """`global_kernel`: the builder for topologies of more than 128 non-reference buses (matrix in global memory, panels in LDS:
+    `ptdf_build_kernel`) forced on the small grids too -- the default on these grids is the register-resident kernel."""
+    if global_kernel:
+        monkeypatch.setenv("GRIDPF_PTDFB_GLOBAL", "1")
     m = load_model(name)
     rng = np.random.default_rng(21)
     topos = random_topologies(m, n_topo, rng)
