@@ -210,9 +210,12 @@ def test_bench_grids_run_on_ahead_of_time_objects_without_a_compiler(load_model,
     __graft_entry__.build() on the CPU box, found by a hash of (generated header, variant, flags, kernel sources) -- even when NO compiler
     is available at run time (GRIDPF_HIPCC pointing nowhere, an empty cache): nothing is compiled, results equal the shipped kernels'.
     (A header that changed since the manifest was recorded simply misses the ahead-of-time objects: then this test reports it.)"""
+    import glob
     import json
     import subprocess
     import sys
+    if not glob.glob(os.path.join(ROOT, "grid2op_amd", "_aot", "hdr_*.ok")):
+        pytest.skip("no ahead-of-time code objects in this tree (__graft_entry__.build() makes them from grid2op_amd/aot/)")
     code = r'''
 import json, sys, numpy as np
 sys.path.insert(0, %r); sys.path.insert(0, %r)
