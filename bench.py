@@ -465,6 +465,7 @@ def measure_modes(ctx, eng, k, w, step_kw, n_win, preroll_steps, spl=None, last_
     return w_obs, w_last, t
 
 
+N1_118_SPL = int(os.environ.get("GRIDPF_BENCH_N1_118_SPL", "4"))   # env steps per launch of the 118-substation N-1 fan-out (its observation trajectory is 2.7 GB per step)
 N_WIN_CFG = 5           # timed windows of every BASELINE-config secondary (min / median / max reported)
 
 
@@ -750,7 +751,7 @@ def main():
                "secondary": lambda: workload_wcci(ctx, "l2rpn_wcci_2022_dev", 1024, k_o, w_o, args.cascade),
                "secondary_env_dynamics": lambda: workload_wcci_dynamics(ctx, "l2rpn_wcci_2022_dev", 1024, k_o, w_o),
                "dc_ptdf": lambda: workload_ptdf(ctx, "l2rpn_idf_2023", 2048, 50, k_sec=k_o, w_sec=w_o),
-               "n1_fanout_118": lambda: workload_n1(ctx, "l2rpn_wcci_2022_dev", 1024, k_sec=8, profile=TRAFFIC_N1_118, spl=4),
+               "n1_fanout_118": lambda: workload_n1(ctx, "l2rpn_wcci_2022_dev", 1024, k_sec=2 * N1_118_SPL, profile=TRAFFIC_N1_118, spl=N1_118_SPL),
                "ptdf_build_batch": lambda: workload_ptdf_build_batch(ctx, "l2rpn_idf_2023", 2048, 256)}[args.only]()
         if rank == 0:
             rec["specialization"] = ctx.specialization()
@@ -996,7 +997,7 @@ def main():
     # ---- configs[2] on a REAL 118-substation grid (BASELINE says "IEEE 118-bus"; the bundled l2rpn_neurips_2020_track1 is a 36-substation
     #      sub-area): 1024 envs x (1 intact + 186 single-line outages) = 191 488 lanes, observation per step ------------------
     if secondary and world == 1:
-        res["n1_fanout_118"] = workload_n1(ctx, "l2rpn_wcci_2022_dev", 1024, k_sec=8, profile=TRAFFIC_N1_118, spl=4)
+        res["n1_fanout_118"] = workload_n1(ctx, "l2rpn_wcci_2022_dev", 1024, k_sec=2 * N1_118_SPL, profile=TRAFFIC_N1_118, spl=N1_118_SPL)
 
     # ---- BASELINE.json configs[3]: 118-substation grid, storage set-points + zero-sum redispatch, 1024 lanes per GPU -----------
     if secondary:
