@@ -465,7 +465,7 @@ def measure_modes(ctx, eng, k, w, step_kw, n_win, preroll_steps, spl=None, last_
     return w_obs, w_last, t
 
 
-N1_118_SPL = int(os.environ.get("GRIDPF_BENCH_N1_118_SPL", "4"))   # env steps per launch of the 118-substation N-1 fan-out (its observation trajectory is 2.7 GB per step)
+N1_118_SPL = int(os.environ.get("GRIDPF_BENCH_N1_118_SPL", "16"))   # env steps per launch of the 118-substation N-1 fan-out (its observation trajectory is 2.7 GB per step: 43 GB of the 288 GB at 16)
 N_WIN_CFG = 5           # timed windows of every BASELINE-config secondary (min / median / max reported)
 
 
@@ -1047,8 +1047,8 @@ def main():
 
 
 def workload_n1(ctx, env, n_envs, k_sec, profile=None, spl=None):
-    """`spl`: env steps per launch of this workload (default: --steps-per-launch); the 118-substation fan-out (191 488 lanes) runs 4 steps
-    per launch -- its observation trajectory is 2.7 GB per step"""
+    """`spl`: env steps per launch of this workload (default: --steps-per-launch); the 118-substation fan-out (191 488 lanes) runs
+    N1_118_SPL = 16 steps per launch -- its observation trajectory is 2.7 GB per step, 43 GB of the 288 GB (4 per launch: -12 %)"""
     m, ch = load_env(env)
     fan = 1 + m.n_line
     eng, T, _ = setup_engine(ctx, m, ch, n_envs, fan)

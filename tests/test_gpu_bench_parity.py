@@ -102,7 +102,7 @@ def test_n1_fanout_1024_envs_x_60_lanes_vs_oracle(load_model, load_npz):
 def test_n1_fanout_118_substations_1024_envs_x_187_lanes_vs_oracle(load_model, load_npz):
     """configs[2] on a REAL 118-substation grid (BASELINE.json says "IEEE 118-bus"; the bundled l2rpn_neurips_2020_track1 is a
     36-substation sub-area, grid2op/tests/test_attached_envs.py:31-35): l2rpn_wcci_2022_dev, 1 024 envs x (1 intact + 186 single-line
-    outages) = 191 488 lanes stepped together as bench.py's `n1_fanout_118` does (4 steps per launch, observation per step).  All 187
+    outages) = 191 488 lanes stepped together as bench.py's `n1_fanout_118` does (observation per step; 4 steps per launch here, 16 in the bench).  All 187
     lanes of two envs and 80 random lanes are re-solved by the C oracle from the inputs the lanes hold on the device, incl. the
     contingencies that island the grid (grid2op/Reward/n1Reward.py:70-99, Environment/_obsEnv.py:321-428 is what the fan-out replaces)."""
     name, n_envs = "l2rpn_wcci_2022_dev", 1024

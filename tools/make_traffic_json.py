@@ -39,6 +39,6 @@ out = {
     "valu_busy_frac": 4.0 * valu / 1024.0 / (disp_us * 1e-6 * clk_ghz * 1e9) if valu else None,
     "waves_per_simd": waves / 1024.0 if waves else None,
     "note": "PMC passes of the bench workload under rocprofv3 --pmc (one counter group per pass, observation trajectory on in every dispatch: "
-            "tools/profile_r04.sh); busy fractions assume 2.4 GHz (profiled runs clock lower: upper bounds)",
+            "tools/profile_r05.sh); busy fractions assume 2.4 GHz (profiled runs clock lower: upper bounds)",
 }
 print(json.dumps(out, indent=1))

@@ -30,7 +30,7 @@ for w in "$@"; do
     case14) prof r05_step_kernel_case14 20 $((1472*4096*20)) "step_sparse_kernel<1, 2, 2" "$FULL" "--steps 400 --warmup 400" --steps 60 --warmup 20 --steps-per-launch 20 --windows 2 --no-secondary ;;
     case14_1) prof r05_step_kernel_case14_1perlaunch 1 $((1472*4096)) "step_sparse_kernel<1, 2, 2" "pmc_fetch:FETCH_SIZE pmc_write:WRITE_SIZE" "--steps 400 --warmup 400" --steps 40 --warmup 20 --windows 2 --no-secondary --steps-per-launch 1 ;;
     n1) prof r05_step_kernel_n1_neurips36 20 $((4639*61440*20)) "step_sparse_kernel<1, 0, 1, 2, 1" "$LITE" "" --only n1_fanout --steps 20 --warmup 5 --steps-per-launch 20 ;;
-    n1_118) prof r05_step_kernel_n1_wcci118 4 $((13790*191488*4)) "step_sparse_kernel<1, 0, 1, 2, 2" "$LITE" "" --only n1_fanout_118 --steps 20 --warmup 5 ;;
+    n1_118) prof r05_step_kernel_n1_wcci118 16 $((13790*191488*16)) "step_sparse_kernel<1, 0, 1, 2, 2" "$LITE" "" --only n1_fanout_118 --steps 20 --warmup 5 ;;
     wcci) prof r05_step_kernel_wcci118 20 $((13790*1024*20)) "step_sparse_kernel<1, 0, 1, 2, 2" "$LITE" "--steps 200 --warmup 40" --only secondary --steps 60 --warmup 20 --steps-per-launch 20 ;;
     # l2rpn_idf_2023, 2 048 lanes: every step launch is two dispatches of 1 024 lanes (one residency round each)
     idf) prof r05_kernels_idf118 20 $((14014*1024*20)) "step_sparse_kernel<1, 0, 1, 2, 2" "$LITE" "--steps 200 --warmup 40" --only dc_ptdf --steps 60 --warmup 20 --steps-per-launch 20 ;;
