@@ -49,6 +49,41 @@ __global__ void fanout_kernel(GridDev g, Bufs b, int src, int dst0, int n_dst, c
   for (int i = tid; i < g.n_shunt; i += blockDim.x) ds[i] = ss[i];
 }
 
+// gpf_solve_lane: the lane's inputs straight from the pinned host block (device-mapped: one PCIe read per element, all in flight
+// together) into the lane's rows, and its result rows straight back into it -- two dispatches instead of eleven staged copies
+// (5.6 us each on the stream: 60 of the 73 us a one-lane runpf took).  Offsets in bytes, 16-byte aligned pieces.
+struct LaneBlob { size_t o_inj, o_topo, o_sb, o_out, o_tv, o_sbo, o_ls, o_st, o_vm, o_va; };
+__global__ void lane_scatter_kernel(GridDev g, Bufs b, int lane, const unsigned char* __restrict__ blob, LaneBlob o) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const double* inj = reinterpret_cast<const double*>(blob + o.o_inj);
+  const int* topo = reinterpret_cast<const int*>(blob + o.o_topo);
+  const int* sb = reinterpret_cast<const int*>(blob + o.o_sb);
+  double* dinj = b.inj + (size_t)lane * g.n_inj;
+  int* dt = b.topo + (size_t)lane * g.dim_topo;
+  int* d0 = const_cast<int*>(b.topo0) + (size_t)lane * g.dim_topo;
+  int* ds = b.shunt_bus + (size_t)lane * g.n_shunt;
+  for (int i = tid; i < g.n_inj; i += nt) dinj[i] = inj[i];
+  for (int i = tid; i < g.dim_topo; i += nt) { const int v = topo[i]; dt[i] = v; d0[i] = v; }
+  for (int i = tid; i < g.n_shunt; i += nt) ds[i] = sb[i];
+}
+__global__ void lane_gather_kernel(GridDev g, Bufs b, int lane, unsigned char* __restrict__ blob, LaneBlob o) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  float* out = reinterpret_cast<float*>(blob + o.o_out);
+  int* tv = reinterpret_cast<int*>(blob + o.o_tv);
+  int* sbo = reinterpret_cast<int*>(blob + o.o_sbo);
+  unsigned char* ls = blob + o.o_ls;
+  int* st = reinterpret_cast<int*>(blob + o.o_st);
+  double* vm = reinterpret_cast<double*>(blob + o.o_vm);
+  double* va = reinterpret_cast<double*>(blob + o.o_va);
+  for (int i = tid; i < g.n_out; i += nt) out[i] = b.out[(size_t)lane * g.n_out + i];
+  for (int i = tid; i < g.dim_topo; i += nt) tv[i] = b.topo_out[(size_t)lane * g.dim_topo + i];
+  for (int i = tid; i < g.n_shunt; i += nt) sbo[i] = b.shunt_bus_out[(size_t)lane * g.n_shunt + i];
+  for (int i = tid; i < g.n_line; i += nt) ls[i] = b.line_status[(size_t)lane * g.n_line + i];
+  if (tid < 4) st[tid] = b.status[(size_t)lane * 4 + tid];
+  for (int i = tid; i < g.nb_tot; i += nt) { vm[i] = b.bus_vm[(size_t)lane * g.nb_tot + i]; va[i] = b.bus_va[(size_t)lane * g.nb_tot + i]; }
+  __threadfence_system();
+}
+
 // gpf_simulate_batch: topology / shunt rows of the source lanes -> one dense staging buffer (a single device-to-host copy)
 __global__ void gather_topo_kernel(GridDev g, Bufs b, const int* __restrict__ src_lanes, int n_src, int* __restrict__ dst) {
   const int k = blockIdx.x;
@@ -214,7 +249,8 @@ struct gpf_engine {
   DevArr<float> rd_after;
   double rd_eps = 1e-4;
   bool rd_ready = false;
-  unsigned char* pin = nullptr;         // pinned host staging of gpf_solve_lane (one lane in, one lane out)
+  unsigned char* pin = nullptr;         // pinned host block of gpf_solve_lane (one lane in, one lane out), mapped into the device
+  unsigned char* pin_dev = nullptr;     // its device-side address (hipHostGetDevicePointer)
   size_t pin_bytes = 0;
   GpfJit jit;                           // grid-specialised step kernels (gpf_jit_enable; gridpf_jit.hip)
   gpf::GridDev jit_g;                   // the grid-level part of the parameter block the specialisation was generated from
@@ -1409,6 +1445,24 @@ int gpf_runpf(gpf_handle e, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
   return GPF_OK;
 }
 
+// A blocking hipStreamSynchronize wakes up 10-15 us after the stream drained (interrupt + scheduler): a consumer of short launches
+// (one 20-step launch of 14 substations is 0.4 ms, a one-lane runpf 30 us) pays that on every synchronisation.  Poll the stream for up
+// to ~0.5 ms first (GRIDPF_SYNC_SPIN_US, 0: never), then block: long waits do not burn a host core.
+static hipError_t sync_stream_spin(hipStream_t st) {
+  static const long spin_us = getenv("GRIDPF_SYNC_SPIN_US") ? atol(getenv("GRIDPF_SYNC_SPIN_US")) : 500;
+  if (spin_us > 0) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t q = hipStreamQuery(st);
+      if (q == hipSuccess) return hipSuccess;
+      if (q != hipErrorNotReady) break;
+      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
+    }
+    (void)hipGetLastError();
+  }
+  return hipStreamSynchronize(st);
+}
+
 // The whole of HipBackend.runpf for ONE lane in a single call: push the lane's injections and topology (apply_action's
 // scatter, pandaPowerBackend.py:920-975), solve (runpf -> pp.runpp / rundcpp, :1078-1120), read every result buffer back
 // (the getters, :1566-1619) -- everything queued on the stream through one pinned staging block, ONE synchronisation.
@@ -1431,8 +1485,12 @@ int gpf_solve_lane(gpf_handle e, int32_t lane, const double* inj, const int32_t*
   if (e->pin_bytes < total) {
     if (e->pin) (void)hipHostFree(e->pin);
     e->pin = nullptr; e->pin_bytes = 0;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->pin), total, hipHostMallocDefault));
+    // coherent (fine-grained) mapping: the device reads / writes it uncached, what the gather kernel wrote is in host memory when the
+    // stream has drained
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->pin), total, hipHostMallocMapped | hipHostMallocCoherent));
     e->pin_bytes = total;
+    e->pin_dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&e->pin_dev), e->pin, 0));
   }
   unsigned char* P = e->pin;
   std::memcpy(P + o_inj, inj, (size_t)g.n_inj * 8);
@@ -1465,10 +1523,19 @@ int gpf_solve_lane(gpf_handle e, int32_t lane, const double* inj, const int32_t*
       if (g.n_shunt) std::memcpy(ms, shunt_bus, (size_t)g.n_shunt * sizeof(int));
     }
   }
+  // GRIDPF_LANE_STAGED=1 (developer A/B): the eleven staged copies of rounds 1 - 4 instead of the two zero-copy dispatches
+  static const bool staged = [] { const char* v = std::getenv("GRIDPF_LANE_STAGED"); return v && std::atoi(v) > 0; }();
+  const gpf::LaneBlob lb{o_inj, o_topo, o_sb, o_out, o_tv, o_sbo, o_ls, o_st, o_vm, o_va};
+  const gpf::Bufs bufs = e->bufs();
+  if (staged) {
   HIP_TRY(hipMemcpyAsync(e->inj.p + (size_t)lane * g.n_inj, P + o_inj, (size_t)g.n_inj * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(e->topo.p + (size_t)lane * g.dim_topo, P + o_topo, (size_t)g.dim_topo * 4, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(e->topo0.p + (size_t)lane * g.dim_topo, P + o_topo, (size_t)g.dim_topo * 4, hipMemcpyHostToDevice, st));
   if (g.n_shunt) HIP_TRY(hipMemcpyAsync(e->shunt_bus.p + (size_t)lane * g.n_shunt, P + o_sb, (size_t)g.n_shunt * 4, hipMemcpyHostToDevice, st));
+  } else {
+    hipLaunchKernelGGL(gpf::lane_scatter_kernel, dim3(1), dim3(256), 0, st, g, bufs, (int)lane, (const unsigned char*)e->pin_dev, lb);
+    HIP_TRY(hipGetLastError());
+  }
   const double tol_pu = tol_mva / g.sn_mva;
   p.jit = pb.jit = jit_for_launch(e);
   HIP_TRY(gpf_launch_runpf_sparse(p, e->device, e->d_params_s, st, lane, 1, is_dc, max_iter, tol_pu));
@@ -1476,10 +1543,15 @@ int gpf_solve_lane(gpf_handle e, int32_t lane, const double* inj, const int32_t*
   if (e->window) { ++e->win_launches; e->win_marked = false; }
 #define DL1(off, arr, stride, bytes_per) \
   if ((stride) > 0) HIP_TRY(hipMemcpyAsync(P + (off), e->arr.p + (size_t)lane * (stride), (size_t)(stride) * (bytes_per), hipMemcpyDeviceToHost, st))
+  if (staged) {
   DL1(o_out, out, g.n_out, 4); DL1(o_tv, topo_out, g.dim_topo, 4); DL1(o_sbo, shunt_bus_out, g.n_shunt, 4); DL1(o_ls, line_status, g.n_line, 1);
   DL1(o_st, status, 4, 4); DL1(o_vm, bus_vm, g.nb_tot, 8); DL1(o_va, bus_va, g.nb_tot, 8);
+  } else {
+    hipLaunchKernelGGL(gpf::lane_gather_kernel, dim3(1), dim3(256), 0, st, g, bufs, (int)lane, e->pin_dev, lb);
+    HIP_TRY(hipGetLastError());
+  }
 #undef DL1
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipStreamSynchronize(st));          // (a wait this short: the runtime's own active wait beats polling hipStreamQuery by 3 - 5 us)
   if (out) std::memcpy(out, P + o_out, (size_t)g.n_out * 4);
   if (topo_vect) std::memcpy(topo_vect, P + o_tv, (size_t)g.dim_topo * 4);
   if (shunt_bus_out && g.n_shunt) std::memcpy(shunt_bus_out, P + o_sbo, (size_t)g.n_shunt * 4);
@@ -2189,21 +2261,7 @@ int gpf_get_step_outputs(gpf_handle e, int32_t lane0, int32_t n, float* rho, int
 int gpf_sync(gpf_handle e) {
   if (!e) return fail(GPF_E_INVALID, "gpf_sync: null");
   HIP_TRY(hipSetDevice(e->device));
-  // A blocking hipStreamSynchronize wakes up 10-15 us after the stream drained (interrupt + scheduler): a consumer that steps in short
-  // launches (one 20-step launch of 14 substations is 0.4 ms) pays that on every synchronisation.  Poll the stream for up to ~0.5 ms
-  // first (GRIDPF_SYNC_SPIN_US, 0: never), then block: long waits do not burn a host core.
-  static const long spin_us = getenv("GRIDPF_SYNC_SPIN_US") ? atol(getenv("GRIDPF_SYNC_SPIN_US")) : 500;
-  if (spin_us > 0) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-      const hipError_t q = hipStreamQuery(e->stream);
-      if (q == hipSuccess) return GPF_OK;
-      if (q != hipErrorNotReady) { (void)hipGetLastError(); break; }
-      if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > spin_us) break;
-    }
-    (void)hipGetLastError();
-  }
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(sync_stream_spin(e->stream));           // (polls for up to GRIDPF_SYNC_SPIN_US before blocking, see sync_stream_spin)
   return GPF_OK;
 }
 
