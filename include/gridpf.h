@@ -156,7 +156,8 @@ int gpf_fanout_n1(gpf_handle h, int32_t src_lane, int32_t dst_lane0, int32_t n_o
 int gpf_runpf(gpf_handle h, int32_t lane0, int32_t n, int32_t is_dc, int32_t max_iter, double tol_mva);
 
 /* The single-environment plugin path in ONE call (what HipBackend.runpf does per power flow): gpf_set_injections +
- * gpf_set_topology + gpf_runpf + gpf_get_results for one lane, staged through pinned host memory and synchronised once
+ * gpf_set_topology + gpf_runpf + gpf_get_results for one lane through a device-mapped pinned host block (one dispatch
+ * reads the inputs from it into the lane's rows, one writes the result rows back into it; no staged copies), synchronised once
  * (apply_action pandaPowerBackend.py:902-975, runpf :1220-1255, getters :1566-1619).  inj [n_inj], topo [dim_topo],
  * shunt_bus [n_shunt] (required when the grid has shunts); output pointers as in gpf_get_results (any may be NULL).
  * Synchronous. */
