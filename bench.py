@@ -224,10 +224,13 @@ class Ctx:
             else:
                 dist.init_process_group(backend=args.dist_backend)
 
-    def cuda_sync(self):
+    def cuda_ok(self):
         if self._cuda is None:                 # (asked once: torch.cuda.is_available() costs microseconds, this runs inside the timed brackets)
             self._cuda = bool(self.torch is not None and not self.args.stub_engine and self.torch.cuda.is_available())
-        if self._cuda:
+        return self._cuda
+
+    def cuda_sync(self):
+        if self.cuda_ok():
             self.torch.cuda.synchronize()
 
     def sync_all(self, *engines):
@@ -624,6 +627,9 @@ def compact_record(res, full_path=None):
         "ptdf_1row": _cfg_line(dc) if dc else None,
         "ptdf_build_batch": _cfg_line(res.get("ptdf_build_batch"), extra=("classes", "host_builds_per_sec")),
     }
+    act = (res.get("secondary_env_dynamics") or {}).get("acting_every_step")
+    if act and configs["wcci_env_dynamics"]:                # agents acting at EVERY step: actions from the host / written on the device
+        configs["wcci_env_dynamics"]["acting_every_step"] = {k: _r(act[k]["value_median"], 4) for k in ("host_actions", "device_actions") if k in act}
     out["configs"] = {k: v for k, v in configs.items() if v}
     side = {}
     for k in ("shipped_kernels", "one_launch_per_step", "rollout_last_observation_only", "cascade_on", "cascade_tripping", "split_topologies"):
@@ -1119,6 +1125,48 @@ def workload_wcci(ctx, env, n_envs, k_sec, w_sec, cascade):
     return out
 
 
+def acting_every_step(ctx, eng, m, red, sto, t, kw, n=200, n_win=3):
+    """Agents that act at EVERY step (one single-step launch per env step, a new redispatch +-1 MW and storage action per lane and
+    step): (a) actions handed over from the host (`set_lane_actions`: PCIe upload + synchronisation per step), (b) written on the
+    device into the engine's action buffers by torch ops on the engine's stream (`lane_actions_on_device`: nothing crosses PCIe)."""
+    torch = ctx.torch
+    if torch is None or not ctx.cuda_ok() or not hasattr(eng, "lane_actions_on_device"):
+        return None
+    B = red.shape[0]
+    v = eng.device_views()
+    dev = v["act_redispatch"].device
+    red_pm = [red, -red]
+    red_dev = [torch.from_numpy(a).to(dev) for a in red_pm]
+    sto_dev = torch.from_numpy(sto).to(dev)
+
+    def run(on_device, t0, k_steps):
+        for k in range(k_steps):
+            if on_device:
+                with torch.cuda.stream(v["stream"]):
+                    v["act_redispatch"].copy_(red_dev[k % 2])
+                    v["act_storage"].copy_(sto_dev)
+                eng.lane_actions_on_device(redispatch=True, storage_power=True)
+            else:
+                eng.set_lane_actions(red_pm[k % 2], sto)
+            eng.step(t0 + k, n_steps=1, **kw)
+        return t0 + k_steps
+    res = {}
+    for label, on_device in (("host_actions", False), ("device_actions", True)):
+        t = run(on_device, t, 20)
+        wins = []
+        for _ in range(n_win):
+            ctx.sync_all(eng)
+            w0 = time.perf_counter()
+            t = run(on_device, t, n)
+            ctx.sync_all(eng)
+            wins.append((ctx.max(time.perf_counter() - w0), 0.0, 0))
+        res[label] = dict(summarize(wins, ctx.world * B * n), us_per_step=median_window(wins)[0] / n * 1e6)
+    res["what"] = ("one single-step launch per env step, a new redispatch + storage action per lane and step; host_actions: set_lane_actions "
+                   "(PCIe + synchronisation per step), device_actions: torch copies into device_views()['act_*'] on the engine's stream + "
+                   "lane_actions_on_device (no PCIe, no synchronisation)")
+    return res
+
+
 def workload_wcci_dynamics(ctx, env, n_envs, k_sec, w_sec):
     """configs[3] with gpf_set_env_dynamics: every lane holds a storage action U(-2, 2) MW per unit over the launch and starts it with a
     zero-sum +-1 MW redispatch on two generators; the kernel evolves the state of charge and re-solves the ramp-limited dispatch
@@ -1170,6 +1218,7 @@ def workload_wcci_dynamics(ctx, env, n_envs, k_sec, w_sec):
     med = median_window(wins)[0]
     r = eng.results()
     st = eng.env_state()
+    acting = acting_every_step(ctx, eng, m, red, sto, t, kw)
     out = None
     if ctx.rank == 0:
         out = {"workload": f"{env} (118 substations), batch={B} lanes per GPU, environment injection dynamics ON (gpf_set_env_dynamics): per lane a "
@@ -1181,6 +1230,7 @@ def workload_wcci_dynamics(ctx, env, n_envs, k_sec, w_sec):
                "windows": summarize(wins, ctx.world * B * k_sec), "frac_converged": float(r.converged.mean()),
                "frac_infeasible_redispatch": float((r.status[:, 0] == 6).mean()),
                "mean_abs_actual_dispatch_mw": float(np.abs(st["actual"]).mean()), "mean_state_of_charge_mwh": float(st["charge"].mean()),
+               "acting_every_step": acting,
                "oracle_check": oracle_spot_check(ctx, eng, 32, seed=7, alive_only=True)}
     eng.close()
     return out

@@ -1855,6 +1855,21 @@ int gpf_set_lane_actions(gpf_handle e, const float* redispatch, const float* sto
   return GPF_OK;
 }
 
+int gpf_lane_actions_on_device(gpf_handle e, int32_t redispatch, int32_t storage_power, int32_t curtailment, int32_t hold_storage) {
+  if (!e) return fail(GPF_E_INVALID, "gpf_lane_actions_on_device: null");
+  if (!e->env_on) return fail(GPF_E_INVALID, "gpf_lane_actions_on_device: the environment dynamics are off (gpf_set_env_dynamics)");
+  if (curtailment && !e->env_has_ren) return fail(GPF_E_INVALID, "gpf_lane_actions_on_device: curtailment needs gpf_set_gen_renewable");
+  HIP_TRY(hipSetDevice(e->device));
+  // a buffer that held an action of the host path and is now declared empty is cleared, as gpf_set_lane_actions(NULL) does
+  if (redispatch) e->env_act_r = true;
+  else if (e->env_act_r) { HIP_TRY(hipMemsetAsync(e->env_act_redisp.p, 0, e->env_act_redisp.n * sizeof(float), e->stream)); e->env_act_r = false; }
+  if (storage_power && e->g.n_sto) e->env_act_s = true;
+  else if (e->env_act_s) { HIP_TRY(hipMemsetAsync(e->env_act_storage.p, 0, e->env_act_storage.n * sizeof(float), e->stream)); e->env_act_s = false; }
+  e->env_act_c = curtailment != 0;
+  e->env_hold = hold_storage != 0;
+  return GPF_OK;
+}
+
 int gpf_set_gen_renewable(gpf_handle e, const uint8_t* renewable) {
   if (!e) return fail(GPF_E_INVALID, "gpf_set_gen_renewable: null");
   HIP_TRY(hipSetDevice(e->device));
@@ -2873,6 +2888,9 @@ int gpf_device_pointers_n(gpf_handle e, void** out, int32_t n_ptrs, void** strea
   const bool obs = e->traj_cap && (e->traj_what & GPF_TRAJ_OBS);
   ptrs[18] = obs ? e->traj_out.p : nullptr; ptrs[19] = obs ? e->traj_topo.p : nullptr; ptrs[20] = obs ? e->traj_shb.p : nullptr;
   ptrs[21] = obs ? e->traj_lstat.p : nullptr;
+  ptrs[22] = e->env_on ? e->env_act_redisp.p : nullptr; ptrs[23] = e->env_on ? e->env_act_storage.p : nullptr;
+  ptrs[24] = e->env_on ? e->env_act_curtail.p : nullptr; ptrs[25] = e->env_on ? e->env_target.p : nullptr;
+  ptrs[26] = e->env_on ? e->env_actual.p : nullptr; ptrs[27] = e->env_on ? e->env_charge.p : nullptr;
   for (int i = 0; i < n_ptrs; ++i) out[i] = i < GPF_N_DEVICE_POINTERS ? ptrs[i] : nullptr;     // never writes beyond the caller's array
   if (stream) *stream = e->stream;
   return GPF_OK;

@@ -525,6 +525,15 @@ class PowerFlowEngine:
             np.ascontiguousarray(storage_power, dtype=np.float32).reshape(self.n_lanes, self.model.n_storage)
         check(self._lib.gpf_set_lane_actions(self._h, ptr(r, C.c_float), ptr(s_, C.c_float), int(bool(hold_storage))), "gpf_set_lane_actions")
 
+    def lane_actions_on_device(self, redispatch: bool = False, storage_power: bool = False, curtailment: bool = False,
+                               hold_storage: bool = False):
+        """The actions of the NEXT launch were written ON THE DEVICE, into ``device_views()["act_redispatch" / "act_storage" /
+        "act_curtail"]`` (on ``views["stream"]`` or ordered before the launch): say which buffers hold an action.  Same semantics as
+        `set_lane_actions` / `set_lane_curtailment`, no PCIe transfer, no synchronisation -- the hand-over of an agent that lives next
+        to the engine (curtailment ratios are NOT range-checked on this path)."""
+        check(self._lib.gpf_lane_actions_on_device(self._h, int(bool(redispatch)), int(bool(storage_power)), int(bool(curtailment)),
+                                                   int(bool(hold_storage))), "gpf_lane_actions_on_device")
+
     def set_gen_renewable(self, renewable):
         """``gen_renewable`` mask (curtailment only acts on these generators); None switches curtailment off."""
         r = None if renewable is None else np.ascontiguousarray(renewable, dtype=np.uint8).reshape(self.model.n_gen)
@@ -624,12 +633,14 @@ class PowerFlowEngine:
         """The engine's result buffers as torch tensors that ALIAS the device memory (no copy, no PCIe): ``out`` float32
         ``[n_lanes, n_out]`` (columns: `out_slices`), ``rho`` ``[n_lanes, n_line]``, ``status`` int32 ``[n_lanes, 4]``,
         ``topo_vect``, ``line_status`` uint8, ``overflow_count``, ``done`` uint8, ``episode`` int32 ``[n_lanes, 2]``, ``inj``
-        float64, ``bus_vm`` / ``bus_va`` float64.  The engine works on its own HIP stream: call `sync` (or make the consumer's
+        float64, ``bus_vm`` / ``bus_va`` float64; with the environment dynamics on also the action buffers ``act_redispatch`` /
+        ``act_curtail`` ``[n_lanes, n_gen]``, ``act_storage`` ``[n_lanes, n_storage]`` (`lane_actions_on_device`) and
+        ``target_dispatch`` / ``actual_dispatch`` / ``storage_charge`` float32 (obs.target_dispatch, ...).  The engine works on its own HIP stream: call `sync` (or make the consumer's
         stream wait on ``views["stream"]``, a ``torch.cuda.ExternalStream``) before reading."""
         import torch
-        ptrs = (C.c_void_p * 22)()
+        ptrs = (C.c_void_p * 28)()
         stream = C.c_void_p()
-        check(self._lib.gpf_device_pointers_n(self._h, ptrs, 22, C.byref(stream)), "gpf_device_pointers_n")
+        check(self._lib.gpf_device_pointers_n(self._h, ptrs, 28, C.byref(stream)), "gpf_device_pointers_n")
         cap = self._lib.gpf_lane_capacity(self._h)
         m = self.model
         dev = torch.device("cuda", self.device)
@@ -648,7 +659,10 @@ class PowerFlowEngine:
              "topo_vect": view(4, m.dim_topo, "<i4"), "line_status": view(5, m.n_line, "|u1"), "status": view(6, 4, "<i4"),
              "rho": view(8, m.n_line, "<f4"), "overflow_count": view(9, m.n_line, "<i4"), "done": view(10, 1, "|u1"),
              "episode": view(11, 2, "<i4"), "bus_vm": view(12, self.nb_total, "<f8"), "bus_va": view(13, self.nb_total, "<f8"),
-             "disc_round": view(15, m.n_line, "<i4")}
+             "disc_round": view(15, m.n_line, "<i4"),
+             "act_redispatch": view(22, m.n_gen, "<f4"), "act_storage": view(23, m.n_storage, "<f4"), "act_curtail": view(24, m.n_gen, "<f4"),
+             "target_dispatch": view(25, m.n_gen, "<f4"), "actual_dispatch": view(26, m.n_gen, "<f4"),
+             "storage_charge": view(27, m.n_storage, "<f4")}
 
         def tview(idx, cols, typestr):       # trajectory buffers: [cap_steps][cap][cols]
             if cols == 0 or not ptrs[idx] or not getattr(self, "_traj_cap", 0):

@@ -316,6 +316,11 @@ class ShardedEngine:
             cut = lambda a: None if a is None else np.asarray(a)[b0:b0 + bn]  # noqa: E731
             eng.set_lane_actions(cut(redispatch), cut(storage_power), hold_storage)
 
+    def lane_actions_on_device(self, *a, **kw):
+        """every device's action buffers (`device_views()[k]["act_*"]`) hold the next launch's actions of its own lanes"""
+        for eng in self.engines:
+            eng.lane_actions_on_device(*a, **kw)
+
     def set_gen_renewable(self, renewable):
         for eng in self.engines:
             eng.set_gen_renewable(renewable)

@@ -103,8 +103,9 @@ typedef struct gpf_layout {
 const char* gpf_last_error(void);
 /* ABI version of the library = GPF_ABI_VERSION of the header it was built from.  A binding MUST compare the two before any other
  * call (grid2op_amd/_capi.py does): 300 = round 4 (gpf_set_trajectory(h, cap, what), 22 device pointers, GPF_ST_REDISPATCH,
- * gpf_device_pointers_n); 310 = + gpf_jit_*, GPF_E_UNSUPPORTED, gpf_set_profiling mode 3. */
-#define GPF_ABI_VERSION 320
+ * gpf_device_pointers_n); 310 = + gpf_jit_*, GPF_E_UNSUPPORTED, gpf_set_profiling mode 3; 321 = 28 device pointers (action buffers and
+ * dispatch / charge state of the environment dynamics), gpf_lane_actions_on_device. */
+#define GPF_ABI_VERSION 321
 int gpf_version(void);
 /* Bitwise run-to-run reproducibility is the DEFAULT on every grid: the same lane inputs give bit-identical results from run to
  * run and whatever the lane's position in the batch (grid2op's determinism contract: same seeds -> same episode,
@@ -294,6 +295,13 @@ int gpf_set_storage_params(gpf_handle h, const double* emax, const double* emin,
                            const double* eff_discharge, const float* charge0, double delta_time_seconds, int32_t activate_loss);
 int gpf_set_env_dynamics(gpf_handle h, int32_t on, double tol_poly);
 int gpf_set_lane_actions(gpf_handle h, const float* redispatch, const float* storage_power, int32_t hold_storage);
+/* The same hand-over for agents that live ON THE DEVICE (a policy network next to the engine): the caller has written the actions of
+ * the next launch into the engine's own action buffers -- gpf_device_pointers_n entries 22 (redispatch [lanes][n_gen] MW), 23 (storage
+ * power [lanes][n_storage] MW), 24 (curtailment [lanes][n_gen], ratios in [0, 1] or -1: NOT validated here) -- on the engine's stream
+ * or ordered before the next launch; the flags say which of them hold an action (the others count as "none").  Nothing crosses PCIe,
+ * nothing is synchronised.  Consumption is as for gpf_set_lane_actions / gpf_set_lane_curtailment: the launch's first step takes the
+ * actions, then the redispatch buffer (and the storage buffer unless hold_storage) is zeroed behind the launch. */
+int gpf_lane_actions_on_device(gpf_handle h, int32_t redispatch, int32_t storage_power, int32_t curtailment, int32_t hold_storage);
 int gpf_set_gen_renewable(gpf_handle h, const uint8_t* renewable);
 int gpf_set_lane_curtailment(gpf_handle h, const float* limit);
 int gpf_get_env_state(gpf_handle h, int32_t lane0, int32_t n, float* target, float* actual, float* prev_p, uint8_t* already_modified,
@@ -447,8 +455,11 @@ int gpf_get_plan(gpf_handle h, int32_t out[8]);
  * torch tensors).  ptrs[0..21] = inj, topo, shunt_bus, out, topo_vect, line_status, status, chronics, rho, overflow_count, done,
  * episode, bus_vm, bus_va, shunt_bus_out, disc_round, then the trajectory buffers (NULL when not set): traj_rho, traj_status,
  * traj_out, traj_topo_vect, traj_shunt_bus, traj_line_status (rows are padded to gpf_lane_capacity lanes; trajectory buffers are
- * [cap][gpf_lane_capacity][row]); stream = hipStream_t */
-#define GPF_N_DEVICE_POINTERS 22
+ * [cap][gpf_lane_capacity][row]); 22..27 = the environment dynamics (NULL while they are off): the action buffers redispatch
+ * [lanes][n_gen], storage power [lanes][n_storage], curtailment [lanes][n_gen] (gpf_lane_actions_on_device), then target dispatch,
+ * actual dispatch [lanes][n_gen] and state of charge [lanes][n_storage] (obs.target_dispatch / actual_dispatch / storage_charge);
+ * stream = hipStream_t */
+#define GPF_N_DEVICE_POINTERS 28
 int gpf_device_pointers(gpf_handle h, void** ptrs /* [GPF_N_DEVICE_POINTERS] */, void** stream);
 /* The same with the length of the caller's array: entries beyond n_ptrs are not written, entries beyond the library's count are
  * NULL -- a caller built against an older / newer header cannot be overrun. */

@@ -311,3 +311,72 @@ def test_sharded_copy_lanes_across_devices_carries_the_dynamics_state(load_model
         assert np.array_equal(s1[k], s2[k]), k
     one.close()
     se.close()
+
+
+@pytest.mark.parametrize("name,curtail", [("educ_case14_storage", False), ("l2rpn_wcci_2022_dev", True)])
+def test_actions_written_on_the_device_between_single_step_launches(name, curtail, load_model, load_npz):
+    """An agent that lives on the device acts at EVERY step: it writes its redispatch / storage / curtailment actions into the engine's
+    own action buffers (`device_views()["act_*"]`, on the engine's stream) and says so with `lane_actions_on_device`; nothing crosses
+    PCIe.  Eight single-step launches with a new action per lane and step must leave exactly the rows, the dynamics state and the
+    observable dispatch / charge views that the host hand-over (`set_lane_actions` / `set_lane_curtailment`) leaves on a twin engine --
+    incl. steps without redispatch (flag off: the buffer counts as empty), a held storage action, and one 3-step launch."""
+    import torch
+    m = load_model(name)
+    fx = load_npz(f"envdyn_{name}.npz")
+    B = 37
+    host, dev = _engine(m, fx, B), _engine(m, fx, B)
+    rng = np.random.default_rng(5)
+    off = rng.integers(0, 6, B).astype(np.int32)
+    for e in (host, dev):
+        e.set_lane_chronics(lane_offset=off)
+    v = dev.device_views()
+    assert v["act_redispatch"].shape == (B, m.n_gen) and v["act_redispatch"].dtype == torch.float32
+    assert (v["act_storage"] is None) == (m.n_storage == 0)
+    disp = np.nonzero(fx["redispatchable"])[0]
+    ren = np.nonzero(fx["renewable"])[0] if curtail and "renewable" in fx else np.zeros(0, int)
+    t = 1
+    for k_launch, n_steps in enumerate([1, 1, 1, 1, 3, 1, 1, 1]):
+        with_red = k_launch not in (2, 5)                     # two launches carry no redispatch at all
+        hold = k_launch == 4                                  # the 3-step launch holds its storage action
+        red = np.zeros((B, m.n_gen), np.float32)
+        sto = rng.uniform(-3.0, 3.0, (B, m.n_storage)).astype(np.float32)
+        cur = np.full((B, m.n_gen), -1.0, np.float32)
+        for k in range(B):
+            if with_red and rng.random() < 0.7:
+                g2 = rng.choice(disp, 2, replace=False)
+                amp = np.float32(fx["ramp_up"][g2[0]] * rng.uniform(0.05, 0.3))
+                red[k, g2[0]], red[k, g2[1]] = amp, -amp
+            if ren.size and rng.random() < 0.3:
+                cur[k, rng.choice(ren)] = np.float32(rng.uniform(0.3, 1.0))
+        # host hand-over
+        host.set_lane_actions(red if with_red else None, sto if m.n_storage else None, hold_storage=hold)
+        if ren.size:
+            host.set_lane_curtailment(cur)
+        host.step(t, n_steps=n_steps)
+        # device hand-over: the "agent" writes on the engine's stream
+        with torch.cuda.stream(v["stream"]):
+            if with_red:
+                v["act_redispatch"].copy_(torch.from_numpy(red).to(v["act_redispatch"].device, non_blocking=False))
+            if m.n_storage:
+                v["act_storage"].copy_(torch.from_numpy(sto).to(v["act_storage"].device))
+            if ren.size:
+                v["act_curtail"].copy_(torch.from_numpy(cur).to(v["act_curtail"].device))
+        dev.lane_actions_on_device(redispatch=with_red, storage_power=bool(m.n_storage), curtailment=bool(ren.size), hold_storage=hold)
+        dev.step(t, n_steps=n_steps)
+        rh, rd = host.results(), dev.results()
+        assert np.array_equal(rh.status, rd.status) and np.array_equal(rh.out, rd.out, equal_nan=True), k_launch
+        sh, sd = host.env_state(), dev.env_state()
+        for key in sh:
+            assert np.array_equal(sh[key], sd[key]), (k_launch, key)
+        dev.sync()
+        assert np.array_equal(v["target_dispatch"].cpu().numpy(), sd["target"]) and np.array_equal(v["actual_dispatch"].cpu().numpy(), sd["actual"])
+        if m.n_storage:
+            assert np.array_equal(v["storage_charge"].cpu().numpy(), sd["charge"])
+        t += n_steps
+    assert host.results().converged.sum() > B // 2 and np.abs(host.env_state()["actual"]).max() > 0.1
+    # with the dynamics off the action views are gone and the call is refused
+    dev.set_env_dynamics(False)
+    assert dev.device_views()["act_redispatch"] is None
+    with pytest.raises(Exception, match="dynamics are off"):
+        dev.lane_actions_on_device(redispatch=True)
+    host.close(); dev.close()
