@@ -1791,8 +1791,10 @@ int gpf_step_n(gpf_handle e, int32_t t0, int32_t n_steps, const gpf_step_opts* o
   if (rc != GPF_OK) return rc;
   e->traj_valid = e->traj_cap ? n_steps : 0;
   if (e->env_on) {                          // the actions were consumed by this launch (a held storage action stays)
-    if (e->env_act_r) { HIP_TRY(hipMemsetAsync(e->env_act_redisp.p, 0, e->env_act_redisp.n * sizeof(float), e->stream)); e->env_act_r = false; }
-    if (e->env_act_s && !e->env_hold) { HIP_TRY(hipMemsetAsync(e->env_act_storage.p, 0, e->env_act_storage.n * sizeof(float), e->stream)); e->env_act_s = false; }
+    // (the kernels only read an action buffer whose flag is set -- EnvDyn::act_* is NULL otherwise --, so "consumed" is the flag: no
+    //  clearing dispatch behind every launch of an agent that acts at every step)
+    e->env_act_r = false;
+    if (!e->env_hold) e->env_act_s = false;
     e->env_act_c = false;                   // (the curtailment limits live on in the lanes' state)
   }
   return GPF_OK;
@@ -1847,9 +1849,9 @@ int gpf_set_lane_actions(gpf_handle e, const float* redispatch, const float* sto
   HIP_TRY(hipSetDevice(e->device));
   const size_t B = e->n_lanes, ng = e->g.n_gen, ns = e->g.n_sto;
   if (redispatch) { HIP_TRY(hipMemcpyAsync(e->env_act_redisp.p, redispatch, B * ng * sizeof(float), hipMemcpyHostToDevice, e->stream)); e->env_act_r = true; }
-  else if (e->env_act_r) { HIP_TRY(hipMemsetAsync(e->env_act_redisp.p, 0, e->env_act_redisp.n * sizeof(float), e->stream)); e->env_act_r = false; }
+  else e->env_act_r = false;
   if (storage_power && ns) { HIP_TRY(hipMemcpyAsync(e->env_act_storage.p, storage_power, B * ns * sizeof(float), hipMemcpyHostToDevice, e->stream)); e->env_act_s = true; }
-  else if (e->env_act_s) { HIP_TRY(hipMemsetAsync(e->env_act_storage.p, 0, e->env_act_storage.n * sizeof(float), e->stream)); e->env_act_s = false; }
+  else e->env_act_s = false;
   e->env_hold = hold_storage != 0;
   HIP_TRY(hipStreamSynchronize(e->stream));
   return GPF_OK;
@@ -1860,11 +1862,8 @@ int gpf_lane_actions_on_device(gpf_handle e, int32_t redispatch, int32_t storage
   if (!e->env_on) return fail(GPF_E_INVALID, "gpf_lane_actions_on_device: the environment dynamics are off (gpf_set_env_dynamics)");
   if (curtailment && !e->env_has_ren) return fail(GPF_E_INVALID, "gpf_lane_actions_on_device: curtailment needs gpf_set_gen_renewable");
   HIP_TRY(hipSetDevice(e->device));
-  // a buffer that held an action of the host path and is now declared empty is cleared, as gpf_set_lane_actions(NULL) does
-  if (redispatch) e->env_act_r = true;
-  else if (e->env_act_r) { HIP_TRY(hipMemsetAsync(e->env_act_redisp.p, 0, e->env_act_redisp.n * sizeof(float), e->stream)); e->env_act_r = false; }
-  if (storage_power && e->g.n_sto) e->env_act_s = true;
-  else if (e->env_act_s) { HIP_TRY(hipMemsetAsync(e->env_act_storage.p, 0, e->env_act_storage.n * sizeof(float), e->stream)); e->env_act_s = false; }
+  e->env_act_r = redispatch != 0;
+  e->env_act_s = storage_power != 0 && e->g.n_sto > 0;
   e->env_act_c = curtailment != 0;
   e->env_hold = hold_storage != 0;
   return GPF_OK;

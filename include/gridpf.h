@@ -300,7 +300,7 @@ int gpf_set_lane_actions(gpf_handle h, const float* redispatch, const float* sto
  * power [lanes][n_storage] MW), 24 (curtailment [lanes][n_gen], ratios in [0, 1] or -1: NOT validated here) -- on the engine's stream
  * or ordered before the next launch; the flags say which of them hold an action (the others count as "none").  Nothing crosses PCIe,
  * nothing is synchronised.  Consumption is as for gpf_set_lane_actions / gpf_set_lane_curtailment: the launch's first step takes the
- * actions, then the redispatch buffer (and the storage buffer unless hold_storage) is zeroed behind the launch. */
+ * actions; afterwards the redispatch buffer (and the storage buffer unless hold_storage) counts as empty until declared again. */
 int gpf_lane_actions_on_device(gpf_handle h, int32_t redispatch, int32_t storage_power, int32_t curtailment, int32_t hold_storage);
 int gpf_set_gen_renewable(gpf_handle h, const uint8_t* renewable);
 int gpf_set_lane_curtailment(gpf_handle h, const float* limit);
