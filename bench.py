@@ -720,7 +720,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; default) or gloo")
     ap.add_argument("--only-env-dynamics", action="store_true",
                     help="developer (profiling): run only the 118-substation workload with the injection dynamics on and print its record")
-    ap.add_argument("--only", default=None, choices=["n1_fanout", "n1_fanout_118", "secondary", "dc_ptdf", "secondary_env_dynamics", "ptdf_build_batch"],
+    ap.add_argument("--only", default=None, choices=["n1_fanout", "n1_fanout_118", "secondary", "dc_ptdf", "secondary_env_dynamics", "ptdf_build_batch", "simulate"],
                     help="developer (profiling): run only that BASELINE config's workload exactly as the default run does and print its record")
     ap.add_argument("--profile", action="store_true",
                     help="developer (rocprofv3 runs): no pre-roll launches of odd sizes and no last-observation-only sibling windows, so that "
@@ -758,7 +758,8 @@ def main():
                "secondary_env_dynamics": lambda: workload_wcci_dynamics(ctx, "l2rpn_wcci_2022_dev", 1024, k_o, w_o),
                "dc_ptdf": lambda: workload_ptdf(ctx, "l2rpn_idf_2023", 2048, 50, k_sec=k_o, w_sec=w_o),
                "n1_fanout_118": lambda: workload_n1(ctx, "l2rpn_wcci_2022_dev", 1024, k_sec=2 * N1_118_SPL, profile=TRAFFIC_N1_118, spl=N1_118_SPL),
-               "ptdf_build_batch": lambda: workload_ptdf_build_batch(ctx, "l2rpn_idf_2023", 2048, 256)}[args.only]()
+               "ptdf_build_batch": lambda: workload_ptdf_build_batch(ctx, "l2rpn_idf_2023", 2048, 256),
+               "simulate": lambda: workload_simulate(ctx, args.env, 256, 16)}[args.only]()
         if rank == 0:
             rec["specialization"] = ctx.specialization()
             print(json.dumps(rec))

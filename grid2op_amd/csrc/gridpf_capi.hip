@@ -236,6 +236,8 @@ struct gpf_engine {
   DevArr<float> forecast;               // [chron_tables][chron_T][fc_h][n_chron] *_forecasted tables (gpf_upload_forecasts), or empty
   int fc_h = 0;
   DevArr<int> sim_src, sim_rows;        // gpf_simulate_batch staging: source lane list, gathered topology rows
+  int* sim_pin = nullptr;               // its pinned host block (grow-only): gathered source rows | candidate topology rows | candidate shunt rows
+  size_t sim_pin_n = 0;
   DevArr<signed char> traj_status;
   DevArr<float> traj_out;               // per-step observation trajectory (GPF_TRAJ_OBS): [traj_cap][cap_lanes][n_out] ...
   DevArr<int> traj_topo, traj_shb;
@@ -1236,6 +1238,7 @@ int gpf_destroy(gpf_handle e) {
   e->lane_scale.release(); e->thermal_limit.release(); e->rho.release(); e->line_status.release();
   e->d_init_inj.release(); e->d_init_topo.release(); e->d_init_shunt_bus.release();
   if (e->pin) (void)hipHostFree(e->pin);
+  if (e->sim_pin) (void)hipHostFree(e->sim_pin);
   e->maint.release(); e->forecast.release(); e->sim_src.release(); e->sim_rows.release();
   e->env_target.release(); e->env_actual.release(); e->env_prev.release(); e->env_charge.release(); e->env_amount_prev.release();
   e->env_act_redisp.release(); e->env_act_storage.release(); e->sto_charge0.release(); e->env_already.release(); e->env_fresh.release();
@@ -1286,21 +1289,27 @@ int gpf_set_injections(gpf_handle e, int32_t lane0, int32_t n, const double* inj
   return GPF_OK;
 }
 
-int gpf_set_topology(gpf_handle e, int32_t lane0, int32_t n, const int32_t* topo, const int32_t* shunt_bus) {
-  if (!check_range(e, lane0, n) || !topo) return fail(GPF_E_INVALID, "gpf_set_topology: bad range");
-  HIP_TRY(hipSetDevice(e->device));
+}  // extern "C"
+namespace {
+// gpf_set_topology.  `engine_rows`: the rows were built by the library itself in its own PINNED block (gpf_simulate_batch: validated
+// action items applied to rows that came from the device) -- no validation pass, the uploads are true asynchronous DMA and nothing is
+// waited for (the block stays untouched until the stream has drained: the next user of it synchronises first).
+int set_topology_rows(gpf_engine* e, int32_t lane0, int32_t n, const int32_t* topo, const int32_t* shunt_bus, bool engine_rows) {
   const gpf::GridDev& g = e->g;
-  // validate BOTH arrays before anything is queued: a rejected call leaves the device state and the host mirror untouched
-  auto bad_bus = [&g](int v) { return v == 0 || v < -1 || v > g.n_busbar; };
-  for (size_t i = 0; i < (size_t)n * g.dim_topo; ++i)
-    if (bad_bus(topo[i])) return fail(GPF_E_INVALID, "gpf_set_topology: local bus ids must be -1 or 1..n_busbar");
-  if (shunt_bus && g.n_shunt)
-    for (size_t i = 0; i < (size_t)n * g.n_shunt; ++i)
-      if (bad_bus(shunt_bus[i])) return fail(GPF_E_INVALID, "gpf_set_topology: shunt bus ids must be -1 or 1..n_busbar");
+  if (!engine_rows) {
+    // validate BOTH arrays before anything is queued: a rejected call leaves the device state and the host mirror untouched
+    auto bad_bus = [&g](int v) { return v == 0 || v < -1 || v > g.n_busbar; };
+    for (size_t i = 0; i < (size_t)n * g.dim_topo; ++i)
+      if (bad_bus(topo[i])) return fail(GPF_E_INVALID, "gpf_set_topology: local bus ids must be -1 or 1..n_busbar");
+    if (shunt_bus && g.n_shunt)
+      for (size_t i = 0; i < (size_t)n * g.n_shunt; ++i)
+        if (bad_bus(shunt_bus[i])) return fail(GPF_E_INVALID, "gpf_set_topology: shunt bus ids must be -1 or 1..n_busbar");
+  }
   HIP_TRY(hipMemcpyAsync(e->topo.p + (size_t)lane0 * g.dim_topo, topo, (size_t)n * g.dim_topo * sizeof(int),
                          hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipMemcpyAsync(e->topo0.p + (size_t)lane0 * g.dim_topo, topo, (size_t)n * g.dim_topo * sizeof(int),
-                         hipMemcpyHostToDevice, e->stream));
+  // the rows an auto-reset restores: copied on the device from the rows just uploaded (not a second trip over PCIe)
+  HIP_TRY(hipMemcpyAsync(e->topo0.p + (size_t)lane0 * g.dim_topo, e->topo.p + (size_t)lane0 * g.dim_topo, (size_t)n * g.dim_topo * sizeof(int),
+                         hipMemcpyDeviceToDevice, e->stream));
   std::vector<int> sb_host;
   if (shunt_bus && g.n_shunt) {
     HIP_TRY(hipMemcpyAsync(e->shunt_bus.p + (size_t)lane0 * g.n_shunt, shunt_bus, (size_t)n * g.n_shunt * sizeof(int),
@@ -1310,7 +1319,7 @@ int gpf_set_topology(gpf_handle e, int32_t lane0, int32_t n, const int32_t* topo
     HIP_TRY(hipMemcpyAsync(sb_host.data(), e->shunt_bus.p + (size_t)lane0 * g.n_shunt, sb_host.size() * sizeof(int),
                            hipMemcpyDeviceToHost, e->stream));
   }
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (!engine_rows || !sb_host.empty()) HIP_TRY(hipStreamSynchronize(e->stream));
   bool changed = false;
   for (int k = 0; k < n; ++k) {
     const int* t = topo + (size_t)k * g.dim_topo;
@@ -1328,6 +1337,14 @@ int gpf_set_topology(gpf_handle e, int32_t lane0, int32_t n, const int32_t* topo
   }
   if (changed) e->plan_valid = false;
   return GPF_OK;
+}
+}  // namespace
+extern "C" {
+
+int gpf_set_topology(gpf_handle e, int32_t lane0, int32_t n, const int32_t* topo, const int32_t* shunt_bus) {
+  if (!check_range(e, lane0, n) || !topo) return fail(GPF_E_INVALID, "gpf_set_topology: bad range");
+  HIP_TRY(hipSetDevice(e->device));
+  return set_topology_rows(e, lane0, n, topo, shunt_bus, false);
 }
 
 int gpf_get_injections(gpf_handle e, int32_t lane0, int32_t n, double* inj) {
@@ -1761,8 +1778,13 @@ void apply_topo_action(const gpf_engine* e, int* row, int* sb, const int* last, 
     const int l = items[3 * k + 1], v = items[3 * k + 2];
     if (v < 0) disco(l); else if (v > 0) reco(l);
   }
-  std::vector<int> or_before(g.n_line), ex_before(g.n_line);
-  for (int l = 0; l < g.n_line; ++l) { or_before[l] = row[e->h_line_or_pos[l]]; ex_before[l] = row[e->h_line_ex_pos[l]]; }
+  bool any_bus = false;                                         // (the line ends "before" are only needed by rule V)
+  for (int k = 0; k < n_items && !any_bus; ++k) any_bus = items[3 * k] == GPF_ACT_CHANGE_BUS || (items[3 * k] == GPF_ACT_SET_BUS && items[3 * k + 2] != 0);
+  static thread_local std::vector<int> or_before, ex_before;
+  if (any_bus) {
+    or_before.resize(g.n_line); ex_before.resize(g.n_line);
+    for (int l = 0; l < g.n_line; ++l) { or_before[l] = row[e->h_line_or_pos[l]]; ex_before[l] = row[e->h_line_ex_pos[l]]; }
+  }
   // IV change_bus, then set_bus
   bool bus_modif = false;
   for (int k = 0; k < n_items; ++k) if (items[3 * k] == GPF_ACT_CHANGE_BUS) { int& v = row[items[3 * k + 1]]; if (v > 0) v = (1 - v) + 2; bus_modif = true; }
@@ -1984,6 +2006,9 @@ int gpf_simulate_batch(gpf_handle e, int32_t t_obs, int32_t time_step, int32_t n
       return fail(GPF_E_INVALID, "gpf_simulate_batch: bad action item (kind, id or bus; change_bus needs exactly 2 busbars per substation)");
   }
   HIP_TRY(hipSetDevice(e->device));
+  static const bool sim_timing = getenv("GRIDPF_SIM_TIMING") != nullptr;        // developer: stage times of the call on stderr
+  auto now_us = [] { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() * 1e-3; };
+  const double tm0 = sim_timing ? now_us() : 0.0;
   // 1. the source lanes' topology / shunt rows as they are on the device NOW (trips and maintenance included) -> host
   const int w = g.dim_topo + g.n_shunt;
   if (e->sim_src.n < (size_t)n_src) { e->sim_src.release(); HIP_TRY(e->sim_src.alloc((size_t)n_src)); }
@@ -1991,11 +2016,24 @@ int gpf_simulate_batch(gpf_handle e, int32_t t_obs, int32_t time_step, int32_t n
   HIP_TRY(hipMemcpyAsync(e->sim_src.p, src_lanes, (size_t)n_src * sizeof(int), hipMemcpyHostToDevice, e->stream));
   hipLaunchKernelGGL(gpf::gather_topo_kernel, dim3(n_src), dim3(64), 0, e->stream, e->g, e->bufs(), e->sim_src.p, n_src, e->sim_rows.p);
   HIP_TRY(hipGetLastError());
-  std::vector<int> rows((size_t)n_src * w);
-  HIP_TRY(hipMemcpyAsync(rows.data(), e->sim_rows.p, rows.size() * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  // one pinned host block for the rows that cross PCIe in this call (true DMA both ways, no zero-filled vectors): the gathered source
+  // rows, then the candidate topology / shunt rows.  It is only rewritten after the synchronisation below, i.e. when the uploads of
+  // the previous call have long been consumed.
+  const size_t n_rows = (size_t)n_src * w, n_topo = (size_t)n_dst * g.dim_topo, n_sb = (size_t)n_dst * std::max(g.n_shunt, 1);
+  if (e->sim_pin_n < n_rows + n_topo + n_sb) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->sim_pin) (void)hipHostFree(e->sim_pin);
+    e->sim_pin = nullptr; e->sim_pin_n = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->sim_pin), (n_rows + n_topo + n_sb) * sizeof(int), hipHostMallocDefault));
+    e->sim_pin_n = n_rows + n_topo + n_sb;
+  }
+  int* const rows = e->sim_pin;
+  HIP_TRY(hipMemcpyAsync(rows, e->sim_rows.p, n_rows * sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  const double tm1 = sim_timing ? now_us() : 0.0;
   // 2. candidate topologies on the host (the launch planner needs them anyway: busbars per substation, topology classes)
-  std::vector<int> topo((size_t)n_dst * g.dim_topo), sb((size_t)n_dst * std::max(g.n_shunt, 1));
+  int* const topo = e->sim_pin + n_rows;
+  int* const sb = topo + n_topo;
   // Scheduled maintenance ahead of the observation (_ObsEnv.init, Environment/_obsEnv.py:361-385 with
   // BaseEnv._update_vector_with_timestep, baseEnv.py:4768-4825): a forecast `time_step` >= 1 steps ahead has the lines out whose
   // NEXT maintenance (the one obs.time_next_maintenance / duration_next_maintenance describe: the first flagged row from the
@@ -2022,16 +2060,18 @@ int gpf_simulate_batch(gpf_handle e, int32_t t_obs, int32_t time_step, int32_t n
   }
   for (int b = 0; b < n_src; ++b)
     for (int k = 0; k < n_act; ++k) {
-      int* row = topo.data() + ((size_t)b * n_act + k) * g.dim_topo;
-      int* srow = sb.data() + ((size_t)b * n_act + k) * std::max(g.n_shunt, 1);
-      std::memcpy(row, rows.data() + (size_t)b * w, (size_t)g.dim_topo * sizeof(int));
-      if (g.n_shunt) std::memcpy(srow, rows.data() + (size_t)b * w + g.dim_topo, (size_t)g.n_shunt * sizeof(int));
+      int* row = topo + ((size_t)b * n_act + k) * g.dim_topo;
+      int* srow = sb + ((size_t)b * n_act + k) * std::max(g.n_shunt, 1);
+      std::memcpy(row, rows + (size_t)b * w, (size_t)g.dim_topo * sizeof(int));
+      if (g.n_shunt) std::memcpy(srow, rows + (size_t)b * w + g.dim_topo, (size_t)g.n_shunt * sizeof(int));
       for (int l : maint_out[b]) { row[e->h_line_or_pos[l]] = -1; row[e->h_line_ex_pos[l]] = -1; }
       apply_topo_action(e, row, g.n_shunt ? srow : nullptr, last_bus ? last_bus + (size_t)b * g.dim_topo : nullptr,
                         act_items + 3 * (size_t)act_off[k], act_off[k + 1] - act_off[k]);
     }
-  int rc = gpf_set_topology(e, dst_lane0, (int)n_dst, topo.data(), g.n_shunt ? sb.data() : nullptr);
+  const double tm2 = sim_timing ? now_us() : 0.0;
+  int rc = set_topology_rows(e, dst_lane0, (int)n_dst, topo, g.n_shunt ? sb : nullptr, true);
   if (rc != GPF_OK) return rc;
+  const double tm3 = sim_timing ? now_us() : 0.0;
   // 3. everything else of the source lanes + the chronics / forecast row to step on, on the device
   const bool fc = time_step > 0;
   const int T_eff = fc ? e->chron_T * e->fc_h : e->chron_T;
@@ -2070,7 +2110,12 @@ int gpf_simulate_batch(gpf_handle e, int32_t t_obs, int32_t time_step, int32_t n
   b.traj_rho = nullptr; b.traj_status = nullptr; b.traj_out = nullptr; b.traj_topo = nullptr; b.traj_shb = nullptr; b.traj_lstat = nullptr; b.traj_cap = 0;
   gpf_step_opts oo = *o;
   oo.auto_reset = 0; oo.warm_start = 0;
-  return step_range(e, b, dst_lane0, (int)n_dst, 0, T_eff, 1, &oo, "gpf_simulate_batch");
+  const double tm4 = sim_timing ? now_us() : 0.0;
+  rc = step_range(e, b, dst_lane0, (int)n_dst, 0, T_eff, 1, &oo, "gpf_simulate_batch");
+  if (sim_timing)
+    fprintf(stderr, "[gridpf] simulate_batch %lld lanes: gather + sync %.0f us, candidate rows %.0f, gpf_set_topology %.0f, prepare + mirror %.0f, plan + launch %.0f\n",
+            n_dst, tm1 - tm0, tm2 - tm1, tm3 - tm2, tm4 - tm3, now_us() - tm4);
+  return rc;
 }
 
 int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double rebalance, int32_t cascade, float hard_overflow,
