@@ -236,6 +236,10 @@ struct gpf_engine {
   DevArr<float> forecast;               // [chron_tables][chron_T][fc_h][n_chron] *_forecasted tables (gpf_upload_forecasts), or empty
   int fc_h = 0;
   DevArr<int> sim_src, sim_rows;        // gpf_simulate_batch staging: source lane list, gathered topology rows
+  struct PtdfbCached { std::vector<int> row, desc, c2b; };      // gpf_ptdf_build_batch: descriptor of a topology row seen before
+  std::unordered_map<uint64_t, std::vector<PtdfbCached>> ptdfb_cache;
+  size_t ptdfb_cache_n = 0;
+  int ptdfb_cache_stride = 0;
   int* sim_pin = nullptr;               // its pinned host block (grow-only): gathered source rows | candidate topology rows | candidate shunt rows
   size_t sim_pin_n = 0;
   DevArr<signed char> traj_status;
@@ -2538,31 +2542,50 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
   const gpf::GridDev& g = e->g;
   const gpf::OutOff& oo = e->oo;
   const int nl = g.n_line, nbt = g.nb_tot, nsh = g.n_shunt;
+  static const bool stage_timing = getenv("GRIDPF_SIM_TIMING") != nullptr;      // developer: stage times of the call on stderr
+  auto now_us = [] { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() * 1e-3; };
+  double tm[6] = {0, 0, 0, 0, 0, 0};
   // the lanes' topology rows as they are on the device (a cascade inside gpf_step_n may have tripped lines the host never saw)
   std::vector<int> topo((size_t)n * g.dim_topo), sb((size_t)n * std::max(nsh, 1));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  if (stage_timing) tm[0] = now_us();
   HIP_TRY(hipMemcpy(topo.data(), e->topo.p + (size_t)lane0 * g.dim_topo, topo.size() * sizeof(int), hipMemcpyDeviceToHost));
   if (nsh) HIP_TRY(hipMemcpy(sb.data(), e->shunt_bus.p + (size_t)lane0 * nsh, (size_t)n * nsh * sizeof(int), hipMemcpyDeviceToHost));
+  if (stage_timing) tm[1] = now_us();
   // ---- classes: lanes with identical (topology row, shunt buses) ----------------------------------------------------------------------
   std::unordered_map<uint64_t, std::vector<int>> cls_of;     // row hash -> classes with that hash (rows compared on a hit)
   std::vector<int> first_lane;                       // representative lane (index in the range) of each class
+  std::vector<uint64_t> first_hash;                  // its row hash (key of the descriptor cache)
   e->h_ptdfb_lane_class.assign(n, -1);
   auto same_rows = [&](int a, int b) {
     return std::memcmp(topo.data() + (size_t)a * g.dim_topo, topo.data() + (size_t)b * g.dim_topo, (size_t)g.dim_topo * sizeof(int)) == 0 &&
            (!nsh || std::memcmp(sb.data() + (size_t)a * nsh, sb.data() + (size_t)b * nsh, (size_t)nsh * sizeof(int)) == 0);
   };
+  cls_of.reserve((size_t)n);
   for (int k = 0; k < n; ++k) {
-    uint64_t h = 1469598103934665603ull;
+    // row hash: four independent multiply-xor chains over the row (one dependent multiply per int was 1 ms for 2 048 rows of 560 ints);
+    // equal hashes are confirmed by comparing the rows, so the hash only has to spread
     const int* tp = topo.data() + (size_t)k * g.dim_topo;
-    for (int i = 0; i < g.dim_topo; ++i) { h ^= (uint32_t)tp[i]; h *= 1099511628211ull; }
-    for (int i = 0; i < nsh; ++i) { h ^= (uint32_t)sb[(size_t)k * nsh + i] + 0x9E3779B9u; h *= 1099511628211ull; }
+    uint64_t h0 = 1469598103934665603ull, h1 = 0x9E3779B97F4A7C15ull, h2 = 0xC2B2AE3D27D4EB4Full, h3 = 0x165667B19E3779F9ull;
+    int i = 0;
+    for (; i + 8 <= g.dim_topo; i += 8) {
+      h0 = (h0 ^ ((uint64_t)(uint32_t)tp[i] | ((uint64_t)(uint32_t)tp[i + 1] << 32))) * 0x9FB21C651E98DF25ull;
+      h1 = (h1 ^ ((uint64_t)(uint32_t)tp[i + 2] | ((uint64_t)(uint32_t)tp[i + 3] << 32))) * 0xD6E8FEB86659FD93ull;
+      h2 = (h2 ^ ((uint64_t)(uint32_t)tp[i + 4] | ((uint64_t)(uint32_t)tp[i + 5] << 32))) * 0xA0761D6478BD642Full;
+      h3 = (h3 ^ ((uint64_t)(uint32_t)tp[i + 6] | ((uint64_t)(uint32_t)tp[i + 7] << 32))) * 0xE7037ED1A0B428DBull;
+    }
+    for (; i < g.dim_topo; ++i) h0 = (h0 ^ (uint32_t)tp[i]) * 1099511628211ull;
+    for (int q = 0; q < nsh; ++q) h1 = (h1 ^ ((uint32_t)sb[(size_t)k * nsh + q] + 0x9E3779B9u)) * 1099511628211ull;
+    uint64_t h = h0 ^ (h1 >> 29 | h1 << 35) ^ (h2 >> 17 | h2 << 47) ^ (h3 >> 41 | h3 << 23);
+    h ^= h >> 32;
     std::vector<int>& cand = cls_of[h];
     int c = -1;
     for (int cc : cand) if (same_rows(first_lane[cc], k)) { c = cc; break; }
-    if (c < 0) { c = (int)first_lane.size(); first_lane.push_back(k); cand.push_back(c); }
+    if (c < 0) { c = (int)first_lane.size(); first_lane.push_back(k); first_hash.push_back(h); cand.push_back(c); }
     e->h_ptdfb_lane_class[k] = c;
   }
   const int nc = (int)first_lane.size();
+  if (stage_timing) tm[2] = now_us();
   // descriptor: header | lf | lt | inj_bus | lflag | row pointers of B' [PTDFB_MAX_N + 1] | row entries [2 n_line] (gridpf_ptdf_batch.hpp)
   if (nl > 65535) return fail(GPF_E_CAPACITY, "gpf_ptdf_build_batch: more than 65535 lines");
   const int stride = (gpf::PTDFB_HDR + 3 * nl + g.n_inj + gpf::PTDFB_MAX_N + 1 + 2 * nl + 3) & ~3;
@@ -2570,7 +2593,11 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
   e->h_ptdfb_bus.assign(nc, std::vector<int>());
   int npad_max = 16, nact_max = 1;
   auto bus_of = [&](int sub, int local) -> int { return (local >= 1 && local <= g.n_busbar) ? sub + (local - 1) * g.n_sub : -1; };
-  for (int c = 0; c < nc; ++c) {
+  // One descriptor per class: ~3 us of table walks each (800 us for 256 classes of a 118-substation grid on one core)
+  struct ClsScratch { std::vector<char> act, ref, has_ref; std::vector<int> bf, bt, n_lines_at, n_other_at, ibus, compact, comp, cnt; int npad_max = 16, nact_max = 1; };
+  auto build_class = [&](int c, ClsScratch& S_) -> int {
+    std::vector<char>&act = S_.act, &ref = S_.ref, &has_ref = S_.has_ref;
+    std::vector<int>&bf = S_.bf, &bt = S_.bt, &n_lines_at = S_.n_lines_at, &n_other_at = S_.n_other_at, &ibus = S_.ibus, &compact = S_.compact, &comp = S_.comp, &cnt = S_.cnt;
     const int* tp = topo.data() + (size_t)first_lane[c] * g.dim_topo;
     const int* sbp = sb.data() + (size_t)first_lane[c] * std::max(nsh, 1);
     int* d = desc.data() + (size_t)c * stride;
@@ -2578,18 +2605,18 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
     int* lt = lf + nl;
     int* ib = lt + nl;
     int* lflag = ib + g.n_inj;
-    std::vector<char> act(nbt, 0), ref(nbt, 0);
-    std::vector<int> bf(nl, -1), bt(nl, -1);
-    std::vector<int> n_lines_at(nbt, 0), n_other_at(nbt, 0);   // in-service line ends / other elements on each bus
+    act.assign(nbt, 0); ref.assign(nbt, 0);
+    bf.assign(nl, -1); bt.assign(nl, -1);
+    n_lines_at.assign(nbt, 0); n_other_at.assign(nbt, 0);      // in-service line ends / other elements on each bus
     for (int l = 0; l < nl; ++l) {
       const int bo = tp[e->h_line_or_pos[l]], be = tp[e->h_line_ex_pos[l]];
       if (bo >= 1 && be >= 1) {
         bf[l] = bus_of(e->h_line_or_sub[l], bo); bt[l] = bus_of(e->h_line_ex_sub[l], be);
-        if (bf[l] < 0 || bt[l] < 0) return fail(GPF_E_INVALID, "gpf_ptdf_build_batch: bus id out of range");
+        if (bf[l] < 0 || bt[l] < 0) return 1;
         act[bf[l]] = act[bt[l]] = 1;
       }
     }
-    std::vector<int> ibus(g.n_inj, -1);
+    ibus.assign(g.n_inj, -1);
     for (int i = 0; i < g.n_gen; ++i) {
       const int b = bus_of(e->h_gen_sub[i], tp[e->h_gen_pos[i]]);
       if (b < 0) continue;
@@ -2602,8 +2629,9 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
     for (int i = 0; i < nsh; ++i) { const int b = bus_of(e->h_shunt_sub[i], sbp[i]); if (b >= 0) { act[b] = 1; ++n_other_at[b]; ibus[oo.inj_sh_p + i] = b; } }
     for (int l = 0; l < nl; ++l) if (bf[l] >= 0) { ++n_lines_at[bf[l]]; ++n_lines_at[bt[l]]; }
     // compact numbering: active non-reference buses first, then the active reference buses
-    std::vector<int> compact(nbt, -1);
+    compact.assign(nbt, -1);
     std::vector<int>& c2b = e->h_ptdfb_bus[c];
+    c2b.reserve(nbt);
     int nr = 0, n_act = 0;
     for (int b = 0; b < nbt; ++b) if (act[b] && !ref[b]) { compact[b] = nr++; c2b.push_back(b); }
     n_act = nr;
@@ -2612,16 +2640,16 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
     // connectivity (rundcpp(check_connectivity=True), pandaPowerBackend.py:1090): every active bus must reach a reference bus
     int status = any_ref ? 0 : 3;
     if (any_ref) {
-      std::vector<int> comp(nbt);
+      comp.resize(nbt);
       for (int b = 0; b < nbt; ++b) comp[b] = b;
       auto find = [&](int x) { while (comp[x] != x) { comp[x] = comp[comp[x]]; x = comp[x]; } return x; };
       for (int l = 0; l < nl; ++l) if (bf[l] >= 0 && bf[l] != bt[l]) comp[find(bf[l])] = find(bt[l]);
-      std::vector<char> has_ref(nbt, 0);
+      has_ref.assign(nbt, 0);
       for (int b = 0; b < nbt; ++b) if (act[b] && ref[b]) has_ref[find(b)] = 1;
       for (int b = 0; b < nbt; ++b) if (act[b] && !has_ref[find(b)]) { status = 2; break; }
     }
     const int n_pad = std::max(16, (nr + 15) & ~15);
-    if (n_pad > gpf::PTDFB_MAX_N) return fail(GPF_E_CAPACITY, "gpf_ptdf_build_batch: more than 256 active non-reference buses in one topology");
+    if (n_pad > gpf::PTDFB_MAX_N) return 2;
     d[0] = nr; d[1] = n_act; d[2] = n_pad; d[3] = status;
     for (int l = 0; l < nl; ++l) {
       const bool on = bf[l] >= 0 && bf[l] != bt[l];
@@ -2632,7 +2660,7 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
     {   // rows of the reduced B': for every non-reference bus r the lines at it, ascending, as line | other end << 16
       int* cptr = lflag + nl;
       int* cent = cptr + gpf::PTDFB_MAX_N + 1;
-      std::vector<int> cnt(nr + 1, 0);
+      cnt.assign(nr + 1, 0);
       for (int l = 0; l < nl; ++l) { if (lf[l] < 0) continue; if (lf[l] < nr) ++cnt[lf[l]]; if (lt[l] < nr) ++cnt[lt[l]]; }
       int acc = 0;
       for (int r = 0; r < nr; ++r) { cptr[r] = acc; acc += cnt[r]; cnt[r] = cptr[r]; }
@@ -2645,9 +2673,46 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
       }
     }
     for (int i = 0; i < g.n_inj; ++i) ib[i] = ibus[i] >= 0 ? compact[ibus[i]] : -1;
-    npad_max = std::max(npad_max, n_pad);
-    nact_max = std::max(nact_max, n_act);
+    S_.npad_max = std::max(S_.npad_max, n_pad);
+    S_.nact_max = std::max(S_.nact_max, n_act);
+    return 0;
+  };
+  {
+    // Descriptors are cached by topology row (hash + the row itself, compared on a hit): a rebuild after some lanes changed their topology
+    // -- or the next contingency scan over the same family of topologies -- only walks the tables for classes it has not seen.
+    ClsScratch scr;
+    const size_t row_ints = (size_t)g.dim_topo + (size_t)nsh;
+    const bool no_cache = getenv("GRIDPF_PTDFB_NO_CACHE") != nullptr;      // developer / bench: every class counts as never seen (read at every call)
+    if (no_cache || e->ptdfb_cache_stride != stride || e->ptdfb_cache_n > 8192) { e->ptdfb_cache.clear(); e->ptdfb_cache_n = 0; e->ptdfb_cache_stride = stride; }
+    for (int c = 0; c < nc; ++c) {
+      const int* tp = topo.data() + (size_t)first_lane[c] * g.dim_topo;
+      const int* sbp = sb.data() + (size_t)first_lane[c] * std::max(nsh, 1);
+      int* d = desc.data() + (size_t)c * stride;
+      std::vector<gpf_engine::PtdfbCached>& bucket = e->ptdfb_cache[first_hash[c]];
+      const gpf_engine::PtdfbCached* hit = nullptr;
+      for (const auto& ce : bucket)
+        if (std::memcmp(ce.row.data(), tp, (size_t)g.dim_topo * sizeof(int)) == 0 && (!nsh || std::memcmp(ce.row.data() + g.dim_topo, sbp, (size_t)nsh * sizeof(int)) == 0)) { hit = &ce; break; }
+      if (hit) {
+        std::memcpy(d, hit->desc.data(), (size_t)stride * sizeof(int));
+        e->h_ptdfb_bus[c] = hit->c2b;
+      } else {
+        const int err = build_class(c, scr);
+        if (err == 1) return fail(GPF_E_INVALID, "gpf_ptdf_build_batch: bus id out of range");
+        if (err == 2) return fail(GPF_E_CAPACITY, "gpf_ptdf_build_batch: more than 256 active non-reference buses in one topology");
+        gpf_engine::PtdfbCached ce;
+        ce.row.resize(row_ints);
+        std::memcpy(ce.row.data(), tp, (size_t)g.dim_topo * sizeof(int));
+        if (nsh) std::memcpy(ce.row.data() + g.dim_topo, sbp, (size_t)nsh * sizeof(int));
+        ce.desc.assign(d, d + stride);
+        ce.c2b = e->h_ptdfb_bus[c];
+        bucket.push_back(std::move(ce));
+        ++e->ptdfb_cache_n;
+      }
+      npad_max = std::max(npad_max, d[2]);
+      nact_max = std::max(nact_max, d[1]);
+    }
   }
+  if (stage_timing) tm[3] = now_us();
   // ---- slots: lanes grouped by class, every group padded to a multiple of 16 ------------------------------------------------------------
   std::vector<std::vector<int>> members(nc);
   for (int k = 0; k < n; ++k) members[e->h_ptdfb_lane_class[k]].push_back(lane0 + k);
@@ -2696,6 +2761,7 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_set[e->device & 63][resident] = lds;
   }
+  if (stage_timing) tm[4] = now_us();
   hipEvent_t ea = nullptr, eb = nullptr;
   HIP_TRY(hipEventCreate(&ea)); HIP_TRY(hipEventCreate(&eb));
   HIP_TRY(hipEventRecord(ea, e->stream));
@@ -2711,6 +2777,9 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
   (void)hipEventElapsedTime(&ms, ea, eb);
   (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
   e->ptdfb_kernel_ms = ms;
+  if (stage_timing)
+    fprintf(stderr, "[gridpf] ptdf_build_batch %d lanes, %d classes: rows to the host %.0f us, grouping %.0f, descriptors %.0f, slots + uploads %.0f, kernel + status %.0f\n",
+            n, nc, tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], now_us() - tm[4]);
   if (want_dbg) {
     std::vector<long long> h((size_t)nc * 8);
     (void)hipMemcpy(h.data(), dbg.p, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
@@ -2723,7 +2792,7 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
     dbg.release();
   }
   if (e->window) { ++e->win_launches; e->win_marked = false; }
-  e->h_ptdfb_desc = desc;
+  e->h_ptdfb_desc = std::move(desc);
   e->ptdfb_lane0 = lane0; e->ptdfb_n = n; e->ptdfb_classes = nc; e->ptdfb_slots = (int)order.size(); e->ptdfb_kpad = kpad;
   e->ptdfb_npad_max = npad_max; e->ptdfb_desc_stride = stride;
   e->ptdf_nb_pad = nb_pad; e->ptdf_line_pad = line_pad;

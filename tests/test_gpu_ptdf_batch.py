@@ -203,3 +203,45 @@ def test_bench_shape_2048_lanes_256_topologies_on_118_substations(load_model, lo
     others = np.setdiff1d(np.nonzero(okl)[0], [k])
     assert np.array_equal(f2[others], flows[others])
     eng.close()
+
+
+def test_rebuilds_reuse_cached_descriptors_and_follow_changed_topologies(load_model, monkeypatch):
+    """The host keeps the descriptor of every topology row it has built (hash + the row, compared on a hit): a rebuild after SOME lanes
+    changed -- to topologies seen before, to new ones, and back -- must give, class by class and bit for bit, the tables a build
+    without the cache gives (`GRIDPF_PTDFB_NO_CACHE`), with the classes numbered by first appearance in the lane range."""
+    name = "l2rpn_neurips_2020_track1"
+    m = load_model(name)
+    rng = np.random.default_rng(21)
+    B, n_topo = 96, 30
+    topos = random_topologies(m, n_topo + 12, rng)
+    eng = _engine(m, B)
+
+    def tables(lane_topo):
+        eng.set_topology(np.stack([topos[i] for i in lane_topo]).astype(np.int32))
+        info = eng.ptdf_build_batch(with_lodf=True)
+        tabs = [eng.ptdf_class(c, lodf=True) if info["class_status"][c] == 0 else None for c in range(info["n_classes"])]
+        return info, tabs
+
+    def same(a, b):
+        (ia, ta), (ib, tb) = a, b
+        assert ia["n_classes"] == ib["n_classes"] and np.array_equal(ia["lane_class"], ib["lane_class"])
+        assert np.array_equal(ia["class_status"], ib["class_status"]) and np.array_equal(ia["class_n"], ib["class_n"])
+        for x, y in zip(ta, tb):
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1], equal_nan=True)
+
+    lt0 = rng.integers(0, n_topo, B)
+    lt1 = lt0.copy()
+    lt1[rng.choice(B, 20, replace=False)] = rng.integers(n_topo, n_topo + 12, 20)      # 20 lanes move to topologies never built
+    lt1[rng.choice(B, 10, replace=False)] = rng.integers(0, n_topo, 10)                # 10 to ones seen before
+    runs = {}
+    for label, env in (("cached", None), ("uncached", "1")):
+        if env:
+            monkeypatch.setenv("GRIDPF_PTDFB_NO_CACHE", env)
+        runs[label] = [tables(lt0), tables(lt1), tables(lt0)]
+    for a, b in zip(runs["cached"], runs["uncached"]):
+        same(a, b)
+    same(runs["cached"][0], runs["cached"][2])                                       # back to the first assignment: the first tables
+    assert runs["cached"][1][0]["n_classes"] != runs["cached"][0][0]["n_classes"] or not np.array_equal(runs["cached"][1][0]["lane_class"], runs["cached"][0][0]["lane_class"])
+    eng.close()
