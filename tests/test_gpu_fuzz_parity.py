@@ -1,0 +1,23 @@
+"""A small randomised parity sweep inside the GPU suite (the large ones are run with tests/fuzz_parity.py as a script and summarised in
+profiles/r05_fuzz_parity.json): per grid 768 lanes with random outages / bus splits (islanding combinations kept) and +-20 % load
+jitter, 384 of them re-solved by the C oracle from the inputs the lanes hold on the device -- AC, DC, and the final state of a
+three-step rollout with the protections on.  Bit-exact status / iteration count / topo_vect / line status; float32 outputs within
+2e-4 + 5e-6 |x|; float64 pre-cast flows below 1e-4 pu of the grid's base."""
+import pytest
+
+from fuzz_parity import GRIDS, fuzz_grid
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("env", GRIDS)
+@pytest.mark.parametrize("cascade", [False, True])
+def test_random_topologies_and_injections_vs_the_c_oracle(env, cascade):
+    res = fuzz_grid(env, 768, 384, seed=1234 + GRIDS.index(env) + (100 if cascade else 0), cascade=cascade)
+    for key in ("ac", "dc"):
+        if key not in res:
+            continue
+        v = res[key]
+        assert v["ok"] and v["status_mismatch"] == 0 and v["n_iter_mismatch"] == 0 and v["topo_vect_mismatch"] == 0 and v["line_status_mismatch"] == 0, (key, v)
+        assert v["nan_in_converged"] == 0 and v["non_nan_in_failed"] == 0, (key, v)
+    assert 0 < res["ac"]["n_converged"] <= res["ac"]["n"]
