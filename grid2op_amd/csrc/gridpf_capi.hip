@@ -240,6 +240,9 @@ struct gpf_engine {
   std::unordered_map<uint64_t, std::vector<PtdfbCached>> ptdfb_cache;
   size_t ptdfb_cache_n = 0;
   int ptdfb_cache_stride = 0;
+  float* act_pin = nullptr;             // pinned staging of gpf_set_lane_actions / gpf_set_lane_curtailment (redispatch | storage | curtailment)
+  size_t act_pin_n = 0;
+  hipEvent_t act_up = nullptr;          // recorded behind the uploads that read it: the next call waits for it before rewriting the block
   int* sim_pin = nullptr;               // its pinned host block (grow-only): gathered source rows | candidate topology rows | candidate shunt rows
   size_t sim_pin_n = 0;
   DevArr<signed char> traj_status;
@@ -1243,6 +1246,8 @@ int gpf_destroy(gpf_handle e) {
   e->d_init_inj.release(); e->d_init_topo.release(); e->d_init_shunt_bus.release();
   if (e->pin) (void)hipHostFree(e->pin);
   if (e->sim_pin) (void)hipHostFree(e->sim_pin);
+  if (e->act_pin) (void)hipHostFree(e->act_pin);
+  if (e->act_up) (void)hipEventDestroy(e->act_up);
   e->maint.release(); e->forecast.release(); e->sim_src.release(); e->sim_rows.release();
   e->env_target.release(); e->env_actual.release(); e->env_prev.release(); e->env_charge.release(); e->env_amount_prev.release();
   e->env_act_redisp.release(); e->env_act_storage.release(); e->sto_charge0.release(); e->env_already.release(); e->env_fresh.release();
@@ -1869,17 +1874,49 @@ int gpf_set_env_dynamics(gpf_handle e, int32_t on, double tol_poly) {
   return reset_env_state(e, 0, e->cap_lanes);
 }
 
+}  // extern "C"
+namespace {
+// The agents' per-launch actions go through a pinned block of the engine: the caller's (pageable) arrays are copied into it, the
+// uploads are true asynchronous DMA behind whatever the stream is doing, and NOTHING is waited for -- a host agent that acts at every
+// step paid a staged pageable copy plus a stream synchronisation per step before.  The block is rewritten by the next call, which
+// first waits for the event recorded behind this call's uploads (reached long before: they sit in front of the step launch).
+// Layout: redispatch [B][n_gen] | storage [B][n_sto] | curtailment [B][n_gen].
+int act_pin_begin(gpf_engine* e) {
+  const size_t B = e->n_lanes, ng = e->g.n_gen, ns = e->g.n_sto, need = B * (2 * ng + ns);
+  if (e->act_up) HIP_TRY(hipEventSynchronize(e->act_up));
+  if (e->act_pin_n < need) {
+    if (e->act_pin) (void)hipHostFree(e->act_pin);
+    e->act_pin = nullptr; e->act_pin_n = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->act_pin), need * sizeof(float), hipHostMallocDefault));
+    e->act_pin_n = need;
+  }
+  if (!e->act_up) HIP_TRY(hipEventCreateWithFlags(&e->act_up, hipEventDisableTiming));
+  return GPF_OK;
+}
+}  // namespace
+extern "C" {
+
 int gpf_set_lane_actions(gpf_handle e, const float* redispatch, const float* storage_power, int32_t hold_storage) {
   if (!e) return fail(GPF_E_INVALID, "gpf_set_lane_actions: null");
   if (!e->env_on) return fail(GPF_E_INVALID, "gpf_set_lane_actions: the environment dynamics are off (gpf_set_env_dynamics)");
   HIP_TRY(hipSetDevice(e->device));
   const size_t B = e->n_lanes, ng = e->g.n_gen, ns = e->g.n_sto;
-  if (redispatch) { HIP_TRY(hipMemcpyAsync(e->env_act_redisp.p, redispatch, B * ng * sizeof(float), hipMemcpyHostToDevice, e->stream)); e->env_act_r = true; }
-  else e->env_act_r = false;
-  if (storage_power && ns) { HIP_TRY(hipMemcpyAsync(e->env_act_storage.p, storage_power, B * ns * sizeof(float), hipMemcpyHostToDevice, e->stream)); e->env_act_s = true; }
-  else e->env_act_s = false;
+  if (redispatch || (storage_power && ns)) {
+    const int rc = act_pin_begin(e);
+    if (rc != GPF_OK) return rc;
+  }
+  if (redispatch) {
+    std::memcpy(e->act_pin, redispatch, B * ng * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(e->env_act_redisp.p, e->act_pin, B * ng * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  }
+  e->env_act_r = redispatch != nullptr;
+  if (storage_power && ns) {
+    std::memcpy(e->act_pin + B * ng, storage_power, B * ns * sizeof(float));
+    HIP_TRY(hipMemcpyAsync(e->env_act_storage.p, e->act_pin + B * ng, B * ns * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  }
+  e->env_act_s = storage_power != nullptr && ns > 0;
   e->env_hold = hold_storage != 0;
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  if (redispatch || (storage_power && ns)) HIP_TRY(hipEventRecord(e->act_up, e->stream));
   return GPF_OK;
 }
 
@@ -1913,8 +1950,14 @@ int gpf_set_lane_curtailment(gpf_handle e, const float* limit) {
   if (!limit) { e->env_act_c = false; return GPF_OK; }
   const size_t n = (size_t)e->n_lanes * e->g.n_gen;
   for (size_t i = 0; i < n; ++i) if (!(limit[i] == -1.0f || (limit[i] >= 0.0f && limit[i] <= 1.0f))) return fail(GPF_E_INVALID, "gpf_set_lane_curtailment: limits are ratios in [0, 1], -1 = no change");
-  HIP_TRY(hipMemcpyAsync(e->env_act_curtail.p, limit, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  {
+    const int rc = act_pin_begin(e);
+    if (rc != GPF_OK) return rc;
+  }
+  float* stage = e->act_pin + (size_t)e->n_lanes * (e->g.n_gen + e->g.n_sto);
+  std::memcpy(stage, limit, n * sizeof(float));
+  HIP_TRY(hipMemcpyAsync(e->env_act_curtail.p, stage, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipEventRecord(e->act_up, e->stream));
   e->env_act_c = true;
   return GPF_OK;
 }
