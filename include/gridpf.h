@@ -281,7 +281,8 @@ int gpf_redispatch(gpf_handle h, int32_t lane0, int32_t n, const double* new_p, 
  *   gpf_set_lane_actions   : the agents' actions of the NEXT launch: redispatch [n_lanes][n_gen] MW (added to the target dispatch
  *                            by the launch's first step, then consumed) and storage power [n_lanes][n_storage] MW (applied by the
  *                            first step only -- grid2op's semantics of a storage action -- or, hold_storage != 0, by every step
- *                            until replaced); NULL = none.
+ *                            until replaced); NULL = none.  The arrays are copied into pinned staging before the call returns;
+ *                            the upload rides the engine's stream, nothing is synchronised.
  *   gpf_set_gen_renewable  : gen_renewable [n_gen] (NULL: no curtailment);  gpf_set_lane_curtailment: the curtailment action of
  *                            the NEXT launch, [n_lanes][n_gen] ratios of pmax in [0, 1], -1 = no change (consumed by the first
  *                            step; the limits then live in the lanes' state, like BaseEnv._limit_curtailment).
