@@ -66,6 +66,64 @@ def fuzz_grid(env, n_lanes, n_check, seed, cascade=False):
     return res
 
 
+def _random_engine(env, n_lanes, seed, limits_scale=None):
+    """(model, engine, T) with random topologies / chronics rows / load jitter, as fuzz_grid sets them up"""
+    from grid2op_amd.engine import PowerFlowEngine
+    from grid2op_amd.grid_model import GridModel
+    from test_gpu_ptdf_batch import random_topologies
+    m = GridModel.load_npz(os.path.join(GOLD, f"{env}.grid.npz"))
+    chp = os.path.join(GOLD, f"{env}.chronics.npz")
+    ch = dict(np.load(chp)) if os.path.exists(chp) else {}
+    if "prod_p" not in ch:
+        f = (1.0 + 0.1 * np.random.default_rng(99).uniform(-1, 1, (8, 1))).astype(np.float32)
+        ch = {"load_p": f * m.load_p0.astype(np.float32), "load_q": f * m.load_q0.astype(np.float32), "prod_p": f * m.gen_p0.astype(np.float32)}
+    rng = np.random.default_rng(seed)
+    eng = PowerFlowEngine(m, n_lanes=n_lanes)
+    pv = ch.get("prod_v", np.tile((m.gen_vm0 * m.sub_vn_kv[m.gen_sub]).astype(np.float32), (ch["prod_p"].shape[0], 1)))
+    tab = eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], pv)
+    eng.upload_chronics(tab)
+    n_topo = min(n_lanes, 256)
+    topos = random_topologies(m, n_topo, rng, max_out=2, max_split=2)
+    topo = np.stack([topos[i] for i in rng.integers(0, n_topo, n_lanes)]).astype(np.int32)
+    topo[: n_lanes // 4] = m.initial_topo_vect()
+    eng.set_topology(topo)
+    sc = (1.0 + 0.2 * rng.uniform(-1.0, 1.0, (n_lanes, 2 * m.n_load))).astype(np.float32)
+    eng.set_lane_chronics(lane_offset=rng.integers(0, tab.shape[0], n_lanes).astype(np.int32), lane_scale=sc)
+    if limits_scale is not None and "thermal_limits" in ch:
+        eng.set_thermal_limits(np.asarray(ch["thermal_limits"]) * limits_scale)
+    return m, eng, tab.shape[0]
+
+
+def fuzz_multistep(env, n_lanes, seed, n_steps=6, auto_reset=False):
+    """ONE launch of `n_steps` env steps == `n_steps` single-step launches, bit for bit, on random topologies with the protections on
+    (thermal limits x 0.85: lines trip, lanes black out, with `auto_reset` they restart): the result rows, topo_vect, line status, status,
+    protection counters, line cooldowns and episode counters of every lane after the last step, and the status of every step."""
+    _, a, T = _random_engine(env, n_lanes, seed, limits_scale=0.85)
+    _, b, _ = _random_engine(env, n_lanes, seed, limits_scale=0.85)
+    kw = dict(rebalance=1.02, cascade=True, auto_reset=auto_reset)
+    t0 = int(np.random.default_rng(seed + 1).integers(0, T))
+    a.set_trajectory(n_steps, a.TRAJ_RHO)
+    a.step(t0, n_steps=n_steps, **kw)
+    _, st_a = a.trajectory(n_steps)
+    st_b = []
+    for j in range(n_steps):
+        b.step(t0 + j, n_steps=1, **kw)
+        st_b.append(b.results(with_bus=False).status[:, 0].astype(np.int8))
+    ra, rb = a.results(), b.results()
+    same = {"out": np.array_equal(ra.out, rb.out, equal_nan=True), "status": np.array_equal(ra.status, rb.status),
+            "topo_vect": np.array_equal(ra.topo_vect, rb.topo_vect), "line_status": np.array_equal(ra.line_status, rb.line_status),
+            "step_status": np.array_equal(st_a, np.stack(st_b)), "step_outputs": all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a.step_outputs(), b.step_outputs())),
+            "cooldown": np.array_equal(a.cooldown(), b.cooldown()), "episode": all(np.array_equal(x, y) for x, y in zip(a.episode(), b.episode())),
+            # (float64 state behind the float32 rows: a multi-step launch starts Newton from the DC factors it keeps across its steps,
+            #  a single-step launch factorises afresh -- same solution, last bits of the float64 voltages may differ)
+            "bus_vm": bool(np.allclose(ra.bus_vm, rb.bus_vm, rtol=0.0, atol=1e-12, equal_nan=True)),
+            "bus_va": bool(np.allclose(ra.bus_va, rb.bus_va, rtol=0.0, atol=1e-10, equal_nan=True))}
+    res = {"same": same, "ok": all(same.values()), "converged_last": int(ra.converged.sum()), "tripped_lanes": int((a.step_outputs()[2] >= 0).any(axis=1).sum()),
+           "failed_some_step": int((st_a != 0).any(axis=0).sum())}
+    a.close(); b.close()
+    return res
+
+
 def main(argv):
     n_lanes = int(argv[1]) if len(argv) > 1 else 4096
     n_check = int(argv[2]) if len(argv) > 2 else 1500

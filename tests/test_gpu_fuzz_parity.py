@@ -5,7 +5,7 @@ three-step rollout with the protections on.  Bit-exact status / iteration count 
 2e-4 + 5e-6 |x|; float64 pre-cast flows below 1e-4 pu of the grid's base."""
 import pytest
 
-from fuzz_parity import GRIDS, fuzz_grid
+from fuzz_parity import GRIDS, fuzz_grid, fuzz_multistep
 
 pytestmark = pytest.mark.gpu
 
@@ -21,3 +21,13 @@ def test_random_topologies_and_injections_vs_the_c_oracle(env, cascade):
         assert v["ok"] and v["status_mismatch"] == 0 and v["n_iter_mismatch"] == 0 and v["topo_vect_mismatch"] == 0 and v["line_status_mismatch"] == 0, (key, v)
         assert v["nan_in_converged"] == 0 and v["non_nan_in_failed"] == 0, (key, v)
     assert 0 < res["ac"]["n_converged"] <= res["ac"]["n"]
+
+
+@pytest.mark.parametrize("env", GRIDS)
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_one_multi_step_launch_equals_single_step_launches_on_random_topologies(env, auto_reset):
+    """ONE 6-step launch == 6 single-step launches, bit for bit, with the protections on and lines tripping, on random topologies (bus
+    splits -> topology-class kernels, outages); with auto-reset the failed lanes restart inside the launch as they do between launches."""
+    res = fuzz_multistep(env, 320, seed=4321 + GRIDS.index(env), n_steps=6, auto_reset=auto_reset)
+    assert res["ok"], res
+    assert res["converged_last"] > 0
