@@ -124,6 +124,31 @@ def fuzz_multistep(env, n_lanes, seed, n_steps=6, auto_reset=False):
     return res
 
 
+def fuzz_specialised(env, n_lanes, seed, cache_dir, n_steps=4):
+    """The grid-specialised step kernels (gpf_jit_enable) == the shipped ones, bit for bit, on random topologies (topology-class kernels
+    of the split lanes included) with the protections on: everything a launch leaves behind, the float64 bus voltages too."""
+    _, a, T = _random_engine(env, n_lanes, seed, limits_scale=0.85)
+    _, b, _ = _random_engine(env, n_lanes, seed, limits_scale=0.85)
+    b.specialize(True, cache_dir=cache_dir, verify=False)
+    kw = dict(rebalance=1.02, cascade=True, auto_reset=True)
+    t0 = int(np.random.default_rng(seed + 1).integers(0, T))
+    for e in (a, b):
+        e.set_trajectory(n_steps, e.TRAJ_RHO)
+        e.step(t0, n_steps=n_steps, **kw)
+        e.step(t0 + n_steps, n_steps=1, **kw)
+    ra, rb = a.results(), b.results()
+    info = b.specialization()
+    same = {"out": np.array_equal(ra.out, rb.out, equal_nan=True), "status": np.array_equal(ra.status, rb.status),
+            "topo_vect": np.array_equal(ra.topo_vect, rb.topo_vect), "line_status": np.array_equal(ra.line_status, rb.line_status),
+            "step_outputs": all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a.step_outputs(), b.step_outputs())),
+            "cooldown": np.array_equal(a.cooldown(), b.cooldown()), "episode": all(np.array_equal(x, y) for x, y in zip(a.episode(), b.episode())),
+            "bus_vm": np.array_equal(ra.bus_vm, rb.bus_vm, equal_nan=True), "bus_va": np.array_equal(ra.bus_va, rb.bus_va, equal_nan=True)}
+    res = {"same": same, "ok": all(same.values()) and info["failed"] == 0 and info["launches"] > 0 and a.specialization()["launches"] == 0,
+           "specialization": info, "converged_last": int(ra.converged.sum())}
+    a.close(); b.close()
+    return res
+
+
 def main(argv):
     n_lanes = int(argv[1]) if len(argv) > 1 else 4096
     n_check = int(argv[2]) if len(argv) > 2 else 1500

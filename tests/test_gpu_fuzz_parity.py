@@ -5,7 +5,7 @@ three-step rollout with the protections on.  Bit-exact status / iteration count 
 2e-4 + 5e-6 |x|; float64 pre-cast flows below 1e-4 pu of the grid's base."""
 import pytest
 
-from fuzz_parity import GRIDS, fuzz_grid, fuzz_multistep
+from fuzz_parity import GRIDS, fuzz_grid, fuzz_multistep, fuzz_specialised
 
 pytestmark = pytest.mark.gpu
 
@@ -31,3 +31,11 @@ def test_one_multi_step_launch_equals_single_step_launches_on_random_topologies(
     res = fuzz_multistep(env, 320, seed=4321 + GRIDS.index(env), n_steps=6, auto_reset=auto_reset)
     assert res["ok"], res
     assert res["converged_last"] > 0
+
+
+@pytest.mark.parametrize("env", ["l2rpn_case14_sandbox", "l2rpn_neurips_2020_track1", "l2rpn_wcci_2022_dev"])
+def test_specialised_kernels_equal_the_shipped_ones_on_random_topologies(env, tmp_path_factory):
+    """gpf_jit_enable on random topologies (outages, bus splits -> topology-class launches), protections on, auto-reset: every buffer a
+    4-step + a 1-step launch leave behind is bit-identical to the shipped kernels', float64 bus voltages included."""
+    res = fuzz_specialised(env, 192, seed=999 + GRIDS.index(env), cache_dir=str(tmp_path_factory.mktemp("jit_fuzz")))
+    assert res["ok"], res
