@@ -16,7 +16,7 @@ __all__ = ["lib", "GridPFError", "GpfGridDesc", "GpfLayout", "GpfStepOpts", "lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libgridpf.so"
-ABI_VERSION = 321          # include/gridpf.h GPF_ABI_VERSION
+ABI_VERSION = 322          # include/gridpf.h GPF_ABI_VERSION
 
 EXPORTED_SYMBOLS = [
     "gpf_last_error", "gpf_version", "gpf_set_deterministic", "gpf_device_count", "gpf_create", "gpf_destroy", "gpf_get_layout", "gpf_n_lanes",
@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = [
     "gpf_upload_maintenance", "gpf_upload_hazards", "gpf_set_lane_chronics", "gpf_set_thermal_limits", "gpf_step", "gpf_step_n", "gpf_set_lane_redispatch", "gpf_set_gen_limits", "gpf_redispatch", "gpf_set_trajectory",
     "gpf_get_trajectory", "gpf_get_trajectory_obs", "gpf_upload_forecasts", "gpf_simulate_batch", "gpf_set_overflow_count",
     "gpf_set_storage_params", "gpf_set_env_dynamics", "gpf_set_lane_actions", "gpf_lane_actions_on_device", "gpf_get_env_state", "gpf_get_env_illegal", "gpf_set_env_illegal", "gpf_set_env_state", "gpf_set_gen_renewable", "gpf_set_lane_curtailment", "gpf_get_episode", "gpf_lane_capacity", "gpf_get_step_outputs", "gpf_sync",
-    "gpf_set_profiling", "gpf_get_kernel_time", "gpf_get_plan", "gpf_device_pointers", "gpf_device_pointers_n",
+    "gpf_get_results_pinned", "gpf_set_profiling", "gpf_get_kernel_time", "gpf_get_plan", "gpf_device_pointers", "gpf_device_pointers_n",
     "gpf_get_counters", "gpf_upload_outage_durations", "gpf_get_cooldown", "gpf_set_cooldown", "gpf_get_trajectory_cooldown", "gpf_ptdf_build", "gpf_ptdf_build_batch", "gpf_ptdf_batch_info", "gpf_ptdf_batch_get", "gpf_ptdf_get", "gpf_ptdf_flows", "gpf_get_ptdf_flows", "gpf_ptdf_flows_rows", "gpf_get_ptdf_flows_rows", "gpf_lodf_screen",
     "gpf_jit_enable", "gpf_jit_disable", "gpf_jit_info", "gpf_jit_source",
 ]
@@ -129,6 +129,7 @@ def lib() -> C.CDLL:
     L.gpf_fanout_n1.argtypes = [h, i32, i32, i32, _ip]
     L.gpf_runpf.argtypes = [h, i32, i32, i32, i32, C.c_double]
     L.gpf_get_results.argtypes = [h, i32, i32, _fp, _ip, _ip, _bp, _ip, _dp, _dp]
+    L.gpf_get_results_pinned.argtypes = [h, i32, i32, i32, C.POINTER(C.c_void_p)]
     L.gpf_solve_lane.argtypes = [h, i32, _dp, _ip, _ip, i32, i32, C.c_double, _fp, _ip, _ip, _bp, _ip, _dp, _dp]
     L.gpf_upload_chronics.argtypes = [h, i32, i32, _fp]
     L.gpf_upload_maintenance.argtypes = [h, i32, i32, _bp]

@@ -240,6 +240,8 @@ struct gpf_engine {
   std::unordered_map<uint64_t, std::vector<PtdfbCached>> ptdfb_cache;
   size_t ptdfb_cache_n = 0;
   int ptdfb_cache_stride = 0;
+  unsigned char* res_pin = nullptr;     // pinned block of gpf_get_results_pinned
+  size_t res_pin_bytes = 0;
   float* act_pin = nullptr;             // pinned staging of gpf_set_lane_actions / gpf_set_lane_curtailment (redispatch | storage | curtailment)
   size_t act_pin_n = 0;
   hipEvent_t act_up = nullptr;          // recorded behind the uploads that read it: the next call waits for it before rewriting the block
@@ -1247,6 +1249,7 @@ int gpf_destroy(gpf_handle e) {
   if (e->pin) (void)hipHostFree(e->pin);
   if (e->sim_pin) (void)hipHostFree(e->sim_pin);
   if (e->act_pin) (void)hipHostFree(e->act_pin);
+  if (e->res_pin) (void)hipHostFree(e->res_pin);
   if (e->act_up) (void)hipEventDestroy(e->act_up);
   e->maint.release(); e->forecast.release(); e->sim_src.release(); e->sim_rows.release();
   e->env_target.release(); e->env_actual.release(); e->env_prev.release(); e->env_charge.release(); e->env_amount_prev.release();
@@ -1600,6 +1603,37 @@ int gpf_get_results(gpf_handle e, int32_t lane0, int32_t n, float* out, int32_t*
   DL(out, out, g.n_out); DL(topo_vect, topo_out, g.dim_topo); DL(shunt_bus, shunt_bus_out, g.n_shunt);
   DL(line_status, line_status, g.n_line); DL(status, status, 4); DL(bus_vm, bus_vm, g.nb_tot); DL(bus_va, bus_va, g.nb_tot);
 #undef DL
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return GPF_OK;
+}
+
+// gpf_get_results into the engine's own PINNED block: the copies are true DMA (a pageable destination is staged through the runtime's
+// bounce buffers at a fraction of the PCIe rate), one synchronisation, and the caller reads the rows where they landed -- no second
+// host copy.  ptrs[k] = address of piece k inside the block (NULL when not asked for); valid until the next call of this function.
+int gpf_get_results_pinned(gpf_handle e, int32_t lane0, int32_t n, int32_t what, void** ptrs) {
+  if (!check_range(e, lane0, n) || !ptrs) return fail(GPF_E_INVALID, "gpf_get_results_pinned: bad range");
+  HIP_TRY(hipSetDevice(e->device));
+  const gpf::GridDev& g = e->g;
+  const size_t N = (size_t)n;
+  auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+  const size_t bytes[8] = {N * g.n_out * 4, N * g.dim_topo * 4, N * g.n_shunt * 4, N * g.n_line, N * 16, N * g.nb_tot * 8, N * g.nb_tot * 8, N * g.n_line * 4};
+  size_t off[8], total = 0;
+  for (int k = 0; k < 8; ++k) { off[k] = total; if ((what >> k) & 1) total += al(bytes[k]); }
+  if (e->res_pin_bytes < total) {
+    if (e->res_pin) (void)hipHostFree(e->res_pin);
+    e->res_pin = nullptr; e->res_pin_bytes = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->res_pin), total, hipHostMallocDefault));
+    e->res_pin_bytes = total;
+  }
+  const void* src[8] = {e->out.p + (size_t)lane0 * g.n_out, e->topo_out.p + (size_t)lane0 * g.dim_topo, e->shunt_bus_out.p + (size_t)lane0 * g.n_shunt,
+                        e->line_status.p + (size_t)lane0 * g.n_line, e->status.p + (size_t)lane0 * 4, e->bus_vm.p + (size_t)lane0 * g.nb_tot,
+                        e->bus_va.p + (size_t)lane0 * g.nb_tot, e->rho.p + (size_t)lane0 * g.n_line};
+  for (int k = 0; k < 8; ++k) {
+    ptrs[k] = nullptr;
+    if (!((what >> k) & 1) || bytes[k] == 0) continue;
+    HIP_TRY(hipMemcpyAsync(e->res_pin + off[k], src[k], bytes[k], hipMemcpyDeviceToHost, e->stream));
+    ptrs[k] = e->res_pin + off[k];
+  }
   HIP_TRY(hipStreamSynchronize(e->stream));
   return GPF_OK;
 }

@@ -358,9 +358,25 @@ class PowerFlowEngine:
         return LaneResults(out=out, topo_vect=tv, shunt_bus=sb, line_status=ls.astype(bool), status=st, bus_vm=bvm, bus_va=bva,
                            _slices=self.out_slices)
 
-    def results(self, lane0: int = 0, n: Optional[int] = None, with_bus: bool = True) -> LaneResults:
+    def results(self, lane0: int = 0, n: Optional[int] = None, with_bus: bool = True, pinned: bool = False) -> LaneResults:
+        """The result rows of lanes ``[lane0, lane0 + n)`` on the host.  ``pinned=True``: the arrays ALIAS a pinned block the engine owns
+        (gpf_get_results_pinned: DMA at the PCIe rate, no second host copy) and are only valid until the next ``results(pinned=True)``
+        call -- for a host agent that reads every lane at every step; copy what must outlive the step."""
         lane0, n = self._range(lane0, n)
         m = self.model
+        if pinned:
+            ptrs = (C.c_void_p * 8)()
+            what = 0b0011111 | (0b1100000 if with_bus else 0)
+            check(self._lib.gpf_get_results_pinned(self._h, lane0, n, what, ptrs), "gpf_get_results_pinned")
+
+            def arr(k, cols, ctype, dtype):
+                if not ptrs[k] or cols == 0:
+                    return np.empty((n, cols), dtype=dtype)
+                return np.ctypeslib.as_array(C.cast(ptrs[k], C.POINTER(ctype)), shape=(n, cols))
+            return LaneResults(out=arr(0, self.n_out, C.c_float, np.float32), topo_vect=arr(1, m.dim_topo, C.c_int32, np.int32),
+                               shunt_bus=arr(2, m.n_shunt, C.c_int32, np.int32), line_status=arr(3, m.n_line, C.c_uint8, np.uint8).view(np.bool_),
+                               status=arr(4, 4, C.c_int32, np.int32), bus_vm=arr(5, self.nb_total, C.c_double, np.float64) if with_bus else None,
+                               bus_va=arr(6, self.nb_total, C.c_double, np.float64) if with_bus else None, _slices=self.out_slices)
         out = np.empty((n, self.n_out), dtype=np.float32)
         tv = np.empty((n, m.dim_topo), dtype=np.int32)
         sb = np.empty((n, m.n_shunt), dtype=np.int32)

@@ -104,8 +104,8 @@ const char* gpf_last_error(void);
 /* ABI version of the library = GPF_ABI_VERSION of the header it was built from.  A binding MUST compare the two before any other
  * call (grid2op_amd/_capi.py does): 300 = round 4 (gpf_set_trajectory(h, cap, what), 22 device pointers, GPF_ST_REDISPATCH,
  * gpf_device_pointers_n); 310 = + gpf_jit_*, GPF_E_UNSUPPORTED, gpf_set_profiling mode 3; 321 = 28 device pointers (action buffers and
- * dispatch / charge state of the environment dynamics), gpf_lane_actions_on_device. */
-#define GPF_ABI_VERSION 321
+ * dispatch / charge state of the environment dynamics), gpf_lane_actions_on_device; 322 = + gpf_get_results_pinned. */
+#define GPF_ABI_VERSION 322
 int gpf_version(void);
 /* Bitwise run-to-run reproducibility is the DEFAULT on every grid: the same lane inputs give bit-identical results from run to
  * run and whatever the lane's position in the batch (grid2op's determinism contract: same seeds -> same episode,
@@ -165,6 +165,12 @@ int gpf_runpf(gpf_handle h, int32_t lane0, int32_t n, int32_t is_dc, int32_t max
 int gpf_solve_lane(gpf_handle h, int32_t lane, const double* inj, const int32_t* topo, const int32_t* shunt_bus, int32_t is_dc,
                    int32_t max_iter, double tol_mva, float* out, int32_t* topo_vect, int32_t* shunt_bus_out, uint8_t* line_status,
                    int32_t* status, double* bus_vm, double* bus_va);
+
+/* gpf_get_results without the second host copy: the rows asked for (bit k of `what`: 0 out, 1 topo_vect, 2 shunt_bus, 3 line_status,
+ * 4 status, 5 bus_vm, 6 bus_va, 7 rho [n][n_line] float32) are copied by DMA into a pinned block the engine owns and ptrs[k] (k < 8)
+ * points at piece k inside it (NULL: not asked for) -- valid until the next call of this function.  A host agent that reads every
+ * lane's rows at every step gets the PCIe rate instead of the pageable-copy rate.  Synchronous. */
+int gpf_get_results_pinned(gpf_handle h, int32_t lane0, int32_t n, int32_t what, void** ptrs /* [8] */);
 
 /* Getters (pandaPowerBackend.py:1566-1619, 278-301, 1439-1462, 1486): synchronise, then copy rows
  * lane0..lane0+n-1.  Any pointer may be NULL.

@@ -107,6 +107,15 @@ def test_random_injections_and_topologies(name, n, seed, load_model):
         _compare(m, r, k, o)
         n_conv += int(o.converged)
     assert n_conv > n // 2
+    # the same rows through the engine's pinned block (gpf_get_results_pinned: DMA, arrays alias the block), whole range and a sub-range
+    rp = eng.results(pinned=True)
+    for key in ("out", "topo_vect", "shunt_bus", "line_status", "status", "bus_vm", "bus_va"):
+        assert np.array_equal(getattr(r, key), getattr(rp, key), equal_nan=True), key
+    assert np.array_equal(rp.p_or, r.p_or, equal_nan=True) and np.array_equal(rp.converged, r.converged)
+    keep = rp.out.copy()
+    lo = n // 3
+    rs = eng.results(lo, n - lo, with_bus=False, pinned=True)              # rewrites the block: `rp` is stale from here on
+    assert rs.bus_vm is None and np.array_equal(rs.out, keep[lo:], equal_nan=True) and np.array_equal(rs.status, r.status[lo:])
     eng.close()
 
 
