@@ -191,9 +191,10 @@ class ShardedEngine:
         for eng in self.engines:
             eng.sync()
 
-    def results(self, lane0: int = 0, n=None, with_bus: bool = True):
+    def results(self, lane0: int = 0, n=None, with_bus: bool = True, pinned: bool = False):
+        """(``pinned``: every device's rows come over by DMA into its engine's pinned block; the concatenation below is the one host copy)"""
         from .engine import LaneResults
-        rs = [eng.results(l0, k, with_bus=with_bus) for eng, l0, k, _ in self._parts(lane0, n)]
+        rs = [eng.results(l0, k, with_bus=with_bus, **({"pinned": True} if pinned else {})) for eng, l0, k, _ in self._parts(lane0, n)]
         cat = lambda f: None if getattr(rs[0], f) is None else np.concatenate([getattr(r, f) for r in rs])  # noqa: E731
         return LaneResults(out=cat("out"), topo_vect=cat("topo_vect"), shunt_bus=cat("shunt_bus"), line_status=cat("line_status"),
                            status=cat("status"), bus_vm=cat("bus_vm"), bus_va=cat("bus_va"), _slices=rs[0]._slices)
