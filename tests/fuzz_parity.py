@@ -95,7 +95,7 @@ def _random_engine(env, n_lanes, seed, limits_scale=None):
 
 
 def fuzz_multistep(env, n_lanes, seed, n_steps=6, auto_reset=False):
-    """ONE launch of `n_steps` env steps == `n_steps` single-step launches, bit for bit, on random topologies with the protections on
+    """ONE launch of `n_steps` env steps == `n_steps` single-step launches (integers bit for bit, floats to float32 rounding) on random topologies with the protections on
     (thermal limits x 0.85: lines trip, lanes black out, with `auto_reset` they restart): the result rows, topo_vect, line status, status,
     protection counters, line cooldowns and episode counters of every lane after the last step, and the status of every step."""
     _, a, T = _random_engine(env, n_lanes, seed, limits_scale=0.85)
@@ -110,9 +110,16 @@ def fuzz_multistep(env, n_lanes, seed, n_steps=6, auto_reset=False):
         b.step(t0 + j, n_steps=1, **kw)
         st_b.append(b.results(with_bus=False).status[:, 0].astype(np.int8))
     ra, rb = a.results(), b.results()
-    same = {"out": np.array_equal(ra.out, rb.out, equal_nan=True), "status": np.array_equal(ra.status, rb.status),
+    # Integers (status, iteration counts, topology, line status, protection counters, cooldowns, episode counters) bit for bit.  The float
+    # rows to float32 rounding: steps >= 2 of a launch start Newton from DC angles obtained with the factors / the static inverse the
+    # launch keeps, a single-step launch factorises afresh -- the float64 solutions agree to ~1e-16 and a float32 cast can round the
+    # other way (seen on 14 substations in the 1 024-lane sweeps: a handful of entries, 1 ulp).
+    so_a, so_b = a.step_outputs(), b.step_outputs()
+    same = {"out": bool(np.array_equal(np.isnan(ra.out), np.isnan(rb.out)) and np.allclose(ra.out, rb.out, rtol=2e-6, atol=2e-5, equal_nan=True)),
+            "status": np.array_equal(ra.status, rb.status),
             "topo_vect": np.array_equal(ra.topo_vect, rb.topo_vect), "line_status": np.array_equal(ra.line_status, rb.line_status),
-            "step_status": np.array_equal(st_a, np.stack(st_b)), "step_outputs": all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a.step_outputs(), b.step_outputs())),
+            "step_status": np.array_equal(st_a, np.stack(st_b)),
+            "step_outputs": bool(np.allclose(so_a[0], so_b[0], rtol=2e-6, atol=1e-6, equal_nan=True) and np.array_equal(so_a[1], so_b[1]) and np.array_equal(so_a[2], so_b[2])),
             "cooldown": np.array_equal(a.cooldown(), b.cooldown()), "episode": all(np.array_equal(x, y) for x, y in zip(a.episode(), b.episode())),
             # (float64 state behind the float32 rows: a multi-step launch starts Newton from the DC factors it keeps across its steps,
             #  a single-step launch factorises afresh -- same solution, last bits of the float64 voltages may differ)

@@ -26,7 +26,7 @@ def test_random_topologies_and_injections_vs_the_c_oracle(env, cascade):
 @pytest.mark.parametrize("env", GRIDS)
 @pytest.mark.parametrize("auto_reset", [False, True])
 def test_one_multi_step_launch_equals_single_step_launches_on_random_topologies(env, auto_reset):
-    """ONE 6-step launch == 6 single-step launches, bit for bit, with the protections on and lines tripping, on random topologies (bus
+    """ONE 6-step launch == 6 single-step launches (integers bit for bit, floats to float32 rounding), protections on and lines tripping, on random topologies (bus
     splits -> topology-class kernels, outages); with auto-reset the failed lanes restart inside the launch as they do between launches."""
     res = fuzz_multistep(env, 320, seed=4321 + GRIDS.index(env), n_steps=6, auto_reset=auto_reset)
     assert res["ok"], res
