@@ -562,7 +562,10 @@ def _cfg_line(rec, value_key="value", extra=()):
     """one BASELINE config: value, unit, [min, median, max] over its windows, roofline fraction, oracle verdict"""
     if not rec:
         return None
-    out = {"value": _r(rec.get(value_key), 5), "unit": (rec.get("unit") or "").split(" (")[0].split(",")[0]}
+    out = {"value": _r(rec.get(value_key), 5)}
+    unit = (rec.get("unit") or "").split(" (")[0].split(",")[0]
+    if unit != "env steps/sec":                               # (the headline's unit goes without saying: the line has a size target)
+        out["unit"] = unit
     if rec.get("windows"):
         out["min_med_max"] = _win3(rec["windows"])          # over N_WIN_CFG = 5 timed windows
     rf = rec.get("roofline")
@@ -602,7 +605,7 @@ def compact_record(res, full_path=None):
                      "observations": "every env step -> HBM" if obs.startswith("every env step") else "last step of a launch only",
                      "cascade": cfg.get("cascade"), "kernels": cfg.get("kernels"), "parallelism": f"static lane shards x{res.get('n_gpus')}, no collective"}
     w = res.get("windows") or {}
-    out["windows"] = {"n": w.get("n"), "steps_each": w.get("steps_each"), "min_med_max": _win3(w), "timed": res.get("timed_quantity")}
+    out["windows"] = {"n": w.get("n"), "steps_each": w.get("steps_each"), "min_med_max": _win3(w), "timed": "wall clock of K steps, barrier + synchronize brackets, MAX over ranks, median window"}
     if res.get("value_hip_event_window") is not None:        # (`value` itself is the wall-clock figure)
         out["value_hip_event_window"] = _r(res["value_hip_event_window"], 6)
     out["roofline"] = _roof(res.get("roofline"))
@@ -610,7 +613,7 @@ def compact_record(res, full_path=None):
     if cb:
         ac = cb.get("all_cores") or {}
         out["cpu_baseline"] = {"value": _r(cb.get("value"), 5), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
-                               "sample": (cb.get("sample") or "")[:72], "all_cores": {"value": _r(ac.get("value"), 5), "cores": ac.get("cores")} if ac else None,
+                               "sample": (cb.get("sample") or "")[:56], "all_cores": {"value": _r(ac.get("value"), 5), "cores": ac.get("cores")} if ac else None,
                                "note": "dense-NR C port of pandapower's algorithm: weak stand-in for lightsim2grid's sparse KLU",
                                "pandapower": "unavailable (not installed)", "lightsim2grid": "unavailable (not installed)"}
     else:
