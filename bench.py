@@ -143,8 +143,11 @@ def reference_step_loop():
             err = repr(exc)[:200]
     else:
         err = None
-    for rel, src in ((os.path.join("profiles", "r04_reference_step_loop_mi355x.json"),
-                      "committed profiles/r04_reference_step_loop_mi355x.json: tests/reference_on_hip.py timing on an MI355X box with the unmodified "
+    import glob
+    staged = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_reference_step_loop_mi355x.json")))      # the newest round's record
+    rel_staged = os.path.relpath(staged[-1], ROOT) if staged else os.path.join("profiles", "r05_reference_step_loop_mi355x.json")
+    for rel, src in ((rel_staged,
+                      f"committed {rel_staged}: tests/reference_on_hip.py timing on an MI355X box with the unmodified "
                       "reference package staged for that call (tools/gpurun_staged.sh); NOT measured in this run (the reference cannot be staged here)"),
                      (os.path.join("profiles", "r02_framework_loop_cpu.json"), "committed profiles/r02_framework_loop_cpu.json (build container CPU, round 2)")):
         try:
@@ -468,6 +471,16 @@ def measure_modes(ctx, eng, k, w, step_kw, n_win, preroll_steps, spl=None, last_
     return w_obs, w_last, t
 
 
+DEFAULT_STEPS_PER_LAUNCH = 16
+DRIVER_STEPS = 20             # the driver's command: bench.py --gpus 1 --steps 20 --warmup W (BENCH_rNN.json)
+
+
+def launch_length(steps: int, spl: int = DEFAULT_STEPS_PER_LAUNCH) -> int:
+    """Env steps per kernel launch of the headline for a timed window of ``steps`` steps: a window of K <= 2 * spl steps is ONE launch of K
+    steps, not two half-size ones (reported in config; tests/test_gpu_bench_parity.py checks the headline at exactly these lengths)."""
+    return steps if (spl > 1 and spl < steps <= 2 * spl) else spl
+
+
 N1_118_SPL = int(os.environ.get("GRIDPF_BENCH_N1_118_SPL", "16"))   # env steps per launch of the 118-substation N-1 fan-out (its observation trajectory is 2.7 GB per step: 43 GB of the 288 GB at 16)
 N_WIN_CFG = 5           # timed windows of every BASELINE-config secondary (min / median / max reported)
 
@@ -701,7 +714,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each (the median one is reported)")
-    ap.add_argument("--steps-per-launch", type=int, default=16,
+    ap.add_argument("--steps-per-launch", type=int, default=DEFAULT_STEPS_PER_LAUNCH,
                     help="env steps per kernel launch (gpf_step_n): every step does the full work and writes its results; between "
                          "the steps of a launch the lane state stays on chip (1 = one launch per step, also reported)")
     ap.add_argument("--env", default="l2rpn_case14_sandbox")
@@ -741,8 +754,7 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args, sys.argv[1:]))
     ctx = Ctx(args)
-    if args.steps_per_launch > 1 and args.steps_per_launch < args.steps <= 2 * args.steps_per_launch:
-        args.steps_per_launch = args.steps     # a timed window of K <= 32 steps is ONE launch of K steps (not two half-size ones); reported in config
+    args.steps_per_launch = launch_length(args.steps, args.steps_per_launch)
     if ctx.world != args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ctx.world}: launch with --nproc-per-node {args.gpus} "
                          f"(or without torchrun: bench.py starts the ranks itself)\n")

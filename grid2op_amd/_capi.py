@@ -16,7 +16,7 @@ __all__ = ["lib", "GridPFError", "GpfGridDesc", "GpfLayout", "GpfStepOpts", "lib
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libgridpf.so"
-ABI_VERSION = 322          # include/gridpf.h GPF_ABI_VERSION
+ABI_VERSION = 323          # include/gridpf.h GPF_ABI_VERSION
 
 EXPORTED_SYMBOLS = [
     "gpf_last_error", "gpf_version", "gpf_set_deterministic", "gpf_device_count", "gpf_create", "gpf_destroy", "gpf_get_layout", "gpf_n_lanes",
@@ -78,7 +78,7 @@ class GpfLayout(C.Structure):
 class GpfStepOpts(C.Structure):
     _fields_ = [("max_iter", C.c_int32), ("tol_mva", C.c_double), ("rebalance", C.c_double), ("cascade", C.c_int32),
                 ("hard_overflow", C.c_float), ("soft_overflow", C.c_float), ("nb_ts_allowed", C.c_int32), ("max_rounds", C.c_int32),
-                ("is_dc", C.c_int32), ("auto_reset", C.c_int32), ("warm_start", C.c_int32), ("nb_ts_reco", C.c_int32)]
+                ("is_dc", C.c_int32), ("auto_reset", C.c_int32), ("warm_start", C.c_int32), ("track_cooldown", C.c_int32), ("nb_ts_reco", C.c_int32)]
 
 
 _lib: Optional[C.CDLL] = None

@@ -85,7 +85,10 @@ class _LanePool:
 class HipBackend(Backend):
     """See module docstring.  Keyword arguments mirror ``PandaPowerBackend.__init__``
     (pandaPowerBackend.py:119-143) so that ``Runner`` can re-instantiate the class from ``_my_kwargs``
-    (Runner/runner.py:739-756); ``lightsim2grid``, ``dist_slack`` and ``with_numba`` are accepted and ignored."""
+    (Runner/runner.py:739-756); ``lightsim2grid`` and ``with_numba`` select pandapower solver variants with the same results and are
+    accepted and ignored.  ``dist_slack=True`` is REFUSED (`BackendError`): pandapower then spreads the slack power over the generators by
+    ``gen.slack_weight`` (pandaPowerBackend.py:1097-1105, ``distributed_slack=self._dist_slack``), the engine solves the single-slack power
+    flow only -- accepting the flag would return results that silently differ from PandaPowerBackend's."""
 
     shunts_data_available = True
 
@@ -102,6 +105,9 @@ class HipBackend(Backend):
         """``specialize`` (beyond PandaPowerBackend's arguments): the engine's kernels are compiled at run time for the loaded grid
         (`PowerFlowEngine.specialize`: bit-identical results, ~12 % less time per ``runpf``; needs hipcc on the host -- without it the
         shipped kernels stay and a warning says so)."""
+        if dist_slack:
+            raise BackendError("HipBackend: dist_slack=True (pandapower's distributed slack, pandaPowerBackend.py:1097-1105) is not implemented -- "
+                               "the engine solves the single-slack power flow; refusing rather than returning results that differ silently")
         Backend.__init__(self,
                          detailed_infos_for_cascading_failures=detailed_infos_for_cascading_failures,
                          can_be_copied=can_be_copied,

@@ -47,6 +47,10 @@ __global__ void fanout_kernel(GridDev g, Bufs b, int src, int dst0, int n_dst, c
   const int* ss = b.shunt_bus + (size_t)src * g.n_shunt;
   int* ds = b.shunt_bus + (size_t)dst * g.n_shunt;
   for (int i = tid; i < g.n_shunt; i += blockDim.x) ds[i] = ss[i];
+  // the contingency lane is the source's environment with one line out: its protection counters and line cooldowns are the source's
+  // (as gpf_copy_lanes and simulate_prepare_kernel copy them; a step that tracks cooldowns would otherwise start from stale ones)
+  if (b.overflow_count) for (int i = tid; i < g.n_line; i += blockDim.x) b.overflow_count[(size_t)dst * g.n_line + i] = b.overflow_count[(size_t)src * g.n_line + i];
+  if (b.cooldown) for (int i = tid; i < g.n_line; i += blockDim.x) b.cooldown[(size_t)dst * g.n_line + i] = b.cooldown[(size_t)src * g.n_line + i];
 }
 
 // gpf_solve_lane: the lane's inputs straight from the pinned host block (device-mapped: one PCIe read per element, all in flight
@@ -447,6 +451,7 @@ bool upload_flats(const gpf::Symbolic& S, DevArr<int>& buf, gpf::SymDev& D, int 
     gpf::FlatDev& f = D.fl[k];
     f.n_fwd = F.n_fwd; f.n_scale = F.n_scale; f.n_scale_rhs = F.n_scale_rhs; f.n_back = F.n_back; f.scale_off = F.scale_off;
     f.back_off = F.back_off; f.rhs_field0 = F.rhs_field0; f.n_words = (int)F.words.size(); f.wave_closed = F.wave_closed ? 1 : 0;
+    f.solo_fwd = (int)F.solo_fwd; f.solo_back = (int)F.solo_back;
   }
   if (buf.upload(all.data(), all.size()) != hipSuccess) return false;
   for (int k = 0; k < 4; ++k) D.flat[k] = buf.p + off[k];
@@ -636,7 +641,7 @@ int plan_launch_uncached(gpf_engine* e, int lane0, int n, LaunchPlan& p, LaunchP
   const bool blocks_ok = e->g.n_busbar <= GPF_MAX_BUSBAR_BLOCKS;
   if (e->g.n_sub * mb <= 32000) {
 #ifdef GPF_TIMING
-    if (e->work.n < (size_t)e->cap_lanes * 40) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->cap_lanes * 40)); }
+    if (e->work.n < (size_t)e->cap_lanes * gpf::GPF_WORK_ROW) { e->work.release(); HIP_TRY(e->work.alloc((size_t)e->cap_lanes * gpf::GPF_WORK_ROW)); }
 #endif
     // lanes with split substations: (1) topology classes -- the single-busbar kernel on the lane's bus-level graph --, else
     // (2) the NB = n_busbar kernel; the lanes without a split keep the plain single-busbar kernel (mixed batch: two launches)
@@ -1786,7 +1791,7 @@ int step_range(gpf_engine* e, const gpf::Bufs& b_in, int lane0, int n, int t0, i
   sa.t = t0; sa.T = T; sa.rebalance_on = o->rebalance > 0.0 ? 1 : 0; sa.rebalance = o->rebalance; sa.cascade = o->cascade;
   sa.is_dc = o->is_dc ? 1 : 0; sa.n_steps = n_steps; sa.auto_reset = o->auto_reset ? 1 : 0; sa.warm_start = o->warm_start ? 1 : 0;
   sa.nb_ts_allowed = o->nb_ts_allowed; sa.max_rounds = o->max_rounds; sa.hard_overflow = o->hard_overflow; sa.soft_overflow = o->soft_overflow;
-  sa.nb_ts_reco = o->nb_ts_reco;
+  sa.nb_ts_reco = o->track_cooldown ? std::max(o->nb_ts_reco, 0) : -1;      // (kernel side: < 0 = the counters are not maintained)
   sa.lane0 = lane0;
   const double tol_pu = o->tol_mva / e->g.sn_mva;
   hipEvent_t ea = nullptr, eb = nullptr;
@@ -2188,9 +2193,11 @@ int gpf_simulate_batch(gpf_handle e, int32_t t_obs, int32_t time_step, int32_t n
   gpf::Bufs b = e->bufs();
   if (fc) b.chron = e->forecast.p;
   b.maint = nullptr;
+  b.maint_dur = nullptr;               // (the cursor of a scratch lane is a row of the FORECAST tables: the outage tables have no such rows)
   b.traj_rho = nullptr; b.traj_status = nullptr; b.traj_out = nullptr; b.traj_topo = nullptr; b.traj_shb = nullptr; b.traj_lstat = nullptr; b.traj_cap = 0;
   gpf_step_opts oo = *o;
   oo.auto_reset = 0; oo.warm_start = 0;
+  oo.track_cooldown = 0;               // one look-ahead step: the cooldowns copied from the source lanes stand
   const double tm4 = sim_timing ? now_us() : 0.0;
   rc = step_range(e, b, dst_lane0, (int)n_dst, 0, T_eff, 1, &oo, "gpf_simulate_batch");
   if (sim_timing)
@@ -2203,7 +2210,7 @@ int gpf_step(gpf_handle e, int32_t t, int32_t max_iter, double tol_mva, double r
              float soft_overflow, int32_t nb_ts_allowed, int32_t max_rounds, int32_t is_dc) {
   gpf_step_opts o{};
   o.max_iter = max_iter; o.tol_mva = tol_mva; o.rebalance = rebalance; o.cascade = cascade; o.hard_overflow = hard_overflow;
-  o.soft_overflow = soft_overflow; o.nb_ts_allowed = nb_ts_allowed; o.max_rounds = max_rounds; o.is_dc = is_dc; o.auto_reset = 0; o.warm_start = 0; o.nb_ts_reco = -1;
+  o.soft_overflow = soft_overflow; o.nb_ts_allowed = nb_ts_allowed; o.max_rounds = max_rounds; o.is_dc = is_dc; o.auto_reset = 0; o.warm_start = 0; o.track_cooldown = 0; o.nb_ts_reco = 0;
   return gpf_step_n(e, t, 1, &o);
 }
 
@@ -2583,7 +2590,7 @@ int gpf_ptdf_build(gpf_handle e, int32_t lane) {
       const bool dangling = (n_lines_at[lf[k]] == 1 && n_other_at[lf[k]] == 0) || (n_lines_at[lt[k]] == 1 && n_other_at[lt[k]] == 0);
       for (int l = 0; l < g.n_line; ++l) {
         const double hlk = e->h_ptdf[(size_t)l * nbt + lf[k]] - e->h_ptdf[(size_t)l * nbt + lt[k]];
-        lo_[(size_t)l * line_pad + k] = std::fabs(den) < 1e-8 ? (dangling ? 0.0 : std::nan("")) : (l == k ? -1.0 : hlk / den);
+        lo_[(size_t)l * line_pad + k] = std::fabs(den) < 1e-8 ? (dangling ? (l == k ? -1.0 : 0.0) : std::nan("")) : (l == k ? -1.0 : hlk / den);   // (diagonal -1 as in the batch builder)
       }
     }
     e->lodf.release();
@@ -2616,6 +2623,9 @@ static gpf::PtdfDev ptdf_dev(gpf_engine* e) {
 int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lodf, int32_t* n_classes_out) {
   if (!check_range(e, lane0, n) || n <= 0) return fail(GPF_E_INVALID, "gpf_ptdf_build_batch: bad lane range");
   HIP_TRY(hipSetDevice(e->device));
+  // a rebuild overwrites the lane -> class map and may regrow the device tables before it can fail: from here until it has succeeded there
+  // are NO tables (gpf_ptdf_flows / gpf_ptdf_batch_get refuse), instead of new lane classes against old tables
+  e->ptdf_ready = false; e->ptdf_batch = false;
   const gpf::GridDev& g = e->g;
   const gpf::OutOff& oo = e->oo;
   const int nl = g.n_line, nbt = g.nb_tot, nsh = g.n_shunt;
@@ -2839,20 +2849,22 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
     lds_set[e->device & 63][resident] = lds;
   }
   if (stage_timing) tm[4] = now_us();
-  hipEvent_t ea = nullptr, eb = nullptr;
-  HIP_TRY(hipEventCreate(&ea)); HIP_TRY(hipEventCreate(&eb));
-  HIP_TRY(hipEventRecord(ea, e->stream));
+  struct EvPair {                                   // destroyed on every path out of the function
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EvPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+  } ev;
+  HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b));
+  HIP_TRY(hipEventRecord(ev.a, e->stream));
   if (resident) hipLaunchKernelGGL(gpf::ptdf_build_lds_kernel, dim3(nc), dim3(gpf::PTDFB_LDS_THREADS), lds, e->stream, D);
   else hipLaunchKernelGGL(gpf::ptdf_build_kernel, dim3(nc), dim3(gpf::PTDFB_THREADS), lds, e->stream, D);
   hipError_t le = hipGetLastError();
-  HIP_TRY(hipEventRecord(eb, e->stream));
-  if (le != hipSuccess) { (void)hipEventDestroy(ea); (void)hipEventDestroy(eb); return fail(GPF_E_DEVICE, std::string("ptdf_build_kernel: ") + hipGetErrorString(le)); }
+  HIP_TRY(hipEventRecord(ev.b, e->stream));
+  if (le != hipSuccess) return fail(GPF_E_DEVICE, std::string("ptdf_build_kernel: ") + hipGetErrorString(le));
   e->h_ptdfb_status.assign(nc, 0);
   HIP_TRY(hipMemcpyAsync(e->h_ptdfb_status.data(), e->ptdfb_status.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, ea, eb);
-  (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+  (void)hipEventElapsedTime(&ms, ev.a, ev.b);
   e->ptdfb_kernel_ms = ms;
   if (stage_timing)
     fprintf(stderr, "[gridpf] ptdf_build_batch %d lanes, %d classes: rows to the host %.0f us, grouping %.0f, descriptors %.0f, slots + uploads %.0f, kernel + status %.0f\n",

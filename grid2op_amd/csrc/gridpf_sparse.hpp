@@ -91,8 +91,9 @@ __host__ __device__ inline size_t stat_bytes(const StatOff& o, int tier, bool nb
 struct FlatDev {
   int n_fwd, n_scale, n_scale_rhs, n_back, scale_off, back_off, rhs_field0, n_words;
   int wave_closed;   // (group width 128) every destination of a pass is accumulated by ONE wavefront (FlatProg::wave_closed)
+  int solo_fwd, solo_back;   // (group width 128) bit k: forward / back pass k only has items in wavefront 0 (FlatProg::solo_fwd)
 };
-#define GPF_FLATDEV_INTS(X) X(n_fwd) X(n_scale) X(n_scale_rhs) X(n_back) X(scale_off) X(back_off) X(rhs_field0) X(n_words) X(wave_closed)
+#define GPF_FLATDEV_INTS(X) X(n_fwd) X(n_scale) X(n_scale_rhs) X(n_back) X(scale_off) X(back_off) X(rhs_field0) X(n_words) X(wave_closed) X(solo_fwd) X(solo_back)
 static_assert(sizeof(FlatDev) == sizeof(int) * (0 GPF_FLATDEV_INTS(GPF_COUNT_FIELD)), "GPF_FLATDEV_INTS must list every field of FlatDev");
 // group width (threads per instance) -> index of its flat-program variant: 16, 32, 64, 128 -> 0 .. 3
 __host__ __device__ constexpr int gw_index(int gw) { return gw >= 128 ? 3 : gw >= 64 ? 2 : gw >= 32 ? 1 : 0; }
@@ -145,12 +146,16 @@ struct DevParamsS {
 // at the next barrier and distort the phases) and written to b.work[inst][32] once at the end of the kernel.
 #ifdef GPF_TIMING
 constexpr int GPF_NSTAMP = 40;
+constexpr int GPF_NPASS_T = 48;     // + per-pass stamps of the first factorisation of a solve (block_lu_flat), kept in LDS
+constexpr int GPF_WORK_ROW = GPF_NSTAMP + GPF_NPASS_T;
+static __shared__ long long gpf_pass_t[GPF_NPASS_T];
 struct Stamps { long long v[GPF_NSTAMP]; };
 #define GPF_STAMPS(k) do { stamps.v[(k)] = (long long)__builtin_readcyclecounter(); } while (0)
 #define GPF_STAMPS_PARAM , Stamps& stamps
 #define GPF_STAMPS_ARG , stamps
 #define GPF_STAMPS_DECL Stamps stamps; for (int k_ = 0; k_ < GPF_NSTAMP; ++k_) stamps.v[k_] = 0
-#define GPF_STAMPS_FLUSH(inst_) do { if (tid == 0) for (int k_ = 0; k_ < GPF_NSTAMP; ++k_) P->b.work[(size_t)(inst_) * GPF_NSTAMP + k_] = (double)stamps.v[k_]; } while (0)
+#define GPF_STAMPS_FLUSH(inst_) do { if (tid == 0) { for (int k_ = 0; k_ < GPF_NSTAMP; ++k_) P->b.work[(size_t)(inst_) * GPF_WORK_ROW + k_] = (double)stamps.v[k_]; \
+    for (int k_ = 0; k_ < GPF_NPASS_T; ++k_) P->b.work[(size_t)(inst_) * GPF_WORK_ROW + GPF_NSTAMP + k_] = (double)gpf_pass_t[k_]; } } while (0)
 #else
 #define GPF_STAMPS(k) do {} while (0)
 #define GPF_STAMPS_PARAM
@@ -177,8 +182,12 @@ struct Stamps { long long v[GPF_NSTAMP]; };
 // phase -- a full LDS round trip (~100+ cycles) on each of the ~150 phases of a step.  Instances served by several wavefronts
 // (GW > WAVE) keep the real workgroup barrier.  -DGPF_HARD_SYNC restores __syncthreads() everywhere.
 #ifndef GPF_HARD_SYNC
-#define GPF_LSYNC() do { if (GW > WAVE) __syncthreads(); else { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } } while (0)
+// (several wavefronts per instance: the boundary waits for the wavefront's LDS operations and the workgroup barrier -- NOT, as __syncthreads()
+//  would, for its global loads / stores in flight: the flat-program sweeps fetch their item words from L2 two passes ahead, GPF_PF2_ON)
+#define GPF_PF2_ON true
+#define GPF_LSYNC() do { if (GW > WAVE) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); } } while (0)
 #else
+#define GPF_PF2_ON false
 #define GPF_LSYNC() GPF_SYNC()
 #endif
 
@@ -665,62 +674,102 @@ __device__ inline bool block_lu_flat(const FlatDev& F, PP prog, double* __restri
   const long long t_lu0 = __builtin_readcyclecounter();
 #endif
   bool ok = true;
+  constexpr bool PF2 = GPF_PF2_ON && GW > WAVE;      // item words fetched TWO passes ahead (see GPF_LSYNC)
   char* const a0 = reinterpret_cast<char*>(A);
   char* const a1 = a0 + HS * 8;
 #define FL_LD2(base, f) (*reinterpret_cast<const double2*>((base) + (f)))
 #define FL_D(base, f) (reinterpret_cast<double*>((base) + (f)))
-  {
-    int at = 2 * tid;
-    unsigned w0 = (unsigned)prog[at], w1 = (unsigned)prog[at + 1];
-    for (int k = 0; k < F.n_fwd; ++k) {
-      at += 2 * GW;
-      const unsigned n0 = (unsigned)prog[at], n1 = (unsigned)prog[at + 1];     // words of the next pass
-      if (w0 != 0xffffffffu) {
-        const unsigned fd = w0 & 0xffffu, fl = w0 >> 16, fu = w1 & 0xffffu, fp = w1 >> 16;
-        const double2 dA = FL_LD2(a0, fp), dB = FL_LD2(a1, fp), lA = FL_LD2(a0, fl), lB = FL_LD2(a1, fl);
-        const double2 uA = FL_LD2(a0, fu), uB = FL_LD2(a1, fu);
-        const double rd = -fast_rcp(fma(dA.x, dB.y, -dA.y * dB.x));
-        // T = A_l * adj(D)
-        const double t00 = fma(lA.x, dB.y, -lA.y * dB.x), t01 = fma(lA.y, dA.x, -lA.x * dA.y);
-        const double t10 = fma(lB.x, dB.y, -lB.y * dB.x), t11 = fma(lB.y, dA.x, -lB.x * dA.y);
-        double* d0_ = FL_D(a0, fd);
-        double* d1_ = FL_D(a1, fd);
-        atomicAdd(&d0_[0], fma(t00, uA.x, t01 * uB.x) * rd);
-        atomicAdd(&d1_[0], fma(t10, uA.x, t11 * uB.x) * rd);
-        if (fd < (unsigned)F.rhs_field0) {     // (a right-hand-side pseudo-slot: its second column is padding, nothing to accumulate)
-          atomicAdd(&d0_[1], fma(t00, uA.y, t01 * uB.y) * rd);
-          atomicAdd(&d1_[1], fma(t10, uA.y, t11 * uB.y) * rd);
-        }
+#ifdef GPF_TIMING
+#define GPF_PASS_T(i_) do { if (dbg && tid == 0 && (i_) < GPF_NPASS_T) gpf_pass_t[(i_)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define GPF_PASS_T(i_) do {} while (0)
+#endif
+  GPF_PASS_T(0);
+  // the lane's item of a forward pass: A[dst] -= A[l] inv(D_p) A[u]
+  auto fwd_item = [&](const unsigned w0, const unsigned w1) {
+    if (w0 != 0xffffffffu) {
+      const unsigned fd = w0 & 0xffffu, fl = w0 >> 16, fu = w1 & 0xffffu, fp = w1 >> 16;
+      const double2 dA = FL_LD2(a0, fp), dB = FL_LD2(a1, fp), lA = FL_LD2(a0, fl), lB = FL_LD2(a1, fl);
+      const double2 uA = FL_LD2(a0, fu), uB = FL_LD2(a1, fu);
+      const double rd = -fast_rcp(fma(dA.x, dB.y, -dA.y * dB.x));
+      // T = A_l * adj(D)
+      const double t00 = fma(lA.x, dB.y, -lA.y * dB.x), t01 = fma(lA.y, dA.x, -lA.x * dA.y);
+      const double t10 = fma(lB.x, dB.y, -lB.y * dB.x), t11 = fma(lB.y, dA.x, -lB.x * dA.y);
+      double* d0_ = FL_D(a0, fd);
+      double* d1_ = FL_D(a1, fd);
+      atomicAdd(&d0_[0], fma(t00, uA.x, t01 * uB.x) * rd);
+      atomicAdd(&d1_[0], fma(t10, uA.x, t11 * uB.x) * rd);
+      if (fd < (unsigned)F.rhs_field0) {     // (a right-hand-side pseudo-slot: its second column is padding, nothing to accumulate)
+        atomicAdd(&d0_[1], fma(t00, uA.y, t01 * uB.y) * rd);
+        atomicAdd(&d1_[1], fma(t10, uA.y, t11 * uB.y) * rd);
       }
-      GPF_LSYNC();
-      w0 = n0; w1 = n1;
     }
+  };
+  // Walk of a sweep's passes: lane t executes item t of every pass, then the phase boundary.
+  //  * The words of pass k + 1 are fetched before pass k computes; PF2 (several wavefronts per instance, whose phase boundary does not
+  //    wait for global loads): those of pass k + 2, through three register pairs in rotation -- a plain copy "next = the one after"
+  //    would wait for the load it copies.
+  //  * SOLO passes (several wavefronts per instance; FlatDev::solo_fwd / solo_back): every item of the pass sits in wavefront 0, which
+  //    runs it alone, and between two consecutive solo passes there is NO workgroup barrier and no wait for the atomics -- the LDS
+  //    executes one wavefront's operations in issue order, the other wavefront sleeps at the barrier that ends the run.  A pass is
+  //    latency (LDS round trip -> arithmetic -> LDS round trip, tools/lds_pass_bench.hip: 450 cycles for one wavefront alone, 630 -- 800
+  //    for two wavefronts with the barrier and 4 instances per CU): the narrow tail levels and the back substitution of the
+  //    118-substation grids (12 of 19 passes per factorisation) pay the single-wavefront price.
+#define GPF_WALK(n_, at0_, MASK_, NEXT_SOLO_, ITEM_, TB_)                                                                                   \
+  {                                                                                                                                \
+    const unsigned solo_ = GW > WAVE ? (unsigned)(MASK_) : 0u;                                                                     \
+    const int n_pass_ = (n_);                                                                                                      \
+    auto step_ = [&](const unsigned a_, const unsigned b_, const int k) {                                                          \
+      const bool so_ = GW > WAVE && k < 32 && ((solo_ >> (k & 31)) & 1u);                                                          \
+      if (!so_ || tid < WAVE) ITEM_(a_, b_);                                                                                       \
+      const bool sn_ = so_ && (k + 1 < n_pass_ ? (k + 1 < 32 && ((solo_ >> ((k + 1) & 31)) & 1u)) : (GW > WAVE && (NEXT_SOLO_)));  \
+      if (sn_) { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }                 \
+      else GPF_LSYNC();                                                                                                            \
+      GPF_PASS_T((TB_) + k);                                                                                                       \
+    };                                                                                                                             \
+    int at = (at0_) + 2 * tid;                                                                                                     \
+    unsigned p0 = (unsigned)prog[at], p1 = (unsigned)prog[at + 1];                                                                 \
+    if (PF2) {                                                                                                                     \
+      at += 2 * GW;                                                                                                                \
+      unsigned q0 = (unsigned)prog[at], q1 = (unsigned)prog[at + 1], r0, r1;                                                       \
+      for (int k = 0; k < n_pass_; k += 3) {                                                                                       \
+        at += 2 * GW; r0 = (unsigned)prog[at]; r1 = (unsigned)prog[at + 1];                                                        \
+        step_(p0, p1, k);                                                                                                          \
+        if (k + 1 >= n_pass_) break;                                                                                               \
+        at += 2 * GW; p0 = (unsigned)prog[at]; p1 = (unsigned)prog[at + 1];                                                        \
+        step_(q0, q1, k + 1);                                                                                                      \
+        if (k + 2 >= n_pass_) break;                                                                                               \
+        at += 2 * GW; q0 = (unsigned)prog[at]; q1 = (unsigned)prog[at + 1];                                                        \
+        step_(r0, r1, k + 2);                                                                                                      \
+      }                                                                                                                            \
+    } else {                                                                                                                       \
+      for (int k = 0; k < n_pass_; ++k) {                                                                                          \
+        at += 2 * GW;                                                                                                              \
+        const unsigned n0 = (unsigned)prog[at], n1 = (unsigned)prog[at + 1];     /* words of the next pass */                      \
+        step_(p0, p1, k);                                                                                                          \
+        p0 = n0; p1 = n1;                                                                                                          \
+      }                                                                                                                            \
+    }                                                                                                                              \
   }
+  GPF_WALK(F.n_fwd, 0, F.solo_fwd, F.n_back > 0 && (F.solo_back & 1), fwd_item, 1)   // (the first back pass continues a solo run)
 #ifdef GPF_TIMING
   const long long t_lu1 = __builtin_readcyclecounter();
 #endif
   // back substitution, levels in reverse, every entry of a level concurrently: s_p -= A_pj x_j with x_j = inv(D_j) s_j formed by
   // the item itself from the column's accumulated right-hand side (complete: j was eliminated after p, its own entries ran in an
   // earlier pass) -- U and the right-hand side are never scaled, so there is no scaling pass between the two sweeps
-  {
-    int at = F.back_off + 2 * tid;
-    unsigned w0 = (unsigned)prog[at], w1 = (unsigned)prog[at + 1];
-    for (int k = 0; k < F.n_back; ++k) {
-      at += 2 * GW;
-      const unsigned n0 = (unsigned)prog[at], n1 = (unsigned)prog[at + 1];
-      if (w0 != 0xffffffffu) {
-        const unsigned fu = w0 & 0xffffu, fj = w0 >> 16, fdj = fj - (unsigned)F.rhs_field0;
-        const double2 uA = FL_LD2(a0, fu), uB = FL_LD2(a1, fu), dA = FL_LD2(a0, fdj), dB = FL_LD2(a1, fdj);
-        const double s0 = *FL_D(a0, fj), s1 = *FL_D(a1, fj);
-        const double rd = fast_rcp(fma(dA.x, dB.y, -dA.y * dB.x));
-        const double x0 = fma(dB.y, s0, -dA.y * s1) * rd, x1 = fma(dA.x, s1, -dB.x * s0) * rd;
-        atomicAdd(FL_D(a0, w1), -fma(uA.x, x0, uA.y * x1));
-        atomicAdd(FL_D(a1, w1), -fma(uB.x, x0, uB.y * x1));
-      }
-      GPF_LSYNC();
-      w0 = n0; w1 = n1;
+  auto back_item = [&](const unsigned w0, const unsigned w1) {
+    if (w0 != 0xffffffffu) {
+      const unsigned fu = w0 & 0xffffu, fj = w0 >> 16, fdj = fj - (unsigned)F.rhs_field0;
+      const double2 uA = FL_LD2(a0, fu), uB = FL_LD2(a1, fu), dA = FL_LD2(a0, fdj), dB = FL_LD2(a1, fdj);
+      const double s0 = *FL_D(a0, fj), s1 = *FL_D(a1, fj);
+      const double rd = fast_rcp(fma(dA.x, dB.y, -dA.y * dB.x));
+      const double x0 = fma(dB.y, s0, -dA.y * s1) * rd, x1 = fma(dA.x, s1, -dB.x * s0) * rd;
+      atomicAdd(FL_D(a0, w1), -fma(uA.x, x0, uA.y * x1));
+      atomicAdd(FL_D(a1, w1), -fma(uB.x, x0, uB.y * x1));
     }
-  }
+  };
+  GPF_WALK(F.n_back, F.back_off, F.solo_back, false, back_item, 1 + F.n_fwd)
 #ifdef GPF_TIMING
   if (dbg) { dbg[0] = t_lu1 - t_lu0; dbg[1] = (long long)__builtin_readcyclecounter() - t_lu1; }
 #endif
@@ -740,49 +789,40 @@ __device__ inline bool scalar_lu_flat(const FlatDev& F, PP prog, double* __restr
   const long long t_lu0 = __builtin_readcyclecounter();
 #endif
   bool ok = true;
+  constexpr bool PF2 = GPF_PF2_ON && GW > WAVE;
   char* const a0 = reinterpret_cast<char*>(A);
   char* const fb = reinterpret_cast<char*>(fac);
   auto facp = [&](unsigned f) -> double* { return reinterpret_cast<double*>(fb + (COMPACT ? (f >> 1) : f)); };
-  {
-    int at = 2 * tid;
-    unsigned w0 = (unsigned)prog[at], w1 = (unsigned)prog[at + 1];
-    for (int k = 0; k < F.n_fwd; ++k) {
-      at += 2 * GW;
-      const unsigned n0 = (unsigned)prog[at], n1 = (unsigned)prog[at + 1];
-      const unsigned fd = w0 & 0xffffu, fl = w0 >> 16, fu = w1 & 0xffffu, fp = w1 >> 16;
-      const bool is_r = (int)fd >= F.rhs_field0;
-      if (w0 != 0xffffffffu && (FACTOR || is_r)) {
-        const double d = *facp(fp), al = *facp(fl);
-        const double x = is_r ? *FL_D(a0, fu) : *facp(fu);
-        double* dst = is_r ? FL_D(a0, fd) : facp(fd);
-        atomicAdd(dst, -(al * x) * fast_rcp(d));
-      }
-      GPF_LSYNC();
-      w0 = n0; w1 = n1;
+  auto fwd_item = [&](const unsigned w0, const unsigned w1) {
+    const unsigned fd = w0 & 0xffffu, fl = w0 >> 16, fu = w1 & 0xffffu, fp = w1 >> 16;
+    const bool is_r = (int)fd >= F.rhs_field0;
+    if (w0 != 0xffffffffu && (FACTOR || is_r)) {
+      const double d = *facp(fp), al = *facp(fl);
+      const double x = is_r ? *FL_D(a0, fu) : *facp(fu);
+      double* dst = is_r ? FL_D(a0, fd) : facp(fd);
+      atomicAdd(dst, -(al * x) * fast_rcp(d));
     }
-  }
+  };
+#undef GPF_PASS_T
+#define GPF_PASS_T(i_) do {} while (0)
+  GPF_WALK(F.n_fwd, 0, F.solo_fwd, F.n_back > 0 && (F.solo_back & 1), fwd_item, 0)
 #ifdef GPF_TIMING
   const long long t_lu1 = __builtin_readcyclecounter();
 #endif
-  {
-    int at = F.back_off + 2 * tid;
-    unsigned w0 = (unsigned)prog[at], w1 = (unsigned)prog[at + 1];
-    for (int k = 0; k < F.n_back; ++k) {
-      at += 2 * GW;
-      const unsigned n0 = (unsigned)prog[at], n1 = (unsigned)prog[at + 1];
-      if (w0 != 0xffffffffu) {
-        const unsigned fj = w0 >> 16;
-        atomicAdd(FL_D(a0, w1), -(*facp(w0 & 0xffffu) * *FL_D(a0, fj)) * fast_rcp(*facp(fj - (unsigned)F.rhs_field0)));
-      }
-      GPF_LSYNC();
-      w0 = n0; w1 = n1;
+  auto back_item = [&](const unsigned w0, const unsigned w1) {
+    if (w0 != 0xffffffffu) {
+      const unsigned fj = w0 >> 16;
+      atomicAdd(FL_D(a0, w1), -(*facp(w0 & 0xffffu) * *FL_D(a0, fj)) * fast_rcp(*facp(fj - (unsigned)F.rhs_field0)));
     }
-  }
+  };
+  GPF_WALK(F.n_back, F.back_off, F.solo_back, false, back_item, 0)
 #ifdef GPF_TIMING
   if (dbg) { dbg[0] = t_lu1 - t_lu0; dbg[1] = (long long)__builtin_readcyclecounter() - t_lu1; }
 #endif
   return ok;
 }
+#undef GPF_PASS_T
+#undef GPF_WALK
 #undef FL_LD2
 #undef FL_D
 
@@ -1596,7 +1636,11 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         if (G::block_all_u(done)) break;
         GPF_LSYNC();
         if (it == 1) GPF_STAMPS(12);
+#ifdef GPF_TIMING
+        const bool ok = lu_ac(it == 1 ? &stamps.v[32] : nullptr);
+#else
         const bool ok = lu_ac(nullptr);
+#endif
         if (it == 1) GPF_STAMPS(13);
         // update (groups that are done keep their state) + preparation of the next pair phase (every group)
         bool fin = true, piv_ok = true;

@@ -76,6 +76,10 @@ struct Symbolic {
 struct FlatProg {
   int gw = 0;
   bool wave_closed = true;                                     // gw > 64: every destination of a pass is written by ONE wavefront (below)
+  // gw > 64: bit k set = every item of forward / back pass k sits in lanes [0, 64) -- a SOLO pass: wavefront 0 runs it alone, and a run of
+  // consecutive solo passes needs no workgroup barrier in between (the LDS executes the operations of one wavefront in issue order).
+  // Passes beyond the 32nd count as shared.
+  unsigned solo_fwd = 0, solo_back = 0;
   int n_fwd = 0, n_scale = 0, n_scale_rhs = 0, n_back = 0;     // passes
   int scale_off = 0, back_off = 0;                             // int offsets of the sections (forward starts at 0)
   int rhs_field0 = 0;                                          // rslot0 * 16: fields >= this are right-hand-side pseudo-slots
@@ -520,6 +524,13 @@ inline FlatProg build_flat(const Symbolic& S, int gw, int lane_opt) {
         flat_assign_lanes(acc, words, gw, gw > 64 ? 64 : gw, lane_opt);
         std::copy(words.begin(), words.end(), seq.begin() + (size_t)pz * gw);
       }
+    if (gw > 64)
+      for (int pz = 0; pz < n_pass; ++pz) {
+        bool solo = true;
+        for (int t = 64; t < gw; ++t) solo &= seq[(size_t)pz * gw + t].first == INV;
+        const int k = (back ? F.n_back : F.n_fwd) + pz;
+        if (solo && k < 32) (back ? F.solo_back : F.solo_fwd) |= 1u << k;
+      }
     for (auto& w : seq) { W.push_back((int)w.first); W.push_back((int)w.second); }
     return n_pass;
   };
@@ -571,7 +582,8 @@ inline FlatProg build_flat(const Symbolic& S, int gw, int lane_opt) {
     }
     F.n_back += emit_items(items, true);
   }
-  for (int k = 0; k < gw; ++k) { W.push_back((int)INV); W.push_back((int)INV); }
+  // (two all-invalid passes behind the last one when several wavefronts share the instance: their sweeps fetch the words TWO passes ahead)
+  for (int k = 0; k < (gw > 64 ? 2 : 1) * gw; ++k) { W.push_back((int)INV); W.push_back((int)INV); }
   while (W.size() & 3) W.push_back((int)INV);
   return F;
 }

@@ -324,7 +324,7 @@ class PowerFlowEngine:
         off, items = self.pack_actions(actions)
         lb = None if last_bus is None else np.ascontiguousarray(last_bus, dtype=np.int32).reshape(src.size, self.model.dim_topo)
         o = GpfStepOpts(int(max_iter), float(tol_mva), float(rebalance), int(bool(cascade)), float(hard_overflow), float(soft_overflow),
-                        int(nb_ts_allowed), int(max_rounds), int(bool(is_dc)), 0, 0, -1)
+                        int(nb_ts_allowed), int(max_rounds), int(bool(is_dc)), 0, 0, 0, 0)
         check(self._lib.gpf_simulate_batch(self._h, int(t_obs), int(time_step), src.size, ptr(src, C.c_int32), len(actions),
                                            ptr(off, C.c_int32), ptr(items if items.size else None, C.c_int32), ptr(lb, C.c_int32),
                                            int(dst_lane0), C.byref(o)), "gpf_simulate_batch")
@@ -475,7 +475,7 @@ class PowerFlowEngine:
         if nb_ts_reco is None:
             nb_ts_reco = 10 if (cascade or getattr(self, "_has_outages", False)) else -1
         o = GpfStepOpts(int(max_iter), float(tol_mva), float(rebalance), int(bool(cascade)), float(hard_overflow), float(soft_overflow),
-                        int(nb_ts_allowed), int(max_rounds), int(bool(is_dc)), int(bool(auto_reset)), int(bool(warm_start)), int(nb_ts_reco))
+                        int(nb_ts_allowed), int(max_rounds), int(bool(is_dc)), int(bool(auto_reset)), int(bool(warm_start)), int(nb_ts_reco >= 0), max(int(nb_ts_reco), 0))
         check(self._lib.gpf_step_n(self._h, int(t), int(n_steps), C.byref(o)), "gpf_step_n")
 
     def set_lane_redispatch(self, delta_mw):
@@ -823,7 +823,8 @@ class PowerFlowEngine:
             return self.specialization()
         if verify:
             self._verify_specialization(cache_dir)
-        src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc").encode()
+        # (the kernel sources beside this package; $GRIDPF_JIT_SRC: those of another build -- same-box A/B runs of a library selected with $GRIDPF_LIB)
+        src = (os.environ.get("GRIDPF_JIT_SRC") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")).encode()
         check(self._lib.gpf_jit_enable(self._h, src, cache_dir.encode() if cache_dir else None), "gpf_jit_enable")
         return self.specialization()
 
@@ -858,7 +859,7 @@ class PowerFlowEngine:
                 return got
 
             ref = run()
-            src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc").encode()
+            src = (os.environ.get("GRIDPF_JIT_SRC") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")).encode()
             check(twin._lib.gpf_jit_enable(twin._h, src, cache_dir.encode() if cache_dir else None), "gpf_jit_enable")
             got = run()
             info = twin.specialization()

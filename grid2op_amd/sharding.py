@@ -265,6 +265,34 @@ class ShardedEngine:
                                    status=cat("status"), bus_vm=None, bus_va=None, _slices=rs[0]._slices))
         return out
 
+    def trajectory_cooldown(self, n_steps: int, step0: int = 0, lane0: int = 0, n=None):
+        return np.concatenate([eng.trajectory_cooldown(n_steps, step0, l0, k) for eng, l0, k, _ in self._parts(lane0, n)], axis=1)
+
+    def counters(self) -> dict:
+        """Step launches / kernel dispatches summed over the devices."""
+        cs = [eng.counters() for eng in self.engines]
+        return {k: sum(c[k] for c in cs) for k in cs[0]}
+
+    # DC sensitivities of per-lane topologies: every device builds the tables of the topologies ITS lanes hold; class ids are per shard
+    # (a class of shard s is reported as ``class_offset[s] + local id``), so that `ptdf_class` finds the owner again
+    def ptdf_build_batch(self, lane0: int = 0, n=None, with_lodf: bool = True) -> dict:
+        if n is None:
+            n = self.n_lanes - lane0
+        lc = np.empty(n, np.int32)
+        st, cn, ms, self._ptdfb_owner = [], [], 0.0, []
+        for eng, l0, k, off in self._parts(lane0, n):
+            r = eng.ptdf_build_batch(l0, k, with_lodf=with_lodf)
+            base = len(st)
+            lc[off:off + k] = np.where(r["lane_class"] >= 0, r["lane_class"] + base, -1)
+            st.extend(r["class_status"].tolist()); cn.extend(r["class_n"].tolist())
+            self._ptdfb_owner.extend((eng, c) for c in range(r["n_classes"]))
+            ms = max(ms, r["kernel_ms"])                      # the devices run concurrently
+        return {"n_classes": len(st), "lane_class": lc, "class_status": np.asarray(st, np.int32), "class_n": np.asarray(cn, np.int32), "kernel_ms": ms}
+
+    def ptdf_class(self, cls: int, lodf: bool = False):
+        eng, c = self._ptdfb_owner[int(cls)]
+        return eng.ptdf_class(c, lodf=lodf)
+
     def copy_lanes(self, src: int, dst: int, n: int = 1):
         """Device-side copy inside one shard; a copy that crosses devices goes through the host (inputs, protection counters and --
         when the injection dynamics are on -- the dispatch / storage / curtailment state: the results of the destination lanes are

@@ -105,7 +105,7 @@ const char* gpf_last_error(void);
  * call (grid2op_amd/_capi.py does): 300 = round 4 (gpf_set_trajectory(h, cap, what), 22 device pointers, GPF_ST_REDISPATCH,
  * gpf_device_pointers_n); 310 = + gpf_jit_*, GPF_E_UNSUPPORTED, gpf_set_profiling mode 3; 321 = 28 device pointers (action buffers and
  * dispatch / charge state of the environment dynamics), gpf_lane_actions_on_device; 322 = + gpf_get_results_pinned. */
-#define GPF_ABI_VERSION 322
+#define GPF_ABI_VERSION 323
 int gpf_version(void);
 /* Bitwise run-to-run reproducibility is the DEFAULT on every grid: the same lane inputs give bit-identical results from run to
  * run and whatever the lane's position in the batch (grid2op's determinism contract: same seeds -> same episode,
@@ -199,7 +199,7 @@ int gpf_upload_maintenance(gpf_handle h, int32_t n_tables, int32_t T, const uint
  * "hazards" modification the environment applies every step); the two tables are independent, the device applies their union. */
 int gpf_upload_hazards(gpf_handle h, int32_t n_tables, int32_t T, const uint8_t* data);
 /* Remaining duration (steps, incl. the current one) of the maintenance / hazard under way at every row, [n_tables][T][n_line] uint16: what the
- * line cooldowns are raised to during an outage (gpf_step_opts::nb_ts_reco; GridValue.get_maintenance_duration_1d / get_hazard_duration_1d,
+ * line cooldowns are raised to during an outage (gpf_step_opts::track_cooldown; GridValue.get_maintenance_duration_1d / get_hazard_duration_1d,
  * grid2op/Chronics/gridValue.py:339).  By default the library derives it from the uploaded outage tables (one backward scan); a caller whose
  * tables are a WINDOW of longer chronics passes the true values here, because an outage that runs past the end of the window looks shorter than it
  * is.  Used where an outage table flags the line; NULL: back to the derived values. */
@@ -231,14 +231,17 @@ typedef struct gpf_step_opts {
                             performs on every runpf (pandaPowerBackend.py:1086 _pf_init = "dc"; LightSimBackend-style warm start).
                             Same solution within the solver tolerance, fewer iterations: n_iter and the last digits differ
                             from the reference's.  Default 0 = the reference's algorithm. */
-  int32_t nb_ts_reco;    /* >= 0: maintain the environment's LINE COOLDOWNS (BaseEnv._times_before_line_status_actionable =
+  int32_t track_cooldown; /* != 0: maintain the environment's LINE COOLDOWNS (BaseEnv._times_before_line_status_actionable =
                             obs.time_before_cooldown_line, Environment/baseEnv.py:3352-3358, 2590-2597) at every converged step: decremented,
-                            set to this value (Parameters.NB_TIMESTEP_RECONNECTION, default 10) for a line the protections trip in
-                            the step, raised to the remaining duration of a maintenance / hazard under way (the uploaded outage
-                            tables).  < 0: the counters are left alone (gpf_step: always).  Read with gpf_get_cooldown /
-                            gpf_get_trajectory_cooldown; cleared by gpf_reset_lanes and by an auto-reset, copied by gpf_copy_lanes and
-                            gpf_simulate_batch.  (Cooldowns caused by the agents' own line / substation actions belong to the
-                            caller: a DoNothing step has none.) */
+                            set to nb_ts_reco for a line the protections trip in the step, raised to the remaining duration of a
+                            maintenance / hazard under way (the uploaded outage tables).  0 (what a zero-initialised struct says, like every
+                            other field): the counters are left alone (gpf_step: always).  Read with gpf_get_cooldown /
+                            gpf_get_trajectory_cooldown; cleared by gpf_reset_lanes and by an auto-reset, copied by gpf_copy_lanes,
+                            gpf_fanout_n1 and gpf_simulate_batch -- whose scratch step never maintains them (one look-ahead step on the
+                            forecast tables: the source's counters are what obs.simulate starts from, _obsEnv.py:321-428).
+                            (Cooldowns caused by the agents' own line / substation actions belong to the caller: a DoNothing step has none.) */
+  int32_t nb_ts_reco;    /* Parameters.NB_TIMESTEP_RECONNECTION (default 10; >= 0): the cooldown of a line the protections trip;
+                            only read when track_cooldown != 0 */
 } gpf_step_opts;
 /* n_steps consecutive DoNothing env.step (t0, t0+1, ...) of every lane in ONE launch.  Every step does the whole of gpf_step;
  * between the steps of a launch the lane state stays on chip and whatever only depends on the topology (element->bus maps, bus
@@ -378,7 +381,7 @@ int gpf_get_episode(gpf_handle h, int32_t lane0, int32_t n, uint8_t* done, int32
  * consecutive steps each line has spent above its thermal limit), [n][n_line]: what an environment restored from an observation
  * hands over (Environment/_obsEnv.py init copies obs.timestep_overflow).  gpf_step / gpf_step_n maintain them on the device. */
 int gpf_set_overflow_count(gpf_handle h, int32_t lane0, int32_t n, const int32_t* overflow_count);
-/* The lanes' line cooldowns (gpf_step_opts::nb_ts_reco), [n][n_line]; gpf_set_cooldown: what an environment restored from an observation
+/* The lanes' line cooldowns (gpf_step_opts::track_cooldown), [n][n_line]; gpf_set_cooldown: what an environment restored from an observation
  * hands over (obs.time_before_cooldown_line).  gpf_get_trajectory_cooldown: the counters after every step of the last multi-step launch,
  * int16 [n_steps][n][n_line] (saturating at 32767), kept with any trajectory (gpf_set_trajectory). */
 int gpf_get_cooldown(gpf_handle h, int32_t lane0, int32_t n, int32_t* line_cooldown);

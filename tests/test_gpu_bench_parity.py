@@ -35,20 +35,28 @@ def _bench_engine(load_model, load_npz, name, n_envs, fan=1):
     return m, eng, tab, off, sc
 
 
-def test_headline_16_step_launch_4096_lanes_every_step_vs_oracle(load_model, load_npz):
-    """configs[1] as bench.py's headline runs it: l2rpn_case14_sandbox, 4 096 lanes, 16 env steps per launch with the observation
-    trajectory on.  64 sampled lanes x 4 steps of the launch are recomputed by the C oracle FROM THE CHRONICS TABLE (this covers
-    the device-side chronics gather, jitter and rebalancing too), and all 4 096 x 16 observations obey KCL."""
+def _headline_launch_lengths():
+    """The launch lengths bench.py's headline really uses: its default, and what the driver's command (--steps 20) turns it into."""
+    import bench
+    return sorted({bench.launch_length(bench.DRIVER_STEPS), bench.launch_length(2000)})
+
+
+@pytest.mark.parametrize("n", _headline_launch_lengths())
+def test_headline_launch_4096_lanes_every_step_vs_oracle(load_model, load_npz, n):
+    """configs[1] as bench.py's headline runs it: l2rpn_case14_sandbox, 4 096 lanes, ``n`` env steps per launch (bench.py's own launch
+    lengths: 16 by default, 20 under the driver's command) with the observation trajectory on.  64 sampled lanes x 4 steps of the launch are
+    recomputed by the C oracle FROM THE CHRONICS TABLE (this covers the device-side chronics gather, jitter and rebalancing too), and all
+    4 096 x n observations obey KCL."""
     m, eng, tab, off, sc = _bench_engine(load_model, load_npz, "l2rpn_case14_sandbox", 4096)
     assert eng.plan()["instances_per_wavefront"] == 2
-    n, t0 = 16, 32
+    t0 = 32
     eng.set_trajectory(n, eng.TRAJ_OBS)
     eng.step(0, n_steps=n, rebalance=1.02)            # a first launch, so that the checked one starts from a used state
     eng.step(t0, n_steps=n, rebalance=1.02)
     obs = eng.trajectory_obs(n)
     _, st = eng.trajectory(n)
     lanes = np.sort(np.random.default_rng(5).choice(4096, 64, replace=False))
-    for k in (0, 5, 10, 15):
+    for k in (0, 5, 10, n - 1):
         res = check_step(m, tab, off, sc, 1.02, t0 + k, lanes, obs[k].out[lanes], st[k][lanes])
         assert res["ok"] and res["n_converged"] == 64, (k, res)
         r = obs[k]

@@ -194,7 +194,7 @@ def test_parity_suites_on_specialised_kernels(jit_cache):
     env = dict(os.environ, GRIDPF_JIT="1", GRIDPF_JIT_CACHE=jit_cache)
     sel = ["tests/test_gpu_multistep.py", "tests/test_gpu_envdyn.py", "tests/test_gpu_simulate.py", "tests/test_gpu_conditioning.py",
            "tests/test_gpu_parity.py::test_more_than_three_busbars_through_topology_classes",
-           "tests/test_gpu_bench_parity.py::test_headline_16_step_launch_4096_lanes_every_step_vs_oracle"]
+           "tests/test_gpu_bench_parity.py::test_headline_launch_4096_lanes_every_step_vs_oracle"]
     n_before = len([f for f in os.listdir(jit_cache) if f.endswith(".hsaco")])
     p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", *sel], capture_output=True, text=True,
                        cwd=ROOT, env=env, timeout=1500)

@@ -24,12 +24,15 @@ ch = dict(np.load(os.path.join(gold, f"{env}.chronics.npz")))
 eng = PowerFlowEngine(m, n_lanes=B)
 eng.upload_chronics(eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch.get("prod_v", np.tile((m.gen_vm0 * m.sub_vn_kv[m.gen_sub]).astype(np.float32), (ch["prod_p"].shape[0], 1)))))
 eng.set_lane_chronics(lane_offset=(7 * np.arange(B)) % ch["load_p"].shape[0])
+if os.environ.get("PT_JIT"):      # the grid-specialised kernels with the stamps: GRIDPF_JIT_FLAGS=-DGPF_TIMING PT_JIT=1 (the library must be the timing build too)
+    print("specialised:", eng.specialize(verify=False))
 NS = int(os.environ.get("NSTEPS", "1"))
 for t in range(5):
     eng.step(t * NS, rebalance=1.02, n_steps=NS)
 eng.sync()
 L = _capi.lib()
-buf = np.zeros((B, 40))
+ROW = 88
+buf = np.zeros((B, ROW))
 L.gpf_debug_read_work.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int64]
 assert L.gpf_debug_read_work(eng._h, buf.ctypes.data_as(C.POINTER(C.c_double)), buf.size) == 0
 SPARSE = True
@@ -62,4 +65,14 @@ if SPARSE:
     print(f"  K1 detail: topo row -> LDS {med[27] - med[0]:.0f}, element loops (atomics) {med[28] - med[27]:.0f}, types / counts {med[1] - med[28]:.0f}")
     print(f"  results detail: line flows {med[22] - med[5]:.0f}, loads/storages/shunts {med[23] - med[22]:.0f}, gen accumulate {med[24] - med[23]:.0f}, "
           f"gen write {med[25] - med[24]:.0f}, topo_out {med[26] - med[25]:.0f}, bus V {med[6] - med[26]:.0f}")
+    pt = buf[:, 40:]
+    ok = pt[:, 0] > 0
+    if ok.any():
+        d = np.diff(pt[ok], axis=1)
+        d = np.where((pt[ok][:, 1:] > 0) & (d > 0), d, np.nan)
+        print("  first factorisation, cycles per pass (forward then back; median / min / max over lanes):")
+        for k in range(min(d.shape[1], 20)):
+            if np.isfinite(d[:, k]).any():
+                print(f"    pass {k:2d}: {np.nanmedian(d[:, k]):7.0f} {np.nanmin(d[:, k]):7.0f} {np.nanmax(d[:, k]):7.0f}")
+    print(f"  LU of iteration 1: forward {med[32]:.0f}, back {med[33]:.0f}")
     sys.exit(0)
