@@ -242,6 +242,8 @@ struct CarveP {
   int* topo;      // alias of A during K1
   i16 *lor_b, *lex_b, *gen_b, *load_b, *sto_b, *sh_b;
   i8* sub_bb;     // [n_sub] live busbar (local id) of each substation (NB == 1)
+  float* out_l;   // != nullptr: the float32 results row of the last solve as it was staged in LDS (row-1 half of the block array, dead by
+                  // then) before it went to HBM in whole 128-byte lines (solve_instance_sparse: ROWLDS); set by every solve
 };
 
 // LDS bytes of ONE instance (without the program copy, which is shared by the IPW instances of a block).
@@ -915,6 +917,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   const auto shb = gptr(b.shunt_bus) + (size_t)inst * g.n_shunt;
   n_iter_out = 0;
   nb_out = 0;
+  c.out_l = nullptr;                                     // (set by the results phase when it stages the row in LDS)
   GPF_STAMPS(0);
   const auto inj_g = gptr(b.inj) + (size_t)inst * g.n_inj;
   if (STAGE && !ctl.inj_staged) {
@@ -1550,7 +1553,38 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
             if (act && (yuv.x != 0.0 || yuv.y != 0.0)) { atomicAdd(wave1 ? rhsT(u) : SreP(u), tr_); atomicAdd(wave1 ? rhsV(u) : SimP(u), ti_); }
             if (act && (yvu.x != 0.0 || yvu.y != 0.0)) { atomicAdd(wave1 ? rhsT(v) : SreP(v), sr_); atomicAdd(wave1 ? rhsV(v) : SimP(v), si_); }
           };
-          if (YR) {
+          if (YR && S.n_up <= 2 * GW) {
+            // at most two pairs per lane (the 118-substation grids: 179 pairs on 128 lanes): the bus values of BOTH pairs are requested
+            // before the first pair computes -- one LDS round trip for the phase instead of two (the second trip used to queue behind
+            // the first pair's block stores and atomics); same arithmetic, same order of the atomics
+            struct PairOps { int btu, btv; double2 efu, efv; double ivmu, ivmv; };
+            auto pair_load = [&](const unsigned w0) -> PairOps {
+              const int u = (int)(w0 & 0xffffu), v = (int)(w0 >> 16);
+              PairOps o;
+              o.btu = c.btype[u]; o.btv = c.btype[v]; o.efu = EF(u); o.efv = EF(v); o.ivmu = c.ivm[u]; o.ivmv = c.ivm[v];
+              return o;
+            };
+            auto pair_fin = [&](const PairOps& o, const unsigned w0, const unsigned w1, const double2 yuv, const double2 yvu) {
+              const int u = (int)(w0 & 0xffffu), v = (int)(w0 >> 16), suv = (int)(w1 & 0xffffu), svu = (int)(w1 >> 16);
+              const int btu = o.btu, btv = o.btv;
+              const double eu = o.efu.x, fu = o.efu.y, ivmu = o.ivmu, ev = o.efv.x, fv = o.efv.y, ivmv = o.ivmv;
+              double tr_, ti_, sr_, si_;
+              t_of(yuv, eu, fu, ev, fv, tr_, ti_);
+              t_of(yvu, ev, fv, eu, fu, sr_, si_);
+              const bool act = (btu != BT_OFF) && (btv != BT_OFF);
+              const bool uP = (btu == BT_PQ || btu == BT_PV), uQ = (btu == BT_PQ), vP = (btv == BT_PQ || btv == BT_PV), vQ = (btv == BT_PQ);
+              *reinterpret_cast<double2*>(bel(suv, 0, 0)) = make_double2((uP && vP) ? ti_ : 0.0, (uP && vQ) ? tr_ * ivmv : 0.0);
+              *reinterpret_cast<double2*>(bel(suv, 1, 0)) = make_double2((uQ && vP) ? -tr_ : 0.0, (uQ && vQ) ? ti_ * ivmv : 0.0);
+              *reinterpret_cast<double2*>(bel(svu, 0, 0)) = make_double2((vP && uP) ? si_ : 0.0, (vP && uQ) ? sr_ * ivmu : 0.0);
+              *reinterpret_cast<double2*>(bel(svu, 1, 0)) = make_double2((vQ && uP) ? -sr_ : 0.0, (vQ && uQ) ? si_ * ivmu : 0.0);
+              if (act && (yuv.x != 0.0 || yuv.y != 0.0)) { atomicAdd(wave1 ? rhsT(u) : SreP(u), tr_); atomicAdd(wave1 ? rhsV(u) : SimP(u), ti_); }
+              if (act && (yvu.x != 0.0 || yvu.y != 0.0)) { atomicAdd(wave1 ? rhsT(v) : SreP(v), sr_); atomicAdd(wave1 ? rhsV(v) : SimP(v), si_); }
+            };
+            const bool on0 = tid < S.n_up, on1 = tid + GW < S.n_up;
+            const PairOps o0 = pair_load(rcreg[0]), o1 = pair_load(rcreg[2]);         // (lanes without a pair: words 0 -> bus 0, harmless reads)
+            if (on0) pair_fin(o0, rcreg[0], rcreg[1], yreg[0], yreg[1]);
+            if (on1) pair_fin(o1, rcreg[2], rcreg[3], yreg[2], yreg[3]);
+          } else if (YR) {
   #pragma unroll
             for (int k = 0; k < YR_PASSES; ++k) if (tid + k * GW < S.n_up) upair_item(rcreg[2 * k], rcreg[2 * k + 1], yreg[2 * k], yreg[2 * k + 1]);
           } else {
@@ -1690,6 +1724,22 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
   const auto out = gptr(ctl.otraj ? b.traj_out : b.out) + (size_t)ctl.orow * g.n_out;
   const auto lstat = gptr(ctl.otraj ? b.traj_lstat : b.line_status) + (size_t)ctl.orow * g.n_line;
   const bool wtopo = !reuse || ctl.write_topo;
+  // WHOLE-LINE RESULT STORES (several wavefronts per instance: the 118-substation grids).  The row is 25 field segments of n_line / n_gen /
+  // ... floats at offsets that are no multiples of a 128-byte line: stored field by field, every segment leaves a partial line at both
+  // ends (PMC, round 5: 1.33 x the row's bytes written, 1.5 x the algorithmic traffic).  The lanes therefore put their values into a
+  // copy of the row in LDS -- the row-1 half of the block array, whose blocks are dead after the last Newton iteration and are rebuilt
+  // by the next solve -- placed so that LDS and HBM addresses agree modulo 128, and the block then stores it as 16 bytes per lane, 2 KB
+  // per instruction, every instruction whole lines (dword stores only before the first and behind the last whole line of the row).
+#ifdef GPF_NO_ROWLDS
+  constexpr bool ROWLDS = false;
+#else
+  constexpr bool ROWLDS = NB == 1 && WPI > 1;
+#endif
+  const unsigned row_mis = (unsigned)((((size_t)ctl.orow * (size_t)g.n_out) * 4u) & 127u);       // (the arrays themselves are 256-byte aligned)
+  const bool rowlds = ROWLDS && (size_t)S.rslot0 * 16 >= (size_t)g.n_out * 4 + 128;               // block-uniform: the row fits the slot part of the half
+  float* const out_l = reinterpret_cast<float*>(c.A + HS) + row_mis / 4u;
+  c.out_l = rowlds ? out_l : nullptr;
+  auto put = [&](int idx, float v) { if (ROWLDS && rowlds) out_l[idx] = v; else out[idx] = v; };
   const double RAD2DEG = 57.295779513082320877;
   const double SQRT3 = 1.7320508075688772935;
   GPF_LSYNC();
@@ -1832,35 +1882,35 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       v_or = (float)(vmf * vnf); v_ex = (float)(vmt * vnt);
       th_or = (float)(c.va[f] * RAD2DEG); th_ex = (float)(c.va[t] * RAD2DEG);
     }
-    out[oo.p_or + l] = p_or; out[oo.q_or + l] = q_or; out[oo.v_or + l] = v_or; out[oo.a_or + l] = a_or; out[oo.th_or + l] = th_or;
+    put(oo.p_or + l, p_or); put(oo.q_or + l, q_or); put(oo.v_or + l, v_or); put(oo.a_or + l, a_or); put(oo.th_or + l, th_or);
     if (l == tid) a_or_first = a_or;                 // the step kernel derives rho / the protection counters of this line from it
-    out[oo.p_ex + l] = p_ex; out[oo.q_ex + l] = q_ex; out[oo.v_ex + l] = v_ex; out[oo.a_ex + l] = a_ex; out[oo.th_ex + l] = th_ex;
+    put(oo.p_ex + l, p_ex); put(oo.q_ex + l, q_ex); put(oo.v_ex + l, v_ex); put(oo.a_ex + l, a_ex); put(oo.th_ex + l, th_ex);
   }
   GPF_STAMPS(22);
   for (int i = tid; i < g.n_load; i += GW) {
     const int bu = c.load_b[i];
     const bool on = bu >= 0;
-    out[oo.load_p + i] = on ? (float)GPF_INJ(oo.inj_load_p + i) : 0.f;
-    out[oo.load_q + i] = (on && !is_dc) ? (float)GPF_INJ(oo.inj_load_q + i) : 0.f;
-    out[oo.load_v + i] = on ? (float)(c.vm[bu] * sv.load_vn[i]) : 0.f;
-    out[oo.load_th + i] = on ? (float)(c.va[bu] * RAD2DEG) : 0.f;
+    put(oo.load_p + i, on ? (float)GPF_INJ(oo.inj_load_p + i) : 0.f);
+    put(oo.load_q + i, (on && !is_dc) ? (float)GPF_INJ(oo.inj_load_q + i) : 0.f);
+    put(oo.load_v + i, on ? (float)(c.vm[bu] * sv.load_vn[i]) : 0.f);
+    put(oo.load_th + i, on ? (float)(c.va[bu] * RAD2DEG) : 0.f);
   }
   for (int i = tid; i < g.n_sto; i += GW) {
     const int bu = c.sto_b[i];
     const bool on = bu >= 0;
-    out[oo.sto_p + i] = on ? (float)GPF_INJ(oo.inj_sto_p + i) : 0.f;
-    out[oo.sto_q + i] = (on && !is_dc) ? (float)GPF_INJ(oo.inj_sto_q + i) : 0.f;
-    out[oo.sto_v + i] = on ? (float)(c.vm[bu] * sv.sto_vn[i]) : 0.f;
-    out[oo.sto_th + i] = on ? (float)(c.va[bu] * RAD2DEG) : 0.f;
+    put(oo.sto_p + i, on ? (float)GPF_INJ(oo.inj_sto_p + i) : 0.f);
+    put(oo.sto_q + i, (on && !is_dc) ? (float)GPF_INJ(oo.inj_sto_q + i) : 0.f);
+    put(oo.sto_v + i, on ? (float)(c.vm[bu] * sv.sto_vn[i]) : 0.f);
+    put(oo.sto_th + i, on ? (float)(c.va[bu] * RAD2DEG) : 0.f);
   }
   const auto sbo = gptr(ctl.otraj ? b.traj_shb : b.shunt_bus_out) + (size_t)ctl.orow * g.n_shunt;
   for (int i = tid; i < g.n_shunt; i += GW) {
     const int bu = c.sh_b[i];
     const bool on = bu >= 0;
     const double v = on ? c.vm[bu] : 0.0;
-    out[oo.sh_p + i] = on ? (float)(GPF_INJ(oo.inj_sh_p + i) * sv.shunt_fact[i] * v * v) : 0.f;
-    out[oo.sh_q + i] = (on && !is_dc) ? (float)(GPF_INJ(oo.inj_sh_q + i) * sv.shunt_fact[i] * v * v) : 0.f;
-    out[oo.sh_v + i] = on ? (float)(v * sv.shunt_vn[i]) : 0.f;
+    put(oo.sh_p + i, on ? (float)(GPF_INJ(oo.inj_sh_p + i) * sv.shunt_fact[i] * v * v) : 0.f);
+    put(oo.sh_q + i, (on && !is_dc) ? (float)(GPF_INJ(oo.inj_sh_q + i) * sv.shunt_fact[i] * v * v) : 0.f);
+    put(oo.sh_v + i, on ? (float)(v * sv.shunt_vn[i]) : 0.f);
     if (wtopo) sbo[i] = on ? shb[i] : -1;
   }
   // generators (pypower pfsoln): per-bus totals accumulated in LDS with atomics (the block array is dead by now and
@@ -1911,9 +1961,23 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         gv = (float)(c.vm[bu] * sv.gen_vn[i]);
         gth = (float)(c.va[bu] * RAD2DEG);
       }
-      out[oo.gen_p + i] = gp; out[oo.gen_q + i] = gq; out[oo.gen_v + i] = gv; out[oo.gen_th + i] = gth;
+      put(oo.gen_p + i, gp); put(oo.gen_q + i, gq); put(oo.gen_v + i, gv); put(oo.gen_th + i, gth);
     }
   }
+  }
+  if (ROWLDS && rowlds) {
+    GPF_LSYNC();                                                   // the row is complete in LDS
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    const int n_out = g.n_out;
+    int a = (int)(((128u - row_mis) & 127u) / 4u);                 // floats before the first whole line of the row
+    a = a < n_out ? a : n_out;
+    if (tid < a) out[tid] = out_l[tid];
+    const int n4 = (n_out - a) / 4;
+    const v4f_* const sl = reinterpret_cast<const v4f_*>(out_l + a);          // 16-byte aligned: out_l = row (mod 128)
+    const auto dg = (GPF_GLOBAL v4f_*)(out + a);
+    for (int i = tid; i < n4; i += GW) dg[i] = sl[i];
+    const int t0 = a + 4 * n4;
+    if (tid < n_out - t0) out[t0 + tid] = out_l[t0 + tid];
   }
   GPF_STAMPS(25);
   if (wtopo) {                           // topo_vect only depends on the topology: it stands when the topology does
@@ -2421,9 +2485,21 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
         for (int l = tid; l < g.n_line; l += GW) if (mrow[l]) { c.topo[sv.line_or_pos[l]] = -1; c.topo[sv.line_ex_pos[l]] = -1; }
       }
       float pp_pre = pf_pp, pv_pre = pf_pv, lp_pre = pf_lp, lq_pre = pf_lq;
+      // several wavefronts per instance (the load / generator loops run on wavefront 0 alone, two trips for up to 128 loads): ALL chronics
+      // values of the lane -- both trips of the load loop, the generator's -- are requested here, one HBM round trip instead of three
+      constexpr bool PRE2 = WPI > 1;
+      constexpr int gw9 = WPI > 1 ? WAVE : GW;
+      float lp2 = 0.f, lq2 = 0.f, sc2p = 1.f, sc2q = 1.f;
       if (!PF9) {
         pp_pre = tid < g.n_gen ? ch[2 * g.n_load + tid] : 0.f;
         pv_pre = tid < g.n_gen ? ch[2 * g.n_load + g.n_gen + tid] : 1.f;
+        if (PRE2 && tid < gw9) {
+          if (tid < g.n_load) { lp_pre = ch[tid]; lq_pre = ch[g.n_load + tid]; }
+          if (tid + gw9 < g.n_load) {
+            lp2 = ch[tid + gw9]; lq2 = ch[g.n_load + tid + gw9];
+            if (has_sc) { sc2p = sc[tid + gw9]; sc2q = sc[g.n_load + tid + gw9]; }
+          }
+        }
       }
       if (PF9 && !last) {                           // next step's first values: in flight during this step's power flow
         const int row_n = row + 1 >= sa.T ? 0 : row + 1;
@@ -2444,12 +2520,12 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
       GPF_STAMPS(16);
       // several wavefronts per instance: the loops below (which also accumulate the bus sums when the maps stand) run on wavefront 0
       // alone -- fixed order of the LDS atomics and of the load / generation totals: bitwise reproducibility, see solve_instance_sparse
-      constexpr int gw9 = WPI > 1 ? WAVE : GW;
       const bool lane9 = tid < gw9;
       if (lane9)
       for (int i = tid; i < g.n_load; i += gw9) {
-        float lp = (PF9 && i == tid) ? lp_pre : ch[i], lq = (PF9 && i == tid) ? lq_pre : ch[g.n_load + i];
-        if (has_sc) { lp *= (i == tid) ? sc_p0 : sc[i]; lq *= (i == tid) ? sc_q0 : sc[g.n_load + i]; }
+        const bool i0_ = (PF9 || PRE2) && i == tid, i1_ = PRE2 && i == tid + gw9;
+        float lp = i0_ ? lp_pre : i1_ ? lp2 : ch[i], lq = i0_ ? lq_pre : i1_ ? lq2 : ch[g.n_load + i];
+        if (has_sc) { lp *= (i == tid) ? sc_p0 : i1_ ? sc2p : sc[i]; lq *= (i == tid) ? sc_q0 : i1_ ? sc2q : sc[g.n_load + i]; }
         if (STAGE) { c.inj[oo.inj_load_p + i] = (double)lp; c.inj[oo.inj_load_q + i] = (double)lq; }   // HBM copy: end of kernel
         else { inj_g[oo.inj_load_p + i] = (double)lp; inj_g[oo.inj_load_q + i] = (double)lq; }
         sum_load += (double)lp;
@@ -2561,7 +2637,7 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
         const auto thermal_limit = gptr(b.thermal_limit);
         for (int l = tid; l < g.n_line; l += GW) {
           const bool own = l == tid;
-          const float a = own ? a_first : (float)out[oo.a_or + l];
+          const float a = own ? a_first : (c.out_l ? c.out_l[oo.a_or + l] : (float)out[oo.a_or + l]);     // (staged row: the lane's value is in LDS)
           const float lim = own ? lim_first : (float)thermal_limit[l];
           const bool on = c.lor_b[l] >= 0;
           bool disc = on && (a > sa.hard_overflow * lim);
@@ -2603,7 +2679,7 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
       for (int l = tid; l < g.n_line; l += GW) {
         const bool own = l == tid;
         const float lim = own ? lim_first : (float)thermal_limit[l];
-        const float a = own ? a_first : (float)out[oo.a_or + l];              // (this lane wrote out[a_or + l] itself)
+        const float a = own ? a_first : ((st == 0 && c.out_l) ? c.out_l[oo.a_or + l] : (float)out[oo.a_or + l]);   // (this lane wrote out[a_or + l] itself -- to the staged row in LDS or to HBM)
         const float r_ = a / lim;
         rho[l] = r_;
         if (traj) traj[l] = r_;
