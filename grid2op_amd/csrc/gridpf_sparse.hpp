@@ -379,6 +379,13 @@ __device__ __forceinline__ double dpp_group_sum(double v) {
   return readlane_f64(v, 63);
 }
 
+// workgroup barrier for exchanges that only go through LDS (the collectives below): waits for the wavefront's LDS operations, not -- as
+// __syncthreads() would -- for its global loads / stores in flight
+#ifndef GPF_HARD_SYNC
+#define GPF_WG_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define GPF_WG_LDS_BARRIER() __syncthreads()
+#endif
 template <int IPW, int WPI = 1>
 struct Grp {
   static_assert(IPW == 1 || WPI == 1, "either several instances per wavefront or several wavefronts per instance");
@@ -406,9 +413,9 @@ struct Grp {
       __shared__ double red_[WPI > 1 ? WPI : 1];
 #pragma unroll
       for (int off = WAVE / 2; off; off >>= 1) v += __shfl_xor(v, off);
-      __syncthreads();
+      GPF_WG_LDS_BARRIER();
       if ((threadIdx.x & (WAVE - 1)) == 0) red_[threadIdx.x / WAVE] = v;
-      __syncthreads();
+      GPF_WG_LDS_BARRIER();
       double t = 0.0;
 #pragma unroll
       for (int k = 0; k < WPI; ++k) t += red_[k];
@@ -433,7 +440,7 @@ struct Grp {
     if (WPI > 1) {
       __shared__ unsigned redb_[4][WPI > 1 ? WPI : 1];
       if ((threadIdx.x & (WAVE - 1)) == 0) redb_[BUF][threadIdx.x / WAVE] = w;
-      __syncthreads();
+      GPF_WG_LDS_BARRIER();
       unsigned r = 0;
 #pragma unroll
       for (int k = 0; k < WPI; ++k) r |= redb_[BUF][k];
@@ -451,7 +458,7 @@ struct Grp {
 #pragma unroll
       for (int off = WAVE / 2; off; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); }
       if ((threadIdx.x & (WAVE - 1)) == 0) { reds_[BUF][2 * (threadIdx.x / WAVE)] = a; reds_[BUF][2 * (threadIdx.x / WAVE) + 1] = b; }
-      __syncthreads();
+      GPF_WG_LDS_BARRIER();
       double ta = 0.0, tb = 0.0;
 #pragma unroll
       for (int k = 0; k < WPI; ++k) { ta += reds_[BUF][2 * k]; tb += reds_[BUF][2 * k + 1]; }
@@ -1668,7 +1675,9 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
           else ++it;
         }
         if (G::block_all_u(done)) break;
-        GPF_LSYNC();
+        // (several wavefronts per instance: the collective above -- executed by every lane, `done` is block-uniform -- ended with the
+        //  workgroup barrier that orders the mismatch phase's LDS writes before the factorisation: no second one)
+        if (!(WPI > 1 && IPW == 1)) GPF_LSYNC();
         if (it == 1) GPF_STAMPS(12);
 #ifdef GPF_TIMING
         const bool ok = lu_ac(it == 1 ? &stamps.v[32] : nullptr);
@@ -1709,7 +1718,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         }
         if (BS == 2) { for (int i = S.nslot_y * 2 + tid; i < S.nslot * 2; i += GW) { c.A[i] = 0.0; c.A[HS + i] = 0.0; } }
       else for (int i = S.nslot_y * B2 + tid; i < S.nslot_lu * B2; i += GW) c.A[i] = 0.0;
-        GPF_LSYNC();
+        if (!(WPI > 1 && IPW == 1)) GPF_LSYNC();      // (several wavefronts per instance: the barrier of the collective below is the boundary)
         if (!done && G::template any2<1>(!ok || !piv_ok, !fin) != 0u) { status = 4; done = true; }
         if (it == 1) GPF_STAMPS(14);
       }

@@ -55,6 +55,110 @@ static int dense_solve(double* A, double* b, int n) {
   return 0;
 }
 
+/* ---- SPARSE variant of the two linear solves (pfo_set_solver(1)) ---------------------------------------------------------------
+ * What a sparse CPU power flow does -- pandapower's newtonpf calls scipy.sparse.linalg.spsolve per iteration
+ * (grid2op/Backend/pandaPowerBackend.py:1081-1083 picks the solver), lightsim2grid factorises with KLU and keeps the symbolic
+ * analysis --: LU without pivoting on a minimum-degree ordering of the bus graph (power-flow Jacobians are factorised that way by
+ * every production solver; a tiny pivot falls back to the dense elimination above), fill pattern computed once per
+ * (topology, bus types) and reused by every iteration and every solve with the same pattern.  Same Newton iteration as the dense
+ * path: tests/test_oracle_c.py pins the two against each other (1e-10) on every golden grid and on random topologies.  Used by
+ * bench.py's per-config cpu_baseline -- the dense path is a straw man on 118 substations (1.4 ms per power flow). */
+typedef struct {
+  int n, nnz, cap_n, cap_nnz;
+  int *rp, *ci, *dpos;      /* CSR of L + U in the permuted numbering, columns sorted, diagonal position per row */
+  double *val, *w;          /* values, dense work row */
+  int* mark;
+} splu_t;
+
+static void __attribute__((unused)) splu_free(splu_t* s) { free(s->rp); free(s->ci); free(s->dpos); free(s->val); free(s->w); free(s->mark); memset(s, 0, sizeof(*s)); }
+
+/* pattern of A given as rows of (permuted) column indices arp / aci (unsorted, duplicates allowed) -> filled pattern of L + U */
+static int splu_symbolic(splu_t* s, int n, const int* arp, const int* aci) {
+  if (n > s->cap_n) {
+    free(s->rp); free(s->dpos); free(s->w); free(s->mark);
+    s->cap_n = n + 16;
+    s->rp = (int*)malloc(sizeof(int) * (size_t)(s->cap_n + 1));
+    s->dpos = (int*)malloc(sizeof(int) * (size_t)s->cap_n);
+    s->w = (double*)malloc(sizeof(double) * (size_t)s->cap_n);
+    s->mark = (int*)malloc(sizeof(int) * (size_t)s->cap_n);
+    if (!s->rp || !s->dpos || !s->w || !s->mark) return 1;
+  }
+  s->n = n;
+  int nnz = 0;
+  s->rp[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    for (int j = 0; j < n; ++j) s->mark[j] = 0;
+    s->mark[i] = 1;
+    for (int q = arp[i]; q < arp[i + 1]; ++q) s->mark[aci[q]] = 1;
+    /* row i takes the pattern right of the diagonal of every row k < i it has an entry in (ascending k: fill adds more of them) */
+    for (int k = 0; k < i; ++k) {
+      if (!s->mark[k]) continue;
+      for (int q = s->dpos[k] + 1; q < s->rp[k + 1]; ++q) s->mark[s->ci[q]] = 1;
+    }
+    int cnt = 0;
+    for (int j = 0; j < n; ++j) cnt += s->mark[j];
+    if (nnz + cnt > s->cap_nnz) {
+      s->cap_nnz = 2 * (nnz + cnt) + 1024;
+      s->ci = (int*)realloc(s->ci, sizeof(int) * (size_t)s->cap_nnz);
+      s->val = (double*)realloc(s->val, sizeof(double) * (size_t)s->cap_nnz);
+      if (!s->ci || !s->val) return 1;
+    }
+    for (int j = 0; j < n; ++j)
+      if (s->mark[j]) { if (j == i) s->dpos[i] = nnz; s->ci[nnz++] = j; }
+    s->rp[i + 1] = nnz;
+  }
+  s->nnz = nnz;
+  return 0;
+}
+static inline int splu_pos(const splu_t* s, int r, int c) {      /* position of (r, c): binary search in the sorted row */
+  int lo = s->rp[r], hi = s->rp[r + 1] - 1;
+  while (lo <= hi) { int mid = (lo + hi) >> 1; if (s->ci[mid] == c) return mid; if (s->ci[mid] < c) lo = mid + 1; else hi = mid - 1; }
+  return -1;
+}
+/* in-place LU of the values in s->val (row-wise IKJ elimination over the filled pattern); 1: a pivot is unusable */
+static int splu_factor(splu_t* s) {
+  const int n = s->n;
+  double* w = s->w;
+  for (int i = 0; i < n; ++i) {
+    double rmax = 0.0;
+    for (int q = s->rp[i]; q < s->rp[i + 1]; ++q) { w[s->ci[q]] = s->val[q]; if (fabs(s->val[q]) > rmax) rmax = fabs(s->val[q]); }
+    for (int q = s->rp[i]; q < s->dpos[i]; ++q) {
+      const int k = s->ci[q];
+      const double l = w[k] / s->val[s->dpos[k]];
+      w[k] = l;
+      if (l != 0.0) for (int r = s->dpos[k] + 1; r < s->rp[k + 1]; ++r) w[s->ci[r]] -= l * s->val[r];
+    }
+    for (int q = s->rp[i]; q < s->rp[i + 1]; ++q) s->val[q] = w[s->ci[q]];
+    const double piv = s->val[s->dpos[i]];
+    if (!(fabs(piv) > 1e-11 * rmax) || !(fabs(piv) > 1e-300) || !(fabs(piv) < 1e300)) return 1;
+  }
+  return 0;
+}
+static void splu_solve(const splu_t* s, double* b) {              /* b (permuted numbering) -> solution */
+  const int n = s->n;
+  for (int i = 0; i < n; ++i) { double t = b[i]; for (int q = s->rp[i]; q < s->dpos[i]; ++q) t -= s->val[q] * b[s->ci[q]]; b[i] = t; }
+  for (int i = n - 1; i >= 0; --i) {
+    double t = b[i];
+    for (int q = s->dpos[i] + 1; q < s->rp[i + 1]; ++q) t -= s->val[q] * b[s->ci[q]];
+    b[i] = t / s->val[s->dpos[i]];
+  }
+}
+
+/* per-thread solver state: the bus graph, the elimination order and the two symbolic factorisations of the last pattern seen */
+typedef struct {
+  int sparse;
+  uint64_t key; int have;
+  int nbt, *ap, *ai;            /* bus adjacency (CSR incl. the diagonal) over the in-service lines */
+  int *order, *upos, *rank;     /* elimination order of the buses with unknowns; first permuted AC unknown (theta) of each bus and its DC unknown, -1: none */
+  int cap_b, cap_a;
+  splu_t dc, ac;
+  cplx* yv; int cap_y;          /* Ybus values aligned with ai */
+  int *pat_rp, *pat_ci; int cap_pr, cap_pc;
+} spctx_t;
+static __thread spctx_t g_sp;
+void pfo_set_solver(int sparse) { g_sp.sparse = sparse != 0; }
+int pfo_get_solver(void) { return g_sp.sparse; }
+
 typedef struct {
   int p_or, q_or, v_or, a_or, th_or, p_ex, q_ex, v_ex, a_ex, th_ex;
   int gen_p, gen_q, gen_v, gen_th, load_p, load_q, load_v, load_th, sto_p, sto_q, sto_v, sto_th, sh_p, sh_q, sh_v;
@@ -93,9 +197,115 @@ static void fill_fail(const gpf_grid_desc* d, const offsets_t* o, double* out, i
 }
 
 /* One power flow of one grid instance.  status4 = {GPF_ST_*, n_iter, n_active_bus, 0}. */
-int pfo_solve(const gpf_grid_desc* d, const double* inj, const int32_t* topo, const int32_t* shunt_bus, int is_dc,
+#define PFO_RETRY_DENSE (-77)      /* sparse path: a pivot was unusable -> the caller repeats the solve with the dense elimination */
+static uint64_t sp_hash(uint64_t h, const void* p, size_t n) {
+  const unsigned char* b = (const unsigned char*)p;
+  for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+  return h;
+}
+/* (re)build the bus graph, the elimination order and both symbolic factorisations for the pattern at hand; 0 on success */
+static int sp_prepare(spctx_t* c, int nbt, int nl, const int* lor, const int* lex, const uint8_t* line_status, const int* active,
+                      const int* pidx, const int* qidx, int npvpq, int npq) {
+  uint64_t key = 1469598103934665603ull;
+  key = sp_hash(key, &nbt, sizeof(nbt)); key = sp_hash(key, lor, sizeof(int) * (size_t)nl); key = sp_hash(key, lex, sizeof(int) * (size_t)nl);
+  key = sp_hash(key, line_status, (size_t)nl); key = sp_hash(key, pidx, sizeof(int) * (size_t)nbt); key = sp_hash(key, qidx, sizeof(int) * (size_t)nbt);
+  key = sp_hash(key, active, sizeof(int) * (size_t)nbt);
+  if (c->have && c->key == key && c->nbt == nbt) return 0;
+  c->have = 0;
+  if (nbt > c->cap_b) {
+    free(c->ap); free(c->order); free(c->upos); free(c->rank);
+    c->cap_b = nbt + 16;
+    c->ap = (int*)malloc(sizeof(int) * (size_t)(c->cap_b + 1));
+    c->order = (int*)malloc(sizeof(int) * (size_t)c->cap_b);
+    c->upos = (int*)malloc(sizeof(int) * (size_t)c->cap_b);
+    c->rank = (int*)malloc(sizeof(int) * (size_t)c->cap_b);
+  }
+  if (2 * nl + nbt > c->cap_a) { free(c->ai); c->cap_a = 2 * nl + nbt + 64; c->ai = (int*)malloc(sizeof(int) * (size_t)c->cap_a); }
+  if (!c->ap || !c->order || !c->upos || !c->rank || !c->ai) return 1;
+  c->nbt = nbt;
+  unsigned char* adj = (unsigned char*)calloc((size_t)nbt * nbt, 1);
+  int* deg = (int*)calloc((size_t)2 * nbt, sizeof(int));
+  int* gone = deg + nbt;
+  if (!adj || !deg) { free(adj); free(deg); return 1; }
+  for (int l = 0; l < nl; ++l)
+    if (line_status[l] && lor[l] != lex[l]) { adj[lor[l] * nbt + lex[l]] = 1; adj[lex[l] * nbt + lor[l]] = 1; }
+  /* adjacency over ALL active buses (Ibus needs the reference buses too), diagonal first */
+  int na = 0;
+  for (int b = 0; b < nbt; ++b) {
+    c->ap[b] = na;
+    if (!active[b]) continue;
+    c->ai[na++] = b;
+    for (int j = 0; j < nbt; ++j) if (adj[b * nbt + j]) c->ai[na++] = j;
+  }
+  c->ap[nbt] = na;
+  /* minimum-degree order of the buses that carry unknowns (reference buses drop out of the reduced systems) */
+  for (int b = 0; b < nbt; ++b) {
+    gone[b] = pidx[b] < 0;
+    if (gone[b]) for (int j = 0; j < nbt; ++j) { adj[b * nbt + j] = 0; adj[j * nbt + b] = 0; }
+  }
+  for (int b = 0; b < nbt; ++b) { deg[b] = 0; for (int j = 0; j < nbt; ++j) deg[b] += adj[b * nbt + j]; }
+  int* nbv = (int*)malloc(sizeof(int) * (size_t)nbt);
+  if (!nbv) { free(adj); free(deg); return 1; }
+  for (int k = 0; k < npvpq; ++k) {
+    int best = -1;
+    for (int b = 0; b < nbt; ++b) if (!gone[b] && (best < 0 || deg[b] < deg[best])) best = b;
+    c->order[k] = best;
+    gone[best] = 1;
+    int nn = 0;
+    for (int j = 0; j < nbt; ++j) if (adj[best * nbt + j]) { nbv[nn++] = j; adj[best * nbt + j] = 0; adj[j * nbt + best] = 0; --deg[j]; }
+    for (int x = 0; x < nn; ++x)
+      for (int y = x + 1; y < nn; ++y)
+        if (!adj[nbv[x] * nbt + nbv[y]]) { adj[nbv[x] * nbt + nbv[y]] = 1; adj[nbv[y] * nbt + nbv[x]] = 1; ++deg[nbv[x]]; ++deg[nbv[y]]; }
+  }
+  free(nbv); free(adj); free(deg);
+  /* permuted numbering: DC unknown of bus b = its rank in the order; AC: theta_b at upos[b], |V|_b right behind it (PQ buses) */
+  int* const rank = c->rank;
+  for (int b = 0; b < nbt; ++b) { rank[b] = -1; c->upos[b] = -1; }
+  int u = 0;
+  for (int k = 0; k < npvpq; ++k) { const int b = c->order[k]; rank[b] = k; c->upos[b] = u; u += 1 + (qidx[b] >= 0); }
+  /* patterns of the two systems */
+  const int n_ac = npvpq + npq;
+  const size_t need_c = (size_t)4 * (size_t)na + 16;
+  if (n_ac + 1 > c->cap_pr) { free(c->pat_rp); c->cap_pr = n_ac + 17; c->pat_rp = (int*)malloc(sizeof(int) * (size_t)c->cap_pr); }
+  if ((int)need_c > c->cap_pc) { free(c->pat_ci); c->cap_pc = (int)need_c; c->pat_ci = (int*)malloc(sizeof(int) * need_c); }
+  if (!c->pat_rp || !c->pat_ci) return 1;
+  int q = 0;
+  for (int k = 0; k < npvpq; ++k) {                      /* DC: one row per bus */
+    const int b = c->order[k];
+    c->pat_rp[k] = q;
+    for (int a = c->ap[b]; a < c->ap[b + 1]; ++a) if (rank[c->ai[a]] >= 0) c->pat_ci[q++] = rank[c->ai[a]];
+  }
+  c->pat_rp[npvpq] = q;
+  int rc = splu_symbolic(&c->dc, npvpq, c->pat_rp, c->pat_ci);
+  q = 0;
+  int r = 0;
+  for (int k = 0; k < npvpq && !rc; ++k) {               /* AC: the theta row and (PQ buses) the |V| row of a bus share their columns */
+    const int b = c->order[k];
+    for (int rep = 0; rep < 1 + (qidx[b] >= 0); ++rep) {
+      c->pat_rp[r++] = q;
+      for (int a = c->ap[b]; a < c->ap[b + 1]; ++a) {
+        const int j = c->ai[a];
+        if (c->upos[j] < 0) continue;
+        c->pat_ci[q++] = c->upos[j];
+        if (qidx[j] >= 0) c->pat_ci[q++] = c->upos[j] + 1;
+      }
+    }
+  }
+  c->pat_rp[r] = q;
+  if (!rc) rc = splu_symbolic(&c->ac, n_ac, c->pat_rp, c->pat_ci);
+  if (na > c->cap_y) { free(c->yv); c->cap_y = na + 64; c->yv = (cplx*)malloc(sizeof(cplx) * (size_t)c->cap_y); if (!c->yv) rc = 1; }
+  if (rc) return 1;
+  c->key = key; c->have = 1;
+  return 0;
+}
+static inline int sp_apos(const spctx_t* c, int b, int j) {          /* position of (b, j) in the bus adjacency */
+  for (int a = c->ap[b]; a < c->ap[b + 1]; ++a) if (c->ai[a] == j) return a;
+  return -1;
+}
+
+static int pfo_solve_impl(const gpf_grid_desc* d, const double* inj, const int32_t* topo, const int32_t* shunt_bus, int is_dc,
               int max_iter, double tol_mva, double* out, int32_t* topo_out, int32_t* shunt_bus_out, uint8_t* line_status,
-              int32_t* status4, double* bus_vm, double* bus_va) {
+              int32_t* status4, double* bus_vm, double* bus_va, const int sparse) {
   const offsets_t o = make_offsets(d);
   const int ns_ = d->n_sub, nbt = d->n_sub * d->n_busbar;
   const int nl = d->n_line, ng = d->n_gen, nd = d->n_load, nst = d->n_storage, nsh = d->n_shunt;
@@ -203,8 +413,35 @@ int pfo_solve(const gpf_grid_desc* d, const double* inj, const int32_t* topo, co
     qidx[b] = (active[b] && btype[b] == 0) ? npq++ : -1;
   }
 
+  spctx_t* const sp = &g_sp;
+  if (sparse && sp_prepare(sp, nbt, nl, lor, lex, line_status, active, pidx, qidx, npvpq, npq)) { rc = PFO_RETRY_DENSE; goto done; }
   /* DC solve */
-  {
+  if (sparse) {
+    splu_t* L = &sp->dc;
+    double* rhs = (double*)malloc(sizeof(double) * (size_t)(npvpq + 1));
+    for (int q = 0; q < L->nnz; ++q) L->val[q] = 0.0;
+    for (int l = 0; l < nl; ++l) {
+      if (!line_status[l]) continue;
+      const int f = lor[l], t = lex[l];
+      const double bb = d->br_bdc[l];
+      const int kf = sp->rank[f], kt = sp->rank[t];                                 /* DC unknowns of the two ends, -1: a reference bus */
+      if (kf >= 0) L->val[L->dpos[kf]] += bb;
+      if (kt >= 0) L->val[L->dpos[kt]] += bb;
+      if (kf >= 0 && kt >= 0 && f != t) { L->val[splu_pos(L, kf, kt)] -= bb; L->val[splu_pos(L, kt, kf)] -= bb; }
+      else if (kf >= 0 && kt >= 0) { L->val[L->dpos[kf]] -= 2.0 * bb; }            /* (a line between the two busbars' same bus: cancels) */
+    }
+    for (int k = 0; k < npvpq; ++k) { const int b = sp->order[k]; rhs[k] = P[b] - Gs[b]; }
+    if (npvpq > 0) {
+      if (splu_factor(L)) { free(rhs); rc = PFO_RETRY_DENSE; goto done; }
+      splu_solve(L, rhs);
+    }
+    for (int b = 0; b < nbt; ++b) { va[b] = 0.0; vm[b] = (btype[b] == 0) ? 1.0 : vset[b]; }
+    for (int k = 0; k < npvpq; ++k) {
+      va[sp->order[k]] = rhs[k];
+      if (!(fabs(rhs[k]) < 1e300)) { free(rhs); rc = GPF_ST_SINGULAR; goto done; }
+    }
+    free(rhs);
+  } else {
     int n = npvpq;
     B = (double*)calloc((size_t)n * n + n + 1, sizeof(double));
     double* rhs = B + (size_t)n * n;
@@ -227,10 +464,100 @@ int pfo_solve(const gpf_grid_desc* d, const double* inj, const int32_t* topo, co
     }
   }
 
-  Y = (cplx*)calloc((size_t)nbt * nbt, sizeof(cplx));
   V = (cplx*)calloc((size_t)2 * nbt, sizeof(cplx));
   cplx* Ibus = V + nbt;
-  if (!is_dc) {
+  if (!is_dc && sparse) {
+    /* Ybus over the bus adjacency */
+    cplx* const yv = sp->yv;
+    const int na = sp->ap[nbt];
+    for (int a = 0; a < na; ++a) yv[a] = 0.0;
+    for (int l = 0; l < nl; ++l) {
+      if (!line_status[l]) continue;
+      const int f = lor[l], t = lex[l];
+      const double* y = d->br_y + 8 * (size_t)l;
+      yv[sp->ap[f]] += y[0] + I * y[1];
+      yv[sp_apos(sp, f, t)] += y[2] + I * y[3];
+      yv[sp_apos(sp, t, f)] += y[4] + I * y[5];
+      yv[sp->ap[t]] += y[6] + I * y[7];
+    }
+    for (int i = 0; i < nsh; ++i)
+      if (shb[i] >= 0) yv[sp->ap[shb[i]]] += (inj[o.inj_sh_p + i] - I * inj[o.inj_sh_q + i]) * d->shunt_fact[i] / sn;
+    splu_t* L = &sp->ac;
+    const int n = npvpq + npq;
+    const double tol = tol_mva / sn;
+    F = (double*)malloc(sizeof(double) * ((size_t)n + 1));
+    int converged = 0;
+    for (;;) {
+      for (int b = 0; b < nbt; ++b) V[b] = active[b] ? vm[b] * cexp(I * va[b]) : 0.0;
+      double fmax = 0.0;
+      int bad = 0;
+      for (int b = 0; b < nbt; ++b) {
+        if (!active[b]) continue;
+        cplx ib = 0.0;
+        for (int a = sp->ap[b]; a < sp->ap[b + 1]; ++a) ib += yv[a] * V[sp->ai[a]];
+        Ibus[b] = ib;
+        const cplx s_ = V[b] * conj(ib);
+        const int u = sp->upos[b];
+        if (u >= 0) {
+          const double mp = creal(s_) - P[b];
+          F[u] = mp;
+          if (!(fabs(mp) <= 1e300)) bad = 1;
+          if (fabs(mp) > fmax) fmax = fabs(mp);
+          if (qidx[b] >= 0) {
+            const double mq = cimag(s_) - Q[b];
+            F[u + 1] = mq;
+            if (!(fabs(mq) <= 1e300)) bad = 1;
+            if (fabs(mq) > fmax) fmax = fabs(mq);
+          }
+        }
+      }
+      if (bad) { rc = GPF_ST_MAXITER; break; }
+      if (fmax < tol) { converged = 1; break; }
+      if (n_iter >= max_iter) break;
+      ++n_iter;
+      for (int q = 0; q < L->nnz; ++q) L->val[q] = 0.0;
+      for (int i = 0; i < nbt; ++i) {
+        const int ri = sp->upos[i];
+        if (ri < 0) continue;
+        const int iq = qidx[i] >= 0;
+        for (int a = sp->ap[i]; a < sp->ap[i + 1]; ++a) {
+          const int j = sp->ai[a], cj = sp->upos[j];
+          if (cj < 0) continue;
+          const cplx T = V[i] * conj(yv[a] * V[j]);
+          cplx dva, dvm;
+          if (i == j) {
+            const cplx S = V[i] * conj(Ibus[i]);
+            dva = I * (S - T);
+            dvm = (T + S) / vm[j];
+          } else {
+            dva = -I * T;
+            dvm = T / vm[j];
+          }
+          const int p0 = splu_pos(L, ri, cj);
+          L->val[p0] = creal(dva);
+          if (qidx[j] >= 0) L->val[p0 + 1] = creal(dvm);              /* (columns sorted: the |V| column of a bus follows its theta column) */
+          if (iq) {
+            const int p1 = splu_pos(L, ri + 1, cj);
+            L->val[p1] = cimag(dva);
+            if (qidx[j] >= 0) L->val[p1 + 1] = cimag(dvm);
+          }
+        }
+      }
+      for (int i = 0; i < n; ++i) F[i] = -F[i];
+      if (splu_factor(L)) { rc = PFO_RETRY_DENSE; break; }
+      splu_solve(L, F);
+      for (int b = 0; b < nbt; ++b) {
+        if (!active[b]) continue;
+        const int u = sp->upos[b];
+        if (u >= 0) { va[b] += F[u]; if (qidx[b] >= 0) vm[b] += F[u + 1]; }
+        if (vm[b] < 0.0) { vm[b] = -vm[b]; va[b] += M_PI; }
+        va[b] = remainder(va[b], 2.0 * M_PI);
+      }
+    }
+    if (rc == GPF_ST_CONVERGED && !converged) rc = GPF_ST_MAXITER;
+    if (rc != GPF_ST_CONVERGED) goto done;
+  } else if (!is_dc) {
+    Y = (cplx*)calloc((size_t)nbt * nbt, sizeof(cplx));
     for (int l = 0; l < nl; ++l) {
       if (!line_status[l]) continue;
       int f = lor[l], t = lex[l];
@@ -406,10 +733,22 @@ int pfo_solve(const gpf_grid_desc* d, const double* inj, const int32_t* topo, co
   }
 
 done:
+  if (rc == PFO_RETRY_DENSE) { free(lor); free(P); free(Y); free(V); free(J); free(F); free(B); return rc; }
   if (rc != GPF_ST_CONVERGED) fill_fail(d, &o, out, topo_out, shunt_bus_out, line_status, bus_vm, bus_va);
   status4[0] = rc; status4[1] = n_iter; status4[2] = nb; status4[3] = 0;
   free(lor); free(P); free(Y); free(V); free(J); free(F); free(B);
   return rc;
+}
+
+int pfo_solve(const gpf_grid_desc* d, const double* inj, const int32_t* topo, const int32_t* shunt_bus, int is_dc,
+              int max_iter, double tol_mva, double* out, int32_t* topo_out, int32_t* shunt_bus_out, uint8_t* line_status,
+              int32_t* status4, double* bus_vm, double* bus_va) {
+  if (g_sp.sparse) {
+    const int rc = pfo_solve_impl(d, inj, topo, shunt_bus, is_dc, max_iter, tol_mva, out, topo_out, shunt_bus_out, line_status, status4, bus_vm,
+                                  bus_va, 1);
+    if (rc != PFO_RETRY_DENSE) return rc;
+  }
+  return pfo_solve_impl(d, inj, topo, shunt_bus, is_dc, max_iter, tol_mva, out, topo_out, shunt_bus_out, line_status, status4, bus_vm, bus_va, 0);
 }
 
 /* The synthetic DoNothing step of bench.py for lanes [lane0, lane0+n): chronics row -> injections

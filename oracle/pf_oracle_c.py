@@ -70,6 +70,13 @@ def _desc(m, n_busbar=2):
     return d, keep
 
 
+def set_solver(sparse: bool):
+    """Linear solves of THIS thread's power flows: dense Gaussian elimination (default; the version pinned to the golden vectors) or the
+    sparse LU on a minimum-degree ordering with a cached symbolic analysis (what a CPU power-flow solver does -- pandapower: scipy spsolve,
+    pandaPowerBackend.py:1081-1083; lightsim2grid: KLU).  Same Newton iteration; tests/test_oracle_c.py pins the two to each other."""
+    _load().pfo_set_solver(1 if sparse else 0)
+
+
 class COracle:
     """One grid; `solve_rows` runs independent power flows with the result-row layout of include/gridpf.h."""
 
@@ -117,10 +124,11 @@ class COracle:
         return nconv, out, st
 
 
-def time_steps(m, ch, T, budget_s=12.0, chunk=512):
+def time_steps(m, ch, T, budget_s=12.0, chunk=512, sparse=False):
     """bench.py cpu_baseline leg: run the synthetic DoNothing workload on ONE host thread until ~budget_s of
     solver time has been spent.  Only the C call is timed (generating the synthetic jitter is not)."""
     orc = COracle(m)
+    set_solver(sparse)
     tab = np.ascontiguousarray(np.concatenate([ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"]], axis=-1), np.float32)
     n_total, spent, k0 = 0, 0.0, 0
     while spent < budget_s:
@@ -134,12 +142,14 @@ def time_steps(m, ch, T, budget_s=12.0, chunk=512):
         spent += time.perf_counter() - t1
         n_total += chunk
         k0 += chunk
+    set_solver(False)
     return n_total, spent
 
 
 def _all_cores_worker(args):
     """One process of `time_steps_all_cores`: worker `w` of `n` solves lanes w, w+n, w+2n, ... of the same global batch."""
-    grid_npz, chron_npz, w, n_workers, budget_s, start_at = args
+    grid_npz, chron_npz, w, n_workers, budget_s, start_at = args[:6]
+    sparse = bool(args[6]) if len(args) > 6 else False
     import sys
     root = os.path.dirname(_HERE)
     if root not in sys.path:
@@ -151,6 +161,7 @@ def _all_cores_worker(args):
         ch["prod_v"] = np.tile((m.gen_vm0 * m.sub_vn_kv[m.gen_sub]).astype(np.float32), (ch["prod_p"].shape[0], 1))
     T = ch["load_p"].shape[0]
     orc = COracle(m)
+    set_solver(sparse)
     tab = np.ascontiguousarray(np.concatenate([ch["load_p"], ch["load_q"], ch["prod_p"], ch["prod_v"]], axis=-1), np.float32)
     chunk = 256                              # this worker's lanes: w, w + n, w + 2n, ... stepped through t = 0, 1, 2, ...
     lanes = w + n_workers * np.arange(chunk)
@@ -169,7 +180,7 @@ def _all_cores_worker(args):
     return n_total, t_begin, time.time()
 
 
-def time_steps_all_cores(grid_npz, chron_npz, n_workers, budget_s=10.0, startup_s=None):
+def time_steps_all_cores(grid_npz, chron_npz, n_workers, budget_s=10.0, startup_s=None, sparse=False):
     """bench.py cpu_baseline leg, all host cores: `n_workers` single-thread processes (fresh interpreters -- the parent has
     initialised HIP, which must not be forked) split the lanes of the same synthetic workload between them.  Returns
     (lane-steps, wall seconds from the common start to the last worker's end)."""
@@ -180,7 +191,7 @@ def time_steps_all_cores(grid_npz, chron_npz, n_workers, budget_s=10.0, startup_
     start_at = time.time() + startup_s
     root = os.path.dirname(_HERE)
     procs = [subprocess.Popen([sys.executable, "-m", "oracle.pf_oracle_c", grid_npz, chron_npz, str(w), str(n_workers), str(budget_s),
-                               repr(start_at)], cwd=root, stdout=subprocess.PIPE, text=True,
+                               repr(start_at), "1" if sparse else "0"], cwd=root, stdout=subprocess.PIPE, text=True,
                               env=dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1"))
              for w in range(n_workers)]
     rs = []
@@ -198,4 +209,4 @@ if __name__ == "__main__":
     import json
     import sys
     a = sys.argv[1:]
-    print(json.dumps(_all_cores_worker((a[0], a[1], int(a[2]), int(a[3]), float(a[4]), float(a[5])))))
+    print(json.dumps(_all_cores_worker((a[0], a[1], int(a[2]), int(a[3]), float(a[4]), float(a[5]), int(a[6]) if len(a) > 6 else 0))))
