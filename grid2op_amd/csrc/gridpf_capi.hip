@@ -153,18 +153,22 @@ int fail(int code, const std::string& msg) {
       return fail(GPF_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));         \
   } while (0)
 
+// gpf_create(device = GPF_DEVICE_NONE): a HEADER-ONLY handle is being built -- every host-side step of gpf_create runs (symbolic analysis, static
+// tables, launch planning), nothing is allocated on or copied to a device (there may be none).  Thread-local: set for the duration of that call.
+static thread_local bool g_dry_create = false;
+
 template <typename T>
 struct DevArr {
   T* p = nullptr;
   size_t n = 0;
   hipError_t alloc(size_t count) {
     n = count;
-    if (count == 0) { p = nullptr; return hipSuccess; }
+    if (count == 0 || g_dry_create) { p = nullptr; return hipSuccess; }
     return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
   }
   hipError_t upload(const T* src, size_t count) {
     hipError_t e = alloc(count);
-    if (e != hipSuccess || count == 0) return e;
+    if (e != hipSuccess || count == 0 || g_dry_create) return e;
     return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
   }
   void release() {
@@ -195,6 +199,7 @@ struct DevArr {
 
 struct gpf_engine {
   int device = 0;
+  bool dry = false;                     // header-only handle (gpf_create with GPF_DEVICE_NONE): no device resources, no launches
   int n_lanes = 0;
   hipStream_t stream = nullptr;
   gpf::GridDev g{};
@@ -455,6 +460,10 @@ bool upload_flats(const gpf::Symbolic& S, DevArr<int>& buf, gpf::SymDev& D, int 
   }
   if (buf.upload(all.data(), all.size()) != hipSuccess) return false;
   for (int k = 0; k < 4; ++k) D.flat[k] = buf.p + off[k];
+  if (g_dry_create) {                           // header-only handle: no device copy; "has flat programs" is what the planner asks (never dereferenced on the host)
+    static int dry_words;
+    for (int k = 0; k < 4; ++k) D.flat[k] = &dry_words;
+  }
   return true;
 }
 
@@ -931,14 +940,19 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   if (d->n_line > 256) return fail(GPF_E_CAPACITY, "gpf_create: n_line > 256 not supported by the step kernel");
   if (d->n_busbar > GPF_MAX_BUSBAR)
     return fail(GPF_E_CAPACITY, "gpf_create: more than 64 busbars per substation (GPF_MAX_BUSBAR)");
-  int ndev = 0;
-  hipError_t e0 = hipGetDeviceCount(&ndev);
-  if (e0 != hipSuccess || ndev == 0)
-    return fail(GPF_E_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e0));
-  if (device < 0 || device >= ndev) return fail(GPF_E_INVALID, "gpf_create: bad device index");
-  HIP_TRY(hipSetDevice(device));
+  const bool dry = device == GPF_DEVICE_NONE;
+  struct DryGuard { bool on; explicit DryGuard(bool d_) : on(d_) { if (on) g_dry_create = true; } ~DryGuard() { if (on) g_dry_create = false; } } dry_guard(dry);
+  if (!dry) {
+    int ndev = 0;
+    hipError_t e0 = hipGetDeviceCount(&ndev);
+    if (e0 != hipSuccess || ndev == 0)
+      return fail(GPF_E_DEVICE, std::string("no HIP device available: ") + hipGetErrorString(e0));
+    if (device < 0 || device >= ndev) return fail(GPF_E_INVALID, "gpf_create: bad device index");
+    HIP_TRY(hipSetDevice(device));
+  }
   gpf_engine* e = new gpf_engine();
   e->device = device;
+  e->dry = dry;
   {
     const char* np_ = std::getenv("GRIDPF_NO_PARTITION");
     e->no_partition = np_ && np_[0] == '1';
@@ -1035,8 +1049,10 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
   AL(lane_table, B); AL(lane_offset, B); AL(thermal_limit, nl); AL(tmp_lines, std::max<size_t>(B, 1));
 #undef UP
 #undef AL
-  hipError_t es = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-  if (es != hipSuccess) { gpf_destroy(e); return fail(GPF_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(es)); }
+  if (!dry) {
+    hipError_t es = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (es != hipSuccess) { gpf_destroy(e); return fail(GPF_E_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(es)); }
+  }
   count_lane(e, e->h_init_topo.data(), nsh ? e->h_init_shunt_bus.data() : nullptr, e->init_nb, e->init_nj, e->init_mb);
   e->lane_nb.assign(e->cap_lanes, e->init_nb);
   e->lane_nj.assign(e->cap_lanes, e->init_nj);
@@ -1214,6 +1230,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     const char* fs_ = std::getenv("GRIDPF_FORCE_STAGE");
     if (fs_ && fs_[0] >= '0' && fs_[0] <= '2') e->stage_force = fs_[0] - '0';
   }
+  if (dry) { *out_h = e; return GPF_OK; }      // header-only handle: gpf_jit_source / gpf_get_plan / gpf_get_layout / gpf_destroy
   HIP_TRY(hipMemsetAsync(e->status.p, 0xFF, B * 4 * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->overflow_count.p, 0, B * nl * sizeof(int), e->stream));
   HIP_TRY(hipMemsetAsync(e->cooldown.p, 0, B * nl * sizeof(int), e->stream));
@@ -1238,6 +1255,7 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
 
 int gpf_destroy(gpf_handle e) {
   if (!e) return GPF_OK;
+  if (e->dry) { for (auto* c : e->classes) delete c; delete e; return GPF_OK; }      // (a header-only handle owns no device resource)
   (void)hipSetDevice(e->device);
   if (e->stream) { (void)hipStreamSynchronize(e->stream); (void)hipStreamDestroy(e->stream); }
   if (e->win_a) { (void)hipEventDestroy(e->win_a); (void)hipEventDestroy(e->win_b); }

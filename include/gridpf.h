@@ -104,7 +104,8 @@ const char* gpf_last_error(void);
 /* ABI version of the library = GPF_ABI_VERSION of the header it was built from.  A binding MUST compare the two before any other
  * call (grid2op_amd/_capi.py does): 300 = round 4 (gpf_set_trajectory(h, cap, what), 22 device pointers, GPF_ST_REDISPATCH,
  * gpf_device_pointers_n); 310 = + gpf_jit_*, GPF_E_UNSUPPORTED, gpf_set_profiling mode 3; 321 = 28 device pointers (action buffers and
- * dispatch / charge state of the environment dynamics), gpf_lane_actions_on_device; 322 = + gpf_get_results_pinned. */
+ * dispatch / charge state of the environment dynamics), gpf_lane_actions_on_device; 322 = + gpf_get_results_pinned; 323 = gpf_step_opts::track_cooldown,
+ * GPF_DEVICE_NONE (header-only handles). */
 #define GPF_ABI_VERSION 323
 int gpf_version(void);
 /* Bitwise run-to-run reproducibility is the DEFAULT on every grid: the same lane inputs give bit-identical results from run to
@@ -122,7 +123,14 @@ int gpf_set_deterministic(gpf_handle h, int32_t flag);
 int gpf_device_count(int32_t* n_devices);
 
 /* load_grid (pandaPowerBackend.py:356): build an engine with `n_lanes` lanes on HIP device `device`.
- * Every lane starts in the pristine state. */
+ * Every lane starts in the pristine state.
+ * device = GPF_DEVICE_NONE: a HEADER-ONLY handle -- every host-side step of the construction runs (validation, symbolic analysis of the
+ * substation graph, static tables, launch planning for `n_lanes` lanes) but nothing is allocated on a device, and none is needed: what
+ * works on it is gpf_jit_source (the header the grid-specialised kernels are compiled with -- pure grid arithmetic), gpf_get_plan (the
+ * kernel variant a launch over all lanes would take), gpf_get_layout, gpf_n_lanes and gpf_destroy; every other entry point fails with
+ * GPF_E_DEVICE.  It is how the ahead-of-time objects of a NEW grid are prepared on a machine without a GPU
+ * (python -m grid2op_amd.aot). */
+#define GPF_DEVICE_NONE (-1)
 int gpf_create(const gpf_grid_desc* desc, int32_t n_lanes, int32_t device, gpf_handle* out);
 /* close (pandaPowerBackend.py:1411-1423) */
 int gpf_destroy(gpf_handle h);
