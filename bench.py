@@ -671,7 +671,7 @@ def compact_record(res, full_path=None):
         "idf_ac_118sub": _cfg_line(dc.get("ac_env_steps")),
         "ptdf_rows": _cfg_line(rows, extra=("rows_per_launch",)),
         "ptdf_1row": _cfg_line(dc) if dc else None,
-        "ptdf_build_batch": _cfg_line(res.get("ptdf_build_batch"), extra=("classes", "host_builds_per_sec")),
+        "ptdf_build_batch": _cfg_line(res.get("ptdf_build_batch"), extra=("classes", "call_value", "call_value_unseen_topologies", "enqueue_ms_unseen_topologies", "host_builds_per_sec")),
     }
     act = (res.get("secondary_env_dynamics") or {}).get("acting_every_step")
     if act and configs["wcci_env_dynamics"]:                # agents acting at EVERY step: actions from the host / written on the device
@@ -1416,24 +1416,39 @@ def workload_ptdf_build_batch(ctx, env, B, n_topo, reps=5):
     eng.set_topology(np.stack([topos[i] for i in lane_topo]).astype(np.int32))
     eng.step(3, n_steps=1, rebalance=1.02)                       # the lanes hold the injections of their chronics row
     info = eng.ptdf_build_batch(with_lodf=True)                   # warm-up (allocations, LDS attribute)
-    k_ms, w_ms = [], []
+    # THE CALL A USER MAKES, end to end: host grouping + descriptors + upload + kernel + class status back (ptdf_build_batch returns the
+    # status: it waits for the kernel); beside it the ENQUEUE time (info=False: the call returns once the kernel is queued -- the flows /
+    # screening calls that consume the tables queue behind it on the same stream)
+    eng.sync()
+    k_ms, w_ms, q_ms = [], [], []
     for _ in range(reps):
         t0 = time.perf_counter()
         info = eng.ptdf_build_batch(with_lodf=True)
         w_ms.append((time.perf_counter() - t0) * 1e3)
         k_ms.append(info["kernel_ms"])
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        eng.ptdf_build_batch(with_lodf=True, info=False)
+        q_ms.append((time.perf_counter() - t0) * 1e3)
+        eng.sync()
     k_med, w_med = float(np.median(k_ms)), float(np.median(w_ms))
     os.environ["GRIDPF_PTDFB_NO_CACHE"] = "1"                   # the same call when NONE of the topologies has been seen before
-    w_new = []
+    w_new, q_new = [], []
     for _ in range(5):
         t0 = time.perf_counter()
         eng.ptdf_build_batch(with_lodf=True)
         w_new.append((time.perf_counter() - t0) * 1e3)
+    for _ in range(5):
+        t0 = time.perf_counter()
+        eng.ptdf_build_batch(with_lodf=True, info=False)
+        q_new.append((time.perf_counter() - t0) * 1e3)
+        eng.sync()
     del os.environ["GRIDPF_PTDFB_NO_CACHE"]
     info = eng.ptdf_build_batch(with_lodf=True)
     ok_cls = info["class_status"] == 0
     npad = (np.maximum(info["class_n"], 1) + 15) // 16 * 16
-    flops = float((2.0 * npad[ok_cls].astype(np.float64) ** 3).sum())
+    flops_padded = float((2.0 * npad[ok_cls].astype(np.float64) ** 3).sum())
+    flops = float((2.0 * info["class_n"][ok_cls].astype(np.float64) ** 3).sum())      # ALGORITHMIC: 2 n^3, n = the reduced dimension itself (117 -> 128 in tiles is x 1.31)
     tf = flops / (k_med * 1e-3) / 1e12
     # the host path beside it: gpf_ptdf_build of 8 of the same topologies (one lane each)
     reps_h = [int(np.nonzero(info["lane_class"] == c)[0][0]) for c in np.nonzero(ok_cls)[0][:8]]
@@ -1466,12 +1481,15 @@ def workload_ptdf_build_batch(ctx, env, B, n_topo, reps=5):
            "call_ms": w_med, "call_value": float(ok_cls.sum()) / (w_med * 1e-3), "call_is": "host grouping of the lanes' topology rows + descriptor upload + kernel + status readback "
            "(topologies seen by an earlier call: their descriptors come from the engine's cache)",
            "call_ms_unseen_topologies": float(np.median(w_new)), "call_value_unseen_topologies": float(ok_cls.sum()) / (float(np.median(w_new)) * 1e-3),
+           "enqueue_ms": float(np.median(q_ms)), "enqueue_ms_unseen_topologies": float(np.median(q_new)),
+           "enqueue_is": "the same call with info=False: it returns once the kernel is queued (host grouping + descriptors + upload); consumers queue behind it on the stream",
            "host_builds_per_sec": 1.0 / host_s, "host_is": "gpf_ptdf_build: the same matrices by Gauss-Jordan on ONE host core (round-3 path), per topology",
            "speedup_vs_host_path": (float(ok_cls.sum()) / (w_med * 1e-3)) * host_s,
            "roofline": {"bound": "mfma", "achieved": tf, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F64_PEAK_TFLOPS,
                         "traffic": ptdf_traffic("ptdf_build_lds_kernel")[0], "traffic_source": ptdf_traffic("ptdf_build_lds_kernel")[1],
                         "hbm_gbs": (ptdf_traffic("ptdf_build_lds_kernel")[0] or 0.0) / (k_med * 1e-3) / 1e9,
-                        "flops_per_launch": flops, "flops_are": "2 n^3 per class, n = reduced dimension padded to 16 (the tiles the matrix cores run)",
+                        "flops_per_launch": flops, "flops_are": "ALGORITHMIC: 2 n^3 per class, n = the reduced dimension (unpadded)", "flops_padded_to_tiles": flops_padded,
+                        "frac_on_padded_flops": flops_padded / (k_med * 1e-3) / 1e12 / F64_PEAK_TFLOPS,
                         "avg_launch_us": k_med * 1e3, "kernel": "ptdf_build_lds_kernel (reduced dimension <= 128: matrix in LDS)"},
            "flows_per_lane_topology": {"value": B / (f_ms / max(f_n, 1) * 1e-3), "unit": "DC power flows/sec (each lane x its own PTDF)", "us_per_batch": f_ms / max(f_n, 1) * 1e3},
            "lodf_n1_value": B * m.n_line / lodf_s, "lodf_n1_unit": "DC contingency cases/sec, every lane screened against the LODF of ITS topology (result copied to the host)",

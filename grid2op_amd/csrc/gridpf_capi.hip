@@ -24,6 +24,9 @@
 #include "gridpf_ptdf_batch.hpp"
 #include "gridpf_redispatch.hpp"
 #include <string>
+#include <thread>
+#include <condition_variable>
+#include <functional>
 #include <unordered_map>
 #include "gridpf_symbolic.hpp"
 
@@ -308,6 +311,10 @@ struct gpf_engine {
   std::vector<int> h_ptdfb_lane_class, h_ptdfb_status, h_ptdfb_desc;
   std::vector<std::vector<int>> h_ptdfb_bus;   // per class: compact bus index -> bus id (sub + (local - 1) * n_sub)
   double ptdfb_kernel_ms = 0.0;            // duration of the last build kernel (HIP events)
+  // the build call returns once its kernel is QUEUED: class status + kernel time are fetched when somebody asks (gpf_ptdf_batch_info)
+  hipEvent_t ptdfb_ev_a = nullptr, ptdfb_ev_b = nullptr;
+  int* ptdfb_status_pin = nullptr; size_t ptdfb_status_pin_n = 0;
+  bool ptdfb_pending = false;
   DevArr<double> dc_inv_g;     // static DC inverse of the larger grids (gpf::SymDev::dc_inv_g)
   DevArr<double> stat_dbl;     // static blob of kernel S (gpf::StatOff)
   DevArr<int> stat_int;
@@ -325,6 +332,7 @@ struct gpf_engine {
   // host mirror of the topology last SENT for every lane (gpf_set_topology skips the per-lane bookkeeping when a lane is
   // re-sent unchanged: agents resend whole batches with few changes); first entry INT_MIN = unknown
   std::vector<int> h_lane_topo, h_lane_sb;
+  bool dev_topo_dirty = false;           // a kernel may have rewritten topology rows (cascade trips, scheduled outages): the host mirrors are not the device rows any more
   std::vector<int> lane_class;          // per lane: topology class (-1: no split substation / classes disabled)
   DevArr<gpf::TopoClassDev> d_classes;  // device copy of classes[*].dev
   size_t d_classes_count = 0;
@@ -1274,6 +1282,8 @@ int gpf_destroy(gpf_handle e) {
   if (e->act_pin) (void)hipHostFree(e->act_pin);
   if (e->res_pin) (void)hipHostFree(e->res_pin);
   if (e->act_up) (void)hipEventDestroy(e->act_up);
+  if (e->ptdfb_ev_a) { (void)hipEventDestroy(e->ptdfb_ev_a); (void)hipEventDestroy(e->ptdfb_ev_b); }
+  if (e->ptdfb_status_pin) (void)hipHostFree(e->ptdfb_status_pin);
   e->maint.release(); e->forecast.release(); e->sim_src.release(); e->sim_rows.release();
   e->env_target.release(); e->env_actual.release(); e->env_prev.release(); e->env_charge.release(); e->env_amount_prev.release();
   e->env_act_redisp.release(); e->env_act_storage.release(); e->sto_charge0.release(); e->env_already.release(); e->env_fresh.release();
@@ -1805,6 +1815,7 @@ int step_range(gpf_engine* e, const gpf::Bufs& b_in, int lane0, int n, int t0, i
   if (n_steps > 1 && pb.sparse_nb)
     return fail(GPF_E_INVALID, std::string(who) + ": multi-step launches need a batch that runs as ONE launch (mixed split / unsplit lanes "
                                "without topology classes run as two): use n_steps = 1");
+  if (o->cascade != 0 || b.maint != nullptr) e->dev_topo_dirty = true;     // (lines tripped / taken out by the kernel: see gpf_ptdf_build_batch)
   gpf::StepArgs sa{};
   sa.t = t0; sa.T = T; sa.rebalance_on = o->rebalance > 0.0 ? 1 : 0; sa.rebalance = o->rebalance; sa.cascade = o->cascade;
   sa.is_dc = o->is_dc ? 1 : 0; sa.n_steps = n_steps; sa.auto_reset = o->auto_reset ? 1 : 0; sa.warm_start = o->warm_start ? 1 : 0;
@@ -2637,6 +2648,77 @@ static gpf::PtdfDev ptdf_dev(gpf_engine* e) {
   return P;
 }
 
+// A few PERSISTENT host threads for the table walks of gpf_ptdf_build_batch (row hashes / comparisons, descriptors of unseen classes): creating
+// threads per call cost more than the work it spread (measured on the MI355X box: no gain from 4 fresh std::threads on 0.8 ms of work).
+// Workers sleep on a condition variable between calls; they are detached at process exit (never joined: no ordering against the HIP runtime).
+namespace {
+class HostPool {
+ public:
+  static HostPool& get() { static HostPool* p = new HostPool(); return *p; }      // (intentionally leaked)
+  int size() const { return n_workers_ + 1; }
+  // body(part, n_parts) for part = 0 .. n_parts - 1, part 0 on the caller's thread; returns when all parts are done
+  void run(int n_parts, const std::function<void(int, int)>& body) {
+    n_parts = std::max(1, std::min(n_parts, size()));
+    if (n_parts == 1) { body(0, 1); return; }
+    std::lock_guard<std::mutex> call_lk(call_mu_);          // one parallel region at a time
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      body_ = &body; parts_ = n_parts; next_ = 1; left_ = n_parts - 1; ++gen_;
+    }
+    cv_.notify_all();
+    body(0, n_parts);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return left_ == 0; });
+    body_ = nullptr;
+  }
+ private:
+  HostPool() {
+    const char* v = getenv("GRIDPF_PTDFB_THREADS");
+    int t = v ? atoi(v) : 4;
+    const int hw = (int)std::thread::hardware_concurrency();
+    if (hw > 0 && t > hw) t = hw;
+    n_workers_ = std::max(0, t - 1);
+    for (int w = 0; w < n_workers_; ++w) std::thread([this] { loop(); }).detach();
+  }
+  void loop() {
+    unsigned long long seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] { return gen_ != seen && next_ < parts_; });
+      const unsigned long long g = gen_;
+      while (gen_ == g && next_ < parts_) {
+        const int part = next_++;
+        const std::function<void(int, int)>* b = body_;
+        const int np = parts_;
+        lk.unlock();
+        (*b)(part, np);
+        lk.lock();
+        if (--left_ == 0) done_.notify_all();
+      }
+      seen = g;
+    }
+  }
+  std::mutex mu_, call_mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int, int)>* body_ = nullptr;
+  int n_workers_ = 0, parts_ = 0, next_ = 0, left_ = 0;
+  unsigned long long gen_ = 0;
+};
+}  // namespace
+
+// completes the asynchronous tail of gpf_ptdf_build_batch: class status in h_ptdfb_status, kernel duration in ptdfb_kernel_ms
+static int ptdfb_finish(gpf_engine* e) {
+  if (!e->ptdfb_pending) return GPF_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  std::copy(e->ptdfb_status_pin, e->ptdfb_status_pin + e->h_ptdfb_status.size(), e->h_ptdfb_status.begin());
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e->ptdfb_ev_a, e->ptdfb_ev_b);
+  e->ptdfb_kernel_ms = ms;
+  e->ptdfb_pending = false;
+  return GPF_OK;
+}
+
 /* ---- PTDF / LODF of every distinct topology of a lane range, built on the device (gridpf_ptdf_batch.hpp) --------------------------- */
 int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lodf, int32_t* n_classes_out) {
   if (!check_range(e, lane0, n) || n <= 0) return fail(GPF_E_INVALID, "gpf_ptdf_build_batch: bad lane range");
@@ -2644,6 +2726,7 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
   // a rebuild overwrites the lane -> class map and may regrow the device tables before it can fail: from here until it has succeeded there
   // are NO tables (gpf_ptdf_flows / gpf_ptdf_batch_get refuse), instead of new lane classes against old tables
   e->ptdf_ready = false; e->ptdf_batch = false;
+  e->ptdfb_pending = false;                        // (a status nobody asked for: the stream orders the next build behind the last one)
   const gpf::GridDev& g = e->g;
   const gpf::OutOff& oo = e->oo;
   const int nl = g.n_line, nbt = g.nb_tot, nsh = g.n_shunt;
@@ -2651,11 +2734,27 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
   auto now_us = [] { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() * 1e-3; };
   double tm[6] = {0, 0, 0, 0, 0, 0};
   // the lanes' topology rows as they are on the device (a cascade inside gpf_step_n may have tripped lines the host never saw)
-  std::vector<int> topo((size_t)n * g.dim_topo), sb((size_t)n * std::max(nsh, 1));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  // (when no kernel can have rewritten them -- no cascade, no outage tables since the engine was created -- and the host sent every row of the
+  //  range itself, the host mirrors ARE the device rows: no trip over PCIe, no synchronisation; 2 048 rows of 560 ints are 4.6 MB)
+  std::vector<int> topo_own, sb_own;
+  const int* topo_p = nullptr;
+  const int* sb_p = nullptr;
+  bool mirror_ok = !e->dev_topo_dirty && getenv("GRIDPF_PTDFB_NO_MIRROR") == nullptr;
+  for (int k = lane0; k < lane0 + n && mirror_ok; ++k)
+    mirror_ok = e->h_lane_topo[(size_t)k * g.dim_topo] != INT_MIN && (!nsh || e->h_lane_sb[(size_t)k * nsh] != INT_MIN);
   if (stage_timing) tm[0] = now_us();
-  HIP_TRY(hipMemcpy(topo.data(), e->topo.p + (size_t)lane0 * g.dim_topo, topo.size() * sizeof(int), hipMemcpyDeviceToHost));
-  if (nsh) HIP_TRY(hipMemcpy(sb.data(), e->shunt_bus.p + (size_t)lane0 * nsh, (size_t)n * nsh * sizeof(int), hipMemcpyDeviceToHost));
+  if (mirror_ok) {
+    topo_p = e->h_lane_topo.data() + (size_t)lane0 * g.dim_topo;
+    sb_p = e->h_lane_sb.data() + (size_t)lane0 * std::max(nsh, 1);
+  } else {
+    topo_own.resize((size_t)n * g.dim_topo); sb_own.resize((size_t)n * std::max(nsh, 1));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (stage_timing) tm[0] = now_us();
+    HIP_TRY(hipMemcpy(topo_own.data(), e->topo.p + (size_t)lane0 * g.dim_topo, topo_own.size() * sizeof(int), hipMemcpyDeviceToHost));
+    if (nsh) HIP_TRY(hipMemcpy(sb_own.data(), e->shunt_bus.p + (size_t)lane0 * nsh, (size_t)n * nsh * sizeof(int), hipMemcpyDeviceToHost));
+    topo_p = topo_own.data(); sb_p = sb_own.data();
+  }
+  struct RowView { const int* p; const int* data() const { return p; } int operator[](size_t i) const { return p[i]; } } topo{topo_p}, sb{sb_p};
   if (stage_timing) tm[1] = now_us();
   // ---- classes: lanes with identical (topology row, shunt buses) ----------------------------------------------------------------------
   std::unordered_map<uint64_t, std::vector<int>> cls_of;     // row hash -> classes with that hash (rows compared on a hit)
@@ -2667,7 +2766,16 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
            (!nsh || std::memcmp(sb.data() + (size_t)a * nsh, sb.data() + (size_t)b * nsh, (size_t)nsh * sizeof(int)) == 0);
   };
   cls_of.reserve((size_t)n);
-  for (int k = 0; k < n; ++k) {
+  // host threads for the two table walks of this call (row hashes, descriptors of unseen classes): a few hundred microseconds of one core each
+  // for 2 048 lanes / 256 classes of a 118-substation grid, embarrassingly parallel
+  HostPool& pool = HostPool::get();
+  auto par_for = [&](int count, int min_per_thread, const std::function<void(int, int, int)>& body) {     // body(begin, end, part index)
+    const int nt = std::max(1, std::min(pool.size(), count / std::max(1, min_per_thread)));
+    pool.run(nt, [&](int part, int n_parts) { body((int)((long long)count * part / n_parts), (int)((long long)count * (part + 1) / n_parts), part); });
+  };
+  std::vector<uint64_t> row_hash((size_t)n);
+  par_for(n, 256, [&](int k0, int k1, int) {
+  for (int k = k0; k < k1; ++k) {
     // row hash: four independent multiply-xor chains over the row (one dependent multiply per int was 1 ms for 2 048 rows of 560 ints);
     // equal hashes are confirmed by comparing the rows, so the hash only has to spread
     const int* tp = topo.data() + (size_t)k * g.dim_topo;
@@ -2683,9 +2791,27 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
     for (int q = 0; q < nsh; ++q) h1 = (h1 ^ ((uint32_t)sb[(size_t)k * nsh + q] + 0x9E3779B9u)) * 1099511628211ull;
     uint64_t h = h0 ^ (h1 >> 29 | h1 << 35) ^ (h2 >> 17 | h2 << 47) ^ (h3 >> 41 | h3 << 23);
     h ^= h >> 32;
+    row_hash[k] = h;
+  }
+  });
+  // classes by hash first (no row is touched), then every lane's row is compared with its class representative's -- in parallel: the two
+  // passes over the rows (hash, confirm) are what grouping costs (4.6 MB each for 2 048 lanes of a 118-substation grid, memory-bound on one core)
+  for (int k = 0; k < n; ++k) {
+    const uint64_t h = row_hash[k];
+    std::vector<int>& cand = cls_of[h];
+    if (cand.empty()) { cand.push_back((int)first_lane.size()); first_lane.push_back(k); first_hash.push_back(h); }
+    e->h_ptdfb_lane_class[k] = cand[0];
+  }
+  std::vector<char> differs((size_t)n, 0);
+  par_for(n, 256, [&](int k0, int k1, int) {
+    for (int k = k0; k < k1; ++k) { const int rep = first_lane[e->h_ptdfb_lane_class[k]]; differs[k] = (rep != k && !same_rows(rep, k)) ? 1 : 0; }
+  });
+  for (int k = 0; k < n; ++k) {                     // (a 64-bit hash collision between different rows: never seen; handled the slow way)
+    if (!differs[k]) continue;
+    const uint64_t h = row_hash[k];
     std::vector<int>& cand = cls_of[h];
     int c = -1;
-    for (int cc : cand) if (same_rows(first_lane[cc], k)) { c = cc; break; }
+    for (size_t q = 1; q < cand.size(); ++q) if (same_rows(first_lane[cand[q]], k)) { c = cand[q]; break; }
     if (c < 0) { c = (int)first_lane.size(); first_lane.push_back(k); first_hash.push_back(h); cand.push_back(c); }
     e->h_ptdfb_lane_class[k] = c;
   }
@@ -2789,30 +2915,50 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
     const size_t row_ints = (size_t)g.dim_topo + (size_t)nsh;
     const bool no_cache = getenv("GRIDPF_PTDFB_NO_CACHE") != nullptr;      // developer / bench: every class counts as never seen (read at every call)
     if (no_cache || e->ptdfb_cache_stride != stride || e->ptdfb_cache_n > 8192) { e->ptdfb_cache.clear(); e->ptdfb_cache_n = 0; e->ptdfb_cache_stride = stride; }
+    std::vector<int> miss;
     for (int c = 0; c < nc; ++c) {
       const int* tp = topo.data() + (size_t)first_lane[c] * g.dim_topo;
       const int* sbp = sb.data() + (size_t)first_lane[c] * std::max(nsh, 1);
       int* d = desc.data() + (size_t)c * stride;
-      std::vector<gpf_engine::PtdfbCached>& bucket = e->ptdfb_cache[first_hash[c]];
+      auto it_b = e->ptdfb_cache.find(first_hash[c]);
       const gpf_engine::PtdfbCached* hit = nullptr;
-      for (const auto& ce : bucket)
-        if (std::memcmp(ce.row.data(), tp, (size_t)g.dim_topo * sizeof(int)) == 0 && (!nsh || std::memcmp(ce.row.data() + g.dim_topo, sbp, (size_t)nsh * sizeof(int)) == 0)) { hit = &ce; break; }
+      if (it_b != e->ptdfb_cache.end())
+        for (const auto& ce : it_b->second)
+          if (std::memcmp(ce.row.data(), tp, (size_t)g.dim_topo * sizeof(int)) == 0 && (!nsh || std::memcmp(ce.row.data() + g.dim_topo, sbp, (size_t)nsh * sizeof(int)) == 0)) { hit = &ce; break; }
       if (hit) {
         std::memcpy(d, hit->desc.data(), (size_t)stride * sizeof(int));
         e->h_ptdfb_bus[c] = hit->c2b;
-      } else {
-        const int err = build_class(c, scr);
-        if (err == 1) return fail(GPF_E_INVALID, "gpf_ptdf_build_batch: bus id out of range");
-        if (err == 2) return fail(GPF_E_CAPACITY, "gpf_ptdf_build_batch: more than 256 active non-reference buses in one topology");
-        gpf_engine::PtdfbCached ce;
+      } else miss.push_back(c);
+    }
+    // the classes never seen before: their descriptors are independent table walks -- spread over the host threads
+    std::vector<int> miss_err(miss.size(), 0);
+    std::vector<gpf_engine::PtdfbCached> miss_ce(miss.size());      // (the cache entries too: three allocations + 9 KB of copies per class)
+    (void)scr;
+    par_for((int)miss.size(), 16, [&](int q0, int q1, int) {
+      ClsScratch scr_t;
+      for (int q = q0; q < q1; ++q) {
+        const int c = miss[q];
+        miss_err[q] = build_class(c, scr_t);
+        if (miss_err[q]) continue;
+        gpf_engine::PtdfbCached& ce = miss_ce[q];
         ce.row.resize(row_ints);
-        std::memcpy(ce.row.data(), tp, (size_t)g.dim_topo * sizeof(int));
-        if (nsh) std::memcpy(ce.row.data() + g.dim_topo, sbp, (size_t)nsh * sizeof(int));
+        std::memcpy(ce.row.data(), topo.data() + (size_t)first_lane[c] * g.dim_topo, (size_t)g.dim_topo * sizeof(int));
+        if (nsh) std::memcpy(ce.row.data() + g.dim_topo, sb.data() + (size_t)first_lane[c] * nsh, (size_t)nsh * sizeof(int));
+        const int* d = desc.data() + (size_t)c * stride;
         ce.desc.assign(d, d + stride);
         ce.c2b = e->h_ptdfb_bus[c];
-        bucket.push_back(std::move(ce));
-        ++e->ptdfb_cache_n;
       }
+    });
+    for (size_t q = 0; q < miss.size(); ++q) {
+      const int c = miss[q];
+      const int err = miss_err[q];
+      if (err == 1) return fail(GPF_E_INVALID, "gpf_ptdf_build_batch: bus id out of range");
+      if (err == 2) return fail(GPF_E_CAPACITY, "gpf_ptdf_build_batch: more than 256 active non-reference buses in one topology");
+      e->ptdfb_cache[first_hash[c]].push_back(std::move(miss_ce[q]));
+      ++e->ptdfb_cache_n;
+    }
+    for (int c = 0; c < nc; ++c) {
+      const int* d = desc.data() + (size_t)c * stride;
       npad_max = std::max(npad_max, d[2]);
       nact_max = std::max(nact_max, d[1]);
     }
@@ -2867,23 +3013,27 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
     lds_set[e->device & 63][resident] = lds;
   }
   if (stage_timing) tm[4] = now_us();
-  struct EvPair {                                   // destroyed on every path out of the function
-    hipEvent_t a = nullptr, b = nullptr;
-    ~EvPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
-  } ev;
-  HIP_TRY(hipEventCreate(&ev.a)); HIP_TRY(hipEventCreate(&ev.b));
+  if (!e->ptdfb_ev_a) { HIP_TRY(hipEventCreate(&e->ptdfb_ev_a)); HIP_TRY(hipEventCreate(&e->ptdfb_ev_b)); }     // (the engine's: destroyed with it)
+  if (e->ptdfb_status_pin_n < (size_t)nc) {
+    if (e->ptdfb_status_pin) (void)hipHostFree(e->ptdfb_status_pin);
+    e->ptdfb_status_pin = nullptr; e->ptdfb_status_pin_n = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->ptdfb_status_pin), ((size_t)nc + nc / 4 + 64) * sizeof(int), hipHostMallocDefault));
+    e->ptdfb_status_pin_n = (size_t)nc + nc / 4 + 64;
+  }
+  struct { hipEvent_t a, b; } ev{e->ptdfb_ev_a, e->ptdfb_ev_b};
   HIP_TRY(hipEventRecord(ev.a, e->stream));
   if (resident) hipLaunchKernelGGL(gpf::ptdf_build_lds_kernel, dim3(nc), dim3(gpf::PTDFB_LDS_THREADS), lds, e->stream, D);
   else hipLaunchKernelGGL(gpf::ptdf_build_kernel, dim3(nc), dim3(gpf::PTDFB_THREADS), lds, e->stream, D);
   hipError_t le = hipGetLastError();
   HIP_TRY(hipEventRecord(ev.b, e->stream));
   if (le != hipSuccess) return fail(GPF_E_DEVICE, std::string("ptdf_build_kernel: ") + hipGetErrorString(le));
+  // the class status comes back by DMA into a pinned block behind the kernel; nobody waits here -- the flows / screening calls queue on the
+  // same stream, gpf_ptdf_batch_info (status, kernel time) synchronises when it is asked (ptdfb_finish)
   e->h_ptdfb_status.assign(nc, 0);
-  HIP_TRY(hipMemcpyAsync(e->h_ptdfb_status.data(), e->ptdfb_status.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, e->stream));
-  HIP_TRY(hipStreamSynchronize(e->stream));
+  HIP_TRY(hipMemcpyAsync(e->ptdfb_status_pin, e->ptdfb_status.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  e->ptdfb_pending = true;
   float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, ev.a, ev.b);
-  e->ptdfb_kernel_ms = ms;
+  if (stage_timing || want_dbg) { int rc_f = ptdfb_finish(e); if (rc_f != GPF_OK) return rc_f; ms = (float)e->ptdfb_kernel_ms; }
   if (stage_timing)
     fprintf(stderr, "[gridpf] ptdf_build_batch %d lanes, %d classes: rows to the host %.0f us, grouping %.0f, descriptors %.0f, slots + uploads %.0f, kernel + status %.0f\n",
             n, nc, tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], now_us() - tm[4]);
@@ -2913,6 +3063,7 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
 int gpf_ptdf_batch_info(gpf_handle e, int32_t* lane_class, int32_t* class_status, int32_t* class_n, double* kernel_ms) {
   if (!e) return fail(GPF_E_INVALID, "gpf_ptdf_batch_info: null");
   if (!e->ptdf_ready || !e->ptdf_batch) return fail(GPF_E_INVALID, "gpf_ptdf_batch_info: call gpf_ptdf_build_batch first");
+  if (class_status || kernel_ms) { const int rc_f = ptdfb_finish(e); if (rc_f != GPF_OK) return rc_f; }
   if (lane_class) std::copy(e->h_ptdfb_lane_class.begin(), e->h_ptdfb_lane_class.end(), lane_class);
   if (class_status) std::copy(e->h_ptdfb_status.begin(), e->h_ptdfb_status.end(), class_status);
   if (class_n) for (int c = 0; c < e->ptdfb_classes; ++c) class_n[c] = e->h_ptdfb_desc[(size_t)c * e->ptdfb_desc_stride];

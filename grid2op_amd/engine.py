@@ -732,7 +732,7 @@ class PowerFlowEngine:
         """Factorise the DC system of the topology currently held by ``lane`` (once per topology)."""
         check(self._lib.gpf_ptdf_build(self._h, int(lane)), "gpf_ptdf_build")
 
-    def ptdf_build_batch(self, lane0: int = 0, n: Optional[int] = None, with_lodf: bool = True) -> dict:
+    def ptdf_build_batch(self, lane0: int = 0, n: Optional[int] = None, with_lodf: bool = True, info: bool = True) -> dict:
         """PTDF (and LODF) tables of EVERY distinct topology the lanes ``[lane0, lane0 + n)`` hold right now, built on the device in
         one launch (gpf_ptdf_build_batch: one workgroup per topology class, blocked Gauss-Jordan on the FP64 matrix cores).  Afterwards
         `ptdf_flows` / `ptdf_flows_rows` / `lodf_screen` evaluate every lane against the tables of its own class.  Returns
@@ -741,6 +741,15 @@ class PowerFlowEngine:
         lane0, n = self._range(lane0, n)
         nc = C.c_int32(0)
         check(self._lib.gpf_ptdf_build_batch(self._h, lane0, n, 1 if with_lodf else 0, C.byref(nc)), "gpf_ptdf_build_batch")
+        if not info:                                        # asynchronous: the build kernel is queued, nobody waits (`ptdf_batch_info()` later)
+            return {"n_classes": int(nc.value)}
+        return self.ptdf_batch_info(n, nc.value)
+
+    def ptdf_batch_info(self, n: Optional[int] = None, n_classes: Optional[int] = None) -> dict:
+        """Lane -> class map, class status / dimension and the kernel time of the last `ptdf_build_batch` (waits for its kernel)."""
+        if n is None or n_classes is None:
+            raise ValueError("ptdf_batch_info: pass the lane count and the class count of the build call")
+        nc = C.c_int32(int(n_classes))
         lc, st, cn = np.empty(n, np.int32), np.empty(nc.value, np.int32), np.empty(nc.value, np.int32)
         ms = C.c_double(0.0)
         check(self._lib.gpf_ptdf_batch_info(self._h, ptr(lc, C.c_int32), ptr(st, C.c_int32), ptr(cn, C.c_int32), C.byref(ms)), "gpf_ptdf_batch_info")
