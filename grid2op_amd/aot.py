@@ -74,8 +74,34 @@ def add_to_manifest(out_dir, label, hdr, variants):
     return hid
 
 
+def refresh(out_dir, grid_dir, n_busbar: int = 2):
+    """Regenerate every header of the manifest from ``<grid_dir>/<label>.grid.npz`` (after a change of the kernel sources' parameter structs
+    or of the symbolic programs), keeping each entry's kernel variants; headers are named by their hash, so the manifest keys change."""
+    mp = os.path.join(out_dir, "manifest.json")
+    man = json.load(open(mp))
+    new = {}
+    for ent in man.values():
+        label = ent["grids"][0]
+        hdr, _ = header_and_variants(_model(os.path.join(grid_dir, f"{label}.grid.npz")), [1], n_busbar)
+        hid = hashlib.sha1(hdr.encode()).hexdigest()[:12]
+        old = os.path.join(out_dir, ent["header"])
+        if os.path.exists(old):
+            os.remove(old)
+        with open(os.path.join(out_dir, f"{hid}.h"), "w") as f:
+            f.write(hdr)
+        new[hid] = {"header": f"{hid}.h", "grids": ent["grids"], "variants": ent["variants"]}
+        print(f"{label}: {ent['header']} -> {hid}.h")
+    with open(mp, "w") as f:
+        json.dump(new, f, indent=1, sort_keys=True)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    if argv is None:
+        argv = sys.argv[1:]
+    if argv and argv[0] == "--refresh":                    # python -m grid2op_amd.aot --refresh <grid dir> [out dir]
+        refresh(argv[2] if len(argv) > 2 else os.path.join(HERE, "aot"), argv[1])
+        return 0
     ap.add_argument("grid", help="grid.json of a grid2op environment (pandapower JSON) or a GridModel .npz")
     ap.add_argument("--lanes", type=int, action="append", help="batch size(s) the engine will be created with (default: 1 and 4096)")
     ap.add_argument("--n-busbar", type=int, default=2)

@@ -11,6 +11,7 @@
 // array.  Assembly uses native LDS f64 atomics from branch / element lanes; the pipeline (K9, K1..K7) and its reference
 // counterparts are listed in gridpf_common.hpp.
 #pragma once
+#include <type_traits>
 #include "gridpf_common.hpp"
 
 namespace gpf {
@@ -683,7 +684,13 @@ __device__ inline bool block_lu_flat(const FlatDev& F, PP prog, double* __restri
   const long long t_lu0 = __builtin_readcyclecounter();
 #endif
   bool ok = true;
-  constexpr bool PF2 = GPF_PF2_ON && GW > WAVE;      // item words fetched TWO passes ahead (see GPF_LSYNC)
+  // item words fetched TWO passes ahead: several wavefronts per instance (see GPF_LSYNC), and -- GPF_PF2_IG -- the instance-group kernels, whose
+  // passes (~500 cycles) are no longer than an L2 round trip under load
+#ifdef GPF_PF2_IG
+  constexpr bool PF2 = GPF_PF2_ON && (GW > WAVE || (GW <= 32 && !std::is_same<PP, const int*>::value));
+#else
+  constexpr bool PF2 = GPF_PF2_ON && GW > WAVE;
+#endif
   char* const a0 = reinterpret_cast<char*>(A);
   char* const a1 = a0 + HS * 8;
 #define FL_LD2(base, f) (*reinterpret_cast<const double2*>((base) + (f)))
@@ -798,7 +805,11 @@ __device__ inline bool scalar_lu_flat(const FlatDev& F, PP prog, double* __restr
   const long long t_lu0 = __builtin_readcyclecounter();
 #endif
   bool ok = true;
+#ifdef GPF_PF2_IG
+  constexpr bool PF2 = GPF_PF2_ON && (GW > WAVE || (GW <= 32 && !std::is_same<PP, const int*>::value));
+#else
   constexpr bool PF2 = GPF_PF2_ON && GW > WAVE;
+#endif
   char* const a0 = reinterpret_cast<char*>(A);
   char* const fb = reinterpret_cast<char*>(fac);
   auto facp = [&](unsigned f) -> double* { return reinterpret_cast<double*>(fb + (COMPACT ? (f >> 1) : f)); };
@@ -851,6 +862,11 @@ struct SolveCtl {
   int orow;           // lane's own row `orow` = lane of out / topo_out / shunt_bus_out / line_status (see write_nan_results)
   bool write_topo;    // write the topology-only outputs (topo_vect, line status, shunt buses) even when `reuse` says they stand:
                       // every row of the observation trajectory is complete
+  // (several wavefronts per instance, tables in global memory, step kernel) the chronics-driven injections of this step were NOT written to the
+  // lane's injection row: K9's owner lanes -- wavefront 0, load tid / tid + 64, generator tid -- hand them over in registers (a step of a
+  // multi-step launch whose topology stands; the row gets the last step's values).  2.8 KB less HBM traffic per lane and step on 118 substations.
+  bool inj_regs;
+  float r_lp0, r_lq0, r_lp1, r_lq1, r_pp, r_vm;
 };
 // per-group results of the topology phases, kept by the caller across solves
 struct TopoState {
@@ -1076,13 +1092,19 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       const int vi = c.vidx[i];
       // initial |V|: set-point of the last in-service generator on PV / reference buses, 1 pu elsewhere
       const double vm_pq = warm ? c.vm[i] : 1.0;
-      c.vm[i] = (vi >= 0 && (bt == BT_PV || bt == BT_REF)) ? GPF_INJ(oo.inj_gen_vm + vi) : vm_pq;
+      const bool has_sp = vi >= 0 && (bt == BT_PV || bt == BT_REF);
+      if (!(WPI > 1 && ctl.inj_regs)) c.vm[i] = has_sp ? GPF_INJ(oo.inj_gen_vm + vi) : vm_pq;
+      else if (!has_sp) c.vm[i] = vm_pq;                    // (the set-point buses are written by their generator's lane, below)
       if (!reuse) c.lab[i] = (bt == BT_REF) ? 1 : 0;
     }
     if (!reuse) {
       nb += G::count(bt != BT_OFF);
       nref += G::count(bt == BT_REF);
     }
+  }
+  if (WPI > 1 && ctl.inj_regs && tid < g.n_gen) {           // voltage set-point of generator tid from K9's register (SolveCtl::inj_regs)
+    const int bu = c.gen_b[tid];
+    if (bu >= 0 && c.vidx[bu] == tid) { const int bt = c.btype[bu]; if (bt == BT_PV || bt == BT_REF) c.vm[bu] = (double)ctl.r_vm; }
   }
   if (reuse) nb = ts.nb;
   nb_out = nb;
@@ -1896,11 +1918,18 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
     put(oo.p_ex + l, p_ex); put(oo.q_ex + l, q_ex); put(oo.v_ex + l, v_ex); put(oo.a_ex + l, a_ex); put(oo.th_ex + l, th_ex);
   }
   GPF_STAMPS(22);
+  const bool inj_regs = WPI > 1 && ctl.inj_regs;
+  if (inj_regs && tid < WAVE) {                              // load p / q from the registers of K9's owner lanes (wavefront 0: loads tid, tid + 64)
+    if (tid < g.n_load) { const bool on = c.load_b[tid] >= 0; put(oo.load_p + tid, on ? ctl.r_lp0 : 0.f); put(oo.load_q + tid, (on && !is_dc) ? ctl.r_lq0 : 0.f); }
+    if (tid + WAVE < g.n_load) { const bool on = c.load_b[tid + WAVE] >= 0; put(oo.load_p + tid + WAVE, on ? ctl.r_lp1 : 0.f); put(oo.load_q + tid + WAVE, (on && !is_dc) ? ctl.r_lq1 : 0.f); }
+  }
   for (int i = tid; i < g.n_load; i += GW) {
     const int bu = c.load_b[i];
     const bool on = bu >= 0;
-    put(oo.load_p + i, on ? (float)GPF_INJ(oo.inj_load_p + i) : 0.f);
-    put(oo.load_q + i, (on && !is_dc) ? (float)GPF_INJ(oo.inj_load_q + i) : 0.f);
+    if (!inj_regs) {
+      put(oo.load_p + i, on ? (float)GPF_INJ(oo.inj_load_p + i) : 0.f);
+      put(oo.load_q + i, (on && !is_dc) ? (float)GPF_INJ(oo.inj_load_q + i) : 0.f);
+    }
     put(oo.load_v + i, on ? (float)(c.vm[bu] * sv.load_vn[i]) : 0.f);
     put(oo.load_th + i, on ? (float)(c.va[bu] * RAD2DEG) : 0.f);
   }
@@ -1964,7 +1993,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
         else if (cn == 1) q = qtot;
         else if (qmn == qmx) q = qtot * fast_rcp((double)cn);
         else q = mn + (qtot - qmn) * fast_rcp(qmx - qmn + 2.220446049250313e-16) * (mx - mn);
-        double p = GPF_INJ(oo.inj_gen_p + i);
+        double p = (inj_regs && i == tid) ? (double)ctl.r_pp : GPF_INJ(oo.inj_gen_p + i);       // (n_gen <= 64: generator i is lane i's in K9 too)
         if (sv.gen_slack[i]) p = (*SreP(bu) - c.Psp[bu]) * sn * fast_rcp((double)ns);
         gp = (float)p; gq = (float)q;
         gv = (float)(c.vm[bu] * sv.gen_vn[i]);
@@ -2107,7 +2136,7 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void runpf_sparse_kerne
   GPF_STAMPS_DECL;
   SolveCtl ctl;
   ctl.inj_staged = false; ctl.topo_staged = false; ctl.reuse = false; ctl.dcf = false; ctl.write_bus = true; ctl.warm = false; ctl.sums_done = false;
-  ctl.otraj = false; ctl.orow = inst; ctl.write_topo = true;
+  ctl.otraj = false; ctl.orow = inst; ctl.write_topo = true; ctl.inj_regs = false;
   TopoState ts;
   ts.status = 0; ts.nb = 0; ts.dc_base = false; ts.dc_out = -1; ts.gen_base = false; ts.tc[0] = ts.tc[1] = -1;
   const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, is_dc, max_iter, tol_pu, tid, ctl, ts, n_iter, nb, a_first GPF_STAMPS_ARG);
@@ -2407,9 +2436,13 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
   int n_iter = 0, nb = 0, st = 0, rounds = 0;
   // state of the lane's OWN line (line `tid`: the line loops all map line l to lane l % GW) kept in registers for the launch:
   // thermal limit, protection counter (written back by every step) and the "already counted in this call" flag of K7
-  float lim_first = 1e30f;
-  int ovc_first = 0, inc_first = 0;
+  float lim_first = 1e30f, lim_second = 1e30f;
+  int ovc_first = 0, inc_first = 0, ovc_second = 0;
   if (tid < g.n_line) { lim_first = gptr(b.thermal_limit)[tid]; ovc_first = gptr(b.overflow_count)[(size_t)inst * g.n_line + tid]; }
+  // (at most two lines per lane: the protection counters of both stay in registers for the whole launch and go to HBM with the last step --
+  //  every step used to rewrite the lane's counter row, and its rho row although the trajectory carries rho: 1.5 KB per lane and step on 118 substations)
+  const bool regs2 = g.n_line <= 2 * GW;
+  if (regs2 && tid + GW < g.n_line) { lim_second = gptr(b.thermal_limit)[tid + GW]; ovc_second = gptr(b.overflow_count)[(size_t)inst * g.n_line + tid + GW]; }
   int ep_steps = 0, ep_resets = 0;
   if (tid == 0 && !ghost) { ep_steps = gptr(b.episode)[2 * (size_t)inst]; ep_resets = gptr(b.episode)[2 * (size_t)inst + 1]; }
   // environment injection dynamics (opt-in): lane k of the instance's first LWE lanes carries generator k and storage unit k
@@ -2467,7 +2500,8 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
     int orow = otraj ? step * (int)b.lane_stride + inst : inst;
     GPF_STAMPS(19);
     // ---- K9: chronics row -> injections -----------------------------------------------------------------------------------
-    bool sums_in_k9 = false;
+    bool sums_in_k9 = false, skip_inj = false;
+    float k9_lp0 = 0.f, k9_lq0 = 0.f, k9_lp1 = 0.f, k9_lq1 = 0.f, k9_pp = 0.f, k9_vm = 1.f;
     {
       const auto ch = gptr(b.chron) + ((size_t)tab * sa.T + row) * g.n_chron;
       const auto sc = gptr(b.lane_scale) + (size_t)inst * 2 * g.n_load;
@@ -2520,6 +2554,10 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
       // The element -> bus maps stand (reuse): every element adds its new set-point to the bus sums Psp / Qsp / Gs right here
       // (the same LDS atomics K1 would issue from four more loops over the injection row, SolveCtl::sums_done)
       sums_in_k9 = reuse;
+      // the chronics-driven injections stay in the owner lanes' registers instead of going to the lane's injection row and coming back (SolveCtl::inj_regs):
+      // a step whose topology stands (nobody reads the row: K9 has the bus sums), not the last of the launch (the row holds the last step's values
+      // for the API), no cascade (a re-solve after a trip rebuilds the sums FROM the row), no injection dynamics
+      skip_inj = WPI > 1 && !STAGE && sums_in_k9 && !last && !env_on && sa.cascade == 0 && g.n_load <= 2 * WAVE && g.n_gen <= WAVE;
       const double inv_sn9 = g.inv_sn_mva;
       if (sums_in_k9) {
         const int nbus9 = TC ? S.n : g.n_sub * NB;
@@ -2536,7 +2574,8 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
         float lp = i0_ ? lp_pre : i1_ ? lp2 : ch[i], lq = i0_ ? lq_pre : i1_ ? lq2 : ch[g.n_load + i];
         if (has_sc) { lp *= (i == tid) ? sc_p0 : i1_ ? sc2p : sc[i]; lq *= (i == tid) ? sc_q0 : i1_ ? sc2q : sc[g.n_load + i]; }
         if (STAGE) { c.inj[oo.inj_load_p + i] = (double)lp; c.inj[oo.inj_load_q + i] = (double)lq; }   // HBM copy: end of kernel
-        else { inj_g[oo.inj_load_p + i] = (double)lp; inj_g[oo.inj_load_q + i] = (double)lq; }
+        else if (!skip_inj) { inj_g[oo.inj_load_p + i] = (double)lp; inj_g[oo.inj_load_q + i] = (double)lq; }
+        if (i == tid) { k9_lp0 = lp; k9_lq0 = lq; } else if (i1_) { k9_lp1 = lp; k9_lq1 = lq; }
         sum_load += (double)lp;
         if (sums_in_k9) {
           const int bu = c.load_b[i];
@@ -2578,7 +2617,8 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
         const float vn = (float)sv.gen_vn[i];
         const double vm_pu = (double)(pv_kv / vn);
         if (STAGE) { c.inj[oo.inj_gen_p + i] = (double)pp; c.inj[oo.inj_gen_vm + i] = vm_pu; }
-        else { inj_g[oo.inj_gen_p + i] = (double)pp; inj_g[oo.inj_gen_vm + i] = vm_pu; }
+        else if (!skip_inj) { inj_g[oo.inj_gen_p + i] = (double)pp; inj_g[oo.inj_gen_vm + i] = vm_pu; }
+        if (i == tid) { k9_pp = pp; k9_vm = pv_kv / vn; }
         if (sums_in_k9) {
           const int bu = c.gen_b[i];
           if (bu >= 0 && !sv.gen_slack[i]) atomicAdd(&c.Psp[bu], (double)pp * inv_sn9);
@@ -2603,7 +2643,7 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
           }
         }
       }
-      GPF_SYNC_IF(!STAGE);                         // tier 0: the injection row went to global memory and is read back from there
+      GPF_SYNC_IF(!STAGE && !skip_inj);            // tier 0: the injection row went to global memory and is read back from there
       GPF_STAMPS(30);
     }
     // ---- power flow + K7 (Backend.next_grid_state) --------------------------------------------------------------------------
@@ -2630,6 +2670,7 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
       ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && sa.n_steps > 1; ctl.write_bus = last; ctl.warm = sa.warm_start != 0; ctl.sums_done = first && sums_in_k9;
       orow = otraj ? step * (int)b.lane_stride + inst : inst;          // (re-derived: see GPF_REDERIVE)
       ctl.otraj = otraj; ctl.orow = orow; ctl.write_topo = otraj;
+      ctl.inj_regs = skip_inj; ctl.r_lp0 = k9_lp0; ctl.r_lq0 = k9_lq0; ctl.r_lp1 = k9_lp1; ctl.r_lq1 = k9_lq1; ctl.r_pp = k9_pp; ctl.r_vm = k9_vm;
       GPF_STAMPS(31);
       const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, sa.is_dc, max_iter, tol_pu, tid, ctl, ts, it_k, nb_k, a_first GPF_STAMPS_ARG);
       first = false;
@@ -2645,14 +2686,14 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
         const auto topo = gptr(b.topo) + (size_t)inst * g.dim_topo;
         const auto thermal_limit = gptr(b.thermal_limit);
         for (int l = tid; l < g.n_line; l += GW) {
-          const bool own = l == tid;
+          const bool own = l == tid, own2 = regs2 && l == tid + GW;
           const float a = own ? a_first : (c.out_l ? c.out_l[oo.a_or + l] : (float)out[oo.a_or + l]);     // (staged row: the lane's value is in LDS)
-          const float lim = own ? lim_first : (float)thermal_limit[l];
+          const float lim = own ? lim_first : own2 ? lim_second : (float)thermal_limit[l];
           const bool on = c.lor_b[l] >= 0;
           bool disc = on && (a > sa.hard_overflow * lim);
           int inc = own ? inc_first : (int)inc_flag[l];
           if (on && (a > sa.soft_overflow * lim) && !inc) { inc = 1; if (own) inc_first = 1; else inc_flag[l] = 1; }
-          if (on && ((own ? ovc_first : (int)ovc[l]) + inc) > sa.nb_ts_allowed) disc = true;
+          if (on && ((own ? ovc_first : own2 ? ovc_second : (int)ovc[l]) + inc) > sa.nb_ts_allowed) disc = true;
           if (disc) {
             topo[sv.line_or_pos[l]] = -1;
             topo[sv.line_ex_pos[l]] = -1;
@@ -2686,17 +2727,17 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
       GPF_GLOBAL float* traj = nullptr;
       if (b.traj_rho && step < b.traj_cap) traj = gptr(b.traj_rho) + ((size_t)step * b.lane_stride + inst) * g.n_line;
       for (int l = tid; l < g.n_line; l += GW) {
-        const bool own = l == tid;
-        const float lim = own ? lim_first : (float)thermal_limit[l];
+        const bool own = l == tid, own2 = regs2 && l == tid + GW;
+        const float lim = own ? lim_first : own2 ? lim_second : (float)thermal_limit[l];
         const float a = own ? a_first : ((st == 0 && c.out_l) ? c.out_l[oo.a_or + l] : (float)out[oo.a_or + l]);   // (this lane wrote out[a_or + l] itself -- to the staged row in LDS or to HBM)
         const float r_ = a / lim;
-        rho[l] = r_;
+        if (!traj || last || sa.cascade) rho[l] = r_;        // (the lane's own row = the last step; with the cascade on it doubles as the rounds' flag row)
         if (traj) traj[l] = r_;
         if (!ghost) {
-          const int prev = own ? ovc_first : (int)ovc[l];
+          const int prev = own ? ovc_first : own2 ? ovc_second : (int)ovc[l];
           const int now = (a > sa.soft_overflow * lim) ? prev + 1 : 0;
-          if (own) ovc_first = now;
-          ovc[l] = now;
+          if (own) ovc_first = now; else if (own2) ovc_second = now;
+          if (!regs2 || last) ovc[l] = now;
         }
       }
       // line cooldowns (obs.time_before_cooldown_line): one step passed; a line the protections tripped in this step starts its
@@ -2737,7 +2778,7 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
       for (int i = tid; i < g.dim_topo; i += GW) topo[i] = t0[i];
       for (int l = tid; l < g.n_line; l += GW) ovc[l] = 0;
       if (sa.nb_ts_reco >= 0) { const auto cool = gptr(b.cooldown) + (size_t)inst * g.n_line; for (int l = tid; l < g.n_line; l += GW) cool[l] = 0; }   // env.reset(): baseEnv.py:3979
-      ovc_first = 0;
+      ovc_first = 0; ovc_second = 0;
       if (env_on) {                                              // env.reset(): dispatch cleared, storage back to its initial charge
         er.target = er.actual = er.prev_p = er.amount_prev = er.curt_prev = 0.f; er.limit = 1.f; er.already = false; er.fresh = true;
         er.illegal = 0;

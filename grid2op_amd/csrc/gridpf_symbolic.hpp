@@ -582,8 +582,9 @@ inline FlatProg build_flat(const Symbolic& S, int gw, int lane_opt) {
     }
     F.n_back += emit_items(items, true);
   }
-  // (two all-invalid passes behind the last one when several wavefronts share the instance: their sweeps fetch the words TWO passes ahead)
-  for (int k = 0; k < (gw > 64 ? 2 : 1) * gw; ++k) { W.push_back((int)INV); W.push_back((int)INV); }
+  // (two all-invalid passes behind the last one where the sweeps fetch the words TWO passes ahead: several wavefronts per instance, and the
+  //  instance-group kernels, which stream the program from global memory -- those programs are never staged in LDS, the padding costs nothing there)
+  for (int k = 0; k < ((gw > 64 || gw <= 32) ? 2 : 1) * gw; ++k) { W.push_back((int)INV); W.push_back((int)INV); }
   while (W.size() & 3) W.push_back((int)INV);
   return F;
 }
