@@ -65,12 +65,12 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 F64_PEAK_TFLOPS = 78.6         # MI355X FP64 vector == FP64 matrix peak (spec)
-TRAFFIC_PROFILE = os.path.join("profiles", "r05_traffic.json")
-TRAFFIC_N1 = os.path.join("profiles", "r05_traffic_n1_neurips36.json")
-TRAFFIC_N1_118 = os.path.join("profiles", "r05_traffic_n1_wcci118.json")
-TRAFFIC_WCCI = os.path.join("profiles", "r05_traffic_wcci118.json")
-TRAFFIC_IDF = os.path.join("profiles", "r05_traffic_idf118.json")
-TRAFFIC_1PL = os.path.join("profiles", "r05_traffic_case14_1perlaunch.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r06_traffic.json")
+TRAFFIC_N1 = os.path.join("profiles", "r06_traffic_n1_neurips36.json")
+TRAFFIC_N1_118 = os.path.join("profiles", "r06_traffic_n1_wcci118.json")
+TRAFFIC_WCCI = os.path.join("profiles", "r06_traffic_wcci118.json")
+TRAFFIC_IDF = os.path.join("profiles", "r06_traffic_idf118.json")
+TRAFFIC_1PL = os.path.join("profiles", "r06_traffic_case14_1perlaunch.json")
 TRAFFIC_PTDF = os.path.join("profiles", "r05_traffic_ptdf.json")
 CASCADE_LIMIT_SCALE = 0.85     # `cascade_tripping` secondary: thermal limits x 0.85 -> ~20 % of the lane-steps overflow softly
 
@@ -654,10 +654,10 @@ def compact_record(res, full_path=None):
     if cb:
         ac = cb.get("all_cores") or {}
         out["cpu_baseline"] = {"value": _r(cb.get("value"), 5), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
-                               "solver": "sparse LU", "sample": (cb.get("sample") or "")[:48],
+                               "solver": "sparse LU", "sample": (cb.get("sample") or "")[:40],
                                "all_cores": {"value": _r(ac.get("value"), 5), "cores": ac.get("cores")} if ac else None,
                                "dense_1core": _r((cb.get("dense_1core") or {}).get("value"), 4),
-                               "per_config": "configs[*].cpu = [1 core, all cores, n] lane PF/s, same sparse port",
+                               "per_config": "configs[*].cpu = [1 core, all cores, n] lane PF/s",
                                "pandapower": "unavailable (not installed)", "lightsim2grid": "unavailable (not installed)"}
     else:
         out["cpu_baseline"] = None
@@ -671,7 +671,7 @@ def compact_record(res, full_path=None):
         "idf_ac_118sub": _cfg_line(dc.get("ac_env_steps")),
         "ptdf_rows": _cfg_line(rows, extra=("rows_per_launch",)),
         "ptdf_1row": _cfg_line(dc) if dc else None,
-        "ptdf_build_batch": _cfg_line(res.get("ptdf_build_batch"), extra=("classes", "call_value", "call_value_unseen_topologies", "enqueue_ms_unseen_topologies", "host_builds_per_sec")),
+        "ptdf_build_batch": _cfg_line(res.get("ptdf_build_batch"), extra=("classes", "call_value", "call_value_unseen_topologies")),
     }
     act = (res.get("secondary_env_dynamics") or {}).get("acting_every_step")
     if act and configs["wcci_env_dynamics"]:                # agents acting at EVERY step: actions from the host / written on the device

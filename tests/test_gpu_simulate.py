@@ -167,12 +167,14 @@ def test_a_scratch_lane_cannot_be_the_source_of_another_simulation(load_model, l
     eng.close()
 
 
-def test_scratch_step_with_two_horizons_ignores_outage_tables_and_keeps_cooldowns(load_model, load_npz):
+def test_scratch_step_with_two_horizons_reads_no_outage_table_and_keeps_cooldowns(load_model, load_npz):
     """the scratch step of gpf_simulate_batch runs on a row of the FORECAST tables ([table][T][n_horizons][..]); the outage
-    tables and their remaining-duration table have [table][T] rows only, so that step must neither apply them nor maintain the line cooldowns --
-    whatever the caller's gpf_step_opts say (a C caller's track_cooldown = 1 here; a zero-initialised struct before ABI 323 meant "track").
-    Two forecast horizons + an uploaded maintenance table: the candidates' results equal those of an engine that never saw an outage table,
-    and every scratch lane keeps the cooldowns copied from its source."""
+    tables and their remaining-duration table have [table][T] rows only.  The planned maintenance of the simulated step reaches the candidates
+    through the call's own host-side rule (as obs.simulate applies it, _obsEnv.py:321-428); the KERNEL of the scratch step must neither index
+    the outage / duration tables with its forecast cursor nor maintain the line cooldowns -- whatever the caller's gpf_step_opts say (a C
+    caller's track_cooldown = 1 here; a zero-initialised struct before ABI 323 meant "track").  Two forecast horizons + an uploaded
+    maintenance table with line 5 out at every row: the candidates' results equal those of an engine WITHOUT outage tables whose candidates
+    open line 5 themselves, and every scratch lane keeps the cooldowns copied from its source."""
     import ctypes as C
     from grid2op_amd._capi import GpfStepOpts, check, ptr
     from grid2op_amd.engine import PowerFlowEngine
@@ -180,10 +182,12 @@ def test_scratch_step_with_two_horizons_ignores_outage_tables_and_keeps_cooldown
     m = load_model(name)
     ch = dict(load_npz(f"{name}.chronics.npz"))
     prod_v = np.tile((m.gen_vm0 * m.sub_vn_kv[m.gen_sub]).astype(np.float32), (ch["prod_p"].shape[0], 1))
-    B, cands = 3, [{}, {"set_line_status": [(1, -1)]}, {"lines_or_bus": [(2, 2)]}]
-    K = len(cands)
+    B, K = 3, 3
     outs = []
     for with_tables in (False, True):
+        cands = [{}, {"set_line_status": [(1, -1)]}, {"set_line_status": [(3, -1)]}]
+        if not with_tables:
+            cands = [dict(set_line_status=c.get("set_line_status", []) + [(5, -1)]) for c in cands]
         eng = PowerFlowEngine(m, n_lanes=B + B * K, device=0)
         tab = eng.pack_chronics(ch["load_p"], ch["load_q"], ch["prod_p"], ch.get("prod_v", prod_v))[:48]
         eng.upload_chronics(tab)
@@ -195,18 +199,17 @@ def test_scratch_step_with_two_horizons_ignores_outage_tables_and_keeps_cooldown
         cool[0, 3], cool[1, 7], cool[2, 0] = 4, 9, 2
         if with_tables:
             mt = np.zeros((48, m.n_line), np.uint8)
-            mt[:, 5] = 1                                       # line 5 "in maintenance" at every row: the scratch step must NOT take it out
-            mt[40:, 9] = 1
+            mt[:, 5] = 1                                       # line 5 in maintenance at every row
             eng.upload_maintenance(mt)
             eng.set_cooldown(cool, lane0=0)
         src = np.arange(B, dtype=np.int32)
         a_off, items = eng.pack_actions(cands)
         o = GpfStepOpts(10, 1e-8, 0.0, 0, 2.0, 1.0, 2, 16, 0, 0, 0, 1, 10)       # track_cooldown = 1, nb_ts_reco = 10: must be ignored here
         for ts in (1, 2):
-            check(eng._lib.gpf_simulate_batch(eng._h, 2, ts, B, ptr(src, C.c_int32), K, ptr(a_off, C.c_int32), ptr(items, C.c_int32), None, B, C.byref(o)),
-                  "gpf_simulate_batch")
+            check(eng._lib.gpf_simulate_batch(eng._h, 2, ts, B, ptr(src, C.c_int32), K, ptr(a_off, C.c_int32), ptr(items if items.size else None, C.c_int32),
+                                              None, B, C.byref(o)), "gpf_simulate_batch")
             r = eng.results(B, B * K)
-            assert r.converged.all() and r.line_status[:, 5].all(), ts          # (candidate 1 opens line 1, nobody opens line 5)
+            assert r.converged.all() and not r.line_status[:, 5].any(), ts
             outs.append((with_tables, ts, r.out.copy(), r.topo_vect.copy()))
             if with_tables:
                 got = eng.cooldown(B, B * K).reshape(B, K, m.n_line)
