@@ -1478,8 +1478,8 @@ def workload_ptdf_build_batch(ctx, env, B, n_topo, reps=5):
            "classes": int(info["n_classes"]), "classes_ok": int(ok_cls.sum()), "classes_islanded": int((info["class_status"] == 2).sum()),
            "reduced_dimension": {"min": int(info["class_n"].min()), "max": int(info["class_n"].max())},
            "value": float(ok_cls.sum()) / (k_med * 1e-3), "unit": "topologies factorised/sec (build kernel)", "kernel_ms": k_med, "kernel_ms_all": [round(x, 4) for x in k_ms],
-           "call_ms": w_med, "call_value": float(ok_cls.sum()) / (w_med * 1e-3), "call_is": "host grouping of the lanes' topology rows + descriptor upload + kernel + status readback "
-           "(topologies seen by an earlier call: their descriptors come from the engine's cache)",
+           "call_ms": w_med, "call_value": float(ok_cls.sum()) / (w_med * 1e-3), "call_is": "the whole call a user makes: grouping of the lanes' topology rows + class descriptors ON THE DEVICE "
+           "(gridpf_ptdf_group.hpp: hash, one-workgroup sort, verification, one workgroup per class; six integers read back) + factorisation kernel + class status / lane -> class map back",
            "call_ms_unseen_topologies": float(np.median(w_new)), "call_value_unseen_topologies": float(ok_cls.sum()) / (float(np.median(w_new)) * 1e-3),
            "enqueue_ms": float(np.median(q_ms)), "enqueue_ms_unseen_topologies": float(np.median(q_new)),
            "enqueue_is": "the same call with info=False: it returns once the kernel is queued (host grouping + descriptors + upload); consumers queue behind it on the stream",

@@ -22,6 +22,7 @@
 #include "gridpf_host.hpp"
 #include "gridpf_ptdf.hpp"
 #include "gridpf_ptdf_batch.hpp"
+#include "gridpf_ptdf_group.hpp"
 #include "gridpf_redispatch.hpp"
 #include <string>
 #include <thread>
@@ -315,6 +316,13 @@ struct gpf_engine {
   hipEvent_t ptdfb_ev_a = nullptr, ptdfb_ev_b = nullptr;
   int* ptdfb_status_pin = nullptr; size_t ptdfb_status_pin_n = 0;
   bool ptdfb_pending = false;
+  // device-side grouping + descriptors (gridpf_ptdf_group.hpp): their outputs, and the host mirrors fetched on demand
+  DevArr<unsigned long long> ptdfg_hash;
+  DevArr<int> ptdfg_lane_class, ptdfg_first, ptdfg_c2b, ptdfg_info;
+  int* ptdfg_info_pin = nullptr;
+  bool ptdfb_host_stale = false;           // h_ptdfb_lane_class / h_ptdfb_hdr are not what the device holds: ptdfb_fetch_host
+  bool ptdfb_bus_stale = false;            // ... nor h_ptdfb_bus (only gpf_ptdf_batch_get reads it)
+  std::vector<int> h_ptdfb_hdr;            // device path: the 4-int headers of the class descriptors (nr, n_act, n_pad, status); empty: h_ptdfb_desc has them
   DevArr<double> dc_inv_g;     // static DC inverse of the larger grids (gpf::SymDev::dc_inv_g)
   DevArr<double> stat_dbl;     // static blob of kernel S (gpf::StatOff)
   DevArr<int> stat_int;
@@ -1284,6 +1292,8 @@ int gpf_destroy(gpf_handle e) {
   if (e->act_up) (void)hipEventDestroy(e->act_up);
   if (e->ptdfb_ev_a) { (void)hipEventDestroy(e->ptdfb_ev_a); (void)hipEventDestroy(e->ptdfb_ev_b); }
   if (e->ptdfb_status_pin) (void)hipHostFree(e->ptdfb_status_pin);
+  if (e->ptdfg_info_pin) (void)hipHostFree(e->ptdfg_info_pin);
+  e->ptdfg_hash.release(); e->ptdfg_lane_class.release(); e->ptdfg_first.release(); e->ptdfg_c2b.release(); e->ptdfg_info.release();
   e->maint.release(); e->forecast.release(); e->sim_src.release(); e->sim_rows.release();
   e->env_target.release(); e->env_actual.release(); e->env_prev.release(); e->env_charge.release(); e->env_amount_prev.release();
   e->env_act_redisp.release(); e->env_act_storage.release(); e->sto_charge0.release(); e->env_already.release(); e->env_fresh.release();
@@ -2719,6 +2729,78 @@ static int ptdfb_finish(gpf_engine* e) {
   return GPF_OK;
 }
 
+// lane -> class map and descriptor headers of a build whose integer half ran on the device: to the host mirrors, on demand (12 KB for 2 048
+// lanes / 256 classes; the descriptors themselves stay on the device); with_bus: the compact -> bus maps too (gpf_ptdf_batch_get)
+static int ptdfb_fetch_host(gpf_engine* e, bool with_bus = false) {
+  if (!e->ptdfb_host_stale && !(with_bus && e->ptdfb_bus_stale)) return GPF_OK;
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const int n = e->ptdfb_n, nc = e->ptdfb_classes, stride = e->ptdfb_desc_stride, nbt = e->g.nb_tot;
+  if (e->ptdfb_host_stale) {
+    e->h_ptdfb_lane_class.resize(n);
+    HIP_TRY(hipMemcpy(e->h_ptdfb_lane_class.data(), e->ptdfg_lane_class.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    e->h_ptdfb_hdr.resize((size_t)nc * 4);
+    HIP_TRY(hipMemcpy2D(e->h_ptdfb_hdr.data(), 4 * sizeof(int), e->ptdfb_desc.p, (size_t)stride * sizeof(int), 4 * sizeof(int), (size_t)nc, hipMemcpyDeviceToHost));
+    e->ptdfb_host_stale = false;
+  }
+  if (with_bus && e->ptdfb_bus_stale) {
+    std::vector<int> c2b((size_t)nc * nbt);
+    HIP_TRY(hipMemcpy(c2b.data(), e->ptdfg_c2b.p, c2b.size() * sizeof(int), hipMemcpyDeviceToHost));
+    e->h_ptdfb_bus.assign(nc, std::vector<int>());
+    for (int c = 0; c < nc; ++c) {
+      const int n_act = e->h_ptdfb_hdr[(size_t)c * 4 + 1];
+      e->h_ptdfb_bus[c].assign(c2b.begin() + (size_t)c * nbt, c2b.begin() + (size_t)c * nbt + n_act);
+    }
+    e->ptdfb_bus_stale = false;
+  }
+  return GPF_OK;
+}
+
+// The integer half of gpf_ptdf_build_batch on the device.  out[0..3] = classes, slots, largest n_pad, largest n_act.  Returns GPF_OK with
+// *done = false when the device path does not apply or flagged something (hash collision inside a class, bus id out of range, capacity):
+// the caller then takes the host path, which reports the error properly.
+static int ptdfb_group_on_device(gpf_engine* e, int lane0, int n, int stride, int out[4], bool* done) {
+  *done = false;
+  const gpf::GridDev& g = e->g;
+  if (n > gpf::PTDFG_MAX_LANES || g.nb_tot > gpf::PTDFG_MAX_BUS || g.n_line > 256 || getenv("GRIDPF_PTDFB_HOST")) return GPF_OK;
+  HIP_TRY(e->ptdfg_hash.ensure((size_t)n)); HIP_TRY(e->ptdfg_lane_class.ensure((size_t)n)); HIP_TRY(e->ptdfg_first.ensure((size_t)n));
+  HIP_TRY(e->ptdfb_order.ensure((size_t)16 * n)); HIP_TRY(e->ptdfb_blk_class.ensure((size_t)n));
+  HIP_TRY(e->ptdfb_desc.ensure((size_t)n * stride)); HIP_TRY(e->ptdfg_c2b.ensure((size_t)n * g.nb_tot)); HIP_TRY(e->ptdfg_info.ensure(8));
+  if (!e->ptdfg_info_pin) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->ptdfg_info_pin), 8 * sizeof(int), hipHostMallocDefault));
+  gpf::PtdfGroupDev D{};
+  D.topo = e->topo.p; D.shunt_bus = e->shunt_bus.p;
+  D.lane0 = lane0; D.n = n; D.dim_topo = g.dim_topo; D.n_shunt = g.n_shunt; D.n_sub = g.n_sub; D.n_busbar = g.n_busbar; D.n_line = g.n_line;
+  D.n_gen = g.n_gen; D.n_load = g.n_load; D.n_sto = g.n_sto; D.n_inj = g.n_inj;
+  D.inj_gen_p = e->oo.inj_gen_p; D.inj_load_p = e->oo.inj_load_p; D.inj_sto_p = e->oo.inj_sto_p; D.inj_sh_p = e->oo.inj_sh_p;
+  D.line_or_pos = e->line_or_pos.p; D.line_ex_pos = e->line_ex_pos.p; D.line_or_sub = e->line_or_sub.p; D.line_ex_sub = e->line_ex_sub.p;
+  D.gen_pos = e->gen_pos.p; D.gen_sub = e->gen_sub.p; D.load_pos = e->load_pos.p; D.load_sub = e->load_sub.p; D.sto_pos = e->sto_pos.p;
+  D.sto_sub = e->sto_sub.p; D.shunt_sub = e->shunt_sub.p; D.gen_slack = e->gen_slack.p;
+  D.desc_stride = stride;
+  D.hash = e->ptdfg_hash.p; D.lane_class = e->ptdfg_lane_class.p; D.first_lane = e->ptdfg_first.p; D.order = e->ptdfb_order.p;
+  D.blk_class = e->ptdfb_blk_class.p; D.desc = e->ptdfb_desc.p; D.c2b = e->ptdfg_c2b.p; D.info = e->ptdfg_info.p;
+  HIP_TRY(hipMemsetAsync(e->ptdfg_info.p, 0, 8 * sizeof(int), e->stream));
+  hipLaunchKernelGGL(gpf::ptdfg_hash_kernel, dim3(n), dim3(64), 0, e->stream, D);
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  const size_t lds_sort = (size_t)np2 * 20;
+  static size_t lds_sort_set[64] = {0};
+  if (lds_sort > lds_sort_set[e->device & 63]) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&gpf::ptdfg_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sort));
+    lds_sort_set[e->device & 63] = lds_sort;
+  }
+  hipLaunchKernelGGL(gpf::ptdfg_group_kernel, dim3(1), dim3(gpf::PTDFG_SORT_THREADS), lds_sort, e->stream, D);
+  hipLaunchKernelGGL(gpf::ptdfg_verify_kernel, dim3(n), dim3(64), 0, e->stream, D);
+  hipLaunchKernelGGL(gpf::ptdfg_desc_kernel, dim3(n), dim3(gpf::PTDFG_DESC_THREADS), 0, e->stream, D);     // (blocks beyond the class count return at once)
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(e->ptdfg_info_pin, e->ptdfg_info.p, 8 * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  const int* info = e->ptdfg_info_pin;
+  if (info[4] || info[5] || info[0] <= 0) return GPF_OK;           // -> host path
+  out[0] = info[0]; out[1] = info[1]; out[2] = std::max(16, info[2]); out[3] = std::max(1, info[3]);
+  *done = true;
+  return GPF_OK;
+}
+
 /* ---- PTDF / LODF of every distinct topology of a lane range, built on the device (gridpf_ptdf_batch.hpp) --------------------------- */
 int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lodf, int32_t* n_classes_out) {
   if (!check_range(e, lane0, n) || n <= 0) return fail(GPF_E_INVALID, "gpf_ptdf_build_batch: bad lane range");
@@ -2733,6 +2815,15 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
   static const bool stage_timing = getenv("GRIDPF_SIM_TIMING") != nullptr;      // developer: stage times of the call on stderr
   auto now_us = [] { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() * 1e-3; };
   double tm[6] = {0, 0, 0, 0, 0, 0};
+  // ---- the integer half: on the device (gridpf_ptdf_group.hpp) when the range allows it, else -- and whenever the device flagged something -- on the host
+  const int stride = (gpf::PTDFB_HDR + 3 * nl + g.n_inj + gpf::PTDFB_MAX_N + 1 + 2 * nl + 3) & ~3;
+  int nc = 0, npad_max = 16, nact_max = 1;
+  size_t n_slots = 0;
+  std::vector<int> desc, order, blk_class;
+  int grp[4] = {0, 0, 0, 0};
+  bool dev = false;
+  { const int rc_g = ptdfb_group_on_device(e, lane0, n, stride, grp, &dev); if (rc_g != GPF_OK) return rc_g; }
+  auto host_group = [&]() -> int {
   // the lanes' topology rows as they are on the device (a cascade inside gpf_step_n may have tripped lines the host never saw)
   // (when no kernel can have rewritten them -- no cascade, no outage tables since the engine was created -- and the host sent every row of the
   //  range itself, the host mirrors ARE the device rows: no trip over PCIe, no synchronisation; 2 048 rows of 560 ints are 4.6 MB)
@@ -2815,14 +2906,12 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
     if (c < 0) { c = (int)first_lane.size(); first_lane.push_back(k); first_hash.push_back(h); cand.push_back(c); }
     e->h_ptdfb_lane_class[k] = c;
   }
-  const int nc = (int)first_lane.size();
+  nc = (int)first_lane.size();
   if (stage_timing) tm[2] = now_us();
   // descriptor: header | lf | lt | inj_bus | lflag | row pointers of B' [PTDFB_MAX_N + 1] | row entries [2 n_line] (gridpf_ptdf_batch.hpp)
   if (nl > 65535) return fail(GPF_E_CAPACITY, "gpf_ptdf_build_batch: more than 65535 lines");
-  const int stride = (gpf::PTDFB_HDR + 3 * nl + g.n_inj + gpf::PTDFB_MAX_N + 1 + 2 * nl + 3) & ~3;
-  std::vector<int> desc((size_t)nc * stride, -1);
+  desc.assign((size_t)nc * stride, -1);
   e->h_ptdfb_bus.assign(nc, std::vector<int>());
-  int npad_max = 16, nact_max = 1;
   auto bus_of = [&](int sub, int local) -> int { return (local >= 1 && local <= g.n_busbar) ? sub + (local - 1) * g.n_sub : -1; };
   // One descriptor per class: ~3 us of table walks each (800 us for 256 classes of a 118-substation grid on one core)
   struct ClsScratch { std::vector<char> act, ref, has_ref; std::vector<int> bf, bt, n_lines_at, n_other_at, ibus, compact, comp, cnt; int npad_max = 16, nact_max = 1; };
@@ -2967,19 +3056,25 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
   // ---- slots: lanes grouped by class, every group padded to a multiple of 16 ------------------------------------------------------------
   std::vector<std::vector<int>> members(nc);
   for (int k = 0; k < n; ++k) members[e->h_ptdfb_lane_class[k]].push_back(lane0 + k);
-  std::vector<int> order, blk_class;
   for (int c = 0; c < nc; ++c) {
     for (int ln : members[c]) order.push_back(ln);
     while (order.size() & 15) order.push_back(-1);
     while (blk_class.size() * 16 < order.size()) blk_class.push_back(c);
   }
+  n_slots = order.size();
+  return GPF_OK;
+  };
+  if (dev) { nc = grp[0]; n_slots = (size_t)grp[1]; npad_max = grp[2]; nact_max = grp[3]; }
+  else { const int rc_h = host_group(); if (rc_h != GPF_OK) return rc_h; }
   const int line_pad = (nl + 15) & ~15;
   const int nb_pad = std::max(4, (nact_max + 3) & ~3), kpad = (nb_pad + 31) & ~31;
   e->ptdf_ready = false;
   // (grow-only buffers: a rebuild after a few topology changes allocates nothing; uploads ride the engine's stream in front of the kernel)
-  HIP_TRY(e->ptdfb_desc.put(desc.data(), desc.size(), e->stream));
-  HIP_TRY(e->ptdfb_order.put(order.data(), order.size(), e->stream));
-  HIP_TRY(e->ptdfb_blk_class.put(blk_class.data(), blk_class.size(), e->stream));
+  if (!dev) {
+    HIP_TRY(e->ptdfb_desc.put(desc.data(), desc.size(), e->stream));
+    HIP_TRY(e->ptdfb_order.put(order.data(), order.size(), e->stream));
+    HIP_TRY(e->ptdfb_blk_class.put(blk_class.data(), blk_class.size(), e->stream));
+  }
   HIP_TRY(e->ptdfb_status.ensure(nc));
   HIP_TRY(e->ptdfb_work.ensure((size_t)nc * npad_max * npad_max));
   HIP_TRY(e->ptdfb_t.ensure((size_t)nc * kpad * line_pad));
@@ -3044,13 +3139,14 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
     while (c_ok < nc - 1 && e->h_ptdfb_status[c_ok] != 0) ++c_ok;
     const long long* s_ = h.data() + (size_t)c_ok * 8;
     fprintf(stderr, "[gridpf] ptdf_build_kernel class %d (n_pad %d), shader clocks: assemble %lld, gauss-jordan %lld (panel loads %lld, tile inversions %lld, trailing "
-                    "updates %lld), PTDF^T %lld, LODF %lld (row builds %lld); kernel %.1f us\n", c_ok, desc[(size_t)c_ok * stride + 2], s_[1] - s_[0], s_[3] - s_[1], s_[7], s_[2], s_[6],
+                    "updates %lld), PTDF^T %lld, LODF %lld (row builds %lld); kernel %.1f us\n", c_ok, dev ? 0 : desc[(size_t)c_ok * stride + 2], s_[1] - s_[0], s_[3] - s_[1], s_[7], s_[2], s_[6],
             s_[4] - s_[3], s_[5] ? s_[5] - s_[4] : 0LL, s_[7], ms * 1e3);
     dbg.release();
   }
   if (e->window) { ++e->win_launches; e->win_marked = false; }
-  e->h_ptdfb_desc = std::move(desc);
-  e->ptdfb_lane0 = lane0; e->ptdfb_n = n; e->ptdfb_classes = nc; e->ptdfb_slots = (int)order.size(); e->ptdfb_kpad = kpad;
+  if (!dev) { e->h_ptdfb_desc = std::move(desc); e->h_ptdfb_hdr.clear(); }
+  e->ptdfb_host_stale = dev; e->ptdfb_bus_stale = dev;                       // (device path: lane -> class map, descriptors, compact -> bus maps are fetched when somebody asks)
+  e->ptdfb_lane0 = lane0; e->ptdfb_n = n; e->ptdfb_classes = nc; e->ptdfb_slots = (int)n_slots; e->ptdfb_kpad = kpad;
   e->ptdfb_npad_max = npad_max; e->ptdfb_desc_stride = stride;
   e->ptdf_nb_pad = nb_pad; e->ptdf_line_pad = line_pad;
   e->ptdf_rows_valid = 0;
@@ -3064,9 +3160,10 @@ int gpf_ptdf_batch_info(gpf_handle e, int32_t* lane_class, int32_t* class_status
   if (!e) return fail(GPF_E_INVALID, "gpf_ptdf_batch_info: null");
   if (!e->ptdf_ready || !e->ptdf_batch) return fail(GPF_E_INVALID, "gpf_ptdf_batch_info: call gpf_ptdf_build_batch first");
   if (class_status || kernel_ms) { const int rc_f = ptdfb_finish(e); if (rc_f != GPF_OK) return rc_f; }
+  if (lane_class || class_n) { const int rc_m = ptdfb_fetch_host(e); if (rc_m != GPF_OK) return rc_m; }
   if (lane_class) std::copy(e->h_ptdfb_lane_class.begin(), e->h_ptdfb_lane_class.end(), lane_class);
   if (class_status) std::copy(e->h_ptdfb_status.begin(), e->h_ptdfb_status.end(), class_status);
-  if (class_n) for (int c = 0; c < e->ptdfb_classes; ++c) class_n[c] = e->h_ptdfb_desc[(size_t)c * e->ptdfb_desc_stride];
+  if (class_n) for (int c = 0; c < e->ptdfb_classes; ++c) class_n[c] = e->h_ptdfb_hdr.empty() ? e->h_ptdfb_desc[(size_t)c * e->ptdfb_desc_stride] : e->h_ptdfb_hdr[(size_t)c * 4];
   if (kernel_ms) *kernel_ms = e->ptdfb_kernel_ms;
   return GPF_OK;
 }
@@ -3075,6 +3172,7 @@ int gpf_ptdf_batch_get(gpf_handle e, int32_t cls, double* ptdf, double* lodf) {
   if (!e) return fail(GPF_E_INVALID, "gpf_ptdf_batch_get: null");
   if (!e->ptdf_ready || !e->ptdf_batch) return fail(GPF_E_INVALID, "gpf_ptdf_batch_get: call gpf_ptdf_build_batch first");
   if (cls < 0 || cls >= e->ptdfb_classes) return fail(GPF_E_INVALID, "gpf_ptdf_batch_get: bad class");
+  { const int rc_m = ptdfb_fetch_host(e, true); if (rc_m != GPF_OK) return rc_m; }
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   const int nl = e->g.n_line, lp = e->ptdf_line_pad, nbt = e->g.nb_tot, kpad = e->ptdfb_kpad;

@@ -82,14 +82,15 @@ __device__ inline void ptdfg_scan_excl(int* v, int* tmp, int n, int tid, int nt)
 }
 
 __global__ __launch_bounds__(PTDFG_SORT_THREADS) void ptdfg_group_kernel(PtdfGroupDev D) {
-  __shared__ unsigned long long s_key[PTDFG_MAX_LANES];
-  __shared__ int s_idx[PTDFG_MAX_LANES];
-  __shared__ int s_a[PTDFG_MAX_LANES];
-  __shared__ int s_b[PTDFG_MAX_LANES];
+  extern __shared__ __attribute__((aligned(16))) unsigned char ptdfg_smem[];        // 20 bytes per element of the padded range (host: lds_sort)
   __shared__ int s_nc;
   const int tid = threadIdx.x, nt = blockDim.x, n = D.n;
   int np2 = 1;
   while (np2 < n) np2 <<= 1;
+  unsigned long long* const s_key = reinterpret_cast<unsigned long long*>(ptdfg_smem);
+  int* const s_idx = reinterpret_cast<int*>(s_key + np2);
+  int* const s_a = s_idx + np2;
+  int* const s_b = s_a + np2;
   for (int i = tid; i < np2; i += nt) { s_key[i] = i < n ? D.hash[i] : ~0ull; s_idx[i] = i < n ? i : 0x7fffffff; }
   __syncthreads();
   // bitonic sort by (key, idx) ascending
@@ -128,8 +129,8 @@ __global__ __launch_bounds__(PTDFG_SORT_THREADS) void ptdfg_group_kernel(PtdfGro
   for (int i = tid; i < n; i += nt) if (i == 0 || s_key[i] != s_key[i - 1]) s_a[s_b[i]] = i;
   __syncthreads();
   // padded sizes -> slot offsets
-  int* s_pad = reinterpret_cast<int*>(s_key);            // (the keys are no longer needed: heads are in s_a / s_b)  [n] ints
-  int* s_tmp = s_pad + PTDFG_MAX_LANES;                  // second half of the key array
+  int* s_pad = reinterpret_cast<int*>(s_key);            // (the keys are no longer needed: heads are in s_a / s_b)  [np2] ints
+  int* s_tmp = s_pad + np2;                              // second half of the key array
   // keep head positions in registers-free form: copy to s_tmp2 = s_idx is still needed; use s_pad for padded sizes
   for (int c = tid; c < nc; c += nt) { const int sz = (c + 1 < nc ? s_a[c + 1] : n) - s_a[c]; s_pad[c] = (sz + 15) & ~15; }
   __syncthreads();

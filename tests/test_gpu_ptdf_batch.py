@@ -245,3 +245,41 @@ def test_rebuilds_reuse_cached_descriptors_and_follow_changed_topologies(load_mo
     same(runs["cached"][0], runs["cached"][2])                                       # back to the first assignment: the first tables
     assert runs["cached"][1][0]["n_classes"] != runs["cached"][0][0]["n_classes"] or not np.array_equal(runs["cached"][1][0]["lane_class"], runs["cached"][0][0]["lane_class"])
     eng.close()
+
+
+@pytest.mark.parametrize("name,B,n_topo", [("l2rpn_neurips_2020_track1", 96, 30), ("l2rpn_wcci_2022_dev", 300, 40), ("l2rpn_case14_sandbox", 17, 6)])
+def test_device_grouping_equals_the_host_path(name, B, n_topo, load_model, monkeypatch):
+    """Round 6: which lanes share a topology, and the descriptor of every distinct topology (live buses, compact numbering, connectivity
+    verdict, rows of B'), are computed ON THE DEVICE (gridpf_ptdf_group.hpp: hash, one-workgroup sort, verification, one workgroup per
+    class) instead of on the host from rows read back over PCIe.  Same partition of the lanes (class numbers are in hash order there, in
+    order of first appearance on the host), and per class the same status, dimension, PTDF and LODF bit for bit -- the factorisation
+    kernel gets identical descriptors; flows of every lane equal."""
+    m = load_model(name)
+    rng = np.random.default_rng(5)
+    topos = random_topologies(m, n_topo, rng)
+    lane_topo = np.concatenate([np.arange(n_topo), rng.integers(0, n_topo, B - n_topo)])
+    rng.shuffle(lane_topo)
+    eng = _engine(m, B)
+    eng.set_topology(np.stack([topos[i] for i in lane_topo]).astype(np.int32))
+    got = {}
+    for label in ("device", "host"):
+        if label == "host":
+            monkeypatch.setenv("GRIDPF_PTDFB_HOST", "1")
+        info = eng.ptdf_build_batch(with_lodf=True)
+        tabs = [eng.ptdf_class(c, lodf=True) if info["class_status"][c] == 0 else None for c in range(info["n_classes"])]
+        got[label] = (info, tabs, eng.ptdf_flows())
+    monkeypatch.delenv("GRIDPF_PTDFB_HOST")
+    (i_d, t_d, f_d), (i_h, t_h, f_h) = got["device"], got["host"]
+    assert i_d["n_classes"] == i_h["n_classes"] == len(set(lane_topo.tolist()))
+    # same partition: the map device class -> host class is a bijection consistent on every lane
+    d2h = {}
+    for cd, chh in zip(i_d["lane_class"].tolist(), i_h["lane_class"].tolist()):
+        assert d2h.setdefault(cd, chh) == chh
+    assert len(set(d2h.values())) == len(d2h) == i_d["n_classes"]
+    for cd, chh in d2h.items():
+        assert i_d["class_status"][cd] == i_h["class_status"][chh] and i_d["class_n"][cd] == i_h["class_n"][chh]
+        assert (t_d[cd] is None) == (t_h[chh] is None)
+        if t_d[cd] is not None:
+            assert np.array_equal(t_d[cd][0], t_h[chh][0]) and np.array_equal(t_d[cd][1], t_h[chh][1], equal_nan=True)
+    assert np.array_equal(f_d, f_h, equal_nan=True)
+    eng.close()
