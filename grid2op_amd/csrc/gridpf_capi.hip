@@ -320,6 +320,8 @@ struct gpf_engine {
   DevArr<unsigned long long> ptdfg_hash;
   DevArr<int> ptdfg_lane_class, ptdfg_first, ptdfg_c2b, ptdfg_info;
   int* ptdfg_info_pin = nullptr;
+  int* ptdfg_back_pin = nullptr; size_t ptdfg_back_pin_n = 0;     // lane -> class map + descriptor headers, queued behind the factorisation (pinned)
+  bool ptdfb_prefetched = false;
   bool ptdfb_host_stale = false;           // h_ptdfb_lane_class / h_ptdfb_hdr are not what the device holds: ptdfb_fetch_host
   bool ptdfb_bus_stale = false;            // ... nor h_ptdfb_bus (only gpf_ptdf_batch_get reads it)
   std::vector<int> h_ptdfb_hdr;            // device path: the 4-int headers of the class descriptors (nr, n_act, n_pad, status); empty: h_ptdfb_desc has them
@@ -1293,6 +1295,7 @@ int gpf_destroy(gpf_handle e) {
   if (e->ptdfb_ev_a) { (void)hipEventDestroy(e->ptdfb_ev_a); (void)hipEventDestroy(e->ptdfb_ev_b); }
   if (e->ptdfb_status_pin) (void)hipHostFree(e->ptdfb_status_pin);
   if (e->ptdfg_info_pin) (void)hipHostFree(e->ptdfg_info_pin);
+  if (e->ptdfg_back_pin) (void)hipHostFree(e->ptdfg_back_pin);
   e->ptdfg_hash.release(); e->ptdfg_lane_class.release(); e->ptdfg_first.release(); e->ptdfg_c2b.release(); e->ptdfg_info.release();
   e->maint.release(); e->forecast.release(); e->sim_src.release(); e->sim_rows.release();
   e->env_target.release(); e->env_actual.release(); e->env_prev.release(); e->env_charge.release(); e->env_amount_prev.release();
@@ -2722,6 +2725,13 @@ static int ptdfb_finish(gpf_engine* e) {
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(hipStreamSynchronize(e->stream));
   std::copy(e->ptdfb_status_pin, e->ptdfb_status_pin + e->h_ptdfb_status.size(), e->h_ptdfb_status.begin());
+  if (e->ptdfb_prefetched && e->ptdfb_host_stale) {            // (device path: the class map and the descriptor headers came back behind the status)
+    const int n = e->ptdfb_n, nc = e->ptdfb_classes;
+    e->h_ptdfb_lane_class.assign(e->ptdfg_back_pin, e->ptdfg_back_pin + n);
+    e->h_ptdfb_hdr.assign(e->ptdfg_back_pin + n, e->ptdfg_back_pin + n + (size_t)nc * 4);
+    e->ptdfb_host_stale = false;
+  }
+  e->ptdfb_prefetched = false;
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, e->ptdfb_ev_a, e->ptdfb_ev_b);
   e->ptdfb_kernel_ms = ms;
@@ -2778,7 +2788,6 @@ static int ptdfb_group_on_device(gpf_engine* e, int lane0, int n, int stride, in
   D.desc_stride = stride;
   D.hash = e->ptdfg_hash.p; D.lane_class = e->ptdfg_lane_class.p; D.first_lane = e->ptdfg_first.p; D.order = e->ptdfb_order.p;
   D.blk_class = e->ptdfb_blk_class.p; D.desc = e->ptdfb_desc.p; D.c2b = e->ptdfg_c2b.p; D.info = e->ptdfg_info.p;
-  HIP_TRY(hipMemsetAsync(e->ptdfg_info.p, 0, 8 * sizeof(int), e->stream));
   hipLaunchKernelGGL(gpf::ptdfg_hash_kernel, dim3(n), dim3(64), 0, e->stream, D);
   int np2 = 1;
   while (np2 < n) np2 <<= 1;
@@ -3126,6 +3135,21 @@ int gpf_ptdf_build_batch(gpf_handle e, int32_t lane0, int32_t n, int32_t with_lo
   // same stream, gpf_ptdf_batch_info (status, kernel time) synchronises when it is asked (ptdfb_finish)
   e->h_ptdfb_status.assign(nc, 0);
   HIP_TRY(hipMemcpyAsync(e->ptdfb_status_pin, e->ptdfb_status.p, (size_t)nc * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  e->ptdfb_n = n; e->ptdfb_classes = nc; e->ptdfb_desc_stride = stride;      // (what ptdfb_finish / ptdfb_fetch_host size their copies by)
+  e->ptdfb_host_stale = dev; e->ptdfb_bus_stale = dev;
+  e->ptdfb_prefetched = false;
+  if (dev) {                                        // what gpf_ptdf_batch_info will be asked for rides the same stream: one wait gets it all
+    const size_t need = (size_t)n + (size_t)nc * 4;
+    if (e->ptdfg_back_pin_n < need) {
+      if (e->ptdfg_back_pin) (void)hipHostFree(e->ptdfg_back_pin);
+      e->ptdfg_back_pin = nullptr; e->ptdfg_back_pin_n = 0;
+      HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->ptdfg_back_pin), (need + need / 4 + 256) * sizeof(int), hipHostMallocDefault));
+      e->ptdfg_back_pin_n = need + need / 4 + 256;
+    }
+    HIP_TRY(hipMemcpyAsync(e->ptdfg_back_pin, e->ptdfg_lane_class.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpy2DAsync(e->ptdfg_back_pin + n, 4 * sizeof(int), e->ptdfb_desc.p, (size_t)stride * sizeof(int), 4 * sizeof(int), (size_t)nc, hipMemcpyDeviceToHost, e->stream));
+    e->ptdfb_prefetched = true;
+  }
   e->ptdfb_pending = true;
   float ms = 0.f;
   if (stage_timing || want_dbg) { int rc_f = ptdfb_finish(e); if (rc_f != GPF_OK) return rc_f; ms = (float)e->ptdfb_kernel_ms; }

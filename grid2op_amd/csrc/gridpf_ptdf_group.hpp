@@ -52,6 +52,7 @@ __device__ __forceinline__ unsigned long long ptdfg_mix(unsigned long long x) { 
 // one wavefront per lane: sum over the positions of mix(position, value) -- order-free, so the lanes of the wavefront add up in any order
 __global__ __launch_bounds__(64) void ptdfg_hash_kernel(PtdfGroupDev D) {
   const int k = blockIdx.x, l = threadIdx.x;
+  if (k == 0 && l < 8) D.info[l] = 0;                     // (the kernels behind this one on the stream fill it)
   if (k >= D.n) return;
   const int* tp = D.topo + (size_t)(D.lane0 + k) * D.dim_topo;
   unsigned long long h = 0;
@@ -278,8 +279,15 @@ __global__ __launch_bounds__(PTDFG_DESC_THREADS) void ptdfg_desc_kernel(PtdfGrou
     lflag[l] = (on && ((s_nl[f] == 1 && s_no[f] == 0) || (s_nl[t] == 1 && s_no[t] == 0))) ? 1 : 0;
   }
   for (int i = tid; i < D.n_inj; i += nt) { const int b = ib[i]; ib[i] = b >= 0 ? s_cmp[b] : -1; }
-  __syncthreads();                                                   // lf / lt (global) are read back below by other threads
-  __threadfence_block();
+  // (the compact line ends once more in LDS -- s_bf / s_bt are dead --: the row walks below read them nl times per thread)
+  __syncthreads();
+  for (int l = tid; l < nl; l += nt) {
+    const int f = s_bf[l], t = s_bt[l];
+    const bool on = f >= 0 && f != t;
+    const short cf = on ? (short)s_cmp[f] : (short)-1, ct = on ? (short)s_cmp[t] : (short)-1;
+    s_bf[l] = cf; s_bt[l] = ct;
+  }
+  __syncthreads();
   // rows of the reduced B': for every non-reference bus r its lines in ascending order, as line | other end << 16.  Row lengths first
   // (thread r walks all lines: no atomics, ascending by construction), then an exclusive scan for the row pointers
   int* s_cnt = s_lab;                                                // (labels are dead)
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(PTDFG_DESC_THREADS) void ptdfg_desc_kernel(PtdfGrou
   __syncthreads();
   for (int r = tid; r < nr; r += nt) {
     int cnt = 0;
-    for (int l = 0; l < nl; ++l) { const int a = lf[l], b = lt[l]; if (a >= 0 && (a == r || b == r)) ++cnt; }
+    for (int l = 0; l < nl; ++l) { const int a = s_bf[l], b = s_bt[l]; if (a >= 0 && (a == r || b == r)) ++cnt; }
     s_cnt[r] = cnt;
   }
   __syncthreads();
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(PTDFG_DESC_THREADS) void ptdfg_desc_kernel(PtdfGrou
   for (int r = tid; r < nr; r += nt) {
     int q = s_cnt[r];
     for (int l = 0; l < nl; ++l) {
-      const int a = lf[l], b = lt[l];
+      const int a = s_bf[l], b = s_bt[l];
       if (a < 0) continue;
       if (a == r) cent[q++] = l | (b << 16);
       else if (b == r) cent[q++] = l | (a << 16);

@@ -288,3 +288,43 @@ def test_ptdf_path_at_bench_size_vs_dc_oracle(B, load_model):
     if B > 2048:                                                # tiled inputs: identical lanes give identical flows
         assert np.array_equal(flows[:2048], flows[B - 2048:])
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["l2rpn_wcci_2022_dev", "l2rpn_idf_2023"])
+def test_118_substations_every_step_of_a_launch_vs_oracle_from_the_chronics_table(name, load_model, load_npz):
+    """Round 6: on the two-wavefront kernels the chronics-driven injections of the steps INSIDE a launch no longer pass through the lane's
+    injection row (K9's owner lanes hand them to the results phase in registers), the results row goes to HBM through a staged copy in
+    LDS, and the narrow LU passes run on one wavefront.  512 lanes, one 20-step launch with the observation trajectory (the launch length of
+    the driver's bench): steps 0, 1, 9, 18 and 19 of 48 sampled lanes are recomputed by the C oracle FROM THE CHRONICS TABLE (gather, jitter,
+    rebalancing, power flow, result row) -- status and iteration count bit for bit --, every observation of the launch obeys KCL, and the
+    injection row the launch leaves behind is the LAST step's."""
+    import bench
+    B, n, t0 = 512, bench.launch_length(bench.DRIVER_STEPS), 11
+    m, eng, tab, off, sc = _bench_engine(load_model, load_npz, name, B)
+    assert eng.plan()["wavefronts_per_instance"] == 2
+    eng.set_trajectory(n, eng.TRAJ_OBS)
+    eng.step(0, n_steps=n, rebalance=1.02)             # a first launch: the checked one starts from a used state
+    eng.step(t0, n_steps=n, rebalance=1.02)
+    obs = eng.trajectory_obs(n)
+    _, st = eng.trajectory(n)
+    lanes = np.sort(np.random.default_rng(3).choice(B, 48, replace=False))
+    for k in (0, 1, 9, n - 2, n - 1):
+        res = check_step(m, tab, off, sc, 1.02, t0 + k, lanes, obs[k].out[lanes], st[k][lanes])
+        assert res["ok"] and res["n_converged"] == 48 and res.get("n_iter_mismatch", 0) == 0, (k, res)
+    for k in range(n):
+        r = obs[k]
+        assert (st[k] == 0).all()
+        p_bus = np.zeros((B, m.n_sub))
+        for sub, val in [(m.line_or_sub, r.p_or), (m.line_ex_sub, r.p_ex), (m.load_sub, r.load_p), (m.gen_sub, -r.gen_p),
+                         (m.shunt_sub, r.shunt_p), (m.storage_sub, r.storage_p)]:
+            np.add.at(p_bus, (slice(None), sub), val.astype(np.float64))
+        assert np.abs(p_bus).max() < 2e-2, k
+    last = eng.results(with_bus=False)
+    assert np.array_equal(last.out, obs[n - 1].out)
+    lay, nl = eng.layout, m.n_load
+    inj_d = eng.get_injections()
+    T = tab.shape[0]
+    for k in lanes[:16]:
+        row = tab[(t0 + n - 1 + off[k]) % T]
+        assert np.array_equal(inj_d[k, lay.inj_load_p:lay.inj_load_p + nl], (row[:nl] * sc[k, :nl]).astype(np.float64))
+    eng.close()
