@@ -224,6 +224,12 @@ struct gpf_engine {
   DevArr<double> inj, bus_vm, bus_va, work;
   DevArr<int> topo, shunt_bus, topo_out, shunt_bus_out, status, overflow_count, disc_round, lane_table, lane_offset, tmp_lines;
   DevArr<int> cooldown;                 // [B][n_line] line cooldowns of the environment (gpf::Bufs::cooldown)
+  // topology-derived state of the reference topology shared by the lanes of one-step launches (gpf::KeepArgs): two blobs (Ybus in LDS /
+  // in registers), allocated and keyed by the first gpf_step_n with n_steps = 1; GRIDPF_KEEP=0 at gpf_create turns it off
+  DevArr<unsigned char> keep;
+  gpf::KeepArgs keep_args{};
+  int keep_launch = 0;
+  bool keep_enabled = true;
   DevArr<unsigned short> maint_dur;     // [chron_tables][chron_T][n_line] remaining duration of the maintenance / hazard under way, or empty
   DevArr<short> traj_cool;              // [traj_cap][cap_lanes][n_line]
   DevArr<float> out, chron, lane_scale, thermal_limit, rho;
@@ -1245,6 +1251,8 @@ int gpf_create(const gpf_grid_desc* d, int32_t n_lanes, int32_t device, gpf_hand
     e->no_yreg = yv && yv[0] == '0';
     const char* sv_ = std::getenv("GRIDPF_STAGE");
     if (sv_ && sv_[0] >= '0' && sv_[0] <= '2') e->stage_max = sv_[0] - '0';
+    const char* kp_ = std::getenv("GRIDPF_KEEP");
+    e->keep_enabled = !(kp_ && kp_[0] == '0');
     const char* fs_ = std::getenv("GRIDPF_FORCE_STAGE");
     if (fs_ && fs_[0] >= '0' && fs_[0] <= '2') e->stage_force = fs_[0] - '0';
   }
@@ -1283,7 +1291,7 @@ int gpf_destroy(gpf_handle e) {
   e->line_ex_pos.release(); e->gen_sub.release(); e->gen_pos.release(); e->load_sub.release(); e->load_pos.release();
   e->sto_sub.release(); e->sto_pos.release(); e->shunt_sub.release(); e->gen_slack.release();
   e->inj.release(); e->bus_vm.release(); e->bus_va.release(); e->work.release(); e->topo.release(); e->shunt_bus.release();
-  e->topo_out.release(); e->shunt_bus_out.release(); e->status.release(); e->overflow_count.release(); e->disc_round.release(); e->cooldown.release(); e->maint_dur.release(); e->traj_cool.release();
+  e->topo_out.release(); e->shunt_bus_out.release(); e->status.release(); e->overflow_count.release(); e->disc_round.release(); e->cooldown.release(); e->keep.release(); e->maint_dur.release(); e->traj_cool.release();
   e->lane_table.release(); e->lane_offset.release(); e->tmp_lines.release(); e->out.release(); e->chron.release();
   e->lane_scale.release(); e->thermal_limit.release(); e->rho.release(); e->line_status.release();
   e->d_init_inj.release(); e->d_init_topo.release(); e->d_init_shunt_bus.release();
@@ -1813,7 +1821,8 @@ int gpf_set_thermal_limits(gpf_handle e, const float* limit_a) {
 }  // extern "C"
 namespace {
 // n_steps env steps of lanes [lane0, lane0 + n) from time index t0 (T rows per chronics table in `b.chron`)
-int step_range(gpf_engine* e, const gpf::Bufs& b_in, int lane0, int n, int t0, int T, int n_steps, const gpf_step_opts* o, const char* who) {
+int step_range(gpf_engine* e, const gpf::Bufs& b_in, int lane0, int n, int t0, int T, int n_steps, const gpf_step_opts* o, const char* who,
+               bool keep_state = false) {
   LaunchPlan p, pb;
   int rc = plan_launch(e, lane0, n, p, pb);
   if (rc != GPF_OK) return rc;
@@ -1835,6 +1844,35 @@ int step_range(gpf_engine* e, const gpf::Bufs& b_in, int lane0, int n, int t0, i
   sa.nb_ts_allowed = o->nb_ts_allowed; sa.max_rounds = o->max_rounds; sa.hard_overflow = o->hard_overflow; sa.soft_overflow = o->soft_overflow;
   sa.nb_ts_reco = o->track_cooldown ? std::max(o->nb_ts_reco, 0) : -1;      // (kernel side: < 0 = the counters are not maintained)
   sa.lane0 = lane0;
+  // one-step launches of the engine's own lanes share the topology-derived state of the reference topology (gpf::KeepArgs): single-busbar
+  // kernels only (the split lanes of a mixed batch -- topology classes, NB = 2 -- rebuild theirs).  The key is the pristine (ghost) lane's rows.
+  if (keep_state && e->keep_enabled && n_steps == 1 && p.sparse_nb == 1 && !p.tc) {
+    if (!e->keep.p) {
+      gpf::KeepArgs k{};
+      gpf::keep_layout(k, e->g, e->sym.nslot, e->sym.nslot_y, e->sym_dev.n_up);
+      const size_t bytes = 2 * (size_t)k.stride;
+      const gpf::OutOff& oo = e->oo;
+      if (e->cap_lanes > e->n_lanes && e->keep.alloc(bytes) == hipSuccess) {
+        HIP_TRY(hipMemsetAsync(e->keep.p, 0, bytes, e->stream));
+        const size_t gl = (size_t)e->n_lanes;                   // first ghost lane: the state every lane is reset to, never mutated
+        const int keyed = gpf::KEEP_KEYED;
+        for (int v = 0; v < 2; ++v) {
+          unsigned char* kb = e->keep.p + (size_t)v * (size_t)k.stride;
+          int* kt = reinterpret_cast<int*>(kb) + gpf::KEEP_HDR_INTS;
+          HIP_TRY(hipMemcpyAsync(kt, e->topo.p + gl * e->g.dim_topo, (size_t)e->g.dim_topo * sizeof(int), hipMemcpyDeviceToDevice, e->stream));
+          if (e->g.n_shunt) {
+            HIP_TRY(hipMemcpyAsync(kt + e->g.dim_topo, e->shunt_bus.p + gl * e->g.n_shunt, (size_t)e->g.n_shunt * sizeof(int), hipMemcpyDeviceToDevice, e->stream));
+            HIP_TRY(hipMemcpyAsync(kb + k.off_kd, e->inj.p + gl * e->g.n_inj + oo.inj_sh_p, 2 * (size_t)e->g.n_shunt * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+          }
+          HIP_TRY(hipMemcpyAsync(kb, &keyed, sizeof(int), hipMemcpyHostToDevice, e->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(e->stream));               // (`keyed` is on this frame)
+        k.p = e->keep.p;
+        e->keep_args = k;
+      } else { (void)hipGetLastError(); e->keep.release(); e->keep_enabled = false; }
+    }
+    if (e->keep.p) { sa.keep = e->keep_args; sa.keep.launch = ++e->keep_launch; }
+  }
   const double tol_pu = o->tol_mva / e->g.sn_mva;
   hipEvent_t ea = nullptr, eb = nullptr;
   rc = upload_params_s(e, b, p.tc ? &p : (pb.tc ? &pb : nullptr), p.dcf);
@@ -1899,7 +1937,7 @@ int gpf_step_n(gpf_handle e, int32_t t0, int32_t n_steps, const gpf_step_opts* o
   if (e->traj_cap && n_steps > e->traj_cap)
     return fail(GPF_E_INVALID, "gpf_step_n: n_steps exceeds the trajectory buffer (gpf_set_trajectory sizes it; 0 releases it)");
   HIP_TRY(hipSetDevice(e->device));
-  int rc = step_range(e, e->bufs(), 0, e->n_lanes, t0, e->chron_T, n_steps, o, "gpf_step_n");
+  int rc = step_range(e, e->bufs(), 0, e->n_lanes, t0, e->chron_T, n_steps, o, "gpf_step_n", true);
   if (rc != GPF_OK) return rc;
   e->traj_valid = e->traj_cap ? n_steps : 0;
   if (e->env_on) {                          // the actions were consumed by this launch (a held storage action stays)

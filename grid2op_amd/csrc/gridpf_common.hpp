@@ -130,6 +130,26 @@ struct EnvDyn {
   const float* charge0;                 // [n_storage] state of charge after a reset
 };
 
+// Topology-derived state of the grid's REFERENCE topology, shared by every lane that is on it, for ONE-STEP launches (gpf_step_n with
+// n_steps = 1: agents that act at every step).  What a later step of a multi-step launch finds in LDS / registers -- element -> bus maps, bus
+// types, the Ybus blocks, the factored DC matrix, the verdicts of K1 / connectivity -- is what a one-step launch rebuilds from the lane's
+// topology row every time (20-25 % of its cycles, tools/phase_timing.py).  The blob holds that state for ONE key: the topology row, shunt
+// buses and shunt set-points of the engine's pristine lane (the state every lane starts from and an agent that only moves injections never
+// leaves).  A lane whose rows equal the key loads the blob -- 2-19 KB that every block reads, so they come from L2 -- and runs its step like a
+// step whose topology stands (SolveCtl::reuse); any other lane rebuilds as before.  (A blob PER LANE was measured first: the burst of
+// 1 024 x 19 KB at the start of a launch cost as much as the rebuild it saved.)  The state is written once, by the first lane on the key that
+// wins the claim in header word 0, and trusted only by LATER launches (the word carries the writer's launch number).
+// Layout: [16 ints header][key ints: dim_topo + n_shunt][off_kd: 2 n_shunt doubles][off_m: n_m ints = the LDS range btype .. sub_bb][off_y: Ybus,
+// (2 n_up + n_bus) double2 of the register layout (YR kernels: second blob) or nslot_y double2][off_d: nslot doubles DC factors]
+struct KeepArgs {
+  unsigned char* p;        // [2][stride]: blob of the kernels with Ybus in LDS, blob of the kernels with Ybus in registers; nullptr: off
+  long long stride;        // bytes per blob (multiple of 16)
+  int launch;              // number of this launch (>= 1): a state written by launch k carries KEEP_VALID + k in header word 0
+  int off_kd, off_m, off_y, off_d, n_m;
+};
+constexpr int KEEP_HDR_INTS = 16;      // [0] KEEP_KEYED / KEEP_CLAIMED / KEEP_VALID + launch, [1] status | nb << 8, [2] dc_base | gen_base << 1 | DC factors held << 2 | (dc_out + 1) << 3
+constexpr int KEEP_KEYED = 1, KEEP_CLAIMED = 2, KEEP_VALID = 16;
+
 struct StepArgs {
   int t, T, rebalance_on, cascade, nb_ts_allowed, max_rounds, is_dc;
   int lane0;         // first lane of a contiguous launch (gpf_simulate_batch steps a sub-range; 0 for gpf_step_n)
@@ -139,6 +159,7 @@ struct StepArgs {
   int nb_ts_reco;    // Parameters.NB_TIMESTEP_RECONNECTION: cooldown a line gets when the protections trip it; < 0: the cooldown counters are not maintained
   double rebalance;
   float hard_overflow, soft_overflow;
+  KeepArgs keep;     // (gpf_step_n, n_steps = 1, single-busbar kernels without topology classes)
 };
 
 // results-row offsets (must match gpf_layout in include/gridpf.h)

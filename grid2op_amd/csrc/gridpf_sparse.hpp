@@ -272,6 +272,21 @@ __host__ __device__ inline size_t lds_bytes_sparse(const GridDev& g, int nslot, 
   return (size_t)ipw * lds_bytes_instance<NB>(g, nslot, nslot_y, stage_inj, n_rows, dcf) + static_bytes;
 }
 
+// Byte layout of a lane's blob of kept topology-derived state (KeepArgs, gridpf_common.hpp) for the single-busbar kernels of a grid: the
+// host sizes the buffer with it, the kernels read the offsets from StepArgs::keep.
+__host__ __device__ inline void keep_layout(KeepArgs& k, const GridDev& g, int nslot, int nslot_y, int n_up) {
+  const size_t nbus = (size_t)g.n_sub;
+  const size_t n16 = 2 * (size_t)g.n_line + g.n_gen + g.n_load + g.n_sto + g.n_shunt;
+  size_t o = (size_t)KEEP_HDR_INTS * 4 + ((size_t)g.dim_topo + g.n_shunt) * 4;
+  o = (o + 7) & ~(size_t)7; k.off_kd = (int)o; o += 2 * (size_t)g.n_shunt * 8;
+  o = (o + 15) & ~(size_t)15; k.off_m = (int)o;
+  k.n_m = (int)((2 * nbus * 4 + n16 * 2 + g.n_sub + 3) / 4); o += (((size_t)k.n_m + 3) & ~(size_t)3) * 4;     // (whole 16-byte chunks)
+  o = (o + 15) & ~(size_t)15; k.off_y = (int)o;
+  const size_t ny = (size_t)nslot_y > 2 * (size_t)n_up + nbus ? (size_t)nslot_y : 2 * (size_t)n_up + nbus;
+  o += ny * 16; k.off_d = (int)o; o += (size_t)nslot * 8;
+  k.stride = (long long)((o + 15) & ~(size_t)15);
+}
+
 // Stage the static data in LDS (STAGE, see stat_bytes) or view it in place; visible to the block after the first barrier.
 // NB1: single-busbar kernel -- its program is the flat program `flat` (n_flat ints, global memory) of the kernel's group width.
 // global -> LDS copy of n16 16-byte chunks (both 16-byte aligned) with four loads in flight per lane: a plain element loop waits
@@ -867,6 +882,7 @@ struct SolveCtl {
   // multi-step launch whose topology stands; the row gets the last step's values).  2.8 KB less HBM traffic per lane and step on 118 substations.
   bool inj_regs;
   float r_lp0, r_lq0, r_lp1, r_lq1, r_pp, r_vm;
+  bool tc_rebuild;    // (with reuse + write_topo) TopoState::tc is not this launch's: the first topology positions are derived again (state loaded from a KeepArgs blob)
 };
 // per-group results of the topology phases, kept by the caller across solves
 struct TopoState {
@@ -2030,7 +2046,7 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       const int i = tid + k * GW;
       if (i < g.dim_topo) {
         int val;
-        if (reuse) val = ts.tc[k];
+        if (reuse && !ctl.tc_rebuild) val = ts.tc[k];
         else {
           const int v = topo_g[i], pl = sv.pos_line[i];
           const bool line_out = pl >= 0 && c.lor_b[pl] < 0;
@@ -2136,7 +2152,7 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void runpf_sparse_kerne
   GPF_STAMPS_DECL;
   SolveCtl ctl;
   ctl.inj_staged = false; ctl.topo_staged = false; ctl.reuse = false; ctl.dcf = false; ctl.write_bus = true; ctl.warm = false; ctl.sums_done = false;
-  ctl.otraj = false; ctl.orow = inst; ctl.write_topo = true; ctl.inj_regs = false;
+  ctl.otraj = false; ctl.orow = inst; ctl.write_topo = true; ctl.inj_regs = false; ctl.tc_rebuild = false;
   TopoState ts;
   ts.status = 0; ts.nb = 0; ts.dc_base = false; ts.dc_out = -1; ts.gen_base = false; ts.tc[0] = ts.tc[1] = -1;
   const int st = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, is_dc, max_iter, tol_pu, tid, ctl, ts, n_iter, nb, a_first GPF_STAMPS_ARG);
@@ -2418,6 +2434,62 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
   if (STAGE) GPF_SYNC();                                       // the static tables are read from here on
   GPF_STAMPS_DECL;
   GPF_STAMPS(8);
+  // ---- kept state of the reference topology (KeepArgs), first half: EVERY load of the blob and of the lane's key rows is issued here, ahead of
+  //      the lane constants, so that they share the launch's first (cold) round trip; they are used at the end of the prologue.  (Waiting for
+  //      the key comparison before fetching the state cost three round trips: 14 k cycles on 118 substations, more than K1's rebuild.) -------
+  typedef int v4i_ __attribute__((ext_vector_type(4)));
+  typedef int v2i_ __attribute__((ext_vector_type(2)));
+  typedef double v2d_ __attribute__((ext_vector_type(2)));
+  constexpr bool KEEP = NB == 1 && !TC;
+  const bool keep_on = KEEP && sa.keep.p != nullptr;            // kernel-uniform
+  const bool keep_dcf = P->dcf != 0;
+  constexpr int KT = 2, KC = 2, KY = 4, KA = 8;                 // unrolled trips of the key / image / Ybus / DC-factor loads (longer rows: loops in the second half)
+  int k_h0 = 0, k_h1 = 0, k_h2 = 0;                             // header words (KEEP_HDR_INTS)
+  int kk[KT] = {}, tn[KT] = {};
+  v4i_ im[KC] = {};
+  double2 yy[KY] = {};
+  double aa[KA] = {};
+  bool k_same = true;
+  if (keep_on) {
+    const auto kb = (GPF_GLOBAL const unsigned char*)sa.keep.p + (YR ? (size_t)sa.keep.stride : 0);
+    const auto hdr = (GPF_GLOBAL const int*)kb;
+    { int z_ = 0; asm volatile("" : "+v"(z_)); k_h0 = hdr[z_]; k_h1 = hdr[z_ + 1]; k_h2 = hdr[z_ + 2]; }   // (vector loads: three more live SGPRs spilled this kernel to scratch)
+    const auto kt = hdr + KEEP_HDR_INTS;
+    const auto topo_now = gptr(b.topo) + (size_t)inst * g.dim_topo;
+#pragma unroll
+    for (int u = 0; u < KT; ++u) { const int i = tid + u * GW; const bool on_ = i < g.dim_topo; kk[u] = on_ ? kt[i] : 0; tn[u] = on_ ? topo_now[i] : 0; }
+    if (tid < g.n_shunt) k_same = kt[g.dim_topo + tid] == gptr(b.shunt_bus)[(size_t)inst * g.n_shunt + tid];
+    {                                                           // shunt p | q set-points: part of Ybus
+      const auto kd = (GPF_GLOBAL const double*)(kb + sa.keep.off_kd);
+      const auto inj_now = gptr(b.inj) + (size_t)inst * g.n_inj + oo.inj_sh_p;
+      const double a0_ = tid < 2 * g.n_shunt ? kd[tid] : 0.0, b0_ = tid < 2 * g.n_shunt ? inj_now[tid] : 0.0;
+      const double a1_ = tid + GW < 2 * g.n_shunt ? kd[tid + GW] : 0.0, b1_ = tid + GW < 2 * g.n_shunt ? inj_now[tid + GW] : 0.0;
+      k_same &= a0_ == b0_ && a1_ == b1_;
+    }
+    const auto km16 = (GPF_GLOBAL const v4i_*)(kb + sa.keep.off_m);
+    const int n_ch = (sa.keep.n_m + 3) >> 2;                    // 16-byte chunks of the LDS image (the blob is padded to whole chunks)
+#pragma unroll
+    for (int u = 0; u < KC; ++u) { const int ch = tid + u * GW; im[u] = ch < n_ch ? km16[ch] : v4i_{0, 0, 0, 0}; }
+    const auto ky = (GPF_GLOBAL const v2d_*)(kb + sa.keep.off_y);
+    auto ld2 = [&](int i_) { const v2d_ t_ = ky[i_]; return make_double2(t_.x, t_.y); };
+    if (YR) {
+#pragma unroll
+      for (int k = 0; k < YR_PASSES; ++k) {
+        const int pr = tid + k * GW;
+        const bool on_ = pr < S.n_up;
+        rcreg[2 * k] = on_ ? (unsigned)sv.up[2 * pr] : 0u; rcreg[2 * k + 1] = on_ ? (unsigned)sv.up[2 * pr + 1] : 0u;
+        yreg[2 * k] = on_ ? ld2(2 * pr) : make_double2(0.0, 0.0);
+        yreg[2 * k + 1] = on_ ? ld2(2 * pr + 1) : make_double2(0.0, 0.0);
+      }
+      yreg[2 * YR_PASSES] = tid < g.n_sub ? ld2(2 * S.n_up + tid) : make_double2(0.0, 0.0);
+    } else {
+#pragma unroll
+      for (int u = 0; u < KY; ++u) { const int i = tid + u * GW; yy[u] = i < S.nslot_y ? ld2(i) : make_double2(0.0, 0.0); }
+    }
+    const auto ka = (GPF_GLOBAL const double*)(kb + sa.keep.off_d);
+#pragma unroll
+    for (int u = 0; u < KA; ++u) { const int q = tid + u * GW; aa[u] = (keep_dcf && q < S.nslot) ? ka[q] : 0.0; }
+  }
   // ---- per-lane constants of the launch --------------------------------------------------------------------------------------
   const int tab = b.lane_table ? gptr(b.lane_table)[inst] : 0;
   const int off = b.lane_offset ? gptr(b.lane_offset)[inst] : 0;
@@ -2481,6 +2553,70 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
     if (tid < g.n_load) { pf_lp = ch0[tid]; pf_lq = ch0[g.n_load + tid]; }
     if (tid < g.n_gen) { pf_pp = ch0[2 * g.n_load + tid]; pf_pv = ch0[2 * g.n_load + g.n_gen + tid]; }
   }
+  // ---- kept state of the reference topology, second half: key comparison, state -> LDS, verdict of the block ----------------------------------
+  bool keep_hit = false, keep_dirty = false;                    // block-uniform
+  bool keep_claim = false;                                      // this instance is on the key and the blob has no state yet
+  GPF_STAMPS(34);
+  if (keep_on) {
+    const auto kb = (GPF_GLOBAL const unsigned char*)sa.keep.p + (YR ? (size_t)sa.keep.stride : 0);
+    const auto kt = (GPF_GLOBAL const int*)kb + KEEP_HDR_INTS;
+    bool same = k_same;
+#pragma unroll
+    for (int u = 0; u < KT; ++u) same &= kk[u] == tn[u];
+    {                                                           // (rows longer than the unrolled trips: grids beyond the shipped ones)
+      const auto topo_now = gptr(b.topo) + (size_t)inst * g.dim_topo;
+      const auto shb_now = gptr(b.shunt_bus) + (size_t)inst * g.n_shunt;
+      const auto kd = (GPF_GLOBAL const double*)(kb + sa.keep.off_kd);
+      const auto inj_now = gptr(b.inj) + (size_t)inst * g.n_inj + oo.inj_sh_p;
+      for (int i = tid + KT * GW; i < g.dim_topo; i += GW) same &= kt[i] == topo_now[i];
+      for (int i = tid + GW; i < g.n_shunt; i += GW) same &= kt[g.dim_topo + i] == shb_now[i];
+      for (int i = tid + 2 * GW; i < 2 * g.n_shunt; i += GW) same &= kd[i] == inj_now[i];
+    }
+    GPF_STAMPS(36);
+    // a state is trusted when an EARLIER launch wrote it (every store of that kernel is visible; the writer of this launch may be half way)
+    const bool valid = k_h0 > KEEP_VALID && k_h0 - KEEP_VALID < sa.keep.launch;
+    // ---- the state goes to LDS whatever the comparison says: a lane that misses rebuilds every one of these arrays from scratch ---------------
+    {
+      const auto km16 = (GPF_GLOBAL const v4i_*)(kb + sa.keep.off_m);
+      const auto ky = (GPF_GLOBAL const v2d_*)(kb + sa.keep.off_y);
+      const auto ka = (GPF_GLOBAL const double*)(kb + sa.keep.off_d);
+      int* const img = c.btype;                                  // btype | vidx | element -> bus maps | sub_bb: one contiguous range of the carve (8-byte aligned)
+      v2i_* const img2 = reinterpret_cast<v2i_*>(img);
+      const int n_m = sa.keep.n_m;                               // ints of the range (the blob is padded to whole 16-byte chunks, the carve is not)
+      auto put4 = [&](int ch, const v4i_ t_) {
+        if (4 * ch + 3 < n_m) { img2[2 * ch] = v2i_{t_.x, t_.y}; img2[2 * ch + 1] = v2i_{t_.z, t_.w}; }
+        else { if (4 * ch < n_m) img[4 * ch] = t_.x; if (4 * ch + 1 < n_m) img[4 * ch + 1] = t_.y; if (4 * ch + 2 < n_m) img[4 * ch + 2] = t_.z; }
+      };
+      const int n_ch = (n_m + 3) >> 2;
+#pragma unroll
+      for (int u = 0; u < KC; ++u) { const int ch = tid + u * GW; if (ch < n_ch) put4(ch, im[u]); }
+      for (int ch = tid + KC * GW; ch < n_ch; ch += GW) put4(ch, km16[ch]);
+      if (!YR) {
+        double2* const yl = reinterpret_cast<double2*>(c.Yb);
+#pragma unroll
+        for (int u = 0; u < KY; ++u) { const int i = tid + u * GW; if (i < S.nslot_y) yl[i] = yy[u]; }
+        for (int i = tid + KY * GW; i < S.nslot_y; i += GW) { const v2d_ t_ = ky[i]; yl[i] = make_double2(t_.x, t_.y); }
+      }
+      if (keep_dcf && (k_h2 & 4)) {                              // (a blob written from the static-inverse DC start holds no factors)
+#pragma unroll
+        for (int u = 0; u < KA; ++u) { const int q = tid + u * GW; if (q < S.nslot) c.Adc[q] = aa[u]; }
+        for (int q = tid + KA * GW; q < S.nslot; q += GW) c.Adc[q] = ka[q];
+      }
+    }
+    GPF_STAMPS(37);
+    // every instance of the block must hit; the DC start of the block is the static inverse for all (no factors needed) or the kept factors
+    const unsigned hb = G::template any_bits<3, 4>(((same && valid) ? 0u : 1u) | ((k_h2 & 1) ? 0u : 2u) | ((k_h2 & 4) ? 0u : 4u) | (same ? 0u : 8u));
+    const unsigned hbb = IPW == 1 ? hb : ((__any(hb & 1u) ? 1u : 0u) | (__any(hb & 2u) ? 2u : 0u) | (__any(hb & 4u) ? 4u : 0u));
+    keep_hit = !(hbb & 1u) && (!keep_dcf || !(hbb & 2u) || !(hbb & 4u));
+    keep_claim = !(hb & 8u) && k_h0 == KEEP_KEYED && !ghost;
+    if (keep_hit) {
+      ts.status = k_h1 & 0xff; ts.nb = k_h1 >> 8; ts.dc_base = (k_h2 & 1) != 0; ts.gen_base = (k_h2 & 2) != 0; ts.dc_out = (k_h2 >> 3) - 1;
+      reuse = true;
+    }
+    GPF_STAMPS(38);
+    GPF_LSYNC();                                   // (a miss: K1 initialises these arrays with another lane mapping)
+  }
+  GPF_STAMPS(39);
   // Every step (and every cascade round) runs the same code on the same addresses, so the compiler would hoist each per-thread
   // pointer, offset and table entry it finds out of the loops (loop-invariant code motion) and keep them live for the whole
   // launch: > 250 VGPRs plus scratch spills.  GPF_REDERIVE makes the thread's coordinates opaque and re-derives the LDS carve
@@ -2659,6 +2795,7 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
       if (sa.cascade) for (int l = tid + GW; l < g.n_line; l += GW) inc_flag[l] = 0;      // (line tid: inc_first)
       inc_first = 0;
     }
+    if (!reuse) keep_dirty = true;                              // this step rebuilds the topology-derived state
     bool more = true;                                           // this group still cascades
     bool first = true;
     bool tripped = false;                                       // this group tripped a line during this step
@@ -2667,9 +2804,10 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
       // a group whose cascade has ended re-solves its unchanged state along with the others (same results)
       int it_k = 0, nb_k = 0;
       SolveCtl ctl;
-      ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && sa.n_steps > 1; ctl.write_bus = last; ctl.warm = sa.warm_start != 0; ctl.sums_done = first && sums_in_k9;
+      ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && (sa.n_steps > 1 || keep_on); ctl.write_bus = last; ctl.warm = sa.warm_start != 0; ctl.sums_done = first && sums_in_k9;
       orow = otraj ? step * (int)b.lane_stride + inst : inst;          // (re-derived: see GPF_REDERIVE)
-      ctl.otraj = otraj; ctl.orow = orow; ctl.write_topo = otraj;
+      ctl.otraj = otraj; ctl.orow = orow; ctl.write_topo = otraj || (keep_hit && step == 0);   // (kept state: the lane's topology outputs may be another launch's)
+      ctl.tc_rebuild = keep_hit && step == 0;
       ctl.inj_regs = skip_inj; ctl.r_lp0 = k9_lp0; ctl.r_lq0 = k9_lq0; ctl.r_lp1 = k9_lp1; ctl.r_lq1 = k9_lq1; ctl.r_pp = k9_pp; ctl.r_vm = k9_vm;
       GPF_STAMPS(31);
       const int st_k = solve_instance_sparse<NB, STAGE, IPW, WPI, TC, YR>(P, S, FL, sv, c, yreg, rcreg, inst, sa.is_dc, max_iter, tol_pu, tid, ctl, ts, it_k, nb_k, a_first GPF_STAMPS_ARG);
@@ -2793,6 +2931,42 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
   }
 #undef GPF_REDERIVE
   grp = grp0; tid = tid0; inst = inst0;
+  if (keep_on) {
+    // The blob has a key but no state yet, this instance is on the key, rebuilt the state in this launch and nothing tripped or failed since
+    // (`reuse`: LDS / registers hold the state of the lane's rows, which still equal the key): the first instance to claim the blob writes it.
+    const auto kb = (GPF_GLOBAL unsigned char*)sa.keep.p + (YR ? (size_t)sa.keep.stride : 0);
+    const auto hdr = (GPF_GLOBAL int*)kb;
+    bool won = false;
+    if (keep_claim && reuse && keep_dirty && tid == 0) won = atomicCAS((int*)hdr, KEEP_KEYED, KEEP_CLAIMED) == KEEP_KEYED;
+    const bool all_dcb = G::block_all_u(ts.dc_base);     // (what solve_instance_sparse decided on: dc_inv)
+    if (G::any(won)) {
+      typedef double v2d_ __attribute__((ext_vector_type(2)));
+      const auto km = (GPF_GLOBAL int*)(kb + sa.keep.off_m);
+      const int* const img = c.btype;
+      for (int i = tid; i < sa.keep.n_m; i += GW) km[i] = img[i];
+      const auto ky = (GPF_GLOBAL v2d_*)(kb + sa.keep.off_y);
+      auto st2 = [&](int i_, const double2 v_) { v2d_ t_; t_.x = v_.x; t_.y = v_.y; ky[i_] = t_; };
+      if (YR) {
+#pragma unroll
+        for (int k = 0; k < YR_PASSES; ++k) {
+          const int pr = tid + k * GW;
+          if (pr < S.n_up) { st2(2 * pr, yreg[2 * k]); st2(2 * pr + 1, yreg[2 * k + 1]); }
+        }
+        if (tid < g.n_sub) st2(2 * S.n_up + tid, yreg[2 * YR_PASSES]);
+      } else {
+        const double2* const yl = reinterpret_cast<const double2*>(c.Yb);
+        for (int i = tid; i < S.nslot_y; i += GW) st2(i, yl[i]);
+      }
+      // the factors are in LDS unless every instance of the block started from the static DC inverse (solve_instance_sparse: dc_inv)
+      const bool adc = keep_dcf && !all_dcb;
+      if (adc) { const auto ka = (GPF_GLOBAL double*)(kb + sa.keep.off_d); for (int q = tid; q < S.nslot; q += GW) ka[q] = c.Adc[q]; }
+      if (tid == 0) {
+        hdr[1] = (ts.status & 0xff) | (ts.nb << 8);
+        hdr[2] = (ts.dc_base ? 1 : 0) | (ts.gen_base ? 2 : 0) | (adc ? 4 : 0) | ((ts.dc_out + 1) << 3);
+        hdr[0] = KEEP_VALID + sa.keep.launch;     // (trusted by later launches only: no ordering needed against the stores above)
+      }
+    }
+  }
   if (tobs) {
     // the getters / device views of the lane's own rows return the LAST step: copy its trajectory rows there
     const int ls = sa.n_steps <= b.traj_cap ? sa.n_steps - 1 : b.traj_cap - 1;

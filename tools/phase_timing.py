@@ -44,6 +44,7 @@ if SPARSE:
     print(f"[kernel S] {env} batch {B}, {NS} step(s) per launch: median cycle counts per phase (LAST step of the launch)")
     print(f"  launch prologue (carve, static staging, lane constants) {med[19] - med[8]:10.0f}" if NS == 1 else
           f"  whole launch {med[15] - med[8]:.0f} cycles = {(med[15] - med[8]) / NS:.0f} per step")
+    m8 = float(med[8])
     med[8] = med[19]
     names_s[9] = "cascade check"
     names_s[7] = "rho + counters + episode"
@@ -53,6 +54,9 @@ if SPARSE:
         print(f"  {names_s[k]:45s} {med[k] - prev:10.0f}")
         prev = med[k]
     print(f"  {'TOTAL (one step)':45s} {med[7] - med[8]:10.0f}")
+    if med[39] > 0 and NS == 1:
+        print(f"  prologue detail: before the kept-state block {med[34] - m8:.0f}, loads + key comparison {med[36] - med[34]:.0f}, state -> LDS {med[37] - med[36]:.0f}, "
+              f"block verdict {med[38] - med[37]:.0f}, barrier {med[39] - med[38]:.0f}, rest {med[19] - med[39]:.0f}")
     print(f"  DC block-LU: elimination levels + scaling {med[20]:.0f}, back substitution {med[21]:.0f} cycles")
     print(f"  first Newton iteration: initial sincos {med[10] - med[4]:.0f}, Jacobian blocks + S {med[11] - med[10]:.0f}, "
           f"diag + mismatch + test {med[12] - med[11]:.0f}, block LU {med[13] - med[12]:.0f}, update + sincos {med[14] - med[13]:.0f}")
