@@ -2827,7 +2827,7 @@ static int ptdfb_group_on_device(gpf_engine* e, int lane0, int n, int stride, in
   D.hash = e->ptdfg_hash.p; D.lane_class = e->ptdfg_lane_class.p; D.first_lane = e->ptdfg_first.p; D.order = e->ptdfb_order.p;
   D.blk_class = e->ptdfb_blk_class.p; D.desc = e->ptdfb_desc.p; D.c2b = e->ptdfg_c2b.p; D.info = e->ptdfg_info.p;
   hipLaunchKernelGGL(gpf::ptdfg_hash_kernel, dim3(n), dim3(64), 0, e->stream, D);
-  int np2 = 1;
+  int np2 = gpf::PTDFG_SORT_THREADS;                   // (ptdfg_group_kernel sorts a multiple of its workgroup)
   while (np2 < n) np2 <<= 1;
   const size_t lds_sort = (size_t)np2 * 20;
   static size_t lds_sort_set[64] = {0};

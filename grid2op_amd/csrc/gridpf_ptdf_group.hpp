@@ -82,33 +82,77 @@ __device__ inline void ptdfg_scan_excl(int* v, int* tmp, int n, int tid, int nt)
   if (b != v) { for (int i = tid; i < n; i += nt) v[i] = b[i]; __syncthreads(); }
 }
 
+// Bitonic sort of NV = PTDFG_SORT_THREADS * E (key, index) pairs, ascending, by one workgroup: thread t holds the E consecutive elements
+// t E .. t E + E - 1 in registers.  An exchange at distance j < E stays inside the thread, j < 64 E goes through wavefront shuffles, the rest
+// (10 of the 66 steps of 2 048 elements) through LDS -- the all-LDS version with a barrier per step took 48 us of the 0.25 ms of a
+// gpf_ptdf_build_batch call.  Leaves the sorted pairs in s_key / s_idx.
+template <int E>
+__device__ inline void ptdfg_sort_regs(const unsigned long long* __restrict__ hash, int n, unsigned long long* s_key, int* s_idx, int tid) {
+  constexpr int NV = PTDFG_SORT_THREADS * E;
+  unsigned long long key[E];
+  int idx[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { const int i = tid * E + e; key[e] = i < n ? hash[i] : ~0ull; idx[e] = i < n ? i : 0x40000000 + i; }
+  auto less = [](unsigned long long ka, int ia, unsigned long long kb, int ib) { return ka < kb || (ka == kb && ia < ib); };
+  for (int k = 2; k <= NV; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j < E) {                                             // partner in this thread (register indices are literals after unrolling)
+        const bool up = ((tid * E) & k) == 0;                  // (k > j: the same for the thread's E elements when k >= E; k < E: per pair below)
+#pragma unroll
+        for (int jj = 1; jj < E; jj <<= 1) {
+          if (j != jj) continue;
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            if ((e & jj) || (e | jj) >= E) continue;
+            const int f = e | jj;
+            const bool up_e = k >= E ? up : (e & k) == 0;
+            if (less(key[f], idx[f], key[e], idx[e]) == up_e) { const unsigned long long tk = key[e]; key[e] = key[f]; key[f] = tk; const int ti = idx[e]; idx[e] = idx[f]; idx[f] = ti; }
+          }
+        }
+      } else if (j < 64 * E) {                                 // partner in this wavefront
+        const int m = j / E;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int i = tid * E + e;
+          const unsigned long long kb = __shfl_xor(key[e], m);
+          const int ib = __shfl_xor(idx[e], m);
+          const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+          if (less(kb, ib, key[e], idx[e]) == keep_min) { key[e] = kb; idx[e] = ib; }
+        }
+      } else {                                                 // through LDS
+#pragma unroll
+        for (int e = 0; e < E; ++e) { s_key[tid * E + e] = key[e]; s_idx[tid * E + e] = idx[e]; }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const int i = tid * E + e, p = i ^ j;
+          const unsigned long long kb = s_key[p];
+          const int ib = s_idx[p];
+          const bool keep_min = ((i & j) == 0) == ((i & k) == 0);
+          if (less(kb, ib, key[e], idx[e]) == keep_min) { key[e] = kb; idx[e] = ib; }
+        }
+        __syncthreads();
+      }
+    }
+#pragma unroll
+  for (int e = 0; e < E; ++e) { s_key[tid * E + e] = key[e]; s_idx[tid * E + e] = idx[e]; }
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(PTDFG_SORT_THREADS) void ptdfg_group_kernel(PtdfGroupDev D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ptdfg_smem[];        // 20 bytes per element of the padded range (host: lds_sort)
   __shared__ int s_nc;
   const int tid = threadIdx.x, nt = blockDim.x, n = D.n;
-  int np2 = 1;
+  int np2 = PTDFG_SORT_THREADS;                           // (the sort works on a multiple of the workgroup: host sizes the LDS alike)
   while (np2 < n) np2 <<= 1;
   unsigned long long* const s_key = reinterpret_cast<unsigned long long*>(ptdfg_smem);
   int* const s_idx = reinterpret_cast<int*>(s_key + np2);
   int* const s_a = s_idx + np2;
   int* const s_b = s_a + np2;
-  for (int i = tid; i < np2; i += nt) { s_key[i] = i < n ? D.hash[i] : ~0ull; s_idx[i] = i < n ? i : 0x7fffffff; }
-  __syncthreads();
-  // bitonic sort by (key, idx) ascending
-  for (int k = 2; k <= np2; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < np2; i += nt) {
-        const int p = i ^ j;
-        if (p > i) {
-          const bool up = (i & k) == 0;
-          const unsigned long long ka = s_key[i], kb = s_key[p];
-          const int ia = s_idx[i], ib = s_idx[p];
-          const bool gt = ka > kb || (ka == kb && ia > ib);
-          if (gt == up) { s_key[i] = kb; s_key[p] = ka; s_idx[i] = ib; s_idx[p] = ia; }
-        }
-      }
-      __syncthreads();
-    }
+  // sorted by (key, lane) ascending: equal hashes are adjacent, lanes ascending inside a run
+  if (np2 == PTDFG_SORT_THREADS) ptdfg_sort_regs<1>(D.hash, n, s_key, s_idx, tid);
+  else if (np2 == 2 * PTDFG_SORT_THREADS) ptdfg_sort_regs<2>(D.hash, n, s_key, s_idx, tid);
+  else ptdfg_sort_regs<4>(D.hash, n, s_key, s_idx, tid);
   // heads of the runs of equal keys -> class index of every sorted position
   for (int i = tid; i < n; i += nt) s_a[i] = (i == 0 || s_key[i] != s_key[i - 1]) ? 1 : 0;
   __syncthreads();

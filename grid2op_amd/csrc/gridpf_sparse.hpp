@@ -2689,7 +2689,9 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
       double sum_load = 0.0, sum_prod = 0.0;
       // The element -> bus maps stand (reuse): every element adds its new set-point to the bus sums Psp / Qsp / Gs right here
       // (the same LDS atomics K1 would issue from four more loops over the injection row, SolveCtl::sums_done)
-      sums_in_k9 = reuse;
+      // (a first step that runs on the kept state of the reference topology -- KeepArgs -- leaves the sums to K1: its accumulation order is the
+      //  one of a launch that rebuilds, so the launch's results do not depend on whether the blob was there: bit-identical either way)
+      sums_in_k9 = reuse && !(keep_hit && step == 0);
       // the chronics-driven injections stay in the owner lanes' registers instead of going to the lane's injection row and coming back (SolveCtl::inj_regs):
       // a step whose topology stands (nobody reads the row: K9 has the bus sums), not the last of the launch (the row holds the last step's values
       // for the API), no cascade (a re-solve after a trip rebuilds the sums FROM the row), no injection dynamics
