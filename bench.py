@@ -948,6 +948,9 @@ def main():
         if rank == 0:
             res["one_launch_per_step"] = dict(summarize(w, world * B * k_sec), unit="env steps/sec", steps_each=k_sec,
                                               observations="every env step (one launch per step: the lane's own rows)",
+                                              kept_state="lanes on the reference topology load its derived state (element -> bus maps, Ybus blocks, DC factors) "
+                                                         "from one shared blob instead of rebuilding it in every launch (gpf::KeepArgs; GRIDPF_KEEP=0 turns "
+                                                         "it off; results bit-identical either way, tests/test_gpu_keep.py)",
                                               us_per_step=median_window(w)[0] / k_sec * 1e6,
                                               roofline=roofline_block(eng, w, B, k_sec, TRAFFIC_1PL,
                                                                       note="one env step per launch: the float64 bus voltages and the injection row go "
@@ -1216,7 +1219,8 @@ def acting_every_step(ctx, eng, m, red, sto, t, kw, n=200, n_win=3):
         res[label] = dict(summarize(wins, ctx.world * B * n), us_per_step=median_window(wins)[0] / n * 1e6)
     res["what"] = ("one single-step launch per env step, a new redispatch + storage action per lane and step; host_actions: set_lane_actions "
                    "(PCIe + synchronisation per step), device_actions: torch copies into device_views()['act_*'] on the engine's stream + "
-                   "lane_actions_on_device (no PCIe, no synchronisation)")
+                   "lane_actions_on_device (no PCIe, no synchronisation); the launches load the reference topology's derived state from the "
+                   "shared blob (gpf::KeepArgs, GRIDPF_KEEP=0: off)")
     return res
 
 

@@ -232,6 +232,7 @@ __device__ inline int ptdfg_flag_scan(bool f, int tid, int* s_w, int* total) {
 __global__ __launch_bounds__(PTDFG_DESC_THREADS) void ptdfg_desc_kernel(PtdfGroupDev D) {
   __shared__ int s_act[PTDFG_MAX_BUS], s_ref[PTDFG_MAX_BUS], s_nl[PTDFG_MAX_BUS], s_no[PTDFG_MAX_BUS], s_cmp[PTDFG_MAX_BUS], s_lab[PTDFG_MAX_BUS];
   __shared__ short s_bf[256], s_bt[256];
+  __shared__ __attribute__((aligned(16))) int s_ab[256];           // compact ends of line l: from | to << 16 (0xffff: out of service), read four at a time
   __shared__ int s_w[PTDFG_DESC_THREADS / 64], s_flag;
   const int c = blockIdx.x, tid = threadIdx.x, nt = PTDFG_DESC_THREADS;
   if (c >= D.info[0]) return;
@@ -330,16 +331,23 @@ __global__ __launch_bounds__(PTDFG_DESC_THREADS) void ptdfg_desc_kernel(PtdfGrou
     const bool on = f >= 0 && f != t;
     const short cf = on ? (short)s_cmp[f] : (short)-1, ct = on ? (short)s_cmp[t] : (short)-1;
     s_bf[l] = cf; s_bt[l] = ct;
+    s_ab[l] = (int)((unsigned)(unsigned short)cf | ((unsigned)(unsigned short)ct << 16));
   }
+  for (int l = nl + tid; l < ((nl + 3) & ~3); l += nt) s_ab[l] = -1;
   __syncthreads();
   // rows of the reduced B': for every non-reference bus r its lines in ascending order, as line | other end << 16.  Row lengths first
   // (thread r walks all lines: no atomics, ascending by construction), then an exclusive scan for the row pointers
   int* s_cnt = s_lab;                                                // (labels are dead)
   for (int r = tid; r < PTDFB_MAX_N + 1; r += nt) s_cnt[r] = 0;
   __syncthreads();
-  for (int r = tid; r < nr; r += nt) {
+  typedef int v4i_ __attribute__((ext_vector_type(4)));
+  for (int r = tid; r < nr; r += nt) {                               // (r < n_pad <= 128 never equals the 0xffff of a line out of service)
     int cnt = 0;
-    for (int l = 0; l < nl; ++l) { const int a = s_bf[l], b = s_bt[l]; if (a >= 0 && (a == r || b == r)) ++cnt; }
+    for (int l0 = 0; l0 < nl; l0 += 4) {
+      const v4i_ v = *reinterpret_cast<const v4i_*>(&s_ab[l0]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const unsigned w = (unsigned)v[q]; cnt += ((int)(w & 0xffffu) == r || (int)(w >> 16) == r) ? 1 : 0; }
+    }
     s_cnt[r] = cnt;
   }
   __syncthreads();
@@ -354,11 +362,15 @@ __global__ __launch_bounds__(PTDFG_DESC_THREADS) void ptdfg_desc_kernel(PtdfGrou
   __syncthreads();
   for (int r = tid; r < nr; r += nt) {
     int q = s_cnt[r];
-    for (int l = 0; l < nl; ++l) {
-      const int a = s_bf[l], b = s_bt[l];
-      if (a < 0) continue;
-      if (a == r) cent[q++] = l | (b << 16);
-      else if (b == r) cent[q++] = l | (a << 16);
+    for (int l0 = 0; l0 < nl; l0 += 4) {
+      const v4i_ v = *reinterpret_cast<const v4i_*>(&s_ab[l0]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned w = (unsigned)v[k];
+        const int a = (int)(w & 0xffffu), b = (int)(w >> 16);
+        if (a == r) cent[q++] = (l0 + k) | (b << 16);
+        else if (b == r) cent[q++] = (l0 + k) | (a << 16);
+      }
     }
   }
 }

@@ -1026,6 +1026,26 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       if (NB == 1 && !TC) { c.sub_bb[so] = (i8)bo; c.sub_bb[se] = (i8)be; }
     }
   }
+  // (loads before generators: the order in which K9 adds the set-points of a step whose topology stands -- SolveCtl::sums_done --, so that a bus
+  //  sum is the same floating-point number whichever phase accumulated it)
+  if (acc_lane)
+  for (int i = tid; i < g.n_load; i += GWA) {
+    int bu;
+    if (!reuse) {
+      const int lb = topo[sv.load_pos[i]];
+      const int sb = sv.load_sub[i];
+      bu = lb >= 1 ? bus_of(sb, lb) : -1;
+      c.load_b[i] = (i16)bu;
+      if (bu >= 0) {
+        atomicMax(&c.btype[bu], BT_PQ);
+        if (NB == 1 && !TC) c.sub_bb[sb] = (i8)lb;
+      }
+    } else bu = c.load_b[i];
+    if (bu >= 0) {
+      atomicAdd(&c.Psp[bu], -GPF_INJ(oo.inj_load_p + i) * inv_sn);
+      atomicAdd(&c.Qsp[bu], -GPF_INJ(oo.inj_load_q + i) * inv_sn);
+    }
+  }
   if (acc_lane)
   for (int i = tid; i < g.n_gen; i += GWA) {
     int bu;
@@ -1044,24 +1064,6 @@ __device__ inline int solve_instance_sparse(const DevParamsS* __restrict__ P, co
       }
     } else bu = c.gen_b[i];
     if (bu >= 0 && !sl) atomicAdd(&c.Psp[bu], GPF_INJ(oo.inj_gen_p + i) * inv_sn);
-  }
-  if (acc_lane)
-  for (int i = tid; i < g.n_load; i += GWA) {
-    int bu;
-    if (!reuse) {
-      const int lb = topo[sv.load_pos[i]];
-      const int sb = sv.load_sub[i];
-      bu = lb >= 1 ? bus_of(sb, lb) : -1;
-      c.load_b[i] = (i16)bu;
-      if (bu >= 0) {
-        atomicMax(&c.btype[bu], BT_PQ);
-        if (NB == 1 && !TC) c.sub_bb[sb] = (i8)lb;
-      }
-    } else bu = c.load_b[i];
-    if (bu >= 0) {
-      atomicAdd(&c.Psp[bu], -GPF_INJ(oo.inj_load_p + i) * inv_sn);
-      atomicAdd(&c.Qsp[bu], -GPF_INJ(oo.inj_load_q + i) * inv_sn);
-    }
   }
   if (acc_lane)
   for (int i = tid; i < g.n_sto; i += GWA) {
@@ -2691,7 +2693,7 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
       // (the same LDS atomics K1 would issue from four more loops over the injection row, SolveCtl::sums_done)
       // (a first step that runs on the kept state of the reference topology -- KeepArgs -- leaves the sums to K1: its accumulation order is the
       //  one of a launch that rebuilds, so the launch's results do not depend on whether the blob was there: bit-identical either way)
-      sums_in_k9 = reuse && !(keep_hit && step == 0);
+      sums_in_k9 = reuse;
       // the chronics-driven injections stay in the owner lanes' registers instead of going to the lane's injection row and coming back (SolveCtl::inj_regs):
       // a step whose topology stands (nobody reads the row: K9 has the bus sums), not the last of the launch (the row holds the last step's values
       // for the API), no cascade (a re-solve after a trip rebuilds the sums FROM the row), no injection dynamics

@@ -177,3 +177,27 @@ def test_acting_agents_on_118_substations_with_kept_state(load_model, load_npz):
         for key in a[3]:
             assert np.array_equal(a[3][key], b[3][key], equal_nan=True), (k, key)
     assert (outs[1][-1][1][:, 0] == 0).all()
+
+
+@pytest.mark.parametrize("name", GRIDS)
+def test_multi_step_launch_is_bit_identical_to_one_step_launches(name, load_model, load_npz):
+    """K1 (a step that rebuilds) and K9 (a step whose topology stands) add the set-points of a bus in the same order -- loads, generators,
+    storages --, and everything downstream is the same deterministic arithmetic on the same numbers: the observation of step k of ONE
+    launch equals, bit for bit, the observation of the k-th of k one-step launches that rebuild everything (GRIDPF_KEEP=0)."""
+    m = load_model(name)
+    ch = dict(load_npz(f"{name}.chronics.npz"))
+    prod_v = np.tile((m.gen_vm0 * m.sub_vn_kv[m.gen_sub]).astype(np.float32), (ch["prod_p"].shape[0], 1))
+    B, K = 21, 5
+    one, multi = _engine(m, ch, B, False, prod_v), _engine(m, ch, B, True, prod_v)
+    multi.set_trajectory(K, multi.TRAJ_OBS)
+    multi.step(3, rebalance=1.02, n_steps=K)
+    obs = multi.trajectory_obs(K)
+    for k in range(K):
+        one.step(3 + k, rebalance=1.02)
+        r = one.results()
+        assert (r.status[:, 0] == 0).all()
+        assert np.array_equal(obs[k].out, r.out, equal_nan=True), k
+        assert np.array_equal(obs[k].topo_vect, r.topo_vect) and np.array_equal(obs[k].line_status, r.line_status), k
+    rm = multi.results()
+    assert np.array_equal(rm.bus_vm, r.bus_vm, equal_nan=True) and np.array_equal(rm.bus_va, r.bus_va, equal_nan=True)
+    assert np.array_equal(rm.status, r.status)
