@@ -1846,7 +1846,7 @@ int step_range(gpf_engine* e, const gpf::Bufs& b_in, int lane0, int n, int t0, i
   sa.lane0 = lane0;
   // one-step launches of the engine's own lanes share the topology-derived state of the reference topology (gpf::KeepArgs): single-busbar
   // kernels only (the split lanes of a mixed batch -- topology classes, NB = 2 -- rebuild theirs).  The key is the pristine (ghost) lane's rows.
-  if (keep_state && e->keep_enabled && n_steps == 1 && p.sparse_nb == 1 && !p.tc) {
+  if (keep_state && e->keep_enabled && n_steps == 1 && p.sparse_nb == 1 && !p.tc && !o->is_dc) {        // (a DC step builds no Ybus blocks)
     if (!e->keep.p) {
       gpf::KeepArgs k{};
       gpf::keep_layout(k, e->g, e->sym.nslot, e->sym.nslot_y, e->sym_dev.n_up);

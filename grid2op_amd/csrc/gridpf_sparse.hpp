@@ -2808,7 +2808,7 @@ __global__ __launch_bounds__(WAVE * WPI, GPF_MINW(MINW)) void step_sparse_kernel
       // a group whose cascade has ended re-solves its unchanged state along with the others (same results)
       int it_k = 0, nb_k = 0;
       SolveCtl ctl;
-      ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && (sa.n_steps > 1 || keep_on); ctl.write_bus = last; ctl.warm = sa.warm_start != 0; ctl.sums_done = first && sums_in_k9;
+      ctl.inj_staged = true; ctl.topo_staged = first; ctl.reuse = first && reuse; ctl.dcf = P->dcf != 0 && (sa.n_steps > 1 || keep_on); ctl.write_bus = last; ctl.warm = sa.warm_start != 0 && !(keep_hit && step == 0); ctl.sums_done = first && sums_in_k9;   // (kept state holds no voltages to start from)
       orow = otraj ? step * (int)b.lane_stride + inst : inst;          // (re-derived: see GPF_REDERIVE)
       ctl.otraj = otraj; ctl.orow = orow; ctl.write_topo = otraj || (keep_hit && step == 0);   // (kept state: the lane's topology outputs may be another launch's)
       ctl.tc_rebuild = keep_hit && step == 0;

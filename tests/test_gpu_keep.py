@@ -107,6 +107,10 @@ def test_one_step_launches_with_kept_lane_state_equal_launches_without(name, loa
     t[0] += 4
     both(lambda e: None, "multi-step launch")
     steps(2, "after a multi-step launch")
+    # DC steps (no Ybus blocks: they neither read nor write the blob) and warm-started steps (the kept state holds no voltages) in between
+    steps(2, "DC steps", is_dc=True)
+    steps(2, "AC again")
+    steps(2, "warm start requested", warm_start=True)
     # shunt set-points are part of Ybus, hence of the key
     if m.n_shunt:
         inj = s["inj"].copy()
