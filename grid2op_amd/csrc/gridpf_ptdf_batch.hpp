@@ -570,43 +570,46 @@ __global__ __launch_bounds__(PTDFB_LDS_THREADS) void ptdf_build_lds_kernel(PtdfB
   if (tid == 0) D.status[cls] = bad ? 1 : 0;
   PTDFB_STAMP(4);
   if (!LO) return;
-  // ---- 4. LODF[m][k] = (PTDF[m][from_k] - PTDF[m][to_k]) / (1 - H[k][k]); LODF[k][k] = -1.  Rounds of PTDFB_LROWS lines m: all threads
-  //         build the PTDF rows of those lines over the reduced buses in LDS (rows of X read contiguously: no bank conflicts), then thread
-  //         k takes its two entries of every row (2 gathers per output instead of 4) and stores column k (coalesced) ----------------------
-  PTDFB_LDS_BARRIER();                                                 // (NOT __syncthreads(): the PTDF^T stores keep draining behind the LODF rounds)
-  const int kk = tid < D.line_pad ? tid : -1;                          // (line_pad <= the block's threads is checked by the host)
-  const int kf = kk >= 0 ? s_lf[kk] : -1, kt = kk >= 0 ? s_lt[kk] : -1;
+  // ---- 4. LODF[m][k] = (PTDF[m][from_k] - PTDF[m][to_k]) / (1 - H[k][k]); LODF[k][k] = -1.  With PTDF[m][b] = bdc_m (X[from_m][b] - X[to_m][b])
+  //         and X symmetric, PTDF[m][from_k] - PTDF[m][to_k] = bdc_m (PT[from_m][k] - PT[to_m][k]) / bdc_k: two entries of the PTDF^T table phase 3
+  //         just wrote, on ROW from_m / to_m (the same for every thread) and the thread's own column k -- coalesced reads through L1 / L2
+  //         instead of gathers of X at random columns of LDS (4 per output: the lanes' from-buses collide in the 32 eight-byte banks, 47 k
+  //         cycles; before that the PTDF rows of 8 lines at a time were staged in LDS, 24 rounds x 2 barriers: 74 k of the kernel's 218 k).
+  //         Thread (k, stripe) owns column k for the lines of its stripe; no barrier inside the phase. ---------------------------------------
+  __syncthreads();                                                     // the PTDF^T stores of every thread have left the CU (vmcnt) before another thread reads them
+  const int n_str = PTDFB_LDS_THREADS / D.line_pad;                    // stripes of lines (line_pad <= the block's threads is checked by the host)
+  const int kk = tid < n_str * D.line_pad ? tid % D.line_pad : -1;
+  const int str = tid / D.line_pad;
+  const int kf = kk >= 0 ? s_lf[kk] : -1;
   const double khd = kk >= 0 ? hden[kk] : 0.0;
   long long acc_b = 0;
-  for (int m0 = 0; m0 < D.n_line; m0 += PTDFB_LROWS) {
-    const long long tb_ = D.dbg ? (long long)__builtin_readcyclecounter() : 0;
-    for (int e = tid; e < PTDFB_LROWS * n_pad; e += PTDFB_LDS_THREADS) {
-      const int u = e / n_pad, b = e - u * n_pad, m = m0 + u;
-      double v = 0.0;
-      if (m < D.n_line && b < nr && !bad) {
+  if (kk >= 0) {
+    const int per = (D.n_line + n_str - 1) / n_str;
+    const int m_lo = str * per, m_hi = (m_lo + per < D.n_line) ? m_lo + per : D.n_line;
+    const double kbd = s_bdc[kk];
+    const double ksc = (kf >= 0 && kbd != 0.0) ? khd / kbd : 0.0;      // 1 / (bdc_k (1 - H[k][k]))
+    const double* const PTk = PT + kk;
+    constexpr int UN = 8;                                              // lines in flight per thread: every load of a trip is issued before the first is used
+    for (int m0 = m_lo; m0 < m_hi; m0 += UN) {
+      double a_[UN], b_[UN], bm_[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int m = m0 + u < m_hi ? m0 + u : m_hi - 1;
         const int fm = s_lf[m], tm = s_lt[m];
-        if (fm >= 0) v = s_bdc[m] * ((fm < nr ? M[(size_t)fm * ldm + b] : 0.0) - (tm < nr ? M[(size_t)tm * ldm + b] : 0.0));
-      }
-      rows[e] = v;
-    }
-    PTDFB_LDS_BARRIER();
-    if (D.dbg) acc_b += (long long)__builtin_readcyclecounter() - tb_;
-    if (kk >= 0) {
-      double hf[PTDFB_LROWS], ht[PTDFB_LROWS];
-#pragma unroll
-      for (int u = 0; u < PTDFB_LROWS; ++u) {
-        hf[u] = (kf >= 0 && kf < nr) ? rows[u * n_pad + kf] : 0.0;
-        ht[u] = (kf >= 0 && kt < nr) ? rows[u * n_pad + kt] : 0.0;
+        const bool on_ = fm >= 0 && !bad;
+        bm_[u] = on_ ? s_bdc[m] : 0.0;
+        a_[u] = PTk[(size_t)(on_ ? fm : 0) * D.line_pad];              // (rows of reference / padding buses hold zeros)
+        b_[u] = PTk[(size_t)(on_ ? tm : 0) * D.line_pad];
       }
 #pragma unroll
-      for (int u = 0; u < PTDFB_LROWS; ++u) {
+      for (int u = 0; u < UN; ++u) {
         const int m = m0 + u;
+        if (m >= m_hi) break;
         double v = 0.0;
-        if (kf >= 0) v = (khd != khd) ? khd : (m == kk ? -1.0 : (hf[u] - ht[u]) * khd);
-        if (m < D.n_line) LO[(size_t)m * D.line_pad + kk] = (float)v;
+        if (kf >= 0) v = (khd != khd) ? khd : (m == kk ? -1.0 : bm_[u] * (a_[u] - b_[u]) * ksc);
+        LO[(size_t)m * D.line_pad + kk] = (float)v;
       }
     }
-    PTDFB_LDS_BARRIER();
   }
   if (D.dbg && tid == 0) D.dbg[(size_t)cls * 8 + 7] = acc_b;
   PTDFB_STAMP(5);
