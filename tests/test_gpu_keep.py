@@ -13,7 +13,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-GRIDS = ["l2rpn_case14_sandbox", "l2rpn_neurips_2020_track1", "l2rpn_wcci_2022_dev"]
+GRIDS = ["rte_case5_example", "l2rpn_case14_sandbox", "l2rpn_neurips_2020_track1", "l2rpn_wcci_2022_dev"]      # 4 / 2 / 1 instances per wavefront, 2 wavefronts per instance
 
 
 def _engine(m, ch, B, keep, prod_v):
