@@ -1307,7 +1307,8 @@ int gpf_destroy(gpf_handle e) {
   e->ptdfg_hash.release(); e->ptdfg_lane_class.release(); e->ptdfg_first.release(); e->ptdfg_c2b.release(); e->ptdfg_info.release();
   e->maint.release(); e->forecast.release(); e->sim_src.release(); e->sim_rows.release();
   e->env_target.release(); e->env_actual.release(); e->env_prev.release(); e->env_charge.release(); e->env_amount_prev.release();
-  e->env_act_redisp.release(); e->env_act_storage.release(); e->sto_charge0.release(); e->env_already.release(); e->env_fresh.release();
+  e->env_act_storage.p = nullptr; e->env_act_storage.n = 0;       // (an alias into env_act_redisp)
+  e->env_act_redisp.release(); e->sto_charge0.release(); e->env_already.release(); e->env_fresh.release();
   e->sto_emax.release(); e->sto_emin.release(); e->sto_loss.release(); e->sto_effc.release(); e->sto_effd.release();
   e->env_limit.release(); e->env_curt_prev.release(); e->env_act_curtail.release(); e->env_renewable.release(); e->env_illegal.release();
   e->rd_pmin.release(); e->rd_pmax.release(); e->rd_ru.release(); e->rd_rd.release(); e->rd_in.release(); e->rd_redisp.release();
@@ -1981,7 +1982,8 @@ int gpf_set_env_dynamics(gpf_handle e, int32_t on, double tol_poly) {
   if (!e->env_target.p) {
     HIP_TRY(e->env_target.alloc(B * ng)); HIP_TRY(e->env_actual.alloc(B * ng)); HIP_TRY(e->env_prev.alloc(B * ng)); HIP_TRY(e->env_already.alloc(B * ng));
     HIP_TRY(e->env_charge.alloc(B * ns)); HIP_TRY(e->env_amount_prev.alloc(B)); HIP_TRY(e->env_fresh.alloc(B));
-    HIP_TRY(e->env_act_redisp.alloc(B * ng)); HIP_TRY(e->env_act_storage.alloc(B * ns));
+    // the redispatch and storage action rows of all lanes are ONE allocation ([B][n_gen] | [B][n_storage]): a host agent's two uploads per step are one DMA
+    HIP_TRY(e->env_act_redisp.alloc(B * ng + B * ns)); e->env_act_storage.p = e->env_act_redisp.p + B * ng; e->env_act_storage.n = B * ns;
     HIP_TRY(e->env_limit.alloc(B * ng)); HIP_TRY(e->env_curt_prev.alloc(B)); HIP_TRY(e->env_act_curtail.alloc(B * ng)); HIP_TRY(e->env_illegal.alloc(B));
     HIP_TRY(hipMemset(e->env_act_redisp.p, 0, B * ng * sizeof(float))); HIP_TRY(hipMemset(e->env_act_storage.p, 0, B * ns * sizeof(float)));
     HIP_TRY(hipMemset(e->env_charge.p, 0, B * ns * sizeof(float)));
@@ -2001,12 +2003,13 @@ namespace {
 // first waits for the event recorded behind this call's uploads (reached long before: they sit in front of the step launch).
 // Layout: redispatch [B][n_gen] | storage [B][n_sto] | curtailment [B][n_gen].
 int act_pin_begin(gpf_engine* e) {
-  const size_t B = e->n_lanes, ng = e->g.n_gen, ns = e->g.n_sto, need = B * (2 * ng + ns);
+  const size_t B = e->cap_lanes, ng = e->g.n_gen, ns = std::max(e->g.n_sto, 1), need = B * (2 * ng + ns);     // (the device layout: padded lane count)
   if (e->act_up) HIP_TRY(hipEventSynchronize(e->act_up));
   if (e->act_pin_n < need) {
     if (e->act_pin) (void)hipHostFree(e->act_pin);
     e->act_pin = nullptr; e->act_pin_n = 0;
     HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->act_pin), need * sizeof(float), hipHostMallocDefault));
+    std::memset(e->act_pin, 0, need * sizeof(float));           // (the padding lanes' rows travel with the others)
     e->act_pin_n = need;
   }
   if (!e->act_up) HIP_TRY(hipEventCreateWithFlags(&e->act_up, hipEventDisableTiming));
@@ -2024,15 +2027,17 @@ int gpf_set_lane_actions(gpf_handle e, const float* redispatch, const float* sto
     const int rc = act_pin_begin(e);
     if (rc != GPF_OK) return rc;
   }
-  if (redispatch) {
-    std::memcpy(e->act_pin, redispatch, B * ng * sizeof(float));
+  const size_t Bc = e->cap_lanes, so = Bc * ng;                  // storage rows: behind the (padded) redispatch rows, on the host block as on the device
+  if (redispatch) std::memcpy(e->act_pin, redispatch, B * ng * sizeof(float));
+  if (storage_power && ns) std::memcpy(e->act_pin + so, storage_power, B * ns * sizeof(float));
+  if (redispatch && storage_power && ns) {
+    HIP_TRY(hipMemcpyAsync(e->env_act_redisp.p, e->act_pin, (so + B * ns) * sizeof(float), hipMemcpyHostToDevice, e->stream));     // one DMA for both
+  } else if (redispatch) {
     HIP_TRY(hipMemcpyAsync(e->env_act_redisp.p, e->act_pin, B * ng * sizeof(float), hipMemcpyHostToDevice, e->stream));
+  } else if (storage_power && ns) {
+    HIP_TRY(hipMemcpyAsync(e->env_act_storage.p, e->act_pin + so, B * ns * sizeof(float), hipMemcpyHostToDevice, e->stream));
   }
   e->env_act_r = redispatch != nullptr;
-  if (storage_power && ns) {
-    std::memcpy(e->act_pin + B * ng, storage_power, B * ns * sizeof(float));
-    HIP_TRY(hipMemcpyAsync(e->env_act_storage.p, e->act_pin + B * ng, B * ns * sizeof(float), hipMemcpyHostToDevice, e->stream));
-  }
   e->env_act_s = storage_power != nullptr && ns > 0;
   e->env_hold = hold_storage != 0;
   if (redispatch || (storage_power && ns)) HIP_TRY(hipEventRecord(e->act_up, e->stream));
@@ -2073,7 +2078,7 @@ int gpf_set_lane_curtailment(gpf_handle e, const float* limit) {
     const int rc = act_pin_begin(e);
     if (rc != GPF_OK) return rc;
   }
-  float* stage = e->act_pin + (size_t)e->n_lanes * (e->g.n_gen + e->g.n_sto);
+  float* stage = e->act_pin + (size_t)e->cap_lanes * (e->g.n_gen + std::max(e->g.n_sto, 1));       // (behind the redispatch | storage rows: act_pin_begin)
   std::memcpy(stage, limit, n * sizeof(float));
   HIP_TRY(hipMemcpyAsync(e->env_act_curtail.p, stage, n * sizeof(float), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipEventRecord(e->act_up, e->stream));
