@@ -397,7 +397,7 @@ __global__ __launch_bounds__(PTDFB_LDS_THREADS) void ptdf_build_lds_kernel(PtdfB
   double* Rold = M;                                                   // during the elimination: block row k as it was [16][ldm]
   double* Rnew = M + (size_t)PTDFB_TILE * ldm;                        // ... and after the row-panel update (tile k = P)
   double* hden = M + (size_t)n_pad * ldm;                             // [line_pad] 1 / (1 - H[k][k]); 0: column of zeros; NaN: islanding outage
-  double* rows = hden + D.line_pad;                                   // [PTDFB_LROWS][n_pad] PTDF rows of a LODF round
+  double* rows = hden + D.line_pad;                                   // [PTDFB_LROWS][n_pad] (staging rows of the LODF phase until round 6: unused, the layout is kept)
   double* Pa = rows + (size_t)PTDFB_LROWS * n_pad;                    // inverse of the current diagonal tile [16][18]
   double* Pb = Pa + PTDFB_TILE * PTDFB_PT;                            // ... of the next one (lookahead)
   double* s_bdc = Pb + PTDFB_TILE * PTDFB_PT;                         // [line_pad]
