@@ -254,6 +254,10 @@ typedef struct gpf_step_opts {
 /* n_steps consecutive DoNothing env.step (t0, t0+1, ...) of every lane in ONE launch.  Every step does the whole of gpf_step;
  * between the steps of a launch the lane state stays on chip and whatever only depends on the topology (element->bus maps, bus
  * types, Ybus, the factored DC matrix) is kept until a line trips or a lane fails.
+ * n_steps = 1 (an agent that acts between any two steps: the reference's loop, Environment/baseEnv.py:3562-3931): a lane whose topology
+ * row, shunt buses and shunt set-points are those the engine was created with loads that topology-only state from one blob the engine
+ * keeps (written by the first such launch) instead of rebuilding it; every other lane rebuilds.  Results are bit-identical either way,
+ * and equal to the same steps inside one multi-step launch bit for bit (GRIDPF_KEEP=0 at gpf_create: always rebuild).
  * What is retrievable afterwards: the getters (gpf_get_results, gpf_get_step_outputs, device views) return the LAST step only --
  * without a trajectory buffer each step overwrites the lane's result row, so the observations of the earlier steps never exist in
  * HBM.  gpf_set_trajectory(h, cap, GPF_TRAJ_OBS) keeps the complete backend observation of EVERY step (what BaseEnv.step hands
